@@ -1,0 +1,212 @@
+/*
+ * xclim_hip.h — C ABI of libxclimhip.so, the MI355X (gfx950) backend for xclim's
+ * index / run-length / percentile / quantile-mapping hot path.
+ *
+ * The reference (Ouranosinc/xclim, /root/reference) has NO FFI: its "operator
+ * boundary" is a set of Python module attributes plus the numpy callees handed to
+ * xr.apply_ufunc.  Every entry point below names the reference
+ * function(s) (file:line under /root/reference/src/xclim) it replaces.
+ *
+ * Conventions
+ *   - every function returns int: 0 = XH_OK, <0 = error (message: xh_last_error()).
+ *   - `x`, `out`, ... are DEVICE pointers (xh_malloc / any hipMalloc'd memory);
+ *     host<->device staging is explicit (xh_memcpy_h2d / xh_memcpy_d2h).
+ *   - arrays are 2-D views (T, C): T time steps, C grid cells (lat*lon flattened).
+ *     `st`, `sc` are ELEMENT strides of the time and cell axes.  Streaming kernels
+ *     need sc == 1 ("time-major", xarray's native (time, lat, lon) C order);
+ *     column kernels (full-series quantiles) take st == 1 ("time-minor", what
+ *     apply_ufunc hands its callee) or transpose internally.
+ *   - periods of `resample(time=freq)` are contiguous time segments described by
+ *     seg_off[P+1] (host computes them from the calendar, xclim_amd/timeaxis.py).
+ *   - work is enqueued on the context's HIP stream; xh_sync / xh_memcpy_d2h wait.
+ *   - a context is not re-entrant (one per device per caller thread).
+ */
+#ifndef XCLIM_HIP_H
+#define XCLIM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XH_ABI_VERSION 1
+
+/* error codes */
+#define XH_OK 0
+#define XH_ERR_HIP (-1)      /* a HIP runtime call failed */
+#define XH_ERR_ARG (-2)      /* invalid argument value */
+#define XH_ERR_LAYOUT (-3)   /* unsupported stride / alignment combination */
+#define XH_ERR_OP (-4)       /* operator / reducer not recognized (gen:285) */
+#define XH_ERR_NOTIMPL (-5)
+#define XH_ERR_NODEVICE (-6) /* no gfx950 device visible */
+#define XH_ERR_LIMIT (-7)    /* problem exceeds an on-chip capacity limit */
+
+/* comparison operators — xclim.indices.generic.binary_ops (indices/generic.py:40-75, 255-298) */
+#define XH_OP_GT 0
+#define XH_OP_LT 1
+#define XH_OP_GE 2
+#define XH_OP_LE 3
+#define XH_OP_EQ 4
+#define XH_OP_NE 5
+
+/* threshold kinds for xh_threshold_count */
+#define XH_THR_SCALAR_F32 0 /* python-float threshold: compare in fp32 (NumPy weak scalar) */
+#define XH_THR_SCALAR_F64 1 /* np.float64 threshold: data widened to fp64 */
+#define XH_THR_DOY_F64 2    /* per-day-of-year table (D, C) fp64 + tidx[T] (resample_doy, core/calendar.py:763-790) */
+#define XH_THR_DOY_F32 3
+#define XH_THR_FULL_F64 4   /* full (T, C) threshold array */
+#define XH_THR_FULL_F32 5
+
+/* segmented reducers — select_resample_op (indices/generic.py:83-125) */
+#define XH_RED_SUM 0
+#define XH_RED_MEAN 1
+#define XH_RED_MIN 2
+#define XH_RED_MAX 3
+#define XH_RED_STD 4
+#define XH_RED_VAR 5
+#define XH_RED_COUNT 6
+#define XH_RED_ARGMIN 7
+#define XH_RED_ARGMAX 8
+
+/* run statistics — rle_statistics reducers and friends (indices/run_length.py:275-540) */
+#define XH_RUN_MAX 0    /* rle_statistics(reducer="max") / longest_run */
+#define XH_RUN_MIN 1
+#define XH_RUN_SUM 2    /* rle_statistics("sum") == windowed_run_count (window>1 or freq) */
+#define XH_RUN_COUNT 3  /* rle_statistics("count") == windowed_run_events */
+#define XH_RUN_MEAN 4
+#define XH_RUN_STD 5
+#define XH_RUN_FIRST 6  /* first_run: index of first element of first run >= window, NaN if none */
+#define XH_RUN_LAST 7   /* last_run:  index of last element of last run >= window, NaN if none  */
+#define XH_RUN_PLAINSUM 8 /* windowed_run_count(window==1, freq=None): da.sum(dim) (rl:478-479) */
+
+typedef struct xh_ctx xh_ctx;
+
+/* ---- context, memory, timing ------------------------------------------------------------ */
+int xh_abi_version(void);
+const char* xh_last_error(void);
+int xh_device_count(int* n);
+int xh_create(int device, xh_ctx** out);
+int xh_destroy(xh_ctx* ctx);
+int xh_sync(xh_ctx* ctx);
+int xh_device_name(xh_ctx* ctx, char* buf, size_t buflen);
+int xh_mem_info(xh_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
+int xh_malloc(xh_ctx* ctx, size_t bytes, void** dptr);
+int xh_free(xh_ctx* ctx, void* dptr);
+int xh_memset(xh_ctx* ctx, void* dptr, int value, size_t bytes);
+int xh_memcpy_h2d(xh_ctx* ctx, void* dst, const void* src, size_t bytes);
+int xh_memcpy_d2h(xh_ctx* ctx, void* dst, const void* src, size_t bytes); /* synchronises */
+int xh_memcpy_d2d(xh_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* HIP-event timer on the context's stream (bench.py roofline: kernel time without host overhead) */
+int xh_timer_start(xh_ctx* ctx);
+int xh_timer_stop(xh_ctx* ctx, float* elapsed_ms); /* synchronises */
+/* raw hipStream_t of the context, for interop (e.g. ordering against RCCL collectives) */
+int xh_stream(xh_ctx* ctx, void** stream);
+
+/* ---- synthetic inputs: counter-based generator, restated in oracle/synth.py -- */
+/* out[t, c] = base[t] + amp * z(seed, t, cell0 + c),  z = sum of 4 hashed uniforms - 2 (var 1/3);
+ * kind 0: temperature-like (as above); kind 1: precipitation-like (wet w.p. p_wet, amount = amp*u^3,
+ * else 0); nan_per_million: independent NaN probability.  Layout (T, C) with row stride st. */
+int xh_fill_synthetic(xh_ctx* ctx, float* out, int64_t T, int64_t C, int64_t st, int kind, uint64_t seed,
+                      int64_t cell0, const float* base /* device, T */, float amp, float p_wet,
+                      uint32_t nan_per_million);
+
+/* tiled transpose (T, C) -> (C, T) (row strides in elements); used by column kernels */
+int xh_transpose_f32(xh_ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t in_stride, float* out,
+                     int64_t out_stride);
+
+/* ---- threshold / count family (G1-G3, M1) -------------------------------------------------- */
+/* threshold_count (indices/generic.py:329-361) = (compare(da, op, thr) * 1).resample(time=freq).sum("time")
+ * fused with MissingAny's valid count (core/missing.py:201-220, 318-322).
+ *   thr_kind scalar: `thr_scalar`; DOY: thr_table (D, C) row stride thr_stride, tidx[T] row index per step;
+ *   FULL: thr_table (T, C) row stride thr_stride.
+ *   count_out (P, C) int32; valid_out (P, C) int32 = #non-NaN of x per period (may be NULL). */
+int xh_threshold_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op,
+                       int thr_kind, double thr_scalar, const void* thr_table, int64_t thr_stride,
+                       const int32_t* tidx, const int64_t* seg_off, int P, int32_t* count_out,
+                       int32_t* valid_out);
+
+/* domain_count / count_occurrences-style two-sided scalar conditions (indices/generic.py:364-392):
+ *   cond = (x op1 thr1) AND|OR (x op2 thr2);  combine: 1 = and, 2 = or.  fp32 compares. */
+int xh_domain_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op1,
+                    double thr1, int op2, double thr2, int combine, const int64_t* seg_off, int P,
+                    int32_t* count_out, int32_t* valid_out);
+
+/* select_resample_op (indices/generic.py:83-125): segmented reduction over periods.
+ *   float reducers write float32 `out` (P, C) (fp64 accumulation); COUNT/ARGMIN/ARGMAX write int32.
+ *   skipna != 0: NaN ignored (all-NaN -> NaN, SUM -> 0) as xarray's default for floats.
+ *   valid_out (P, C) int32 may be NULL. */
+int xh_resample_reduce(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int reducer,
+                       int skipna, const int64_t* seg_off, int P, void* out, int32_t* valid_out);
+
+/* MissingAny (core/missing.py:318-322): out64[p, c] = valid[p, c] != expected[p] ? NaN : value.
+ * value_kind 0: int32 input, 1: float32 input. */
+int xh_apply_missing_mask(xh_ctx* ctx, const void* value, int value_kind, const int32_t* valid,
+                          const int32_t* expected, int P, int64_t C, double* out64);
+
+/* rolling(time=window, center).{sum,mean,min,max,std,var,count}() (indices/generic.py:128-174);
+ * NaN anywhere in the window -> NaN (min_periods == window), incomplete windows -> NaN. */
+int xh_rolling_reduce(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window,
+                      int center, int reducer, float* out, int64_t out_st);
+
+/* ---- run-length family (R1-R5, S1 fast path) ------------------------------------------------ */
+/* _cumsum_reset (indices/run_length.py:143-219): c[t] = b[t] * (c[t-1] + 1), NaN -> 0;
+ * index_first != 0 runs the recurrence from the end. */
+int xh_cumsum_reset(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int index_first,
+                    float* out, int64_t out_st);
+/* rle (indices/run_length.py:223-272): run length at the first (last) element of each run, NaN inside,
+ * 0 outside. */
+int xh_rle(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int index_first, float* out,
+           int64_t out_st);
+
+/* rle_statistics / longest_run / windowed_run_count / windowed_run_events / first_run / last_run
+ * (indices/run_length.py:275-488, 543-740), optionally fused with the spell condition of
+ * spell_length_statistics (indices/generic.py:499-502, 543-585):
+ *   fused_op < 0 : x IS the mask (float32: >0 True, 0 False, NaN = NaN as select_time leaves it)
+ *   fused_op >= 0: mask = compare(x, fused_op, thr) in fp32 (NaN -> False); valid_out counts non-NaN x.
+ *   cut_at_segments != 0: resample BEFORE run length (runs cut at period edges, rl:122-129);
+ *   else resample AFTER (run attributed to the period of its first/last element, rl:330-334).
+ *   out (P, C) float32 (integer valued; NaN for FIRST/LAST when no run); valid_out may be NULL. */
+int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int fused_op,
+                 double thr, int window, int stat, int index_first, const int64_t* seg_off, int P,
+                 int cut_at_segments, float* out, int32_t* valid_out);
+
+/* ---- quantile / percentile family (Q1-Q3) --------------------------------------------------- */
+/* calc_perc / _nan_quantile (core/utils.py:279-557): NaN-aware Hyndman-Fan quantiles of N samples per
+ * cell.  x is (N, C) with sample stride sn and cell stride sc (either may be 1).  q[nq] in [0, 1].
+ * out (nq, C) float64 (row stride C). */
+int xh_nan_quantile(xh_ctx* ctx, const float* x, int64_t N, int64_t C, int64_t sn, int64_t sc, const double* q,
+                    int nq, double alpha, double beta, double* out);
+
+/* percentile_doy (core/calendar.py:395-494) before the 366-day adjustment: for each day-of-year row d
+ * and year y, tbase[y * ndoy + d] is the time index of that calendar day (or -1 if the year lacks it);
+ * the sample set is x[tbase - window/2 .. tbase + window - 1 - window/2] over all years (NaN outside
+ * [0, T)), reduced with _nan_quantile.  out (nper, ndoy, C) float64. */
+int xh_percentile_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
+                      const int32_t* tbase, int nyears, int ndoy, int window, const double* per /* host */,
+                      int nper, double alpha, double beta, double* out);
+
+/* _interpolate_doy_calendar (core/calendar.py:690-726): interpolate_na along doy then linear re-grid
+ * D_in -> D_out with host-computed tables (scipy interp1d form): slope = (in[i1[j]] - in[i0[j]]) / dxs[j];
+ * out[j] = slope * dxn[j] + in[i0[j]],  dxn = x_new - x_lo, dxs = x_hi - x_lo.  in (D_in, C), out (D_out, C). */
+int xh_doy_interp(xh_ctx* ctx, const double* in, int D_in, int64_t C, const int32_t* i0, const int32_t* i1,
+                  const double* dxn, const double* dxs, int D_out, double* out);
+
+/* ---- sdba empirical quantile mapping (E1-E4; xsdba >= 0.4.0, not in the reference tree) ------ */
+/* nbutils.quantile: per-cell NaN-aware type-7 quantiles of the whole series at nq nodes. out (nq, C) f32 */
+int xh_quantile_series(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
+                       const double* q /* host */, int nq, float* out);
+/* eqm_train: ref_q, hist_q = quantile(ref), quantile(hist); af = ref_q - hist_q (kind 0 "+") or
+ * ref_q / hist_q (kind 1 "*").  af, hist_q (nq, C) float32. */
+int xh_eqm_train(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, int64_t sc,
+                 const double* q /* host */, int nq, int kind, float* af, float* hist_q);
+/* qm_adjust: af_t = interp_on_quantiles(sim, hist_q, af) (interp 0 nearest, 1 linear; extrap 0 constant,
+ * 1 nan); scen = sim + af_t (kind 0) or sim * af_t (kind 1).  scen (T, C) row stride scen_st. */
+int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const float* af,
+                  const float* hist_q, int nq, int kind, int interp, int extrap, float* scen, int64_t scen_st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XCLIM_HIP_H */

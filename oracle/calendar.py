@@ -1,0 +1,91 @@
+"""Oracle: day-of-year percentiles (reference: src/xclim/core/calendar.py:395-494, 690-790).  TEST INFRASTRUCTURE ONLY."""
+
+from __future__ import annotations
+
+import numpy as np
+from scipy.interpolate import interp1d
+
+from .quantile import calc_perc
+from .timeutil import OTime
+
+_MAX_DOY = {"standard": 366, "gregorian": 366, "proleptic_gregorian": 366, "noleap": 365, "365_day": 365,
+            "360_day": 360, "all_leap": 366, "366_day": 366}
+
+
+def rolling_construct_center(arr, window):
+    """``arr.rolling(time=window, center=True, min_periods=1).construct("window")`` (cal:448): NaN padded windows
+    [t - w//2, t + w - 1 - w//2] stacked on a new LAST axis."""
+    arr = np.asarray(arr)
+    T = arr.shape[0]
+    start = window // 2
+    pad_shape = (window - 1,) + arr.shape[1:]
+    fl = arr.astype(np.result_type(arr.dtype, np.float32), copy=False)
+    padded = np.concatenate([np.full((start,) + arr.shape[1:], np.nan, fl.dtype), fl,
+                             np.full((pad_shape[0] - start,) + arr.shape[1:], np.nan, fl.dtype)], axis=0)
+    return np.stack([padded[k : k + T] for k in range(window)], axis=-1)
+
+
+def percentile_doy(arr, time: OTime, window=5, per=10.0, alpha=1.0 / 3.0, beta=1.0 / 3.0):
+    """cal:395-494.  Returns (p, doys) with p of shape (ndoy, ..., nper) float64 (doy axis first here).
+
+    rolling window -> (year, dayofyear) MultiIndex -> unstack("time") [missing (year, doy) pairs become NaN] ->
+    stack(stack_dim=("year", "window")) -> calc_perc over stack_dim; then, when doy 366 exists, drop it and
+    re-interpolate 365 -> 366 (cal:484-485).
+    """
+    arr = np.asarray(arr)
+    rr = rolling_construct_center(arr, window)  # (T, ..., w)
+    years = np.unique(time.year)
+    doys = np.unique(time.doy)
+    trailing = rr.shape[1:-1]
+    stack = np.full((len(doys), len(years)) + trailing + (window,), np.nan, dtype=rr.dtype)
+    yi = np.searchsorted(years, time.year)
+    di = np.searchsorted(doys, time.doy)
+    stack[di, yi] = rr
+    # (doy, year, ..., w) -> (doy, ..., year*w)
+    stack = np.moveaxis(stack, 1, -2)
+    stack = stack.reshape(stack.shape[:-2] + (len(years) * window,))
+    pers = [per] if np.isscalar(per) else list(per)
+    p = calc_perc(stack, percentiles=pers, alpha=alpha, beta=beta)  # (doy, ..., nper)
+    if doys.max() == 366:
+        keep = doys < 366
+        p, doys = adjust_doy_calendar(p[keep], doys[keep], time)
+    return p, doys
+
+
+def interpolate_doy_calendar(source, src_doys, doy_max, doy_min=1):
+    """cal:690-726 `_interpolate_doy_calendar`: interpolate_na (linear in the doy coordinate, NaN beyond the outer
+    valid points), relabel to linspace(doy_min, doy_max, n), then scipy interp1d (xarray's `interp` path for N-D
+    linear) onto the integer doys."""
+    source = np.asarray(source, dtype=np.float64)
+    n = source.shape[0]
+    filled = source.copy()
+    flat = filled.reshape(n, -1)
+    x = np.asarray(src_doys, dtype=np.float64)
+    for j in range(flat.shape[1]):
+        col = flat[:, j]
+        nans = np.isnan(col)
+        if nans.any() and not nans.all():
+            col[nans] = np.interp(x[nans], x[~nans], col[~nans], left=np.nan, right=np.nan)
+    newx = np.linspace(doy_min, doy_max, n)
+    target = np.arange(doy_min, doy_max + 1)
+    f = interp1d(newx, filled, kind="linear", axis=0, bounds_error=False, fill_value=np.nan, assume_sorted=True)
+    return f(target.astype(np.float64)), target
+
+
+def adjust_doy_calendar(source, src_doys, target_time: OTime):
+    """cal:729-760.  `has_similar_doys` compares bound methods (always False, cal:756) -> only the full-calendar test."""
+    max_t, min_t = int(target_time.doy.max()), int(target_time.doy.min())
+    if src_doys.max() == _MAX_DOY[target_time.calendar]:
+        return source, src_doys
+    return interpolate_doy_calendar(source, src_doys, max_t, min_t)
+
+
+def resample_doy(doy_arr, src_doys, time: OTime):
+    """cal:763-790: thresh[t] = adjusted_doy[dayofyear(t)]; NaN where the doy is absent from the table (reindex)."""
+    adoy, doys = adjust_doy_calendar(doy_arr, np.asarray(src_doys), time)
+    pos = np.searchsorted(doys, time.doy)
+    pos_c = np.clip(pos, 0, len(doys) - 1)
+    ok = doys[pos_c] == time.doy
+    out = np.asarray(adoy)[pos_c].astype(np.float64, copy=True)
+    out[~ok] = np.nan
+    return out

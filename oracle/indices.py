@@ -1,0 +1,51 @@
+"""Oracle: the index compositions on the benchmark path + MissingAny.  TEST INFRASTRUCTURE ONLY.
+
+Reference: indices/_simple.py:76-113 (tg_mean), indices/_multivariate.py:1534-1592 (tx90p),
+indices/_threshold.py:2895-2937 (maximum_consecutive_dry_days), core/missing.py:201-220, 318-322 (MissingAny).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import calendar as ocal
+from . import generic as ogen
+from .timeutil import OTime, days_in_period, groups
+
+
+def missing_any(da, time: OTime, freq):
+    """core/missing.py:318-322: period is missing iff count(notnull) != expected number of days (missing.py:64-160)."""
+    da = np.asarray(da)
+    valid = np.stack([(~np.isnan(da[idx])).sum(axis=0) for _, idx in groups(time, freq)], axis=0)
+    expected = days_in_period(time, freq)
+    return valid != expected.reshape((-1,) + (1,) * (da.ndim - 1))
+
+
+def apply_missing(out, da, time: OTime, freq):
+    """Indicator._postprocess (core/indicator.py:1522-1549): out.where(~mask) -> float64 NaN where missing."""
+    mask = missing_any(da, time, freq)
+    res = np.asarray(out).astype(np.float64)
+    res[mask] = np.nan
+    return res
+
+
+def tg_mean(tas, time: OTime, freq="YS"):
+    """indices/_simple.py:113: select_resample_op(tas, op="mean", freq)."""
+    return ogen.select_resample_op(tas, "mean", time, freq)
+
+
+def tx90p(tasmax, tasmax_per, per_doys, time: OTime, freq="YS", op=">"):
+    """indices/_multivariate.py:1584-1592: thresh = resample_doy(per, tasmax); threshold_count(tasmax, op, thresh).
+
+    `tasmax_per` is the (ndoy, ...) float64 output of percentile_doy for one percentile; the compare is evaluated
+    in float64 because the threshold array is float64 (numpy promotion).
+    """
+    thresh = ocal.resample_doy(tasmax_per, per_doys, time)
+    return ogen.threshold_count(tasmax, op, thresh, time, freq, constrain=(">", ">="))
+
+
+def maximum_consecutive_dry_days(pr, thresh, time: OTime, freq="YS", resample_before_rl=True):
+    """indices/_threshold.py:2925-2937: spell_length_statistics(pr, thresh, 1, None, "<", "max", freq).
+
+    `thresh` must be a python float already in the units of `pr` (convert_units_to is host work)."""
+    return ogen.spell_length_statistics(pr, float(thresh), 1, None, "<", "max", time, freq, resample_before_rl)

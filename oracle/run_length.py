@@ -1,0 +1,300 @@
+"""Oracle: run-length algorithms (reference: src/xclim/indices/run_length.py).  TEST INFRASTRUCTURE ONLY.
+
+numpy restatement with time on axis 0.  xarray semantics restated explicitly: ``where`` promotes small unsigned
+ints to float32 (float64 from uint32 up), ``shift(fill_value=0)``, ``resample(time=freq).map``.
+"""
+
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from .timeutil import OTime, groups
+
+
+def _smallest_uint(T: int):
+    """rl:135-139."""
+    for dt in (np.uint8, np.uint16, np.uint32, np.uint64):
+        if np.iinfo(dt).max > T:
+            return dt
+    return np.uint64
+
+
+def _promote(dtype):
+    """xarray dtypes.maybe_promote for the dtypes that occur here."""
+    dtype = np.dtype(dtype)
+    if dtype.kind == "f":
+        return dtype
+    if dtype.kind == "b":
+        return np.dtype(object)  # never needed: bool arrays are converted before `where`
+    return np.dtype(np.float32) if dtype.itemsize <= 2 else np.dtype(np.float64)
+
+
+def where_nan(a, cond):
+    """``a.where(cond)``: NaN where cond is False, with xarray's dtype promotion."""
+    a = np.asarray(a)
+    out = a.astype(_promote(a.dtype), copy=True)
+    out[~np.broadcast_to(cond, out.shape)] = np.nan
+    return out
+
+
+def shift0(a, n, fill):
+    """``a.shift(time=n, fill_value=fill)`` along axis 0 (n > 0 moves data towards later times)."""
+    a = np.asarray(a)
+    out = np.full_like(a, fill)
+    if n == 0:
+        return a.copy()
+    if abs(n) >= a.shape[0]:
+        return out
+    if n > 0:
+        out[n:] = a[:-n]
+    else:
+        out[:n] = a[-n:]
+    return out
+
+
+def cumsum_reset_np(arr, index, one):
+    """rl:143-151 `_cumsum_reset_np` with the core dim on axis 0 instead of -1.  100110111 -> 100120123."""
+    T = arr.shape[0]
+    it = range(1, T) if index == "last" else range(T - 2, -1, -1)
+    step = 1 if index == "last" else -1
+    for i in it:
+        arr[i] *= arr[i - step] + one
+    return arr
+
+
+def cumsum_reset(da, index="last"):
+    """rl:172-219 `_cumsum_reset` fast track: NaN -> 0, then the njit recurrence."""
+    da = np.asarray(da)
+    typ = _smallest_uint(da.shape[0])
+    if da.dtype.kind == "f":
+        a = np.where(np.isnan(da), da.dtype.type(0), da)  # fillna(typ(0)) keeps the float dtype
+    elif da.dtype.kind == "b":
+        a = da.astype(typ)  # where(notnull, bool, uint) -> uint
+    else:
+        a = da.astype(np.result_type(da.dtype, typ))
+    return cumsum_reset_np(a.copy(), index, typ(1))
+
+
+def cumsum_reset_xr(da, index, reset_on_zero):
+    """rl:154-169 `_cumsum_reset_xr` (float capable; NaN handling differs from the fast track)."""
+    da = np.asarray(da)
+    if index == "first":
+        da = da[::-1]
+    with np.errstate(invalid="ignore"):
+        cs = np.nancumsum(da, axis=0) if da.dtype.kind == "f" else np.cumsum(da, axis=0)
+    if da.dtype.kind == "f":
+        # xarray cumsum(skipna=True): NaN treated as 0 in the running sum (result not NaN)
+        pass
+    cond = (da == 0) if reset_on_zero else np.isnan(da)
+    cs2 = where_nan(cs, cond)
+    cs2[0] = 0
+    # ffill along axis 0
+    idx = np.where(~np.isnan(cs2), np.arange(cs2.shape[0]).reshape((-1,) + (1,) * (cs2.ndim - 1)), 0)
+    idx = np.maximum.accumulate(idx, axis=0)
+    cs2 = np.take_along_axis(cs2, idx, axis=0)
+    out = cs - cs2
+    if index == "first":
+        out = out[::-1]
+    return out
+
+
+def rle(da, index="first"):
+    """rl:223-272 `rle`."""
+    da = np.asarray(da)
+    if da.shape[0] == 0:
+        return da.astype(np.float32)
+    if index == "first":
+        da = da[::-1]
+    cs_s = cumsum_reset(da)
+    # keep numbers with a 0 to the right (and the last number); NaN neighbours compare False (rl:264)
+    with np.errstate(invalid="ignore"):
+        nxt = shift0(da.astype(np.float64) if da.dtype.kind != "f" else da, -1, 0)
+        cs_s = where_nan(cs_s, nxt == 0)
+        pos = da > 0
+    out = np.where(pos, cs_s, cs_s.dtype.type(0))  # .where(da > 0, 0)
+    if index == "first":
+        out = out[::-1]
+    return out
+
+
+def _rl_stat(d, window, reducer):
+    """rl:311-327 `get_rl_stat` on one (sub-)array, time on axis 0."""
+    with np.errstate(invalid="ignore"):
+        ok = d >= window
+    dw = where_nan(d, ok)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        if reducer == "max":
+            stat = np.nanmax(dw, axis=0)
+        elif reducer == "min":
+            stat = np.nanmin(dw, axis=0)
+        elif reducer == "sum":
+            stat = np.nansum(dw, axis=0)
+        elif reducer == "mean":
+            stat = np.nanmean(dw, axis=0)
+        elif reducer == "std":
+            stat = np.nanstd(dw, axis=0)
+        elif reducer == "count":
+            stat = np.sum(~np.isnan(dw), axis=0)
+        elif reducer.startswith("q") and reducer[1:].isdigit():
+            stat = np.nanquantile(dw.astype(np.float64), float(f"0.{reducer[1:]}"), axis=0)
+        else:
+            raise ValueError(reducer)
+    with np.errstate(invalid="ignore"):
+        none = (np.isnan(d) | (d < window)).all(axis=0)
+    return np.where(none, 0, stat)
+
+
+def _map_groups(arr, time: OTime, freq, func):
+    """``arr.resample(time=freq).map(func)`` with func reducing axis 0."""
+    outs = []
+    for _, idx in groups(time, freq):
+        outs.append(func(arr[idx], time.isel(idx)))
+    return np.stack(outs, axis=0)
+
+
+def rle_statistics(da, reducer, window, time: OTime | None = None, freq=None, index="first"):
+    """rl:275-335 (N-D path, ufunc_1dim=False): resample AFTER the run-length encoding when freq is given."""
+    d = rle(da, index=index)
+    if freq is None:
+        return _rl_stat(d, window, reducer)
+    return _map_groups(d, time, freq, lambda g, _t: _rl_stat(g, window, reducer))
+
+
+def longest_run(da, time=None, freq=None, index="first"):
+    """rl:338-378."""
+    return rle_statistics(da, "max", 1, time, freq, index)
+
+
+def windowed_run_events(da, window, time=None, freq=None, index="first"):
+    """rl:381-434."""
+    da = np.asarray(da)
+    if window == 1:
+        shift = 1 if index == "first" else -1
+        with np.errstate(invalid="ignore"):
+            d = np.where(shift0(da.astype(np.float64), shift, 0) == 0, 1, 0)
+            d = np.where(da == 1, d, 0)
+    else:
+        d = rle(da, index=index)
+        with np.errstate(invalid="ignore"):
+            d = np.where(d >= window, 1, 0)
+    if freq is not None:
+        return _map_groups(d, time, freq, lambda g, _t: g.sum(axis=0))
+    return d.sum(axis=0)
+
+
+def windowed_run_count(da, window, time=None, freq=None, index="first"):
+    """rl:437-488."""
+    da = np.asarray(da)
+    if window == 1 and freq is None:
+        return np.nansum(da.astype(np.float64) if da.dtype.kind != "f" else da, axis=0)
+    d = rle(da, index=index)
+    with np.errstate(invalid="ignore"):
+        d = np.where(d >= window, d, 0)  # d.where(d >= window, 0): NaN >= window False -> 0
+    if freq is not None:
+        return _map_groups(d, time, freq, lambda g, _t: g.sum(axis=0))
+    return d.sum(axis=0)
+
+
+def windowed_max_run_sum(da, window, time=None, freq=None, index="first"):
+    """rl:491-540."""
+    da = np.asarray(da)
+    if window == 1 and freq is None:
+        return np.nanmax(cumsum_reset_xr(da, index, True), axis=0)
+    d_rse = cumsum_reset_xr(da, index, True)
+    d_rle = rle((da > 0), index=index)
+    with np.errstate(invalid="ignore"):
+        d = np.where(d_rle >= window, d_rse, 0)
+    if freq is not None:
+        return _map_groups(d, time, freq, lambda g, _t: np.nanmax(g, axis=0))
+    return np.nanmax(d, axis=0)
+
+
+def _find_boundary_run(runs, position):
+    """rl:591-603 `find_boundary_run` (index output, coord=False)."""
+    T = runs.shape[0]
+    if position == "last":
+        runs = runs[::-1]
+    dmax = runs.argmax(axis=0)
+    out = np.where(dmax != runs.argmin(axis=0), dmax.astype(np.float64), np.nan)
+    if position == "last":
+        out = T - out - 1
+    return out
+
+
+def boundary_run(da, window, time=None, freq=None, position="first"):
+    """rl:543-640 `_boundary_run`, N-D path (ufunc_1dim=False), coord=False."""
+    da = np.asarray(da)
+    if da.dtype.kind == "f":
+        da = np.where(np.isnan(da), da.dtype.type(0), da)
+    if window == 1:
+        if freq is not None:
+            return _map_groups(da, time, freq, lambda g, _t: _find_boundary_run(g, position))
+        return _find_boundary_run(da, position)
+    d = cumsum_reset(da, index=position)
+    d = np.where(d >= window, 1, 0)
+    if freq is not None:
+        return _map_groups(d, time, freq, lambda g, _t: _find_boundary_run(g, position))
+    return _find_boundary_run(d, position)
+
+
+def first_run(da, window, time=None, freq=None):
+    """rl:643-690."""
+    return boundary_run(da, window, time, freq, "first")
+
+
+def last_run(da, window, time=None, freq=None):
+    """rl:693-740."""
+    return boundary_run(da, window, time, freq, "last")
+
+
+def resample_and_rl(da, resample_before_rl, compute, *args, time: OTime, freq, **kwargs):
+    """rl:87-132: resample before (cut the series per period, then compute with freq=None) or after."""
+    if resample_before_rl:
+        return _map_groups(np.asarray(da), time, freq, lambda g, t: compute(g, *args, time=t, freq=None, **kwargs))
+    return compute(da, *args, time=time, freq=freq, **kwargs)
+
+
+# ---- 1-D variants (rl:1334-1618), for small cases ----
+def rle_1d(arr):
+    """rl:1334-1340 `_rle_1d` + rl:1343-1405: (values, run lengths, start positions)."""
+    ia = np.asarray(arr)
+    n = len(ia)
+    if n == 0:
+        return None, None, None
+    y = ia[1:] != ia[:-1]
+    i = np.append(np.nonzero(y)[0], n - 1)
+    rl_ = np.diff(np.append(-1, i))
+    pos = np.cumsum(np.append(0, rl_))[:-1]
+    return ia[i], rl_, pos
+
+
+def statistics_run_1d(arr, reducer, window):
+    """rl:1408-1437."""
+    v, rls, _ = rle_1d(arr)
+    sel = rls[np.where(v & (rls >= window), True, False)] if v is not None else np.array([])
+    sel = rls[(v.astype(bool)) & (rls >= window)]
+    if sel.size == 0:
+        return 0
+    return getattr(np, f"nan{reducer}")(sel)
+
+
+def windowed_run_count_1d(arr, window):
+    """rl:1440-1458."""
+    v, rls, _ = rle_1d(arr)
+    return np.where(v * rls >= window, rls, 0).sum()
+
+
+def windowed_run_events_1d(arr, window):
+    """rl:1461-1480."""
+    v, rls, _ = rle_1d(arr)
+    return (v * rls >= window).sum()
+
+
+def first_run_1d(arr, window):
+    """rl:1483-1497 (NaN when no run)."""
+    v, rls, pos = rle_1d(arr)
+    ind = np.where(v * rls >= window, pos, np.inf).min()
+    return np.nan if np.isinf(ind) else ind

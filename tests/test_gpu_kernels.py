@@ -1,0 +1,321 @@
+"""GPU parity: every HIP entry point (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): integer counts / run lengths bit-exact; float quantiles / means <= 1e-6 relative.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import calendar as ocal
+from oracle import generic as ogen
+from oracle import quantile as oq
+from oracle import run_length as orl
+from oracle import sdba as osdba
+from oracle import synth as osynth
+from oracle.timeutil import OTime
+from xclim_amd import kernels as K
+from xclim_amd.timeaxis import TimeAxis
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6  # float tolerance stated by the north star
+
+
+def _field(rng, T, C, nan_frac=0.0, kind="temp"):
+    t = np.arange(T)[:, None]
+    if kind == "temp":
+        x = 288 + 12 * np.sin(2 * np.pi * (t - 100) / 365) + rng.normal(0, 3, (T, C))
+    else:
+        x = np.where(rng.random((T, C)) < 0.3, rng.gamma(0.8, 8.0, (T, C)) / 86400.0, 0.0)
+    x = x.astype(np.float32)
+    if nan_frac:
+        x[rng.random((T, C)) < nan_frac] = np.nan
+    return x
+
+
+def _times(start, T, calendar="standard"):
+    if calendar == "standard":
+        return TimeAxis.daily(start, T), OTime.standard(start, T)
+    return TimeAxis.daily(start, T, calendar), OTime.noleap(int(start[:4]), T, calendar)
+
+
+@pytest.mark.parametrize("C", [1, 7, 256, 1000])
+@pytest.mark.parametrize("op", [">", "<", ">=", "<=", "==", "!="])
+def test_threshold_count_scalar(dev, rng, C, op):
+    T = 800
+    x = _field(rng, T, C, nan_frac=0.01)
+    x[5] = np.float32(290.0)  # exact ties for ==, >=
+    ta, ot = _times("2000-03-15", T)
+    for freq in ("YS", "MS", "QS-DEC", "YS-JUL"):
+        seg, _ = ta.segments(freq)
+        cnt, val = K.threshold_count(dev, dev.to_device(x), op, seg, scalar=290.0)
+        exp = ogen.count_occurrences(x, 290.0, op, ot, freq)
+        np.testing.assert_array_equal(cnt.get(), exp)
+        expv = ogen.select_resample_op(x, "count", ot, freq)
+        np.testing.assert_array_equal(val.get(), expv)
+
+
+def test_threshold_count_scalar_promotion(dev, rng):
+    """python-float threshold -> fp32 compare; np.float64 threshold -> fp64 compare."""
+    T, C = 400, 64
+    thr = 1.0 / 86400.0
+    x = np.full((T, C), np.float32(thr), dtype=np.float32)  # equals the fp32-rounded threshold
+    x[::2] = np.nextafter(np.float32(thr), np.float32(0))
+    ta, ot = _times("2001-01-01", T)
+    seg, _ = ta.segments("YS")
+    d = dev.to_device(x)
+    c32, _ = K.threshold_count(dev, d, "<", seg, scalar=thr)
+    c64, _ = K.threshold_count(dev, d, "<", seg, scalar=thr, scalar_f64=True)
+    np.testing.assert_array_equal(c32.get(), ogen.threshold_count(x, "<", thr, ot, "YS"))
+    np.testing.assert_array_equal(c64.get(), ogen.threshold_count(x, "<", np.float64(thr), ot, "YS"))
+    assert not np.array_equal(c32.get(), c64.get())
+
+
+@pytest.mark.parametrize("C", [3, 512])
+def test_threshold_count_doy_and_full(dev, rng, C):
+    T = 365 * 3 + 1
+    x = _field(rng, T, C, nan_frac=0.005)
+    ta, ot = _times("2001-01-01", T)
+    seg, _ = ta.segments("YS")
+    table = (288 + 12 * np.sin(2 * np.pi * (np.arange(366)[:, None] - 100) / 365) + rng.normal(0, 1, (366, C)))
+    tidx = (ta.doy - 1).astype(np.int32)
+    full = table[tidx]
+    d = dev.to_device(x)
+    c1, _ = K.threshold_count(dev, d, ">", seg, doy_table=dev.to_device(table), tidx=tidx)
+    c2, _ = K.threshold_count(dev, d, ">", seg, full=dev.to_device(full))
+    exp = ogen.threshold_count(x, ">", full, ot, "YS")
+    np.testing.assert_array_equal(c1.get(), exp)
+    np.testing.assert_array_equal(c2.get(), exp)
+    t32 = table.astype(np.float32)
+    c3, _ = K.threshold_count(dev, d, ">=", seg, doy_table=dev.to_device(t32), tidx=tidx)
+    np.testing.assert_array_equal(c3.get(), ogen.threshold_count(x, ">=", t32[tidx], ot, "YS"))
+
+
+def test_domain_count(dev, rng):
+    T, C = 730, 300
+    x = _field(rng, T, C, nan_frac=0.01)
+    ta, ot = _times("2000-01-01", T)
+    seg, _ = ta.segments("MS")
+    c, _ = K.domain_count(dev, dev.to_device(x), ">", 285.0, "<=", 295.0, "and", seg)
+    np.testing.assert_array_equal(c.get(), ogen.domain_count(x, np.float32(285.0), np.float32(295.0), ot, "MS"))
+
+
+@pytest.mark.parametrize("reducer", ["sum", "mean", "min", "max", "std", "var", "count", "argmin", "argmax"])
+@pytest.mark.parametrize("C", [5, 1024])
+def test_resample_reduce(dev, rng, reducer, C):
+    T = 900
+    x = _field(rng, T, C, nan_frac=0.02)
+    x[:40, 0] = np.nan  # an all-NaN month
+    ta, ot = _times("1999-11-20", T)
+    for freq in ("YS", "MS"):
+        seg, _ = ta.segments(freq)
+        out, _ = K.resample_reduce(dev, dev.to_device(x), reducer, seg)
+        exp = ogen.select_resample_op(x, reducer, ot, freq)
+        if reducer in ("count", "argmin", "argmax"):
+            np.testing.assert_array_equal(out.get(), exp)
+        else:
+            np.testing.assert_allclose(out.get(), exp, rtol=RTOL, atol=1e-30 if reducer not in ("std", "var") else 1e-6,
+                                       equal_nan=True)
+
+
+@pytest.mark.parametrize("window,center", [(5, True), (3, False), (14, True), (4, True)])
+@pytest.mark.parametrize("reducer", ["sum", "mean", "min", "max", "std"])
+def test_rolling_reduce(dev, rng, window, center, reducer):
+    T, C = 120, 70
+    x = _field(rng, T, C, nan_frac=0.02)
+    out = K.rolling_reduce(dev, dev.to_device(x), window, reducer, center)
+    exp = ogen.rolling(x, window, reducer, center)
+    np.testing.assert_allclose(out.get(), exp, rtol=RTOL, atol=2e-6 if reducer == "std" else 0, equal_nan=True)
+
+
+def _mask(rng, T, C, p=0.6, nan_frac=0.0):
+    m = (rng.random((T, C)) < p).astype(np.float32)
+    # long runs
+    m[10:60, : C // 3] = 1
+    if nan_frac:
+        m[rng.random((T, C)) < nan_frac] = np.nan
+    return m
+
+
+@pytest.mark.parametrize("index", ["first", "last"])
+@pytest.mark.parametrize("nan_frac", [0.0, 0.05])
+def test_cumsum_reset_and_rle(dev, rng, index, nan_frac):
+    T, C = 200, 130
+    m = _mask(rng, T, C, nan_frac=nan_frac)
+    m[:, 0] = np.nan  # all-NaN column -> 0 (tests/test_run_length.py:89-91)
+    m[:, 1] = 1
+    m[:, 2] = 0
+    d = dev.to_device(m)
+    np.testing.assert_array_equal(K.cumsum_reset(dev, d, index).get(), orl.cumsum_reset(m, index))
+    np.testing.assert_array_equal(K.rle(dev, d, index).get(), orl.rle(m, index))
+
+
+@pytest.mark.parametrize("stat", ["max", "min", "sum", "count", "mean", "std"])
+@pytest.mark.parametrize("index", ["first", "last"])
+@pytest.mark.parametrize("cut", [True, False])
+def test_run_stats_mask(dev, rng, stat, index, cut):
+    T, C = 800, 260
+    ta, ot = _times("2000-02-10", T)
+    for nan_frac, window, freq in ((0.0, 1, "YS"), (0.03, 3, "MS"), (0.03, 1, "QS-DEC")):
+        m = _mask(rng, T, C, nan_frac=nan_frac)
+        seg, _ = ta.segments(freq)
+        out, _ = K.run_stats(dev, dev.to_device(m), stat, window, seg, cut=cut, index=index)
+        exp = orl.resample_and_rl(m, cut, orl.rle_statistics, time=ot, freq=freq, reducer=stat, window=window, index=index)
+        if stat in ("mean", "std"):
+            np.testing.assert_allclose(out.get(), exp, rtol=RTOL, atol=1e-5 if stat == "std" else 0)
+        else:
+            np.testing.assert_array_equal(out.get(), exp)
+
+
+@pytest.mark.parametrize("window", [1, 2, 5])
+@pytest.mark.parametrize("index", ["first", "last"])
+def test_windowed_run_count_events(dev, rng, window, index):
+    T, C = 500, 100
+    ta, ot = _times("2003-01-01", T)
+    m = _mask(rng, T, C, nan_frac=0.02)
+    seg, _ = ta.segments("MS")
+    d = dev.to_device(m)
+    for cut in (True, False):
+        ev, _ = K.run_stats(dev, d, "count", window, seg, cut=cut, index=index)
+        exp_ev = orl.resample_and_rl(m, cut, orl.windowed_run_events, window, time=ot, freq="MS", index=index)
+        np.testing.assert_array_equal(ev.get(), exp_ev)
+        stat = "plainsum" if (window == 1 and cut) else "sum"
+        cn, _ = K.run_stats(dev, d, stat, window, seg, cut=cut, index=index)
+        exp_cn = orl.resample_and_rl(m, cut, orl.windowed_run_count, window, time=ot, freq="MS", index=index)
+        np.testing.assert_array_equal(cn.get(), exp_cn)
+
+
+@pytest.mark.parametrize("window", [1, 3, 7])
+@pytest.mark.parametrize("cut", [True, False])
+def test_first_last_run(dev, rng, window, cut):
+    T, C = 730, 90
+    ta, ot = _times("2001-01-01", T)
+    m = _mask(rng, T, C, p=0.5, nan_frac=0.02)
+    m[:, 0] = 1  # all-True quirk (rl:603-605)
+    m[:, 1] = 0
+    m[300:420, 2] = 1  # a run covering a whole month
+    seg, _ = ta.segments("MS")
+    d = dev.to_device(m)
+    if window == 1 and not cut:
+        pytest.skip("window == 1 with freq always maps per group in the reference (rl:618-621)")
+    f, _ = K.run_stats(dev, d, "first", window, seg, cut=cut)
+    l, _ = K.run_stats(dev, d, "last", window, seg, cut=cut)
+    exp_f = orl.resample_and_rl(m, cut, orl.first_run, window, time=ot, freq="MS")
+    exp_l = orl.resample_and_rl(m, cut, orl.last_run, window, time=ot, freq="MS")
+    np.testing.assert_array_equal(f.get(), exp_f)
+    np.testing.assert_array_equal(l.get(), exp_l)
+
+
+def test_cdd_fused(dev, rng):
+    """maximum_consecutive_dry_days: fused compare + rle max, before/after resampling (26 vs 30 style)."""
+    T, C = 1461, 500
+    pr = _field(rng, T, C, nan_frac=0.001, kind="pr")
+    thr = 1.0 / 86400.0
+    ta, ot = _times("2000-01-01", T)
+    seg, _ = ta.segments("YS")
+    d = dev.to_device(pr)
+    for cut in (True, False):
+        out, val = K.run_stats(dev, d, "max", 1, seg, cut=cut, fused_op="<", thresh=thr)
+        exp = ogen.spell_length_statistics(pr, thr, 1, None, "<", "max", ot, "YS", resample_before_rl=cut)
+        np.testing.assert_array_equal(out.get(), exp)
+        np.testing.assert_array_equal(val.get(), ogen.select_resample_op(pr, "count", ot, "YS"))
+
+
+@pytest.mark.parametrize("N,C", [(1, 10), (2, 10), (5, 300), (8, 64), (13, 70), (30, 129), (150, 200), (365, 40)])
+@pytest.mark.parametrize("ab", [(1.0, 1.0), (1 / 3, 1 / 3)])
+def test_nan_quantile(dev, rng, N, C, ab):
+    x = rng.normal(0, 1, (N, C)).astype(np.float32)
+    x[rng.random((N, C)) < 0.1] = np.nan
+    if C > 3:
+        x[:, 0] = np.nan
+        x[1:, 1] = np.nan
+        x[:, 2] = 1.5
+    q = np.array([0.0, 0.1, 0.5, 0.9, 0.99, 1.0])
+    out = K.nan_quantile(dev, dev.to_device(x), q, *ab).get()
+    exp = oq.nan_quantile(x, q, 0, *ab)
+    np.testing.assert_allclose(out, exp, rtol=1e-12, atol=0, equal_nan=True)
+    # sample-minor layout (what apply_ufunc hands calc_perc)
+    out2 = K.nan_quantile(dev, dev.to_device(np.ascontiguousarray(x.T)), q, *ab, sample_axis=1).get()
+    np.testing.assert_allclose(out2, exp, rtol=1e-12, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("nyears,window,C,calendar", [(1, 5, 260, "noleap"), (1, 5, 64, "standard"), (3, 5, 33, "standard"),
+                                                     (6, 5, 70, "noleap"), (9, 7, 20, "standard"), (30, 5, 24, "noleap"),
+                                                     (2, 4, 16, "noleap")])
+def test_percentile_doy(dev, rng, nyears, window, C, calendar):
+    start = "2000-01-01"
+    T = 365 * nyears + (nyears + 3) // 4 if calendar == "standard" else 365 * nyears
+    x = _field(rng, T, C, nan_frac=0.01)
+    ta, ot = _times(start, T, calendar)
+    tb, years, doys = ta.doy_table()
+    per = [10.0, 50.0, 90.0]
+    out = K.percentile_doy(dev, dev.to_device(x), tb, window, per).get()  # (nper, ndoy, C)
+    # oracle without the 366 adjustment: call the stacked calc_perc directly
+    rr = ocal.rolling_construct_center(x, window)
+    stack = np.full((len(doys), len(years), C, window), np.nan, dtype=np.float32)
+    stack[np.searchsorted(doys, ot.doy), np.searchsorted(years, ot.year)] = rr
+    stack = np.moveaxis(stack, 1, -2).reshape(len(doys), C, len(years) * window)
+    exp = oq.calc_perc(stack, per, 1 / 3, 1 / 3)  # (ndoy, C, nper)
+    np.testing.assert_allclose(out, np.moveaxis(exp, -1, 0), rtol=1e-12, atol=0, equal_nan=True)
+
+
+def test_doy_interp(dev, rng):
+    C = 50
+    src = rng.normal(280, 5, (365, C))
+    src[100:104, 3] = np.nan
+    src[:2, 4] = np.nan
+    src[-3:, 5] = np.nan
+    exp, target = ocal.interpolate_doy_calendar(src, np.arange(1, 366), 366, 1)
+    from xclim_amd.calendar import doy_interp_tables
+
+    i0, i1, dxn, dxs = doy_interp_tables(365, 366, 1)
+    out = K.doy_interp(dev, dev.to_device(src, dtype=np.float64), i0, i1, dxn, dxs).get()
+    np.testing.assert_allclose(out, exp, rtol=1e-13, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("T,C", [(365, 100), (40, 7), (1000, 33), (5000, 6), (10950, 5)])
+def test_quantile_series(dev, rng, T, C):
+    x = _field(rng, T, C, nan_frac=0.01)
+    x[:, 0] = np.nan
+    q = osdba.equally_spaced_nodes(20)
+    exp = osdba.quantile(x, q)
+    out = K.quantile_series(dev, dev.to_device(x), q).get()
+    np.testing.assert_allclose(out, exp, rtol=RTOL, atol=0, equal_nan=True)
+    out2 = K.quantile_series(dev, dev.to_device(np.ascontiguousarray(x.T)), q, time_axis=1).get()
+    np.testing.assert_allclose(out2, exp, rtol=RTOL, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("interp", ["nearest", "linear"])
+@pytest.mark.parametrize("extrap", ["constant", "nan"])
+def test_eqm_train_adjust(dev, rng, kind, interp, extrap):
+    T, C = 730, 150
+    ref = _field(rng, T, C)
+    hist = (_field(rng, T, C) + 1.5).astype(np.float32)
+    sim = (_field(rng, T, C, nan_frac=0.01) + 2.0).astype(np.float32)
+    hist[:, 0] = np.nan
+    q = osdba.equally_spaced_nodes(20)
+    af, hq = K.eqm_train(dev, dev.to_device(ref), dev.to_device(hist), q, kind)
+    eaf, ehq = osdba.eqm_train(ref, hist, 20, kind)
+    np.testing.assert_allclose(hq.get(), ehq, rtol=RTOL, equal_nan=True)
+    np.testing.assert_allclose(af.get(), eaf, rtol=1e-5 if kind == "+" else RTOL, atol=1e-5 if kind == "+" else 0,
+                               equal_nan=True)
+    # adjust from the ORACLE's nodes so the comparison isolates the search/interp kernel (bit-exact expected)
+    scen = K.eqm_adjust(dev, dev.to_device(sim), dev.to_device(eaf), dev.to_device(ehq), kind, interp, extrap).get()
+    exp = osdba.eqm_adjust(sim, eaf, ehq, kind, interp, extrap)
+    np.testing.assert_allclose(scen, exp, rtol=RTOL, atol=0, equal_nan=True)
+
+
+def test_synthetic_matches_oracle(dev):
+    T, C = 400, 777
+    base = osynth.seasonal_base(T)
+    for kind, amp in ((0, 3.0), (1, 40.0 / 86400.0)):
+        b = base if kind == 0 else np.zeros(T, np.float32)
+        g = K.fill_synthetic(dev, T, C, kind, 42, b, amp, 0.3, 1000, cell0=5000).get()
+        e = osynth.fill_synthetic(T, np.arange(5000, 5000 + C), kind, 42, b, amp, 0.3, 1000)
+        np.testing.assert_array_equal(g, e)
+
+
+def test_transpose(dev, rng):
+    x = rng.normal(size=(130, 77)).astype(np.float32)
+    np.testing.assert_array_equal(K.transpose(dev, dev.to_device(x)).get(), x.T)

@@ -1,0 +1,263 @@
+"""ctypes binding of libxclimhip.so (include/xclim_hip.h) — the thin C-ABI layer named by the north star.
+
+No torch, no cffi (not installed offline).  The library is looked up in-tree (xclim_amd/lib/libxclimhip.so, built by
+``__graft_entry__.build()`` / ``make -C xclim_amd/csrc``).  Every compute call goes to the HIP kernels; there is NO CPU
+fallback: if the library or a GPU is missing the call raises :class:`BackendUnavailable`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libxclimhip.so")
+
+XH_OK = 0
+XH_ERR_HIP, XH_ERR_ARG, XH_ERR_LAYOUT, XH_ERR_OP, XH_ERR_NOTIMPL, XH_ERR_NODEVICE, XH_ERR_LIMIT = -1, -2, -3, -4, -5, -6, -7
+
+OPS = {">": 0, "gt": 0, "<": 1, "lt": 1, ">=": 2, "ge": 2, "<=": 3, "le": 3, "==": 4, "eq": 4, "!=": 5, "ne": 5}
+THR_SCALAR_F32, THR_SCALAR_F64, THR_DOY_F64, THR_DOY_F32, THR_FULL_F64, THR_FULL_F32 = range(6)
+REDUCERS = {"sum": 0, "integral": 0, "mean": 1, "min": 2, "max": 3, "std": 4, "var": 5, "count": 6, "argmin": 7, "argmax": 8}
+RUN_STATS = {"max": 0, "min": 1, "sum": 2, "count": 3, "mean": 4, "std": 5, "first": 6, "last": 7, "plainsum": 8}
+
+
+class BackendUnavailable(RuntimeError):
+    """libxclimhip.so is not built/loadable or no MI355X device is visible."""
+
+
+class XclimHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[xclimhip {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+_i32, _i64, _u32, _u64 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
+_vp, _dbl, _flt, _int, _sz = C.c_void_p, C.c_double, C.c_float, C.c_int, C.c_size_t
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES); mirrors include/xclim_hip.h one to one
+SIGNATURES: dict[str, list] = {
+    "xh_abi_version": [],
+    "xh_last_error": [],
+    "xh_device_count": [C.POINTER(_int)],
+    "xh_create": [_int, C.POINTER(_vp)],
+    "xh_destroy": [_vp],
+    "xh_sync": [_vp],
+    "xh_device_name": [_vp, C.c_char_p, _sz],
+    "xh_mem_info": [_vp, C.POINTER(_sz), C.POINTER(_sz)],
+    "xh_malloc": [_vp, _sz, C.POINTER(_vp)],
+    "xh_free": [_vp, _vp],
+    "xh_memset": [_vp, _vp, _int, _sz],
+    "xh_memcpy_h2d": [_vp, _vp, _vp, _sz],
+    "xh_memcpy_d2h": [_vp, _vp, _vp, _sz],
+    "xh_memcpy_d2d": [_vp, _vp, _vp, _sz],
+    "xh_timer_start": [_vp],
+    "xh_timer_stop": [_vp, C.POINTER(_flt)],
+    "xh_stream": [_vp, C.POINTER(_vp)],
+    "xh_fill_synthetic": [_vp, _vp, _i64, _i64, _i64, _int, _u64, _i64, _vp, _flt, _flt, _u32],
+    "xh_transpose_f32": [_vp, _vp, _i64, _i64, _i64, _vp, _i64],
+    "xh_threshold_count": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _dbl, _vp, _i64, _vp, _vp, _int, _vp, _vp],
+    "xh_domain_count": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _int, _dbl, _int, _vp, _int, _vp, _vp],
+    "xh_resample_reduce": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _int, _vp, _vp],
+    "xh_apply_missing_mask": [_vp, _vp, _int, _vp, _vp, _int, _i64, _vp],
+    "xh_rolling_reduce": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _vp, _i64],
+    "xh_cumsum_reset": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64],
+    "xh_rle": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64],
+    "xh_run_stats": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _int, _int, _int, _vp, _int, _int, _vp, _vp],
+    "xh_nan_quantile": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _dbl, _dbl, _vp],
+    "xh_percentile_doy": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _vp, _int, _dbl, _dbl, _vp],
+    "xh_doy_interp": [_vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _int, _vp],
+    "xh_quantile_series": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp],
+    "xh_eqm_train": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _vp, _vp],
+    "xh_eqm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64],
+}
+_RESTYPES = {"xh_last_error": C.c_char_p}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """Load libxclimhip.so and declare every prototype of include/xclim_hip.h.  Raises BackendUnavailable."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise BackendUnavailable(
+                f"{_LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C xclim_amd/csrc` (needs hipcc)"
+            )
+        try:
+            lib = C.CDLL(_LIB_PATH)
+        except OSError as err:  # pragma: no cover
+            raise BackendUnavailable(f"cannot load {_LIB_PATH}: {err}") from err
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the header and the library diverge
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, _int)
+        _lib = lib
+        return lib
+
+
+def _check(lib, rc: int):
+    if rc != XH_OK:
+        msg = lib.xh_last_error()
+        msg = msg.decode() if msg else ""
+        if rc == XH_ERR_NODEVICE:
+            raise BackendUnavailable(msg)
+        if rc == XH_ERR_OP:
+            raise ValueError(msg)
+        raise XclimHipError(rc, msg)
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = _int(0)
+    _check(lib, lib.xh_device_count(C.byref(n)))
+    return n.value
+
+
+class DeviceArray:
+    """A typed device buffer owned by a :class:`Device` (hipMalloc'd through xh_malloc)."""
+
+    __slots__ = ("dev", "ptr", "shape", "dtype", "_owner")
+
+    def __init__(self, dev: "Device", ptr: int, shape, dtype, owner=True):
+        self.dev = dev
+        self.ptr = ptr
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self._owner = owner
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
+
+    @property
+    def nbytes(self) -> int:
+        return self.size * self.dtype.itemsize
+
+    def reshape(self, *shape) -> "DeviceArray":
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        shape = tuple(shape)
+        if -1 in shape:
+            known = int(np.prod([s for s in shape if s != -1], dtype=np.int64))
+            shape = tuple(self.size // max(known, 1) if s == -1 else s for s in shape)
+        assert int(np.prod(shape, dtype=np.int64)) == self.size, (shape, self.shape)
+        view = DeviceArray(self.dev, self.ptr, shape, self.dtype, owner=False)
+        view._owner = self  # keep the parent alive
+        return view
+
+    def get(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.size:
+            lib = self.dev.lib
+            _check(lib, lib.xh_memcpy_d2h(self.dev.ctx, out.ctypes.data_as(_vp), _vp(self.ptr), out.nbytes))
+        return out
+
+    def free(self):
+        if self._owner is True and self.ptr and self.dev is not None and self.dev.ctx:
+            lib = self.dev.lib
+            lib.xh_free(self.dev.ctx, _vp(self.ptr))
+        self.ptr = 0
+        self._owner = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # pragma: no cover
+            pass
+
+
+class Device:
+    """One xh_ctx (HIP stream + scratch) on one GPU.  Not re-entrant: calls are serialised by a lock."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        ctx = _vp()
+        _check(self.lib, self.lib.xh_create(device, C.byref(ctx)))
+        self.ctx = ctx
+        self.index = device
+        self.lock = threading.RLock()
+
+    # ---- memory ----
+    def empty(self, shape, dtype) -> DeviceArray:
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = _vp()
+        _check(self.lib, self.lib.xh_malloc(self.ctx, max(nbytes, 16), C.byref(p)))
+        return DeviceArray(self, p.value, shape, dtype)
+
+    def zeros(self, shape, dtype) -> DeviceArray:
+        a = self.empty(shape, dtype)
+        if a.nbytes:
+            _check(self.lib, self.lib.xh_memset(self.ctx, _vp(a.ptr), 0, a.nbytes))
+        return a
+
+    def to_device(self, arr: np.ndarray, dtype=None) -> DeviceArray:
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        d = self.empty(arr.shape, arr.dtype)
+        if arr.nbytes:
+            _check(self.lib, self.lib.xh_memcpy_h2d(self.ctx, _vp(d.ptr), arr.ctypes.data_as(_vp), arr.nbytes))
+        return d
+
+    def wrap(self, ptr: int, shape, dtype) -> DeviceArray:
+        """Wrap foreign device memory (e.g. a torch tensor's data_ptr()) without taking ownership."""
+        return DeviceArray(self, int(ptr), shape, dtype, owner=False)
+
+    def sync(self):
+        _check(self.lib, self.lib.xh_sync(self.ctx))
+
+    def name(self) -> str:
+        buf = C.create_string_buffer(256)
+        _check(self.lib, self.lib.xh_device_name(self.ctx, buf, 256))
+        return buf.value.decode()
+
+    def mem_info(self) -> tuple[int, int]:
+        f, t = _sz(0), _sz(0)
+        _check(self.lib, self.lib.xh_mem_info(self.ctx, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    def timer_start(self):
+        _check(self.lib, self.lib.xh_timer_start(self.ctx))
+
+    def timer_stop(self) -> float:
+        ms = _flt(0)
+        _check(self.lib, self.lib.xh_timer_stop(self.ctx, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if self.ctx:
+            self.lib.xh_destroy(self.ctx)
+            self.ctx = None
+
+    def call(self, name: str, *args):
+        """Invoke an entry point with this context as first argument and raise on error."""
+        with self.lock:
+            _check(self.lib, getattr(self.lib, name)(self.ctx, *args))
+
+
+_default_device: Device | None = None
+
+
+def get_device(index: int | None = None) -> Device:
+    """Process-wide default context (device from XCLIM_AMD_DEVICE / LOCAL_RANK, else 0)."""
+    global _default_device
+    if index is None:
+        index = int(os.environ.get("XCLIM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if _default_device is None or _default_device.index != index or _default_device.ctx is None:
+        _default_device = Device(index)
+    return _default_device
+
+
+def np_ptr(a: np.ndarray) -> _vp:
+    return a.ctypes.data_as(_vp)

@@ -1,0 +1,129 @@
+"""Host mirror of ``xclim.core.calendar`` for the percentile path (reference: core/calendar.py:395-494, 690-790).
+
+Same names and argument meaning as the reference; arrays are numpy (uploaded) or device arrays with TIME ON AXIS 0
+and a :class:`~xclim_amd.timeaxis.TimeAxis` instead of an xarray time coordinate.  All arithmetic runs in the HIP
+kernels (``xh_percentile_doy``, ``xh_doy_interp``); this module only builds the integer/real tables they consume.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import kernels as K
+from ._capi import DeviceArray, get_device
+from .timeaxis import TimeAxis
+
+
+class DoyPercentile:
+    """Result of :func:`percentile_doy`: device table ``data`` (nper, ndoy, C) float64 + coordinates/attrs.
+
+    Carries what the reference stores in DataArray attrs (cal:487-494): climatology_bounds, window, alpha, beta.
+    """
+
+    def __init__(self, data: DeviceArray, doys, percentiles, cell_shape, attrs):
+        self.data = data
+        self.dayofyear = np.asarray(doys)
+        self.percentiles = np.asarray(percentiles, dtype=np.float64)
+        self.cell_shape = tuple(cell_shape)
+        self.attrs = dict(attrs)
+
+    def sel(self, percentiles) -> "DoyPercentile":
+        j = int(np.nonzero(self.percentiles == percentiles)[0][0])
+        nper, nd, C = self.data.shape
+        sub = self.data.dev.wrap(self.data.ptr + j * nd * C * 8, (1, nd, C), np.float64)
+        sub._owner = self.data
+        return DoyPercentile(sub, self.dayofyear, [percentiles], self.cell_shape, self.attrs)
+
+    def values(self) -> np.ndarray:
+        """numpy array (ndoy, *cells, nper) — the reference's dim order up to the position of dayofyear."""
+        a = self.data.get()  # (nper, ndoy, C)
+        return np.moveaxis(a, 0, -1).reshape((len(self.dayofyear),) + self.cell_shape + (len(self.percentiles),))
+
+
+def doy_interp_tables(n_src: int, doy_max: int, doy_min: int = 1):
+    """Index/offset tables of ``_interpolate_doy_calendar`` (cal:716-726) in scipy interp1d form.
+
+    The n_src source rows are relabelled ``linspace(doy_min, doy_max, n_src)`` and evaluated at the integers
+    doy_min..doy_max: idx = searchsorted(x, x_new) clipped to [1, n-1], lo = idx-1, hi = idx.
+    """
+    x = np.linspace(doy_min, doy_max, n_src)
+    xn = np.arange(doy_min, doy_max + 1).astype(np.float64)
+    idx = np.clip(np.searchsorted(x, xn), 1, n_src - 1)
+    lo, hi = idx - 1, idx
+    return lo.astype(np.int32), hi.astype(np.int32), xn - x[lo], x[hi] - x[lo]
+
+
+def _flatten(arr, dev):
+    """(T, *cells) numpy/device array -> (DeviceArray (T, C), cell_shape)."""
+    if isinstance(arr, DeviceArray):
+        cell_shape = arr.shape[1:]
+        return arr.reshape(arr.shape[0], -1), cell_shape
+    a = np.asarray(arr)
+    cell_shape = a.shape[1:]
+    return dev.to_device(a.reshape(a.shape[0], -1), dtype=np.float32), cell_shape
+
+
+def percentile_doy(arr, time: TimeAxis, window: int = 5, per=10.0, alpha: float = 1.0 / 3.0, beta: float = 1.0 / 3.0,
+                   copy: bool = True, device=None) -> DoyPercentile:
+    """Percentile value for each day of the year (cal:395-494).
+
+    ``copy`` is accepted for signature parity; the device kernels never mutate their input, so it is a no-op.
+    """
+    dev = device or get_device()
+    x, cell_shape = _flatten(arr, dev)
+    if len(time) != x.shape[0]:
+        raise ValueError("time axis length does not match the data")
+    tb, years, doys = time.doy_table()
+    pers = [per] if np.isscalar(per) else list(per)
+    p = K.percentile_doy(dev, x, tb, window, pers, alpha, beta)  # (nper, ndoy, C)
+    if doys.max() == 366:
+        # cal:484-485: drop doy 366 and re-interpolate 1..365 -> 1..366 (adjust_doy_calendar towards `arr`)
+        keep = doys < 366
+        nper, nd, C = p.shape
+        nsrc = int(keep.sum())
+        max_t, min_t = int(time.doy.max()), int(time.doy.min())
+        i0, i1, dxn, dxs = doy_interp_tables(nsrc, max_t, min_t)
+        out = dev.empty((nper, len(i0), C), np.float64)
+        for j in range(nper):
+            src = dev.wrap(p.ptr + j * nd * C * 8, (nsrc, C), np.float64)  # rows 0..nsrc-1 are doys < 366
+            res = K.doy_interp(dev, src, i0, i1, dxn, dxs)
+            dev.call("xh_memcpy_d2d", out.ptr + j * len(i0) * C * 8, res.ptr, res.nbytes)
+            dev.sync()
+        p = out
+        doys = np.arange(min_t, max_t + 1)
+    attrs = {
+        "window": window,
+        "alpha": alpha,
+        "beta": beta,
+        "climatology_bounds": [f"{time.year[0]:04d}-{time.month[0]:02d}-{time.day[0]:02d}",
+                               f"{time.year[-1]:04d}-{time.month[-1]:02d}-{time.day[-1]:02d}"],
+        "history": "percentile_doy(arr, window=%d, per=%s, alpha=%r, beta=%r)" % (window, pers, alpha, beta),
+    }
+    return DoyPercentile(p, doys, pers, cell_shape, attrs)
+
+
+def adjust_doy_calendar(source: DoyPercentile, target_time: TimeAxis, device=None) -> DoyPercentile:
+    """cal:729-760: re-grid the doy axis when the source does not span the target calendar's full year."""
+    dev = device or get_device()
+    if int(source.dayofyear.max()) == target_time.max_doy():
+        return source
+    max_t, min_t = int(target_time.doy.max()), int(target_time.doy.min())
+    nper, nd, C = source.data.shape
+    i0, i1, dxn, dxs = doy_interp_tables(nd, max_t, min_t)
+    out = dev.empty((nper, len(i0), C), np.float64)
+    for j in range(nper):
+        src = dev.wrap(source.data.ptr + j * nd * C * 8, (nd, C), np.float64)
+        res = K.doy_interp(dev, src, i0, i1, dxn, dxs)
+        dev.call("xh_memcpy_d2d", out.ptr + j * len(i0) * C * 8, res.ptr, res.nbytes)
+        dev.sync()
+    return DoyPercentile(out, np.arange(min_t, max_t + 1), source.percentiles, source.cell_shape, source.attrs)
+
+
+def resample_doy_index(doy: DoyPercentile, time: TimeAxis):
+    """cal:763-790 as an index table: row of the (adjusted) doy table for each time step (the gather itself is
+    fused into ``xh_threshold_count``; the (T, Y, X) fp64 temporary of the reference is never materialised)."""
+    pos = np.searchsorted(doy.dayofyear, time.doy)
+    pos_c = np.clip(pos, 0, len(doy.dayofyear) - 1)
+    if not np.all(doy.dayofyear[pos_c] == time.doy):
+        raise ValueError("day-of-year table does not cover every day of the target time axis")
+    return pos_c.astype(np.int32)

@@ -1,0 +1,141 @@
+// common.h — internal helpers shared by the HIP translation units of libxclimhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/xclim_hip.h"
+
+struct xh_ctx {
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev0, ev1;
+  // small device scratch for tables (seg_off, quantiles ...) uploaded per call
+  void* scratch;
+  size_t scratch_bytes;
+  // large scratch (transposes), grown on demand
+  void* big;
+  size_t big_bytes;
+  int num_cu;
+};
+
+void xh_set_error(const char* fmt, ...);
+
+#define XH_CHECK_HIP(expr)                                                                  \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      xh_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return XH_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+#define XH_REQUIRE(cond, code, ...) \
+  do {                              \
+    if (!(cond)) {                  \
+      xh_set_error(__VA_ARGS__);    \
+      return (code);                \
+    }                               \
+  } while (0)
+
+#define XH_LAUNCH_CHECK()                                                                      \
+  do {                                                                                         \
+    hipError_t _e = hipGetLastError();                                                         \
+    if (_e != hipSuccess) {                                                                    \
+      xh_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return XH_ERR_HIP;                                                                       \
+    }                                                                                          \
+  } while (0)
+
+// Upload a small host table into the context scratch (bump allocated per call via `*cursor`).
+int xh_scratch_upload(xh_ctx* ctx, size_t* cursor, const void* host, size_t bytes, void** dptr);
+int xh_big_scratch(xh_ctx* ctx, size_t bytes, void** dptr);
+
+__host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers ---------------------------------------------------------------------------
+#define XH_BLOCK 256
+
+__device__ __forceinline__ bool xh_cmp_f32(float a, int op, float b) {
+  switch (op) {
+    case XH_OP_GT: return a > b;
+    case XH_OP_LT: return a < b;
+    case XH_OP_GE: return a >= b;
+    case XH_OP_LE: return a <= b;
+    case XH_OP_EQ: return a == b;
+    default: return a != b;
+  }
+}
+__device__ __forceinline__ bool xh_cmp_f64(double a, int op, double b) {
+  switch (op) {
+    case XH_OP_GT: return a > b;
+    case XH_OP_LT: return a < b;
+    case XH_OP_GE: return a >= b;
+    case XH_OP_LE: return a <= b;
+    case XH_OP_EQ: return a == b;
+    default: return a != b;
+  }
+}
+
+template <int OP>
+__device__ __forceinline__ bool xh_cmp_t(float a, float b) {
+  if (OP == XH_OP_GT) return a > b;
+  if (OP == XH_OP_LT) return a < b;
+  if (OP == XH_OP_GE) return a >= b;
+  if (OP == XH_OP_LE) return a <= b;
+  if (OP == XH_OP_EQ) return a == b;
+  return a != b;
+}
+
+// vector-of-cells loads: VEC consecutive cells per lane (16 B per lane when VEC == 4)
+template <int VEC>
+struct VecF;
+template <>
+struct VecF<1> {
+  float v[1];
+};
+template <>
+struct VecF<2> {
+  float v[2];
+};
+template <>
+struct VecF<4> {
+  float v[4];
+};
+
+template <int VEC>
+__device__ __forceinline__ VecF<VEC> xh_load(const float* __restrict__ p) {
+  VecF<VEC> r;
+  if (VEC == 4) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    r.v[0] = t.x; r.v[1 % VEC] = t.y; r.v[2 % VEC] = t.z; r.v[3 % VEC] = t.w;
+  } else if (VEC == 2) {
+    float2 t = *reinterpret_cast<const float2*>(p);
+    r.v[0] = t.x; r.v[1 % VEC] = t.y;
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+
+// order-preserving float <-> uint32 key (ascending; NaN maps above +inf so it sorts last like numpy)
+__device__ __forceinline__ uint32_t xh_f2key(float f) {
+  uint32_t u = __float_as_uint(f);
+  if (f != f) return 0xFFFFFFFFu;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float xh_key2f(uint32_t k) {
+  if (k == 0xFFFFFFFFu) return __uint_as_float(0x7FC00000u);
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(u);
+}
+
+__device__ __forceinline__ double xh_nan64() { return __longlong_as_double(0x7FF8000000000000LL); }
+__device__ __forceinline__ float xh_nan32() { return __uint_as_float(0x7FC00000u); }
+
+// choose cells-per-lane: 4 when rows are 16-byte aligned, else 1
+static inline int xh_pick_vec(const void* p, int64_t C, int64_t st) {
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (C % 4) == 0 && (st % 4) == 0) return 4;
+  return 1;
+}

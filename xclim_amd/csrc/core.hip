@@ -1,0 +1,282 @@
+// core.hip — context, device memory, timers, synthetic input generator, tiled transpose.
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void xh_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+int xh_abi_version(void) { return XH_ABI_VERSION; }
+const char* xh_last_error(void) { return g_err; }
+
+int xh_device_count(int* n) {
+  XH_REQUIRE(n != nullptr, XH_ERR_ARG, "xh_device_count: n is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    c = 0;
+  }
+  *n = c;
+  return XH_OK;
+}
+
+int xh_create(int device, xh_ctx** out) {
+  XH_REQUIRE(out != nullptr, XH_ERR_ARG, "xh_create: out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    xh_set_error("xh_create: no HIP device visible (%s)", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    return XH_ERR_NODEVICE;
+  }
+  XH_REQUIRE(device >= 0 && device < n, XH_ERR_ARG, "xh_create: device %d out of range [0,%d)", device, n);
+  XH_CHECK_HIP(hipSetDevice(device));
+  xh_ctx* ctx = new xh_ctx();
+  memset(ctx, 0, sizeof(*ctx));
+  ctx->device = device;
+  XH_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  XH_CHECK_HIP(hipEventCreate(&ctx->ev0));
+  XH_CHECK_HIP(hipEventCreate(&ctx->ev1));
+  ctx->scratch_bytes = 8u << 20;
+  XH_CHECK_HIP(hipMalloc(&ctx->scratch, ctx->scratch_bytes));
+  hipDeviceProp_t prop;
+  XH_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  ctx->num_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return XH_OK;
+}
+
+int xh_destroy(xh_ctx* ctx) {
+  if (!ctx) return XH_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->big) (void)hipFree(ctx->big);
+  (void)hipEventDestroy(ctx->ev0);
+  (void)hipEventDestroy(ctx->ev1);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return XH_OK;
+}
+
+int xh_sync(xh_ctx* ctx) {
+  XH_REQUIRE(ctx, XH_ERR_ARG, "xh_sync: ctx is NULL");
+  XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return XH_OK;
+}
+
+int xh_device_name(xh_ctx* ctx, char* buf, size_t buflen) {
+  XH_REQUIRE(ctx && buf && buflen > 0, XH_ERR_ARG, "xh_device_name: bad args");
+  hipDeviceProp_t prop;
+  XH_CHECK_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  snprintf(buf, buflen, "%s|%s|cu=%d", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return XH_OK;
+}
+
+int xh_mem_info(xh_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+  XH_REQUIRE(ctx && free_bytes && total_bytes, XH_ERR_ARG, "xh_mem_info: bad args");
+  XH_CHECK_HIP(hipSetDevice(ctx->device));
+  XH_CHECK_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  return XH_OK;
+}
+
+int xh_malloc(xh_ctx* ctx, size_t bytes, void** dptr) {
+  XH_REQUIRE(ctx && dptr, XH_ERR_ARG, "xh_malloc: bad args");
+  XH_CHECK_HIP(hipSetDevice(ctx->device));
+  if (bytes == 0) bytes = 16;
+  XH_CHECK_HIP(hipMalloc(dptr, bytes));
+  return XH_OK;
+}
+
+int xh_free(xh_ctx* ctx, void* dptr) {
+  XH_REQUIRE(ctx, XH_ERR_ARG, "xh_free: ctx is NULL");
+  if (!dptr) return XH_OK;
+  XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  XH_CHECK_HIP(hipFree(dptr));
+  return XH_OK;
+}
+
+int xh_memset(xh_ctx* ctx, void* dptr, int value, size_t bytes) {
+  XH_REQUIRE(ctx && dptr, XH_ERR_ARG, "xh_memset: bad args");
+  XH_CHECK_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+  return XH_OK;
+}
+
+int xh_memcpy_h2d(xh_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  XH_REQUIRE(ctx && (bytes == 0 || (dst && src)), XH_ERR_ARG, "xh_memcpy_h2d: bad args");
+  if (bytes == 0) return XH_OK;
+  XH_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // the host buffer is pageable and caller owned: do not return before it has been consumed
+  XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return XH_OK;
+}
+
+int xh_memcpy_d2h(xh_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  XH_REQUIRE(ctx && (bytes == 0 || (dst && src)), XH_ERR_ARG, "xh_memcpy_d2h: bad args");
+  if (bytes == 0) return XH_OK;
+  XH_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return XH_OK;
+}
+
+int xh_memcpy_d2d(xh_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  XH_REQUIRE(ctx && (bytes == 0 || (dst && src)), XH_ERR_ARG, "xh_memcpy_d2d: bad args");
+  if (bytes == 0) return XH_OK;
+  XH_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return XH_OK;
+}
+
+int xh_timer_start(xh_ctx* ctx) {
+  XH_REQUIRE(ctx, XH_ERR_ARG, "xh_timer_start: ctx is NULL");
+  XH_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  return XH_OK;
+}
+
+int xh_timer_stop(xh_ctx* ctx, float* elapsed_ms) {
+  XH_REQUIRE(ctx && elapsed_ms, XH_ERR_ARG, "xh_timer_stop: bad args");
+  XH_CHECK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  XH_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+  XH_CHECK_HIP(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+  return XH_OK;
+}
+
+int xh_stream(xh_ctx* ctx, void** stream) {
+  XH_REQUIRE(ctx && stream, XH_ERR_ARG, "xh_stream: bad args");
+  *stream = (void*)ctx->stream;
+  return XH_OK;
+}
+
+}  // extern "C"
+
+int xh_scratch_upload(xh_ctx* ctx, size_t* cursor, const void* host, size_t bytes, void** dptr) {
+  size_t off = (*cursor + 255) & ~(size_t)255;
+  if (off + bytes > ctx->scratch_bytes) {
+    // grow: wait for in-flight users of the old scratch first
+    XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    size_t nb = ctx->scratch_bytes;
+    while (off + bytes > nb) nb *= 2;
+    void* n = nullptr;
+    XH_CHECK_HIP(hipMalloc(&n, nb));
+    if (off) XH_CHECK_HIP(hipMemcpy(n, ctx->scratch, off, hipMemcpyDeviceToDevice));
+    XH_CHECK_HIP(hipFree(ctx->scratch));
+    ctx->scratch = n;
+    ctx->scratch_bytes = nb;
+  }
+  char* d = (char*)ctx->scratch + off;
+  XH_CHECK_HIP(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // host tables are tiny, caller-owned and possibly stack/temporary: wait so they can be released
+  XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  *dptr = d;
+  *cursor = off + bytes;
+  return XH_OK;
+}
+
+int xh_big_scratch(xh_ctx* ctx, size_t bytes, void** dptr) {
+  if (bytes > ctx->big_bytes) {
+    XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->big) XH_CHECK_HIP(hipFree(ctx->big));
+    ctx->big = nullptr;
+    ctx->big_bytes = 0;
+    XH_CHECK_HIP(hipMalloc(&ctx->big, bytes));
+    ctx->big_bytes = bytes;
+  }
+  *dptr = ctx->big;
+  return XH_OK;
+}
+
+// ---- synthetic generator --------------------------------------------------------------------
+__device__ __forceinline__ uint64_t xh_mix64(uint64_t z) {
+  z ^= z >> 30;
+  z *= 0xBF58476D1CE4E5B9ULL;
+  z ^= z >> 27;
+  z *= 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return z;
+}
+
+__global__ void __launch_bounds__(XH_BLOCK)
+k_fill_synthetic(float* __restrict__ out, int64_t T, int64_t C, int64_t st, int kind, uint64_t seed, int64_t cell0,
+                 const float* __restrict__ base, float amp, float p_wet, uint32_t nan_ppm) {
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  uint64_t cell = (uint64_t)(cell0 + c);
+  for (int64_t t = blockIdx.y; t < T; t += gridDim.y) {
+    uint64_t key = seed * 0xD1342543DE82EF95ULL + (uint64_t)t * 0x9E3779B97F4A7C15ULL + cell * 0xC2B2AE3D27D4EB4FULL;
+    uint64_t z = xh_mix64(key);
+    uint64_t w = xh_mix64(z + 0x9E3779B97F4A7C15ULL);
+    float val;
+    if (kind == 0) {
+      float u0 = (float)(z & 0xFFFF) * (1.0f / 65536.0f);
+      float u1 = (float)((z >> 16) & 0xFFFF) * (1.0f / 65536.0f);
+      float u2 = (float)((z >> 32) & 0xFFFF) * (1.0f / 65536.0f);
+      float u3 = (float)((z >> 48) & 0xFFFF) * (1.0f / 65536.0f);
+      float z4 = ((u0 + u1) + (u2 + u3)) - 2.0f;
+      val = base[t] + amp * z4;
+    } else {
+      float uw = (float)(w & 0xFFFFFF) * (1.0f / 16777216.0f);
+      float ua = (float)(z >> 40) * (1.0f / 16777216.0f);
+      float amount = ((ua * ua) * ua) * amp;
+      val = (uw < p_wet) ? (base[t] + amount) : 0.0f;
+    }
+    uint32_t r = (uint32_t)((((w >> 32) & 0xFFFFFFFFULL) * 1000000ULL) >> 32);
+    if (r < nan_ppm) val = xh_nan32();
+    out[t * st + c] = val;
+  }
+}
+
+// ---- tiled transpose ------------------------------------------------------------------------
+__global__ void __launch_bounds__(XH_BLOCK)
+k_transpose_f32(const float* __restrict__ in, int64_t rows, int64_t cols, int64_t in_stride, float* __restrict__ out,
+                int64_t out_stride) {
+  __shared__ float tile[64][65];
+  int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 row groups
+  for (int i = ty; i < 64; i += 4) {
+    int64_t r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[i][tx] = in[r * in_stride + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    int64_t c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) out[c * out_stride + r] = tile[tx][i];
+  }
+}
+
+extern "C" {
+
+int xh_fill_synthetic(xh_ctx* ctx, float* out, int64_t T, int64_t C, int64_t st, int kind, uint64_t seed, int64_t cell0,
+                      const float* base, float amp, float p_wet, uint32_t nan_per_million) {
+  XH_REQUIRE(ctx && out && base, XH_ERR_ARG, "xh_fill_synthetic: NULL argument");
+  XH_REQUIRE(T >= 0 && C >= 0 && st >= C, XH_ERR_ARG, "xh_fill_synthetic: bad shape");
+  XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "xh_fill_synthetic: kind must be 0 or 1");
+  if (T == 0 || C == 0) return XH_OK;
+  dim3 grid((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(T < 64 ? T : 64));
+  hipLaunchKernelGGL(k_fill_synthetic, grid, dim3(XH_BLOCK), 0, ctx->stream, out, T, C, st, kind, seed, cell0, base, amp,
+                     p_wet, nan_per_million);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_transpose_f32(xh_ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t in_stride, float* out,
+                     int64_t out_stride) {
+  XH_REQUIRE(ctx && in && out, XH_ERR_ARG, "xh_transpose_f32: NULL argument");
+  XH_REQUIRE(rows >= 0 && cols >= 0 && in_stride >= cols && out_stride >= rows, XH_ERR_ARG,
+             "xh_transpose_f32: bad shape/strides");
+  if (rows == 0 || cols == 0) return XH_OK;
+  dim3 grid((unsigned)cdiv64(cols, 64), (unsigned)cdiv64(rows, 64));
+  XH_REQUIRE(grid.y <= 65535u, XH_ERR_LIMIT, "xh_transpose_f32: too many row tiles");
+  hipLaunchKernelGGL(k_transpose_f32, grid, dim3(XH_BLOCK), 0, ctx->stream, in, rows, cols, in_stride, out, out_stride);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+}  // extern "C"

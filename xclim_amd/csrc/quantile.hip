@@ -1,0 +1,328 @@
+// quantile.hip — NaN-aware Hyndman-Fan quantiles per cell: calc_perc / percentile_doy / doy re-gridding.
+//
+// Reference: core/utils.py:370-557 (_compute_virtual_index, _get_indexes, _get_gamma, _linear_interpolation,
+// _nan_quantile) and core/calendar.py:395-494 (percentile_doy), 690-726 (_interpolate_doy_calendar).
+//
+// Sample set of (doy row d, cell c): for every year y with tb = tbase[y*ndoy + d] >= 0 the `window` values
+// x[tb - window/2 + k], k = 0..window-1 (NaN outside [0, T)); years lacking the day contribute NaNs
+// (rolling(center=True, min_periods=1).construct + unstack/stack, cal:448-458).  N = nyears * window samples.
+//   N <= 32 : samples gathered into registers, bitonic network on order-preserving uint32 keys  (k_pdoy_reg)
+//   N  > 32 : lane-private LDS column, bitonic network in LDS (no cross-lane traffic, no barriers) (k_pdoy_lds)
+// Time-major layout, one lane per cell (VEC cells in the register path); neighbouring doys re-read rows from L2.
+#include "common.h"
+
+// Hyndman-Fan quantile from a sorted sample (ascending, NaN last).  `get(i)` returns sorted element i as float.
+// L = total slots, n = non-NaN count.  Follows utl:494-557 step by step.
+template <typename Getter>
+__device__ __forceinline__ double xh_hf_quantile(int L, int n, double q, double alpha, double beta, Getter get) {
+  if (L == 1) return (double)get(0);  // utl:508-510
+  if (n < 2) {                        // utl:519-523: vi = NaN -> last slot (NaN) -> nanmax fallback (utl:552-554)
+    return n == 1 ? (double)get(0) : xh_nan64();
+  }
+  double nn = (double)n;
+  // utl:395  n * quantiles + (alpha + quantiles * (1 - alpha - beta)) - 1   (no FMA: built with -ffp-contract=off)
+  double vi = nn * q + (alpha + q * (1.0 - alpha - beta)) - 1.0;
+  if (vi >= nn - 1.0) return (double)get(n - 1);  // utl:443-447 + nanmax fallback
+  if (vi < 0.0) return (double)get(0);            // utl:449-452
+  double prev = floor(vi);
+  int ip = (int)prev;
+  double gamma = vi - prev;                // utl:412
+  float left = get(ip), right = get(ip + 1);
+  float diff = right - left;               // utl:486 np.subtract in the data dtype (fp32)
+  double r = (double)left + (double)diff * gamma;
+  if (gamma >= 0.5) r = (double)right - (double)diff * (1.0 - gamma);  // utl:488
+  if (r != r) r = (double)get(n - 1);      // utl:552-554
+  return r;
+}
+
+// ---- register path --------------------------------------------------------------------------------
+template <int NMAX>
+__device__ __forceinline__ void bitonic_regs(uint32_t (&k)[NMAX]) {
+#pragma unroll
+  for (int size = 2; size <= NMAX; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+      for (int i = 0; i < NMAX; ++i) {
+        int j = i ^ stride;
+        if (j > i) {
+          bool up = ((i & size) == 0);
+          uint32_t a = k[i], b = k[j];
+          uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+          k[i] = up ? lo : hi;
+          k[j] = up ? hi : lo;
+        }
+      }
+    }
+  }
+}
+
+template <int NMAX, int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_pdoy_reg(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
+           int ndoy, int window, const double* __restrict__ qs, int nper, double alpha, double beta,
+           double* __restrict__ out) {
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int half = window / 2;
+  const int N = nyears * window;
+  for (int d = blockIdx.y; d < ndoy; d += gridDim.y) {
+    uint32_t key[VEC][NMAX];
+    int nvalid[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) nvalid[v] = 0;
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+      // slot i -> (year y, window offset k)
+      int y = i / window, k = i - y * window;
+      bool inb = i < N;
+      int64_t tb = inb ? (int64_t)tbase[(int64_t)y * ndoy + d] : -1;
+      int64_t t = tb - half + k;
+      bool ok = inb && tb >= 0 && t >= 0 && t < T;
+      if (ok) {
+        VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          key[v][i] = xh_f2key(xv.v[v]);
+          nvalid[v] += (xv.v[v] == xv.v[v]) ? 1 : 0;
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) key[v][i] = 0xFFFFFFFFu;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      bitonic_regs<NMAX>(key[v]);
+      auto get = [&](int idx) -> float {
+        uint32_t r = key[v][0];
+#pragma unroll
+        for (int i = 1; i < NMAX; ++i) r = (i == idx) ? key[v][i] : r;
+        return xh_key2f(r);
+      };
+      for (int j = 0; j < nper; ++j) {
+        double r = xh_hf_quantile(N, nvalid[v], qs[j], alpha, beta, get);
+        out[((int64_t)j * ndoy + d) * C + c + v] = r;
+      }
+    }
+  }
+}
+
+// ---- LDS path -------------------------------------------------------------------------------------
+// One wave (64 lanes) per block; lane l owns column l of an [NP][64] uint32 LDS array (conflict-free: the bank
+// is the lane).  All lanes execute the same compare-exchange sequence on their own column, so no barriers.
+__global__ void __launch_bounds__(64)
+k_pdoy_lds(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
+           int ndoy, int window, int NP, const double* __restrict__ qs, int nper, double alpha, double beta,
+           double* __restrict__ out) {
+  extern __shared__ uint32_t lds[];
+  const int lane = threadIdx.x;
+  int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  const bool active = c < C;
+  const int half = window / 2;
+  const int N = nyears * window;
+  uint32_t* col = lds + lane;  // element i at col[i * 64]
+  for (int d = blockIdx.y; d < ndoy; d += gridDim.y) {
+    int nvalid = 0;
+    for (int y = 0; y < nyears; ++y) {
+      int64_t tb = (int64_t)tbase[(int64_t)y * ndoy + d];
+      for (int k = 0; k < window; ++k) {
+        int64_t t = tb - half + k;
+        float v = xh_nan32();
+        if (active && tb >= 0 && t >= 0 && t < T) v = x[t * st + c];
+        nvalid += (v == v) ? 1 : 0;
+        col[(y * window + k) * 64] = xh_f2key(v);
+      }
+    }
+    for (int i = N; i < NP; ++i) col[i * 64] = 0xFFFFFFFFu;
+    // bitonic sort of NP keys, lane-private
+    for (int size = 2; size <= NP; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = 0; i < NP; ++i) {
+          int j = i ^ stride;
+          if (j > i) {
+            bool up = ((i & size) == 0);
+            uint32_t a = col[i * 64], b = col[j * 64];
+            uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+            col[i * 64] = up ? lo : hi;
+            col[j * 64] = up ? hi : lo;
+          }
+        }
+      }
+    }
+    if (active) {
+      auto get = [&](int idx) -> float { return xh_key2f(col[idx * 64]); };
+      for (int j = 0; j < nper; ++j) {
+        double r = xh_hf_quantile(N, nvalid, qs[j], alpha, beta, get);
+        out[((int64_t)j * ndoy + d) * C + c] = r;
+      }
+    }
+  }
+}
+
+// ---- doy re-gridding --------------------------------------------------------------------------------
+// _interpolate_doy_calendar (cal:690-726): interpolate_na(dim="dayofyear") [linear in the doy coordinate, no
+// extrapolation past the first/last valid point] then interp onto the target doys: host supplies, for each
+// output doy j, the bracketing source rows i0[j], i1[j], dxn[j] = x_new - x_lo and dxs[j] = x_hi - x_lo.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_doy_interp(const double* __restrict__ in, int D_in, int64_t C, const int32_t* __restrict__ i0,
+             const int32_t* __restrict__ i1, const double* __restrict__ dxn, const double* __restrict__ dxs, int D_out,
+             double* __restrict__ out, double* __restrict__ filled) {
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  // pass 1: interpolate_na along doy (source coordinate = row index; uniform spacing, so index weights are exact
+  // enough: (d - a) / (b - a) with integer a, b, d)
+  int last = -1;
+  double lastv = 0.0;
+  for (int d = 0; d < D_in; ++d) {
+    double v = in[(int64_t)d * C + c];
+    if (v == v) {
+      if (last >= 0 && d - last > 1) {
+        for (int g = last + 1; g < d; ++g) {
+          // np.interp form: slope * (x - xlo) + ylo
+          double slope = (v - lastv) / (double)(d - last);
+          filled[(int64_t)g * C + c] = slope * (double)(g - last) + lastv;
+        }
+      } else if (last < 0) {
+        for (int g = 0; g < d; ++g) filled[(int64_t)g * C + c] = xh_nan64();
+      }
+      filled[(int64_t)d * C + c] = v;
+      last = d;
+      lastv = v;
+    }
+  }
+  for (int g = last + 1; g < D_in; ++g) filled[(int64_t)g * C + c] = xh_nan64();
+  // pass 2: linear re-grid, scipy interp1d form: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope * (x - x_lo) + y_lo
+  for (int j = 0; j < D_out; ++j) {
+    double a = filled[(int64_t)i0[j] * C + c], b = filled[(int64_t)i1[j] * C + c];
+    double slope = (b - a) / dxs[j];
+    out[(int64_t)j * C + c] = slope * dxn[j] + a;
+  }
+}
+
+static int next_pow2(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+static int launch_pdoy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tbase, int nyears,
+                       int ndoy, int window, const double* d_q, int nper, double alpha, double beta, double* out) {
+  int N = nyears * window;
+  unsigned gy = (unsigned)(ndoy > 1024 ? 1024 : ndoy);
+  if (N <= 8 && xh_pick_vec(x, C, st) == 4) {
+    dim3 grid((unsigned)cdiv64(cdiv64(C, 4), XH_BLOCK), gy);
+    hipLaunchKernelGGL((k_pdoy_reg<8, 4>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, d_tbase, nyears, ndoy,
+                       window, d_q, nper, alpha, beta, out);
+  } else if (N <= 8) {
+    dim3 grid((unsigned)cdiv64(C, XH_BLOCK), gy);
+    hipLaunchKernelGGL((k_pdoy_reg<8, 1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, d_tbase, nyears, ndoy,
+                       window, d_q, nper, alpha, beta, out);
+  } else if (N <= 16) {
+    dim3 grid((unsigned)cdiv64(C, XH_BLOCK), gy);
+    hipLaunchKernelGGL((k_pdoy_reg<16, 1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, d_tbase, nyears, ndoy,
+                       window, d_q, nper, alpha, beta, out);
+  } else if (N <= 32) {
+    dim3 grid((unsigned)cdiv64(C, XH_BLOCK), gy);
+    hipLaunchKernelGGL((k_pdoy_reg<32, 1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, d_tbase, nyears, ndoy,
+                       window, d_q, nper, alpha, beta, out);
+  } else {
+    int NP = next_pow2(N);
+    size_t lds = (size_t)NP * 64 * sizeof(uint32_t);
+    XH_REQUIRE(lds <= 160 * 1024, XH_ERR_LIMIT,
+               "percentile: %d samples per cell exceed the per-wave LDS column capacity (640)", N);
+    if (lds > 64 * 1024) {
+      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_pdoy_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    dim3 grid((unsigned)cdiv64(C, 64), gy);
+    hipLaunchKernelGGL(k_pdoy_lds, grid, dim3(64), lds, ctx->stream, x, T, C, st, d_tbase, nyears, ndoy, window, NP, d_q,
+                       nper, alpha, beta, out);
+  }
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+extern "C" {
+
+int xh_percentile_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* tbase,
+                      int nyears, int ndoy, int window, const double* per, int nper, double alpha, double beta,
+                      double* out) {
+  XH_REQUIRE(ctx && x && tbase && per && out, XH_ERR_ARG, "xh_percentile_doy: NULL argument");
+  XH_REQUIRE(T >= 1 && C >= 0 && nyears >= 1 && ndoy >= 1 && window >= 1 && nper >= 1, XH_ERR_ARG,
+             "xh_percentile_doy: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_percentile_doy: needs a time-major view (sc == 1, st >= C)");
+  for (int j = 0; j < nper; ++j)
+    XH_REQUIRE(per[j] >= 0.0 && per[j] <= 100.0, XH_ERR_ARG, "xh_percentile_doy: percentile %g outside [0, 100]", per[j]);
+  if (C == 0) return XH_OK;
+  double qh[64];
+  XH_REQUIRE(nper <= 64, XH_ERR_LIMIT, "xh_percentile_doy: at most 64 percentiles per call");
+  for (int j = 0; j < nper; ++j) qh[j] = per[j] / 100.0;  // utl:366
+  size_t cur = 0;
+  void *d_tb = nullptr, *d_q = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, tbase, sizeof(int32_t) * (size_t)nyears * ndoy, &d_tb);
+  if (rc) return rc;
+  rc = xh_scratch_upload(ctx, &cur, qh, sizeof(double) * nper, &d_q);
+  if (rc) return rc;
+  return launch_pdoy(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const double*)d_q, nper, alpha, beta,
+                     out);
+}
+
+int xh_nan_quantile(xh_ctx* ctx, const float* x, int64_t N, int64_t C, int64_t sn, int64_t sc, const double* q, int nq,
+                    double alpha, double beta, double* out) {
+  XH_REQUIRE(ctx && x && q && out, XH_ERR_ARG, "xh_nan_quantile: NULL argument");
+  XH_REQUIRE(N >= 1 && C >= 0 && nq >= 1 && nq <= 64, XH_ERR_ARG, "xh_nan_quantile: bad shape (N >= 1, 1 <= nq <= 64)");
+  XH_REQUIRE(N <= 640, XH_ERR_LIMIT, "xh_nan_quantile: N = %lld samples exceed 640 (use xh_quantile_series)",
+             (long long)N);
+  if (C == 0) return XH_OK;
+  const float* xs = x;
+  int64_t st = sn;
+  if (!(sc == 1 && sn >= C)) {
+    // sample-minor input (what apply_ufunc hands calc_perc): transpose into scratch to a sample-major view
+    XH_REQUIRE(sn == 1 && sc >= N, XH_ERR_LAYOUT, "xh_nan_quantile: one of the two strides must be 1");
+    void* tmp = nullptr;
+    int rc = xh_big_scratch(ctx, sizeof(float) * (size_t)N * (size_t)C, &tmp);
+    if (rc) return rc;
+    rc = xh_transpose_f32(ctx, x, C, N, sc, (float*)tmp, C);
+    if (rc) return rc;
+    xs = (const float*)tmp;
+    st = C;
+  }
+  // one "doy" row, N "years", window 1, tbase[y] = y
+  int32_t tb[640];
+  for (int i = 0; i < (int)N; ++i) tb[i] = i;
+  size_t cur = 0;
+  void *d_tb = nullptr, *d_q = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, tb, sizeof(int32_t) * (size_t)N, &d_tb);
+  if (rc) return rc;
+  rc = xh_scratch_upload(ctx, &cur, q, sizeof(double) * nq, &d_q);
+  if (rc) return rc;
+  return launch_pdoy(ctx, xs, N, C, st, (const int32_t*)d_tb, (int)N, 1, 1, (const double*)d_q, nq, alpha, beta, out);
+}
+
+int xh_doy_interp(xh_ctx* ctx, const double* in, int D_in, int64_t C, const int32_t* i0, const int32_t* i1,
+                  const double* dxn, const double* dxs, int D_out, double* out) {
+  XH_REQUIRE(ctx && in && i0 && i1 && dxn && dxs && out, XH_ERR_ARG, "xh_doy_interp: NULL argument");
+  XH_REQUIRE(D_in >= 1 && D_out >= 1 && C >= 0, XH_ERR_ARG, "xh_doy_interp: bad shape");
+  for (int j = 0; j < D_out; ++j)
+    XH_REQUIRE(i0[j] >= 0 && i0[j] < D_in && i1[j] >= 0 && i1[j] < D_in, XH_ERR_ARG, "xh_doy_interp: index out of range");
+  if (C == 0) return XH_OK;
+  size_t cur = 0;
+  void *d_i0 = nullptr, *d_i1 = nullptr, *d_w = nullptr, *d_s = nullptr, *filled = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, i0, sizeof(int32_t) * D_out, &d_i0);
+  if (rc) return rc;
+  rc = xh_scratch_upload(ctx, &cur, i1, sizeof(int32_t) * D_out, &d_i1);
+  if (rc) return rc;
+  rc = xh_scratch_upload(ctx, &cur, dxn, sizeof(double) * D_out, &d_w);
+  if (rc) return rc;
+  rc = xh_scratch_upload(ctx, &cur, dxs, sizeof(double) * D_out, &d_s);
+  if (rc) return rc;
+  rc = xh_big_scratch(ctx, sizeof(double) * (size_t)D_in * (size_t)C, &filled);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_doy_interp, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, in, D_in, C,
+                     (const int32_t*)d_i0, (const int32_t*)d_i1, (const double*)d_w, (const double*)d_s, D_out, out,
+                     (double*)filled);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,391 @@
+// runlen.hip — run-length family: one marching state machine per cell along time.
+//
+// Reference semantics (indices/run_length.py):
+//   _cumsum_reset_np  rl:143-151   c[t] = b[t] * (c[t-1] + 1)           (NaN -> 0 first, rl:208)
+//   rle               rl:223-272   length kept at the first/last element of a run, NaN inside, 0 outside;
+//                                  QUIRK restated on purpose: the kept element is masked by
+//                                  `da.shift(-1, fill_value=0) == 0` on the NaN-carrying input, so a run whose
+//                                  outer neighbour (before its first element for index="first", after its last
+//                                  for index="last") is NaN loses its length ("invisible" run).
+//   rle_statistics    rl:275-335   reducer over runs >= window, 0 when none
+//   windowed_run_*    rl:381-488
+//   _boundary_run     rl:543-640   first_run / last_run incl. the argmax == argmin "no run" test
+// Layout: time-major (T, C); a lane owns VEC consecutive cells; state lives in registers; HBM traffic is the
+// compulsory 4 B per cell-timestep read plus the (P, C) outputs.
+#include "common.h"
+
+struct RunAcc {
+  int mx, mn, sum, cnt;
+  double sumsq;
+};
+
+__device__ __forceinline__ void acc_reset(RunAcc& a) {
+  a.mx = 0; a.mn = 0x7FFFFFFF; a.sum = 0; a.cnt = 0; a.sumsq = 0.0;
+}
+__device__ __forceinline__ void acc_add(RunAcc& a, int len) {
+  a.mx = len > a.mx ? len : a.mx;
+  a.mn = len < a.mn ? len : a.mn;
+  a.sum += len;
+  a.cnt += 1;
+  a.sumsq += (double)len * (double)len;
+}
+__device__ __forceinline__ float acc_result(const RunAcc& a, int stat, int plainsum) {
+  if (stat == XH_RUN_PLAINSUM) return (float)plainsum;
+  if (a.cnt == 0) return 0.0f;  // rl:326: no qualifying run -> 0
+  switch (stat) {
+    case XH_RUN_MAX: return (float)a.mx;
+    case XH_RUN_MIN: return (float)a.mn;
+    case XH_RUN_SUM: return (float)a.sum;
+    case XH_RUN_COUNT: return (float)a.cnt;
+    case XH_RUN_MEAN: return (float)((double)a.sum / (double)a.cnt);
+    default: {  // population std (ddof = 0), tests/test_run_length.py:255-256
+      double m = (double)a.sum / (double)a.cnt;
+      double v = a.sumsq / (double)a.cnt - m * m;
+      return (float)sqrt(v > 0.0 ? v : 0.0);
+    }
+  }
+}
+
+// per-cell run state
+struct RunState {
+  int run;       // current run length (0 = not in a run)
+  bool vis;      // index="first": outer neighbour before the run start was not NaN
+  bool prevnan;  // previous element was NaN (mask mode only)
+  int startp;    // period of the run's first element (resample-after mode)
+};
+
+template <int VEC, bool CUT>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int fused_op, float thr, int window, int stat,
+            int index_first, const int64_t* __restrict__ seg_off, int P, float* __restrict__ out,
+            int32_t* __restrict__ valid_out) {
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const bool fused = fused_op >= 0;
+
+  if (CUT) {
+    for (int p = blockIdx.y; p < P; p += gridDim.y) {
+      int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+      RunAcc acc[VEC];
+      RunState s[VEC];
+      int nvalid[VEC], plainsum[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        acc_reset(acc[i]);
+        s[i].run = 0; s[i].vis = true; s[i].prevnan = false; s[i].startp = 0;
+        nvalid[i] = 0; plainsum[i] = 0;
+      }
+#pragma unroll 4
+      for (int64_t t = t0; t < t1; ++t) {
+        VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          float v = xv.v[i];
+          bool isn = v != v;
+          bool on = fused ? xh_cmp_f32(v, fused_op, thr) : (v > 0.0f);
+          bool masknan = (!fused) && isn;
+          nvalid[i] += isn ? 0 : 1;
+          plainsum[i] += on ? 1 : 0;
+          if (on) {
+            if (s[i].run == 0) s[i].vis = !s[i].prevnan;
+            s[i].run++;
+          } else if (s[i].run > 0) {
+            bool visible = index_first ? s[i].vis : !masknan;
+            if (visible && s[i].run >= window) acc_add(acc[i], s[i].run);
+            s[i].run = 0;
+          }
+          s[i].prevnan = masknan;
+        }
+      }
+      int64_t o = (int64_t)p * C + c;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        if (s[i].run > 0) {
+          bool visible = index_first ? s[i].vis : true;  // beyond the segment end: shift fill_value 0
+          if (visible && s[i].run >= window) acc_add(acc[i], s[i].run);
+        }
+        out[o + i] = acc_result(acc[i], stat, plainsum[i]);
+        if (valid_out) valid_out[o + i] = nvalid[i];
+      }
+    }
+  } else {
+    // resample AFTER run length: runs cross period edges, attributed to the period of the indexed element
+    RunAcc acc[VEC];
+    RunState s[VEC];
+    int accp[VEC], nvalid[VEC], plainsum[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      acc_reset(acc[i]);
+      s[i].run = 0; s[i].vis = true; s[i].prevnan = false; s[i].startp = 0;
+      accp[i] = 0; nvalid[i] = 0; plainsum[i] = 0;
+    }
+    int pt = 0;  // period of the current time step (uniform across lanes)
+    int64_t tend = seg_off[P];
+    for (int64_t t = seg_off[0]; t < tend; ++t) {
+      while (t >= seg_off[pt + 1]) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          if (valid_out) valid_out[(int64_t)pt * C + c + i] = nvalid[i];
+          if (stat == XH_RUN_PLAINSUM) out[(int64_t)pt * C + c + i] = (float)plainsum[i];
+          nvalid[i] = 0; plainsum[i] = 0;
+        }
+        pt++;
+      }
+      VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float v = xv.v[i];
+        bool isn = v != v;
+        bool on = fused ? xh_cmp_f32(v, fused_op, thr) : (v > 0.0f);
+        bool masknan = (!fused) && isn;
+        nvalid[i] += isn ? 0 : 1;
+        plainsum[i] += on ? 1 : 0;
+        if (on) {
+          if (s[i].run == 0) { s[i].vis = !s[i].prevnan; s[i].startp = pt; }
+          s[i].run++;
+        } else if (s[i].run > 0) {
+          bool visible = index_first ? s[i].vis : !masknan;
+          if (visible && s[i].run >= window && stat != XH_RUN_PLAINSUM) {
+            // the run ended at t-1; its last element is in period pt unless t is the first step of pt
+            int pa = pt;
+            if (index_first) pa = s[i].startp;
+            else while (pa > 0 && t - 1 < seg_off[pa]) pa--;  // skip empty periods before t
+            while (accp[i] < pa) {
+              out[(int64_t)accp[i] * C + c + i] = acc_result(acc[i], stat, 0);
+              acc_reset(acc[i]);
+              accp[i]++;
+            }
+            acc_add(acc[i], s[i].run);
+          }
+          s[i].run = 0;
+        }
+        s[i].prevnan = masknan;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if (s[i].run > 0 && stat != XH_RUN_PLAINSUM) {
+        bool visible = index_first ? s[i].vis : true;
+        if (visible && s[i].run >= window) {
+          int pa = index_first ? s[i].startp : pt;
+          while (accp[i] < pa) {
+            out[(int64_t)accp[i] * C + c + i] = acc_result(acc[i], stat, 0);
+            acc_reset(acc[i]);
+            accp[i]++;
+          }
+          acc_add(acc[i], s[i].run);
+        }
+      }
+      if (stat != XH_RUN_PLAINSUM) {
+        while (accp[i] < P) {
+          out[(int64_t)accp[i] * C + c + i] = acc_result(acc[i], stat, 0);
+          acc_reset(acc[i]);
+          accp[i]++;
+        }
+      }
+      // trailing periods (pt .. P-1): the last one holds the live counters, later ones are empty
+      for (int p = pt; p < P; ++p) {
+        if (valid_out) valid_out[(int64_t)p * C + c + i] = (p == pt) ? nvalid[i] : 0;
+        if (stat == XH_RUN_PLAINSUM) out[(int64_t)p * C + c + i] = (p == pt) ? (float)plainsum[i] : 0.0f;
+      }
+    }
+  }
+}
+
+// first_run / last_run (rl:543-740).  d[t] = (c[t] >= window) with c the reset-cumsum run towards the far end of
+// the run (index="first": remaining length from t on -> march backwards; "last": length ending at t -> forwards);
+// window == 1: d = (mask > 0) [fillna(0)].  Result per period: first (last) t with d == 1, relative to the
+// period start; NaN when d is constant over the period (argmax == argmin, rl:603-605: also the all-True case).
+template <bool FIRST, bool CUT>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_boundary_run(const float* __restrict__ x, int64_t C, int64_t st, int fused_op, float thr, int window,
+               const int64_t* __restrict__ seg_off, int P, float* __restrict__ out, int32_t* __restrict__ valid_out) {
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  const bool fused = fused_op >= 0;
+  int run = 0;
+  int pstep = CUT ? (int)gridDim.y : 1;
+  int pbeg = CUT ? (int)blockIdx.y : 0;
+  for (int pp = pbeg; pp < P; pp += pstep) {
+    int p = FIRST ? (P - 1 - pp) : pp;  // FIRST marches backwards through periods
+    int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    if (CUT) run = 0;
+    int ones = 0, nvalid = 0;
+    int64_t hit = -1;
+    if (FIRST) {
+#pragma unroll 4
+      for (int64_t t = t1 - 1; t >= t0; --t) {
+        float v = x[t * st + c];
+        bool on = fused ? xh_cmp_f32(v, fused_op, thr) : (v > 0.0f);
+        nvalid += (v == v) ? 1 : 0;
+        run = on ? run + 1 : 0;
+        if (run >= window) { hit = t; ones++; }
+      }
+    } else {
+#pragma unroll 4
+      for (int64_t t = t0; t < t1; ++t) {
+        float v = x[t * st + c];
+        bool on = fused ? xh_cmp_f32(v, fused_op, thr) : (v > 0.0f);
+        nvalid += (v == v) ? 1 : 0;
+        run = on ? run + 1 : 0;
+        if (run >= window) { hit = t; ones++; }
+      }
+    }
+    int len = (int)(t1 - t0);
+    float r = (ones == 0 || ones == len) ? xh_nan32() : (float)(hit - t0);
+    out[(int64_t)p * C + c] = r;
+    if (valid_out) valid_out[(int64_t)p * C + c] = nvalid;
+  }
+}
+
+// _cumsum_reset (full-shape output).  MODE 0: cumsum_reset; MODE 1: rle.
+template <int MODE>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_cumsum_rle(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int index_first, float* __restrict__ out,
+             int64_t out_st) {
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  if (MODE == 0) {
+    float run = 0.f;
+    if (index_first) {
+      for (int64_t t = T - 1; t >= 0; --t) {
+        float v = x[t * st + c];
+        float b = (v == v) ? v : 0.f;
+        run = b * (run + 1.0f);  // rl:150 — exact for binary input
+        out[t * out_st + c] = run;
+      }
+    } else {
+      for (int64_t t = 0; t < T; ++t) {
+        float v = x[t * st + c];
+        float b = (v == v) ? v : 0.f;
+        run = b * (run + 1.0f);
+        out[t * out_st + c] = run;
+      }
+    }
+  } else {
+    // rle: march in the direction that finishes at the indexed element.
+    // index="first": reversed marching (t = T-1 .. 0), the kept element is the last one visited of each run,
+    // whose outer neighbour is x[t-1]; index="last": forward marching, outer neighbour x[t+1].
+    float run = 0.f;
+    const float nanv = xh_nan32();
+    if (index_first) {
+      float cur = T > 0 ? x[(T - 1) * st + c] : 0.f;
+      for (int64_t t = T - 1; t >= 0; --t) {
+        float nxt = t > 0 ? x[(t - 1) * st + c] : 0.f;  // shift(-1, fill_value=0) in reversed order
+        float b = (cur == cur) ? cur : 0.f;
+        run = b * (run + 1.0f);
+        float o = (nxt == 0.0f) ? run : nanv;  // rl:264
+        o = (cur > 0.0f) ? o : 0.0f;           // rl:265
+        out[t * out_st + c] = o;
+        cur = nxt;
+      }
+    } else {
+      float cur = T > 0 ? x[c] : 0.f;
+      for (int64_t t = 0; t < T; ++t) {
+        float nxt = t + 1 < T ? x[(t + 1) * st + c] : 0.f;
+        float b = (cur == cur) ? cur : 0.f;
+        run = b * (run + 1.0f);
+        float o = (nxt == 0.0f) ? run : nanv;
+        o = (cur > 0.0f) ? o : 0.0f;
+        out[t * out_st + c] = o;
+        cur = nxt;
+      }
+    }
+  }
+}
+
+static int check_tc2(const char* fn, xh_ctx* ctx, const void* x, int64_t T, int64_t C, int64_t st, int64_t sc) {
+  XH_REQUIRE(ctx && x, XH_ERR_ARG, "%s: NULL argument", fn);
+  XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "%s: negative shape", fn);
+  XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT,
+             "%s: streaming kernels need a time-major view (sc == 1, st >= C); got st=%lld sc=%lld — transpose first",
+             fn, (long long)st, (long long)sc);
+  return XH_OK;
+}
+
+extern "C" {
+
+int xh_cumsum_reset(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int index_first,
+                    float* out, int64_t out_st) {
+  int rc = check_tc2("xh_cumsum_reset", ctx, x, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(out && out_st >= C, XH_ERR_ARG, "xh_cumsum_reset: out NULL or out_st < C");
+  if (T == 0 || C == 0) return XH_OK;
+  hipLaunchKernelGGL((k_cumsum_rle<0>), dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st,
+                     index_first, out, out_st);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_rle(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int index_first, float* out,
+           int64_t out_st) {
+  int rc = check_tc2("xh_rle", ctx, x, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(out && out_st >= C, XH_ERR_ARG, "xh_rle: out NULL or out_st < C");
+  if (T == 0 || C == 0) return XH_OK;
+  hipLaunchKernelGGL((k_cumsum_rle<1>), dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st,
+                     index_first, out, out_st);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int fused_op, double thr,
+                 int window, int stat, int index_first, const int64_t* seg_off, int P, int cut_at_segments, float* out,
+                 int32_t* valid_out) {
+  int rc = check_tc2("xh_run_stats", ctx, x, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(fused_op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", fused_op);
+  XH_REQUIRE(window >= 1, XH_ERR_ARG, "xh_run_stats: window must be >= 1");
+  XH_REQUIRE(stat >= XH_RUN_MAX && stat <= XH_RUN_PLAINSUM, XH_ERR_OP, "xh_run_stats: stat %d not recognized", stat);
+  XH_REQUIRE(out && seg_off && P >= 1, XH_ERR_ARG, "xh_run_stats: NULL out/seg_off or P < 1");
+  for (int p = 0; p < P; ++p)
+    XH_REQUIRE(seg_off[p] <= seg_off[p + 1] && seg_off[p] >= 0 && seg_off[p + 1] <= T, XH_ERR_ARG,
+               "xh_run_stats: seg_off must be non-decreasing within [0, T]");
+  size_t cur = 0;
+  void* d = nullptr;
+  rc = xh_scratch_upload(ctx, &cur, seg_off, sizeof(int64_t) * (size_t)(P + 1), &d);
+  if (rc) return rc;
+  const int64_t* d_seg = (const int64_t*)d;
+  if (C == 0) return XH_OK;
+  unsigned py = (unsigned)(P > 4096 ? 4096 : P);
+  if (stat == XH_RUN_FIRST || stat == XH_RUN_LAST) {
+    dim3 grid((unsigned)cdiv64(C, XH_BLOCK), cut_at_segments ? py : 1u);
+    if (stat == XH_RUN_FIRST) {
+      if (cut_at_segments)
+        hipLaunchKernelGGL((k_boundary_run<true, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, fused_op,
+                           (float)thr, window, d_seg, P, out, valid_out);
+      else
+        hipLaunchKernelGGL((k_boundary_run<true, false>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, fused_op,
+                           (float)thr, window, d_seg, P, out, valid_out);
+    } else {
+      if (cut_at_segments)
+        hipLaunchKernelGGL((k_boundary_run<false, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, fused_op,
+                           (float)thr, window, d_seg, P, out, valid_out);
+      else
+        hipLaunchKernelGGL((k_boundary_run<false, false>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, fused_op,
+                           (float)thr, window, d_seg, P, out, valid_out);
+    }
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+  }
+  int vec = xh_pick_vec(x, C, st);
+  if (cut_at_segments) {
+    dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), py);
+    if (vec == 4)
+      hipLaunchKernelGGL((k_run_stats<4, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, fused_op, (float)thr,
+                         window, stat, index_first, d_seg, P, out, valid_out);
+    else
+      hipLaunchKernelGGL((k_run_stats<1, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, fused_op, (float)thr,
+                         window, stat, index_first, d_seg, P, out, valid_out);
+  } else {
+    XH_REQUIRE(seg_off[0] == 0 && seg_off[P] == T, XH_ERR_ARG,
+               "xh_run_stats: resample-after mode needs segments covering [0, T)");
+    dim3 grid((unsigned)cdiv64(C, XH_BLOCK), 1);
+    hipLaunchKernelGGL((k_run_stats<1, false>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, fused_op, (float)thr,
+                       window, stat, index_first, d_seg, P, out, valid_out);
+  }
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+}  // extern "C"

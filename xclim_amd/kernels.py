@@ -1,0 +1,237 @@
+"""Typed Python wrappers over the C ABI (one function per entry point of include/xclim_hip.h).
+
+Inputs are :class:`~xclim_amd._capi.DeviceArray` views of shape (T, C) (time-major, C contiguous) unless stated;
+numpy inputs are uploaded.  Outputs stay on the device (call ``.get()``), so chained ops (percentile_doy ->
+threshold_count) never cross PCIe.  No CPU fallback exists here by design.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import OPS, REDUCERS, RUN_STATS, Device, DeviceArray, np_ptr
+
+_vp = C.c_void_p
+
+
+def as_device(dev: Device, a, dtype=np.float32) -> DeviceArray:
+    if isinstance(a, DeviceArray):
+        if a.dtype != np.dtype(dtype):
+            raise TypeError(f"device array dtype {a.dtype} != {np.dtype(dtype)}")
+        return a
+    return dev.to_device(np.asarray(a), dtype=dtype)
+
+
+def _tc(x: DeviceArray):
+    if len(x.shape) != 2:
+        raise ValueError(f"expected a 2-D (time, cells) array, got shape {x.shape}")
+    return int(x.shape[0]), int(x.shape[1])
+
+
+def _seg(seg_off):
+    s = np.ascontiguousarray(seg_off, dtype=np.int64)
+    return s, len(s) - 1
+
+
+def op_code(op: str) -> int:
+    if op == "gteq":
+        op = "ge"
+    if op == "lteq":
+        op = "le"
+    if op not in OPS:
+        raise ValueError(f"Operation `{op}` not recognized.")
+    return OPS[op]
+
+
+def fill_synthetic(dev: Device, T, C_, kind, seed, base, amp, p_wet=0.3, nan_per_million=0, cell0=0) -> DeviceArray:
+    out = dev.empty((T, C_), np.float32)
+    dbase = as_device(dev, np.asarray(base, dtype=np.float32))
+    dev.call("xh_fill_synthetic", _vp(out.ptr), T, C_, C_, int(kind), int(seed), int(cell0), _vp(dbase.ptr), float(amp),
+             float(p_wet), int(nan_per_million))
+    dev.sync()
+    return out
+
+
+def transpose(dev: Device, x: DeviceArray) -> DeviceArray:
+    r, c = _tc(x)
+    out = dev.empty((c, r), np.float32)
+    dev.call("xh_transpose_f32", _vp(x.ptr), r, c, c, _vp(out.ptr), r)
+    return out
+
+
+def threshold_count(dev: Device, x: DeviceArray, op: str, seg_off, *, scalar=None, scalar_f64=False, doy_table=None,
+                    tidx=None, full=None, want_valid=True):
+    """xh_threshold_count.  Exactly one of scalar / (doy_table, tidx) / full.  Returns (count, valid) (P, C) int32."""
+    T, C_ = _tc(x)
+    seg, P = _seg(seg_off)
+    count = dev.empty((P, C_), np.int32)
+    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    table_ptr, tstride, tidx_ptr, kind, thr = _vp(0), 0, _vp(0), capi.THR_SCALAR_F32, 0.0
+    keep = []
+    if scalar is not None:
+        kind = capi.THR_SCALAR_F64 if scalar_f64 else capi.THR_SCALAR_F32
+        thr = float(scalar)
+    elif doy_table is not None:
+        kind = capi.THR_DOY_F64 if doy_table.dtype == np.float64 else capi.THR_DOY_F32
+        table_ptr, tstride = _vp(doy_table.ptr), int(doy_table.shape[-1])
+        dt = dev.to_device(np.ascontiguousarray(tidx, dtype=np.int32))
+        keep.append(dt)
+        tidx_ptr = _vp(dt.ptr)
+    elif full is not None:
+        kind = capi.THR_FULL_F64 if full.dtype == np.float64 else capi.THR_FULL_F32
+        table_ptr, tstride = _vp(full.ptr), int(full.shape[-1])
+    else:
+        raise ValueError("a threshold is required")
+    dev.call("xh_threshold_count", _vp(x.ptr), T, C_, C_, 1, op_code(op), kind, thr, table_ptr, tstride, tidx_ptr,
+             np_ptr(seg), P, _vp(count.ptr), _vp(valid.ptr if valid else 0))
+    if keep:
+        dev.sync()
+    return count, valid
+
+
+def domain_count(dev: Device, x: DeviceArray, op1, thr1, op2, thr2, combine, seg_off, want_valid=True):
+    T, C_ = _tc(x)
+    seg, P = _seg(seg_off)
+    count = dev.empty((P, C_), np.int32)
+    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    dev.call("xh_domain_count", _vp(x.ptr), T, C_, C_, 1, op_code(op1), float(thr1), op_code(op2), float(thr2),
+             {"and": 1, "or": 2}[combine], np_ptr(seg), P, _vp(count.ptr), _vp(valid.ptr if valid else 0))
+    return count, valid
+
+
+def resample_reduce(dev: Device, x: DeviceArray, reducer: str, seg_off, skipna=True, want_valid=True):
+    T, C_ = _tc(x)
+    seg, P = _seg(seg_off)
+    if reducer not in REDUCERS:
+        raise ValueError(f"Reducer `{reducer}` not recognized.")
+    odt = np.int32 if reducer in ("count", "argmin", "argmax") else np.float32
+    out = dev.empty((P, C_), odt)
+    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    dev.call("xh_resample_reduce", _vp(x.ptr), T, C_, C_, 1, REDUCERS[reducer], int(bool(skipna)), np_ptr(seg), P,
+             _vp(out.ptr), _vp(valid.ptr if valid else 0))
+    return out, valid
+
+
+def apply_missing_mask(dev: Device, value: DeviceArray, valid: DeviceArray, expected) -> DeviceArray:
+    P, C_ = _tc(value)
+    exp = np.ascontiguousarray(expected, dtype=np.int32)
+    assert exp.shape == (P,)
+    out = dev.empty((P, C_), np.float64)
+    kind = 0 if value.dtype == np.int32 else 1
+    dev.call("xh_apply_missing_mask", _vp(value.ptr), kind, _vp(valid.ptr), np_ptr(exp), P, C_, _vp(out.ptr))
+    return out
+
+
+def rolling_reduce(dev: Device, x: DeviceArray, window: int, reducer: str, center=True) -> DeviceArray:
+    T, C_ = _tc(x)
+    out = dev.empty((T, C_), np.float32)
+    dev.call("xh_rolling_reduce", _vp(x.ptr), T, C_, C_, 1, int(window), int(bool(center)), REDUCERS[reducer],
+             _vp(out.ptr), C_)
+    return out
+
+
+def cumsum_reset(dev: Device, x: DeviceArray, index="last") -> DeviceArray:
+    T, C_ = _tc(x)
+    out = dev.empty((T, C_), np.float32)
+    dev.call("xh_cumsum_reset", _vp(x.ptr), T, C_, C_, 1, int(index == "first"), _vp(out.ptr), C_)
+    return out
+
+
+def rle(dev: Device, x: DeviceArray, index="first") -> DeviceArray:
+    T, C_ = _tc(x)
+    out = dev.empty((T, C_), np.float32)
+    dev.call("xh_rle", _vp(x.ptr), T, C_, C_, 1, int(index == "first"), _vp(out.ptr), C_)
+    return out
+
+
+def run_stats(dev: Device, x: DeviceArray, stat: str, window: int, seg_off, *, cut=True, index="first", fused_op=None,
+              thresh=0.0, want_valid=True):
+    T, C_ = _tc(x)
+    seg, P = _seg(seg_off)
+    out = dev.empty((P, C_), np.float32)
+    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    fop = -1 if fused_op is None else op_code(fused_op)
+    dev.call("xh_run_stats", _vp(x.ptr), T, C_, C_, 1, fop, float(thresh), int(window), RUN_STATS[stat],
+             int(index == "first"), np_ptr(seg), P, int(bool(cut)), _vp(out.ptr), _vp(valid.ptr if valid else 0))
+    return out, valid
+
+
+def nan_quantile(dev: Device, x: DeviceArray, q, alpha=1.0, beta=1.0, sample_axis=0) -> DeviceArray:
+    """x: (N, C) if sample_axis == 0 else (C, N).  Returns (nq, C) float64."""
+    q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+    if sample_axis == 0:
+        N, C_ = _tc(x)
+        sn, sc = C_, 1
+    else:
+        C_, N = _tc(x)
+        sn, sc = 1, N
+    out = dev.empty((len(q), C_), np.float64)
+    dev.call("xh_nan_quantile", _vp(x.ptr), N, C_, sn, sc, np_ptr(q), len(q), float(alpha), float(beta), _vp(out.ptr))
+    return out
+
+
+def percentile_doy(dev: Device, x: DeviceArray, tbase, window: int, per, alpha=1.0 / 3, beta=1.0 / 3) -> DeviceArray:
+    """Returns (nper, ndoy, C) float64 — percentile_doy before the 366-day adjustment."""
+    T, C_ = _tc(x)
+    tb = np.ascontiguousarray(tbase, dtype=np.int32)
+    nyears, ndoy = tb.shape
+    per = np.ascontiguousarray(np.atleast_1d(per), dtype=np.float64)
+    out = dev.empty((len(per), ndoy, C_), np.float64)
+    dev.call("xh_percentile_doy", _vp(x.ptr), T, C_, C_, 1, np_ptr(tb), nyears, ndoy, int(window), np_ptr(per), len(per),
+             float(alpha), float(beta), _vp(out.ptr))
+    return out
+
+
+def doy_interp(dev: Device, table: DeviceArray, i0, i1, dxn, dxs) -> DeviceArray:
+    """table (D_in, C) float64 -> (D_out, C) float64 (xh_doy_interp)."""
+    D_in, C_ = _tc(table)
+    i0 = np.ascontiguousarray(i0, dtype=np.int32)
+    i1 = np.ascontiguousarray(i1, dtype=np.int32)
+    dxn = np.ascontiguousarray(dxn, dtype=np.float64)
+    dxs = np.ascontiguousarray(dxs, dtype=np.float64)
+    out = dev.empty((len(i0), C_), np.float64)
+    dev.call("xh_doy_interp", _vp(table.ptr), D_in, C_, np_ptr(i0), np_ptr(i1), np_ptr(dxn), np_ptr(dxs), len(i0),
+             _vp(out.ptr))
+    return out
+
+
+def quantile_series(dev: Device, x: DeviceArray, q, time_axis=0) -> DeviceArray:
+    """Per-cell quantiles of the whole series: x (T, C) [time_axis 0] or (C, T) [time_axis 1] -> (nq, C) float32."""
+    q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+    if time_axis == 0:
+        T, C_ = _tc(x)
+        st, sc = C_, 1
+    else:
+        C_, T = _tc(x)
+        st, sc = 1, T
+    out = dev.empty((len(q), C_), np.float32)
+    dev.call("xh_quantile_series", _vp(x.ptr), T, C_, st, sc, np_ptr(q), len(q), _vp(out.ptr))
+    return out
+
+
+def eqm_train(dev: Device, ref: DeviceArray, hist: DeviceArray, q, kind="+", time_axis=0):
+    q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+    if time_axis == 0:
+        T, C_ = _tc(ref)
+        st, sc = C_, 1
+    else:
+        C_, T = _tc(ref)
+        st, sc = 1, T
+    af = dev.empty((len(q), C_), np.float32)
+    hq = dev.empty((len(q), C_), np.float32)
+    dev.call("xh_eqm_train", _vp(ref.ptr), _vp(hist.ptr), T, C_, st, sc, np_ptr(q), len(q), {"+": 0, "*": 1}[kind],
+             _vp(af.ptr), _vp(hq.ptr))
+    return af, hq
+
+
+def eqm_adjust(dev: Device, sim: DeviceArray, af: DeviceArray, hist_q: DeviceArray, kind="+", interp="nearest",
+               extrapolation="constant", out: DeviceArray | None = None) -> DeviceArray:
+    T, C_ = _tc(sim)
+    nq = int(af.shape[0])
+    scen = out if out is not None else dev.empty((T, C_), np.float32)
+    dev.call("xh_eqm_adjust", _vp(sim.ptr), T, C_, C_, 1, _vp(af.ptr), _vp(hist_q.ptr), nq, {"+": 0, "*": 1}[kind],
+             {"nearest": 0, "linear": 1}[interp], {"constant": 0, "nan": 1}[extrapolation], _vp(scen.ptr), C_)
+    return scen

@@ -1,0 +1,170 @@
+"""Host-side calendar arithmetic: resample segments, day-of-year tables, expected counts.
+
+All of this is O(T) coordinate work that stays on the host (SURVEY.md §2.1 "Rest of calendar: OUT OF SCOPE"); the
+device kernels only see integer tables (``seg_off``, ``tidx``, ``tbase``).  Mirrors the grouping semantics of
+``xarray.DataArray.resample(time=freq)`` for the start-anchored frequencies xclim uses (``YS[-MMM]``, ``QS[-MMM]``,
+``MS``) and ``core/missing.py:64-160`` (``expected_count``) for the three calendars the survey's fixtures need.
+cftime is not installed, so non-standard calendars are handled with integer arithmetic.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+MONTHS = ["JAN", "FEB", "MAR", "APR", "MAY", "JUN", "JUL", "AUG", "SEP", "OCT", "NOV", "DEC"]
+_MLEN_NOLEAP = np.array([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])
+
+
+def _is_leap(year, calendar: str):
+    year = np.asarray(year)
+    if calendar in ("noleap", "365_day", "360_day"):
+        return np.zeros(year.shape, dtype=bool)
+    if calendar in ("all_leap", "366_day"):
+        return np.ones(year.shape, dtype=bool)
+    return ((year % 4 == 0) & (year % 100 != 0)) | (year % 400 == 0)
+
+
+def _month_len(year: int, month: int, calendar: str) -> int:
+    if calendar == "360_day":
+        return 30
+    n = int(_MLEN_NOLEAP[month - 1])
+    if month == 2 and bool(_is_leap(year, calendar)):
+        n += 1
+    return n
+
+
+def parse_freq(freq: str) -> tuple[str, int]:
+    """Return (base, anchor_month) with base in {"Y", "Q", "M"}.  Only start-anchored offsets are supported."""
+    f = freq.upper()
+    for old, new in (("AS", "YS"), ("A-", "Y-")):
+        if f.startswith(old):
+            f = new + f[len(old):]
+    if f == "MS":
+        return "M", 1
+    for base in ("YS", "QS"):
+        if f == base:
+            return base[0], 1
+        if f.startswith(base + "-"):
+            mon = f.split("-", 1)[1]
+            if mon not in MONTHS:
+                raise ValueError(f"Unknown anchor month in frequency {freq!r}")
+            return base[0], MONTHS.index(mon) + 1
+    raise NotImplementedError(f"Resampling frequency {freq!r} is not supported by the HIP backend host helper.")
+
+
+class TimeAxis:
+    """A daily (or coarser) time coordinate reduced to integer fields."""
+
+    def __init__(self, year, month, day, calendar: str = "standard"):
+        self.year = np.asarray(year, dtype=np.int64)
+        self.month = np.asarray(month, dtype=np.int64)
+        self.day = np.asarray(day, dtype=np.int64)
+        self.calendar = calendar
+        if calendar == "360_day":
+            self.doy = (self.month - 1) * 30 + self.day
+        else:
+            cum = np.concatenate([[0], np.cumsum(_MLEN_NOLEAP)])[:-1]
+            self.doy = cum[self.month - 1] + self.day + ((self.month > 2) & _is_leap(self.year, calendar))
+        self.doy = self.doy.astype(np.int64)
+
+    def __len__(self):
+        return int(self.year.shape[0])
+
+    # ---- constructors ----
+    @classmethod
+    def from_pandas(cls, index) -> "TimeAxis":
+        return cls(index.year.values, index.month.values, index.day.values, "standard")
+
+    @classmethod
+    def daily(cls, start: str, periods: int, calendar: str = "standard") -> "TimeAxis":
+        """Daily axis starting at ``YYYY-MM-DD``."""
+        y, m, d = (int(p) for p in start.split("-"))
+        if calendar == "standard":
+            import pandas as pd
+
+            return cls.from_pandas(pd.date_range(start, periods=periods, freq="D"))
+        years = np.empty(periods, dtype=np.int64)
+        months = np.empty(periods, dtype=np.int64)
+        days = np.empty(periods, dtype=np.int64)
+        i = 0
+        while i < periods:
+            ml = _month_len(y, m, calendar)
+            n = min(ml - d + 1, periods - i)
+            years[i : i + n] = y
+            months[i : i + n] = m
+            days[i : i + n] = np.arange(d, d + n)
+            i += n
+            d = 1
+            m += 1
+            if m > 12:
+                m = 1
+                y += 1
+        return cls(years, months, days, calendar)
+
+    def subset(self, sl) -> "TimeAxis":
+        out = TimeAxis.__new__(TimeAxis)
+        out.year, out.month, out.day, out.doy = self.year[sl], self.month[sl], self.day[sl], self.doy[sl]
+        out.calendar = self.calendar
+        return out
+
+    # ---- resample segments ----
+    def _period_key(self, freq: str):
+        base, anchor = parse_freq(freq)
+        m0 = self.year * 12 + (self.month - 1)
+        if base == "M":
+            return m0, 1, 0
+        if base == "Y":
+            off = anchor - 1
+            return (m0 - off) // 12, 12, off
+        off = (anchor - 1) % 3
+        return (m0 - off) // 3, 3, off
+
+    def segments(self, freq: str):
+        """Period segments of ``resample(time=freq)``.
+
+        Returns ``(seg_off, starts)``: ``seg_off`` int64[P+1] offsets into the (sorted) time axis — empty periods
+        inside the span are kept, as pandas does — and ``starts`` a list of ``(year, month)`` period start labels.
+        """
+        key, nmon, off = self._period_key(freq)
+        if len(key) == 0:
+            return np.zeros(1, dtype=np.int64), []
+        if np.any(np.diff(key) < 0):
+            raise ValueError("time axis must be sorted")
+        k0, k1 = int(key[0]), int(key[-1])
+        keys = np.arange(k0, k1 + 1)
+        seg_off = np.searchsorted(key, np.concatenate([keys, [k1 + 1]]), side="left").astype(np.int64)
+        starts = []
+        for k in keys:
+            mstart = int(k) * nmon + off
+            starts.append((mstart // 12, mstart % 12 + 1))
+        return seg_off, starts
+
+    def expected_count(self, freq: str) -> np.ndarray:
+        """Days in each full resampling period (core/missing.py:137-159, daily source)."""
+        _, starts = self.segments(freq)
+        base, _ = parse_freq(freq)
+        nmon = {"M": 1, "Q": 3, "Y": 12}[base]
+        out = np.zeros(len(starts), dtype=np.int32)
+        for i, (y, m) in enumerate(starts):
+            n = 0
+            for _ in range(nmon):
+                n += _month_len(y, m, self.calendar)
+                m += 1
+                if m > 12:
+                    m, y = 1, y + 1
+            out[i] = n
+        return out
+
+    # ---- day-of-year tables ----
+    def doy_table(self):
+        """(tbase int32[nyears, ndoy], years, doys): time index of each (year, doy), -1 when absent (cal:450-458)."""
+        years = np.unique(self.year)
+        doys = np.unique(self.doy)
+        tb = np.full((len(years), len(doys)), -1, dtype=np.int32)
+        yi = np.searchsorted(years, self.year)
+        di = np.searchsorted(doys, self.doy)
+        tb[yi, di] = np.arange(len(self), dtype=np.int32)
+        return tb, years, doys
+
+    def max_doy(self) -> int:
+        return {"360_day": 360, "noleap": 365, "365_day": 365}.get(self.calendar, 366)
