@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""bench.py — the reference's headline workload on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu] [--no-extra]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): tx90p = percentile_doy(window 5, per 90) + threshold_count(">", per-doy fp64
+threshold, freq "YS") + MissingAny mask on a synthetic 365 x 1440 x 720 fp32 tasmax grid (noleap, time-major), all
+resident in HBM.  One "step" = one full pass of that chain through the C ABI.  With N > 1 every rank owns one
+1440x720 slab of an N-times larger grid (lat split, weak scaling) and the reduced (P, C) outputs are all-gathered
+over RCCL at the end of each step (the only exchange on this path).
+
+Prints ONE JSON line (rank 0): metric = grid-cells x timesteps / s (whole job), plus
+  roofline     — dominant kernel (percentile_doy), algorithmic bytes / HIP-event time on the kernel's own stream
+  cpu_baseline — the numpy oracle (a port: the reference stack is not installable) on a bounded lat-band sample
+  extra        — the two other north-star workloads at the same grid (cdd run-length, EQM train+adjust)
+torch is imported only for N > 1 (torch.distributed rendezvous + RCCL all_gather); the product path is torch-free.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s best measured copy)
+
+
+def event_time(dev, fn, reps):
+    """Average duration (ms) of `fn` over `reps` launches, HIP events on the kernel's own stream."""
+    fn()
+    dev.sync()
+    dev.timer_start()
+    for _ in range(reps):
+        fn()
+    return dev.timer_stop() / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=str, default="365x1440x720")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+
+    from xclim_amd import kernels as K
+    from xclim_amd._capi import Device
+    from xclim_amd.timeaxis import TimeAxis
+
+    dev = Device(local_rank)
+    T, Y, X = (int(v) for v in args.grid.split("x"))
+    C = Y * X
+    ta = TimeAxis.daily("2001-01-01", T, "noleap")
+    tb, years, doys = ta.doy_table()
+    seg, _ = ta.segments("YS")
+    P = len(seg) - 1
+    expected = ta.expected_count("YS")
+    tidx_h = np.searchsorted(doys, ta.doy).astype(np.int32)
+    sys.path.insert(0, ROOT)
+    from oracle import synth  # input generator restated on the host (bit-identical to xh_fill_synthetic)
+
+    base = synth.seasonal_base(T)
+    tasmax = K.fill_synthetic(dev, T, C, 0, 2, base, 3.0, cell0=rank * C)
+    per = dev.empty((1, len(doys), C), np.float64)
+    cnt, val = dev.empty((P, C), np.int32), dev.empty((P, C), np.int32)
+    res = dev.empty((P, C), np.float64)
+    tidx = dev.to_device(tidx_h)
+    table = per.reshape(len(doys), C)
+    gathered = None
+    if world > 1:
+        res_t = torch.empty((P, C), dtype=torch.float64, device="cuda")
+        gathered = torch.empty((world, P, C), dtype=torch.float64, device="cuda")
+        res = dev.wrap(res_t.data_ptr(), (P, C), np.float64)
+
+    def k_pdoy():
+        K.percentile_doy(dev, tasmax, tb, 5, [90.0], out=per)
+
+    def k_count():
+        K.threshold_count(dev, tasmax, ">", seg, doy_table=table, tidx=tidx, out=(cnt, val))
+
+    def k_mask():
+        K.apply_missing_mask(dev, cnt, val, expected, out=res)
+
+    def step():
+        k_pdoy()
+        k_count()
+        k_mask()
+        if world > 1:
+            dev.sync()
+            dist.all_gather_into_tensor(gathered.view(world * P, C), res_t)
+
+    def fence():
+        dev.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    units_step = float(T) * C * world
+    value = units_step * args.steps / dt
+
+    # ---- roofline of the dominant kernel (per launch, this rank) ----
+    reps = max(5, min(args.steps, 20))
+    ms_pdoy = event_time(dev, k_pdoy, reps)
+    ms_count = event_time(dev, k_count, reps)
+    ms_mask = event_time(dev, k_mask, reps)
+    E = float(T) * C
+    D = float(len(doys))
+    bytes_pdoy = 4 * E + 8 * D * C  # read x once, write (D, C) fp64
+    bytes_count = 4 * E + 8 * D * C + 8 * P * C  # read x, read per-doy fp64 table, write count+valid int32
+    roofline = {
+        "bound": "hbm",
+        "kernel": "k_pdoy_reg<8,4> (xh_percentile_doy)",
+        "achieved": bytes_pdoy / (ms_pdoy * 1e-3) / 1e9,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": bytes_pdoy / (ms_pdoy * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "traffic": None,
+        "algorithmic_bytes": bytes_pdoy,
+        "ms": ms_pdoy,
+        "chain": {
+            "percentile_doy": {"ms": ms_pdoy, "GB/s": bytes_pdoy / ms_pdoy / 1e6},
+            "threshold_count_doy": {"ms": ms_count, "GB/s": bytes_count / ms_count / 1e6},
+            "missing_mask": {"ms": ms_mask},
+            "tx90p_unfused_total": {"ms": ms_pdoy + ms_count + ms_mask,
+                                    "GB/s": (bytes_pdoy + bytes_count) / (ms_pdoy + ms_count + ms_mask) / 1e6},
+        },
+    }
+
+    extra = {}
+    if not args.no_extra and rank == 0 and world == 1:
+        extra = bench_extra(dev, K, ta, T, C, seg, P, synth)
+
+    cpu = None
+    if not args.no_cpu and rank == 0 and world == 1:
+        cpu = cpu_baseline(T, Y, X, synth)
+
+    if rank == 0:
+        line = {
+            "metric": "grid-cells x timesteps / s (tx90p = percentile_doy + threshold_count + missing mask)",
+            "value": value,
+            "unit": "cell-timesteps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"tx90p (percentile_doy window 5 per 90 + threshold_count > + MissingAny) on {T}x{Y}x{X} fp32 "
+                                   f"per GPU, noleap, freq YS, time-major, resident in HBM",
+                       "grid_per_gpu": [T, Y, X], "sharding": "lat slabs, one per rank; RCCL all_gather of (P,C) fp64"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "extra": extra,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_extra(dev, K, ta, T, C, seg, P, synth):
+    """The other two north-star workloads on the same 365 x 1440 x 720 grid (HIP-event times, one GPU)."""
+    out = {}
+    E = float(T) * C
+    # --- maximum_consecutive_dry_days: fused compare + run-length max + valid count ---
+    pr = K.fill_synthetic(dev, T, C, 1, 3, np.zeros(T, np.float32), 40.0 / 86400.0, 0.3)
+    o, v = dev.empty((P, C), np.float32), dev.empty((P, C), np.int32)
+    ms = event_time(dev, lambda: K.run_stats(dev, pr, "max", 1, seg, cut=True, fused_op="<", thresh=1.0 / 86400.0,
+                                             out=(o, v)), 10)
+    b = 4 * E + 8 * P * C
+    out["cdd_rle_365"] = {"ms": ms, "GB/s": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS,
+                          "cell-timesteps/s": E / (ms * 1e-3), "algorithmic_bytes": b}
+    del pr
+    # --- EQM train + adjust (nquantiles 20, "+", nearest, constant) ---
+    base = synth.seasonal_base(T)
+    ref = K.fill_synthetic(dev, T, C, 0, 4, base, 3.0)
+    hist = K.fill_synthetic(dev, T, C, 0, 5, base + np.float32(1.5), 3.3)
+    sim = K.fill_synthetic(dev, T, C, 0, 6, base + np.float32(3.5), 3.3)
+    q = (np.arange(20) + 0.5) / 20
+    af, hq = dev.empty((20, C), np.float32), dev.empty((20, C), np.float32)
+    scen = dev.empty((T, C), np.float32)
+    ms_tr = event_time(dev, lambda: K.eqm_train(dev, ref, hist, q, "+", out=(af, hq)), 3)
+    ms_ad = event_time(dev, lambda: K.eqm_adjust(dev, sim, af, hq, "+", "nearest", "constant", out=scen), 10)
+    b_tr = 8 * E + 8 * 20 * C
+    b_ad = 8 * E + 8 * 20 * C
+    out["eqm_train_365"] = {"ms": ms_tr, "GB/s": b_tr / ms_tr / 1e6, "frac": b_tr / ms_tr / 1e6 / HBM_PEAK_GBS,
+                            "algorithmic_bytes": b_tr, "note": "time-major input: includes the internal transpose"}
+    out["eqm_adjust_365"] = {"ms": ms_ad, "GB/s": b_ad / ms_ad / 1e6, "frac": b_ad / ms_ad / 1e6 / HBM_PEAK_GBS,
+                             "algorithmic_bytes": b_ad}
+    out["eqm_train_adjust_365"] = {"ms": ms_tr + ms_ad, "GB/s": (b_tr + b_ad) / (ms_tr + ms_ad) / 1e6,
+                                   "frac": (b_tr + b_ad) / (ms_tr + ms_ad) / 1e6 / HBM_PEAK_GBS,
+                                   "cell-timesteps/s": E / ((ms_tr + ms_ad) * 1e-3)}
+    return out
+
+
+def cpu_baseline(T, Y, X, synth, budget_s=20.0):
+    """Oracle (numpy restatement of the reference) on a lat-band sample of the SAME synthetic field, one core.
+
+    Chunked over 512-cell blocks (cache-resident temporaries); one untimed warm-up block, then timed blocks until
+    ~budget_s seconds have elapsed.
+    """
+    from oracle import calendar as ocal
+    from oracle import indices as oidx
+    from oracle.timeutil import OTime
+
+    ot = OTime.noleap(2001, T)
+    base = synth.seasonal_base(T)
+    chunk = 512
+
+    def one(c0):
+        xs = synth.fill_synthetic(T, np.arange(c0, c0 + chunk), 0, 2, base, 3.0)
+        t0 = time.perf_counter()
+        p, doys = ocal.percentile_doy(xs, ot, 5, 90.0)
+        cnt = oidx.tx90p(xs, p[..., 0], doys, ot, "YS")
+        oidx.apply_missing(cnt, xs, ot, "YS")
+        return time.perf_counter() - t0
+
+    one(0)
+    spent, ncells, c0 = 0.0, 0, chunk
+    while spent < budget_s and c0 + chunk <= Y * X:
+        spent += one(c0)
+        ncells += chunk
+        c0 += chunk
+    return {"value": T * ncells / spent, "unit": "cell-timesteps/s", "cores": 1, "kind": "port",
+            "sample": f"tx90p oracle (numpy) on {ncells} cells x {T} steps of the same synthetic field, "
+                      f"{spent:.1f} s timed, 512-cell blocks, 1 thread"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""Host mirror of ``xclim.indices.generic`` (reference: src/xclim/indices/generic.py) over the HIP kernels.
+
+Same function names, argument meaning and error behaviour as the reference; differences forced by the missing
+xarray: data are numpy/device arrays with TIME ON AXIS 0 and the time coordinate is a
+:class:`~xclim_amd.timeaxis.TimeAxis`; thresholds are plain numbers in the units of the data (unit conversion is
+pint/host work, out of scope).  Every function returns numpy (``(P, *cells)``) unless ``keep=True`` (device array
+``(P, C)``), and can also return the fused MissingAny valid count (``with_valid=True``).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import kernels as K
+from ._capi import OPS, DeviceArray, get_device
+from .calendar import DoyPercentile, _flatten, adjust_doy_calendar, resample_doy_index
+from .timeaxis import TimeAxis
+
+binary_ops = {">": "gt", "<": "lt", ">=": "ge", "<=": "le", "==": "eq", "!=": "ne"}
+
+
+def get_op(op: str, constrain=None) -> str:
+    """gen:255-298: validate an operator name; returns the canonical symbol."""
+    if op == "gteq":
+        op = "ge"
+    if op == "lteq":
+        op = "le"
+    if op in binary_ops:
+        sym = op
+    elif op in binary_ops.values():
+        sym = {v: k for k, v in binary_ops.items()}[op]
+    else:
+        raise ValueError(f"Operation `{op}` not recognized.")
+    if constrain:
+        allowed = list(constrain) + [binary_ops[c] for c in constrain if c in binary_ops]
+        if op not in allowed:
+            raise ValueError(f"Operation `{op}` not permitted for indice.")
+    return sym
+
+
+def _finish(out: DeviceArray, valid, cell_shape, keep, with_valid):
+    if keep:
+        return (out, valid) if with_valid else out
+    o = out.get().reshape((out.shape[0],) + tuple(cell_shape))
+    if with_valid:
+        return o, valid.get().reshape(o.shape)
+    return o
+
+
+def threshold_count(da, op: str, threshold, time: TimeAxis, freq: str, constrain=None, *, device=None, keep=False,
+                    with_valid=False):
+    """gen:329-361.  ``threshold``: python float (fp32 compare, NumPy weak-scalar rule), ``np.float64`` scalar (fp64
+    compare), a :class:`DoyPercentile` (resample_doy fused: per-doy fp64 table, cal:763-790) or a full (T, *cells)
+    array / device array."""
+    if constrain is None:
+        constrain = (">", "<", ">=", "<=")
+    sym = get_op(op, constrain)
+    dev = device or get_device()
+    x, cell_shape = _flatten(da, dev)
+    seg, _ = time.segments(freq)
+    if isinstance(threshold, DoyPercentile):
+        doy = adjust_doy_calendar(threshold, time, dev)
+        if doy.data.shape[0] != 1:
+            raise ValueError("select one percentile first (DoyPercentile.sel)")
+        table = doy.data.reshape(doy.data.shape[1], doy.data.shape[2])
+        cnt, val = K.threshold_count(dev, x, sym, seg, doy_table=table, tidx=resample_doy_index(doy, time))
+    elif isinstance(threshold, DeviceArray):
+        cnt, val = K.threshold_count(dev, x, sym, seg, full=threshold.reshape(threshold.shape[0], -1))
+    elif np.ndim(threshold) == 0:
+        # NumPy 2 promotion: python float is a weak scalar (fp32 compare); an np.float64 scalar forces fp64
+        f64 = isinstance(threshold, np.float64)
+        cnt, val = K.threshold_count(dev, x, sym, seg, scalar=float(threshold), scalar_f64=bool(f64))
+    else:
+        th = np.asarray(threshold)
+        dt = np.float64 if th.dtype == np.float64 else np.float32
+        full = dev.to_device(np.broadcast_to(th, np.shape(da)).reshape(x.shape), dtype=dt)
+        cnt, val = K.threshold_count(dev, x, sym, seg, full=full)
+    return _finish(cnt, val, cell_shape, keep, with_valid)
+
+
+def count_occurrences(da, threshold: float, op: str, time: TimeAxis, freq: str, constrain=None, **kw):
+    """gen:960-999 (all six operators allowed)."""
+    return threshold_count(da, op, threshold, time, freq, constrain=constrain or tuple(OPS), **kw)
+
+
+def domain_count(da, low: float, high: float, time: TimeAxis, freq: str, *, device=None, keep=False, with_valid=False):
+    """gen:364-392: count of ``low < da <= high`` per period."""
+    dev = device or get_device()
+    x, cell_shape = _flatten(da, dev)
+    seg, _ = time.segments(freq)
+    cnt, val = K.domain_count(dev, x, ">", low, "<=", high, "and", seg)
+    return _finish(cnt, val, cell_shape, keep, with_valid)
+
+
+def select_resample_op(da, op: str, time: TimeAxis, freq: str = "YS", *, device=None, keep=False, with_valid=False):
+    """gen:83-125 (string ops, no indexer): min/max/mean/std/var/count/sum/integral/argmax/argmin per period."""
+    dev = device or get_device()
+    x, cell_shape = _flatten(da, dev)
+    seg, _ = time.segments(freq)
+    out, val = K.resample_reduce(dev, x, op, seg)
+    return _finish(out, val, cell_shape, keep, with_valid)
+
+
+def select_rolling_resample_op(da, op: str, window: int, time: TimeAxis, window_center: bool = True,
+                               window_op: str = "mean", freq: str = "YS", *, device=None, keep=False,
+                               with_valid=False):
+    """gen:128-174: rolling(window).window_op() then select_resample_op."""
+    dev = device or get_device()
+    x, cell_shape = _flatten(da, dev)
+    rolled = K.rolling_reduce(dev, x, window, window_op, window_center)
+    seg, _ = time.segments(freq)
+    out, val = K.resample_reduce(dev, rolled, op, seg)
+    return _finish(out, val, cell_shape, keep, with_valid)
+
+
+def spell_length_statistics(data, threshold: float, window: int, win_reducer, op: str, spell_reducer: str,
+                            time: TimeAxis, freq: str, min_gap: int = 1, resample_before_rl: bool = True, *,
+                            device=None, keep=False, with_valid=False):
+    """gen:588-686 / 543-585.  window == 1 (the path of maximum_consecutive_dry/wet_days and friends): compare,
+    astype(float32), rle_statistics(window=1) fused in ONE kernel pass.  window > 1 is not wired yet."""
+    if window != 1 or min_gap != 1:
+        raise NotImplementedError("spell_length_statistics: only window == 1, min_gap == 1 run on the HIP path yet")
+    sym = get_op(op)
+    dev = device or get_device()
+    x, cell_shape = _flatten(data, dev)
+    seg, _ = time.segments(freq)
+    out, val = K.run_stats(dev, x, spell_reducer, 1, seg, cut=resample_before_rl, fused_op=sym, thresh=float(threshold))
+    return _finish(out, val, cell_shape, keep, with_valid)

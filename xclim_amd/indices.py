@@ -1,0 +1,108 @@
+"""Index compositions on the hot path, with the Indicator-level MissingAny mask fused in.
+
+Reference: indices/_simple.py:76-113 (tg_mean & co.), indices/_multivariate.py:1440-1592 (t*10p/t*90p),
+indices/_threshold.py:2815-2937 (maximum_consecutive_{dry,wet}_days), Indicator._postprocess
+(core/indicator.py:1522-1549) + MissingAny (core/missing.py:318-322).
+
+Every function returns what ``xclim.atmos.<indicator>`` returns after ``check_missing="any"``: a float64 array
+(P, *cells) with NaN where the period has a missing/invalid day.  ``mask_missing=False`` gives the raw
+``xclim.indices`` result.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import generic
+from . import kernels as K
+from ._capi import get_device
+from .calendar import DoyPercentile
+from .timeaxis import TimeAxis
+
+
+def _masked(out, valid, time: TimeAxis, freq, dev, cell_shape, mask_missing):
+    if not mask_missing:
+        o = out.get()
+        return o.reshape((o.shape[0],) + tuple(cell_shape))
+    res = K.apply_missing_mask(dev, out, valid, time.expected_count(freq)).get()
+    return res.reshape((res.shape[0],) + tuple(cell_shape))
+
+
+def _cells(da):
+    return tuple(np.shape(da)[1:]) if not hasattr(da, "dev") else tuple(da.shape[1:])
+
+
+def _resample_index(da, op, time, freq, device, mask_missing):
+    dev = device or get_device()
+    out, val = generic.select_resample_op(da, op, time, freq, device=dev, keep=True, with_valid=True)
+    return _masked(out, val, time, freq, dev, _cells(da), mask_missing)
+
+
+def tg_mean(tas, time: TimeAxis, freq: str = "YS", *, device=None, mask_missing=True):
+    """indices/_simple.py:76-113."""
+    return _resample_index(tas, "mean", time, freq, device, mask_missing)
+
+
+def tg_max(tas, time, freq="YS", **kw):
+    return _resample_index(tas, "max", time, freq, kw.get("device"), kw.get("mask_missing", True))
+
+
+def tg_min(tas, time, freq="YS", **kw):
+    return _resample_index(tas, "min", time, freq, kw.get("device"), kw.get("mask_missing", True))
+
+
+tx_max = tn_max = tg_max
+tx_min = tn_min = tg_min
+tx_mean = tn_mean = tg_mean
+
+
+def _percentile_count(da, per: DoyPercentile, time, freq, op, constrain, device, mask_missing):
+    dev = device or get_device()
+    cnt, val = generic.threshold_count(da, op, per, time, freq, constrain=constrain, device=dev, keep=True,
+                                       with_valid=True)
+    return _masked(cnt, val, time, freq, dev, _cells(da), mask_missing)
+
+
+def tx90p(tasmax, tasmax_per: DoyPercentile, time: TimeAxis, freq: str = "YS", op: str = ">", *, device=None,
+          mask_missing=True):
+    """indices/_multivariate.py:1534-1592: days with tasmax > its 90th day-of-year percentile."""
+    return _percentile_count(tasmax, tasmax_per, time, freq, op, (">", ">="), device, mask_missing)
+
+
+tg90p = tn90p = tx90p
+
+
+def tx10p(tasmax, tasmax_per: DoyPercentile, time: TimeAxis, freq: str = "YS", op: str = "<", *, device=None,
+          mask_missing=True):
+    """indices/_multivariate.py:1596-1650."""
+    return _percentile_count(tasmax, tasmax_per, time, freq, op, ("<", "<="), device, mask_missing)
+
+
+tg10p = tn10p = tx10p
+
+
+def _spell(da, thresh, op, reducer, time, freq, resample_before_rl, device, mask_missing):
+    dev = device or get_device()
+    out, val = generic.spell_length_statistics(da, thresh, 1, None, op, reducer, time, freq,
+                                               resample_before_rl=resample_before_rl, device=dev, keep=True,
+                                               with_valid=True)
+    return _masked(out, val, time, freq, dev, _cells(da), mask_missing)
+
+
+def maximum_consecutive_dry_days(pr, thresh: float, time: TimeAxis, freq: str = "YS", resample_before_rl: bool = True,
+                                 op: str = "<", *, device=None, mask_missing=True):
+    """indices/_threshold.py:2895-2937; ``thresh`` in the units of ``pr`` (1 mm/day = 1/86400 kg m-2 s-1)."""
+    return _spell(pr, thresh, op, "max", time, freq, resample_before_rl, device, mask_missing)
+
+
+def maximum_consecutive_wet_days(pr, thresh: float, time: TimeAxis, freq: str = "YS", resample_before_rl: bool = True,
+                                 op: str = ">", *, device=None, mask_missing=True):
+    """indices/_threshold.py:2815-2860."""
+    return _spell(pr, thresh, op, "max", time, freq, resample_before_rl, device, mask_missing)
+
+
+def frost_days(tasmin, time: TimeAxis, thresh: float = 273.15, freq: str = "YS", *, device=None, mask_missing=True):
+    """indices/_threshold.py (threshold_count(tasmin, "<", thresh, freq))."""
+    dev = device or get_device()
+    cnt, val = generic.threshold_count(tasmin, "<", float(thresh), time, freq, device=dev, keep=True, with_valid=True)
+    return _masked(cnt, val, time, freq, dev, _cells(tasmin), mask_missing)

@@ -63,12 +63,15 @@ def transpose(dev: Device, x: DeviceArray) -> DeviceArray:
 
 
 def threshold_count(dev: Device, x: DeviceArray, op: str, seg_off, *, scalar=None, scalar_f64=False, doy_table=None,
-                    tidx=None, full=None, want_valid=True):
+                    tidx=None, full=None, want_valid=True, out=None):
     """xh_threshold_count.  Exactly one of scalar / (doy_table, tidx) / full.  Returns (count, valid) (P, C) int32."""
     T, C_ = _tc(x)
     seg, P = _seg(seg_off)
-    count = dev.empty((P, C_), np.int32)
-    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    if out is not None:
+        count, valid = out
+    else:
+        count = dev.empty((P, C_), np.int32)
+        valid = dev.empty((P, C_), np.int32) if want_valid else None
     table_ptr, tstride, tidx_ptr, kind, thr = _vp(0), 0, _vp(0), capi.THR_SCALAR_F32, 0.0
     keep = []
     if scalar is not None:
@@ -77,8 +80,11 @@ def threshold_count(dev: Device, x: DeviceArray, op: str, seg_off, *, scalar=Non
     elif doy_table is not None:
         kind = capi.THR_DOY_F64 if doy_table.dtype == np.float64 else capi.THR_DOY_F32
         table_ptr, tstride = _vp(doy_table.ptr), int(doy_table.shape[-1])
-        dt = dev.to_device(np.ascontiguousarray(tidx, dtype=np.int32))
-        keep.append(dt)
+        if isinstance(tidx, DeviceArray):
+            dt = tidx
+        else:
+            dt = dev.to_device(np.ascontiguousarray(tidx, dtype=np.int32))
+            keep.append(dt)
         tidx_ptr = _vp(dt.ptr)
     elif full is not None:
         kind = capi.THR_FULL_F64 if full.dtype == np.float64 else capi.THR_FULL_F32
@@ -115,11 +121,11 @@ def resample_reduce(dev: Device, x: DeviceArray, reducer: str, seg_off, skipna=T
     return out, valid
 
 
-def apply_missing_mask(dev: Device, value: DeviceArray, valid: DeviceArray, expected) -> DeviceArray:
+def apply_missing_mask(dev: Device, value: DeviceArray, valid: DeviceArray, expected, out=None) -> DeviceArray:
     P, C_ = _tc(value)
     exp = np.ascontiguousarray(expected, dtype=np.int32)
     assert exp.shape == (P,)
-    out = dev.empty((P, C_), np.float64)
+    out = out if out is not None else dev.empty((P, C_), np.float64)
     kind = 0 if value.dtype == np.int32 else 1
     dev.call("xh_apply_missing_mask", _vp(value.ptr), kind, _vp(valid.ptr), np_ptr(exp), P, C_, _vp(out.ptr))
     return out
@@ -148,11 +154,14 @@ def rle(dev: Device, x: DeviceArray, index="first") -> DeviceArray:
 
 
 def run_stats(dev: Device, x: DeviceArray, stat: str, window: int, seg_off, *, cut=True, index="first", fused_op=None,
-              thresh=0.0, want_valid=True):
+              thresh=0.0, want_valid=True, out=None):
     T, C_ = _tc(x)
     seg, P = _seg(seg_off)
-    out = dev.empty((P, C_), np.float32)
-    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    if out is not None:
+        out, valid = out
+    else:
+        out = dev.empty((P, C_), np.float32)
+        valid = dev.empty((P, C_), np.int32) if want_valid else None
     fop = -1 if fused_op is None else op_code(fused_op)
     dev.call("xh_run_stats", _vp(x.ptr), T, C_, C_, 1, fop, float(thresh), int(window), RUN_STATS[stat],
              int(index == "first"), np_ptr(seg), P, int(bool(cut)), _vp(out.ptr), _vp(valid.ptr if valid else 0))
@@ -173,13 +182,14 @@ def nan_quantile(dev: Device, x: DeviceArray, q, alpha=1.0, beta=1.0, sample_axi
     return out
 
 
-def percentile_doy(dev: Device, x: DeviceArray, tbase, window: int, per, alpha=1.0 / 3, beta=1.0 / 3) -> DeviceArray:
+def percentile_doy(dev: Device, x: DeviceArray, tbase, window: int, per, alpha=1.0 / 3, beta=1.0 / 3,
+                   out=None) -> DeviceArray:
     """Returns (nper, ndoy, C) float64 — percentile_doy before the 366-day adjustment."""
     T, C_ = _tc(x)
     tb = np.ascontiguousarray(tbase, dtype=np.int32)
     nyears, ndoy = tb.shape
     per = np.ascontiguousarray(np.atleast_1d(per), dtype=np.float64)
-    out = dev.empty((len(per), ndoy, C_), np.float64)
+    out = out if out is not None else dev.empty((len(per), ndoy, C_), np.float64)
     dev.call("xh_percentile_doy", _vp(x.ptr), T, C_, C_, 1, np_ptr(tb), nyears, ndoy, int(window), np_ptr(per), len(per),
              float(alpha), float(beta), _vp(out.ptr))
     return out
@@ -212,7 +222,7 @@ def quantile_series(dev: Device, x: DeviceArray, q, time_axis=0) -> DeviceArray:
     return out
 
 
-def eqm_train(dev: Device, ref: DeviceArray, hist: DeviceArray, q, kind="+", time_axis=0):
+def eqm_train(dev: Device, ref: DeviceArray, hist: DeviceArray, q, kind="+", time_axis=0, out=None):
     q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
     if time_axis == 0:
         T, C_ = _tc(ref)
@@ -220,8 +230,11 @@ def eqm_train(dev: Device, ref: DeviceArray, hist: DeviceArray, q, kind="+", tim
     else:
         C_, T = _tc(ref)
         st, sc = 1, T
-    af = dev.empty((len(q), C_), np.float32)
-    hq = dev.empty((len(q), C_), np.float32)
+    if out is not None:
+        af, hq = out
+    else:
+        af = dev.empty((len(q), C_), np.float32)
+        hq = dev.empty((len(q), C_), np.float32)
     dev.call("xh_eqm_train", _vp(ref.ptr), _vp(hist.ptr), T, C_, st, sc, np_ptr(q), len(q), {"+": 0, "*": 1}[kind],
              _vp(af.ptr), _vp(hq.ptr))
     return af, hq
