@@ -31,6 +31,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s best measured copy)
 
 
+def pmc_traffic(kernel, grid):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE collected in
+    separate runs by tools/profile_bench.sh, corrected per MI355X_MICROARCH.md by tools/summarize_pmc.py).  Only
+    valid for the grid the profile was taken on (365x1440x720); None otherwise."""
+    if tuple(grid) != (365, 1440, 720):
+        return None
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
+    try:
+        return json.load(open(path))[kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def event_time(dev, fn, reps):
     """Average duration (ms) of `fn` over `reps` launches, HIP events on the kernel's own stream."""
     fn()
@@ -143,12 +156,12 @@ def main():
     bytes_count = 4 * E + 8 * D * C + 8 * P * C  # read x, read per-doy fp64 table, write count+valid int32
     roofline = {
         "bound": "hbm",
-        "kernel": "k_pdoy_reg<8,4> (xh_percentile_doy)",
+        "kernel": "k_pdoy_slide<5, 4> (xh_percentile_doy)",
         "achieved": bytes_pdoy / (ms_pdoy * 1e-3) / 1e9,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": bytes_pdoy / (ms_pdoy * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": pmc_traffic("k_pdoy_slide<5, 4>", (T, Y, X)),
         "algorithmic_bytes": bytes_pdoy,
         "ms": ms_pdoy,
         "chain": {

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected in separate runs by tools/profile_bench.sh)
+into HBM bytes per launch per kernel -> profiles/<tag>/pmc_hbm_traffic.json.
+
+Units/corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: both counters are in KiB; on gfx950
+FETCH_SIZE reports exactly 1/2 of the bytes of a coalesced streaming read, so it is doubled for the streaming
+kernels (calibration on this code: k_threshold_count reads x (1.514 GB) + the fp64 table (3.028 GB) = 4.542 GB and
+FETCH_SIZE*1024*2 = 4.542 GB; k_run_max_fused reads 1.514 GB, FETCH_SIZE*1024*2 = 1.514 GB; k_fill_synthetic writes
+1.514 GB and WRITE_SIZE*1024 = 1.514 GB, i.e. writes need no correction).  The strided-gather select kernels are
+NOT calibrated and are reported uncorrected.
+
+usage: tools/summarize_pmc.py gpurun_out/prof_<tag> profiles/<tag>
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+UNCALIBRATED = ("k_select", "__amd_rocclr")
+
+
+def main(src, dst):
+    out = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for f in files:
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != cname:
+                    continue
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                agg[k][0] += 1
+                agg[k][1] += float(r["Counter_Value"])
+        for k, (n, v) in agg.items():
+            out.setdefault(k, {})[cname + "_KiB_mean"] = v / n
+            out[k]["launches"] = n
+    for k, d in out.items():
+        x2 = not k.startswith(UNCALIBRATED)
+        f = d.get("FETCH_SIZE_KiB_mean", 0.0) * 1024 * (2 if x2 else 1)
+        w = d.get("WRITE_SIZE_KiB_mean", 0.0) * 1024
+        d["fetch_x2_correction"] = x2
+        d["hbm_read_bytes_per_launch"] = f
+        d["hbm_write_bytes_per_launch"] = w
+        d["hbm_bytes_per_launch"] = f + w
+    os.makedirs(dst, exist_ok=True)
+    json.dump(out, open(os.path.join(dst, "pmc_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
+    for k, d in sorted(out.items()):
+        print(f"{k:40s} read {d['hbm_read_bytes_per_launch'] / 1e9:7.3f} GB  write {d['hbm_write_bytes_per_launch'] / 1e9:7.3f} GB")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -51,6 +51,12 @@ void xh_set_error(const char* fmt, ...);
 // Upload a small host table into the context scratch (bump allocated per call via `*cursor`).
 int xh_scratch_upload(xh_ctx* ctx, size_t* cursor, const void* host, size_t bytes, void** dptr);
 int xh_big_scratch(xh_ctx* ctx, size_t bytes, void** dptr);
+// select.hip: per-column exact multi-quantile selection on a time-minor view (d_q: device pointer)
+int xh_select_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const double* d_q,
+                      int nq, float* out, int64_t out_cstride, int64_t out_qstride);
+// short series read straight from a time-major view; XH_ERR_NOTIMPL when the shape does not fit
+int xh_select_time_major(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq,
+                         float* out, int64_t out_cstride, int64_t out_qstride);
 
 __host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -117,6 +123,36 @@ __device__ __forceinline__ VecF<VEC> xh_load(const float* __restrict__ p) {
     r.v[0] = *p;
   }
   return r;
+}
+
+// March along time over rows [t0, t1) of the lane's VEC cells with double-buffered batches of U rows: the loads of
+// batch b+1 are in flight while batch b is consumed, so a lane keeps U..2U independent 16-byte loads outstanding
+// (the serial state machines of the time-marching kernels are otherwise HBM-latency bound).
+template <int VEC, int U, typename F>
+__device__ __forceinline__ void xh_march_rows(const float* __restrict__ p, int64_t st, int64_t t0, int64_t t1, F&& f) {
+  int64_t t = t0;
+  int64_t nfull = (t1 - t0) / U;
+  if (nfull > 0) {
+    VecF<VEC> buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = xh_load<VEC>(p + (t + u) * st);
+    for (int64_t b = 0; b < nfull; ++b) {
+      VecF<VEC> nxt[U];
+      const bool more = b + 1 < nfull;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = xh_load<VEC>(p + (t + U + u) * st);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) f(t + u, buf[u]);
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) buf[u] = nxt[u];
+      }
+      t += U;
+    }
+  }
+  for (; t < t1; ++t) f(t, xh_load<VEC>(p + t * st));
 }
 
 // order-preserving float <-> uint32 key (ascending; NaN maps above +inf so it sorts last like numpy)

@@ -8,83 +8,7 @@
 //   utils.apply_correction  : scen = sim + af_t  |  sim * af_t
 #include "common.h"
 
-// ---- per-column sort + quantiles ------------------------------------------------------------------------
-// Columns are contiguous in memory (time-minor).  WAVE_COLS: each of the 4 waves of a block sorts its own column
-// (NP <= 4096 keys) in its LDS slice; otherwise the whole block sorts one column (NP <= 32768).  Bitonic network on
-// order-preserving uint32 keys (NaN -> 0xFFFFFFFF sorts last, as numpy).
-template <bool WAVE_COLS>
-__global__ void __launch_bounds__(XH_BLOCK)
-k_colsort_quantile(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col_stride, int NP,
-                   const double* __restrict__ qs, int nq, float* __restrict__ out, int64_t out_cstride,
-                   int64_t out_qstride) {
-  extern __shared__ uint32_t lds[];
-  __shared__ int s_nvalid[4];
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int cols_per_block = WAVE_COLS ? 4 : 1;
-  const int nthr = WAVE_COLS ? 64 : XH_BLOCK;   // threads cooperating on one column
-  const int me = WAVE_COLS ? lane : tid;
-  uint32_t* keys = lds + (WAVE_COLS ? (size_t)wave * NP : 0);
-
-  for (int64_t cb = (int64_t)blockIdx.x * cols_per_block; cb < ncols; cb += (int64_t)gridDim.x * cols_per_block) {
-    int64_t col = cb + (WAVE_COLS ? wave : 0);
-    bool have = col < ncols;
-    if (tid < 4) s_nvalid[tid] = 0;
-    __syncthreads();
-    int nv = 0;
-    for (int i = me; i < NP; i += nthr) {
-      uint32_t k = 0xFFFFFFFFu;
-      if (have && i < T) {
-        float v = x[col * col_stride + i];
-        k = xh_f2key(v);
-        nv += (v == v) ? 1 : 0;
-      }
-      keys[i] = k;
-    }
-    if (nv) atomicAdd(&s_nvalid[WAVE_COLS ? wave : 0], nv);
-    __syncthreads();
-    for (int size = 2; size <= NP; size <<= 1) {
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        for (int idx = me; idx < (NP >> 1); idx += nthr) {
-          int i = 2 * idx - (idx & (stride - 1));
-          int j = i + stride;
-          bool up = ((i & size) == 0);
-          uint32_t a = keys[i], b = keys[j];
-          uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-          keys[i] = up ? lo : hi;
-          keys[j] = up ? hi : lo;
-        }
-        __syncthreads();
-      }
-    }
-    if (have && me < nq) {
-      int n = s_nvalid[WAVE_COLS ? wave : 0];
-      double q = qs[me];
-      double r;
-      // same Hyndman-Fan evaluation as quantile.hip::xh_hf_quantile with alpha = beta = 1
-      if (T == 1) r = (double)xh_key2f(keys[0]);
-      else if (n < 2) r = n == 1 ? (double)xh_key2f(keys[0]) : xh_nan64();
-      else {
-        double nn = (double)n;
-        double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;
-        if (vi >= nn - 1.0) r = (double)xh_key2f(keys[n - 1]);
-        else if (vi < 0.0) r = (double)xh_key2f(keys[0]);
-        else {
-          double prev = floor(vi);
-          int ip = (int)prev;
-          double gamma = vi - prev;
-          float left = xh_key2f(keys[ip]), right = xh_key2f(keys[ip + 1]);
-          float diff = right - left;
-          r = (double)left + (double)diff * gamma;
-          if (gamma >= 0.5) r = (double)right - (double)diff * (1.0 - gamma);
-          if (r != r) r = (double)xh_key2f(keys[n - 1]);
-        }
-      }
-      out[col * out_cstride + (int64_t)me * out_qstride] = (float)r;
-    }
-    __syncthreads();
-  }
-}
+// Per-column quantiles: exact multi-select kernels in select.hip (xh_select_columns).
 
 // af from ref_q / hist_q  (get_correction)
 __global__ void __launch_bounds__(XH_BLOCK)
@@ -165,47 +89,16 @@ k_eqm_adjust(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, co
   }
 }
 
-static int next_pow2_i(int64_t n) {
-  int p = 1;
-  while (p < n) p <<= 1;
-  return p;
-}
-
-// quantiles of all columns of a time-minor view
-static int colsort_launch(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride,
-                          const double* d_q, int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
-  int NP = next_pow2_i(T);
-  if (NP < 64) NP = 64;
-  XH_REQUIRE(NP <= 32768, XH_ERR_LIMIT, "quantile_series: T = %lld exceeds the 32768-sample LDS column limit", (long long)T);
-  bool wave_cols = NP <= 4096;
-  size_t lds = (size_t)NP * sizeof(uint32_t) * (wave_cols ? 4 : 1);
-  int64_t nblk = wave_cols ? cdiv64(ncols, 4) : ncols;
-  int64_t maxblk = (int64_t)ctx->num_cu * 8;
-  if (nblk > maxblk) nblk = maxblk;
-  if (wave_cols) {
-    if (lds > 64 * 1024)
-      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_colsort_quantile<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
-    hipLaunchKernelGGL((k_colsort_quantile<true>), dim3((unsigned)nblk), dim3(XH_BLOCK), lds, ctx->stream, xcols, T, ncols,
-                       col_stride, NP, d_q, nq, out, out_cstride, out_qstride);
-  } else {
-    if (lds > 64 * 1024)
-      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_colsort_quantile<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
-    hipLaunchKernelGGL((k_colsort_quantile<false>), dim3((unsigned)nblk), dim3(XH_BLOCK), lds, ctx->stream, xcols, T,
-                       ncols, col_stride, NP, d_q, nq, out, out_cstride, out_qstride);
-  }
-  XH_LAUNCH_CHECK();
-  return XH_OK;
-}
-
 static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
                                 const double* d_q, int nq, float* out) {
   if (st == 1 && sc >= T) {
-    return colsort_launch(ctx, x, T, C, sc, d_q, nq, out, 1, C);
+    return xh_select_columns(ctx, x, T, C, sc, d_q, nq, out, 1, C);
   }
   XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "quantile_series: one of the strides must be 1 (st=%lld sc=%lld)",
              (long long)st, (long long)sc);
+  // short series: 8-lane groups read the time-major rows directly (no transpose)
+  int rc0 = xh_select_time_major(ctx, x, T, C, st, d_q, nq, out, 1, C);
+  if (rc0 != XH_ERR_NOTIMPL) return rc0;
   // time-major: transpose batches of columns into scratch (not counted as algorithmic bytes)
   int64_t batch = (int64_t)((1ull << 30) / (sizeof(float) * (size_t)T));
   batch = (batch / 64) * 64;
@@ -218,7 +111,7 @@ static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t 
     int64_t nb = C - c0 < batch ? C - c0 : batch;
     rc = xh_transpose_f32(ctx, x + c0, T, nb, st, (float*)tmp, T);
     if (rc) return rc;
-    rc = colsort_launch(ctx, (const float*)tmp, T, nb, T, d_q, nq, out + c0, 1, C);
+    rc = xh_select_columns(ctx, (const float*)tmp, T, nb, T, d_q, nq, out + c0, 1, C);
     if (rc) return rc;
   }
   return XH_OK;
@@ -279,7 +172,11 @@ int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
 #define XH_ADJ(NQM, IP)                                                                                              \
   hipLaunchKernelGGL((k_eqm_adjust<NQM, IP>), grid, dim3(XH_BLOCK), 0, ctx->stream, sim, T, C, st, af, hist_q, nq, kind, \
                      extrap, scen, scen_st)
-  if (nq <= 32) {
+  if (nq <= 10) {
+    if (interp == 0) XH_ADJ(10, 0); else XH_ADJ(10, 1);
+  } else if (nq <= 20) {
+    if (interp == 0) XH_ADJ(20, 0); else XH_ADJ(20, 1);
+  } else if (nq <= 32) {
     if (interp == 0) XH_ADJ(32, 0); else XH_ADJ(32, 1);
   } else {
     if (interp == 0) XH_ADJ(64, 0); else XH_ADJ(64, 1);

@@ -94,16 +94,157 @@ k_pdoy_reg(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const 
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       bitonic_regs<NMAX>(key[v]);
-      auto get = [&](int idx) -> float {
-        uint32_t r = key[v][0];
+      auto get = [&](int idx) -> float {  // OR of masked values: keeps the array in registers (see k_pdoy_slide)
+        uint32_t r = 0;
 #pragma unroll
-        for (int i = 1; i < NMAX; ++i) r = (i == idx) ? key[v][i] : r;
+        for (int i = 0; i < NMAX; ++i) r |= (i == idx) ? key[v][i] : 0u;
         return xh_key2f(r);
       };
       for (int j = 0; j < nper; ++j) {
         double r = xh_hf_quantile(N, nvalid[v], qs[j], alpha, beta, get);
         out[((int64_t)j * ndoy + d) * C + c + v] = r;
       }
+    }
+  }
+}
+
+// ---- sliding-window path (one contiguous year: the 365 x 1440 x 720 benchmark shape) -----------------
+// With a single year of contiguous days the sample set of doy d+1 is the set of doy d shifted by one row, so a
+// lane keeps the W keys of its VEC cells in registers, loads ONE new row per doy and re-sorts a copy: x is read
+// once from HBM (plus a (W-1)-row halo per doy chunk), the (D, C) fp64 result is written once.
+// The Hyndman-Fan index arithmetic depends only on (percentile, valid count n): the host evaluates it in fp64
+// exactly as utl:395/417-461 do and ships a tiny table (lo, hi, gamma) per (j, n), staged in LDS.
+struct QTab {
+  int lo, hi;     // sorted slots to combine; lo < 0 -> NaN (no valid sample)
+  double gamma;   // interpolation weight (0 when lo == hi)
+};
+
+__device__ __forceinline__ void ce(uint32_t& a, uint32_t& b) {
+  uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo;
+  b = hi;
+}
+
+template <int W>
+__device__ __forceinline__ void sort_small(uint32_t (&k)[W]) {
+  if (W == 1) return;
+  if (W == 2) { ce(k[0], k[1 % W]); return; }
+  if (W == 3) { ce(k[0], k[1 % W]); ce(k[1 % W], k[2 % W]); ce(k[0], k[1 % W]); return; }
+  if (W == 5) {  // optimal 9-comparator network
+    ce(k[0], k[1 % W]); ce(k[3 % W], k[4 % W]); ce(k[2 % W], k[4 % W]); ce(k[2 % W], k[3 % W]); ce(k[0], k[3 % W]);
+    ce(k[0], k[2 % W]); ce(k[1 % W], k[4 % W]); ce(k[1 % W], k[3 % W]); ce(k[1 % W], k[2 % W]);
+    return;
+  }
+  // generic: odd-even transposition (W rounds), fine for the small windows this path accepts
+#pragma unroll
+  for (int r = 0; r < W; ++r) {
+#pragma unroll
+    for (int i = (r & 1); i + 1 < W; i += 2) ce(k[i], k[i + 1]);
+  }
+}
+
+template <int W, int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_pdoy_slide(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int64_t t_first, int ndoy, int chunk,
+             const QTab* __restrict__ qtab, int nper, double* __restrict__ out) {
+  __shared__ QTab s_tab[8 * (W + 1)];
+  for (int i = threadIdx.x; i < nper * (W + 1); i += XH_BLOCK) s_tab[i] = qtab[i];
+  __syncthreads();
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int half = W / 2;
+  int d0 = blockIdx.y * chunk, d1 = d0 + chunk;
+  if (d1 > ndoy) d1 = ndoy;
+  uint32_t win[VEC][W];
+  auto loadrow = [&](int64_t t, int slot) {
+    if (t >= 0 && t < T) {
+      VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) win[v][slot] = xh_f2key(xv.v[v]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) win[v][slot] = 0xFFFFFFFFu;
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < W - 1; ++k) loadrow(t_first + d0 - half + k, k + 1);
+#pragma unroll 2
+  for (int d = d0; d < d1; ++d) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+      for (int k = 0; k < W - 1; ++k) win[v][k] = win[v][k + 1];
+    }
+    loadrow(t_first + d - half + (W - 1), W - 1);
+    uint32_t s[VEC][W];
+    int n[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      n[v] = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        s[v][k] = win[v][k];
+        n[v] += (s[v][k] != 0xFFFFFFFFu) ? 1 : 0;
+      }
+      sort_small<W>(s[v]);
+    }
+    for (int j = 0; j < nper; ++j) {
+      double r[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        // register-array select written as an OR of masked values: a select chain gets folded back into a
+        // dynamically indexed (scratch) array by the optimizer
+        auto get = [&](int idx) -> float {
+          uint32_t g = 0;
+#pragma unroll
+          for (int i = 0; i < W; ++i) g |= (i == idx) ? s[v][i] : 0u;
+          return xh_key2f(g);
+        };
+        QTab e = s_tab[j * (W + 1) + n[v]];
+        float left = get(e.lo), right = get(e.hi);
+        float diff = right - left;
+        double rr = (double)left + (double)diff * e.gamma;
+        if (e.gamma >= 0.5) rr = (double)right - (double)diff * (1.0 - e.gamma);
+        if (rr != rr && n[v] > 0 && W > 1) rr = (double)get(n[v] - 1);
+        r[v] = (e.lo < 0) ? xh_nan64() : rr;
+      }
+      double* op = out + ((int64_t)j * ndoy + d) * C + c;
+      if (VEC == 4) {
+        *reinterpret_cast<double2*>(op) = make_double2(r[0], r[1 % VEC]);
+        *reinterpret_cast<double2*>(op + 2) = make_double2(r[2 % VEC], r[3 % VEC]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) op[v] = r[v];
+      }
+    }
+  }
+}
+
+// Host side of the table: one entry per (percentile j, valid count n), mirroring xh_hf_quantile.
+static void build_qtab(int L, const double* qs, int nper, double alpha, double beta, QTab* tab) {
+  for (int j = 0; j < nper; ++j) {
+    for (int n = 0; n <= L; ++n) {
+      QTab e;
+      e.gamma = 0.0;
+      if (L == 1) { e.lo = e.hi = 0; }
+      else if (n < 2) { e.lo = e.hi = (n == 1 ? 0 : -1); }
+      else {
+        double nn = (double)n, q = qs[j];
+        volatile double a = nn * q;
+        volatile double b = q * (1.0 - alpha - beta);
+        volatile double cc = alpha + b;
+        volatile double s = a + cc;
+        double vi = s - 1.0;
+        if (vi >= nn - 1.0) { e.lo = e.hi = n - 1; }
+        else if (vi < 0.0) { e.lo = e.hi = 0; }
+        else {
+          double prev = __builtin_floor(vi);
+          e.lo = (int)prev;
+          e.hi = e.lo + 1;
+          e.gamma = vi - prev;
+        }
+      }
+      tab[j * (L + 1) + n] = e;
     }
   }
 }
@@ -259,6 +400,31 @@ int xh_percentile_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t
   for (int j = 0; j < nper; ++j) qh[j] = per[j] / 100.0;  // utl:366
   size_t cur = 0;
   void *d_tb = nullptr, *d_q = nullptr;
+  // fast path: one year of contiguous days -> sliding register window
+  bool contiguous = nyears == 1 && nper <= 8 && (window == 3 || window == 5 || window == 7) && tbase[0] >= 0;
+  for (int d = 1; contiguous && d < ndoy; ++d) contiguous = tbase[d] == tbase[0] + d;
+  if (contiguous) {
+    QTab tab[8 * 8];
+    build_qtab(window, qh, nper, alpha, beta, tab);
+    void* d_tab = nullptr;
+    int rc = xh_scratch_upload(ctx, &cur, tab, sizeof(QTab) * (size_t)nper * (window + 1), &d_tab);
+    if (rc) return rc;
+    const int chunk = 32;
+    int vec = xh_pick_vec(x, C, st);
+    if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) vec = 1;
+    dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), (unsigned)((ndoy + chunk - 1) / chunk));
+#define XH_SLIDE(W, V)                                                                                              \
+  hipLaunchKernelGGL((k_pdoy_slide<W, V>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, (int64_t)tbase[0], ndoy, \
+                     chunk, (const QTab*)d_tab, nper, out)
+    if (vec == 4) {
+      if (window == 3) XH_SLIDE(3, 4); else if (window == 5) XH_SLIDE(5, 4); else XH_SLIDE(7, 4);
+    } else {
+      if (window == 3) XH_SLIDE(3, 1); else if (window == 5) XH_SLIDE(5, 1); else XH_SLIDE(7, 1);
+    }
+#undef XH_SLIDE
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+  }
   int rc = xh_scratch_upload(ctx, &cur, tbase, sizeof(int32_t) * (size_t)nyears * ndoy, &d_tb);
   if (rc) return rc;
   rc = xh_scratch_upload(ctx, &cur, qh, sizeof(double) * nper, &d_q);

@@ -21,9 +21,7 @@ k_threshold_count(const float* __restrict__ x, int64_t C, int64_t st, int op, fl
     int cnt[VEC], val[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) cnt[i] = 0, val[i] = 0;
-#pragma unroll 4
-    for (int64_t t = t0; t < t1; ++t) {
-      VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
+    xh_march_rows<VEC, 8>(x + c, st, t0, t1, [&](int64_t t, const VecF<VEC>& xv) {
       if (KIND == XH_THR_SCALAR_F32) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) cnt[i] += xh_cmp_f32(xv.v[i], op, thr32) ? 1 : 0;
@@ -52,7 +50,7 @@ k_threshold_count(const float* __restrict__ x, int64_t C, int64_t st, int op, fl
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) val[i] += (xv.v[i] == xv.v[i]) ? 1 : 0;
-    }
+    });
     int64_t o = (int64_t)p * C + c;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) count_out[o + i] = cnt[i];
@@ -103,16 +101,14 @@ k_domain_count(const float* __restrict__ x, int64_t C, int64_t st, int op1, floa
     int cnt[VEC], val[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) cnt[i] = 0, val[i] = 0;
-#pragma unroll 4
-    for (int64_t t = t0; t < t1; ++t) {
-      VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
+    xh_march_rows<VEC, 8>(x + c, st, t0, t1, [&](int64_t, const VecF<VEC>& xv) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         bool a = xh_cmp_f32(xv.v[i], op1, thr1), b = xh_cmp_f32(xv.v[i], op2, thr2);
         cnt[i] += ((combine == 1) ? (a && b) : (a || b)) ? 1 : 0;
         val[i] += (xv.v[i] == xv.v[i]) ? 1 : 0;
       }
-    }
+    });
     int64_t o = (int64_t)p * C + c;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) count_out[o + i] = cnt[i];
@@ -167,9 +163,7 @@ k_resample_reduce(const float* __restrict__ x, int64_t C, int64_t st, int skipna
         }
       }
     } else {
-#pragma unroll 4
-      for (int64_t t = t0; t < t1; ++t) {
-        VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
+      xh_march_rows<VEC, 8>(x + c, st, t0, t1, [&](int64_t t, const VecF<VEC>& xv) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           float v = xv.v[i];
@@ -188,7 +182,7 @@ k_resample_reduce(const float* __restrict__ x, int64_t C, int64_t st, int skipna
             nanseen[i] = 1;
           }
         }
-      }
+      });
     }
     int64_t o = (int64_t)p * C + c;
     int len = (int)(t1 - t0);

@@ -16,18 +16,26 @@
 
 struct RunAcc {
   int mx, mn, sum, cnt;
-  double sumsq;
+  unsigned long long sumsq;  // exact: sum of squared run lengths <= T^2
 };
 
 __device__ __forceinline__ void acc_reset(RunAcc& a) {
-  a.mx = 0; a.mn = 0x7FFFFFFF; a.sum = 0; a.cnt = 0; a.sumsq = 0.0;
+  a.mx = 0; a.mn = 0x7FFFFFFF; a.sum = 0; a.cnt = 0; a.sumsq = 0ull;
 }
 __device__ __forceinline__ void acc_add(RunAcc& a, int len) {
   a.mx = len > a.mx ? len : a.mx;
   a.mn = len < a.mn ? len : a.mn;
   a.sum += len;
   a.cnt += 1;
-  a.sumsq += (double)len * (double)len;
+  a.sumsq += (unsigned long long)((unsigned)len) * (unsigned)len;
+}
+// predicated form: len == 0 means "no run finished here"
+__device__ __forceinline__ void acc_add_if(RunAcc& a, int len) {
+  a.mx = len > a.mx ? len : a.mx;
+  a.mn = (len > 0 && len < a.mn) ? len : a.mn;
+  a.sum += len;
+  a.cnt += len > 0 ? 1 : 0;
+  a.sumsq += (unsigned long long)((unsigned)len) * (unsigned)len;
 }
 __device__ __forceinline__ float acc_result(const RunAcc& a, int stat, int plainsum) {
   if (stat == XH_RUN_PLAINSUM) return (float)plainsum;
@@ -40,7 +48,7 @@ __device__ __forceinline__ float acc_result(const RunAcc& a, int stat, int plain
     case XH_RUN_MEAN: return (float)((double)a.sum / (double)a.cnt);
     default: {  // population std (ddof = 0), tests/test_run_length.py:255-256
       double m = (double)a.sum / (double)a.cnt;
-      double v = a.sumsq / (double)a.cnt - m * m;
+      double v = (double)a.sumsq / (double)a.cnt - m * m;
       return (float)sqrt(v > 0.0 ? v : 0.0);
     }
   }
@@ -75,9 +83,7 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
         s[i].run = 0; s[i].vis = true; s[i].prevnan = false; s[i].startp = 0;
         nvalid[i] = 0; plainsum[i] = 0;
       }
-#pragma unroll 4
-      for (int64_t t = t0; t < t1; ++t) {
-        VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
+      xh_march_rows<VEC, 8>(x + c, st, t0, t1, [&](int64_t, const VecF<VEC>& xv) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           float v = xv.v[i];
@@ -86,17 +92,16 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
           bool masknan = (!fused) && isn;
           nvalid[i] += isn ? 0 : 1;
           plainsum[i] += on ? 1 : 0;
-          if (on) {
-            if (s[i].run == 0) s[i].vis = !s[i].prevnan;
-            s[i].run++;
-          } else if (s[i].run > 0) {
-            bool visible = index_first ? s[i].vis : !masknan;
-            if (visible && s[i].run >= window) acc_add(acc[i], s[i].run);
-            s[i].run = 0;
-          }
+          // branch-free state machine (the serial march is VALU-issue bound otherwise)
+          bool visible = index_first ? s[i].vis : !masknan;
+          bool ended = !on && s[i].run > 0;
+          int len = (ended && visible && s[i].run >= window) ? s[i].run : 0;
+          acc_add_if(acc[i], len);
+          s[i].vis = (on && s[i].run == 0) ? !s[i].prevnan : s[i].vis;
+          s[i].run = on ? s[i].run + 1 : 0;
           s[i].prevnan = masknan;
         }
-      }
+      });
       int64_t o = (int64_t)p * C + c;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -188,6 +193,38 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
         if (valid_out) valid_out[(int64_t)p * C + c + i] = (p == pt) ? nvalid[i] : 0;
         if (stat == XH_RUN_PLAINSUM) out[(int64_t)p * C + c + i] = (p == pt) ? (float)plainsum[i] : 0.0f;
       }
+    }
+  }
+}
+
+// Fast path of maximum_consecutive_{dry,wet}_days & friends (gen:543-585 with window == 1, reducer "max", resample
+// before run length): the mask comes from a compare, so it has no NaN and every run is visible; the longest run is
+// max over t of the running length, no run-end bookkeeping at all.  ~6 VALU ops per cell-step -> HBM bound.
+template <int VEC, int OP>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_run_max_fused(const float* __restrict__ x, int64_t C, int64_t st, float thr, int window,
+                const int64_t* __restrict__ seg_off, int P, float* __restrict__ out, int32_t* __restrict__ valid_out) {
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    int run[VEC], mx[VEC], nvalid[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) run[i] = 0, mx[i] = 0, nvalid[i] = 0;
+    xh_march_rows<VEC, 8>(x + c, st, t0, t1, [&](int64_t, const VecF<VEC>& xv) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float v = xv.v[i];
+        run[i] = xh_cmp_t<OP>(v, thr) ? run[i] + 1 : 0;
+        mx[i] = run[i] > mx[i] ? run[i] : mx[i];
+        nvalid[i] += (v == v) ? 1 : 0;
+      }
+    });
+    int64_t o = (int64_t)p * C + c;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      out[o + i] = mx[i] >= window ? (float)mx[i] : 0.0f;
+      if (valid_out) valid_out[o + i] = nvalid[i];
     }
   }
 }
@@ -369,6 +406,24 @@ int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, 
     return XH_OK;
   }
   int vec = xh_pick_vec(x, C, st);
+  if (cut_at_segments && fused_op >= 0 && stat == XH_RUN_MAX) {
+    dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), py);
+#define XH_RMF(V, O)                                                                                                   \
+  case O:                                                                                                              \
+    hipLaunchKernelGGL((k_run_max_fused<V, O>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, (float)thr, window, d_seg, \
+                       P, out, valid_out);                                                                             \
+    break;
+    if (vec == 4) {
+      switch (fused_op) { XH_RMF(4, XH_OP_GT) XH_RMF(4, XH_OP_LT) XH_RMF(4, XH_OP_GE) XH_RMF(4, XH_OP_LE) XH_RMF(4, XH_OP_EQ)
+        XH_RMF(4, XH_OP_NE) }
+    } else {
+      switch (fused_op) { XH_RMF(1, XH_OP_GT) XH_RMF(1, XH_OP_LT) XH_RMF(1, XH_OP_GE) XH_RMF(1, XH_OP_LE) XH_RMF(1, XH_OP_EQ)
+        XH_RMF(1, XH_OP_NE) }
+    }
+#undef XH_RMF
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+  }
   if (cut_at_segments) {
     dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), py);
     if (vec == 4)

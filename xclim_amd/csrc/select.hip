@@ -1,0 +1,508 @@
+// select.hip — exact multi-quantile selection per column (xsdba nbutils.quantile; E1 of SURVEY.md §8a).
+//
+// A full sort is ~30x more work than the 2*nq order statistics need.  Per column (one wave for T <= 2048, one
+// workgroup above) the samples are held in registers as order-preserving uint32 keys and go through ONE counting
+// pass of an MSD radix sort over the key range [kmin, kmax]:
+//   1. histogram of NB linear-in-key bins in LDS (ds atomics), exclusive scan -> bin offsets;
+//   2. scatter keys to their bin's slot range (grouped by bin, unordered inside a bin);
+//   3. each target rank (prev/next of every quantile) finds its bin by binary search in the offsets and selects
+//      exactly inside the bin (typically 1-3 keys; all-equal bins — e.g. dry days — short-circuit).
+// Binning uses integer arithmetic on the keys, hence is monotone and exact; duplicates and NaNs (excluded, counted)
+// are handled.  ~20 VALU ops + 2 LDS atomics per sample instead of ~200+ for a bitonic network.
+#include <stdlib.h>
+
+#include "common.h"
+
+template <int NT>
+__device__ __forceinline__ void group_sync() {
+  __syncthreads();
+}
+
+// inclusive scan of one value per thread over a group of NT threads (NT multiple of 64); tmp: NT/64 uints in LDS
+template <int NT>
+__device__ __forceinline__ uint32_t group_incl_scan(uint32_t v, int tid_in_group, uint32_t* tmp) {
+  const int lane = tid_in_group & 63, w = tid_in_group >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t o = __shfl_up(v, off, 64);
+    if (lane >= off) v += o;
+  }
+  if (NT > 64) {
+    if (lane == 63) tmp[w] = v;
+    __syncthreads();
+    uint32_t add = 0;
+    for (int i = 0; i < w; ++i) add += tmp[i];
+    v += add;
+    __syncthreads();
+  }
+  return v;
+}
+
+template <int NT>
+__device__ __forceinline__ uint32_t group_reduce_min(uint32_t v, int tid_in_group, uint32_t* tmp) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    uint32_t o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  if (NT > 64) {
+    const int lane = tid_in_group & 63, w = tid_in_group >> 6;
+    if (lane == 0) tmp[w] = v;
+    __syncthreads();
+    v = tmp[0];
+    for (int i = 1; i < NT / 64; ++i) v = tmp[i] < v ? tmp[i] : v;
+    __syncthreads();
+  }
+  return v;
+}
+template <int NT>
+__device__ __forceinline__ uint32_t group_reduce_max(uint32_t v, int tid_in_group, uint32_t* tmp) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    uint32_t o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  if (NT > 64) {
+    const int lane = tid_in_group & 63, w = tid_in_group >> 6;
+    if (lane == 0) tmp[w] = v;
+    __syncthreads();
+    v = tmp[0];
+    for (int i = 1; i < NT / 64; ++i) v = tmp[i] > v ? tmp[i] : v;
+    __syncthreads();
+  }
+  return v;
+}
+template <int NT>
+__device__ __forceinline__ uint32_t group_reduce_sum(uint32_t v, int tid_in_group, uint32_t* tmp) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (NT > 64) {
+    const int lane = tid_in_group & 63, w = tid_in_group >> 6;
+    if (lane == 0) tmp[w] = v;
+    __syncthreads();
+    v = 0;
+    for (int i = 0; i < NT / 64; ++i) v += tmp[i];
+    __syncthreads();
+  }
+  return v;
+}
+
+// NT threads per column, KPL keys per thread (T <= NT*KPL), NB bins (multiple of NT), GROUPS columns per block.
+// LDS layout per group: sorted[Tpad] | offs[NB+1] | cursor[NB] | vals[2*64] | tmp[16]
+template <int NT, int KPL, int NB>
+__global__ void __launch_bounds__(NT <= 256 ? 256 : NT)
+k_select_quantile(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col_stride, const double* __restrict__ qs,
+                  int nq, float* __restrict__ out, int64_t out_cstride, int64_t out_qstride) {
+  extern __shared__ uint32_t lds[];
+  constexpr int BLOCK = NT <= 256 ? 256 : NT;
+  constexpr int GROUPS = BLOCK / NT;
+  constexpr int BPT = NB / NT;  // bins per thread in the scan
+  const int tid = threadIdx.x;
+  const int g = tid / NT, gt = tid % NT;
+  const int Tpad = (int)((T + 63) & ~(int64_t)63);
+  const int per_group = Tpad + (NB + 1) + NB + 128 + 16;
+  uint32_t* sorted = lds + (size_t)g * per_group;
+  uint32_t* offs = sorted + Tpad;
+  uint32_t* cursor = offs + NB + 1;
+  float* vals = reinterpret_cast<float*>(cursor + NB);
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(vals + 128);
+
+  for (int64_t cb = (int64_t)blockIdx.x * GROUPS; cb < ncols; cb += (int64_t)gridDim.x * GROUPS) {
+    const int64_t col = cb + g;
+    const bool have = col < ncols;
+    // ---- load keys into registers
+    uint32_t key[KPL];
+    uint32_t nv = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+      int i = gt + k * NT;
+      uint32_t kk = 0xFFFFFFFFu;
+      if (have && i < T) kk = xh_f2key(x[col * col_stride + i]);
+      key[k] = kk;
+      if (kk != 0xFFFFFFFFu) {
+        nv++;
+        kmin = kk < kmin ? kk : kmin;
+        kmax = kk > kmax ? kk : kmax;
+      }
+    }
+    const uint32_t n = group_reduce_sum<NT>(nv, gt, tmp);
+    kmin = group_reduce_min<NT>(kmin, gt, tmp);
+    kmax = group_reduce_max<NT>(kmax, gt, tmp);
+    const uint32_t range = (n > 0) ? (kmax - kmin) : 0u;
+    int shift = 0;
+    while ((range >> shift) >= (uint32_t)NB) shift++;
+    // ---- histogram
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) offs[gt + b * NT] = 0;
+    group_sync<NT>();
+#pragma unroll
+    for (int k = 0; k < KPL; ++k)
+      if (key[k] != 0xFFFFFFFFu) atomicAdd(&offs[(key[k] - kmin) >> shift], 1u);
+    group_sync<NT>();
+    // ---- exclusive scan of NB bins: thread owns BPT consecutive bins
+    {
+      uint32_t loc[BPT], s = 0;
+#pragma unroll
+      for (int b = 0; b < BPT; ++b) { loc[b] = offs[gt * BPT + b]; s += loc[b]; }
+      uint32_t incl = group_incl_scan<NT>(s, gt, tmp);
+      uint32_t run = incl - s;
+      group_sync<NT>();
+#pragma unroll
+      for (int b = 0; b < BPT; ++b) {
+        offs[gt * BPT + b] = run;
+        cursor[gt * BPT + b] = run;
+        run += loc[b];
+      }
+      if (gt == NT - 1) offs[NB] = run;
+    }
+    group_sync<NT>();
+    // ---- scatter (grouped by bin)
+#pragma unroll
+    for (int k = 0; k < KPL; ++k)
+      if (key[k] != 0xFFFFFFFFu) {
+        uint32_t pos = atomicAdd(&cursor[(key[k] - kmin) >> shift], 1u);
+        sorted[pos] = key[k];
+      }
+    group_sync<NT>();
+    // ---- targets: 2 per quantile (prev, next); thread tgt handles target tgt
+    for (int tgt = gt; tgt < 2 * nq; tgt += NT) {
+      const int j = tgt >> 1;
+      float v = xh_nan32();
+      if (n >= 1) {
+        int r;
+        if (T == 1 || n < 2) r = 0;
+        else {
+          double nn = (double)n, q = qs[j];
+          double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;  // utl:395 with alpha = beta = 1
+          if (vi >= nn - 1.0) r = (int)n - 1;
+          else if (vi < 0.0) r = 0;
+          else r = (int)floor(vi) + (tgt & 1);
+        }
+        // bin containing rank r: largest b with offs[b] <= r  (offs non-decreasing, offs[NB] = n)
+        int lo = 0, hi = NB;  // invariant: offs[lo] <= r < offs[hi]
+        while (hi - lo > 1) {
+          int mid = (lo + hi) >> 1;
+          if (offs[mid] <= (uint32_t)r) lo = mid; else hi = mid;
+        }
+        const uint32_t s0 = offs[lo], s1 = offs[lo + 1];
+        const uint32_t kth = (uint32_t)r - s0;
+        uint32_t ans = sorted[s0];
+        if (s1 - s0 > 1) {
+          // exact selection inside the bin: candidate e is the answer iff #(k < e) <= kth < #(k <= e)
+          for (uint32_t a = s0; a < s1; ++a) {
+            uint32_t e = sorted[a], less = 0, leq = 0;
+            for (uint32_t b2 = s0; b2 < s1; ++b2) {
+              uint32_t kk = sorted[b2];
+              less += kk < e ? 1u : 0u;
+              leq += kk <= e ? 1u : 0u;
+            }
+            if (less <= kth && kth < leq) { ans = e; break; }
+            if (less == 0 && leq == s1 - s0) { ans = e; break; }  // all keys of the bin are equal
+          }
+        }
+        v = xh_key2f(ans);
+      }
+      vals[tgt] = v;
+    }
+    group_sync<NT>();
+    for (int j = gt; j < nq; j += NT) {
+      if (have) {
+        double r;
+        if (n == 0) r = xh_nan64();
+        else if (T == 1 || n < 2) r = (double)vals[2 * j];
+        else {
+          double nn = (double)n, q = qs[j];
+          double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;
+          float left = vals[2 * j], right = vals[2 * j + 1];
+          if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
+          else {
+            double gamma = vi - floor(vi);
+            float diff = right - left;
+            r = (double)left + (double)diff * gamma;
+            if (gamma >= 0.5) r = (double)right - (double)diff * (1.0 - gamma);
+          }
+        }
+        out[col * out_cstride + (int64_t)j * out_qstride] = (float)r;
+      }
+    }
+    group_sync<NT>();
+  }
+}
+
+// ---- short series (T <= 512): G lanes per column, 64/G columns per wave, 256/G columns per workgroup ----------
+// With one wave per column the per-column fixed costs (reductions, scan, target search on a few lanes) dominate
+// for T ~ 365; sharing every wave instruction between 64/G columns cuts the issued instructions per column.
+// TIME_MAJOR reads x[t * stride + col] directly: a workgroup covers 256/G adjacent cells per row (64..128 bytes),
+// so no transpose pass is needed for the common (time, lat, lon) layout.
+// Columns never span waves here (G <= 64), so phases only need wave-level ordering of the LDS traffic: the LDS
+// executes one wave's instructions in issue order; this fence just stops the compiler from reordering across it.
+__device__ __forceinline__ void wave_sync() {
+  // compiler-only barrier: no s_waitcnt vmcnt(0) (a fence would drain the prefetched global loads of the next
+  // column at every phase boundary); cross-lane visibility inside one wave comes from the in-order LDS pipeline
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int G, int KPL, int NB, bool TIME_MAJOR>
+__global__ void __launch_bounds__(256)
+k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stride, const double* __restrict__ qs, int nq,
+             float* __restrict__ out, int64_t out_cstride, int64_t out_qstride, int abl) {
+  constexpr int COLS = 256 / G;             // columns per workgroup
+  constexpr int BPL = NB / G;               // bins per lane in the scan
+  // LDS words per column: cur | sorted | vals, padded so that PER % 32 == G: the 64/G columns that share a wave
+  // then sit on disjoint LDS banks for the lane-structured accesses
+  constexpr int PER0 = NB + G * KPL + 128;
+  constexpr int PER = PER0 + ((G % 32) - (PER0 % 32) + 32) % 32;
+  __shared__ uint32_t lds[COLS * PER];
+  const int tid = threadIdx.x;
+  const int l = tid & (G - 1), g = tid / G;
+  uint32_t* cur = lds + g * PER;
+  uint32_t* sorted = cur + NB;
+  float* vals = reinterpret_cast<float*>(sorted + G * KPL);
+
+  // software pipeline: the raw samples of the NEXT column are in flight while the current one is processed
+  float raw[KPL];
+  auto issue_loads = [&](int64_t cb) {
+    const int64_t col = cb + g;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+      int t = l + k * G;
+      raw[k] = xh_nan32();
+      if (col < ncols && t < T) raw[k] = TIME_MAJOR ? x[(int64_t)t * stride + col] : x[col * stride + t];
+    }
+  };
+  const int64_t cstep = (int64_t)gridDim.x * COLS;
+  int64_t cb = (int64_t)blockIdx.x * COLS;
+  if (cb < ncols) issue_loads(cb);
+  for (; cb < ncols; cb += cstep) {
+    const int64_t col = cb + g;
+    const bool have = col < ncols;
+    uint32_t key[KPL];
+    uint32_t nv = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+      uint32_t kk = xh_f2key(raw[k]);
+      key[k] = kk;
+      bool ok = kk != 0xFFFFFFFFu;
+      nv += ok ? 1u : 0u;
+      kmin = (ok && kk < kmin) ? kk : kmin;
+      kmax = (ok && kk > kmax) ? kk : kmax;
+    }
+    if (cb + cstep < ncols) issue_loads(cb + cstep);
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+      nv += __shfl_xor(nv, off, G);
+      uint32_t a = __shfl_xor(kmin, off, G), b = __shfl_xor(kmax, off, G);
+      kmin = a < kmin ? a : kmin;
+      kmax = b > kmax ? b : kmax;
+    }
+    const uint32_t n = nv;
+    const uint32_t range = n > 0 ? kmax - kmin : 0u;
+    // smallest shift with (range >> shift) < NB
+    int shift = 32 - __clz((int)range) - (31 - __clz(NB));  // bits(range) - log2(NB)
+    shift = (range == 0u || shift < 0) ? 0 : shift;
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) cur[l + b * G] = 0;
+    wave_sync();
+    if (!(abl & 1)) {
+#pragma unroll
+    for (int k = 0; k < KPL; ++k)
+      if (key[k] != 0xFFFFFFFFu) atomicAdd(&cur[(key[k] - kmin) >> shift], 1u);
+    }
+    wave_sync();
+    {
+      uint32_t loc[BPL], s = 0;
+#pragma unroll
+      for (int b = 0; b < BPL; ++b) { loc[b] = cur[l * BPL + b]; s += loc[b]; }
+      uint32_t incl = s;
+#pragma unroll
+      for (int off = 1; off < G; off <<= 1) {
+        uint32_t o = __shfl_up(incl, off, G);
+        if (l >= off) incl += o;
+      }
+      uint32_t run = incl - s;
+      wave_sync();
+#pragma unroll
+      for (int b = 0; b < BPL; ++b) { cur[l * BPL + b] = run; run += loc[b]; }
+    }
+    wave_sync();
+    if (!(abl & 2)) {
+      // scatter, atomics issued in batches of 8 so that their latencies overlap
+#pragma unroll
+      for (int k0 = 0; k0 < KPL; k0 += 8) {
+        uint32_t pos[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k0 + k < KPL) pos[k] = (key[k0 + k] != 0xFFFFFFFFu) ? atomicAdd(&cur[(key[k0 + k] - kmin) >> shift], 1u) : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k0 + k < KPL && key[k0 + k] != 0xFFFFFFFFu) sorted[pos[k]] = key[k0 + k];
+      }
+    }
+    wave_sync();
+    // after the scatter cur[b] is the END of bin b (== start of bin b+1)
+    for (int tgt = l; tgt < 2 * nq && !(abl & 4); tgt += G) {
+      const int j = tgt >> 1;
+      float v = xh_nan32();
+      if (n >= 1) {
+        int r;
+        if (T == 1 || n < 2) r = 0;
+        else {
+          double nn = (double)n, q = qs[j];
+          double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;  // utl:395 with alpha = beta = 1
+          if (vi >= nn - 1.0) r = (int)n - 1;
+          else if (vi < 0.0) r = 0;
+          else r = (int)floor(vi) + (tgt & 1);
+        }
+        // first bin whose end exceeds r
+        int lo = -1, hi = NB - 1;  // invariant: end[lo] <= r < end[hi]   (end[-1] = 0, end[NB-1] = n)
+        while (hi - lo > 1) {
+          int mid = (lo + hi) >> 1;
+          if (cur[mid] <= (uint32_t)r) lo = mid; else hi = mid;
+        }
+        const uint32_t s0 = hi > 0 ? cur[hi - 1] : 0u, s1 = cur[hi];
+        const uint32_t kth = (uint32_t)r - s0, m = s1 - s0;
+        uint32_t ans;
+        if (m <= 8) {
+          // exact k-th smallest of <= 8 keys, all in registers (independent LDS loads, no dependent chain)
+          uint32_t kk[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) kk[i] = (uint32_t)i < m ? sorted[s0 + i] : 0xFFFFFFFFu;
+          ans = kk[0];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            uint32_t less = 0, leq = 0;
+#pragma unroll
+            for (int i2 = 0; i2 < 8; ++i2) {
+              less += kk[i2] < kk[i] ? 1u : 0u;
+              leq += kk[i2] <= kk[i] ? 1u : 0u;
+            }
+            ans = (less <= kth && kth < leq) ? kk[i] : ans;
+          }
+        } else {
+          ans = sorted[s0];
+          for (uint32_t a = s0; a < s1; ++a) {
+            uint32_t e = sorted[a], less = 0, leq = 0;
+            for (uint32_t b2 = s0; b2 < s1; ++b2) {
+              uint32_t k2 = sorted[b2];
+              less += k2 < e ? 1u : 0u;
+              leq += k2 <= e ? 1u : 0u;
+            }
+            if (less <= kth && kth < leq) { ans = e; break; }
+            if (less == 0 && leq == m) { ans = e; break; }
+          }
+        }
+        v = xh_key2f(ans);
+      }
+      vals[tgt] = v;
+    }
+    wave_sync();
+    for (int j = l; j < nq && !(abl & 8); j += G) {
+      if (have) {
+        double r;
+        if (n == 0) r = xh_nan64();
+        else if (T == 1 || n < 2) r = (double)vals[2 * j];
+        else {
+          double nn = (double)n, q = qs[j];
+          double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;
+          float left = vals[2 * j], right = vals[2 * j + 1];
+          if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
+          else {
+            double gamma = vi - floor(vi);
+            float diff = right - left;
+            r = (double)left + (double)diff * gamma;
+            if (gamma >= 0.5) r = (double)right - (double)diff * (1.0 - gamma);
+          }
+        }
+        out[col * out_cstride + (int64_t)j * out_qstride] = (float)r;
+      }
+    }
+    wave_sync();
+  }
+}
+
+template <int G, bool TM>
+static int launch_select_grp_g(xh_ctx* ctx, const float* x, int64_t T, int64_t ncols, int64_t stride, const double* d_q,
+                               int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
+  constexpr int COLS = 256 / G;
+  int64_t nblk = cdiv64(ncols, COLS);
+  int64_t maxblk = (int64_t)ctx->num_cu * 64;
+  if (nblk > maxblk) nblk = maxblk;
+  const char* ea = getenv("XH_SELECT_ABL");  // diagnostics: skip phases (results become wrong)
+  const int abl = ea ? atoi(ea) : 0;
+  if (T <= 384)
+    hipLaunchKernelGGL((k_select_grp<G, 384 / G, 256, TM>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, x, T, ncols,
+                       stride, d_q, nq, out, out_cstride, out_qstride, abl);
+  else
+    hipLaunchKernelGGL((k_select_grp<G, 512 / G, 256, TM>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, x, T, ncols,
+                       stride, d_q, nq, out, out_cstride, out_qstride, abl);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+// lanes per column for short series; XH_SELECT_G (8 | 16 | 32) overrides the tuned default for experiments
+// measured on MI355X, T = 365, 1 036 800 columns: time-major 32 lanes/column 2.2 ms (64: 4.0, 16: 2.6, 8: 6.1);
+// time-minor 64 lanes/column 1.4 ms (32: 1.44, 16: 1.8)
+static int select_group_size(bool time_major) {
+  const char* e = getenv("XH_SELECT_G");
+  int g = e ? atoi(e) : (time_major ? 32 : 64);
+  if (g != 8 && g != 16 && g != 32 && g != 64) g = time_major ? 32 : 64;
+  return g;
+}
+
+template <bool TM>
+static int launch_select_grp(xh_ctx* ctx, const float* x, int64_t T, int64_t ncols, int64_t stride, const double* d_q,
+                             int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
+  switch (select_group_size(TM)) {
+    case 8: return launch_select_grp_g<8, TM>(ctx, x, T, ncols, stride, d_q, nq, out, out_cstride, out_qstride);
+    case 32: return launch_select_grp_g<32, TM>(ctx, x, T, ncols, stride, d_q, nq, out, out_cstride, out_qstride);
+    case 64: return launch_select_grp_g<64, TM>(ctx, x, T, ncols, stride, d_q, nq, out, out_cstride, out_qstride);
+    default: return launch_select_grp_g<16, TM>(ctx, x, T, ncols, stride, d_q, nq, out, out_cstride, out_qstride);
+  }
+}
+
+// quantiles for short series straight from a time-major (T, C) view (no transpose); returns XH_ERR_NOTIMPL when
+// the shape does not fit so that the caller can fall back to the transposed path
+int xh_select_time_major(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq,
+                         float* out, int64_t out_cstride, int64_t out_qstride) {
+  if (T > 512 || nq > 64) return XH_ERR_NOTIMPL;
+  return launch_select_grp<true>(ctx, x, T, C, st, d_q, nq, out, out_cstride, out_qstride);
+}
+
+template <int NT, int KPL, int NB>
+static int launch_select(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const double* d_q,
+                         int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
+  constexpr int BLOCK = NT <= 256 ? 256 : NT;
+  constexpr int GROUPS = BLOCK / NT;
+  int Tpad = (int)((T + 63) & ~(int64_t)63);
+  size_t lds = (size_t)GROUPS * (Tpad + (NB + 1) + NB + 128 + 16) * sizeof(uint32_t);
+  XH_REQUIRE(lds <= 160 * 1024, XH_ERR_LIMIT, "quantile_series: LDS need %zu exceeds 160 KiB", lds);
+  auto kern = k_select_quantile<NT, KPL, NB>;
+  if (lds > 64 * 1024)
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int64_t nblk = cdiv64(ncols, GROUPS);
+  int64_t maxblk = (int64_t)ctx->num_cu * 16;
+  if (nblk > maxblk) nblk = maxblk;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BLOCK), lds, ctx->stream, xcols, T, ncols, col_stride, d_q, nq, out,
+                     out_cstride, out_qstride);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+// Entry used by eqm.hip: quantiles of `ncols` contiguous columns (time-minor view).
+int xh_select_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const double* d_q,
+                      int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
+  XH_REQUIRE(nq <= 64, XH_ERR_LIMIT, "quantile_series: at most 64 quantiles");
+  if (T <= 512) return launch_select_grp<false>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
+  // longer series: one workgroup per column.  The whole column lives in LDS (sorted[T]), which allows only 1-3
+  // workgroups per CU, so the workgroup is made as wide as the series allows (1024 threads = 16 waves) to keep
+  // enough waves resident to hide the LDS-atomic and HBM latencies.
+  if (T <= 1024) return launch_select<64, 16, 512>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
+  if (T <= 2048) return launch_select<256, 8, 1024>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
+  if (T <= 4096) return launch_select<512, 8, 1024>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
+  if (T <= 8192) return launch_select<1024, 8, 2048>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
+  if (T <= 16384) return launch_select<1024, 16, 4096>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
+  XH_REQUIRE(T <= 32768, XH_ERR_LIMIT, "quantile_series: T = %lld exceeds the 32768-sample column limit", (long long)T);
+  return launch_select<1024, 32, 2048>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
+}
