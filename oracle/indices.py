@@ -44,6 +44,12 @@ def tx90p(tasmax, tasmax_per, per_doys, time: OTime, freq="YS", op=">"):
     return ogen.threshold_count(tasmax, op, thresh, time, freq, constrain=(">", ">="))
 
 
+def tx10p(tasmax, tasmax_per, per_doys, time: OTime, freq="YS", op="<"):
+    """indices/_multivariate.py:1596-1650 (same as tx90p with the "<" family of operators)."""
+    thresh = ocal.resample_doy(tasmax_per, per_doys, time)
+    return ogen.threshold_count(tasmax, op, thresh, time, freq, constrain=("<", "<="))
+
+
 def maximum_consecutive_dry_days(pr, thresh, time: OTime, freq="YS", resample_before_rl=True):
     """indices/_threshold.py:2925-2937: spell_length_statistics(pr, thresh, 1, None, "<", "max", freq).
 

@@ -33,6 +33,8 @@ def nan_quantile(arr: np.ndarray, quantiles, axis: int = 0, alpha: float = 1.0, 
     if L == 1:
         return np.broadcast_to(a[0], (q.size,) + a[0].shape).copy()
     a = np.array(a, copy=True)
+    if a.ndim == 1:  # 1-D input: run the N-D code on a (L, 1) view and drop the dummy cell axis at the end
+        return nan_quantile(a[:, None], q, 0, alpha, beta)[:, 0]
     n = (L - np.isnan(a).sum(axis=0)).astype(np.float64)
     n[n < 2] = np.nan
     n = n[..., None]

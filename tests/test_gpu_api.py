@@ -1,0 +1,235 @@
+"""GPU parity at the API level: the host mirrors of the reference modules (xclim_amd.{calendar,generic,run_length,
+indices,utils,sdba}) against the oracle, plus the reference's own known answers run through the HIP path."""
+
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import calendar as ocal
+from oracle import generic as ogen
+from oracle import indices as oidx
+from oracle import quantile as oq
+from oracle import run_length as orl
+from oracle import sdba as osdba
+from oracle.timeutil import OTime
+from xclim_amd import generic as xgen
+from xclim_amd import indices as xi
+from xclim_amd import run_length as xrl
+from xclim_amd import sdba as xsdba
+from xclim_amd import utils as xutils
+from xclim_amd.calendar import percentile_doy
+from xclim_amd.timeaxis import TimeAxis
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+
+
+def _temp(rng, T, shape, nan_frac=0.0):
+    t = np.arange(T).reshape((T,) + (1,) * len(shape))
+    x = (288 + 12 * np.sin(2 * np.pi * (t - 100) / 365) + rng.normal(0, 3, (T,) + shape)).astype(np.float32)
+    if nan_frac:
+        x[rng.random(x.shape) < nan_frac] = np.nan
+    return x
+
+
+def _axes(start, T, calendar="standard"):
+    if calendar == "standard":
+        return TimeAxis.daily(start, T), OTime.standard(start, T)
+    return TimeAxis.daily(start, T, calendar), OTime.noleap(int(start[:4]), T, calendar)
+
+
+@pytest.mark.parametrize("calendar,T", [("standard", 1461), ("standard", 366), ("noleap", 1095), ("noleap", 365)])
+@pytest.mark.parametrize("per", [90.0, [10.0, 50.0]])
+def test_percentile_doy_full(dev, rng, calendar, T, per):
+    """percentile_doy including the drop-366 / re-interpolate step (cal:484-485) and its attrs."""
+    x = _temp(rng, T, (6, 5), nan_frac=0.002)
+    ta, ot = _axes("2000-01-01", T, calendar)
+    p = percentile_doy(x, ta, window=5, per=per, device=dev)
+    exp, doys = ocal.percentile_doy(x, ot, 5, per)
+    np.testing.assert_array_equal(p.dayofyear, doys)
+    np.testing.assert_allclose(p.values(), exp, rtol=1e-12, atol=0, equal_nan=True)
+    assert p.attrs["window"] == 5 and p.attrs["alpha"] == 1 / 3 and "percentile_doy" in p.attrs["history"]
+    assert p.attrs["climatology_bounds"][0] == "2000-01-01"
+
+
+@pytest.mark.parametrize("calendar,T,freq", [("standard", 1461, "YS"), ("standard", 800, "MS"), ("noleap", 1095, "QS-DEC"),
+                                             ("noleap", 365, "YS")])
+def test_tx90p_tx10p_indicator_level(dev, rng, calendar, T, freq):
+    x = _temp(rng, T, (7, 9), nan_frac=0.001)
+    ta, ot = _axes("2000-01-01", T, calendar)
+    for per, fn, ofn in ((90.0, xi.tx90p, oidx.tx90p), (10.0, xi.tx10p, oidx.tx10p)):
+        p = percentile_doy(x, ta, window=5, per=per, device=dev)
+        got = fn(x, p, ta, freq=freq, device=dev)
+        pe, doys = ocal.percentile_doy(x, ot, 5, per)
+        exp = oidx.apply_missing(ofn(x, pe[..., 0], doys, ot, freq), x, ot, freq)
+        assert got.dtype == np.float64 and got.shape == exp.shape
+        np.testing.assert_array_equal(got, exp)
+        raw = fn(x, p, ta, freq=freq, device=dev, mask_missing=False)
+        np.testing.assert_array_equal(raw, ofn(x, pe[..., 0], doys, ot, freq))
+
+
+def test_tg_mean_and_friends(dev, rng):
+    x = _temp(rng, 800, (4, 4), nan_frac=0.001)
+    ta, ot = _axes("1999-12-01", 800)
+    for freq in ("YS", "MS"):
+        got = xi.tg_mean(x, ta, freq, device=dev)
+        exp = oidx.apply_missing(oidx.tg_mean(x, ot, freq), x, ot, freq)
+        np.testing.assert_allclose(got, exp, rtol=1e-6, equal_nan=True)
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    np.testing.assert_array_equal(xi.tg_max(x, ta, "YS", device=dev, mask_missing=False),
+                                  ogen.select_resample_op(x, "max", ot, "YS"))
+
+
+@pytest.mark.parametrize("before", [True, False])
+def test_reference_cdd_known_answers(dev, before):
+    """reference tests/test_indices.py:2354-2381 through the HIP path: 10 ; 26 (resample before) vs 30 (after)."""
+    ta = TimeAxis.daily("2000-07-01", 365)
+    thr = 1.0 / 86400.0
+    a = np.zeros(365, np.float32) + 10
+    a[5:15] = 0
+    assert xi.maximum_consecutive_dry_days(a[:, None], thr, ta, "ME", before, device=dev, mask_missing=False)[0, 0] == 10
+    a = np.zeros(365, np.float32) + 10
+    a[5:35] = 0
+    out = xi.maximum_consecutive_dry_days(a[:, None], thr, ta, "ME", before, device=dev, mask_missing=False)
+    assert out[0, 0] == (26 if before else 30)
+
+
+def test_reference_txp_known_answers(dev):
+    """reference tests/test_indices.py:2529-2625: t*10p Jan 0 / Jun 5 ; t*90p (per=10) Jan 30 / Feb 29 / Jun 25."""
+    tas = np.arange(366).astype(np.float32)
+    ta = TimeAxis.daily("2000-01-01", 366)
+    t10 = percentile_doy(tas[:, None], ta, per=10.0, device=dev)
+    assert len(t10.dayofyear) == 366
+    tas[175:180] = 1
+    out = xi.tx10p(tas[:, None], t10, ta, "MS", device=dev, mask_missing=False)[:, 0]
+    assert out[0] == 0 and out[5] == 5
+    out = xi.tx90p(tas[:, None], t10, ta, "MS", device=dev, mask_missing=False)[:, 0]
+    assert out[0] == 30 and out[1] == 29 and out[5] == 25
+
+
+def test_reference_percentile_doy_known_answers(dev):
+    """reference tests/test_calendar.py:83-104."""
+    tas = np.arange(365).astype(np.float32)
+    ta = TimeAxis.daily("2001-01-01", 365)
+    p = percentile_doy(np.stack([tas, tas], 1), ta, window=5, per=50, device=dev)
+    assert p.values()[2, 0, 0] == 2
+    tas[1] = np.nan
+    p = percentile_doy(np.stack([tas, tas], 1), ta, window=5, per=50, device=dev)
+    assert p.values()[2, 0, 0] == 2.5
+
+
+def test_reference_run_length_known_answers(dev):
+    """reference tests/test_run_length.py:166-296, 356-424 through the HIP path."""
+    v = np.ones(365, np.float32)
+    v[35] = 0
+    ta = TimeAxis.daily("2000-01-01", 365)
+    m = v[:, None]
+    assert xrl.rle_statistics(m, "min", 1, freq="YS", time=ta, device=dev)[0, 0] == 35
+    assert xrl.rle_statistics(m, "mean", 36, freq="YS", time=ta, device=dev)[0, 0] == 329
+    assert xrl.rle_statistics(m, "std", 1, freq="YS", time=ta, device=dev)[0, 0] == 147
+    ta7 = TimeAxis.daily("2000-07-01", 365)
+    after = xrl.rle_statistics(m, "max", 1, freq="ME", time=ta7, device=dev)[:, 0]
+    assert after[0] == 35 and after[1] == 365 - 35 - 1
+    before = xrl.resample_and_rl(m, True, xrl.rle_statistics, "max", 1, freq="ME", time=ta7, device=dev)[:, 0]
+    assert before[0] == 31 and before[1] == 26
+    a = np.zeros((50, 1), np.float32)
+    a[4:7] = 1
+    a[34:45] = 1
+    for index in ("first", "last"):
+        assert xrl.windowed_run_events(a, 3, index=index, device=dev)[0] == 2
+        assert xrl.windowed_run_count(a, 3, index=index, device=dev)[0] == 14
+    t = np.zeros((60, 2), np.float32)
+    t[30:40] = 2
+    np.testing.assert_array_equal(xrl.first_run(t, 1, device=dev), [30, 30])
+    np.testing.assert_array_equal(xrl.last_run(t, 1, device=dev), [39, 39])
+    t[0] = 2
+    tj = TimeAxis.daily("2000-01-01", 60)
+    np.testing.assert_array_equal(xrl.first_run(t, 1, freq="MS", time=tj, device=dev), [[0, 0], [0, 0]])
+    np.testing.assert_array_equal(xrl.last_run(t, 1, freq="MS", time=tj, device=dev), [[30, 30], [8, 8]])
+    with pytest.raises(ValueError):
+        xrl.rle_statistics(m, "max", 1, freq="YS", ufunc_1dim=True, time=ta, device=dev)
+
+
+def test_run_length_mirror_vs_oracle(dev, rng):
+    T, shape = 500, (5, 6)
+    m = (rng.random((T,) + shape) < 0.6)
+    ta, ot = _axes("2001-03-01", T)
+    np.testing.assert_array_equal(xrl.rle(m, device=dev), orl.rle(m.astype(np.float32)))
+    np.testing.assert_array_equal(xrl._cumsum_reset(m, index="first", device=dev), orl.cumsum_reset(m.astype(np.float32), "first"))
+    np.testing.assert_array_equal(xrl.longest_run(m, device=dev), orl.longest_run(m))
+    np.testing.assert_array_equal(xrl.windowed_run_count(m, 1, device=dev), orl.windowed_run_count(m, 1))
+    np.testing.assert_array_equal(xrl.windowed_run_count(m, 4, freq="MS", time=ta, device=dev),
+                                  orl.windowed_run_count(m, 4, time=ot, freq="MS"))
+    np.testing.assert_array_equal(xrl.first_run(m, 3, freq="MS", time=ta, device=dev), orl.first_run(m, 3, time=ot, freq="MS"))
+
+
+def test_generic_mirror_vs_oracle(dev, rng):
+    T = 730
+    x = _temp(rng, T, (8,), nan_frac=0.01)
+    ta, ot = _axes("2000-01-01", T)
+    np.testing.assert_array_equal(xgen.threshold_count(x, ">", 290.0, ta, "MS", device=dev), ogen.threshold_count(x, ">", 290.0, ot, "MS"))
+    np.testing.assert_array_equal(xgen.threshold_count(x, ">", np.float64(290.1), ta, "MS", device=dev),
+                                  ogen.threshold_count(x, ">", np.float64(290.1), ot, "MS"))
+    full = rng.normal(289, 2, x.shape)
+    np.testing.assert_array_equal(xgen.threshold_count(x, "<", full, ta, "YS", device=dev), ogen.threshold_count(x, "<", full, ot, "YS"))
+    np.testing.assert_array_equal(xgen.domain_count(x, 285.0, 295.0, ta, "YS", device=dev),
+                                  ogen.domain_count(x, np.float32(285), np.float32(295), ot, "YS"))
+    np.testing.assert_array_equal(xgen.count_occurrences(x, 290.0, "!=", ta, "YS", device=dev), ogen.count_occurrences(x, 290.0, "!=", ot, "YS"))
+    got = xgen.select_rolling_resample_op(x, "max", 5, ta, True, "mean", "YS", device=dev)
+    np.testing.assert_allclose(got, ogen.select_rolling_resample_op(x, "max", 5, ot, True, "mean", "YS"), rtol=1e-6)
+    with pytest.raises(ValueError, match="not permitted"):
+        xgen.threshold_count(x, "==", 1.0, ta, "YS", device=dev)
+    with pytest.raises(ValueError, match="not recognized"):
+        xgen.threshold_count(x, "=>", 1.0, ta, "YS", device=dev)
+
+
+@pytest.mark.parametrize("k", range(7))
+def test_calc_perc_on_reference_golden_vectors(dev, k):
+    """The apply_ufunc callee (utl:279-323) through the HIP path against the reference's own outputs."""
+    x = GOLD[f"q_in_{k}"]
+    pers = list(GOLD["q_pers"])
+    for typ, ab in (("t7", (1.0, 1.0)), ("t8", (1 / 3, 1 / 3))):
+        got = xutils.calc_perc(x, pers, *ab, device=dev)
+        np.testing.assert_allclose(got, GOLD[f"q_{typ}_{k}"], rtol=1e-12, atol=0, equal_nan=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_allclose(xutils.calc_perc(x, pers, device=dev), oq.calc_perc(x, pers), rtol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("kind,interp", [("+", "nearest"), ("*", "linear")])
+def test_eqm_object_api(dev, rng, kind, interp):
+    T, shape = 1095, (6, 7)
+    ref = _temp(rng, T, shape)
+    hist = (_temp(rng, T, shape) * 1.01 + 1.5).astype(np.float32)
+    sim = (_temp(rng, T, shape, nan_frac=0.01) + 2).astype(np.float32)
+    eqm = xsdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=20, kind=kind, group="time", device=dev)
+    eaf, ehq = osdba.eqm_train(ref.reshape(T, -1), hist.reshape(T, -1), 20, kind)
+    np.testing.assert_allclose(eqm.hist_q.reshape(20, -1), ehq, rtol=1e-6)
+    np.testing.assert_allclose(eqm.af.reshape(20, -1), eaf, rtol=1e-5, atol=1e-5 if kind == "+" else 0)
+    scen = eqm.adjust(sim, interp=interp, extrapolation="constant")
+    exp = osdba.eqm_adjust(sim.reshape(T, -1), eqm.af.reshape(20, -1), eqm.hist_q.reshape(20, -1), kind, interp, "constant")
+    np.testing.assert_allclose(scen.reshape(T, -1), exp, rtol=1e-6, equal_nan=True)
+    assert eqm.adj_params["kind"] == kind
+    np.testing.assert_allclose(xsdba.quantile(ref, eqm.quantiles, device=dev).reshape(20, -1), osdba.quantile(ref.reshape(T, -1), eqm.quantiles), rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        xsdba.EmpiricalQuantileMapping.train(ref, hist, group="time.month", device=dev)
+
+
+def test_eqm_uniform_to_normal_like_reference_testqm(dev):
+    """Analytic check modelled on reference tests/test_xsdba.py:113-155 (TestQM.test_quantiles): mapping a uniform
+    `hist` onto a normal `ref` reproduces ppf differences to 1 decimal in the interior."""
+    from scipy.stats import norm, uniform
+
+    rng = np.random.default_rng(0)
+    n = 10000
+    u = rng.random(n)
+    x = uniform.ppf(u, loc=1, scale=1).astype(np.float32)[:, None]
+    y = norm.ppf(u, loc=2, scale=1).astype(np.float32)[:, None]
+    eqm = xsdba.EmpiricalQuantileMapping.train(y, x, nquantiles=50, kind="+", device=dev)
+    q = eqm.quantiles
+    expected = norm.ppf(q, 2, 1) - uniform.ppf(q, 1, 1)
+    np.testing.assert_almost_equal(eqm.af[2:-2, 0], expected[2:-2], 1)
+    p = eqm.adjust(x, interp="linear")
+    np.testing.assert_almost_equal(np.sort(p[:, 0])[n // 2 - 5 : n // 2 + 5], np.sort(y[:, 0])[n // 2 - 5 : n // 2 + 5], 1)

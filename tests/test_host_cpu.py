@@ -1,0 +1,138 @@
+"""CPU-side checks that need no GPU: calendar tables vs pandas, C-ABI symbol export, host-side validation, and the
+synthetic generator's determinism.  (`-m "not gpu"` suite.)"""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import synth
+from oracle.timeutil import OTime, days_in_period, groups
+from xclim_amd import _capi, generic
+from xclim_amd import run_length as xrl
+from xclim_amd.calendar import doy_interp_tables
+from xclim_amd.timeaxis import TimeAxis, parse_freq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- calendar tables -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("start,n", [("2000-07-01", 365), ("1999-12-15", 800), ("2001-01-01", 1461), ("2000-02-28", 3)])
+@pytest.mark.parametrize("freq", ["YS", "MS", "QS-DEC", "YS-JUL", "QS", "ME", "YE", "QE-NOV", "AS-JUL"])
+def test_segments_match_pandas_resample(start, n, freq):
+    ta = TimeAxis.daily(start, n)
+    seg, starts = ta.segments(freq)
+    idx = pd.date_range(start, periods=n, freq="D")
+    pfreq = freq.replace("AS", "YS")
+    sizes = pd.Series(np.arange(n), index=idx).resample(pfreq).count().values
+    np.testing.assert_array_equal(np.diff(seg), sizes)
+    assert seg[0] == 0 and seg[-1] == n
+    # same as the oracle's independent grouping
+    og = groups(OTime.standard(start, n), pfreq)
+    assert [len(g[1]) for g in og] == list(np.diff(seg))
+
+
+@pytest.mark.parametrize("freq", ["YS", "MS", "QS-DEC", "YS-JUL"])
+def test_expected_count_matches_oracle(freq):
+    ta = TimeAxis.daily("1999-11-20", 900)
+    np.testing.assert_array_equal(ta.expected_count(freq), days_in_period(OTime.standard("1999-11-20", 900), freq))
+
+
+@pytest.mark.parametrize("calendar,ndoy", [("noleap", 365), ("360_day", 360)])
+def test_nonstandard_calendars(calendar, ndoy):
+    ta = TimeAxis.daily("2001-01-01", ndoy * 3, calendar)
+    ot = OTime.noleap(2001, ndoy * 3, calendar)
+    np.testing.assert_array_equal(ta.doy, ot.doy)
+    np.testing.assert_array_equal(ta.month, ot.month)
+    seg, _ = ta.segments("YS")
+    np.testing.assert_array_equal(seg, [0, ndoy, 2 * ndoy, 3 * ndoy])
+    np.testing.assert_array_equal(ta.expected_count("YS"), [ndoy] * 3)
+    tb, years, doys = ta.doy_table()
+    assert tb.shape == (3, ndoy) and (tb >= 0).all() and tb[1, 0] == ndoy
+
+
+def test_doy_table_leap():
+    ta = TimeAxis.daily("1999-01-01", 365 + 366)
+    tb, years, doys = ta.doy_table()
+    assert tb.shape == (2, 366) and tb[0, 365] == -1 and tb[1, 365] == 365 + 365
+    np.testing.assert_array_equal(ta.doy, pd.date_range("1999-01-01", periods=731).dayofyear.values)
+
+
+def test_parse_freq_errors():
+    assert parse_freq("YS-JUL") == ("Y", 7) and parse_freq("QE-NOV") == ("Q", 12) and parse_freq("YE") == ("Y", 1)
+    with pytest.raises(NotImplementedError):
+        parse_freq("7D")
+    with pytest.raises(ValueError):
+        parse_freq("YS-FOO")
+
+
+def test_doy_interp_tables():
+    i0, i1, dxn, dxs = doy_interp_tables(365, 366, 1)
+    assert len(i0) == 366 and i0[0] == 0 and i1[-1] == 364 and (i1 == i0 + 1).all()
+    x = np.linspace(1, 366, 365)
+    np.testing.assert_allclose(x[i0] + dxn, np.arange(1, 367))
+    np.testing.assert_allclose(dxs, x[i1] - x[i0])
+
+
+# ---- C ABI -------------------------------------------------------------------------------------------------------
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "xclim_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(xh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_header_symbol():
+    """The library must load on a GPU-less host and export exactly what include/xclim_hip.h declares."""
+    lib = _capi.load_library()
+    names = _header_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+        assert n in _capi.SIGNATURES, f"{n} has no ctypes prototype"
+    assert set(_capi.SIGNATURES) == set(names)
+    assert lib.xh_abi_version() == 1
+    n = ctypes.c_int(-1)
+    assert lib.xh_device_count(ctypes.byref(n)) == 0 and n.value >= 0
+
+
+def test_no_cpu_fallback_without_device():
+    """The product path fails loudly when no GPU is visible (no silent CPU fallback)."""
+    if _capi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_capi.BackendUnavailable):
+        _capi.Device(0)
+    with pytest.raises(_capi.BackendUnavailable):
+        generic.threshold_count(np.zeros((3, 2), np.float32), ">", 1.0, TimeAxis.daily("2000-01-01", 3), "YS")
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "xclim_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+# ---- host-side validation (mirrors the reference's error behaviour) ---------------------------------------------
+def test_operator_validation():
+    assert generic.get_op("gt") == ">" and generic.get_op(">=") == ">=" and generic.get_op("ne") == "!="
+    with pytest.raises(ValueError, match="not recognized"):
+        generic.get_op("=>")
+    with pytest.raises(ValueError, match="not permitted"):
+        generic.get_op("==", constrain=(">", "<"))
+    with pytest.raises(ValueError, match="not implemented for 1d method"):
+        xrl.use_ufunc(True, freq="YS")
+
+
+# ---- synthetic generator ---------------------------------------------------------------------------------------------
+def test_synthetic_generator_is_counter_based():
+    base = synth.seasonal_base(50)
+    a = synth.fill_synthetic(50, np.arange(100, 140), 0, 7, base, 3.0, nan_per_million=20000)
+    b = synth.fill_synthetic(50, np.arange(120, 130), 0, 7, base, 3.0, nan_per_million=20000)
+    np.testing.assert_array_equal(a[:, 20:30], b)  # a shard sees the same global field
+    assert a.dtype == np.float32 and np.isnan(a).any() and abs(np.nanstd(a - base[:, None]) - 3.0 / np.sqrt(3)) < 0.1
+    pr = synth.fill_synthetic(400, np.arange(64), 1, 3, np.zeros(400, np.float32), 40 / 86400.0, 0.3)
+    assert 0.25 < (pr > 0).mean() < 0.35 and pr.min() == 0

@@ -1,0 +1,234 @@
+"""The reference's own synthetic known-answer tests, restated on the oracle.
+
+Each test names the reference test it ports (paths under /root/reference/tests).  The fixtures mirror
+``test_timeseries`` (src/xclim/testing/helpers.py:163-217): daily series starting 2000-07-01 unless stated.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import calendar as ocal
+from oracle import generic as ogen
+from oracle import indices as oidx
+from oracle import run_length as orl
+from oracle.timeutil import OTime
+
+START = "2000-07-01"
+
+
+def _t(n, start=START):
+    return OTime.standard(start, n)
+
+
+# ---- tests/test_run_length.py ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("index", ["first", "last"])
+def test_rle(index):  # test_run_length.py:100-130
+    values = np.zeros((365, 4, 4))
+    values[1:11] = 1
+    out = orl.rle(values != 0, index=index).mean(axis=(1, 2))
+    expected = np.zeros(365)
+    if index == "last":
+        expected[1:10] = np.nan
+        expected[10] = 10
+    else:
+        expected[1] = 10
+        expected[2:11] = np.nan
+    np.testing.assert_array_equal(out, expected)
+
+
+def test_rle_all_nan():  # test_run_length.py:89-91
+    assert (orl.rle(np.full(365, np.nan)) == 0).all()
+
+
+class TestStatisticsRun:  # test_run_length.py:166-296
+    def _both(self, da, freq, reducer, window):
+        t = _t(len(da)) if not hasattr(self, "_start") else OTime.standard(self._start, len(da))
+        before = orl.resample_and_rl(da, True, orl.rle_statistics, time=t, freq=freq, reducer=reducer, window=window)
+        after = orl.rle_statistics(da, reducer, window, time=t, freq=freq)
+        return before, after
+
+    def test_simple(self):
+        v = np.zeros(365)
+        v[1:11] = 1
+        for lt in self._both(v != 0, "ME", "max", 1):
+            assert lt[0] == 10
+            np.testing.assert_array_equal(lt[1:], 0)
+
+    def test_start_at_0(self):
+        v = np.zeros(365)
+        v[0:10] = 1
+        for lt in self._both(v != 0, "ME", "max", 1):
+            assert lt[0] == 10
+            np.testing.assert_array_equal(lt[1:], 0)
+
+    def test_end_start_at_0(self):
+        v = np.zeros(365)
+        v[-10:] = 1
+        for lt in self._both(v != 0, "ME", "max", 1):
+            assert lt[-1] == 10
+            np.testing.assert_array_equal(lt[:-1], 0)
+
+    def test_all_true(self):
+        v = np.ones(365)
+        before, after = self._both(v != 0, "ME", "max", 1)
+        np.testing.assert_array_equal(before, [31, 31, 30, 31, 30, 31, 31, 28, 31, 30, 31, 30])
+        expected = np.zeros(12)
+        expected[0] = 365
+        np.testing.assert_array_equal(after, expected)
+
+    def test_almost_all_true(self):
+        v = np.ones(365)
+        v[35] = 0
+        before, after = self._both(v != 0, "ME", "max", 1)
+        assert before[0] == 31 and before[1] == 26
+        assert after[0] == 35 and after[1] == 365 - 35 - 1
+
+    def test_other_stats(self):
+        v = np.ones(365)
+        v[35] = 0
+        self._start = "2000-01-01"
+        try:
+            for lt in self._both(v != 0, "YS", "min", 1):
+                assert lt == 35
+            for lt in self._both(v != 0, "YS", "mean", 36):
+                assert lt == 329
+            for lt in self._both(v != 0, "YS", "std", 1):
+                assert lt == 147
+            _, q90 = self._both(v != 0, "YS", "q90", 1)
+            _, q10 = self._both(v != 0, "YS", "q10", 1)
+            assert q90 == 299.6 and q10 == 64.4
+        finally:
+            del self._start
+
+    @pytest.mark.parametrize("op", ["min", "max"])
+    def test_resampling_order(self, op):
+        self._start = "2000-01-01"
+        try:
+            v = np.ones(365)
+            v[35:45] = 0
+            b, a = self._both(v != 0, "MS", op, 1)
+            assert (b != a).any()
+            v = np.zeros(365)
+            v[0:-1:31] = 1
+            b, a = self._both(v != 0, "MS", op, 1)
+            assert (b == a).any()
+        finally:
+            del self._start
+
+
+def test_first_run():  # test_run_length.py:299-353
+    a = np.zeros(100, bool)
+    a[10:20] = 1
+    assert orl.first_run(a, 5) == 10
+    t = np.zeros(60)
+    t[30:40] = 2
+    runs = np.stack([t, t], axis=1)
+    np.testing.assert_array_equal(orl.first_run(runs, 1), [30, 30])
+    t[0] = 2
+    runs = np.stack([t, t], axis=1)
+    out = orl.first_run(runs, 1, time=OTime.standard("2000-01-01", 60), freq="MS")
+    np.testing.assert_array_equal(out, [[0, 0], [0, 0]])
+
+
+def test_last_run():  # test_run_length.py:384-424
+    t = np.zeros(60)
+    t[30:40] = 2
+    runs = np.stack([t, t], axis=1)
+    np.testing.assert_array_equal(orl.last_run(runs, 1), [39, 39])
+    t[0] = 2
+    runs = np.stack([t, t], axis=1)
+    out = orl.last_run(runs, 1, time=OTime.standard("2000-01-01", 60), freq="MS")
+    np.testing.assert_array_equal(out, [[30, 30], [8, 8]])
+
+
+@pytest.mark.parametrize("index", ["first", "last"])
+def test_windowed_run_events_count_sum(index):  # test_run_length.py:356-381
+    a = np.zeros(50, bool)
+    a[4:7] = True
+    a[34:45] = True
+    assert orl.windowed_run_events(a, 3, index=index) == 2
+    assert orl.windowed_run_count(a, 3, index=index) == 3 + 11
+    f = np.zeros(50, float)
+    f[4:6] = 5
+    f[25:30] = 5
+    f[35:45] = 5
+    assert orl.windowed_max_run_sum(f, 3, index=index) == 50
+
+
+# ---- tests/test_generic.py ----------------------------------------------------------------------------------------
+def test_threshold_count_and_domain_count():  # test_generic.py:70-82
+    ts = np.arange(365).astype(np.float64)
+    np.testing.assert_array_equal(ogen.threshold_count(ts, "<", 50, _t(365), "YE"), [50, 0])
+    np.testing.assert_array_equal(ogen.domain_count(ts, 10, 20, _t(365), "YE"), [10, 0])
+
+
+def test_get_op_errors():  # generic.py:285, 296
+    with pytest.raises(ValueError, match="not recognized"):
+        ogen.get_op("=>")
+    with pytest.raises(ValueError, match="not permitted"):
+        ogen.threshold_count(np.arange(3.0), "==", 1, _t(3), "YS")
+
+
+# ---- tests/test_calendar.py -----------------------------------------------------------------------------------
+def test_percentile_doy():  # test_calendar.py:83-104
+    tas = np.arange(365).astype(np.float64)
+    tas2 = np.stack([tas, tas], axis=1)
+    ot = OTime.standard("2001-01-01", 365)
+    p, doys = ocal.percentile_doy(tas2, ot, window=5, per=50)
+    assert p[list(doys).index(3), 0, 0] == 2
+    tasn = tas.copy()
+    tasn[ot.doy == 2] = np.nan
+    p, doys = ocal.percentile_doy(np.stack([tasn, tasn], axis=1), ot, window=5, per=50)
+    assert p[list(doys).index(3), 0, 0] == 2.5
+
+
+# ---- tests/test_indices.py ------------------------------------------------------------------------------------
+class TestMaximumConsecutiveDryDays:  # test_indices.py:2354-2381
+    thr = 1.0 / 86400.0  # "1 mm/day" in kg m-2 s-1 (hydro context)
+
+    def test_simple(self):
+        a = np.zeros(365) + 10
+        a[5:15] = 0
+        out = oidx.maximum_consecutive_dry_days(a.astype(np.float32), self.thr, _t(365), "ME")
+        assert out[0] == 10
+
+    def test_run_start_at_0(self):
+        a = np.zeros(365) + 10
+        a[:10] = 0
+        assert oidx.maximum_consecutive_dry_days(a.astype(np.float32), self.thr, _t(365), "ME")[0] == 10
+
+    @pytest.mark.parametrize("before,expected", [(True, 26), (False, 30)])
+    def test_resampling_order(self, before, expected):
+        a = np.zeros(365) + 10
+        a[5:35] = 0
+        out = oidx.maximum_consecutive_dry_days(a.astype(np.float32), self.thr, _t(365), "ME", resample_before_rl=before)
+        assert out[0] == expected
+
+
+class TestTGXNp:  # test_indices.py:2529-2625 (leap year: 366 -> 365 + re-interpolation path of percentile_doy)
+    def _setup(self):
+        tas = np.arange(366).astype(np.float64)
+        ot = OTime.standard("2000-01-01", 366)
+        p, doys = ocal.percentile_doy(tas, ot, per=10)
+        assert len(doys) == 366
+        tas = tas.copy()
+        tas[175:180] = 1  # cold spell in June
+        return tas, p[..., 0], doys, ot
+
+    def test_t10p(self):
+        tas, t10, doys, ot = self._setup()
+        out = oidx.tx10p(tas, t10, doys, ot, "MS", op="<")
+        assert out[0] == 0 and out[5] == 5
+
+    def test_t90p(self):
+        tas, t10, doys, ot = self._setup()
+        out = oidx.tx90p(tas, t10, doys, ot, "MS", op=">")
+        assert out[0] == 30 and out[1] == 29 and out[5] == 25
+
+
+def test_tg_mean_and_missing():  # test_temperature.py:162-191 semantics: NaN day -> period masked (MissingAny)
+    tas = np.full(731, 280.0, np.float32)
+    tas[400] = np.nan
+    ot = OTime.standard("2001-01-01", 731)
+    out = oidx.apply_missing(oidx.tg_mean(tas, ot, "YS"), tas, ot, "YS")
+    assert out[0] == 280.0 and np.isnan(out[1]) and np.isnan(out[2])  # 2002 has the NaN, 2003 is a 1-day stub

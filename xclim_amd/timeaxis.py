@@ -39,8 +39,17 @@ def parse_freq(freq: str) -> tuple[str, int]:
     for old, new in (("AS", "YS"), ("A-", "Y-")):
         if f.startswith(old):
             f = new + f[len(old):]
-    if f == "MS":
-        return "M", 1
+    if f in ("MS", "ME", "M"):
+        return "M", 1  # end-anchored offsets give the same segments (only the labels differ)
+    for end, start in (("YE", "YS"), ("QE", "QS"), ("Y", "YS"), ("Q", "QS")):
+        # "YE-MMM"/"QE-MMM": periods END in month MMM -> they START the month after
+        if f == end:
+            f = start  # year/quarter ending in DEC == starting in JAN
+        elif f.startswith(end + "-") and not f.startswith(start):
+            mon = f.split("-", 1)[1]
+            if mon not in MONTHS:
+                raise ValueError(f"Unknown anchor month in frequency {freq!r}")
+            f = f"{start}-{MONTHS[(MONTHS.index(mon) + 1) % 12]}"
     for base in ("YS", "QS"):
         if f == base:
             return base[0], 1
