@@ -172,6 +172,29 @@ int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, 
                  double thr, int window, int stat, int index_first, const int64_t* seg_off, int P,
                  int cut_at_segments, float* out, int32_t* valid_out);
 
+/* spell_mask (indices/generic.py:434-540): out[t] = 1 iff day t belongs to any window of `window` consecutive
+ * days whose statistic (win_reducer 0 sum, 1 mean, 2 min, 3 max, 4 weighted mean with host `weights[window]`)
+ * satisfies `stat op thr`; NaN in a window -> not satisfied.  out (T, C) float32 0/1. */
+int xh_spell_mask(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window,
+                  int win_reducer, int op, double thr, const float* weights /* host, may be NULL */, float* out,
+                  int64_t out_st);
+/* runs_with_holes (indices/run_length.py:844-888): hysteresis mask — on after window_start consecutive `start`,
+ * off after window_stop consecutive `stop` (stop == NULL means stop = NOT start); out (T, C) float32 0/1. */
+int xh_runs_with_holes(xh_ctx* ctx, const float* start, const float* stop, int64_t T, int64_t C, int64_t st,
+                       int64_t sc, int window_start, int window_stop, float* out, int64_t out_st);
+/* keep_longest_run (indices/run_length.py:805-841): keep only the first longest run of each period. */
+int xh_keep_longest_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
+                        const int64_t* seg_off, int P, float* out, int64_t out_st);
+/* season (indices/run_length.py:891-1145) per period: start / end indices relative to the period start (NaN when
+ * undefined) and length.  mid_idx[P]: index of `mid_date` inside each period, < 0 when absent; NULL = no date. */
+int xh_season(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window,
+              const int64_t* seg_off, const int32_t* mid_idx, int P, float* start_out, float* end_out,
+              float* len_out);
+/* windowed_max_run_sum (indices/run_length.py:491-540), runs cut at period edges: max over runs (x > 0) of at
+ * least `window` steps of the run's sum; out (P, C) float32. */
+int xh_max_run_sum(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window,
+                   const int64_t* seg_off, int P, float* out);
+
 /* ---- quantile / percentile family (Q1-Q3) --------------------------------------------------- */
 /* calc_perc / _nan_quantile (core/utils.py:279-557): NaN-aware Hyndman-Fan quantiles of N samples per
  * cell.  x is (N, C) with sample stride sn and cell stride sc (either may be 1).  q[nq] in [0, 1].

@@ -135,9 +135,32 @@ def select_rolling_resample_op(da, op, window, time: OTime, window_center=True, 
     return select_resample_op(rolling(da, window, window_op, window_center), op, time, freq)
 
 
-def spell_mask(data, window, win_reducer, op, thresh, min_gap=1):
-    """gen:434-540, single variable, no weights; min_gap > 1 not restated (needs runs_with_holes)."""
+def spell_mask(data, window, win_reducer, op, thresh, min_gap=1, weights=None):
+    """gen:434-540, single variable."""
+    m = _spell_mask_nogap(data, window, win_reducer, op, thresh, weights)
+    if min_gap > 1:
+        m = rl.runs_with_holes(m, 1, ~m, min_gap).astype(bool)  # gen:537-538
+    return m
+
+
+def _spell_mask_nogap(data, window, win_reducer, op, thresh, weights=None):
     data = np.asarray(data)
+    if weights is not None:
+        if win_reducer != "mean":
+            raise ValueError(f"Argument 'weights' is only supported if 'win_reducer' is 'mean'. Got :  {win_reducer}")
+        if len(weights) != window:
+            raise ValueError(f"Weights have a different length ({len(weights)}) than the window ({window}).")
+        T = data.shape[0]
+        pad = np.concatenate([data, np.full((window,) + data.shape[1:], np.nan, dtype=data.dtype)], axis=0)
+        sv = np.full(pad.shape, np.nan)
+        w = np.asarray(weights, dtype=np.float64)
+        for t in range(window - 1, pad.shape[0]):
+            sv[t] = np.tensordot(w, pad[t - window + 1 : t + 1].astype(np.float64), axes=(0, 0))
+        mask = compare(sv.astype(np.float32), op, thresh)
+        msum = rolling(mask.astype(np.float64), window, "sum", center=False)
+        with np.errstate(invalid="ignore"):
+            is_in = msum >= 1
+        return rl.shift0(is_in, -(window - 1), False)[:T]
     if window == 1:
         return compare(data, op, thresh)
     if (win_reducer == "min" and op in [">", ">=", "ge", "gt"]) or (win_reducer == "max" and op in ["`<", "<=", "le", "lt"]):
@@ -168,8 +191,8 @@ def spell_mask(data, window, win_reducer, op, thresh, min_gap=1):
 
 
 def spell_length_statistics(data, thresh, window, win_reducer, op, spell_reducer, time: OTime, freq,
-                            resample_before_rl=True):
+                            resample_before_rl=True, min_gap=1):
     """gen:543-585 / 588-686 without indexer: mask -> float32 -> resample_and_rl(rle_statistics, window=1)."""
-    mask = spell_mask(data, window, win_reducer, op, thresh).astype(np.float32)
+    mask = spell_mask(data, window, win_reducer, op, thresh, min_gap=min_gap).astype(np.float32)
     return rl.resample_and_rl(mask, resample_before_rl, rl.rle_statistics, time=time, freq=freq, reducer=spell_reducer,
                               window=1)

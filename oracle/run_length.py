@@ -298,3 +298,99 @@ def first_run_1d(arr, window):
     v, rls, pos = rle_1d(arr)
     ind = np.where(v * rls >= window, pos, np.inf).min()
     return np.nan if np.isinf(ind) else ind
+
+
+# ---- hysteresis runs, longest run, seasons (rl:805-1145) ----
+def _ffill0(a):
+    """ffill along axis 0."""
+    idx = np.where(~np.isnan(a), np.arange(a.shape[0]).reshape((-1,) + (1,) * (a.ndim - 1)), 0)
+    idx = np.maximum.accumulate(idx, axis=0)
+    return np.take_along_axis(a, idx, axis=0)
+
+
+def runs_with_holes(da_start, window_start, da_stop, window_stop):
+    """rl:844-888."""
+    a = np.nan_to_num(np.asarray(da_start).astype(np.float64)).astype(int)
+    b = np.nan_to_num(np.asarray(da_stop).astype(np.float64)).astype(int)
+    start_runs = cumsum_reset(a.astype(bool), index="first")
+    stop_runs = cumsum_reset(b.astype(bool), index="first")
+    start_pos = np.where(start_runs >= window_start, 1.0, np.nan)
+    stop_pos = np.where(stop_runs >= window_stop, 0.0, np.nan)
+    runs = np.where(np.isnan(stop_pos), start_pos, stop_pos)  # stop_positions.combine_first(start_positions)
+    runs = _ffill0(runs)
+    return np.nan_to_num(runs, nan=0.0)
+
+
+def keep_longest_run(da, time=None, freq=None):
+    """rl:805-841."""
+    da = np.asarray(da)
+    rls = rle(da)
+
+    def _get_out(_rls, _t=None):
+        T = _rls.shape[0]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            am = np.nanargmax(np.where(np.isnan(_rls).all(axis=0), 0, _rls), axis=0)
+        ar = np.arange(T).reshape((-1,) + (1,) * (_rls.ndim - 1))
+        out = np.where(ar == am, _rls + 1, _rls)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            return _ffill0(out) == np.nanmax(out, axis=0)
+
+    if freq is not None:
+        return np.concatenate([_get_out(rls[idx]) for _, idx in groups(time, freq)], axis=0)
+    return _get_out(rls)
+
+
+def _date_index(time: OTime, date):
+    """rl:1621-1665 `index_of_date` for "MM-DD" strings (every year matches); returns an index array."""
+    if date is None:
+        return None
+    m, d = (int(v) for v in date.split("-"))
+    return np.nonzero((time.month == m) & (time.day == d))[0]
+
+
+def first_run_before_date(da, window, date, time: OTime):
+    """rl:1287-1331."""
+    da = np.asarray(da, dtype=np.float64)
+    if date is not None:
+        idx = _date_index(time, date)
+        if idx.size == 0:
+            return np.full(da.shape[1:], np.nan)
+        lim = idx[0] + window - 1
+        da = da.copy()
+        da[lim:] = np.nan  # da.where(t < t[mid + window - 1])
+    return first_run(da, window)
+
+
+def first_run_after_date(da, window, date, time: OTime):
+    """rl:1204-1244."""
+    da = np.asarray(da, dtype=np.float64)
+    idx = _date_index(time, date)
+    mid = 0 if idx is None else (idx[0] if idx.size else None)
+    if mid is None:
+        return np.full(da.shape[1:], np.nan)
+    da = da.copy()
+    da[:mid] = np.nan
+    return first_run(da, window)
+
+
+def season(da, window, mid_date, time: OTime):
+    """rl:998-1110 with coord=False: (start, end, length) index arrays for ONE group (time on axis 0)."""
+    da = np.asarray(da).astype(bool)
+    T = da.shape[0]
+    beg = first_run_before_date(da, window, mid_date, time)
+    ar = np.arange(T).reshape((-1,) + (1,) * (da.ndim - 1))
+    not_da = np.where(ar >= np.nan_to_num(beg, nan=0.0), (~da).astype(np.float64), np.nan)
+    end = first_run_after_date(not_da, window, mid_date, time)
+    with np.errstate(invalid="ignore"):
+        length = np.where(np.isnan(beg), 0, np.where(np.isnan(end), T - beg, end - beg))
+        end = np.where(np.isnan(end) & ~np.isnan(beg), T - 1, end)
+        end = np.where(np.isnan(beg), np.nan, end)
+    return beg, end, length
+
+
+def season_per_period(da, window, mid_date, time: OTime, freq):
+    """gen:841-853 pattern: resample(time=freq).map(rl.season ...) with index outputs."""
+    outs = [season(np.asarray(da)[idx], window, mid_date, time.isel(idx)) for _, idx in groups(time, freq)]
+    return tuple(np.stack([o[k] for o in outs], axis=0) for k in range(3))

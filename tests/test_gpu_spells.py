@@ -1,0 +1,153 @@
+"""GPU parity for the spell / hysteresis / season state machines (spell.hip) against the oracle."""
+
+import numpy as np
+import pytest
+
+from oracle import generic as ogen
+from oracle import run_length as orl
+from oracle.timeutil import OTime
+from xclim_amd import generic as xgen
+from xclim_amd import run_length as xrl
+from xclim_amd.timeaxis import TimeAxis
+
+pytestmark = pytest.mark.gpu
+
+
+def _pr(rng, T, C, nan_frac=0.0):
+    x = np.where(rng.random((T, C)) < 0.45, rng.gamma(0.8, 8.0, (T, C)), 0.0).astype(np.float32)
+    if nan_frac:
+        x[rng.random((T, C)) < nan_frac] = np.nan
+    return x
+
+
+@pytest.mark.parametrize("window,red,op", [(3, "min", ">"), (3, "max", "<="), (4, "sum", ">="), (5, "mean", ">"), (2, "max", "<"),
+                                           (1, None, ">"), (7, "min", ">=")])
+@pytest.mark.parametrize("nan_frac", [0.0, 0.02])
+def test_spell_mask(dev, rng, window, red, op, nan_frac):
+    T, C = 150, 90
+    x = _pr(rng, T, C, nan_frac)
+    thr = {"sum": 12.0, "mean": 3.0}.get(red, 1.0)
+    got = xgen.spell_mask(x, window, red, op, thr, device=dev)
+    exp = ogen.spell_mask(x, window, red, op, thr)
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_spell_mask_weights_and_gap(dev, rng):
+    T, C = 120, 40
+    x = _pr(rng, T, C)
+    w = [0.5, 0.25, 0.25]
+    np.testing.assert_array_equal(xgen.spell_mask(x, 3, "mean", ">", 2.0, weights=w, device=dev),
+                                  ogen.spell_mask(x, 3, "mean", ">", 2.0, weights=w))
+    for gap in (2, 3):
+        np.testing.assert_array_equal(xgen.spell_mask(x, 2, "min", ">", 1.0, min_gap=gap, device=dev),
+                                      ogen.spell_mask(x, 2, "min", ">", 1.0, min_gap=gap))
+    with pytest.raises(ValueError, match="only supported"):
+        xgen.spell_mask(x, 3, "max", ">", 2.0, weights=w, device=dev)
+    with pytest.raises(ValueError, match="different length"):
+        xgen.spell_mask(x, 4, "mean", ">", 2.0, weights=w, device=dev)
+
+
+@pytest.mark.parametrize("window,red,reducer,before", [(3, "min", "max", True), (3, "sum", "count", True), (2, "max", "sum", False)])
+def test_spell_length_statistics_general(dev, rng, window, red, reducer, before):
+    T, C = 730, 60
+    x = _pr(rng, T, C, 0.005)
+    ta, ot = TimeAxis.daily("2001-01-01", T), OTime.standard("2001-01-01", T)
+    op, thr = (">", 1.0) if red != "sum" else (">=", 10.0)
+    got = xgen.spell_length_statistics(x, thr, window, red, op, reducer, ta, "YS", resample_before_rl=before, device=dev)
+    exp = ogen.spell_length_statistics(x, thr, window, red, op, reducer, ot, "YS", resample_before_rl=before)
+    np.testing.assert_array_equal(got, exp)
+    got = xgen.spell_length_statistics(x, thr, window, red, op, reducer, ta, "YS", min_gap=2, resample_before_rl=before, device=dev)
+    exp = ogen.spell_length_statistics(x, thr, window, red, op, reducer, ot, "YS", resample_before_rl=before, min_gap=2)
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_reference_spell_length_statistics_answer(dev):
+    """reference tests/test_generic.py:784-797 pattern: two spells of 34 and 4 days -> max 34."""
+    x = np.zeros((365, 1), np.float32)
+    x[10:44] = 5
+    x[100:104] = 5
+    ta = TimeAxis.daily("2001-01-01", 365)
+    assert xgen.spell_length_statistics(x, 1.0, 3, "min", ">", "max", ta, "YS", device=dev)[0, 0] == 34
+    assert xgen.spell_length_statistics(x, 1.0, 3, "min", ">", "count", ta, "YS", device=dev)[0, 0] == 2
+
+
+@pytest.mark.parametrize("ws,wt", [(1, 1), (2, 3), (3, 2), (5, 5)])
+def test_runs_with_holes(dev, rng, ws, wt):
+    T, C = 200, 70
+    a = rng.random((T, C)) < 0.5
+    b = rng.random((T, C)) < 0.4
+    np.testing.assert_array_equal(xrl.runs_with_holes(a, ws, b, wt, device=dev), orl.runs_with_holes(a, ws, b, wt))
+    # identity (reference test_run_length.py:135-147): start = da, stop = ~da, windows 1
+    np.testing.assert_array_equal(xrl.runs_with_holes(a, 1, ~a, 1, device=dev), a.astype(np.float32))
+
+
+def test_keep_longest_run(dev, rng):
+    T, C = 400, 50
+    a = rng.random((T, C)) < 0.6
+    a[:, 0] = False
+    a[:, 1] = True
+    ta, ot = TimeAxis.daily("2000-01-01", T), OTime.standard("2000-01-01", T)
+    np.testing.assert_array_equal(xrl.keep_longest_run(a, device=dev), orl.keep_longest_run(a))
+    np.testing.assert_array_equal(xrl.keep_longest_run(a, freq="MS", time=ta, device=dev), orl.keep_longest_run(a, ot, "MS"))
+    # reference test_run_length.py:451-454
+    m = np.array([1, 0, 0, 1, 1, 1, 0, 0, 1, 1, 1, 1], bool)[:, None]
+    np.testing.assert_array_equal(xrl.keep_longest_run(m, device=dev)[:, 0], [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1])
+
+
+@pytest.mark.parametrize("window", [1, 3, 5])
+@pytest.mark.parametrize("mid_date", [None, "07-01", "02-10"])
+def test_season(dev, rng, window, mid_date):
+    T, C = 365 * 2 + 120, 80
+    t = np.arange(T)[:, None]
+    tas = 5 + 12 * np.sin(2 * np.pi * (t - 110) / 365) + rng.normal(0, 4, (T, C))
+    cond = tas > 5
+    cond[:, 0] = True
+    cond[:, 1] = False
+    ta, ot = TimeAxis.daily("2001-01-01", T), OTime.standard("2001-01-01", T)
+    got = xrl.season(cond, window, mid_date, time=ta, freq="YS", device=dev)
+    es, ee, el = orl.season_per_period(cond, window, mid_date, ot, "YS")
+    np.testing.assert_array_equal(got["start"], es)
+    np.testing.assert_array_equal(got["end"], ee)
+    np.testing.assert_array_equal(got["length"], el)
+    # whole-array form
+    g1 = xrl.season(cond[:365], window, mid_date, time=ta.subset(slice(0, 365)), device=dev)
+    s1, e1, l1 = orl.season(cond[:365], window, mid_date, ot.isel(slice(0, 365)))
+    np.testing.assert_array_equal(g1["start"], s1)
+    np.testing.assert_array_equal(g1["length"], l1)
+
+
+def test_reference_season_answers(dev):
+    """reference tests/test_run_length.py:484-502 (season_length 70 / 50 / 0) and :675-690 (start 140, end 150)."""
+    ta = TimeAxis.daily("2000-01-01", 366)
+    a = np.zeros((366, 1), bool)
+    a[50:100] = True
+    a[100:110] = False
+    a[110:130] = True
+    # mid_date inside the first run: season = first run of >=5 True .. first run of >= 5 False after mid
+    out = xrl.season(a, 5, "03-01", time=ta, device=dev)
+    assert out["start"][0] == 50 and out["end"][0] == 100 and out["length"][0] == 50
+    b = np.zeros((366, 1), bool)
+    assert xrl.season_length(b, 5, "07-01", time=ta, device=dev)[0] == 0
+    c = np.zeros((366, 1), bool)
+    c[140:150] = True
+    o = xrl.season(c, 3, "05-25", time=ta, device=dev)  # doy 146 inside the run
+    assert o["start"][0] == 140 and o["end"][0] == 150 and o["length"][0] == 10
+    od = xrl.season(c, 3, "05-25", coord="dayofyear", time=ta, device=dev)
+    assert od["start"][0] == 141 and od["end"][0] == 151
+
+
+@pytest.mark.parametrize("window", [1, 3])
+def test_windowed_max_run_sum(dev, rng, window):
+    T, C = 300, 60
+    x = _pr(rng, T, C)
+    ta, ot = TimeAxis.daily("2002-01-01", T), OTime.standard("2002-01-01", T)
+    got = xrl.windowed_max_run_sum(x, window, device=dev)
+    np.testing.assert_allclose(got, orl.windowed_max_run_sum(x, window), rtol=1e-6)
+    got = xrl.windowed_max_run_sum(x, window, freq="MS", time=ta, device=dev)
+    exp = orl.resample_and_rl(x, True, orl.windowed_max_run_sum, window, time=ot, freq="MS")
+    np.testing.assert_allclose(got, exp, rtol=1e-6)
+    f = np.zeros((50, 1), np.float32)
+    f[4:6] = 5
+    f[25:30] = 5
+    f[35:45] = 5
+    assert xrl.windowed_max_run_sum(f, 3, device=dev)[0] == 50  # reference test_run_length.py:373-381

@@ -67,6 +67,11 @@ SIGNATURES: dict[str, list] = {
     "xh_cumsum_reset": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64],
     "xh_rle": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64],
     "xh_run_stats": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _int, _int, _int, _vp, _int, _int, _vp, _vp],
+    "xh_spell_mask": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _dbl, _vp, _vp, _i64],
+    "xh_runs_with_holes": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _i64],
+    "xh_keep_longest_run": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _i64],
+    "xh_season": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, _vp],
+    "xh_max_run_sum": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _int, _vp],
     "xh_nan_quantile": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _dbl, _dbl, _vp],
     "xh_percentile_doy": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _vp, _int, _dbl, _dbl, _vp],
     "xh_doy_interp": [_vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _int, _vp],

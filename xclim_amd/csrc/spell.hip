@@ -1,0 +1,300 @@
+// spell.hip — spell masks, seasons, hysteresis runs: the remaining state machines of the run-length family.
+//
+// Reference: indices/generic.py:434-540 (spell_mask), indices/run_length.py:844-888 (runs_with_holes), 805-841
+// (keep_longest_run), 891-1145 (season_start / season_end / season / season_length), 491-540 (windowed_max_run_sum).
+// Same layout as runlen.hip: time-major (T, C), one lane per cell marching along time, periods on blockIdx.y.
+#include "common.h"
+
+// ---- spell_mask ------------------------------------------------------------------------------------------
+// A day is in a spell iff it belongs to ANY window of `window` consecutive days whose statistic satisfies the
+// condition (gen:519-535; the min/max fast path of gen:503-518 gives the same mask).  cond[t'] is evaluated on the
+// trailing window [t'-w+1, t'] (NaN anywhere or an incomplete window -> False, xarray rolling min_periods = w);
+// out[t] = any cond[t'] for t' in [t, t+w-1].  The window is re-read from L2 (w loads per step).
+// win_red: 0 sum, 1 mean, 2 min, 3 max, 4 weighted mean (dot with weights[w]).
+__global__ void __launch_bounds__(XH_BLOCK)
+k_spell_mask(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int window, int win_red, int op, float thr,
+             const float* __restrict__ weights, float* __restrict__ out, int64_t out_st) {
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  int64_t last_true = -1;
+  for (int64_t tp = 0; tp < T + window - 1; ++tp) {
+    bool cond = false;
+    if (tp < T && tp >= window - 1) {
+      double s = 0.0;
+      float e = x[(tp - window + 1) * st + c];
+      bool nan = false;
+      for (int k = 0; k < window; ++k) {
+        float v = x[(tp - window + 1 + k) * st + c];
+        nan |= (v != v);
+        if (win_red == 2) e = v < e ? v : e;
+        else if (win_red == 3) e = v > e ? v : e;
+        else if (win_red == 4) s += (double)v * (double)weights[k];
+        else s += (double)v;
+      }
+      float stat = (win_red == 2 || win_red == 3) ? e : (win_red == 1 ? (float)(s / (double)window) : (float)s);
+      cond = !nan && xh_cmp_f32(stat, op, thr);
+    }
+    if (cond) last_true = tp;
+    int64_t t = tp - (window - 1);
+    if (t >= 0) out[t * out_st + c] = (last_true >= t) ? 1.0f : 0.0f;
+  }
+}
+
+// ---- runs_with_holes -------------------------------------------------------------------------------------
+// state[t] = 1 where a run of >= w_start True of `start` begins/continues with >= w_start elements remaining,
+//            0 where the same holds for `stop` with w_stop (stop wins), else the previous state; initial 0.
+// Backward sweep computes the remaining-run lengths and writes 1 / 0 / NaN marks, forward sweep forward-fills.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_runs_with_holes(const float* __restrict__ a, const float* __restrict__ b, int64_t T, int64_t C, int64_t sa, int64_t sb,
+                  int w_start, int w_stop, int stop_is_not_start, float* __restrict__ out, int64_t out_st) {
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  int ra = 0, rb = 0;
+  for (int64_t t = T - 1; t >= 0; --t) {
+    float va = a[t * sa + c];
+    bool on_a = va > 0.0f;  // astype(int).fillna(0): NaN -> 0
+    bool on_b = stop_is_not_start ? !(on_a) : (b[t * sb + c] > 0.0f);
+    ra = on_a ? ra + 1 : 0;
+    rb = on_b ? rb + 1 : 0;
+    float mark = xh_nan32();
+    if (ra >= w_start) mark = 1.0f;
+    if (rb >= w_stop) mark = 0.0f;  // combine_first: stop positions take precedence
+    out[t * out_st + c] = mark;
+  }
+  float state = 0.0f;
+  for (int64_t t = 0; t < T; ++t) {
+    float m = out[t * out_st + c];
+    if (m == m) state = m;
+    out[t * out_st + c] = state;
+  }
+}
+
+// ---- keep_longest_run (per period) -----------------------------------------------------------------------------
+__global__ void __launch_bounds__(XH_BLOCK)
+k_keep_longest_run(const float* __restrict__ x, int64_t C, int64_t st, const int64_t* __restrict__ seg_off, int P,
+                   float* __restrict__ out, int64_t out_st) {
+  // rle() runs over the WHOLE series (rl:823), then each period keeps, among the runs that START inside it, the
+  // first one with the largest FULL length (it may extend past the period end; only its part inside the period is
+  // marked); the leading part of a run that started in an earlier period is never marked (NaN == max is False).
+  // Quirk restated (rl:826-833): a period without any run start marks its first non-run element.
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  int rem = 0;  // remaining run length from t on (backward march over the whole series)
+  for (int p = P - 1; p >= 0; --p) {
+    int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    int best = 0;
+    int64_t best_start = -1, first_zero = -1;
+    for (int64_t t = t1 - 1; t >= t0; --t) {
+      bool on = x[t * st + c] > 0.0f;
+      rem = on ? rem + 1 : 0;
+      bool prev_on = t > 0 && (x[(t - 1) * st + c] > 0.0f);
+      if (on && !prev_on && rem >= best) { best = rem; best_start = t; }  // >=: earlier start wins ties
+      if (!on) first_zero = t;
+    }
+    for (int64_t t = t0; t < t1; ++t) {
+      bool m = best > 0 ? (t >= best_start && t < best_start + best) : (t == first_zero);
+      out[t * out_st + c] = m ? 1.0f : 0.0f;
+    }
+  }
+}
+
+// ---- season (per period) -------------------------------------------------------------------------------------
+// start = first_run_before_date(da, window, mid): first t with `window` consecutive True, all inside t < mid+window-1
+// end   = first t >= max(start, mid) with `window` consecutive False (runs cut at that lower bound);
+// length: 0 if no start; T - start if no end; else end - start.  Reported end = T-1 when none, NaN when no start.
+// mid_idx[p] < 0 : the date is not in the group -> start NaN (rl:1319-1321) ; mid_idx == INT_MAX-ish : date=None.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_season(const float* __restrict__ x, int64_t C, int64_t st, int window, const int64_t* __restrict__ seg_off,
+         const int32_t* __restrict__ mid_idx, int has_date, int P, float* __restrict__ start_out,
+         float* __restrict__ end_out, float* __restrict__ len_out) {
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    int len = (int)(t1 - t0);
+    int mid = has_date ? mid_idx[p] : 0;  // relative to the period start
+    float fs = xh_nan32(), fe = xh_nan32(), fl = 0.0f;
+    if (!(has_date && mid < 0)) {
+      // phase 1: start
+      int limit = has_date ? (mid + window - 1) : len;  // da.where(t < mid + window - 1)
+      if (limit > len) limit = len;
+      int run = 0, beg = -1, ones = 0;
+      for (int i = 0; i < limit; ++i) {
+        bool on = x[(t0 + i) * st + c] > 0.0f;
+        run = on ? run + 1 : 0;
+        ones += on ? 1 : 0;
+        if (run >= window && beg < 0) { beg = i - window + 1; if (window > 1) break; }
+      }
+      if (window == 1 && limit == len && ones == len) beg = -1;  // argmax == argmin quirk (rl:603-605)
+      if (beg >= 0) {
+        fs = (float)beg;
+        // phase 2: end — window consecutive False at t >= max(beg, mid)
+        int lb = beg > mid ? beg : mid;
+        int runf = 0, end = -1, onesf = 0;
+        for (int i = lb; i < len; ++i) {
+          bool off = !(x[(t0 + i) * st + c] > 0.0f);
+          runf = off ? runf + 1 : 0;
+          onesf += off ? 1 : 0;
+          if (runf >= window && end < 0) { end = i - window + 1; if (window > 1) break; }
+        }
+        if (window == 1 && lb == 0 && onesf == len) end = -1;
+        fl = end < 0 ? (float)(len - beg) : (float)(end - beg);
+        fe = end < 0 ? (float)(len - 1) : (float)end;
+      }
+    }
+    int64_t o = (int64_t)p * C + c;
+    start_out[o] = fs;
+    end_out[o] = fe;
+    len_out[o] = fl;
+  }
+}
+
+// ---- windowed_max_run_sum (cut at segments / whole series) ------------------------------------------------------
+// rl:491-540: d_rse = reset-cumsum of the VALUES from the run's first element to the next exact zero (NaN adds 0
+// and does not reset), kept where rle(da > 0) >= window, max over the period.  Backward march.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_max_run_sum(const float* __restrict__ x, int64_t C, int64_t st, int window, const int64_t* __restrict__ seg_off, int P,
+              float* __restrict__ out) {
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    // the reference's arithmetic, restated so that results are bit-identical: cs = running fp32 cumsum of the
+    // reversed series (NaN adds 0, never reset), csr = cs at the latest exact zero, d_rse = cs - csr (rl:154-169)
+    float cs = 0.0f, csr = 0.0f;
+    int run = 0;
+    float best = 0.0f;
+    bool any = false;
+    for (int64_t t = t1 - 1; t >= t0; --t) {
+      float v = x[t * st + c];
+      cs = cs + ((v == v) ? v : 0.0f);
+      if (v == 0.0f) csr = cs;
+      float acc = cs - csr;
+      bool on = v > 0.0f;
+      run = on ? run + 1 : 0;
+      bool first_of_run = on && (t == t0 || !(x[(t - 1) * st + c] > 0.0f));
+      float d = (first_of_run && run >= window) ? acc : 0.0f;
+      best = (!any || d > best) ? d : best;
+      any = true;
+    }
+    out[(int64_t)p * C + c] = any ? best : xh_nan32();
+  }
+}
+
+static int chk(const char* fn, xh_ctx* ctx, const void* x, int64_t T, int64_t C, int64_t st, int64_t sc) {
+  XH_REQUIRE(ctx && x, XH_ERR_ARG, "%s: NULL argument", fn);
+  XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "%s: negative shape", fn);
+  XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "%s: needs a time-major view (sc == 1, st >= C)", fn);
+  return XH_OK;
+}
+
+static int upload_seg(xh_ctx* ctx, size_t* cur, const int64_t* seg_off, int P, int64_t T, const char* fn,
+                      const int64_t** d_seg) {
+  XH_REQUIRE(seg_off && P >= 1, XH_ERR_ARG, "%s: seg_off NULL or P < 1", fn);
+  for (int p = 0; p < P; ++p)
+    XH_REQUIRE(seg_off[p] <= seg_off[p + 1] && seg_off[p] >= 0 && seg_off[p + 1] <= T, XH_ERR_ARG,
+               "%s: seg_off must be non-decreasing within [0, T]", fn);
+  void* d = nullptr;
+  int rc = xh_scratch_upload(ctx, cur, seg_off, sizeof(int64_t) * (size_t)(P + 1), &d);
+  if (rc) return rc;
+  *d_seg = (const int64_t*)d;
+  return XH_OK;
+}
+
+extern "C" {
+
+int xh_spell_mask(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, int win_reducer,
+                  int op, double thr, const float* weights, float* out, int64_t out_st) {
+  int rc = chk("xh_spell_mask", ctx, x, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(out && out_st >= C, XH_ERR_ARG, "xh_spell_mask: out NULL or out_st < C");
+  XH_REQUIRE(window >= 1, XH_ERR_ARG, "xh_spell_mask: window must be >= 1");
+  XH_REQUIRE(win_reducer >= 0 && win_reducer <= 4, XH_ERR_OP, "xh_spell_mask: win_reducer %d not recognized", win_reducer);
+  XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
+  XH_REQUIRE(win_reducer != 4 || weights, XH_ERR_ARG, "xh_spell_mask: weights required for the weighted mean");
+  if (T == 0 || C == 0) return XH_OK;
+  const float* d_w = nullptr;
+  if (win_reducer == 4) {
+    size_t cur = 0;
+    void* d = nullptr;
+    rc = xh_scratch_upload(ctx, &cur, weights, sizeof(float) * (size_t)window, &d);
+    if (rc) return rc;
+    d_w = (const float*)d;
+  }
+  hipLaunchKernelGGL(k_spell_mask, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window,
+                     win_reducer, op, (float)thr, d_w, out, out_st);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_runs_with_holes(xh_ctx* ctx, const float* start, const float* stop, int64_t T, int64_t C, int64_t st, int64_t sc,
+                       int window_start, int window_stop, float* out, int64_t out_st) {
+  int rc = chk("xh_runs_with_holes", ctx, start, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(out && out_st >= C, XH_ERR_ARG, "xh_runs_with_holes: out NULL or out_st < C");
+  XH_REQUIRE(window_start >= 1 && window_stop >= 1, XH_ERR_ARG, "xh_runs_with_holes: windows must be >= 1");
+  if (T == 0 || C == 0) return XH_OK;
+  hipLaunchKernelGGL(k_runs_with_holes, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, start,
+                     stop ? stop : start, T, C, st, st, window_start, window_stop, stop ? 0 : 1, out, out_st);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_keep_longest_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int64_t* seg_off,
+                        int P, float* out, int64_t out_st) {
+  int rc = chk("xh_keep_longest_run", ctx, x, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(out && out_st >= C, XH_ERR_ARG, "xh_keep_longest_run: out NULL or out_st < C");
+  size_t cur = 0;
+  const int64_t* d_seg = nullptr;
+  rc = upload_seg(ctx, &cur, seg_off, P, T, "xh_keep_longest_run", &d_seg);
+  if (rc) return rc;
+  if (C == 0) return XH_OK;
+  XH_REQUIRE(seg_off[0] == 0 && seg_off[P] == T, XH_ERR_ARG, "xh_keep_longest_run: segments must cover [0, T)");
+  hipLaunchKernelGGL(k_keep_longest_run, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, C, st,
+                     d_seg, P, out, out_st);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_season(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window,
+              const int64_t* seg_off, const int32_t* mid_idx, int P, float* start_out, float* end_out, float* len_out) {
+  int rc = chk("xh_season", ctx, x, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(start_out && end_out && len_out, XH_ERR_ARG, "xh_season: NULL output");
+  XH_REQUIRE(window >= 1, XH_ERR_ARG, "xh_season: window must be >= 1");
+  size_t cur = 0;
+  const int64_t* d_seg = nullptr;
+  rc = upload_seg(ctx, &cur, seg_off, P, T, "xh_season", &d_seg);
+  if (rc) return rc;
+  void* d_mid = nullptr;
+  if (mid_idx) {
+    rc = xh_scratch_upload(ctx, &cur, mid_idx, sizeof(int32_t) * (size_t)P, &d_mid);
+    if (rc) return rc;
+  }
+  if (C == 0) return XH_OK;
+  hipLaunchKernelGGL(k_season, dim3((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)), dim3(XH_BLOCK), 0,
+                     ctx->stream, x, C, st, window, d_seg, (const int32_t*)d_mid, mid_idx ? 1 : 0, P, start_out, end_out,
+                     len_out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_max_run_sum(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window,
+                   const int64_t* seg_off, int P, float* out) {
+  int rc = chk("xh_max_run_sum", ctx, x, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(out, XH_ERR_ARG, "xh_max_run_sum: out is NULL");
+  XH_REQUIRE(window >= 1, XH_ERR_ARG, "xh_max_run_sum: window must be >= 1");
+  size_t cur = 0;
+  const int64_t* d_seg = nullptr;
+  rc = upload_seg(ctx, &cur, seg_off, P, T, "xh_max_run_sum", &d_seg);
+  if (rc) return rc;
+  if (C == 0) return XH_OK;
+  hipLaunchKernelGGL(k_max_run_sum, dim3((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)), dim3(XH_BLOCK), 0,
+                     ctx->stream, x, C, st, window, d_seg, P, out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+}  // extern "C"

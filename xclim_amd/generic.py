@@ -118,11 +118,55 @@ def spell_length_statistics(data, threshold: float, window: int, win_reducer, op
                             device=None, keep=False, with_valid=False):
     """gen:588-686 / 543-585.  window == 1 (the path of maximum_consecutive_dry/wet_days and friends): compare,
     astype(float32), rle_statistics(window=1) fused in ONE kernel pass.  window > 1 is not wired yet."""
-    if window != 1 or min_gap != 1:
-        raise NotImplementedError("spell_length_statistics: only window == 1, min_gap == 1 run on the HIP path yet")
     sym = get_op(op)
     dev = device or get_device()
     x, cell_shape = _flatten(data, dev)
     seg, _ = time.segments(freq)
-    out, val = K.run_stats(dev, x, spell_reducer, 1, seg, cut=resample_before_rl, fused_op=sym, thresh=float(threshold))
+    if window == 1 and min_gap == 1:
+        out, val = K.run_stats(dev, x, spell_reducer, 1, seg, cut=resample_before_rl, fused_op=sym, thresh=float(threshold))
+        return _finish(out, val, cell_shape, keep, with_valid)
+    mask = spell_mask(x, window, win_reducer, op, threshold, min_gap=min_gap, device=dev, keep=True)
+    out, _ = K.run_stats(dev, mask, spell_reducer, 1, seg, cut=resample_before_rl, want_valid=False)
+    val = None
+    if with_valid:  # valid count of the DATA, not of the mask
+        _, val = K.resample_reduce(dev, x, "count", seg)
     return _finish(out, val, cell_shape, keep, with_valid)
+
+
+def spell_mask(data, window: int, win_reducer: str, op: str, thresh: float, min_gap: int = 1, weights=None,
+               var_reducer: str = "all", *, device=None, keep=False):
+    """gen:434-540 for one variable: boolean (0/1 float32) mask of the days that are part of a spell."""
+    if weights is not None:
+        if win_reducer != "mean":
+            raise ValueError(f"Argument 'weights' is only supported if 'win_reducer' is 'mean'. Got :  {win_reducer}")
+        if len(weights) != window:
+            raise ValueError(f"Weights have a different length ({len(weights)}) than the window ({window}).")
+    sym = get_op(op)
+    dev = device or get_device()
+    x, cell_shape = _flatten(data, dev)
+    if window == 1:
+        m = K.spell_mask(dev, x, 1, "min", sym, float(thresh))
+    else:
+        m = K.spell_mask(dev, x, window, win_reducer, sym, float(thresh), weights)
+    if min_gap > 1:
+        m = K.runs_with_holes(dev, m, 1, None, min_gap)  # rl.runs_with_holes(mask, 1, ~mask, min_gap), gen:537-538
+    if keep:
+        return m
+    return m.get().reshape((m.shape[0],) + tuple(cell_shape)).astype(bool)
+
+
+def season(data, thresh: float, window: int, op: str, time: TimeAxis, freq: str, mid_date: str | None = None, *,
+           device=None):
+    """gen:769-853: start / end (as day of year) / length of the season per period.
+
+    cond = compare(data, op, thresh); per period rl.season(cond, window, mid_date) with coord="dayofyear".
+    Returns a dict of numpy arrays (P, *cells): "start", "end" (day of year, NaN when undefined), "length" (days).
+    """
+    from . import run_length as hrl
+
+    sym = get_op(op)
+    dev = device or get_device()
+    x, cell_shape = _flatten(data, dev)
+    cond = K.spell_mask(dev, x, 1, "min", sym, float(thresh))
+    return hrl.season(cond.reshape((x.shape[0],) + tuple(cell_shape)), window, mid_date, time=time, freq=freq,
+                      coord="dayofyear", device=dev)

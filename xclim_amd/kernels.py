@@ -168,6 +168,53 @@ def run_stats(dev: Device, x: DeviceArray, stat: str, window: int, seg_off, *, c
     return out, valid
 
 
+WIN_REDUCERS = {"sum": 0, "mean": 1, "min": 2, "max": 3, "wmean": 4}
+
+
+def spell_mask(dev: Device, x: DeviceArray, window: int, win_reducer: str, op: str, thresh: float, weights=None) -> DeviceArray:
+    T, C_ = _tc(x)
+    out = dev.empty((T, C_), np.float32)
+    w = np.ascontiguousarray(weights, dtype=np.float32) if weights is not None else None
+    red = WIN_REDUCERS["wmean" if w is not None else (win_reducer or "min")]
+    dev.call("xh_spell_mask", _vp(x.ptr), T, C_, C_, 1, int(window), red, op_code(op), float(thresh),
+             np_ptr(w) if w is not None else _vp(0), _vp(out.ptr), C_)
+    return out
+
+
+def runs_with_holes(dev: Device, start: DeviceArray, window_start: int, stop: DeviceArray | None, window_stop: int) -> DeviceArray:
+    T, C_ = _tc(start)
+    out = dev.empty((T, C_), np.float32)
+    dev.call("xh_runs_with_holes", _vp(start.ptr), _vp(stop.ptr if stop is not None else 0), T, C_, C_, 1, int(window_start),
+             int(window_stop), _vp(out.ptr), C_)
+    return out
+
+
+def keep_longest_run(dev: Device, x: DeviceArray, seg_off) -> DeviceArray:
+    T, C_ = _tc(x)
+    seg, P = _seg(seg_off)
+    out = dev.empty((T, C_), np.float32)
+    dev.call("xh_keep_longest_run", _vp(x.ptr), T, C_, C_, 1, np_ptr(seg), P, _vp(out.ptr), C_)
+    return out
+
+
+def season(dev: Device, x: DeviceArray, window: int, seg_off, mid_idx=None):
+    T, C_ = _tc(x)
+    seg, P = _seg(seg_off)
+    s, e, ln = (dev.empty((P, C_), np.float32) for _ in range(3))
+    mid = np.ascontiguousarray(mid_idx, dtype=np.int32) if mid_idx is not None else None
+    dev.call("xh_season", _vp(x.ptr), T, C_, C_, 1, int(window), np_ptr(seg), np_ptr(mid) if mid is not None else _vp(0), P,
+             _vp(s.ptr), _vp(e.ptr), _vp(ln.ptr))
+    return s, e, ln
+
+
+def max_run_sum(dev: Device, x: DeviceArray, window: int, seg_off) -> DeviceArray:
+    T, C_ = _tc(x)
+    seg, P = _seg(seg_off)
+    out = dev.empty((P, C_), np.float32)
+    dev.call("xh_max_run_sum", _vp(x.ptr), T, C_, C_, 1, int(window), np_ptr(seg), P, _vp(out.ptr))
+    return out
+
+
 def nan_quantile(dev: Device, x: DeviceArray, q, alpha=1.0, beta=1.0, sample_axis=0) -> DeviceArray:
     """x: (N, C) if sample_axis == 0 else (C, N).  Returns (nq, C) float64."""
     q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)

@@ -110,6 +110,98 @@ def last_run(da, window: int, dim="time", freq=None, coord=None, ufunc_1dim="fro
     return _run(da, "last", window, time, freq, "first", device, keep, cut=(window == 1))
 
 
+def windowed_max_run_sum(da, window: int, dim="time", freq=None, index="first", *, time=None, device=None, keep=False):
+    """rl:491-540 for non-negative NaN-free values (the documented use: precipitation sums over wet runs).  With
+    `freq` the runs are cut at the period edges (resample-before semantics)."""
+    dev = device or get_device()
+    m, cell_shape = _mask(da, dev)
+    seg = _whole(m.shape[0]) if freq is None else time.segments(freq)[0]
+    out = K.max_run_sum(dev, m, window, seg)
+    if keep:
+        return out
+    o = out.get().reshape((out.shape[0],) + tuple(cell_shape))
+    return o[0] if freq is None else o
+
+
+def runs_with_holes(da_start, window_start: int, da_stop, window_stop: int, dim="time", *, device=None, keep=False):
+    """rl:844-888."""
+    dev = device or get_device()
+    a, cell_shape = _mask(da_start, dev)
+    b, _ = _mask(da_stop, dev)
+    out = K.runs_with_holes(dev, a, window_start, b, window_stop)
+    return out if keep else out.get().reshape((a.shape[0],) + tuple(cell_shape))
+
+
+def keep_longest_run(da, dim="time", freq=None, *, time=None, device=None, keep=False):
+    """rl:805-841."""
+    dev = device or get_device()
+    m, cell_shape = _mask(da, dev)
+    seg = _whole(m.shape[0]) if freq is None else time.segments(freq)[0]
+    out = K.keep_longest_run(dev, m, seg)
+    return out if keep else out.get().reshape((m.shape[0],) + tuple(cell_shape)).astype(bool)
+
+
+def index_of_date(time: TimeAxis, date: str | None, max_idxs=None, default: int = 0) -> np.ndarray:
+    """rl:1621-1665 for "MM-DD" and "YYYY-MM-DD" strings."""
+    if date is None:
+        return np.array([default])
+    parts = date.split("-")
+    if len(parts) == 2:
+        m, d = int(parts[0]), int(parts[1])
+        cond = (time.month == m) & (time.day == d)
+    else:
+        y, m, d = (int(p) for p in parts)
+        cond = (time.year == y) & (time.month == m) & (time.day == d)
+    idxs = np.where(cond)[0]
+    if max_idxs is not None and idxs.size > max_idxs:
+        raise ValueError(f"More than {max_idxs} instance of date {date} found in the coordinate array.")
+    return idxs
+
+
+def season(da, window: int, mid_date: str | None = None, dim="time", stat=None, coord=False, *, time: TimeAxis | None = None,
+           freq: str | None = None, device=None):
+    """rl:998-1110, mapped per period when `freq` is given (the gen.season pattern, gen:841-853).
+
+    Returns {"start", "end", "length"} as numpy arrays; coord=False -> indices relative to the period start,
+    coord="dayofyear" -> day of year of those steps (NaN preserved).
+    """
+    dev = device or get_device()
+    m, cell_shape = _mask(da, dev)
+    T = m.shape[0]
+    seg = _whole(T) if freq is None else time.segments(freq)[0]
+    P = len(seg) - 1
+    mid = None
+    if mid_date is not None:
+        mid = np.full(P, -1, dtype=np.int32)
+        for p in range(P):
+            idx = index_of_date(time.subset(slice(int(seg[p]), int(seg[p + 1]))), mid_date, max_idxs=1)
+            if idx.size:
+                mid[p] = idx[0]
+    s, e, ln = (a.get() for a in K.season(dev, m, window, seg, mid))
+    if coord:
+        if coord != "dayofyear":
+            raise NotImplementedError("only coord='dayofyear' is supported")
+        for arr in (s, e):
+            for p in range(P):
+                ok = ~np.isnan(arr[p])
+                arr[p, ok] = time.doy[int(seg[p]) + arr[p, ok].astype(np.int64)]
+    shp = (P,) + tuple(cell_shape)
+    out = {"start": s.reshape(shp), "end": e.reshape(shp), "length": ln.reshape(shp)}
+    if freq is None:
+        out = {k: v[0] for k, v in out.items()}
+    return out
+
+
+def season_length(da, window: int, mid_date: str | None = None, dim="time", *, time=None, freq=None, device=None):
+    """rl:1113-1145."""
+    return season(da, window, mid_date, time=time, freq=freq, device=device)["length"]
+
+
+def season_start(da, window: int, mid_date: str | None = None, dim="time", coord=False, *, time=None, freq=None, device=None):
+    """rl:891-929 (= first_run_before_date)."""
+    return season(da, window, mid_date, coord=coord, time=time, freq=freq, device=device)["start"]
+
+
 _STATS = {"rle_statistics", "longest_run", "windowed_run_events", "windowed_run_count", "first_run", "last_run"}
 
 
