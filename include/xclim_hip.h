@@ -210,6 +210,14 @@ int xh_percentile_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t
                       const int32_t* tbase, int nyears, int ndoy, int window, const double* per /* host */,
                       int nper, double alpha, double beta, double* out);
 
+/* percentile_doy on a VIRTUAL time axis: tbase indexes virtual days 0..Tv-1 and vmap[Tv] (host) maps each virtual
+ * day to a physical row of x (-1 = absent -> NaN).  Lets percentile_bootstrap (core/bootstrapping.py:81-282) swap a
+ * year of the base period for another one by changing the index table instead of deep-copying the data. */
+int xh_percentile_doy_mapped(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
+                             const int32_t* tbase, int nyears, int ndoy, int window, const double* per /* host */,
+                             int nper, double alpha, double beta, const int32_t* vmap /* host */, int64_t Tv,
+                             double* out);
+
 /* _interpolate_doy_calendar (core/calendar.py:690-726): interpolate_na along doy then linear re-grid
  * D_in -> D_out with host-computed tables (scipy interp1d form): slope = (in[i1[j]] - in[i0[j]]) / dxs[j];
  * out[j] = slope * dxn[j] + in[i0[j]],  dxn = x_new - x_lo, dxs = x_hi - x_lo.  in (D_in, C), out (D_out, C). */

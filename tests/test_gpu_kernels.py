@@ -259,6 +259,49 @@ def test_percentile_doy(dev, rng, nyears, window, C, calendar):
     np.testing.assert_allclose(out, np.moveaxis(exp, -1, 0), rtol=1e-12, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("nyears,window,calendar,nan_frac", [(30, 5, "standard", 0.0), (40, 3, "noleap", 0.3), (12, 7, "standard", 0.05),
+                                                           (64, 5, "noleap", 0.01), (8, 5, "standard", 0.9)])
+def test_percentile_doy_merge_path(dev, rng, nyears, window, calendar, nan_frac):
+    """Multi-year base periods: per-day sorted lists + W-way tail merge (k_pdoy_merge) + LDS fallback on the
+    irregular days of year, all percentiles from both ends."""
+    C = 70
+    T = 365 * nyears + (nyears + 3) // 4 if calendar == "standard" else 365 * nyears
+    x = _field(rng, T, C, nan_frac=nan_frac)
+    x[:, 0] = np.nan
+    x[:, 1] = 280.0
+    ta, ot = _times("2000-01-01", T, calendar)
+    tb, years, doys = ta.doy_table()
+    per = [0.0, 2.0, 10.0, 50.0, 75.0, 90.0, 99.0, 100.0]
+    out = K.percentile_doy(dev, dev.to_device(x), tb, window, per).get()
+    rr = ocal.rolling_construct_center(x, window)
+    stack = np.full((len(doys), len(years), C, window), np.nan, dtype=np.float32)
+    stack[np.searchsorted(doys, ot.doy), np.searchsorted(years, ot.year)] = rr
+    stack = np.moveaxis(stack, 1, -2).reshape(len(doys), C, len(years) * window)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = oq.calc_perc(stack, per, 1 / 3, 1 / 3)
+    np.testing.assert_allclose(out, np.moveaxis(exp, -1, 0), rtol=1e-12, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("nyears", [4, 12])
+def test_percentile_doy_virtual_time_map(dev, rng, nyears):
+    """vmap: percentile_doy of a series in which one year was replaced by another, without copying the data."""
+    C, window = 40, 5
+    T = 365 * nyears
+    x = _field(rng, T, C, nan_frac=0.01)
+    ta, ot = _times("2001-01-01", T, "noleap")
+    tb, years, doys = ta.doy_table()
+    vmap = np.arange(T, dtype=np.int32)
+    vmap[365 * 1 : 365 * 2] = np.arange(365 * 3, 365 * 4)  # year 1 <- year 3
+    vmap[365 * 2 + 59] = -1  # and a day the replica lacks
+    out = K.percentile_doy(dev, dev.to_device(x), tb, window, [10.0, 90.0], vmap=vmap).get()
+    xm = np.where(vmap[:, None] >= 0, x[np.clip(vmap, 0, None)], np.nan).astype(np.float32)
+    exp, _ = ocal.percentile_doy(xm, ot, window, [10.0, 90.0])
+    np.testing.assert_allclose(out, np.moveaxis(exp, -1, 0), rtol=1e-12, atol=0, equal_nan=True)
+
+
 def test_doy_interp(dev, rng):
     C = 50
     src = rng.normal(280, 5, (365, C))

@@ -27,6 +27,7 @@ void xh_set_error(const char* fmt, ...);
     hipError_t _e = (expr);                                                                 \
     if (_e != hipSuccess) {                                                                 \
       xh_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      (void)hipGetLastError(); /* do not leave a sticky error for the next launch check */  \
       return XH_ERR_HIP;                                                                    \
     }                                                                                       \
   } while (0)

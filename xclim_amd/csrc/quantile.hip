@@ -9,6 +9,8 @@
 //   N <= 32 : samples gathered into registers, bitonic network on order-preserving uint32 keys  (k_pdoy_reg)
 //   N  > 32 : lane-private LDS column, bitonic network in LDS (no cross-lane traffic, no barriers) (k_pdoy_lds)
 // Time-major layout, one lane per cell (VEC cells in the register path); neighbouring doys re-read rows from L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 // Hyndman-Fan quantile from a sorted sample (ascending, NaN last).  `get(i)` returns sorted element i as float.
@@ -255,7 +257,8 @@ static void build_qtab(int L, const double* qs, int nper, double alpha, double b
 __global__ void __launch_bounds__(64)
 k_pdoy_lds(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
            int ndoy, int window, int NP, const double* __restrict__ qs, int nper, double alpha, double beta,
-           double* __restrict__ out) {
+           double* __restrict__ out, const int32_t* __restrict__ vmap, int64_t Tv, const int32_t* __restrict__ doy_list,
+           int ndl) {
   extern __shared__ uint32_t lds[];
   const int lane = threadIdx.x;
   int64_t c = (int64_t)blockIdx.x * 64 + lane;
@@ -263,14 +266,19 @@ k_pdoy_lds(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const 
   const int half = window / 2;
   const int N = nyears * window;
   uint32_t* col = lds + lane;  // element i at col[i * 64]
-  for (int d = blockIdx.y; d < ndoy; d += gridDim.y) {
+  const int nd = doy_list ? ndl : ndoy;
+  for (int di = blockIdx.y; di < nd; di += gridDim.y) {
+    const int d = doy_list ? doy_list[di] : di;
     int nvalid = 0;
     for (int y = 0; y < nyears; ++y) {
       int64_t tb = (int64_t)tbase[(int64_t)y * ndoy + d];
       for (int k = 0; k < window; ++k) {
-        int64_t t = tb - half + k;
+        int64_t t = tb - half + k;  // virtual time index
         float v = xh_nan32();
-        if (active && tb >= 0 && t >= 0 && t < T) v = x[t * st + c];
+        if (tb >= 0 && t >= 0 && t < Tv) {
+          int64_t tp = vmap ? (int64_t)vmap[t] : t;  // physical row (-1: a day the replica does not have)
+          if (active && tp >= 0 && tp < T) v = x[tp * st + c];
+        }
         nvalid += (v == v) ? 1 : 0;
         col[(y * window + k) * 64] = xh_f2key(v);
       }
@@ -297,6 +305,197 @@ k_pdoy_lds(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const 
         double r = xh_hf_quantile(N, nvalid, qs[j], alpha, beta, get);
         out[((int64_t)j * ndoy + d) * C + c] = r;
       }
+    }
+  }
+}
+
+// ---- multi-year path: per-day sorted lists + W-way tail merge ---------------------------------------------
+// For a base period of NY years the sample set of a day of year is the union over the W window days of "that
+// calendar day in every year".  Consecutive doys share W-1 of those day-sets, so each day-set is gathered and
+// sorted ONCE (register bitonic on NYP <= 64 keys), kept in an LDS ring of W lists per lane, and the two order
+// statistics of a percentile are found by popping from the W sorted lists (from the top or the bottom, whichever
+// is closer): ~min(k, N-k) * 25 ops instead of a (N log^2 N) sort of all W*NY samples per doy.
+// Days where the union-of-lists identity does not hold (the first/last W/2 days of the year, doy 365/366 in mixed
+// leap/non-leap periods) are flagged by the host (regular[d] == 0) and computed by k_pdoy_lds instead.
+// One wave per workgroup; lane = cell.  ring[slot][i][lane]; cnt[slot][lane] = number of non-NaN keys of the list.
+// Ring layout (compact): only the KT largest and KB smallest valid keys of every day-set can ever be popped (the
+// host derives KT / KB from the percentiles: e.g. per = 90, N = 150 -> KT = 16, KB = 0..1), so the LDS footprint per
+// wave is W * (KT + KB + 1) * 256 B instead of W * NYP * 256 B and more waves fit on a CU.
+//   ringT[w][j][lane] : j-th largest valid key of list w     ringB[w][i][lane] : i-th smallest     cnt[w][lane]
+// OFFSET = false: lists are day-sets shared between neighbouring doys (one new list per doy, chunked over blockIdx.y).
+// OFFSET = true : doys from `doy_list` whose window does not decompose into day-sets; the W lists are built from the
+//                 window offsets themselves (list k = { x[tbase[y][d] - W/2 + k] : y }), no reuse, always exact.
+template <int W, int NYP, bool OFFSET>
+__global__ void __launch_bounds__(64)
+k_pdoy_merge(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
+             int ndoy, int chunk, const QTab* __restrict__ qtab, int nper, double* __restrict__ out,
+             const int32_t* __restrict__ vmap, int64_t Tv, const uint8_t* __restrict__ regular,
+             const int32_t* __restrict__ doy_list, int ndl, int KT, int KB) {
+  extern __shared__ uint32_t lds[];
+  const int lane = threadIdx.x;
+  int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  const bool active = c < C;
+  constexpr int half = W / 2;
+  const int N = nyears * W;
+  uint32_t* ringT = lds;                          // [W][KT][64]
+  uint32_t* ringB = ringT + W * KT * 64;          // [W][KB][64]
+  uint32_t* cnt = ringB + W * KB * 64;            // [W][64]
+
+  // gather one list (virtual day index per year given by `vidx(y)`), sort it, store its two ends in slot `slot`
+  auto build = [&](int slot, auto vidx) {
+    uint32_t key[NYP];
+    int nv = 0;
+#pragma unroll
+    for (int y = 0; y < NYP; ++y) {
+      uint32_t kk = 0xFFFFFFFFu;
+      if (y < nyears) {
+        int64_t v = vidx(y);
+        if (v >= 0 && v < Tv) {
+          int64_t tp = vmap ? (int64_t)vmap[v] : v;
+          if (active && tp >= 0 && tp < T) kk = xh_f2key(x[tp * st + c]);
+        }
+      }
+      key[y] = kk;
+      nv += (kk != 0xFFFFFFFFu) ? 1 : 0;
+    }
+    bitonic_regs<NYP>(key);
+#pragma unroll
+    for (int i = 0; i < NYP; ++i) {
+      int rt = nv - 1 - i;  // rank from the top of sorted slot i
+      if (i < nv && rt < KT) ringT[(slot * KT + rt) * 64 + lane] = key[i];
+      if (i < nv && i < KB) ringB[(slot * KB + i) * 64 + lane] = key[i];
+    }
+    cnt[slot * 64 + lane] = (uint32_t)nv;
+  };
+
+  auto select_and_store = [&](int d) {
+    int n = 0, cw[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      cw[w] = (int)cnt[w * 64 + lane];
+      n += cw[w];
+    }
+    for (int j = 0; j < nper; ++j) {
+      QTab e = qtab[j * (N + 1) + n];
+      double r = xh_nan64();
+      if (e.lo >= 0) {
+        const bool from_top = (n - 1 - e.hi) < e.lo;  // pops needed from either end to reach ranks lo <= hi
+        uint32_t klo = 0, khi = 0;
+        if (from_top) {
+          int pt[W];
+          uint32_t h[W];
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            pt[w] = 0;
+            h[w] = (cw[w] > 0 && KT > 0) ? ringT[(w * KT) * 64 + lane] : 0u;
+          }
+          const int npop = n - e.lo;  // ranks n-1 ... lo
+          for (int it = 0; it < npop; ++it) {
+            uint32_t m = h[0];
+#pragma unroll
+            for (int w = 1; w < W; ++w) m = h[w] > m ? h[w] : m;
+            if (it == n - 1 - e.hi) khi = m;
+            klo = m;  // the last pop is rank lo
+            bool done = false;
+            int wsel = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+              bool is = !done && h[w] == m && pt[w] < cw[w];
+              wsel = is ? w : wsel;
+              done |= is;
+            }
+            int psel = 0, csel = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+              pt[w] += (w == wsel) ? 1 : 0;
+              psel = (w == wsel) ? pt[w] : psel;
+              csel = (w == wsel) ? cw[w] : csel;
+            }
+            bool more = psel < csel && psel < KT;
+            uint32_t nh = more ? ringT[(wsel * KT + psel) * 64 + lane] : 0u;
+#pragma unroll
+            for (int w = 0; w < W; ++w) h[w] = (w == wsel) ? nh : h[w];
+          }
+        } else {
+          int pb[W];
+          uint32_t h[W];
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            pb[w] = 0;
+            h[w] = cw[w] > 0 ? (KB > 0 ? ringB[(w * KB) * 64 + lane] : ringT[(w * KT + cw[w] - 1) * 64 + lane]) : 0xFFFFFFFFu;
+          }
+          const int npop = e.hi + 1;  // ranks 0 ... hi
+          for (int it = 0; it < npop; ++it) {
+            uint32_t m = h[0];
+#pragma unroll
+            for (int w = 1; w < W; ++w) m = h[w] < m ? h[w] : m;
+            if (it == e.lo) klo = m;
+            khi = m;
+            bool done = false;
+            int wsel = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+              bool is = !done && h[w] == m && pb[w] < cw[w];
+              wsel = is ? w : wsel;
+              done |= is;
+            }
+            int psel = 0, csel = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+              pb[w] += (w == wsel) ? 1 : 0;
+              psel = (w == wsel) ? pb[w] : psel;
+              csel = (w == wsel) ? cw[w] : csel;
+            }
+            bool more = psel < csel && (KB > 0 ? psel < KB : true);
+            uint32_t nh = more ? (KB > 0 ? ringB[(wsel * KB + psel) * 64 + lane] : ringT[(wsel * KT + (csel - 1 - psel)) * 64 + lane])
+                               : 0xFFFFFFFFu;
+#pragma unroll
+            for (int w = 0; w < W; ++w) h[w] = (w == wsel) ? nh : h[w];
+          }
+        }
+        float left = xh_key2f(klo), right = xh_key2f(khi);
+        float diff = right - left;
+        r = (double)left + (double)diff * e.gamma;
+        if (e.gamma >= 0.5) r = (double)right - (double)diff * (1.0 - e.gamma);
+        if (r != r && n > 0) {  // +-inf samples: nanmax fallback of utl:552-554 (KT >= 1 always)
+          uint32_t m = 0;
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            uint32_t t0 = cw[w] > 0 ? ringT[(w * KT) * 64 + lane] : 0u;
+            m = t0 > m ? t0 : m;
+          }
+          r = (double)xh_key2f(m);
+        }
+      }
+      if (active) out[((int64_t)j * ndoy + d) * C + c] = r;
+    }
+  };
+
+  if (OFFSET) {
+    for (int di = blockIdx.y; di < ndl; di += gridDim.y) {
+      const int d = doy_list[di];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        build(k, [&](int y) -> int64_t {
+          int v = tbase[(int64_t)y * ndoy + d];
+          return v < 0 ? (int64_t)-1 : (int64_t)v - half + k;
+        });
+      }
+      select_and_store(d);
+    }
+  } else {
+    int d0 = blockIdx.y * chunk, d1 = d0 + chunk;
+    if (d1 > ndoy) d1 = ndoy;
+    auto build_doy = [&](int dn) {
+      const int slot = ((dn % W) + W) % W;
+      build(slot, [&](int y) -> int64_t {
+        return (dn >= 0 && dn < ndoy) ? (int64_t)tbase[(int64_t)y * ndoy + dn] : (int64_t)-1;
+      });
+    };
+    for (int dn = d0 - half; dn < d0 + half; ++dn) build_doy(dn);
+    for (int d = d0; d < d1; ++d) {
+      build_doy(d + half);
+      if (regular[d]) select_and_store(d);
     }
   }
 }
@@ -347,6 +546,24 @@ static int next_pow2(int n) {
   return p;
 }
 
+static int launch_pdoy_lds(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tbase,
+                           int nyears, int ndoy, int window, const double* d_q, int nper, double alpha, double beta,
+                           double* out, const int32_t* d_vmap, int64_t Tv, const int32_t* d_doy_list, int ndl) {
+  int N = nyears * window;
+  int NP = next_pow2(N < 2 ? 2 : N);
+  size_t lds = (size_t)NP * 64 * sizeof(uint32_t);
+  XH_REQUIRE(lds <= 160 * 1024, XH_ERR_LIMIT, "percentile: %d samples per cell exceed the per-wave LDS column capacity (640)",
+             N);
+  if (lds > 64 * 1024)
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_pdoy_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int nd = d_doy_list ? ndl : ndoy;
+  dim3 grid((unsigned)cdiv64(C, 64), (unsigned)(nd > 1024 ? 1024 : nd));
+  hipLaunchKernelGGL(k_pdoy_lds, grid, dim3(64), lds, ctx->stream, x, T, C, st, d_tbase, nyears, ndoy, window, NP, d_q, nper,
+                     alpha, beta, out, d_vmap, Tv, d_doy_list, ndl);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
 static int launch_pdoy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tbase, int nyears,
                        int ndoy, int window, const double* d_q, int nper, double alpha, double beta, double* out) {
   int N = nyears * window;
@@ -368,40 +585,24 @@ static int launch_pdoy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
     hipLaunchKernelGGL((k_pdoy_reg<32, 1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, d_tbase, nyears, ndoy,
                        window, d_q, nper, alpha, beta, out);
   } else {
-    int NP = next_pow2(N);
-    size_t lds = (size_t)NP * 64 * sizeof(uint32_t);
-    XH_REQUIRE(lds <= 160 * 1024, XH_ERR_LIMIT,
-               "percentile: %d samples per cell exceed the per-wave LDS column capacity (640)", N);
-    if (lds > 64 * 1024) {
-      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_pdoy_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    dim3 grid((unsigned)cdiv64(C, 64), gy);
-    hipLaunchKernelGGL(k_pdoy_lds, grid, dim3(64), lds, ctx->stream, x, T, C, st, d_tbase, nyears, ndoy, window, NP, d_q,
-                       nper, alpha, beta, out);
+    return launch_pdoy_lds(ctx, x, T, C, st, d_tbase, nyears, ndoy, window, d_q, nper, alpha, beta, out, nullptr, T, nullptr,
+                           0);
   }
   XH_LAUNCH_CHECK();
   return XH_OK;
 }
 
-extern "C" {
-
-int xh_percentile_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* tbase,
-                      int nyears, int ndoy, int window, const double* per, int nper, double alpha, double beta,
-                      double* out) {
-  XH_REQUIRE(ctx && x && tbase && per && out, XH_ERR_ARG, "xh_percentile_doy: NULL argument");
-  XH_REQUIRE(T >= 1 && C >= 0 && nyears >= 1 && ndoy >= 1 && window >= 1 && nper >= 1, XH_ERR_ARG,
-             "xh_percentile_doy: bad shape");
-  XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_percentile_doy: needs a time-major view (sc == 1, st >= C)");
-  for (int j = 0; j < nper; ++j)
-    XH_REQUIRE(per[j] >= 0.0 && per[j] <= 100.0, XH_ERR_ARG, "xh_percentile_doy: percentile %g outside [0, 100]", per[j]);
-  if (C == 0) return XH_OK;
-  double qh[64];
-  XH_REQUIRE(nper <= 64, XH_ERR_LIMIT, "xh_percentile_doy: at most 64 percentiles per call");
-  for (int j = 0; j < nper; ++j) qh[j] = per[j] / 100.0;  // utl:366
+// Shared implementation of xh_percentile_doy / xh_percentile_doy_mapped.  `vmap` (host, Tv entries, may be NULL) maps
+// the virtual time axis the calendar tables refer to onto physical rows of x (-1 = day absent): the bootstrap of
+// core/bootstrapping.py:235-282 becomes a different index table per replica instead of a deep copy of the base period.
+static int pdoy_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* tbase, int nyears,
+                     int ndoy, int window, const double* qh, int nper, double alpha, double beta, const int32_t* vmap,
+                     int64_t Tv, double* out) {
   size_t cur = 0;
-  void *d_tb = nullptr, *d_q = nullptr;
+  void *d_tb = nullptr, *d_q = nullptr, *d_vmap = nullptr;
+  const int N = nyears * window;
   // fast path: one year of contiguous days -> sliding register window
-  bool contiguous = nyears == 1 && nper <= 8 && (window == 3 || window == 5 || window == 7) && tbase[0] >= 0;
+  bool contiguous = !vmap && nyears == 1 && nper <= 8 && (window == 3 || window == 5 || window == 7) && tbase[0] >= 0;
   for (int d = 1; contiguous && d < ndoy; ++d) contiguous = tbase[d] == tbase[0] + d;
   if (contiguous) {
     QTab tab[8 * 8];
@@ -429,8 +630,127 @@ int xh_percentile_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t
   if (rc) return rc;
   rc = xh_scratch_upload(ctx, &cur, qh, sizeof(double) * nper, &d_q);
   if (rc) return rc;
-  return launch_pdoy(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const double*)d_q, nper, alpha, beta,
-                     out);
+  if (vmap) {
+    rc = xh_scratch_upload(ctx, &cur, vmap, sizeof(int32_t) * (size_t)Tv, &d_vmap);
+    if (rc) return rc;
+  }
+  if (!vmap && N <= 32)
+    return launch_pdoy(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const double*)d_q, nper, alpha, beta,
+                       out);
+  const bool mergeable = N > 32 && nyears <= 64 && (window == 3 || window == 5 || window == 7) && nper <= 16;
+  if (!mergeable)
+    return launch_pdoy_lds(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const double*)d_q, nper, alpha,
+                           beta, out, (const int32_t*)d_vmap, Tv, nullptr, 0);
+  // ---- merge path: flag the doys for which "window sample set == union of the W day-sets" holds exactly
+  const int half = window / 2;
+  uint8_t* regular = (uint8_t*)malloc((size_t)ndoy);
+  int32_t* irregular = (int32_t*)malloc(sizeof(int32_t) * (size_t)ndoy);
+  QTab* tab = (QTab*)malloc(sizeof(QTab) * (size_t)nper * (N + 1));
+  if (!regular || !irregular || !tab) {
+    free(regular); free(irregular); free(tab);
+    xh_set_error("xh_percentile_doy: out of host memory");
+    return XH_ERR_ARG;
+  }
+  int nirr = 0;
+  for (int d = 0; d < ndoy; ++d) {
+    bool ok = true;
+    for (int y = 0; ok && y < nyears; ++y) {
+      int v = tbase[(int64_t)y * ndoy + d];
+      for (int k = 0; ok && k < window; ++k) {
+        int64_t a = -1;  // virtual index the window semantic reads
+        if (v >= 0) {
+          int64_t t = (int64_t)v - half + k;
+          if (t >= 0 && t < Tv) a = t;
+        }
+        int dn = d - half + k;
+        int64_t b = (dn >= 0 && dn < ndoy) ? (int64_t)tbase[(int64_t)y * ndoy + dn] : -1;
+        // compare the PHYSICAL rows (two virtual days may map to the same / to an absent row)
+        int64_t pa = a < 0 ? -1 : (vmap ? vmap[a] : a), pb = b < 0 ? -1 : (vmap ? vmap[b] : b);
+        if (pa >= T) pa = -1;
+        if (pb >= T) pb = -1;
+        ok = pa == pb;
+      }
+    }
+    regular[d] = ok ? 1 : 0;
+    if (!ok) irregular[nirr++] = d;
+  }
+  build_qtab(N, qh, nper, alpha, beta, tab);
+  // deepest pop from either end over all percentiles and valid counts (same from_top rule as the kernel)
+  int KT = 1, KB = 0;
+  for (int j = 0; j < nper; ++j)
+    for (int n = 0; n <= N; ++n) {
+      const QTab& e = tab[j * (N + 1) + n];
+      if (e.lo < 0) continue;
+      if ((n - 1 - e.hi) < e.lo) { if (n - e.lo > KT) KT = n - e.lo; }
+      else { if (e.hi + 1 > KB) KB = e.hi + 1; }
+    }
+  if (KT > nyears) KT = nyears;
+  if (KB > nyears) KB = nyears;
+  if (KT + KB >= nyears) { KT = nyears; KB = 0; }  // full mode: whole list in ringT, bottom pops index it from the end
+  void *d_reg = nullptr, *d_tab = nullptr, *d_irr = nullptr;
+  rc = xh_scratch_upload(ctx, &cur, regular, (size_t)ndoy, &d_reg);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, tab, sizeof(QTab) * (size_t)nper * (N + 1), &d_tab);
+  if (!rc && nirr) rc = xh_scratch_upload(ctx, &cur, irregular, sizeof(int32_t) * (size_t)nirr, &d_irr);
+  free(regular); free(irregular); free(tab);
+  if (rc) return rc;
+  const int chunk = 24;
+  const int NYP = nyears <= 32 ? 32 : 64;
+  size_t lds = ((size_t)window * (KT + KB) * 64 + (size_t)window * 64) * sizeof(uint32_t);
+  dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
+  dim3 grid_irr((unsigned)cdiv64(C, 64), (unsigned)(nirr > 0 ? nirr : 1));
+#define XH_MERGE(W, NY)                                                                                                    \
+  do {                                                                                                                     \
+    if (lds > 64 * 1024) {                                                                                                 \
+      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_pdoy_merge<W, NY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds));                                                                         \
+      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_pdoy_merge<W, NY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                       (int)lds));                                                                         \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((k_pdoy_merge<W, NY, false>), grid, dim3(64), lds, ctx->stream, x, T, C, st, (const int32_t*)d_tb,   \
+                       nyears, ndoy, chunk, (const QTab*)d_tab, nper, out, (const int32_t*)d_vmap, Tv,                      \
+                       (const uint8_t*)d_reg, (const int32_t*)nullptr, 0, KT, KB);                                          \
+    if (nirr)                                                                                                              \
+      hipLaunchKernelGGL((k_pdoy_merge<W, NY, true>), grid_irr, dim3(64), lds, ctx->stream, x, T, C, st,                    \
+                         (const int32_t*)d_tb, nyears, ndoy, chunk, (const QTab*)d_tab, nper, out, (const int32_t*)d_vmap,  \
+                         Tv, (const uint8_t*)d_reg, (const int32_t*)d_irr, nirr, KT, KB);                                   \
+  } while (0)
+  if (NYP == 32) {
+    if (window == 3) XH_MERGE(3, 32); else if (window == 5) XH_MERGE(5, 32); else XH_MERGE(7, 32);
+  } else {
+    if (window == 3) XH_MERGE(3, 64); else if (window == 5) XH_MERGE(5, 64); else XH_MERGE(7, 64);
+  }
+#undef XH_MERGE
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+extern "C" {
+
+int xh_percentile_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* tbase,
+                      int nyears, int ndoy, int window, const double* per, int nper, double alpha, double beta,
+                      double* out) {
+  return xh_percentile_doy_mapped(ctx, x, T, C, st, sc, tbase, nyears, ndoy, window, per, nper, alpha, beta, nullptr, T, out);
+}
+
+int xh_percentile_doy_mapped(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
+                             const int32_t* tbase, int nyears, int ndoy, int window, const double* per, int nper,
+                             double alpha, double beta, const int32_t* vmap, int64_t Tv, double* out) {
+  XH_REQUIRE(ctx && x && tbase && per && out, XH_ERR_ARG, "xh_percentile_doy: NULL argument");
+  XH_REQUIRE(T >= 1 && C >= 0 && nyears >= 1 && ndoy >= 1 && window >= 1 && nper >= 1 && Tv >= 1, XH_ERR_ARG,
+             "xh_percentile_doy: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_percentile_doy: needs a time-major view (sc == 1, st >= C)");
+  XH_REQUIRE(nper <= 64, XH_ERR_LIMIT, "xh_percentile_doy: at most 64 percentiles per call");
+  for (int j = 0; j < nper; ++j)
+    XH_REQUIRE(per[j] >= 0.0 && per[j] <= 100.0, XH_ERR_ARG, "xh_percentile_doy: percentile %g outside [0, 100]", per[j]);
+  for (int64_t i = 0; i < (int64_t)nyears * ndoy; ++i)
+    XH_REQUIRE(tbase[i] >= -1 && tbase[i] < Tv, XH_ERR_ARG, "xh_percentile_doy: tbase entry out of range");
+  if (vmap)
+    for (int64_t i = 0; i < Tv; ++i)
+      XH_REQUIRE(vmap[i] >= -1 && vmap[i] < T, XH_ERR_ARG, "xh_percentile_doy: vmap entry out of range");
+  if (C == 0) return XH_OK;
+  double qh[64];
+  for (int j = 0; j < nper; ++j) qh[j] = per[j] / 100.0;  // utl:366
+  return pdoy_impl(ctx, x, T, C, st, tbase, nyears, ndoy, window, qh, nper, alpha, beta, vmap, Tv, out);
 }
 
 int xh_nan_quantile(xh_ctx* ctx, const float* x, int64_t N, int64_t C, int64_t sn, int64_t sc, const double* q, int nq,

@@ -230,15 +230,22 @@ def nan_quantile(dev: Device, x: DeviceArray, q, alpha=1.0, beta=1.0, sample_axi
 
 
 def percentile_doy(dev: Device, x: DeviceArray, tbase, window: int, per, alpha=1.0 / 3, beta=1.0 / 3,
-                   out=None) -> DeviceArray:
-    """Returns (nper, ndoy, C) float64 — percentile_doy before the 366-day adjustment."""
+                   out=None, vmap=None) -> DeviceArray:
+    """Returns (nper, ndoy, C) float64 — percentile_doy before the 366-day adjustment.
+
+    `vmap` (int32[Tv], optional): virtual-day -> physical-row table; `tbase` then indexes virtual days."""
     T, C_ = _tc(x)
     tb = np.ascontiguousarray(tbase, dtype=np.int32)
     nyears, ndoy = tb.shape
     per = np.ascontiguousarray(np.atleast_1d(per), dtype=np.float64)
     out = out if out is not None else dev.empty((len(per), ndoy, C_), np.float64)
-    dev.call("xh_percentile_doy", _vp(x.ptr), T, C_, C_, 1, np_ptr(tb), nyears, ndoy, int(window), np_ptr(per), len(per),
-             float(alpha), float(beta), _vp(out.ptr))
+    if vmap is None:
+        dev.call("xh_percentile_doy", _vp(x.ptr), T, C_, C_, 1, np_ptr(tb), nyears, ndoy, int(window), np_ptr(per), len(per),
+                 float(alpha), float(beta), _vp(out.ptr))
+    else:
+        vm = np.ascontiguousarray(vmap, dtype=np.int32)
+        dev.call("xh_percentile_doy_mapped", _vp(x.ptr), T, C_, C_, 1, np_ptr(tb), nyears, ndoy, int(window), np_ptr(per),
+                 len(per), float(alpha), float(beta), np_ptr(vm), len(vm), _vp(out.ptr))
     return out
 
 
