@@ -185,6 +185,37 @@ def test_generic_mirror_vs_oracle(dev, rng):
         xgen.threshold_count(x, "=>", 1.0, ta, "YS", device=dev)
 
 
+@pytest.mark.parametrize("calendar,start,nyears,base,freq", [("noleap", "2000-01-01", 7, (2001, 2004), "YS"),
+                                                             ("noleap", "2000-01-01", 6, (2000, 2003), "MS"),
+                                                             ("standard", "1998-01-01", 7, (1999, 2002), "YS"),
+                                                             ("standard", "1999-01-01", 5, (1999, 2001), "QS-DEC")])
+def test_percentile_bootstrap(dev, rng, calendar, start, nyears, base, freq):
+    """core/bootstrapping.py: in-base years are averaged over n-1 replicas built through virtual time maps; must equal
+    the oracle, which materialises every replica like `build_bootstrap_year_da` (incl. the 365 <-> 366 rules)."""
+    from oracle import bootstrapping as oboot
+    from xclim_amd import bootstrapping as xboot
+
+    T = 365 * nyears + (sum(1 for y in range(int(start[:4]), int(start[:4]) + nyears) if y % 4 == 0) if calendar == "standard" else 0)
+    x = _temp(rng, T, (3, 4), nan_frac=0.003)
+    ta, ot = _axes(start, T, calendar)
+    got = xboot.bootstrap_exceedance(x, ta, base, freq, ">", 5, 90.0, device=dev)
+    exp = oboot.bootstrap_exceedance(x, ot, base, freq, ">", 5, 90.0)
+    assert got.shape == exp.shape
+    np.testing.assert_array_equal(got, exp)
+    # in-base years see fewer exceedances without the bootstrap (Zhang 2005; reference tests/test_bootstrapping.py:24-75)
+    from xclim_amd.calendar import percentile_doy as pdoy
+
+    b0 = int(np.nonzero(ta.year >= base[0])[0][0])
+    b1 = int(np.nonzero(ta.year <= base[1])[0][-1]) + 1
+    p = pdoy(x[b0:b1], ta.subset(slice(b0, b1)), 5, 90.0, device=dev)
+    plain = xi.tx90p(x, p, ta, freq=freq, device=dev, mask_missing=False)
+    seg, starts = ta.segments(freq)
+    inb = np.array([base[0] <= (y if (freq == "YS" or m != 12) else y + 1) <= base[1] for y, m in starts])
+    assert got[inb].sum() >= plain[inb].sum()
+    with pytest.raises(KeyError):
+        xboot.bootstrap_exceedance(x, ta, (int(start[:4]), int(start[:4]) + nyears), freq, device=dev)
+
+
 @pytest.mark.parametrize("k", range(7))
 def test_calc_perc_on_reference_golden_vectors(dev, k):
     """The apply_ufunc callee (utl:279-323) through the HIP path against the reference's own outputs."""
