@@ -133,6 +133,26 @@ int xh_domain_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t s
                     double thr1, int op2, double thr2, int combine, const int64_t* seg_off, int P,
                     int32_t* count_out, int32_t* valid_out);
 
+/* Two-variable counts: count_level_crossings (indices/generic.py:913-957) and bivariate_count_occurrences
+ * (generic.py:1002-1073): cond = (x1 op1 thr1) AND(1)|OR(2) (x2 op2 thr2), summed per period.  valid_out counts
+ * the days on which both variables are non-NaN. */
+int xh_bivariate_count(xh_ctx* ctx, const float* x1, const float* x2, int64_t T, int64_t C, int64_t st1, int64_t st2,
+                       int op1, double thr1, int op2, double thr2, int combine, const int64_t* seg_off, int P,
+                       int32_t* count_out, int32_t* valid_out);
+
+/* Thresholded reductions per period, out (P, C) float32:
+ *   mode 0 thresholded_statistics (generic.py:1278-1320): reducer (XH_RED_SUM|MEAN|MIN|MAX) of data.where(cond)
+ *   mode 1 temperature_sum        (generic.py:1323-1357): direction * sum((data - thr).where(cond))
+ *   mode 2 cumulative_difference  (generic.py:1514-1552): sum(clip(data - thr, 0)) or sum(clip(thr - data, 0)) */
+int xh_thresholded_reduce(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op,
+                          double thr, int mode, int reducer, const int64_t* seg_off, int P, float* out,
+                          int32_t* valid_out);
+
+/* climatological_mean_doy (core/calendar.py:907-931): per-doy nanmean / nanstd (ddof 0) over all years and the
+ * centred window; same tbase table as xh_percentile_doy.  mean_out, std_out (ndoy, C) float32. */
+int xh_doy_mean_std(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* tbase,
+                    int nyears, int ndoy, int window, float* mean_out, float* std_out);
+
 /* select_resample_op (indices/generic.py:83-125): segmented reduction over periods.
  *   float reducers write float32 `out` (P, C) (fp64 accumulation); COUNT/ARGMIN/ARGMAX write int32.
  *   skipna != 0: NaN ignored (all-NaN -> NaN, SUM -> 0) as xarray's default for floats.

@@ -52,6 +52,25 @@ def percentile_doy(arr, time: OTime, window=5, per=10.0, alpha=1.0 / 3.0, beta=1
     return p, doys
 
 
+def climatological_mean_doy(arr, time: OTime, window=5):
+    """cal:907-931: rolling(center, min_periods=1).construct -> groupby dayofyear -> mean / std over (time, window)."""
+    import warnings
+
+    arr = np.asarray(arr)
+    rr = rolling_construct_center(arr, window)  # (T, ..., w)
+    doys = np.unique(time.doy)
+    m = np.empty((len(doys),) + arr.shape[1:], dtype=arr.dtype)
+    s = np.empty_like(m)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for i, d in enumerate(doys):
+            g = np.moveaxis(rr[time.doy == d], -1, 1)  # (nyears, w, ...)
+            g = g.reshape((-1,) + arr.shape[1:]).astype(np.float64)
+            m[i] = np.nanmean(g, axis=0)
+            s[i] = np.nanstd(g, axis=0)
+    return m, s, doys
+
+
 def interpolate_doy_calendar(source, src_doys, doy_max, doy_min=1):
     """cal:690-726 `_interpolate_doy_calendar`: interpolate_na (linear in the doy coordinate, NaN beyond the outer
     valid points), relabel to linspace(doy_min, doy_max, n), then scipy interp1d (xarray's `interp` path for N-D

@@ -63,6 +63,47 @@ def count_occurrences(da, threshold, op, time: OTime, freq, constrain=None):
     return _resample_reduce(c, time, freq, lambda g: g.sum(axis=0))
 
 
+def count_level_crossings(low, high, threshold, time: OTime, freq, op_low="<", op_high=">="):
+    """gen:913-957."""
+    c = (compare(low, op_low, threshold, ("<", "<=")) & compare(high, op_high, threshold, (">", ">="))) * 1
+    return _resample_reduce(c, time, freq, lambda g: g.sum(axis=0))
+
+
+def bivariate_count_occurrences(v1, v2, t1, t2, time: OTime, freq, op1, op2, var_reducer):
+    """gen:1002-1073."""
+    c1, c2 = compare(v1, op1, t1), compare(v2, op2, t2)
+    c = ((c1 & c2) if var_reducer == "all" else (c1 | c2)) * 1
+    return _resample_reduce(c, time, freq, lambda g: g.sum(axis=0))
+
+
+def thresholded_statistics(data, op, threshold, reducer, time: OTime, freq):
+    """gen:1278-1320: getattr(data.where(cond).resample(time=freq), reducer)()."""
+    data = np.asarray(data)
+    masked = np.where(compare(data, op, threshold), data, np.nan).astype(data.dtype)
+    return _resample_reduce(masked, time, freq, lambda g: _nanreduce(g, reducer))
+
+
+def temperature_sum(data, op, threshold, time: OTime, freq):
+    """gen:1323-1357."""
+    data = np.asarray(data)
+    cond = compare(data, op, threshold, ("<", "<=", ">", ">="))
+    direction = -1 if op in ["<", "<=", "lt", "le"] else 1
+    d = np.where(cond, data - threshold, np.nan).astype(data.dtype)
+    return direction * _resample_reduce(d, time, freq, lambda g: _nanreduce(g, "sum"))
+
+
+def cumulative_difference(data, threshold, op, time: OTime, freq):
+    """gen:1514-1552."""
+    data = np.asarray(data)
+    if op in ["<", "<=", "lt", "le"]:
+        diff = np.clip(threshold - data, 0, None)
+    elif op in [">", ">=", "gt", "ge"]:
+        diff = np.clip(data - threshold, 0, None)
+    else:
+        raise NotImplementedError(f"Condition not supported: '{op}'.")
+    return _resample_reduce(diff.astype(data.dtype), time, freq, lambda g: _nanreduce(g, "sum"))
+
+
 def _nanreduce(g, op, acc_dtype=np.float64):
     """xarray's default float reductions (skipna=True) on one group; accumulation dtype stated: fp64."""
     with warnings.catch_warnings():

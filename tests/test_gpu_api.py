@@ -216,6 +216,47 @@ def test_percentile_bootstrap(dev, rng, calendar, start, nyears, base, freq):
         xboot.bootstrap_exceedance(x, ta, (int(start[:4]), int(start[:4]) + nyears), freq, device=dev)
 
 
+def test_bivariate_and_thresholded_generic(dev, rng):
+    T = 800
+    tn = _temp(rng, T, (5, 4), nan_frac=0.01) - 15
+    tx = tn + np.abs(rng.normal(6, 2, tn.shape)).astype(np.float32)
+    ta, ot = _axes("2000-05-01", T)
+    for freq in ("YS", "MS"):
+        np.testing.assert_array_equal(xgen.count_level_crossings(tn, tx, 273.15, ta, freq, device=dev),
+                                      ogen.count_level_crossings(tn, tx, 273.15, ot, freq))
+        for red in ("all", "any"):
+            got = xgen.bivariate_count_occurrences(data_var1=tn, data_var2=tx, threshold_var1=270.0, threshold_var2=285.0, time=ta,
+                                                   freq=freq, op_var1="<", op_var2=">", var_reducer=red, device=dev)
+            np.testing.assert_array_equal(got, ogen.bivariate_count_occurrences(tn, tx, 270.0, 285.0, ot, freq, "<", ">", red))
+        for red in ("sum", "mean", "min", "max"):
+            got = xgen.thresholded_statistics(tx, ">", 285.0, red, ta, freq, device=dev)
+            np.testing.assert_allclose(got, ogen.thresholded_statistics(tx, ">", 285.0, red, ot, freq), rtol=1e-6, equal_nan=True)
+        for op in (">", "<="):
+            np.testing.assert_allclose(xgen.temperature_sum(tx, op, 283.0, ta, freq, device=dev),
+                                       ogen.temperature_sum(tx, op, 283.0, ot, freq), rtol=1e-6, atol=1e-4)
+            np.testing.assert_allclose(xgen.cumulative_difference(tx, 283.0, op, ta, freq, device=dev),
+                                       ogen.cumulative_difference(tx, 283.0, op, ot, freq), rtol=1e-6, atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        xgen.cumulative_difference(tx, 283.0, "==", ta, "YS", device=dev)
+    with pytest.raises(ValueError):
+        xgen.bivariate_count_occurrences(data_var1=tn, data_var2=tx, threshold_var1=0, threshold_var2=0, time=ta, freq="YS",
+                                         op_var1="<", op_var2=">", var_reducer="some", device=dev)
+
+
+@pytest.mark.parametrize("calendar", ["standard", "noleap"])
+def test_climatological_mean_doy(dev, rng, calendar):
+    from xclim_amd.calendar import climatological_mean_doy
+
+    T = 365 * 4 + (1 if calendar == "standard" else 0)
+    x = _temp(rng, T, (3, 5), nan_frac=0.01)
+    ta, ot = _axes("2000-01-01", T, calendar)
+    m, s, doys = climatological_mean_doy(x, ta, window=5, device=dev)
+    em, es, edoys = ocal.climatological_mean_doy(x, ot, 5)
+    np.testing.assert_array_equal(doys, edoys)
+    np.testing.assert_allclose(m, em, rtol=1e-6)
+    np.testing.assert_allclose(s, es, rtol=2e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("k", range(7))
 def test_calc_perc_on_reference_golden_vectors(dev, k):
     """The apply_ufunc callee (utl:279-323) through the HIP path against the reference's own outputs."""

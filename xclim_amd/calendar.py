@@ -102,6 +102,17 @@ def percentile_doy(arr, time: TimeAxis, window: int = 5, per=10.0, alpha: float 
     return DoyPercentile(p, doys, pers, cell_shape, attrs)
 
 
+def climatological_mean_doy(arr, time: TimeAxis, window: int = 5, *, device=None):
+    """cal:907-931: (mean, std) per day of year over all years and a centred `window`; numpy (ndoy, *cells) float32,
+    plus the day-of-year coordinate."""
+    dev = device or get_device()
+    x, cell_shape = _flatten(arr, dev)
+    tb, years, doys = time.doy_table()
+    m, s = K.doy_mean_std(dev, x, tb, window)
+    shp = (len(doys),) + tuple(cell_shape)
+    return m.get().reshape(shp), s.get().reshape(shp), doys
+
+
 def adjust_doy_calendar(source: DoyPercentile, target_time: TimeAxis, device=None) -> DoyPercentile:
     """cal:729-760: re-grid the doy axis when the source does not span the target calendar's full year."""
     dev = device or get_device()

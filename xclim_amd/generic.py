@@ -92,6 +92,68 @@ def domain_count(da, low: float, high: float, time: TimeAxis, freq: str, *, devi
     return _finish(cnt, val, cell_shape, keep, with_valid)
 
 
+def count_level_crossings(low_data, high_data, threshold: float, time: TimeAxis, freq: str, *, op_low: str = "<",
+                          op_high: str = ">=", device=None, keep=False, with_valid=False):
+    """gen:913-957: days with `low_data op_low threshold` AND `high_data op_high threshold` (freeze-thaw cycles)."""
+    dev = device or get_device()
+    lo, cell_shape = _flatten(low_data, dev)
+    hi, _ = _flatten(high_data, dev)
+    seg, _ = time.segments(freq)
+    cnt, val = K.bivariate_count(dev, lo, hi, get_op(op_low, ("<", "<=")), threshold, get_op(op_high, (">", ">=")), threshold,
+                                 "all", seg)
+    return _finish(cnt, val, cell_shape, keep, with_valid)
+
+
+def bivariate_count_occurrences(*, data_var1, data_var2, threshold_var1: float, threshold_var2: float, time: TimeAxis,
+                                freq: str, op_var1: str, op_var2: str, var_reducer: str, constrain_var1=None,
+                                constrain_var2=None, device=None, keep=False, with_valid=False):
+    """gen:1002-1073: count days where the two conditions hold for `all` / `any` of the variables."""
+    if var_reducer not in ("all", "any"):
+        raise ValueError(f"Unsupported value for var_reducer: {var_reducer}")
+    dev = device or get_device()
+    a, cell_shape = _flatten(data_var1, dev)
+    b, _ = _flatten(data_var2, dev)
+    seg, _ = time.segments(freq)
+    cnt, val = K.bivariate_count(dev, a, b, get_op(op_var1, constrain_var1), threshold_var1, get_op(op_var2, constrain_var2),
+                                 threshold_var2, var_reducer, seg)
+    return _finish(cnt, val, cell_shape, keep, with_valid)
+
+
+def _thresholded(data, op, threshold, mode, reducer, time, freq, constrain, device, keep, with_valid):
+    sym = get_op(op, constrain)
+    dev = device or get_device()
+    x, cell_shape = _flatten(data, dev)
+    seg, _ = time.segments(freq)
+    out, val = K.thresholded_reduce(dev, x, sym, float(threshold), mode, reducer, seg)
+    return _finish(out, val, cell_shape, keep, with_valid)
+
+
+def statistics(data, reducer: str, time: TimeAxis, freq: str, **kw):
+    """gen:1255-1275: data.resample(time=freq).<max|min|mean|sum>()."""
+    return select_resample_op(data, reducer, time, freq, **kw)
+
+
+def thresholded_statistics(data, op: str, threshold: float, reducer: str, time: TimeAxis, freq: str, constrain=None, *,
+                           device=None, keep=False, with_valid=False):
+    """gen:1278-1320: reducer of the values that satisfy `data op threshold`."""
+    if reducer not in ("max", "min", "mean", "sum"):
+        raise ValueError(f"Reducer `{reducer}` not recognized.")
+    return _thresholded(data, op, threshold, 0, reducer, time, freq, constrain, device, keep, with_valid)
+
+
+def temperature_sum(data, op: str, threshold: float, time: TimeAxis, freq: str, *, device=None, keep=False, with_valid=False):
+    """gen:1323-1357: direction * sum of (data - threshold) over the days satisfying the condition (degree-days)."""
+    return _thresholded(data, op, threshold, 1, "sum", time, freq, ("<", "<=", ">", ">="), device, keep, with_valid)
+
+
+def cumulative_difference(data, threshold: float, op: str, time: TimeAxis, freq: str, *, device=None, keep=False,
+                          with_valid=False):
+    """gen:1514-1552: sum over the period of the positive part of (data - threshold) or (threshold - data)."""
+    if get_op(op) not in ("<", "<=", ">", ">="):
+        raise NotImplementedError(f"Condition not supported: '{op}'.")
+    return _thresholded(data, op, threshold, 2, "sum", time, freq, None, device, keep, with_valid)
+
+
 def select_resample_op(da, op: str, time: TimeAxis, freq: str = "YS", *, device=None, keep=False, with_valid=False):
     """gen:83-125 (string ops, no indexer): min/max/mean/std/var/count/sum/integral/argmax/argmin per period."""
     dev = device or get_device()

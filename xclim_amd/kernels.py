@@ -168,6 +168,36 @@ def run_stats(dev: Device, x: DeviceArray, stat: str, window: int, seg_off, *, c
     return out, valid
 
 
+def bivariate_count(dev: Device, x1: DeviceArray, x2: DeviceArray, op1, thr1, op2, thr2, combine, seg_off, want_valid=True):
+    T, C_ = _tc(x1)
+    assert x2.shape == x1.shape
+    seg, P = _seg(seg_off)
+    count = dev.empty((P, C_), np.int32)
+    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    dev.call("xh_bivariate_count", _vp(x1.ptr), _vp(x2.ptr), T, C_, C_, C_, op_code(op1), float(thr1), op_code(op2), float(thr2),
+             {"all": 1, "and": 1, "any": 2, "or": 2}[combine], np_ptr(seg), P, _vp(count.ptr), _vp(valid.ptr if valid else 0))
+    return count, valid
+
+
+def thresholded_reduce(dev: Device, x: DeviceArray, op, thr, mode: int, reducer: str, seg_off, want_valid=True):
+    T, C_ = _tc(x)
+    seg, P = _seg(seg_off)
+    out = dev.empty((P, C_), np.float32)
+    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    dev.call("xh_thresholded_reduce", _vp(x.ptr), T, C_, C_, 1, op_code(op), float(thr), int(mode), REDUCERS.get(reducer, 0),
+             np_ptr(seg), P, _vp(out.ptr), _vp(valid.ptr if valid else 0))
+    return out, valid
+
+
+def doy_mean_std(dev: Device, x: DeviceArray, tbase, window: int):
+    T, C_ = _tc(x)
+    tb = np.ascontiguousarray(tbase, dtype=np.int32)
+    nyears, ndoy = tb.shape
+    m, s = dev.empty((ndoy, C_), np.float32), dev.empty((ndoy, C_), np.float32)
+    dev.call("xh_doy_mean_std", _vp(x.ptr), T, C_, C_, 1, np_ptr(tb), nyears, ndoy, int(window), _vp(m.ptr), _vp(s.ptr))
+    return m, s
+
+
 WIN_REDUCERS = {"sum": 0, "mean": 1, "min": 2, "max": 3, "wmean": 4}
 
 
