@@ -148,6 +148,11 @@ int xh_thresholded_reduce(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int
                           double thr, int mode, int reducer, const int64_t* seg_off, int P, float* out,
                           int32_t* valid_out);
 
+/* da.where(lo[p] <= t - seg_off[p] < hi[p]).fillna(0) as a 0/1 mask (invert != 0: of NOT da): the masking step of
+ * first_run_after_date / last_run_before_date / first_run_before_date / run_end_after_date (run_length.py:1148-1331). */
+int xh_mask_rows(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int64_t* seg_off, int P,
+                 const int32_t* lo, const int32_t* hi, int invert, float* out, int64_t out_st);
+
 /* climatological_mean_doy (core/calendar.py:907-931): per-doy nanmean / nanstd (ddof 0) over all years and the
  * centred window; same tbase table as xh_percentile_doy.  mean_out, std_out (ndoy, C) float32. */
 int xh_doy_mean_std(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* tbase,

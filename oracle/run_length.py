@@ -375,6 +375,41 @@ def first_run_after_date(da, window, date, time: OTime):
     return first_run(da, window)
 
 
+def last_run_before_date(da, window, date, time: OTime):
+    """rl:1247-1284."""
+    da = np.asarray(da, dtype=np.float64)
+    idx = _date_index(time, date)
+    if idx.size == 0:
+        return np.full(da.shape[1:], np.nan)
+    da = da.copy()
+    da[idx[0] + 1 :] = np.nan  # da.where(t <= t[mid])
+    return last_run(da, window)
+
+
+def run_end_after_date(da, window, date, time: OTime):
+    """rl:1148-1201 with coord=False."""
+    da = np.asarray(da).astype(bool)
+    T = da.shape[0]
+    idx = _date_index(time, date)
+    if idx.size == 0:
+        return np.full(da.shape[1:], np.nan)
+    mid = idx[0]
+    nd = (~da).astype(np.float64)
+    nd[:mid] = np.nan
+    end = first_run(nd, window)
+    d2 = da.astype(np.float64)
+    d2[mid:] = np.nan
+    beg = first_run(d2, window)
+    with np.errstate(invalid="ignore"):
+        end = np.where(np.isnan(end) & ~np.isnan(beg), T - 1, end)
+    return np.where(np.isnan(beg), np.nan, end)
+
+
+def map_groups_fn(fn, da, time: OTime, freq, *args):
+    """resample(time=freq).map(fn): apply a one-group function to every period and stack."""
+    return np.stack([fn(np.asarray(da)[idx], *args, time.isel(idx)) for _, idx in groups(time, freq)], axis=0)
+
+
 def season(da, window, mid_date, time: OTime):
     """rl:998-1110 with coord=False: (start, end, length) index arrays for ONE group (time on axis 0)."""
     da = np.asarray(da).astype(bool)

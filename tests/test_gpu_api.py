@@ -243,6 +243,36 @@ def test_bivariate_and_thresholded_generic(dev, rng):
                                          op_var1="<", op_var2=">", var_reducer="some", device=dev)
 
 
+def test_occurrence_and_doy_extremes(dev, rng):
+    """first/last_occurrence, first_day_threshold_reached (gen:1108-1201, 1555-1608), doymax/doymin (gen:177-221)."""
+    T = 365 * 2 + 150
+    x = _temp(rng, T, (4, 5)) - 273.15
+    x[:, 0, 0] = 30.0  # constant: all-True condition (first_run quirk) and std == 0 (doymax -> NaN)
+    ta, ot = _axes("2001-01-01", T)
+
+    def omap(fn, cond, *a):
+        res = orl.map_groups_fn(fn, cond, ot, "YS", *a)
+        out = np.full(res.shape, np.nan)
+        for p, (_, idx) in enumerate(__import__("oracle.timeutil", fromlist=["groups"]).groups(ot, "YS")):
+            ok = ~np.isnan(res[p])
+            out[p][ok] = ot.doy[idx[0] + res[p][ok].astype(int)]
+        return out
+
+    cond = x > 20.0
+    np.testing.assert_array_equal(xgen.first_occurrence(x, 20.0, ">", ta, "YS", device=dev),
+                                  omap(lambda g, t: orl.first_run(g, 1), cond))
+    np.testing.assert_array_equal(xgen.last_occurrence(x, 20.0, ">", ta, "YS", device=dev),
+                                  omap(lambda g, t: orl.last_run(g, 1), cond))
+    got = xgen.first_day_threshold_reached(x, threshold=15.0, op=">", after_date="03-01", time=ta, window=3, freq="YS", device=dev)
+    np.testing.assert_array_equal(got, omap(lambda g, w, d, t: orl.first_run_after_date(g, w, d, t), x > 15.0, 3, "03-01"))
+    dm = xgen.doymax(x, ta, "YS", device=dev)
+    assert np.isnan(dm[:, 0, 0]).all()
+    seg, _ = ta.segments("YS")
+    exp = np.stack([ta.doy[seg[p] + np.argmax(x[seg[p]:seg[p + 1]], axis=0)] for p in range(len(seg) - 1)]).astype(float)
+    exp[:, 0, 0] = np.nan
+    np.testing.assert_array_equal(dm, exp)
+
+
 @pytest.mark.parametrize("calendar", ["standard", "noleap"])
 def test_climatological_mean_doy(dev, rng, calendar):
     from xclim_amd.calendar import climatological_mean_doy

@@ -136,6 +136,28 @@ def test_reference_season_answers(dev):
     assert od["start"][0] == 141 and od["end"][0] == 151
 
 
+@pytest.mark.parametrize("window", [1, 2, 4])
+@pytest.mark.parametrize("date", ["07-01", "03-15"])
+def test_date_bounded_runs(dev, rng, window, date):
+    """first_run_after_date / last_run_before_date / first_run_before_date / run_end_after_date (rl:1148-1331)."""
+    T, C = 365 * 2 + 200, 70
+    a = rng.random((T, C)) < 0.55
+    a[:, 0] = True
+    a[:, 1] = False
+    ta, ot = TimeAxis.daily("2001-01-01", T), OTime.standard("2001-01-01", T)
+    for xfn, ofn in ((xrl.first_run_after_date, orl.first_run_after_date), (xrl.last_run_before_date, orl.last_run_before_date),
+                     (xrl.first_run_before_date, orl.first_run_before_date), (xrl.run_end_after_date, orl.run_end_after_date)):
+        got = xfn(a, window, date, time=ta, freq="YS", device=dev)
+        exp = orl.map_groups_fn(ofn, a, ot, "YS", window, date)
+        np.testing.assert_array_equal(got, exp, err_msg=xfn.__name__)
+    # the third "year" has only 200 days: 07-01 is inside (day 181), the group is still handled; an absent date -> NaN
+    short = xrl.first_run_after_date(a[:100], 2, "07-01", time=ta.subset(slice(0, 100)), device=dev)
+    assert np.isnan(short).all()
+    g = xrl.first_run_after_date(a[:365], window, date, coord="dayofyear", time=ta.subset(slice(0, 365)), device=dev)
+    e = orl.first_run_after_date(a[:365], window, date, ot.isel(slice(0, 365)))
+    np.testing.assert_array_equal(g, e + 1)
+
+
 @pytest.mark.parametrize("window", [1, 3])
 def test_windowed_max_run_sum(dev, rng, window):
     T, C = 300, 60

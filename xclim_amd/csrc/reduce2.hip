@@ -127,6 +127,25 @@ k_doy_mean_std(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, co
   }
 }
 
+// ---- row-range masking (da.where(t in range), fillna(0)) used by the date-bounded run functions (rl:1148-1331) ----
+__global__ void __launch_bounds__(XH_BLOCK)
+k_mask_rows(const float* __restrict__ x, int64_t C, int64_t st, const int64_t* __restrict__ seg_off, int P,
+            const int32_t* __restrict__ lo, const int32_t* __restrict__ hi, int invert, float* __restrict__ out,
+            int64_t out_st) {
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    for (int64_t t = t0; t < t1; ++t) {
+      int i = (int)(t - t0);
+      float v = x[t * st + c];
+      bool on = v > 0.0f;
+      if (invert) on = !on;  // (~da)
+      out[t * out_st + c] = (i >= lo[p] && i < hi[p] && on) ? 1.0f : 0.0f;
+    }
+  }
+}
+
 static int chk2(const char* fn, xh_ctx* ctx, const void* x, int64_t T, int64_t C, int64_t st, int64_t sc) {
   XH_REQUIRE(ctx && x, XH_ERR_ARG, "%s: NULL argument", fn);
   XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "%s: negative shape", fn);
@@ -198,6 +217,28 @@ int xh_thresholded_reduce(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int
   else
     hipLaunchKernelGGL((k_thresholded_reduce<1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, op, (float)thr, mode,
                        reducer, d_seg, P, out, valid_out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_mask_rows(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int64_t* seg_off, int P,
+                 const int32_t* lo, const int32_t* hi, int invert, float* out, int64_t out_st) {
+  int rc = chk2("xh_mask_rows", ctx, x, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(lo && hi && out && out_st >= C, XH_ERR_ARG, "xh_mask_rows: NULL argument or out_st < C");
+  size_t cur = 0;
+  const int64_t* d_seg = nullptr;
+  rc = up_seg(ctx, &cur, seg_off, P, T, "xh_mask_rows", &d_seg);
+  if (rc) return rc;
+  void *d_lo = nullptr, *d_hi = nullptr;
+  rc = xh_scratch_upload(ctx, &cur, lo, sizeof(int32_t) * (size_t)P, &d_lo);
+  if (rc) return rc;
+  rc = xh_scratch_upload(ctx, &cur, hi, sizeof(int32_t) * (size_t)P, &d_hi);
+  if (rc) return rc;
+  if (C == 0) return XH_OK;
+  dim3 grid((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P));
+  hipLaunchKernelGGL(k_mask_rows, grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, d_seg, P, (const int32_t*)d_lo,
+                     (const int32_t*)d_hi, invert, out, out_st);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

@@ -217,6 +217,66 @@ def spell_mask(data, window: int, win_reducer: str, op: str, thresh: float, min_
     return m.get().reshape((m.shape[0],) + tuple(cell_shape)).astype(bool)
 
 
+def _occurrence(data, threshold, op, time, freq, constrain, device, last):
+    from . import run_length as hrl
+
+    sym = get_op(op, constrain)
+    dev = device or get_device()
+    x, cell_shape = _flatten(data, dev)
+    cond = K.spell_mask(dev, x, 1, "min", sym, float(threshold))
+    seg, _ = time.segments(freq)
+    out, _ = K.run_stats(dev, cond, "last" if last else "first", 1, seg, cut=True, want_valid=False)
+    res = hrl._to_coord(out.get(), seg, "dayofyear", time)
+    return res.reshape((res.shape[0],) + tuple(cell_shape))
+
+
+def first_occurrence(data, threshold: float, op: str, time: TimeAxis, freq: str, constrain=None, *, device=None):
+    """gen:1108-1152: day of year of the first time step satisfying the condition in each period (NaN if none)."""
+    return _occurrence(data, threshold, op, time, freq, constrain, device, last=False)
+
+
+def last_occurrence(data, threshold: float, op: str, time: TimeAxis, freq: str, constrain=None, *, device=None):
+    """gen:1155-1201."""
+    return _occurrence(data, threshold, op, time, freq, constrain, device, last=True)
+
+
+def first_day_threshold_reached(data, *, threshold: float, op: str, after_date: str, time: TimeAxis, window: int = 1,
+                                freq: str = "YS", constrain=None, device=None):
+    """gen:1555-1608: day of year of the first run of `window` days satisfying the condition on/after `after_date`."""
+    from . import run_length as hrl
+
+    sym = get_op(op, constrain)
+    dev = device or get_device()
+    x, cell_shape = _flatten(data, dev)
+    cond = K.spell_mask(dev, x, 1, "min", sym, float(threshold))
+    return hrl.first_run_after_date(cond.reshape((x.shape[0],) + tuple(cell_shape)), window, after_date, coord="dayofyear",
+                                    time=time, freq=freq, device=dev)
+
+
+def doymax(da, time: TimeAxis, freq: str = "YS", *, device=None):
+    """gen:177-198: day of year of the period maximum."""
+    return _doy_extreme(da, time, freq, "argmax", device)
+
+
+def doymin(da, time: TimeAxis, freq: str = "YS", *, device=None):
+    """gen:201-221."""
+    return _doy_extreme(da, time, freq, "argmin", device)
+
+
+def _doy_extreme(da, time, freq, which, device):
+    dev = device or get_device()
+    x, cell_shape = _flatten(da, dev)
+    seg, _ = time.segments(freq)
+    idx, _ = K.resample_reduce(dev, x, which, seg)
+    std, _ = K.resample_reduce(dev, x, "std", seg, want_valid=False)
+    i, s = idx.get(), std.get()
+    out = np.full(i.shape, np.nan)
+    for p in range(i.shape[0]):
+        ok = (i[p] >= 0) & (s[p] != 0)  # tmax.where(std != 0), gen:190-192
+        out[p, ok] = time.doy[int(seg[p]) + i[p, ok]]
+    return out.reshape((out.shape[0],) + tuple(cell_shape))
+
+
 def season(data, thresh: float, window: int, op: str, time: TimeAxis, freq: str, mid_date: str | None = None, *,
            device=None):
     """gen:769-853: start / end (as day of year) / length of the season per period.

@@ -189,6 +189,16 @@ def thresholded_reduce(dev: Device, x: DeviceArray, op, thr, mode: int, reducer:
     return out, valid
 
 
+def mask_rows(dev: Device, x: DeviceArray, seg_off, lo, hi, invert=False) -> DeviceArray:
+    T, C_ = _tc(x)
+    seg, P = _seg(seg_off)
+    lo = np.ascontiguousarray(lo, dtype=np.int32)
+    hi = np.ascontiguousarray(hi, dtype=np.int32)
+    out = dev.empty((T, C_), np.float32)
+    dev.call("xh_mask_rows", _vp(x.ptr), T, C_, C_, 1, np_ptr(seg), P, np_ptr(lo), np_ptr(hi), int(bool(invert)), _vp(out.ptr), C_)
+    return out
+
+
 def doy_mean_std(dev: Device, x: DeviceArray, tbase, window: int):
     T, C_ = _tc(x)
     tb = np.ascontiguousarray(tbase, dtype=np.int32)

@@ -202,6 +202,84 @@ def season_start(da, window: int, mid_date: str | None = None, dim="time", coord
     return season(da, window, mid_date, coord=coord, time=time, freq=freq, device=device)["start"]
 
 
+def _date_bounded(da, window, date, time, freq, device, *, side, invert=False, last=False):
+    """Shared body of the date-bounded run functions (rl:1148-1331): mask rows relative to `date`, then first/last run.
+
+    side: "ge" keep t >= date ; "le" keep t <= date ; "lt" keep t < date ; "lt_w" keep t < date + window - 1.
+    Returns ((P, C) float32 indices relative to the period start, seg, cell_shape)."""
+    dev = device or get_device()
+    m, cell_shape = _mask(da, dev)
+    T = m.shape[0]
+    seg = _whole(T) if freq is None else time.segments(freq)[0]
+    P = len(seg) - 1
+    lo = np.zeros(P, dtype=np.int32)
+    hi = np.zeros(P, dtype=np.int32)
+    absent = np.zeros(P, dtype=bool)
+    for p in range(P):
+        n = int(seg[p + 1] - seg[p])
+        if date is None:
+            lo[p], hi[p] = 0, n
+            continue
+        idx = index_of_date(time.subset(slice(int(seg[p]), int(seg[p + 1]))), date, max_idxs=None if side == "le" else 1,
+                            default=-1 if side == "le" else 0)
+        if idx.size == 0:
+            absent[p] = True
+            continue
+        mid = int(idx[0])
+        lo[p], hi[p] = {"ge": (mid, n), "le": (0, mid + 1), "lt": (0, mid), "lt_w": (0, min(n, mid + window - 1))}[side]
+    masked = K.mask_rows(dev, m, seg, lo, hi, invert=invert)
+    out, _ = K.run_stats(dev, masked, "last" if last else "first", window, seg, cut=True, want_valid=False)
+    res = out.get()
+    res[absent] = np.nan  # the date is not within the group (rl:1235-1237)
+    return res, seg, cell_shape
+
+
+def _to_coord(res, seg, coord, time):
+    if coord:
+        if coord != "dayofyear":
+            raise NotImplementedError("only coord='dayofyear' is supported")
+        for p in range(res.shape[0]):
+            ok = ~np.isnan(res[p])
+            res[p, ok] = time.doy[int(seg[p]) + res[p, ok].astype(np.int64)]
+    return res
+
+
+def _shape(res, cell_shape, freq):
+    out = res.reshape((res.shape[0],) + tuple(cell_shape))
+    return out[0] if freq is None else out
+
+
+def first_run_after_date(da, window: int, date: str | None = "07-01", dim="time", coord=False, *, time=None, freq=None,
+                         device=None):
+    """rl:1204-1244."""
+    res, seg, cs = _date_bounded(da, window, date, time, freq, device, side="ge")
+    return _shape(_to_coord(res, seg, coord, time), cs, freq)
+
+
+def last_run_before_date(da, window: int, date: str = "07-01", dim="time", coord=False, *, time=None, freq=None, device=None):
+    """rl:1247-1284."""
+    res, seg, cs = _date_bounded(da, window, date, time, freq, device, side="le", last=True)
+    return _shape(_to_coord(res, seg, coord, time), cs, freq)
+
+
+def first_run_before_date(da, window: int, date: str | None = "07-01", dim="time", coord=False, *, time=None, freq=None,
+                          device=None):
+    """rl:1287-1331."""
+    res, seg, cs = _date_bounded(da, window, date, time, freq, device, side="lt_w")
+    return _shape(_to_coord(res, seg, coord, time), cs, freq)
+
+
+def run_end_after_date(da, window: int, date: str = "07-01", dim="time", coord=False, *, time=None, freq=None, device=None):
+    """rl:1148-1201: end of the first run that started before `date` (first run of `window` False after the date)."""
+    end, seg, cs = _date_bounded(da, window, date, time, freq, device, side="ge", invert=True)
+    beg, _, _ = _date_bounded(da, window, date, time, freq, device, side="lt")
+    lens = np.diff(seg).astype(np.float32)[:, None]
+    with np.errstate(invalid="ignore"):
+        end = np.where(np.isnan(end) & ~np.isnan(beg), lens - 1, end)
+        end = np.where(np.isnan(beg), np.nan, end).astype(np.float32)
+    return _shape(_to_coord(end, seg, coord, time), cs, freq)
+
+
 _STATS = {"rle_statistics", "longest_run", "windowed_run_events", "windowed_run_count", "first_run", "last_run"}
 
 
