@@ -175,7 +175,7 @@ def main():
 
     extra = {}
     if not args.no_extra and rank == 0 and world == 1:
-        extra = bench_extra(dev, K, ta, T, C, seg, P, synth)
+        extra = bench_extra(dev, K, ta, T, C, seg, P, synth, tasmax, tb, per, len(doys))
 
     cpu = None
     if not args.no_cpu and rank == 0 and world == 1:
@@ -208,10 +208,15 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_extra(dev, K, ta, T, C, seg, P, synth):
+def bench_extra(dev, K, ta, T, C, seg, P, synth, tasmax, tb, per, D):
     """The other two north-star workloads on the same 365 x 1440 x 720 grid (HIP-event times, one GPU)."""
     out = {}
     E = float(T) * C
+    # --- percentile_doy at a percentile that needs the full sort + lerp (per = 90 with 5 samples clips to the sample
+    #     maximum, utl:443-447, and takes the no-sort fast path; per = 50 does not)
+    ms50 = event_time(dev, lambda: K.percentile_doy(dev, tasmax, tb, 5, [50.0], out=per), 10)
+    b50 = 4 * E + 8 * D * C
+    out["percentile_doy_per50"] = {"ms": ms50, "GB/s": b50 / ms50 / 1e6, "frac": b50 / ms50 / 1e6 / HBM_PEAK_GBS}
     # --- maximum_consecutive_dry_days: fused compare + run-length max + valid count ---
     pr = K.fill_synthetic(dev, T, C, 1, 3, np.zeros(T, np.float32), 40.0 / 86400.0, 0.3)
     o, v = dev.empty((P, C), np.float32), dev.empty((P, C), np.int32)

@@ -158,11 +158,17 @@ k_pdoy_slide(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int6
   int d0 = blockIdx.y * chunk, d1 = d0 + chunk;
   if (d1 > ndoy) d1 = ndoy;
   uint32_t win[VEC][W];
+  int n[VEC];  // valid keys currently in the window (maintained incrementally)
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { n[v] = 0; win[v][0] = 0xFFFFFFFFu; }
   auto loadrow = [&](int64_t t, int slot) {
     if (t >= 0 && t < T) {
       VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) win[v][slot] = xh_f2key(xv.v[v]);
+      for (int v = 0; v < VEC; ++v) {
+        win[v][slot] = xh_f2key(xv.v[v]);
+        n[v] += (xv.v[v] == xv.v[v]) ? 1 : 0;
+      }
     } else {
 #pragma unroll
       for (int v = 0; v < VEC; ++v) win[v][slot] = 0xFFFFFFFFu;
@@ -174,41 +180,82 @@ k_pdoy_slide(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int6
   for (int d = d0; d < d1; ++d) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
+      n[v] -= (win[v][0] != 0xFFFFFFFFu) ? 1 : 0;  // the day leaving the window
 #pragma unroll
       for (int k = 0; k < W - 1; ++k) win[v][k] = win[v][k + 1];
     }
     loadrow(t_first + d - half + (W - 1), W - 1);
+    bool full = true;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) full &= (n[v] == W);
+    // Wave-uniform fast path: no NaN in any window of the wave -> the table entry (lo, hi, gamma) is the same for
+    // all lanes, selection needs no per-lane index, and when the Hyndman-Fan index clips to the sample maximum /
+    // minimum (utl:443-452; e.g. per = 90 with 5 samples) no sort is needed at all.
+    const bool uniform = __all(full ? 1 : 0) != 0;
     uint32_t s[VEC][W];
-    int n[VEC];
+    bool sorted = false;
+    auto ensure_sorted = [&]() {
+      if (!sorted) {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      n[v] = 0;
+        for (int v = 0; v < VEC; ++v) {
 #pragma unroll
-      for (int k = 0; k < W; ++k) {
-        s[v][k] = win[v][k];
-        n[v] += (s[v][k] != 0xFFFFFFFFu) ? 1 : 0;
+          for (int k = 0; k < W; ++k) s[v][k] = win[v][k];
+          sort_small<W>(s[v]);
+        }
+        sorted = true;
       }
-      sort_small<W>(s[v]);
-    }
+    };
     for (int j = 0; j < nper; ++j) {
       double r[VEC];
+      if (uniform) {
+        const QTab e = s_tab[j * (W + 1) + W];
+        const int lo = __builtin_amdgcn_readfirstlane(e.lo), hi = __builtin_amdgcn_readfirstlane(e.hi);
+        if (lo == hi && (lo == W - 1 || lo == 0) && W > 1) {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        // register-array select written as an OR of masked values: a select chain gets folded back into a
-        // dynamically indexed (scratch) array by the optimizer
-        auto get = [&](int idx) -> float {
-          uint32_t g = 0;
+          for (int v = 0; v < VEC; ++v) {
+            uint32_t m = win[v][0];
 #pragma unroll
-          for (int i = 0; i < W; ++i) g |= (i == idx) ? s[v][i] : 0u;
-          return xh_key2f(g);
-        };
-        QTab e = s_tab[j * (W + 1) + n[v]];
-        float left = get(e.lo), right = get(e.hi);
-        float diff = right - left;
-        double rr = (double)left + (double)diff * e.gamma;
-        if (e.gamma >= 0.5) rr = (double)right - (double)diff * (1.0 - e.gamma);
-        if (rr != rr && n[v] > 0 && W > 1) rr = (double)get(n[v] - 1);
-        r[v] = (e.lo < 0) ? xh_nan64() : rr;
+            for (int k = 1; k < W; ++k) m = (lo == 0) ? (win[v][k] < m ? win[v][k] : m) : (win[v][k] > m ? win[v][k] : m);
+            r[v] = (double)xh_key2f(m);
+          }
+        } else {
+          ensure_sorted();
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            uint32_t kl = s[v][0], kh = s[v][0];
+#pragma unroll
+            for (int i = 1; i < W; ++i) {  // lo / hi are wave-uniform: these selects are scalar-predicated moves
+              kl = (i == lo) ? s[v][i] : kl;
+              kh = (i == hi) ? s[v][i] : kh;
+            }
+            float left = xh_key2f(kl), right = xh_key2f(kh);
+            float diff = right - left;
+            double rr = (double)left + (double)diff * e.gamma;
+            if (e.gamma >= 0.5) rr = (double)right - (double)diff * (1.0 - e.gamma);
+            if (rr != rr) rr = (double)xh_key2f(s[v][W - 1]);
+            r[v] = rr;
+          }
+        }
+      } else {
+        ensure_sorted();
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          // register-array select written as an OR of masked values: a select chain gets folded back into a
+          // dynamically indexed (scratch) array by the optimizer
+          auto get = [&](int idx) -> float {
+            uint32_t g = 0;
+#pragma unroll
+            for (int i = 0; i < W; ++i) g |= (i == idx) ? s[v][i] : 0u;
+            return xh_key2f(g);
+          };
+          QTab e = s_tab[j * (W + 1) + n[v]];
+          float left = get(e.lo), right = get(e.hi);
+          float diff = right - left;
+          double rr = (double)left + (double)diff * e.gamma;
+          if (e.gamma >= 0.5) rr = (double)right - (double)diff * (1.0 - e.gamma);
+          if (rr != rr && n[v] > 0 && W > 1) rr = (double)get(n[v] - 1);
+          r[v] = (e.lo < 0) ? xh_nan64() : rr;
+        }
       }
       double* op = out + ((int64_t)j * ndoy + d) * C + c;
       if (VEC == 4) {
