@@ -328,6 +328,33 @@ def test_quantile_series(dev, rng, T, C):
     np.testing.assert_allclose(out2, exp, rtol=RTOL, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("T", [1200, 3000, 5000, 10950])
+@pytest.mark.parametrize("kind", ["pr", "clustered", "constant", "nan_heavy"])
+def test_quantile_series_hard_distributions(dev, rng, T, kind):
+    """Long series through the list-free selection kernel: exact-zero bins (constant big bin), big non-constant bins
+    (bisection fallback), constant columns, mostly-NaN columns."""
+    C = 9
+    if kind == "pr":
+        x = _field(rng, T, C, kind="pr")
+    elif kind == "clustered":
+        x = (1.0 + rng.integers(0, 50, (T, C)) * 1.1920929e-07).astype(np.float32)  # 50 adjacent float32 values
+        x[rng.random((T, C)) < 0.02] = 1.0e6  # outliers stretch the key range: the cluster lands in one bin
+    elif kind == "constant":
+        x = np.full((T, C), 3.25, np.float32)
+        x[:, 1] = np.linspace(0, 1, T, dtype=np.float32)
+    else:
+        x = _field(rng, T, C)
+        x[rng.random((T, C)) < 0.97] = np.nan
+        x[:, 0] = np.nan
+    q = np.concatenate([osdba.equally_spaced_nodes(20), [0.0, 1.0, 0.5]])
+    q.sort()
+    exp = osdba.quantile(x, q)
+    out = K.quantile_series(dev, dev.to_device(np.ascontiguousarray(x.T)), q, time_axis=1).get()
+    np.testing.assert_allclose(out, exp, rtol=RTOL, atol=0, equal_nan=True)
+    out2 = K.quantile_series(dev, dev.to_device(x), q).get()
+    np.testing.assert_allclose(out2, exp, rtol=RTOL, atol=0, equal_nan=True)
+
+
 @pytest.mark.parametrize("kind", ["+", "*"])
 @pytest.mark.parametrize("interp", ["nearest", "linear"])
 @pytest.mark.parametrize("extrap", ["constant", "nan"])

@@ -3,7 +3,7 @@
 TAG=${1:-x}; export XH_SELECT_G=${2:-32}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/tools/bench_eqm.py 365 1036800"
+CMD="python $GRAFT_REPO_ROOT/tools/bench_eqm.py ${3:-365} ${4:-1036800}"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/a -o a -- $CMD > $OUT/a.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/b -o b -- $CMD > $OUT/b.log 2>&1
 for f in $(find $OUT -name "*counter_collection.csv"); do

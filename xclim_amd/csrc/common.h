@@ -55,6 +55,9 @@ int xh_big_scratch(xh_ctx* ctx, size_t bytes, void** dptr);
 // select.hip: per-column exact multi-quantile selection on a time-minor view (d_q: device pointer)
 int xh_select_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const double* d_q,
                       int nq, float* out, int64_t out_cstride, int64_t out_qstride);
+// select2.hip: long series (1024 < T <= 16384) without a per-column LDS copy; XH_ERR_NOTIMPL outside that range
+int xh_select_columns_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride,
+                           const double* d_q, int nq, float* out, int64_t out_cstride, int64_t out_qstride);
 // short series read straight from a time-major view; XH_ERR_NOTIMPL when the shape does not fit
 int xh_select_time_major(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq,
                          float* out, int64_t out_cstride, int64_t out_qstride);

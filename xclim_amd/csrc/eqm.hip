@@ -100,18 +100,19 @@ static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t 
   int rc0 = xh_select_time_major(ctx, x, T, C, st, d_q, nq, out, 1, C);
   if (rc0 != XH_ERR_NOTIMPL) return rc0;
   // time-major: transpose batches of columns into scratch (not counted as algorithmic bytes)
-  int64_t batch = (int64_t)((1ull << 30) / (sizeof(float) * (size_t)T));
+  const int64_t Tp = (T + 3) & ~(int64_t)3;  // padded column stride: every scratch column starts 16-byte aligned
+  int64_t batch = (int64_t)((1ull << 30) / (sizeof(float) * (size_t)Tp));
   batch = (batch / 64) * 64;
   if (batch < 64) batch = 64;
   if (batch > C) batch = C;
   void* tmp = nullptr;
-  int rc = xh_big_scratch(ctx, sizeof(float) * (size_t)batch * (size_t)T, &tmp);
+  int rc = xh_big_scratch(ctx, sizeof(float) * (size_t)batch * (size_t)Tp, &tmp);
   if (rc) return rc;
   for (int64_t c0 = 0; c0 < C; c0 += batch) {
     int64_t nb = C - c0 < batch ? C - c0 : batch;
-    rc = xh_transpose_f32(ctx, x + c0, T, nb, st, (float*)tmp, T);
+    rc = xh_transpose_f32(ctx, x + c0, T, nb, st, (float*)tmp, Tp);
     if (rc) return rc;
-    rc = xh_select_columns(ctx, (const float*)tmp, T, nb, T, d_q, nq, out + c0, 1, C);
+    rc = xh_select_columns(ctx, (const float*)tmp, T, nb, Tp, d_q, nq, out + c0, 1, C);
     if (rc) return rc;
   }
   return XH_OK;

@@ -13,10 +13,15 @@ __global__ void __launch_bounds__(XH_BLOCK)
 k_threshold_count(const float* __restrict__ x, int64_t C, int64_t st, int op, float thr32, double thr64,
                   const void* __restrict__ table, int64_t tstride, const int32_t* __restrict__ tidx,
                   const int64_t* __restrict__ seg_off, int P, int32_t* __restrict__ count_out,
-                  int32_t* __restrict__ valid_out) {
-  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+                  int32_t* __restrict__ valid_out, int period_fast) {
+  // period_fast: periods on blockIdx.x, cell tiles on blockIdx.y — workgroups that are dispatched together then
+  // work on the SAME cell tile in different years and share the per-doy threshold rows through L2 / Infinity Cache
+  // (otherwise a multi-year tx90p re-reads the (D, C) fp64 table from HBM once per year).
+  const unsigned tile = period_fast ? blockIdx.y : blockIdx.x;
+  const int pstart = period_fast ? blockIdx.x : blockIdx.y, pstep = period_fast ? gridDim.x : gridDim.y;
+  int64_t c = ((int64_t)tile * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
-  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+  for (int p = pstart; p < P; p += pstep) {
     int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
     int cnt[VEC], val[VEC];
 #pragma unroll
@@ -64,11 +69,11 @@ k_threshold_count(const float* __restrict__ x, int64_t C, int64_t st, int op, fl
 template <int VEC>
 static int launch_threshold_count(xh_ctx* ctx, int kind, dim3 grid, const float* x, int64_t C, int64_t st, int op,
                                   double thr, const void* table, int64_t tstride, const int32_t* tidx,
-                                  const int64_t* seg, int P, int32_t* count_out, int32_t* valid_out) {
+                                  const int64_t* seg, int P, int32_t* count_out, int32_t* valid_out, int period_fast) {
 #define XH_TC(K)                                                                                                      \
   case K:                                                                                                             \
     hipLaunchKernelGGL((k_threshold_count<VEC, K>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, op, (float)thr, thr, \
-                       table, tstride, tidx, seg, P, count_out, valid_out);                                           \
+                       table, tstride, tidx, seg, P, count_out, valid_out, period_fast);                              \
     break;
   switch (kind) {
     XH_TC(XH_THR_SCALAR_F32)
@@ -347,12 +352,15 @@ int xh_threshold_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
     size_t esz = (thr_kind == XH_THR_DOY_F64 || thr_kind == XH_THR_FULL_F64) ? 8 : 4;
     if ((reinterpret_cast<uintptr_t>(thr_table) & 15) != 0 || (thr_stride * esz) % 16 != 0) vec = 1;
   }
-  dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), period_grid(P));
+  unsigned tiles = (unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK);
+  const bool doy = thr_kind == XH_THR_DOY_F64 || thr_kind == XH_THR_DOY_F32;
+  const int period_fast = (doy && P > 1 && tiles <= 65535u) ? 1 : 0;
+  dim3 grid = period_fast ? dim3(period_grid(P), tiles) : dim3(tiles, period_grid(P));
   if (vec == 4)
     return launch_threshold_count<4>(ctx, thr_kind, grid, x, C, st, op, thr_scalar, thr_table, thr_stride, tidx, d_seg, P,
-                                     count_out, valid_out);
+                                     count_out, valid_out, period_fast);
   return launch_threshold_count<1>(ctx, thr_kind, grid, x, C, st, op, thr_scalar, thr_table, thr_stride, tidx, d_seg, P,
-                                   count_out, valid_out);
+                                   count_out, valid_out, period_fast);
 }
 
 int xh_domain_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op1, double thr1,
