@@ -1,0 +1,42 @@
+// pdoy.h — pieces shared by the percentile_doy kernels in quantile.hip and pdoy_top.hip.
+#pragma once
+#include "common.h"
+
+// (lo, hi, gamma) of the Hyndman-Fan estimate for one (percentile j, valid count n): built on the host in fp64 exactly
+// as utl:395/417-461 evaluate it (build_qtab in quantile.hip), indexed [j * (N + 1) + n].
+struct QTab {
+  int lo, hi;     // sorted slots to combine; lo < 0 -> NaN (no valid sample)
+  double gamma;   // interpolation weight (0 when lo == hi)
+};
+// Gather plumbing shared by the multi-year kernels.  Lane y resolves the physical row of (year y, doy dn, offset off)
+// with ONE vector load chain (tbase -> vmap); the unrolled gather then reads the rows with readlane + unconditional,
+// clamped loads.  (Resolving the rows with per-year scalar loads serialised every gather behind two s_load latencies:
+// ~22k clk per doy, 4x the whole rest of the kernel.)
+__device__ __forceinline__ int pdoy_row(int lane, int nyears, int ndoy, int dn, int off, const int32_t* __restrict__ tbase,
+                                        const int32_t* __restrict__ vmap, int64_t Tv, int64_t T) {
+  int tp = -1;
+  if (lane < nyears && dn >= 0 && dn < ndoy) {
+    const int v = tbase[(int64_t)lane * ndoy + dn];
+    const int64_t vv = (int64_t)v + off;
+    if (v >= 0 && vv >= 0 && vv < Tv) {
+      const int64_t p = vmap ? (int64_t)vmap[vv] : vv;
+      if (p >= 0 && p < T) tp = (int)p;
+    }
+  }
+  return tp;
+}
+template <int NYP>
+__device__ __forceinline__ void pdoy_gather(float (&raw)[NYP], int rowv, const float* __restrict__ x, int64_t st, int64_t cc) {
+#pragma unroll
+  for (int y = 0; y < NYP; ++y) {
+    const int tp = __builtin_amdgcn_readlane(rowv, y);
+    const float f = x[(int64_t)(tp < 0 ? 0 : tp) * st + cc];
+    raw[y] = tp < 0 ? xh_nan32() : f;
+  }
+}
+
+// pdoy_top.hip: register top-16 kernel for the percentiles in jmap[0..nsub) (rev = 0: all of them select within the 16
+// largest samples; rev = 1: within the 16 smallest).  Regular doys on the chunk grid, irregular ones from d_irr.
+int xh_launch_pdoy_top16(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
+                         int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int nsub, int rev, double* out,
+                         const int32_t* d_vmap, int64_t Tv, const uint8_t* d_reg, const int32_t* d_irr, int nirr);

@@ -1,0 +1,177 @@
+// pdoy_top.hip — percentile_doy on multi-year base periods, register top-16 variant.
+#include "pdoy.h"
+
+// ---- multi-year path, register variant: top-16 of the W day-sets by bitonic half-merges ---------------------
+// For high (or, mirrored, low) percentiles only the 16 largest samples of a doy can be selected (e.g. per = 90 over
+// 30 years x 5 days: ranks 134/135 of 150).  Each day-set is sorted once (descending, NaN last) and only its top 16
+// are kept — in REGISTERS: ring[W][16].  The top 16 of the union of W lists come from W-1 bitonic half-merges
+// (C[i] = max(A[i], B[15-i]) is bitonic and holds the 16 largest of A u B; 4 compare-exchange stages re-sort it):
+// static networks, no LDS, no data-dependent loops, lots of independent work per lane.
+// rev mirrors the key order so that the same code serves low percentiles (bottom-16).  Valid keys are never 0.
+__device__ __forceinline__ void ce_desc(uint32_t& a, uint32_t& b) {
+  uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+  a = hi;
+  b = lo;
+}
+
+template <int NP>
+__device__ __forceinline__ void bitonic_desc(uint32_t (&k)[NP]) {  // full sort, descending
+#pragma unroll
+  for (int size = 2; size <= NP; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        int j = i ^ stride;
+        if (j > i) {
+          bool desc = ((i & size) == 0);
+          uint32_t a = k[i], b = k[j];
+          uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+          k[i] = desc ? hi : lo;
+          k[j] = desc ? lo : hi;
+        }
+      }
+    }
+  }
+}
+
+// t <- the 16 largest of (t u b), sorted descending; t and b sorted descending
+__device__ __forceinline__ void merge_top16(uint32_t (&t)[16], const uint32_t (&b)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t[i] = t[i] > b[15 - i] ? t[i] : b[15 - i];
+#pragma unroll
+  for (int stride = 8; stride > 0; stride >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if ((i & stride) == 0) ce_desc(t[i], t[i + stride]);
+  }
+}
+
+template <int W, int NYP, bool OFFSET>
+__global__ void __launch_bounds__(64)
+k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
+             int ndoy, int chunk, const QTab* __restrict__ qtab, const int32_t* __restrict__ jmap, int nsub,
+             double* __restrict__ out, const int32_t* __restrict__ vmap, int64_t Tv, const uint8_t* __restrict__ regular,
+             const int32_t* __restrict__ doy_list, int ndl, int rev) {
+  const uint32_t rmask = rev ? 0xFFFFFFFFu : 0u;  // mirrored key order for the bottom-16 case
+  const int lane = threadIdx.x;
+  int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  const bool active = c < C;
+  constexpr int half = W / 2;
+  const int N = nyears * W;
+  uint32_t ring[W][16];
+  int cnt[W];
+  float raw[NYP];
+
+  const int64_t cc = active ? c : C - 1;  // inactive lanes read a valid cell and never store
+  auto rows_of = [&](int dn, int off) { return pdoy_row(lane, nyears, ndoy, dn, off, tbase, vmap, Tv, T); };
+  auto gather = [&](int rowv) { pdoy_gather<NYP>(raw, rowv, x, st, cc); };
+  // sort the gathered day-set and return its top 16 (in the possibly mirrored order) + valid count
+  auto finish = [&](uint32_t (&top)[16], int& nv) {
+    uint32_t key[NYP];
+    nv = 0;
+#pragma unroll
+    for (int y = 0; y < NYP; ++y) {
+      uint32_t kk = xh_f2key(raw[y]);
+      bool ok = kk != 0xFFFFFFFFu;
+      nv += ok ? 1 : 0;
+      key[y] = ok ? (kk ^ rmask) : 0u;  // NaN / padding -> 0 = smallest
+    }
+    bitonic_desc<NYP>(key);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) top[i] = key[i];
+  };
+  auto select_and_store = [&](int d) {
+    uint32_t t16[16];
+    int n = cnt[0];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t16[i] = ring[0][i];
+#pragma unroll
+    for (int w = 1; w < W; ++w) {
+      merge_top16(t16, ring[w]);
+      n += cnt[w];
+    }
+    auto get = [&](int idx) -> float {
+      uint32_t g = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) g |= (i == idx) ? t16[i] : 0u;
+      return xh_key2f(g ^ rmask);
+    };
+    for (int jj = 0; jj < nsub; ++jj) {
+      const int j = jmap[jj];
+      const QTab e = qtab[j * (N + 1) + n];
+      double r = xh_nan64();
+      if (e.lo >= 0) {
+        // position in the (mirrored) descending top-16: rev -> rank from the bottom, else rank from the top
+        const int plo = rev ? e.lo : (n - 1 - e.lo), phi = rev ? e.hi : (n - 1 - e.hi);
+        float left = get(plo), right = get(phi);
+        float diff = right - left;
+        r = (double)left + (double)diff * e.gamma;
+        if (e.gamma >= 0.5) r = (double)right - (double)diff * (1.0 - e.gamma);
+        if (r != r && n > 0) r = (double)get(rev ? (n - 1 < 15 ? n - 1 : 15) : 0);  // +-inf: nanmax fallback (utl:552-554)
+      }
+      if (active) out[((int64_t)j * ndoy + d) * C + c] = r;
+    }
+  };
+
+  if (OFFSET) {
+    for (int di = blockIdx.y; di < ndl; di += gridDim.y) {
+      const int d = doy_list[di];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        gather(rows_of(d, k - half));
+        finish(ring[k], cnt[k]);
+      }
+      select_and_store(d);
+    }
+  } else {
+    int d0 = blockIdx.y * chunk, d1 = d0 + chunk;
+    if (d1 > ndoy) d1 = ndoy;
+    // ring[w] holds the day-set of doy (d - half + w); prologue fills slots 1..W-1 for d = d0 - 1
+#pragma unroll
+    for (int w = 1; w < W; ++w) {
+      gather(rows_of(d0 - 1 - half + w, 0));
+      finish(ring[w], cnt[w]);
+    }
+    gather(rows_of(d0 + half, 0));
+    int rows_next = rows_of(d0 + half + 1, 0);
+    for (int d = d0; d < d1; ++d) {
+#pragma unroll
+      for (int w = 0; w < W - 1; ++w) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ring[w][i] = ring[w + 1][i];
+        cnt[w] = cnt[w + 1];
+      }
+      finish(ring[W - 1], cnt[W - 1]);
+      if (d + 1 < d1) {
+        gather(rows_next);
+        rows_next = rows_of(d + 2 + half, 0);
+      }
+      if (regular[d]) select_and_store(d);
+    }
+  }
+}
+
+int xh_launch_pdoy_top16(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
+                         int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int nsub, int rev, double* out,
+                         const int32_t* d_vmap, int64_t Tv, const uint8_t* d_reg, const int32_t* d_irr, int nirr) {
+  const int chunk = 24;
+  const dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
+  const dim3 grid_irr((unsigned)cdiv64(C, 64), (unsigned)(nirr > 0 ? nirr : 1));
+#define XH_TOP16(W, NY)                                                                                                   \
+  do {                                                                                                                    \
+    hipLaunchKernelGGL((k_pdoy_top16<W, NY, false>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, \
+                       d_tab, d_jmap, nsub, out, d_vmap, Tv, d_reg, (const int32_t*)nullptr, 0, rev);                     \
+    if (nirr)                                                                                                             \
+      hipLaunchKernelGGL((k_pdoy_top16<W, NY, true>), grid_irr, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, \
+                         chunk, d_tab, d_jmap, nsub, out, d_vmap, Tv, d_reg, d_irr, nirr, rev);                           \
+  } while (0)
+  if (nyears <= 32) {
+    if (window == 3) XH_TOP16(3, 32); else if (window == 5) XH_TOP16(5, 32); else XH_TOP16(7, 32);
+  } else {
+    if (window == 3) XH_TOP16(3, 64); else if (window == 5) XH_TOP16(5, 64); else XH_TOP16(7, 64);
+  }
+#undef XH_TOP16
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}

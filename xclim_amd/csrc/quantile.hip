@@ -11,7 +11,7 @@
 // Time-major layout, one lane per cell (VEC cells in the register path); neighbouring doys re-read rows from L2.
 #include <stdlib.h>
 
-#include "common.h"
+#include "pdoy.h"
 
 // Hyndman-Fan quantile from a sorted sample (ascending, NaN last).  `get(i)` returns sorted element i as float.
 // L = total slots, n = non-NaN count.  Follows utl:494-557 step by step.
@@ -116,11 +116,6 @@ k_pdoy_reg(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const 
 // once from HBM (plus a (W-1)-row halo per doy chunk), the (D, C) fp64 result is written once.
 // The Hyndman-Fan index arithmetic depends only on (percentile, valid count n): the host evaluates it in fp64
 // exactly as utl:395/417-461 do and ships a tiny table (lo, hi, gamma) per (j, n), staged in LDS.
-struct QTab {
-  int lo, hi;     // sorted slots to combine; lo < 0 -> NaN (no valid sample)
-  double gamma;   // interpolation weight (0 when lo == hi)
-};
-
 __device__ __forceinline__ void ce(uint32_t& a, uint32_t& b) {
   uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
   a = lo;
@@ -375,9 +370,9 @@ k_pdoy_lds(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const 
 template <int W, int NYP, bool OFFSET>
 __global__ void __launch_bounds__(64)
 k_pdoy_merge(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
-             int ndoy, int chunk, const QTab* __restrict__ qtab, int nper, double* __restrict__ out,
-             const int32_t* __restrict__ vmap, int64_t Tv, const uint8_t* __restrict__ regular,
-             const int32_t* __restrict__ doy_list, int ndl, int KT, int KB) {
+             int ndoy, int chunk, const QTab* __restrict__ qtab, const int32_t* __restrict__ jmap, int nper,
+             double* __restrict__ out, const int32_t* __restrict__ vmap, int64_t Tv, const uint8_t* __restrict__ regular,
+             const int32_t* __restrict__ doy_list, int ndl, int KT, int KB, int abl) {
   extern __shared__ uint32_t lds[];
   const int lane = threadIdx.x;
   int64_t c = (int64_t)blockIdx.x * 64 + lane;
@@ -388,24 +383,21 @@ k_pdoy_merge(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
   uint32_t* ringB = ringT + W * KT * 64;          // [W][KB][64]
   uint32_t* cnt = ringB + W * KB * 64;            // [W][64]
 
-  // gather one list (virtual day index per year given by `vidx(y)`), sort it, store its two ends in slot `slot`
-  auto build = [&](int slot, auto vidx) {
+  // gather one list (virtual day index per year given by `vidx(y)`) into registers ...
+  float raw[NYP];
+  const int64_t cc = active ? c : C - 1;  // inactive lanes read a valid cell and never store
+  auto rows_of = [&](int dn, int off) { return pdoy_row(lane, nyears, ndoy, dn, off, tbase, vmap, Tv, T); };
+  auto gather = [&](int rowv) { pdoy_gather<NYP>(raw, rowv, x, st, cc); };
+  // ... then sort it and store its two ends in ring slot `slot`
+  auto finish = [&](int slot) {
     uint32_t key[NYP];
     int nv = 0;
 #pragma unroll
     for (int y = 0; y < NYP; ++y) {
-      uint32_t kk = 0xFFFFFFFFu;
-      if (y < nyears) {
-        int64_t v = vidx(y);
-        if (v >= 0 && v < Tv) {
-          int64_t tp = vmap ? (int64_t)vmap[v] : v;
-          if (active && tp >= 0 && tp < T) kk = xh_f2key(x[tp * st + c]);
-        }
-      }
-      key[y] = kk;
-      nv += (kk != 0xFFFFFFFFu) ? 1 : 0;
+      key[y] = xh_f2key(raw[y]);
+      nv += (key[y] != 0xFFFFFFFFu) ? 1 : 0;
     }
-    bitonic_regs<NYP>(key);
+    if (!(abl & 1)) bitonic_regs<NYP>(key);
 #pragma unroll
     for (int i = 0; i < NYP; ++i) {
       int rt = nv - 1 - i;  // rank from the top of sorted slot i
@@ -413,6 +405,10 @@ k_pdoy_merge(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
       if (i < nv && i < KB) ringB[(slot * KB + i) * 64 + lane] = key[i];
     }
     cnt[slot * 64 + lane] = (uint32_t)nv;
+  };
+  auto build = [&](int slot, int rowv) {
+    gather(rowv);
+    finish(slot);
   };
 
   auto select_and_store = [&](int d) {
@@ -422,7 +418,8 @@ k_pdoy_merge(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
       cw[w] = (int)cnt[w * 64 + lane];
       n += cw[w];
     }
-    for (int j = 0; j < nper; ++j) {
+    for (int jj = 0; jj < nper; ++jj) {
+      const int j = jmap[jj];
       QTab e = qtab[j * (N + 1) + n];
       double r = xh_nan64();
       if (e.lo >= 0) {
@@ -522,27 +519,25 @@ k_pdoy_merge(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
     for (int di = blockIdx.y; di < ndl; di += gridDim.y) {
       const int d = doy_list[di];
 #pragma unroll
-      for (int k = 0; k < W; ++k) {
-        build(k, [&](int y) -> int64_t {
-          int v = tbase[(int64_t)y * ndoy + d];
-          return v < 0 ? (int64_t)-1 : (int64_t)v - half + k;
-        });
-      }
+      for (int k = 0; k < W; ++k) build(k, rows_of(d, k - half));
       select_and_store(d);
     }
   } else {
     int d0 = blockIdx.y * chunk, d1 = d0 + chunk;
     if (d1 > ndoy) d1 = ndoy;
-    auto build_doy = [&](int dn) {
-      const int slot = ((dn % W) + W) % W;
-      build(slot, [&](int y) -> int64_t {
-        return (dn >= 0 && dn < ndoy) ? (int64_t)tbase[(int64_t)y * ndoy + dn] : (int64_t)-1;
-      });
-    };
-    for (int dn = d0 - half; dn < d0 + half; ++dn) build_doy(dn);
+    for (int dn = d0 - half; dn < d0 + half; ++dn) build(((dn % W) + W) % W, rows_of(dn, 0));
+    // software pipeline: the day-set of doy d+half+1 is in flight (and the rows of d+half+2 resolved) while doy d is
+    // selected
+    gather(rows_of(d0 + half, 0));
+    int rows_next = rows_of(d0 + half + 1, 0);
     for (int d = d0; d < d1; ++d) {
-      build_doy(d + half);
-      if (regular[d]) select_and_store(d);
+      const int dn = d + half;
+      finish(((dn % W) + W) % W);
+      if (d + 1 < d1) {
+        gather(rows_next);
+        rows_next = rows_of(dn + 2, 0);
+      }
+      if (regular[d] && !(abl & 2)) select_and_store(d);
     }
   }
 }
@@ -722,11 +717,27 @@ static int pdoy_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
     if (!ok) irregular[nirr++] = d;
   }
   build_qtab(N, qh, nper, alpha, beta, tab);
-  // deepest pop from either end over all percentiles and valid counts (same from_top rule as the kernel)
-  int KT = 1, KB = 0;
-  for (int j = 0; j < nper; ++j)
+  // Classify the percentiles: "top" / "bottom" when, for every possible valid count n, both order statistics lie within
+  // the 16 largest / smallest samples (register kernel k_pdoy_top16), otherwise "rest" (LDS-ring kernel k_pdoy_merge).
+  int32_t jtop[64], jbot[64], jrest[64];
+  int ntop = 0, nbot = 0, nrest = 0;
+  for (int j = 0; j < nper; ++j) {
+    int dt = 0, db = 0;
     for (int n = 0; n <= N; ++n) {
       const QTab& e = tab[j * (N + 1) + n];
+      if (e.lo < 0) continue;
+      if (n - e.lo > dt) dt = n - e.lo;
+      if (e.hi + 1 > db) db = e.hi + 1;
+    }
+    if (dt <= 16) jtop[ntop++] = j;
+    else if (db <= 16) jbot[nbot++] = j;
+    else jrest[nrest++] = j;
+  }
+  // deepest pop from either end over the "rest" percentiles and all valid counts (same from_top rule as the kernel)
+  int KT = 1, KB = 0;
+  for (int jj = 0; jj < nrest; ++jj)
+    for (int n = 0; n <= N; ++n) {
+      const QTab& e = tab[jrest[jj] * (N + 1) + n];
       if (e.lo < 0) continue;
       if ((n - 1 - e.hi) < e.lo) { if (n - e.lo > KT) KT = n - e.lo; }
       else { if (e.hi + 1 > KB) KB = e.hi + 1; }
@@ -734,17 +745,37 @@ static int pdoy_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
   if (KT > nyears) KT = nyears;
   if (KB > nyears) KB = nyears;
   if (KT + KB >= nyears) { KT = nyears; KB = 0; }  // full mode: whole list in ringT, bottom pops index it from the end
-  void *d_reg = nullptr, *d_tab = nullptr, *d_irr = nullptr;
+  void *d_reg = nullptr, *d_tab = nullptr, *d_irr = nullptr, *d_jtop = nullptr, *d_jbot = nullptr, *d_jrest = nullptr;
   rc = xh_scratch_upload(ctx, &cur, regular, (size_t)ndoy, &d_reg);
   if (!rc) rc = xh_scratch_upload(ctx, &cur, tab, sizeof(QTab) * (size_t)nper * (N + 1), &d_tab);
   if (!rc && nirr) rc = xh_scratch_upload(ctx, &cur, irregular, sizeof(int32_t) * (size_t)nirr, &d_irr);
+  if (!rc && ntop) rc = xh_scratch_upload(ctx, &cur, jtop, sizeof(int32_t) * (size_t)ntop, &d_jtop);
+  if (!rc && nbot) rc = xh_scratch_upload(ctx, &cur, jbot, sizeof(int32_t) * (size_t)nbot, &d_jbot);
+  if (!rc && nrest) rc = xh_scratch_upload(ctx, &cur, jrest, sizeof(int32_t) * (size_t)nrest, &d_jrest);
   free(regular); free(irregular); free(tab);
   if (rc) return rc;
   const int chunk = 24;
+  const char* ea = getenv("XH_PDOY_ABL");  // diagnostics only (results become wrong)
+  const int abl = ea ? atoi(ea) : 0;
   const int NYP = nyears <= 32 ? 32 : 64;
-  size_t lds = ((size_t)window * (KT + KB) * 64 + (size_t)window * 64) * sizeof(uint32_t);
   dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
   dim3 grid_irr((unsigned)cdiv64(C, 64), (unsigned)(nirr > 0 ? nirr : 1));
+  // ---- register top-16 kernel (pdoy_top.hip) for the top / bottom groups
+  if (ntop) {
+    rc = xh_launch_pdoy_top16(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const QTab*)d_tab,
+                              (const int32_t*)d_jtop, ntop, 0, out, (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg,
+                              (const int32_t*)d_irr, nirr);
+    if (rc) return rc;
+  }
+  if (nbot) {
+    rc = xh_launch_pdoy_top16(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const QTab*)d_tab,
+                              (const int32_t*)d_jbot, nbot, 1, out, (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg,
+                              (const int32_t*)d_irr, nirr);
+    if (rc) return rc;
+  }
+  if (nrest == 0) return XH_OK;
+  // ---- LDS-ring kernel for the remaining percentiles
+  size_t lds = ((size_t)window * (KT + KB) * 64 + (size_t)window * 64) * sizeof(uint32_t);
 #define XH_MERGE(W, NY)                                                                                                    \
   do {                                                                                                                     \
     if (lds > 64 * 1024) {                                                                                                 \
@@ -754,12 +785,12 @@ static int pdoy_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
                                        (int)lds));                                                                         \
     }                                                                                                                      \
     hipLaunchKernelGGL((k_pdoy_merge<W, NY, false>), grid, dim3(64), lds, ctx->stream, x, T, C, st, (const int32_t*)d_tb,   \
-                       nyears, ndoy, chunk, (const QTab*)d_tab, nper, out, (const int32_t*)d_vmap, Tv,                      \
-                       (const uint8_t*)d_reg, (const int32_t*)nullptr, 0, KT, KB);                                          \
+                       nyears, ndoy, chunk, (const QTab*)d_tab, (const int32_t*)d_jrest, nrest, out,                        \
+                       (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg, (const int32_t*)nullptr, 0, KT, KB, abl);         \
     if (nirr)                                                                                                              \
       hipLaunchKernelGGL((k_pdoy_merge<W, NY, true>), grid_irr, dim3(64), lds, ctx->stream, x, T, C, st,                    \
-                         (const int32_t*)d_tb, nyears, ndoy, chunk, (const QTab*)d_tab, nper, out, (const int32_t*)d_vmap,  \
-                         Tv, (const uint8_t*)d_reg, (const int32_t*)d_irr, nirr, KT, KB);                                   \
+                         (const int32_t*)d_tb, nyears, ndoy, chunk, (const QTab*)d_tab, (const int32_t*)d_jrest, nrest, out, \
+                         (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg, (const int32_t*)d_irr, nirr, KT, KB, abl);      \
   } while (0)
   if (NYP == 32) {
     if (window == 3) XH_MERGE(3, 32); else if (window == 5) XH_MERGE(5, 32); else XH_MERGE(7, 32);
