@@ -113,11 +113,18 @@ k_select_quantile(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t
     // ---- load keys into registers
     uint32_t key[KPL];
     uint32_t nv = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+    // unconditional, clamped loads first (a load inside an `if` is followed by s_waitcnt vmcnt(0): one full memory
+    // latency PER element), conversion afterwards
+    const int64_t colc = have ? col : ncols - 1;
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
       int i = gt + k * NT;
-      uint32_t kk = 0xFFFFFFFFu;
-      if (have && i < T) kk = xh_f2key(x[col * col_stride + i]);
+      key[k] = __float_as_uint(x[colc * col_stride + (i < T ? i : (int)T - 1)]);
+    }
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+      int i = gt + k * NT;
+      uint32_t kk = (have && i < T) ? xh_f2key(__uint_as_float(key[k])) : 0xFFFFFFFFu;
       key[k] = kk;
       if (kk != 0xFFFFFFFFu) {
         nv++;

@@ -1,38 +1,49 @@
 // select2.hip — long-series multi-quantile selection WITHOUT a per-column copy of the series in LDS.
 //
-// select.hip keeps the whole column (sorted[T]) in LDS, which allows 1-2 workgroups per CU for a 30-year daily series
-// and leaves the kernel latency bound (PMC: waves parked 74 % of their residency, 4 waves/SIMD).  Only the keys that
-// fall into the <= 2*nq TARGET bins matter, so here:
-//   pass 1  histogram of NB linear-in-key bins (keys stay in registers), exclusive scan
-//   target  every target rank finds its bin, its rank inside the bin and the bin population m
-//   pass 2  keys whose bin is a target bin are appended to a small LDS list (bins with m <= BIGM) or only update the
-//           bin's min/max key (bigger bins: e.g. the "exact zero" bin of a precipitation series -> min == max, done)
-//   select  exact k-th smallest inside the (tiny) bin list; a bin that is big AND not constant falls back to a
-//           32-step bisection on the key value with workgroup-wide counting sweeps (rare, slow, exact)
-// LDS per workgroup ~20 KB instead of ~60 KB -> 4 workgroups (32 waves) per CU.
+// One workgroup per column, the column's keys stay in registers (KPL per thread).  Only the keys that fall into the
+// <= 2*nq TARGET bins matter:
+//   A  load (unconditional clamped loads, all in flight at once), key conversion, (n, kmin, kmax) reduction
+//   B  target ranks (Hyndman-Fan type 7, utl:395) -> LDS; histogram of NB linear-in-key bins (ds_add_u32)
+//   C  exclusive scan; every thread looks for the target ranks that fall into ITS bins (ranks are broadcast from
+//      registers with readlane — no dependent LDS chains), allocates the bin's list region (or a min/max slot for bins
+//      with more than BIGM keys, e.g. the "exact zero" bin of a precipitation series) and tags cur[bin] with the cursor
+//   D  keys whose bin is tagged are appended to the LDS list / update the big bin's min & max
+//   E  exact k-th smallest inside the (tiny) bin lists, (target x candidate) pairs spread over the workgroup; a bin
+//      that is big AND not constant falls back to a bisection on the key value with workgroup-wide counting sweeps
+//   F  Hyndman-Fan lerp and store
+// The phases are separated by LDS-only barriers (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also wait
+// for the result stores (vmcnt(0)) — a full memory round trip per column.  Measured phase costs: XH_SELECT_PROF=1.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
+
+#ifndef XH_LEAN_MINB
+#define XH_LEAN_MINB 4
+#endif
 
 namespace {
 
 constexpr int BIGM = 64;       // target bins up to this population are listed
 constexpr int LISTCAP = 2048;  // LDS list capacity (keys); more -> the affected bins are treated as "big"
 constexpr int MAXT = 128;      // targets = 2 * nq <= 128
+constexpr uint32_t F_LIST = 0x80000000u, F_BIG = 0x40000000u, F_MASK = 0x3FFFFFFFu;
 
 struct TInfo {
-  int bin, kth, m, region;  // region: list offset, or -(slot+1) for big bins (valid on the bin's OWNER target)
-  int owner;                // first target that refers to the same bin
+  int bin, kth, m, region;  // region: list offset, or -(slot+1) for big bins
 };
+
+// workgroup barrier that only orders LDS traffic (no vmcnt wait)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int NT>
 __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* red) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  __syncthreads();
+  lds_barrier();
   if (lane == 0) red[w] = v;
-  __syncthreads();
+  lds_barrier();
   uint32_t s = 0;
 #pragma unroll
   for (int i = 0; i < NT / 64; ++i) s += red[i];
@@ -40,39 +51,66 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* red) {
 }
 
 template <int NT, int KPL, int NB>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, XH_LEAN_MINB)
 k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col_stride, const double* __restrict__ qs,
-              int nq, float* __restrict__ out, int64_t out_cstride, int64_t out_qstride, int abl) {
+              int nq, float* __restrict__ out, int64_t out_cstride, int64_t out_qstride, int abl,
+              unsigned long long* __restrict__ prof) {
   constexpr int BPT = NB / NT;
   constexpr int NW = NT / 64;
-  __shared__ uint32_t cur[NB];
-  __shared__ uint32_t bmL[NB / 32], bmB[NB / 32];  // target-bin bitmaps: listed / big
+  __shared__ uint32_t cur[NB + 1];  // [NB]: dummy bin of the NaN keys (keeps the histogram atomics branch-free)
   __shared__ TInfo tinfo[MAXT];
+  __shared__ int trank[MAXT];
   __shared__ uint32_t bmin[MAXT], bmax[MAXT];
-  __shared__ uint32_t list[LISTCAP];
+  __shared__ uint32_t list[LISTCAP + 2 * 8 + 4];  // padded: the in-bin select reads (masked) past a bin's keys
   __shared__ float vals[MAXT];
   __shared__ uint32_t red[4 * NW + 8];
   __shared__ int s_slow, s_off, s_nslot;
   const int gt = threadIdx.x;
   const int lane = gt & 63, w = gt >> 6;
   const int ntgt = 2 * nq;
+  const double tq = gt < ntgt ? qs[gt >> 1] : 0.0;  // quantile of "my" target / of "my" output (gt < nq)
+  const double oq = gt < nq ? qs[gt] : 0.0;
 
+  // phase timers (diagnostics, XH_SELECT_PROF=1): thread 0 accumulates cycle-counter deltas per phase
+  unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0ull;
+#define XH_PHASE(i)                                              \
+  if (prof && gt == 0) {                                         \
+    unsigned long long tn = __builtin_readcyclecounter();        \
+    atomicAdd(&prof[i], tn - tprev);                             \
+    tprev = tn;                                                  \
+  }
   for (int64_t col = blockIdx.x; col < ncols; col += gridDim.x) {
-    // ---- load + one-pass reduction of (n, kmin, kmax)
+    // ---- A: load + one-pass reduction of (n, kmin, kmax).  Unconditional, clamped loads first: a load inside a
+    //      conditional is followed by s_waitcnt vmcnt(0), i.e. one full memory latency PER element
     uint32_t key[KPL];
     uint32_t nv = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+    const float* __restrict__ xc = x + col * col_stride;  // wave-uniform base, 32-bit lane offsets
+    const uint32_t Tm1 = (uint32_t)T - 1u;
+    // `g` is made opaque per column: otherwise the KPL clamped offsets and KPL range masks are hoisted out of the column
+    // loop and stay live across it (~70 registers -> spills or one workgroup per CU)
+    uint32_t g = (uint32_t)gt;
+    asm volatile("" : "+v"(g));
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
-      int i = gt + k * NT;
-      key[k] = (i < T) ? xh_f2key(x[col * col_stride + i]) : 0xFFFFFFFFu;
+      const uint32_t i = g + (uint32_t)(k * NT);
+      key[k] = __float_as_uint(xc[i < Tm1 ? i : Tm1]);
     }
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) cur[gt + b * NT] = 0;
+    if (gt == 0) { s_slow = 0; s_off = 0; s_nslot = 0; cur[NB] = 0; }
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+      const uint32_t i = g + (uint32_t)(k * NT);
+      const uint32_t kk = xh_f2key(__uint_as_float(key[k]));
+      key[k] = (i <= Tm1) ? kk : 0xFFFFFFFFu;
+    }
+    // NaN key = 0xFFFFFFFF never wins a min; kmax is tracked as (key + 1) so that the NaN key wraps to 0
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
       uint32_t kk = key[k];
-      bool ok = kk != 0xFFFFFFFFu;
-      nv += ok ? 1u : 0u;
-      kmin = (ok && kk < kmin) ? kk : kmin;
-      kmax = (ok && kk > kmax) ? kk : kmax;
+      nv += kk != 0xFFFFFFFFu ? 1u : 0u;
+      kmin = kk < kmin ? kk : kmin;
+      kmax = kk + 1u > kmax ? kk + 1u : kmax;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -81,12 +119,10 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
       kmin = a < kmin ? a : kmin;
       kmax = b > kmax ? b : kmax;
     }
+    kmax -= 1u;  // (only meaningful when nv > 0)
     if (lane == 0) { red[w] = nv; red[NW + w] = kmin; red[2 * NW + w] = kmax; }
-#pragma unroll
-    for (int b = 0; b < BPT; ++b) cur[gt + b * NT] = 0;
-    if (gt < NB / 32) { bmL[gt] = 0; bmB[gt] = 0; }
-    if (gt == 0) s_slow = 0;
-    __syncthreads();
+    lds_barrier();
+    XH_PHASE(0);
     uint32_t n = 0;
     kmin = 0xFFFFFFFFu; kmax = 0u;
 #pragma unroll
@@ -98,153 +134,209 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
     const uint32_t range = n > 0 ? kmax - kmin : 0u;
     int shift = 32 - __clz((int)range) - (31 - __clz(NB));
     shift = (range == 0u || shift < 0) ? 0 : shift;
-    // ---- pass 1: histogram
-    if (!(abl & 1)) {
-#pragma unroll
-    for (int k = 0; k < KPL; ++k)
-      if (key[k] != 0xFFFFFFFFu) atomicAdd(&cur[(key[k] - kmin) >> shift], 1u);
-    }
-    __syncthreads();
-    {  // exclusive scan: cur[b] = number of keys in bins < b
-      uint32_t loc[BPT], s = 0;
-#pragma unroll
-      for (int b = 0; b < BPT; ++b) { loc[b] = cur[gt * BPT + b]; s += loc[b]; }
-      uint32_t incl = s;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        uint32_t o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
-      }
-      if (lane == 63) red[3 * NW + w] = incl;
-      __syncthreads();
-      uint32_t add = 0;
-      for (int i = 0; i < w; ++i) add += red[3 * NW + i];
-      uint32_t run = incl - s + add;
-#pragma unroll
-      for (int b = 0; b < BPT; ++b) { cur[gt * BPT + b] = run; run += loc[b]; }
-    }
-    __syncthreads();
-    // ---- targets: rank -> (bin, rank in bin, bin population)
-    if (gt < ntgt && !(abl & 8)) {
-      TInfo ti;
-      ti.bin = -1; ti.kth = 0; ti.m = 0; ti.region = 0; ti.owner = gt;
+    // ---- B: target ranks + histogram
+    if (gt < ntgt) {
+      int r = -1;
       if (n >= 1) {
-        const int j = gt >> 1;
-        int r;
         if (T == 1 || n < 2) r = 0;
         else {
-          double nn = (double)n, q = qs[j];
-          double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;  // utl:395 with alpha = beta = 1
+          double nn = (double)n;
+          double vi = nn * tq + (1.0 + tq * (1.0 - 1.0 - 1.0)) - 1.0;  // utl:395 with alpha = beta = 1
           if (vi >= nn - 1.0) r = (int)n - 1;
           else if (vi < 0.0) r = 0;
           else r = (int)floor(vi) + (gt & 1);
         }
-        int lo = 0, hi = NB;  // largest b with start[b] <= r (empty bins share their start with the next bin)
-        while (hi - lo > 1) {
-          int mid = (lo + hi) >> 1;
-          if (cur[mid] <= (uint32_t)r) lo = mid; else hi = mid;
-        }
-        const uint32_t s0 = cur[lo], s1 = (lo + 1 < NB) ? cur[lo + 1] : n;
-        ti.bin = lo; ti.kth = (int)((uint32_t)r - s0); ti.m = (int)(s1 - s0);
       }
-      tinfo[gt] = ti;
+      trank[gt] = r;
+      tinfo[gt].bin = -1;
     }
-    __syncthreads();
-    // ---- list regions: the first target of every distinct bin ("owner") allocates the bin's list region (or a
-    //      min/max slot for big bins) with an atomic bump; targets are NOT assumed to be sorted by rank
-    if (gt == 0) { s_off = 0; s_nslot = 0; }
-    __syncthreads();
-    if (gt < ntgt) {
-      TInfo ti = tinfo[gt];
-      int owner = gt;
-      if (ti.bin >= 0) {
-        for (int s2 = 0; s2 < gt; ++s2)
-          if (tinfo[s2].bin == ti.bin) { owner = s2; break; }
-        if (owner == gt) {
-          int region;
-          int off = (ti.m <= BIGM) ? atomicAdd(&s_off, ti.m) : LISTCAP + 1;
-          if (ti.m <= BIGM && off + ti.m <= LISTCAP) {
-            region = off;
-            cur[ti.bin] = (uint32_t)off;  // becomes the append cursor of this bin
-            atomicOr(&bmL[ti.bin >> 5], 1u << (ti.bin & 31));
-          } else {
-            int slot = atomicAdd(&s_nslot, 1);
-            region = -(slot + 1);
-            cur[ti.bin] = (uint32_t)slot;  // slot of the min/max trackers
-            bmin[slot] = 0xFFFFFFFFu; bmax[slot] = 0u;
-            atomicOr(&bmB[ti.bin >> 5], 1u << (ti.bin & 31));
-          }
-          tinfo[gt].region = region;
-        }
-      }
-      tinfo[gt].owner = owner;
-    }
-    __syncthreads();
-    // ---- pass 2: collect the keys of the target bins
-    if (!(abl & 2))
+    if (!(abl & 1)) {
 #pragma unroll
-    for (int k = 0; k < KPL; ++k) {
-      if (key[k] == 0xFFFFFFFFu) continue;
-      const uint32_t b = (key[k] - kmin) >> shift;
-      const uint32_t bit = 1u << (b & 31);
-      if (bmL[b >> 5] & bit) {
-        uint32_t pos = atomicAdd(&cur[b], 1u);
-        list[pos] = key[k];
-      } else if (bmB[b >> 5] & bit) {
-        const uint32_t slot = cur[b];
-        atomicMin(&bmin[slot], key[k]);
-        atomicMax(&bmax[slot], key[k]);
+      for (int k = 0; k < KPL; ++k) {
+        const uint32_t b = (key[k] - kmin) >> shift;
+        atomicAdd(&cur[key[k] != 0xFFFFFFFFu ? b : (uint32_t)NB], 1u);
       }
     }
-    __syncthreads();
-    // ---- select inside the bins: (target, candidate) pairs are spread over the whole workgroup — a candidate key is
-    //      the answer iff #(keys < e) <= kth < #(keys <= e); O(m) LDS reads per thread instead of O(m^2) per target
-    if (gt < ntgt) {
-      const TInfo ti = tinfo[gt];
-      float v = xh_nan32();
-      if (ti.bin >= 0) {
-        const int region = tinfo[ti.owner].region;
-        if (region < 0) {
-          const int slot = -region - 1;
-          if (bmin[slot] == bmax[slot]) v = xh_key2f(bmin[slot]);  // constant bin (e.g. all the dry days)
-          else atomicOr((unsigned int*)&s_slow, 1u);
+    lds_barrier();
+    XH_PHASE(1);
+    // ---- C: exclusive scan (thread gt owns bins gt*BPT ... gt*BPT+BPT-1), targets, list regions
+    uint32_t loc[BPT], s = 0;
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) { loc[b] = cur[gt * BPT + b]; s += loc[b]; }
+    uint32_t incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) red[3 * NW + w] = incl;
+    const int myr0 = lane < ntgt ? trank[lane] : -1, myr1 = lane + 64 < ntgt ? trank[lane + 64] : -1;
+    lds_barrier();
+    XH_PHASE(2);
+    {
+      uint32_t add = 0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) add += (i < w) ? red[3 * NW + i] : 0u;
+      const uint32_t first = incl - s + add;  // keys in the bins before mine
+      // Targets whose rank falls into this WAVE's bins — all on scalars: the owner lane is the last lane whose `first`
+      // is <= r (ballot + popcount), its scan state comes over with readlane, the list region / big-bin slot of a bin
+      // is allocated once (the ranks are sorted up to lo_{j+1} < hi_j, so a bin can only repeat among the last two).
+      // Counts left in cur[] never reach the tag bits, so only the target bins are rewritten.
+      const uint32_t wfirst = __builtin_amdgcn_readfirstlane(add);
+      const uint32_t wend = wfirst + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      int pb0 = -1, pb1 = -1;
+      uint32_t pt0 = 0, pt1 = 0;
+      // (lane l holds the ranks of targets l and l + 64: one vector compare finds the wave's targets; a scalar loop
+      //  over all 2*nq targets costs ~100 clk per iteration in dependent s_cmp / s_cbranch chains)
+      unsigned long long in0 = __ballot(myr0 >= 0 && (uint32_t)myr0 >= wfirst && (uint32_t)myr0 < wend);
+      unsigned long long in1 = __ballot(myr1 >= 0 && (uint32_t)myr1 >= wfirst && (uint32_t)myr1 < wend);
+      if (abl & 8) { in0 = 0; in1 = 0; }
+      while (in0 | in1) {
+        int t, r;
+        if (in0) {
+          const int l = __ffsll((long long)in0) - 1;
+          in0 &= in0 - 1;
+          t = l; r = __builtin_amdgcn_readlane(myr0, l);
+        } else {
+          const int l = __ffsll((long long)in1) - 1;
+          in1 &= in1 - 1;
+          t = l + 64; r = __builtin_amdgcn_readlane(myr1, l);
+        }
+        const int L = __popcll(__ballot(first <= (uint32_t)r)) - 1;
+        uint32_t st0 = (uint32_t)__builtin_amdgcn_readlane((int)first, L);
+        int bin = 0, m = 0, kth = 0;
+        bool found = false;
+#pragma unroll
+        for (int b = 0; b < BPT; ++b) {
+          const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)loc[b], L);
+          if (!found && (uint32_t)r < st0 + lb) {
+            found = true;
+            bin = (w * 64 + L) * BPT + b; m = (int)lb; kth = (int)((uint32_t)r - st0);
+          }
+          st0 += lb;
+        }
+        uint32_t tag;
+        if (bin == pb0) tag = pt0;
+        else if (bin == pb1) tag = pt1;
+        else {
+          int off = LISTCAP + 1;
+          if (m <= BIGM) {
+            if (lane == 0) off = atomicAdd(&s_off, m);
+            off = __builtin_amdgcn_readfirstlane(off);
+          }
+          if (m <= BIGM && off + m <= LISTCAP) tag = F_LIST | (uint32_t)off;
+          else {
+            int slot = 0;
+            if (lane == 0) {
+              slot = atomicAdd(&s_nslot, 1);
+              bmin[slot] = 0xFFFFFFFFu; bmax[slot] = 0u;
+            }
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            tag = F_BIG | (uint32_t)slot;
+          }
+          if (lane == 0) cur[bin] = tag;  // append cursor / min-max slot of the bin
+          pb1 = pb0; pt1 = pt0; pb0 = bin; pt0 = tag;
+        }
+        if (lane == 0) {
+          TInfo ti;
+          ti.bin = bin; ti.kth = kth; ti.m = m;
+          ti.region = (tag & F_LIST) ? (int)(tag & F_MASK) : -((int)(tag & F_MASK) + 1);
+          tinfo[t] = ti;
         }
       }
-      vals[gt] = v;
     }
-    __syncthreads();
+    lds_barrier();
+    XH_PHASE(3);
+    // ---- D: collect the keys of the target bins (chunks of CH keys: tags, then the append atomics, then the list
+    //      writes — independent LDS operations in flight instead of one dependent chain per key)
+    if (!(abl & 2)) {
+      constexpr int CH = KPL % 8 == 0 ? 8 : 4;
+#pragma unroll
+      for (int k0 = 0; k0 < KPL; k0 += CH) {
+        uint32_t cf[CH], pos[CH];
+        bool anybig = false;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const uint32_t b = (key[k0 + k] - kmin) >> shift;
+          cf[k] = cur[key[k0 + k] != 0xFFFFFFFFu ? b : (uint32_t)NB];  // cur[NB] carries no tag
+          anybig |= (cf[k] & F_BIG) != 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          pos[k] = 0;
+          if (cf[k] & F_LIST) pos[k] = atomicAdd(&cur[(key[k0 + k] - kmin) >> shift], 1u) & F_MASK;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+          if (cf[k] & F_LIST) list[pos[k]] = key[k0 + k];
+        if (__any(anybig)) {
+#pragma unroll
+          for (int k = 0; k < CH; ++k)
+            if (cf[k] & F_BIG) {
+              const uint32_t slot = cf[k] & F_MASK;
+              atomicMin(&bmin[slot], key[k0 + k]);
+              atomicMax(&bmax[slot], key[k0 + k]);
+            }
+        }
+      }
+    }
+    lds_barrier();
+    XH_PHASE(4);
+    // ---- E: select inside the bins: (target, candidate) pairs are spread over the whole workgroup — a candidate key
+    //      is the answer iff #(keys < e) <= kth < #(keys <= e); O(m) LDS reads per thread, not O(m^2) per target
     if (!(abl & 4)) {
-      constexpr int CPT = 16;  // candidate lanes per target
+      constexpr int CPT = 8;  // candidate lanes per target
       for (int t = gt / CPT; t < ntgt; t += NT / CPT) {
         const TInfo ti = tinfo[t];
-        if (ti.bin < 0) continue;
-        const int region = tinfo[ti.owner].region;
-        if (region < 0) continue;
-        const uint32_t m = (uint32_t)ti.m, kth = (uint32_t)ti.kth;
-        for (uint32_t a2 = gt % CPT; a2 < m; a2 += CPT) {
-          const uint32_t e = list[region + a2];
-          uint32_t less = 0, leq = 0;
-          for (uint32_t b2 = 0; b2 < m; ++b2) {
-            const uint32_t k2 = list[region + b2];
-            less += k2 < e ? 1u : 0u;
-            leq += k2 <= e ? 1u : 0u;
+        const int a0 = gt % CPT;
+        if (ti.bin < 0) {  // no valid sample
+          if (a0 == 0) vals[t] = xh_nan32();
+          continue;
+        }
+        if (ti.region < 0) {
+          if (a0 == 0) {
+            const int slot = -ti.region - 1;
+            float v = xh_nan32();
+            if (bmin[slot] == bmax[slot]) v = xh_key2f(bmin[slot]);  // constant bin (e.g. all the dry days)
+            else s_slow = 1;
+            vals[t] = v;
           }
-          if (less <= kth && kth < leq) vals[t] = xh_key2f(e);  // every winner writes the same value
+          continue;
+        }
+        // two candidates per lane and pass, four list keys per step: independent LDS reads in flight (a one-key-per-
+        // iteration loop waits one LDS latency per key).  Reads past the bin's m keys are masked (list is padded).
+        const uint32_t m = (uint32_t)ti.m, kth = (uint32_t)ti.kth;
+        const uint32_t* lp = list + ti.region;
+        for (uint32_t a2 = a0; a2 < m; a2 += 2 * CPT) {
+          const uint32_t e0 = lp[a2];
+          uint32_t e1 = lp[a2 + CPT];
+          e1 = a2 + CPT < m ? e1 : 0u;  // key 0 never wins (valid keys are > 0)
+          uint32_t less0 = 0, leq0 = 0, less1 = 0, leq1 = 0;
+          for (uint32_t b2 = 0; b2 < m; b2 += 4) {
+            uint32_t k0 = lp[b2], k1 = lp[b2 + 1], k2 = lp[b2 + 2], k3 = lp[b2 + 3];
+            k1 = b2 + 1 < m ? k1 : 0xFFFFFFFFu;
+            k2 = b2 + 2 < m ? k2 : 0xFFFFFFFFu;
+            k3 = b2 + 3 < m ? k3 : 0xFFFFFFFFu;
+            less0 += (k0 < e0 ? 1u : 0u) + (k1 < e0 ? 1u : 0u) + (k2 < e0 ? 1u : 0u) + (k3 < e0 ? 1u : 0u);
+            leq0 += (k0 <= e0 ? 1u : 0u) + (k1 <= e0 ? 1u : 0u) + (k2 <= e0 ? 1u : 0u) + (k3 <= e0 ? 1u : 0u);
+            less1 += (k0 < e1 ? 1u : 0u) + (k1 < e1 ? 1u : 0u) + (k2 < e1 ? 1u : 0u) + (k3 < e1 ? 1u : 0u);
+            leq1 += (k0 <= e1 ? 1u : 0u) + (k1 <= e1 ? 1u : 0u) + (k2 <= e1 ? 1u : 0u) + (k3 <= e1 ? 1u : 0u);
+          }
+          if (less0 <= kth && kth < leq0) vals[t] = xh_key2f(e0);  // every winner writes the same value
+          if (e1 != 0u && less1 <= kth && kth < leq1) vals[t] = xh_key2f(e1);
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
+    XH_PHASE(5);
     // ---- rare: big non-constant target bins -> bisection on the key value with counting sweeps
     if (s_slow) {
       for (int t = 0; t < ntgt; ++t) {
-        TInfo ti = tinfo[t];
-        if (ti.bin < 0) continue;
-        ti.region = tinfo[ti.owner].region;
-        if (ti.region >= 0) continue;
+        const TInfo ti = tinfo[t];
+        if (ti.bin < 0 || ti.region >= 0) continue;
         const int slot = -ti.region - 1;
         uint32_t lo = bmin[slot], hi = bmax[slot];
         if (lo == hi) continue;
-        // global rank wanted: (#keys in lower bins) + kth ; recover it from the bin start
         // smallest K in [lo, hi] with #(key <= K, key in this bin) >= kth + 1
         const uint32_t binlo = kmin + ((uint32_t)ti.bin << shift);
         while (lo < hi) {
@@ -256,18 +348,19 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
           if (c >= (uint32_t)ti.kth + 1u) hi = mid; else lo = mid + 1;
         }
         if (gt == 0) vals[t] = xh_key2f(lo);
-        __syncthreads();
+        lds_barrier();
       }
     }
-    // ---- Hyndman-Fan lerp (type 7) and store
+    XH_PHASE(6);
+    // ---- F: Hyndman-Fan lerp (type 7) and store
     if (gt < nq) {
       const int j = gt;
       double r;
       if (n == 0) r = xh_nan64();
       else if (T == 1 || n < 2) r = (double)vals[2 * j];
       else {
-        double nn = (double)n, q = qs[j];
-        double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;
+        double nn = (double)n;
+        double vi = nn * oq + (1.0 + oq * (1.0 - 1.0 - 1.0)) - 1.0;
         float left = vals[2 * j], right = vals[2 * j + 1];
         if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
         else {
@@ -279,8 +372,10 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
       }
       out[col * out_cstride + (int64_t)j * out_qstride] = (float)r;
     }
-    __syncthreads();
+    lds_barrier();  // vals / tinfo / red are rewritten by the next column
+    XH_PHASE(7);
   }
+#undef XH_PHASE
 }
 
 template <int NT, int KPL, int NB>
@@ -290,9 +385,28 @@ int launch_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64
   int64_t maxblk = (int64_t)ctx->num_cu * 16;
   if (nblk > maxblk) nblk = maxblk;
   const char* ea = getenv("XH_SELECT_ABL");  // diagnostics only: skip phases (results become wrong)
+  const char* ep = getenv("XH_SELECT_PROF");  // diagnostics only: per-phase cycle counts on stderr
+  unsigned long long* d_prof = nullptr;
+  if (ep && atoi(ep)) {
+    XH_CHECK_HIP(hipMalloc((void**)&d_prof, 16 * sizeof(unsigned long long)));
+    XH_CHECK_HIP(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
+  }
   hipLaunchKernelGGL((k_select_lean<NT, KPL, NB>), dim3((unsigned)nblk), dim3(NT), 0, ctx->stream, xcols, T, ncols, col_stride,
-                     d_q, nq, out, out_cstride, out_qstride, ea ? atoi(ea) : 0);
+                     d_q, nq, out, out_cstride, out_qstride, ea ? atoi(ea) : 0, d_prof);
   XH_LAUNCH_CHECK();
+  if (d_prof) {
+    unsigned long long h[16];
+    XH_CHECK_HIP(hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    XH_CHECK_HIP(hipFree(d_prof));
+    static const char* names[10] = {"A load+reduce", "B ranks+hist", "C scan", "C targets", "D collect", "E in-bin select",
+                                    "slow path", "F lerp+store", "-", "-"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 10; ++i) tot += h[i];
+    fprintf(stderr, "k_select_lean<%d,%d,%d> phases (cycles per column per workgroup, %lld columns):\n", NT, KPL, NB, (long long)ncols);
+    for (int i = 0; i < 10; ++i)
+      fprintf(stderr, "  %-14s %10.0f  %5.1f %%\n", names[i], (double)h[i] / (double)ncols, 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+  }
   return XH_OK;
 }
 
@@ -303,9 +417,24 @@ int xh_select_columns_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t n
                            const double* d_q, int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
   if (T <= 1024 || T > 16384 || nq > 64) return XH_ERR_NOTIMPL;
 #define XH_LEAN(NT, KPL, NB) return launch_lean<NT, KPL, NB>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride)
+  const char* ent = getenv("XH_LEAN_NT");  // tuning only
+  const int nt = ent ? atoi(ent) : 512;
   if (T <= 2048) XH_LEAN(256, 8, 1024);
   if (T <= 3072) XH_LEAN(256, 12, 1024);
   if (T <= 4096) XH_LEAN(256, 16, 1024);
+  if (nt == 256) {
+    if (T <= 6144) XH_LEAN(256, 24, 2048);
+    if (T <= 8192) XH_LEAN(256, 32, 2048);
+    if (T <= 10240) XH_LEAN(256, 40, 2048);
+    if (T <= 12288) XH_LEAN(256, 48, 2048);
+    if (T <= 14336) XH_LEAN(256, 56, 2048);
+    XH_LEAN(256, 64, 2048);
+  }
+  if (nt == 1024) {
+    if (T <= 8192) XH_LEAN(1024, 8, 2048);
+    if (T <= 12288) XH_LEAN(1024, 12, 2048);
+    XH_LEAN(1024, 16, 2048);
+  }
   if (T <= 6144) XH_LEAN(512, 12, 2048);
   if (T <= 8192) XH_LEAN(512, 16, 2048);
   if (T <= 10240) XH_LEAN(512, 20, 2048);
