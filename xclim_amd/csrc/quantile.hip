@@ -73,6 +73,10 @@ k_pdoy_reg(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const 
     int nvalid[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) nvalid[v] = 0;
+    // all the loads first, unconditional with a clamped row (a load inside a conditional is followed by s_waitcnt
+    // vmcnt(0): the gathers would be serialised), conversion and masking afterwards
+    VecF<VEC> raw[NMAX];
+    bool okm[NMAX];
 #pragma unroll
     for (int i = 0; i < NMAX; ++i) {
       // slot i -> (year y, window offset k)
@@ -80,17 +84,16 @@ k_pdoy_reg(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const 
       bool inb = i < N;
       int64_t tb = inb ? (int64_t)tbase[(int64_t)y * ndoy + d] : -1;
       int64_t t = tb - half + k;
-      bool ok = inb && tb >= 0 && t >= 0 && t < T;
-      if (ok) {
-        VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
+      okm[i] = inb && tb >= 0 && t >= 0 && t < T;
+      raw[i] = xh_load<VEC>(x + (okm[i] ? t : (int64_t)0) * st + c);
+    }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          key[v][i] = xh_f2key(xv.v[v]);
-          nvalid[v] += (xv.v[v] == xv.v[v]) ? 1 : 0;
-        }
-      } else {
+    for (int i = 0; i < NMAX; ++i) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) key[v][i] = 0xFFFFFFFFu;
+      for (int v = 0; v < VEC; ++v) {
+        const uint32_t kk = okm[i] ? xh_f2key(raw[i].v[v]) : 0xFFFFFFFFu;
+        key[v][i] = kk;
+        nvalid[v] += (kk != 0xFFFFFFFFu) ? 1 : 0;
       }
     }
 #pragma unroll
@@ -156,21 +159,29 @@ k_pdoy_slide(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int6
   int n[VEC];  // valid keys currently in the window (maintained incrementally)
 #pragma unroll
   for (int v = 0; v < VEC; ++v) { n[v] = 0; win[v][0] = 0xFFFFFFFFu; }
-  auto loadrow = [&](int64_t t, int slot) {
-    if (t >= 0 && t < T) {
-      VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
+  // rows are fetched unconditionally (clamped row index: a load inside a conditional is followed by s_waitcnt
+  // vmcnt(0)) and one doy AHEAD of their use, so the row of doy d+1 is in flight while doy d is selected and stored
+  auto fetch = [&](int64_t t) -> VecF<VEC> {
+    const int64_t tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+    return xh_load<VEC>(x + tc * st + c);
+  };
+  auto insert = [&](const VecF<VEC>& xv, int64_t t, int slot) {
+    const bool inside = t >= 0 && t < T;
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        win[v][slot] = xh_f2key(xv.v[v]);
-        n[v] += (xv.v[v] == xv.v[v]) ? 1 : 0;
-      }
-    } else {
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) win[v][slot] = 0xFFFFFFFFu;
+    for (int v = 0; v < VEC; ++v) {
+      const uint32_t kk = inside ? xh_f2key(xv.v[v]) : 0xFFFFFFFFu;
+      win[v][slot] = kk;
+      n[v] += (kk != 0xFFFFFFFFu) ? 1 : 0;
     }
   };
+  {
+    VecF<VEC> pre[W > 1 ? W - 1 : 1];
 #pragma unroll
-  for (int k = 0; k < W - 1; ++k) loadrow(t_first + d0 - half + k, k + 1);
+    for (int k = 0; k < W - 1; ++k) pre[k] = fetch(t_first + d0 - half + k);
+#pragma unroll
+    for (int k = 0; k < W - 1; ++k) insert(pre[k], t_first + d0 - half + k, k + 1);
+  }
+  VecF<VEC> nxt = fetch(t_first + d0 - half + (W - 1));
 #pragma unroll 2
   for (int d = d0; d < d1; ++d) {
 #pragma unroll
@@ -179,7 +190,9 @@ k_pdoy_slide(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int6
 #pragma unroll
       for (int k = 0; k < W - 1; ++k) win[v][k] = win[v][k + 1];
     }
-    loadrow(t_first + d - half + (W - 1), W - 1);
+    const VecF<VEC> cur = nxt;
+    nxt = fetch(t_first + d + 1 - half + (W - 1));  // (one clamped extra row at the end of the chunk)
+    insert(cur, t_first + d - half + (W - 1), W - 1);
     bool full = true;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) full &= (n[v] == W);
