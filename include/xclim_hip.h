@@ -140,6 +140,21 @@ int xh_bivariate_count(xh_ctx* ctx, const float* x1, const float* x2, int64_t T,
                        int op1, double thr1, int op2, double thr2, int combine, const int64_t* seg_off, int P,
                        int32_t* count_out, int32_t* valid_out);
 
+/* Two-variable range reductions per period, out (P, C) float32, all NaN-skipping (xarray default for floats):
+ *   mode 0 diurnal_temperature_range          (generic.py:1076-1105): reducer (XH_RED_SUM|MEAN|MIN|MAX) of (high - low)
+ *   mode 1 interday_diurnal_temperature_range (generic.py:1360-1385): mean of |d(high - low)/dt| (diff drops day 0)
+ *   mode 2 extreme_temperature_range          (generic.py:1388-1414): max(high) - min(low)
+ * valid_out counts the days on which both variables are non-NaN. */
+int xh_range_reduce(xh_ctx* ctx, const float* low, const float* high, int64_t T, int64_t C, int64_t st_low,
+                    int64_t st_high, int mode, int reducer, const int64_t* seg_off, int P, float* out,
+                    int32_t* valid_out);
+
+/* compare (generic.py:301-326) / get_daily_events (generic.py:395-431) as an elementwise map of a (T, C) field against a
+ * scalar (fp32 compare, or fp64 when thr_is_f64) or a second field b (NULL for the scalar form):
+ *   out_kind 0: uint8 mask    1: float32 1/0 with NaN where a is NaN    2: float32 a.where(cond) (NaN elsewhere) */
+int xh_compare_map(xh_ctx* ctx, const float* a, int64_t T, int64_t C, int64_t st, int op, double thr, int thr_is_f64,
+                   const float* b, int64_t st_b, int out_kind, void* out, int64_t st_out);
+
 /* Thresholded reductions per period, out (P, C) float32:
  *   mode 0 thresholded_statistics (generic.py:1278-1320): reducer (XH_RED_SUM|MEAN|MIN|MAX) of data.where(cond)
  *   mode 1 temperature_sum        (generic.py:1323-1357): direction * sum((data - thr).where(cond))
@@ -219,6 +234,22 @@ int xh_season(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int
  * least `window` steps of the run's sum; out (P, C) float32. */
 int xh_max_run_sum(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window,
                    const int64_t* seg_off, int P, float* out);
+
+/* Event compaction for run_bounds (run_length.py:745-802) and find_events / _find_events (run_length.py:1760-1901).
+ * `runs` is a 0/1 float field (a mask, or xh_runs_with_holes output).  The k-th run (time order) of (period p, cell c)
+ * writes element [(p * maxev + k) * C + c] of every non-NULL output, rows past the last run are NaN:
+ *   start_out  first step of the run, relative to the period start      end_out  first step after the run (NaN if none)
+ *   len_out    run length       eff_out  steps of the run where `eff` != 0 (NULL: = length)
+ *   sum_out    sum of `data` from the run start to the first NaN of data inside the run (the reference's
+ *              _cumsum_reset_xr(..., reset_on_zero=False) arithmetic in fp32) */
+int xh_run_events(xh_ctx* ctx, const float* runs, const float* eff, const float* data, int64_t T, int64_t C, int64_t st,
+                  int64_t sc, const int64_t* seg_off, int P, int maxev, float* start_out, float* end_out, float* len_out,
+                  float* eff_out, float* sum_out);
+
+/* suspicious_run / suspicious_run_1d (run_length.py:1668-1757): out (T, C) uint8 = 1 on steps that belong to a run of at
+ * least `window` identical values whose value satisfies `op thresh` (op = -1: no threshold). */
+int xh_suspicious_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, int op,
+                      double thresh, uint8_t* out, int64_t out_st);
 
 /* ---- quantile / percentile family (Q1-Q3) --------------------------------------------------- */
 /* calc_perc / _nan_quantile (core/utils.py:279-557): NaN-aware Hyndman-Fan quantiles of N samples per

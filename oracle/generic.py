@@ -76,6 +76,38 @@ def bivariate_count_occurrences(v1, v2, t1, t2, time: OTime, freq, op1, op2, var
     return _resample_reduce(c, time, freq, lambda g: g.sum(axis=0))
 
 
+def get_daily_events(da, threshold, op, constrain=None):
+    """gen:395-431: 1 where the condition holds, 0 where not, NaN where da is NaN."""
+    da = np.asarray(da)
+    events = compare(da, op, threshold, constrain) * 1
+    return np.where(np.isnan(da), np.nan, events)
+
+
+def diurnal_temperature_range(low_data, high_data, reducer, time: OTime, freq="YS"):
+    """gen:1076-1105: reducer((high - low).resample(time=freq)); NaN-skipping xarray reducers."""
+    dtr = np.asarray(high_data) - np.asarray(low_data)
+    return _resample_reduce(dtr, time, freq, lambda g: _nanreduce(g, reducer))
+
+
+def interday_diurnal_temperature_range(low_data, high_data, time: OTime, freq="YS"):
+    """gen:1360-1385: abs((high - low).diff("time")).resample(time=freq).mean(); diff drops the first day, so the
+    first period holds one value less."""
+    dtr = np.asarray(high_data) - np.asarray(low_data)
+    vdtr = np.abs(np.diff(dtr, axis=0))
+    out = []
+    for _, idx in groups(time, freq):
+        idx = idx[idx >= 1] - 1  # position in the diff'ed series (time coordinate = the later day)
+        out.append(_nanreduce(vdtr[idx], "mean"))
+    return np.stack(out)
+
+
+def extreme_temperature_range(low_data, high_data, time: OTime, freq="YS"):
+    """gen:1388-1414: high.resample.max() - low.resample.min()."""
+    hi = _resample_reduce(np.asarray(high_data), time, freq, lambda g: _nanreduce(g, "max"))
+    lo = _resample_reduce(np.asarray(low_data), time, freq, lambda g: _nanreduce(g, "min"))
+    return hi - lo
+
+
 def thresholded_statistics(data, op, threshold, reducer, time: OTime, freq):
     """gen:1278-1320: getattr(data.where(cond).resample(time=freq), reducer)()."""
     data = np.asarray(data)

@@ -429,3 +429,107 @@ def season_per_period(da, window, mid_date, time: OTime, freq):
     """gen:841-853 pattern: resample(time=freq).map(rl.season ...) with index outputs."""
     outs = [season(np.asarray(da)[idx], window, mid_date, time.isel(idx)) for _, idx in groups(time, freq)]
     return tuple(np.stack([o[k] for o in outs], axis=0) for k in range(3))
+
+
+def run_bounds(mask):
+    """rl:745-802 with coord=False: (2, events, *cells) start / end indices of the runs of True, NaN-padded."""
+    mask = np.asarray(mask).astype(bool)
+    mi = mask.astype(int)
+    diff = np.concatenate((mi[:1], np.diff(mi, axis=0)), axis=0)
+    nstarts = int((diff == 1).sum(axis=0).max()) if mask.size else 0
+
+    def _get_indices(arr, N):
+        out = np.full((N,), np.nan, dtype=float)
+        inds = np.where(arr)[0]
+        out[: len(inds)] = inds
+        return out
+
+    cells = mask.shape[1:]
+    starts = np.full((nstarts,) + cells, np.nan)
+    ends = np.full((nstarts,) + cells, np.nan)
+    for ix in np.ndindex(*cells):
+        sl = (slice(None),) + ix
+        starts[sl] = _get_indices(diff[sl] == 1, nstarts)
+        ends[sl] = _get_indices(diff[sl] == -1, nstarts)
+    return np.stack((starts, ends))
+
+
+def _find_events(da_start, da_stop, data, window_start, window_stop):
+    """rl:1760-1842 on one period: dict of (event, *cells) arrays; event_start as a step index."""
+    da_start = np.asarray(da_start).astype(bool)
+    da_stop = np.asarray(da_stop).astype(bool)
+    runs = runs_with_holes(da_start, window_start, da_stop, window_stop)
+    event_length = np.nan_to_num(rle(runs).astype(np.float64), nan=0.0)
+    eff = cumsum_reset_xr(np.where(runs == 1, da_start.astype(np.float32), np.float32(np.nan)), "first", False)
+    eff = np.nan_to_num(eff, nan=0.0).astype(np.int16)
+    T = da_start.shape[0]
+    cells = da_start.shape[1:]
+    nev = int(np.ceil(T / (window_start + window_stop)))
+    out = {"event_length": np.full((nev,) + cells, np.nan), "event_effective_length": np.full((nev,) + cells, np.nan),
+           "event_start": np.full((nev,) + cells, np.nan)}
+    esum = None
+    if data is not None:
+        data = np.asarray(data)
+        esum = cumsum_reset_xr(np.where(runs == 1, data, data.dtype.type(np.nan)), "first", False)
+        out["event_sum"] = np.full((nev,) + cells, np.nan)
+    tidx = np.arange(T)
+    for ix in np.ndindex(*cells):
+        sl = (slice(None),) + ix
+        sel = event_length[sl] > 0
+        k = int(sel.sum())
+        out["event_length"][(slice(0, k),) + ix] = event_length[sl][sel]
+        out["event_effective_length"][(slice(0, k),) + ix] = eff[sl][sel]
+        out["event_start"][(slice(0, k),) + ix] = tidx[sel]
+        if esum is not None:
+            out["event_sum"][(slice(0, k),) + ix] = esum[sl][sel]
+    return out
+
+
+def find_events(condition, window, condition_stop=None, window_stop=1, data=None, time=None, freq=None):
+    """rl:1846-1901."""
+    condition = np.asarray(condition).astype(bool)
+    if condition_stop is None:
+        condition_stop = ~condition
+    if freq is None:
+        return _find_events(condition, condition_stop, data, window, window_stop)
+    parts = [_find_events(condition[idx], np.asarray(condition_stop)[idx], None if data is None else np.asarray(data)[idx],
+                          window, window_stop) for _, idx in groups(time, freq)]
+    nev = max(p["event_length"].shape[0] for p in parts)
+
+    def pad(a):
+        o = np.full((nev,) + a.shape[1:], np.nan)
+        o[: a.shape[0]] = a
+        return o
+
+    return {k: np.stack([pad(p[k]) for p in parts]) for k in parts[0]}
+
+
+def suspicious_run_1d(arr, window=10, op=">", thresh=None):
+    """rl:1668-1714."""
+    import operator
+
+    arr = np.asarray(arr)
+    v, rl_, pos = rle_1d(arr)
+    sus_runs = rl_ >= window
+    if thresh is not None:
+        f = {">": operator.gt, "gt": operator.gt, "<": operator.lt, "lt": operator.lt, "==": operator.eq, "eq": operator.eq,
+             "!=": operator.ne, "ne": operator.ne, ">=": operator.ge, "ge": operator.ge, "gteq": operator.ge,
+             "<=": operator.le, "le": operator.le, "lteq": operator.le}
+        if op not in f:
+            raise NotImplementedError(f"{op}")
+        with np.errstate(invalid="ignore"):
+            sus_runs = sus_runs & f[op](v, thresh)
+    out = np.zeros_like(arr, dtype=bool)
+    for st, length in zip(pos[sus_runs], rl_[sus_runs]):
+        out[st : st + length] = True
+    return out
+
+
+def suspicious_run(arr, window=10, op=">", thresh=None):
+    """rl:1717-1757: vectorised over the cells (time on axis 0)."""
+    arr = np.asarray(arr)
+    out = np.zeros(arr.shape, dtype=bool)
+    for ix in np.ndindex(*arr.shape[1:]):
+        sl = (slice(None),) + ix
+        out[sl] = suspicious_run_1d(arr[sl], window, op, thresh)
+    return out

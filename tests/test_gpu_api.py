@@ -335,3 +335,35 @@ def test_eqm_uniform_to_normal_like_reference_testqm(dev):
     np.testing.assert_almost_equal(eqm.af[2:-2, 0], expected[2:-2], 1)
     p = eqm.adjust(x, interp="linear")
     np.testing.assert_almost_equal(np.sort(p[:, 0])[n // 2 - 5 : n // 2 + 5], np.sort(y[:, 0])[n // 2 - 5 : n // 2 + 5], 1)
+
+
+def test_range_reductions_and_daily_events(dev, rng):
+    """diurnal / interday / extreme temperature range (gen:1076-1105, 1360-1414), compare and get_daily_events."""
+    T = 800
+    tn = _temp(rng, T, (5, 4), nan_frac=0.02)
+    tx = tn + np.abs(rng.normal(6, 2, tn.shape)).astype(np.float32)
+    tx[rng.random(tx.shape) < 0.02] = np.nan
+    tn[:40, 0, 0] = np.nan  # an all-NaN month
+    ta, ot = _axes("2000-05-01", T)
+    for freq in ("YS", "MS", "QS-DEC"):
+        for red in ("max", "min", "mean", "sum"):
+            got = xgen.diurnal_temperature_range(tn, tx, red, ta, freq, device=dev)
+            ref = ogen.diurnal_temperature_range(tn, tx, red, ot, freq)
+            np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-5 if red == "sum" else 0, equal_nan=True)
+        np.testing.assert_allclose(xgen.interday_diurnal_temperature_range(tn, tx, ta, freq, device=dev),
+                                   ogen.interday_diurnal_temperature_range(tn, tx, ot, freq), rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(xgen.extreme_temperature_range(tn, tx, ta, freq, device=dev),
+                                   ogen.extreme_temperature_range(tn, tx, ot, freq), rtol=1e-6, equal_nan=True)
+    out, valid = xgen.diurnal_temperature_range(tn, tx, "mean", ta, "MS", device=dev, with_valid=True)
+    seg, _ = ta.segments("MS")
+    both = (~np.isnan(tn) & ~np.isnan(tx)).astype(np.int32)
+    np.testing.assert_array_equal(valid, np.stack([both[a:b].sum(axis=0) for a, b in zip(seg[:-1], seg[1:])]))
+    for op in (">", "<=", "==", "!="):
+        for thr in (285.0, np.float64(285.1)):
+            np.testing.assert_array_equal(xgen.compare(tx, op, thr, device=dev), ogen.compare(tx, op, thr))
+            np.testing.assert_array_equal(xgen.get_daily_events(tx, thr, op, device=dev), ogen.get_daily_events(tx, thr, op))
+    np.testing.assert_array_equal(xgen.compare(tx, ">", tn + np.float32(6.0), device=dev), ogen.compare(tx, ">", tn + np.float32(6.0)))
+    with pytest.raises(ValueError):
+        xgen.compare(tx, "<", 1.0, constrain=(">", ">="), device=dev)
+    with pytest.raises(ValueError):
+        xgen.diurnal_temperature_range(tn, tx, "std", ta, "YS", device=dev)

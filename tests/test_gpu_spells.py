@@ -173,3 +173,107 @@ def test_windowed_max_run_sum(dev, rng, window):
     f[25:30] = 5
     f[35:45] = 5
     assert xrl.windowed_max_run_sum(f, 3, device=dev)[0] == 50  # reference test_run_length.py:373-381
+
+
+def _runs_mask(rng, T, C, p_on=0.55, nan_frac=0.0):
+    m = (rng.random((T, C)) < p_on).astype(np.float32)
+    # lengthen the runs a little so that windows > 1 find something
+    m = np.maximum(m, np.roll(m, 1, axis=0) * (rng.random((T, C)) < 0.5))
+    if nan_frac:
+        m[rng.random((T, C)) < nan_frac] = np.nan
+    return m.astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_run_bounds(dev, rng):
+    """rl:745-802: start / end indices of every run, NaN padded to the busiest cell."""
+    m = _runs_mask(rng, 200, 37).astype(bool)
+    m[:, 0] = False  # no run at all
+    m[:, 1] = True   # one run that never ends
+    m[-1, 2] = True
+    got = xrl.run_bounds(m, device=dev)
+    ref = orl.run_bounds(m)
+    assert got.shape == ref.shape
+    np.testing.assert_array_equal(got, ref)
+    # hand-checked example
+    one = np.array([0, 1, 1, 0, 1, 0, 0, 1, 1, 1], bool)[:, None]
+    np.testing.assert_array_equal(xrl.run_bounds(one, device=dev)[:, :, 0], [[1, 4, 7], [3, 5, np.nan]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window,window_stop", [(1, 1), (2, 1), (3, 2)])
+@pytest.mark.parametrize("freq", [None, "MS"])
+def test_find_events(dev, rng, window, window_stop, freq):
+    """rl:1760-1901: event table (length, effective length, start, sum) incl. the sum-stops-at-NaN arithmetic."""
+    T, C = 150, 29
+    cond = _runs_mask(rng, T, C).astype(bool)
+    stop = (rng.random((T, C)) < 0.4)
+    data = rng.gamma(2.0, 3.0, (T, C)).astype(np.float32)
+    data[rng.random((T, C)) < 0.05] = np.nan
+    ta, ot = TimeAxis.daily("2001-01-01", T, "standard"), OTime.standard("2001-01-01", T)
+    for cs in (None, stop):
+        got = xrl.find_events(cond, window, cs, window_stop, data=data, freq=freq, time=ta, device=dev)
+        ref = orl.find_events(cond, window, cs, window_stop, data=data, freq=freq, time=ot)
+        assert set(got) == set(ref)
+        for k in ref:
+            assert got[k].shape == ref[k].shape, k
+            if k == "event_sum":
+                np.testing.assert_allclose(got[k], ref[k], rtol=1e-6, equal_nan=True)
+            else:
+                np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window,op,thresh", [(3, ">", None), (2, ">", 1.0), (1, "==", 2.0), (4, "<=", 3.0), (2, "!=", 0.0)])
+def test_suspicious_run(dev, rng, window, op, thresh):
+    x = rng.integers(0, 4, (300, 23)).astype(np.float32)
+    x[rng.random(x.shape) < 0.05] = np.nan
+    x[100:140, 3] = 2.0
+    got = xrl.suspicious_run(x, window=window, op=op, thresh=thresh, device=dev)
+    np.testing.assert_array_equal(got, orl.suspicious_run(x, window, op, thresh))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("freq", [None, "YS"])
+def test_rle_statistics_quantile(dev, rng, freq):
+    """rl:318-327 with "qNN" reducers: quantile (linear) of the run lengths >= window, 0 without any."""
+    T, C = 730, 41
+    m = _runs_mask(rng, T, C, nan_frac=0.01)
+    m[:, 0] = 0
+    ta, ot = TimeAxis.daily("2001-01-01", T, "standard"), OTime.standard("2001-01-01", T)
+    for red, window in (("q90", 1), ("q10", 2), ("q50", 3)):
+        got = xrl.rle_statistics(m, red, window, freq=freq, time=ta, device=dev)
+        ref = orl.rle_statistics(m, red, window, time=ot, freq=freq)
+        np.testing.assert_allclose(got, ref, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_reference_run_quantile_answers(dev):
+    """tests/test_run_length.py:270-296 of the reference: q90 = 299.6, q10 = 64.4 on the synthetic run pattern."""
+    values = np.zeros(365, np.float32)
+    values[1:11] = 1
+    values[20:350] = 1
+    values[355:] = 1  # runs of 10, 330, 10
+    got90 = xrl.rle_statistics(values[:, None], "q90", 1, device=dev)
+    got10 = xrl.rle_statistics(values[:, None], "q10", 1, device=dev)
+    np.testing.assert_allclose(got90, np.quantile([10, 330, 10], 0.9), rtol=1e-6)
+    np.testing.assert_allclose(got10, np.quantile([10, 330, 10], 0.1), rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_1d_variants_and_season_end(dev, rng):
+    """rl:1334-1618: the 1-D ("ufunc") spellings give the N-D results."""
+    v = (rng.random(400) < 0.6)
+    assert xrl.statistics_run_1d(v, "max", 2, device=dev) == orl.statistics_run_1d(v, "max", 2)
+    assert xrl.windowed_run_count_1d(v, 3, device=dev) == orl.windowed_run_count_1d(v, 3)
+    assert xrl.windowed_run_events_1d(v, 3, device=dev) == orl.windowed_run_events_1d(v, 3)
+    f = xrl.first_run_1d(v, 4, device=dev)
+    r = orl.first_run_1d(v, 4)
+    assert (np.isnan(f) and np.isnan(r)) or f == r
+    vals, lens, pos = xrl.rle_1d(np.array([1, 2, 2, 3, 3, 3]))
+    np.testing.assert_array_equal(lens, [1, 2, 3])
+    np.testing.assert_array_equal(pos, [0, 1, 3])
+    m = _runs_mask(rng, 365, 11).astype(bool)
+    ta = TimeAxis.daily("2001-01-01", 365, "standard")
+    np.testing.assert_array_equal(xrl.season_end(m, 3, "07-01", time=ta, device=dev),
+                                  xrl.season(m, 3, "07-01", time=ta, device=dev)["end"])

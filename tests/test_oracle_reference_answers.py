@@ -232,3 +232,23 @@ def test_tg_mean_and_missing():  # test_temperature.py:162-191 semantics: NaN da
     ot = OTime.standard("2001-01-01", 731)
     out = oidx.apply_missing(oidx.tg_mean(tas, ot, "YS"), tas, ot, "YS")
     assert out[0] == 280.0 and np.isnan(out[1]) and np.isnan(out[2])  # 2002 has the NaN, 2003 is a 1-day stub
+
+
+def test_range_reductions_known_answers():
+    """Hand-computed answers for the two-variable range reductions (gen:1076-1105, 1360-1414), in the style of
+    tests/test_indices.py::TestDailyTemperatureRange / TestETR / TestVDTR of the reference."""
+    from oracle import generic as ogen
+    from oracle.timeutil import OTime
+
+    T = 10
+    low = np.full((T, 1), 280.0, np.float32)
+    high = low + np.arange(T, dtype=np.float32)[:, None]  # ranges 0..9
+    high[3, 0] = np.nan
+    t = OTime.standard("2000-01-01", T)
+    assert ogen.diurnal_temperature_range(low, high, "max", t, "YS")[0, 0] == 9
+    assert ogen.diurnal_temperature_range(low, high, "mean", t, "YS")[0, 0] == np.float32((45 - 3) / 9)
+    # |diff| of (0,1,2,nan,4,...,9): 1,1,nan,nan,1,1,1,1,1 -> mean 1
+    assert ogen.interday_diurnal_temperature_range(low, high, t, "YS")[0, 0] == 1
+    assert ogen.extreme_temperature_range(low, high, t, "YS")[0, 0] == 9
+    ev = ogen.get_daily_events(high[:, 0], 283.5, ">")
+    assert np.isnan(ev[3]) and ev[:3].sum() == 0 and ev[4:].sum() == 6

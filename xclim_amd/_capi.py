@@ -68,11 +68,15 @@ SIGNATURES: dict[str, list] = {
     "xh_rle": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64],
     "xh_run_stats": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _int, _int, _int, _vp, _int, _int, _vp, _vp],
     "xh_bivariate_count": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _int, _dbl, _int, _vp, _int, _vp, _vp],
+    "xh_range_reduce": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _int, _vp, _vp],
+    "xh_compare_map": [_vp, _vp, _i64, _i64, _i64, _int, _dbl, _int, _vp, _i64, _int, _vp, _i64],
     "xh_thresholded_reduce": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _int, _int, _vp, _int, _vp, _vp],
     "xh_mask_rows": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _vp, _int, _vp, _i64],
     "xh_doy_mean_std": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _vp, _vp],
     "xh_spell_mask": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _dbl, _vp, _vp, _i64],
     "xh_runs_with_holes": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _i64],
+    "xh_run_events": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "xh_suspicious_run": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _dbl, _vp, _i64],
     "xh_keep_longest_run": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _i64],
     "xh_season": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, _vp],
     "xh_max_run_sum": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _int, _vp],
@@ -212,6 +216,9 @@ class Device:
         if a.nbytes:
             _check(self.lib, self.lib.xh_memset(self.ctx, _vp(a.ptr), 0, a.nbytes))
         return a
+
+    def copy_d2d(self, dst_ptr: int, src_ptr: int, nbytes: int) -> None:
+        _check(self.lib, self.lib.xh_memcpy_d2d(self.ctx, _vp(dst_ptr), _vp(src_ptr), int(nbytes)))
 
     def to_device(self, arr: np.ndarray, dtype=None) -> DeviceArray:
         arr = np.ascontiguousarray(arr, dtype=dtype)

@@ -1,0 +1,153 @@
+// elemwise.hip — two-variable range reductions and the elementwise compare map.
+//
+// Reference (xclim/indices/generic.py):
+//   diurnal_temperature_range           gen:1076-1105   reducer((high - low).resample(time=freq))
+//   extreme_temperature_range           gen:1388-1414   high.resample.max() - low.resample.min()
+//   interday_diurnal_temperature_range  gen:1360-1385   abs((high - low).diff("time")).resample(time=freq).mean()
+//   compare / get_daily_events          gen:301-326, 395-431
+// Time-major (T, C), one lane owns VEC consecutive cells, periods on blockIdx.y.  (high - low) and the day-to-day
+// difference are formed in fp32 like the reference (fp32 arrays), sums accumulate in fp64.  All reducers skip NaN
+// (xarray's default for floats): empty / all-NaN period -> NaN, except sum -> 0.
+#include "common.h"
+
+template <int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_range_reduce(const float* __restrict__ lo, const float* __restrict__ hi, int64_t C, int64_t st_lo, int64_t st_hi, int mode,
+               int reducer, const int64_t* __restrict__ seg_off, int P, float* __restrict__ out,
+               int32_t* __restrict__ valid_out) {
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    double s[VEC];
+    float e1[VEC], e2[VEC], prev[VEC];
+    int n[VEC], n2[VEC], val[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      s[i] = 0.0; n[i] = 0; n2[i] = 0; val[i] = 0; e1[i] = 0.f; e2[i] = 0.f;
+      prev[i] = xh_nan32();
+    }
+    if (mode == 1 && t0 > 0) {  // the difference at the first day of the period uses the last day of the previous one
+      VecF<VEC> a = xh_load<VEC>(lo + (t0 - 1) * st_lo + c), b = xh_load<VEC>(hi + (t0 - 1) * st_hi + c);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) prev[i] = b.v[i] - a.v[i];
+    }
+#pragma unroll 4
+    for (int64_t t = t0; t < t1; ++t) {
+      VecF<VEC> a = xh_load<VEC>(lo + t * st_lo + c), b = xh_load<VEC>(hi + t * st_hi + c);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float l = a.v[i], h = b.v[i];
+        val[i] += (l == l && h == h) ? 1 : 0;
+        if (mode == 2) {  // extreme range: max(high), min(low) tracked separately
+          if (h == h) { e1[i] = (n[i] == 0 || h > e1[i]) ? h : e1[i]; n[i]++; }
+          if (l == l) { e2[i] = (n2[i] == 0 || l < e2[i]) ? l : e2[i]; n2[i]++; }
+        } else {
+          const float d = h - l;
+          float v = d;
+          if (mode == 1) {
+            v = fabsf(d - prev[i]);  // NaN on the very first day of the series (diff drops it) and next to NaNs
+            prev[i] = d;
+          }
+          if (v == v) {
+            s[i] += (double)v;
+            e1[i] = (n[i] == 0 || (reducer == XH_RED_MIN ? v < e1[i] : v > e1[i])) ? v : e1[i];
+            n[i]++;
+          }
+        }
+      }
+    }
+    const int64_t o = (int64_t)p * C + c;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float r;
+      if (mode == 2) r = (n[i] == 0 || n2[i] == 0) ? xh_nan32() : e1[i] - e2[i];
+      else if (mode == 1 || reducer == XH_RED_MEAN) r = n[i] == 0 ? xh_nan32() : (float)(s[i] / (double)n[i]);
+      else if (reducer == XH_RED_SUM) r = (float)s[i];
+      else r = n[i] == 0 ? xh_nan32() : e1[i];
+      out[o + i] = r;
+      if (valid_out) valid_out[o + i] = val[i];
+    }
+  }
+}
+
+// out_kind 0: uint8 mask (compare)        1: float 1/0, NaN where a is NaN (get_daily_events)
+//          2: float a where the condition holds, NaN elsewhere (da.where(cond))
+template <bool F64>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_compare_map(const float* __restrict__ a, int64_t T, int64_t C, int64_t st, int op, double thr, const float* __restrict__ b,
+              int64_t st_b, int out_kind, void* __restrict__ out_v, int64_t st_out) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
+  int64_t ta = (int64_t)blockIdx.y * chunk, tb = ta + chunk;
+  if (tb > T) tb = T;
+  const float thr32 = (float)thr;
+#pragma unroll 4
+  for (int64_t t = ta; t < tb; ++t) {
+    const float v = a[t * st + c];
+    bool cond;
+    if (b) cond = xh_cmp_f32(v, op, b[t * st_b + c]);
+    else cond = F64 ? xh_cmp_f64((double)v, op, thr) : xh_cmp_f32(v, op, thr32);
+    if (out_kind == 0) reinterpret_cast<uint8_t*>(out_v)[t * st_out + c] = cond ? 1 : 0;
+    else if (out_kind == 1) reinterpret_cast<float*>(out_v)[t * st_out + c] = (v == v) ? (cond ? 1.f : 0.f) : xh_nan32();
+    else reinterpret_cast<float*>(out_v)[t * st_out + c] = cond ? v : xh_nan32();
+  }
+}
+
+extern "C" {
+
+int xh_range_reduce(xh_ctx* ctx, const float* low, const float* high, int64_t T, int64_t C, int64_t st_low, int64_t st_high,
+                    int mode, int reducer, const int64_t* seg_off, int P, float* out, int32_t* valid_out) {
+  XH_REQUIRE(ctx && low && high && out, XH_ERR_ARG, "xh_range_reduce: NULL argument");
+  XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "xh_range_reduce: negative shape");
+  XH_REQUIRE(st_low >= C && st_high >= C, XH_ERR_LAYOUT, "xh_range_reduce: needs time-major views (row strides >= C)");
+  XH_REQUIRE(mode >= 0 && mode <= 2, XH_ERR_ARG, "xh_range_reduce: mode must be 0 (range), 1 (interday) or 2 (extreme)");
+  XH_REQUIRE(mode != 0 || (reducer >= XH_RED_SUM && reducer <= XH_RED_MAX), XH_ERR_OP,
+             "xh_range_reduce: reducer %d not recognized", reducer);
+  XH_REQUIRE(seg_off && P >= 1, XH_ERR_ARG, "xh_range_reduce: seg_off NULL or P < 1");
+  for (int p = 0; p < P; ++p)
+    XH_REQUIRE(seg_off[p] <= seg_off[p + 1] && seg_off[p] >= 0 && seg_off[p + 1] <= T, XH_ERR_ARG,
+               "xh_range_reduce: seg_off must be non-decreasing within [0, T]");
+  size_t cur = 0;
+  void* d_seg = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, seg_off, sizeof(int64_t) * (size_t)(P + 1), &d_seg);
+  if (rc) return rc;
+  if (C == 0) return XH_OK;
+  const int vec = (xh_pick_vec(low, C, st_low) == 4 && xh_pick_vec(high, C, st_high) == 4) ? 4 : 1;
+  dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P));
+  if (vec == 4)
+    hipLaunchKernelGGL((k_range_reduce<4>), grid, dim3(XH_BLOCK), 0, ctx->stream, low, high, C, st_low, st_high, mode, reducer,
+                       (const int64_t*)d_seg, P, out, valid_out);
+  else
+    hipLaunchKernelGGL((k_range_reduce<1>), grid, dim3(XH_BLOCK), 0, ctx->stream, low, high, C, st_low, st_high, mode, reducer,
+                       (const int64_t*)d_seg, P, out, valid_out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_compare_map(xh_ctx* ctx, const float* a, int64_t T, int64_t C, int64_t st, int op, double thr, int thr_is_f64,
+                   const float* b, int64_t st_b, int out_kind, void* out, int64_t st_out) {
+  XH_REQUIRE(ctx && a && out, XH_ERR_ARG, "xh_compare_map: NULL argument");
+  XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "xh_compare_map: negative shape");
+  XH_REQUIRE(st >= C && st_out >= C && (!b || st_b >= C), XH_ERR_LAYOUT, "xh_compare_map: needs time-major views");
+  XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
+  XH_REQUIRE(out_kind >= 0 && out_kind <= 2, XH_ERR_ARG, "xh_compare_map: out_kind must be 0, 1 or 2");
+  if (T == 0 || C == 0) return XH_OK;
+  const int64_t cblocks = cdiv64(C, XH_BLOCK);
+  int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
+  if (gy < 1) gy = 1;
+  if (gy > T) gy = T;
+  if (gy > 1024) gy = 1024;
+  dim3 grid((unsigned)cblocks, (unsigned)gy);
+  if (thr_is_f64 && !b)
+    hipLaunchKernelGGL((k_compare_map<true>), grid, dim3(XH_BLOCK), 0, ctx->stream, a, T, C, st, op, thr, b, st_b, out_kind, out,
+                       st_out);
+  else
+    hipLaunchKernelGGL((k_compare_map<false>), grid, dim3(XH_BLOCK), 0, ctx->stream, a, T, C, st, op, thr, b, st_b, out_kind,
+                       out, st_out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+}  // extern "C"

@@ -181,6 +181,93 @@ k_max_run_sum(const float* __restrict__ x, int64_t C, int64_t st, int window, co
   }
 }
 
+// ---- event compaction: run_bounds (rl:745-802) and find_events (rl:1760-1901) -------------------------------------
+// `runs` is a 0/1 field (a mask, or the output of runs_with_holes).  Per (period, cell) the k-th run in time order
+// writes row k of the (P, maxev, C) outputs; rows past the number of runs stay NaN (the reference pads with NaN):
+//   start : index of the run's first step, relative to the period start       end : index of the first step after
+//   the run (diff == -1 in run_bounds; NaN when the run reaches the period end)    len : run length (rle)
+//   eff   : steps of the run where `eff` is true (event_effective_length; = len when eff is NULL)
+//   sum   : _cumsum_reset_xr(data.where(runs == 1), index="first", reset_on_zero=False) at the run start, restated
+//           with the reference's arithmetic (fp32 cumsum of the reversed series, NaN adds 0, minus its value at the
+//           latest NaN): the sum of `data` from the run start up to the first NaN of data inside the run.
+// Pass 1 counts the runs (the backward march numbers them from the end), pass 2 marches backward.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_run_events(const float* __restrict__ runs, const float* __restrict__ eff, const float* __restrict__ data, int64_t C,
+             int64_t st, const int64_t* __restrict__ seg_off, int P, int maxev, float* __restrict__ o_start,
+             float* __restrict__ o_end, float* __restrict__ o_len, float* __restrict__ o_eff, float* __restrict__ o_sum) {
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    int ne = 0;
+    bool prev = false;
+    for (int64_t t = t0; t < t1; ++t) {
+      const bool on = runs[t * st + c] == 1.0f;
+      ne += (on && !prev) ? 1 : 0;
+      prev = on;
+    }
+    const int64_t base = (int64_t)p * maxev * C + c;
+    for (int k = (ne < maxev ? ne : maxev); k < maxev; ++k) {
+      const int64_t o = base + (int64_t)k * C;
+      o_start[o] = xh_nan32();
+      if (o_end) o_end[o] = xh_nan32();
+      if (o_len) o_len[o] = xh_nan32();
+      if (o_eff) o_eff[o] = xh_nan32();
+      if (o_sum) o_sum[o] = xh_nan32();
+    }
+    int k = ne, run = 0, effc = 0;
+    float cs = 0.0f, csr = 0.0f, endv = xh_nan32();
+    bool on = t1 > t0 ? (runs[(t1 - 1) * st + c] == 1.0f) : false;
+    for (int64_t t = t1 - 1; t >= t0; --t) {
+      const bool before = t > t0 ? (runs[(t - 1) * st + c] == 1.0f) : false;
+      float dv = xh_nan32();
+      if (data && on) dv = data[t * st + c];
+      cs = cs + ((dv == dv) ? dv : 0.0f);
+      if (!(dv == dv)) csr = cs;
+      if (on) {
+        if (run == 0) endv = (t + 1 < t1) ? (float)(t + 1 - t0) : xh_nan32();
+        run++;
+        if (eff) { const float e = eff[t * st + c]; effc += (e == e && e != 0.0f) ? 1 : 0; } else effc++;
+        if (!before) {  // first step of the run
+          k--;
+          if (k < maxev) {
+            const int64_t o = base + (int64_t)k * C;
+            o_start[o] = (float)(t - t0);
+            if (o_end) o_end[o] = endv;
+            if (o_len) o_len[o] = (float)run;
+            if (o_eff) o_eff[o] = (float)effc;
+            if (o_sum) o_sum[o] = cs - csr;
+          }
+          run = 0; effc = 0;
+        }
+      }
+      on = before;
+    }
+  }
+}
+
+// ---- suspicious_run (rl:1668-1757): steps that belong to a run of >= window IDENTICAL values (optionally only runs
+// whose value satisfies `op thresh`).  rle_1d compares with != , so every NaN is a run of its own.  Forward march;
+// when a run reaches `window` its first window-1 steps are flagged retroactively.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_suspicious_run(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int window, int op, float thresh,
+                 uint8_t* __restrict__ out, int64_t out_st) {
+  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  float cur = 0.0f;
+  int cnt = 0;
+  for (int64_t t = 0; t < T; ++t) {
+    const float v = x[t * st + c];
+    cnt = (t > 0 && v == cur) ? cnt + 1 : 1;  // NaN == NaN is false: NaNs never extend a run
+    cur = v;
+    const bool okv = op < 0 ? true : xh_cmp_f32(v, op, thresh);
+    const bool flag = okv && cnt >= window;
+    out[t * out_st + c] = flag ? 1 : 0;
+    if (flag && cnt == window)
+      for (int k = 1; k < window; ++k) out[(t - k) * out_st + c] = 1;
+  }
+}
+
 static int chk(const char* fn, xh_ctx* ctx, const void* x, int64_t T, int64_t C, int64_t st, int64_t sc) {
   XH_REQUIRE(ctx && x, XH_ERR_ARG, "%s: NULL argument", fn);
   XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "%s: negative shape", fn);
@@ -293,6 +380,39 @@ int xh_max_run_sum(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   if (C == 0) return XH_OK;
   hipLaunchKernelGGL(k_max_run_sum, dim3((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)), dim3(XH_BLOCK), 0,
                      ctx->stream, x, C, st, window, d_seg, P, out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_run_events(xh_ctx* ctx, const float* runs, const float* eff, const float* data, int64_t T, int64_t C, int64_t st,
+                  int64_t sc, const int64_t* seg_off, int P, int maxev, float* start_out, float* end_out, float* len_out,
+                  float* eff_out, float* sum_out) {
+  int rc = chk("xh_run_events", ctx, runs, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(start_out, XH_ERR_ARG, "xh_run_events: start_out is NULL");
+  XH_REQUIRE(maxev >= 0, XH_ERR_ARG, "xh_run_events: maxev must be >= 0");
+  XH_REQUIRE(!sum_out || data, XH_ERR_ARG, "xh_run_events: sum_out needs data");
+  size_t cur = 0;
+  const int64_t* d_seg = nullptr;
+  rc = upload_seg(ctx, &cur, seg_off, P, T, "xh_run_events", &d_seg);
+  if (rc) return rc;
+  if (C == 0 || maxev == 0) return XH_OK;
+  hipLaunchKernelGGL(k_run_events, dim3((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)), dim3(XH_BLOCK), 0,
+                     ctx->stream, runs, eff, data, C, st, d_seg, P, maxev, start_out, end_out, len_out, eff_out, sum_out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_suspicious_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, int op,
+                      double thresh, uint8_t* out, int64_t out_st) {
+  int rc = chk("xh_suspicious_run", ctx, x, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(out && out_st >= C, XH_ERR_ARG, "xh_suspicious_run: out NULL or out_st < C");
+  XH_REQUIRE(window >= 1, XH_ERR_ARG, "xh_suspicious_run: window must be >= 1");
+  XH_REQUIRE(op >= -1 && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
+  if (C == 0 || T == 0) return XH_OK;
+  hipLaunchKernelGGL(k_suspicious_run, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window,
+                     op, (float)thresh, out, out_st);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

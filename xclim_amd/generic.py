@@ -119,6 +119,68 @@ def bivariate_count_occurrences(*, data_var1, data_var2, threshold_var1: float, 
     return _finish(cnt, val, cell_shape, keep, with_valid)
 
 
+def compare(left, op: str, right, constrain=None, *, device=None, keep=False):
+    """gen:301-326: elementwise ``left op right`` -> bool mask (NaN compares False, True for ``!=``).  ``right``: python
+    float (fp32 compare), ``np.float64`` (fp64 compare) or an array of the shape of ``left``."""
+    sym = get_op(op, constrain)
+    dev = device or get_device()
+    x, cell_shape = _flatten(left, dev)
+    if np.ndim(right) == 0 and not isinstance(right, DeviceArray):
+        m = K.compare_map(dev, x, sym, right, "mask")
+    else:
+        b, _ = _flatten(np.broadcast_to(np.asarray(right, dtype=np.float32), np.shape(left))
+                        if not isinstance(right, DeviceArray) else right, dev)
+        m = K.compare_map(dev, x, sym, b, "mask")
+    if keep:
+        return m
+    return m.get().reshape((x.shape[0],) + tuple(cell_shape)).astype(bool)
+
+
+def get_daily_events(da, threshold, op: str, constrain=None, *, device=None, keep=False):
+    """gen:395-431: 1 where ``da op threshold``, 0 where not, NaN where ``da`` is NaN (float32)."""
+    sym = get_op(op, constrain)
+    dev = device or get_device()
+    x, cell_shape = _flatten(da, dev)
+    if np.ndim(threshold) == 0 and not isinstance(threshold, DeviceArray):
+        ev = K.compare_map(dev, x, sym, threshold, "events")
+    else:
+        b, _ = _flatten(np.broadcast_to(np.asarray(threshold, dtype=np.float32), np.shape(da))
+                        if not isinstance(threshold, DeviceArray) else threshold, dev)
+        ev = K.compare_map(dev, x, sym, b, "events")
+    if keep:
+        return ev
+    return ev.get().reshape((x.shape[0],) + tuple(cell_shape))
+
+
+def _range(low_data, high_data, mode, reducer, time, freq, device, keep, with_valid):
+    dev = device or get_device()
+    lo, cell_shape = _flatten(low_data, dev)
+    hi, _ = _flatten(high_data, dev)
+    seg, _ = time.segments(freq)
+    out, val = K.range_reduce(dev, lo, hi, mode, reducer, seg)
+    return _finish(out, val, cell_shape, keep, with_valid)
+
+
+def diurnal_temperature_range(low_data, high_data, reducer: str, time: TimeAxis, freq: str, *, device=None, keep=False,
+                              with_valid=False):
+    """gen:1076-1105: ``reducer`` in {max, min, mean, sum} of (high - low) per period."""
+    if reducer not in ("max", "min", "mean", "sum"):
+        raise ValueError(f"Reducer `{reducer}` not supported.")
+    return _range(low_data, high_data, "range", reducer, time, freq, device, keep, with_valid)
+
+
+def interday_diurnal_temperature_range(low_data, high_data, time: TimeAxis, freq: str, *, device=None, keep=False,
+                                       with_valid=False):
+    """gen:1360-1385: mean absolute day-to-day difference of the diurnal range."""
+    return _range(low_data, high_data, "interday", "mean", time, freq, device, keep, with_valid)
+
+
+def extreme_temperature_range(low_data, high_data, time: TimeAxis, freq: str, *, device=None, keep=False,
+                              with_valid=False):
+    """gen:1388-1414: max of the daily maxima minus min of the daily minima."""
+    return _range(low_data, high_data, "extreme", "max", time, freq, device, keep, with_valid)
+
+
 def _thresholded(data, op, threshold, mode, reducer, time, freq, constrain, device, keep, with_valid):
     sym = get_op(op, constrain)
     dev = device or get_device()

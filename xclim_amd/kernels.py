@@ -179,6 +179,32 @@ def bivariate_count(dev: Device, x1: DeviceArray, x2: DeviceArray, op1, thr1, op
     return count, valid
 
 
+def range_reduce(dev: Device, low: DeviceArray, high: DeviceArray, mode: str, reducer: str, seg_off, want_valid=True):
+    """mode: "range" (reducer of high - low) | "interday" (mean |diff|) | "extreme" (max(high) - min(low))."""
+    T, C_ = _tc(low)
+    assert high.shape == low.shape
+    seg, P = _seg(seg_off)
+    out = dev.empty((P, C_), np.float32)
+    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    dev.call("xh_range_reduce", _vp(low.ptr), _vp(high.ptr), T, C_, C_, C_, {"range": 0, "interday": 1, "extreme": 2}[mode],
+             REDUCERS.get(reducer, 0), np_ptr(seg), P, _vp(out.ptr), _vp(valid.ptr if valid else 0))
+    return out, valid
+
+
+def compare_map(dev: Device, a: DeviceArray, op, thr, kind: str = "mask") -> DeviceArray:
+    """kind: "mask" (uint8) | "events" (float 1/0/NaN) | "where" (a where cond else NaN); thr: scalar or DeviceArray."""
+    T, C_ = _tc(a)
+    ok = {"mask": 0, "events": 1, "where": 2}[kind]
+    out = dev.empty(a.shape, np.uint8 if ok == 0 else np.float32)
+    if isinstance(thr, DeviceArray):
+        assert thr.shape == a.shape and thr.dtype == np.float32
+        dev.call("xh_compare_map", _vp(a.ptr), T, C_, C_, op_code(op), 0.0, 0, _vp(thr.ptr), C_, ok, _vp(out.ptr), C_)
+    else:
+        dev.call("xh_compare_map", _vp(a.ptr), T, C_, C_, op_code(op), float(thr), int(isinstance(thr, np.float64)), _vp(0), 0, ok,
+                 _vp(out.ptr), C_)
+    return out
+
+
 def thresholded_reduce(dev: Device, x: DeviceArray, op, thr, mode: int, reducer: str, seg_off, want_valid=True):
     T, C_ = _tc(x)
     seg, P = _seg(seg_off)
@@ -226,6 +252,28 @@ def runs_with_holes(dev: Device, start: DeviceArray, window_start: int, stop: De
     out = dev.empty((T, C_), np.float32)
     dev.call("xh_runs_with_holes", _vp(start.ptr), _vp(stop.ptr if stop is not None else 0), T, C_, C_, 1, int(window_start),
              int(window_stop), _vp(out.ptr), C_)
+    return out
+
+
+def run_events(dev: Device, runs: DeviceArray, seg_off, maxev: int, eff: DeviceArray | None = None,
+               data: DeviceArray | None = None, want=("start", "end", "len")):
+    """Event compaction (xh_run_events): dict of (P, maxev, C) float32 arrays, NaN past the last run."""
+    T, C_ = _tc(runs)
+    seg, P = _seg(seg_off)
+    out = {k: dev.empty((P, int(maxev), C_), np.float32) for k in want}
+    if "start" not in out:
+        out["start"] = dev.empty((P, int(maxev), C_), np.float32)
+    ptr = lambda k: _vp(out[k].ptr if k in out else 0)
+    dev.call("xh_run_events", _vp(runs.ptr), _vp(eff.ptr if eff is not None else 0), _vp(data.ptr if data is not None else 0), T, C_,
+             C_, 1, np_ptr(seg), P, int(maxev), ptr("start"), ptr("end"), ptr("len"), ptr("eff"), ptr("sum"))
+    return out
+
+
+def suspicious_run(dev: Device, x: DeviceArray, window: int, op=None, thresh=None) -> DeviceArray:
+    T, C_ = _tc(x)
+    out = dev.empty((T, C_), np.uint8)
+    dev.call("xh_suspicious_run", _vp(x.ptr), T, C_, C_, 1, int(window), -1 if thresh is None else op_code(op),
+             0.0 if thresh is None else float(thresh), _vp(out.ptr), C_)
     return out
 
 
@@ -302,7 +350,7 @@ def doy_interp(dev: Device, table: DeviceArray, i0, i1, dxn, dxs) -> DeviceArray
     return out
 
 
-def quantile_series(dev: Device, x: DeviceArray, q, time_axis=0) -> DeviceArray:
+def quantile_series(dev: Device, x: DeviceArray, q, time_axis=0, out=None) -> DeviceArray:
     """Per-cell quantiles of the whole series: x (T, C) [time_axis 0] or (C, T) [time_axis 1] -> (nq, C) float32."""
     q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
     if time_axis == 0:
@@ -311,7 +359,8 @@ def quantile_series(dev: Device, x: DeviceArray, q, time_axis=0) -> DeviceArray:
     else:
         C_, T = _tc(x)
         st, sc = 1, T
-    out = dev.empty((len(q), C_), np.float32)
+    if out is None:
+        out = dev.empty((len(q), C_), np.float32)
     dev.call("xh_quantile_series", _vp(x.ptr), T, C_, st, sc, np_ptr(q), len(q), _vp(out.ptr))
     return out
 

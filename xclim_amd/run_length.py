@@ -72,9 +72,33 @@ def rle_statistics(da, reducer: str, window: int, dim="time", freq=None, ufunc_1
                    time: TimeAxis | None = None, device=None, keep=False):
     """rl:275-335.  ``freq`` given -> resample AFTER the run-length encoding."""
     use_ufunc(ufunc_1dim, freq=freq, index=index)
-    if reducer.startswith("q"):
-        raise NotImplementedError("quantile run statistics are not wired to the HIP path yet")
+    if reducer.startswith("q") and reducer[1:].isdigit():
+        return _run_quantile(da, float(f"0.{reducer[1:]}"), window, time, freq, index, device, keep)
     return _run(da, reducer, window, time, freq, index, device, keep)
+
+
+def _run_quantile(da, q, window, time, freq, index, device, keep):
+    """rl:318-327 with reducer "qNN": d.where(d >= window).quantile(q) (linear / Hyndman-Fan type 7, NaN-skipping) of the
+    run lengths of each period, 0 where the period holds no run of at least `window`."""
+    dev = device or get_device()
+    m, cell_shape = _mask(da, dev)
+    T, C_ = m.shape
+    d = K.compare_map(dev, K.rle(dev, m, index), ">=", float(window), "where")
+    seg = _whole(T) if freq is None else time.segments(freq)[0]
+    P = len(seg) - 1
+    out = dev.empty((P, C_), np.float32)
+    for p in range(P):
+        t0, t1 = int(seg[p]), int(seg[p + 1])
+        if t1 <= t0:
+            continue
+        view = DeviceArray(dev, d.ptr + t0 * C_ * 4, (t1 - t0, C_), np.float32, owner=False)
+        row = DeviceArray(dev, out.ptr + p * C_ * 4, (1, C_), np.float32, owner=False)
+        K.quantile_series(dev, view, [q], out=row)
+    o = np.nan_to_num(out.get(), nan=0.0)  # no qualifying run -> 0 (rl:326)
+    if keep:
+        return dev.to_device(o)
+    o = o.reshape((P,) + tuple(cell_shape))
+    return o[0] if freq is None else o
 
 
 def longest_run(da, dim="time", freq=None, ufunc_1dim="from_context", index="first", *, time=None, device=None,
@@ -313,3 +337,140 @@ def resample_and_rl(da, resample_before_rl: bool, compute, *args, freq: str, tim
     seg, _ = time.segments(freq)
     out, _ = K.run_stats(dev, m, stat, window, seg, cut=True, index=index, want_valid=False)
     return out if keep else out.get().reshape((out.shape[0],) + tuple(cell_shape))
+
+
+def season_end(da, window: int, mid_date: str | None = None, dim="time", coord=False, *, time: TimeAxis | None = None,
+               device=None):
+    """rl:932-995 (stand-alone form: a season with a start but no end ends on the last step)."""
+    return season(da, window, mid_date, dim, coord=coord, time=time, device=device)["end"]
+
+
+def run_bounds(mask, dim="time", coord=False, *, time: TimeAxis | None = None, device=None):
+    """rl:745-802: (2, events, *cells) float array of [start, end) step indices of every run of True values, the events
+    axis as long as the cell with most runs needs and NaN-padded.  ``end`` is the first step AFTER the run (the position
+    of the -1 in the differenced mask), NaN for a run that reaches the end.  coord="dayofyear" maps the indices."""
+    dev = device or get_device()
+    m, cell_shape = _mask(mask, dev)
+    T = m.shape[0]
+    seg = _whole(T)
+    nruns, _ = K.run_stats(dev, m, "count", 1, seg, cut=True, want_valid=False)
+    n = int(np.nanmax(nruns.get())) if m.shape[1] else 0
+    ev = K.run_events(dev, m, seg, n, want=("start", "end"))
+    out = np.stack([ev["start"].get()[0], ev["end"].get()[0]]).astype(np.float64).reshape((2, n) + tuple(cell_shape))
+    if coord:
+        if coord != "dayofyear":
+            raise NotImplementedError("only coord='dayofyear' is supported")
+        ok = ~np.isnan(out)
+        out[ok] = time.doy[out[ok].astype(np.int64)]
+    return out
+
+
+def find_events(condition, window: int, condition_stop=None, window_stop: int = 1, data=None, freq: str | None = None, *,
+                time: TimeAxis | None = None, device=None):
+    """rl:1846-1901 / 1760-1842.  Returns a dict of (event, *cells) arrays (or (period, event, *cells) with ``freq``):
+    event_length, event_effective_length, event_start (step index relative to the period start; the reference converts
+    it to a date with the time coordinate) and event_sum when ``data`` is given; NaN past the last event.  The event
+    axis has ceil(T / (window + window_stop)) entries like the reference's."""
+    dev = device or get_device()
+    a, cell_shape = _mask(condition, dev)
+    T, C_ = a.shape
+    if condition_stop is None:
+        b = K.compare_map(dev, a, "==", 0.0, "events")  # ~condition (NaN stays NaN and counts as False in the kernel)
+    else:
+        b, _ = _mask(condition_stop, dev)
+    dat = None
+    if data is not None:
+        dat, _ = _flatten(np.asarray(data, dtype=np.float32) if not isinstance(data, DeviceArray) else data, dev)
+    seg = _whole(T) if freq is None else time.segments(freq)[0]
+    P = len(seg) - 1
+    lens = np.diff(seg)
+    nev = int(np.ceil((int(lens.max()) if P else 0) / (window + window_stop)))
+    # runs with holes are found independently in every period (resample(...).map in the reference)
+    runs = dev.empty((T, C_), np.float32)
+    for p in range(P):
+        t0, t1 = int(seg[p]), int(seg[p + 1])
+        if t1 <= t0:
+            continue
+        va = DeviceArray(dev, a.ptr + t0 * C_ * 4, (t1 - t0, C_), np.float32, owner=False)
+        vb = DeviceArray(dev, b.ptr + t0 * C_ * 4, (t1 - t0, C_), np.float32, owner=False)
+        r = K.runs_with_holes(dev, va, window, vb, window_stop)
+        dev.copy_d2d(runs.ptr + t0 * C_ * 4, r.ptr, (t1 - t0) * C_ * 4)
+    want = ("start", "len", "eff") + (("sum",) if dat is not None else ())
+    ev = K.run_events(dev, runs, seg, nev, eff=a, data=dat, want=want)
+    shp = (P, nev) + tuple(cell_shape)
+    out = {"event_length": ev["len"].get().reshape(shp), "event_effective_length": ev["eff"].get().reshape(shp),
+           "event_start": ev["start"].get().reshape(shp)}
+    if dat is not None:
+        out["event_sum"] = ev["sum"].get().reshape(shp)
+    if freq is None:
+        out = {k: v[0] for k, v in out.items()}
+    return out
+
+
+def suspicious_run(arr, dim="time", window: int = 10, op: str = ">", thresh=None, *, device=None, keep=False):
+    """rl:1717-1757: True on the steps that belong to a run of at least ``window`` identical values (optionally only
+    values satisfying ``op thresh``)."""
+    from .generic import get_op
+
+    dev = device or get_device()
+    x, cell_shape = _flatten(np.asarray(arr, dtype=np.float32) if not isinstance(arr, DeviceArray) else arr, dev)
+    out = K.suspicious_run(dev, x, window, get_op(op) if thresh is not None else None, thresh)
+    return out if keep else out.get().reshape((x.shape[0],) + tuple(cell_shape)).astype(bool)
+
+
+# ---- 1-D "ufunc" variants (rl:1334-1618): same results as the N-D functions on this backend -------------------------
+def rle_1d(arr):
+    """rl:1334-1389: (values, run lengths, start positions) of the runs of identical values of a 1-D array.  Pure host
+    bookkeeping (variable-length output), restated with numpy."""
+    ia = np.asarray(arr)
+    n = len(ia)
+    if n == 0:
+        import warnings
+
+        warnings.warn("run length array empty", stacklevel=2)
+        return np.array(np.nan), 0, np.array(np.nan)
+    y = ia[1:] != ia[:-1]
+    i = np.append(np.nonzero(y)[0], n - 1)
+    rl_ = np.diff(np.append(-1, i))
+    pos = np.cumsum(np.append(0, rl_))[:-1]
+    return ia[i], rl_, pos
+
+
+def statistics_run_1d(arr, reducer: str, window: int, *, device=None):
+    """rl:1436-1465."""
+    return rle_statistics(np.asarray(arr)[:, None], reducer, window, device=device)[0]
+
+
+def windowed_run_count_1d(arr, window: int, *, device=None):
+    """rl:1468-1486."""
+    return windowed_run_count(np.asarray(arr)[:, None], window, device=device)[0]
+
+
+def windowed_run_events_1d(arr, window: int, *, device=None):
+    """rl:1489-1507."""
+    return windowed_run_events(np.asarray(arr)[:, None], window, device=device)[0]
+
+
+def first_run_1d(arr, window: int, *, device=None):
+    """rl:1392-1414."""
+    return first_run(np.asarray(arr)[:, None], window, device=device)[0]
+
+
+def statistics_run_ufunc(x, reducer: str, window: int, dim="time", *, device=None):
+    """rl:1531-1562 (vectorised 1-D form == N-D form here)."""
+    return rle_statistics(x, reducer, window, dim, device=device)
+
+
+def windowed_run_count_ufunc(x, window: int, dim="time", *, device=None):
+    """rl:1565-1590."""
+    return windowed_run_count(x, window, dim, device=device)
+
+
+def windowed_run_events_ufunc(x, window: int, dim="time", *, device=None):
+    """rl:1510-1528."""
+    return windowed_run_events(x, window, dim, device=device)
+
+
+def first_run_ufunc(x, window: int, dim="time", *, device=None):
+    """rl:1593-1618."""
+    return first_run(x, window, dim, device=device)
