@@ -151,7 +151,8 @@ int xh_range_reduce(xh_ctx* ctx, const float* low, const float* high, int64_t T,
 
 /* compare (generic.py:301-326) / get_daily_events (generic.py:395-431) as an elementwise map of a (T, C) field against a
  * scalar (fp32 compare, or fp64 when thr_is_f64) or a second field b (NULL for the scalar form):
- *   out_kind 0: uint8 mask    1: float32 1/0 with NaN where a is NaN    2: float32 a.where(cond) (NaN elsewhere) */
+ *   out_kind 0: uint8 mask    1: float32 1/0 with NaN where a is NaN    2: float32 a.where(cond) (NaN elsewhere)
+ *            3: float32 1/0 (the boolean mask as float, NaN compares False) */
 int xh_compare_map(xh_ctx* ctx, const float* a, int64_t T, int64_t C, int64_t st, int op, double thr, int thr_is_f64,
                    const float* b, int64_t st_b, int out_kind, void* out, int64_t st_out);
 
@@ -218,6 +219,13 @@ int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, 
 int xh_spell_mask(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window,
                   int win_reducer, int op, double thr, const float* weights /* host, may be NULL */, float* out,
                   int64_t out_st);
+
+/* spell_mask on a list of variables (generic.py:434-540, `data` a sequence): xs[nvar] device pointers to (T, C) fields of
+ * the same layout, thrs[nvar] their thresholds (host arrays); the per-variable window conditions are combined with
+ * all (combine = 1) or any (2) before the spell is propagated.  nvar <= 8. */
+int xh_spell_mask_multi(xh_ctx* ctx, const float* const* xs, int nvar, const double* thrs, int combine, int64_t T,
+                        int64_t C, int64_t st, int64_t sc, int window, int win_reducer, int op, const float* weights,
+                        float* out, int64_t out_st);
 /* runs_with_holes (indices/run_length.py:844-888): hysteresis mask — on after window_start consecutive `start`,
  * off after window_stop consecutive `stop` (stop == NULL means stop = NOT start); out (T, C) float32 0/1. */
 int xh_runs_with_holes(xh_ctx* ctx, const float* start, const float* stop, int64_t T, int64_t C, int64_t st,

@@ -208,54 +208,62 @@ def select_rolling_resample_op(da, op, window, time: OTime, window_center=True, 
     return select_resample_op(rolling(da, window, window_op, window_center), op, time, freq)
 
 
-def spell_mask(data, window, win_reducer, op, thresh, min_gap=1, weights=None):
-    """gen:434-540, single variable."""
-    m = _spell_mask_nogap(data, window, win_reducer, op, thresh, weights)
+def spell_mask(data, window, win_reducer, op, thresh, min_gap=1, weights=None, var_reducer="all"):
+    """gen:434-540.  `data` may be a list of variables (with a list of thresholds): the reference concatenates them
+    along a "variable" dimension and reduces the per-variable condition with all / any at the point restated here."""
+    if isinstance(data, (list, tuple)):
+        if not isinstance(thresh, (list, tuple)) or len(thresh) != len(data):
+            raise ValueError("When `data` is a sequence, `thresh` must be a sequence of the same length.")
+        m = _spell_mask_nogap([np.asarray(d) for d in data], window, win_reducer, op, list(thresh), weights, var_reducer)
+    else:
+        m = _spell_mask_nogap([np.asarray(data)], window, win_reducer, op, [thresh], weights, "all")
     if min_gap > 1:
         m = rl.runs_with_holes(m, 1, ~m, min_gap).astype(bool)  # gen:537-538
     return m
 
 
-def _spell_mask_nogap(data, window, win_reducer, op, thresh, weights=None):
-    data = np.asarray(data)
+def _spell_mask_nogap(datas, window, win_reducer, op, threshs, weights=None, var_reducer="all"):
+    def reduce_vars(masks):
+        st = np.stack(masks)
+        return st.all(axis=0) if var_reducer == "all" else st.any(axis=0)
+
     if weights is not None:
         if win_reducer != "mean":
             raise ValueError(f"Argument 'weights' is only supported if 'win_reducer' is 'mean'. Got :  {win_reducer}")
         if len(weights) != window:
             raise ValueError(f"Weights have a different length ({len(weights)}) than the window ({window}).")
-        T = data.shape[0]
-        pad = np.concatenate([data, np.full((window,) + data.shape[1:], np.nan, dtype=data.dtype)], axis=0)
-        sv = np.full(pad.shape, np.nan)
-        w = np.asarray(weights, dtype=np.float64)
-        for t in range(window - 1, pad.shape[0]):
-            sv[t] = np.tensordot(w, pad[t - window + 1 : t + 1].astype(np.float64), axes=(0, 0))
-        mask = compare(sv.astype(np.float32), op, thresh)
-        msum = rolling(mask.astype(np.float64), window, "sum", center=False)
-        with np.errstate(invalid="ignore"):
-            is_in = msum >= 1
-        return rl.shift0(is_in, -(window - 1), False)[:T]
+    T = datas[0].shape[0]
     if window == 1:
-        return compare(data, op, thresh)
-    if (win_reducer == "min" and op in [">", ">=", "ge", "gt"]) or (win_reducer == "max" and op in ["`<", "<=", "le", "lt"]):
+        return reduce_vars([compare(d, op, th) for d, th in zip(datas, threshs)])
+    if weights is None and ((win_reducer == "min" and op in [">", ">=", "ge", "gt"])
+                            or (win_reducer == "max" and op in ["`<", "<=", "le", "lt"])):
         # gen:503-518 (the literal "`<" typo of gen:504 is kept: "<" takes the general path)
-        mask = compare(data, op, thresh)
+        mask = reduce_vars([compare(d, op, th) for d, th in zip(datas, threshs)])
         cs_s = rl.cumsum_reset(mask)
         with np.errstate(invalid="ignore"):
             cs_s = rl.where_nan(cs_s, rl.shift0(mask.astype(np.float64), -1, 0) == 0)
             v = rl.where_nan(cs_s, cs_s >= window)
         v = np.where(mask > 0, v, 0)
         # bfill along time
-        T = v.shape[0]
         idx = np.where(~np.isnan(v), np.arange(T).reshape((-1,) + (1,) * (v.ndim - 1)), T - 1)
         idx = np.minimum.accumulate(idx[::-1], axis=0)[::-1]
         filled = np.take_along_axis(v, idx, axis=0)
         with np.errstate(invalid="ignore"):
             return filled > 0
     # general path gen:519-535
-    T = data.shape[0]
-    pad = np.concatenate([data, np.full((window,) + data.shape[1:], np.nan, dtype=data.dtype)], axis=0)
-    spell_value = rolling(pad, window, win_reducer, center=False)
-    mask = compare(spell_value, op, thresh)
+    masks = []
+    for data, thresh in zip(datas, threshs):
+        pad = np.concatenate([data, np.full((window,) + data.shape[1:], np.nan, dtype=data.dtype)], axis=0)
+        if weights is not None:
+            sv = np.full(pad.shape, np.nan)
+            w = np.asarray(weights, dtype=np.float64)
+            for t in range(window - 1, pad.shape[0]):
+                sv[t] = np.tensordot(w, pad[t - window + 1 : t + 1].astype(np.float64), axes=(0, 0))
+            spell_value = sv.astype(np.float32)
+        else:
+            spell_value = rolling(pad, window, win_reducer, center=False)
+        masks.append(compare(spell_value, op, thresh))
+    mask = reduce_vars(masks)
     msum = rolling(mask.astype(np.float64), window, "sum", center=False)
     with np.errstate(invalid="ignore"):
         is_in = msum >= 1
@@ -265,7 +273,8 @@ def _spell_mask_nogap(data, window, win_reducer, op, thresh, weights=None):
 
 def spell_length_statistics(data, thresh, window, win_reducer, op, spell_reducer, time: OTime, freq,
                             resample_before_rl=True, min_gap=1):
-    """gen:543-585 / 588-686 without indexer: mask -> float32 -> resample_and_rl(rle_statistics, window=1)."""
+    """gen:543-585 / 588-686 (and the bivariate form gen:689-766 when data / thresh are lists) without indexer:
+    mask -> float32 -> resample_and_rl(rle_statistics, window=1)."""
     mask = spell_mask(data, window, win_reducer, op, thresh, min_gap=min_gap).astype(np.float32)
     return rl.resample_and_rl(mask, resample_before_rl, rl.rle_statistics, time=time, freq=freq, reducer=spell_reducer,
                               window=1)

@@ -277,3 +277,49 @@ def test_1d_variants_and_season_end(dev, rng):
     ta = TimeAxis.daily("2001-01-01", 365, "standard")
     np.testing.assert_array_equal(xrl.season_end(m, 3, "07-01", time=ta, device=dev),
                                   xrl.season(m, 3, "07-01", time=ta, device=dev)["end"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window,red,op", [(1, "min", ">"), (3, "min", ">="), (3, "max", "<"), (4, "mean", ">"), (2, "sum", "<="),
+                                           (3, "max", "<=")])
+@pytest.mark.parametrize("var_reducer", ["all", "any"])
+def test_spell_mask_two_variables(dev, rng, window, red, op, var_reducer):
+    """gen:434-540 with a list of variables, incl. the daily-combination fast path of gen:503-518."""
+    a = _pr(rng, 300, 31, nan_frac=0.02)
+    b = _pr(rng, 300, 31, nan_frac=0.02) * 1.5
+    th = [2.0, 3.5] if red != "sum" else [5.0, 8.0]
+    got = xgen.spell_mask([a, b], window, red, op, th, var_reducer=var_reducer, device=dev)
+    ref = ogen.spell_mask([a, b], window, red, op, th, var_reducer=var_reducer)
+    np.testing.assert_array_equal(got, ref)
+    got2 = xgen.spell_mask([a, b], window, red, op, th, min_gap=3, var_reducer=var_reducer, device=dev)
+    np.testing.assert_array_equal(got2, ogen.spell_mask([a, b], window, red, op, th, min_gap=3, var_reducer=var_reducer))
+
+
+@pytest.mark.gpu
+def test_bivariate_spell_length_statistics_and_thresholded_events(dev, rng):
+    T = 500
+    pr = _pr(rng, T, 23, nan_frac=0.01)
+    tas = (rng.normal(2.0, 4.0, (T, 23))).astype(np.float32)
+    ta, ot = TimeAxis.daily("2001-03-01", T, "standard"), OTime.standard("2001-03-01", T)
+    for window, red in ((1, "min"), (3, "min"), (3, "mean")):
+        for sr in ("max", "sum", "count"):
+            got = xgen.bivariate_spell_length_statistics(pr, 1.0, tas, 0.0, window, red, ">=", sr, ta, "YS", device=dev)
+            ref = ogen.spell_length_statistics([pr, tas], [1.0, 0.0], window, red, ">=", sr, ot, "YS")
+            np.testing.assert_array_equal(got, ref)
+    both = xgen.bivariate_spell_length_statistics(pr, 1.0, tas, 0.0, 2, "min", ">=", ("max", "count"), ta, "MS", device=dev)
+    assert isinstance(both, tuple) and len(both) == 2
+    with pytest.raises(ValueError):
+        xgen.spell_mask([pr, tas], 2, "min", ">", 1.0, device=dev)
+    # thresholded_events (gen:1739-1804) = find_events on compare masks
+    for kw in ({}, {"thresh_stop": 0.5}, {"op_stop": "<", "thresh_stop": 0.2}):
+        got = xgen.thresholded_events(pr, 1.0, ">=", 2, window_stop=2, time=ta, device=dev, **kw)
+        start = ogen.compare(pr, ">=", 1.0)
+        if not kw:
+            stop = ~start
+        elif "op_stop" in kw:
+            stop = ogen.compare(pr, "<", 0.2)
+        else:
+            stop = ~ogen.compare(pr, ">=", 0.5)
+        ref = orl.find_events(start, 2, stop, 2, data=pr)
+        for k in ref:
+            np.testing.assert_allclose(got[k], ref[k], rtol=1e-6, equal_nan=True, err_msg=k)

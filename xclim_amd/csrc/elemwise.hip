@@ -72,7 +72,7 @@ k_range_reduce(const float* __restrict__ lo, const float* __restrict__ hi, int64
 }
 
 // out_kind 0: uint8 mask (compare)        1: float 1/0, NaN where a is NaN (get_daily_events)
-//          2: float a where the condition holds, NaN elsewhere (da.where(cond))
+//          2: float a where the condition holds, NaN elsewhere (da.where(cond))     3: float 1/0 (bool mask as float)
 template <bool F64>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_compare_map(const float* __restrict__ a, int64_t T, int64_t C, int64_t st, int op, double thr, const float* __restrict__ b,
@@ -91,7 +91,8 @@ k_compare_map(const float* __restrict__ a, int64_t T, int64_t C, int64_t st, int
     else cond = F64 ? xh_cmp_f64((double)v, op, thr) : xh_cmp_f32(v, op, thr32);
     if (out_kind == 0) reinterpret_cast<uint8_t*>(out_v)[t * st_out + c] = cond ? 1 : 0;
     else if (out_kind == 1) reinterpret_cast<float*>(out_v)[t * st_out + c] = (v == v) ? (cond ? 1.f : 0.f) : xh_nan32();
-    else reinterpret_cast<float*>(out_v)[t * st_out + c] = cond ? v : xh_nan32();
+    else if (out_kind == 2) reinterpret_cast<float*>(out_v)[t * st_out + c] = cond ? v : xh_nan32();
+    else reinterpret_cast<float*>(out_v)[t * st_out + c] = cond ? 1.f : 0.f;
   }
 }
 
@@ -132,7 +133,7 @@ int xh_compare_map(xh_ctx* ctx, const float* a, int64_t T, int64_t C, int64_t st
   XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "xh_compare_map: negative shape");
   XH_REQUIRE(st >= C && st_out >= C && (!b || st_b >= C), XH_ERR_LAYOUT, "xh_compare_map: needs time-major views");
   XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
-  XH_REQUIRE(out_kind >= 0 && out_kind <= 2, XH_ERR_ARG, "xh_compare_map: out_kind must be 0, 1 or 2");
+  XH_REQUIRE(out_kind >= 0 && out_kind <= 3, XH_ERR_ARG, "xh_compare_map: out_kind must be 0, 1, 2 or 3");
   if (T == 0 || C == 0) return XH_OK;
   const int64_t cblocks = cdiv64(C, XH_BLOCK);
   int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);

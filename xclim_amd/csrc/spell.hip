@@ -11,8 +11,15 @@
 // trailing window [t'-w+1, t'] (NaN anywhere or an incomplete window -> False, xarray rolling min_periods = w);
 // out[t] = any cond[t'] for t' in [t, t+w-1].  The window is re-read from L2 (w loads per step).
 // win_red: 0 sum, 1 mean, 2 min, 3 max, 4 weighted mean (dot with weights[w]).
+// Several variables (gen:434-540 with a list of DataArrays): the per-variable conditions are combined with all (1) /
+// any (2) before the second rolling step; xs / thrs hold nvar device pointers / thresholds.
+struct SpellVars {
+  const float* x[8];
+  float thr[8];
+};
+
 __global__ void __launch_bounds__(XH_BLOCK)
-k_spell_mask(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int window, int win_red, int op, float thr,
+k_spell_mask(SpellVars vars, int nvar, int combine, int64_t T, int64_t C, int64_t st, int window, int win_red, int op,
              const float* __restrict__ weights, float* __restrict__ out, int64_t out_st) {
   int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
   if (c >= C) return;
@@ -20,19 +27,24 @@ k_spell_mask(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
   for (int64_t tp = 0; tp < T + window - 1; ++tp) {
     bool cond = false;
     if (tp < T && tp >= window - 1) {
-      double s = 0.0;
-      float e = x[(tp - window + 1) * st + c];
-      bool nan = false;
-      for (int k = 0; k < window; ++k) {
-        float v = x[(tp - window + 1 + k) * st + c];
-        nan |= (v != v);
-        if (win_red == 2) e = v < e ? v : e;
-        else if (win_red == 3) e = v > e ? v : e;
-        else if (win_red == 4) s += (double)v * (double)weights[k];
-        else s += (double)v;
+      cond = combine == 1;
+      for (int iv = 0; iv < nvar; ++iv) {
+        const float* __restrict__ x = vars.x[iv];
+        double s = 0.0;
+        float e = x[(tp - window + 1) * st + c];
+        bool nan = false;
+        for (int k = 0; k < window; ++k) {
+          float v = x[(tp - window + 1 + k) * st + c];
+          nan |= (v != v);
+          if (win_red == 2) e = v < e ? v : e;
+          else if (win_red == 3) e = v > e ? v : e;
+          else if (win_red == 4) s += (double)v * (double)weights[k];
+          else s += (double)v;
+        }
+        float stat = (win_red == 2 || win_red == 3) ? e : (win_red == 1 ? (float)(s / (double)window) : (float)s);
+        const bool cv = !nan && xh_cmp_f32(stat, op, vars.thr[iv]);
+        cond = combine == 1 ? (cond && cv) : (cond || cv);
       }
-      float stat = (win_red == 2 || win_red == 3) ? e : (win_red == 1 ? (float)(s / (double)window) : (float)s);
-      cond = !nan && xh_cmp_f32(stat, op, thr);
     }
     if (cond) last_true = tp;
     int64_t t = tp - (window - 1);
@@ -290,28 +302,51 @@ static int upload_seg(xh_ctx* ctx, size_t* cur, const int64_t* seg_off, int P, i
 
 extern "C" {
 
-int xh_spell_mask(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, int win_reducer,
-                  int op, double thr, const float* weights, float* out, int64_t out_st) {
-  int rc = chk("xh_spell_mask", ctx, x, T, C, st, sc);
-  if (rc) return rc;
-  XH_REQUIRE(out && out_st >= C, XH_ERR_ARG, "xh_spell_mask: out NULL or out_st < C");
-  XH_REQUIRE(window >= 1, XH_ERR_ARG, "xh_spell_mask: window must be >= 1");
-  XH_REQUIRE(win_reducer >= 0 && win_reducer <= 4, XH_ERR_OP, "xh_spell_mask: win_reducer %d not recognized", win_reducer);
+static int spell_mask_impl(xh_ctx* ctx, const char* fn, const float* const* xs, int nvar, const double* thrs, int combine,
+                           int64_t T, int64_t C, int64_t st, int64_t sc, int window, int win_reducer, int op,
+                           const float* weights, float* out, int64_t out_st) {
+  XH_REQUIRE(ctx && xs && thrs, XH_ERR_ARG, "%s: NULL argument", fn);
+  XH_REQUIRE(nvar >= 1 && nvar <= 8, XH_ERR_LIMIT, "%s: 1 to 8 variables are supported (got %d)", fn, nvar);
+  XH_REQUIRE(combine == 1 || combine == 2, XH_ERR_ARG, "%s: combine must be 1 (all) or 2 (any)", fn);
+  for (int i = 0; i < nvar; ++i) {
+    int rc = chk(fn, ctx, xs[i], T, C, st, sc);
+    if (rc) return rc;
+  }
+  XH_REQUIRE(out && out_st >= C, XH_ERR_ARG, "%s: out NULL or out_st < C", fn);
+  XH_REQUIRE(window >= 1, XH_ERR_ARG, "%s: window must be >= 1", fn);
+  XH_REQUIRE(win_reducer >= 0 && win_reducer <= 4, XH_ERR_OP, "%s: win_reducer %d not recognized", fn, win_reducer);
   XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
-  XH_REQUIRE(win_reducer != 4 || weights, XH_ERR_ARG, "xh_spell_mask: weights required for the weighted mean");
+  XH_REQUIRE(win_reducer != 4 || weights, XH_ERR_ARG, "%s: weights required for the weighted mean", fn);
   if (T == 0 || C == 0) return XH_OK;
   const float* d_w = nullptr;
   if (win_reducer == 4) {
     size_t cur = 0;
     void* d = nullptr;
-    rc = xh_scratch_upload(ctx, &cur, weights, sizeof(float) * (size_t)window, &d);
+    int rc = xh_scratch_upload(ctx, &cur, weights, sizeof(float) * (size_t)window, &d);
     if (rc) return rc;
     d_w = (const float*)d;
   }
-  hipLaunchKernelGGL(k_spell_mask, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window,
-                     win_reducer, op, (float)thr, d_w, out, out_st);
+  SpellVars vars;
+  for (int i = 0; i < 8; ++i) {
+    vars.x[i] = i < nvar ? xs[i] : nullptr;
+    vars.thr[i] = i < nvar ? (float)thrs[i] : 0.0f;
+  }
+  hipLaunchKernelGGL(k_spell_mask, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, vars, nvar, combine, T, C,
+                     st, window, win_reducer, op, d_w, out, out_st);
   XH_LAUNCH_CHECK();
   return XH_OK;
+}
+
+int xh_spell_mask(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, int win_reducer,
+                  int op, double thr, const float* weights, float* out, int64_t out_st) {
+  return spell_mask_impl(ctx, "xh_spell_mask", &x, 1, &thr, 1, T, C, st, sc, window, win_reducer, op, weights, out, out_st);
+}
+
+int xh_spell_mask_multi(xh_ctx* ctx, const float* const* xs, int nvar, const double* thrs, int combine, int64_t T, int64_t C,
+                        int64_t st, int64_t sc, int window, int win_reducer, int op, const float* weights, float* out,
+                        int64_t out_st) {
+  return spell_mask_impl(ctx, "xh_spell_mask_multi", xs, nvar, thrs, combine, T, C, st, sc, window, win_reducer, op, weights,
+                         out, out_st);
 }
 
 int xh_runs_with_holes(xh_ctx* ctx, const float* start, const float* stop, int64_t T, int64_t C, int64_t st, int64_t sc,

@@ -237,29 +237,58 @@ def select_rolling_resample_op(da, op: str, window: int, time: TimeAxis, window_
     return _finish(out, val, cell_shape, keep, with_valid)
 
 
-def spell_length_statistics(data, threshold: float, window: int, win_reducer, op: str, spell_reducer: str,
-                            time: TimeAxis, freq: str, min_gap: int = 1, resample_before_rl: bool = True, *,
-                            device=None, keep=False, with_valid=False):
+def spell_length_statistics(data, threshold, window: int, win_reducer, op: str, spell_reducer, time: TimeAxis, freq: str,
+                            min_gap: int = 1, resample_before_rl: bool = True, *, device=None, keep=False,
+                            with_valid=False):
     """gen:588-686 / 543-585.  window == 1 (the path of maximum_consecutive_dry/wet_days and friends): compare,
-    astype(float32), rle_statistics(window=1) fused in ONE kernel pass.  window > 1 is not wired yet."""
+    astype(float32), rle_statistics(window=1) fused in ONE kernel pass; window > 1 / min_gap > 1 / several variables go
+    through :func:`spell_mask`.  ``spell_reducer`` may be a sequence (-> tuple of results)."""
+    if not isinstance(spell_reducer, str):
+        return tuple(spell_length_statistics(data, threshold, window, win_reducer, op, sr, time, freq, min_gap,
+                                             resample_before_rl, device=device, keep=keep, with_valid=with_valid)
+                     for sr in spell_reducer)
     sym = get_op(op)
     dev = device or get_device()
-    x, cell_shape = _flatten(data, dev)
+    multi = isinstance(data, (list, tuple))
     seg, _ = time.segments(freq)
-    if window == 1 and min_gap == 1:
+    if multi:
+        flat = [_flatten(d, dev) for d in data]
+        x, cell_shape = flat[0]
+    else:
+        x, cell_shape = _flatten(data, dev)
+    if window == 1 and min_gap == 1 and not multi:
         out, val = K.run_stats(dev, x, spell_reducer, 1, seg, cut=resample_before_rl, fused_op=sym, thresh=float(threshold))
         return _finish(out, val, cell_shape, keep, with_valid)
-    mask = spell_mask(x, window, win_reducer, op, threshold, min_gap=min_gap, device=dev, keep=True)
+    mask = spell_mask([f[0] for f in flat] if multi else x, window, win_reducer, op, threshold, min_gap=min_gap, device=dev,
+                      keep=True)
     out, _ = K.run_stats(dev, mask, spell_reducer, 1, seg, cut=resample_before_rl, want_valid=False)
     val = None
-    if with_valid:  # valid count of the DATA, not of the mask
-        _, val = K.resample_reduce(dev, x, "count", seg)
+    if with_valid:  # valid count of the DATA, not of the mask (every variable must be present)
+        if multi:
+            _, val = K.bivariate_count(dev, flat[0][0], flat[1][0], ">", 0.0, ">", 0.0, "all", seg)
+        else:
+            _, val = K.resample_reduce(dev, x, "count", seg)
     return _finish(out, val, cell_shape, keep, with_valid)
 
 
-def spell_mask(data, window: int, win_reducer: str, op: str, thresh: float, min_gap: int = 1, weights=None,
+def bivariate_spell_length_statistics(data1, threshold1: float, data2, threshold2: float, window: int, win_reducer, op: str,
+                                      spell_reducer, time: TimeAxis, freq: str, min_gap: int = 1,
+                                      resample_before_rl: bool = True, *, device=None, keep=False, with_valid=False):
+    """gen:689-766: spell statistics where BOTH variables fulfil their window condition."""
+    return spell_length_statistics([data1, data2], [threshold1, threshold2], window, win_reducer, op, spell_reducer, time,
+                                   freq, min_gap, resample_before_rl, device=device, keep=keep, with_valid=with_valid)
+
+
+def spell_mask(data, window: int, win_reducer: str, op: str, thresh, min_gap: int = 1, weights=None,
                var_reducer: str = "all", *, device=None, keep=False):
-    """gen:434-540 for one variable: boolean (0/1 float32) mask of the days that are part of a spell."""
+    """gen:434-540: boolean mask of the days that are part of a spell.  ``data`` may be a list of variables with one
+    (scalar) threshold each; their window conditions are combined with ``var_reducer`` (all / any)."""
+    multi = isinstance(data, (list, tuple))
+    if multi:
+        if not isinstance(thresh, (list, tuple)) or len(thresh) != len(data):
+            raise ValueError("When `data` is a sequence, `thresh` must be a sequence of the same length.")
+        if var_reducer not in ("all", "any"):
+            raise ValueError(f"Unsupported value for var_reducer: {var_reducer}")
     if weights is not None:
         if win_reducer != "mean":
             raise ValueError(f"Argument 'weights' is only supported if 'win_reducer' is 'mean'. Got :  {win_reducer}")
@@ -267,16 +296,55 @@ def spell_mask(data, window: int, win_reducer: str, op: str, thresh: float, min_
             raise ValueError(f"Weights have a different length ({len(weights)}) than the window ({window}).")
     sym = get_op(op)
     dev = device or get_device()
-    x, cell_shape = _flatten(data, dev)
-    if window == 1:
-        m = K.spell_mask(dev, x, 1, "min", sym, float(thresh))
+    if multi:
+        flat = [_flatten(d, dev) for d in data]
+        xs, cell_shape = [f[0] for f in flat], flat[0][1]
+        th = [float(t) for t in thresh]
+        fast = weights is None and ((win_reducer == "min" and op in (">", ">=", "ge", "gt"))
+                                    or (win_reducer == "max" and op in ("`<", "<=", "le", "lt")))
+        if window == 1:
+            m = K.spell_mask_multi(dev, xs, 1, "min", sym, th, var_reducer)
+        elif fast:
+            # gen:503-518: the DAILY conditions are combined first, then runs of >= window days are kept (this differs
+            # from the general path for var_reducer="any"; the "`<" typo of gen:504 sends "<" to the general path)
+            daily = K.spell_mask_multi(dev, xs, 1, "min", sym, th, var_reducer)
+            m = K.spell_mask(dev, daily, window, "min", ">=", 1.0)
+        else:
+            m = K.spell_mask_multi(dev, xs, window, win_reducer, sym, th, var_reducer, weights)
     else:
-        m = K.spell_mask(dev, x, window, win_reducer, sym, float(thresh), weights)
+        x, cell_shape = _flatten(data, dev)
+        if window == 1:
+            m = K.spell_mask(dev, x, 1, "min", sym, float(thresh))
+        else:
+            m = K.spell_mask(dev, x, window, win_reducer, sym, float(thresh), weights)
     if min_gap > 1:
         m = K.runs_with_holes(dev, m, 1, None, min_gap)  # rl.runs_with_holes(mask, 1, ~mask, min_gap), gen:537-538
     if keep:
         return m
     return m.get().reshape((m.shape[0],) + tuple(cell_shape)).astype(bool)
+
+
+def thresholded_events(data, thresh: float, op: str, window: int, thresh_stop=None, op_stop=None, window_stop: int = 1,
+                       freq: str | None = None, *, time: TimeAxis | None = None, device=None):
+    """gen:1739-1804: event table of run_length.find_events with start condition ``data op thresh`` and stop condition
+    ``data op_stop thresh_stop`` (default: the negation of the start condition)."""
+    from . import run_length as hrl
+
+    dev = device or get_device()
+    x, _ = _flatten(data, dev)
+    start = K.compare_map(dev, x, get_op(op), thresh, "maskf")
+    if thresh_stop is None and op_stop is None:
+        stop = None
+    else:
+        ts = thresh if thresh_stop is None else thresh_stop
+        if op_stop is not None:
+            stop = K.compare_map(dev, x, get_op(op_stop), ts, "maskf")
+        else:
+            stop = K.compare_map(dev, K.compare_map(dev, x, get_op(op), ts, "maskf"), "==", 0.0, "maskf")
+    shape = np.shape(data) if not isinstance(data, DeviceArray) else data.shape
+    st = start.reshape(*shape)
+    sp = None if stop is None else stop.reshape(*shape)
+    return hrl.find_events(st, window, sp, window_stop, data=x.reshape(*shape), freq=freq, time=time, device=dev)
 
 
 def _occurrence(data, threshold, op, time, freq, constrain, device, last):

@@ -192,9 +192,10 @@ def range_reduce(dev: Device, low: DeviceArray, high: DeviceArray, mode: str, re
 
 
 def compare_map(dev: Device, a: DeviceArray, op, thr, kind: str = "mask") -> DeviceArray:
-    """kind: "mask" (uint8) | "events" (float 1/0/NaN) | "where" (a where cond else NaN); thr: scalar or DeviceArray."""
+    """kind: "mask" (uint8) | "maskf" (float 1/0) | "events" (float 1/0/NaN) | "where" (a where cond else NaN); thr: scalar
+    or DeviceArray."""
     T, C_ = _tc(a)
-    ok = {"mask": 0, "events": 1, "where": 2}[kind]
+    ok = {"mask": 0, "events": 1, "where": 2, "maskf": 3}[kind]
     out = dev.empty(a.shape, np.uint8 if ok == 0 else np.float32)
     if isinstance(thr, DeviceArray):
         assert thr.shape == a.shape and thr.dtype == np.float32
@@ -244,6 +245,20 @@ def spell_mask(dev: Device, x: DeviceArray, window: int, win_reducer: str, op: s
     red = WIN_REDUCERS["wmean" if w is not None else (win_reducer or "min")]
     dev.call("xh_spell_mask", _vp(x.ptr), T, C_, C_, 1, int(window), red, op_code(op), float(thresh),
              np_ptr(w) if w is not None else _vp(0), _vp(out.ptr), C_)
+    return out
+
+
+def spell_mask_multi(dev: Device, xs, window: int, win_reducer: str, op: str, threshs, var_reducer="all", weights=None) -> DeviceArray:
+    """spell_mask on a list of (T, C) device arrays with one threshold each (xh_spell_mask_multi)."""
+    T, C_ = _tc(xs[0])
+    assert all(x.shape == xs[0].shape for x in xs) and len(threshs) == len(xs)
+    out = dev.empty((T, C_), np.float32)
+    w = np.ascontiguousarray(weights, dtype=np.float32) if weights is not None else None
+    red = WIN_REDUCERS["wmean" if w is not None else (win_reducer or "min")]
+    ptrs = np.array([x.ptr for x in xs], dtype=np.uint64)
+    thr = np.ascontiguousarray(threshs, dtype=np.float64)
+    dev.call("xh_spell_mask_multi", np_ptr(ptrs), len(xs), np_ptr(thr), {"all": 1, "any": 2}[var_reducer], T, C_, C_, 1,
+             int(window), red, op_code(op), np_ptr(w) if w is not None else _vp(0), _vp(out.ptr), C_)
     return out
 
 

@@ -375,7 +375,7 @@ def find_events(condition, window: int, condition_stop=None, window_stop: int = 
     a, cell_shape = _mask(condition, dev)
     T, C_ = a.shape
     if condition_stop is None:
-        b = K.compare_map(dev, a, "==", 0.0, "events")  # ~condition (NaN stays NaN and counts as False in the kernel)
+        b = K.compare_map(dev, a, "==", 0.0, "maskf")  # ~condition
     else:
         b, _ = _mask(condition_stop, dev)
     dat = None
