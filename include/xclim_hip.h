@@ -288,6 +288,15 @@ int xh_percentile_doy_mapped(xh_ctx* ctx, const float* x, int64_t T, int64_t C, 
 int xh_doy_interp(xh_ctx* ctx, const double* in, int D_in, int64_t C, const int32_t* i0, const int32_t* i1,
                   const double* dxn, const double* dxs, int D_out, double* out);
 
+/* resample_doy (core/calendar.py:763-790): out (T, C) float64 = table[tidx[t]] for a (D, C) per-doy table; tidx is the
+ * host array of table rows per time step.  (xh_threshold_count fuses this gather; this entry materialises the field.) */
+int xh_doy_broadcast(xh_ctx* ctx, const double* table, int D, int64_t C, const int32_t* tidx, int64_t T, double* out);
+
+/* within_bnds_doy (core/calendar.py:934-954): out (T, C) uint8 = (low[tidx[t]] < x[t]) && (x[t] < high[tidx[t]]),
+ * fp64 compares, low / high (D, C) float64 per-doy tables. */
+int xh_within_bnds_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* low,
+                       const double* high, int D, const int32_t* tidx, uint8_t* out);
+
 /* ---- sdba empirical quantile mapping (E1-E4; xsdba >= 0.4.0, not in the reference tree) ------ */
 /* nbutils.quantile: per-cell NaN-aware type-7 quantiles of the whole series at nq nodes. out (nq, C) f32 */
 int xh_quantile_series(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,

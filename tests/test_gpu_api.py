@@ -367,3 +367,28 @@ def test_range_reductions_and_daily_events(dev, rng):
         xgen.compare(tx, "<", 1.0, constrain=(">", ">="), device=dev)
     with pytest.raises(ValueError):
         xgen.diurnal_temperature_range(tn, tx, "std", ta, "YS", device=dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("calendar,T", [("standard", 1461), ("noleap", 1095)])
+def test_resample_doy_and_within_bnds_doy(dev, rng, calendar, T):
+    """cal:763-790 / 934-954: per-doy tables broadcast onto the time axis."""
+    from xclim_amd.calendar import resample_doy, within_bnds_doy
+
+    x = _temp(rng, T, (4, 5), nan_frac=0.01)
+    ta, ot = _axes("2000-01-01", T, calendar)
+    p = percentile_doy(x, ta, window=5, per=[10.0, 90.0], device=dev)
+    exp, doys = ocal.percentile_doy(x, ot, 5, [10.0, 90.0])
+    # target axis in another span (incl. other leap years)
+    T2 = 900
+    y = _temp(rng, T2, (4, 5), nan_frac=0.01)
+    ta2, ot2 = _axes("2003-02-01", T2, calendar)
+    lo = resample_doy(p.sel(10.0), ta2, device=dev)
+    hi = resample_doy(p.sel(90.0), ta2, device=dev)
+    np.testing.assert_allclose(lo, ocal.resample_doy(exp[..., 0], doys, ot2), rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(hi, ocal.resample_doy(exp[..., 1], doys, ot2), rtol=1e-12, equal_nan=True)
+    got = within_bnds_doy(y, low=p.sel(10.0), high=p.sel(90.0), time=ta2, device=dev)
+    with np.errstate(invalid="ignore"):
+        ref = (ocal.resample_doy(exp[..., 0], doys, ot2) < y) * (y < ocal.resample_doy(exp[..., 1], doys, ot2))
+    np.testing.assert_array_equal(got, ref)
+    assert got.any() and not got.all()

@@ -138,3 +138,29 @@ def resample_doy_index(doy: DoyPercentile, time: TimeAxis):
     if not np.all(doy.dayofyear[pos_c] == time.doy):
         raise ValueError("day-of-year table does not cover every day of the target time axis")
     return pos_c.astype(np.int32)
+
+
+def resample_doy(doy: DoyPercentile, time: TimeAxis, *, device=None, keep=False):
+    """cal:763-790: the (T, *cells) float64 field whose step t holds the doy table's row for dayofyear(t) (after
+    adjust_doy_calendar).  The index functions do not need it (the gather is fused into xh_threshold_count)."""
+    dev = device or get_device()
+    adoy = adjust_doy_calendar(doy, time, dev)
+    if adoy.data.shape[0] != 1:
+        raise ValueError("select one percentile first (DoyPercentile.sel)")
+    table = adoy.data.reshape(adoy.data.shape[1], adoy.data.shape[2])
+    out = K.doy_broadcast(dev, table, resample_doy_index(adoy, time))
+    return out if keep else out.get().reshape((len(time),) + doy.cell_shape)
+
+
+def within_bnds_doy(arr, *, low: DoyPercentile, high: DoyPercentile, time: TimeAxis, device=None, keep=False):
+    """cal:934-954: (low_doy < arr) & (arr < high_doy) with the bounds broadcast by day of year."""
+    dev = device or get_device()
+    x, cell_shape = _flatten(arr, dev)
+    lo, hi = adjust_doy_calendar(low, time, dev), adjust_doy_calendar(high, time, dev)
+    if lo.data.shape[0] != 1 or hi.data.shape[0] != 1:
+        raise ValueError("select one percentile first (DoyPercentile.sel)")
+    tl, th = resample_doy_index(lo, time), resample_doy_index(hi, time)
+    if not np.array_equal(tl, th):
+        raise ValueError("low and high must share their dayofyear coordinate")
+    out = K.within_bnds_doy(dev, x, lo.data.reshape(lo.data.shape[1], -1), hi.data.reshape(hi.data.shape[1], -1), tl)
+    return out if keep else out.get().reshape((x.shape[0],) + tuple(cell_shape)).astype(bool)

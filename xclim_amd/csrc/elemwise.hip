@@ -96,6 +96,62 @@ k_compare_map(const float* __restrict__ a, int64_t T, int64_t C, int64_t st, int
   }
 }
 
+// ---- per-doy tables broadcast onto the time axis (core/calendar.py) ----------------------------------------------
+//   resample_doy     cal:763-790   out[t] = table[tidx[t]]  (fp64; the fused kernels never materialise this field)
+//   within_bnds_doy  cal:934-954   (low[tidx[t]] < x[t]) && (x[t] < high[tidx[t]]), compared in fp64
+__global__ void __launch_bounds__(XH_BLOCK)
+k_doy_broadcast(const double* __restrict__ table, int64_t C, const int32_t* __restrict__ tidx, int64_t T,
+                double* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
+  int64_t ta = (int64_t)blockIdx.y * chunk, tb = ta + chunk;
+  if (tb > T) tb = T;
+#pragma unroll 4
+  for (int64_t t = ta; t < tb; ++t) {
+    const int r = tidx[t];
+    out[t * C + c] = table[(int64_t)(r < 0 ? 0 : r) * C + c];
+  }
+}
+
+__global__ void __launch_bounds__(XH_BLOCK)
+k_within_bnds_doy(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const double* __restrict__ low,
+                  const double* __restrict__ high, const int32_t* __restrict__ tidx, uint8_t* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
+  int64_t ta = (int64_t)blockIdx.y * chunk, tb = ta + chunk;
+  if (tb > T) tb = T;
+#pragma unroll 4
+  for (int64_t t = ta; t < tb; ++t) {
+    const int64_t r = tidx[t];
+    const double v = (double)x[t * st + c];
+    out[t * C + c] = (low[r * C + c] < v && v < high[r * C + c]) ? 1 : 0;
+  }
+}
+
+static dim3 time_chunk_grid(xh_ctx* ctx, int64_t T, int64_t C) {
+  const int64_t cblocks = cdiv64(C, XH_BLOCK);
+  int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
+  if (gy < 1) gy = 1;
+  if (gy > T) gy = T;
+  if (gy > 1024) gy = 1024;
+  return dim3((unsigned)cblocks, (unsigned)gy);
+}
+
+static int upload_tidx(xh_ctx* ctx, const char* fn, const int32_t* tidx, int64_t T, int D, const int32_t** d_tidx) {
+  XH_REQUIRE(tidx, XH_ERR_ARG, "%s: tidx is NULL", fn);
+  for (int64_t t = 0; t < T; ++t)
+    XH_REQUIRE(tidx[t] >= 0 && tidx[t] < D, XH_ERR_ARG, "%s: tidx[%lld] = %d outside the table (D = %d)", fn, (long long)t,
+               tidx[t], D);
+  size_t cur = 0;
+  void* d = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, tidx, sizeof(int32_t) * (size_t)T, &d);
+  if (rc) return rc;
+  *d_tidx = (const int32_t*)d;
+  return XH_OK;
+}
+
 extern "C" {
 
 int xh_range_reduce(xh_ctx* ctx, const float* low, const float* high, int64_t T, int64_t C, int64_t st_low, int64_t st_high,
@@ -147,6 +203,33 @@ int xh_compare_map(xh_ctx* ctx, const float* a, int64_t T, int64_t C, int64_t st
   else
     hipLaunchKernelGGL((k_compare_map<false>), grid, dim3(XH_BLOCK), 0, ctx->stream, a, T, C, st, op, thr, b, st_b, out_kind,
                        out, st_out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_doy_broadcast(xh_ctx* ctx, const double* table, int D, int64_t C, const int32_t* tidx, int64_t T, double* out) {
+  XH_REQUIRE(ctx && table && out, XH_ERR_ARG, "xh_doy_broadcast: NULL argument");
+  XH_REQUIRE(D >= 1 && C >= 0 && T >= 0, XH_ERR_ARG, "xh_doy_broadcast: bad shape");
+  if (T == 0 || C == 0) return XH_OK;
+  const int32_t* d_tidx = nullptr;
+  int rc = upload_tidx(ctx, "xh_doy_broadcast", tidx, T, D, &d_tidx);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_doy_broadcast, time_chunk_grid(ctx, T, C), dim3(XH_BLOCK), 0, ctx->stream, table, C, d_tidx, T, out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_within_bnds_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* low,
+                       const double* high, int D, const int32_t* tidx, uint8_t* out) {
+  XH_REQUIRE(ctx && x && low && high && out, XH_ERR_ARG, "xh_within_bnds_doy: NULL argument");
+  XH_REQUIRE(D >= 1 && C >= 0 && T >= 0, XH_ERR_ARG, "xh_within_bnds_doy: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_within_bnds_doy: needs a time-major view (sc == 1, st >= C)");
+  if (T == 0 || C == 0) return XH_OK;
+  const int32_t* d_tidx = nullptr;
+  int rc = upload_tidx(ctx, "xh_within_bnds_doy", tidx, T, D, &d_tidx);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_within_bnds_doy, time_chunk_grid(ctx, T, C), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, low, high,
+                     d_tidx, out);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

@@ -365,6 +365,25 @@ def doy_interp(dev: Device, table: DeviceArray, i0, i1, dxn, dxs) -> DeviceArray
     return out
 
 
+def doy_broadcast(dev: Device, table: DeviceArray, tidx) -> DeviceArray:
+    """(D, C) float64 per-doy table -> (T, C) float64 field, row tidx[t] at step t (resample_doy)."""
+    D, C_ = table.shape
+    tidx = np.ascontiguousarray(tidx, dtype=np.int32)
+    out = dev.empty((len(tidx), C_), np.float64)
+    dev.call("xh_doy_broadcast", _vp(table.ptr), D, C_, np_ptr(tidx), len(tidx), _vp(out.ptr))
+    return out
+
+
+def within_bnds_doy(dev: Device, x: DeviceArray, low: DeviceArray, high: DeviceArray, tidx) -> DeviceArray:
+    T, C_ = _tc(x)
+    D = low.shape[0]
+    tidx = np.ascontiguousarray(tidx, dtype=np.int32)
+    assert len(tidx) == T and low.shape == high.shape == (D, C_)
+    out = dev.empty((T, C_), np.uint8)
+    dev.call("xh_within_bnds_doy", _vp(x.ptr), T, C_, C_, 1, _vp(low.ptr), _vp(high.ptr), D, np_ptr(tidx), _vp(out.ptr))
+    return out
+
+
 def quantile_series(dev: Device, x: DeviceArray, q, time_axis=0, out=None) -> DeviceArray:
     """Per-cell quantiles of the whole series: x (T, C) [time_axis 0] or (C, T) [time_axis 1] -> (nq, C) float32."""
     q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
