@@ -212,6 +212,8 @@ def test_percentile_bootstrap(dev, rng, calendar, start, nyears, base, freq):
     seg, starts = ta.segments(freq)
     inb = np.array([base[0] <= (y if (freq == "YS" or m != 12) else y + 1) <= base[1] for y, m in starts])
     assert got[inb].sum() >= plain[inb].sum()
+    # the index-level spelling: tx90p(..., bootstrap=True) reads the base period and window from the percentile attrs
+    np.testing.assert_array_equal(xi.tx90p(x, p, ta, freq=freq, device=dev, bootstrap=True), got)
     with pytest.raises(KeyError):
         xboot.bootstrap_exceedance(x, ta, (int(start[:4]), int(start[:4]) + nyears), freq, device=dev)
 

@@ -124,3 +124,35 @@ def bootstrap_exceedance(da, time: TimeAxis, base_years: tuple[int, int], freq: 
             acc.append(count(t0, t1, per_table, per_doys))
     out = np.concatenate(acc, axis=0)
     return out.reshape((out.shape[0],) + tuple(cell_shape))
+
+
+def bootstrap_func(compute_index_func, da, per: DoyPercentile, time: TimeAxis, freq: str = "YS", op: str | None = None, *,
+                   device=None) -> np.ndarray:
+    """bootstrapping.py:81-211 for the percentile-exceedance indices (tx90p / tn10p ... families): the percentile
+    reference period, window, alpha and beta are read from the attributes percentile_doy stored (cal:487-494) and the
+    index of every in-base year is averaged over the n-1 replicas in which that year is replaced."""
+    for k in ("climatology_bounds", "window", "alpha", "beta"):
+        if k not in per.attrs:
+            raise KeyError(f"`bootstrap` can only be used with percentiles computed by percentile_doy (missing attr {k}).")
+    if len(per.percentiles) != 1:
+        raise ValueError("select one percentile first (DoyPercentile.sel)")
+    b0, b1 = per.attrs["climatology_bounds"]
+    if op is None:
+        op = getattr(compute_index_func, "_default_op", ">")
+    return bootstrap_exceedance(da, time, (int(str(b0)[:4]), int(str(b1)[:4])), freq, op, int(per.attrs["window"]),
+                                float(per.percentiles[0]), float(per.attrs["alpha"]), float(per.attrs["beta"]), device=device)
+
+
+def percentile_bootstrap(func):
+    """bootstrapping.py:22-78: decorator adding ``bootstrap=True`` support to an index function with the signature
+    ``func(da, per, time, freq=..., op=..., device=...)``."""
+    import functools
+
+    @functools.wraps(func)
+    def wrapper(da, per, time, freq="YS", *args, bootstrap: bool = False, **kwargs):
+        if not bootstrap:
+            return func(da, per, time, freq, *args, **kwargs)
+        op = kwargs.get("op", args[0] if args else None)
+        return bootstrap_func(func, da, per, time, freq, op, device=kwargs.get("device"))
+
+    return wrapper

@@ -16,6 +16,7 @@ import numpy as np
 from . import generic
 from . import kernels as K
 from ._capi import get_device
+from .bootstrapping import percentile_bootstrap
 from .calendar import DoyPercentile
 from .timeaxis import TimeAxis
 
@@ -63,21 +64,26 @@ def _percentile_count(da, per: DoyPercentile, time, freq, op, constrain, device,
     return _masked(cnt, val, time, freq, dev, _cells(da), mask_missing)
 
 
-def tx90p(tasmax, tasmax_per: DoyPercentile, time: TimeAxis, freq: str = "YS", op: str = ">", *, device=None,
-          mask_missing=True):
-    """indices/_multivariate.py:1534-1592: days with tasmax > its 90th day-of-year percentile."""
+def _tx90p(tasmax, tasmax_per: DoyPercentile, time: TimeAxis, freq: str = "YS", op: str = ">", *, device=None,
+           mask_missing=True):
+    """indices/_multivariate.py:1534-1592: days with tasmax > its 90th day-of-year percentile.  ``bootstrap=True``
+    (keyword) averages the in-base years over the bootstrap replicas (core/bootstrapping.py)."""
     return _percentile_count(tasmax, tasmax_per, time, freq, op, (">", ">="), device, mask_missing)
 
 
+_tx90p._default_op = ">"
+tx90p = percentile_bootstrap(_tx90p)
 tg90p = tn90p = tx90p
 
 
-def tx10p(tasmax, tasmax_per: DoyPercentile, time: TimeAxis, freq: str = "YS", op: str = "<", *, device=None,
-          mask_missing=True):
-    """indices/_multivariate.py:1596-1650."""
+def _tx10p(tasmax, tasmax_per: DoyPercentile, time: TimeAxis, freq: str = "YS", op: str = "<", *, device=None,
+           mask_missing=True):
+    """indices/_multivariate.py:1596-1650 (``bootstrap=True`` supported like tx90p)."""
     return _percentile_count(tasmax, tasmax_per, time, freq, op, ("<", "<="), device, mask_missing)
 
 
+_tx10p._default_op = "<"
+tx10p = percentile_bootstrap(_tx10p)
 tg10p = tn10p = tx10p
 
 
