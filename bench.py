@@ -70,12 +70,14 @@ def main():
     if args.gpus > 1 and world == 1:
         sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = torch = None
-    if world > 1:
+    # XH_BENCH_FORCE_DIST=1: go through the torch.distributed / RCCL path even with one rank (single-GPU validation)
+    use_dist = world > 1 or bool(os.environ.get("XH_BENCH_FORCE_DIST"))
+    if use_dist:
         import torch
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from xclim_amd import kernels as K
     from xclim_amd._capi import Device
@@ -101,7 +103,7 @@ def main():
     tidx = dev.to_device(tidx_h)
     table = per.reshape(len(doys), C)
     gathered = None
-    if world > 1:
+    if use_dist:
         res_t = torch.empty((P, C), dtype=torch.float64, device="cuda")
         gathered = torch.empty((world, P, C), dtype=torch.float64, device="cuda")
         res = dev.wrap(res_t.data_ptr(), (P, C), np.float64)
@@ -119,13 +121,13 @@ def main():
         k_pdoy()
         k_count()
         k_mask()
-        if world > 1:
+        if use_dist:
             dev.sync()
             dist.all_gather_into_tensor(gathered.view(world * P, C), res_t)
 
     def fence():
         dev.sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -138,7 +140,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -203,7 +205,7 @@ def main():
             "extra": extra,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
