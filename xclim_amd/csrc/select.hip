@@ -251,26 +251,48 @@ __device__ __forceinline__ void wave_sync() {
   asm volatile("" ::: "memory");
 }
 
-template <int G, int KPL, int NB, bool TIME_MAJOR>
-__global__ void __launch_bounds__(256)
+// workgroup barrier that only orders LDS traffic (no vmcnt wait: prefetched global loads stay in flight)
+__device__ __forceinline__ void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// STAGE (time-major input, NT = 512, G = 32 -> 16 columns per workgroup): the rows are loaded COALESCED (a half-wave
+// reads 2 rows x 16 adjacent cells = two full 64-byte sectors; the lane-owns-column mapping reads 8 bytes per sector,
+// PMC: 3x over-fetch), staged through an LDS tile (row pitch 17 words: conflict-free both ways) and picked up by the
+// owner lanes; the tile is then reused as the `sorted` arrays.  The next tile is prefetched into registers meanwhile.
+template <int G, int KPL, int NB, bool TIME_MAJOR, int NT = 256, bool STAGE = false>
+__global__ void __launch_bounds__(NT)
 k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stride, const double* __restrict__ qs, int nq,
              float* __restrict__ out, int64_t out_cstride, int64_t out_qstride, int abl) {
-  constexpr int COLS = 256 / G;             // columns per workgroup
+  constexpr int COLS = NT / G;              // columns per workgroup
+  static_assert(!STAGE || (TIME_MAJOR && G == 32 && NT == 512), "staged loads: time-major, 32 lanes per column, 512 threads");
   constexpr int BPL = NB / G;               // bins per lane in the scan
   // LDS words per column: cur | sorted | vals, padded so that PER % 32 == G: the 64/G columns that share a wave
   // then sit on disjoint LDS banks for the lane-structured accesses
-  constexpr int PER0 = NB + G * KPL + 128;
+  constexpr int PER0 = NB + (STAGE ? 0 : G * KPL) + 128;
   constexpr int PER = PER0 + ((G % 32) - (PER0 % 32) + 32) % 32;
-  __shared__ uint32_t lds[COLS * PER];
+  constexpr int PITCH = COLS + 1;                         // tile row pitch (words)
+  constexpr int TILEW = STAGE ? G * KPL * PITCH : 0;      // tile words (>= COLS * G * KPL: reused as sorted[])
+  __shared__ uint32_t lds[COLS * PER + TILEW];
   const int tid = threadIdx.x;
   const int l = tid & (G - 1), g = tid / G;
   uint32_t* cur = lds + g * PER;
-  uint32_t* sorted = cur + NB;
-  float* vals = reinterpret_cast<float*>(sorted + G * KPL);
+  uint32_t* tile = lds + COLS * PER;
+  uint32_t* sorted = STAGE ? tile + g * (G * KPL) : cur + NB;
+  float* vals = reinterpret_cast<float*>(cur + NB + (STAGE ? 0 : G * KPL));
 
   // software pipeline: the raw samples of the NEXT column are in flight while the current one is processed
   float raw[KPL];
+  const int sc = tid % COLS, sr = tid / COLS;  // staged mapping: column / first row of this thread (NT / COLS = G rows per pass)
   auto issue_loads = [&](int64_t cb) {
+    if (STAGE) {
+      // unconditional, clamped loads (a load under a condition is followed by s_waitcnt vmcnt(0)); masked when used
+      const int64_t colc = (cb + sc < ncols) ? cb + sc : ncols - 1;
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) {
+        const int t = sr + k * G;
+        raw[k] = x[(int64_t)(t < T ? t : (int)T - 1) * stride + colc];
+      }
+      return;
+    }
     const int64_t col = cb + g;
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
@@ -279,6 +301,11 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
       if (col < ncols && t < T) raw[k] = TIME_MAJOR ? x[(int64_t)t * stride + col] : x[col * stride + t];
     }
   };
+  constexpr int NROUND = (128 + G - 1) / G;  // rounds of the target loop (2 * nq <= 128 targets, G lanes)
+  int rank_c[NROUND];
+  uint32_t rank_n = 0xFFFFFFFFu;
+#pragma unroll
+  for (int rr = 0; rr < NROUND; ++rr) rank_c[rr] = 0;
   const int64_t cstep = (int64_t)gridDim.x * COLS;
   int64_t cb = (int64_t)blockIdx.x * COLS;
   if (cb < ncols) issue_loads(cb);
@@ -287,6 +314,19 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
     const bool have = col < ncols;
     uint32_t key[KPL];
     uint32_t nv = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+    if (STAGE) {
+      // registers (coalesced mapping) -> LDS tile -> owner lanes; rows >= T and columns >= ncols become NaN keys
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) tile[(sr + k * G) * PITCH + sc] = __float_as_uint(raw[k]);
+      block_sync_lds();
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) {
+        const int t = l + k * G;
+        const float f = __uint_as_float(tile[t * PITCH + g]);
+        raw[k] = (have && t < T) ? f : xh_nan32();
+      }
+      block_sync_lds();  // the tile is dead from here on: it becomes the sorted[] arrays
+    }
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
       uint32_t kk = xh_f2key(raw[k]);
@@ -349,19 +389,30 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
     }
     wave_sync();
     // after the scatter cur[b] is the END of bin b (== start of bin b+1)
-    for (int tgt = l; tgt < 2 * nq && !(abl & 4); tgt += G) {
-      const int j = tgt >> 1;
+    int round = 0;
+    for (int tgt = l; tgt < 2 * nq && !(abl & 4); tgt += G, ++round) {
       float v = xh_nan32();
       if (n >= 1) {
-        int r;
-        if (T == 1 || n < 2) r = 0;
-        else {
-          double nn = (double)n, q = qs[j];
-          double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;  // utl:395 with alpha = beta = 1
-          if (vi >= nn - 1.0) r = (int)n - 1;
-          else if (vi < 0.0) r = 0;
-          else r = (int)floor(vi) + (tgt & 1);
+        // the rank depends on (n, target) only: cached per lane and recomputed when the valid count changes
+        if (n != rank_n) {
+#pragma unroll
+          for (int rr = 0; rr < NROUND; ++rr) {
+            const int tg = l + rr * G;
+            int r0 = 0;
+            if (tg < 2 * nq && !(T == 1 || n < 2)) {
+              double nn = (double)n, q = qs[tg >> 1];
+              double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;  // utl:395 with alpha = beta = 1
+              if (vi >= nn - 1.0) r0 = (int)n - 1;
+              else if (vi < 0.0) r0 = 0;
+              else r0 = (int)floor(vi) + (tg & 1);
+            }
+            rank_c[rr] = r0;
+          }
+          rank_n = n;
         }
+        int r = 0;
+#pragma unroll
+        for (int rr = 0; rr < NROUND; ++rr) r = (rr == round) ? rank_c[rr] : r;
         // first bin whose end exceeds r
         int lo = -1, hi = NB - 1;  // invariant: end[lo] <= r < end[hi]   (end[-1] = 0, end[NB-1] = n)
         while (hi - lo > 1) {
@@ -372,21 +423,19 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
         const uint32_t kth = (uint32_t)r - s0, m = s1 - s0;
         uint32_t ans;
         if (m <= 8) {
-          // exact k-th smallest of <= 8 keys, all in registers (independent LDS loads, no dependent chain)
+          // exact k-th smallest of <= 8 keys: independent LDS loads, optimal 19-comparator network (0xFFFFFFFF pads
+          // sort last), k-th picked with an OR of masked values (no dynamic register indexing)
           uint32_t kk[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) kk[i] = (uint32_t)i < m ? sorted[s0 + i] : 0xFFFFFFFFu;
-          ans = kk[0];
+#define XH_CE8(i, j) { uint32_t a_ = kk[i] < kk[j] ? kk[i] : kk[j], b_ = kk[i] < kk[j] ? kk[j] : kk[i]; kk[i] = a_; kk[j] = b_; }
+          XH_CE8(0, 1) XH_CE8(2, 3) XH_CE8(4, 5) XH_CE8(6, 7) XH_CE8(0, 2) XH_CE8(1, 3) XH_CE8(4, 6) XH_CE8(5, 7)
+          XH_CE8(1, 2) XH_CE8(5, 6) XH_CE8(0, 4) XH_CE8(3, 7) XH_CE8(1, 5) XH_CE8(2, 6) XH_CE8(1, 4) XH_CE8(3, 6)
+          XH_CE8(2, 4) XH_CE8(3, 5) XH_CE8(3, 4)
+#undef XH_CE8
+          ans = 0u;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            uint32_t less = 0, leq = 0;
-#pragma unroll
-            for (int i2 = 0; i2 < 8; ++i2) {
-              less += kk[i2] < kk[i] ? 1u : 0u;
-              leq += kk[i2] <= kk[i] ? 1u : 0u;
-            }
-            ans = (less <= kth && kth < leq) ? kk[i] : ans;
-          }
+          for (int i = 0; i < 8; ++i) ans |= ((uint32_t)i == kth) ? kk[i] : 0u;
         } else {
           ans = sorted[s0];
           for (uint32_t a = s0; a < s1; ++a) {
@@ -425,7 +474,8 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
         out[col * out_cstride + (int64_t)j * out_qstride] = (float)r;
       }
     }
-    wave_sync();
+    if (STAGE) block_sync_lds();  // every wave is done with sorted[] before the next tile overwrites it
+    else wave_sync();
   }
 }
 
@@ -438,6 +488,19 @@ static int launch_select_grp_g(xh_ctx* ctx, const float* x, int64_t T, int64_t n
   if (nblk > maxblk) nblk = maxblk;
   const char* ea = getenv("XH_SELECT_ABL");  // diagnostics: skip phases (results become wrong)
   const int abl = ea ? atoi(ea) : 0;
+  if (TM && G == 32 && !getenv("XH_SELECT_NOSTAGE")) {
+    constexpr int SG = 32;  // (fixed: the staged kernel is only instantiated for 32 lanes per column)
+    int64_t nb2 = cdiv64(ncols, 512 / SG);
+    if (nb2 > (int64_t)ctx->num_cu * 32) nb2 = (int64_t)ctx->num_cu * 32;
+    if (T <= 384)
+      hipLaunchKernelGGL((k_select_grp<SG, 384 / SG, 256, true, 512, true>), dim3((unsigned)nb2), dim3(512), 0, ctx->stream, x,
+                         T, ncols, stride, d_q, nq, out, out_cstride, out_qstride, abl);
+    else
+      hipLaunchKernelGGL((k_select_grp<SG, 512 / SG, 256, true, 512, true>), dim3((unsigned)nb2), dim3(512), 0, ctx->stream, x,
+                         T, ncols, stride, d_q, nq, out, out_cstride, out_qstride, abl);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+  }
   if (T <= 384)
     hipLaunchKernelGGL((k_select_grp<G, 384 / G, 256, TM>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, x, T, ncols,
                        stride, d_q, nq, out, out_cstride, out_qstride, abl);
