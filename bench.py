@@ -219,6 +219,16 @@ def bench_extra(dev, K, ta, T, C, seg, P, synth, tasmax, tb, per, D):
     ms50 = event_time(dev, lambda: K.percentile_doy(dev, tasmax, tb, 5, [50.0], out=per), 10)
     b50 = 4 * E + 8 * D * C
     out["percentile_doy_per50"] = {"ms": ms50, "GB/s": b50 / ms50 / 1e6, "frac": b50 / ms50 / 1e6 / HBM_PEAK_GBS}
+    # --- tx90p with the percentile table fused away (xh_percentile_doy_count): same counts as the timed chain, the
+    #     (D, C) fp64 table is never written / re-read.  Reported next to the API-faithful two-step chain, not as `value`.
+    cntf, valf = dev.empty((P, C), np.int32), dev.empty((P, C), np.int32)
+    period = (np.searchsorted(seg, tb[0], side="right") - 1).astype(np.int32)
+    if K.percentile_doy_count(dev, tasmax, tb, 5, 90.0, ">", period, P, out=(cntf, valf)) is not None:
+        msf = event_time(dev, lambda: K.percentile_doy_count(dev, tasmax, tb, 5, 90.0, ">", period, P, out=(cntf, valf)), 10)
+        bf = 4 * E + 8 * P * C
+        out["tx90p_fused"] = {"ms": msf, "GB/s": bf / msf / 1e6, "frac": bf / msf / 1e6 / HBM_PEAK_GBS,
+                              "cell-timesteps/s": E / (msf * 1e-3), "algorithmic_bytes": bf,
+                              "note": "percentile_doy + threshold_count in one kernel (k_pdoy_slide<5,4,COUNT>)"}
     # --- maximum_consecutive_dry_days: fused compare + run-length max + valid count ---
     pr = K.fill_synthetic(dev, T, C, 1, 3, np.zeros(T, np.float32), 40.0 / 86400.0, 0.3)
     o, v = dev.empty((P, C), np.float32), dev.empty((P, C), np.int32)

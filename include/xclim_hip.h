@@ -282,6 +282,15 @@ int xh_percentile_doy_mapped(xh_ctx* ctx, const float* x, int64_t T, int64_t C, 
                              int nper, double alpha, double beta, const int32_t* vmap /* host */, int64_t Tv,
                              double* out);
 
+/* Fused percentile_doy + threshold_count (the tx90p family, indices/_multivariate.py:1534-1650, when the percentile
+ * base period IS the analysed series and spans one contiguous year): count_out[p, c] = #{d in period p :
+ * x[d, c] op percentile_doy(x)[d, c]} (fp64 compare), valid_out[p, c] = non-NaN days (may be NULL), doy_period[ndoy] =
+ * period of every doy row.  The (D, C) float64 table is never materialised.  Returns XH_ERR_NOTIMPL for shapes the
+ * fused kernel does not cover (several years, windows other than 3 / 5 / 7, gaps): use the two-step chain there. */
+int xh_percentile_doy_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* tbase,
+                            int nyears, int ndoy, int window, double per, double alpha, double beta, int op,
+                            const int32_t* doy_period, int P, int32_t* count_out, int32_t* valid_out);
+
 /* _interpolate_doy_calendar (core/calendar.py:690-726): interpolate_na along doy then linear re-grid
  * D_in -> D_out with host-computed tables (scipy interp1d form): slope = (in[i1[j]] - in[i0[j]]) / dxs[j];
  * out[j] = slope * dxn[j] + in[i0[j]],  dxn = x_new - x_lo, dxs = x_hi - x_lo.  in (D_in, C), out (D_out, C). */

@@ -394,3 +394,26 @@ def test_resample_doy_and_within_bnds_doy(dev, rng, calendar, T):
         ref = (ocal.resample_doy(exp[..., 0], doys, ot2) < y) * (y < ocal.resample_doy(exp[..., 1], doys, ot2))
     np.testing.assert_array_equal(got, ref)
     assert got.any() and not got.all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("calendar,T,freq,window,per,op", [("noleap", 365, "YS", 5, 90.0, ">"), ("noleap", 365, "MS", 5, 10.0, "<"),
+                                                           ("noleap", 365, "QS-DEC", 3, 50.0, ">="), ("standard", 365, "MS", 7, 90.0, ">"),
+                                                           ("noleap", 200, "MS", 5, 75.0, ">"), ("noleap", 1095, "YS", 5, 90.0, ">"),
+                                                           ("standard", 366, "YS", 5, 90.0, ">")])
+def test_percentile_exceedance_fused(dev, rng, calendar, T, freq, window, per, op):
+    """The fused percentile_doy + threshold_count kernel must reproduce the two-step chain bit for bit (and fall back
+    to it for several years / 366-day years)."""
+    x = _temp(rng, T, (7, 9), nan_frac=0.01)
+    x[10:13, 0, 0] = np.nan
+    start = "2001-01-01" if T != 366 else "2000-01-01"
+    ta, ot = _axes(start, T, calendar)
+    got = xi.percentile_exceedance(x, ta, freq, op, window, per, device=dev)
+    p = percentile_doy(x, ta, window=window, per=per, device=dev)
+    f = xi.tx90p if op in (">", ">=") else xi.tx10p
+    ref = f(x, p, ta, freq, op, device=dev)
+    np.testing.assert_array_equal(got, ref)
+    exp, doys = ocal.percentile_doy(x, ot, window, per)
+    raw = xi.percentile_exceedance(x, ta, freq, op, window, per, device=dev, mask_missing=False)
+    of = oidx.tx90p if op in (">", ">=") else oidx.tx10p
+    np.testing.assert_array_equal(raw, of(x, exp[..., 0], doys, ot, freq, op))

@@ -11,6 +11,8 @@
 // Time-major layout, one lane per cell (VEC cells in the register path); neighbouring doys re-read rows from L2.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pdoy.h"
 
 // Hyndman-Fan quantile from a sorted sample (ascending, NaN last).  `get(i)` returns sorted element i as float.
@@ -143,109 +145,161 @@ __device__ __forceinline__ void sort_small(uint32_t (&k)[W]) {
   }
 }
 
-template <int W, int VEC>
+// COUNT = true (xh_percentile_doy_count): the percentile of doy d is compared at once with the day's own value and the
+// exceedances are counted per period — the (D, C) fp64 table of the unfused tx90p chain (2/3 of its HBM traffic) is
+// never written; partial counts of a doy chunk are combined with global atomics (nper must be 1).
+//
+// The kernel is VALU-bound (PMC: 331 VALU wave-instructions per 4-cell doy step before this layout), so the window is
+// a RING: the day loop is unrolled by W, the row of step k lands in the static slot (k + W - 1) % W — the slot of the
+// day that leaves — and nothing is ever shifted (sorting and min/max do not care about the order).  `fast` (host:
+// every percentile clips to the window maximum (1) / minimum (2) when the window is full, e.g. per = 90 with 5
+// samples, utl:443-452) selects a path without the sorting network when no lane of the wave holds a NaN.
+template <int W, int VEC, bool COUNT = false>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_pdoy_slide(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int64_t t_first, int ndoy, int chunk,
-             const QTab* __restrict__ qtab, int nper, double* __restrict__ out) {
+             const QTab* __restrict__ qtab, int nper, double* __restrict__ out, int fast, int op = 0,
+             const int32_t* __restrict__ doy_period = nullptr, int32_t* __restrict__ cnt_out = nullptr,
+             int32_t* __restrict__ valid_out = nullptr) {
   __shared__ QTab s_tab[8 * (W + 1)];
   for (int i = threadIdx.x; i < nper * (W + 1); i += XH_BLOCK) s_tab[i] = qtab[i];
   __syncthreads();
   int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
-  const int half = W / 2;
+  constexpr int half = W / 2;
   int d0 = blockIdx.y * chunk, d1 = d0 + chunk;
   if (d1 > ndoy) d1 = ndoy;
   uint32_t win[VEC][W];
   int n[VEC];  // valid keys currently in the window (maintained incrementally)
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) { n[v] = 0; win[v][0] = 0xFFFFFFFFu; }
+  for (int v = 0; v < VEC; ++v) {
+    n[v] = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) win[v][k] = 0xFFFFFFFFu;
+  }
   // rows are fetched unconditionally (clamped row index: a load inside a conditional is followed by s_waitcnt
   // vmcnt(0)) and one doy AHEAD of their use, so the row of doy d+1 is in flight while doy d is selected and stored
   auto fetch = [&](int64_t t) -> VecF<VEC> {
     const int64_t tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
     return xh_load<VEC>(x + tc * st + c);
   };
-  auto insert = [&](const VecF<VEC>& xv, int64_t t, int slot) {
-    const bool inside = t >= 0 && t < T;
+  int ccnt[VEC], cval[VEC], cper = -1;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const uint32_t kk = inside ? xh_f2key(xv.v[v]) : 0xFFFFFFFFu;
-      win[v][slot] = kk;
-      n[v] += (kk != 0xFFFFFFFFu) ? 1 : 0;
+  for (int v = 0; v < VEC; ++v) { ccnt[v] = 0; cval[v] = 0; }
+  auto flush_counts = [&]() {
+    if (cper >= 0) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if (ccnt[v]) atomicAdd(&cnt_out[(int64_t)cper * C + c + v], ccnt[v]);
+        if (valid_out && cval[v]) atomicAdd(&valid_out[(int64_t)cper * C + c + v], cval[v]);
+        ccnt[v] = 0; cval[v] = 0;
+      }
     }
   };
+  // result of doy d for percentile j: stored, or compared with the day's own value (window centre) and counted
+  auto emit = [&](int d, int j, const double (&r)[VEC], const uint32_t (&centre)[VEC]) {
+    if (COUNT) {
+      const int p = doy_period[d];
+      if (p != cper) { flush_counts(); cper = p; }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float xv = xh_key2f(centre[v]);
+        ccnt[v] += xh_cmp_f64((double)xv, op, r[v]) ? 1 : 0;
+        cval[v] += (xv == xv) ? 1 : 0;
+      }
+    } else {
+      double* optr = out + ((int64_t)j * ndoy + d) * C + c;
+      if (VEC == 4) {
+        *reinterpret_cast<double2*>(optr) = make_double2(r[0], r[1 % VEC]);
+        *reinterpret_cast<double2*>(optr + 2) = make_double2(r[2 % VEC], r[3 % VEC]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) optr[v] = r[v];
+      }
+    }
+  };
+  // prologue: rows d0-half .. d0+half-1 into slots 0 .. W-2
   {
     VecF<VEC> pre[W > 1 ? W - 1 : 1];
 #pragma unroll
     for (int k = 0; k < W - 1; ++k) pre[k] = fetch(t_first + d0 - half + k);
 #pragma unroll
-    for (int k = 0; k < W - 1; ++k) insert(pre[k], t_first + d0 - half + k, k + 1);
+    for (int k = 0; k < W - 1; ++k) {
+      const int64_t t = t_first + d0 - half + k;
+      const bool inside = t >= 0 && t < T;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const uint32_t kk = inside ? xh_f2key(pre[k].v[v]) : 0xFFFFFFFFu;
+        win[v][k] = kk;
+        n[v] += (kk != 0xFFFFFFFFu) ? 1 : 0;
+      }
+    }
   }
   VecF<VEC> nxt = fetch(t_first + d0 - half + (W - 1));
-#pragma unroll 2
-  for (int d = d0; d < d1; ++d) {
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      n[v] -= (win[v][0] != 0xFFFFFFFFu) ? 1 : 0;  // the day leaving the window
-#pragma unroll
-      for (int k = 0; k < W - 1; ++k) win[v][k] = win[v][k + 1];
-    }
+
+  // one doy; U = (d - d0) % W is static
+  auto step = [&](int d, auto UC) {
+    constexpr int U = decltype(UC)::value;
+    constexpr int SLOT = (U + W - 1) % W;   // slot of the row entering (== slot of the row leaving)
+    constexpr int CEN = (U + half) % W;     // slot of day d itself
     const VecF<VEC> cur = nxt;
     nxt = fetch(t_first + d + 1 - half + (W - 1));  // (one clamped extra row at the end of the chunk)
-    insert(cur, t_first + d - half + (W - 1), W - 1);
+    const int64_t tin = t_first + d - half + (W - 1);
+    const bool inside = tin >= 0 && tin < T;
     bool full = true;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) full &= (n[v] == W);
-    // Wave-uniform fast path: no NaN in any window of the wave -> the table entry (lo, hi, gamma) is the same for
-    // all lanes, selection needs no per-lane index, and when the Hyndman-Fan index clips to the sample maximum /
-    // minimum (utl:443-452; e.g. per = 90 with 5 samples) no sort is needed at all.
+    for (int v = 0; v < VEC; ++v) {
+      const uint32_t kk = inside ? xh_f2key(cur.v[v]) : 0xFFFFFFFFu;
+      n[v] += ((kk != 0xFFFFFFFFu) ? 1 : 0) - ((win[v][SLOT] != 0xFFFFFFFFu) ? 1 : 0);
+      win[v][SLOT] = kk;
+      full &= (n[v] == W);
+    }
+    uint32_t centre[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) centre[v] = win[v][CEN];
+    // Wave-uniform fast paths: no NaN in any window of the wave -> the table entry (lo, hi, gamma) is the same for
+    // all lanes and selection needs no per-lane index.
     const bool uniform = __all(full ? 1 : 0) != 0;
-    uint32_t s[VEC][W];
-    bool sorted = false;
-    auto ensure_sorted = [&]() {
-      if (!sorted) {
+    if (uniform && fast != 0) {
+      // every percentile clips to the sample maximum / minimum (utl:443-452): no sort at all
+      double r[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
+      for (int v = 0; v < VEC; ++v) {
+        uint32_t m = win[v][0];
 #pragma unroll
-          for (int k = 0; k < W; ++k) s[v][k] = win[v][k];
-          sort_small<W>(s[v]);
-        }
-        sorted = true;
+        for (int k = 1; k < W; ++k) m = (fast == 2) ? (win[v][k] < m ? win[v][k] : m) : (win[v][k] > m ? win[v][k] : m);
+        r[v] = (double)xh_key2f(m);
       }
-    };
+      for (int j = 0; j < nper; ++j) emit(d, j, r, centre);
+      return;
+    }
+    uint32_t s[VEC][W];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) s[v][k] = win[v][k];
+      sort_small<W>(s[v]);
+    }
     for (int j = 0; j < nper; ++j) {
       double r[VEC];
       if (uniform) {
         const QTab e = s_tab[j * (W + 1) + W];
         const int lo = __builtin_amdgcn_readfirstlane(e.lo), hi = __builtin_amdgcn_readfirstlane(e.hi);
-        if (lo == hi && (lo == W - 1 || lo == 0) && W > 1) {
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            uint32_t m = win[v][0];
+        for (int v = 0; v < VEC; ++v) {
+          uint32_t kl = s[v][0], kh = s[v][0];
 #pragma unroll
-            for (int k = 1; k < W; ++k) m = (lo == 0) ? (win[v][k] < m ? win[v][k] : m) : (win[v][k] > m ? win[v][k] : m);
-            r[v] = (double)xh_key2f(m);
+          for (int i = 1; i < W; ++i) {  // lo / hi are wave-uniform: these selects are scalar-predicated moves
+            kl = (i == lo) ? s[v][i] : kl;
+            kh = (i == hi) ? s[v][i] : kh;
           }
-        } else {
-          ensure_sorted();
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            uint32_t kl = s[v][0], kh = s[v][0];
-#pragma unroll
-            for (int i = 1; i < W; ++i) {  // lo / hi are wave-uniform: these selects are scalar-predicated moves
-              kl = (i == lo) ? s[v][i] : kl;
-              kh = (i == hi) ? s[v][i] : kh;
-            }
-            float left = xh_key2f(kl), right = xh_key2f(kh);
-            float diff = right - left;
-            double rr = (double)left + (double)diff * e.gamma;
-            if (e.gamma >= 0.5) rr = (double)right - (double)diff * (1.0 - e.gamma);
-            if (rr != rr) rr = (double)xh_key2f(s[v][W - 1]);
-            r[v] = rr;
-          }
+          float left = xh_key2f(kl), right = xh_key2f(kh);
+          float diff = right - left;
+          double rr = (double)left + (double)diff * e.gamma;
+          if (e.gamma >= 0.5) rr = (double)right - (double)diff * (1.0 - e.gamma);
+          if (rr != rr) rr = (double)xh_key2f(s[v][W - 1]);
+          r[v] = rr;
         }
       } else {
-        ensure_sorted();
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           // register-array select written as an OR of masked values: a select chain gets folded back into a
@@ -265,16 +319,20 @@ k_pdoy_slide(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int6
           r[v] = (e.lo < 0) ? xh_nan64() : rr;
         }
       }
-      double* op = out + ((int64_t)j * ndoy + d) * C + c;
-      if (VEC == 4) {
-        *reinterpret_cast<double2*>(op) = make_double2(r[0], r[1 % VEC]);
-        *reinterpret_cast<double2*>(op + 2) = make_double2(r[2 % VEC], r[3 % VEC]);
-      } else {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) op[v] = r[v];
-      }
+      emit(d, j, r, centre);
     }
+  };
+
+  for (int d = d0; d < d1; d += W) {
+    step(d, std::integral_constant<int, 0>{});
+    if (W > 1 && d + 1 < d1) step(d + 1, std::integral_constant<int, 1 % W>{});
+    if (W > 2 && d + 2 < d1) step(d + 2, std::integral_constant<int, 2 % W>{});
+    if (W > 3 && d + 3 < d1) step(d + 3, std::integral_constant<int, 3 % W>{});
+    if (W > 4 && d + 4 < d1) step(d + 4, std::integral_constant<int, 4 % W>{});
+    if (W > 5 && d + 5 < d1) step(d + 5, std::integral_constant<int, 5 % W>{});
+    if (W > 6 && d + 6 < d1) step(d + 6, std::integral_constant<int, 6 % W>{});
   }
+  if (COUNT) flush_counts();
 }
 
 // Host side of the table: one entry per (percentile j, valid count n), mirroring xh_hf_quantile.
@@ -647,6 +705,17 @@ static int launch_pdoy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
   return XH_OK;
 }
 
+// 1 / 2 when every percentile of the table clips to the maximum / minimum of a FULL window (n == W), else 0
+static int slide_fast_mode(const QTab* tab, int nper, int W) {
+  bool allmax = W > 1, allmin = W > 1;
+  for (int j = 0; j < nper; ++j) {
+    const QTab& e = tab[j * (W + 1) + W];
+    allmax = allmax && e.lo == e.hi && e.lo == W - 1;
+    allmin = allmin && e.lo == e.hi && e.lo == 0;
+  }
+  return allmax ? 1 : (allmin ? 2 : 0);
+}
+
 // Shared implementation of xh_percentile_doy / xh_percentile_doy_mapped.  `vmap` (host, Tv entries, may be NULL) maps
 // the virtual time axis the calendar tables refer to onto physical rows of x (-1 = day absent): the bootstrap of
 // core/bootstrapping.py:235-282 becomes a different index table per replica instead of a deep copy of the base period.
@@ -671,7 +740,7 @@ static int pdoy_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
     dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), (unsigned)((ndoy + chunk - 1) / chunk));
 #define XH_SLIDE(W, V)                                                                                              \
   hipLaunchKernelGGL((k_pdoy_slide<W, V>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, (int64_t)tbase[0], ndoy, \
-                     chunk, (const QTab*)d_tab, nper, out)
+                     chunk, (const QTab*)d_tab, nper, out, slide_fast_mode(tab, nper, window))
     if (vec == 4) {
       if (window == 3) XH_SLIDE(3, 4); else if (window == 5) XH_SLIDE(5, 4); else XH_SLIDE(7, 4);
     } else {
@@ -815,6 +884,42 @@ static int pdoy_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
   return XH_OK;
 }
 
+// tx90p-style fused chain for a base period that is ONE contiguous year and also the analysed period
+static int pdoy_count_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* tbase, int ndoy,
+                           int window, double per, double alpha, double beta, int op, const int32_t* doy_period, int P,
+                           int32_t* count_out, int32_t* valid_out) {
+  bool contiguous = (window == 3 || window == 5 || window == 7) && tbase[0] >= 0;
+  for (int d = 1; contiguous && d < ndoy; ++d) contiguous = tbase[d] == tbase[0] + d;
+  if (!contiguous) return XH_ERR_NOTIMPL;
+  for (int d = 0; d < ndoy; ++d)
+    XH_REQUIRE(doy_period[d] >= 0 && doy_period[d] < P, XH_ERR_ARG, "xh_percentile_doy_count: doy_period[%d] outside [0, P)", d);
+  size_t cur = 0;
+  QTab tab[8];
+  const double q = per / 100.0;
+  build_qtab(window, &q, 1, alpha, beta, tab);
+  void *d_tab = nullptr, *d_dp = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, tab, sizeof(QTab) * (size_t)(window + 1), &d_tab);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, doy_period, sizeof(int32_t) * (size_t)ndoy, &d_dp);
+  if (rc) return rc;
+  XH_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int32_t) * (size_t)P * (size_t)C, ctx->stream));
+  if (valid_out) XH_CHECK_HIP(hipMemsetAsync(valid_out, 0, sizeof(int32_t) * (size_t)P * (size_t)C, ctx->stream));
+  const int chunk = 32;
+  const int vec = xh_pick_vec(x, C, st);
+  dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), (unsigned)((ndoy + chunk - 1) / chunk));
+#define XH_SLIDEC(W, V)                                                                                                   \
+  hipLaunchKernelGGL((k_pdoy_slide<W, V, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, (int64_t)tbase[0], ndoy, \
+                     chunk, (const QTab*)d_tab, 1, (double*)nullptr, slide_fast_mode(tab, 1, window), op,          \
+                     (const int32_t*)d_dp, count_out, valid_out)
+  if (vec == 4) {
+    if (window == 3) XH_SLIDEC(3, 4); else if (window == 5) XH_SLIDEC(5, 4); else XH_SLIDEC(7, 4);
+  } else {
+    if (window == 3) XH_SLIDEC(3, 1); else if (window == 5) XH_SLIDEC(5, 1); else XH_SLIDEC(7, 1);
+  }
+#undef XH_SLIDEC
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
 extern "C" {
 
 int xh_percentile_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* tbase,
@@ -842,6 +947,19 @@ int xh_percentile_doy_mapped(xh_ctx* ctx, const float* x, int64_t T, int64_t C, 
   double qh[64];
   for (int j = 0; j < nper; ++j) qh[j] = per[j] / 100.0;  // utl:366
   return pdoy_impl(ctx, x, T, C, st, tbase, nyears, ndoy, window, qh, nper, alpha, beta, vmap, Tv, out);
+}
+
+int xh_percentile_doy_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* tbase,
+                            int nyears, int ndoy, int window, double per, double alpha, double beta, int op,
+                            const int32_t* doy_period, int P, int32_t* count_out, int32_t* valid_out) {
+  XH_REQUIRE(ctx && x && tbase && doy_period && count_out, XH_ERR_ARG, "xh_percentile_doy_count: NULL argument");
+  XH_REQUIRE(T >= 1 && C >= 0 && ndoy >= 1 && P >= 1, XH_ERR_ARG, "xh_percentile_doy_count: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_percentile_doy_count: needs a time-major view (sc == 1, st >= C)");
+  XH_REQUIRE(per >= 0.0 && per <= 100.0, XH_ERR_ARG, "xh_percentile_doy_count: percentile outside [0, 100]");
+  XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
+  if (nyears != 1) return XH_ERR_NOTIMPL;  // multi-year base periods: use xh_percentile_doy + xh_threshold_count
+  if (C == 0) return XH_OK;
+  return pdoy_count_impl(ctx, x, T, C, st, tbase, ndoy, window, per, alpha, beta, op, doy_period, P, count_out, valid_out);
 }
 
 int xh_nan_quantile(xh_ctx* ctx, const float* x, int64_t N, int64_t C, int64_t sn, int64_t sc, const double* q, int nq,

@@ -87,6 +87,30 @@ tx10p = percentile_bootstrap(_tx10p)
 tg10p = tn10p = tx10p
 
 
+def percentile_exceedance(da, time: TimeAxis, freq: str = "YS", op: str = ">", window: int = 5, per: float = 90.0,
+                          alpha: float = 1.0 / 3.0, beta: float = 1.0 / 3.0, *, device=None, mask_missing=True):
+    """``tx90p(da, percentile_doy(da, window, per), freq)`` in one pass when the percentile base period is the analysed
+    series itself (calendar.py:395-494 + indices/_multivariate.py:1534-1650): identical counts, but the
+    (dayofyear, lat, lon) float64 percentile field — 2/3 of the chain's HBM traffic — is never materialised.  Falls back
+    to the two-step chain for shapes the fused kernel does not cover (several years, 366-day years, other windows)."""
+    from .calendar import _flatten, percentile_doy
+
+    dev = device or get_device()
+    sym = generic.get_op(op)
+    x, cell_shape = _flatten(da, dev)
+    tb, years, doys = time.doy_table()
+    seg, _ = time.segments(freq)
+    res = None
+    if tb.shape[0] == 1 and doys.max() != 366 and len(doys) == len(time):
+        period = (np.searchsorted(seg, tb[0], side="right") - 1).astype(np.int32)  # period of every doy row
+        res = K.percentile_doy_count(dev, x, tb, window, per, sym, period, len(seg) - 1, alpha, beta)
+    if res is None:
+        p = percentile_doy(x, time, window, per, alpha, beta, device=dev)
+        res = generic.threshold_count(x, sym, p, time, freq, device=dev, keep=True, with_valid=True)
+    cnt, val = res
+    return _masked(cnt, val, time, freq, dev, cell_shape, mask_missing)
+
+
 def _spell(da, thresh, op, reducer, time, freq, resample_before_rl, device, mask_missing):
     dev = device or get_device()
     out, val = generic.spell_length_statistics(da, thresh, 1, None, op, reducer, time, freq,

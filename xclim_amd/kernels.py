@@ -352,6 +352,32 @@ def percentile_doy(dev: Device, x: DeviceArray, tbase, window: int, per, alpha=1
     return out
 
 
+def percentile_doy_count(dev: Device, x: DeviceArray, tbase, window: int, per: float, op: str, doy_period, P: int,
+                         alpha=1.0 / 3, beta=1.0 / 3, want_valid=True, out=None):
+    """Fused percentile_doy + threshold_count (xh_percentile_doy_count): (count, valid) int32 (P, C), or None when the
+    shape is not covered by the fused kernel (the caller then runs the two-step chain)."""
+    from ._capi import XH_ERR_NOTIMPL, XclimHipError
+
+    T, C_ = _tc(x)
+    tb = np.ascontiguousarray(tbase, dtype=np.int32)
+    nyears, ndoy = tb.shape
+    dp = np.ascontiguousarray(doy_period, dtype=np.int32)
+    assert dp.shape == (ndoy,)
+    if out is not None:
+        cnt, val = out
+    else:
+        cnt = dev.empty((int(P), C_), np.int32)
+        val = dev.empty((int(P), C_), np.int32) if want_valid else None
+    try:
+        dev.call("xh_percentile_doy_count", _vp(x.ptr), T, C_, C_, 1, np_ptr(tb), nyears, ndoy, int(window), float(per),
+                 float(alpha), float(beta), op_code(op), np_ptr(dp), int(P), _vp(cnt.ptr), _vp(val.ptr if val else 0))
+    except XclimHipError as e:
+        if e.code == XH_ERR_NOTIMPL:
+            return None
+        raise
+    return cnt, val
+
+
 def doy_interp(dev: Device, table: DeviceArray, i0, i1, dxn, dxs) -> DeviceArray:
     """table (D_in, C) float64 -> (D_out, C) float64 (xh_doy_interp)."""
     D_in, C_ = _tc(table)
