@@ -355,6 +355,21 @@ def test_quantile_series_hard_distributions(dev, rng, T, kind):
     np.testing.assert_allclose(out2, exp, rtol=RTOL, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("T,C", [(365, 70001), (500, 33333), (800, 20011), (1500, 9001), (3650, 5003), (10950, 4801)])
+def test_quantile_series_many_columns(dev, rng, T, C):
+    """More columns than resident workgroups (grid-stride column loops, ragged last tiles of the staged time-major
+    kernel, the padded transpose batches), every column checked against the oracle."""
+    x = _field(rng, T, C, nan_frac=0.005)
+    x[:, -1] = np.nan
+    x[: T // 2, 17] = np.nan
+    q = osdba.equally_spaced_nodes(20)
+    exp = osdba.quantile(x, q)
+    out = K.quantile_series(dev, dev.to_device(x), q).get()
+    np.testing.assert_allclose(out, exp, rtol=RTOL, atol=0, equal_nan=True)
+    out2 = K.quantile_series(dev, dev.to_device(np.ascontiguousarray(x.T)), q, time_axis=1).get()
+    np.testing.assert_allclose(out2, exp, rtol=RTOL, atol=0, equal_nan=True)
+
+
 @pytest.mark.parametrize("kind", ["+", "*"])
 @pytest.mark.parametrize("interp", ["nearest", "linear"])
 @pytest.mark.parametrize("extrap", ["constant", "nan"])
