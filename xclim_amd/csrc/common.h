@@ -11,6 +11,9 @@ struct xh_ctx {
   int device;
   hipStream_t stream;
   hipEvent_t ev0, ev1;
+  // second stream + events: transposes of the next column batch run next to the selection of the current one
+  hipStream_t stream2;
+  hipEvent_t ev_ready[2], ev_done[2];
   // small device scratch for tables (seg_off, quantiles ...) uploaded per call
   void* scratch;
   size_t scratch_bytes;

@@ -46,6 +46,11 @@ int xh_create(int device, xh_ctx** out) {
   XH_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   XH_CHECK_HIP(hipEventCreate(&ctx->ev0));
   XH_CHECK_HIP(hipEventCreate(&ctx->ev1));
+  XH_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    XH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_ready[i], hipEventDisableTiming));
+    XH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
+  }
   ctx->scratch_bytes = 8u << 20;
   XH_CHECK_HIP(hipMalloc(&ctx->scratch, ctx->scratch_bytes));
   hipDeviceProp_t prop;
@@ -63,6 +68,12 @@ int xh_destroy(xh_ctx* ctx) {
   if (ctx->big) (void)hipFree(ctx->big);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
+  (void)hipStreamSynchronize(ctx->stream2);
+  for (int i = 0; i < 2; ++i) {
+    (void)hipEventDestroy(ctx->ev_ready[i]);
+    (void)hipEventDestroy(ctx->ev_done[i]);
+  }
+  (void)hipStreamDestroy(ctx->stream2);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return XH_OK;

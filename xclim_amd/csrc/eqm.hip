@@ -99,21 +99,46 @@ static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t 
   // short series: 8-lane groups read the time-major rows directly (no transpose)
   int rc0 = xh_select_time_major(ctx, x, T, C, st, d_q, nq, out, 1, C);
   if (rc0 != XH_ERR_NOTIMPL) return rc0;
-  // time-major: transpose batches of columns into scratch (not counted as algorithmic bytes)
+  // time-major: transpose batches of columns into scratch (not counted as algorithmic bytes).  Two scratch
+  // buffers and two streams: batch k+1 is transposed on stream2 while batch k is selected on the main stream (the
+  // selection kernels are latency bound and leave the memory pipe mostly idle).
   const int64_t Tp = (T + 3) & ~(int64_t)3;  // padded column stride: every scratch column starts 16-byte aligned
-  int64_t batch = (int64_t)((1ull << 30) / (sizeof(float) * (size_t)Tp));
+  int64_t batch = (int64_t)((1ull << 29) / (sizeof(float) * (size_t)Tp));
   batch = (batch / 64) * 64;
   if (batch < 64) batch = 64;
   if (batch > C) batch = C;
+  const size_t buf_elems = (size_t)batch * (size_t)Tp;
   void* tmp = nullptr;
-  int rc = xh_big_scratch(ctx, sizeof(float) * (size_t)batch * (size_t)Tp, &tmp);
+  int rc = xh_big_scratch(ctx, 2 * sizeof(float) * buf_elems, &tmp);
   if (rc) return rc;
-  for (int64_t c0 = 0; c0 < C; c0 += batch) {
-    int64_t nb = C - c0 < batch ? C - c0 : batch;
-    rc = xh_transpose_f32(ctx, x + c0, T, nb, st, (float*)tmp, Tp);
+  float* bufs[2] = {(float*)tmp, (float*)tmp + buf_elems};
+  hipStream_t s_main = ctx->stream, s_tr = ctx->stream2;
+  // stream2 starts after everything already queued on the main stream (the producer of x)
+  XH_CHECK_HIP(hipEventRecord(ctx->ev_done[0], s_main));
+  XH_CHECK_HIP(hipStreamWaitEvent(s_tr, ctx->ev_done[0], 0));
+  const int64_t nbatch = cdiv64(C, batch);
+  auto transpose_batch = [&](int64_t k) -> int {
+    const int64_t c0 = k * batch, nb = C - c0 < batch ? C - c0 : batch;
+    if (k >= 2) XH_CHECK_HIP(hipStreamWaitEvent(s_tr, ctx->ev_done[k & 1], 0));  // buffer free again
+    ctx->stream = s_tr;
+    int r = xh_transpose_f32(ctx, x + c0, T, nb, st, bufs[k & 1], Tp);
+    ctx->stream = s_main;
+    if (r) return r;
+    XH_CHECK_HIP(hipEventRecord(ctx->ev_ready[k & 1], s_tr));
+    return XH_OK;
+  };
+  rc = transpose_batch(0);
+  if (rc) return rc;
+  for (int64_t k = 0; k < nbatch; ++k) {
+    const int64_t c0 = k * batch, nb = C - c0 < batch ? C - c0 : batch;
+    if (k + 1 < nbatch) {
+      rc = transpose_batch(k + 1);
+      if (rc) return rc;
+    }
+    XH_CHECK_HIP(hipStreamWaitEvent(s_main, ctx->ev_ready[k & 1], 0));
+    rc = xh_select_columns(ctx, bufs[k & 1], T, nb, Tp, d_q, nq, out + c0, 1, C);
     if (rc) return rc;
-    rc = xh_select_columns(ctx, (const float*)tmp, T, nb, Tp, d_q, nq, out + c0, 1, C);
-    if (rc) return rc;
+    XH_CHECK_HIP(hipEventRecord(ctx->ev_done[k & 1], s_main));
   }
   return XH_OK;
 }
