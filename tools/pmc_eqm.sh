@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC counters for the select kernels (EQM train).  Usage: tools/pmc_eqm.sh <tag> [G]
+export XH_DIAGNOSTICS=1  # the library ignores its diagnostic switches without it
 TAG=${1:-x}; export XH_SELECT_G=${2:-32}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

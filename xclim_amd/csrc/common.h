@@ -25,6 +25,11 @@ struct xh_ctx {
 
 void xh_set_error(const char* fmt, ...);
 
+// Diagnostic / tuning switches (phase ablation, phase timers, kernel-shape overrides) are read from the environment
+// ONLY when XH_DIAGNOSTICS=1 is set as well: an ablation switch makes results wrong on purpose and must never be picked
+// up by accident in production.  Used by tools/bench_select_abl.sh, tools/pmc_eqm.sh.
+const char* xh_diag_env(const char* name);
+
 #define XH_CHECK_HIP(expr)                                                                  \
   do {                                                                                      \
     hipError_t _e = (expr);                                                                 \

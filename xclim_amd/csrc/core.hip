@@ -1,6 +1,8 @@
 // core.hip — context, device memory, timers, synthetic input generator, tiled transpose.
 #include <stdarg.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -10,6 +12,12 @@ void xh_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+const char* xh_diag_env(const char* name) {
+  const char* on = getenv("XH_DIAGNOSTICS");
+  if (!on || on[0] != '1') return nullptr;
+  return getenv(name);
 }
 
 extern "C" {

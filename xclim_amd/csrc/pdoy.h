@@ -36,7 +36,8 @@ __device__ __forceinline__ void pdoy_gather(float (&raw)[NYP], int rowv, const f
 }
 
 // pdoy_top.hip: register top-16 kernel for the percentiles in jmap[0..nsub) (rev = 0: all of them select within the 16
-// largest samples; rev = 1: within the 16 smallest).  Regular doys on the chunk grid, irregular ones from d_irr.
+// largest samples; rev = 1: within the 16 smallest) on the REGULAR doys (d_reg[d] != 0) of the chunk grid; irregular doys
+// (window does not decompose into day-sets, e.g. around Feb 29) are left to k_pdoy_merge.
 int xh_launch_pdoy_top16(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
                          int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int nsub, int rev, double* out,
-                         const int32_t* d_vmap, int64_t Tv, const uint8_t* d_reg, const int32_t* d_irr, int nirr);
+                         const int32_t* d_vmap, int64_t Tv, const uint8_t* d_reg);

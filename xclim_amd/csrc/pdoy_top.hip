@@ -35,6 +35,23 @@ __device__ __forceinline__ void bitonic_desc(uint32_t (&k)[NP]) {  // full sort,
   }
 }
 
+// 16 keys sorted descending with the 60-comparator, 10-layer optimal network (verified exhaustively with the 0-1
+// principle; the bitonic sorter needs 80)
+__device__ __forceinline__ void sort16_desc(uint32_t (&k)[16]) {
+#define XH_C(i, j) ce_desc(k[i], k[j]);
+  XH_C(0, 13) XH_C(1, 12) XH_C(2, 15) XH_C(3, 14) XH_C(4, 8) XH_C(5, 6) XH_C(7, 11) XH_C(9, 10)
+  XH_C(0, 5) XH_C(1, 7) XH_C(2, 9) XH_C(3, 4) XH_C(6, 13) XH_C(8, 14) XH_C(10, 15) XH_C(11, 12)
+  XH_C(0, 1) XH_C(2, 3) XH_C(4, 5) XH_C(6, 8) XH_C(7, 9) XH_C(10, 11) XH_C(12, 13) XH_C(14, 15)
+  XH_C(0, 2) XH_C(1, 3) XH_C(4, 10) XH_C(5, 11) XH_C(6, 7) XH_C(8, 9) XH_C(12, 14) XH_C(13, 15)
+  XH_C(1, 2) XH_C(3, 12) XH_C(4, 6) XH_C(5, 7) XH_C(8, 10) XH_C(9, 11) XH_C(13, 14)
+  XH_C(1, 4) XH_C(2, 6) XH_C(5, 8) XH_C(7, 10) XH_C(9, 13) XH_C(11, 14)
+  XH_C(2, 4) XH_C(3, 6) XH_C(9, 12) XH_C(11, 13)
+  XH_C(3, 5) XH_C(6, 8) XH_C(7, 9) XH_C(10, 12)
+  XH_C(3, 4) XH_C(5, 6) XH_C(7, 8) XH_C(9, 10) XH_C(11, 12)
+  XH_C(6, 7) XH_C(8, 9)
+#undef XH_C
+}
+
 // t <- the 16 largest of (t u b), sorted descending; t and b sorted descending
 __device__ __forceinline__ void merge_top16(uint32_t (&t)[16], const uint32_t (&b)[16]) {
 #pragma unroll
@@ -47,12 +64,12 @@ __device__ __forceinline__ void merge_top16(uint32_t (&t)[16], const uint32_t (&
   }
 }
 
-template <int W, int NYP, bool OFFSET>
+template <int W, int NYP>
 __global__ void __launch_bounds__(64)
 k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
              int ndoy, int chunk, const QTab* __restrict__ qtab, const int32_t* __restrict__ jmap, int nsub,
              double* __restrict__ out, const int32_t* __restrict__ vmap, int64_t Tv, const uint8_t* __restrict__ regular,
-             const int32_t* __restrict__ doy_list, int ndl, int rev) {
+             int rev) {
   const uint32_t rmask = rev ? 0xFFFFFFFFu : 0u;  // mirrored key order for the bottom-16 case
   const int lane = threadIdx.x;
   int64_t c = (int64_t)blockIdx.x * 64 + lane;
@@ -77,9 +94,19 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
       nv += ok ? 1 : 0;
       key[y] = ok ? (kk ^ rmask) : 0u;  // NaN / padding -> 0 = smallest
     }
-    bitonic_desc<NYP>(key);
+    // top 16 of the NYP keys: sort blocks of 16 with the optimal network, combine with half-merges
+    // (NYP = 32: 60 + 60 + 16 + 32 = 168 comparator-equivalents instead of 240 for a full bitonic-32)
+    uint32_t blk[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) top[i] = key[i];
+    sort16_desc(top);
+#pragma unroll
+    for (int b = 1; b < NYP / 16; ++b) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) blk[i] = key[b * 16 + i];
+      sort16_desc(blk);
+      merge_top16(top, blk);
+    }
   };
   auto select_and_store = [&](int d) {
     uint32_t t16[16];
@@ -114,17 +141,7 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
     }
   };
 
-  if (OFFSET) {
-    for (int di = blockIdx.y; di < ndl; di += gridDim.y) {
-      const int d = doy_list[di];
-#pragma unroll
-      for (int k = 0; k < W; ++k) {
-        gather(rows_of(d, k - half));
-        finish(ring[k], cnt[k]);
-      }
-      select_and_store(d);
-    }
-  } else {
+  {
     int d0 = blockIdx.y * chunk, d1 = d0 + chunk;
     if (d1 > ndoy) d1 = ndoy;
     // ring[w] holds the day-set of doy (d - half + w); prologue fills slots 1..W-1 for d = d0 - 1
@@ -154,18 +171,12 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
 
 int xh_launch_pdoy_top16(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
                          int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int nsub, int rev, double* out,
-                         const int32_t* d_vmap, int64_t Tv, const uint8_t* d_reg, const int32_t* d_irr, int nirr) {
+                         const int32_t* d_vmap, int64_t Tv, const uint8_t* d_reg) {
   const int chunk = 24;
   const dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
-  const dim3 grid_irr((unsigned)cdiv64(C, 64), (unsigned)(nirr > 0 ? nirr : 1));
 #define XH_TOP16(W, NY)                                                                                                   \
-  do {                                                                                                                    \
-    hipLaunchKernelGGL((k_pdoy_top16<W, NY, false>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, \
-                       d_tab, d_jmap, nsub, out, d_vmap, Tv, d_reg, (const int32_t*)nullptr, 0, rev);                     \
-    if (nirr)                                                                                                             \
-      hipLaunchKernelGGL((k_pdoy_top16<W, NY, true>), grid_irr, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, \
-                         chunk, d_tab, d_jmap, nsub, out, d_vmap, Tv, d_reg, d_irr, nirr, rev);                           \
-  } while (0)
+  hipLaunchKernelGGL((k_pdoy_top16<W, NY>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, d_tab,  \
+                     d_jmap, nsub, out, d_vmap, Tv, d_reg, rev)
   if (nyears <= 32) {
     if (window == 3) XH_TOP16(3, 32); else if (window == 5) XH_TOP16(5, 32); else XH_TOP16(7, 32);
   } else {

@@ -815,64 +815,77 @@ static int pdoy_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
     else if (db <= 16) jbot[nbot++] = j;
     else jrest[nrest++] = j;
   }
-  // deepest pop from either end over the "rest" percentiles and all valid counts (same from_top rule as the kernel)
-  int KT = 1, KB = 0;
-  for (int jj = 0; jj < nrest; ++jj)
-    for (int n = 0; n <= N; ++n) {
-      const QTab& e = tab[jrest[jj] * (N + 1) + n];
-      if (e.lo < 0) continue;
-      if ((n - 1 - e.hi) < e.lo) { if (n - e.lo > KT) KT = n - e.lo; }
-      else { if (e.hi + 1 > KB) KB = e.hi + 1; }
-    }
-  if (KT > nyears) KT = nyears;
-  if (KB > nyears) KB = nyears;
-  if (KT + KB >= nyears) { KT = nyears; KB = 0; }  // full mode: whole list in ringT, bottom pops index it from the end
-  void *d_reg = nullptr, *d_tab = nullptr, *d_irr = nullptr, *d_jtop = nullptr, *d_jbot = nullptr, *d_jrest = nullptr;
+  // deepest pop from either end over a set of percentiles and all valid counts (same from_top rule as the kernel):
+  // "rest" for the regular doys, ALL percentiles for the irregular doys (those always take the LDS-ring kernel)
+  auto ring_depth = [&](const int32_t* js, int nj, int* pKT, int* pKB) {
+    int kt = 1, kb = 0;
+    for (int jj = 0; jj < nj; ++jj)
+      for (int n = 0; n <= N; ++n) {
+        const QTab& e = tab[js[jj] * (N + 1) + n];
+        if (e.lo < 0) continue;
+        if ((n - 1 - e.hi) < e.lo) { if (n - e.lo > kt) kt = n - e.lo; }
+        else { if (e.hi + 1 > kb) kb = e.hi + 1; }
+      }
+    if (kt > nyears) kt = nyears;
+    if (kb > nyears) kb = nyears;
+    if (kt + kb >= nyears) { kt = nyears; kb = 0; }  // full mode: whole list in ringT, bottom pops index it from the end
+    *pKT = kt; *pKB = kb;
+  };
+  int32_t jall[64];
+  for (int j = 0; j < nper; ++j) jall[j] = j;
+  int KT = 1, KB = 0, KTa = 1, KBa = 0;
+  ring_depth(jrest, nrest, &KT, &KB);
+  ring_depth(jall, nper, &KTa, &KBa);
+  void *d_reg = nullptr, *d_tab = nullptr, *d_irr = nullptr, *d_jtop = nullptr, *d_jbot = nullptr, *d_jrest = nullptr,
+       *d_jall = nullptr;
   rc = xh_scratch_upload(ctx, &cur, regular, (size_t)ndoy, &d_reg);
   if (!rc) rc = xh_scratch_upload(ctx, &cur, tab, sizeof(QTab) * (size_t)nper * (N + 1), &d_tab);
   if (!rc && nirr) rc = xh_scratch_upload(ctx, &cur, irregular, sizeof(int32_t) * (size_t)nirr, &d_irr);
   if (!rc && ntop) rc = xh_scratch_upload(ctx, &cur, jtop, sizeof(int32_t) * (size_t)ntop, &d_jtop);
   if (!rc && nbot) rc = xh_scratch_upload(ctx, &cur, jbot, sizeof(int32_t) * (size_t)nbot, &d_jbot);
   if (!rc && nrest) rc = xh_scratch_upload(ctx, &cur, jrest, sizeof(int32_t) * (size_t)nrest, &d_jrest);
+  if (!rc && nirr) rc = xh_scratch_upload(ctx, &cur, jall, sizeof(int32_t) * (size_t)nper, &d_jall);
   free(regular); free(irregular); free(tab);
   if (rc) return rc;
   const int chunk = 24;
-  const char* ea = getenv("XH_PDOY_ABL");  // diagnostics only (results become wrong)
+  const char* ea = xh_diag_env("XH_PDOY_ABL");  // diagnostics only (results become wrong)
   const int abl = ea ? atoi(ea) : 0;
   const int NYP = nyears <= 32 ? 32 : 64;
   dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
   dim3 grid_irr((unsigned)cdiv64(C, 64), (unsigned)(nirr > 0 ? nirr : 1));
-  // ---- register top-16 kernel (pdoy_top.hip) for the top / bottom groups
+  // ---- register top-16 kernel (pdoy_top.hip) for the top / bottom groups, regular doys
   if (ntop) {
     rc = xh_launch_pdoy_top16(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const QTab*)d_tab,
-                              (const int32_t*)d_jtop, ntop, 0, out, (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg,
-                              (const int32_t*)d_irr, nirr);
+                              (const int32_t*)d_jtop, ntop, 0, out, (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg);
     if (rc) return rc;
   }
   if (nbot) {
     rc = xh_launch_pdoy_top16(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const QTab*)d_tab,
-                              (const int32_t*)d_jbot, nbot, 1, out, (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg,
-                              (const int32_t*)d_irr, nirr);
+                              (const int32_t*)d_jbot, nbot, 1, out, (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg);
     if (rc) return rc;
   }
-  if (nrest == 0) return XH_OK;
-  // ---- LDS-ring kernel for the remaining percentiles
-  size_t lds = ((size_t)window * (KT + KB) * 64 + (size_t)window * 64) * sizeof(uint32_t);
+  if (nrest == 0 && nirr == 0) return XH_OK;
+  // ---- LDS-ring kernel: the remaining percentiles on the regular doys, every percentile on the irregular doys
+  const size_t lds = ((size_t)window * (KT + KB) * 64 + (size_t)window * 64) * sizeof(uint32_t);
+  const size_t lds_a = ((size_t)window * (KTa + KBa) * 64 + (size_t)window * 64) * sizeof(uint32_t);
 #define XH_MERGE(W, NY)                                                                                                    \
   do {                                                                                                                     \
-    if (lds > 64 * 1024) {                                                                                                 \
-      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_pdoy_merge<W, NY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)lds));                                                                         \
-      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_pdoy_merge<W, NY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                       (int)lds));                                                                         \
+    if (nrest) {                                                                                                           \
+      if (lds > 64 * 1024)                                                                                                 \
+        XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_pdoy_merge<W, NY, false>,                                          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+      hipLaunchKernelGGL((k_pdoy_merge<W, NY, false>), grid, dim3(64), lds, ctx->stream, x, T, C, st, (const int32_t*)d_tb, \
+                         nyears, ndoy, chunk, (const QTab*)d_tab, (const int32_t*)d_jrest, nrest, out,                      \
+                         (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg, (const int32_t*)nullptr, 0, KT, KB, abl);       \
     }                                                                                                                      \
-    hipLaunchKernelGGL((k_pdoy_merge<W, NY, false>), grid, dim3(64), lds, ctx->stream, x, T, C, st, (const int32_t*)d_tb,   \
-                       nyears, ndoy, chunk, (const QTab*)d_tab, (const int32_t*)d_jrest, nrest, out,                        \
-                       (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg, (const int32_t*)nullptr, 0, KT, KB, abl);         \
-    if (nirr)                                                                                                              \
-      hipLaunchKernelGGL((k_pdoy_merge<W, NY, true>), grid_irr, dim3(64), lds, ctx->stream, x, T, C, st,                    \
-                         (const int32_t*)d_tb, nyears, ndoy, chunk, (const QTab*)d_tab, (const int32_t*)d_jrest, nrest, out, \
-                         (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg, (const int32_t*)d_irr, nirr, KT, KB, abl);      \
+    if (nirr) {                                                                                                            \
+      if (lds_a > 64 * 1024)                                                                                               \
+        XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_pdoy_merge<W, NY, true>,                                           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));                         \
+      hipLaunchKernelGGL((k_pdoy_merge<W, NY, true>), grid_irr, dim3(64), lds_a, ctx->stream, x, T, C, st,                  \
+                         (const int32_t*)d_tb, nyears, ndoy, chunk, (const QTab*)d_tab, (const int32_t*)d_jall, nper, out,  \
+                         (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg, (const int32_t*)d_irr, nirr, KTa, KBa, abl);    \
+    }                                                                                                                      \
   } while (0)
   if (NYP == 32) {
     if (window == 3) XH_MERGE(3, 32); else if (window == 5) XH_MERGE(5, 32); else XH_MERGE(7, 32);

@@ -486,9 +486,9 @@ static int launch_select_grp_g(xh_ctx* ctx, const float* x, int64_t T, int64_t n
   int64_t nblk = cdiv64(ncols, COLS);
   int64_t maxblk = (int64_t)ctx->num_cu * 64;
   if (nblk > maxblk) nblk = maxblk;
-  const char* ea = getenv("XH_SELECT_ABL");  // diagnostics: skip phases (results become wrong)
+  const char* ea = xh_diag_env("XH_SELECT_ABL");  // diagnostics: skip phases (results become wrong)
   const int abl = ea ? atoi(ea) : 0;
-  if (TM && G == 32 && !getenv("XH_SELECT_NOSTAGE")) {
+  if (TM && G == 32 && !xh_diag_env("XH_SELECT_NOSTAGE")) {
     constexpr int SG = 32;  // (fixed: the staged kernel is only instantiated for 32 lanes per column)
     int64_t nb2 = cdiv64(ncols, 512 / SG);
     if (nb2 > (int64_t)ctx->num_cu * 32) nb2 = (int64_t)ctx->num_cu * 32;
@@ -515,7 +515,7 @@ static int launch_select_grp_g(xh_ctx* ctx, const float* x, int64_t T, int64_t n
 // measured on MI355X, T = 365, 1 036 800 columns: time-major 32 lanes/column 2.2 ms (64: 4.0, 16: 2.6, 8: 6.1);
 // time-minor 64 lanes/column 1.4 ms (32: 1.44, 16: 1.8)
 static int select_group_size(bool time_major) {
-  const char* e = getenv("XH_SELECT_G");
+  const char* e = xh_diag_env("XH_SELECT_G");
   int g = e ? atoi(e) : (time_major ? 32 : 64);
   if (g != 8 && g != 16 && g != 32 && g != 64) g = time_major ? 32 : 64;
   return g;

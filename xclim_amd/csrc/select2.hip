@@ -384,8 +384,8 @@ int launch_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64
   int64_t nblk = ncols;
   int64_t maxblk = (int64_t)ctx->num_cu * 16;
   if (nblk > maxblk) nblk = maxblk;
-  const char* ea = getenv("XH_SELECT_ABL");  // diagnostics only: skip phases (results become wrong)
-  const char* ep = getenv("XH_SELECT_PROF");  // diagnostics only: per-phase cycle counts on stderr
+  const char* ea = xh_diag_env("XH_SELECT_ABL");  // diagnostics only: skip phases (results become wrong)
+  const char* ep = xh_diag_env("XH_SELECT_PROF");  // diagnostics only: per-phase cycle counts on stderr
   unsigned long long* d_prof = nullptr;
   if (ep && atoi(ep)) {
     XH_CHECK_HIP(hipMalloc((void**)&d_prof, 16 * sizeof(unsigned long long)));
@@ -417,7 +417,7 @@ int xh_select_columns_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t n
                            const double* d_q, int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
   if (T <= 1024 || T > 16384 || nq > 64) return XH_ERR_NOTIMPL;
 #define XH_LEAN(NT, KPL, NB) return launch_lean<NT, KPL, NB>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride)
-  const char* ent = getenv("XH_LEAN_NT");  // tuning only
+  const char* ent = xh_diag_env("XH_LEAN_NT");  // tuning only
   const int nt = ent ? atoi(ent) : 512;
   if (T <= 2048) XH_LEAN(256, 8, 1024);
   if (T <= 3072) XH_LEAN(256, 12, 1024);
