@@ -306,6 +306,12 @@ int xh_doy_broadcast(xh_ctx* ctx, const double* table, int D, int64_t C, const i
 int xh_within_bnds_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* low,
                        const double* high, int D, const int32_t* tidx, uint8_t* out);
 
+/* compare(da, op, resample_doy(per, da)) as a float32 1/0 mask (fp64 compare against the (D, C) per-doy table): the
+ * first step of warm_spell_duration_index / cold_spell_duration_index (indices/_multivariate.py:66-152, 1693-1793);
+ * xh_run_stats on the mask gives the index. */
+int xh_compare_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, const double* table,
+                   int D, const int32_t* tidx, float* out, int64_t st_out);
+
 /* ---- sdba empirical quantile mapping (E1-E4; xsdba >= 0.4.0, not in the reference tree) ------ */
 /* nbutils.quantile: per-cell NaN-aware type-7 quantiles of the whole series at nq nodes. out (nq, C) f32 */
 int xh_quantile_series(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,

@@ -55,3 +55,21 @@ def maximum_consecutive_dry_days(pr, thresh, time: OTime, freq="YS", resample_be
 
     `thresh` must be a python float already in the units of `pr` (convert_units_to is host work)."""
     return ogen.spell_length_statistics(pr, float(thresh), 1, None, "<", "max", time, freq, resample_before_rl)
+
+
+def warm_spell_duration_index(tasmax, tasmax_per, per_doys, time: OTime, window=6, freq="YS", resample_before_rl=True, op=">"):
+    """indices/_multivariate.py:1779-1793: above = compare(tasmax, op, resample_doy(per)); windowed_run_count."""
+    from . import run_length as rl
+
+    thresh = ocal.resample_doy(tasmax_per, per_doys, time)
+    above = ogen.compare(tasmax, op, thresh, constrain=(">", ">="))
+    return rl.resample_and_rl(above, resample_before_rl, rl.windowed_run_count, time=time, freq=freq, window=window)
+
+
+def cold_spell_duration_index(tasmin, tasmin_per, per_doys, time: OTime, window=6, freq="YS", resample_before_rl=True, op="<"):
+    """indices/_multivariate.py:139-152."""
+    from . import run_length as rl
+
+    thresh = ocal.resample_doy(tasmin_per, per_doys, time)
+    below = ogen.compare(tasmin, op, thresh, constrain=("<", "<="))
+    return rl.resample_and_rl(below, resample_before_rl, rl.windowed_run_count, time=time, freq=freq, window=window)

@@ -417,3 +417,33 @@ def test_percentile_exceedance_fused(dev, rng, calendar, T, freq, window, per, o
     raw = xi.percentile_exceedance(x, ta, freq, op, window, per, device=dev, mask_missing=False)
     of = oidx.tx90p if op in (">", ">=") else oidx.tx10p
     np.testing.assert_array_equal(raw, of(x, exp[..., 0], doys, ot, freq, op))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("calendar,T", [("standard", 1461), ("noleap", 1095)])
+@pytest.mark.parametrize("before", [True, False])
+def test_percentile_spell_indices(dev, rng, calendar, T, before):
+    """warm / cold spell duration index (indices/_multivariate.py:66-152, 1693-1793): per-doy percentile threshold ->
+    windowed_run_count; the first `next` row of SURVEY.md section 8f."""
+    x = _temp(rng, T, (5, 6), nan_frac=0.004)
+    # slow anomalies so that multi-day spells above / below the percentiles exist
+    x += np.repeat(rng.normal(0, 3.0, (T // 7 + 1, 5, 6)), 7, axis=0)[:T].astype(np.float32)
+    ta, ot = _axes("2000-01-01", T, calendar)
+    p = percentile_doy(x, ta, window=5, per=[25.0, 75.0], device=dev)
+    exp, doys = ocal.percentile_doy(x, ot, 5, [25.0, 75.0])
+    for freq in ("YS", "MS"):
+        for window in (2, 6):
+            got = xi.warm_spell_duration_index(x, p.sel(75.0), ta, window, freq, before, device=dev, mask_missing=False)
+            ref = oidx.warm_spell_duration_index(x, exp[..., 1], doys, ot, window, freq, before)
+            np.testing.assert_array_equal(got, ref)
+            got = xi.cold_spell_duration_index(x, p.sel(25.0), ta, window, freq, before, device=dev, mask_missing=False)
+            ref = oidx.cold_spell_duration_index(x, exp[..., 0], doys, ot, window, freq, before)
+            np.testing.assert_array_equal(got, ref)
+    assert xi.warm_spell_duration_index(x, p.sel(75.0), ta, 2, "YS", device=dev, mask_missing=False).sum() > 0
+    masked = xi.warm_spell_duration_index(x, p.sel(75.0), ta, 6, "MS", device=dev)
+    nan_month = np.isnan(masked)
+    seg, _ = ta.segments("MS")
+    has_nan = np.stack([np.isnan(x[a:b]).any(axis=0) for a, b in zip(seg[:-1], seg[1:])])
+    np.testing.assert_array_equal(nan_month, has_nan)
+    with pytest.raises(ValueError):
+        xi.warm_spell_duration_index(x, p.sel(75.0), ta, op="<", device=dev)

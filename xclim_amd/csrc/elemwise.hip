@@ -130,6 +130,24 @@ k_within_bnds_doy(const float* __restrict__ x, int64_t T, int64_t C, int64_t st,
   }
 }
 
+// mask of `x op table[tidx[t]]` (fp64 compare against a per-doy table): the `compare(da, op, resample_doy(per, da))` step of
+// the percentile-spell indices (warm/cold_spell_duration_index, indices/_multivariate.py:66-152, 1693-1793) without the
+// (T, C) fp64 threshold field.  out float32 1/0.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_compare_doy(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int op, const double* __restrict__ table,
+              const int32_t* __restrict__ tidx, float* __restrict__ out, int64_t st_out) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
+  int64_t ta = (int64_t)blockIdx.y * chunk, tb = ta + chunk;
+  if (tb > T) tb = T;
+#pragma unroll 4
+  for (int64_t t = ta; t < tb; ++t) {
+    const int64_t r = tidx[t];
+    out[t * st_out + c] = xh_cmp_f64((double)x[t * st + c], op, table[r * C + c]) ? 1.f : 0.f;
+  }
+}
+
 static dim3 time_chunk_grid(xh_ctx* ctx, int64_t T, int64_t C) {
   const int64_t cblocks = cdiv64(C, XH_BLOCK);
   int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
@@ -230,6 +248,22 @@ int xh_within_bnds_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
   if (rc) return rc;
   hipLaunchKernelGGL(k_within_bnds_doy, time_chunk_grid(ctx, T, C), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, low, high,
                      d_tidx, out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_compare_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, const double* table,
+                   int D, const int32_t* tidx, float* out, int64_t st_out) {
+  XH_REQUIRE(ctx && x && table && out, XH_ERR_ARG, "xh_compare_doy: NULL argument");
+  XH_REQUIRE(D >= 1 && C >= 0 && T >= 0, XH_ERR_ARG, "xh_compare_doy: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C && st_out >= C, XH_ERR_LAYOUT, "xh_compare_doy: needs time-major views (sc == 1, st >= C)");
+  XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
+  if (T == 0 || C == 0) return XH_OK;
+  const int32_t* d_tidx = nullptr;
+  int rc = upload_tidx(ctx, "xh_compare_doy", tidx, T, D, &d_tidx);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_compare_doy, time_chunk_grid(ctx, T, C), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, op, table, d_tidx,
+                     out, st_out);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

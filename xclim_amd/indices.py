@@ -111,6 +111,37 @@ def percentile_exceedance(da, time: TimeAxis, freq: str = "YS", op: str = ">", w
     return _masked(cnt, val, time, freq, dev, cell_shape, mask_missing)
 
 
+def _percentile_spell(da, per: DoyPercentile, window, time, freq, resample_before_rl, op, constrain, device, mask_missing):
+    from .calendar import _flatten, adjust_doy_calendar, resample_doy_index
+
+    dev = device or get_device()
+    sym = generic.get_op(op, constrain)
+    x, cell_shape = _flatten(da, dev)
+    doy = adjust_doy_calendar(per, time, dev)
+    if doy.data.shape[0] != 1:
+        raise ValueError("select one percentile first (DoyPercentile.sel)")
+    table = doy.data.reshape(doy.data.shape[1], doy.data.shape[2])
+    mask = K.compare_doy(dev, x, sym, table, resample_doy_index(doy, time))
+    seg, _ = time.segments(freq)
+    # rl.windowed_run_count: total length of the runs of at least `window` steps (run_length.py:437-488)
+    out, _ = K.run_stats(dev, mask, "sum", window, seg, cut=resample_before_rl, want_valid=False)
+    _, val = K.resample_reduce(dev, x, "count", seg)
+    return _masked(out, val, time, freq, dev, cell_shape, mask_missing)
+
+
+def warm_spell_duration_index(tasmax, tasmax_per: DoyPercentile, time: TimeAxis, window: int = 6, freq: str = "YS",
+                              resample_before_rl: bool = True, op: str = ">", *, device=None, mask_missing=True):
+    """indices/_multivariate.py:1693-1793: days that are part of a spell of at least `window` consecutive days with
+    tasmax above its day-of-year percentile."""
+    return _percentile_spell(tasmax, tasmax_per, window, time, freq, resample_before_rl, op, (">", ">="), device, mask_missing)
+
+
+def cold_spell_duration_index(tasmin, tasmin_per: DoyPercentile, time: TimeAxis, window: int = 6, freq: str = "YS",
+                              resample_before_rl: bool = True, op: str = "<", *, device=None, mask_missing=True):
+    """indices/_multivariate.py:66-152: same with tasmin below its day-of-year percentile."""
+    return _percentile_spell(tasmin, tasmin_per, window, time, freq, resample_before_rl, op, ("<", "<="), device, mask_missing)
+
+
 def _spell(da, thresh, op, reducer, time, freq, resample_before_rl, device, mask_missing):
     dev = device or get_device()
     out, val = generic.spell_length_statistics(da, thresh, 1, None, op, reducer, time, freq,

@@ -410,6 +410,17 @@ def within_bnds_doy(dev: Device, x: DeviceArray, low: DeviceArray, high: DeviceA
     return out
 
 
+def compare_doy(dev: Device, x: DeviceArray, op: str, table: DeviceArray, tidx) -> DeviceArray:
+    """float32 1/0 mask of x[t] op table[tidx[t]] (fp64 compare, (D, C) float64 per-doy table)."""
+    T, C_ = _tc(x)
+    D = table.shape[0]
+    tidx = np.ascontiguousarray(tidx, dtype=np.int32)
+    assert len(tidx) == T and table.shape == (D, C_)
+    out = dev.empty((T, C_), np.float32)
+    dev.call("xh_compare_doy", _vp(x.ptr), T, C_, C_, 1, op_code(op), _vp(table.ptr), D, np_ptr(tidx), _vp(out.ptr), C_)
+    return out
+
+
 def quantile_series(dev: Device, x: DeviceArray, q, time_axis=0, out=None) -> DeviceArray:
     """Per-cell quantiles of the whole series: x (T, C) [time_axis 0] or (C, T) [time_axis 1] -> (nq, C) float32."""
     q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
