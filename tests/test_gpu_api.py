@@ -447,3 +447,28 @@ def test_percentile_spell_indices(dev, rng, calendar, T, before):
     np.testing.assert_array_equal(nan_month, has_nan)
     with pytest.raises(ValueError):
         xi.warm_spell_duration_index(x, p.sel(75.0), ta, op="<", device=dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["linear", "median_unbiased", "weibull", "hazen"])
+@pytest.mark.parametrize("R", [5, 21, 60])
+def test_ensemble_percentiles(dev, rng, method, R):
+    """ensembles/_base.py:213-372 (second caller of calc_perc): percentiles over the realization axis, min_members."""
+    from oracle import ensembles as oens
+    from xclim_amd import ensembles as xens
+
+    ens = rng.normal(10.0, 3.0, (R, 24, 7, 5)).astype(np.float32)
+    ens[rng.random(ens.shape) < 0.1] = np.nan
+    ens[:, 0, 0, 0] = np.nan
+    ens[: R - 2, 1, 1, 1] = np.nan
+    for mm in (1, None, max(1, R // 2)):
+        got = xens.ensemble_percentiles(ens, [10, 50, 90], min_members=mm, method=method, device=dev)
+        ref = oens.ensemble_percentiles(ens, [10, 50, 90], min_members=mm, method=method)
+        assert got.shape == ref.shape == (24, 7, 5, 3)
+        np.testing.assert_allclose(got, ref, rtol=1e-12, equal_nan=True)
+    # reference known answer (tests/test_ensembles.py style): percentiles of 0..R-1 with the linear method
+    lin = np.arange(R, dtype=np.float32)[:, None]
+    got = xens.ensemble_percentiles(lin, [0, 50, 100], device=dev)
+    np.testing.assert_allclose(got[0], [0, (R - 1) / 2, R - 1], rtol=1e-12)
+    with pytest.raises(NotImplementedError):
+        xens.ensemble_percentiles(ens, weights=np.ones(R), device=dev)
