@@ -391,6 +391,25 @@ def test_eqm_train_adjust(dev, rng, kind, interp, extrap):
     np.testing.assert_allclose(scen, exp, rtol=RTOL, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("extrap", ["constant", "nan"])
+@pytest.mark.parametrize("nq", [20, 7, 32])
+def test_eqm_adjust_cubic(dev, rng, kind, extrap, nq):
+    """interp="cubic": scipy interp1d(kind="cubic") (not-a-knot spline) per cell, incl. NaN nodes dropped first."""
+    T, C = 500, 90
+    ref = _field(rng, T, C)
+    hist = (_field(rng, T, C) + 1.5).astype(np.float32)
+    sim = (_field(rng, T, C, nan_frac=0.01) + 2.0).astype(np.float32)
+    eaf, ehq = osdba.eqm_train(ref, hist, nq, kind)
+    eaf, ehq = eaf.astype(np.float32), ehq.astype(np.float32)
+    eaf[1, 3] = np.nan           # an invalid node in one cell (dropped before the spline is built)
+    ehq[nq - 2, 5] = np.nan
+    scen = K.eqm_adjust(dev, dev.to_device(sim), dev.to_device(eaf), dev.to_device(ehq), kind, "cubic", extrap).get()
+    exp = osdba.eqm_adjust(sim, eaf, ehq, kind, "cubic", extrap)
+    np.testing.assert_allclose(scen, exp, rtol=2e-6, atol=0, equal_nan=True)
+    assert np.isfinite(scen).mean() > 0.5
+
+
 def test_synthetic_matches_oracle(dev):
     T, C = 400, 777
     base = osynth.seasonal_base(T)

@@ -89,6 +89,123 @@ k_eqm_adjust(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, co
   }
 }
 
+// ---- adjust, interp = "cubic" ----------------------------------------------------------------------------------
+// scipy.interpolate.interp1d(kind="cubic") = interpolating cubic spline with not-a-knot end conditions
+// (make_interp_spline(k=3)).  Restated in its classical form: second derivatives M_i from the tridiagonal system
+//   h_{i-1} M_{i-1} + 2 (h_{i-1} + h_i) M_i + h_i M_{i+1} = 6 (d_i - d_{i-1}),   d_i = (y_{i+1} - y_i) / h_i,
+// with M_0 and M_{m-1} eliminated through the not-a-knot conditions (continuous third derivative at x_1 and x_{m-2}).
+// Everything in fp64 like scipy (which converts the float32 nodes first); the value is rounded to fp32 once.
+// Set-up kernel: one lane per cell drops the NaN nodes, solves the system (Thomas) in a (rows, C) fp64 workspace
+// (coalesced across lanes) and leaves x, y, M per node; fewer than 4 valid nodes -> count 0 (result NaN).
+__global__ void __launch_bounds__(XH_BLOCK)
+k_cubic_setup(const float* __restrict__ af, const float* __restrict__ hq, int nq, int64_t C, double* __restrict__ wx,
+              double* __restrict__ wy, double* __restrict__ wM, double* __restrict__ wc, int32_t* __restrict__ wm) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  int m = 0;
+  for (int j = 0; j < nq; ++j) {
+    const float xj = hq[(int64_t)j * C + c], yj = af[(int64_t)j * C + c];
+    if (xj == xj && yj == yj) {
+      wx[(int64_t)m * C + c] = (double)xj;
+      wy[(int64_t)m * C + c] = (double)yj;
+      m++;
+    }
+  }
+  for (int j = m; j < nq; ++j) {
+    wx[(int64_t)j * C + c] = __longlong_as_double(0x7FF0000000000000LL);  // +inf: never selected
+    wy[(int64_t)j * C + c] = 0.0;
+    wM[(int64_t)j * C + c] = 0.0;
+  }
+  if (m < 4) { wm[c] = 0; return; }
+  wm[c] = m;
+  auto X = [&](int i) { return wx[(int64_t)i * C + c]; };
+  auto Y = [&](int i) { return wy[(int64_t)i * C + c]; };
+  auto H = [&](int i) { return X(i + 1) - X(i); };
+  auto D = [&](int i) { return (Y(i + 1) - Y(i)) / H(i); };
+  // forward sweep over the unknowns M_1 .. M_{m-2}
+  double cp_prev = 0.0, rp_prev = 0.0;
+  for (int i = 1; i <= m - 2; ++i) {
+    const double hm = H(i - 1), hi = H(i);
+    double a = hm, b = 2.0 * (hm + hi), cc = hi;
+    const double r = 6.0 * (D(i) - D(i - 1));
+    if (i == 1) {  // M_0 = ((h_0 + h_1) M_1 - h_0 M_2) / h_1
+      b += hm * (hm + hi) / hi;
+      cc -= hm * hm / hi;
+      a = 0.0;
+    }
+    if (i == m - 2) {  // M_{m-1} = ((h_{m-2} + h_{m-3}) M_{m-2} - h_{m-2} M_{m-3}) / h_{m-3}
+      a -= hi * hi / hm;
+      b += hi * (hi + hm) / hm;
+      cc = 0.0;
+    }
+    const double den = b - a * cp_prev;
+    cp_prev = cc / den;
+    rp_prev = (r - a * rp_prev) / den;
+    wc[(int64_t)i * C + c] = cp_prev;
+    wM[(int64_t)i * C + c] = rp_prev;
+  }
+  // back substitution
+  double Mn = wM[(int64_t)(m - 2) * C + c];
+  for (int i = m - 3; i >= 1; --i) {
+    Mn = wM[(int64_t)i * C + c] - wc[(int64_t)i * C + c] * Mn;
+    wM[(int64_t)i * C + c] = Mn;
+  }
+  {
+    const double h0 = H(0), h1 = H(1), M1 = wM[(int64_t)1 * C + c], M2 = wM[(int64_t)2 * C + c];
+    wM[c] = ((h0 + h1) * M1 - h0 * M2) / h1;
+    const double ha = H(m - 2), hb = H(m - 3), Ma = wM[(int64_t)(m - 2) * C + c], Mb = wM[(int64_t)(m - 3) * C + c];
+    wM[(int64_t)(m - 1) * C + c] = ((ha + hb) * Ma - ha * Mb) / hb;
+  }
+}
+
+template <int NQMAX>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_eqm_adjust_cubic(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, const double* __restrict__ wx,
+                   const double* __restrict__ wy, const double* __restrict__ wM, const int32_t* __restrict__ wm, int nq,
+                   int kind, int extrap, float* __restrict__ scen, int64_t scen_st) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  double xn[NQMAX], yn[NQMAX], Mn[NQMAX];
+  const int m = wm[c];
+#pragma unroll
+  for (int j = 0; j < NQMAX; ++j) {
+    const bool in = j < nq;
+    xn[j] = in ? wx[(int64_t)j * C + c] : __longlong_as_double(0x7FF0000000000000LL);
+    yn[j] = in ? wy[(int64_t)j * C + c] : 0.0;
+    Mn[j] = in ? wM[(int64_t)j * C + c] : 0.0;
+  }
+  double xlast = xn[0], ylast = yn[0];
+#pragma unroll
+  for (int j = 1; j < NQMAX; ++j) {
+    const bool v = j < m;
+    xlast = v ? xn[j] : xlast;
+    ylast = v ? yn[j] : ylast;
+  }
+  const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
+  int64_t ta = (int64_t)blockIdx.y * chunk, tb = ta + chunk;
+  if (tb > T) tb = T;
+  for (int64_t t = ta; t < tb; ++t) {
+    const float xs = sim[t * st + c];
+    float a = xh_nan32();
+    if (m >= 4 && xs == xs) {
+      const double x = (double)xs;
+      double xi = xn[0], yi = yn[0], Mi = Mn[0], x1 = xn[1], y1 = yn[1], M1 = Mn[1];
+#pragma unroll
+      for (int j = 1; j < NQMAX - 1; ++j) {
+        const bool take = (x >= xn[j]) && (j <= m - 2);
+        xi = take ? xn[j] : xi; yi = take ? yn[j] : yi; Mi = take ? Mn[j] : Mi;
+        x1 = take ? xn[j + 1] : x1; y1 = take ? yn[j + 1] : y1; M1 = take ? Mn[j + 1] : M1;
+      }
+      const double h = x1 - xi, tt = x - xi, d = (y1 - yi) / h;
+      double S = yi + tt * (d - h * (2.0 * Mi + M1) / 6.0) + tt * tt * (Mi * 0.5) + tt * tt * tt * ((M1 - Mi) / (6.0 * h));
+      if (x < xn[0]) S = extrap == 0 ? yn[0] : xh_nan64();
+      if (x > xlast) S = extrap == 0 ? ylast : xh_nan64();
+      a = (float)S;
+    }
+    scen[t * scen_st + c] = kind == 0 ? (xs + a) : (xs * a);
+  }
+}
+
 static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
                                 const double* d_q, int nq, float* out) {
   if (st == 1 && sc >= T) {
@@ -185,7 +302,7 @@ int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   XH_REQUIRE(T >= 0 && C >= 0 && nq >= 1 && nq <= 64, XH_ERR_ARG, "xh_eqm_adjust: bad shape (1 <= nq <= 64)");
   XH_REQUIRE(sc == 1 && st >= C && scen_st >= C, XH_ERR_LAYOUT, "xh_eqm_adjust: needs time-major views (sc == 1)");
   XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "xh_eqm_adjust: kind must be 0 (+) or 1 (*)");
-  XH_REQUIRE(interp == 0 || interp == 1, XH_ERR_ARG, "xh_eqm_adjust: interp must be 0 (nearest) or 1 (linear)");
+  XH_REQUIRE(interp >= 0 && interp <= 2, XH_ERR_ARG, "xh_eqm_adjust: interp must be 0 (nearest), 1 (linear) or 2 (cubic)");
   XH_REQUIRE(extrap == 0 || extrap == 1, XH_ERR_ARG, "xh_eqm_adjust: extrap must be 0 (constant) or 1 (nan)");
   if (T == 0 || C == 0) return XH_OK;
   int64_t cblocks = cdiv64(C, XH_BLOCK);
@@ -195,6 +312,26 @@ int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   if (gy > T) gy = T;
   if (gy > 1024) gy = 1024;
   dim3 grid((unsigned)cblocks, (unsigned)gy);
+  if (interp == 2) {
+    XH_REQUIRE(nq <= 32, XH_ERR_LIMIT, "xh_eqm_adjust: cubic interpolation supports at most 32 quantile nodes (got %d)", nq);
+    // workspace: x, y, M, c' as (nq, C) float64 + the valid-node count per cell
+    const size_t plane = sizeof(double) * (size_t)nq * (size_t)C;
+    void* ws = nullptr;
+    int rc = xh_big_scratch(ctx, 4 * plane + sizeof(int32_t) * (size_t)C, &ws);
+    if (rc) return rc;
+    double *wx = (double*)ws, *wy = wx + (size_t)nq * C, *wM = wy + (size_t)nq * C, *wc = wM + (size_t)nq * C;
+    int32_t* wm = (int32_t*)(wc + (size_t)nq * C);
+    hipLaunchKernelGGL(k_cubic_setup, dim3((unsigned)cblocks), dim3(XH_BLOCK), 0, ctx->stream, af, hist_q, nq, C, wx, wy, wM, wc,
+                       wm);
+    if (nq <= 20)
+      hipLaunchKernelGGL((k_eqm_adjust_cubic<20>), grid, dim3(XH_BLOCK), 0, ctx->stream, sim, T, C, st, wx, wy, wM, wm, nq, kind,
+                         extrap, scen, scen_st);
+    else
+      hipLaunchKernelGGL((k_eqm_adjust_cubic<32>), grid, dim3(XH_BLOCK), 0, ctx->stream, sim, T, C, st, wx, wy, wM, wm, nq, kind,
+                         extrap, scen, scen_st);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+  }
 #define XH_ADJ(NQM, IP)                                                                                              \
   hipLaunchKernelGGL((k_eqm_adjust<NQM, IP>), grid, dim3(XH_BLOCK), 0, ctx->stream, sim, T, C, st, af, hist_q, nq, kind, \
                      extrap, scen, scen_st)

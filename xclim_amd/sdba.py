@@ -61,8 +61,8 @@ class EmpiricalQuantileMapping:
         return cls(dev, af, hq, q, kind, cell_shape)
 
     def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", keep=False):
-        if interp not in ("nearest", "linear"):
-            raise NotImplementedError(f"interp={interp!r} (cubic is not supported)")
+        if interp not in ("nearest", "linear", "cubic"):
+            raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
         s, cell_shape = _flatten(sim, self._dev)
         if tuple(cell_shape) != self.cell_shape:
             raise ValueError("sim does not match the trained grid")
