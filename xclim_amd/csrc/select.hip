@@ -540,199 +540,6 @@ int xh_select_time_major(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
   return launch_select_grp<true>(ctx, x, T, C, st, d_q, nq, out, out_cstride, out_qstride);
 }
 
-// ---- long series: one workgroup per column, tuned critical path --------------------------------------------------
-// Same algorithm as k_select_quantile with the serial part of every column shortened: (n, kmin, kmax) reduced in one
-// pass, the NEXT column's samples prefetched into registers while the current one is processed, a single offsets array
-// (after the scatter cursor[b] is the END of bin b), and in-register selection inside small bins.
-template <int NT, int KPL, int NB>
-__global__ void __launch_bounds__(NT)
-k_select_block(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col_stride, const double* __restrict__ qs,
-               int nq, float* __restrict__ out, int64_t out_cstride, int64_t out_qstride) {
-  extern __shared__ uint32_t lds[];
-  constexpr int BPT = NB / NT;
-  constexpr int NW = NT / 64;
-  const int gt = threadIdx.x;
-  const int lane = gt & 63, w = gt >> 6;
-  const int Tpad = (int)((T + 63) & ~(int64_t)63);
-  uint32_t* sorted = lds;                 // [Tpad]
-  uint32_t* cur = sorted + Tpad;          // [NB]
-  float* vals = reinterpret_cast<float*>(cur + NB);  // [128]
-  uint32_t* red = reinterpret_cast<uint32_t*>(vals + 128);  // [3 * NW + NW]
-
-  float raw[KPL];
-  auto issue_loads = [&](int64_t col) {
-#pragma unroll
-    for (int k = 0; k < KPL; ++k) {
-      int i = gt + k * NT;
-      raw[k] = (col < ncols && i < T) ? x[col * col_stride + i] : xh_nan32();
-    }
-  };
-  int64_t col = blockIdx.x;
-  if (col < ncols) issue_loads(col);
-  for (; col < ncols; col += gridDim.x) {
-    uint32_t key[KPL];
-    uint32_t nv = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
-#pragma unroll
-    for (int k = 0; k < KPL; ++k) {
-      uint32_t kk = xh_f2key(raw[k]);
-      key[k] = kk;
-      bool ok = kk != 0xFFFFFFFFu;
-      nv += ok ? 1u : 0u;
-      kmin = (ok && kk < kmin) ? kk : kmin;
-      kmax = (ok && kk > kmax) ? kk : kmax;
-    }
-    if (col + gridDim.x < ncols) issue_loads(col + gridDim.x);
-    // one-pass reduction of (n, kmin, kmax)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      nv += __shfl_xor(nv, off, 64);
-      uint32_t a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
-      kmin = a < kmin ? a : kmin;
-      kmax = b > kmax ? b : kmax;
-    }
-    if (lane == 0) { red[w] = nv; red[NW + w] = kmin; red[2 * NW + w] = kmax; }
-#pragma unroll
-    for (int b = 0; b < BPT; ++b) cur[gt + b * NT] = 0;
-    __syncthreads();
-    uint32_t n = 0;
-    kmin = 0xFFFFFFFFu; kmax = 0u;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      n += red[i];
-      kmin = red[NW + i] < kmin ? red[NW + i] : kmin;
-      kmax = red[2 * NW + i] > kmax ? red[2 * NW + i] : kmax;
-    }
-    const uint32_t range = n > 0 ? kmax - kmin : 0u;
-    int shift = 32 - __clz((int)range) - (31 - __clz(NB));
-    shift = (range == 0u || shift < 0) ? 0 : shift;
-#pragma unroll
-    for (int k = 0; k < KPL; ++k)
-      if (key[k] != 0xFFFFFFFFu) atomicAdd(&cur[(key[k] - kmin) >> shift], 1u);
-    __syncthreads();
-    {
-      uint32_t loc[BPT], s = 0;
-#pragma unroll
-      for (int b = 0; b < BPT; ++b) { loc[b] = cur[gt * BPT + b]; s += loc[b]; }
-      uint32_t incl = s;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        uint32_t o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
-      }
-      if (lane == 63) red[3 * NW + w] = incl;
-      __syncthreads();
-      uint32_t add = 0;
-      for (int i = 0; i < w; ++i) add += red[3 * NW + i];
-      uint32_t run = incl - s + add;
-#pragma unroll
-      for (int b = 0; b < BPT; ++b) { cur[gt * BPT + b] = run; run += loc[b]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k0 = 0; k0 < KPL; k0 += 8) {
-      uint32_t pos[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (k0 + k < KPL) pos[k] = (key[k0 + k] != 0xFFFFFFFFu) ? atomicAdd(&cur[(key[k0 + k] - kmin) >> shift], 1u) : 0u;
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (k0 + k < KPL && key[k0 + k] != 0xFFFFFFFFu) sorted[pos[k]] = key[k0 + k];
-    }
-    __syncthreads();
-    for (int tgt = gt; tgt < 2 * nq; tgt += NT) {
-      const int j = tgt >> 1;
-      float v = xh_nan32();
-      if (n >= 1) {
-        int r;
-        if (T == 1 || n < 2) r = 0;
-        else {
-          double nn = (double)n, q = qs[j];
-          double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;  // utl:395 with alpha = beta = 1
-          if (vi >= nn - 1.0) r = (int)n - 1;
-          else if (vi < 0.0) r = 0;
-          else r = (int)floor(vi) + (tgt & 1);
-        }
-        int lo = -1, hi = NB - 1;  // invariant: end[lo] <= r < end[hi]
-        while (hi - lo > 1) {
-          int mid = (lo + hi) >> 1;
-          if (cur[mid] <= (uint32_t)r) lo = mid; else hi = mid;
-        }
-        const uint32_t s0 = hi > 0 ? cur[hi - 1] : 0u, s1 = cur[hi];
-        const uint32_t kth = (uint32_t)r - s0, m = s1 - s0;
-        uint32_t ans;
-        if (m <= 8) {
-          uint32_t kk[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) kk[i] = (uint32_t)i < m ? sorted[s0 + i] : 0xFFFFFFFFu;
-          ans = kk[0];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            uint32_t less = 0, leq = 0;
-#pragma unroll
-            for (int i2 = 0; i2 < 8; ++i2) {
-              less += kk[i2] < kk[i] ? 1u : 0u;
-              leq += kk[i2] <= kk[i] ? 1u : 0u;
-            }
-            ans = (less <= kth && kth < leq) ? kk[i] : ans;
-          }
-        } else {
-          ans = sorted[s0];
-          for (uint32_t a = s0; a < s1; ++a) {
-            uint32_t e = sorted[a], less = 0, leq = 0;
-            for (uint32_t b2 = s0; b2 < s1; ++b2) {
-              uint32_t k2 = sorted[b2];
-              less += k2 < e ? 1u : 0u;
-              leq += k2 <= e ? 1u : 0u;
-            }
-            if (less <= kth && kth < leq) { ans = e; break; }
-            if (less == 0 && leq == m) { ans = e; break; }
-          }
-        }
-        v = xh_key2f(ans);
-      }
-      vals[tgt] = v;
-    }
-    __syncthreads();
-    for (int j = gt; j < nq; j += NT) {
-      double r;
-      if (n == 0) r = xh_nan64();
-      else if (T == 1 || n < 2) r = (double)vals[2 * j];
-      else {
-        double nn = (double)n, q = qs[j];
-        double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;
-        float left = vals[2 * j], right = vals[2 * j + 1];
-        if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
-        else {
-          double gamma = vi - floor(vi);
-          float diff = right - left;
-          r = (double)left + (double)diff * gamma;
-          if (gamma >= 0.5) r = (double)right - (double)diff * (1.0 - gamma);
-        }
-      }
-      out[col * out_cstride + (int64_t)j * out_qstride] = (float)r;
-    }
-    __syncthreads();
-  }
-}
-
-template <int NT, int KPL, int NB>
-static int launch_select_block(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride,
-                               const double* d_q, int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
-  int Tpad = (int)((T + 63) & ~(int64_t)63);
-  size_t lds = (size_t)(Tpad + NB + 128 + 4 * (NT / 64) + 8) * sizeof(uint32_t);
-  XH_REQUIRE(lds <= 160 * 1024, XH_ERR_LIMIT, "quantile_series: LDS need %zu exceeds 160 KiB", lds);
-  auto kern = k_select_block<NT, KPL, NB>;
-  if (lds > 64 * 1024)
-    XH_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int64_t nblk = ncols;
-  int64_t maxblk = (int64_t)ctx->num_cu * 8;
-  if (nblk > maxblk) nblk = maxblk;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, ctx->stream, xcols, T, ncols, col_stride, d_q, nq, out,
-                     out_cstride, out_qstride);
-  XH_LAUNCH_CHECK();
-  return XH_OK;
-}
-
 template <int NT, int KPL, int NB>
 static int launch_select(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const double* d_q,
                          int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
@@ -758,18 +565,15 @@ int xh_select_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols,
                       int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
   XH_REQUIRE(nq <= 64, XH_ERR_LIMIT, "quantile_series: at most 64 quantiles");
   if (T <= 512) return launch_select_grp<false>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
-  // longer series: one workgroup per column.  The whole column lives in LDS (sorted[T]), which allows only 1-3
-  // workgroups per CU, so the workgroup is made as wide as the series allows (1024 threads = 16 waves) to keep
-  // enough waves resident to hide the LDS-atomic and HBM latencies.
+  // 512 < T <= 1024: one WAVE per column with the column in LDS (the per-column fixed costs of a whole workgroup are
+  // 3x slower here: measured 11.1 vs 3.55 ms at T = 800, 1 036 800 columns)
   if (T <= 1024) return launch_select<64, 16, 512>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
+  // longer series: one workgroup per column, keys in registers, list-free selection (select2.hip)
   {
     int rc_lean = xh_select_columns_lean(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
     if (rc_lean != XH_ERR_NOTIMPL) return rc_lean;
   }
-  if (T <= 2048) return launch_select_block<256, 8, 1024>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
-  if (T <= 4096) return launch_select_block<256, 16, 1024>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
-  if (T <= 8192) return launch_select_block<512, 16, 2048>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
-  if (T <= 16384) return launch_select_block<512, 32, 4096>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
+  // T > 16384: the whole column lives in LDS (sorted[T]), 1024-thread workgroups
   XH_REQUIRE(T <= 32768, XH_ERR_LIMIT, "quantile_series: T = %lld exceeds the 32768-sample column limit", (long long)T);
   return launch_select<1024, 32, 2048>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
 }
