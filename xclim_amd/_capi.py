@@ -147,14 +147,15 @@ def device_count() -> int:
 class DeviceArray:
     """A typed device buffer owned by a :class:`Device` (hipMalloc'd through xh_malloc)."""
 
-    __slots__ = ("dev", "ptr", "shape", "dtype", "_owner")
+    __slots__ = ("dev", "ptr", "shape", "dtype", "_owner", "_alloc")
 
-    def __init__(self, dev: "Device", ptr: int, shape, dtype, owner=True):
+    def __init__(self, dev: "Device", ptr: int, shape, dtype, owner=True, alloc: int = 0):
         self.dev = dev
         self.ptr = ptr
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
         self._owner = owner
+        self._alloc = int(alloc)  # bytes obtained from xh_malloc (0: foreign / view); lets free() hand it to the pool
 
     @property
     def size(self) -> int:
@@ -185,8 +186,7 @@ class DeviceArray:
 
     def free(self):
         if self._owner is True and self.ptr and self.dev is not None and self.dev.ctx:
-            lib = self.dev.lib
-            lib.xh_free(self.dev.ctx, _vp(self.ptr))
+            self.dev._release(self.ptr, self._alloc)
         self.ptr = 0
         self._owner = False
 
@@ -207,14 +207,45 @@ class Device:
         self.ctx = ctx
         self.index = device
         self.lock = threading.RLock()
+        # Freed buffers are kept per exact size and handed out again: hipMalloc / hipFree cost ~0.1-0.4 ms each and
+        # hipFree synchronises the device, which is as long as a whole kernel of this library.  Re-use is safe because
+        # every kernel of a context runs on its one stream (stream order protects a buffer that is still being read).
+        self._pool: dict[int, list[int]] = {}
+        self._pool_bytes = 0
+        self._pool_cap = int(os.environ.get("XCLIM_AMD_POOL_BYTES", str(32 << 30)))
 
     # ---- memory ----
     def empty(self, shape, dtype) -> DeviceArray:
         shape = (shape,) if np.isscalar(shape) else tuple(shape)
-        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        nbytes = max(int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize, 16)
+        with self.lock:
+            free = self._pool.get(nbytes)
+            if free:
+                self._pool_bytes -= nbytes
+                return DeviceArray(self, free.pop(), shape, dtype, alloc=nbytes)
         p = _vp()
-        _check(self.lib, self.lib.xh_malloc(self.ctx, max(nbytes, 16), C.byref(p)))
-        return DeviceArray(self, p.value, shape, dtype)
+        rc = self.lib.xh_malloc(self.ctx, nbytes, C.byref(p))
+        if rc != XH_OK and self._pool_bytes:
+            self.trim()  # out of memory with buffers parked in the pool: give them back and retry once
+            rc = self.lib.xh_malloc(self.ctx, nbytes, C.byref(p))
+        _check(self.lib, rc)
+        return DeviceArray(self, p.value, shape, dtype, alloc=nbytes)
+
+    def _release(self, ptr: int, nbytes: int) -> None:
+        with self.lock:
+            if nbytes and self._pool_bytes + nbytes <= self._pool_cap and len(self._pool.get(nbytes, ())) < 8:
+                self._pool.setdefault(nbytes, []).append(ptr)
+                self._pool_bytes += nbytes
+                return
+        self.lib.xh_free(self.ctx, _vp(ptr))
+
+    def trim(self) -> None:
+        """Return every pooled buffer to the driver."""
+        with self.lock:
+            pool, self._pool, self._pool_bytes = self._pool, {}, 0
+        for ptrs in pool.values():
+            for ptr in ptrs:
+                self.lib.xh_free(self.ctx, _vp(ptr))
 
     def zeros(self, shape, dtype) -> DeviceArray:
         a = self.empty(shape, dtype)
@@ -259,6 +290,7 @@ class Device:
 
     def close(self):
         if self.ctx:
+            self.trim()
             self.lib.xh_destroy(self.ctx)
             self.ctx = None
 
