@@ -4,6 +4,7 @@
 // 64*VEC*4 contiguous bytes per time step (1 KiB at VEC = 4).  Periods (resample segments) are mapped to
 // blockIdx.y so that P periods give P-fold more workgroups.  All kernels are HBM-bound.
 #include "common.h"
+#include "window.h"
 
 // ---- threshold_count ------------------------------------------------------------------------------
 // Reference: threshold_count (indices/generic.py:329-361) + compare (gen:301-326) + resample.sum, fused
@@ -432,6 +433,10 @@ int xh_rolling_reduce(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t
   // xarray: center=True -> window covers [t - w//2, t + w - 1 - w//2]; else trailing [t - w + 1, t]
   int left = center ? window / 2 : window - 1;
   int right = window - 1 - left;
+  {  // windows of up to 8 steps: register ring, every row read once (window.hip)
+    int rr = xh_launch_rolling_ring(ctx, x, T, C, st, window, left, right, reducer, out, out_st);
+    if (rr != XH_ERR_NOTIMPL) return rr;
+  }
   unsigned ny = (unsigned)(T < 64 ? T : 64);
   dim3 grid((unsigned)cdiv64(C, XH_BLOCK), ny);
 #define XH_RO(R)                                                                                                      \

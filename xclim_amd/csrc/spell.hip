@@ -4,6 +4,7 @@
 // (keep_longest_run), 891-1145 (season_start / season_end / season / season_length), 491-540 (windowed_max_run_sum).
 // Same layout as runlen.hip: time-major (T, C), one lane per cell marching along time, periods on blockIdx.y.
 #include "common.h"
+#include "window.h"
 
 // ---- spell_mask ------------------------------------------------------------------------------------------
 // A day is in a spell iff it belongs to ANY window of `window` consecutive days whose statistic satisfies the
@@ -325,6 +326,10 @@ static int spell_mask_impl(xh_ctx* ctx, const char* fn, const float* const* xs, 
     int rc = xh_scratch_upload(ctx, &cur, weights, sizeof(float) * (size_t)window, &d);
     if (rc) return rc;
     d_w = (const float*)d;
+  }
+  if (nvar == 1) {  // one variable, window <= 8: register ring (window.hip)
+    int rr = xh_launch_spell_ring(ctx, xs[0], T, C, st, window, win_reducer, op, (float)thrs[0], d_w, out, out_st);
+    if (rr != XH_ERR_NOTIMPL) return rr;
   }
   SpellVars vars;
   for (int i = 0; i < 8; ++i) {

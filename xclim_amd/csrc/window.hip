@@ -1,0 +1,229 @@
+// window.hip — rolling-window kernels with the window in a REGISTER ring (window <= 8 time steps).
+//
+//   k_rolling_ring   select_rolling_resample_op's rolling step (indices/generic.py:128-174): da.rolling(time=w, center)
+//   k_spell_ring     spell_mask for one variable (indices/generic.py:434-540)
+// The generic kernels (reduce.hip: k_rolling_reduce, spell.hip: k_spell_mask) re-read the window from L2 at every step
+// (w dependent loads per output); here every input row is loaded exactly once, in double-buffered batches of 8 rows
+// (xh_march_rows), shifted through ring[WMAX] and reduced in registers in the SAME order (oldest -> newest, fp64
+// accumulation) so the results are bit-identical to the generic kernels.  A lane owns VEC consecutive cells; the time
+// axis is cut into chunks over blockIdx.y, each chunk re-reads its (w - 1)-row halo.
+#include "common.h"
+#include "window.h"
+
+namespace {
+
+constexpr int WMAX = 8;
+
+template <int VEC>
+struct Ring {
+  float v[VEC][WMAX];
+  __device__ __forceinline__ void fill_nan() {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+#pragma unroll
+      for (int k = 0; k < WMAX; ++k) v[i][k] = xh_nan32();
+  }
+  __device__ __forceinline__ void push(const VecF<VEC>& x) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+#pragma unroll
+      for (int k = 0; k < WMAX - 1; ++k) v[i][k] = v[i][k + 1];
+      v[i][WMAX - 1] = x.v[i];
+    }
+  }
+};
+
+// statistic of the last `w` ring entries (oldest first).  RED: XH_RED_* ; returns NaN when any entry is NaN (xarray
+// rolling with min_periods = window), except COUNT (number of valid entries).
+template <int RED>
+__device__ __forceinline__ float ring_stat(const float (&r)[WMAX], int w, const float* wts) {
+  double s = 0.0;
+  float e = 0.f;
+  bool nan = false, first = true;
+  int n = 0;
+#pragma unroll
+  for (int k = 0; k < WMAX; ++k) {
+    if (k >= WMAX - w) {  // uniform predicate
+      const float x = r[k];
+      nan |= (x != x);
+      n += (x == x) ? 1 : 0;
+      if (RED == XH_RED_MIN) e = (first || x < e) ? x : e;
+      else if (RED == XH_RED_MAX) e = (first || x > e) ? x : e;
+      else if (RED == 100) s += (double)x * (double)wts[k];  // weighted mean (spell_mask weights)
+      else s += (double)x;
+      first = false;
+    }
+  }
+  if (RED == XH_RED_COUNT) return (float)n;
+  float out;
+  if (RED == XH_RED_MIN || RED == XH_RED_MAX) out = e;
+  else if (RED == XH_RED_MEAN) out = (float)(s / (double)w);
+  else if (RED == XH_RED_SUM || RED == 100) out = (float)s;
+  else {  // var / std: two passes over the registers, population (ddof = 0)
+    const double m = s / (double)w;
+    double s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < WMAX; ++k)
+      if (k >= WMAX - w) { const double d = (double)r[k] - m; s2 += d * d; }
+    out = (RED == XH_RED_VAR) ? (float)(s2 / (double)w) : (float)sqrt(s2 / (double)w);
+  }
+  return nan ? xh_nan32() : out;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&r)[VEC]) {
+  if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+  else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p[i] = r[i];
+  }
+}
+
+template <int VEC, int RED>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_rolling_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w, int left, int right,
+               float* __restrict__ out, int64_t out_st) {
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
+  const int64_t ta = (int64_t)blockIdx.y * chunk;
+  int64_t tb = ta + chunk;
+  if (tb > T) tb = T;
+  if (ta >= tb) return;
+  Ring<VEC> ring;
+  ring.fill_nan();
+  // rows needed: [ta - left, tb - 1 + right] clipped to [0, T); a row tp completes the window of t = tp - right
+  const int64_t r0 = ta - left < 0 ? 0 : ta - left;
+  const int64_t r1 = tb + right > T ? T : tb + right;
+  auto emit = [&](int64_t tp) {
+    const int64_t t = tp - right;
+    if (t < ta || t >= tb) return;
+    float r[VEC];
+    const bool whole = (t - left >= 0) && (t + right < T);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float s = ring_stat<RED>(ring.v[i], w, nullptr);
+      r[i] = (RED == XH_RED_COUNT || whole) ? s : xh_nan32();
+    }
+    store_vec<VEC>(out + t * out_st + c, r);
+  };
+  xh_march_rows<VEC, 8>(x + c, st, r0, r1, [&](int64_t tp, const VecF<VEC>& xv) {
+    ring.push(xv);
+    emit(tp);
+  });
+  // windows that reach past the end of the series: NaN rows keep sliding in
+  VecF<VEC> nanrow;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) nanrow.v[i] = xh_nan32();
+  for (int64_t tp = r1; tp < tb + right; ++tp) {
+    ring.push(nanrow);
+    emit(tp);
+  }
+}
+
+// out[t] = any cond[t'] for t' in [t, t + w - 1], cond[t'] = stat(x[t'-w+1 .. t']) op thr (False for incomplete / NaN windows)
+template <int VEC, int RED>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w, int op, float thr,
+             const float* __restrict__ weights, float* __restrict__ out, int64_t out_st) {
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
+  const int64_t ta = (int64_t)blockIdx.y * chunk;
+  int64_t tb = ta + chunk;
+  if (tb > T) tb = T;
+  if (ta >= tb) return;
+  float wts[WMAX];
+#pragma unroll
+  for (int k = 0; k < WMAX; ++k) wts[k] = (RED == 100 && k >= WMAX - w) ? weights[k - (WMAX - w)] : 0.f;
+  Ring<VEC> ring;
+  ring.fill_nan();
+  int64_t last_true[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) last_true[i] = -1;
+  // outputs t in [ta, tb) need cond[t'] for t' in [ta, tb + w - 2], i.e. rows [ta - (w - 1), tb + w - 2]
+  const int64_t r0 = ta - (w - 1) < 0 ? 0 : ta - (w - 1);
+  const int64_t r1 = tb + w - 1 > T ? T : tb + w - 1;
+  auto emit = [&](int64_t tp, bool have_row) {
+    float r[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      bool cond = false;
+      if (have_row && tp >= w - 1) {
+        const float s = ring_stat<RED>(ring.v[i], w, wts);
+        cond = (s == s) && xh_cmp_f32(s, op, thr);
+      }
+      if (cond) last_true[i] = tp;
+      r[i] = (last_true[i] >= tp - (w - 1)) ? 1.0f : 0.0f;
+    }
+    const int64_t t = tp - (w - 1);
+    if (t >= ta && t < tb) store_vec<VEC>(out + t * out_st + c, r);
+  };
+  xh_march_rows<VEC, 8>(x + c, st, r0, r1, [&](int64_t tp, const VecF<VEC>& xv) {
+    ring.push(xv);
+    emit(tp, true);
+  });
+  for (int64_t tp = r1; tp < tb + w - 1; ++tp) emit(tp, false);
+}
+
+static dim3 window_grid(xh_ctx* ctx, int64_t T, int64_t C, int vec) {
+  const int64_t cblocks = cdiv64(cdiv64(C, vec), XH_BLOCK);
+  int64_t gy = cdiv64((int64_t)ctx->num_cu * 12, cblocks);
+  if (gy < 1) gy = 1;
+  if (gy > cdiv64(T, 32)) gy = cdiv64(T, 32);  // chunks of at least 32 steps: the halo stays below 25 %
+  if (gy < 1) gy = 1;
+  return dim3((unsigned)cblocks, (unsigned)gy);
+}
+
+}  // namespace
+
+int xh_launch_rolling_ring(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int window, int left, int right,
+                           int reducer, float* out, int64_t out_st) {
+  if (window > WMAX) return XH_ERR_NOTIMPL;
+  const int vec = (xh_pick_vec(x, C, st) == 4 && xh_pick_vec(out, C, out_st) == 4) ? 4 : 1;
+  const dim3 grid = window_grid(ctx, T, C, vec);
+#define XH_RR(R)                                                                                                          \
+  case R:                                                                                                                 \
+    if (vec == 4)                                                                                                         \
+      hipLaunchKernelGGL((k_rolling_ring<4, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, left, right, out, \
+                         out_st);                                                                                         \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((k_rolling_ring<1, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, left, right, out, \
+                         out_st);                                                                                         \
+    break;
+  switch (reducer) {
+    XH_RR(XH_RED_SUM) XH_RR(XH_RED_MEAN) XH_RR(XH_RED_MIN) XH_RR(XH_RED_MAX) XH_RR(XH_RED_STD) XH_RR(XH_RED_VAR)
+    XH_RR(XH_RED_COUNT)
+    default:
+      return XH_ERR_NOTIMPL;
+  }
+#undef XH_RR
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_launch_spell_ring(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int window, int win_red, int op,
+                         float thr, const float* d_weights, float* out, int64_t out_st) {
+  if (window > WMAX) return XH_ERR_NOTIMPL;
+  const int vec = (xh_pick_vec(x, C, st) == 4 && xh_pick_vec(out, C, out_st) == 4) ? 4 : 1;
+  const dim3 grid = window_grid(ctx, T, C, vec);
+  // win_red (spell.hip): 0 sum, 1 mean, 2 min, 3 max, 4 weighted mean
+  const int red = win_red == 0 ? XH_RED_SUM : win_red == 1 ? XH_RED_MEAN : win_red == 2 ? XH_RED_MIN : win_red == 3 ? XH_RED_MAX : 100;
+#define XH_SR(R)                                                                                                       \
+  case R:                                                                                                              \
+    if (vec == 4)                                                                                                      \
+      hipLaunchKernelGGL((k_spell_ring<4, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
+                         out, out_st);                                                                                 \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_spell_ring<1, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
+                         out, out_st);                                                                                 \
+    break;
+  switch (red) {
+    XH_SR(XH_RED_SUM) XH_SR(XH_RED_MEAN) XH_SR(XH_RED_MIN) XH_SR(XH_RED_MAX) XH_SR(100)
+    default:
+      return XH_ERR_NOTIMPL;
+  }
+#undef XH_SR
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
