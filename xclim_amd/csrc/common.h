@@ -167,6 +167,34 @@ __device__ __forceinline__ void xh_march_rows(const float* __restrict__ p, int64
   for (; t < t1; ++t) f(t, xh_load<VEC>(p + t * st));
 }
 
+// Same march in REVERSE time order (t1-1 down to t0) for the backward state machines.
+template <int VEC, int U, typename F>
+__device__ __forceinline__ void xh_march_rows_rev(const float* __restrict__ p, int64_t st, int64_t t0, int64_t t1, F&& f) {
+  int64_t t = t1;  // rows [t - U, t) are the next batch
+  int64_t nfull = (t1 - t0) / U;
+  if (nfull > 0) {
+    VecF<VEC> buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = xh_load<VEC>(p + (t - 1 - u) * st);
+    for (int64_t b = 0; b < nfull; ++b) {
+      VecF<VEC> nxt[U];
+      const bool more = b + 1 < nfull;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = xh_load<VEC>(p + (t - U - 1 - u) * st);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) f(t - 1 - u, buf[u]);
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) buf[u] = nxt[u];
+      }
+      t -= U;
+    }
+  }
+  for (t = t - 1; t >= t0; --t) f(t, xh_load<VEC>(p + t * st));
+}
+
 // order-preserving float <-> uint32 key (ascending; NaN maps above +inf so it sorts last like numpy)
 __device__ __forceinline__ uint32_t xh_f2key(float f) {
   uint32_t u = __float_as_uint(f);

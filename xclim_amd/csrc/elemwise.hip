@@ -73,11 +73,13 @@ k_range_reduce(const float* __restrict__ lo, const float* __restrict__ hi, int64
 
 // out_kind 0: uint8 mask (compare)        1: float 1/0, NaN where a is NaN (get_daily_events)
 //          2: float a where the condition holds, NaN elsewhere (da.where(cond))     3: float 1/0 (bool mask as float)
-template <bool F64>
+// A lane owns VEC consecutive cells (16-byte loads / stores when the views are aligned), the time axis is cut into
+// chunks over blockIdx.y.
+template <bool F64, int VEC>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_compare_map(const float* __restrict__ a, int64_t T, int64_t C, int64_t st, int op, double thr, const float* __restrict__ b,
               int64_t st_b, int out_kind, void* __restrict__ out_v, int64_t st_out) {
-  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
   const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
   int64_t ta = (int64_t)blockIdx.y * chunk, tb = ta + chunk;
@@ -85,14 +87,36 @@ k_compare_map(const float* __restrict__ a, int64_t T, int64_t C, int64_t st, int
   const float thr32 = (float)thr;
 #pragma unroll 4
   for (int64_t t = ta; t < tb; ++t) {
-    const float v = a[t * st + c];
-    bool cond;
-    if (b) cond = xh_cmp_f32(v, op, b[t * st_b + c]);
-    else cond = F64 ? xh_cmp_f64((double)v, op, thr) : xh_cmp_f32(v, op, thr32);
-    if (out_kind == 0) reinterpret_cast<uint8_t*>(out_v)[t * st_out + c] = cond ? 1 : 0;
-    else if (out_kind == 1) reinterpret_cast<float*>(out_v)[t * st_out + c] = (v == v) ? (cond ? 1.f : 0.f) : xh_nan32();
-    else if (out_kind == 2) reinterpret_cast<float*>(out_v)[t * st_out + c] = cond ? v : xh_nan32();
-    else reinterpret_cast<float*>(out_v)[t * st_out + c] = cond ? 1.f : 0.f;
+    const VecF<VEC> v = xh_load<VEC>(a + t * st + c);
+    VecF<VEC> w;
+    if (b) w = xh_load<VEC>(b + t * st_b + c);
+    float r[VEC];
+    uint8_t m[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      bool cond;
+      if (b) cond = xh_cmp_f32(v.v[i], op, w.v[i]);
+      else cond = F64 ? xh_cmp_f64((double)v.v[i], op, thr) : xh_cmp_f32(v.v[i], op, thr32);
+      m[i] = cond ? 1 : 0;
+      if (out_kind == 1) r[i] = (v.v[i] == v.v[i]) ? (cond ? 1.f : 0.f) : xh_nan32();
+      else if (out_kind == 2) r[i] = cond ? v.v[i] : xh_nan32();
+      else r[i] = cond ? 1.f : 0.f;
+    }
+    if (out_kind == 0) {
+      uint8_t* o = reinterpret_cast<uint8_t*>(out_v) + t * st_out + c;
+      if (VEC == 4) *reinterpret_cast<uchar4*>(o) = make_uchar4(m[0], m[1 % VEC], m[2 % VEC], m[3 % VEC]);
+      else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = m[i];
+      }
+    } else {
+      float* o = reinterpret_cast<float*>(out_v) + t * st_out + c;
+      if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+      else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = r[i];
+      }
+    }
   }
 }
 
@@ -209,18 +233,27 @@ int xh_compare_map(xh_ctx* ctx, const float* a, int64_t T, int64_t C, int64_t st
   XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
   XH_REQUIRE(out_kind >= 0 && out_kind <= 3, XH_ERR_ARG, "xh_compare_map: out_kind must be 0, 1, 2 or 3");
   if (T == 0 || C == 0) return XH_OK;
-  const int64_t cblocks = cdiv64(C, XH_BLOCK);
+  // 16-byte path: every view aligned (the uint8 output needs 4-byte alignment of its rows)
+  int vec = xh_pick_vec(a, C, st);
+  if (b && xh_pick_vec(b, C, st_b) != 4) vec = 1;
+  if (out_kind == 0) {
+    if ((reinterpret_cast<uintptr_t>(out) & 3) != 0 || (st_out & 3) != 0) vec = 1;
+  } else if (xh_pick_vec((const float*)out, C, st_out) != 4) vec = 1;
+  const int64_t cblocks = cdiv64(cdiv64(C, vec), XH_BLOCK);
   int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
   if (gy < 1) gy = 1;
   if (gy > T) gy = T;
   if (gy > 1024) gy = 1024;
   dim3 grid((unsigned)cblocks, (unsigned)gy);
-  if (thr_is_f64 && !b)
-    hipLaunchKernelGGL((k_compare_map<true>), grid, dim3(XH_BLOCK), 0, ctx->stream, a, T, C, st, op, thr, b, st_b, out_kind, out,
-                       st_out);
-  else
-    hipLaunchKernelGGL((k_compare_map<false>), grid, dim3(XH_BLOCK), 0, ctx->stream, a, T, C, st, op, thr, b, st_b, out_kind,
-                       out, st_out);
+#define XH_CM(F, V)                                                                                                   \
+  hipLaunchKernelGGL((k_compare_map<F, V>), grid, dim3(XH_BLOCK), 0, ctx->stream, a, T, C, st, op, thr, b, st_b, out_kind, \
+                     out, st_out)
+  if (thr_is_f64 && !b) {
+    if (vec == 4) XH_CM(true, 4); else XH_CM(true, 1);
+  } else {
+    if (vec == 4) XH_CM(false, 4); else XH_CM(false, 1);
+  }
+#undef XH_CM
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

@@ -116,49 +116,63 @@ k_keep_longest_run(const float* __restrict__ x, int64_t C, int64_t st, const int
 // end   = first t >= max(start, mid) with `window` consecutive False (runs cut at that lower bound);
 // length: 0 if no start; T - start if no end; else end - start.  Reported end = T-1 when none, NaN when no start.
 // mid_idx[p] < 0 : the date is not in the group -> start NaN (rl:1319-1321) ; mid_idx == INT_MAX-ish : date=None.
+// One forward march per period (rows loaded once, in double-buffered batches), branch-free state machine:
+//   start search while i < limit and no start yet; end search from lb = max(start, mid) on.  The start is known at
+//   i = start + window - 1 >= start, and the steps start .. start + window - 1 are all True, so the end search that
+//   formally begins at lb can be switched on as soon as the start is known without changing its counters.
+template <int VEC>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_season(const float* __restrict__ x, int64_t C, int64_t st, int window, const int64_t* __restrict__ seg_off,
          const int32_t* __restrict__ mid_idx, int has_date, int P, float* __restrict__ start_out,
          float* __restrict__ end_out, float* __restrict__ len_out) {
-  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
   for (int p = blockIdx.y; p < P; p += gridDim.y) {
-    int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
-    int len = (int)(t1 - t0);
-    int mid = has_date ? mid_idx[p] : 0;  // relative to the period start
-    float fs = xh_nan32(), fe = xh_nan32(), fl = 0.0f;
-    if (!(has_date && mid < 0)) {
-      // phase 1: start
-      int limit = has_date ? (mid + window - 1) : len;  // da.where(t < mid + window - 1)
-      if (limit > len) limit = len;
-      int run = 0, beg = -1, ones = 0;
-      for (int i = 0; i < limit; ++i) {
-        bool on = x[(t0 + i) * st + c] > 0.0f;
-        run = on ? run + 1 : 0;
-        ones += on ? 1 : 0;
-        if (run >= window && beg < 0) { beg = i - window + 1; if (window > 1) break; }
+    const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    const int len = (int)(t1 - t0);
+    const int mid = has_date ? mid_idx[p] : 0;  // relative to the period start
+    const bool nodate = has_date && mid < 0;
+    int limit = has_date ? (mid + window - 1) : len;  // da.where(t < mid + window - 1)
+    if (limit > len) limit = len;
+    int run[VEC], beg[VEC], ones[VEC], runf[VEC], end[VEC], onesf[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { run[v] = 0; beg[v] = -1; ones[v] = 0; runf[v] = 0; end[v] = -1; onesf[v] = 0; }
+    xh_march_rows<VEC, 8>(x + c, st, t0, t1, [&](int64_t t, const VecF<VEC>& xv) {
+      const int i = (int)(t - t0);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const bool on = xv.v[v] > 0.0f;
+        // phase 1: start (window == 1 keeps counting the Trues for the argmax == argmin quirk)
+        const bool p1 = i < limit && (beg[v] < 0 || window == 1);
+        run[v] = p1 ? (on ? run[v] + 1 : 0) : run[v];
+        ones[v] += (p1 && on) ? 1 : 0;
+        beg[v] = (p1 && beg[v] < 0 && run[v] >= window) ? i - window + 1 : beg[v];
+        // phase 2: end — window consecutive False at i >= max(beg, mid)
+        const int lb = beg[v] > mid ? beg[v] : mid;
+        const bool p2 = beg[v] >= 0 && i >= lb && (end[v] < 0 || window == 1);
+        const bool off = !on;
+        runf[v] = p2 ? (off ? runf[v] + 1 : 0) : runf[v];
+        onesf[v] += (p2 && off) ? 1 : 0;
+        end[v] = (p2 && end[v] < 0 && runf[v] >= window) ? i - window + 1 : end[v];
       }
-      if (window == 1 && limit == len && ones == len) beg = -1;  // argmax == argmin quirk (rl:603-605)
-      if (beg >= 0) {
-        fs = (float)beg;
-        // phase 2: end — window consecutive False at t >= max(beg, mid)
-        int lb = beg > mid ? beg : mid;
-        int runf = 0, end = -1, onesf = 0;
-        for (int i = lb; i < len; ++i) {
-          bool off = !(x[(t0 + i) * st + c] > 0.0f);
-          runf = off ? runf + 1 : 0;
-          onesf += off ? 1 : 0;
-          if (runf >= window && end < 0) { end = i - window + 1; if (window > 1) break; }
-        }
-        if (window == 1 && lb == 0 && onesf == len) end = -1;
-        fl = end < 0 ? (float)(len - beg) : (float)(end - beg);
-        fe = end < 0 ? (float)(len - 1) : (float)end;
+    });
+    const int64_t o = (int64_t)p * C + c;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float fs = xh_nan32(), fe = xh_nan32(), fl = 0.0f;
+      int b = beg[v], e = end[v];
+      if (window == 1 && limit == len && ones[v] == len) b = -1;  // argmax == argmin quirk (rl:603-605)
+      if (!nodate && b >= 0) {
+        const int lb = b > mid ? b : mid;
+        if (window == 1 && lb == 0 && onesf[v] == len) e = -1;
+        fs = (float)b;
+        fl = e < 0 ? (float)(len - b) : (float)(e - b);
+        fe = e < 0 ? (float)(len - 1) : (float)e;
       }
+      start_out[o + v] = fs;
+      end_out[o + v] = fe;
+      len_out[o + v] = fl;
     }
-    int64_t o = (int64_t)p * C + c;
-    start_out[o] = fs;
-    end_out[o] = fe;
-    len_out[o] = fl;
   }
 }
 
@@ -400,9 +414,14 @@ int xh_season(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int
     if (rc) return rc;
   }
   if (C == 0) return XH_OK;
-  hipLaunchKernelGGL(k_season, dim3((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)), dim3(XH_BLOCK), 0,
-                     ctx->stream, x, C, st, window, d_seg, (const int32_t*)d_mid, mid_idx ? 1 : 0, P, start_out, end_out,
-                     len_out);
+  if (xh_pick_vec(x, C, st) == 4)
+    hipLaunchKernelGGL((k_season<4>), dim3((unsigned)cdiv64(cdiv64(C, 4), XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)),
+                       dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, d_seg, (const int32_t*)d_mid, mid_idx ? 1 : 0, P,
+                       start_out, end_out, len_out);
+  else
+    hipLaunchKernelGGL((k_season<1>), dim3((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)), dim3(XH_BLOCK), 0,
+                       ctx->stream, x, C, st, window, d_seg, (const int32_t*)d_mid, mid_idx ? 1 : 0, P, start_out, end_out,
+                       len_out);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }
