@@ -167,6 +167,35 @@ __device__ __forceinline__ void xh_march_rows(const float* __restrict__ p, int64
   for (; t < t1; ++t) f(t, xh_load<VEC>(p + t * st));
 }
 
+// Two arrays of the same layout marched together (q may alias p).
+template <int VEC, int U, typename F>
+__device__ __forceinline__ void xh_march_rows2(const float* __restrict__ p, const float* __restrict__ q, int64_t st,
+                                               int64_t sq, int64_t t0, int64_t t1, F&& f) {
+  int64_t t = t0;
+  int64_t nfull = (t1 - t0) / U;
+  if (nfull > 0) {
+    VecF<VEC> bp[U], bq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { bp[u] = xh_load<VEC>(p + (t + u) * st); bq[u] = xh_load<VEC>(q + (t + u) * sq); }
+    for (int64_t b = 0; b < nfull; ++b) {
+      VecF<VEC> np[U], nq[U];
+      const bool more = b + 1 < nfull;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { np[u] = xh_load<VEC>(p + (t + U + u) * st); nq[u] = xh_load<VEC>(q + (t + U + u) * sq); }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) f(t + u, bp[u], bq[u]);
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { bp[u] = np[u]; bq[u] = nq[u]; }
+      }
+      t += U;
+    }
+  }
+  for (; t < t1; ++t) f(t, xh_load<VEC>(p + t * st), xh_load<VEC>(q + t * sq));
+}
+
 // Same march in REVERSE time order (t1-1 down to t0) for the backward state machines.
 template <int VEC, int U, typename F>
 __device__ __forceinline__ void xh_march_rows_rev(const float* __restrict__ p, int64_t st, int64_t t0, int64_t t1, F&& f) {

@@ -82,6 +82,54 @@ k_runs_with_holes(const float* __restrict__ a, const float* __restrict__ b, int6
   }
 }
 
+// Single forward pass for windows up to 64 steps: "a run of >= w True starts at t" is known w - 1 steps later (the
+// trailing run at t + w - 1 reaches w), so the two mark series are kept in per-lane 64-bit shift registers and the
+// state is emitted D = max(w_start, w_stop) - 1 steps behind the read position: 4 B in (8 B with a stop mask) + 4 B out
+// per step instead of the 20 B of the two-pass kernel.
+template <int VEC, bool TWO>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_runs_with_holes_fwd(const float* __restrict__ a, const float* __restrict__ b, int64_t T, int64_t C, int64_t sa, int64_t sb,
+                      int w_start, int w_stop, float* __restrict__ out, int64_t out_st) {
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int D = (w_start > w_stop ? w_start : w_stop) - 1;
+  const int bit_s = D - (w_start - 1), bit_t = D - (w_stop - 1);
+  int ra[VEC], rb[VEC];
+  unsigned long long ms[VEC], mt[VEC];
+  float state[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { ra[v] = 0; rb[v] = 0; ms[v] = 0ull; mt[v] = 0ull; state[v] = 0.0f; }
+  auto step = [&](int64_t tp, const VecF<VEC>& xa, const VecF<VEC>& xb, bool inside) {
+    float r[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const bool on_a = inside && xa.v[v] > 0.0f;  // astype(int).fillna(0): NaN -> 0
+      const bool on_b = inside && (TWO ? (xb.v[v] > 0.0f) : !(xa.v[v] > 0.0f));
+      ra[v] = on_a ? ra[v] + 1 : 0;
+      rb[v] = on_b ? rb[v] + 1 : 0;
+      ms[v] = (ms[v] << 1) | (ra[v] >= w_start ? 1ull : 0ull);
+      mt[v] = (mt[v] << 1) | (rb[v] >= w_stop ? 1ull : 0ull);
+      const bool m1 = (ms[v] >> bit_s) & 1ull, m0 = (mt[v] >> bit_t) & 1ull;
+      state[v] = m0 ? 0.0f : (m1 ? 1.0f : state[v]);  // combine_first: stop positions take precedence
+      r[v] = state[v];
+    }
+    const int64_t t = tp - D;
+    if (t >= 0) {
+      if (VEC == 4) *reinterpret_cast<float4*>(out + t * out_st + c) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+      else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) out[t * out_st + c + v] = r[v];
+      }
+    }
+  };
+  if (TWO) xh_march_rows2<VEC, 8>(a + c, b + c, sa, sb, 0, T, [&](int64_t tp, const VecF<VEC>& xa, const VecF<VEC>& xb) { step(tp, xa, xb, true); });
+  else xh_march_rows<VEC, 8>(a + c, sa, 0, T, [&](int64_t tp, const VecF<VEC>& xa) { step(tp, xa, xa, true); });
+  VecF<VEC> z;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) z.v[v] = 0.f;
+  for (int64_t tp = T; tp < T + D; ++tp) step(tp, z, z, false);
+}
+
 // ---- keep_longest_run (per period) -----------------------------------------------------------------------------
 __global__ void __launch_bounds__(XH_BLOCK)
 k_keep_longest_run(const float* __restrict__ x, int64_t C, int64_t st, const int64_t* __restrict__ seg_off, int P,
@@ -179,32 +227,42 @@ k_season(const float* __restrict__ x, int64_t C, int64_t st, int window, const i
 // ---- windowed_max_run_sum (cut at segments / whole series) ------------------------------------------------------
 // rl:491-540: d_rse = reset-cumsum of the VALUES from the run's first element to the next exact zero (NaN adds 0
 // and does not reset), kept where rle(da > 0) >= window, max over the period.  Backward march.
+template <int VEC>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_max_run_sum(const float* __restrict__ x, int64_t C, int64_t st, int window, const int64_t* __restrict__ seg_off, int P,
               float* __restrict__ out) {
-  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
   for (int p = blockIdx.y; p < P; p += gridDim.y) {
-    int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
     // the reference's arithmetic, restated so that results are bit-identical: cs = running fp32 cumsum of the
-    // reversed series (NaN adds 0, never reset), csr = cs at the latest exact zero, d_rse = cs - csr (rl:154-169)
-    float cs = 0.0f, csr = 0.0f;
-    int run = 0;
-    float best = 0.0f;
-    bool any = false;
-    for (int64_t t = t1 - 1; t >= t0; --t) {
-      float v = x[t * st + c];
-      cs = cs + ((v == v) ? v : 0.0f);
-      if (v == 0.0f) csr = cs;
-      float acc = cs - csr;
-      bool on = v > 0.0f;
-      run = on ? run + 1 : 0;
-      bool first_of_run = on && (t == t0 || !(x[(t - 1) * st + c] > 0.0f));
-      float d = (first_of_run && run >= window) ? acc : 0.0f;
-      best = (!any || d > best) ? d : best;
-      any = true;
+    // reversed series (NaN adds 0, never reset), csr = cs at the latest exact zero, d_rse = cs - csr (rl:154-169).
+    // Whether step t is the FIRST of its run is known one step later in the backward march, so the candidate of
+    // step t is held back until t - 1 has been seen (rows are loaded once, in double-buffered batches).
+    float cs[VEC], csr[VEC], best[VEC], pacc[VEC];
+    int run[VEC], prun[VEC];
+    bool pon[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { cs[v] = 0.f; csr[v] = 0.f; best[v] = 0.f; pacc[v] = 0.f; run[v] = 0; prun[v] = 0; pon[v] = false; }
+    xh_march_rows_rev<VEC, 8>(x + c, st, t0, t1, [&](int64_t, const VecF<VEC>& xv) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float val = xv.v[v];
+        const bool on = val > 0.0f;
+        const float d = (pon[v] && !on && prun[v] >= window) ? pacc[v] : 0.0f;  // step t + 1 was the first of its run
+        best[v] = d > best[v] ? d : best[v];
+        cs[v] = cs[v] + ((val == val) ? val : 0.0f);
+        if (val == 0.0f) csr[v] = cs[v];
+        run[v] = on ? run[v] + 1 : 0;
+        pon[v] = on; pacc[v] = cs[v] - csr[v]; prun[v] = run[v];
+      }
+    });
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float d = (pon[v] && prun[v] >= window) ? pacc[v] : 0.0f;  // a run that starts on the first step
+      const float b2 = d > best[v] ? d : best[v];
+      out[(int64_t)p * C + c + v] = (t1 > t0) ? b2 : xh_nan32();
     }
-    out[(int64_t)p * C + c] = any ? best : xh_nan32();
   }
 }
 
@@ -375,6 +433,20 @@ int xh_runs_with_holes(xh_ctx* ctx, const float* start, const float* stop, int64
   XH_REQUIRE(out && out_st >= C, XH_ERR_ARG, "xh_runs_with_holes: out NULL or out_st < C");
   XH_REQUIRE(window_start >= 1 && window_stop >= 1, XH_ERR_ARG, "xh_runs_with_holes: windows must be >= 1");
   if (T == 0 || C == 0) return XH_OK;
+  if (window_start <= 64 && window_stop <= 64) {
+    // VEC = 4 only when that still leaves a few workgroups per CU (no time chunking is possible here)
+    const bool v4 = xh_pick_vec(start, C, st) == 4 && (!stop || xh_pick_vec(stop, C, st) == 4) && xh_pick_vec(out, C, out_st) == 4 &&
+                    cdiv64(cdiv64(C, 4), XH_BLOCK) >= 4 * (int64_t)ctx->num_cu;
+    const dim3 grid((unsigned)cdiv64(cdiv64(C, v4 ? 4 : 1), XH_BLOCK));
+#define XH_RWH(V, TW)                                                                                                   \
+  hipLaunchKernelGGL((k_runs_with_holes_fwd<V, TW>), grid, dim3(XH_BLOCK), 0, ctx->stream, start, stop ? stop : start, T, C, st, \
+                     st, window_start, window_stop, out, out_st)
+    if (v4) { if (stop) XH_RWH(4, true); else XH_RWH(4, false); }
+    else { if (stop) XH_RWH(1, true); else XH_RWH(1, false); }
+#undef XH_RWH
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+  }
   hipLaunchKernelGGL(k_runs_with_holes, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, start,
                      stop ? stop : start, T, C, st, st, window_start, window_stop, stop ? 0 : 1, out, out_st);
   XH_LAUNCH_CHECK();
@@ -437,8 +509,12 @@ int xh_max_run_sum(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   rc = upload_seg(ctx, &cur, seg_off, P, T, "xh_max_run_sum", &d_seg);
   if (rc) return rc;
   if (C == 0) return XH_OK;
-  hipLaunchKernelGGL(k_max_run_sum, dim3((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)), dim3(XH_BLOCK), 0,
-                     ctx->stream, x, C, st, window, d_seg, P, out);
+  if (xh_pick_vec(x, C, st) == 4)
+    hipLaunchKernelGGL((k_max_run_sum<4>), dim3((unsigned)cdiv64(cdiv64(C, 4), XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)),
+                       dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, d_seg, P, out);
+  else
+    hipLaunchKernelGGL((k_max_run_sum<1>), dim3((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)), dim3(XH_BLOCK),
+                       0, ctx->stream, x, C, st, window, d_seg, P, out);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }
