@@ -75,16 +75,18 @@ __host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return 
 // ---- device helpers ---------------------------------------------------------------------------
 #define XH_BLOCK 256
 
+// Run-time operator as four wave-uniform masks (greater / less / equal / unordered) instead of a switch: the masks are
+// loop invariant scalars, every element costs the same three or four v_cmp whatever the operator, and the compiler can
+// keep the loop bodies branch-free.  NaN compares False except for != (numpy semantics): only NE sets `un`.
 __device__ __forceinline__ bool xh_cmp_f32(float a, int op, float b) {
-  switch (op) {
-    case XH_OP_GT: return a > b;
-    case XH_OP_LT: return a < b;
-    case XH_OP_GE: return a >= b;
-    case XH_OP_LE: return a <= b;
-    case XH_OP_EQ: return a == b;
-    default: return a != b;
-  }
+  const bool gt = op == XH_OP_GT || op == XH_OP_GE || op == XH_OP_NE;
+  const bool lt = op == XH_OP_LT || op == XH_OP_LE || op == XH_OP_NE;
+  const bool eq = op == XH_OP_GE || op == XH_OP_LE || op == XH_OP_EQ;
+  const bool un = op == XH_OP_NE;
+  return (gt & (a > b)) | (lt & (a < b)) | (eq & (a == b)) | (un & ((a != a) | (b != b)));
 }
+// fp64 compares are half rate: here the switch is kept (the compiler unswitches the loops on the uniform operator and
+// every element costs ONE compare; measured 0.75 vs 0.80 ms for the per-doy threshold_count of the tx90p chain)
 __device__ __forceinline__ bool xh_cmp_f64(double a, int op, double b) {
   switch (op) {
     case XH_OP_GT: return a > b;

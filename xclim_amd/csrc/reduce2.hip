@@ -92,36 +92,47 @@ k_thresholded_reduce(const float* __restrict__ x, int64_t C, int64_t st, int op,
 
 // ---- climatological_mean_doy (cal:907-931) ---------------------------------------------------------------------
 // Same sample set as percentile_doy (all years x centred window, NaN outside the series): nanmean and nanstd (ddof 0).
+// Loads are unconditional (clamped row, validity applied afterwards): a load under a condition is followed by
+// s_waitcnt vmcnt(0) and the `window` samples of a year would arrive one memory latency after the other.
+template <int W>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_doy_mean_std(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
                int ndoy, int window, float* __restrict__ mean_out, float* __restrict__ std_out) {
   int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
   if (c >= C) return;
-  const int half = window / 2;
+  const int w = W > 0 ? W : window;  // W == 0: run-time window
+  const int half = w / 2;
   for (int d = blockIdx.y; d < ndoy; d += gridDim.y) {
     double s = 0.0;
     int n = 0;
-    for (int y = 0; y < nyears; ++y) {
-      int64_t tb = tbase[(int64_t)y * ndoy + d];
-      if (tb < 0) continue;
-      for (int k = 0; k < window; ++k) {
-        int64_t t = tb - half + k;
-        if (t < 0 || t >= T) continue;
-        float v = x[t * st + c];
-        if (v == v) { s += (double)v; n++; }
+    auto pass = [&](auto&& f) {
+      for (int y = 0; y < nyears; ++y) {
+        const int64_t tb = tbase[(int64_t)y * ndoy + d];
+        if (W > 0) {
+          float v[W > 0 ? W : 1];
+#pragma unroll
+          for (int k = 0; k < W; ++k) {
+            const int64_t t = tb - half + k;
+            v[k] = x[(t < 0 ? 0 : (t >= T ? T - 1 : t)) * st + c];
+          }
+#pragma unroll
+          for (int k = 0; k < W; ++k) {
+            const int64_t t = tb - half + k;
+            if (tb >= 0 && t >= 0 && t < T && v[k] == v[k]) f(v[k]);
+          }
+        } else {
+          for (int k = 0; k < w; ++k) {
+            const int64_t t = tb - half + k;
+            const float v = x[(t < 0 ? 0 : (t >= T ? T - 1 : t)) * st + c];
+            if (tb >= 0 && t >= 0 && t < T && v == v) f(v);
+          }
+        }
       }
-    }
-    double m = n > 0 ? s / (double)n : 0.0, s2 = 0.0;
-    for (int y = 0; y < nyears; ++y) {
-      int64_t tb = tbase[(int64_t)y * ndoy + d];
-      if (tb < 0) continue;
-      for (int k = 0; k < window; ++k) {
-        int64_t t = tb - half + k;
-        if (t < 0 || t >= T) continue;
-        float v = x[t * st + c];
-        if (v == v) { double dv = (double)v - m; s2 += dv * dv; }
-      }
-    }
+    };
+    pass([&](float v) { s += (double)v; n++; });
+    const double m = n > 0 ? s / (double)n : 0.0;
+    double s2 = 0.0;
+    pass([&](float v) { const double dv = (double)v - m; s2 += dv * dv; });
     mean_out[(int64_t)d * C + c] = n > 0 ? (float)m : xh_nan32();
     std_out[(int64_t)d * C + c] = n > 0 ? (float)sqrt(s2 / (double)n) : xh_nan32();
   }
@@ -255,8 +266,11 @@ int xh_doy_mean_std(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t s
   rc = xh_scratch_upload(ctx, &cur, tbase, sizeof(int32_t) * (size_t)nyears * ndoy, &d_tb);
   if (rc) return rc;
   dim3 grid((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(ndoy > 1024 ? 1024 : ndoy));
-  hipLaunchKernelGGL(k_doy_mean_std, grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy,
-                     window, mean_out, std_out);
+#define XH_DMS(W)                                                                                                        \
+  hipLaunchKernelGGL((k_doy_mean_std<W>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, \
+                     window, mean_out, std_out)
+  if (window == 5) XH_DMS(5); else if (window == 3) XH_DMS(3); else if (window == 7) XH_DMS(7); else XH_DMS(0);
+#undef XH_DMS
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

@@ -29,13 +29,15 @@ __device__ __forceinline__ void acc_add(RunAcc& a, int len) {
   a.cnt += 1;
   a.sumsq += (unsigned long long)((unsigned)len) * (unsigned)len;
 }
-// predicated form: len == 0 means "no run finished here"
+// predicated form: len == 0 means "no run finished here".  SG (stat group, compile time) prunes the fields the
+// requested statistic does not read: 0 all, 1 max, 2 sum / count / mean, 3 min.
+template <int SG = 0>
 __device__ __forceinline__ void acc_add_if(RunAcc& a, int len) {
-  a.mx = len > a.mx ? len : a.mx;
-  a.mn = (len > 0 && len < a.mn) ? len : a.mn;
-  a.sum += len;
-  a.cnt += len > 0 ? 1 : 0;
-  a.sumsq += (unsigned long long)((unsigned)len) * (unsigned)len;
+  if (SG == 0 || SG == 1) a.mx = len > a.mx ? len : a.mx;
+  if (SG == 0 || SG == 3) a.mn = (len > 0 && len < a.mn) ? len : a.mn;
+  if (SG == 0 || SG == 2) a.sum += len;
+  if (SG == 0 || SG == 2 || SG == 3 || SG == 1) a.cnt += len > 0 ? 1 : 0;
+  if (SG == 0) a.sumsq += (unsigned long long)((unsigned)len) * (unsigned)len;
 }
 __device__ __forceinline__ float acc_result(const RunAcc& a, int stat, int plainsum) {
   if (stat == XH_RUN_PLAINSUM) return (float)plainsum;
@@ -62,7 +64,7 @@ struct RunState {
   int startp;    // period of the run's first element (resample-after mode)
 };
 
-template <int VEC, bool CUT>
+template <int VEC, bool CUT, int SG = 0>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int fused_op, float thr, int window, int stat,
             int index_first, const int64_t* __restrict__ seg_off, int P, float* __restrict__ out,
@@ -96,7 +98,7 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
           bool visible = index_first ? s[i].vis : !masknan;
           bool ended = !on && s[i].run > 0;
           int len = (ended && visible && s[i].run >= window) ? s[i].run : 0;
-          acc_add_if(acc[i], len);
+          acc_add_if<SG>(acc[i], len);
           s[i].vis = (on && s[i].run == 0) ? !s[i].prevnan : s[i].vis;
           s[i].run = on ? s[i].run + 1 : 0;
           s[i].prevnan = masknan;
@@ -126,7 +128,7 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
     }
     int pt = 0;  // period of the current time step (uniform across lanes)
     int64_t tend = seg_off[P];
-    for (int64_t t = seg_off[0]; t < tend; ++t) {
+    xh_march_rows<VEC, 8>(x + c, st, seg_off[0], tend, [&](int64_t t, const VecF<VEC>& xv) {
       while (t >= seg_off[pt + 1]) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
@@ -136,7 +138,6 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
         }
         pt++;
       }
-      VecF<VEC> xv = xh_load<VEC>(x + t * st + c);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         float v = xv.v[i];
@@ -166,7 +167,7 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
         }
         s[i].prevnan = masknan;
       }
-    }
+    });
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       if (s[i].run > 0 && stat != XH_RUN_PLAINSUM) {
@@ -426,12 +427,19 @@ int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, 
   }
   if (cut_at_segments) {
     dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), py);
-    if (vec == 4)
-      hipLaunchKernelGGL((k_run_stats<4, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, fused_op, (float)thr,
-                         window, stat, index_first, d_seg, P, out, valid_out);
-    else
-      hipLaunchKernelGGL((k_run_stats<1, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, fused_op, (float)thr,
-                         window, stat, index_first, d_seg, P, out, valid_out);
+    // stat group (compile time): the accumulator fields the statistic does not read are not maintained
+    // (measured at 365 x 1440 x 720: max 0.55 -> 0.50 ms; the sum / count group came out SLOWER than the generic body,
+    //  0.68 vs 0.54 ms, so only max is specialised)
+    const int sg = stat == XH_RUN_MAX ? 1 : 0;
+#define XH_RS(V, G)                                                                                                    \
+  hipLaunchKernelGGL((k_run_stats<V, true, G>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, fused_op, (float)thr, \
+                     window, stat, index_first, d_seg, P, out, valid_out)
+    if (vec == 4) {
+      if (sg == 1) XH_RS(4, 1); else XH_RS(4, 0);
+    } else {
+      if (sg == 1) XH_RS(1, 1); else XH_RS(1, 0);
+    }
+#undef XH_RS
   } else {
     XH_REQUIRE(seg_off[0] == 0 && seg_off[P] == T, XH_ERR_ARG,
                "xh_run_stats: resample-after mode needs segments covering [0, T)");
