@@ -323,3 +323,24 @@ def test_bivariate_spell_length_statistics_and_thresholded_events(dev, rng):
         ref = orl.find_events(start, 2, stop, 2, data=pr)
         for k in ref:
             np.testing.assert_allclose(got[k], ref[k], rtol=1e-6, equal_nan=True, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_runs_with_holes_long_windows_and_pool(dev, rng):
+    """windows > 64 take the two-pass kernel (the single-pass one keeps its marks in 64-bit shift registers); both must
+    agree with the oracle.  Also: freed device buffers are re-used by the pooled allocator of the Python Device."""
+    T, C = 900, 19
+    a = (rng.random((T, C)) < 0.93)
+    b = (rng.random((T, C)) < 0.9)
+    for ws, wt in ((70, 3), (5, 66), (64, 64), (65, 1)):
+        got = xrl.runs_with_holes(a, ws, b, wt, device=dev)
+        np.testing.assert_array_equal(got, orl.runs_with_holes(a, ws, b, wt))
+    x = dev.empty((1234, 7), np.float32)
+    ptr = x.ptr
+    x.free()
+    y = dev.empty((1234, 7), np.float32)
+    assert y.ptr == ptr  # same size -> the pooled buffer comes back
+    y.free()
+    dev.trim()
+    z = dev.empty((1234, 7), np.float32)
+    z.free()
