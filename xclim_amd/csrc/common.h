@@ -14,9 +14,15 @@ struct xh_ctx {
   // second stream + events: transposes of the next column batch run next to the selection of the current one
   hipStream_t stream2;
   hipEvent_t ev_ready[2], ev_done[2];
-  // small device scratch for tables (seg_off, quantiles ...) uploaded per call
+  // small device scratch for tables (seg_off, quantiles ...) uploaded per call: a RING shared by consecutive calls
+  // with a pinned host mirror, so that uploads are asynchronous (no stream synchronisation per call)
   void* scratch;
   size_t scratch_bytes;
+  char* scratch_host;   // pinned, same size
+  size_t scratch_head;  // next free offset
+  void* retired[16];    // rings replaced by a larger one: kept until xh_destroy (tables handed out earlier in the same
+  char* retired_host[16];  //   call may still point into them)
+  int nretired;
   // large scratch (transposes), grown on demand
   void* big;
   size_t big_bytes;

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -61,6 +62,8 @@ int xh_create(int device, xh_ctx** out) {
   }
   ctx->scratch_bytes = 8u << 20;
   XH_CHECK_HIP(hipMalloc(&ctx->scratch, ctx->scratch_bytes));
+  XH_CHECK_HIP(hipHostMalloc((void**)&ctx->scratch_host, ctx->scratch_bytes, hipHostMallocDefault));
+  ctx->scratch_head = 0;
   hipDeviceProp_t prop;
   XH_CHECK_HIP(hipGetDeviceProperties(&prop, device));
   ctx->num_cu = prop.multiProcessorCount;
@@ -73,6 +76,11 @@ int xh_destroy(xh_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->scratch_host) (void)hipHostFree(ctx->scratch_host);
+  for (int i = 0; i < ctx->nretired; ++i) {
+    (void)hipFree(ctx->retired[i]);
+    (void)hipHostFree(ctx->retired_host[i]);
+  }
   if (ctx->big) (void)hipFree(ctx->big);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
@@ -176,26 +184,40 @@ int xh_stream(xh_ctx* ctx, void** stream) {
 
 }  // extern "C"
 
+// Host tables are tiny, caller-owned and possibly temporaries.  They are copied into a pinned ring that mirrors the device
+// ring and sent with an asynchronous copy on the context's stream: the call does not wait for earlier kernels (the old
+// synchronous upload drained the stream at every entry point).  The ring wraps with ONE stream synchronisation when it is
+// exhausted (8 MiB: hundreds of calls), so a slot is never overwritten while an earlier kernel may still read it.
 int xh_scratch_upload(xh_ctx* ctx, size_t* cursor, const void* host, size_t bytes, void** dptr) {
-  size_t off = (*cursor + 255) & ~(size_t)255;
-  if (off + bytes > ctx->scratch_bytes) {
-    // grow: wait for in-flight users of the old scratch first
+  size_t off = (ctx->scratch_head + 255) & ~(size_t)255;
+  if (bytes > ctx->scratch_bytes / 4) {
+    // an unusually large table: grow both rings (wait for in-flight users of the old one first)
     XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     size_t nb = ctx->scratch_bytes;
-    while (off + bytes > nb) nb *= 2;
+    while (bytes > nb / 4) nb *= 2;
     void* n = nullptr;
+    char* nh = nullptr;
     XH_CHECK_HIP(hipMalloc(&n, nb));
-    if (off) XH_CHECK_HIP(hipMemcpy(n, ctx->scratch, off, hipMemcpyDeviceToDevice));
-    XH_CHECK_HIP(hipFree(ctx->scratch));
+    XH_CHECK_HIP(hipHostMalloc((void**)&nh, nb, hipHostMallocDefault));
+    if (ctx->nretired < 16) {
+      ctx->retired[ctx->nretired] = ctx->scratch;
+      ctx->retired_host[ctx->nretired] = ctx->scratch_host;
+      ctx->nretired++;
+    }  // (else: leaked on purpose — never reached with doubling sizes)
     ctx->scratch = n;
+    ctx->scratch_host = nh;
     ctx->scratch_bytes = nb;
+    off = 0;
+  } else if (off + bytes > ctx->scratch_bytes) {
+    XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // wrap: every earlier consumer has finished
+    off = 0;
   }
   char* d = (char*)ctx->scratch + off;
-  XH_CHECK_HIP(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-  // host tables are tiny, caller-owned and possibly stack/temporary: wait so they can be released
-  XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(ctx->scratch_host + off, host, bytes);
+  XH_CHECK_HIP(hipMemcpyAsync(d, ctx->scratch_host + off, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ctx->scratch_head = off + bytes;
   *dptr = d;
-  *cursor = off + bytes;
+  *cursor += bytes;
   return XH_OK;
 }
 
@@ -259,10 +281,17 @@ k_transpose_f32(const float* __restrict__ in, int64_t rows, int64_t cols, int64_
   __shared__ float tile[64][65];
   int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
   int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 row groups
-  for (int i = ty; i < 64; i += 4) {
-    int64_t r = r0 + i, c = c0 + tx;
-    if (r < rows && c < cols) tile[i][tx] = in[r * in_stride + c];
+  // unconditional, clamped loads first (a load under a condition is followed by s_waitcnt vmcnt(0): the 16 loads of a
+  // thread would be serialised); out-of-range elements are never stored
+  float v[16];
+  const int64_t cc = c0 + tx < cols ? c0 + tx : cols - 1;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int64_t r = r0 + ty + 4 * k;
+    v[k] = in[(r < rows ? r : rows - 1) * in_stride + cc];
   }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tile[ty + 4 * k][tx] = v[k];
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     int64_t c = c0 + i, r = r0 + tx;
