@@ -136,8 +136,9 @@ def main():
         k_count()
         k_mask()
         if use_dist:
-            dev.sync()
+            dev.sync()  # the kernels run on the context's stream, RCCL on torch's: order them explicitly
             dist.all_gather_into_tensor(gathered.view(world * P, C), res_t)
+            torch.cuda.current_stream().synchronize()  # the next step overwrites res_t: the gather must have read it
 
     def fence():
         dev.sync()
