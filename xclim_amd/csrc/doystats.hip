@@ -1,0 +1,110 @@
+// doystats.hip — climatological_mean_doy (core/calendar.py:907-931) from per-day-set partial sums.
+//
+// The sample set of doy d is the union of the W day-sets {(year y, doy d + k)} (same decomposition as the multi-year
+// percentile kernels, pdoy.h).  One lane per cell marches over a chunk of doys: every day-set is gathered ONCE (rows
+// resolved with one vector load + readlane, unconditional loads), reduced to (sum, sum of squares, count) of the values
+// shifted by a per-cell pivot K, kept in a ring of W partials; mean = K + S1 / N, var = (S2 - S1^2 / N) / N in fp64 (the
+// shift keeps the one-pass variance well conditioned: |v - K| is of the order of the spread, not of the magnitude).
+// The generic kernel (reduce2.hip) re-reads every row W times and twice for its two-pass std; it remains the exact path
+// for irregular doys (calendar gaps).
+#include "pdoy.h"
+
+namespace {
+
+template <int W, int NYP>
+__global__ void __launch_bounds__(64)
+k_doy_stats_sets(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
+                 int ndoy, int chunk, const uint8_t* __restrict__ regular, float* __restrict__ mean_out,
+                 float* __restrict__ std_out) {
+  const int lane = threadIdx.x;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  const bool active = c < C;
+  const int64_t cc = active ? c : C - 1;
+  constexpr int half = W / 2;
+  int d0 = blockIdx.y * chunk, d1 = d0 + chunk;
+  if (d1 > ndoy) d1 = ndoy;
+  double s1[W], s2[W];
+  int n[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) { s1[w] = 0.0; s2[w] = 0.0; n[w] = 0; }
+  float raw[NYP];
+  float K = 0.0f;
+  bool haveK = false;
+  auto rows_of = [&](int dn) { return pdoy_row(lane, nyears, ndoy, dn, 0, tbase, nullptr, T, T); };
+  auto reduce_into = [&](double& a1, double& a2, int& an) {
+    if (!haveK) {  // pivot: the first valid value this lane meets
+#pragma unroll
+      for (int y = 0; y < NYP; ++y)
+        if (!haveK && raw[y] == raw[y]) { K = raw[y]; haveK = true; }
+    }
+    double b1 = 0.0, b2 = 0.0;
+    int bn = 0;
+#pragma unroll
+    for (int y = 0; y < NYP; ++y) {
+      const float v = raw[y];
+      const bool ok = v == v;
+      const double dv = ok ? (double)v - (double)K : 0.0;
+      b1 += dv;
+      b2 += dv * dv;
+      bn += ok ? 1 : 0;
+    }
+    a1 = b1; a2 = b2; an = bn;
+  };
+  // ring[w] = day-set of doy (d - half + w); prologue fills slots 1 .. W-1 for d = d0 - 1
+#pragma unroll
+  for (int w = 1; w < W; ++w) {
+    pdoy_gather<NYP>(raw, rows_of(d0 - 1 - half + w), x, st, cc);
+    reduce_into(s1[w], s2[w], n[w]);
+  }
+  pdoy_gather<NYP>(raw, rows_of(d0 + half), x, st, cc);
+  int rows_next = rows_of(d0 + half + 1);
+  for (int d = d0; d < d1; ++d) {
+#pragma unroll
+    for (int w = 0; w < W - 1; ++w) { s1[w] = s1[w + 1]; s2[w] = s2[w + 1]; n[w] = n[w + 1]; }
+    reduce_into(s1[W - 1], s2[W - 1], n[W - 1]);
+    if (d + 1 < d1) {
+      pdoy_gather<NYP>(raw, rows_next, x, st, cc);
+      rows_next = rows_of(d + 2 + half);
+    }
+    if (regular[d] && active) {
+      double S1 = 0.0, S2 = 0.0;
+      int N = 0;
+#pragma unroll
+      for (int w = 0; w < W; ++w) { S1 += s1[w]; S2 += s2[w]; N += n[w]; }
+      float m = xh_nan32(), sd = xh_nan32();
+      if (N > 0) {
+        const double mean_s = S1 / (double)N;
+        double var = (S2 - S1 * mean_s) / (double)N;
+        var = var > 0.0 ? var : 0.0;
+        m = (float)((double)K + mean_s);
+        sd = (float)sqrt(var);
+      }
+      mean_out[(int64_t)d * C + c] = m;
+      std_out[(int64_t)d * C + c] = sd;
+    }
+  }
+}
+
+}  // namespace
+
+int xh_launch_doy_stats_sets(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
+                             int ndoy, int window, const uint8_t* d_reg, float* mean_out, float* std_out) {
+  if (!(window == 3 || window == 5 || window == 7) || nyears > 64) return XH_ERR_NOTIMPL;
+  const int chunk = 24;
+  const dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
+#define XH_DS(W, NY)                                                                                                     \
+  hipLaunchKernelGGL((k_doy_stats_sets<W, NY>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, d_reg, \
+                     mean_out, std_out)
+#define XH_DSW(NY)                                                                   \
+  do {                                                                               \
+    if (window == 3) XH_DS(3, NY); else if (window == 5) XH_DS(5, NY); else XH_DS(7, NY); \
+  } while (0)
+  if (nyears <= 2) XH_DSW(2);
+  else if (nyears <= 8) XH_DSW(8);
+  else if (nyears <= 32) XH_DSW(32);
+  else XH_DSW(64);
+#undef XH_DSW
+#undef XH_DS
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}

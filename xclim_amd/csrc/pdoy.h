@@ -35,6 +35,43 @@ __device__ __forceinline__ void pdoy_gather(float (&raw)[NYP], int rowv, const f
   }
 }
 
+// Host: regular[d] = 1 when the window sample set of doy d (time offsets -W/2 .. W/2 around every year's day, NaN outside
+// the series) equals the union of the W neighbouring DAY-SETS {(y, d + k)} — true except around calendar gaps (Feb 29 /
+// doy 366, partial first or last years); the irregular doys are listed for the exact fallback kernels.  Returns their
+// number.  `vmap` / Tv: optional virtual time map (bootstrap replicas), else Tv = T.
+static inline int pdoy_regular_flags(const int32_t* tbase, int nyears, int ndoy, int window, int64_t T, const int32_t* vmap,
+                                     int64_t Tv, uint8_t* regular, int32_t* irregular) {
+  const int half = window / 2;
+  int nirr = 0;
+  for (int d = 0; d < ndoy; ++d) {
+    bool ok = true;
+    for (int y = 0; ok && y < nyears; ++y) {
+      int v = tbase[(int64_t)y * ndoy + d];
+      for (int k = 0; ok && k < window; ++k) {
+        int64_t a = -1;  // virtual index the window semantic reads
+        if (v >= 0) {
+          int64_t t = (int64_t)v - half + k;
+          if (t >= 0 && t < Tv) a = t;
+        }
+        int dn = d - half + k;
+        int64_t b = (dn >= 0 && dn < ndoy) ? (int64_t)tbase[(int64_t)y * ndoy + dn] : -1;
+        // compare the PHYSICAL rows (two virtual days may map to the same / to an absent row)
+        int64_t pa = a < 0 ? -1 : (vmap ? vmap[a] : a), pb = b < 0 ? -1 : (vmap ? vmap[b] : b);
+        if (pa >= T) pa = -1;
+        if (pb >= T) pb = -1;
+        ok = pa == pb;
+      }
+    }
+    regular[d] = ok ? 1 : 0;
+    if (!ok) irregular[nirr++] = d;
+  }
+  return nirr;
+}
+
+// doystats.hip: climatological mean / std per doy from per-day-set partial sums (regular doys of the chunk grid)
+int xh_launch_doy_stats_sets(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
+                             int ndoy, int window, const uint8_t* d_reg, float* mean_out, float* std_out);
+
 // pdoy_top.hip: register top-16 kernel for the percentiles in jmap[0..nsub) (rev = 0: all of them select within the 16
 // largest samples; rev = 1: within the 16 smallest) on the REGULAR doys (d_reg[d] != 0) of the chunk grid; irregular doys
 // (window does not decompose into day-sets, e.g. around Feb 29) are left to k_pdoy_merge.

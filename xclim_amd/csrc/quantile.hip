@@ -766,7 +766,6 @@ static int pdoy_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
     return launch_pdoy_lds(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const double*)d_q, nper, alpha,
                            beta, out, (const int32_t*)d_vmap, Tv, nullptr, 0);
   // ---- merge path: flag the doys for which "window sample set == union of the W day-sets" holds exactly
-  const int half = window / 2;
   uint8_t* regular = (uint8_t*)malloc((size_t)ndoy);
   int32_t* irregular = (int32_t*)malloc(sizeof(int32_t) * (size_t)ndoy);
   QTab* tab = (QTab*)malloc(sizeof(QTab) * (size_t)nper * (N + 1));
@@ -775,29 +774,7 @@ static int pdoy_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
     xh_set_error("xh_percentile_doy: out of host memory");
     return XH_ERR_ARG;
   }
-  int nirr = 0;
-  for (int d = 0; d < ndoy; ++d) {
-    bool ok = true;
-    for (int y = 0; ok && y < nyears; ++y) {
-      int v = tbase[(int64_t)y * ndoy + d];
-      for (int k = 0; ok && k < window; ++k) {
-        int64_t a = -1;  // virtual index the window semantic reads
-        if (v >= 0) {
-          int64_t t = (int64_t)v - half + k;
-          if (t >= 0 && t < Tv) a = t;
-        }
-        int dn = d - half + k;
-        int64_t b = (dn >= 0 && dn < ndoy) ? (int64_t)tbase[(int64_t)y * ndoy + dn] : -1;
-        // compare the PHYSICAL rows (two virtual days may map to the same / to an absent row)
-        int64_t pa = a < 0 ? -1 : (vmap ? vmap[a] : a), pb = b < 0 ? -1 : (vmap ? vmap[b] : b);
-        if (pa >= T) pa = -1;
-        if (pb >= T) pb = -1;
-        ok = pa == pb;
-      }
-    }
-    regular[d] = ok ? 1 : 0;
-    if (!ok) irregular[nirr++] = d;
-  }
+  const int nirr = pdoy_regular_flags(tbase, nyears, ndoy, window, T, vmap, Tv, regular, irregular);
   build_qtab(N, qh, nper, alpha, beta, tab);
   // Classify the percentiles: "top" / "bottom" when, for every possible valid count n, both order statistics lie within
   // the 16 largest / smallest samples (register kernel k_pdoy_top16), otherwise "rest" (LDS-ring kernel k_pdoy_merge).

@@ -1,5 +1,8 @@
 // reduce2.hip — two-variable counts, thresholded reductions, day-of-year climatology (rows G3, G4, Q5 of SURVEY.md §8a).
+#include <stdlib.h>
+
 #include "common.h"
+#include "pdoy.h"
 
 // ---- bivariate counts ---------------------------------------------------------------------------------------
 // count_level_crossings (gen:913-957): ((low op_low thr) & (high op_high thr)).resample.sum
@@ -97,12 +100,15 @@ k_thresholded_reduce(const float* __restrict__ x, int64_t C, int64_t st, int op,
 template <int W>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_doy_mean_std(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
-               int ndoy, int window, float* __restrict__ mean_out, float* __restrict__ std_out) {
+               int ndoy, int window, float* __restrict__ mean_out, float* __restrict__ std_out,
+               const int32_t* __restrict__ doy_list, int ndl) {
   int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
   if (c >= C) return;
   const int w = W > 0 ? W : window;  // W == 0: run-time window
   const int half = w / 2;
-  for (int d = blockIdx.y; d < ndoy; d += gridDim.y) {
+  const int nloop = doy_list ? ndl : ndoy;  // doy_list: only the listed doys (the irregular ones)
+  for (int di = blockIdx.y; di < nloop; di += gridDim.y) {
+    const int d = doy_list ? doy_list[di] : di;
     double s = 0.0;
     int n = 0;
     auto pass = [&](auto&& f) {
@@ -265,10 +271,39 @@ int xh_doy_mean_std(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t s
   void* d_tb = nullptr;
   rc = xh_scratch_upload(ctx, &cur, tbase, sizeof(int32_t) * (size_t)nyears * ndoy, &d_tb);
   if (rc) return rc;
-  dim3 grid((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(ndoy > 1024 ? 1024 : ndoy));
+  // regular doys: per-day-set partial sums (doystats.hip); irregular doys (calendar gaps) and unusual windows: the generic
+  // per-doy kernel below
+  const int32_t* d_list = nullptr;
+  int ndl = 0;
+  bool generic_all = true;
+  if ((window == 3 || window == 5 || window == 7) && nyears <= 64) {
+    uint8_t* regular = (uint8_t*)malloc((size_t)ndoy);
+    int32_t* irregular = (int32_t*)malloc(sizeof(int32_t) * (size_t)ndoy);
+    if (!regular || !irregular) {
+      free(regular); free(irregular);
+      xh_set_error("xh_doy_mean_std: out of host memory");
+      return XH_ERR_ARG;
+    }
+    ndl = pdoy_regular_flags(tbase, nyears, ndoy, window, T, nullptr, T, regular, irregular);
+    void *d_reg = nullptr, *d_irr = nullptr;
+    rc = xh_scratch_upload(ctx, &cur, regular, (size_t)ndoy, &d_reg);
+    if (!rc && ndl) rc = xh_scratch_upload(ctx, &cur, irregular, sizeof(int32_t) * (size_t)ndl, &d_irr);
+    free(regular); free(irregular);
+    if (rc) return rc;
+    rc = xh_launch_doy_stats_sets(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const uint8_t*)d_reg,
+                                  mean_out, std_out);
+    if (rc && rc != XH_ERR_NOTIMPL) return rc;
+    if (rc == XH_OK) {
+      generic_all = false;
+      d_list = (const int32_t*)d_irr;
+      if (ndl == 0) return XH_OK;
+    }
+  }
+  const int nloop = generic_all ? ndoy : ndl;
+  dim3 grid((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(nloop > 1024 ? 1024 : nloop));
 #define XH_DMS(W)                                                                                                        \
   hipLaunchKernelGGL((k_doy_mean_std<W>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, \
-                     window, mean_out, std_out)
+                     window, mean_out, std_out, generic_all ? (const int32_t*)nullptr : d_list, ndl)
   if (window == 5) XH_DMS(5); else if (window == 3) XH_DMS(3); else if (window == 7) XH_DMS(7); else XH_DMS(0);
 #undef XH_DMS
   XH_LAUNCH_CHECK();
