@@ -293,9 +293,11 @@ int xh_percentile_doy_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, i
 
 /* _interpolate_doy_calendar (core/calendar.py:690-726): interpolate_na along doy then linear re-grid
  * D_in -> D_out with host-computed tables (scipy interp1d form): slope = (in[i1[j]] - in[i0[j]]) / dxs[j];
- * out[j] = slope * dxn[j] + in[i0[j]],  dxn = x_new - x_lo, dxs = x_hi - x_lo.  in (D_in, C), out (D_out, C). */
+ * out[j] = slope * dxn[j] + in[i0[j]],  dxn = x_new - x_lo, dxs = x_hi - x_lo.  in (D_in, C), out (D_out, C).
+ * xsrc[D_in] (host, may be NULL = row index): the dayofyear coordinate of the source rows, used by the interpolate_na
+ * step (xarray fills NaN gaps linearly IN THE COORDINATE, which is not uniform when a doy never occurs in the series). */
 int xh_doy_interp(xh_ctx* ctx, const double* in, int D_in, int64_t C, const int32_t* i0, const int32_t* i1,
-                  const double* dxn, const double* dxs, int D_out, double* out);
+                  const double* dxn, const double* dxs, int D_out, double* out, const double* xsrc);
 
 /* resample_doy (core/calendar.py:763-790): out (T, C) float64 = table[tidx[t]] for a (D, C) per-doy table; tidx is the
  * host array of table rows per time step.  (xh_threshold_count fuses this gather; this entry materialises the field.) */

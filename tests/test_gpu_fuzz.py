@@ -1,0 +1,113 @@
+"""Seeded differential fuzzing of the HIP path against the oracle: random shapes (incl. tiny and ragged), NaN fractions,
+windows, operators, frequencies and calendars for the run-length, spell, count and percentile families.  Every case is
+checked with the family's parity bar (bit-exact integers, <= 1e-6 relative for floats)."""
+import numpy as np
+import pytest
+
+from oracle import calendar as ocal
+from oracle import generic as ogen
+from oracle import run_length as orl
+from oracle.timeutil import OTime
+from xclim_amd import generic as xgen
+from xclim_amd import run_length as xrl
+from xclim_amd.calendar import percentile_doy
+from xclim_amd.timeaxis import TimeAxis
+
+pytestmark = pytest.mark.gpu
+
+OPS = [">", "<", ">=", "<=", "==", "!="]
+FREQS = ["YS", "MS", "QS-DEC", "YS-JUL"]
+
+
+def _case(rng):
+    T = int(rng.choice([1, 2, 7, 31, 59, 200, 365, 366, 730, 800]))
+    cells = tuple(int(v) for v in rng.choice([1, 2, 3, 4, 5, 8, 13, 64], size=int(rng.integers(1, 3))))
+    nanf = float(rng.choice([0.0, 0.0, 0.02, 0.3]))
+    start = str(rng.choice(["2000-01-01", "2001-03-15", "1999-12-31", "2004-02-28"]))
+    return T, cells, nanf, start
+
+
+def _axes(start, T):
+    return TimeAxis.daily(start, T, "standard"), OTime.standard(start, T)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_counts_and_reductions(dev, seed):
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(6):
+        T, cells, nanf, start = _case(rng)
+        ta, ot = _axes(start, T)
+        x = rng.integers(-3, 4, (T,) + cells).astype(np.float32) + rng.choice([0.0, 0.25]).astype(np.float32)
+        x[rng.random(x.shape) < nanf] = np.nan
+        freq = str(rng.choice(FREQS))
+        op = str(rng.choice(OPS[:4]))
+        thr = float(rng.choice([-1.0, 0.0, 0.25, 1.0]))
+        np.testing.assert_array_equal(xgen.threshold_count(x, op, thr, ta, freq, device=dev), ogen.threshold_count(x, op, thr, ot, freq),
+                                      err_msg=f"threshold_count T={T} cells={cells} {freq} {op} {thr}")
+        red = str(rng.choice(["sum", "mean", "min", "max", "std", "var", "count"]))
+        got = xgen.select_resample_op(x, red, ta, freq, device=dev)
+        ref = ogen.select_resample_op(x, red, ot, freq)
+        np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-6, equal_nan=True, err_msg=f"resample {red} T={T} {cells} {freq}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_run_length_family(dev, seed):
+    rng = np.random.default_rng(2000 + seed)
+    for _ in range(6):
+        T, cells, nanf, start = _case(rng)
+        ta, ot = _axes(start, T)
+        p_on = float(rng.choice([0.1, 0.5, 0.9]))
+        m = (rng.random((T,) + cells) < p_on).astype(np.float32)
+        m[rng.random(m.shape) < nanf] = np.nan
+        freq = rng.choice(FREQS + [None])
+        freq = None if freq is None else str(freq)
+        window = int(rng.integers(1, 8))
+        index = str(rng.choice(["first", "last"]))
+        tag = f"T={T} cells={cells} nan={nanf} freq={freq} w={window} index={index}"
+        for red in ("max", "min", "sum", "count", "mean", "std"):
+            got = xrl.rle_statistics(m, red, window, freq=freq, time=ta, index=index, device=dev)
+            ref = orl.rle_statistics(m, red, window, time=ot, freq=freq, index=index)
+            np.testing.assert_allclose(got, ref, rtol=1e-6, atol=0, err_msg=f"rle_statistics {red} {tag}")
+        np.testing.assert_array_equal(xrl.rle(m, index=index, device=dev), orl.rle(m, index=index), err_msg=f"rle {tag}")
+        np.testing.assert_array_equal(xrl.windowed_run_count(m, window, freq=freq, time=ta, index=index, device=dev),
+                                      orl.windowed_run_count(m, window, time=ot, freq=freq, index=index), err_msg=f"wrc {tag}")
+        np.testing.assert_array_equal(xrl.windowed_run_events(m, window, freq=freq, time=ta, index=index, device=dev),
+                                      orl.windowed_run_events(m, window, time=ot, freq=freq, index=index), err_msg=f"wre {tag}")
+        mb = np.nan_to_num(m) > 0
+        np.testing.assert_array_equal(xrl.first_run(mb, window, freq=freq, time=ta, device=dev), orl.first_run(mb, window, time=ot, freq=freq),
+                                      err_msg=f"first_run {tag}")
+        np.testing.assert_array_equal(xrl.last_run(mb, window, freq=freq, time=ta, device=dev), orl.last_run(mb, window, time=ot, freq=freq),
+                                      err_msg=f"last_run {tag}")
+        ws, wt = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        np.testing.assert_array_equal(xrl.runs_with_holes(mb, ws, ~mb, wt, device=dev), orl.runs_with_holes(mb, ws, ~mb, wt), err_msg=f"holes {tag}")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_spells_and_percentiles(dev, seed):
+    rng = np.random.default_rng(3000 + seed)
+    for _ in range(4):
+        T, cells, nanf, start = _case(rng)
+        ta, ot = _axes(start, T)
+        x = rng.gamma(0.6, 3.0, (T,) + cells).astype(np.float32) * (rng.random((T,) + cells) < 0.6)
+        x = x.astype(np.float32)
+        x[rng.random(x.shape) < nanf] = np.nan
+        window = int(rng.integers(1, 7))
+        red = str(rng.choice(["min", "max", "sum", "mean"]))
+        op = str(rng.choice([">", ">=", "<", "<="]))
+        thr = float(rng.choice([0.0, 1.0, 3.0]))
+        gap = int(rng.choice([1, 1, 2, 4]))
+        tag = f"T={T} cells={cells} w={window} {red} {op} {thr} gap={gap}"
+        np.testing.assert_array_equal(xgen.spell_mask(x, window, red, op, thr, min_gap=gap, device=dev),
+                                      ogen.spell_mask(x, window, red, op, thr, min_gap=gap), err_msg=f"spell_mask {tag}")
+        freq = str(rng.choice(FREQS))
+        for sr in ("max", "sum", "count"):
+            before = bool(rng.integers(0, 2))
+            np.testing.assert_array_equal(
+                xgen.spell_length_statistics(x, thr, window, red, op, sr, ta, freq, min_gap=gap, resample_before_rl=before, device=dev),
+                ogen.spell_length_statistics(x, thr, window, red, op, sr, ot, freq, before, gap), err_msg=f"sls {sr} {tag} {freq} {before}")
+        if T >= 365:
+            w = int(rng.choice([3, 5, 7, 9]))
+            per = [float(v) for v in rng.choice([1.0, 10.0, 25.0, 50.0, 75.0, 90.0, 99.0], size=2, replace=False)]
+            p = percentile_doy(x, ta, window=w, per=per, device=dev)
+            exp, doys = ocal.percentile_doy(x, ot, w, per)
+            np.testing.assert_allclose(p.values(), exp, rtol=1e-12, atol=0, equal_nan=True, err_msg=f"percentile_doy T={T} w={w} per={per}")

@@ -314,6 +314,16 @@ def test_doy_interp(dev, rng):
     i0, i1, dxn, dxs = doy_interp_tables(365, 366, 1)
     out = K.doy_interp(dev, dev.to_device(src, dtype=np.float64), i0, i1, dxn, dxs).get()
     np.testing.assert_allclose(out, exp, rtol=1e-13, atol=0, equal_nan=True)
+    # a doy that never occurs in the series (365 days from Feb 28 of a leap year: no doy 58): interpolate_na works in
+    # the dayofyear COORDINATE, so the NaN gap next to the missing doy is filled with non-uniform weights
+    doys = np.array([d for d in range(1, 366) if d != 58], dtype=np.float64)
+    src2 = rng.normal(280, 5, (364, C))
+    src2[54:58, 7] = np.nan  # doys 55, 56, 57, 59
+    src2[56, 8] = np.nan
+    exp2, _ = ocal.interpolate_doy_calendar(src2, doys, 366, 1)
+    i0, i1, dxn, dxs = doy_interp_tables(364, 366, 1)
+    out2 = K.doy_interp(dev, dev.to_device(src2, dtype=np.float64), i0, i1, dxn, dxs, xsrc=doys).get()
+    np.testing.assert_allclose(out2, exp2, rtol=1e-13, atol=0, equal_nan=True)
 
 
 @pytest.mark.parametrize("T,C", [(365, 100), (40, 7), (1000, 33), (5000, 6), (10950, 5)])

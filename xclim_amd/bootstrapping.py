@@ -58,7 +58,7 @@ def _percentile_table(dev, x_base, tb, doys, tbase_axis, window, per, alpha, bet
         i0, i1, dxn, dxs = doy_interp_tables(nsrc, max_t, min_t)
         src = dev.wrap(p.ptr, (nsrc, C), np.float64)
         src._owner = p
-        return K.doy_interp(dev, src, i0, i1, dxn, dxs), np.arange(min_t, max_t + 1)
+        return K.doy_interp(dev, src, i0, i1, dxn, dxs, xsrc=doys[doys < 366]), np.arange(min_t, max_t + 1)
     return p.reshape(nd, C), doys
 
 

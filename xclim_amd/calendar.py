@@ -86,7 +86,7 @@ def percentile_doy(arr, time: TimeAxis, window: int = 5, per=10.0, alpha: float 
         out = dev.empty((nper, len(i0), C), np.float64)
         for j in range(nper):
             src = dev.wrap(p.ptr + j * nd * C * 8, (nsrc, C), np.float64)  # rows 0..nsrc-1 are doys < 366
-            res = K.doy_interp(dev, src, i0, i1, dxn, dxs)
+            res = K.doy_interp(dev, src, i0, i1, dxn, dxs, xsrc=doys[keep])  # interpolate_na in the doy coordinate
             dev.call("xh_memcpy_d2d", out.ptr + j * len(i0) * C * 8, res.ptr, res.nbytes)
             dev.sync()
         p = out
@@ -124,7 +124,7 @@ def adjust_doy_calendar(source: DoyPercentile, target_time: TimeAxis, device=Non
     out = dev.empty((nper, len(i0), C), np.float64)
     for j in range(nper):
         src = dev.wrap(source.data.ptr + j * nd * C * 8, (nd, C), np.float64)
-        res = K.doy_interp(dev, src, i0, i1, dxn, dxs)
+        res = K.doy_interp(dev, src, i0, i1, dxn, dxs, xsrc=source.dayofyear)
         dev.call("xh_memcpy_d2d", out.ptr + j * len(i0) * C * 8, res.ptr, res.nbytes)
         dev.sync()
     return DoyPercentile(out, np.arange(min_t, max_t + 1), source.percentiles, source.cell_shape, source.attrs)

@@ -620,21 +620,23 @@ k_pdoy_merge(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
 __global__ void __launch_bounds__(XH_BLOCK)
 k_doy_interp(const double* __restrict__ in, int D_in, int64_t C, const int32_t* __restrict__ i0,
              const int32_t* __restrict__ i1, const double* __restrict__ dxn, const double* __restrict__ dxs, int D_out,
-             double* __restrict__ out, double* __restrict__ filled) {
+             double* __restrict__ out, double* __restrict__ filled, const double* __restrict__ xsrc) {
   int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
   if (c >= C) return;
-  // pass 1: interpolate_na along doy (source coordinate = row index; uniform spacing, so index weights are exact
-  // enough: (d - a) / (b - a) with integer a, b, d)
+  // pass 1: interpolate_na along doy.  xarray interpolates in the dayofyear COORDINATE (use_coordinate=True), which is
+  // not uniform when a doy is absent from the series (e.g. 365 days starting on Feb 28 of a leap year never see doy 58):
+  // xsrc[d] holds the coordinate of source row d (NULL: row index).
   int last = -1;
   double lastv = 0.0;
   for (int d = 0; d < D_in; ++d) {
     double v = in[(int64_t)d * C + c];
     if (v == v) {
       if (last >= 0 && d - last > 1) {
+        const double xl = xsrc ? xsrc[last] : (double)last, xd = xsrc ? xsrc[d] : (double)d;
         for (int g = last + 1; g < d; ++g) {
           // np.interp form: slope * (x - xlo) + ylo
-          double slope = (v - lastv) / (double)(d - last);
-          filled[(int64_t)g * C + c] = slope * (double)(g - last) + lastv;
+          double slope = (v - lastv) / (xd - xl);
+          filled[(int64_t)g * C + c] = slope * ((xsrc ? xsrc[g] : (double)g) - xl) + lastv;
         }
       } else if (last < 0) {
         for (int g = 0; g < d; ++g) filled[(int64_t)g * C + c] = xh_nan64();
@@ -985,7 +987,7 @@ int xh_nan_quantile(xh_ctx* ctx, const float* x, int64_t N, int64_t C, int64_t s
 }
 
 int xh_doy_interp(xh_ctx* ctx, const double* in, int D_in, int64_t C, const int32_t* i0, const int32_t* i1,
-                  const double* dxn, const double* dxs, int D_out, double* out) {
+                  const double* dxn, const double* dxs, int D_out, double* out, const double* xsrc) {
   XH_REQUIRE(ctx && in && i0 && i1 && dxn && dxs && out, XH_ERR_ARG, "xh_doy_interp: NULL argument");
   XH_REQUIRE(D_in >= 1 && D_out >= 1 && C >= 0, XH_ERR_ARG, "xh_doy_interp: bad shape");
   for (int j = 0; j < D_out; ++j)
@@ -1001,11 +1003,16 @@ int xh_doy_interp(xh_ctx* ctx, const double* in, int D_in, int64_t C, const int3
   if (rc) return rc;
   rc = xh_scratch_upload(ctx, &cur, dxs, sizeof(double) * D_out, &d_s);
   if (rc) return rc;
+  void* d_x = nullptr;
+  if (xsrc) {
+    rc = xh_scratch_upload(ctx, &cur, xsrc, sizeof(double) * D_in, &d_x);
+    if (rc) return rc;
+  }
   rc = xh_big_scratch(ctx, sizeof(double) * (size_t)D_in * (size_t)C, &filled);
   if (rc) return rc;
   hipLaunchKernelGGL(k_doy_interp, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, in, D_in, C,
                      (const int32_t*)d_i0, (const int32_t*)d_i1, (const double*)d_w, (const double*)d_s, D_out, out,
-                     (double*)filled);
+                     (double*)filled, (const double*)d_x);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

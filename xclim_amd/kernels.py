@@ -378,16 +378,19 @@ def percentile_doy_count(dev: Device, x: DeviceArray, tbase, window: int, per: f
     return cnt, val
 
 
-def doy_interp(dev: Device, table: DeviceArray, i0, i1, dxn, dxs) -> DeviceArray:
-    """table (D_in, C) float64 -> (D_out, C) float64 (xh_doy_interp)."""
+def doy_interp(dev: Device, table: DeviceArray, i0, i1, dxn, dxs, xsrc=None) -> DeviceArray:
+    """table (D_in, C) float64 -> (D_out, C) float64 (xh_doy_interp).  `xsrc`: dayofyear coordinate of the source rows for
+    the interpolate_na step (None: uniform)."""
     D_in, C_ = _tc(table)
+    xs = None if xsrc is None else np.ascontiguousarray(xsrc, dtype=np.float64)
+    assert xs is None or len(xs) == D_in
     i0 = np.ascontiguousarray(i0, dtype=np.int32)
     i1 = np.ascontiguousarray(i1, dtype=np.int32)
     dxn = np.ascontiguousarray(dxn, dtype=np.float64)
     dxs = np.ascontiguousarray(dxs, dtype=np.float64)
     out = dev.empty((len(i0), C_), np.float64)
     dev.call("xh_doy_interp", _vp(table.ptr), D_in, C_, np_ptr(i0), np_ptr(i1), np_ptr(dxn), np_ptr(dxs), len(i0),
-             _vp(out.ptr))
+             _vp(out.ptr), np_ptr(xs) if xs is not None else _vp(0))
     return out
 
 
