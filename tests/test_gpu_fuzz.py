@@ -111,3 +111,72 @@ def test_fuzz_spells_and_percentiles(dev, seed):
             p = percentile_doy(x, ta, window=w, per=per, device=dev)
             exp, doys = ocal.percentile_doy(x, ot, w, per)
             np.testing.assert_allclose(p.values(), exp, rtol=1e-12, atol=0, equal_nan=True, err_msg=f"percentile_doy T={T} w={w} per={per}")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_seasons_events_quantiles(dev, seed):
+    from oracle import sdba as osdba
+    from xclim_amd import kernels as K
+
+    rng = np.random.default_rng(4000 + seed)
+    for _ in range(4):
+        T, cells, nanf, start = _case(rng)
+        ta, ot = _axes(start, T)
+        p_on = float(rng.choice([0.2, 0.5, 0.8, 1.0, 0.0]))
+        cond = rng.random((T,) + cells) < p_on
+        window = int(rng.integers(1, 7))
+        mid = rng.choice(["07-01", "01-15", "12-31", None])
+        mid = None if mid is None else str(mid)
+        tag = f"T={T} cells={cells} start={start} p_on={p_on} w={window} mid={mid}"
+        # seasons per year (rl:891-1145); a period that does not contain the date gives NaN / 0
+        got = xrl.season(cond, window, mid, time=ta, freq="YS", device=dev)
+        es, ee, el = orl.season_per_period(cond, window, mid, ot, "YS")
+        np.testing.assert_array_equal(got["start"], es, err_msg=f"season start {tag}")
+        np.testing.assert_array_equal(got["end"], ee, err_msg=f"season end {tag}")
+        np.testing.assert_array_equal(got["length"], el, err_msg=f"season length {tag}")
+        # event tables (rl:1760-1901)
+        ws, wt = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        data = rng.gamma(2.0, 2.0, (T,) + cells).astype(np.float32)
+        data[rng.random(data.shape) < nanf] = np.nan
+        g = xrl.find_events(cond, ws, None, wt, data=data, device=dev)
+        r = orl.find_events(cond, ws, None, wt, data=data)
+        for k in r:
+            np.testing.assert_allclose(g[k], r[k], rtol=1e-6, equal_nan=True, err_msg=f"find_events {k} {tag} ws={ws} wt={wt}")
+        np.testing.assert_array_equal(xrl.run_bounds(cond, device=dev), orl.run_bounds(cond), err_msg=f"run_bounds {tag}")
+        np.testing.assert_array_equal(xrl.keep_longest_run(cond, device=dev), orl.keep_longest_run(cond), err_msg=f"keep_longest {tag}")
+        # full-series quantiles (E1) on the same shapes, both layouts
+        x = rng.normal(0, 1, (T, int(np.prod(cells)))).astype(np.float32)
+        x[rng.random(x.shape) < nanf] = np.nan
+        nq = int(rng.choice([1, 5, 20, 50]))
+        q = osdba.equally_spaced_nodes(nq)
+        exp = osdba.quantile(x, q)
+        np.testing.assert_allclose(K.quantile_series(dev, dev.to_device(x), q).get(), exp, rtol=1e-6, atol=0, equal_nan=True,
+                                   err_msg=f"quantile_series {tag} nq={nq}")
+        np.testing.assert_allclose(K.quantile_series(dev, dev.to_device(np.ascontiguousarray(x.T)), q, time_axis=1).get(), exp,
+                                   rtol=1e-6, atol=0, equal_nan=True, err_msg=f"quantile_series T-minor {tag} nq={nq}")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_multi_year_percentiles(dev, seed):
+    rng = np.random.default_rng(5000 + seed)
+    for _ in range(3):
+        nyears = int(rng.choice([2, 3, 7, 12, 31]))
+        cal = str(rng.choice(["standard", "noleap"]))
+        start = str(rng.choice(["1980-01-01", "1991-07-01", "2000-03-01"]))
+        T = int(365.25 * nyears) + int(rng.integers(-40, 40))
+        cells = (int(rng.choice([1, 3, 8])), int(rng.choice([1, 5])))
+        x = (280 + 10 * np.sin(np.arange(T)[:, None, None] / 58.0) + rng.normal(0, 3, (T,) + cells)).astype(np.float32)
+        x[rng.random(x.shape) < float(rng.choice([0.0, 0.01, 0.2]))] = np.nan
+        if cal == "standard":
+            ta, ot = TimeAxis.daily(start, T, "standard"), OTime.standard(start, T)
+        else:
+            if not start.endswith("01-01"):
+                start = start[:4] + "-01-01"  # (the oracle's noleap axis starts on Jan 1)
+            ta, ot = TimeAxis.daily(start, T, "noleap"), OTime.noleap(int(start[:4]), T)
+        w = int(rng.choice([3, 5, 7, 9]))
+        per = sorted(float(v) for v in rng.choice([1.0, 5.0, 10.0, 50.0, 90.0, 95.0, 99.0], size=int(rng.integers(1, 4)), replace=False))
+        p = percentile_doy(x, ta, window=w, per=per, device=dev)
+        exp, doys = ocal.percentile_doy(x, ot, w, per)
+        np.testing.assert_array_equal(p.dayofyear, doys)
+        np.testing.assert_allclose(p.values(), exp, rtol=1e-12, atol=0, equal_nan=True,
+                                   err_msg=f"percentile_doy nyears={nyears} cal={cal} start={start} T={T} w={w} per={per}")
