@@ -180,3 +180,55 @@ def test_fuzz_multi_year_percentiles(dev, seed):
         np.testing.assert_array_equal(p.dayofyear, doys)
         np.testing.assert_allclose(p.values(), exp, rtol=1e-12, atol=0, equal_nan=True,
                                    err_msg=f"percentile_doy nyears={nyears} cal={cal} start={start} T={T} w={w} per={per}")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_eqm_and_two_variable_reductions(dev, seed):
+    from oracle import sdba as osdba
+    from xclim_amd import kernels as K
+    from xclim_amd.calendar import climatological_mean_doy
+
+    rng = np.random.default_rng(6000 + seed)
+    for _ in range(3):
+        T, cells, nanf, start = _case(rng)
+        if T < 20:
+            T = 120
+        ta, ot = _axes(start, T)
+        C = int(np.prod(cells))
+        ref = rng.normal(10, 3, (T, C)).astype(np.float32)
+        hist = (rng.normal(11, 4, (T, C))).astype(np.float32)
+        sim = (rng.normal(12, 4, (T, C))).astype(np.float32)
+        for a in (ref, hist, sim):
+            a[rng.random(a.shape) < nanf * 0.3] = np.nan
+        nq = int(rng.choice([5, 10, 20, 32]))
+        kind = str(rng.choice(["+", "*"]))
+        eaf, ehq = osdba.eqm_train(ref, hist, nq, kind)
+        af, hq = K.eqm_train(dev, dev.to_device(ref), dev.to_device(hist), osdba.equally_spaced_nodes(nq), kind)
+        np.testing.assert_allclose(hq.get(), ehq, rtol=1e-6, equal_nan=True, err_msg=f"hist_q T={T} C={C} nq={nq}")
+        eaf32, ehq32 = eaf.astype(np.float32), ehq.astype(np.float32)
+        for interp in ("nearest", "linear", "cubic"):
+            if interp == "cubic" and (nq < 4 or np.isnan(ehq32).any() or (np.diff(ehq32, axis=0) <= 0).any()):
+                continue  # scipy's cubic needs >= 4 strictly increasing nodes
+            extrap = str(rng.choice(["constant", "nan"]))
+            got = K.eqm_adjust(dev, dev.to_device(sim), dev.to_device(eaf32), dev.to_device(ehq32), kind, interp, extrap).get()
+            exp = osdba.eqm_adjust(sim, eaf32, ehq32, kind, interp, extrap)
+            np.testing.assert_allclose(got, exp, rtol=2e-6, atol=0, equal_nan=True, err_msg=f"adjust {interp} {extrap} {kind} T={T} C={C} nq={nq}")
+        # two-variable range reductions
+        lo = ref.reshape((T,) + cells)
+        hi = (ref + np.abs(hist)).reshape((T,) + cells)
+        freq = str(rng.choice(FREQS))
+        for red in ("max", "min", "mean", "sum"):
+            np.testing.assert_allclose(xgen.diurnal_temperature_range(lo, hi, red, ta, freq, device=dev),
+                                       ogen.diurnal_temperature_range(lo, hi, red, ot, freq), rtol=1e-6, atol=1e-5 if red == "sum" else 0,
+                                       equal_nan=True, err_msg=f"dtr {red} T={T} {cells} {freq}")
+        np.testing.assert_allclose(xgen.interday_diurnal_temperature_range(lo, hi, ta, freq, device=dev),
+                                   ogen.interday_diurnal_temperature_range(lo, hi, ot, freq), rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(xgen.extreme_temperature_range(lo, hi, ta, freq, device=dev),
+                                   ogen.extreme_temperature_range(lo, hi, ot, freq), rtol=1e-6, equal_nan=True)
+        if T >= 365:
+            w = int(rng.choice([3, 5, 7, 9]))
+            m, s, doys = climatological_mean_doy(lo, ta, window=w, device=dev)
+            em, es, ed = ocal.climatological_mean_doy(lo, ot, w)
+            np.testing.assert_array_equal(doys, ed)
+            np.testing.assert_allclose(m, em, rtol=1e-6, equal_nan=True, err_msg=f"doy mean T={T} w={w}")
+            np.testing.assert_allclose(s, es, rtol=2e-6, atol=1e-6, equal_nan=True, err_msg=f"doy std T={T} w={w}")
