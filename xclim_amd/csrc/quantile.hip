@@ -262,12 +262,26 @@ k_pdoy_slide(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int6
     if (uniform && fast != 0) {
       // every percentile clips to the sample maximum / minimum (utl:443-452): no sort at all
       double r[VEC];
+      float rf[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         uint32_t m = win[v][0];
 #pragma unroll
         for (int k = 1; k < W; ++k) m = (fast == 2) ? (win[v][k] < m ? win[v][k] : m) : (win[v][k] > m ? win[v][k] : m);
-        r[v] = (double)xh_key2f(m);
+        rf[v] = xh_key2f(m);
+        r[v] = (double)rf[v];
+      }
+      if (COUNT) {
+        // the percentile IS a float32 sample here, so the fp64 compare of the general path is exactly an fp32 compare
+        // (no conversions, mask-form operator); the window is full: every value is valid
+        const int p = doy_period[d];
+        if (p != cper) { flush_counts(); cper = p; }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          ccnt[v] += xh_cmp_f32(xh_key2f(centre[v]), op, rf[v]) ? 1 : 0;
+          cval[v] += 1;
+        }
+        return;
       }
       for (int j = 0; j < nper; ++j) emit(d, j, r, centre);
       return;
