@@ -6,9 +6,16 @@
 // Sample set of (doy row d, cell c): for every year y with tb = tbase[y*ndoy + d] >= 0 the `window` values
 // x[tb - window/2 + k], k = 0..window-1 (NaN outside [0, T)); years lacking the day contribute NaNs
 // (rolling(center=True, min_periods=1).construct + unstack/stack, cal:448-458).  N = nyears * window samples.
-//   N <= 32 : samples gathered into registers, bitonic network on order-preserving uint32 keys  (k_pdoy_reg)
-//   N  > 32 : lane-private LDS column, bitonic network in LDS (no cross-lane traffic, no barriers) (k_pdoy_lds)
-// Time-major layout, one lane per cell (VEC cells in the register path); neighbouring doys re-read rows from L2.
+// Kernels, chosen on the host (pdoy_impl):
+//   one contiguous year, window 3/5/7  : k_pdoy_slide   sliding register ring, every row read once (the tx90p benchmark);
+//                                         COUNT variant fuses the exceedance count (xh_percentile_doy_count)
+//   N <= 32 samples                    : k_pdoy_reg     gather into registers, bitonic network on uint32 keys
+//   multi-year, regular doys           : k_pdoy_top16   (pdoy_top.hip) register top-16 of the W day-sets, for percentiles
+//                                         whose order statistics lie within the 16 largest / smallest samples
+//                                        k_pdoy_merge   per-day sorted lists in a compact LDS ring + W-way tail merge (other
+//                                         percentiles; OFFSET variant: exact window lists for irregular doys, e.g. Feb 29)
+//   anything else (N <= 640)           : k_pdoy_lds     lane-private LDS column, bitonic network in LDS
+// Time-major layout, one lane per cell (VEC cells in the sliding kernel).
 #include <stdlib.h>
 
 #include <type_traits>

@@ -1,14 +1,17 @@
 // select.hip — exact multi-quantile selection per column (xsdba nbutils.quantile; E1 of SURVEY.md §8a).
 //
-// A full sort is ~30x more work than the 2*nq order statistics need.  Per column (one wave for T <= 2048, one
-// workgroup above) the samples are held in registers as order-preserving uint32 keys and go through ONE counting
-// pass of an MSD radix sort over the key range [kmin, kmax]:
+// A full sort is ~30x more work than the 2*nq order statistics need.  The samples of a column are held as
+// order-preserving uint32 keys and go through ONE counting pass of an MSD radix sort over the key range [kmin, kmax]:
 //   1. histogram of NB linear-in-key bins in LDS (ds atomics), exclusive scan -> bin offsets;
 //   2. scatter keys to their bin's slot range (grouped by bin, unordered inside a bin);
 //   3. each target rank (prev/next of every quantile) finds its bin by binary search in the offsets and selects
 //      exactly inside the bin (typically 1-3 keys; all-equal bins — e.g. dry days — short-circuit).
 // Binning uses integer arithmetic on the keys, hence is monotone and exact; duplicates and NaNs (excluded, counted)
-// are handled.  ~20 VALU ops + 2 LDS atomics per sample instead of ~200+ for a bitonic network.
+// are handled.  Kernels by series length (xh_select_columns / xh_select_time_major):
+//   T <= 512          k_select_grp      32 (time-major, rows staged coalesced through an LDS tile) or 64 lanes per column
+//   512 < T <= 1024   k_select_quantile one wave per column, column in LDS
+//   1024 < T <= 16384 k_select_lean     (select2.hip) one workgroup per column, keys in registers, list-free
+//   T > 16384         k_select_quantile 1024-thread workgroups, column in LDS
 #include <stdlib.h>
 
 #include "common.h"
