@@ -252,3 +252,41 @@ def test_range_reductions_known_answers():
     assert ogen.extreme_temperature_range(low, high, t, "YS")[0, 0] == 9
     ev = ogen.get_daily_events(high[:, 0], 283.5, ">")
     assert np.isnan(ev[3]) and ev[:3].sum() == 0 and ev[4:].sum() == 6
+
+
+def test_sdba_oracle_against_numpy_and_the_reference_testqm():
+    """The EQM oracle is a SPECIFIED restatement (xsdba is not in the tree).  What can be pinned without it:
+    (1) nbutils.quantile is documented as equivalent to np.nanquantile (linear / Hyndman-Fan type 7): the restatement
+        must agree with numpy's own implementation;
+    (2) the reference's only numeric test of the path (tests/test_xsdba.py:113-155, TestQM.test_quantiles: train on
+        hist ~ U(10, 11), ref ~ N(12, 1), 50 quantiles, adjust with interp="linear", compare to 1 decimal in the interior),
+        restated on the oracle for both kinds."""
+    from scipy.stats import norm, uniform
+
+    from oracle import sdba as osdba
+
+    rng = np.random.default_rng(42)
+    x = rng.normal(0, 1, (500, 7)).astype(np.float32)
+    x[rng.random(x.shape) < 0.1] = np.nan
+    x[:, 3] = np.nan
+    q = osdba.equally_spaced_nodes(20)
+    with np.errstate(all="ignore"):
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            ref_np = np.nanquantile(x.astype(np.float64), q, axis=0)
+    np.testing.assert_allclose(osdba.quantile(x, q), ref_np, rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(q, (np.arange(20) + 0.5) / 20)
+
+    u = rng.random(10000)
+    xs = uniform.ppf(u, loc=10, scale=1)
+    ys = norm.ppf(u, loc=12, scale=1)
+    for kind in ("+", "*"):
+        af, hq = osdba.eqm_train(ys[:, None].astype(np.float32), xs[:, None].astype(np.float32), 50, kind)
+        qq = osdba.equally_spaced_nodes(50)
+        expected = (norm.ppf(qq, 12, 1) - uniform.ppf(qq, 10, 1)) if kind == "+" else (norm.ppf(qq, 12, 1) / uniform.ppf(qq, 10, 1))
+        np.testing.assert_array_almost_equal(af[2:-2, 0], expected[2:-2], 1)
+        p = osdba.eqm_adjust(xs[:, None].astype(np.float32), af, hq, kind, "linear", "constant")
+        middle = (u > 1e-2) & (u < 0.99)
+        np.testing.assert_array_almost_equal(p[middle, 0], ys[middle], 1)
