@@ -73,3 +73,27 @@ def cold_spell_duration_index(tasmin, tasmin_per, per_doys, time: OTime, window=
     thresh = ocal.resample_doy(tasmin_per, per_doys, time)
     below = ogen.compare(tasmin, op, thresh, constrain=("<", "<="))
     return rl.resample_and_rl(below, resample_before_rl, rl.windowed_run_count, time=time, freq=freq, window=window)
+
+
+# ---- index-level compositions (indices/_threshold.py etc.), units stripped --------------------------------------------
+def count_days(da, op, thresh, time: OTime, freq, constrain=None):
+    """tx_days_above / dry_days / wetdays / ice_days ...: threshold_count (indices/_threshold.py:2626-2628)."""
+    return ogen.threshold_count(da, op, thresh, time, freq, constrain=constrain)
+
+
+def run_index(da, op, thresh, fn, window, time: OTime, freq, resample_before_rl=True, constrain=None):
+    """hot/cold spell indices: compare -> rl.resample_and_rl(cond, before, fn, window, freq) (indices/_threshold.py:2341-2349)."""
+    from . import run_length as rl
+
+    cond = ogen.compare(da, op, thresh, constrain)
+    f = {"events": rl.windowed_run_events, "count": rl.windowed_run_count}[fn]
+    return rl.resample_and_rl(cond, resample_before_rl, f, time=time, freq=freq, window=window)
+
+
+def longest_run_index(da, op, thresh, window, time: OTime, freq, resample_before_rl=True):
+    """hot_spell_max_length (indices/_threshold.py:2213-2227): longest_run, zeroed below `window`."""
+    from . import run_length as rl
+
+    cond = ogen.compare(da, op, thresh)
+    max_l = rl.resample_and_rl(cond, resample_before_rl, rl.longest_run, time=time, freq=freq)
+    return np.where(max_l >= window, max_l, 0)

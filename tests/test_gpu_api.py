@@ -472,3 +472,56 @@ def test_ensemble_percentiles(dev, rng, method, R):
     np.testing.assert_allclose(got[0], [0, (R - 1) / 2, R - 1], rtol=1e-12)
     with pytest.raises(NotImplementedError):
         xens.ensemble_percentiles(ens, weights=np.ones(R), device=dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("calendar,T", [("standard", 1461), ("noleap", 800)])
+def test_index_level_callers(dev, rng, calendar, T):
+    """Index functions of indices/_threshold.py, _simple.py, _multivariate.py as compositions over the hot path."""
+    tas = _temp(rng, T, (4, 5), nan_frac=0.003)
+    tas += np.repeat(rng.normal(0, 4.0, (T // 5 + 1, 4, 5)), 5, axis=0)[:T].astype(np.float32)
+    tn = tas - np.abs(rng.normal(4, 1.5, tas.shape)).astype(np.float32)
+    tx = tas + np.abs(rng.normal(4, 1.5, tas.shape)).astype(np.float32)
+    pr = (rng.gamma(0.5, 4.0, tas.shape) * (rng.random(tas.shape) < 0.5)).astype(np.float32)
+    ta, ot = _axes("2000-01-01", T, calendar)
+    kw = dict(device=dev, mask_missing=False)
+    for freq in ("YS", "MS"):
+        np.testing.assert_array_equal(xi.tx_days_above(tx, 295.0, ta, freq, **kw), oidx.count_days(tx, ">", 295.0, ot, freq))
+        np.testing.assert_array_equal(xi.tn_days_below(tn, 270.0, ta, freq, "<=", **kw), oidx.count_days(tn, "<=", 270.0, ot, freq))
+        np.testing.assert_array_equal(xi.ice_days(tx, 273.15, ta, freq, **kw), oidx.count_days(tx, "<", 273.15, ot, freq))
+        np.testing.assert_array_equal(xi.dry_days(pr, 0.2, ta, freq, **kw), oidx.count_days(pr, "<", 0.2, ot, freq))
+        np.testing.assert_array_equal(xi.wetdays(pr, 1.0, ta, freq, **kw), oidx.count_days(pr, ">=", 1.0, ot, freq))
+        for before in (True, False):
+            np.testing.assert_array_equal(xi.hot_spell_frequency(tx, 292.0, ta, 3, freq, ">", before, **kw),
+                                          oidx.run_index(tx, ">", 292.0, "events", 3, ot, freq, before))
+            np.testing.assert_array_equal(xi.hot_spell_total_length(tx, 292.0, ta, 3, freq, ">", before, **kw),
+                                          oidx.run_index(tx, ">", 292.0, "count", 3, ot, freq, before))
+            np.testing.assert_array_equal(xi.hot_spell_max_length(tx, 292.0, ta, 4, freq, ">", before, **kw),
+                                          oidx.longest_run_index(tx, ">", 292.0, 4, ot, freq, before))
+            np.testing.assert_array_equal(xi.cold_spell_days(tas, 275.0, ta, 5, freq, "<", before, **kw),
+                                          oidx.run_index(tas, "<", 275.0, "count", 5, ot, freq, before))
+            np.testing.assert_array_equal(xi.cold_spell_frequency(tas, 275.0, ta, 5, freq, "<", before, **kw),
+                                          oidx.run_index(tas, "<", 275.0, "events", 5, ot, freq, before))
+            np.testing.assert_array_equal(xi.maximum_consecutive_tx_days(tx, 290.0, ta, freq, before, **kw),
+                                          oidx.longest_run_index(tx, ">", 290.0, 1, ot, freq, before))
+        np.testing.assert_allclose(xi.growing_degree_days(tas, 277.15, ta, freq, **kw), ogen.cumulative_difference(tas, 277.15, ">", ot, freq),
+                                   rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(xi.heating_degree_days(tas, 290.15, ta, freq, **kw), ogen.cumulative_difference(tas, 290.15, "<", ot, freq),
+                                   rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(xi.daily_temperature_range(tn, tx, ta, freq, "mean", **kw),
+                                   ogen.diurnal_temperature_range(tn, tx, "mean", ot, freq), rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(xi.daily_temperature_range_variability(tn, tx, ta, freq, **kw),
+                                   ogen.interday_diurnal_temperature_range(tn, tx, ot, freq), rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(xi.extreme_temperature_range(tn, tx, ta, freq, **kw),
+                                   ogen.extreme_temperature_range(tn, tx, ot, freq), rtol=1e-6, equal_nan=True)
+    cond = ogen.compare(tas, ">=", 278.15)
+    es, ee, el = orl.season_per_period(cond, 6, "07-01", ot, "YS")
+    np.testing.assert_array_equal(xi.growing_season_length(tas, 278.15, ta, 6, "07-01", "YS", device=dev), el)
+    with pytest.raises(ValueError):
+        xi.tx_days_above(tx, 295.0, ta, "YS", "<", device=dev)
+    # the MissingAny mask at index level: a period with a NaN day is NaN
+    masked = xi.hot_spell_frequency(tx, 292.0, ta, 3, "MS", device=dev)
+    seg, _ = ta.segments("MS")
+    has_nan = np.stack([np.isnan(tx[a:b]).any(axis=0) for a, b in zip(seg[:-1], seg[1:])])
+    incomplete = (np.diff(seg) != ta.expected_count("MS")).reshape((-1,) + (1,) * (tx.ndim - 1))  # e.g. a partial last month
+    np.testing.assert_array_equal(np.isnan(masked), has_nan | incomplete)

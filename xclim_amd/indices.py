@@ -167,3 +167,163 @@ def frost_days(tasmin, time: TimeAxis, thresh: float = 273.15, freq: str = "YS",
     dev = device or get_device()
     cnt, val = generic.threshold_count(tasmin, "<", float(thresh), time, freq, device=dev, keep=True, with_valid=True)
     return _masked(cnt, val, time, freq, dev, _cells(tasmin), mask_missing)
+
+
+# ---- index-level callers of the hot path (indices/_threshold.py, _simple.py, _multivariate.py) -------------------------
+# Thin compositions like the reference's own index functions (unit conversion is host / pint work and stays outside:
+# thresholds are numbers in the units of the data).  Every one returns (P, *cells) with the MissingAny mask applied.
+def _count_index(da, thresh, op, constrain, time, freq, device, mask_missing):
+    dev = device or get_device()
+    cnt, val = generic.threshold_count(da, op, thresh, time, freq, constrain=constrain, device=dev, keep=True, with_valid=True)
+    return _masked(cnt, val, time, freq, dev, _cells(da), mask_missing)
+
+
+def tx_days_above(tasmax, thresh: float, time: TimeAxis, freq: str = "YS", op: str = ">", *, device=None, mask_missing=True):
+    """indices/_threshold.py:2590-2628 (and tn_/tg_days_above :2422-2546)."""
+    return _count_index(tasmax, thresh, op, (">", ">="), time, freq, device, mask_missing)
+
+
+tn_days_above = tg_days_above = tx_days_above
+
+
+def tx_days_below(tasmax, thresh: float, time: TimeAxis, freq: str = "YS", op: str = "<", *, device=None, mask_missing=True):
+    """indices/_threshold.py:2632-2670 (and tn_/tg_days_below :2464-2588)."""
+    return _count_index(tasmax, thresh, op, ("<", "<="), time, freq, device, mask_missing)
+
+
+tn_days_below = tg_days_below = tx_days_below
+
+
+def ice_days(tasmax, thresh: float, time: TimeAxis, freq: str = "YS", *, device=None, mask_missing=True):
+    """indices/_simple.py:412-443: days with tasmax < thresh."""
+    return _count_index(tasmax, thresh, "<", None, time, freq, device, mask_missing)
+
+
+def dry_days(pr, thresh: float, time: TimeAxis, freq: str = "YS", op: str = "<", *, device=None, mask_missing=True):
+    """indices/_threshold.py:756-795."""
+    return _count_index(pr, thresh, op, ("<", "<="), time, freq, device, mask_missing)
+
+
+def wetdays(pr, thresh: float, time: TimeAxis, freq: str = "YS", op: str = ">=", *, device=None, mask_missing=True):
+    """indices/_threshold.py:2749-2788."""
+    return _count_index(pr, thresh, op, (">", ">="), time, freq, device, mask_missing)
+
+
+def _run_index(da, thresh, op, constrain, stat, window, time, freq, resample_before_rl, device, mask_missing):
+    """compare -> resample_and_rl(run statistic): the compare is fused into the run-length kernel."""
+    dev = device or get_device()
+    sym = generic.get_op(op, constrain)
+    from .calendar import _flatten
+
+    x, cell_shape = _flatten(da, dev)
+    seg, _ = time.segments(freq)
+    out, val = K.run_stats(dev, x, stat, int(window), seg, cut=bool(resample_before_rl), fused_op=sym, thresh=float(thresh))
+    return _masked(out, val, time, freq, dev, cell_shape, mask_missing)
+
+
+def hot_spell_frequency(tasmax, thresh: float, time: TimeAxis, window: int = 3, freq: str = "YS", op: str = ">",
+                        resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_threshold.py:2291-2351: number of runs of at least `window` days above the threshold."""
+    return _run_index(tasmax, thresh, op, (">", ">="), "count", window, time, freq, resample_before_rl, device, mask_missing)
+
+
+def hot_spell_total_length(tasmax, thresh: float, time: TimeAxis, window: int = 3, freq: str = "YS", op: str = ">",
+                           resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_threshold.py:2232-2288: days that belong to such runs."""
+    return _run_index(tasmax, thresh, op, (">", ">="), "sum", window, time, freq, resample_before_rl, device, mask_missing)
+
+
+def hot_spell_max_length(tasmax, thresh: float, time: TimeAxis, window: int = 1, freq: str = "YS", op: str = ">",
+                         resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_threshold.py:2169-2228: longest run, 0 when shorter than `window` (max_l.where(max_l >= window, 0))."""
+    out = _run_index(tasmax, thresh, op, (">", ">="), "max", 1, time, freq, resample_before_rl, device, mask_missing)
+    with np.errstate(invalid="ignore"):
+        return np.where(out < window, np.where(np.isnan(out), out, 0.0), out)
+
+
+def cold_spell_days(tas, thresh: float, time: TimeAxis, window: int = 5, freq: str = "YS-JUL", op: str = "<",
+                    resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_threshold.py:158-213."""
+    return _run_index(tas, thresh, op, ("<", "<="), "sum", window, time, freq, resample_before_rl, device, mask_missing)
+
+
+def cold_spell_frequency(tas, thresh: float, time: TimeAxis, window: int = 5, freq: str = "YS-JUL", op: str = "<",
+                         resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_threshold.py:218-264."""
+    return _run_index(tas, thresh, op, ("<", "<="), "count", window, time, freq, resample_before_rl, device, mask_missing)
+
+
+def maximum_consecutive_tx_days(tasmax, thresh: float, time: TimeAxis, freq: str = "YS", resample_before_rl: bool = True, *,
+                                device=None, mask_missing=True):
+    """indices/_threshold.py:3003-3060: longest run of days with tasmax > thresh."""
+    return _run_index(tasmax, thresh, ">", None, "max", 1, time, freq, resample_before_rl, device, mask_missing)
+
+
+def maximum_consecutive_frost_days(tasmin, thresh: float, time: TimeAxis, freq: str = "YS-JUL", resample_before_rl: bool = True,
+                                   *, device=None, mask_missing=True):
+    """indices/_threshold.py:2837-2890: longest run of days with tasmin < thresh."""
+    return _run_index(tasmin, thresh, "<", None, "max", 1, time, freq, resample_before_rl, device, mask_missing)
+
+
+def _degree_days(tas, thresh, op, time, freq, device, mask_missing):
+    dev = device or get_device()
+    out, val = generic.cumulative_difference(tas, thresh, op, time, freq, device=dev, keep=True, with_valid=True)
+    return _masked(out, val, time, freq, dev, _cells(tas), mask_missing)
+
+
+def growing_degree_days(tas, thresh: float, time: TimeAxis, freq: str = "YS", *, device=None, mask_missing=True):
+    """indices/_threshold.py:938-971: sum of (tas - thresh) over the days above the threshold."""
+    return _degree_days(tas, thresh, ">", time, freq, device, mask_missing)
+
+
+def cooling_degree_days(tas, thresh: float, time: TimeAxis, freq: str = "YS", *, device=None, mask_missing=True):
+    """indices/_threshold.py:905-935."""
+    return _degree_days(tas, thresh, ">", time, freq, device, mask_missing)
+
+
+def heating_degree_days(tas, thresh: float, time: TimeAxis, freq: str = "YS", *, device=None, mask_missing=True):
+    """indices/_threshold.py:2127-2165: sum of (thresh - tas) over the days below the threshold."""
+    return _degree_days(tas, thresh, "<", time, freq, device, mask_missing)
+
+
+def daily_temperature_range(tasmin, tasmax, time: TimeAxis, freq: str = "YS", op: str = "mean", *, device=None,
+                            mask_missing=True):
+    """indices/_multivariate.py:514-558: `op` of (tasmax - tasmin) per period."""
+    dev = device or get_device()
+    out, val = generic.diurnal_temperature_range(tasmin, tasmax, op, time, freq, device=dev, keep=True, with_valid=True)
+    return _masked(out, val, time, freq, dev, _cells(tasmin), mask_missing)
+
+
+def daily_temperature_range_variability(tasmin, tasmax, time: TimeAxis, freq: str = "YS", *, device=None, mask_missing=True):
+    """indices/_multivariate.py:561-598: mean absolute day-to-day change of the diurnal range."""
+    dev = device or get_device()
+    out, val = generic.interday_diurnal_temperature_range(tasmin, tasmax, time, freq, device=dev, keep=True, with_valid=True)
+    return _masked(out, val, time, freq, dev, _cells(tasmin), mask_missing)
+
+
+def extreme_temperature_range(tasmin, tasmax, time: TimeAxis, freq: str = "YS", *, device=None, mask_missing=True):
+    """indices/_multivariate.py:601-630: max(tasmax) - min(tasmin) per period."""
+    dev = device or get_device()
+    out, val = generic.extreme_temperature_range(tasmin, tasmax, time, freq, device=dev, keep=True, with_valid=True)
+    return _masked(out, val, time, freq, dev, _cells(tasmin), mask_missing)
+
+
+def growing_season_length(tas, thresh: float, time: TimeAxis, window: int = 6, mid_date: str | None = "07-01",
+                          freq: str = "YS", op: str = ">=", *, device=None):
+    """indices/_threshold.py:1096-1160 -> generic.season(..., stat="length")."""
+    generic.get_op(op, (">", ">="))
+    return generic.season(tas, thresh, window, op, time, freq, mid_date, device=device)["length"]
+
+
+def growing_season_start(tas, thresh: float, time: TimeAxis, mid_date: str | None = "07-01", window: int = 5,
+                         freq: str = "YS", op: str = ">=", *, device=None):
+    """indices/_threshold.py:975-1026 -> day of year of the season start (NaN without a season)."""
+    generic.get_op(op, (">", ">="))
+    return generic.season(tas, thresh, window, op, time, freq, mid_date, device=device)["start"]
+
+
+def growing_season_end(tas, thresh: float, time: TimeAxis, mid_date: str | None = "07-01", window: int = 5,
+                       freq: str = "YS", op: str = ">=", *, device=None):
+    """indices/_threshold.py:1029-1092 -> day of year of the season end."""
+    generic.get_op(op, (">", ">="))
+    return generic.season(tas, thresh, window, op, time, freq, mid_date, device=device)["end"]
