@@ -30,7 +30,7 @@ def main(src, dst):
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] != cname:
                     continue
-                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
                 agg[k][0] += 1
                 agg[k][1] += float(r["Counter_Value"])
         for k, (n, v) in agg.items():
