@@ -131,6 +131,7 @@ k_runs_with_holes_fwd(const float* __restrict__ a, const float* __restrict__ b, 
 }
 
 // ---- keep_longest_run (per period) -----------------------------------------------------------------------------
+template <int VEC>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_keep_longest_run(const float* __restrict__ x, int64_t C, int64_t st, const int64_t* __restrict__ seg_off, int P,
                    float* __restrict__ out, int64_t out_st) {
@@ -138,25 +139,65 @@ k_keep_longest_run(const float* __restrict__ x, int64_t C, int64_t st, const int
   // first one with the largest FULL length (it may extend past the period end; only its part inside the period is
   // marked); the leading part of a run that started in an earlier period is never marked (NaN == max is False).
   // Quirk restated (rl:826-833): a period without any run start marks its first non-run element.
-  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  // One backward march over the whole series (rows loaded once, in double-buffered batches).  Whether step t + 1 starts
+  // a run is known when step t has been seen, so every step is resolved one step late; a period is written out (vector
+  // stores, no loads) as soon as its first step has been resolved.
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
-  int rem = 0;  // remaining run length from t on (backward march over the whole series)
-  for (int p = P - 1; p >= 0; --p) {
-    int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
-    int best = 0;
-    int64_t best_start = -1, first_zero = -1;
-    for (int64_t t = t1 - 1; t >= t0; --t) {
-      bool on = x[t * st + c] > 0.0f;
-      rem = on ? rem + 1 : 0;
-      bool prev_on = t > 0 && (x[(t - 1) * st + c] > 0.0f);
-      if (on && !prev_on && rem >= best) { best = rem; best_start = t; }  // >=: earlier start wins ties
-      if (!on) first_zero = t;
-    }
+  int rem[VEC], prem[VEC], best[VEC];
+  int64_t best_start[VEC], first_zero[VEC];
+  bool pon[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { rem[v] = 0; prem[v] = 0; best[v] = 0; best_start[v] = -1; first_zero[v] = -1; pon[v] = false; }
+  int pc = P - 1;          // period of the pending step
+  int64_t pt = -1;         // pending step (-1: none)
+  int64_t pc0 = seg_off[pc];  // first step of period pc (kept in a register: a scalar load per step would stall)
+  auto prev_period = [&]() { pc--; pc0 = pc >= 0 ? seg_off[pc] : -1; };
+  auto write_period = [&](int p) {
+    const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
     for (int64_t t = t0; t < t1; ++t) {
-      bool m = best > 0 ? (t >= best_start && t < best_start + best) : (t == first_zero);
-      out[t * out_st + c] = m ? 1.0f : 0.0f;
+      float r[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const bool m = best[v] > 0 ? (t >= best_start[v] && t < best_start[v] + best[v]) : (t == first_zero[v]);
+        r[v] = m ? 1.0f : 0.0f;
+      }
+      if (VEC == 4) *reinterpret_cast<float4*>(out + t * out_st + c) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+      else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) out[t * out_st + c + v] = r[v];
+      }
     }
-  }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { best[v] = 0; best_start[v] = -1; first_zero[v] = -1; }
+  };
+  // resolve the pending step given whether the step before it is on; close its period when it was the period's first step
+  auto resolve = [&](const bool (&before_on)[VEC]) {
+    if (pt < 0) return;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+      if (pon[v] && !before_on[v] && prem[v] >= best[v]) { best[v] = prem[v]; best_start[v] = pt; }  // >=: earlier start wins ties
+    if (pt == pc0) { write_period(pc); prev_period(); }
+  };
+  xh_march_rows_rev<VEC, 8>(x + c, st, seg_off[0], seg_off[P], [&](int64_t t, const VecF<VEC>& xv) {
+    bool on[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) on[v] = xv.v[v] > 0.0f;
+    resolve(on);
+    while (pc >= 0 && t < pc0) { write_period(pc); prev_period(); }  // empty periods
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      rem[v] = on[v] ? rem[v] + 1 : 0;
+      if (!on[v]) first_zero[v] = t;
+      pon[v] = on[v]; prem[v] = rem[v];
+    }
+    pt = t;
+  });
+  bool none[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) none[v] = false;
+  resolve(none);
+  while (pc >= 0) { write_period(pc); prev_period(); }
 }
 
 // ---- season (per period) -------------------------------------------------------------------------------------
@@ -464,8 +505,12 @@ int xh_keep_longest_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64
   if (rc) return rc;
   if (C == 0) return XH_OK;
   XH_REQUIRE(seg_off[0] == 0 && seg_off[P] == T, XH_ERR_ARG, "xh_keep_longest_run: segments must cover [0, T)");
-  hipLaunchKernelGGL(k_keep_longest_run, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, C, st,
-                     d_seg, P, out, out_st);
+  if (xh_pick_vec(x, C, st) == 4 && xh_pick_vec(out, C, out_st) == 4 && cdiv64(cdiv64(C, 4), XH_BLOCK) >= 2 * (int64_t)ctx->num_cu)
+    hipLaunchKernelGGL((k_keep_longest_run<4>), dim3((unsigned)cdiv64(cdiv64(C, 4), XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, C,
+                       st, d_seg, P, out, out_st);
+  else
+    hipLaunchKernelGGL((k_keep_longest_run<1>), dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, C, st,
+                       d_seg, P, out, out_st);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }
