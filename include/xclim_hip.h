@@ -314,6 +314,16 @@ int xh_within_bnds_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
 int xh_compare_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, const double* table,
                    int D, const int32_t* tidx, float* out, int64_t st_out);
 
+/* days_over_precip_thresh / fraction_over_precip_thresh (indices/_multivariate.py:1174-1232, 1236-1296) in one pass.
+ * tp = max(table[tidx[t]], thr) in float64 (a NaN percentile gives thr, `pr_per.where(pr_per > thresh, thresh)`); the table
+ * is the (D, C) float64 per-doy percentile, or D = 1 with tidx all 0 for a per-cell percentile.  op is > or >=.
+ *   n_over (P, C) int32 : days with x op tp (float64 compare)                      [may be NULL]
+ *   frac   (P, C) f32   : sum(x where x op tp) / sum(x where x op (float)thr)      [may be NULL]; 0/0 = NaN
+ *   valid_out           : per-period count of non-NaN x                            [may be NULL] */
+int xh_precip_over_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, double thr,
+                       const double* table, int D, const int32_t* tidx, const int64_t* seg_off, int P, float* frac,
+                       int32_t* n_over, int32_t* valid_out);
+
 /* ---- sdba empirical quantile mapping (E1-E4; xsdba >= 0.4.0, not in the reference tree) ------ */
 /* nbutils.quantile: per-cell NaN-aware type-7 quantiles of the whole series at nq nodes. out (nq, C) f32 */
 int xh_quantile_series(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,

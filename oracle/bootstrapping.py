@@ -48,8 +48,10 @@ def _replace_block(base, bloc_idx, src_idx, time: OTime):
     return out
 
 
-def bootstrap_exceedance(da, time: OTime, base_years, freq, op=">", window=5, per=90.0, alpha=1.0 / 3.0, beta=1.0 / 3.0):
-    """tx90p-style index with bootstrap=True.  Returns float64 (P, ...) counts (non-integer inside the base period)."""
+def bootstrap_exceedance(da, time: OTime, base_years, freq, op=">", window=5, per=90.0, alpha=1.0 / 3.0, beta=1.0 / 3.0,
+                         index_fn=None):
+    """tx90p-style index with bootstrap=True.  Returns float64 (P, ...) counts (non-integer inside the base period).
+    `index_fn(x, per, per_doys, time)` replaces the exceedance count (e.g. days_over_precip_thresh)."""
     da = np.asarray(da)
     y0, y1 = base_years
     in_base = (time.year >= y0) & (time.year <= y1)
@@ -67,6 +69,8 @@ def bootstrap_exceedance(da, time: OTime, base_years, freq, op=">", window=5, pe
     constrain = (">", ">=") if op in (">", ">=") else ("<", "<=")
 
     def index(x, t, p, doys):
+        if index_fn is not None:
+            return np.asarray(index_fn(x, p[..., 0], doys, t)).astype(np.float64)
         thresh = ocal.resample_doy(p[..., 0], doys, t)
         return ogen.threshold_count(x, op, thresh, t, freq, constrain=constrain).astype(np.float64)
 

@@ -97,3 +97,66 @@ def longest_run_index(da, op, thresh, window, time: OTime, freq, resample_before
     cond = ogen.compare(da, op, thresh)
     max_l = rl.resample_and_rl(cond, resample_before_rl, rl.longest_run, time=time, freq=freq)
     return np.where(max_l >= window, max_l, 0)
+
+
+# ---- wet-day percentile indices and the heat-wave family --------------------------------------------
+def _wet_percentile_threshold(pr_per, per_doys, thresh, time: OTime):
+    """indices/_multivariate.py:1223-1228: tp = pr_per.where(pr_per > thresh, thresh) (NaN -> thresh), broadcast to the
+    time axis when it carries a dayofyear coordinate (per_doys is not None)."""
+    pr_per = np.asarray(pr_per, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        tp = np.where(pr_per > thresh, pr_per, float(thresh))
+    if per_doys is not None:
+        tp = ocal.resample_doy(tp, per_doys, time)
+    return tp
+
+
+def days_over_precip_thresh(pr, pr_per, per_doys, time: OTime, thresh, freq="YS", op=">"):
+    """indices/_multivariate.py:1220-1232.  `pr_per`: (ndoy, ...) with `per_doys`, or (...) per cell (per_doys None)."""
+    tp = _wet_percentile_threshold(pr_per, per_doys, thresh, time)
+    return ogen.threshold_count(pr, op, tp, time, freq, constrain=(">", ">="))
+
+
+def fraction_over_precip_thresh(pr, pr_per, per_doys, time: OTime, thresh, freq="YS", op=">"):
+    """indices/_multivariate.py:1281-1296: sum of pr over the percentile threshold / sum of pr on wet days."""
+    pr = np.asarray(pr)
+    tp = _wet_percentile_threshold(pr_per, per_doys, thresh, time)
+    constrain = (">", ">=")
+    wet = np.where(ogen.compare(pr, op, float(thresh), constrain), pr, pr.dtype.type(0))
+    big = np.where(ogen.compare(pr, op, tp, constrain), pr, pr.dtype.type(0))
+    total = ogen._resample_reduce(wet, time, freq, lambda g: g.sum(axis=0))
+    over = ogen._resample_reduce(big, time, freq, lambda g: g.sum(axis=0))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return over / total
+
+
+def _heat_wave_cond(tasmin, tasmax, thresh_tasmin, thresh_tasmax, op):
+    constrain = (">", ">=")
+    return ogen.compare(tasmin, op, float(thresh_tasmin), constrain) & ogen.compare(tasmax, op, float(thresh_tasmax), constrain)
+
+
+def heat_wave_frequency(tasmin, tasmax, time: OTime, thresh_tasmin, thresh_tasmax, window=3, freq="YS", op=">",
+                        resample_before_rl=True):
+    """indices/_multivariate.py:701-715: windowed_run_events of (tasmin op a) & (tasmax op b)."""
+    from . import run_length as rl
+
+    cond = _heat_wave_cond(tasmin, tasmax, thresh_tasmin, thresh_tasmax, op)
+    return rl.resample_and_rl(cond, resample_before_rl, rl.windowed_run_events, time=time, freq=freq, window=window)
+
+
+def heat_wave_max_length(tasmin, tasmax, time: OTime, thresh_tasmin, thresh_tasmax, window=3, freq="YS", op=">",
+                         resample_before_rl=True):
+    """indices/_multivariate.py:781-794: rle_statistics(reducer="max", window)."""
+    from . import run_length as rl
+
+    cond = _heat_wave_cond(tasmin, tasmax, thresh_tasmin, thresh_tasmax, op)
+    return rl.resample_and_rl(cond, resample_before_rl, rl.rle_statistics, time=time, freq=freq, reducer="max", window=window)
+
+
+def heat_wave_total_length(tasmin, tasmax, time: OTime, thresh_tasmin, thresh_tasmax, window=3, freq="YS", op=">",
+                           resample_before_rl=True):
+    """indices/_multivariate.py:849-862: windowed_run_count."""
+    from . import run_length as rl
+
+    cond = _heat_wave_cond(tasmin, tasmax, thresh_tasmin, thresh_tasmax, op)
+    return rl.resample_and_rl(cond, resample_before_rl, rl.windowed_run_count, time=time, freq=freq, window=window)

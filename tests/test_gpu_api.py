@@ -525,3 +525,141 @@ def test_index_level_callers(dev, rng, calendar, T):
     has_nan = np.stack([np.isnan(tx[a:b]).any(axis=0) for a, b in zip(seg[:-1], seg[1:])])
     incomplete = (np.diff(seg) != ta.expected_count("MS")).reshape((-1,) + (1,) * (tx.ndim - 1))  # e.g. a partial last month
     np.testing.assert_array_equal(np.isnan(masked), has_nan | incomplete)
+
+
+def _precip(rng, T, shape, nan_frac=0.0):
+    """kg m-2 s-1 daily precipitation: ~55 % dry days, gamma-distributed wet days."""
+    wet = rng.random((T,) + shape) < 0.45
+    x = np.where(wet, rng.gamma(0.8, 6.0, (T,) + shape) / 86400.0, 0.0).astype(np.float32)
+    if nan_frac:
+        x[rng.random(x.shape) < nan_frac] = np.nan
+    return x
+
+
+@pytest.mark.parametrize("calendar,T", [("standard", 1461), ("noleap", 1095)])
+@pytest.mark.parametrize("op", [">", ">="])
+def test_precip_percentile_indices(dev, rng, calendar, T, op):
+    """days_over_precip_thresh / fraction_over_precip_thresh (indices/_multivariate.py:1174-1296): one
+    fused pass against max(percentile_doy row, wet-day threshold); counts bit-exact, fractions <= 1e-6 relative."""
+    pr = _precip(rng, T, (5, 6), nan_frac=0.003)
+    pr[:, 0, 0] = 0.0        # never wet: 0 / 0 -> NaN fraction
+    ta, ot = _axes("2000-01-01", T, calendar)
+    thresh = 1.0 / 86400.0   # the reference default "1 mm/day" in kg m-2 s-1; not representable in float32
+    p = percentile_doy(pr, ta, window=5, per=[75.0, 95.0], device=dev)
+    exp, doys = ocal.percentile_doy(pr, ot, 5, [75.0, 95.0])
+    for freq in ("YS", "MS"):
+        for j, q in enumerate((75.0, 95.0)):
+            got = xi.days_over_precip_thresh(pr, p.sel(q), ta, freq, op, thresh=thresh, device=dev, mask_missing=False)
+            ref = oidx.days_over_precip_thresh(pr, exp[..., j], doys, ot, thresh, freq, op)
+            np.testing.assert_array_equal(got, ref)
+            got = xi.fraction_over_precip_thresh(pr, p.sel(q), ta, freq, op, thresh=thresh, device=dev, mask_missing=False)
+            ref = oidx.fraction_over_precip_thresh(pr, exp[..., j], doys, ot, thresh, freq, op)
+            np.testing.assert_allclose(got, ref, rtol=1e-6, equal_nan=True)
+            assert np.isnan(got[:, 0, 0]).all() and np.nanmax(got) <= 1.0 and np.nanmin(got) >= 0.0
+    # a per-cell percentile (pr.quantile(q, dim="time") in the reference's tests/test_indices.py:1595-1614)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        cell = np.nanquantile(np.where(pr > thresh, pr, np.nan).astype(np.float64), 0.9, axis=0)
+    got = xi.days_over_precip_thresh(pr, cell, ta, "YS", op, thresh=thresh, device=dev, mask_missing=False)
+    np.testing.assert_array_equal(got, oidx.days_over_precip_thresh(pr, cell, None, ot, thresh, "YS", op))
+    got = xi.fraction_over_precip_thresh(pr, cell, ta, "MS", op, thresh=thresh, device=dev, mask_missing=False)
+    np.testing.assert_allclose(got, oidx.fraction_over_precip_thresh(pr, cell, None, ot, thresh, "MS", op), rtol=1e-6, equal_nan=True)
+    # MissingAny
+    masked = xi.days_over_precip_thresh(pr, p.sel(75.0), ta, "MS", op, thresh=thresh, device=dev)
+    seg, _ = ta.segments("MS")
+    has_nan = np.stack([np.isnan(pr[a:b]).any(axis=0) for a, b in zip(seg[:-1], seg[1:])])
+    np.testing.assert_array_equal(np.isnan(masked), has_nan)
+    with pytest.raises(ValueError):
+        xi.days_over_precip_thresh(pr, p.sel(75.0), ta, "YS", "<", thresh=thresh, device=dev)
+
+
+def test_precip_percentile_indices_reference_known_answers(dev):
+    """tests/test_indices.py:1579-1614 (TestDaysOverPrecipThresh) through the HIP path."""
+    from xclim_amd.calendar import DoyPercentile
+
+    a = np.zeros(365, dtype=np.float32)
+    a[:8] = np.arange(8)
+    ta = TimeAxis.daily("2000-01-01", 365)
+    per = np.zeros(366)
+    per[5:] = 5
+    table = dev.to_device(per.reshape(1, 366, 1))
+    p = DoyPercentile(table, np.arange(1, 367), [50.0], (), {})
+    assert xi.days_over_precip_thresh(a[:, None], p, ta, thresh=2.0, device=dev, mask_missing=False)[0, 0] == 4
+    f = xi.fraction_over_precip_thresh(a[:, None], p, ta, thresh=2.0, device=dev, mask_missing=False)
+    np.testing.assert_array_almost_equal(f[0, 0], (3 + 4 + 6 + 7) / (3 + 4 + 5 + 6 + 7))
+    assert xi.days_over_precip_thresh(a[:, None], np.array([5.0]), ta, thresh=2.0, device=dev, mask_missing=False)[0, 0] == 2
+    t300 = TimeAxis.daily("2000-01-01", 300)
+    out = xi.days_over_precip_thresh(np.ones((300, 2, 3), np.float32), np.zeros((2, 3)), t300, thresh=0.5, device=dev,
+                                     mask_missing=False)
+    np.testing.assert_array_equal(out, np.full((1, 2, 3), 300))
+    with pytest.raises(KeyError):  # tests/test_bootstrapping.py:77-86: bootstrap needs a day-of-year percentile
+        xi.days_over_precip_thresh(a[:, None], np.array([5.0]), ta, thresh=2.0, device=dev, bootstrap=True)
+
+
+@pytest.mark.parametrize("stat", ["count", "frac"])
+def test_precip_percentile_bootstrap(dev, rng, stat):
+    """tests/test_bootstrapping.py:38-40: days_over / fraction_over_precip_thresh with bootstrap=True ("MS")."""
+    from oracle import bootstrapping as oboot
+
+    T = 1461
+    pr = _precip(rng, T, (3, 4))
+    ta, ot = _axes("2000-01-01", T)
+    thresh = 1.0 / 86400.0
+    base = (2000, 2001)
+    b = ta.year <= 2001
+    nb = int(b.sum())
+    p = percentile_doy(pr[:nb], ta.subset(slice(0, nb)), window=5, per=98.0, device=dev)
+    f = xi.days_over_precip_thresh if stat == "count" else xi.fraction_over_precip_thresh
+    of = oidx.days_over_precip_thresh if stat == "count" else oidx.fraction_over_precip_thresh
+    got = f(pr, p, ta, "MS", thresh=thresh, device=dev, bootstrap=True)
+    exp = oboot.bootstrap_exceedance(pr, ot, base, "MS", ">", 5, 98.0,
+                                     index_fn=lambda x, pp, dd, t: of(x, pp, dd, t, thresh, "MS", ">"))
+    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0, equal_nan=True)
+    plain = f(pr, p, ta, "MS", thresh=thresh, device=dev, mask_missing=False)
+    out_base = ta.segments("MS")[0][:-1] >= nb
+    np.testing.assert_allclose(got[out_base], plain[out_base], rtol=1e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("before", [True, False])
+@pytest.mark.parametrize("op", [">", ">="])
+def test_heat_wave_indices(dev, rng, before, op):
+    """heat_wave_frequency / max_length / total_length (indices/_multivariate.py:640-862): bivariate daily condition
+    -> resample_and_rl(windowed_run_events | rle_statistics max | windowed_run_count); bit-exact."""
+    T = 1095
+    tn = _temp(rng, T, (5, 6), nan_frac=0.003) - 5.0
+    slow = np.repeat(rng.normal(0, 4.0, (T // 6 + 1, 5, 6)), 6, axis=0)[:T].astype(np.float32)
+    tn += slow
+    tx = tn + 8.0 + rng.normal(0, 1.5, tn.shape).astype(np.float32)
+    tx[rng.random(tx.shape) < 0.003] = np.nan
+    ta, ot = _axes("2001-01-01", T)
+    a, b = 22.0 + 273.15 - 8, 30.0 + 273.15 - 8   # not representable in float32
+    total = 0
+    for freq in ("YS", "MS", "QS-DEC"):
+        for window in (1, 3, 5):
+            for xf, of in ((xi.heat_wave_frequency, oidx.heat_wave_frequency), (xi.heat_wave_max_length, oidx.heat_wave_max_length),
+                           (xi.heat_wave_total_length, oidx.heat_wave_total_length)):
+                got = xf(tn, tx, ta, a, b, window, freq, op, before, device=dev, mask_missing=False)
+                ref = of(tn, tx, ot, a, b, window, freq, op, before)
+                np.testing.assert_array_equal(got, ref)
+                total += got.sum()
+    assert total > 0
+    masked = xi.heat_wave_total_length(tn, tx, ta, a, b, 3, "MS", op, before, device=dev)
+    seg, _ = ta.segments("MS")
+    has_nan = np.stack([(np.isnan(tn[s:e]) | np.isnan(tx[s:e])).any(axis=0) for s, e in zip(seg[:-1], seg[1:])])
+    np.testing.assert_array_equal(np.isnan(masked), has_nan)
+    with pytest.raises(ValueError):
+        xi.heat_wave_frequency(tn, tx, ta, a, b, op="<", device=dev)
+
+
+def test_heat_wave_indices_reference_known_answers(dev):
+    """tests/test_indices.py:1859-1960 through the HIP path."""
+    K2C = 273.15
+    tn = (np.asarray([20, 23, 23, 23, 23, 22, 23, 23, 23, 23]) + K2C).astype(np.float32)[:, None]
+    tx = (np.asarray([29, 31, 31, 31, 29, 31, 31, 31, 31, 31]) + K2C).astype(np.float32)[:, None]
+    ta = TimeAxis.daily("2000-01-01", 10)
+    kw = dict(device=dev, mask_missing=False)
+    for (a, b, w), f, m, tot in [((22, 30, 3), 2, 4, 7), ((10, 10, 3), 1, 10, 10), ((40, 40, 3), 0, 0, 0), ((22, 30, 4), 1, 4, 4),
+                                 ((22, 30, 5), 0, 0, 0)]:
+        assert xi.heat_wave_frequency(tn, tx, ta, a + K2C, b + K2C, w, **kw)[0, 0] == f
+        assert xi.heat_wave_max_length(tn, tx, ta, a + K2C, b + K2C, w, **kw)[0, 0] == m
+        assert xi.heat_wave_total_length(tn, tx, ta, a + K2C, b + K2C, w, **kw)[0, 0] == tot

@@ -290,3 +290,37 @@ def test_sdba_oracle_against_numpy_and_the_reference_testqm():
         p = osdba.eqm_adjust(xs[:, None].astype(np.float32), af, hq, kind, "linear", "constant")
         middle = (u > 1e-2) & (u < 0.99)
         np.testing.assert_array_almost_equal(p[middle, 0], ys[middle], 1)
+
+
+def test_wet_percentile_and_heat_wave_indices_known_answers():
+    """SURVEY 8f rank 1, pinned by the reference's own known answers:
+    tests/test_indices.py:1579-1614 (TestDaysOverPrecipThresh) and :1859-1960 (TestHeatWave{Frequency,MaxLength,TotalLength})."""
+    from oracle import indices as oidx
+    from oracle.timeutil import OTime
+
+    K2C = 273.15
+    a = np.zeros(365, dtype=np.float32)
+    a[:8] = np.arange(8)
+    t = OTime.standard("2000-01-01", 365)
+    per = np.zeros(366)
+    per[5:] = 5
+    doys = np.arange(1, 367)
+    assert oidx.days_over_precip_thresh(a, per, doys, t, 2.0)[0] == 4
+    np.testing.assert_array_almost_equal(oidx.fraction_over_precip_thresh(a, per, doys, t, 2.0)[0], (3 + 4 + 6 + 7) / (3 + 4 + 5 + 6 + 7))
+    # test_quantile: a per-cell percentile of 5 -> only days 6 and 7 qualify
+    assert oidx.days_over_precip_thresh(a, np.float64(5.0), None, t, 2.0)[0] == 2
+    # test_nd: pr = 1 everywhere, percentile 0 -> floored by the 0.5 wet-day threshold, all 300 days count
+    t300 = OTime.standard("2000-01-01", 300)
+    out = oidx.days_over_precip_thresh(np.ones((300, 2, 3), np.float32), np.zeros((2, 3)), None, t300, 0.5)
+    np.testing.assert_array_equal(out, np.full((1, 2, 3), 300))
+
+    tn = (np.asarray([20, 23, 23, 23, 23, 22, 23, 23, 23, 23]) + K2C).astype(np.float32)
+    tx = (np.asarray([29, 31, 31, 31, 29, 31, 31, 31, 31, 31]) + K2C).astype(np.float32)
+    t10 = OTime.standard("2000-01-01", 10)
+    for (a_, b_, w), f, m, tot in [((22, 30, 3), 2, 4, 7), ((10, 10, 3), 1, 10, 10), ((40, 40, 3), 0, 0, 0)]:
+        assert oidx.heat_wave_frequency(tn, tx, t10, a_ + K2C, b_ + K2C, w)[0] == f
+        assert oidx.heat_wave_max_length(tn, tx, t10, a_ + K2C, b_ + K2C, w)[0] == m
+        assert oidx.heat_wave_total_length(tn, tx, t10, a_ + K2C, b_ + K2C, w)[0] == tot
+    assert oidx.heat_wave_frequency(tn, tx, t10, 22 + K2C, 30 + K2C, 4)[0] == 1
+    assert oidx.heat_wave_max_length(tn, tx, t10, 22 + K2C, 30 + K2C, 5)[0] == 0
+    assert oidx.heat_wave_total_length(tn, tx, t10, 22 + K2C, 30 + K2C, 5)[0] == 0

@@ -63,8 +63,11 @@ def _percentile_table(dev, x_base, tb, doys, tbase_axis, window, per, alpha, bet
 
 
 def bootstrap_exceedance(da, time: TimeAxis, base_years: tuple[int, int], freq: str, op: str = ">", window: int = 5,
-                         per: float = 90.0, alpha: float = 1.0 / 3.0, beta: float = 1.0 / 3.0, *, device=None) -> np.ndarray:
+                         per: float = 90.0, alpha: float = 1.0 / 3.0, beta: float = 1.0 / 3.0, *, device=None, floor=None,
+                         stat: str = "count") -> np.ndarray:
     """`tx90p(..., bootstrap=True)`-style exceedance count (percentile_bootstrap + bootstrap_func, :22-211).
+    With `floor` (the wet-day threshold) the index is days_over_precip_thresh (stat "count") or
+    fraction_over_precip_thresh (stat "frac") instead: the percentile is floored by `floor` before the compare.
 
     `base_years` = (first, last) year of the percentile reference period (the `climatology_bounds` of the reference).
     Returns float64 (P, *cells): averaged counts for in-base years, plain counts elsewhere.
@@ -101,6 +104,9 @@ def bootstrap_exceedance(da, time: TimeAxis, base_years: tuple[int, int], freq: 
         tsub = time.subset(slice(t0, t1))
         seg, _ = tsub.segments(freq)
         pos = np.searchsorted(tdoys, tsub.doy).astype(np.int32)
+        if floor is not None:
+            cnt, frac, _ = K.precip_over_doy(dev, sub, sym, float(floor), table, pos, seg, want=(stat,), want_valid=False)
+            return (cnt if stat == "count" else frac).get().astype(np.float64)
         cnt, _ = K.threshold_count(dev, sub, sym, seg, doy_table=table, tidx=pos, want_valid=False)
         return cnt.get().astype(np.float64)
 
@@ -127,7 +133,7 @@ def bootstrap_exceedance(da, time: TimeAxis, base_years: tuple[int, int], freq: 
 
 
 def bootstrap_func(compute_index_func, da, per: DoyPercentile, time: TimeAxis, freq: str = "YS", op: str | None = None, *,
-                   device=None) -> np.ndarray:
+                   device=None, thresh=None) -> np.ndarray:
     """bootstrapping.py:81-211 for the percentile-exceedance indices (tx90p / tn10p ... families): the percentile
     reference period, window, alpha and beta are read from the attributes percentile_doy stored (cal:487-494) and the
     index of every in-base year is averaged over the n-1 replicas in which that year is replaced."""
@@ -140,7 +146,8 @@ def bootstrap_func(compute_index_func, da, per: DoyPercentile, time: TimeAxis, f
     if op is None:
         op = getattr(compute_index_func, "_default_op", ">")
     return bootstrap_exceedance(da, time, (int(str(b0)[:4]), int(str(b1)[:4])), freq, op, int(per.attrs["window"]),
-                                float(per.percentiles[0]), float(per.attrs["alpha"]), float(per.attrs["beta"]), device=device)
+                                float(per.percentiles[0]), float(per.attrs["alpha"]), float(per.attrs["beta"]), device=device,
+                                floor=thresh, stat=getattr(compute_index_func, "_bootstrap_stat", "count"))
 
 
 def percentile_bootstrap(func):
@@ -153,6 +160,8 @@ def percentile_bootstrap(func):
         if not bootstrap:
             return func(da, per, time, freq, *args, **kwargs)
         op = kwargs.get("op", args[0] if args else None)
-        return bootstrap_func(func, da, per, time, freq, op, device=kwargs.get("device"))
+        if not isinstance(per, DoyPercentile):
+            raise KeyError("`bootstrap` can only be used with percentiles computed by percentile_doy")  # bootstrapping.py:117-121
+        return bootstrap_func(func, da, per, time, freq, op, device=kwargs.get("device"), thresh=kwargs.get("thresh"))
 
     return wrapper

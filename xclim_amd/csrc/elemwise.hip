@@ -172,6 +172,54 @@ k_compare_doy(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int
   }
 }
 
+// days_over_precip_thresh / fraction_over_precip_thresh (indices/_multivariate.py:1220-1232, 1281-1296) in one pass:
+//   tp      = table[tidx[t]] > thr ? table[tidx[t]] : thr        (fp64; NaN percentile -> thr)
+//   n_over  = #(x op tp)  [fp64 compare],  over = sum of x where x op tp,  total = sum of x where x op (float)thr [fp32]
+//   frac    = (float)over / (float)total                         (0/0 = NaN like the reference)
+// The reference materialises tp as a (T, C) fp64 field and makes five passes; here x and the (D, C) table rows are read
+// once, in batches of 8 rows whose loads are issued before any use.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_precip_over_doy(const float* __restrict__ x, int64_t C, int64_t st, int op, double thr, const double* __restrict__ table,
+                  const int32_t* __restrict__ tidx, const int64_t* __restrict__ seg_off, int P, float* __restrict__ frac,
+                  int32_t* __restrict__ n_over, int32_t* __restrict__ valid) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  const float thr32 = (float)thr;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    double over = 0.0, total = 0.0;
+    int cnt = 0, nv = 0;
+    auto step = [&](float xv, double tv) {
+      const double tp = tv > thr ? tv : thr;
+      const bool o = xh_cmp_f64((double)xv, op, tp);
+      const bool w = xh_cmp_f32(xv, op, thr32);
+      over += o ? (double)xv : 0.0;
+      total += w ? (double)xv : 0.0;
+      cnt += o ? 1 : 0;
+      nv += (xv == xv) ? 1 : 0;
+    };
+    int64_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+      int r[8];
+      float xv[8];
+      double tv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = tidx[t + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = x[(t + u) * st + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tv[u] = table[(int64_t)r[u] * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) step(xv[u], tv[u]);
+    }
+    for (; t < t1; ++t) step(x[t * st + c], table[(int64_t)tidx[t] * C + c]);
+    const int64_t o = (int64_t)p * C + c;
+    if (frac) frac[o] = (float)over / (float)total;
+    if (n_over) n_over[o] = cnt;
+    if (valid) valid[o] = nv;
+  }
+}
+
 static dim3 time_chunk_grid(xh_ctx* ctx, int64_t T, int64_t C) {
   const int64_t cblocks = cdiv64(C, XH_BLOCK);
   int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
@@ -297,6 +345,36 @@ int xh_compare_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   if (rc) return rc;
   hipLaunchKernelGGL(k_compare_doy, time_chunk_grid(ctx, T, C), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, op, table, d_tidx,
                      out, st_out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_precip_over_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, double thr,
+                       const double* table, int D, const int32_t* tidx, const int64_t* seg_off, int P, float* frac,
+                       int32_t* n_over, int32_t* valid_out) {
+  XH_REQUIRE(ctx && x && table, XH_ERR_ARG, "xh_precip_over_doy: NULL argument");
+  XH_REQUIRE(frac || n_over, XH_ERR_ARG, "xh_precip_over_doy: at least one of frac / n_over is required");
+  XH_REQUIRE(T >= 0 && C >= 0 && D >= 1, XH_ERR_ARG, "xh_precip_over_doy: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_precip_over_doy: needs a time-major view (cell stride 1)");
+  XH_REQUIRE(op == XH_OP_GT || op == XH_OP_GE, XH_ERR_OP, "xh_precip_over_doy: operator must be > or >=");
+  XH_REQUIRE(seg_off && P >= 1, XH_ERR_ARG, "xh_precip_over_doy: seg_off NULL or P < 1");
+  for (int p = 0; p < P; ++p)
+    XH_REQUIRE(seg_off[p] <= seg_off[p + 1] && seg_off[p] >= 0 && seg_off[p + 1] <= T, XH_ERR_ARG,
+               "xh_precip_over_doy: seg_off must be non-decreasing within [0, T]");
+  XH_REQUIRE(tidx, XH_ERR_ARG, "xh_precip_over_doy: tidx is NULL");
+  for (int64_t t = 0; t < T; ++t)
+    XH_REQUIRE(tidx[t] >= 0 && tidx[t] < D, XH_ERR_ARG, "xh_precip_over_doy: tidx[%lld] = %d outside the table (D = %d)",
+               (long long)t, tidx[t], D);
+  size_t cur = 0;
+  void *d_tidx = nullptr, *d_seg = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, tidx, sizeof(int32_t) * (size_t)T, &d_tidx);
+  if (rc) return rc;
+  rc = xh_scratch_upload(ctx, &cur, seg_off, sizeof(int64_t) * (size_t)(P + 1), &d_seg);
+  if (rc) return rc;
+  if (C == 0) return XH_OK;
+  dim3 grid((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P));
+  hipLaunchKernelGGL(k_precip_over_doy, grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, op, thr, table, (const int32_t*)d_tidx,
+                     (const int64_t*)d_seg, P, frac, n_over, valid_out);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

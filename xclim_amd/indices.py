@@ -142,6 +142,87 @@ def cold_spell_duration_index(tasmin, tasmin_per: DoyPercentile, time: TimeAxis,
     return _percentile_spell(tasmin, tasmin_per, window, time, freq, resample_before_rl, op, ("<", "<="), device, mask_missing)
 
 
+def _precip_over(pr, pr_per, time, freq, thresh, op, want, device, mask_missing):
+    from .calendar import _flatten, adjust_doy_calendar, resample_doy_index
+
+    dev = device or get_device()
+    sym = generic.get_op(op, (">", ">="))
+    x, cell_shape = _flatten(pr, dev)
+    if isinstance(pr_per, DoyPercentile):  # one value per day of year: resample_doy is fused into the kernel
+        doy = adjust_doy_calendar(pr_per, time, dev)
+        if doy.data.shape[0] != 1:
+            raise ValueError("select one percentile first (DoyPercentile.sel)")
+        table = doy.data.reshape(doy.data.shape[1], doy.data.shape[2])
+        tidx = resample_doy_index(doy, time)
+    else:  # one value per cell (e.g. pr.quantile(q, dim="time"))
+        per = pr_per if hasattr(pr_per, "dev") else dev.to_device(np.ascontiguousarray(np.asarray(pr_per, dtype=np.float64).reshape(1, -1)))
+        table = per.reshape(1, x.shape[1]) if per.shape != (1, x.shape[1]) else per
+        tidx = np.zeros(len(time), dtype=np.int32)
+    seg, _ = time.segments(freq)
+    cnt, frac, val = K.precip_over_doy(dev, x, sym, float(thresh), table, tidx, seg, want=(want,))
+    return _masked(cnt if want == "count" else frac, val, time, freq, dev, cell_shape, mask_missing)
+
+
+def _days_over_precip_thresh(pr, pr_per, time: TimeAxis, freq: str = "YS", op: str = ">", *, thresh: float, device=None,
+                             mask_missing=True):
+    """indices/_multivariate.py:1174-1232: wet days (pr op thresh) whose precipitation is also over the percentile
+    `pr_per` (a DoyPercentile, or one value per cell).  `thresh` is a float in the units of `pr` (the reference default
+    "1 mm/day" is 1/86400 kg m-2 s-1).  ``bootstrap=True`` as in tx90p."""
+    return _precip_over(pr, pr_per, time, freq, thresh, op, "count", device, mask_missing)
+
+
+def _fraction_over_precip_thresh(pr, pr_per, time: TimeAxis, freq: str = "YS", op: str = ">", *, thresh: float, device=None,
+                                 mask_missing=True):
+    """indices/_multivariate.py:1236-1296: share of the wet-day precipitation that fell on days over the percentile."""
+    return _precip_over(pr, pr_per, time, freq, thresh, op, "frac", device, mask_missing)
+
+
+_days_over_precip_thresh._default_op = _fraction_over_precip_thresh._default_op = ">"
+_days_over_precip_thresh._bootstrap_stat, _fraction_over_precip_thresh._bootstrap_stat = "count", "frac"
+days_over_precip_thresh = percentile_bootstrap(_days_over_precip_thresh)
+fraction_over_precip_thresh = percentile_bootstrap(_fraction_over_precip_thresh)
+
+
+def _heat_wave(tasmin, tasmax, thresh_tasmin, thresh_tasmax, stat, window, time, freq, op, resample_before_rl, device,
+               mask_missing):
+    from .calendar import _flatten
+
+    dev = device or get_device()
+    sym = generic.get_op(op, (">", ">="))
+    tn, cell_shape = _flatten(tasmin, dev)
+    tx, cell_shape_x = _flatten(tasmax, dev)
+    if tuple(cell_shape) != tuple(cell_shape_x) or tn.shape != tx.shape:
+        raise ValueError("tasmin and tasmax must have the same shape")
+    seg, _ = time.segments(freq)
+    cond = K.spell_mask_multi(dev, [tn, tx], 1, None, sym, [float(thresh_tasmin), float(thresh_tasmax)], "all")
+    out, _ = K.run_stats(dev, cond, stat, int(window), seg, cut=bool(resample_before_rl), want_valid=False)
+    # MissingAny over both inputs (core/indicator.py `_mask`: logical_or of the per-variable masks)
+    _, val = K.bivariate_count(dev, tn, tx, sym, float(thresh_tasmin), sym, float(thresh_tasmax), "all", seg)
+    return _masked(out, val, time, freq, dev, cell_shape, mask_missing)
+
+
+def heat_wave_frequency(tasmin, tasmax, time: TimeAxis, thresh_tasmin: float, thresh_tasmax: float, window: int = 3,
+                        freq: str = "YS", op: str = ">", resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_multivariate.py:640-715: number of runs of at least `window` days with tasmin and tasmax both over their
+    thresholds (floats in the units of the data)."""
+    return _heat_wave(tasmin, tasmax, thresh_tasmin, thresh_tasmax, "count", window, time, freq, op, resample_before_rl, device,
+                      mask_missing)
+
+
+def heat_wave_max_length(tasmin, tasmax, time: TimeAxis, thresh_tasmin: float, thresh_tasmax: float, window: int = 3,
+                         freq: str = "YS", op: str = ">", resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_multivariate.py:718-794: longest such run (0 when none reaches `window` days)."""
+    return _heat_wave(tasmin, tasmax, thresh_tasmin, thresh_tasmax, "max", window, time, freq, op, resample_before_rl, device,
+                      mask_missing)
+
+
+def heat_wave_total_length(tasmin, tasmax, time: TimeAxis, thresh_tasmin: float, thresh_tasmax: float, window: int = 3,
+                           freq: str = "YS", op: str = ">", resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_multivariate.py:797-862: days that belong to such runs."""
+    return _heat_wave(tasmin, tasmax, thresh_tasmin, thresh_tasmax, "sum", window, time, freq, op, resample_before_rl, device,
+                      mask_missing)
+
+
 def _spell(da, thresh, op, reducer, time, freq, resample_before_rl, device, mask_missing):
     dev = device or get_device()
     out, val = generic.spell_length_statistics(da, thresh, 1, None, op, reducer, time, freq,

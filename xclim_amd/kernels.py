@@ -424,6 +424,22 @@ def compare_doy(dev: Device, x: DeviceArray, op: str, table: DeviceArray, tidx) 
     return out
 
 
+def precip_over_doy(dev: Device, x: DeviceArray, op: str, thr: float, table: DeviceArray, tidx, seg_off, want=("count",),
+                    want_valid=True):
+    """xh_precip_over_doy: (count | frac | both, valid) against max(table[tidx[t]], thr); table (D, C) float64."""
+    T, C_ = _tc(x)
+    D = table.shape[0]
+    tidx = np.ascontiguousarray(tidx, dtype=np.int32)
+    assert len(tidx) == T and table.shape == (D, C_) and table.dtype == np.float64
+    seg, P = _seg(seg_off)
+    cnt = dev.empty((P, C_), np.int32) if "count" in want else None
+    frac = dev.empty((P, C_), np.float32) if "frac" in want else None
+    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    dev.call("xh_precip_over_doy", _vp(x.ptr), T, C_, C_, 1, op_code(op), float(thr), _vp(table.ptr), D, np_ptr(tidx), np_ptr(seg),
+             P, _vp(frac.ptr if frac else 0), _vp(cnt.ptr if cnt else 0), _vp(valid.ptr if valid else 0))
+    return cnt, frac, valid
+
+
 def quantile_series(dev: Device, x: DeviceArray, q, time_axis=0, out=None) -> DeviceArray:
     """Per-cell quantiles of the whole series: x (T, C) [time_axis 0] or (C, T) [time_axis 1] -> (nq, C) float32."""
     q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
