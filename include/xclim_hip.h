@@ -104,6 +104,23 @@ int xh_timer_stop(xh_ctx* ctx, float* elapsed_ms); /* synchronises */
 /* raw hipStream_t of the context, for interop (e.g. ordering against RCCL collectives) */
 int xh_stream(xh_ctx* ctx, void** stream);
 
+/* ---- block adapter support (chunked host inputs streamed through the device; the reference's
+ * dask / map_blocks layer, indices/helpers.py:898-974, core/indicator.py:865-944) --------------------------------
+ * Pinned host memory (xh_host_alloc, or xh_host_register on caller memory) makes the strided copies below asynchronous
+ * and full PCIe rate.  Lanes: 0 = the compute stream every xh_* op runs on, 1 = copy-in stream, 2 = copy-out stream.
+ * xh_memcpy2d copies `height` rows of `width` bytes (pitches in bytes; a cell slab of a (T, C) host array is
+ * width = slab * 4, spitch = C * 4); kind 0 = host -> device, 1 = device -> host; blocking != 0 waits for the copy
+ * (required for pageable host memory).  xh_lane_fence(a, b): work queued on lane b from now on waits for everything
+ * queued on lane a so far.  xh_lane_sync: the host waits for the lane. */
+int xh_host_alloc(xh_ctx* ctx, size_t bytes, void** hptr);
+int xh_host_free(xh_ctx* ctx, void* hptr);
+int xh_host_register(xh_ctx* ctx, void* hptr, size_t bytes);
+int xh_host_unregister(xh_ctx* ctx, void* hptr);
+int xh_memcpy2d(xh_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int kind,
+                int lane, int blocking);
+int xh_lane_fence(xh_ctx* ctx, int from_lane, int to_lane);
+int xh_lane_sync(xh_ctx* ctx, int lane);
+
 /* ---- synthetic inputs: counter-based generator, restated in oracle/synth.py -- */
 /* out[t, c] = base[t] + amp * z(seed, t, cell0 + c),  z = sum of 4 hashed uniforms - 2 (var 1/3);
  * kind 0: temperature-like (as above); kind 1: precipitation-like (wet w.p. p_wet, amount = amp*u^3,

@@ -136,3 +136,19 @@ def test_synthetic_generator_is_counter_based():
     assert a.dtype == np.float32 and np.isnan(a).any() and abs(np.nanstd(a - base[:, None]) - 3.0 / np.sqrt(3)) < 0.1
     pr = synth.fill_synthetic(400, np.arange(64), 1, 3, np.zeros(400, np.float32), 40 / 86400.0, 0.3)
     assert 0.25 < (pr > 0).mean() < 0.35 and pr.min() == 0
+
+
+def test_cell_blocks_cover_and_align():
+    """blocks.py: slabs tile [0, C) in order, start on multiples of 4 cells, and the default width follows the byte target."""
+    from xclim_amd.blocks import cell_blocks, default_block_cells
+
+    for C, b in [(10, 4), (10, 5), (1003, 256), (1036800, 183856), (3, 1000), (8, 1)]:
+        bl = cell_blocks(C, b)
+        assert bl[0][0] == 0 and bl[-1][1] == C
+        assert all(a1 == b0 for (_, a1), (b0, _) in zip(bl[:-1], bl[1:]))
+        assert all(c0 % 4 == 0 and c1 > c0 for c0, c1 in bl)
+    assert cell_blocks(0, 4) == []
+    assert default_block_cells(365 * 4, 1036800) == 183856
+    assert default_block_cells(365 * 4, 100) == 100
+    with pytest.raises(ValueError):
+        cell_blocks(10, 0)

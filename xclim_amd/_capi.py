@@ -54,6 +54,13 @@ SIGNATURES: dict[str, list] = {
     "xh_memcpy_h2d": [_vp, _vp, _vp, _sz],
     "xh_memcpy_d2h": [_vp, _vp, _vp, _sz],
     "xh_memcpy_d2d": [_vp, _vp, _vp, _sz],
+    "xh_host_alloc": [_vp, _sz, C.POINTER(_vp)],
+    "xh_host_free": [_vp, _vp],
+    "xh_host_register": [_vp, _vp, _sz],
+    "xh_host_unregister": [_vp, _vp],
+    "xh_memcpy2d": [_vp, _vp, _sz, _vp, _sz, _sz, _sz, _int, _int, _int],
+    "xh_lane_fence": [_vp, _int, _int],
+    "xh_lane_sync": [_vp, _int],
     "xh_timer_start": [_vp],
     "xh_timer_stop": [_vp, C.POINTER(_flt)],
     "xh_stream": [_vp, C.POINTER(_vp)],
@@ -214,6 +221,7 @@ class Device:
         self._pool: dict[int, list[int]] = {}
         self._pool_bytes = 0
         self._pool_cap = int(os.environ.get("XCLIM_AMD_POOL_BYTES", str(32 << 30)))
+        self._pinned: dict[int, int] = {}  # page-locked host ranges we own or registered: address -> bytes
 
     # ---- memory ----
     def empty(self, shape, dtype) -> DeviceArray:
@@ -247,6 +255,56 @@ class Device:
         for ptrs in pool.values():
             for ptr in ptrs:
                 self.lib.xh_free(self.ctx, _vp(ptr))
+
+    # ---- pinned host memory + copy lanes (block adapter, blocks.py) ----
+    def pinned_empty(self, shape, dtype) -> np.ndarray:
+        """numpy array over page-locked host memory (xh_host_alloc): strided copies from / to it are asynchronous and run
+        at the full PCIe rate.  Freed when the array (and every view of it) is garbage collected."""
+        import weakref
+
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = _vp()
+        _check(self.lib, self.lib.xh_host_alloc(self.ctx, max(nbytes, 16), C.byref(p)))
+        buf = (C.c_char * max(nbytes, 16)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+        self._pinned[p.value] = max(nbytes, 16)
+        lib, ctx, pinned, addr = self.lib, self.ctx, self._pinned, p.value
+
+        def _free():
+            pinned.pop(addr, None)
+            if ctx:
+                lib.xh_host_free(ctx, _vp(addr))
+
+        weakref.finalize(buf, _free)
+        return arr
+
+    def register(self, arr: np.ndarray) -> None:
+        """Page-lock caller memory (hipHostRegister) for the lifetime of the registration; costs about as much as one
+        copy of the array, so it pays for inputs that are streamed more than once."""
+        assert arr.flags.c_contiguous
+        _check(self.lib, self.lib.xh_host_register(self.ctx, _vp(arr.ctypes.data), arr.nbytes))
+        self._pinned[arr.ctypes.data] = arr.nbytes
+
+    def unregister(self, arr: np.ndarray) -> None:
+        if self._pinned.pop(arr.ctypes.data, None) is not None:
+            _check(self.lib, self.lib.xh_host_unregister(self.ctx, _vp(arr.ctypes.data)))
+
+    def is_pinned(self, arr: np.ndarray) -> bool:
+        a0, a1 = arr.ctypes.data, arr.ctypes.data + arr.nbytes
+        return any(p <= a0 and a1 <= p + n for p, n in self._pinned.items())
+
+    def copy2d(self, dst: int, dpitch: int, src: int, spitch: int, width: int, height: int, kind: str, lane: int = 0,
+               blocking: bool = True) -> None:
+        """xh_memcpy2d: `height` rows of `width` bytes; kind "h2d" | "d2h"; lanes 0 compute / 1 copy-in / 2 copy-out."""
+        _check(self.lib, self.lib.xh_memcpy2d(self.ctx, _vp(dst), dpitch, _vp(src), spitch, width, height,
+                                              {"h2d": 0, "d2h": 1}[kind], lane, int(bool(blocking))))
+
+    def lane_fence(self, from_lane: int, to_lane: int) -> None:
+        _check(self.lib, self.lib.xh_lane_fence(self.ctx, from_lane, to_lane))
+
+    def lane_sync(self, lane: int) -> None:
+        _check(self.lib, self.lib.xh_lane_sync(self.ctx, lane))
 
     def zeros(self, shape, dtype) -> DeviceArray:
         a = self.empty(shape, dtype)

@@ -14,6 +14,10 @@ struct xh_ctx {
   // second stream + events: transposes of the next column batch run next to the selection of the current one
   hipStream_t stream2;
   hipEvent_t ev_ready[2], ev_done[2];
+  // copy lanes of the block adapter (xclim_amd/blocks.py): lane 1 = host -> device, lane 2 = device -> host; lane 0 is
+  // `stream`.  ev_lane is the fence event (record on one lane, wait on another).
+  hipStream_t copy_in, copy_out;
+  hipEvent_t ev_lane;
   // small device scratch for tables (seg_off, quantiles ...) uploaded per call: a RING shared by consecutive calls
   // with a pinned host mirror, so that uploads are asynchronous (no stream synchronisation per call)
   void* scratch;

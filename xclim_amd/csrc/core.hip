@@ -60,6 +60,9 @@ int xh_create(int device, xh_ctx** out) {
     XH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_ready[i], hipEventDisableTiming));
     XH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
   }
+  XH_CHECK_HIP(hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
+  XH_CHECK_HIP(hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
+  XH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_lane, hipEventDisableTiming));
   ctx->scratch_bytes = 8u << 20;
   XH_CHECK_HIP(hipMalloc(&ctx->scratch, ctx->scratch_bytes));
   XH_CHECK_HIP(hipHostMalloc((void**)&ctx->scratch_host, ctx->scratch_bytes, hipHostMallocDefault));
@@ -90,6 +93,11 @@ int xh_destroy(xh_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_done[i]);
   }
   (void)hipStreamDestroy(ctx->stream2);
+  (void)hipStreamSynchronize(ctx->copy_in);
+  (void)hipStreamSynchronize(ctx->copy_out);
+  (void)hipStreamDestroy(ctx->copy_in);
+  (void)hipStreamDestroy(ctx->copy_out);
+  (void)hipEventDestroy(ctx->ev_lane);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return XH_OK;
@@ -159,6 +167,62 @@ int xh_memcpy_d2d(xh_ctx* ctx, void* dst, const void* src, size_t bytes) {
   XH_REQUIRE(ctx && (bytes == 0 || (dst && src)), XH_ERR_ARG, "xh_memcpy_d2d: bad args");
   if (bytes == 0) return XH_OK;
   XH_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return XH_OK;
+}
+
+// ---- host memory + strided copies on the copy lanes (block adapter, xclim_amd/blocks.py) --------------------------------
+static hipStream_t lane_stream(xh_ctx* ctx, int lane) { return lane == 1 ? ctx->copy_in : lane == 2 ? ctx->copy_out : ctx->stream; }
+
+int xh_host_alloc(xh_ctx* ctx, size_t bytes, void** hptr) {
+  XH_REQUIRE(ctx && hptr, XH_ERR_ARG, "xh_host_alloc: bad args");
+  *hptr = nullptr;
+  if (bytes == 0) return XH_OK;
+  XH_CHECK_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+  return XH_OK;
+}
+
+int xh_host_free(xh_ctx* ctx, void* hptr) {
+  XH_REQUIRE(ctx, XH_ERR_ARG, "xh_host_free: ctx is NULL");
+  if (hptr) XH_CHECK_HIP(hipHostFree(hptr));
+  return XH_OK;
+}
+
+int xh_host_register(xh_ctx* ctx, void* hptr, size_t bytes) {
+  XH_REQUIRE(ctx && hptr && bytes > 0, XH_ERR_ARG, "xh_host_register: bad args");
+  XH_CHECK_HIP(hipHostRegister(hptr, bytes, hipHostRegisterDefault));
+  return XH_OK;
+}
+
+int xh_host_unregister(xh_ctx* ctx, void* hptr) {
+  XH_REQUIRE(ctx && hptr, XH_ERR_ARG, "xh_host_unregister: bad args");
+  XH_CHECK_HIP(hipHostUnregister(hptr));
+  return XH_OK;
+}
+
+int xh_memcpy2d(xh_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int kind,
+                int lane, int blocking) {
+  XH_REQUIRE(ctx, XH_ERR_ARG, "xh_memcpy2d: ctx is NULL");
+  XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "xh_memcpy2d: kind must be 0 (host -> device) or 1 (device -> host)");
+  XH_REQUIRE(lane >= 0 && lane <= 2, XH_ERR_ARG, "xh_memcpy2d: lane must be 0, 1 or 2");
+  if (width == 0 || height == 0) return XH_OK;
+  XH_REQUIRE(dst && src && dpitch >= width && spitch >= width, XH_ERR_ARG, "xh_memcpy2d: NULL pointer or pitch < width");
+  hipStream_t s = lane_stream(ctx, lane);
+  XH_CHECK_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, s));
+  if (blocking) XH_CHECK_HIP(hipStreamSynchronize(s));  // pageable host memory: do not return before it has been consumed
+  return XH_OK;
+}
+
+int xh_lane_fence(xh_ctx* ctx, int from_lane, int to_lane) {
+  XH_REQUIRE(ctx && from_lane >= 0 && from_lane <= 2 && to_lane >= 0 && to_lane <= 2, XH_ERR_ARG, "xh_lane_fence: bad args");
+  if (from_lane == to_lane) return XH_OK;
+  XH_CHECK_HIP(hipEventRecord(ctx->ev_lane, lane_stream(ctx, from_lane)));
+  XH_CHECK_HIP(hipStreamWaitEvent(lane_stream(ctx, to_lane), ctx->ev_lane, 0));
+  return XH_OK;
+}
+
+int xh_lane_sync(xh_ctx* ctx, int lane) {
+  XH_REQUIRE(ctx && lane >= 0 && lane <= 2, XH_ERR_ARG, "xh_lane_sync: bad args");
+  XH_CHECK_HIP(hipStreamSynchronize(lane_stream(ctx, lane)));
   return XH_OK;
 }
 
