@@ -331,6 +331,13 @@ int xh_within_bnds_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
 int xh_compare_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, const double* table,
                    int D, const int32_t* tidx, float* out, int64_t st_out);
 
+/* warm / cold_spell_duration_index with resample_before_rl (indices/_multivariate.py:66-152, 1693-1793) in one pass:
+ * xh_run_stats(cut_at_segments = 1) on the condition x[t] op table[tidx[t]] (fp64 compare, (D, C) float64 per-doy
+ * table), without materialising the mask.  stat: XH_RUN_MAX..XH_RUN_STD or XH_RUN_PLAINSUM. */
+int xh_run_stats_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, const double* table,
+                     int D, const int32_t* tidx, int window, int stat, const int64_t* seg_off, int P, float* out,
+                     int32_t* valid_out);
+
 /* days_over_precip_thresh / fraction_over_precip_thresh (indices/_multivariate.py:1174-1232, 1236-1296) in one pass.
  * tp = max(table[tidx[t]], thr) in float64 (a NaN percentile gives thr, `pr_per.where(pr_per > thresh, thresh)`); the table
  * is the (D, C) float64 per-doy percentile, or D = 1 with tidx all 0 for a per-cell percentile.  op is > or >=.

@@ -344,3 +344,36 @@ def test_runs_with_holes_long_windows_and_pool(dev, rng):
     dev.trim()
     z = dev.empty((1234, 7), np.float32)
     z.free()
+
+
+@pytest.mark.parametrize("T,C", [(730, 37), (365, 1024), (1461, 5)])
+@pytest.mark.parametrize("op", [">", "<=", "!="])
+def test_run_stats_doy_fused(dev, rng, T, C, op):
+    """xh_run_stats_doy == compare against the broadcast per-doy table, then run statistics cut at the period edges
+    (rl.resample_and_rl(..., resample_before_rl=True)); every reducer, ragged periods, an empty period, NaN in x and in
+    the table."""
+    from oracle import run_length as orl
+    from xclim_amd import kernels as K
+
+    x = rng.normal(0, 1, (T, C)).astype(np.float32)
+    x += np.repeat(rng.normal(0, 1.5, (T // 5 + 1, C)), 5, axis=0)[:T].astype(np.float32)
+    x[rng.random(x.shape) < 0.01] = np.nan
+    D = 366
+    table = rng.normal(0, 0.5, (D, C))
+    table[rng.random(table.shape) < 0.01] = np.nan
+    tidx = (np.arange(T) * 7 % D).astype(np.int32)
+    seg = np.array([0, 31, 31, 59, 200, T], dtype=np.int64)
+    dx, dt = dev.to_device(x), dev.to_device(table)
+    with np.errstate(invalid="ignore"):
+        cond = {">": np.greater, "<=": np.less_equal, "!=": np.not_equal}[op](x.astype(np.float64), table[tidx])
+    for stat in ("max", "min", "sum", "count", "mean", "std"):
+        for window in (1, 3):
+            got, val = K.run_stats_doy(dev, dx, op, dt, tidx, stat, window, seg)
+            exp = np.stack([orl.rle_statistics(cond[a:b], stat, window) if b > a else np.zeros(C)
+                            for a, b in zip(seg[:-1], seg[1:])])
+            np.testing.assert_allclose(got.get(), exp, rtol=1e-6, err_msg=f"{stat} w{window}")
+            two, _ = K.run_stats(dev, K.compare_doy(dev, dx, op, dt, tidx), stat, window, seg, cut=True, want_valid=False)
+            np.testing.assert_array_equal(got.get(), two.get())
+    np.testing.assert_array_equal(val.get(), np.stack([(~np.isnan(x[a:b])).sum(axis=0) for a, b in zip(seg[:-1], seg[1:])]))
+    with pytest.raises(Exception):
+        K.run_stats_doy(dev, dx, op, dt, tidx + D, "sum", 1, seg)

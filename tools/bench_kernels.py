@@ -62,6 +62,8 @@ run("doy_mean_std w5", lambda: K.doy_mean_std(dev, tas, tb, 5), 4 * E + 8 * len(
 p = K.percentile_doy(dev, tas, tb, 5, [90.0])
 tidx = np.searchsorted(doys, ta.doy).astype(np.int32)
 run("compare_doy", lambda: K.compare_doy(dev, tas, ">", p.reshape(len(doys), C), tidx), 8 * E + 8 * len(doys) * C)
+run("run_stats_doy sum w6 (WSDI fused)", lambda: K.run_stats_doy(dev, tas, ">", p.reshape(len(doys), C), tidx, "sum", 6, seg_y),
+    4 * E + 8 * len(doys) * C)
 run("precip_over_doy (count+frac)", lambda: K.precip_over_doy(dev, tas, ">", 280.0, p.reshape(len(doys), C), tidx, seg_y,
                                                               want=("count", "frac")), 4 * E + 8 * len(doys) * C)
 run("doy_broadcast", lambda: K.doy_broadcast(dev, p.reshape(len(doys), C), tidx), 16 * E)

@@ -341,6 +341,52 @@ static int check_tc2(const char* fn, xh_ctx* ctx, const void* x, int64_t T, int6
   return XH_OK;
 }
 
+// Percentile-spell indices (warm / cold_spell_duration_index, indices/_multivariate.py:66-152, 1693-1793) with
+// resample_before_rl: the daily condition x[t] op table[tidx[t]] (fp64 compare against the per-doy percentile, i.e.
+// compare(da, op, resample_doy(per, da))) feeds the run state machine directly — neither the (T, C) fp64 threshold
+// field of the reference nor a mask is written.  A compare never yields NaN, so every run is visible (rl:223-272).
+// One lane per cell; x rows and table rows are loaded in batches of 8 before any use.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_run_stats_doy(const float* __restrict__ x, int64_t C, int64_t st, int op, const double* __restrict__ table,
+                const int32_t* __restrict__ tidx, int window, int stat, const int64_t* __restrict__ seg_off, int P,
+                float* __restrict__ out, int32_t* __restrict__ valid_out) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    RunAcc acc;
+    acc_reset(acc);
+    int run = 0, nvalid = 0, plainsum = 0;
+    auto step = [&](float xv, double tv) {
+      const bool on = xh_cmp_f64((double)xv, op, tv);
+      nvalid += (xv == xv) ? 1 : 0;
+      plainsum += on ? 1 : 0;
+      const int len = (!on && run >= window) ? run : 0;  // a run of at least `window` (>= 1) steps ended at t - 1
+      acc_add_if<0>(acc, len);
+      run = on ? run + 1 : 0;
+    };
+    int64_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+      int r[8];
+      float xv[8];
+      double tv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = tidx[t + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = x[(t + u) * st + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tv[u] = table[(int64_t)r[u] * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) step(xv[u], tv[u]);
+    }
+    for (; t < t1; ++t) step(x[t * st + c], table[(int64_t)tidx[t] * C + c]);
+    if (run >= window && run > 0) acc_add(acc, run);  // run cut by the period end
+    const int64_t o = (int64_t)p * C + c;
+    out[o] = acc_result(acc, stat, plainsum);
+    if (valid_out) valid_out[o] = nvalid;
+  }
+}
+
 extern "C" {
 
 int xh_cumsum_reset(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int index_first,
@@ -447,6 +493,37 @@ int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, 
     hipLaunchKernelGGL((k_run_stats<1, false>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, fused_op, (float)thr,
                        window, stat, index_first, d_seg, P, out, valid_out);
   }
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_run_stats_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, const double* table,
+                     int D, const int32_t* tidx, int window, int stat, const int64_t* seg_off, int P, float* out,
+                     int32_t* valid_out) {
+  XH_REQUIRE(ctx && x && table && out, XH_ERR_ARG, "xh_run_stats_doy: NULL argument");
+  XH_REQUIRE(T >= 0 && C >= 0 && D >= 1, XH_ERR_ARG, "xh_run_stats_doy: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_run_stats_doy: needs a time-major view (cell stride 1)");
+  XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "xh_run_stats_doy: operator %d not recognized", op);
+  XH_REQUIRE(window >= 1, XH_ERR_ARG, "xh_run_stats_doy: window must be >= 1");
+  XH_REQUIRE((stat >= XH_RUN_MAX && stat <= XH_RUN_STD) || stat == XH_RUN_PLAINSUM, XH_ERR_OP,
+             "xh_run_stats_doy: statistic %d not supported (run-length reducers only)", stat);
+  XH_REQUIRE(seg_off && P >= 1 && tidx, XH_ERR_ARG, "xh_run_stats_doy: seg_off / tidx NULL or P < 1");
+  for (int p = 0; p < P; ++p)
+    XH_REQUIRE(seg_off[p] <= seg_off[p + 1] && seg_off[p] >= 0 && seg_off[p + 1] <= T, XH_ERR_ARG,
+               "xh_run_stats_doy: seg_off must be non-decreasing within [0, T]");
+  for (int64_t t = 0; t < T; ++t)
+    XH_REQUIRE(tidx[t] >= 0 && tidx[t] < D, XH_ERR_ARG, "xh_run_stats_doy: tidx[%lld] = %d outside the table (D = %d)",
+               (long long)t, tidx[t], D);
+  size_t cur = 0;
+  void *d_tidx = nullptr, *d_seg = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, tidx, sizeof(int32_t) * (size_t)T, &d_tidx);
+  if (rc) return rc;
+  rc = xh_scratch_upload(ctx, &cur, seg_off, sizeof(int64_t) * (size_t)(P + 1), &d_seg);
+  if (rc) return rc;
+  if (C == 0) return XH_OK;
+  dim3 grid((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P));
+  hipLaunchKernelGGL(k_run_stats_doy, grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, op, table, (const int32_t*)d_tidx, window,
+                     stat, (const int64_t*)d_seg, P, out, valid_out);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

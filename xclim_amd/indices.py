@@ -121,11 +121,15 @@ def _percentile_spell(da, per: DoyPercentile, window, time, freq, resample_befor
     if doy.data.shape[0] != 1:
         raise ValueError("select one percentile first (DoyPercentile.sel)")
     table = doy.data.reshape(doy.data.shape[1], doy.data.shape[2])
-    mask = K.compare_doy(dev, x, sym, table, resample_doy_index(doy, time))
     seg, _ = time.segments(freq)
+    tidx = resample_doy_index(doy, time)
     # rl.windowed_run_count: total length of the runs of at least `window` steps (run_length.py:437-488)
-    out, _ = K.run_stats(dev, mask, "sum", window, seg, cut=resample_before_rl, want_valid=False)
-    _, val = K.resample_reduce(dev, x, "count", seg)
+    if resample_before_rl:  # compare, run lengths and valid counts in one pass over x and the table
+        out, val = K.run_stats_doy(dev, x, sym, table, tidx, "sum", window, seg)
+    else:
+        mask = K.compare_doy(dev, x, sym, table, tidx)
+        out, _ = K.run_stats(dev, mask, "sum", window, seg, cut=False, want_valid=False)
+        _, val = K.resample_reduce(dev, x, "count", seg)
     return _masked(out, val, time, freq, dev, cell_shape, mask_missing)
 
 

@@ -424,6 +424,20 @@ def compare_doy(dev: Device, x: DeviceArray, op: str, table: DeviceArray, tidx) 
     return out
 
 
+def run_stats_doy(dev: Device, x: DeviceArray, op: str, table: DeviceArray, tidx, stat: str, window: int, seg_off, want_valid=True):
+    """xh_run_stats_doy: run statistics (cut at the period edges) of x[t] op table[tidx[t]]; table (D, C) float64."""
+    T, C_ = _tc(x)
+    D = table.shape[0]
+    tidx = np.ascontiguousarray(tidx, dtype=np.int32)
+    assert len(tidx) == T and table.shape == (D, C_) and table.dtype == np.float64
+    seg, P = _seg(seg_off)
+    out = dev.empty((P, C_), np.float32)
+    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    dev.call("xh_run_stats_doy", _vp(x.ptr), T, C_, C_, 1, op_code(op), _vp(table.ptr), D, np_ptr(tidx), int(window), RUN_STATS[stat],
+             np_ptr(seg), P, _vp(out.ptr), _vp(valid.ptr if valid else 0))
+    return out, valid
+
+
 def precip_over_doy(dev: Device, x: DeviceArray, op: str, thr: float, table: DeviceArray, tidx, seg_off, want=("count",),
                     want_valid=True):
     """xh_precip_over_doy: (count | frac | both, valid) against max(table[tidx[t]], thr); table (D, C) float64."""
