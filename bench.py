@@ -39,9 +39,13 @@ def pmc_traffic(kernel, grid):
         return None
     path = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
     try:
-        return json.load(open(path))[kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+        table = json.load(open(path))
+    except (OSError, ValueError):
         return None
+    for name in (kernel, kernel[:-1] + ", false>"):  # the kernel gained a trailing COUNT template flag (false = this path)
+        if name in table:
+            return table[name]["hbm_bytes_per_launch"]
+    return None
 
 
 def event_time(dev, fn, reps):
