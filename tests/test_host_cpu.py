@@ -152,3 +152,16 @@ def test_cell_blocks_cover_and_align():
     assert default_block_cells(365 * 4, 100) == 100
     with pytest.raises(ValueError):
         cell_blocks(10, 0)
+
+
+def test_bench_finds_pmc_traffic_of_the_dominant_kernel():
+    """bench.py reports roofline.traffic from the committed PMC passes: the lookup must follow the kernel's name."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.pmc_traffic("k_pdoy_slide<5, 4>", (365, 1440, 720))
+    assert t is not None and 4.4e9 < t < 5.5e9   # algorithmic 4.54 GB
+    assert bench.pmc_traffic("k_pdoy_slide<5, 4>", (365, 10, 10)) is None
