@@ -41,6 +41,9 @@ for red in ("mean", "max", "std", "argmax"):
     run(f"resample_reduce {red} YS", lambda red=red: K.resample_reduce(dev, tas, red, seg_y), (8 if red == "std" else 4) * E)
 run("resample_reduce mean MS", lambda: K.resample_reduce(dev, tas, "mean", seg_m), 4 * E)
 run("rolling_reduce mean w5", lambda: K.rolling_reduce(dev, tas, 5, "mean", True), 8 * E)
+run("rolling_reduce sum w5", lambda: K.rolling_reduce(dev, tas, 5, "sum", True), 8 * E)
+run("rolling_reduce max w5", lambda: K.rolling_reduce(dev, tas, 5, "max", True), 8 * E)
+run("rolling_reduce mean w3", lambda: K.rolling_reduce(dev, tas, 3, "mean", True), 8 * E)
 run("bivariate_count", lambda: K.bivariate_count(dev, tas, tas2, "<", 285.0, ">", 295.0, "all", seg_y), 8 * E)
 run("thresholded_reduce sum", lambda: K.thresholded_reduce(dev, tas, ">", 290.0, 0, "sum", seg_y), 4 * E)
 run("range_reduce mean (dtr)", lambda: K.range_reduce(dev, tas, tas2, "range", "mean", seg_y), 8 * E)

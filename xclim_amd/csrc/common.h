@@ -248,6 +248,16 @@ __device__ __forceinline__ float xh_key2f(uint32_t k) {
   return __uint_as_float(u);
 }
 
+// s / n for a small positive integer n, given inv = 1.0 / n: q = RN(s * inv), r = s - n * q (exact with FMA),
+// q' = RN(q + r * inv) is the correctly rounded quotient (Markstein's theorem; inv is the correctly rounded
+// reciprocal) — bit-identical to the division at 3 fp64 FMAs instead of the ~12-instruction IEEE sequence, which
+// matters in the rolling kernels where it runs once per cell-timestep.  Non-finite s: r is NaN, keep q.
+__device__ __forceinline__ double xh_div_int(double s, double n, double inv) {
+  const double q = s * inv;
+  const double r = fma(-q, n, s);
+  return (r == r) ? fma(r, inv, q) : q;
+}
+
 __device__ __forceinline__ double xh_nan64() { return __longlong_as_double(0x7FF8000000000000LL); }
 __device__ __forceinline__ float xh_nan32() { return __uint_as_float(0x7FC00000u); }
 

@@ -36,7 +36,7 @@ struct Ring {
 // statistic of the last `w` ring entries (oldest first).  RED: XH_RED_* ; returns NaN when any entry is NaN (xarray
 // rolling with min_periods = window), except COUNT (number of valid entries).
 template <int RED>
-__device__ __forceinline__ float ring_stat(const float (&r)[WMAX], int w, const float* wts) {
+__device__ __forceinline__ float ring_stat(const float (&r)[WMAX], int w, double inv_w, const float* wts) {
   double s = 0.0;
   float e = 0.f;
   bool nan = false, first = true;
@@ -57,15 +57,16 @@ __device__ __forceinline__ float ring_stat(const float (&r)[WMAX], int w, const 
   if (RED == XH_RED_COUNT) return (float)n;
   float out;
   if (RED == XH_RED_MIN || RED == XH_RED_MAX) out = e;
-  else if (RED == XH_RED_MEAN) out = (float)(s / (double)w);
+  else if (RED == XH_RED_MEAN) out = (float)xh_div_int(s, (double)w, inv_w);
   else if (RED == XH_RED_SUM || RED == 100) out = (float)s;
   else {  // var / std: two passes over the registers, population (ddof = 0)
-    const double m = s / (double)w;
+    const double m = xh_div_int(s, (double)w, inv_w);
     double s2 = 0.0;
 #pragma unroll
     for (int k = 0; k < WMAX; ++k)
       if (k >= WMAX - w) { const double d = (double)r[k] - m; s2 += d * d; }
-    out = (RED == XH_RED_VAR) ? (float)(s2 / (double)w) : (float)sqrt(s2 / (double)w);
+    const double v = xh_div_int(s2, (double)w, inv_w);
+    out = (RED == XH_RED_VAR) ? (float)v : (float)sqrt(v);
   }
   return nan ? xh_nan32() : out;
 }
@@ -90,6 +91,7 @@ k_rolling_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, in
   int64_t tb = ta + chunk;
   if (tb > T) tb = T;
   if (ta >= tb) return;
+  const double inv_w = 1.0 / (double)w;
   Ring<VEC> ring;
   ring.fill_nan();
   // rows needed: [ta - left, tb - 1 + right] clipped to [0, T); a row tp completes the window of t = tp - right
@@ -102,7 +104,7 @@ k_rolling_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, in
     const bool whole = (t - left >= 0) && (t + right < T);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const float s = ring_stat<RED>(ring.v[i], w, nullptr);
+      const float s = ring_stat<RED>(ring.v[i], w, inv_w, nullptr);
       r[i] = (RED == XH_RED_COUNT || whole) ? s : xh_nan32();
     }
     store_vec<VEC>(out + t * out_st + c, r);
@@ -136,6 +138,7 @@ k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
   float wts[WMAX];
 #pragma unroll
   for (int k = 0; k < WMAX; ++k) wts[k] = (RED == 100 && k >= WMAX - w) ? weights[k - (WMAX - w)] : 0.f;
+  const double inv_w = 1.0 / (double)w;
   Ring<VEC> ring;
   ring.fill_nan();
   int64_t last_true[VEC];
@@ -150,7 +153,7 @@ k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
     for (int i = 0; i < VEC; ++i) {
       bool cond = false;
       if (have_row && tp >= w - 1) {
-        const float s = ring_stat<RED>(ring.v[i], w, wts);
+        const float s = ring_stat<RED>(ring.v[i], w, inv_w, wts);
         cond = (s == s) && xh_cmp_f32(s, op, thr);
       }
       if (cond) last_true[i] = tp;
