@@ -278,3 +278,11 @@ def spell_length_statistics(data, thresh, window, win_reducer, op, spell_reducer
     mask = spell_mask(data, window, win_reducer, op, thresh, min_gap=min_gap).astype(np.float32)
     return rl.resample_and_rl(mask, resample_before_rl, rl.rle_statistics, time=time, freq=freq, reducer=spell_reducer,
                               window=1)
+
+
+def spell_length(data, threshold, reducer, time: OTime, freq, op):
+    """gen:1204-1252: cond = compare(data, op, threshold); rle_statistics(reducer, window=1) mapped over the periods."""
+    from . import run_length as rl
+
+    cond = compare(data, op, threshold)
+    return rl.resample_and_rl(cond, True, rl.rle_statistics, time=time, freq=freq, reducer=reducer, window=1)

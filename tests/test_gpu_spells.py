@@ -377,3 +377,19 @@ def test_run_stats_doy_fused(dev, rng, T, C, op):
     np.testing.assert_array_equal(val.get(), np.stack([(~np.isnan(x[a:b])).sum(axis=0) for a, b in zip(seg[:-1], seg[1:])]))
     with pytest.raises(Exception):
         K.run_stats_doy(dev, dx, op, dt, tidx + D, "sum", 1, seg)
+
+
+@pytest.mark.parametrize("reducer", ["max", "min", "mean", "sum"])
+@pytest.mark.parametrize("op", [">", "<=", "=="])
+def test_spell_length(dev, rng, reducer, op):
+    """generic.spell_length (gen:1204-1252): run statistics of the compared series, cut at the period edges."""
+    T = 800
+    x = np.round(rng.normal(0, 2.0, (T, 6, 7)) + np.repeat(rng.normal(0, 2.0, (T // 4, 6, 7)), 4, axis=0)).astype(np.float32)
+    x[rng.random(x.shape) < 0.01] = np.nan
+    ta, ot = TimeAxis.daily("2001-03-01", T), OTime.standard("2001-03-01", T)
+    for freq in ("YS", "MS", "QS-DEC"):
+        got = xgen.spell_length(x, 1.0, reducer, ta, freq, op, device=dev)
+        ref = ogen.spell_length(x, np.float32(1.0), reducer, ot, freq, op)
+        np.testing.assert_allclose(got, ref, rtol=1e-6)
+    with pytest.raises(ValueError):
+        xgen.spell_length(x, 1.0, "std", ta, "YS", op, device=dev)

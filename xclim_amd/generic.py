@@ -271,6 +271,19 @@ def spell_length_statistics(data, threshold, window: int, win_reducer, op: str, 
     return _finish(out, val, cell_shape, keep, with_valid)
 
 
+def spell_length(data, threshold: float, reducer: str, time: TimeAxis, freq: str, op: str, *, device=None, keep=False,
+                 with_valid=False):
+    """gen:1204-1252: ``resample_map(compare(data, op, threshold), rl.rle_statistics, reducer, window=1)`` — statistics of
+    the spell lengths with the series cut at the period edges; compare and run lengths in one kernel pass."""
+    if reducer not in ("max", "min", "mean", "sum"):
+        raise ValueError(f"reducer must be one of max, min, mean, sum; got {reducer!r}")
+    dev = device or get_device()
+    x, cell_shape = _flatten(data, dev)
+    seg, _ = time.segments(freq)
+    out, val = K.run_stats(dev, x, reducer, 1, seg, cut=True, fused_op=get_op(op), thresh=float(threshold))
+    return _finish(out, val, cell_shape, keep, with_valid)
+
+
 def bivariate_spell_length_statistics(data1, threshold1: float, data2, threshold2: float, window: int, win_reducer, op: str,
                                       spell_reducer, time: TimeAxis, freq: str, min_gap: int = 1,
                                       resample_before_rl: bool = True, *, device=None, keep=False, with_valid=False):
