@@ -338,14 +338,26 @@ def test_quantile_series(dev, rng, T, C):
     np.testing.assert_allclose(out2, exp, rtol=RTOL, atol=0, equal_nan=True)
 
 
-@pytest.mark.parametrize("T", [1200, 3000, 5000, 10950])
-@pytest.mark.parametrize("kind", ["pr", "clustered", "constant", "nan_heavy"])
+@pytest.mark.parametrize("T", [40, 365, 512, 600, 1000, 1200, 3000, 5000, 10950])
+@pytest.mark.parametrize("kind", ["pr", "pr_skewed", "two_values", "negative_floor", "clustered", "constant", "nan_heavy"])
 def test_quantile_series_hard_distributions(dev, rng, T, kind):
-    """Long series through the list-free selection kernel: exact-zero bins (constant big bin), big non-constant bins
-    (bisection fallback), constant columns, mostly-NaN columns."""
+    """Every selection kernel (T <= 512 grouped, <= 1024 one workgroup per column, longer: list-free) on the inputs that
+    stress the key histogram: exact-zero floors (the smallest key owns bin 0), skewed wet-day amounts and big
+    non-constant bins (in-bin quickselect / bisection fallback), two-valued and constant columns, a tied NEGATIVE minimum,
+    mostly-NaN columns."""
     C = 9
     if kind == "pr":
         x = _field(rng, T, C, kind="pr")
+    elif kind == "pr_skewed":
+        u = rng.random((T, C))
+        x = np.where(rng.random((T, C)) < 0.6, (u * u * u) * (40.0 / 86400.0), 0.0).astype(np.float32)
+        x[:, 3] = np.where(rng.random(T) < 0.02, 1.0, 0.0)  # a handful of wet days
+    elif kind == "two_values":
+        x = np.where(rng.random((T, C)) < 0.5, 2.5, -1.0).astype(np.float32)
+        x[:, 2] = np.where(np.arange(T) == T // 2, 7.0, 7.5)  # one copy of the smaller value
+    elif kind == "negative_floor":
+        x = np.maximum(rng.normal(0, 1, (T, C)), -0.25).astype(np.float32)  # censored: ~40 % of the days at -0.25
+        x[rng.random((T, C)) < 0.01] = np.nan
     elif kind == "clustered":
         x = (1.0 + rng.integers(0, 50, (T, C)) * 1.1920929e-07).astype(np.float32)  # 50 adjacent float32 values
         x[rng.random((T, C)) < 0.02] = 1.0e6  # outliers stretch the key range: the cluster lands in one bin

@@ -90,6 +90,29 @@ __device__ __forceinline__ uint32_t group_reduce_sum(uint32_t v, int tid_in_grou
   return v;
 }
 
+// k-th smallest (0-based) key of keys[0..m): quickselect on VALUES, the data is not moved (other lanes read the same
+// bin).  The answer stays inside the key interval [lo, hi]; each pass counts #(k < e) and #(k <= e) for a pivot e that
+// is itself a key of the interval, and remembers one key on either side of e inside the interval as the next pivot.
+// O(m) LDS reads per pass, ~2 ln(m) passes expected; a bin of equal keys (the dry days of a precipitation series) ends
+// after one pass.  Replaces a candidate-by-candidate scan that cost O(m^2) on skewed or tied data.
+__device__ __forceinline__ uint32_t select_in_bin(const uint32_t* __restrict__ keys, uint32_t m, uint32_t kth) {
+  uint32_t lo = 0u, hi = 0xFFFFFFFFu;
+  uint32_t e = keys[kth < m ? kth : 0u];
+  for (;;) {
+    uint32_t less = 0, leq = 0, cl = e, ch = e;
+#pragma unroll 4
+    for (uint32_t b = 0; b < m; ++b) {
+      const uint32_t k = keys[b];
+      less += k < e ? 1u : 0u;
+      leq += k <= e ? 1u : 0u;
+      cl = (k < e && k >= lo) ? k : cl;
+      ch = (k > e && k <= hi) ? k : ch;
+    }
+    if (less <= kth && kth < leq) return e;
+    if (kth < less) { hi = e - 1u; e = cl; } else { lo = e + 1u; e = ch; }
+  }
+}
+
 // NT threads per column, KPL keys per thread (T <= NT*KPL), NB bins (multiple of NT), GROUPS columns per block.
 // LDS layout per group: sorted[Tpad] | offs[NB+1] | cursor[NB] | vals[2*64] | tmp[16]
 template <int NT, int KPL, int NB>
@@ -197,19 +220,7 @@ k_select_quantile(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t
         const uint32_t s0 = offs[lo], s1 = offs[lo + 1];
         const uint32_t kth = (uint32_t)r - s0;
         uint32_t ans = sorted[s0];
-        if (s1 - s0 > 1) {
-          // exact selection inside the bin: candidate e is the answer iff #(k < e) <= kth < #(k <= e)
-          for (uint32_t a = s0; a < s1; ++a) {
-            uint32_t e = sorted[a], less = 0, leq = 0;
-            for (uint32_t b2 = s0; b2 < s1; ++b2) {
-              uint32_t kk = sorted[b2];
-              less += kk < e ? 1u : 0u;
-              leq += kk <= e ? 1u : 0u;
-            }
-            if (less <= kth && kth < leq) { ans = e; break; }
-            if (less == 0 && leq == s1 - s0) { ans = e; break; }  // all keys of the bin are equal
-          }
-        }
+        if (s1 - s0 > 1) ans = select_in_bin(sorted + s0, s1 - s0, kth);  // exact selection inside the bin
         v = xh_key2f(ans);
       }
       vals[tgt] = v;
@@ -348,18 +359,44 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
       kmax = b > kmax ? b : kmax;
     }
     const uint32_t n = nv;
-    const uint32_t range = n > 0 ? kmax - kmin : 0u;
-    // smallest shift with (range >> shift) < NB
+    // The smallest key gets bin 0 to itself and the other NB - 1 bins divide [kmin2, kmax], kmin2 = the smallest key
+    // above it: a precipitation series is ~70 % exact zeros followed by a gap of most of the key range (0 -> the
+    // smallest wet amount), which would otherwise squeeze every wet day into a quarter of the bins and leave one bin
+    // of hundreds of tied keys to be searched.  Bin 0 is constant by construction: its targets need no search.
+    uint32_t kmin2 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) kmin2 = (key[k] > kmin && key[k] < kmin2) ? key[k] : kmin2;  // NaN keys are 0xFFFFFFFF
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+      const uint32_t a = __shfl_xor(kmin2, off, G);
+      kmin2 = a < kmin2 ? a : kmin2;
+    }
+    kmin2 = kmin2 == 0xFFFFFFFFu ? kmin : kmin2;  // all valid keys equal
+    // copies of the smallest key are counted in registers, never touch the LDS atomics (hundreds of lanes on one
+    // address) and are not stored: nobody reads bin 0
+    uint32_t cnt0 = 0;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) cnt0 += (key[k] == kmin && key[k] != 0xFFFFFFFFu) ? 1u : 0u;
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) cnt0 += __shfl_xor(cnt0, off, G);
+    const uint32_t range = n > 0 ? kmax - kmin2 : 0u;
+    // smallest shift with (range >> shift) < NB; the top value bin is merged into bin NB - 1 when that index is reached
     int shift = 32 - __clz((int)range) - (31 - __clz(NB));  // bits(range) - log2(NB)
     shift = (range == 0u || shift < 0) ? 0 : shift;
+    auto binof = [&](uint32_t kk) -> uint32_t {
+      const uint32_t b = 1u + ((kk - kmin2) >> shift);
+      return kk == kmin ? 0u : (b < (uint32_t)NB ? b : (uint32_t)NB - 1u);
+    };
 #pragma unroll
     for (int b = 0; b < BPL; ++b) cur[l + b * G] = 0;
     wave_sync();
     if (!(abl & 1)) {
 #pragma unroll
     for (int k = 0; k < KPL; ++k)
-      if (key[k] != 0xFFFFFFFFu) atomicAdd(&cur[(key[k] - kmin) >> shift], 1u);
+      if (key[k] != 0xFFFFFFFFu && key[k] != kmin) atomicAdd(&cur[binof(key[k])], 1u);
     }
+    wave_sync();
+    if (l == 0) cur[0] = cnt0;
     wave_sync();
     {
       uint32_t loc[BPL], s = 0;
@@ -384,12 +421,14 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
         uint32_t pos[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          if (k0 + k < KPL) pos[k] = (key[k0 + k] != 0xFFFFFFFFu) ? atomicAdd(&cur[(key[k0 + k] - kmin) >> shift], 1u) : 0u;
+          if (k0 + k < KPL)
+            pos[k] = (key[k0 + k] != 0xFFFFFFFFu && key[k0 + k] != kmin) ? atomicAdd(&cur[binof(key[k0 + k])], 1u) : 0u;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          if (k0 + k < KPL && key[k0 + k] != 0xFFFFFFFFu) sorted[pos[k]] = key[k0 + k];
+          if (k0 + k < KPL && key[k0 + k] != 0xFFFFFFFFu && key[k0 + k] != kmin) sorted[pos[k]] = key[k0 + k];
       }
     }
+    if (l == 0) cur[0] = cnt0;  // END of bin 0 (its cursor never moved)
     wave_sync();
     // after the scatter cur[b] is the END of bin b (== start of bin b+1)
     int round = 0;
@@ -425,7 +464,8 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
         const uint32_t s0 = hi > 0 ? cur[hi - 1] : 0u, s1 = cur[hi];
         const uint32_t kth = (uint32_t)r - s0, m = s1 - s0;
         uint32_t ans;
-        if (m <= 8) {
+        if (hi == 0) ans = kmin;  // bin 0 holds the copies of the smallest key only
+        else if (m <= 8) {
           // exact k-th smallest of <= 8 keys: independent LDS loads, optimal 19-comparator network (0xFFFFFFFF pads
           // sort last), k-th picked with an OR of masked values (no dynamic register indexing)
           uint32_t kk[8];
@@ -440,17 +480,7 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
 #pragma unroll
           for (int i = 0; i < 8; ++i) ans |= ((uint32_t)i == kth) ? kk[i] : 0u;
         } else {
-          ans = sorted[s0];
-          for (uint32_t a = s0; a < s1; ++a) {
-            uint32_t e = sorted[a], less = 0, leq = 0;
-            for (uint32_t b2 = s0; b2 < s1; ++b2) {
-              uint32_t k2 = sorted[b2];
-              less += k2 < e ? 1u : 0u;
-              leq += k2 <= e ? 1u : 0u;
-            }
-            if (less <= kth && kth < leq) { ans = e; break; }
-            if (less == 0 && leq == m) { ans = e; break; }
-          }
+          ans = select_in_bin(sorted + s0, m, kth);
         }
         v = xh_key2f(ans);
       }
