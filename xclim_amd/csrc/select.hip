@@ -161,16 +161,32 @@ k_select_quantile(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t
     const uint32_t n = group_reduce_sum<NT>(nv, gt, tmp);
     kmin = group_reduce_min<NT>(kmin, gt, tmp);
     kmax = group_reduce_max<NT>(kmax, gt, tmp);
-    const uint32_t range = (n > 0) ? (kmax - kmin) : 0u;
+    // the smallest key owns bin 0 (counted in registers: no atomics, never stored, its targets need no search); the other
+    // bins divide [kmin2, kmax], kmin2 = the smallest key above it — see k_select_grp
+    uint32_t kmin2 = 0xFFFFFFFFu, cnt0 = 0;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+      kmin2 = (key[k] > kmin && key[k] < kmin2) ? key[k] : kmin2;
+      cnt0 += (key[k] == kmin && key[k] != 0xFFFFFFFFu) ? 1u : 0u;
+    }
+    kmin2 = group_reduce_min<NT>(kmin2, gt, tmp);
+    cnt0 = group_reduce_sum<NT>(cnt0, gt, tmp);
+    kmin2 = kmin2 == 0xFFFFFFFFu ? kmin : kmin2;
+    const uint32_t range = (n > 0) ? (kmax - kmin2) : 0u;
     int shift = 0;
     while ((range >> shift) >= (uint32_t)NB) shift++;
+    auto binof = [&](uint32_t kk) -> uint32_t {  // (never called for kmin copies / NaN keys)
+      const uint32_t bb = 1u + ((kk - kmin2) >> shift);
+      return bb < (uint32_t)NB ? bb : (uint32_t)NB - 1u;
+    };
     // ---- histogram
 #pragma unroll
     for (int b = 0; b < BPT; ++b) offs[gt + b * NT] = 0;
     group_sync<NT>();
 #pragma unroll
     for (int k = 0; k < KPL; ++k)
-      if (key[k] != 0xFFFFFFFFu) atomicAdd(&offs[(key[k] - kmin) >> shift], 1u);
+      if (key[k] != 0xFFFFFFFFu && key[k] != kmin) atomicAdd(&offs[binof(key[k])], 1u);
+    if (gt == 0) offs[0] = cnt0;
     group_sync<NT>();
     // ---- exclusive scan of NB bins: thread owns BPT consecutive bins
     {
@@ -192,8 +208,8 @@ k_select_quantile(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t
     // ---- scatter (grouped by bin)
 #pragma unroll
     for (int k = 0; k < KPL; ++k)
-      if (key[k] != 0xFFFFFFFFu) {
-        uint32_t pos = atomicAdd(&cursor[(key[k] - kmin) >> shift], 1u);
+      if (key[k] != 0xFFFFFFFFu && key[k] != kmin) {
+        uint32_t pos = atomicAdd(&cursor[binof(key[k])], 1u);
         sorted[pos] = key[k];
       }
     group_sync<NT>();
@@ -219,8 +235,8 @@ k_select_quantile(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t
         }
         const uint32_t s0 = offs[lo], s1 = offs[lo + 1];
         const uint32_t kth = (uint32_t)r - s0;
-        uint32_t ans = sorted[s0];
-        if (s1 - s0 > 1) ans = select_in_bin(sorted + s0, s1 - s0, kth);  // exact selection inside the bin
+        uint32_t ans = kmin;  // bin 0: the copies of the smallest key (not stored)
+        if (lo > 0) ans = (s1 - s0 > 1) ? select_in_bin(sorted + s0, s1 - s0, kth) : sorted[s0];  // exact selection inside the bin
         v = xh_key2f(ans);
       }
       vals[tgt] = v;

@@ -63,7 +63,7 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
   __shared__ uint32_t bmin[MAXT], bmax[MAXT];
   __shared__ uint32_t list[LISTCAP + 2 * 8 + 4];  // padded: the in-bin select reads (masked) past a bin's keys
   __shared__ float vals[MAXT];
-  __shared__ uint32_t red[4 * NW + 8];
+  __shared__ uint32_t red[5 * NW + 8];
   __shared__ int s_slow, s_off, s_nslot;
   const int gt = threadIdx.x;
   const int lane = gt & 63, w = gt >> 6;
@@ -120,7 +120,24 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
       kmax = b > kmax ? b : kmax;
     }
     kmax -= 1u;  // (only meaningful when nv > 0)
-    if (lane == 0) { red[w] = nv; red[NW + w] = kmin; red[2 * NW + w] = kmax; }
+    // The smallest key gets bin 0 to itself and bins 1 .. NB-1 divide [kmin2, kmax], kmin2 = the smallest key above it:
+    // a precipitation series is mostly exact zeros followed by a gap of most of the key range (0 -> the smallest wet
+    // amount); with [kmin, kmax] divided evenly every wet day lands in a quarter of the bins.  The copies of kmin are
+    // counted in registers: they skip the histogram atomics (thousands of lanes on one address) and are never collected.
+    // Wave level first (shuffles only): wave minimum, smallest key above it, copies of it; one LDS round joins the waves.
+    uint32_t wmin2 = 0xFFFFFFFFu, wcnt = 0;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+      wmin2 = (key[k] > kmin && key[k] < wmin2) ? key[k] : wmin2;  // NaN keys (0xFFFFFFFF) never pass `< wmin2`
+      wcnt += key[k] == kmin ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t a = __shfl_xor(wmin2, off, 64);
+      wmin2 = a < wmin2 ? a : wmin2;
+      wcnt += __shfl_xor(wcnt, off, 64);
+    }
+    if (lane == 0) { red[w] = nv; red[NW + w] = kmin; red[2 * NW + w] = kmax; red[3 * NW + w] = wmin2; red[4 * NW + w] = wcnt; }
     lds_barrier();
     XH_PHASE(0);
     uint32_t n = 0;
@@ -131,9 +148,25 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
       kmin = red[NW + i] < kmin ? red[NW + i] : kmin;
       kmax = red[2 * NW + i] > kmax ? red[2 * NW + i] : kmax;
     }
-    const uint32_t range = n > 0 ? kmax - kmin : 0u;
+    uint32_t kmin2 = 0xFFFFFFFFu, cnt0 = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const bool own = red[NW + i] == kmin;                       // this wave holds copies of the minimum
+      const uint32_t c2 = own ? red[3 * NW + i] : red[NW + i];    // its smallest key above kmin
+      kmin2 = c2 < kmin2 ? c2 : kmin2;
+      cnt0 += own ? red[4 * NW + i] : 0u;
+    }
+    kmin2 = kmin2 == 0xFFFFFFFFu ? kmin : kmin2;  // all valid keys equal
+    cnt0 = n > 0 ? cnt0 : 0u;                     // (all NaN: kmin is the NaN key)
+    const uint32_t range = n > 0 ? kmax - kmin2 : 0u;
     int shift = 32 - __clz((int)range) - (31 - __clz(NB));
     shift = (range == 0u || shift < 0) ? 0 : shift;
+    // bin of a key: NB (dummy, no tag, no atomics) for NaN and for the copies of kmin; the top value bin is merged into
+    // bin NB - 1 when its index is reached
+    auto binof = [&](uint32_t kk) -> uint32_t {
+      const uint32_t b = 1u + ((kk - kmin2) >> shift);
+      return (kk == 0xFFFFFFFFu || kk == kmin) ? (uint32_t)NB : (b < (uint32_t)NB ? b : (uint32_t)NB - 1u);
+    };
     // ---- B: target ranks + histogram
     if (gt < ntgt) {
       int r = -1;
@@ -153,10 +186,11 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
     if (!(abl & 1)) {
 #pragma unroll
       for (int k = 0; k < KPL; ++k) {
-        const uint32_t b = (key[k] - kmin) >> shift;
-        atomicAdd(&cur[key[k] != 0xFFFFFFFFu ? b : (uint32_t)NB], 1u);
+        const uint32_t b = binof(key[k]);
+        if (b != (uint32_t)NB) atomicAdd(&cur[b], 1u);
       }
     }
+    if (gt == 0) cur[0] = cnt0;  // nobody else touches bin 0
     lds_barrier();
     XH_PHASE(1);
     // ---- C: exclusive scan (thread gt owns bins gt*BPT ... gt*BPT+BPT-1), targets, list regions
@@ -220,16 +254,17 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
         else if (bin == pb1) tag = pt1;
         else {
           int off = LISTCAP + 1;
-          if (m <= BIGM) {
+          const bool floor_bin = bin == 0;  // the copies of kmin: a constant bin whose keys are never collected
+          if (m <= BIGM && !floor_bin) {
             if (lane == 0) off = atomicAdd(&s_off, m);
             off = __builtin_amdgcn_readfirstlane(off);
           }
-          if (m <= BIGM && off + m <= LISTCAP) tag = F_LIST | (uint32_t)off;
+          if (m <= BIGM && !floor_bin && off + m <= LISTCAP) tag = F_LIST | (uint32_t)off;
           else {
             int slot = 0;
             if (lane == 0) {
               slot = atomicAdd(&s_nslot, 1);
-              bmin[slot] = 0xFFFFFFFFu; bmax[slot] = 0u;
+              bmin[slot] = floor_bin ? kmin : 0xFFFFFFFFu; bmax[slot] = floor_bin ? kmin : 0u;
             }
             slot = __builtin_amdgcn_readfirstlane(slot);
             tag = F_BIG | (uint32_t)slot;
@@ -257,14 +292,13 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
         bool anybig = false;
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-          const uint32_t b = (key[k0 + k] - kmin) >> shift;
-          cf[k] = cur[key[k0 + k] != 0xFFFFFFFFu ? b : (uint32_t)NB];  // cur[NB] carries no tag
+          cf[k] = cur[binof(key[k0 + k])];  // cur[NB] (NaN keys, copies of kmin) carries no tag
           anybig |= (cf[k] & F_BIG) != 0u;
         }
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
           pos[k] = 0;
-          if (cf[k] & F_LIST) pos[k] = atomicAdd(&cur[(key[k0 + k] - kmin) >> shift], 1u) & F_MASK;
+          if (cf[k] & F_LIST) pos[k] = atomicAdd(&cur[binof(key[k0 + k])], 1u) & F_MASK;
         }
 #pragma unroll
         for (int k = 0; k < CH; ++k)
@@ -338,7 +372,7 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
         uint32_t lo = bmin[slot], hi = bmax[slot];
         if (lo == hi) continue;
         // smallest K in [lo, hi] with #(key <= K, key in this bin) >= kth + 1
-        const uint32_t binlo = kmin + ((uint32_t)ti.bin << shift);
+        const uint32_t binlo = kmin2 + ((uint32_t)(ti.bin - 1) << shift);  // (bin 0 is constant and never gets here)
         while (lo < hi) {
           const uint32_t mid = lo + ((hi - lo) >> 1);
           uint32_t c = 0;
