@@ -3,6 +3,8 @@
 Bar (BASELINE.json north_star): integer counts / run lengths bit-exact; float quantiles / means <= 1e-6 relative.
 """
 
+import warnings
+
 import numpy as np
 import pytest
 
@@ -445,3 +447,30 @@ def test_synthetic_matches_oracle(dev):
 def test_transpose(dev, rng):
     x = rng.normal(size=(130, 77)).astype(np.float32)
     np.testing.assert_array_equal(K.transpose(dev, dev.to_device(x)).get(), x.T)
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("interp", ["nearest", "linear"])
+@pytest.mark.parametrize("extrap", ["constant", "nan"])
+def test_eqm_precipitation_tied_nodes(dev, rng, kind, interp, extrap):
+    """EQM on precipitation: most quantile nodes of hist are tied at exactly 0 (dry days), "*" factors are 0/0 = NaN
+    (dropped) or x/0 = inf, and sim values sit exactly on the tied nodes.  Must follow scipy's interp1d on duplicate
+    nodes (the oracle calls it), including the NaN / inf it produces."""
+    T, C = 730, 120
+    ref = _field(rng, T, C, kind="pr")
+    hist = _field(rng, T, C, kind="pr")
+    hist[:, :30] *= np.float32(0.0)                 # never wet: every node is 0
+    ref[:, 30:60][ref[:, 30:60] < 2e-4] = 0.0       # drier ref: ref_q = 0 where hist_q > 0
+    sim = _field(rng, T, C, kind="pr")
+    sim[rng.random(sim.shape) < 0.01] = np.nan
+    q = osdba.equally_spaced_nodes(20)
+    af, hq = K.eqm_train(dev, dev.to_device(ref), dev.to_device(hist), q, kind)
+    eaf, ehq = osdba.eqm_train(ref, hist, 20, kind)
+    assert (ehq == 0).mean() > 0.3                  # the premise: tied zero nodes
+    np.testing.assert_allclose(hq.get(), ehq, rtol=RTOL, equal_nan=True)
+    np.testing.assert_allclose(af.get(), eaf, rtol=RTOL, atol=1e-12 if kind == "+" else 0, equal_nan=True)
+    scen = K.eqm_adjust(dev, dev.to_device(sim), dev.to_device(eaf), dev.to_device(ehq), kind, interp, extrap).get()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        exp = osdba.eqm_adjust(sim, eaf, ehq, kind, interp, extrap)
+    np.testing.assert_allclose(scen, exp, rtol=RTOL, atol=0, equal_nan=True)
