@@ -473,6 +473,7 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
         for (int rr = 0; rr < NROUND; ++rr) r = (rr == round) ? rank_c[rr] : r;
         // first bin whose end exceeds r
         int lo = -1, hi = NB - 1;  // invariant: end[lo] <= r < end[hi]   (end[-1] = 0, end[NB-1] = n)
+        if (abl & 16) { hi = 1 + (int)(((uint32_t)r * (uint32_t)(NB - 1)) / (n + 1u)); lo = hi - 1; }  // diagnostics: no search
         while (hi - lo > 1) {
           int mid = (lo + hi) >> 1;
           if (cur[mid] <= (uint32_t)r) lo = mid; else hi = mid;
@@ -481,6 +482,7 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
         const uint32_t kth = (uint32_t)r - s0, m = s1 - s0;
         uint32_t ans;
         if (hi == 0) ans = kmin;  // bin 0 holds the copies of the smallest key only
+        else if (abl & (16 | 32)) ans = sorted[s0 < n ? s0 : 0u];  // diagnostics: no in-bin selection (never loops)
         else if (m <= 8) {
           // exact k-th smallest of <= 8 keys: independent LDS loads, optimal 19-comparator network (0xFFFFFFFF pads
           // sort last), k-th picked with an OR of masked values (no dynamic register indexing)
