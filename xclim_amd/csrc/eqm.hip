@@ -49,12 +49,38 @@ k_eqm_adjust(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, co
       m++;
     }
   }
+  // linear: the valid nodes compacted to the front (padded with x = +inf) and the slope of every interval, once per cell:
+  // the per-element work is then one compare and three selects per node instead of a scan that re-derives the valid
+  // pairs, and the division leaves the time loop.  Same fp32 operations as scipy's slope * (x - x_lo) + y_lo.
+  float cx[INTERP == 1 ? NQMAX : 1], cy[INTERP == 1 ? NQMAX : 1], sl[INTERP == 1 ? NQMAX : 1];
+  if (INTERP == 1) {
+    if (__all(m == nq)) {  // no NaN node in the wave (the usual case): nothing to compact
+#pragma unroll
+      for (int j = 0; j < NQMAX; ++j) { cx[j] = j < nq ? nx[j] : inf; cy[j] = ny[j]; }
+    } else {
+      int rank[NQMAX], r = 0;
+#pragma unroll
+      for (int j = 0; j < NQMAX; ++j) { rank[j] = r; r += (nx[j] == nx[j]) ? 1 : 0; }
+#pragma unroll
+      for (int i = 0; i < NQMAX; ++i) {
+        cx[i] = inf; cy[i] = 0.f;
+#pragma unroll
+        for (int j = i; j < NQMAX; ++j) {
+          const bool pick = (nx[j] == nx[j]) && rank[j] == i;
+          cx[i] = pick ? nx[j] : cx[i];
+          cy[i] = pick ? ny[j] : cy[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j + 1 < NQMAX; ++j) sl[j] = (cy[j + 1] - cy[j]) / (cx[j + 1] - cx[j]);
+    sl[NQMAX - 1] = 0.f;
+  }
   int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
   int64_t ta = (int64_t)blockIdx.y * chunk, tb = ta + chunk;
   if (tb > T) tb = T;
-#pragma unroll 2
-  for (int64_t t = ta; t < tb; ++t) {
-    float x = sim[t * st + c];
+  // batches of 8 rows, the loads are issued before any use (8 independent rows in flight per lane instead of 2)
+  auto adjust_one = [&](int64_t t, float x) {
     float a = xh_nan32();
     if (m >= 1 && x == x) {
       bool below = x < firstx, above = x > lastx;
@@ -63,30 +89,31 @@ k_eqm_adjust(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, co
 #pragma unroll
         for (int j = 0; j < NQMAX; ++j) a = (mid[j] < x) ? ny[j] : a;
       } else {
-        float lox = firstx, loy = firsty, hix = firstx, hiy = firsty, px = 0.f, py = 0.f;
-        bool haveprev = false, firstpair = true;
+        // lo = the last node strictly below x (searchsorted side="left", clipped to the first interval); a padded node
+        // (+inf) is never below x, and the last valid node only when x is above the range (overridden below)
+        float lx = cx[0], ly = cy[0], ls = sl[0];
 #pragma unroll
-        for (int j = 0; j < NQMAX; ++j) {
-          bool valid = nx[j] == nx[j];
-          if (valid) {
-            if (haveprev) {
-              bool take = firstpair || (px < x);
-              lox = take ? px : lox; loy = take ? py : loy;
-              hix = take ? nx[j] : hix; hiy = take ? ny[j] : hiy;
-              firstpair = false;
-            }
-            px = nx[j]; py = ny[j]; haveprev = true;
-          }
+        for (int j = 1; j + 1 < NQMAX; ++j) {
+          const bool take = cx[j] < x;
+          lx = take ? cx[j] : lx; ly = take ? cy[j] : ly; ls = take ? sl[j] : ls;
         }
-        float slope = (hiy - loy) / (hix - lox);
-        a = slope * (x - lox) + loy;
+        a = ls * (x - lx) + ly;
         if (m < 2) a = xh_nan32();
       }
       if (below) a = extrap == 0 ? firsty : xh_nan32();
       if (above) a = extrap == 0 ? lasty : xh_nan32();
     }
     scen[t * scen_st + c] = kind == 0 ? (x + a) : (x * a);
+  };
+  int64_t t = ta;
+  for (; t + 8 <= tb; t += 8) {
+    float xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = sim[(t + u) * st + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) adjust_one(t + u, xv[u]);
   }
+  for (; t < tb; ++t) adjust_one(t, sim[t * st + c]);
 }
 
 // ---- adjust, interp = "cubic" ----------------------------------------------------------------------------------
