@@ -474,3 +474,28 @@ def test_eqm_precipitation_tied_nodes(dev, rng, kind, interp, extrap):
         warnings.simplefilter("ignore", RuntimeWarning)
         exp = osdba.eqm_adjust(sim, eaf, ehq, kind, interp, extrap)
     np.testing.assert_allclose(scen, exp, rtol=RTOL, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("nq", [1, 2, 7, 10, 32, 50])
+@pytest.mark.parametrize("interp", ["nearest", "linear"])
+def test_eqm_adjust_node_counts(dev, rng, nq, interp):
+    """Every register-resident node-count variant of the adjust kernel (10 / 20 / 32 / 64), with NaN nodes in some cells
+    (compaction path of the linear search), one and two valid nodes, chunked time (few cells -> many time chunks)."""
+    T, C = 413, 37
+    ref = _field(rng, T, C)
+    hist = (_field(rng, T, C) + 1.5).astype(np.float32)
+    sim = (_field(rng, T, C, nan_frac=0.01) + 2.0).astype(np.float32)
+    eaf, ehq = osdba.eqm_train(ref, hist, nq, "+")
+    eaf, ehq = eaf.astype(np.float32), ehq.astype(np.float32)
+    if nq >= 7:
+        eaf[1, 3] = np.nan
+        ehq[nq - 2, 5] = np.nan
+        ehq[:, 7] = np.nan            # no valid node at all
+        eaf[1:, 9] = np.nan           # one valid node
+        eaf[2:, 11] = np.nan          # two valid nodes
+    for extrap in ("constant", "nan"):
+        scen = K.eqm_adjust(dev, dev.to_device(sim), dev.to_device(eaf), dev.to_device(ehq), "+", interp, extrap).get()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            exp = osdba.eqm_adjust(sim, eaf, ehq, "+", interp, extrap)
+        np.testing.assert_allclose(scen, exp, rtol=RTOL, atol=0, equal_nan=True)

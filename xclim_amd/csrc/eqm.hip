@@ -82,7 +82,7 @@ k_eqm_adjust(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, co
   // batches of 8 rows, the loads are issued before any use (8 independent rows in flight per lane instead of 2)
   auto adjust_one = [&](int64_t t, float x) {
     float a = xh_nan32();
-    if (m >= 1 && x == x) {
+    if (m >= 2 && x == x) {  // fewer than two valid nodes: NaN (scipy's interp1d refuses them; the oracle returns NaN)
       bool below = x < firstx, above = x > lastx;
       if (INTERP == 0) {
         a = firsty;
@@ -98,7 +98,6 @@ k_eqm_adjust(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, co
           lx = take ? cx[j] : lx; ly = take ? cy[j] : ly; ls = take ? sl[j] : ls;
         }
         a = ls * (x - lx) + ly;
-        if (m < 2) a = xh_nan32();
       }
       if (below) a = extrap == 0 ? firsty : xh_nan32();
       if (above) a = extrap == 0 ? lasty : xh_nan32();
