@@ -48,6 +48,13 @@ def pmc_traffic(kernel, grid):
     return None
 
 
+def seasonal_base(T, mean=288.0, amp=12.0, phase=100.0, period=365.0):
+    """Seasonal cycle table handed to xh_fill_synthetic (same formula as oracle/synth.py, which only the CPU baseline
+    leg imports: the measured path does not touch oracle/)."""
+    t = np.arange(T, dtype=np.float64)
+    return (mean + amp * np.sin(2.0 * np.pi * (t - phase) / period)).astype(np.float32)
+
+
 def event_time(dev, fn, reps):
     """Average duration (ms) of `fn` over `reps` launches, HIP events on the kernel's own stream."""
     fn()
@@ -110,10 +117,7 @@ def main():
     P = len(seg) - 1
     expected = ta.expected_count("YS")
     tidx_h = np.searchsorted(doys, ta.doy).astype(np.int32)
-    sys.path.insert(0, ROOT)
-    from oracle import synth  # input generator restated on the host (bit-identical to xh_fill_synthetic)
-
-    base = synth.seasonal_base(T)
+    base = seasonal_base(T)
     tasmax = K.fill_synthetic(dev, T, C, 0, 2, base, 3.0, cell0=rank * C)
     per = dev.empty((1, len(doys), C), np.float64)
     cnt, val = dev.empty((P, C), np.int32), dev.empty((P, C), np.int32)
@@ -232,11 +236,11 @@ def main():
 
     extra = {}
     if not args.no_extra and rank == 0 and world == 1:
-        extra = bench_extra(dev, K, ta, T, C, seg, P, synth, tasmax, tb, per, len(doys))
+        extra = bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, len(doys))
 
     cpu = None
     if not args.no_cpu and rank == 0 and world == 1:
-        cpu = cpu_baseline(T, Y, X, synth)
+        cpu = cpu_baseline(T, Y, X)
 
     if rank == 0:
         line = {
@@ -265,7 +269,7 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_extra(dev, K, ta, T, C, seg, P, synth, tasmax, tb, per, D):
+def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D):
     """The other two north-star workloads on the same 365 x 1440 x 720 grid (HIP-event times, one GPU)."""
     out = {}
     E = float(T) * C
@@ -294,7 +298,7 @@ def bench_extra(dev, K, ta, T, C, seg, P, synth, tasmax, tb, per, D):
                           "cell-timesteps/s": E / (ms * 1e-3), "algorithmic_bytes": b}
     del pr
     # --- EQM train + adjust (nquantiles 20, "+", nearest, constant) ---
-    base = synth.seasonal_base(T)
+    base = seasonal_base(T)
     ref = K.fill_synthetic(dev, T, C, 0, 4, base, 3.0)
     hist = K.fill_synthetic(dev, T, C, 0, 5, base + np.float32(1.5), 3.3)
     sim = K.fill_synthetic(dev, T, C, 0, 6, base + np.float32(3.5), 3.3)
@@ -348,7 +352,7 @@ def _cpu_worker(job):
     return ncells, spent
 
 
-def cpu_baseline(T, Y, X, synth, budget_s=10.0):
+def cpu_baseline(T, Y, X, budget_s=10.0):
     """Oracle (numpy restatement of the reference) on a sample of the SAME synthetic field, on the host cores of this box.
 
     One worker PROCESS per core (up to 16: on the MI355X boxes 64 workers gave LESS aggregate throughput, 1.38e8 vs

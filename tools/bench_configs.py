@@ -13,7 +13,6 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from oracle import synth  # noqa: E402
 from xclim_amd import kernels as K  # noqa: E402
 from xclim_amd._capi import Device  # noqa: E402
 from xclim_amd.timeaxis import TimeAxis  # noqa: E402
@@ -45,7 +44,7 @@ ta = TimeAxis.daily("1981-01-01", T, "noleap")
 tb, years, doys = ta.doy_table()
 seg, _ = ta.segments("YS")
 P = len(seg) - 1
-base = synth.seasonal_base(T)
+base = bench.seasonal_base(T)
 tas = K.fill_synthetic(dev, T, C, 0, 2, base, 3.0)
 per = dev.empty((1, len(doys), C), np.float64)
 cnt, val = dev.empty((P, C), np.int32), dev.empty((P, C), np.int32)

@@ -4,13 +4,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xclim_amd import kernels as K
 from xclim_amd._capi import Device
-from oracle import synth
 import bench
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 365
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 1440 * 720
 dev = Device(0)
-base = synth.seasonal_base(T)
+base = bench.seasonal_base(T)
 ref = K.fill_synthetic(dev, T, C, 0, 4, base, 3.0)
 hist = K.fill_synthetic(dev, T, C, 0, 5, base + np.float32(1.5), 3.3)
 q = (np.arange(20) + 0.5) / 20

@@ -5,11 +5,10 @@ import numpy as np
 import bench
 from xclim_amd import kernels as K
 from xclim_amd._capi import Device
-from oracle import synth
 
 dev = Device(0)
 T, C = 365, 1440 * 720
-base = synth.seasonal_base(T)
+base = bench.seasonal_base(T)
 ref = K.fill_synthetic(dev, T, C, 0, 4, base, 3.0)
 hist = K.fill_synthetic(dev, T, C, 0, 5, base + np.float32(1.5), 3.3)
 q = (np.arange(20) + 0.5) / 20

@@ -5,7 +5,6 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xclim_amd import kernels as K
 from xclim_amd._capi import Device
-from oracle import synth
 import bench
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 365
@@ -13,7 +12,7 @@ C = int(sys.argv[2]) if len(sys.argv) > 2 else 1440 * 720
 dev = Device(0)
 q = (np.arange(20) + 0.5) / 20
 zero = np.zeros(T, dtype=np.float32)
-for name, x in (("tas", K.fill_synthetic(dev, T, C, 0, 4, synth.seasonal_base(T), 3.0)),
+for name, x in (("tas", K.fill_synthetic(dev, T, C, 0, 4, bench.seasonal_base(T), 3.0)),
                 ("pr p_wet=0.3", K.fill_synthetic(dev, T, C, 1, 3, zero, 40.0 / 86400.0, 0.3)),
                 ("pr p_wet=0.6", K.fill_synthetic(dev, T, C, 1, 3, zero, 40.0 / 86400.0, 0.6))):
     ms = bench.event_time(dev, lambda: K.quantile_series(dev, x, q), 3)

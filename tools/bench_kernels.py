@@ -8,7 +8,6 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from oracle import synth  # noqa: E402
 from xclim_amd import kernels as K  # noqa: E402
 from xclim_amd._capi import Device  # noqa: E402
 from xclim_amd.timeaxis import TimeAxis  # noqa: E402
@@ -20,7 +19,7 @@ dev = Device(0)
 ta = TimeAxis.daily("2001-01-01", T, "noleap")
 seg_y, _ = ta.segments("YS")
 seg_m, _ = ta.segments("MS")
-base = synth.seasonal_base(T)
+base = bench.seasonal_base(T)
 tas = K.fill_synthetic(dev, T, C, 0, 2, base, 3.0)
 tas2 = K.fill_synthetic(dev, T, C, 0, 7, base + np.float32(6.0), 3.0)
 pr = K.fill_synthetic(dev, T, C, 1, 3, np.zeros(T, np.float32), 40.0 / 86400.0, 0.3)

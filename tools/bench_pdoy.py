@@ -5,7 +5,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xclim_amd import kernels as K
 from xclim_amd._capi import Device
 from xclim_amd.timeaxis import TimeAxis
-from oracle import synth
 import bench
 
 ny = int(sys.argv[1]) if len(sys.argv) > 1 else 30
@@ -15,7 +14,7 @@ T = 365 * ny if cal == "noleap" else 365 * ny + (ny + 3) // 4
 dev = Device(0)
 ta = TimeAxis.daily("2000-01-01", T, cal)
 tb, years, doys = ta.doy_table()
-x = K.fill_synthetic(dev, T, C, 0, 2, synth.seasonal_base(T), 3.0)
+x = K.fill_synthetic(dev, T, C, 0, 2, bench.seasonal_base(T), 3.0)
 out = dev.empty((1, len(doys), C), np.float64)
 ms = bench.event_time(dev, lambda: K.percentile_doy(dev, x, tb, 5, [90.0], out=out), 2)
 E = float(T) * C
