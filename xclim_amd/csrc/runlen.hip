@@ -234,45 +234,49 @@ k_run_max_fused(const float* __restrict__ x, int64_t C, int64_t st, float thr, i
 // the run (index="first": remaining length from t on -> march backwards; "last": length ending at t -> forwards);
 // window == 1: d = (mask > 0) [fillna(0)].  Result per period: first (last) t with d == 1, relative to the
 // period start; NaN when d is constant over the period (argmax == argmin, rl:603-605: also the all-True case).
-template <bool FIRST, bool CUT>
+template <int VEC, bool FIRST, bool CUT>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_boundary_run(const float* __restrict__ x, int64_t C, int64_t st, int fused_op, float thr, int window,
                const int64_t* __restrict__ seg_off, int P, float* __restrict__ out, int32_t* __restrict__ valid_out) {
-  int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  // a lane owns VEC cells; rows in double-buffered batches of 8 (xh_march_rows / _rev)
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
   const bool fused = fused_op >= 0;
-  int run = 0;
+  int run[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) run[i] = 0;
   int pstep = CUT ? (int)gridDim.y : 1;
   int pbeg = CUT ? (int)blockIdx.y : 0;
   for (int pp = pbeg; pp < P; pp += pstep) {
     int p = FIRST ? (P - 1 - pp) : pp;  // FIRST marches backwards through periods
     int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
-    if (CUT) run = 0;
-    int ones = 0, nvalid = 0;
-    int64_t hit = -1;
-    if (FIRST) {
-#pragma unroll 4
-      for (int64_t t = t1 - 1; t >= t0; --t) {
-        float v = x[t * st + c];
-        bool on = fused ? xh_cmp_f32(v, fused_op, thr) : (v > 0.0f);
-        nvalid += (v == v) ? 1 : 0;
-        run = on ? run + 1 : 0;
-        if (run >= window) { hit = t; ones++; }
-      }
-    } else {
-#pragma unroll 4
-      for (int64_t t = t0; t < t1; ++t) {
-        float v = x[t * st + c];
-        bool on = fused ? xh_cmp_f32(v, fused_op, thr) : (v > 0.0f);
-        nvalid += (v == v) ? 1 : 0;
-        run = on ? run + 1 : 0;
-        if (run >= window) { hit = t; ones++; }
-      }
+    int ones[VEC], nvalid[VEC], hit[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if (CUT) run[i] = 0;
+      ones[i] = 0; nvalid[i] = 0; hit[i] = -1;
     }
-    int len = (int)(t1 - t0);
-    float r = (ones == 0 || ones == len) ? xh_nan32() : (float)(hit - t0);
-    out[(int64_t)p * C + c] = r;
-    if (valid_out) valid_out[(int64_t)p * C + c] = nvalid;
+    auto step = [&](int64_t t, const VecF<VEC>& xv) {
+      const int rel = (int)(t - t0);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float v = xv.v[i];
+        const bool on = fused ? xh_cmp_f32(v, fused_op, thr) : (v > 0.0f);
+        nvalid[i] += (v == v) ? 1 : 0;
+        run[i] = on ? run[i] + 1 : 0;
+        const bool h = run[i] >= window;
+        hit[i] = h ? rel : hit[i];
+        ones[i] += h ? 1 : 0;
+      }
+    };
+    if (FIRST) xh_march_rows_rev<VEC, 8>(x + c, st, t0, t1, step);
+    else xh_march_rows<VEC, 8>(x + c, st, t0, t1, step);
+    const int len = (int)(t1 - t0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      out[(int64_t)p * C + c + i] = (ones[i] == 0 || ones[i] == len) ? xh_nan32() : (float)hit[i];
+      if (valid_out) valid_out[(int64_t)p * C + c + i] = nvalid[i];
+    }
   }
 }
 
@@ -433,22 +437,20 @@ int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, 
   if (C == 0) return XH_OK;
   unsigned py = (unsigned)(P > 4096 ? 4096 : P);
   if (stat == XH_RUN_FIRST || stat == XH_RUN_LAST) {
-    dim3 grid((unsigned)cdiv64(C, XH_BLOCK), cut_at_segments ? py : 1u);
-    if (stat == XH_RUN_FIRST) {
-      if (cut_at_segments)
-        hipLaunchKernelGGL((k_boundary_run<true, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, fused_op,
-                           (float)thr, window, d_seg, P, out, valid_out);
-      else
-        hipLaunchKernelGGL((k_boundary_run<true, false>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, fused_op,
-                           (float)thr, window, d_seg, P, out, valid_out);
+    const int bvec = (xh_pick_vec(x, C, st) == 4 && cdiv64(cdiv64(C, 4), XH_BLOCK) * (cut_at_segments ? py : 1u) >= 2u * (unsigned)ctx->num_cu) ? 4 : 1;
+    dim3 grid((unsigned)cdiv64(cdiv64(C, bvec), XH_BLOCK), cut_at_segments ? py : 1u);
+#define XH_BR(V, F, CU)                                                                                                 \
+  hipLaunchKernelGGL((k_boundary_run<V, F, CU>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, fused_op, (float)thr, window, \
+                     d_seg, P, out, valid_out)
+    const bool first = stat == XH_RUN_FIRST;
+    if (bvec == 4) {
+      if (first) { if (cut_at_segments) XH_BR(4, true, true); else XH_BR(4, true, false); }
+      else { if (cut_at_segments) XH_BR(4, false, true); else XH_BR(4, false, false); }
     } else {
-      if (cut_at_segments)
-        hipLaunchKernelGGL((k_boundary_run<false, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, fused_op,
-                           (float)thr, window, d_seg, P, out, valid_out);
-      else
-        hipLaunchKernelGGL((k_boundary_run<false, false>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, fused_op,
-                           (float)thr, window, d_seg, P, out, valid_out);
+      if (first) { if (cut_at_segments) XH_BR(1, true, true); else XH_BR(1, true, false); }
+      else { if (cut_at_segments) XH_BR(1, false, true); else XH_BR(1, false, false); }
     }
+#undef XH_BR
     XH_LAUNCH_CHECK();
     return XH_OK;
   }
