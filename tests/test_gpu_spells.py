@@ -393,3 +393,36 @@ def test_spell_length(dev, rng, reducer, op):
         np.testing.assert_allclose(got, ref, rtol=1e-6)
     with pytest.raises(ValueError):
         xgen.spell_length(x, 1.0, "std", ta, "YS", op, device=dev)
+
+
+@pytest.mark.parametrize("coord", ["dayofyear", "month", "day", "year"])
+def test_boundary_run_coord(dev, rng, coord):
+    """first_run / last_run / first_run_after_date with coord=<datetime field> (rl:586-597: the index is looked up in
+    da.time.dt.<coord>), whole series and per period."""
+    T = 900
+    x = (rng.random((T, 4, 5)) < 0.35).astype(np.float32)
+    x[:, 0, 0] = 0.0  # no run -> NaN stays NaN
+    ta, ot = TimeAxis.daily("2001-02-10", T), OTime.standard("2001-02-10", T)
+    table = {"dayofyear": ot.doy, "month": ot.month, "day": ot.day, "year": ot.year}[coord]
+
+    def lookup(idx, offsets):
+        out = np.full(idx.shape, np.nan)
+        for p, off in enumerate(offsets):
+            ok = ~np.isnan(idx[p])
+            out[p][ok] = table[off + idx[p][ok].astype(int)]
+        return out
+
+    for window in (1, 3):
+        for f, of in ((xrl.first_run, orl.first_run), (xrl.last_run, orl.last_run)):
+            got = f(x, window, coord=coord, time=ta, device=dev)
+            exp = lookup(of(x > 0, window)[None], [0])[0]
+            np.testing.assert_array_equal(got, exp)
+            seg, _ = ta.segments("YS")
+            got = f(x, window, freq="YS", coord=coord, time=ta, device=dev)
+            exp = lookup(of(x > 0, window, ot, "YS"), seg[:-1])
+            np.testing.assert_array_equal(got, exp)
+    assert np.isnan(xrl.first_run(x, 3, coord=coord, time=ta, device=dev)[0, 0])
+    with pytest.raises(NotImplementedError):
+        xrl.first_run(x, 3, coord="hour", time=ta, device=dev)
+    with pytest.raises(ValueError):
+        xrl.first_run(x, 3, coord=coord, device=dev)

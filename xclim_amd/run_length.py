@@ -124,14 +124,28 @@ def windowed_run_count(da, window: int, dim="time", freq=None, ufunc_1dim="from_
 
 def first_run(da, window: int, dim="time", freq=None, coord=None, ufunc_1dim="from_context", *, time=None, device=None,
               keep=False):
-    """rl:643-690 (index output; coord lookups are host work on the 1-D time axis)."""
-    return _run(da, "first", window, time, freq, "first", device, keep, cut=(window == 1))
+    """rl:643-690.  ``coord`` ("dayofyear", "year", "month", "day") maps the index through the time axis (host work on the
+    small result, rl:586-597); it needs ``time``."""
+    return _boundary(da, "first", window, time, freq, coord, device, keep)
 
 
 def last_run(da, window: int, dim="time", freq=None, coord=None, ufunc_1dim="from_context", *, time=None, device=None,
              keep=False):
-    """rl:693-740."""
-    return _run(da, "last", window, time, freq, "first", device, keep, cut=(window == 1))
+    """rl:693-740 (``coord`` as in :func:`first_run`)."""
+    return _boundary(da, "last", window, time, freq, coord, device, keep)
+
+
+def _boundary(da, stat, window, time, freq, coord, device, keep):
+    res = _run(da, stat, window, time, freq, "first", device, keep, cut=(window == 1))
+    if not coord:
+        return res
+    if keep:
+        raise ValueError("coord lookups are applied to host results: use keep=False")
+    if time is None:
+        raise ValueError("coord needs the time axis (time=TimeAxis)")
+    seg = _whole(len(time)) if freq is None else time.segments(freq)[0]
+    flat = np.array(res, dtype=np.float64).reshape(len(seg) - 1, -1)
+    return _to_coord(flat, seg, coord, time).reshape(np.shape(res))
 
 
 def windowed_max_run_sum(da, window: int, dim="time", freq=None, index="first", *, time=None, device=None, keep=False):
@@ -203,12 +217,11 @@ def season(da, window: int, mid_date: str | None = None, dim="time", stat=None, 
                 mid[p] = idx[0]
     s, e, ln = (a.get() for a in K.season(dev, m, window, seg, mid))
     if coord:
-        if coord != "dayofyear":
-            raise NotImplementedError("only coord='dayofyear' is supported")
+        table = _coord_table(time, coord)
         for arr in (s, e):
             for p in range(P):
                 ok = ~np.isnan(arr[p])
-                arr[p, ok] = time.doy[int(seg[p]) + arr[p, ok].astype(np.int64)]
+                arr[p, ok] = table[int(seg[p]) + arr[p, ok].astype(np.int64)]
     shp = (P,) + tuple(cell_shape)
     out = {"start": s.reshape(shp), "end": e.reshape(shp), "length": ln.reshape(shp)}
     if freq is None:
@@ -258,13 +271,21 @@ def _date_bounded(da, window, date, time, freq, device, *, side, invert=False, l
     return res, seg, cell_shape
 
 
+def _coord_table(time: TimeAxis, coord) -> np.ndarray:
+    """The 1-D array that ``coord`` selects on the time axis (rl:690, 740: ``da[dim].dt.<coord>`` looked up at the run's
+    index through utils.lazy_indexing).  The lookup itself is host work on (period, cell) results."""
+    names = {"dayofyear": "doy", "year": "year", "month": "month", "day": "day"}
+    if coord is True or coord not in names:
+        raise NotImplementedError(f"coord={coord!r}: supported datetime fields are {sorted(names)}")
+    return np.asarray(getattr(time, names[coord]))
+
+
 def _to_coord(res, seg, coord, time):
     if coord:
-        if coord != "dayofyear":
-            raise NotImplementedError("only coord='dayofyear' is supported")
+        table = _coord_table(time, coord)
         for p in range(res.shape[0]):
             ok = ~np.isnan(res[p])
-            res[p, ok] = time.doy[int(seg[p]) + res[p, ok].astype(np.int64)]
+            res[p, ok] = table[int(seg[p]) + res[p, ok].astype(np.int64)]
     return res
 
 
@@ -358,10 +379,9 @@ def run_bounds(mask, dim="time", coord=False, *, time: TimeAxis | None = None, d
     ev = K.run_events(dev, m, seg, n, want=("start", "end"))
     out = np.stack([ev["start"].get()[0], ev["end"].get()[0]]).astype(np.float64).reshape((2, n) + tuple(cell_shape))
     if coord:
-        if coord != "dayofyear":
-            raise NotImplementedError("only coord='dayofyear' is supported")
+        table = _coord_table(time, coord)
         ok = ~np.isnan(out)
-        out[ok] = time.doy[out[ok].astype(np.int64)]
+        out[ok] = table[out[ok].astype(np.int64)]
     return out
 
 
