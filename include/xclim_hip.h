@@ -169,7 +169,8 @@ int xh_range_reduce(xh_ctx* ctx, const float* low, const float* high, int64_t T,
 /* compare (generic.py:301-326) / get_daily_events (generic.py:395-431) as an elementwise map of a (T, C) field against a
  * scalar (fp32 compare, or fp64 when thr_is_f64) or a second field b (NULL for the scalar form):
  *   out_kind 0: uint8 mask    1: float32 1/0 with NaN where a is NaN    2: float32 a.where(cond) (NaN elsewhere)
- *            3: float32 1/0 (the boolean mask as float, NaN compares False) */
+ *            3: float32 1/0 (the boolean mask as float, NaN compares False)
+ *            4: float32 (a - thr).clip(0), NaN where a is NaN (`op` unused; hot_spell_max_magnitude, _threshold.py:2056-2057) */
 int xh_compare_map(xh_ctx* ctx, const float* a, int64_t T, int64_t C, int64_t st, int op, double thr, int thr_is_f64,
                    const float* b, int64_t st_b, int out_kind, void* out, int64_t st_out);
 
@@ -255,10 +256,12 @@ int xh_keep_longest_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64
 int xh_season(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window,
               const int64_t* seg_off, const int32_t* mid_idx, int P, float* start_out, float* end_out,
               float* len_out);
-/* windowed_max_run_sum (indices/run_length.py:491-540), runs cut at period edges: max over runs (x > 0) of at
- * least `window` steps of the run's sum; out (P, C) float32. */
+/* windowed_max_run_sum (indices/run_length.py:491-540): max over the runs (x > 0) of at least `window` steps of the
+ * run's sum; out (P, C) float32.  cut_at_segments != 0: runs cut at the period edges (rl.resample_and_rl with
+ * resample_before_rl, the default of hot_spell_max_magnitude); 0: the reference's own `freq` semantics — cumsum and run
+ * lengths over the whole series, a run's sum attributed to the period of its first step (segments must cover [0, T)). */
 int xh_max_run_sum(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window,
-                   const int64_t* seg_off, int P, float* out);
+                   const int64_t* seg_off, int P, int cut_at_segments, float* out);
 
 /* Event compaction for run_bounds (run_length.py:745-802) and find_events / _find_events (run_length.py:1760-1901).
  * `runs` is a 0/1 float field (a mask, or xh_runs_with_holes output).  The k-th run (time order) of (period p, cell c)

@@ -160,3 +160,13 @@ def heat_wave_total_length(tasmin, tasmax, time: OTime, thresh_tasmin, thresh_ta
 
     cond = _heat_wave_cond(tasmin, tasmax, thresh_tasmin, thresh_tasmax, op)
     return rl.resample_and_rl(cond, resample_before_rl, rl.windowed_run_count, time=time, freq=freq, window=window)
+
+
+def hot_spell_max_magnitude(tasmax, thresh, time: OTime, window=3, freq="YS", resample_before_rl=True):
+    """indices/_threshold.py:2056-2065: over = (tasmax - thresh).clip(0); resample_and_rl(over, ..., windowed_max_run_sum)."""
+    from . import run_length as rl
+
+    tasmax = np.asarray(tasmax)
+    with np.errstate(invalid="ignore"):
+        over = np.clip(tasmax - tasmax.dtype.type(thresh), 0, None)
+    return rl.resample_and_rl(over, resample_before_rl, rl.windowed_max_run_sum, window, time=time, freq=freq)

@@ -663,3 +663,27 @@ def test_heat_wave_indices_reference_known_answers(dev):
         assert xi.heat_wave_frequency(tn, tx, ta, a + K2C, b + K2C, w, **kw)[0, 0] == f
         assert xi.heat_wave_max_length(tn, tx, ta, a + K2C, b + K2C, w, **kw)[0, 0] == m
         assert xi.heat_wave_total_length(tn, tx, ta, a + K2C, b + K2C, w, **kw)[0, 0] == tot
+
+
+@pytest.mark.parametrize("before", [True, False])
+def test_hot_spell_max_magnitude(dev, rng, before):
+    """indices/_threshold.py:2019-2066: (tasmax - thresh).clip(0) -> windowed_max_run_sum, cut at the period edges or
+    resampled after; the reference's known answer (tests/test_indices.py:2132-2142) and seeded parity."""
+    a = np.zeros(365)
+    a[15:20] += 30
+    a[40:42] += 50
+    a[86:96] += 30
+    da = (a + 273.15).astype(np.float32)[:, None]
+    ta = TimeAxis.daily("2000-07-01", 365)
+    out = xi.hot_spell_max_magnitude(da, 25 + 273.15, ta, 3, "ME", device=dev, mask_missing=False)
+    np.testing.assert_allclose(out[:, 0], [25, 0, 30, 20, 0, 0, 0, 0, 0, 0, 0, 0], atol=1e-3)
+    T = 1095
+    x = _temp(rng, T, (5, 6), nan_frac=0.003)
+    x += np.repeat(rng.normal(0, 3.0, (T // 7 + 1, 5, 6)), 7, axis=0)[:T].astype(np.float32)
+    ta, ot = _axes("2001-01-01", T)
+    for freq in ("YS", "MS"):
+        for window in (1, 3):
+            got = xi.hot_spell_max_magnitude(x, 295.15, ta, window, freq, before, device=dev, mask_missing=False)
+            ref = oidx.hot_spell_max_magnitude(x, 295.15, ot, window, freq, before)
+            np.testing.assert_allclose(got, ref, rtol=1e-6, atol=0)
+    assert np.nanmax(got) > 0

@@ -165,9 +165,20 @@ def test_windowed_max_run_sum(dev, rng, window):
     ta, ot = TimeAxis.daily("2002-01-01", T), OTime.standard("2002-01-01", T)
     got = xrl.windowed_max_run_sum(x, window, device=dev)
     np.testing.assert_allclose(got, orl.windowed_max_run_sum(x, window), rtol=1e-6)
-    got = xrl.windowed_max_run_sum(x, window, freq="MS", time=ta, device=dev)
-    exp = orl.resample_and_rl(x, True, orl.windowed_max_run_sum, window, time=ot, freq="MS")
-    np.testing.assert_allclose(got, exp, rtol=1e-6)
+    x[:, 7] = 0.0                      # no run at all
+    x[20:140, 8] = 2.5e-4              # one run across five months: it counts for the month of its first day only
+    for freq in ("MS", "QS-DEC", "YS"):
+        # resample before (runs cut at the period edges): rl.resample_and_rl(..., resample_before_rl=True)
+        exp = orl.resample_and_rl(x, True, orl.windowed_max_run_sum, window, time=ot, freq=freq)
+        got = xrl.resample_and_rl(x, True, xrl.windowed_max_run_sum, window, freq=freq, time=ta, device=dev)
+        np.testing.assert_allclose(got, exp, rtol=1e-6)
+        np.testing.assert_allclose(xrl.windowed_max_run_sum(x, window, freq=freq, time=ta, device=dev, cut=True), exp, rtol=1e-6)
+        # the reference's own `freq` argument resamples AFTER: cumsum and run lengths cross the period edges
+        exp = orl.windowed_max_run_sum(x, window, ot, freq)
+        got = xrl.windowed_max_run_sum(x, window, freq=freq, time=ta, device=dev)
+        np.testing.assert_allclose(got, exp, rtol=1e-6)
+        np.testing.assert_allclose(xrl.resample_and_rl(x, False, xrl.windowed_max_run_sum, window, freq=freq, time=ta, device=dev),
+                                   exp, rtol=1e-6)
     f = np.zeros((50, 1), np.float32)
     f[4:6] = 5
     f[25:30] = 5

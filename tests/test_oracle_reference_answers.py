@@ -324,3 +324,17 @@ def test_wet_percentile_and_heat_wave_indices_known_answers():
     assert oidx.heat_wave_frequency(tn, tx, t10, 22 + K2C, 30 + K2C, 4)[0] == 1
     assert oidx.heat_wave_max_length(tn, tx, t10, 22 + K2C, 30 + K2C, 5)[0] == 0
     assert oidx.heat_wave_total_length(tn, tx, t10, 22 + K2C, 30 + K2C, 5)[0] == 0
+
+
+def test_hot_spell_max_magnitude_known_answer():
+    """tests/test_indices.py:2132-2142 (TestHotSpellMaxMagnitude; the series fixture starts on 2000-07-01, monthly periods)."""
+    from oracle import indices as oidx
+    from oracle.timeutil import OTime
+
+    a = np.zeros(365)
+    a[15:20] += 30
+    a[40:42] += 50
+    a[86:96] += 30
+    da = (a + 273.15).astype(np.float32)
+    out = oidx.hot_spell_max_magnitude(da, 25 + 273.15, OTime.standard("2000-07-01", 365), 3, "MS")
+    np.testing.assert_allclose(out, [25, 0, 30, 20, 0, 0, 0, 0, 0, 0, 0, 0], atol=1e-3)

@@ -100,6 +100,10 @@ k_compare_map(const float* __restrict__ a, int64_t T, int64_t C, int64_t st, int
       m[i] = cond ? 1 : 0;
       if (out_kind == 1) r[i] = (v.v[i] == v.v[i]) ? (cond ? 1.f : 0.f) : xh_nan32();
       else if (out_kind == 2) r[i] = cond ? v.v[i] : xh_nan32();
+      else if (out_kind == 4) {  // (a - thr).clip(0): NaN stays NaN (hot_spell_max_magnitude, _threshold.py:2056-2057)
+        const float dlt = v.v[i] - (b ? w.v[i] : thr32);
+        r[i] = (dlt != dlt) ? dlt : (dlt > 0.f ? dlt : 0.f);
+      }
       else r[i] = cond ? 1.f : 0.f;
     }
     if (out_kind == 0) {
@@ -279,7 +283,7 @@ int xh_compare_map(xh_ctx* ctx, const float* a, int64_t T, int64_t C, int64_t st
   XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "xh_compare_map: negative shape");
   XH_REQUIRE(st >= C && st_out >= C && (!b || st_b >= C), XH_ERR_LAYOUT, "xh_compare_map: needs time-major views");
   XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
-  XH_REQUIRE(out_kind >= 0 && out_kind <= 3, XH_ERR_ARG, "xh_compare_map: out_kind must be 0, 1, 2 or 3");
+  XH_REQUIRE(out_kind >= 0 && out_kind <= 4, XH_ERR_ARG, "xh_compare_map: out_kind must be 0 .. 4");
   if (T == 0 || C == 0) return XH_OK;
   // 16-byte path: every view aligned (the uint8 output needs 4-byte alignment of its rows)
   int vec = xh_pick_vec(a, C, st);

@@ -268,42 +268,79 @@ k_season(const float* __restrict__ x, int64_t C, int64_t st, int window, const i
 // ---- windowed_max_run_sum (cut at segments / whole series) ------------------------------------------------------
 // rl:491-540: d_rse = reset-cumsum of the VALUES from the run's first element to the next exact zero (NaN adds 0
 // and does not reset), kept where rle(da > 0) >= window, max over the period.  Backward march.
-template <int VEC>
+template <int VEC, bool CUT>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_max_run_sum(const float* __restrict__ x, int64_t C, int64_t st, int window, const int64_t* __restrict__ seg_off, int P,
               float* __restrict__ out) {
   int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
-  for (int p = blockIdx.y; p < P; p += gridDim.y) {
-    const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
-    // the reference's arithmetic, restated so that results are bit-identical: cs = running fp32 cumsum of the
-    // reversed series (NaN adds 0, never reset), csr = cs at the latest exact zero, d_rse = cs - csr (rl:154-169).
-    // Whether step t is the FIRST of its run is known one step later in the backward march, so the candidate of
-    // step t is held back until t - 1 has been seen (rows are loaded once, in double-buffered batches).
-    float cs[VEC], csr[VEC], best[VEC], pacc[VEC];
-    int run[VEC], prun[VEC];
-    bool pon[VEC];
+  // the reference's arithmetic, restated so that results are bit-identical: cs = running fp32 cumsum of the
+  // reversed series (NaN adds 0, never reset), csr = cs at the latest exact zero, d_rse = cs - csr (rl:154-169).
+  // Whether step t is the FIRST of its run is known one step later in the backward march, so the candidate of
+  // step t is held back until t - 1 has been seen (rows are loaded once, in double-buffered batches).
+  float cs[VEC], csr[VEC], best[VEC], pacc[VEC];
+  int run[VEC], prun[VEC];
+  bool pon[VEC];
+  auto reset = [&]() {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { cs[v] = 0.f; csr[v] = 0.f; best[v] = 0.f; pacc[v] = 0.f; run[v] = 0; prun[v] = 0; pon[v] = false; }
-    xh_march_rows_rev<VEC, 8>(x + c, st, t0, t1, [&](int64_t, const VecF<VEC>& xv) {
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        const float val = xv.v[v];
-        const bool on = val > 0.0f;
-        const float d = (pon[v] && !on && prun[v] >= window) ? pacc[v] : 0.0f;  // step t + 1 was the first of its run
-        best[v] = d > best[v] ? d : best[v];
-        cs[v] = cs[v] + ((val == val) ? val : 0.0f);
-        if (val == 0.0f) csr[v] = cs[v];
-        run[v] = on ? run[v] + 1 : 0;
-        pon[v] = on; pacc[v] = cs[v] - csr[v]; prun[v] = run[v];
-      }
-    });
+  };
+  auto fold_pending = [&](const bool (&on_now)[VEC]) {  // the pending step is the first of its run iff this one is off
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      const float d = (pon[v] && prun[v] >= window) ? pacc[v] : 0.0f;  // a run that starts on the first step
-      const float b2 = d > best[v] ? d : best[v];
-      out[(int64_t)p * C + c + v] = (t1 > t0) ? b2 : xh_nan32();
+      const float d = (pon[v] && !on_now[v] && prun[v] >= window) ? pacc[v] : 0.0f;
+      best[v] = d > best[v] ? d : best[v];
     }
+  };
+  auto advance = [&](const VecF<VEC>& xv, const bool (&on_now)[VEC]) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float val = xv.v[v];
+      cs[v] = cs[v] + ((val == val) ? val : 0.0f);
+      if (val == 0.0f) csr[v] = cs[v];
+      run[v] = on_now[v] ? run[v] + 1 : 0;
+      pon[v] = on_now[v]; pacc[v] = cs[v] - csr[v]; prun[v] = run[v];
+    }
+  };
+  auto flush = [&](int p, bool nonempty) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { out[(int64_t)p * C + c + v] = nonempty ? best[v] : xh_nan32(); best[v] = 0.f; }
+  };
+  bool off[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) off[v] = false;
+  if (CUT) {
+    for (int p = blockIdx.y; p < P; p += gridDim.y) {
+      const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+      reset();
+      xh_march_rows_rev<VEC, 8>(x + c, st, t0, t1, [&](int64_t, const VecF<VEC>& xv) {
+        bool on[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) on[v] = xv.v[v] > 0.0f;
+        fold_pending(on);
+        advance(xv, on);
+      });
+      fold_pending(off);  // a run that starts on the first step
+      flush(p, t1 > t0);
+    }
+  } else {
+    // resample AFTER (rl:533-538): one march over the whole series — the cumsum and the run lengths cross the period
+    // edges — and a run's sum goes to the period of its first step
+    reset();
+    int pq = P - 1;                   // period of the pending step
+    int64_t q0 = seg_off[pq];
+    bool any = false;                 // period pq holds at least one step
+    xh_march_rows_rev<VEC, 8>(x + c, st, seg_off[0], seg_off[P], [&](int64_t t, const VecF<VEC>& xv) {
+      bool on[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) on[v] = xv.v[v] > 0.0f;
+      fold_pending(on);
+      while (t < q0) { flush(pq, any); any = false; pq--; q0 = seg_off[pq]; }  // the pending step closed its period(s)
+      any = true;
+      advance(xv, on);
+    });
+    fold_pending(off);
+    while (pq >= 0) { flush(pq, any); any = false; pq--; }
   }
 }
 
@@ -544,7 +581,7 @@ int xh_season(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int
 }
 
 int xh_max_run_sum(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window,
-                   const int64_t* seg_off, int P, float* out) {
+                   const int64_t* seg_off, int P, int cut_at_segments, float* out) {
   int rc = chk("xh_max_run_sum", ctx, x, T, C, st, sc);
   if (rc) return rc;
   XH_REQUIRE(out, XH_ERR_ARG, "xh_max_run_sum: out is NULL");
@@ -554,12 +591,18 @@ int xh_max_run_sum(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   rc = upload_seg(ctx, &cur, seg_off, P, T, "xh_max_run_sum", &d_seg);
   if (rc) return rc;
   if (C == 0) return XH_OK;
-  if (xh_pick_vec(x, C, st) == 4)
-    hipLaunchKernelGGL((k_max_run_sum<4>), dim3((unsigned)cdiv64(cdiv64(C, 4), XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)),
-                       dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, d_seg, P, out);
-  else
-    hipLaunchKernelGGL((k_max_run_sum<1>), dim3((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)), dim3(XH_BLOCK),
-                       0, ctx->stream, x, C, st, window, d_seg, P, out);
+  const unsigned py = cut_at_segments ? (unsigned)(P > 4096 ? 4096 : P) : 1u;
+  if (!cut_at_segments)
+    XH_REQUIRE(seg_off[0] == 0 && seg_off[P] == T, XH_ERR_ARG, "xh_max_run_sum: resample-after mode needs segments covering [0, T)");
+  const bool v4 = xh_pick_vec(x, C, st) == 4 && (cut_at_segments || cdiv64(cdiv64(C, 4), XH_BLOCK) >= 2 * (int64_t)ctx->num_cu);
+  dim3 grid((unsigned)cdiv64(cdiv64(C, v4 ? 4 : 1), XH_BLOCK), py);
+  if (v4) {
+    if (cut_at_segments) hipLaunchKernelGGL((k_max_run_sum<4, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, d_seg, P, out);
+    else hipLaunchKernelGGL((k_max_run_sum<4, false>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, d_seg, P, out);
+  } else {
+    if (cut_at_segments) hipLaunchKernelGGL((k_max_run_sum<1, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, d_seg, P, out);
+    else hipLaunchKernelGGL((k_max_run_sum<1, false>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, d_seg, P, out);
+  }
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

@@ -326,6 +326,23 @@ def hot_spell_max_length(tasmax, thresh: float, time: TimeAxis, window: int = 1,
         return np.where(out < window, np.where(np.isnan(out), out, 0.0), out)
 
 
+def hot_spell_max_magnitude(tasmax, thresh: float, time: TimeAxis, window: int = 3, freq: str = "YS",
+                            resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_threshold.py:2019-2066: largest sum of (tasmax - thresh) over a run of at least `window` days above the
+    threshold: rl.windowed_max_run_sum of the clipped excess, cut at the period edges unless ``resample_before_rl=False``."""
+    from . import run_length as hrl
+    from .calendar import _flatten
+
+    dev = device or get_device()
+    x, cell_shape = _flatten(tasmax, dev)
+    over = K.compare_map(dev, x, ">", float(thresh), "excess")
+    seg, _ = time.segments(freq)
+    out = hrl.resample_and_rl(over, resample_before_rl, hrl.windowed_max_run_sum, window, freq=freq, time=time, device=dev,
+                              keep=True)
+    _, val = K.resample_reduce(dev, x, "count", seg)
+    return _masked(out, val, time, freq, dev, cell_shape, mask_missing)
+
+
 def cold_spell_days(tas, thresh: float, time: TimeAxis, window: int = 5, freq: str = "YS-JUL", op: str = "<",
                     resample_before_rl: bool = True, *, device=None, mask_missing=True):
     """indices/_threshold.py:158-213."""

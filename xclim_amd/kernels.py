@@ -192,10 +192,10 @@ def range_reduce(dev: Device, low: DeviceArray, high: DeviceArray, mode: str, re
 
 
 def compare_map(dev: Device, a: DeviceArray, op, thr, kind: str = "mask") -> DeviceArray:
-    """kind: "mask" (uint8) | "maskf" (float 1/0) | "events" (float 1/0/NaN) | "where" (a where cond else NaN); thr: scalar
-    or DeviceArray."""
+    """kind: "mask" (uint8) | "maskf" (float 1/0) | "events" (float 1/0/NaN) | "where" (a where cond else NaN) | "excess"
+    ((a - thr).clip(0), NaN kept; op unused); thr: scalar or DeviceArray."""
     T, C_ = _tc(a)
-    ok = {"mask": 0, "events": 1, "where": 2, "maskf": 3}[kind]
+    ok = {"mask": 0, "events": 1, "where": 2, "maskf": 3, "excess": 4}[kind]
     out = dev.empty(a.shape, np.uint8 if ok == 0 else np.float32)
     if isinstance(thr, DeviceArray):
         assert thr.shape == a.shape and thr.dtype == np.float32
@@ -310,11 +310,12 @@ def season(dev: Device, x: DeviceArray, window: int, seg_off, mid_idx=None):
     return s, e, ln
 
 
-def max_run_sum(dev: Device, x: DeviceArray, window: int, seg_off) -> DeviceArray:
+def max_run_sum(dev: Device, x: DeviceArray, window: int, seg_off, cut=True) -> DeviceArray:
+    """xh_max_run_sum; cut=False: the reference's resample-after semantics (runs cross the period edges)."""
     T, C_ = _tc(x)
     seg, P = _seg(seg_off)
     out = dev.empty((P, C_), np.float32)
-    dev.call("xh_max_run_sum", _vp(x.ptr), T, C_, C_, 1, int(window), np_ptr(seg), P, _vp(out.ptr))
+    dev.call("xh_max_run_sum", _vp(x.ptr), T, C_, C_, 1, int(window), np_ptr(seg), P, int(bool(cut)), _vp(out.ptr))
     return out
 
 

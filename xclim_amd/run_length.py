@@ -148,13 +148,18 @@ def _boundary(da, stat, window, time, freq, coord, device, keep):
     return _to_coord(flat, seg, coord, time).reshape(np.shape(res))
 
 
-def windowed_max_run_sum(da, window: int, dim="time", freq=None, index="first", *, time=None, device=None, keep=False):
-    """rl:491-540 for non-negative NaN-free values (the documented use: precipitation sums over wet runs).  With
-    `freq` the runs are cut at the period edges (resample-before semantics)."""
+def windowed_max_run_sum(da, window: int, dim="time", freq=None, index="first", *, time=None, device=None, keep=False,
+                         cut=False):
+    """rl:491-540: largest sum of the values of a run (da > 0) of at least `window` steps.  With `freq` the reference
+    resamples AFTER (run sums and lengths cross the period edges, a run counts for the period of its first step);
+    ``cut=True`` cuts the runs at the period edges instead — what :func:`resample_and_rl` does with
+    ``resample_before_rl=True`` (the default of hot_spell_max_magnitude)."""
+    if index != "first" and freq is not None and not cut:
+        raise NotImplementedError("windowed_max_run_sum: resampling after the run length needs index='first' on the HIP path")
     dev = device or get_device()
     m, cell_shape = _mask(da, dev)
     seg = _whole(m.shape[0]) if freq is None else time.segments(freq)[0]
-    out = K.max_run_sum(dev, m, window, seg)
+    out = K.max_run_sum(dev, m, window, seg, cut=(cut or freq is None))
     if keep:
         return out
     o = out.get().reshape((out.shape[0],) + tuple(cell_shape))
@@ -325,7 +330,8 @@ def run_end_after_date(da, window: int, date: str = "07-01", dim="time", coord=F
     return _shape(_to_coord(end, seg, coord, time), cs, freq)
 
 
-_STATS = {"rle_statistics", "longest_run", "windowed_run_events", "windowed_run_count", "first_run", "last_run"}
+_STATS = {"rle_statistics", "longest_run", "windowed_run_events", "windowed_run_count", "first_run", "last_run",
+          "windowed_max_run_sum"}
 
 
 def resample_and_rl(da, resample_before_rl: bool, compute, *args, freq: str, time: TimeAxis, dim="time", device=None,
@@ -337,6 +343,8 @@ def resample_and_rl(da, resample_before_rl: bool, compute, *args, freq: str, tim
     if not resample_before_rl:
         return compute(da, *args, freq=freq, time=time, device=device, keep=keep, **kwargs)
     # resample before: same kernel with cut_at_segments = 1
+    if name == "windowed_max_run_sum":
+        return compute(da, *args, freq=freq, time=time, device=device, keep=keep, cut=True, **kwargs)
     params = dict(kwargs)
     names = {"rle_statistics": ("reducer", "window"), "longest_run": (), "windowed_run_events": ("window",),
              "windowed_run_count": ("window",), "first_run": ("window",), "last_run": ("window",)}[name]
