@@ -165,3 +165,18 @@ def test_bench_finds_pmc_traffic_of_the_dominant_kernel():
     t = bench.pmc_traffic("k_pdoy_slide<5, 4>", (365, 1440, 720))
     assert t is not None and 4.4e9 < t < 5.5e9   # algorithmic 4.54 GB
     assert bench.pmc_traffic("k_pdoy_slide<5, 4>", (365, 10, 10)) is None
+
+
+def test_dim_other_than_time_is_refused():
+    """The host mirrors keep the reference's `dim` argument but only march along axis 0 = time: anything else must fail
+    loudly (before any device work), not be ignored."""
+    from xclim_amd import sdba
+
+    x = np.zeros((4, 3), np.float32)
+    for f, args in ((xrl.rle, ()), (xrl.rle_statistics, ("max", 1)), (xrl.first_run, (2,)), (xrl.longest_run, ()),
+                    (xrl.windowed_run_count, (2,)), (xrl.keep_longest_run, ()), (xrl.season, (2,))):
+        with pytest.raises(NotImplementedError, match="dim='time'"):
+            f(x, *args, dim="lat")
+    with pytest.raises(NotImplementedError):
+        sdba.quantile(x, [0.5], dim="lat")
+    assert xrl.rle_statistics.__name__ == "rle_statistics"  # resample_and_rl dispatches on the name

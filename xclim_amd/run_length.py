@@ -502,3 +502,31 @@ def windowed_run_events_ufunc(x, window: int, dim="time", *, device=None):
 def first_run_ufunc(x, window: int, dim="time", *, device=None):
     """rl:1593-1618."""
     return first_run(x, window, dim, device=device)
+
+
+def _time_dim_only(fn):
+    """The kernels march along axis 0 = time; a different ``dim`` must not be ignored silently."""
+    import functools
+    import inspect
+
+    sig = inspect.signature(fn)
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if sig.bind_partial(*args, **kwargs).arguments.get("dim", "time") != "time":
+            raise NotImplementedError(f"{fn.__name__}: only dim='time' (axis 0) is supported on the HIP path")
+        return fn(*args, **kwargs)
+
+    return wrapper
+
+
+for _name, _fn in list(globals().items()):
+    if callable(_fn) and getattr(_fn, "__module__", None) == __name__ and not isinstance(_fn, type):
+        try:
+            import inspect as _inspect
+
+            if "dim" in _inspect.signature(_fn).parameters:
+                globals()[_name] = _time_dim_only(_fn)
+        except (TypeError, ValueError):  # pragma: no cover
+            pass
+del _name, _fn

@@ -28,6 +28,8 @@ def equally_spaced_nodes(n: int, eps=None) -> np.ndarray:
 
 def quantile(da, q, dim="time", *, device=None, keep=False):
     """xsdba.nbutils.quantile along time: (nq, *cells) in float32."""
+    if dim != "time":
+        raise NotImplementedError("quantile: only dim='time' (axis 0) is supported on the HIP path")
     dev = device or get_device()
     x, cell_shape = _flatten(da, dev)
     out = K.quantile_series(dev, x, np.asarray(q, dtype=np.float64))
