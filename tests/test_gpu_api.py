@@ -687,3 +687,33 @@ def test_hot_spell_max_magnitude(dev, rng, before):
             ref = oidx.hot_spell_max_magnitude(x, 295.15, ot, window, freq, before)
             np.testing.assert_allclose(got, ref, rtol=1e-6, atol=0)
     assert np.nanmax(got) > 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("before", [True, False])
+def test_per_cell_thresholds(dev, rng, dtype, before):
+    """A threshold with one value per grid cell (a DataArray threshold in the reference, e.g. a percentile over time):
+    threshold_count, spell_length_statistics and the hot-spell indices compare in place against a one-row table; numpy
+    broadcasting in the oracle.  float32 thresholds compare in float32, float64 ones widen the data."""
+    T = 1095
+    x = _temp(rng, T, (5, 6), nan_frac=0.003)
+    x += np.repeat(rng.normal(0, 3.0, (T // 7 + 1, 5, 6)), 7, axis=0)[:T].astype(np.float32)
+    ta, ot = _axes("2001-01-01", T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        thr = np.nanquantile(x.astype(np.float64), 0.8, axis=0).astype(dtype)
+    thr[0, 0] = x[5, 0, 0]   # exact ties with the data
+    for freq in ("YS", "MS"):
+        got = xgen.threshold_count(x, ">", thr, ta, freq, device=dev)
+        np.testing.assert_array_equal(got, ogen.threshold_count(x, ">", thr, ot, freq))
+        got = xgen.threshold_count(x, "<=", thr[None], ta, freq, device=dev)
+        np.testing.assert_array_equal(got, ogen.threshold_count(x, "<=", thr[None], ot, freq))
+        for red in ("max", "sum", "count"):
+            got = xgen.spell_length_statistics(x, thr, 1, None, ">", red, ta, freq, resample_before_rl=before, device=dev)
+            ref = ogen.spell_length_statistics(x, thr, 1, None, ">", red, ot, freq, resample_before_rl=before)
+            np.testing.assert_array_equal(got, ref)
+        got = xi.hot_spell_frequency(x, thr, ta, 3, freq, ">", before, device=dev, mask_missing=False)
+        np.testing.assert_array_equal(got, oidx.run_index(x, ">", thr, "events", 3, ot, freq, before))
+        got = xi.hot_spell_total_length(x, thr, ta, 3, freq, ">", before, device=dev, mask_missing=False)
+        np.testing.assert_array_equal(got, oidx.run_index(x, ">", thr, "count", 3, ot, freq, before))
+    assert got.sum() > 0

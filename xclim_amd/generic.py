@@ -47,6 +47,23 @@ def _finish(out: DeviceArray, valid, cell_shape, keep, with_valid):
     return o
 
 
+def _cell_threshold(dev, threshold, da):
+    """A threshold with one value per grid cell (e.g. a percentile over time, a climatological field) as the one-row
+    float64 table + all-zero row index that the per-doy kernels take — nothing of shape (T, cells) is materialised, and
+    the float64 compare of exactly converted float32 values equals numpy's float32 compare.  None when `threshold` is
+    not of that shape."""
+    if isinstance(threshold, (DeviceArray, DoyPercentile)) or np.ndim(threshold) == 0:
+        return None
+    th = np.asarray(threshold)
+    shape = tuple(da.shape) if isinstance(da, DeviceArray) else np.shape(da)
+    if th.ndim == len(shape) and th.shape[0] == 1:
+        th = th[0]
+    if th.shape != tuple(shape[1:]) or th.ndim == 0:
+        return None
+    table = dev.to_device(np.ascontiguousarray(th, dtype=np.float64).reshape(1, -1))
+    return table, np.zeros(shape[0], dtype=np.int32)
+
+
 def threshold_count(da, op: str, threshold, time: TimeAxis, freq: str, constrain=None, *, device=None, keep=False,
                     with_valid=False):
     """gen:329-361.  ``threshold``: python float (fp32 compare, NumPy weak-scalar rule), ``np.float64`` scalar (fp64
@@ -66,6 +83,9 @@ def threshold_count(da, op: str, threshold, time: TimeAxis, freq: str, constrain
         cnt, val = K.threshold_count(dev, x, sym, seg, doy_table=table, tidx=resample_doy_index(doy, time))
     elif isinstance(threshold, DeviceArray):
         cnt, val = K.threshold_count(dev, x, sym, seg, full=threshold.reshape(threshold.shape[0], -1))
+    elif _cell_threshold(dev, threshold, da) is not None:  # one value per cell
+        table, tidx = _cell_threshold(dev, threshold, da)
+        cnt, val = K.threshold_count(dev, x, sym, seg, doy_table=table, tidx=tidx)
     elif np.ndim(threshold) == 0:
         # NumPy 2 promotion: python float is a weak scalar (fp32 compare); an np.float64 scalar forces fp64
         f64 = isinstance(threshold, np.float64)
@@ -257,6 +277,15 @@ def spell_length_statistics(data, threshold, window: int, win_reducer, op: str, 
     else:
         x, cell_shape = _flatten(data, dev)
     if window == 1 and min_gap == 1 and not multi:
+        cell = _cell_threshold(dev, threshold, data)
+        if cell is not None:  # one threshold per grid cell: compared in place (one-row table), fused when the runs are cut
+            table, tidx = cell
+            if resample_before_rl:
+                out, val = K.run_stats_doy(dev, x, sym, table, tidx, spell_reducer, 1, seg)
+            else:
+                out, _ = K.run_stats(dev, K.compare_doy(dev, x, sym, table, tidx), spell_reducer, 1, seg, cut=False, want_valid=False)
+                _, val = K.resample_reduce(dev, x, "count", seg)
+            return _finish(out, val, cell_shape, keep, with_valid)
         out, val = K.run_stats(dev, x, spell_reducer, 1, seg, cut=resample_before_rl, fused_op=sym, thresh=float(threshold))
         return _finish(out, val, cell_shape, keep, with_valid)
     mask = spell_mask([f[0] for f in flat] if multi else x, window, win_reducer, op, threshold, min_gap=min_gap, device=dev,

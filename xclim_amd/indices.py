@@ -302,6 +302,15 @@ def _run_index(da, thresh, op, constrain, stat, window, time, freq, resample_bef
 
     x, cell_shape = _flatten(da, dev)
     seg, _ = time.segments(freq)
+    cell = generic._cell_threshold(dev, thresh, da)
+    if cell is not None:  # one threshold per grid cell (a DataArray threshold in the reference)
+        table, tidx = cell
+        if resample_before_rl:
+            out, val = K.run_stats_doy(dev, x, sym, table, tidx, stat, int(window), seg)
+        else:
+            out, _ = K.run_stats(dev, K.compare_doy(dev, x, sym, table, tidx), stat, int(window), seg, cut=False, want_valid=False)
+            _, val = K.resample_reduce(dev, x, "count", seg)
+        return _masked(out, val, time, freq, dev, cell_shape, mask_missing)
     out, val = K.run_stats(dev, x, stat, int(window), seg, cut=bool(resample_before_rl), fused_op=sym, thresh=float(thresh))
     return _masked(out, val, time, freq, dev, cell_shape, mask_missing)
 
