@@ -437,3 +437,26 @@ def test_boundary_run_coord(dev, rng, coord):
         xrl.first_run(x, 3, coord="hour", time=ta, device=dev)
     with pytest.raises(ValueError):
         xrl.first_run(x, 3, coord=coord, device=dev)
+
+
+def test_device_mask_chaining_and_dtype_guard(dev, rng):
+    """compare(..., keep=True) hands a float32 device mask to the run-length mirrors (the drop-in chain
+    cond = compare(...); rl.rle_statistics(cond, ...) without leaving the device); a uint8 / float64 device buffer is
+    refused instead of being reinterpreted as float32."""
+    from xclim_amd import kernels as K
+
+    T = 400
+    x = rng.normal(0, 1, (T, 6, 5)).astype(np.float32)
+    x[rng.random(x.shape) < 0.02] = np.nan
+    ta, ot = TimeAxis.daily("2001-01-01", T), OTime.standard("2001-01-01", T)
+    cond = xgen.compare(x, ">", 0.25, device=dev, keep=True)
+    assert cond.dtype == np.float32
+    got = xrl.rle_statistics(cond.reshape(T, 6, 5), "max", 2, freq="MS", time=ta, device=dev)
+    exp = orl.rle_statistics(ogen.compare(x, ">", np.float32(0.25)), "max", 2, ot, "MS")
+    np.testing.assert_array_equal(got, exp)
+    np.testing.assert_array_equal(xgen.compare(x, ">", 0.25, device=dev), ogen.compare(x, ">", np.float32(0.25)))
+    u8 = K.compare_map(dev, dev.to_device(x.reshape(T, -1)), ">", 0.25, "mask")
+    with pytest.raises(TypeError, match="float32"):
+        xrl.rle_statistics(u8, "max", 2, device=dev)
+    with pytest.raises(TypeError, match="float32"):
+        xgen.threshold_count(dev.to_device(x.astype(np.float64).reshape(T, -1)), ">", 0.0, ta, "YS", device=dev)

@@ -56,6 +56,9 @@ def doy_interp_tables(n_src: int, doy_max: int, doy_min: int = 1):
 def _flatten(arr, dev):
     """(T, *cells) numpy/device array -> (DeviceArray (T, C), cell_shape)."""
     if isinstance(arr, DeviceArray):
+        if arr.dtype != np.float32:  # the kernels read float32 fields: a uint8 / float64 buffer must not be reinterpreted
+            raise TypeError(f"device arrays handed to the kernels must be float32, got {np.dtype(arr.dtype).name} "
+                            "(masks: use the float mask of compare(..., keep=True))")
         cell_shape = arr.shape[1:]
         return arr.reshape(arr.shape[0], -1), cell_shape
     a = np.asarray(arr)

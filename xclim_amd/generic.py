@@ -145,12 +145,15 @@ def compare(left, op: str, right, constrain=None, *, device=None, keep=False):
     sym = get_op(op, constrain)
     dev = device or get_device()
     x, cell_shape = _flatten(left, dev)
+    # keep=True: a float32 1 / 0 mask, the form every device consumer (run_length.*, spell kernels) reads; otherwise a
+    # uint8 mask (a quarter of the bytes over PCIe) turned into numpy bool
+    kind = "maskf" if keep else "mask"
     if np.ndim(right) == 0 and not isinstance(right, DeviceArray):
-        m = K.compare_map(dev, x, sym, right, "mask")
+        m = K.compare_map(dev, x, sym, right, kind)
     else:
         b, _ = _flatten(np.broadcast_to(np.asarray(right, dtype=np.float32), np.shape(left))
                         if not isinstance(right, DeviceArray) else right, dev)
-        m = K.compare_map(dev, x, sym, b, "mask")
+        m = K.compare_map(dev, x, sym, b, kind)
     if keep:
         return m
     return m.get().reshape((x.shape[0],) + tuple(cell_shape)).astype(bool)

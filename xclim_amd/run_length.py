@@ -26,6 +26,9 @@ def use_ufunc(ufunc_1dim, da=None, dim="time", freq=None, index="first") -> bool
 
 def _mask(da, dev):
     if isinstance(da, DeviceArray):
+        if da.dtype != np.float32:
+            raise TypeError(f"device masks must be float32 (1 / 0 / NaN), got {np.dtype(da.dtype).name}: "
+                            "compare(..., keep=True) returns one")
         return da.reshape(da.shape[0], -1), da.shape[1:]
     a = np.asarray(da)
     if a.dtype != np.float32:
