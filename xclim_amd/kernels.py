@@ -25,9 +25,12 @@ def as_device(dev: Device, a, dtype=np.float32) -> DeviceArray:
     return dev.to_device(np.asarray(a), dtype=dtype)
 
 
-def _tc(x: DeviceArray):
+def _tc(x: DeviceArray, dtype=np.float32):
+    """Shape of a 2-D device field; the kernels read raw pointers, so the element type is checked here."""
     if len(x.shape) != 2:
         raise ValueError(f"expected a 2-D (time, cells) array, got shape {x.shape}")
+    if dtype is not None and np.dtype(x.dtype) != np.dtype(dtype):
+        raise TypeError(f"expected a {np.dtype(dtype).name} device array, got {np.dtype(x.dtype).name}")
     return int(x.shape[0]), int(x.shape[1])
 
 
@@ -122,7 +125,7 @@ def resample_reduce(dev: Device, x: DeviceArray, reducer: str, seg_off, skipna=T
 
 
 def apply_missing_mask(dev: Device, value: DeviceArray, valid: DeviceArray, expected, out=None) -> DeviceArray:
-    P, C_ = _tc(value)
+    P, C_ = _tc(value, None)
     exp = np.ascontiguousarray(expected, dtype=np.int32)
     assert exp.shape == (P,)
     out = out if out is not None else dev.empty((P, C_), np.float64)
@@ -382,7 +385,7 @@ def percentile_doy_count(dev: Device, x: DeviceArray, tbase, window: int, per: f
 def doy_interp(dev: Device, table: DeviceArray, i0, i1, dxn, dxs, xsrc=None) -> DeviceArray:
     """table (D_in, C) float64 -> (D_out, C) float64 (xh_doy_interp).  `xsrc`: dayofyear coordinate of the source rows for
     the interpolate_na step (None: uniform)."""
-    D_in, C_ = _tc(table)
+    D_in, C_ = _tc(table, np.float64)
     xs = None if xsrc is None else np.ascontiguousarray(xsrc, dtype=np.float64)
     assert xs is None or len(xs) == D_in
     i0 = np.ascontiguousarray(i0, dtype=np.int32)
