@@ -166,6 +166,10 @@ int xh_range_reduce(xh_ctx* ctx, const float* low, const float* high, int64_t T,
                     int64_t st_high, int mode, int reducer, const int64_t* seg_off, int P, float* out,
                     int32_t* valid_out);
 
+/* A bool / uint8 mask (n elements, non-zero = True) as the float32 1 / 0 mask the run-length entry points read
+ * (`da` of indices/run_length.py is boolean): host masks cross PCIe as bytes. */
+int xh_mask_u8_to_f32(xh_ctx* ctx, const uint8_t* mask, int64_t n, float* out);
+
 /* compare (generic.py:301-326) / get_daily_events (generic.py:395-431) as an elementwise map of a (T, C) field against a
  * scalar (fp32 compare, or fp64 when thr_is_f64) or a second field b (NULL for the scalar form):
  *   out_kind 0: uint8 mask    1: float32 1/0 with NaN where a is NaN    2: float32 a.where(cond) (NaN elsewhere)

@@ -460,3 +460,21 @@ def test_device_mask_chaining_and_dtype_guard(dev, rng):
         xrl.rle_statistics(u8, "max", 2, device=dev)
     with pytest.raises(TypeError, match="float32"):
         xgen.threshold_count(dev.to_device(x.astype(np.float64).reshape(T, -1)), ">", 0.0, ta, "YS", device=dev)
+
+
+@pytest.mark.parametrize("shape", [(37, 5, 7), (365, 1003), (1, 3), (50,)])
+def test_bool_masks_upload_as_bytes(dev, rng, shape):
+    """numpy bool / uint8 masks go to the device as bytes and are widened there (xh_mask_u8_to_f32): same results as the
+    float32 mask, any size (tail not a multiple of 4)."""
+    from xclim_amd import kernels as K
+
+    m = rng.random(shape) < 0.4
+    f = m.astype(np.float32)
+    for fn, args in ((xrl.rle, ()), (xrl.longest_run, ()), (xrl.windowed_run_count, (2,)), (xrl.first_run, (2,))):
+        a = fn(f, *args, device=dev)
+        np.testing.assert_array_equal(fn(m, *args, device=dev), a)
+        np.testing.assert_array_equal(fn(m.astype(np.uint8), *args, device=dev), a)
+    d8 = dev.to_device(m.reshape(shape[0], -1).view(np.uint8))
+    np.testing.assert_array_equal(K.mask_to_f32(dev, d8).get(), f.reshape(shape[0], -1))
+    with pytest.raises(TypeError):
+        K.mask_to_f32(dev, dev.to_device(f.reshape(shape[0], -1)))

@@ -224,6 +224,19 @@ k_precip_over_doy(const float* __restrict__ x, int64_t C, int64_t st, int op, do
   }
 }
 
+// bool / uint8 mask -> the float32 1 / 0 mask the run-length kernels read: host masks cross PCIe as bytes (a quarter of
+// the float form, and no host-side astype of the whole field)
+__global__ void __launch_bounds__(XH_BLOCK)
+k_mask_u8_to_f32(const uint8_t* __restrict__ m, int64_t n, float* __restrict__ out) {
+  const int64_t i = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * 4;
+  if (i + 4 <= n) {
+    const uchar4 v = *reinterpret_cast<const uchar4*>(m + i);
+    *reinterpret_cast<float4*>(out + i) = make_float4(v.x ? 1.f : 0.f, v.y ? 1.f : 0.f, v.z ? 1.f : 0.f, v.w ? 1.f : 0.f);
+  } else {
+    for (int64_t k = i; k < n; ++k) out[k] = m[k] ? 1.f : 0.f;
+  }
+}
+
 static dim3 time_chunk_grid(xh_ctx* ctx, int64_t T, int64_t C) {
   const int64_t cblocks = cdiv64(C, XH_BLOCK);
   int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
@@ -379,6 +392,16 @@ int xh_precip_over_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
   dim3 grid((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P));
   hipLaunchKernelGGL(k_precip_over_doy, grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, op, thr, table, (const int32_t*)d_tidx,
                      (const int64_t*)d_seg, P, frac, n_over, valid_out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_mask_u8_to_f32(xh_ctx* ctx, const uint8_t* mask, int64_t n, float* out) {
+  XH_REQUIRE(ctx && (n == 0 || (mask && out)) && n >= 0, XH_ERR_ARG, "xh_mask_u8_to_f32: bad arguments");
+  XH_REQUIRE(((uintptr_t)mask & 3u) == 0 && ((uintptr_t)out & 15u) == 0, XH_ERR_LAYOUT,
+             "xh_mask_u8_to_f32: mask must be 4-byte and out 16-byte aligned");
+  if (n == 0) return XH_OK;
+  hipLaunchKernelGGL(k_mask_u8_to_f32, dim3((unsigned)cdiv64(cdiv64(n, 4), XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, mask, n, out);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

@@ -209,6 +209,15 @@ def compare_map(dev: Device, a: DeviceArray, op, thr, kind: str = "mask") -> Dev
     return out
 
 
+def mask_to_f32(dev: Device, mask: DeviceArray) -> DeviceArray:
+    """uint8 / bool device mask -> float32 1 / 0 mask of the same shape (xh_mask_u8_to_f32)."""
+    if np.dtype(mask.dtype).itemsize != 1:
+        raise TypeError(f"expected a 1-byte mask, got {np.dtype(mask.dtype).name}")
+    out = dev.empty(mask.shape, np.float32)
+    dev.call("xh_mask_u8_to_f32", _vp(mask.ptr), int(mask.size), _vp(out.ptr))
+    return out
+
+
 def thresholded_reduce(dev: Device, x: DeviceArray, op, thr, mode: int, reducer: str, seg_off, want_valid=True):
     T, C_ = _tc(x)
     seg, P = _seg(seg_off)

@@ -31,6 +31,10 @@ def _mask(da, dev):
                             "compare(..., keep=True) returns one")
         return da.reshape(da.shape[0], -1), da.shape[1:]
     a = np.asarray(da)
+    if a.dtype == np.bool_ or a.dtype == np.uint8:
+        # boolean masks cross PCIe as bytes and become the float mask on the device (no host astype of the field)
+        m8 = dev.to_device(np.ascontiguousarray(a).reshape(a.shape[0], -1).view(np.uint8))
+        return K.mask_to_f32(dev, m8), a.shape[1:]
     if a.dtype != np.float32:
         a = a.astype(np.float32)
     return _flatten(a, dev)
