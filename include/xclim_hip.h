@@ -166,6 +166,11 @@ int xh_range_reduce(xh_ctx* ctx, const float* low, const float* high, int64_t T,
                     int64_t st_high, int mode, int reducer, const int64_t* seg_off, int P, float* out,
                     int32_t* valid_out);
 
+/* select_time (core/calendar.py:1259-1378), the `**indexer` of select_resample_op & co.: out row i = x row idx[i] (host
+ * int64[n]), NaN when idx[i] < 0.  `da.where(mask)`: n = T, idx[t] = mask[t] ? t : -1; `drop=True`: the selected rows. */
+int xh_select_rows(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int64_t* idx, int64_t n,
+                   float* out, int64_t st_out);
+
 /* A bool / uint8 mask (n elements, non-zero = True) as the float32 1 / 0 mask the run-length entry points read
  * (`da` of indices/run_length.py is boolean): host masks cross PCIe as bytes. */
 int xh_mask_u8_to_f32(xh_ctx* ctx, const uint8_t* mask, int64_t n, float* out);

@@ -108,3 +108,51 @@ def resample_doy(doy_arr, src_doys, time: OTime):
     out = np.asarray(adoy)[pos_c].astype(np.float64, copy=True)
     out[~ok] = np.nan
     return out
+
+
+# ---- select_time (cal:1259-1378), the time selections of the `**indexer` arguments -----------------------------------
+def select_time_mask(time: OTime, season=None, month=None, doy_bounds=None, date_bounds=None, include_bounds=(True, True)):
+    """Restated with explicit calendar arithmetic: season / month from the month number, doy_bounds on dayofyear
+    (wrapping over the year end, cal:1137-1163), date_bounds on the day of year of the all_leap calendar for
+    non-uniform calendars (cal:1354-1371) or of the calendar itself for uniform ones."""
+    if isinstance(include_bounds, bool):
+        include_bounds = (include_bounds, include_bounds)
+    mon, day = np.asarray(time.month), np.asarray(time.day)
+
+    def get_doys(start, end):
+        d = list(range(start, end + 1)) if start <= end else list(range(start, 367)) + list(range(0, end + 1))
+        if not include_bounds[0]:
+            d = d[1:]
+        if not include_bounds[1]:
+            d = d[:-1]
+        return d
+
+    if season is not None:
+        names = {"DJF": (12, 1, 2), "MAM": (3, 4, 5), "JJA": (6, 7, 8), "SON": (9, 10, 11)}
+        months = [m for s_ in ([season] if isinstance(season, str) else season) for m in names[s_]]
+        return np.isin(mon, months)
+    if month is not None:
+        return np.isin(mon, [month] if np.isscalar(month) else list(month))
+    if doy_bounds is not None:
+        return np.isin(np.asarray(time.doy), get_doys(*doy_bounds))
+    (ms, ds), (me, de) = (tuple(int(v) for v in b.split("-")) for b in date_bounds)
+    if time.calendar == "360_day":
+        cum = [30 * i for i in range(12)]
+    elif time.calendar in ("noleap", "365_day"):
+        cum = [0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334]
+    else:
+        cum = [0, 31, 60, 91, 121, 152, 182, 213, 244, 274, 305, 335]
+    cum = np.asarray(cum)
+    return np.isin(cum[mon - 1] + day, get_doys(cum[ms - 1] + ds, cum[me - 1] + de))
+
+
+def select_time(da, time: OTime, drop=False, **indexer):
+    """da.where(mask, drop=drop): NaN outside the selection, or only the selected steps (+ their time axis)."""
+    da = np.asarray(da)
+    mask = select_time_mask(time, **indexer)
+    if drop:
+        idx = np.nonzero(mask)[0]
+        return da[idx], time.isel(idx)
+    out = da.astype(np.result_type(da.dtype, np.float32), copy=True)
+    out[~mask] = np.nan
+    return out

@@ -717,3 +717,66 @@ def test_per_cell_thresholds(dev, rng, dtype, before):
         got = xi.hot_spell_total_length(x, thr, ta, 3, freq, ">", before, device=dev, mask_missing=False)
         np.testing.assert_array_equal(got, oidx.run_index(x, ">", thr, "count", 3, ot, freq, before))
     assert got.sum() > 0
+
+
+@pytest.mark.parametrize("calendar,T", [("standard", 1096), ("noleap", 730)])
+def test_select_time_and_indexer(dev, rng, calendar, T):
+    """calendar.select_time (cal:1259-1378) on the device: where-form (NaN outside) and drop-form, and the ``**indexer`` of
+    select_resample_op (gen:109: ``da = select_time(da, **indexer)`` before the reduction)."""
+    from xclim_amd.calendar import select_time
+
+    x = _temp(rng, T, (4, 7), nan_frac=0.004)   # 28 cells: the scalar (non 16-byte) path; (T, 4, 8) below the vector path
+    ta, ot = _axes("2001-01-01", T, calendar)
+    for indexer in (dict(season="DJF"), dict(month=[6, 7, 8]), dict(doy_bounds=(340, 45)), dict(date_bounds=("03-15", "10-01")),
+                    dict(doy_bounds=(100, 200), include_bounds=(False, True))):
+        got = select_time(x, ta, device=dev, **indexer)
+        np.testing.assert_array_equal(got, ocal.select_time(x, ot, **indexer))
+        sub, tsub = select_time(x, ta, drop=True, device=dev, **indexer)
+        esub, etsub = ocal.select_time(x, ot, drop=True, **indexer)
+        np.testing.assert_array_equal(sub, esub)
+        np.testing.assert_array_equal(tsub.doy, np.asarray(etsub.doy))
+        for op in ("mean", "max", "sum", "count", "std"):
+            got = xgen.select_resample_op(x, op, ta, "YS", device=dev, **indexer)
+            ref = ogen.select_resample_op(ocal.select_time(x, ot, **indexer), op, ot, "YS")
+            np.testing.assert_allclose(got, ref, rtol=1e-6, equal_nan=True)
+    x8 = _temp(rng, T, (4, 8))
+    np.testing.assert_array_equal(select_time(x8, ta, device=dev, month=1), ocal.select_time(x8, ot, month=1))
+    assert select_time(x, ta, device=dev) is not None and np.array_equal(select_time(x, ta, device=dev), x, equal_nan=True)
+    with pytest.raises(ValueError):
+        select_time(x, ta, device=dev, month=1, season="DJF")
+
+
+def test_indicator_level_time_selection(dev, rng):
+    """Indicator-level ``**indexer`` (core/indicator.py + core/missing.py:118-135): every input is masked by select_time
+    before the compute and MissingAny expects the selected days only."""
+    T = 1096
+    x = _temp(rng, T, (4, 6))
+    x[rng.random(x.shape) < 0.002] = np.nan
+    ta, ot = _axes("2001-01-01", T)
+
+    def missing(data_m, expected):
+        valid = np.stack([(~np.isnan(data_m[idx])).sum(axis=0) for _, idx in __import__("oracle.timeutil", fromlist=["groups"]).groups(ot, "YS")])
+        return valid != np.asarray(expected).reshape(-1, 1, 1)
+
+    for indexer, nsel in ((dict(season="JJA"), [92, 92, 92, 0]), (dict(month=[1, 2]), [59, 59, 59, 60]),
+                          (dict(date_bounds=("11-15", "12-20")), [36, 36, 36, 0])):
+        xm = ocal.select_time(x, ot, **indexer)
+        # the last "year" holds 2004-01-01 only: its expected count is the selection inside the FULL year 2004
+        exp_cnt = ta.expected_count("YS", **indexer)
+        miss = missing(xm, exp_cnt)
+        got = xi.tg_mean(x, ta, "YS", device=dev, **indexer)
+        ref = ogen.select_resample_op(xm, "mean", ot, "YS").astype(np.float64)
+        ref[miss] = np.nan
+        np.testing.assert_allclose(got, ref, rtol=1e-6, equal_nan=True)
+        got = xi.tx_days_above(x, 295.0, ta, "YS", device=dev, **indexer)
+        ref = oidx.count_days(xm, ">", np.float32(295.0), ot, "YS").astype(np.float64)
+        ref[miss] = np.nan
+        np.testing.assert_array_equal(got, ref)
+        got = xi.hot_spell_frequency(x, 293.0, ta, 2, "YS", device=dev, **indexer)
+        ref = oidx.run_index(xm, ">", np.float32(293.0), "events", 2, ot, "YS").astype(np.float64)
+        ref[miss] = np.nan
+        np.testing.assert_array_equal(got, ref)
+        assert list(exp_cnt[:3]) == nsel[:3]
+    assert np.isfinite(xi.tg_mean(x, ta, "YS", device=dev, season="JJA")[:3]).any()
+    # no selection: unchanged behaviour
+    np.testing.assert_array_equal(xi.tg_mean(x, ta, "YS", device=dev), xi.tg_mean(x, ta, "YS", device=dev, season=None))

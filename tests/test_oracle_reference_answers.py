@@ -338,3 +338,52 @@ def test_hot_spell_max_magnitude_known_answer():
     da = (a + 273.15).astype(np.float32)
     out = oidx.hot_spell_max_magnitude(da, 25 + 273.15, OTime.standard("2000-07-01", 365), 3, "MS")
     np.testing.assert_allclose(out, [25, 0, 30, 20, 0, 0, 0, 0, 0, 0, 0, 0], atol=1e-3)
+
+
+def test_select_time_known_answers():
+    """core/calendar.py:1259-1378 pinned by the reference's tests/test_generic.py:523-690 (month, season, doy bounds that
+    wrap over the year end, date bounds with Feb 29 on a standard calendar) — for the oracle restatement AND the host
+    mirror's mask builder (pure calendar arithmetic, no device)."""
+    import pandas as pd
+
+    from oracle import calendar as ocal
+    from oracle.timeutil import OTime
+    from xclim_amd.calendar import select_time_mask
+    from xclim_amd.timeaxis import TimeAxis
+
+    def both(start, end, **indexer):
+        idx = pd.date_range(start, end)
+        ot, ta = OTime.standard(start, len(idx)), TimeAxis.daily(start, len(idx))
+        m1, m2 = ocal.select_time_mask(ot, **indexer), select_time_mask(ta, **indexer)
+        np.testing.assert_array_equal(m1, m2)
+        return idx[m1]
+
+    def span(*pairs):
+        return pd.DatetimeIndex(np.concatenate([pd.date_range(a, b).values for a, b in pairs]))
+
+    sel = both("1993-01-05", "1994-12-31", month=1)
+    assert len(sel) == 58 and sel.equals(span(("1993-01-05", "1993-01-31"), ("1994-01-01", "1994-01-31")))
+    sel = both("1993-01-05", "1994-12-31", season="DJF")
+    assert sel.equals(span(("1993-01-05", "1993-02-28"), ("1993-12-01", "1994-02-28"), ("1994-12-01", "1994-12-31")))
+    sel = both("2003-02-13", "2004-12-31", doy_bounds=(360, 75))
+    assert sel.equals(span(("2003-02-13", "2003-03-16"), ("2003-12-26", "2004-03-15"), ("2004-12-25", "2004-12-31")))
+    sel = both("2003-02-13", "2004-12-31", doy_bounds=(25, 80))
+    assert sel.equals(span(("2003-02-13", "2003-03-21"), ("2004-01-25", "2004-03-20")))
+    sel = both("2003-02-13", "2005-11-01", date_bounds=("10-05", "02-29"))
+    assert sel.equals(span(("2003-02-13", "2003-02-28"), ("2003-10-05", "2004-02-29"), ("2004-10-05", "2005-02-28"),
+                           ("2005-10-05", "2005-11-01")))
+    sel = both("1990-01-01", "1993-12-31", date_bounds=("02-29", "03-02"))  # the docstring example (cal:1316-1323)
+    assert [str(d.date()) for d in sel] == ["1990-03-01", "1990-03-02", "1991-03-01", "1991-03-02", "1992-02-29", "1992-03-01",
+                                            "1992-03-02", "1993-03-01", "1993-03-02"]
+    # noleap / 360_day axes: seasons and months by month number
+    ot, ta = OTime.noleap(1993, 730), TimeAxis.daily("1993-01-01", 730, "noleap")
+    m = ocal.select_time_mask(ot, season=["MAM", "SON"])
+    np.testing.assert_array_equal(m, select_time_mask(ta, season=["MAM", "SON"]))
+    assert m.sum() == 2 * (92 + 91)
+    ot, ta = OTime.noleap(1993, 720, "360_day"), TimeAxis.daily("1993-01-01", 720, "360_day")
+    m = ocal.select_time_mask(ot, month=[3, 6])
+    np.testing.assert_array_equal(m, select_time_mask(ta, month=[3, 6]))
+    assert m.sum() == 120
+    with pytest.raises(ValueError, match="Only one method"):
+        select_time_mask(ta, month=1, season="DJF")
+    assert select_time_mask(ta) is None

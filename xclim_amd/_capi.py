@@ -85,6 +85,7 @@ SIGNATURES: dict[str, list] = {
     "xh_doy_broadcast": [_vp, _vp, _int, _i64, _vp, _i64, _vp],
     "xh_within_bnds_doy": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp],
     "xh_compare_doy": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _int, _vp, _vp, _i64],
+    "xh_select_rows": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64],
     "xh_mask_u8_to_f32": [_vp, _vp, _i64, _vp],
     "xh_run_stats_doy": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _int, _vp, _int, _int, _vp, _int, _vp, _vp],
     "xh_precip_over_doy": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp],

@@ -66,6 +66,71 @@ def _flatten(arr, dev):
     return dev.to_device(a.reshape(a.shape[0], -1), dtype=np.float32), cell_shape
 
 
+_SEASON_OF_MONTH = np.array([0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 0])  # index = month (1..12): DJF MAM JJA SON
+_SEASONS = {"DJF": 0, "MAM": 1, "JJA": 2, "SON": 3}
+_CUM_LEAP = np.array([0, 31, 60, 91, 121, 152, 182, 213, 244, 274, 305, 335])
+_CUM_NOLEAP = np.array([0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334])
+
+
+def _get_doys(start: int, end: int, inclusive):
+    """cal:1137-1163."""
+    doys = np.arange(start, end + 1) if start <= end else np.concatenate((np.arange(start, 367), np.arange(0, end + 1)))
+    if not inclusive[0]:
+        doys = doys[1:]
+    if not inclusive[1]:
+        doys = doys[:-1]
+    return doys
+
+
+def select_time_mask(time: TimeAxis, *, season=None, month=None, doy_bounds=None, date_bounds=None, include_bounds=True):
+    """The boolean time mask of ``select_time`` (cal:1259-1378); None when no indexer is given."""
+    n = sum(a is not None for a in (season, month, doy_bounds, date_bounds))
+    if n > 1:
+        raise ValueError(f"Only one method of indexing may be given, got {n}.")
+    if n == 0:
+        return None
+    if isinstance(include_bounds, bool):
+        include_bounds = (include_bounds, include_bounds)
+    if season is not None:
+        want = [season] if isinstance(season, str) else list(season)
+        return np.isin(_SEASON_OF_MONTH[time.month], [_SEASONS[s] for s in want])
+    if month is not None:
+        return np.isin(time.month, [month] if np.isscalar(month) else list(month))
+    if doy_bounds is not None:
+        if not all(isinstance(b, (int, np.integer)) for b in doy_bounds):
+            raise NotImplementedError("array-like doy bounds are not supported on the HIP path")
+        return np.isin(time.doy, _get_doys(int(doy_bounds[0]), int(doy_bounds[1]), include_bounds))
+    start, end = date_bounds
+    (ms, ds), (me, de) = (tuple(int(v) for v in b.split("-")) for b in (start, end))
+    if time.calendar in ("360_day",):
+        doy_t, s, e = time.doy, (ms - 1) * 30 + ds, (me - 1) * 30 + de
+    elif time.calendar in ("noleap", "365_day"):
+        doy_t, s, e = time.doy, _CUM_NOLEAP[ms - 1] + ds, _CUM_NOLEAP[me - 1] + de
+    else:  # non-uniform calendars (and all_leap): every date seen in the all_leap calendar (cal:1354-1371)
+        doy_t, s, e = _CUM_LEAP[time.month - 1] + time.day, _CUM_LEAP[ms - 1] + ds, _CUM_LEAP[me - 1] + de
+    return np.isin(doy_t, _get_doys(int(s), int(e), include_bounds))
+
+
+def select_time(da, time: TimeAxis, drop: bool = False, *, season=None, month=None, doy_bounds=None, date_bounds=None,
+                include_bounds=True, device=None, keep=False):
+    """core/calendar.py:1259-1378: ``da.where(mask, drop=drop)`` for the time selections season / month / doy_bounds /
+    date_bounds (the ``**indexer`` of select_resample_op & co.).  drop=False: same length, NaN outside the selection;
+    drop=True: ``(selected rows, their TimeAxis)``.  keep=True returns the (rows, cells) float32 device array."""
+    mask = select_time_mask(time, season=season, month=month, doy_bounds=doy_bounds, date_bounds=date_bounds,
+                            include_bounds=include_bounds)
+    dev = device or get_device()
+    x, cell_shape = _flatten(da, dev)
+    if mask is None:
+        out, sub = x, time
+    elif drop:
+        rows = np.nonzero(mask)[0]
+        out, sub = K.select_rows(dev, x, rows), time.subset(rows)
+    else:
+        out, sub = K.select_rows(dev, x, np.where(mask, np.arange(len(mask)), -1)), time
+    res = out if keep else out.get().reshape((out.shape[0],) + tuple(cell_shape))
+    return (res, sub) if drop else res
+
+
 def percentile_doy(arr, time: TimeAxis, window: int = 5, per=10.0, alpha: float = 1.0 / 3.0, beta: float = 1.0 / 3.0,
                    copy: bool = True, device=None) -> DoyPercentile:
     """Percentile value for each day of the year (cal:395-494).

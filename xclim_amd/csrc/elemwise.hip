@@ -237,6 +237,32 @@ k_mask_u8_to_f32(const uint8_t* __restrict__ m, int64_t n, float* __restrict__ o
   }
 }
 
+// select_time (core/calendar.py:1259-1378): out row i = x row idx[i], or NaN when idx[i] < 0.  da.where(mask) is
+// idx[t] = mask[t] ? t : -1 over all rows; drop=True lists the selected rows only.  Row-uniform choice, 16-byte moves.
+template <int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_select_rows(const float* __restrict__ x, int64_t C, int64_t st, const int64_t* __restrict__ idx, int64_t n,
+              float* __restrict__ out, int64_t st_out) {
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int64_t chunk = cdiv64(n, (int64_t)gridDim.y);
+  int64_t ia = (int64_t)blockIdx.y * chunk, ib = ia + chunk;
+  if (ib > n) ib = n;
+#pragma unroll 4
+  for (int64_t i = ia; i < ib; ++i) {
+    const int64_t r = idx[i];
+    VecF<VEC> v = xh_load<VEC>(x + (r < 0 ? 0 : r) * st + c);  // unconditional load, masked afterwards
+    float o[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = r < 0 ? xh_nan32() : v.v[k];
+    if (VEC == 4) *reinterpret_cast<float4*>(out + i * st_out + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+    else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) out[i * st_out + c + k] = o[k];
+    }
+  }
+}
+
 static dim3 time_chunk_grid(xh_ctx* ctx, int64_t T, int64_t C) {
   const int64_t cblocks = cdiv64(C, XH_BLOCK);
   int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
@@ -402,6 +428,33 @@ int xh_mask_u8_to_f32(xh_ctx* ctx, const uint8_t* mask, int64_t n, float* out) {
              "xh_mask_u8_to_f32: mask must be 4-byte and out 16-byte aligned");
   if (n == 0) return XH_OK;
   hipLaunchKernelGGL(k_mask_u8_to_f32, dim3((unsigned)cdiv64(cdiv64(n, 4), XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, mask, n, out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_select_rows(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int64_t* idx, int64_t n,
+                   float* out, int64_t st_out) {
+  XH_REQUIRE(ctx && x && (n == 0 || (idx && out)), XH_ERR_ARG, "xh_select_rows: NULL argument");
+  XH_REQUIRE(T >= 1 && C >= 0 && n >= 0, XH_ERR_ARG, "xh_select_rows: bad shape (T >= 1)");
+  XH_REQUIRE(sc == 1 && st >= C && st_out >= C, XH_ERR_LAYOUT, "xh_select_rows: needs time-major views (cell stride 1)");
+  for (int64_t i = 0; i < n; ++i)
+    XH_REQUIRE(idx[i] < T, XH_ERR_ARG, "xh_select_rows: idx[%lld] = %lld outside [0, T)", (long long)i, (long long)idx[i]);
+  if (n == 0 || C == 0) return XH_OK;
+  size_t cur = 0;
+  void* d_idx = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, idx, sizeof(int64_t) * (size_t)n, &d_idx);
+  if (rc) return rc;
+  const int vec = (xh_pick_vec(x, C, st) == 4 && xh_pick_vec(out, C, st_out) == 4) ? 4 : 1;
+  const int64_t cblocks = cdiv64(cdiv64(C, vec), XH_BLOCK);
+  int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
+  if (gy < 1) gy = 1;
+  if (gy > n) gy = n;
+  if (gy > 1024) gy = 1024;
+  dim3 grid((unsigned)cblocks, (unsigned)gy);
+  if (vec == 4)
+    hipLaunchKernelGGL((k_select_rows<4>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, (const int64_t*)d_idx, n, out, st_out);
+  else
+    hipLaunchKernelGGL((k_select_rows<1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, (const int64_t*)d_idx, n, out, st_out);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

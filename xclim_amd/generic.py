@@ -239,10 +239,16 @@ def cumulative_difference(data, threshold: float, op: str, time: TimeAxis, freq:
     return _thresholded(data, op, threshold, 2, "sum", time, freq, None, device, keep, with_valid)
 
 
-def select_resample_op(da, op: str, time: TimeAxis, freq: str = "YS", *, device=None, keep=False, with_valid=False):
-    """gen:83-125 (string ops, no indexer): min/max/mean/std/var/count/sum/integral/argmax/argmin per period."""
+def select_resample_op(da, op: str, time: TimeAxis, freq: str = "YS", *, device=None, keep=False, with_valid=False,
+                       **indexer):
+    """gen:83-125 (string ops): min/max/mean/std/var/count/sum/integral/argmax/argmin per period; ``**indexer``
+    (season= / month= / doy_bounds= / date_bounds=) masks the other time steps first (calendar.select_time)."""
     dev = device or get_device()
     x, cell_shape = _flatten(da, dev)
+    if indexer:
+        from .calendar import select_time
+
+        x = select_time(x, time, device=dev, keep=True, **indexer)
     seg, _ = time.segments(freq)
     out, val = K.resample_reduce(dev, x, op, seg)
     return _finish(out, val, cell_shape, keep, with_valid)

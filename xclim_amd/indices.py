@@ -21,12 +21,50 @@ from .calendar import DoyPercentile
 from .timeaxis import TimeAxis
 
 
+import contextvars
+
+# time selection (season= / month= / doy_bounds= / date_bounds=) of the running index call: set by `_indexed`, read by
+# `_masked` so that MissingAny expects the SELECTED days only (core/missing.py:118-135)
+_INDEXER = contextvars.ContextVar("xclim_amd_indexer", default=None)
+_INDEXER_KEYS = ("season", "month", "doy_bounds", "date_bounds", "include_bounds")
+
+
 def _masked(out, valid, time: TimeAxis, freq, dev, cell_shape, mask_missing):
     if not mask_missing:
         o = out.get()
         return o.reshape((o.shape[0],) + tuple(cell_shape))
-    res = K.apply_missing_mask(dev, out, valid, time.expected_count(freq)).get()
+    res = K.apply_missing_mask(dev, out, valid, time.expected_count(freq, **(_INDEXER.get() or {}))).get()
     return res.reshape((res.shape[0],) + tuple(cell_shape))
+
+
+def _indexed(fn, nvars: int):
+    """Indicator-level time selection (core/indicator.py: ``da = select_time(da, **indexer)`` on every input before the
+    compute, the same indexer handed to the missing-value check): the first `nvars` arguments are masked on the device
+    (calendar.select_time) and MissingAny counts against the selected days."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        idx = {k: kwargs.pop(k) for k in _INDEXER_KEYS if k in kwargs}
+        if not any(v is not None for k, v in idx.items() if k != "include_bounds"):
+            return fn(*args, **kwargs)
+        from .calendar import select_time
+
+        time = next((a for a in list(args) + list(kwargs.values()) if isinstance(a, TimeAxis)), None)
+        if time is None:
+            raise ValueError("a time selection needs the TimeAxis argument")
+        dev = kwargs.get("device") or get_device()
+        args = list(args)
+        for i in range(nvars):
+            cells = _cells(args[i])
+            args[i] = select_time(args[i], time, device=dev, keep=True, **idx).reshape((len(time),) + tuple(cells))
+        token = _INDEXER.set(idx)
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            _INDEXER.reset(token)
+
+    return wrapper
 
 
 def _cells(da):
@@ -438,3 +476,12 @@ def growing_season_end(tas, thresh: float, time: TimeAxis, mid_date: str | None 
     """indices/_threshold.py:1029-1092 -> day of year of the season end."""
     generic.get_op(op, (">", ">="))
     return generic.season(tas, thresh, window, op, time, freq, mid_date, device=device)["end"]
+
+
+# ---- Indicator-level time selections on every index of this module -------------------------------------------------------
+_TWO_INPUTS = {"heat_wave_frequency", "heat_wave_max_length", "heat_wave_total_length", "daily_temperature_range",
+               "daily_temperature_range_variability", "extreme_temperature_range"}
+for _n, _f in list(globals().items()):
+    if callable(_f) and not _n.startswith("_") and getattr(_f, "__module__", None) == __name__ and not isinstance(_f, type):
+        globals()[_n] = _indexed(_f, 2 if _n in _TWO_INPUTS else 1)
+del _n, _f

@@ -209,6 +209,15 @@ def compare_map(dev: Device, a: DeviceArray, op, thr, kind: str = "mask") -> Dev
     return out
 
 
+def select_rows(dev: Device, x: DeviceArray, idx) -> DeviceArray:
+    """out row i = x row idx[i], NaN where idx[i] < 0 (xh_select_rows)."""
+    T, C_ = _tc(x)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    out = dev.empty((len(idx), C_), np.float32)
+    dev.call("xh_select_rows", _vp(x.ptr), T, C_, C_, 1, np_ptr(idx), len(idx), _vp(out.ptr), C_)
+    return out
+
+
 def mask_to_f32(dev: Device, mask: DeviceArray) -> DeviceArray:
     """uint8 / bool device mask -> float32 1 / 0 mask of the same shape (xh_mask_u8_to_f32)."""
     if np.dtype(mask.dtype).itemsize != 1:

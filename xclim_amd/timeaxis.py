@@ -148,8 +148,20 @@ class TimeAxis:
             starts.append((mstart // 12, mstart % 12 + 1))
         return seg_off, starts
 
-    def expected_count(self, freq: str) -> np.ndarray:
-        """Days in each full resampling period (core/missing.py:137-159, daily source)."""
+    def expected_count(self, freq: str, **indexer) -> np.ndarray:
+        """Days in each full resampling period (core/missing.py:137-159, daily source).  With a time selection
+        (``season=`` / ``month=`` / ``doy_bounds=`` / ``date_bounds=``, core/missing.py:118-135): the selected days of a
+        complete synthetic series covering the same periods."""
+        if indexer and any(v is not None for k, v in indexer.items() if k != "include_bounds"):
+            from .calendar import select_time_mask
+
+            full = self.expected_count(freq)
+            _, starts = self.segments(freq)
+            y0, m0 = starts[0]
+            synth = TimeAxis.daily(f"{y0:04d}-{m0:02d}-01", int(full.sum()), self.calendar)
+            mask = select_time_mask(synth, **indexer)
+            edges = np.concatenate(([0], np.cumsum(full)))
+            return np.array([int(mask[a:b].sum()) for a, b in zip(edges[:-1], edges[1:])], dtype=np.int32)
         _, starts = self.segments(freq)
         base, _ = parse_freq(freq)
         nmon = {"M": 1, "Q": 3, "Y": 12}[base]
