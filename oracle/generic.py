@@ -272,10 +272,14 @@ def _spell_mask_nogap(datas, window, win_reducer, op, threshs, weights=None, var
 
 
 def spell_length_statistics(data, thresh, window, win_reducer, op, spell_reducer, time: OTime, freq,
-                            resample_before_rl=True, min_gap=1):
+                            resample_before_rl=True, min_gap=1, **indexer):
     """gen:543-585 / 588-686 (and the bivariate form gen:689-766 when data / thresh are lists) without indexer:
     mask -> float32 -> resample_and_rl(rle_statistics, window=1)."""
     mask = spell_mask(data, window, win_reducer, op, thresh, min_gap=min_gap).astype(np.float32)
+    if indexer:  # gen:558: the time selection masks the SPELL MASK (NaN outside)
+        from . import calendar as ocal
+
+        mask = ocal.select_time(mask, time, **indexer)
     return rl.resample_and_rl(mask, resample_before_rl, rl.rle_statistics, time=time, freq=freq, reducer=spell_reducer,
                               window=1)
 

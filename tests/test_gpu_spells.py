@@ -478,3 +478,23 @@ def test_bool_masks_upload_as_bytes(dev, rng, shape):
     np.testing.assert_array_equal(K.mask_to_f32(dev, d8).get(), f.reshape(shape[0], -1))
     with pytest.raises(TypeError):
         K.mask_to_f32(dev, dev.to_device(f.reshape(shape[0], -1)))
+
+
+@pytest.mark.parametrize("before", [True, False])
+@pytest.mark.parametrize("window", [1, 3])
+def test_spell_length_statistics_indexer(dev, rng, before, window):
+    """gen:543-585: ``**indexer`` masks the spell MASK (NaN outside the selection), so the run-length statistics run on a
+    mask with NaN steps — the rle visibility quirk included (a run whose outer neighbour is NaN loses its length)."""
+    T = 1096
+    x = rng.gamma(0.8, 4.0, (T, 5, 6)).astype(np.float32)
+    x[rng.random(x.shape) < 0.55] = 0.0
+    x[rng.random(x.shape) < 0.003] = np.nan
+    ta, ot = TimeAxis.daily("2001-01-01", T), OTime.standard("2001-01-01", T)
+    for indexer in (dict(season="JJA"), dict(month=[4, 5, 6, 7]), dict(date_bounds=("11-01", "03-15"))):
+        for red in ("max", "sum", "count"):
+            for freq in ("YS", "QS-DEC"):
+                got = xgen.spell_length_statistics(x, 1.0, window, "sum" if window > 1 else None, "<", red, ta, freq,
+                                                   resample_before_rl=before, device=dev, **indexer)
+                ref = ogen.spell_length_statistics(x, np.float32(1.0), window, "sum" if window > 1 else None, "<", red, ot, freq,
+                                                   resample_before_rl=before, **indexer)
+                np.testing.assert_array_equal(got, ref, err_msg=f"{indexer} {red} {freq}")

@@ -268,13 +268,14 @@ def select_rolling_resample_op(da, op: str, window: int, time: TimeAxis, window_
 
 def spell_length_statistics(data, threshold, window: int, win_reducer, op: str, spell_reducer, time: TimeAxis, freq: str,
                             min_gap: int = 1, resample_before_rl: bool = True, *, device=None, keep=False,
-                            with_valid=False):
+                            with_valid=False, **indexer):
     """gen:588-686 / 543-585.  window == 1 (the path of maximum_consecutive_dry/wet_days and friends): compare,
     astype(float32), rle_statistics(window=1) fused in ONE kernel pass; window > 1 / min_gap > 1 / several variables go
-    through :func:`spell_mask`.  ``spell_reducer`` may be a sequence (-> tuple of results)."""
+    through :func:`spell_mask`.  ``spell_reducer`` may be a sequence (-> tuple of results).  ``**indexer`` masks the
+    SPELL MASK (gen:558: ``is_in_spell = select_time(is_in_spell, **indexer)``): the run statistics then see NaN steps."""
     if not isinstance(spell_reducer, str):
         return tuple(spell_length_statistics(data, threshold, window, win_reducer, op, sr, time, freq, min_gap,
-                                             resample_before_rl, device=device, keep=keep, with_valid=with_valid)
+                                             resample_before_rl, device=device, keep=keep, with_valid=with_valid, **indexer)
                      for sr in spell_reducer)
     sym = get_op(op)
     dev = device or get_device()
@@ -285,6 +286,20 @@ def spell_length_statistics(data, threshold, window: int, win_reducer, op: str, 
         x, cell_shape = flat[0]
     else:
         x, cell_shape = _flatten(data, dev)
+    if indexer and any(v is not None for k, v in indexer.items() if k != "include_bounds"):
+        from .calendar import select_time
+
+        mask = spell_mask([f[0] for f in flat] if multi else x, window, win_reducer, op, threshold, min_gap=min_gap,
+                          device=dev, keep=True)
+        mask = select_time(mask, time, device=dev, keep=True, **indexer)
+        out, _ = K.run_stats(dev, mask, spell_reducer, 1, seg, cut=resample_before_rl, want_valid=False)
+        val = None
+        if with_valid:
+            if multi:
+                _, val = K.bivariate_count(dev, flat[0][0], flat[1][0], ">", 0.0, ">", 0.0, "all", seg)
+            else:
+                _, val = K.resample_reduce(dev, x, "count", seg)
+        return _finish(out, val, cell_shape, keep, with_valid)
     if window == 1 and min_gap == 1 and not multi:
         cell = _cell_threshold(dev, threshold, data)
         if cell is not None:  # one threshold per grid cell: compared in place (one-row table), fused when the runs are cut
