@@ -498,3 +498,20 @@ def test_spell_length_statistics_indexer(dev, rng, before, window):
                 ref = ogen.spell_length_statistics(x, np.float32(1.0), window, "sum" if window > 1 else None, "<", red, ot, freq,
                                                    resample_before_rl=before, **indexer)
                 np.testing.assert_array_equal(got, ref, err_msg=f"{indexer} {red} {freq}")
+
+
+def test_rolling_and_bivariate_indexer(dev, rng):
+    """``**indexer`` of select_rolling_resample_op (applied to the rolled series, gen:174) and of
+    bivariate_spell_length_statistics (applied to the combined spell mask)."""
+    from oracle import calendar as ocal
+
+    T = 800
+    x = rng.normal(10, 3, (T, 4, 5)).astype(np.float32)
+    y = (x + rng.normal(0, 2, x.shape)).astype(np.float32)
+    ta, ot = TimeAxis.daily("2001-01-01", T), OTime.standard("2001-01-01", T)
+    got = xgen.select_rolling_resample_op(x, "max", 5, ta, True, "mean", "YS", device=dev, season="MAM")
+    ref = ogen.select_resample_op(ocal.select_time(ogen.rolling(x, 5, "mean", True), ot, season="MAM"), "max", ot, "YS")
+    np.testing.assert_allclose(got, ref, rtol=1e-6, equal_nan=True)
+    got = xgen.bivariate_spell_length_statistics(x, 9.0, y, 9.0, 3, "min", ">=", "max", ta, "YS", device=dev, month=[5, 6, 7])
+    ref = ogen.spell_length_statistics([x, y], [np.float32(9.0), np.float32(9.0)], 3, "min", ">=", "max", ot, "YS", month=[5, 6, 7])
+    np.testing.assert_array_equal(got, ref)

@@ -256,11 +256,15 @@ def select_resample_op(da, op: str, time: TimeAxis, freq: str = "YS", *, device=
 
 def select_rolling_resample_op(da, op: str, window: int, time: TimeAxis, window_center: bool = True,
                                window_op: str = "mean", freq: str = "YS", *, device=None, keep=False,
-                               with_valid=False):
-    """gen:128-174: rolling(window).window_op() then select_resample_op."""
+                               with_valid=False, **indexer):
+    """gen:128-174: rolling(window).window_op() then select_resample_op (``**indexer`` applies to the ROLLED series)."""
     dev = device or get_device()
     x, cell_shape = _flatten(da, dev)
     rolled = K.rolling_reduce(dev, x, window, window_op, window_center)
+    if indexer:
+        from .calendar import select_time
+
+        rolled = select_time(rolled, time, device=dev, keep=True, **indexer)
     seg, _ = time.segments(freq)
     out, val = K.resample_reduce(dev, rolled, op, seg)
     return _finish(out, val, cell_shape, keep, with_valid)
@@ -339,10 +343,11 @@ def spell_length(data, threshold: float, reducer: str, time: TimeAxis, freq: str
 
 def bivariate_spell_length_statistics(data1, threshold1: float, data2, threshold2: float, window: int, win_reducer, op: str,
                                       spell_reducer, time: TimeAxis, freq: str, min_gap: int = 1,
-                                      resample_before_rl: bool = True, *, device=None, keep=False, with_valid=False):
+                                      resample_before_rl: bool = True, *, device=None, keep=False, with_valid=False, **indexer):
     """gen:689-766: spell statistics where BOTH variables fulfil their window condition."""
     return spell_length_statistics([data1, data2], [threshold1, threshold2], window, win_reducer, op, spell_reducer, time,
-                                   freq, min_gap, resample_before_rl, device=device, keep=keep, with_valid=with_valid)
+                                   freq, min_gap, resample_before_rl, device=device, keep=keep, with_valid=with_valid,
+                                   **indexer)
 
 
 def spell_mask(data, window: int, win_reducer: str, op: str, thresh, min_gap: int = 1, weights=None,
