@@ -780,3 +780,21 @@ def test_indicator_level_time_selection(dev, rng):
     assert np.isfinite(xi.tg_mean(x, ta, "YS", device=dev, season="JJA")[:3]).any()
     # no selection: unchanged behaviour
     np.testing.assert_array_equal(xi.tg_mean(x, ta, "YS", device=dev), xi.tg_mean(x, ta, "YS", device=dev, season=None))
+
+
+def test_missing_any_standalone(dev, rng):
+    """xclim_amd.missing.missing_any == core/missing.py MissingAny (oracle.indices.missing_any), with and without a time
+    selection; an incomplete last period is always missing."""
+    from xclim_amd import missing as xmiss
+
+    T = 800
+    x = _temp(rng, T, (5, 4), nan_frac=0.002)
+    ta, ot = _axes("2001-01-01", T)
+    for freq in ("YS", "MS", "QS-DEC"):
+        np.testing.assert_array_equal(xmiss.missing_any(x, freq, ta, device=dev), oidx.missing_any(x, ot, freq))
+    got = xmiss.missing_any(x, "YS", ta, device=dev, season="JJA")
+    xm = ocal.select_time(x, ot, season="JJA")
+    seg, _ = ta.segments("YS")
+    valid = np.stack([(~np.isnan(xm[a:b])).sum(axis=0) for a, b in zip(seg[:-1], seg[1:])])
+    np.testing.assert_array_equal(got, valid != np.array([92, 92, 92]).reshape(-1, 1, 1))
+    assert got[-1].all()   # 2003 stops in March: no JJA day at all
