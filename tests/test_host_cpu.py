@@ -180,3 +180,21 @@ def test_dim_other_than_time_is_refused():
     with pytest.raises(NotImplementedError):
         sdba.quantile(x, [0.5], dim="lat")
     assert xrl.rle_statistics.__name__ == "rle_statistics"  # resample_and_rl dispatches on the name
+
+
+def test_threshold_units():
+    """xclim_amd.units.convert_units_to: the threshold strings of the hot-path indicators (core/units.py:334-420; the
+    reference's defaults "25.0 degC", "1 mm/day" with the hydro context -> 1/86400 kg m-2 s-1)."""
+    from xclim_amd.units import convert_units_to as cvt
+
+    assert cvt("25 degC", "K") == pytest.approx(298.15)
+    assert cvt("25.0 degC", "degC") == 25.0 and cvt("-10 C", "K") == pytest.approx(263.15)
+    assert cvt("86 degF", "degC") == pytest.approx(30.0)
+    assert cvt("1 mm/day", "kg m-2 s-1", "hydro") == pytest.approx(1.0 / 86400.0)
+    assert cvt("1 mm/d", "kg/m2/s", context="hydro") == pytest.approx(1.0 / 86400.0)
+    assert cvt("2 kg/m**2/s", "kg m-2 s-1") == 2.0 and cvt("0.5 kg m-2 s-1", "mm/day", "hydro") == pytest.approx(43200.0)
+    assert cvt("1 mm d-1", "mm/day") == 1.0 and cvt("1 cm/day", "mm/day") == pytest.approx(10.0)
+    assert cvt("10 cm", "m") == pytest.approx(0.1) and cvt(3.5, "K") == 3.5
+    for bad in (("1 mm/day", "kg m-2 s-1", None), ("1 mm", "K", None), ("1 furlong", "m", None), ("abc", "K", None)):
+        with pytest.raises(ValueError):
+            cvt(*bad)
