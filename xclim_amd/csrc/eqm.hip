@@ -125,7 +125,8 @@ k_eqm_adjust(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, co
 // (coalesced across lanes) and leaves x, y, M per node; fewer than 4 valid nodes -> count 0 (result NaN).
 __global__ void __launch_bounds__(XH_BLOCK)
 k_cubic_setup(const float* __restrict__ af, const float* __restrict__ hq, int nq, int64_t C, double* __restrict__ wx,
-              double* __restrict__ wy, double* __restrict__ wM, double* __restrict__ wc, int32_t* __restrict__ wm) {
+              double* __restrict__ wy, double* __restrict__ wM, double* __restrict__ wc, double* __restrict__ wd,
+              int32_t* __restrict__ wm) {
   const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
   if (c >= C) return;
   int m = 0;
@@ -142,6 +143,7 @@ k_cubic_setup(const float* __restrict__ af, const float* __restrict__ hq, int nq
     wy[(int64_t)j * C + c] = 0.0;
     wM[(int64_t)j * C + c] = 0.0;
   }
+  for (int j = 0; j < nq; ++j) { wc[(int64_t)j * C + c] = 0.0; wd[(int64_t)j * C + c] = 0.0; }
   if (m < 4) { wm[c] = 0; return; }
   wm[c] = m;
   auto X = [&](int i) { return wx[(int64_t)i * C + c]; };
@@ -182,54 +184,75 @@ k_cubic_setup(const float* __restrict__ af, const float* __restrict__ hq, int nq
     const double ha = H(m - 2), hb = H(m - 3), Ma = wM[(int64_t)(m - 2) * C + c], Mb = wM[(int64_t)(m - 3) * C + c];
     wM[(int64_t)(m - 1) * C + c] = ((ha + hb) * Ma - ha * Mb) / hb;
   }
+  // per-interval polynomial coefficients (the divisions leave the per-element loop; same operations, same results):
+  //   S(x) = y_i + t c1_i + t^2 (M_i / 2) + t^3 c3_i,  t = x - x_i
+  for (int i = 0; i <= m - 2; ++i) {
+    const double h = H(i), d = D(i), Mi = wM[(int64_t)i * C + c], M1 = wM[(int64_t)(i + 1) * C + c];
+    wc[(int64_t)i * C + c] = d - h * (2.0 * Mi + M1) / 6.0;
+    wd[(int64_t)i * C + c] = (M1 - Mi) / (6.0 * h);
+  }
+  wc[(int64_t)(m - 1) * C + c] = 0.0;  // (row m - 2 of the temporary c' is overwritten above, m - 1 was never used)
 }
 
 template <int NQMAX>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_eqm_adjust_cubic(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, const double* __restrict__ wx,
-                   const double* __restrict__ wy, const double* __restrict__ wM, const int32_t* __restrict__ wm, int nq,
-                   int kind, int extrap, float* __restrict__ scen, int64_t scen_st) {
+                   const double* __restrict__ wy, const double* __restrict__ wM, const double* __restrict__ wc,
+                   const double* __restrict__ wd, const int32_t* __restrict__ wm, int nq, int kind, int extrap,
+                   float* __restrict__ scen, int64_t scen_st) {
   const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
   if (c >= C) return;
-  double xn[NQMAX], yn[NQMAX], Mn[NQMAX];
+  // nodes as float (they ARE float32 values: the interval search compares in fp32, exactly), values and coefficients in fp64
+  float xf[NQMAX];
+  double yn[NQMAX], c1[NQMAX], Mn[NQMAX], c3[NQMAX];
   const int m = wm[c];
 #pragma unroll
   for (int j = 0; j < NQMAX; ++j) {
     const bool in = j < nq;
-    xn[j] = in ? wx[(int64_t)j * C + c] : __longlong_as_double(0x7FF0000000000000LL);
+    xf[j] = in ? (float)wx[(int64_t)j * C + c] : __uint_as_float(0x7F800000u);
     yn[j] = in ? wy[(int64_t)j * C + c] : 0.0;
+    c1[j] = in ? wc[(int64_t)j * C + c] : 0.0;
     Mn[j] = in ? wM[(int64_t)j * C + c] : 0.0;
+    c3[j] = in ? wd[(int64_t)j * C + c] : 0.0;
   }
-  double xlast = xn[0], ylast = yn[0];
+  float xlast = xf[0];
+  double ylast = yn[0];
 #pragma unroll
   for (int j = 1; j < NQMAX; ++j) {
     const bool v = j < m;
-    xlast = v ? xn[j] : xlast;
+    xlast = v ? xf[j] : xlast;
     ylast = v ? yn[j] : ylast;
   }
   const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
   int64_t ta = (int64_t)blockIdx.y * chunk, tb = ta + chunk;
   if (tb > T) tb = T;
-  for (int64_t t = ta; t < tb; ++t) {
-    const float xs = sim[t * st + c];
+  auto adjust_one = [&](int64_t t, float xs) {
     float a = xh_nan32();
     if (m >= 4 && xs == xs) {
-      const double x = (double)xs;
-      double xi = xn[0], yi = yn[0], Mi = Mn[0], x1 = xn[1], y1 = yn[1], M1 = Mn[1];
+      float xi = xf[0];
+      double yi = yn[0], ci = c1[0], Mi = Mn[0], di = c3[0];
 #pragma unroll
       for (int j = 1; j < NQMAX - 1; ++j) {
-        const bool take = (x >= xn[j]) && (j <= m - 2);
-        xi = take ? xn[j] : xi; yi = take ? yn[j] : yi; Mi = take ? Mn[j] : Mi;
-        x1 = take ? xn[j + 1] : x1; y1 = take ? yn[j + 1] : y1; M1 = take ? Mn[j + 1] : M1;
+        const bool take = (xs >= xf[j]) && (j <= m - 2);
+        xi = take ? xf[j] : xi; yi = take ? yn[j] : yi; ci = take ? c1[j] : ci; Mi = take ? Mn[j] : Mi; di = take ? c3[j] : di;
       }
-      const double h = x1 - xi, tt = x - xi, d = (y1 - yi) / h;
-      double S = yi + tt * (d - h * (2.0 * Mi + M1) / 6.0) + tt * tt * (Mi * 0.5) + tt * tt * tt * ((M1 - Mi) / (6.0 * h));
-      if (x < xn[0]) S = extrap == 0 ? yn[0] : xh_nan64();
-      if (x > xlast) S = extrap == 0 ? ylast : xh_nan64();
+      const double tt = (double)xs - (double)xi;
+      double S = yi + tt * ci + tt * tt * (Mi * 0.5) + tt * tt * tt * di;
+      if (xs < xf[0]) S = extrap == 0 ? yn[0] : xh_nan64();
+      if (xs > xlast) S = extrap == 0 ? ylast : xh_nan64();
       a = (float)S;
     }
     scen[t * scen_st + c] = kind == 0 ? (xs + a) : (xs * a);
+  };
+  int64_t t = ta;
+  for (; t + 8 <= tb; t += 8) {  // 8 rows in flight per lane
+    float xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = sim[(t + u) * st + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) adjust_one(t + u, xv[u]);
   }
+  for (; t < tb; ++t) adjust_one(t, sim[t * st + c]);
 }
 
 static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
@@ -340,20 +363,21 @@ int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   dim3 grid((unsigned)cblocks, (unsigned)gy);
   if (interp == 2) {
     XH_REQUIRE(nq <= 32, XH_ERR_LIMIT, "xh_eqm_adjust: cubic interpolation supports at most 32 quantile nodes (got %d)", nq);
-    // workspace: x, y, M, c' as (nq, C) float64 + the valid-node count per cell
+    // workspace: x, y, M, c1 (c' during the solve), c3 as (nq, C) float64 + the valid-node count per cell
     const size_t plane = sizeof(double) * (size_t)nq * (size_t)C;
     void* ws = nullptr;
-    int rc = xh_big_scratch(ctx, 4 * plane + sizeof(int32_t) * (size_t)C, &ws);
+    int rc = xh_big_scratch(ctx, 5 * plane + sizeof(int32_t) * (size_t)C, &ws);
     if (rc) return rc;
     double *wx = (double*)ws, *wy = wx + (size_t)nq * C, *wM = wy + (size_t)nq * C, *wc = wM + (size_t)nq * C;
-    int32_t* wm = (int32_t*)(wc + (size_t)nq * C);
-    hipLaunchKernelGGL(k_cubic_setup, dim3((unsigned)cblocks), dim3(XH_BLOCK), 0, ctx->stream, af, hist_q, nq, C, wx, wy, wM, wc,
+    double* wd = wc + (size_t)nq * C;
+    int32_t* wm = (int32_t*)(wd + (size_t)nq * C);
+    hipLaunchKernelGGL(k_cubic_setup, dim3((unsigned)cblocks), dim3(XH_BLOCK), 0, ctx->stream, af, hist_q, nq, C, wx, wy, wM, wc, wd,
                        wm);
     if (nq <= 20)
-      hipLaunchKernelGGL((k_eqm_adjust_cubic<20>), grid, dim3(XH_BLOCK), 0, ctx->stream, sim, T, C, st, wx, wy, wM, wm, nq, kind,
+      hipLaunchKernelGGL((k_eqm_adjust_cubic<20>), grid, dim3(XH_BLOCK), 0, ctx->stream, sim, T, C, st, wx, wy, wM, wc, wd, wm, nq, kind,
                          extrap, scen, scen_st);
     else
-      hipLaunchKernelGGL((k_eqm_adjust_cubic<32>), grid, dim3(XH_BLOCK), 0, ctx->stream, sim, T, C, st, wx, wy, wM, wm, nq, kind,
+      hipLaunchKernelGGL((k_eqm_adjust_cubic<32>), grid, dim3(XH_BLOCK), 0, ctx->stream, sim, T, C, st, wx, wy, wM, wc, wd, wm, nq, kind,
                          extrap, scen, scen_st);
     XH_LAUNCH_CHECK();
     return XH_OK;
