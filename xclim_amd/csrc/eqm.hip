@@ -229,13 +229,13 @@ k_eqm_adjust_cubic(const float* __restrict__ sim, int64_t T, int64_t C, int64_t 
   auto adjust_one = [&](int64_t t, float xs) {
     float a = xh_nan32();
     if (m >= 4 && xs == xs) {
-      float xi = xf[0];
-      double yi = yn[0], ci = c1[0], Mi = Mn[0], di = c3[0];
+      // interval index by counting (the nodes ascend, padded nodes are +inf), then ONE dynamic fetch per coefficient
+      // from the lane's private arrays (scratch, L1-resident) instead of a 5 x 18 select chain per element
+      int idx = 0;
 #pragma unroll
-      for (int j = 1; j < NQMAX - 1; ++j) {
-        const bool take = (xs >= xf[j]) && (j <= m - 2);
-        xi = take ? xf[j] : xi; yi = take ? yn[j] : yi; ci = take ? c1[j] : ci; Mi = take ? Mn[j] : Mi; di = take ? c3[j] : di;
-      }
+      for (int j = 1; j < NQMAX - 1; ++j) idx += ((xs >= xf[j]) && (j <= m - 2)) ? 1 : 0;
+      const float xi = xf[idx];
+      const double yi = yn[idx], ci = c1[idx], Mi = Mn[idx], di = c3[idx];
       const double tt = (double)xs - (double)xi;
       double S = yi + tt * ci + tt * tt * (Mi * 0.5) + tt * tt * tt * di;
       if (xs < xf[0]) S = extrap == 0 ? yn[0] : xh_nan64();
