@@ -247,6 +247,14 @@ int xh_spell_mask(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st,
                   int win_reducer, int op, double thr, const float* weights /* host, may be NULL */, float* out,
                   int64_t out_st);
 
+/* spell_length_statistics with a window > 1, resample_before_rl (generic.py:543-686) in one pass: the spell mask of
+ * xh_spell_mask is not materialised, its run statistics (XH_RUN_MAX .. XH_RUN_STD, runs cut at the period edges) are
+ * accumulated directly.  One variable, window <= 8 (XH_ERR_NOTIMPL beyond: use xh_spell_mask + xh_run_stats).
+ * valid_out: non-NaN steps of x per period (may be NULL). */
+int xh_spell_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, int win_reducer,
+                       int op, double thr, const float* weights /* host, may be NULL */, int stat, const int64_t* seg_off,
+                       int P, float* out, int32_t* valid_out);
+
 /* spell_mask on a list of variables (generic.py:434-540, `data` a sequence): xs[nvar] device pointers to (T, C) fields of
  * the same layout, thrs[nvar] their thresholds (host arrays); the per-variable window conditions are combined with
  * all (combine = 1) or any (2) before the spell is propagated.  nvar <= 8. */

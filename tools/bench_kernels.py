@@ -55,6 +55,7 @@ for stat, w in (("max", 1), ("sum", 6), ("count", 3), ("first", 3)):
 run("run_stats max w1 fused compare", lambda: K.run_stats(dev, pr, "max", 1, seg_y, cut=True, fused_op="<", thresh=1.0 / 86400.0), 4 * E)
 run("run_stats sum w6 MS no-cut", lambda: K.run_stats(dev, mask, "sum", 6, seg_m, cut=False), 4 * E)
 run("spell_mask w3 mean", lambda: K.spell_mask(dev, pr, 3, "mean", ">=", 1.0 / 86400.0), 8 * E)
+run("spell_run_stats w3 mean max (fused)", lambda: K.spell_run_stats(dev, pr, 3, "mean", ">=", 1.0 / 86400.0, "max", seg_y), 4 * E)
 run("runs_with_holes", lambda: K.runs_with_holes(dev, mask, 3, None, 2), 8 * E)
 run("keep_longest_run", lambda: K.keep_longest_run(dev, mask, seg_y), 8 * E)
 run("season w5", lambda: K.season(dev, mask, 5, seg_y, None), 4 * E)

@@ -89,6 +89,7 @@ SIGNATURES: dict[str, list] = {
     "xh_mask_u8_to_f32": [_vp, _vp, _i64, _vp],
     "xh_run_stats_doy": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _int, _vp, _int, _int, _vp, _int, _vp, _vp],
     "xh_precip_over_doy": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _dbl, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp],
+    "xh_spell_run_stats": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _dbl, _vp, _int, _vp, _int, _vp, _vp],
     "xh_spell_mask_multi": [_vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _i64],
     "xh_runs_with_holes": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _i64],
     "xh_run_events": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp],

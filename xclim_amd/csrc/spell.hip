@@ -504,6 +504,32 @@ int xh_spell_mask_multi(xh_ctx* ctx, const float* const* xs, int nvar, const dou
                          out, out_st);
 }
 
+int xh_spell_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, int win_reducer,
+                       int op, double thr, const float* weights, int stat, const int64_t* seg_off, int P, float* out,
+                       int32_t* valid_out) {
+  int rc = chk("xh_spell_run_stats", ctx, x, T, C, st, sc);
+  if (rc) return rc;
+  XH_REQUIRE(out, XH_ERR_ARG, "xh_spell_run_stats: out is NULL");
+  XH_REQUIRE(window >= 1, XH_ERR_ARG, "xh_spell_run_stats: window must be >= 1");
+  XH_REQUIRE(win_reducer >= 0 && win_reducer <= 4, XH_ERR_OP, "xh_spell_run_stats: win_reducer %d not recognized", win_reducer);
+  XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
+  XH_REQUIRE(win_reducer != 4 || weights, XH_ERR_ARG, "xh_spell_run_stats: weights required for the weighted mean");
+  XH_REQUIRE(stat >= XH_RUN_MAX && stat <= XH_RUN_STD, XH_ERR_OP, "xh_spell_run_stats: statistic %d not supported", stat);
+  size_t cur = 0;
+  const int64_t* d_seg = nullptr;
+  rc = upload_seg(ctx, &cur, seg_off, P, T, "xh_spell_run_stats", &d_seg);
+  if (rc) return rc;
+  const float* d_w = nullptr;
+  if (win_reducer == 4) {
+    void* d = nullptr;
+    rc = xh_scratch_upload(ctx, &cur, weights, sizeof(float) * (size_t)window, &d);
+    if (rc) return rc;
+    d_w = (const float*)d;
+  }
+  if (C == 0) return XH_OK;
+  return xh_launch_spell_runs(ctx, x, T, C, st, window, win_reducer, op, (float)thr, d_w, stat, d_seg, P, out, valid_out);
+}
+
 int xh_runs_with_holes(xh_ctx* ctx, const float* start, const float* stop, int64_t T, int64_t C, int64_t st, int64_t sc,
                        int window_start, int window_stop, float* out, int64_t out_st) {
   int rc = chk("xh_runs_with_holes", ctx, start, T, C, st, sc);

@@ -8,6 +8,7 @@
 // accumulation) so the results are bit-identical to the generic kernels.  A lane owns VEC consecutive cells; the time
 // axis is cut into chunks over blockIdx.y, each chunk re-reads its (w - 1)-row halo.
 #include "common.h"
+#include "runacc.h"
 #include "window.h"
 
 namespace {
@@ -169,6 +170,72 @@ k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
   for (int64_t tp = r1; tp < tb + w - 1; ++tp) emit(tp, false);
 }
 
+// spell_length_statistics with a window > 1 in ONE pass (generic.py:543-585 with resample_before_rl): the spell mask of
+// k_spell_ring is not written — the mask value of step t = tp - (w - 1) feeds the run-length accumulator of its period
+// directly (rle_statistics with window = 1 on the mask, runs cut at the period edges).  The mask near a period edge
+// depends on the rows of the neighbouring periods (the reference builds it on the whole series first): every period
+// re-reads a (w - 1)-row halo on both sides.  One workgroup row per period.
+template <int VEC, int RED>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_spell_runs(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w, int op, float thr,
+             const float* __restrict__ weights, int stat, const int64_t* __restrict__ seg_off, int P, float* __restrict__ out,
+             int32_t* __restrict__ valid_out) {
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  float wts[WMAX];
+#pragma unroll
+  for (int k = 0; k < WMAX; ++k) wts[k] = (RED == 100 && k >= WMAX - w) ? weights[k - (WMAX - w)] : 0.f;
+  const double inv_w = 1.0 / (double)w;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    const int64_t ta = seg_off[p], tb = seg_off[p + 1];
+    Ring<VEC> ring;
+    ring.fill_nan();
+    int64_t last_true[VEC];
+    RunAcc acc[VEC];
+    int run[VEC], nvalid[VEC], days[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { last_true[i] = -1; acc_reset(acc[i]); run[i] = 0; nvalid[i] = 0; days[i] = 0; }
+    const int64_t r0 = ta - (w - 1) < 0 ? 0 : ta - (w - 1);
+    const int64_t r1 = tb + w - 1 > T ? T : tb + w - 1;
+    auto emit = [&](int64_t tp, bool have_row) {
+      const int64_t t = tp - (w - 1);
+      const bool inside = t >= ta && t < tb;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        bool cond = false;
+        if (have_row && tp >= w - 1) {
+          const float s = ring_stat<RED>(ring.v[i], w, inv_w, wts);
+          cond = (s == s) && xh_cmp_f32(s, op, thr);
+        }
+        if (cond) last_true[i] = tp;
+        const bool on = inside && (last_true[i] >= tp - (w - 1));
+        const int len = (inside && !on) ? run[i] : 0;  // a spell ended at t - 1
+        acc_add_if<0>(acc[i], len);
+        run[i] = on ? run[i] + 1 : (inside ? 0 : run[i]);
+        days[i] += on ? 1 : 0;
+      }
+    };
+    if (ta < tb) {
+      xh_march_rows<VEC, 8>(x + c, st, r0, r1, [&](int64_t tp, const VecF<VEC>& xv) {
+        ring.push(xv);
+        if (tp >= ta && tp < tb) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) nvalid[i] += (xv.v[i] == xv.v[i]) ? 1 : 0;
+        }
+        emit(tp, true);
+      });
+      for (int64_t tp = r1; tp < tb + w - 1; ++tp) emit(tp, false);
+    }
+    const int64_t o = (int64_t)p * C + c;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if (run[i] > 0) acc_add(acc[i], run[i]);  // spell cut by the period end
+      out[o + i] = acc_result(acc[i], stat, days[i]);
+      if (valid_out) valid_out[o + i] = nvalid[i];
+    }
+  }
+}
+
 static dim3 window_grid(xh_ctx* ctx, int64_t T, int64_t C, int vec) {
   const int64_t cblocks = cdiv64(cdiv64(C, vec), XH_BLOCK);
   int64_t gy = cdiv64((int64_t)ctx->num_cu * 12, cblocks);
@@ -227,6 +294,33 @@ int xh_launch_spell_ring(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
       return XH_ERR_NOTIMPL;
   }
 #undef XH_SR
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_launch_spell_runs(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int window, int win_red, int op, float thr,
+                         const float* d_weights, int stat, const int64_t* d_seg, int P, float* out, int32_t* valid_out) {
+  if (window > WMAX) return XH_ERR_NOTIMPL;
+  const unsigned py = (unsigned)(P > 4096 ? 4096 : P);
+  // four cells per lane only when that still leaves >= 8 workgroups per CU (a period cannot be cut into time chunks)
+  const int vec = (xh_pick_vec(x, C, st) == 4 && cdiv64(cdiv64(C, 4), XH_BLOCK) * py >= 8 * (int64_t)ctx->num_cu) ? 4 : 1;
+  const dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), py);
+  const int red = win_red == 0 ? XH_RED_SUM : win_red == 1 ? XH_RED_MEAN : win_red == 2 ? XH_RED_MIN : win_red == 3 ? XH_RED_MAX : 100;
+#define XH_SRN(R)                                                                                                          \
+  case R:                                                                                                                  \
+    if (vec == 4)                                                                                                          \
+      hipLaunchKernelGGL((k_spell_runs<4, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
+                         stat, d_seg, P, out, valid_out);                                                                  \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((k_spell_runs<1, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
+                         stat, d_seg, P, out, valid_out);                                                                  \
+    break;
+  switch (red) {
+    XH_SRN(XH_RED_SUM) XH_SRN(XH_RED_MEAN) XH_SRN(XH_RED_MIN) XH_SRN(XH_RED_MAX) XH_SRN(100)
+    default:
+      return XH_ERR_NOTIMPL;
+  }
+#undef XH_SRN
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

@@ -316,6 +316,12 @@ def spell_length_statistics(data, threshold, window: int, win_reducer, op: str, 
             return _finish(out, val, cell_shape, keep, with_valid)
         out, val = K.run_stats(dev, x, spell_reducer, 1, seg, cut=resample_before_rl, fused_op=sym, thresh=float(threshold))
         return _finish(out, val, cell_shape, keep, with_valid)
+    if (not multi and min_gap == 1 and resample_before_rl and np.ndim(threshold) == 0 and spell_reducer in
+            ("max", "min", "sum", "count", "mean", "std")):
+        # window > 1, runs cut at the period edges: spell mask and run statistics in one pass, the mask is never written
+        fused = K.spell_run_stats(dev, x, window, win_reducer, sym, float(threshold), spell_reducer, seg)
+        if fused is not None:
+            return _finish(fused[0], fused[1], cell_shape, keep, with_valid)
     mask = spell_mask([f[0] for f in flat] if multi else x, window, win_reducer, op, threshold, min_gap=min_gap, device=dev,
                       keep=True)
     out, _ = K.run_stats(dev, mask, spell_reducer, 1, seg, cut=resample_before_rl, want_valid=False)

@@ -269,6 +269,29 @@ def spell_mask(dev: Device, x: DeviceArray, window: int, win_reducer: str, op: s
     return out
 
 
+def spell_run_stats(dev: Device, x: DeviceArray, window: int, win_reducer: str, op: str, thresh: float, stat: str, seg_off,
+                    weights=None, want_valid=True):
+    """xh_spell_run_stats: run statistics of the spell mask, the mask itself is never written (runs cut at the periods).
+    Returns None when the shape is not covered (window > 8): the caller then takes spell_mask + run_stats."""
+    from ._capi import XH_ERR_NOTIMPL, XclimHipError
+
+    T, C_ = _tc(x)
+    seg, P = _seg(seg_off)
+    out = dev.empty((P, C_), np.float32)
+    valid = dev.empty((P, C_), np.int32) if want_valid else None
+    w = np.ascontiguousarray(weights, dtype=np.float32) if weights is not None else None
+    red = WIN_REDUCERS["wmean" if w is not None else (win_reducer or "min")]
+    try:
+        dev.call("xh_spell_run_stats", _vp(x.ptr), T, C_, C_, 1, int(window), red, op_code(op), float(thresh),
+                 np_ptr(w) if w is not None else _vp(0), RUN_STATS[stat], np_ptr(seg), P, _vp(out.ptr),
+                 _vp(valid.ptr if valid else 0))
+    except XclimHipError as e:
+        if e.code == XH_ERR_NOTIMPL:
+            return None
+        raise
+    return out, valid
+
+
 def spell_mask_multi(dev: Device, xs, window: int, win_reducer: str, op: str, threshs, var_reducer="all", weights=None) -> DeviceArray:
     """spell_mask on a list of (T, C) device arrays with one threshold each (xh_spell_mask_multi)."""
     T, C_ = _tc(xs[0])
