@@ -515,3 +515,29 @@ def test_rolling_and_bivariate_indexer(dev, rng):
     got = xgen.bivariate_spell_length_statistics(x, 9.0, y, 9.0, 3, "min", ">=", "max", ta, "YS", device=dev, month=[5, 6, 7])
     ref = ogen.spell_length_statistics([x, y], [np.float32(9.0), np.float32(9.0)], 3, "min", ">=", "max", ot, "YS", month=[5, 6, 7])
     np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("T,C", [(731, 33), (400, 1024)])
+@pytest.mark.parametrize("win_reducer", ["sum", "mean", "min", "max", "wmean"])
+def test_spell_run_stats_fused_equals_two_step(dev, rng, T, C, win_reducer):
+    """xh_spell_run_stats == xh_spell_mask followed by xh_run_stats (window 1, cut at the periods), bit for bit: every
+    window reducer (incl. weights), windows 2..8, every run statistic, ragged / empty periods, NaN steps; windows > 8 are
+    declined (None) so that callers take the two-step path."""
+    from xclim_amd import kernels as K
+
+    x = rng.gamma(0.8, 3.0, (T, C)).astype(np.float32)
+    x[rng.random(x.shape) < 0.5] = 0.0
+    x[rng.random(x.shape) < 0.01] = np.nan
+    dx = dev.to_device(x)
+    seg = np.array([0, 31, 31, 59, 200, T], dtype=np.int64)
+    for window in (2, 3, 5, 8):
+        weights = (rng.random(window) + 0.5).astype(np.float32) if win_reducer == "wmean" else None
+        red = "mean" if win_reducer == "wmean" else win_reducer
+        for op, thr in ((">=", 2.0), ("<", 1.0)):
+            mask = K.spell_mask(dev, dx, window, red, op, thr, weights)
+            for stat in ("max", "min", "sum", "count", "mean", "std"):
+                two, _ = K.run_stats(dev, mask, stat, 1, seg, cut=True, want_valid=False)
+                fused, val = K.spell_run_stats(dev, dx, window, red, op, thr, stat, seg, weights=weights)
+                np.testing.assert_array_equal(fused.get(), two.get(), err_msg=f"w{window} {op} {stat}")
+            np.testing.assert_array_equal(val.get(), np.stack([(~np.isnan(x[a:b])).sum(axis=0) for a, b in zip(seg[:-1], seg[1:])]))
+    assert K.spell_run_stats(dev, dx, 9, "sum", ">", 1.0, "max", seg) is None
