@@ -235,6 +235,11 @@ int xh_rle(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_
  *   fused_op >= 0: mask = compare(x, fused_op, thr) in fp32 (NaN -> False); valid_out counts non-NaN x.
  *   cut_at_segments != 0: resample BEFORE run length (runs cut at period edges, rl:122-129);
  *   else resample AFTER (run attributed to the period of its first/last element, rl:330-334).
+ *   index_first: 0 = runs indexed by their last step, 1 = by their first step — both as the N-D path of the reference
+ *   (rle, rl:223-272: a run whose outer neighbour is NaN loses its length) — 2 = first step with the semantics of the
+ *   reference's 1-D ufunc path (rle_1d / statistics_run_1d, rl:1334-1618, taken for grids under 9000 cells when no
+ *   resampling follows, rl:70-78): NaN steps only break runs, a run next to a NaN keeps its length; 3 = the same plus
+ *   statistics_run_1d's result for a series WITH NaN steps and WITHOUT a qualifying run: NaN instead of 0 for MAX / MIN / MEAN / STD (numpy's nan-reducers of an empty selection; nansum and the count stay 0).
  *   out (P, C) float32 (integer valued; NaN for FIRST/LAST when no run); valid_out may be NULL. */
 int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int fused_op,
                  double thr, int window, int stat, int index_first, const int64_t* seg_off, int P,

@@ -155,22 +155,54 @@ def _map_groups(arr, time: OTime, freq, func):
     return np.stack(outs, axis=0)
 
 
-def rle_statistics(da, reducer, window, time: OTime | None = None, freq=None, index="first"):
-    """rl:275-335 (N-D path, ufunc_1dim=False): resample AFTER the run-length encoding when freq is given."""
+NPTS_OPT = 9000  # rl:26
+
+
+def use_ufunc(ufunc_1dim, da, freq=None, index="first"):
+    """rl:33-78 with OPTIONS[RUN_LENGTH_UFUNC] = "auto" (the default): grids under 9000 cells take the 1-D ufunc path
+    when the runs are indexed by their first step and no resampling follows."""
+    da = np.asarray(da)
+    if ufunc_1dim is True and freq is not None:
+        raise ValueError("Resampling after run length operations is not implemented for 1d method")
+    if ufunc_1dim in ("auto", "from_context"):
+        ufunc_1dim = (da.size // max(da.shape[0], 1)) < NPTS_OPT
+    return bool(index == "first" and ufunc_1dim and freq is None)
+
+
+def _apply_1d(func, da, *args):
+    """xr.apply_ufunc(..., vectorize=True) over the cells: `func` sees one series at a time (rl:1500-1618)."""
+    da = np.asarray(da)
+    flat = da.reshape(da.shape[0], -1)
+    with np.errstate(invalid="ignore"):
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            out = np.array([func(flat[:, c], *args) for c in range(flat.shape[1])], dtype=np.float64)
+    return out.reshape(da.shape[1:])
+
+
+def rle_statistics(da, reducer, window, time: OTime | None = None, freq=None, index="first", ufunc_1dim="auto"):
+    """rl:275-335: the 1-D ufunc path for small grids (rl:314-316), else the N-D path — resample AFTER the run-length
+    encoding when freq is given."""
+    if use_ufunc(ufunc_1dim, da, freq, index):
+        return _apply_1d(statistics_run_1d, da, reducer, window)
     d = rle(da, index=index)
     if freq is None:
         return _rl_stat(d, window, reducer)
     return _map_groups(d, time, freq, lambda g, _t: _rl_stat(g, window, reducer))
 
 
-def longest_run(da, time=None, freq=None, index="first"):
+def longest_run(da, time=None, freq=None, index="first", ufunc_1dim="auto"):
     """rl:338-378."""
-    return rle_statistics(da, "max", 1, time, freq, index)
+    return rle_statistics(da, "max", 1, time, freq, index, ufunc_1dim)
 
 
-def windowed_run_events(da, window, time=None, freq=None, index="first"):
+def windowed_run_events(da, window, time=None, freq=None, index="first", ufunc_1dim="auto"):
     """rl:381-434."""
     da = np.asarray(da)
+    if use_ufunc(ufunc_1dim, da, freq, index):
+        return _apply_1d(windowed_run_events_1d, da, window)
     if window == 1:
         shift = 1 if index == "first" else -1
         with np.errstate(invalid="ignore"):
@@ -185,9 +217,11 @@ def windowed_run_events(da, window, time=None, freq=None, index="first"):
     return d.sum(axis=0)
 
 
-def windowed_run_count(da, window, time=None, freq=None, index="first"):
+def windowed_run_count(da, window, time=None, freq=None, index="first", ufunc_1dim="auto"):
     """rl:437-488."""
     da = np.asarray(da)
+    if use_ufunc(ufunc_1dim, da, freq, index):
+        return _apply_1d(windowed_run_count_1d, da, window)
     if window == 1 and freq is None:
         return np.nansum(da.astype(np.float64) if da.dtype.kind != "f" else da, axis=0)
     d = rle(da, index=index)
@@ -272,25 +306,32 @@ def rle_1d(arr):
 
 
 def statistics_run_1d(arr, reducer, window):
-    """rl:1408-1437."""
-    v, rls, _ = rle_1d(arr)
-    sel = rls[np.where(v & (rls >= window), True, False)] if v is not None else np.array([])
-    sel = rls[(v.astype(bool)) & (rls >= window)]
-    if sel.size == 0:
-        return 0
-    return getattr(np, f"nan{reducer}")(sel)
+    """rl:1408-1437, verbatim logic: NaN steps form their own (value NaN) runs; `v * rl >= window` is False for them."""
+    v, rls, _ = rle_1d(np.asarray(arr, dtype=np.float64))
+    with np.errstate(invalid="ignore"):
+        if not np.any(v) or np.all(v * rls < window):
+            return 0
+        if reducer == "count":
+            return (v * rls >= window).sum()
+        kwargs = {}
+        if reducer.startswith("q") and reducer[1:].isdigit():
+            kwargs["q"] = float(f"0.{reducer[1:]}")
+            reducer = "quantile"
+        return getattr(np, f"nan{reducer}")(np.where(v * rls >= window, rls, np.nan), **kwargs)
 
 
 def windowed_run_count_1d(arr, window):
     """rl:1440-1458."""
-    v, rls, _ = rle_1d(arr)
-    return np.where(v * rls >= window, rls, 0).sum()
+    v, rls, _ = rle_1d(np.asarray(arr, dtype=np.float64))
+    with np.errstate(invalid="ignore"):
+        return np.where(v * rls >= window, rls, 0).sum()
 
 
 def windowed_run_events_1d(arr, window):
     """rl:1461-1480."""
-    v, rls, _ = rle_1d(arr)
-    return (v * rls >= window).sum()
+    v, rls, _ = rle_1d(np.asarray(arr, dtype=np.float64))
+    with np.errstate(invalid="ignore"):
+        return (v * rls >= window).sum()
 
 
 def first_run_1d(arr, window):

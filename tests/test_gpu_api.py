@@ -798,3 +798,44 @@ def test_missing_any_standalone(dev, rng):
     valid = np.stack([(~np.isnan(xm[a:b])).sum(axis=0) for a, b in zip(seg[:-1], seg[1:])])
     np.testing.assert_array_equal(got, valid != np.array([92, 92, 92]).reshape(-1, 1, 1))
     assert got[-1].all()   # 2003 stops in March: no JJA day at all
+
+
+def test_dry_and_wet_spell_indices(dev, rng):
+    """dry_spell_* / wet_spell_* (indices/_threshold.py:3314-3735) through the HIP path: the reference's known answers
+    (tests/test_indices.py:4067-4171, incl. the date_bounds indexer that masks the SPELL MASK and relies on the 1-D
+    ufunc semantics a single series gets) and seeded parity on windows that take the fused kernel."""
+    from tests.test_oracle_reference_answers import _DRY_FREQ_OP, _DRY_SPELL_CASES
+
+    kw = dict(device=dev, mask_missing=False)
+    for pr, th1, th2, window, outs in _DRY_SPELL_CASES:
+        x = np.asarray(pr, dtype=np.float32)[:, None]
+        ta = TimeAxis.daily("1981-01-01", len(x))
+        got = (xi.dry_spell_frequency(x, ta, th1, window, "YS", **kw)[0, 0],
+               xi.dry_spell_total_length(x, ta, th2, window, "sum", "YS", **kw)[0, 0],
+               xi.dry_spell_total_length(x, ta, th1, window, "max", "YS", **kw)[0, 0],
+               xi.dry_spell_max_length(x, ta, th2, window, "sum", "YS", **kw)[0, 0],
+               xi.dry_spell_max_length(x, ta, th1, window, "max", "YS", **kw)[0, 0])
+        np.testing.assert_allclose(got, outs, rtol=1e-1)
+    x = np.asarray([1] * 5 + [0] * 10 + [1] * 350, dtype=np.float32)[:, None]
+    ta = TimeAxis.daily("1900-01-01", len(x), "noleap")
+    for f in (xi.dry_spell_total_length, xi.dry_spell_max_length):
+        out = f(x, ta, 3.1, 7, "sum", "MS", date_bounds=("01-10", "12-31"), **kw)
+        np.testing.assert_allclose(out[:, 0], [9] + [0] * 11)
+    x = np.asarray(_DRY_FREQ_OP, dtype=np.float32)[:, None]
+    ta = TimeAxis.daily("2000-07-01", len(x))
+    assert xi.dry_spell_frequency(x, ta, 1.0, 3, "MS", op="sum", **kw)[0, 0] == 2
+    assert xi.dry_spell_frequency(x, ta, 1.0, 3, "MS", op="max", **kw)[0, 0] == 3
+    T = 1095
+    pr = (rng.gamma(0.7, 4.0, (T, 5, 6)) * (rng.random((T, 5, 6)) < 0.45)).astype(np.float32)
+    pr[rng.random(pr.shape) < 0.002] = np.nan
+    ta, ot = _axes("2001-01-01", T)
+    for before in (True, False):
+        for window, wop in ((3, "sum"), (5, "max"), (1, "sum"), (10, "sum")):
+            for f, op, red in ((xi.dry_spell_frequency, "<", "count"), (xi.wet_spell_frequency, ">=", "count")):
+                got = f(pr, ta, 1.0, window, "YS", before, wop, **kw)
+                ref = ogen.spell_length_statistics(pr, np.float32(1.0), window, wop, op, red, ot, "YS", resample_before_rl=before)
+                np.testing.assert_array_equal(got, ref)
+            for f, op, red in ((xi.dry_spell_total_length, "<", "sum"), (xi.wet_spell_max_length, ">=", "max")):
+                got = f(pr, ta, 1.0, window, wop, "MS", before, **kw)
+                ref = ogen.spell_length_statistics(pr, np.float32(1.0), window, wop, op, red, ot, "MS", resample_before_rl=before)
+                np.testing.assert_array_equal(got, ref)

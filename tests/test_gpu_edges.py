@@ -57,7 +57,11 @@ def test_single_step_and_all_nan(dev):
     nan = np.full((T, 6), np.nan, np.float32)
     np.testing.assert_array_equal(xgen.threshold_count(nan, ">", 0.0, ta, "YS", device=dev), np.zeros((1, 6)))
     assert np.isnan(xgen.select_resample_op(nan, "max", ta, "YS", device=dev)).all()
-    np.testing.assert_array_equal(xrl.rle_statistics(nan, "max", 1, device=dev), np.zeros(6))  # all-NaN -> 0 (reference)
+    # all-NaN: 0 on the N-D path (tests/test_run_length.py:89-91); the 1-D ufunc path that a 6-cell grid takes by default
+    # ends in np.nanmax of an empty selection -> NaN (statistics_run_1d, rl:1418-1437)
+    np.testing.assert_array_equal(xrl.rle_statistics(nan, "max", 1, device=dev, ufunc_1dim=False), np.zeros(6))
+    assert np.isnan(xrl.rle_statistics(nan, "max", 1, device=dev)).all()
+    np.testing.assert_array_equal(xrl.windowed_run_count(nan, 1, device=dev), np.zeros(6))
     assert np.isnan(K.quantile_series(dev, dev.to_device(nan), q).get()).all()
 
 

@@ -161,12 +161,20 @@ def test_run_stats_mask(dev, rng, stat, index, cut):
     for nan_frac, window, freq in ((0.0, 1, "YS"), (0.03, 3, "MS"), (0.03, 1, "QS-DEC")):
         m = _mask(rng, T, C, nan_frac=nan_frac)
         seg, _ = ta.segments(freq)
+        # the N-D path of the reference (rle quirk: a run next to a NaN step loses its length) ...
         out, _ = K.run_stats(dev, dev.to_device(m), stat, window, seg, cut=cut, index=index)
-        exp = orl.resample_and_rl(m, cut, orl.rle_statistics, time=ot, freq=freq, reducer=stat, window=window, index=index)
+        exp = orl.resample_and_rl(m, cut, orl.rle_statistics, time=ot, freq=freq, reducer=stat, window=window, index=index,
+                                  ufunc_1dim=False)
         if stat in ("mean", "std"):
             np.testing.assert_allclose(out.get(), exp, rtol=RTOL, atol=1e-5 if stat == "std" else 0)
         else:
             np.testing.assert_array_equal(out.get(), exp)
+        # ... and the 1-D ufunc path it takes for grids under 9000 cells when the runs are cut first (index "first")
+        if cut and index == "first":
+            out, _ = K.run_stats(dev, dev.to_device(m), stat, window, seg, cut=True, index=index, one_dim="stat")
+            exp = orl.resample_and_rl(m, True, orl.rle_statistics, time=ot, freq=freq, reducer=stat, window=window,
+                                      ufunc_1dim=True)
+            np.testing.assert_allclose(out.get(), exp, rtol=RTOL, atol=1e-5 if stat == "std" else 0, equal_nan=True)
 
 
 @pytest.mark.parametrize("window", [1, 2, 5])
@@ -179,12 +187,19 @@ def test_windowed_run_count_events(dev, rng, window, index):
     d = dev.to_device(m)
     for cut in (True, False):
         ev, _ = K.run_stats(dev, d, "count", window, seg, cut=cut, index=index)
-        exp_ev = orl.resample_and_rl(m, cut, orl.windowed_run_events, window, time=ot, freq="MS", index=index)
+        exp_ev = orl.resample_and_rl(m, cut, orl.windowed_run_events, window, time=ot, freq="MS", index=index, ufunc_1dim=False)
         np.testing.assert_array_equal(ev.get(), exp_ev)
         stat = "plainsum" if (window == 1 and cut) else "sum"
         cn, _ = K.run_stats(dev, d, stat, window, seg, cut=cut, index=index)
-        exp_cn = orl.resample_and_rl(m, cut, orl.windowed_run_count, window, time=ot, freq="MS", index=index)
+        exp_cn = orl.resample_and_rl(m, cut, orl.windowed_run_count, window, time=ot, freq="MS", index=index, ufunc_1dim=False)
         np.testing.assert_array_equal(cn.get(), exp_cn)
+        if cut and index == "first":  # the 1-D ufunc path (grids under 9000 cells): runs next to a NaN keep their length
+            ev, _ = K.run_stats(dev, d, "count", window, seg, cut=True, one_dim=True)
+            np.testing.assert_array_equal(ev.get(), orl.resample_and_rl(m, True, orl.windowed_run_events, window, time=ot,
+                                                                        freq="MS", ufunc_1dim=True))
+            cn, _ = K.run_stats(dev, d, "sum", window, seg, cut=True, one_dim=True)
+            np.testing.assert_array_equal(cn.get(), orl.resample_and_rl(m, True, orl.windowed_run_count, window, time=ot,
+                                                                        freq="MS", ufunc_1dim=True))
 
 
 @pytest.mark.parametrize("window", [1, 3, 7])

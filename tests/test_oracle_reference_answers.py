@@ -387,3 +387,36 @@ def test_select_time_known_answers():
     with pytest.raises(ValueError, match="Only one method"):
         select_time_mask(ta, month=1, season="DJF")
     assert select_time_mask(ta) is None
+
+
+_DRY_SPELL_CASES = [
+    ([1.01] * 6 + [0.01] * 3 + [0.51] * 2 + [0.75] * 2 + [0.51] + [0.01] * 3 + [1.01] * 3, 3, 3, 7, (1, 12, 20, 12, 20)),
+    ([0.01] * 6 + [1.01] * 3 + [0.51] * 2 + [0.75] * 2 + [0.51] + [0.01] * 3 + [0.01] * 3, 3, 3, 7, (2, 18, 20, 10, 20)),
+    ([3.01] * 358 + [0.99] * 14 + [3.01] * 358, 1, 14, 14, (0, 7, 7, 7, 7)),
+]
+_DRY_FREQ_OP = [29.012, 0.1288, 0.0253, 0.0035, 4.9147, 1.4186, 1.014, 0.5622, 0.8001, 10.5823, 2.8879, 8.2635, 0.292, 0.5242,
+                0.2426, 1.3934, 0.0, 0.4633, 0.1862, 0.0034, 2.4591, 3.8547, 3.1983, 3.0442, 7.422, 14.8854, 13.4334, 0.0012,
+                0.0782, 31.2916, 0.0379]
+
+
+def test_dry_spell_known_answers():
+    """tests/test_indices.py:4067-4171 (test_dry_spell, the indexer variants, test_dry_spell_frequency_op) on the oracle's
+    spell_length_statistics: window sums / maxima under a threshold, spell count / total length / longest spell."""
+    from oracle import generic as ogen
+    from oracle.timeutil import OTime
+
+    for pr, th1, th2, window, outs in _DRY_SPELL_CASES:
+        x = np.asarray(pr, dtype=np.float32)
+        ot = OTime.standard("1981-01-01", len(x))
+        f = lambda th, wop, red: ogen.spell_length_statistics(x, np.float32(th), window, wop, "<", red, ot, "YS")[0]
+        got = (f(th1, "sum", "count"), f(th2, "sum", "sum"), f(th1, "max", "sum"), f(th2, "sum", "max"), f(th1, "max", "max"))
+        np.testing.assert_allclose(got, outs, rtol=1e-1)
+    x = np.asarray([1] * 5 + [0] * 10 + [1] * 350, dtype=np.float32)
+    ot = OTime.standard("1900-01-01", len(x))
+    for red in ("sum", "max"):
+        out = ogen.spell_length_statistics(x, np.float32(3.1), 7, "sum", "<", red, ot, "MS", date_bounds=("01-10", "12-31"))
+        np.testing.assert_allclose(out, [9] + [0] * 11)
+    x = np.asarray(_DRY_FREQ_OP, dtype=np.float32)
+    ot = OTime.standard("2000-07-01", len(x))
+    assert ogen.spell_length_statistics(x, np.float32(1.0), 3, "sum", "<", "count", ot, "MS")[0] == 2
+    assert ogen.spell_length_statistics(x, np.float32(1.0), 3, "max", "<", "count", ot, "MS")[0] == 3

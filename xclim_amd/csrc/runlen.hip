@@ -55,7 +55,7 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
           nvalid[i] += isn ? 0 : 1;
           plainsum[i] += on ? 1 : 0;
           // branch-free state machine (the serial march is VALU-issue bound otherwise)
-          bool visible = index_first ? s[i].vis : !masknan;
+          bool visible = index_first >= 2 ? true : (index_first ? s[i].vis : !masknan);
           bool ended = !on && s[i].run > 0;
           int len = (ended && visible && s[i].run >= window) ? s[i].run : 0;
           acc_add_if<SG>(acc[i], len);
@@ -68,10 +68,15 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         if (s[i].run > 0) {
-          bool visible = index_first ? s[i].vis : true;  // beyond the segment end: shift fill_value 0
+          bool visible = index_first == 1 ? s[i].vis : true;  // beyond the segment end: shift fill_value 0
           if (visible && s[i].run >= window) acc_add(acc[i], s[i].run);
         }
-        out[o + i] = acc_result(acc[i], stat, plainsum[i]);
+        float r = acc_result(acc[i], stat, plainsum[i]);
+        // index mode 3 = statistics_run_1d (rl:1408-1437): with a NaN step in the series and no qualifying run the
+        // early `return 0` is skipped (NaN * length < window is False) and the nan-reducer of an all-NaN list gives NaN
+        if (index_first == 3 && acc[i].cnt == 0 && nvalid[i] < (int)(t1 - t0) && stat != XH_RUN_COUNT && stat != XH_RUN_SUM)
+          r = xh_nan32();  // nanmax / nanmin / nanmean / nanstd of nothing; nansum of nothing is 0
+        out[o + i] = r;
         if (valid_out) valid_out[o + i] = nvalid[i];
       }
     }
@@ -110,7 +115,7 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
           if (s[i].run == 0) { s[i].vis = !s[i].prevnan; s[i].startp = pt; }
           s[i].run++;
         } else if (s[i].run > 0) {
-          bool visible = index_first ? s[i].vis : !masknan;
+          bool visible = index_first >= 2 ? true : (index_first ? s[i].vis : !masknan);
           if (visible && s[i].run >= window && stat != XH_RUN_PLAINSUM) {
             // the run ended at t-1; its last element is in period pt unless t is the first step of pt
             int pa = pt;
@@ -131,7 +136,7 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       if (s[i].run > 0 && stat != XH_RUN_PLAINSUM) {
-        bool visible = index_first ? s[i].vis : true;
+        bool visible = index_first == 1 ? s[i].vis : true;
         if (visible && s[i].run >= window) {
           int pa = index_first ? s[i].startp : pt;
           while (accp[i] < pa) {

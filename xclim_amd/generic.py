@@ -296,7 +296,11 @@ def spell_length_statistics(data, threshold, window: int, win_reducer, op: str, 
         mask = spell_mask([f[0] for f in flat] if multi else x, window, win_reducer, op, threshold, min_gap=min_gap,
                           device=dev, keep=True)
         mask = select_time(mask, time, device=dev, keep=True, **indexer)
-        out, _ = K.run_stats(dev, mask, spell_reducer, 1, seg, cut=resample_before_rl, want_valid=False)
+        from .run_length import use_ufunc
+
+        one_dim = use_ufunc("from_context", x, freq=None if resample_before_rl else freq)  # NaN steps: rl dispatch
+        one_dim = "stat" if one_dim else False  # rl.rle_statistics -> statistics_run_1d
+        out, _ = K.run_stats(dev, mask, spell_reducer, 1, seg, cut=resample_before_rl, want_valid=False, one_dim=one_dim)
         val = None
         if with_valid:
             if multi:

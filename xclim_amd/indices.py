@@ -478,10 +478,60 @@ def growing_season_end(tas, thresh: float, time: TimeAxis, mid_date: str | None 
     return generic.season(tas, thresh, window, op, time, freq, mid_date, device=device)["end"]
 
 
+def _spell_index(pr, thresh, window, win_op, op, spell_reducer, time, freq, resample_before_rl, device, mask_missing):
+    dev = device or get_device()
+    indexer = _INDEXER.get() or {}
+    out, val = generic.spell_length_statistics(pr, float(thresh), int(window), win_op, op, spell_reducer, time, freq,
+                                               resample_before_rl=resample_before_rl, device=dev, keep=True, with_valid=True,
+                                               **indexer)
+    return _masked(out, val, time, freq, dev, _cells(pr), mask_missing)
+
+
+def dry_spell_frequency(pr, time: TimeAxis, thresh: float = 1.0, window: int = 3, freq: str = "YS",
+                        resample_before_rl: bool = True, op: str = "sum", *, device=None, mask_missing=True):
+    """indices/_threshold.py:3314-3382: number of periods of at least `window` days whose accumulated (op="sum") or
+    maximal (op="max") daily amount stays under `thresh`.  `pr` is the DAILY AMOUNT in the units of `thresh` (the
+    reference converts the flux to mm/day first: host work, xclim_amd.units)."""
+    return _spell_index(pr, thresh, window, op, "<", "count", time, freq, resample_before_rl, device, mask_missing)
+
+
+def dry_spell_total_length(pr, time: TimeAxis, thresh: float = 1.0, window: int = 3, op: str = "sum", freq: str = "YS",
+                           resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_threshold.py:3385-3454: days that belong to such dry spells."""
+    return _spell_index(pr, thresh, window, op, "<", "sum", time, freq, resample_before_rl, device, mask_missing)
+
+
+def dry_spell_max_length(pr, time: TimeAxis, thresh: float = 1.0, window: int = 1, op: str = "sum", freq: str = "YS",
+                         resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_threshold.py:3457-3522: the longest such dry spell."""
+    return _spell_index(pr, thresh, window, op, "<", "max", time, freq, resample_before_rl, device, mask_missing)
+
+
+def wet_spell_frequency(pr, time: TimeAxis, thresh: float = 1.0, window: int = 3, freq: str = "YS",
+                        resample_before_rl: bool = True, op: str = "sum", *, device=None, mask_missing=True):
+    """indices/_threshold.py:3525-3593: the same with ``>=``."""
+    return _spell_index(pr, thresh, window, op, ">=", "count", time, freq, resample_before_rl, device, mask_missing)
+
+
+def wet_spell_total_length(pr, time: TimeAxis, thresh: float = 1.0, window: int = 3, op: str = "sum", freq: str = "YS",
+                           resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_threshold.py:3596-3664."""
+    return _spell_index(pr, thresh, window, op, ">=", "sum", time, freq, resample_before_rl, device, mask_missing)
+
+
+def wet_spell_max_length(pr, time: TimeAxis, thresh: float = 1.0, window: int = 1, op: str = "sum", freq: str = "YS",
+                         resample_before_rl: bool = True, *, device=None, mask_missing=True):
+    """indices/_threshold.py:3667-3735."""
+    return _spell_index(pr, thresh, window, op, ">=", "max", time, freq, resample_before_rl, device, mask_missing)
+
+
 # ---- Indicator-level time selections on every index of this module -------------------------------------------------------
 _TWO_INPUTS = {"heat_wave_frequency", "heat_wave_max_length", "heat_wave_total_length", "daily_temperature_range",
                "daily_temperature_range_variability", "extreme_temperature_range"}
+# the spell indices hand the selection to spell_length_statistics, which masks the SPELL MASK (gen:558), not the input
+_MASK_LEVEL = {"dry_spell_frequency", "dry_spell_total_length", "dry_spell_max_length", "wet_spell_frequency",
+               "wet_spell_total_length", "wet_spell_max_length"}
 for _n, _f in list(globals().items()):
     if callable(_f) and not _n.startswith("_") and getattr(_f, "__module__", None) == __name__ and not isinstance(_f, type):
-        globals()[_n] = _indexed(_f, 2 if _n in _TWO_INPUTS else 1)
+        globals()[_n] = _indexed(_f, 0 if _n in _MASK_LEVEL else (2 if _n in _TWO_INPUTS else 1))
 del _n, _f

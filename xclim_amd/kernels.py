@@ -157,7 +157,10 @@ def rle(dev: Device, x: DeviceArray, index="first") -> DeviceArray:
 
 
 def run_stats(dev: Device, x: DeviceArray, stat: str, window: int, seg_off, *, cut=True, index="first", fused_op=None,
-              thresh=0.0, want_valid=True, out=None):
+              thresh=0.0, want_valid=True, out=None, one_dim=False):
+    """xh_run_stats.  ``one_dim``: the NaN semantics of the reference's 1-D ufunc path (index "first" only); True = the
+    windowed_run_count / windowed_run_events form, "stat" = the statistics_run_1d form (NaN for a series with NaN steps and
+    no qualifying run)."""
     T, C_ = _tc(x)
     seg, P = _seg(seg_off)
     if out is not None:
@@ -167,7 +170,8 @@ def run_stats(dev: Device, x: DeviceArray, stat: str, window: int, seg_off, *, c
         valid = dev.empty((P, C_), np.int32) if want_valid else None
     fop = -1 if fused_op is None else op_code(fused_op)
     dev.call("xh_run_stats", _vp(x.ptr), T, C_, C_, 1, fop, float(thresh), int(window), RUN_STATS[stat],
-             int(index == "first"), np_ptr(seg), P, int(bool(cut)), _vp(out.ptr), _vp(valid.ptr if valid else 0))
+             ((3 if one_dim == "stat" else 2) if one_dim else 1) if index == "first" else 0, np_ptr(seg), P, int(bool(cut)), _vp(out.ptr),
+             _vp(valid.ptr if valid else 0))
     return out, valid
 
 

@@ -1,8 +1,9 @@
 """Host mirror of ``xclim.indices.run_length`` (reference: src/xclim/indices/run_length.py) over the HIP kernels.
 
-Inputs are masks with TIME ON AXIS 0 (bool, or float32 with NaN where ``select_time`` masked values); results are
-identical for the reference's N-D and 1-D (``ufunc_1dim``) code paths, so that option is accepted and ignored
-except for the one error the reference raises (rl:67-68).
+Inputs are masks with TIME ON AXIS 0 (bool, or float32 with NaN where ``select_time`` masked values).  The reference's
+N-D and 1-D (``ufunc_1dim``) code paths are the same kernels here; the one place where they disagree — a run next to a
+NaN step keeps its length in the 1-D path and loses it in the N-D path — follows the reference's own dispatch
+(:func:`use_ufunc`: grids under 9000 cells without resampling take the 1-D semantics).
 """
 
 from __future__ import annotations
@@ -17,11 +18,25 @@ from .timeaxis import TimeAxis
 npts_opt = 9000  # rl:26 — kept for API parity; no dispatch depends on it here
 
 
+RUN_LENGTH_UFUNC = "auto"  # the reference's option OPTIONS[RUN_LENGTH_UFUNC] (core/options.py), read for "from_context"
+
+
 def use_ufunc(ufunc_1dim, da=None, dim="time", freq=None, index="first") -> bool:
-    """rl:33-78: only the argument validation matters on this backend."""
+    """rl:33-78.  The reference runs small grids (< `npts_opt` cells, "auto") through its 1-D ufunc path when no
+    resampling follows and runs are indexed by their first step.  Both paths are the same kernels here; they differ in
+    ONE thing the kernels reproduce (``xh_run_stats`` index mode 2): the 1-D path lets a run next to a NaN step keep its
+    length, the N-D path (rle, rl:223-272) drops it."""
     if ufunc_1dim is True and freq is not None:
         raise ValueError("Resampling after run length operations is not implemented for 1d method")
-    return False
+    if ufunc_1dim == "from_context":
+        ufunc_1dim = RUN_LENGTH_UFUNC
+    if ufunc_1dim == "auto":
+        if da is None:
+            ufunc_1dim = False
+        else:
+            shape = tuple(da.shape) if isinstance(da, DeviceArray) else np.shape(da)
+            ufunc_1dim = int(np.prod(shape[1:], dtype=np.int64)) < npts_opt
+    return bool((index == "first") and ufunc_1dim and (freq is None))
 
 
 def _mask(da, dev):
@@ -44,15 +59,18 @@ def _whole(T):
     return np.array([0, T], dtype=np.int64)
 
 
-def _run(da, stat, window, time, freq, index, device, keep, cut=False):
+def _run(da, stat, window, time, freq, index, device, keep, cut=False, ufunc_1dim="from_context", stat_form=False):
     dev = device or get_device()
+    one_dim = use_ufunc(ufunc_1dim, da, freq=freq, index=index)
+    if one_dim and stat_form:
+        one_dim = "stat"  # rle_statistics goes through statistics_run_1d
     m, cell_shape = _mask(da, dev)
     if freq is None:
         seg = _whole(m.shape[0])
         cut = True
     else:
         seg, _ = time.segments(freq)
-    out, _ = K.run_stats(dev, m, stat, window, seg, cut=cut, index=index, want_valid=False)
+    out, _ = K.run_stats(dev, m, stat, window, seg, cut=cut, index=index, want_valid=False, one_dim=one_dim)
     if keep:
         return out
     o = out.get().reshape((out.shape[0],) + tuple(cell_shape))
@@ -78,19 +96,21 @@ def rle(da, dim="time", index="first", *, device=None, keep=False):
 def rle_statistics(da, reducer: str, window: int, dim="time", freq=None, ufunc_1dim="from_context", index="first", *,
                    time: TimeAxis | None = None, device=None, keep=False):
     """rl:275-335.  ``freq`` given -> resample AFTER the run-length encoding."""
-    use_ufunc(ufunc_1dim, freq=freq, index=index)
     if reducer.startswith("q") and reducer[1:].isdigit():
-        return _run_quantile(da, float(f"0.{reducer[1:]}"), window, time, freq, index, device, keep)
-    return _run(da, reducer, window, time, freq, index, device, keep)
+        return _run_quantile(da, float(f"0.{reducer[1:]}"), window, time, freq, index, device, keep,
+                             use_ufunc(ufunc_1dim, da, freq=freq, index=index))
+    return _run(da, reducer, window, time, freq, index, device, keep, ufunc_1dim=ufunc_1dim, stat_form=True)
 
 
-def _run_quantile(da, q, window, time, freq, index, device, keep):
+def _run_quantile(da, q, window, time, freq, index, device, keep, one_dim=False):
     """rl:318-327 with reducer "qNN": d.where(d >= window).quantile(q) (linear / Hyndman-Fan type 7, NaN-skipping) of the
-    run lengths of each period, 0 where the period holds no run of at least `window`."""
+    run lengths of each period, 0 where the period holds no run of at least `window`.  `one_dim` (statistics_run_1d,
+    rl:1408-1437): NaN steps only break runs, and a series with NaN steps but no qualifying run gives NaN."""
     dev = device or get_device()
     m, cell_shape = _mask(da, dev)
     T, C_ = m.shape
-    d = K.compare_map(dev, K.rle(dev, m, index), ">=", float(window), "where")
+    src = K.compare_map(dev, m, ">", 0.0, "maskf") if one_dim else m  # NaN -> 0: the run next to it keeps its length
+    d = K.compare_map(dev, K.rle(dev, src, index), ">=", float(window), "where")
     seg = _whole(T) if freq is None else time.segments(freq)[0]
     P = len(seg) - 1
     out = dev.empty((P, C_), np.float32)
@@ -101,7 +121,13 @@ def _run_quantile(da, q, window, time, freq, index, device, keep):
         view = DeviceArray(dev, d.ptr + t0 * C_ * 4, (t1 - t0, C_), np.float32, owner=False)
         row = DeviceArray(dev, out.ptr + p * C_ * 4, (1, C_), np.float32, owner=False)
         K.quantile_series(dev, view, [q], out=row)
-    o = np.nan_to_num(out.get(), nan=0.0)  # no qualifying run -> 0 (rl:326)
+    o = out.get()
+    if one_dim:  # np.nanquantile of an empty selection is NaN — reached only when the series holds a NaN step
+        _, valid = K.resample_reduce(dev, m, "count", seg)
+        has_nan = valid.get() < np.diff(seg).reshape(-1, 1)
+        o = np.where(np.isnan(o) & ~has_nan, 0.0, o).astype(np.float32)
+    else:
+        o = np.nan_to_num(o, nan=0.0)  # no qualifying run -> 0 (rl:326)
     if keep:
         return dev.to_device(o)
     o = o.reshape((P,) + tuple(cell_shape))
@@ -117,16 +143,14 @@ def longest_run(da, dim="time", freq=None, ufunc_1dim="from_context", index="fir
 def windowed_run_events(da, window: int, dim="time", freq=None, ufunc_1dim="from_context", index="first", *, time=None,
                         device=None, keep=False):
     """rl:381-434."""
-    use_ufunc(ufunc_1dim, freq=freq, index=index)
-    return _run(da, "count", window, time, freq, index, device, keep)
+    return _run(da, "count", window, time, freq, index, device, keep, ufunc_1dim=ufunc_1dim)
 
 
 def windowed_run_count(da, window: int, dim="time", freq=None, ufunc_1dim="from_context", index="first", *, time=None,
                        device=None, keep=False):
     """rl:437-488 (window == 1 and freq None: plain sum, rl:478-479)."""
-    use_ufunc(ufunc_1dim, freq=freq, index=index)
     stat = "plainsum" if (window == 1 and freq is None) else "sum"
-    return _run(da, stat, window, time, freq, index, device, keep)
+    return _run(da, stat, window, time, freq, index, device, keep, ufunc_1dim=ufunc_1dim)
 
 
 def first_run(da, window: int, dim="time", freq=None, coord=None, ufunc_1dim="from_context", *, time=None, device=None,
@@ -369,9 +393,13 @@ def resample_and_rl(da, resample_before_rl: bool, compute, *args, freq: str, tim
     else:
         stat = "first" if name == "first_run" else "last"
     dev = device or get_device()
+    # every period is handed to `compute` with freq=None (rl:122-129): small grids take the 1-D NaN semantics
+    one_dim = use_ufunc(params.get("ufunc_1dim", "from_context"), da, freq=None, index=index)
+    if one_dim and name in ("rle_statistics", "longest_run"):
+        one_dim = "stat"
     m, cell_shape = _mask(da, dev)
     seg, _ = time.segments(freq)
-    out, _ = K.run_stats(dev, m, stat, window, seg, cut=True, index=index, want_valid=False)
+    out, _ = K.run_stats(dev, m, stat, window, seg, cut=True, index=index, want_valid=False, one_dim=one_dim)
     return out if keep else out.get().reshape((out.shape[0],) + tuple(cell_shape))
 
 
