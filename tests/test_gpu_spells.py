@@ -541,3 +541,29 @@ def test_spell_run_stats_fused_equals_two_step(dev, rng, T, C, win_reducer):
                 np.testing.assert_array_equal(fused.get(), two.get(), err_msg=f"w{window} {op} {stat}")
             np.testing.assert_array_equal(val.get(), np.stack([(~np.isnan(x[a:b])).sum(axis=0) for a, b in zip(seg[:-1], seg[1:])]))
     assert K.spell_run_stats(dev, dx, 9, "sum", ">", 1.0, "max", seg) is None
+
+
+def test_use_ufunc_dispatch_by_grid_size(dev, rng):
+    """rl:33-78: the same NaN-carrying mask gives the 1-D semantics under 9000 cells and the N-D semantics (rle quirk) at
+    9000 cells and more, with the default ``ufunc_1dim="from_context"`` — mirrors and oracle dispatch alike, and the two
+    semantics really differ on this input."""
+    T = 90
+    small = (rng.random((T, 40, 50)) < 0.6).astype(np.float32)      # 2000 cells
+    small[rng.random(small.shape) < 0.05] = np.nan
+    big = np.tile(small, (1, 1, 5))[:, :, :225]                      # 40 x 225 = 9000 cells, same columns repeated
+    assert xrl.use_ufunc("from_context", small) and not xrl.use_ufunc("from_context", big)
+    assert not xrl.use_ufunc("from_context", small, freq="YS") and not xrl.use_ufunc("from_context", small, index="last")
+    for red in ("max", "sum", "mean"):
+        gs = xrl.rle_statistics(small, red, 2, device=dev)
+        gb = xrl.rle_statistics(big, red, 2, device=dev)
+        np.testing.assert_allclose(gs, orl.rle_statistics(small, red, 2), rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(gb, orl.rle_statistics(big, red, 2), rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(gb, orl.rle_statistics(big, red, 2, ufunc_1dim=False), rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(xrl.rle_statistics(small, red, 2, device=dev, ufunc_1dim=False),
+                                   orl.rle_statistics(small, red, 2, ufunc_1dim=False), rtol=1e-6, equal_nan=True)
+    assert not np.array_equal(xrl.rle_statistics(small, "sum", 2, device=dev),
+                              xrl.rle_statistics(small, "sum", 2, device=dev, ufunc_1dim=False))
+    np.testing.assert_array_equal(xrl.windowed_run_count(small, 2, device=dev), orl.windowed_run_count(small, 2))
+    np.testing.assert_array_equal(xrl.windowed_run_events(big, 2, device=dev), orl.windowed_run_events(big, 2))
+    with pytest.raises(ValueError, match="1d method"):
+        xrl.rle_statistics(small, "max", 2, freq="YS", ufunc_1dim=True, time=TimeAxis.daily("2001-01-01", T), device=dev)
