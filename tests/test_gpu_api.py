@@ -839,3 +839,28 @@ def test_dry_and_wet_spell_indices(dev, rng):
                 got = f(pr, ta, 1.0, window, wop, "MS", before, **kw)
                 ref = ogen.spell_length_statistics(pr, np.float32(1.0), window, wop, op, red, ot, "MS", resample_before_rl=before)
                 np.testing.assert_array_equal(got, ref)
+
+
+def test_hot_and_cold_spell_reference_known_answers(dev):
+    """tests/test_indices.py:119-147, 2040-2131 through the HIP path (fused compare + run statistics)."""
+    from tests.test_oracle_reference_answers import _HS_FREQ, _HS_LEN, K2C, _spell_series
+
+    kw = dict(device=dev, mask_missing=False)
+    t10 = TimeAxis.daily("2000-07-01", 10)
+    tx = (np.asarray(_HS_FREQ[0]) + K2C).astype(np.float32)[:, None]
+    for th, w, op, exp in _HS_FREQ[1]:
+        assert xi.hot_spell_frequency(tx, th + K2C, t10, w, "YS", op, **kw)[0, 0] == exp
+    tx = (np.asarray(_HS_LEN[0]) + K2C).astype(np.float32)[:, None]
+    for th, w, op, mx, tot in _HS_LEN[1]:
+        assert xi.hot_spell_max_length(tx, th + K2C, t10, w, "YS", op, **kw)[0, 0] == mx
+        assert xi.hot_spell_total_length(tx, th + K2C, t10, w, "YS", op, **kw)[0, 0] == tot
+    hot, _, cold_f, order = _spell_series()
+    t = TimeAxis.daily("2000-07-01", 365)
+    np.testing.assert_array_equal(xi.hot_spell_total_length(hot[:, None], 25 + K2C, t, 5, "ME", **kw)[:, 0], [10, 0, 12, 8] + [0] * 8)
+    cold = (2 * K2C - hot.astype(np.float64)).astype(np.float32)
+    np.testing.assert_array_equal(xi.cold_spell_days(cold[:, None], -10 + K2C, t, 5, "ME", **kw)[:, 0], [10, 0, 12, 8] + [0] * 8)
+    t71 = TimeAxis.daily("1971-01-01", 365)
+    np.testing.assert_array_equal(xi.cold_spell_frequency(cold_f[:, None], -10 + K2C, t71, 5, "ME", **kw)[:, 0], [1, 0, 1, 1] + [0] * 8)
+    assert xi.cold_spell_frequency(cold_f[:, None], -10 + K2C, t71, 5, "YS", **kw)[0, 0] == 3
+    assert xi.hot_spell_frequency(order[:, None], 30 + K2C, t, 3, "MS", ">", True, **kw)[1, 0] == 1
+    assert xi.hot_spell_frequency(order[:, None], 30 + K2C, t, 3, "MS", ">", False, **kw)[1, 0] == 0

@@ -420,3 +420,51 @@ def test_dry_spell_known_answers():
     ot = OTime.standard("2000-07-01", len(x))
     assert ogen.spell_length_statistics(x, np.float32(1.0), 3, "sum", "<", "count", ot, "MS")[0] == 2
     assert ogen.spell_length_statistics(x, np.float32(1.0), 3, "max", "<", "count", ot, "MS")[0] == 3
+
+
+K2C = 273.15
+_HS_FREQ = ([29, 31, 31, 31, 29, 31, 31, 31, 31, 31],
+            [(30, 3, ">", 2), (30, 4, ">", 1), (29, 3, ">", 2), (29, 3, ">=", 1), (10, 3, ">", 1), (40, 5, ">", 0)])
+_HS_LEN = ([28, 31, 31, 31, 29, 31, 31, 31, 31, 31],
+           [(30, 3, ">", 5, 8), (10, 3, ">", 10, 10), (29, 3, ">", 5, 8), (29, 3, ">=", 9, 9), (40, 3, ">", 0, 0), (30, 5, ">", 5, 5)])
+
+
+def _spell_series():
+    hot = np.zeros(365)
+    hot[10:20] += 30
+    hot[40:43] += 50
+    hot[80:100] += 30
+    cold_f = np.zeros(365)
+    cold_f[10:20] -= 15
+    cold_f[40:43] -= 50
+    cold_f[80:86] -= 30
+    cold_f[95:101] -= 30
+    order = np.zeros(365)
+    order[5:35] = 31
+    return (hot + K2C).astype(np.float32), (-hot * 0 + K2C).astype(np.float32), (cold_f + K2C).astype(np.float32), (order + K2C).astype(np.float32)
+
+
+def test_hot_and_cold_spell_known_answers():
+    """tests/test_indices.py:119-147 (cold_spell_days / cold_spell_frequency) and :2040-2131 (hot_spell_frequency /
+    max_length / total_length, incl. the resampling-order case) on the oracle compositions."""
+    from oracle import indices as oidx
+    from oracle.timeutil import OTime
+
+    t10 = OTime.standard("2000-07-01", 10)
+    tx = (np.asarray(_HS_FREQ[0]) + K2C).astype(np.float32)
+    for th, w, op, exp in _HS_FREQ[1]:
+        assert oidx.run_index(tx, op, np.float32(th + K2C), "events", w, t10, "YS")[0] == exp
+    tx = (np.asarray(_HS_LEN[0]) + K2C).astype(np.float32)
+    for th, w, op, mx, tot in _HS_LEN[1]:
+        assert oidx.longest_run_index(tx, op, np.float32(th + K2C), w, t10, "YS")[0] == mx
+        assert oidx.run_index(tx, op, np.float32(th + K2C), "count", w, t10, "YS")[0] == tot
+    hot, _, cold_f, order = _spell_series()
+    t = OTime.standard("2000-07-01", 365)
+    np.testing.assert_array_equal(oidx.run_index(hot, ">", np.float32(25 + K2C), "count", 5, t, "MS"), [10, 0, 12, 8] + [0] * 8)
+    cold = (2 * K2C - hot.astype(np.float64)).astype(np.float32)  # the same pattern below zero: -30 / -50 C
+    np.testing.assert_array_equal(oidx.run_index(cold, "<", np.float32(-10 + K2C), "count", 5, t, "MS"), [10, 0, 12, 8] + [0] * 8)
+    t71 = OTime.standard("1971-01-01", 365)
+    np.testing.assert_array_equal(oidx.run_index(cold_f, "<", np.float32(-10 + K2C), "events", 5, t71, "MS"), [1, 0, 1, 1] + [0] * 8)
+    assert oidx.run_index(cold_f, "<", np.float32(-10 + K2C), "events", 5, t71, "YS")[0] == 3
+    assert oidx.run_index(order, ">", np.float32(30 + K2C), "events", 3, t, "MS", True)[1] == 1
+    assert oidx.run_index(order, ">", np.float32(30 + K2C), "events", 3, t, "MS", False)[1] == 0
