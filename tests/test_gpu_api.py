@@ -864,3 +864,17 @@ def test_hot_and_cold_spell_reference_known_answers(dev):
     assert xi.cold_spell_frequency(cold_f[:, None], -10 + K2C, t71, 5, "YS", **kw)[0, 0] == 3
     assert xi.hot_spell_frequency(order[:, None], 30 + K2C, t, 3, "MS", ">", True, **kw)[1, 0] == 1
     assert xi.hot_spell_frequency(order[:, None], 30 + K2C, t, 3, "MS", ">", False, **kw)[1, 0] == 0
+
+
+def test_growing_season_length_reference_known_answers(dev):
+    """tests/test_indices.py:1681-1707 through the HIP path (generic.season -> xh_season)."""
+    from tests.test_oracle_reference_answers import _GSL_CASES, _gsl_series
+
+    ta = TimeAxis.daily("2000-01-01", 365)
+    for d1, d2, exp in _GSL_CASES:
+        got = xi.growing_season_length(_gsl_series(d1, d2)[:, None], 278.15, ta, device=dev)
+        assert got[0, 0] == exp, (d1, d2, got)
+    ta2 = TimeAxis.daily("2000-01-01", 730)
+    got = xi.growing_season_length(_gsl_series("2000-11-01", "2001-03-01", T=730)[:, None], 278.15, ta2, mid_date="01-01",
+                                   freq="YS-JUL", device=dev)
+    assert got[1, 0] == 121

@@ -468,3 +468,30 @@ def test_hot_and_cold_spell_known_answers():
     assert oidx.run_index(cold_f, "<", np.float32(-10 + K2C), "events", 5, t71, "YS")[0] == 3
     assert oidx.run_index(order, ">", np.float32(30 + K2C), "events", 3, t, "MS", True)[1] == 1
     assert oidx.run_index(order, ">", np.float32(30 + K2C), "events", 3, t, "MS", False)[1] == 0
+
+
+_GSL_CASES = [("1950-01-01", "1951-01-01", 0), ("2000-01-01", "2000-12-31", 365), ("2000-07-10", "2001-01-01", 0),
+              ("2000-06-15", "2001-01-01", 199), ("2000-06-15", "2000-07-15", 31)]
+
+
+def _gsl_series(d1, d2, T=365, start="2000-01-01", cold=0.0, warm=280.0):
+    import pandas as pd
+
+    idx = pd.date_range(start, periods=T)
+    return np.where((idx >= d1) & (idx <= d2), warm, cold).astype(np.float32)
+
+
+def test_growing_season_length_known_answers():
+    """tests/test_indices.py:1681-1707 (growing_season_length: thresh 5 degC, window 6, mid_date 07-01) on the oracle's
+    season restatement, incl. the southern-hemisphere case (mid_date 01-01, freq YS-JUL -> 121)."""
+    from oracle import run_length as orl
+    from oracle.timeutil import OTime
+
+    ot = OTime.standard("2000-01-01", 365)
+    for d1, d2, exp in _GSL_CASES:
+        tas = _gsl_series(d1, d2)
+        assert orl.season(tas >= np.float32(278.15), 6, "07-01", ot)[2] == exp
+    tas = _gsl_series("2000-11-01", "2001-03-01", T=730)
+    ot2 = OTime.standard("2000-01-01", 730)
+    length = orl.season_per_period(tas >= np.float32(278.15), 6, "01-01", ot2, "YS-JUL")[2]
+    assert length[1] == 121  # the period starting 2000-07-01
