@@ -878,3 +878,25 @@ def test_growing_season_length_reference_known_answers(dev):
     got = xi.growing_season_length(_gsl_series("2000-11-01", "2001-03-01", T=730)[:, None], 278.15, ta2, mid_date="01-01",
                                    freq="YS-JUL", device=dev)
     assert got[1, 0] == 121
+
+
+def test_degree_days_reference_known_answers(dev):
+    """tests/test_indices.py:232-247 (cooling_degree_days: 0 and 10), :1617-1622 (growing_degree_days: 1), :1835-1842
+    (heating_degree_days: 6) through the HIP path (xh_thresholded_reduce), and against the oracle's cumulative_difference."""
+    K2C = 273.15
+    kw = dict(device=dev, mask_missing=False)
+    t4 = TimeAxis.daily("2000-07-01", 4)
+    a = (np.array([10, 15, -5, 18]) + K2C).astype(np.float32)[:, None]
+    assert xi.cooling_degree_days(a, 18 + K2C, t4, **kw)[0, 0] == 0
+    a = (np.array([20, 25, -15, 19]) + K2C).astype(np.float32)[:, None]
+    np.testing.assert_allclose(xi.cooling_degree_days(a, 18 + K2C, t4, **kw)[0, 0], 10, rtol=1e-5)
+    np.testing.assert_allclose(ogen.cumulative_difference(a, np.float32(18 + K2C), ">", OTime.standard("2000-07-01", 4), "YS")[0, 0], 10, rtol=1e-5)
+    t = TimeAxis.daily("2000-07-01", 365)
+    g = np.zeros(365)
+    g[0] = 5
+    np.testing.assert_allclose(xi.growing_degree_days((g + K2C).astype(np.float32)[:, None], 4 + K2C, t, **kw)[0, 0], 1, rtol=1e-4)
+    h = np.zeros(365) + 17
+    h[:7] += [-3, -2, -1, 0, 1, 2, 3]
+    out = xi.heating_degree_days((h + K2C).astype(np.float32)[:, None], 17 + K2C, t, **kw)
+    np.testing.assert_allclose(out[0, 0], 6, rtol=1e-4)
+    assert (out[1:] == 0).all()
