@@ -567,3 +567,34 @@ def test_use_ufunc_dispatch_by_grid_size(dev, rng):
     np.testing.assert_array_equal(xrl.windowed_run_events(big, 2, device=dev), orl.windowed_run_events(big, 2))
     with pytest.raises(ValueError, match="1d method"):
         xrl.rle_statistics(small, "max", 2, freq="YS", ufunc_1dim=True, time=TimeAxis.daily("2001-01-01", T), device=dev)
+
+
+def test_more_run_length_reference_known_answers(dev):
+    """tests/test_run_length.py:135-160, 427-434, 451-454, 472-560 through the HIP path (incl. coord="dayofyear")."""
+    from tests.test_oracle_reference_answers import _FIRST_RUN_AFTER, _RUN_END_AFTER, _SEASON_LENGTH, _rwh_series
+
+    values, expected = _rwh_series()
+    np.testing.assert_array_equal(xrl.runs_with_holes((values == 1)[:, None], 1, (values == 0)[:, None], 3, device=dev)[:, 0], expected)
+    ident = np.zeros((365, 4, 4), np.float32)
+    ident[1:11] = 1
+    np.testing.assert_array_equal(xrl.runs_with_holes(ident != 0, 1, ident == 0, 1, device=dev), ident)
+    runs = np.array([0, 1, 1, 1, 0, 0, 1, 1, 1, 0], dtype=bool)[:, None]
+    np.testing.assert_array_equal(xrl.keep_longest_run(runs, device=dev)[:, 0], [0, 1, 1, 1, 0, 0, 0, 0, 0, 0])
+    np.testing.assert_array_equal(xrl.run_bounds(runs, device=dev)[:, :, 0], [[1, 6], [4, 9]])
+    ta = TimeAxis.daily("2000-01-01", 360)
+    for date, end, exp in _SEASON_LENGTH:
+        t = np.zeros((360, 2), np.float32)
+        t[140:end] = 1
+        np.testing.assert_array_equal(xrl.season_length(t == 1, 1, date, time=ta, device=dev), [exp, exp])
+    for date, end, exp in _RUN_END_AFTER:
+        t = np.zeros((360, 2), np.float32)
+        t[140:end] = 1
+        np.testing.assert_array_equal(xrl.run_end_after_date(t == 1, 1, date, time=ta, device=dev), [exp, exp])
+        doy = xrl.run_end_after_date(t == 1, 1, date, coord="dayofyear", time=ta, device=dev)
+        np.testing.assert_array_equal(doy, [exp + 1, exp + 1])  # 2000-01-01 is day 1: 211 / 191 / NaN / 306
+    ta5 = TimeAxis.daily("2000-01-01", 365)
+    for date, beg, exp in _FIRST_RUN_AFTER:
+        t = np.zeros((365, 2), np.float32)
+        if beg:
+            t[beg:] = 1
+        np.testing.assert_array_equal(xrl.first_run_after_date(t == 1, 1, date, time=ta5, device=dev), [exp, exp])

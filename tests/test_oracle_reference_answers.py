@@ -495,3 +495,49 @@ def test_growing_season_length_known_answers():
     ot2 = OTime.standard("2000-01-01", 730)
     length = orl.season_per_period(tas >= np.float32(278.15), 6, "01-01", ot2, "YS-JUL")[2]
     assert length[1] == 121  # the period starting 2000-07-01
+
+
+def _rwh_series():
+    values = np.zeros(365)
+    a = [0, 1, 0, 1, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0]
+    values[: len(a)] = a
+    expected = values * 0
+    expected[1:11] = 1
+    expected[15:20] = 1
+    return values, expected
+
+
+_SEASON_LENGTH = [("07-01", 210, 70), ("07-01", 190, 50), ("04-01", 150, 0), ("11-01", 150, 165), (None, 150, 10)]
+_RUN_END_AFTER = [("07-01", 210, 210), ("07-01", 190, 190), ("04-01", 150, np.nan), ("11-01", 150, 305)]   # indices (doy - 1)
+_FIRST_RUN_AFTER = [("07-01", 210, 210), ("07-01", 190, 190), ("04-01", False, np.nan), ("11-01", 150, 305)]
+
+
+def test_more_run_length_known_answers():
+    """tests/test_run_length.py:135-160 (runs_with_holes), :427-434 (run_bounds), :451-454 (keep_longest_run), :472-560
+    (season_length / run_end_after_date / first_run_after_date with dates) on the oracle."""
+    from oracle import run_length as orl
+    from oracle.timeutil import OTime
+
+    values, expected = _rwh_series()
+    np.testing.assert_array_equal(orl.runs_with_holes(values == 1, 1, values == 0, 3), expected)
+    ident = np.zeros((365, 4))
+    ident[1:11] = 1
+    np.testing.assert_array_equal(orl.runs_with_holes(ident != 0, 1, ident == 0, 1), ident)
+    runs = np.array([0, 1, 1, 1, 0, 0, 1, 1, 1, 0], dtype=bool)
+    np.testing.assert_array_equal(orl.keep_longest_run(runs), [0, 1, 1, 1, 0, 0, 0, 0, 0, 0])
+    np.testing.assert_array_equal(orl.run_bounds(runs), [[1, 6], [4, 9]])
+    ot = OTime.standard("2000-01-01", 360)
+    for date, end, exp in _SEASON_LENGTH:
+        t = np.zeros(360)
+        t[140:end] = 1
+        assert orl.season(t == 1, 1, date, ot)[2] == exp, (date, end)
+    for date, end, exp in _RUN_END_AFTER:
+        t = np.zeros(360)
+        t[140:end] = 1
+        np.testing.assert_array_equal(orl.run_end_after_date(t == 1, 1, date, ot), exp)
+    ot5 = OTime.standard("2000-01-01", 365)
+    for date, beg, exp in _FIRST_RUN_AFTER:
+        t = np.zeros(365)
+        if beg:
+            t[beg:] = 1
+        np.testing.assert_array_equal(orl.first_run_after_date(t == 1, 1, date, ot5), exp)
