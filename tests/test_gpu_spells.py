@@ -598,3 +598,21 @@ def test_more_run_length_reference_known_answers(dev):
         if beg:
             t[beg:] = 1
         np.testing.assert_array_equal(xrl.first_run_after_date(t == 1, 1, date, time=ta5, device=dev), [exp, exp])
+
+
+def test_season_and_find_events_reference_known_answers(dev):
+    """tests/test_run_length.py:675-730 through the HIP path (xh_season, xh_runs_with_holes + xh_run_events)."""
+    from tests.test_oracle_reference_answers import _FIND_EVENTS_COND
+
+    t = np.zeros((360, 2), np.float32)
+    t[140:150] = 1
+    out = xrl.season(t >= 1, 2, time=TimeAxis.daily("2000-01-01", 360), device=dev)
+    np.testing.assert_array_equal(out["start"], [140, 140])
+    np.testing.assert_array_equal(out["end"], [150, 150])
+    np.testing.assert_array_equal(out["length"], [10, 10])
+    ev = xrl.find_events(_FIND_EVENTS_COND, 1, device=dev)
+    exp = np.pad(np.array([[4, np.nan], [2, 4], [4, 1]]), [(0, 0), (0, 4)], constant_values=np.nan).T
+    np.testing.assert_equal(ev["event_length"], exp)
+    np.testing.assert_equal(ev["event_start"][0], [3, 2, 1])
+    ev = xrl.find_events(_FIND_EVENTS_COND, 2, None, 3, device=dev)
+    np.testing.assert_equal(ev["event_length"], np.pad(np.array([[4.0], [9.0], [7.0]]), [(0, 0), (0, 2)], constant_values=np.nan).T)

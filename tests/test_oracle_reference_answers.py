@@ -541,3 +541,26 @@ def test_more_run_length_known_answers():
         if beg:
             t[beg:] = 1
         np.testing.assert_array_equal(orl.first_run_after_date(t == 1, 1, date, ot5), exp)
+
+
+_FIND_EVENTS_COND = np.array([[0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0],   # normal
+                              [0, 0, 1, 1, 0, 0, 1, 1, 1, 1, 0],   # two events, one short, one long
+                              [0, 1, 1, 1, 1, 0, 0, 1, 0, 0, 0]]).T == 1   # (time, cell)
+
+
+def test_season_and_find_events_known_answers():
+    """tests/test_run_length.py:675-690 (rl.season: start 140, end 150, length 10) and :694-730 (find_events: event
+    lengths / starts for window 1 and for window 2 with window_stop 3) on the oracle."""
+    from oracle import run_length as orl
+    from oracle.timeutil import OTime
+
+    t = np.zeros(360)
+    t[140:150] = 1
+    beg, end, length = orl.season(t >= 1, 2, None, OTime.standard("2000-01-01", 360))
+    assert (beg, end, length) == (140, 150, 10)
+    ev = orl.find_events(_FIND_EVENTS_COND, 1)
+    exp = np.pad(np.array([[4, np.nan], [2, 4], [4, 1]]), [(0, 0), (0, 4)], constant_values=np.nan).T
+    np.testing.assert_equal(ev["event_length"], exp)
+    np.testing.assert_equal(ev["event_start"][0], [3, 2, 1])
+    ev = orl.find_events(_FIND_EVENTS_COND, 2, None, 3)
+    np.testing.assert_equal(ev["event_length"], np.pad(np.array([[4.0], [9.0], [7.0]]), [(0, 0), (0, 2)], constant_values=np.nan).T)
