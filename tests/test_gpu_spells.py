@@ -616,3 +616,29 @@ def test_season_and_find_events_reference_known_answers(dev):
     np.testing.assert_equal(ev["event_start"][0], [3, 2, 1])
     ev = xrl.find_events(_FIND_EVENTS_COND, 2, None, 3, device=dev)
     np.testing.assert_equal(ev["event_length"], np.pad(np.array([[4.0], [9.0], [7.0]]), [(0, 0), (0, 2)], constant_values=np.nan).T)
+
+
+def test_spell_mask_reference_known_answers(dev):
+    """tests/test_generic.py:702-766 through the HIP path (xh_spell_mask / xh_spell_mask_multi, per-site thresholds),
+    with the reference's argument errors."""
+    from tests.test_oracle_reference_answers import _SM_D1, _SM_D2, _SM_MULTI, _SM_SINGLE
+
+    for (w, red, op, thr, weights), exp in _SM_SINGLE:
+        got = xgen.spell_mask(_SM_D1[:, None], w, red, op, thr, weights=weights, device=dev)[:, 0]
+        np.testing.assert_array_equal(got, np.array(exp, bool), err_msg=f"{w} {red} {op}")
+    for (w, red, op, thr, weights, vr), exp in _SM_MULTI:
+        got = xgen.spell_mask([_SM_D1[:, None], _SM_D2[:, None]], w, red, op, thr, weights=weights, var_reducer=vr, device=dev)[:, 0]
+        np.testing.assert_array_equal(got, np.array(exp, bool), err_msg=f"{w} {red} {op} {vr}")
+    tn = np.stack([np.arange(365) + 273.15] * 2, axis=1).astype(np.float32)
+    thr = (np.array([330.0, 360.0]) + 273.15).astype(np.float32)
+    out = xgen.spell_length_statistics(tn, thr, 1, "min", ">", "sum", TimeAxis.daily("2001-01-01", 365), "YS", device=dev)
+    np.testing.assert_allclose(out, [[34, 4]])
+    d = _SM_D1[:, None]
+    with pytest.raises(ValueError, match="must be a sequence of the same length"):
+        xgen.spell_mask([d, d], 3, "min", "<=", 2, device=dev)
+    with pytest.raises(ValueError, match="must be a sequence of the same length"):
+        xgen.spell_mask([d, d], 3, "min", "<=", [2], device=dev)
+    with pytest.raises(ValueError, match="is only supported if 'win_reducer' is 'mean'"):
+        xgen.spell_mask(d, 3, "min", "<=", 2, weights=[1, 2, 3], device=dev)
+    with pytest.raises(ValueError, match="Weights have a different length"):
+        xgen.spell_mask(d, 3, "mean", "<=", 2, weights=[1, 2], device=dev)

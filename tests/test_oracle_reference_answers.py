@@ -564,3 +564,29 @@ def test_season_and_find_events_known_answers():
     np.testing.assert_equal(ev["event_start"][0], [3, 2, 1])
     ev = orl.find_events(_FIND_EVENTS_COND, 2, None, 3)
     np.testing.assert_equal(ev["event_length"], np.pad(np.array([[4.0], [9.0], [7.0]]), [(0, 0), (0, 2)], constant_values=np.nan).T)
+
+
+_SM_D1 = np.array([0, 1, 2, 3, 2, 1, 0, 0], dtype=np.float32)
+_SM_D2 = np.array([1, 2, 3, 2, 1, 0, 0, 0], dtype=np.float32)
+_SM_SINGLE = [((3, "min", ">=", 2, None), [0, 0, 1, 1, 1, 0, 0, 0]), ((3, "max", ">=", 2, None), [1, 1, 1, 1, 1, 1, 1, 0]),
+              ((2, "mean", ">=", 2, None), [0, 0, 1, 1, 1, 0, 0, 0]), ((3, "mean", ">", 2, [0.2, 0.4, 0.4]), [0, 1, 1, 1, 1, 0, 0, 0])]
+_SM_MULTI = [((3, "min", ">=", [2, 2], None, "all"), [0] * 8), ((3, "min", ">=", [2, 2], None, "any"), [0, 1, 1, 1, 1, 0, 0, 0]),
+             ((2, "mean", ">=", [2, 2], None, "all"), [0, 0, 1, 1, 0, 0, 0, 0]),
+             ((3, "mean", ">", [2, 1.5], [0.2, 0.4, 0.4], "all"), [0, 1, 1, 1, 1, 0, 0, 0])]
+
+
+def test_spell_mask_known_answers():
+    """tests/test_generic.py:702-732 (TestSpellMask, one and two variables, weights, var_reducer) and :754-766
+    (spell_length_statistics with one threshold per site: [34, 4]) on the oracle."""
+    from oracle import generic as ogen
+    from oracle.timeutil import OTime
+
+    for (w, red, op, thr, weights), exp in _SM_SINGLE:
+        np.testing.assert_array_equal(ogen.spell_mask(_SM_D1, w, red, op, np.float32(thr), weights=weights), np.array(exp, bool))
+    for (w, red, op, thr, weights, vr), exp in _SM_MULTI:
+        got = ogen.spell_mask([_SM_D1, _SM_D2], w, red, op, [np.float32(t) for t in thr], weights=weights, var_reducer=vr)
+        np.testing.assert_array_equal(got, np.array(exp, bool))
+    tn = np.stack([np.arange(365) + 273.15] * 2, axis=1).astype(np.float32)
+    thr = (np.array([330.0, 360.0]) + 273.15).astype(np.float32)
+    out = ogen.spell_length_statistics(tn, thr, 1, "min", ">", "sum", OTime.standard("2001-01-01", 365), "YS")
+    np.testing.assert_allclose(out, [[34, 4]])
