@@ -900,3 +900,40 @@ def test_degree_days_reference_known_answers(dev):
     out = xi.heating_degree_days((h + K2C).astype(np.float32)[:, None], 17 + K2C, t, **kw)
     np.testing.assert_allclose(out[0, 0], 6, rtol=1e-4)
     assert (out[1:] == 0).all()
+
+
+def test_generic_reference_known_answers(dev):
+    """tests/test_generic.py:316-400, 769-797 through the HIP path: cumulative_difference ([0, 5, 10, 0, 0] / [20, 0, 0, 7,
+    0] per daily period), first_day_threshold_reached for every operator, bivariate_spell_length_statistics (one spell,
+    sum == max)."""
+    K2C = 273.15
+    tas = (np.array([-10, 15, 20, 3, 10]) + K2C).astype(np.float32)[:, None]
+    t5 = TimeAxis.daily("2000-07-01", 5)
+    for op, exp in ((">", [0, 5, 10, 0, 0]), (">=", [0, 5, 10, 0, 0]), ("<", [20, 0, 0, 7, 0])):
+        # the reference calls it without freq (whole series reduced per time step group "D"): one value per day here
+        got = [xgen.cumulative_difference(tas[i:i + 1], 10 + K2C, op, TimeAxis.daily("2000-07-01", 1), "YS", device=dev)[0, 0]
+               for i in range(5)]
+        np.testing.assert_allclose(got, exp, atol=1e-4)
+    assert np.isclose(xgen.cumulative_difference(tas, 10 + K2C, ">", t5, "YS", device=dev)[0, 0], 15, atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        xgen.cumulative_difference(tas, 10 + K2C, "!=", t5, "YS", device=dev)
+    a = np.zeros(365, np.float32)
+    a[:8] = (np.arange(8) / 1000).astype(np.float32)
+    ta = TimeAxis.daily("2000-01-01", 365)
+    for op, exp in ((">", 6), (">=", 5), ("==", 5), ("!=", 1)):
+        got = xgen.first_day_threshold_reached(a[:, None], threshold=0.004, op=op, after_date="01-01", time=ta, window=1, freq="YS", device=dev)
+        assert got[0, 0] == exp, (op, got)
+    b = np.zeros(365, np.float32)
+    b[:8] = np.flip(np.arange(8) / 1000).astype(np.float32)
+    for op, exp in (("lt", 5), ("le", 4), ("eq", 4), ("ne", 1)):
+        got = xgen.first_day_threshold_reached(b[:, None], threshold=0.004, op=op, after_date="01-01", time=ta, window=1, freq="YS", device=dev)
+        assert got[0, 0] == exp, (op, got)
+    with pytest.raises(ValueError):
+        xgen.first_day_threshold_reached(b[:, None], threshold=0.004, op=">", after_date="01-01", time=ta, window=1, freq="YS",
+                                         constrain=("<", "<="), device=dev)
+    tn = np.full((365, 1), 270.0, np.float32)
+    ta1 = TimeAxis.daily("2001-01-01", 365)
+    outc, outs, outm = xgen.bivariate_spell_length_statistics(tn, 0 + K2C, tn.copy(), 1 + K2C, 5, "min", "<", ["count", "sum", "max"],
+                                                              ta1, "YS", device=dev)
+    np.testing.assert_array_equal(outs, outm)
+    np.testing.assert_allclose(outc, 1)
