@@ -642,3 +642,34 @@ def test_spell_mask_reference_known_answers(dev):
         xgen.spell_mask(d, 3, "min", "<=", 2, weights=[1, 2, 3], device=dev)
     with pytest.raises(ValueError, match="Weights have a different length"):
         xgen.spell_mask(d, 3, "mean", "<=", 2, weights=[1, 2], device=dev)
+
+
+def test_thresholded_events_reference_known_answers(dev):
+    """tests/test_generic.py:800-905 (TestThresholdedEvents: simple, different stop window, window_stop 3, freq "MS")
+    through the HIP path, and the same numbers from the oracle's find_events on the compare masks."""
+    arr = np.array([0, 0, 0, 1, 2, 3, 0, 3, 3, 10, 0, 0, 0, 0, 0, 1, 2, 2, 2, 0, 0, 0, 0, 0, 0, 1, 3, 3, 2, 0, 0, 0, 2, 0, 0, 0, 0],
+                   dtype=np.float32)[:, None]
+
+    def check(out, length, eff, total, start):
+        keep = ~np.isnan(out["event_length"][..., 0])
+        np.testing.assert_array_equal(out["event_length"][..., 0][keep], length)
+        np.testing.assert_array_equal(out["event_effective_length"][..., 0][keep], eff)
+        np.testing.assert_array_equal(out["event_sum"][..., 0][keep], total)
+        np.testing.assert_array_equal(out["event_start"][..., 0][keep], start)
+
+    out = xgen.thresholded_events(arr, 1.0, ">=", 3, device=dev)
+    assert out["event_length"].shape[0] == np.ceil(arr.shape[0] / (3 + 1))
+    check(out, [3, 3, 4, 4], [3, 3, 4, 4], [6, 16, 7, 9], [3, 7, 15, 25])           # 2000-01-04 / -08 / -16 / -26
+    check(xgen.thresholded_events(arr, 2.0, ">=", 3, window_stop=4, device=dev), [3, 3, 7], [3, 3, 4], [16, 6, 10], [7, 16, 26])
+    check(xgen.thresholded_events(arr, 1.0, ">=", 3, window_stop=3, device=dev), [7, 4, 4], [6, 4, 4], [22, 7, 9], [3, 15, 25])
+    ref = orl.find_events(arr >= 1, 3, arr < 1, 3, data=arr)
+    check(ref, [7, 4, 4], [6, 4, 4], [22, 7, 9], [3, 15, 25])
+    jan = [0, 0, 0, 1, 2, 3, 0, 3, 3, 10, 0, 0, 0, 0, 0, 0, 2, 2, 2, 2, 2, 2, 0, 0, 0, 0, 0, 3, 2, 3, 2]
+    fev = [2, 2, 1, 0, 0, 0, 3, 3, 4, 5, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+    pr = np.array(jan + fev, dtype=np.float32)[:, None]
+    out = xgen.thresholded_events(pr, 1.0, ">=", 3, window_stop=3, freq="MS", time=TimeAxis.daily("2000-01-01", 60), device=dev)
+    assert out["event_length"].shape[:2] == (2, 6)
+    np.testing.assert_array_equal(out["event_length"][:, :3, 0], [[7, 6, 4], [3, 5, np.nan]])
+    np.testing.assert_array_equal(out["event_effective_length"][:, :3, 0], [[6, 6, 4], [3, 5, np.nan]])
+    np.testing.assert_array_equal(out["event_sum"][:, :3, 0], [[22, 12, 10], [5, 17, np.nan]])
+    np.testing.assert_array_equal(out["event_start"][:, :3, 0], [[3, 16, 27], [0, 6, np.nan]])  # days into the month
