@@ -937,3 +937,29 @@ def test_generic_reference_known_answers(dev):
                                                               ta1, "YS", device=dev)
     np.testing.assert_array_equal(outs, outm)
     np.testing.assert_allclose(outc, 1)
+
+
+def test_select_resample_op_reference_known_answers(dev):
+    """tests/test_generic.py:16-83 through the HIP path: select_resample_op with month / season indexers (31; min of DJF
+    0 and 366; 31 + 29 with YS-DEC), select_rolling_resample_op (trailing 14-day mean -> yearly max; rolling max + DJF
+    indexer -> 14, 367, 732; centred 3-day integral per month), threshold_count [50, 0], domain_count [10, 0]."""
+    q = np.arange(1000, dtype=np.float32)[:, None]
+    ta = TimeAxis.daily("2000-01-01", 1000)
+    np.testing.assert_array_equal(xgen.select_resample_op(q, "count", ta, "YS", device=dev, month=3)[:, 0], 31)
+    o = xgen.select_resample_op(q, "min", ta, "YS", device=dev, season="DJF")
+    assert o[0, 0] == 0 and o[1, 0] == 366
+    assert xgen.select_resample_op(q, "count", ta, "YS-DEC", device=dev, season="DJF")[0, 0] == 31 + 29
+    n = 366 + 365 + 365
+    q3 = np.arange(1, n + 1, dtype=np.float32)[:, None]
+    ta3 = TimeAxis.daily("2000-01-01", n)
+    o = xgen.select_rolling_resample_op(q3, "max", 14, ta3, False, "mean", "YS", device=dev)
+    np.testing.assert_allclose(o[:, 0], [np.mean(np.arange(353, 367)), np.mean(np.arange(353 + 365, 367 + 365)),
+                                         np.mean(np.arange(353 + 730, 367 + 730))], rtol=1e-6)
+    o = xgen.select_rolling_resample_op(q3, "min", 14, ta3, False, "max", "YS", device=dev, season="DJF")
+    np.testing.assert_array_equal(o[:, 0], [14, 367, 367 + 365])
+    o = xgen.select_rolling_resample_op(q3, "max", 3, ta3, True, "sum", "MS", device=dev)   # "integral" = sum x 86400 s
+    np.testing.assert_array_equal(o[:2, 0], [30 + 31 + 32, 3 * 29 + 30 + 31 + 32])
+    ts = np.arange(365, dtype=np.float32)[:, None]
+    t = TimeAxis.daily("2000-07-01", 365)
+    np.testing.assert_array_equal(xgen.threshold_count(ts, "<", 50, t, "YS", device=dev)[:, 0], [50, 0])
+    np.testing.assert_array_equal(xgen.domain_count(ts, 10, 20, t, "YS", device=dev)[:, 0], [10, 0])
