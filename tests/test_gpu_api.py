@@ -963,3 +963,38 @@ def test_select_resample_op_reference_known_answers(dev):
     t = TimeAxis.daily("2000-07-01", 365)
     np.testing.assert_array_equal(xgen.threshold_count(ts, "<", 50, t, "YS", device=dev)[:, 0], [50, 0])
     np.testing.assert_array_equal(xgen.domain_count(ts, 10, 20, t, "YS", device=dev)[:, 0], [10, 0])
+
+
+def test_counting_indices_reference_known_answers(dev):
+    """tests/test_generic.py:401-511 through the HIP path: get_daily_events, count_level_crossings for the four operator
+    pairs (and its forbidden pairs), count_occurrences with `constrain`, first / last occurrence (NaN without one)."""
+    K2C = 273.15
+    out = xgen.get_daily_events(np.array([-10, 15, 20, np.nan, 10], np.float32)[:, None], 10.0, ">=", device=dev)[:, 0]
+    np.testing.assert_array_equal(out, [0, 1, 1, np.nan, 1])
+    tn = (np.array([-1, -3, 0, 5, 9, 1, 3]) + K2C).astype(np.float32)[:, None]
+    tx = (np.array([5, 7, 3, 6, 13, 5, 4]) + K2C).astype(np.float32)[:, None]
+    t7 = TimeAxis.daily("2000-07-01", 7)
+    for op_high, op_low, exp in ((">", "<", 1), (">", "<=", 2), (">=", "<", 3), (">=", "<=", 4)):
+        got = xgen.count_level_crossings(tn, tx, 5 + K2C, t7, "YS", op_low=op_low, op_high=op_high, device=dev)
+        assert got[0, 0] == exp, (op_high, op_low, got)
+    for op_high, op_low in (("<=", "<="), (">=", ">="), ("<", ">"), ("==", "!=")):
+        with pytest.raises(ValueError):
+            xgen.count_level_crossings(tn, tx, 5 + K2C, t7, "YS", op_low=op_low, op_high=op_high, device=dev)
+    tas = (np.arange(10) + K2C).astype(np.float32)[:, None]
+    t10 = TimeAxis.daily("2000-07-01", 10)
+    for op, constrain, exp, fail in (("<", ("!=", "<"), 4, False), (">", (">", "<="), 5, False), (">=", (">=", "=="), 6, False),
+                                     ("==", ("==", "!="), 1, False), ("==", (">", ">="), 1, True), ("!=", ("!=", ">"), 9, False),
+                                     ("!=", (">", "=="), 9, True), ("%", ("%", "$", "@"), 0, True)):
+        if fail:
+            with pytest.raises(ValueError):
+                xgen.count_occurrences(tas, 4 + K2C, op, t10, "YS", constrain=constrain, device=dev)
+        else:
+            assert xgen.count_occurrences(tas, 4 + K2C, op, t10, "YS", constrain=constrain, device=dev)[0, 0] == exp
+    tas = (np.array([15, 12, 11, 12, 14, 13, 18, 11, 13]) + K2C).astype(np.float32)[:, None]
+    t9 = TimeAxis.daily("2000-01-01", 9)
+    for f, cases in ((xgen.first_occurrence, (("<", None, np.nan), ("<=", None, 3), ("!=", ("!=",), 1), ("==", ("==", "!="), 3))),
+                     (xgen.last_occurrence, (("<", None, np.nan), ("<=", None, 8), ("!=", ("!=",), 9), ("==", ("==", "!="), 8)))):
+        for op, constrain, exp in cases:
+            np.testing.assert_array_equal(f(tas, 11 + K2C, op, t9, "YS", constrain, device=dev)[0, 0], exp)
+        with pytest.raises(ValueError):
+            f(tas, 11 + K2C, "==", t9, "YS", (">=", ">", "<"), device=dev)
