@@ -998,3 +998,33 @@ def test_counting_indices_reference_known_answers(dev):
             np.testing.assert_array_equal(f(tas, 11 + K2C, op, t9, "YS", constrain, device=dev)[0, 0], exp)
         with pytest.raises(ValueError):
             f(tas, 11 + K2C, "==", t9, "YS", (">=", ">", "<"), device=dev)
+
+
+def test_day_count_indices_reference_known_answers(dev):
+    """tests/test_indices.py:2145-2200 (tn / tg days above / below, operators, forbidden operators) and :4211-4224
+    (wetdays [5, 0, 0, 3, ...] with >= and [4, 0, 0, 2, ...] with >) through the HIP path."""
+    K2C = 273.15
+    kw = dict(device=dev, mask_missing=False)
+    t = TimeAxis.daily("2000-07-01", 365)
+    a = np.zeros(365)
+    a[:6] += [27, 28, 29, 30, 31, 32]
+    mn = (a + K2C).astype(np.float32)[:, None]
+    out = xi.tn_days_above(mn, 30 + K2C, t, **kw)
+    assert out[0, 0] == 2 and (out[1:] == 0).all()
+    assert xi.tn_days_above(mn, 30 + K2C, t, op=">=", **kw)[0, 0] == 3
+    with pytest.raises(ValueError):
+        xi.tn_days_above(mn, 30 + K2C, t, op="<=", **kw)
+    b = np.zeros(365)
+    b[:6] -= [27, 28, 29, 30, 31, 32]
+    mb = (b + K2C).astype(np.float32)[:, None]
+    assert xi.tn_days_below(mb, -10 + K2C, t, **kw)[0, 0] == 6
+    assert xi.tn_days_below(mb, -30 + K2C, t, **kw)[0, 0] == 2
+    assert xi.tn_days_below(mb, -31 + K2C, t, op="<=", **kw)[0, 0] == 2
+    with pytest.raises(ValueError):
+        xi.tn_days_below(mb, 30 + K2C, t, op=">=", **kw)
+    p = np.zeros(365)
+    p[:7] += [4, 5.5, 6, 6, 2, 7, 5]
+    p[100:106] += [1, 6, 7, 5, 2, 1]
+    pr = p.astype(np.float32)[:, None]
+    np.testing.assert_array_equal(xi.wetdays(pr, 5.0, t, "ME", **kw)[:, 0], [5, 0, 0, 3] + [0] * 8)
+    np.testing.assert_array_equal(xi.wetdays(pr, 5.0, t, "ME", ">", **kw)[:, 0], [4, 0, 0, 2] + [0] * 8)
