@@ -1028,3 +1028,22 @@ def test_day_count_indices_reference_known_answers(dev):
     pr = p.astype(np.float32)[:, None]
     np.testing.assert_array_equal(xi.wetdays(pr, 5.0, t, "ME", **kw)[:, 0], [5, 0, 0, 3] + [0] * 8)
     np.testing.assert_array_equal(xi.wetdays(pr, 5.0, t, "ME", ">", **kw)[:, 0], [4, 0, 0, 2] + [0] * 8)
+
+
+def test_consecutive_day_indices_reference_known_answers(dev):
+    """tests/test_indices.py:186-215 (maximum_consecutive_frost_days: 1 / 0 / all year) and :2384-2391
+    (maximum_consecutive_tx_days: 10 in the first month, 0 after) through the HIP path."""
+    K2C = 273.15
+    kw = dict(device=dev, mask_missing=False)
+    t5 = TimeAxis.daily("2000-07-01", 5)
+    a = (np.array([3, 4, 5, -1, 3]) + K2C).astype(np.float32)[:, None]
+    assert xi.maximum_consecutive_frost_days(a, 0 + K2C, t5, "YS-JUL", **kw)[0, 0] == 1
+    a = (np.array([3, 4, 5, 1, 3]) + K2C).astype(np.float32)[:, None]
+    assert xi.maximum_consecutive_frost_days(a, 0 + K2C, t5, "YS-JUL", **kw)[0, 0] == 0
+    a = (np.zeros(365) - 10 + K2C).astype(np.float32)[:, None]
+    out = xi.maximum_consecutive_frost_days(a, 0 + K2C, TimeAxis.daily("2000-07-01", 365), "YS-JUL", **kw)
+    assert out[0, 0] == 365
+    b = np.zeros(365) + 273.15
+    b[5:15] += 30
+    out = xi.maximum_consecutive_tx_days(b.astype(np.float32)[:, None], 25 + K2C, TimeAxis.daily("2010-01-01", 365), "ME", **kw)
+    assert out[0, 0] == 10 and (out[1:] == 0).all()
