@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — the reference's headline workload on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu] [--no-extra]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu] [--no-extra] [--no-full]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]): tx90p = percentile_doy(window 5, per 90) + threshold_count(">", per-doy fp64
@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--grid", type=str, default="365x1440x720")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-full", action="store_true", help="skip the 3650-step / 30-year extras (they allocate up to 182 GB)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,7 +237,7 @@ def main():
 
     extra = {}
     if not args.no_extra and rank == 0 and world == 1:
-        extra = bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, len(doys))
+        extra = bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, len(doys), full_configs=not args.no_full)
 
     cpu = None
     if not args.no_cpu and rank == 0 and world == 1:
@@ -269,7 +270,7 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D):
+def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D, full_configs=True):
     """The other two north-star workloads on the same 365 x 1440 x 720 grid (HIP-event times, one GPU)."""
     out = {}
     E = float(T) * C
@@ -316,6 +317,81 @@ def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D):
     out["eqm_train_adjust_365"] = {"ms": ms_tr + ms_ad, "GB/s": (b_tr + b_ad) / (ms_tr + ms_ad) / 1e6,
                                    "frac": (b_tr + b_ad) / (ms_tr + ms_ad) / 1e6 / HBM_PEAK_GBS,
                                    "cell-timesteps/s": E / ((ms_tr + ms_ad) * 1e-3)}
+    for a in (ref, hist, sim, scen, af, hq):
+        a.free()
+    if full_configs:
+        out.update(bench_full_configs(dev, K, C))
+    return out
+
+
+def bench_full_configs(dev, K, C):
+    """BASELINE configs[2] (cdd on 3650 steps), the 30-year tx90p of configs[4] and configs[3] (EQM on 30 years) at
+    their own size on this GPU's grid (same byte formulas as SURVEY 8d / tools/bench_configs.py), inputs generated on the
+    device.  Up to four 45.4 GB arrays are resident at once."""
+    from xclim_amd.timeaxis import TimeAxis
+
+    out = {}
+    # ---- configs[2]: maximum_consecutive_dry_days, 3650 steps
+    T = 3650
+    ta = TimeAxis.daily("2001-01-01", T, "noleap")
+    seg, _ = ta.segments("YS")
+    P = len(seg) - 1
+    pr = K.fill_synthetic(dev, T, C, 1, 3, np.zeros(T, np.float32), 40.0 / 86400.0, 0.3)
+    o, v = dev.empty((P, C), np.float32), dev.empty((P, C), np.int32)
+    ms = event_time(dev, lambda: K.run_stats(dev, pr, "max", 1, seg, cut=True, fused_op="<", thresh=1.0 / 86400.0,
+                                             out=(o, v)), 5)
+    E = float(T) * C
+    b = 4 * E + 8 * P * C
+    out["cdd_3650"] = {"ms": ms, "GB/s": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS, "cell-timesteps/s": E / ms * 1e3,
+                       "algorithmic_bytes": b}
+    for a in (pr, o, v):
+        a.free()
+    # ---- tx90p on 30 years (150 samples per day of year)
+    T = 10950
+    ta = TimeAxis.daily("1981-01-01", T, "noleap")
+    tb, years, doys = ta.doy_table()
+    seg, _ = ta.segments("YS")
+    P, D = len(seg) - 1, len(doys)
+    base = seasonal_base(T)
+    tas = K.fill_synthetic(dev, T, C, 0, 2, base, 3.0)
+    per = dev.empty((1, D, C), np.float64)
+    cnt, val = dev.empty((P, C), np.int32), dev.empty((P, C), np.int32)
+    tidx = dev.to_device(np.searchsorted(doys, ta.doy).astype(np.int32))
+    ms_p = event_time(dev, lambda: K.percentile_doy(dev, tas, tb, 5, [90.0], out=per), 2)
+    ms_c = event_time(dev, lambda: K.threshold_count(dev, tas, ">", seg, doy_table=per.reshape(D, C), tidx=tidx,
+                                                     out=(cnt, val)), 3)
+    E = float(T) * C
+    bp, bc = 4 * E + 8 * D * C, 4 * E + 8 * D * C + 8 * P * C
+    out["tx90p_30yr"] = {"percentile_doy_ms": ms_p, "percentile_doy_GB/s": bp / ms_p / 1e6, "threshold_count_ms": ms_c,
+                         "threshold_count_GB/s": bc / ms_c / 1e6, "ms": ms_p + ms_c, "GB/s": (bp + bc) / (ms_p + ms_c) / 1e6,
+                         "frac": (bp + bc) / (ms_p + ms_c) / 1e6 / HBM_PEAK_GBS, "cell-timesteps/s": E / (ms_p + ms_c) * 1e3,
+                         "algorithmic_bytes": bp + bc}
+    period = (np.searchsorted(seg, tb, side="right") - 1).astype(np.int32)
+    period[tb < 0] = -1
+    fused = K.percentile_doy_count(dev, tas, tb, 5, 90.0, ">", period, P, out=(cnt, val))
+    if fused is not None:
+        msf = event_time(dev, lambda: K.percentile_doy_count(dev, tas, tb, 5, 90.0, ">", period, P, out=(cnt, val)), 2)
+        bf = 4 * E + 8 * P * C
+        out["tx90p_30yr_fused"] = {"ms": msf, "GB/s": bf / msf / 1e6, "frac": bf / msf / 1e6 / HBM_PEAK_GBS,
+                                   "cell-timesteps/s": E / msf * 1e3, "algorithmic_bytes": bf}
+    for a in (per, cnt, val):
+        a.free()
+    # ---- configs[3]: EQM train + adjust on 30 years
+    ref = tas
+    hist = K.fill_synthetic(dev, T, C, 0, 5, base + np.float32(1.5), 3.3)
+    q = (np.arange(20) + 0.5) / 20
+    af, hq = dev.empty((20, C), np.float32), dev.empty((20, C), np.float32)
+    ms_tr = event_time(dev, lambda: K.eqm_train(dev, ref, hist, q, "+", out=(af, hq)), 2)
+    ref.free()
+    sim = K.fill_synthetic(dev, T, C, 0, 6, base + np.float32(3.5), 3.3)
+    scen = dev.empty((T, C), np.float32)
+    ms_ad = event_time(dev, lambda: K.eqm_adjust(dev, sim, af, hq, "+", "nearest", "constant", out=scen), 3)
+    out["eqm_c4"] = {"train_ms": ms_tr, "train_GB/s": 8 * E / ms_tr / 1e6, "train_frac": 8 * E / ms_tr / 1e6 / HBM_PEAK_GBS,
+                     "adjust_ms": ms_ad, "adjust_GB/s": 8 * E / ms_ad / 1e6, "ms": ms_tr + ms_ad,
+                     "GB/s": 16 * E / (ms_tr + ms_ad) / 1e6, "frac": 16 * E / (ms_tr + ms_ad) / 1e6 / HBM_PEAK_GBS,
+                     "cell-timesteps/s": E / (ms_tr + ms_ad) * 1e3, "algorithmic_bytes": 16 * E}
+    for a in (hist, sim, scen, af, hq):
+        a.free()
     return out
 
 

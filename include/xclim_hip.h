@@ -325,10 +325,12 @@ int xh_percentile_doy_mapped(xh_ctx* ctx, const float* x, int64_t T, int64_t C, 
                              double* out);
 
 /* Fused percentile_doy + threshold_count (the tx90p family, indices/_multivariate.py:1534-1650, when the percentile
- * base period IS the analysed series and spans one contiguous year): count_out[p, c] = #{d in period p :
- * x[d, c] op percentile_doy(x)[d, c]} (fp64 compare), valid_out[p, c] = non-NaN days (may be NULL), doy_period[ndoy] =
- * period of every doy row.  The (D, C) float64 table is never materialised.  Returns XH_ERR_NOTIMPL for shapes the
- * fused kernel does not cover (several years, windows other than 3 / 5 / 7, gaps): use the two-step chain there. */
+ * base period IS the analysed series): count_out[p, c] = #{t in period p : x[t, c] op percentile_doy(x)[doy(t), c]}
+ * (the fp64 compare of the reference), valid_out[p, c] = non-NaN days (may be NULL), doy_period[nyears * ndoy] = period
+ * of every (year, doy) day (< 0 where tbase is -1).  The (D, C) float64 table is never materialised.  Covered: one
+ * contiguous year (sliding-window kernel), and multi-year base periods whose doys are all regular (no calendar gaps) with
+ * a percentile that selects within the 16 largest / smallest samples (register top-16 kernel; ops > >= < <=).  Returns
+ * XH_ERR_NOTIMPL otherwise (windows other than 3 / 5 / 7, gaps, central percentiles): use the two-step chain there. */
 int xh_percentile_doy_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* tbase,
                             int nyears, int ndoy, int window, double per, double alpha, double beta, int op,
                             const int32_t* doy_period, int P, int32_t* count_out, int32_t* valid_out);

@@ -131,3 +131,103 @@ def test_eqm_full_size(dev, rng):
     d = scen_l.get()
     d -= sim.get()
     assert (d.min(axis=0) >= af_h.min(axis=0) - 1e-3).all() and (d.max(axis=0) <= af_h.max(axis=0) + 1e-3).all()
+
+
+# ---- the 30-year configurations at their own size (BASELINE configs 4 and 5) ------------------------------------------
+def _column_block(dev, arr, T, ncols_total, c0, w):
+    """Rows 0..T-1 of cells c0 .. c0+w-1 of a device (T, C) float32 array -> host (T, w), one strided 2-D copy."""
+    host = np.empty((T, w), np.float32)
+    dev.copy2d(host.ctypes.data, w * 4, arr.ptr + int(c0) * 4, ncols_total * 4, w * 4, T, "d2h")
+    return host
+
+
+def _tx90p_30yr(dev, rng, ncells, cell0, nsample):
+    """tx90p on 30 noleap years: percentile_doy (150 samples per doy: the register top-16 kernel + the per-doy count over
+    30 periods), sampled cells recomputed by the oracle, bit-exact counts, non-trivial exceedances."""
+    T = 10950
+    ta, ot = TimeAxis.daily("1981-01-01", T, "noleap"), OTime.noleap(1981, T)
+    tb, years, doys = ta.doy_table()
+    base = synth.seasonal_base(T)
+    x = K.fill_synthetic(dev, T, ncells, 0, 2, base, 3.0, nan_per_million=50, cell0=cell0)
+    seg, _ = ta.segments("YS")
+    P = len(seg) - 1
+    tidx = np.searchsorted(doys, ta.doy).astype(np.int32)
+    p = K.percentile_doy(dev, x, tb, 5, [90.0])
+    table = p.reshape(len(doys), ncells)
+    cnt, val = K.threshold_count(dev, x, ">", seg, doy_table=table, tidx=tidx)
+    cnt_h, val_h = cnt.get(), val.get()
+    assert cnt_h.shape == (P, ncells) and P == 30
+    # ~10 % of the days exceed the 90th percentile of their own climatology
+    assert 30.0 < cnt_h.mean() < 43.0 and cnt_h.min() >= 0 and cnt_h.max() < 120
+    assert (val_h <= 365).all() and val_h.mean() > 364.9
+    # fused kernel (the table is never written) == two-step chain, every cell, every year
+    period = (np.searchsorted(seg, tb, side="right") - 1).astype(np.int32)
+    period[tb < 0] = -1
+    fused = K.percentile_doy_count(dev, x, tb, 5, 90.0, ">", period, P)
+    assert fused is not None
+    np.testing.assert_array_equal(fused[0].get(), cnt_h)
+    np.testing.assert_array_equal(fused[1].get(), val_h)
+    del fused
+    cells = np.sort(rng.choice(ncells, size=nsample, replace=False))
+    xs = synth.fill_synthetic(T, cells + cell0, 0, 2, base, 3.0, nan_per_million=50)
+    exp_p, d2 = ocal.percentile_doy(xs, ot, 5, 90.0)
+    exp_c = oidx.tx90p(xs, exp_p[..., 0], d2, ot, "YS")
+    np.testing.assert_array_equal(cnt_h[:, cells], exp_c)
+    assert exp_c.sum() > 0
+    # the percentile table itself on the first sampled cells (fp64, same operation order as utl:486-488)
+    got = np.stack([dev.wrap(table.ptr + int(c) * 8, (1,), np.float64).get()[0] for c in cells[:16]])
+    np.testing.assert_allclose(got, exp_p[0, :16, 0], rtol=1e-12)
+    return x, cnt_h
+
+
+def test_tx90p_30yr_full_grid(dev, rng):
+    """BASELINE configs[3]/[4] tx90p half at its own size: 10950 x 1440 x 720 fp32 (45.4 GB), every workgroup of the
+    multi-year kernels (k_pdoy_top16 at grid width, per-doy threshold_count over 30 periods)."""
+    x, _ = _tx90p_30yr(dev, rng, C, 0, 512)
+    x.free()
+
+
+def _eqm_30yr(dev, rng, ncells, cell0, nsample):
+    T = 10950
+    base = synth.seasonal_base(T)
+    q = (np.arange(20) + 0.5) / 20
+    ref = K.fill_synthetic(dev, T, ncells, 0, 4, base, 3.0, cell0=cell0)
+    hist = K.fill_synthetic(dev, T, ncells, 0, 5, base + np.float32(1.5), 3.3, cell0=cell0)
+    af, hq = K.eqm_train(dev, ref, hist, q, "+")
+    ref.free()
+    hq_h, af_h = hq.get(), af.get()
+    assert np.isfinite(hq_h).all() and (np.diff(hq_h, axis=0) >= 0).all()
+    cells = np.sort(rng.choice(ncells, size=nsample, replace=False))
+    refs = synth.fill_synthetic(T, cells + cell0, 0, 4, base, 3.0)
+    hists = synth.fill_synthetic(T, cells + cell0, 0, 5, base + np.float32(1.5), 3.3)
+    oaf, ohq = osdba.eqm_train(refs, hists, q, "+")
+    np.testing.assert_allclose(hq_h[:, cells], ohq, rtol=1e-6)
+    np.testing.assert_allclose(af_h[:, cells], oaf, rtol=1e-6, atol=1e-5)
+    hist.free()
+    sim = K.fill_synthetic(dev, T, ncells, 0, 6, base + np.float32(3.5), 3.3, cell0=cell0)
+    scen = K.eqm_adjust(dev, sim, af, hq, "+", "nearest", "constant")
+    # 64 adjacent FULL columns of scen (two places of the grid) against the oracle fed with the device's own nodes
+    for c0 in (int(cells[nsample // 3]) // 64 * 64, max(ncells - 64, 0)):
+        w = min(64, ncells - c0)
+        got = _column_block(dev, scen, T, ncells, c0, w)
+        sims = synth.fill_synthetic(T, np.arange(c0, c0 + w) + cell0, 0, 6, base + np.float32(3.5), 3.3)
+        exp = osdba.eqm_adjust(sims, af_h[:, c0:c0 + w], hq_h[:, c0:c0 + w], "+", "nearest", "constant")
+        np.testing.assert_allclose(got, exp, rtol=1e-6)
+    sim.free()
+    scen.free()
+
+
+def test_eqm_30yr_full_grid(dev, rng):
+    """BASELINE configs[3] at its own size: EQM train + adjust on 10950 x 1440 x 720 (ref, hist, sim, scen: 45.4 GB each;
+    at most three of them are resident at once)."""
+    _eqm_30yr(dev, rng, C, 0, 512)
+
+
+def test_config5_slab(dev, rng):
+    """BASELINE configs[4], the slab ONE of the 8 GPUs owns: 10950 x 360 x 1440 cells of the 2880 x 1440 grid (rank 5's
+    cell range of the global counter-based field), tx90p and EQM, sampled cells against the oracle."""
+    ncells = 360 * 1440
+    cell0 = 5 * ncells
+    x, _ = _tx90p_30yr(dev, rng, ncells, cell0, 256)
+    x.free()
+    _eqm_30yr(dev, rng, ncells, cell0, 256)

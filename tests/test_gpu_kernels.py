@@ -394,6 +394,84 @@ def test_quantile_series_hard_distributions(dev, rng, T, kind):
     np.testing.assert_allclose(out2, exp, rtol=RTOL, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("per,op", [(90.0, ">"), (95.0, ">="), (10.0, "<"), (5.0, "<=")])
+@pytest.mark.parametrize("freq", ["YS", "MS", "QS-DEC"])
+def test_percentile_doy_count_multi_year(dev, rng, per, op, freq):
+    """xh_percentile_doy_count on a 30-year base period (k_pdoy_top16<.., COUNT>): counts and valid counts identical to
+    percentile_doy -> threshold_count (fp64 compare) and to the oracle; the fp32 threshold trick (largest float <= r /
+    smallest float >= r) must agree with the fp64 compare on ties, which rounded values provoke."""
+    T, C = 365 * 30, 150
+    ta, ot = _times("1981-01-01", T, "noleap")
+    x = _field(rng, T, C, nan_frac=0.002)
+    x[:, 5:20] = np.round(x[:, 5:20] * 2) / 2   # many samples equal to the percentile
+    x[:, 3] = np.nan
+    x[: T // 2, 4] = np.nan
+    tb, years, doys = ta.doy_table()
+    seg, _ = ta.segments(freq)
+    P = len(seg) - 1
+    tidx = np.searchsorted(doys, ta.doy).astype(np.int32)
+    xd = dev.to_device(x)
+    p = K.percentile_doy(dev, xd, tb, 5, [per])
+    cnt, val = K.threshold_count(dev, xd, op, seg, doy_table=p.reshape(len(doys), C), tidx=tidx)
+    period = (np.searchsorted(seg, tb, side="right") - 1).astype(np.int32)
+    period[tb < 0] = -1
+    fused = K.percentile_doy_count(dev, xd, tb, 5, per, op, period, P)
+    assert fused is not None
+    np.testing.assert_array_equal(fused[0].get(), cnt.get())
+    np.testing.assert_array_equal(fused[1].get(), val.get())
+    pe, d2 = ocal.percentile_doy(x, ot, 5, per)
+    thresh = ocal.resample_doy(pe[..., 0], d2, ot)
+    np.testing.assert_array_equal(fused[0].get(), ogen.threshold_count(x, op, thresh, ot, freq))
+    # a central percentile is not covered by the register top-16 kernel: the caller falls back to the chain
+    assert K.percentile_doy_count(dev, xd, tb, 5, 50.0, ">", period, P) is None
+
+
+@pytest.mark.parametrize("T", [360, 361, 364, 365, 366])
+@pytest.mark.parametrize("nq", [1, 20, 50, 64])
+def test_quantile_series_one_year_register_sort(dev, rng, T, nq):
+    """k_select_regsort (select3.hip): one-year daily series from the time-major view — two lanes per column, keys in
+    registers, comparator network.  Clean columns take the walk with the shared rank table, all-NaN columns ride along,
+    a tile with ONE partially-NaN column takes the per-lane path; ties, negative NaNs, -0.0, a ragged last
+    tile (C % 32 != 0) and the end-point quantiles are covered.  Bitwise against the oracle (same fp64 lerp)."""
+    C = 32 * 9 + 5
+    x = _field(rng, T, C)
+    x[:, 3] = np.nan                                   # all-NaN column inside a clean tile (regular path)
+    x[:, 40:44] = np.round(x[:, 40:44])                # heavy ties
+    x[:, 45] = -np.abs(x[:, 45]) * 0.0                 # all -0.0
+    x[:, 46] = np.where(rng.random(T) < 0.5, -1.5, 2.5)
+    x[:, 70] = np.float32(7.25)                        # constant
+    x[T // 3, 100] = np.nan                            # one NaN -> its tile is irregular
+    x[:, 130] = np.where(rng.random(T) < 0.9, np.nan, x[:, 130])   # mostly NaN
+    x[: T - 1, 131] = np.nan                           # a single valid sample
+    neg_nan = np.frombuffer(np.uint32(0xFFC00001).tobytes(), np.float32)[0]
+    x[7, 200] = neg_nan                                # sign-bit NaN must still sort last
+    x[:, C - 2] = np.nan                               # in the ragged tile
+    q = np.linspace(0.0, 1.0, nq) if nq > 1 else np.array([0.5])
+    if nq == 20:
+        q = osdba.equally_spaced_nodes(20)
+    exp = osdba.quantile(x, q)
+    out = K.quantile_series(dev, dev.to_device(x), q).get()
+    np.testing.assert_array_equal(out, exp.astype(np.float32))
+
+
+def test_quantile_series_register_sort_matches_histogram_kernels(dev, rng, monkeypatch):
+    """The same clean field through both time-major short-series kernels (diagnostic switch) and through the NaN path of
+    the register kernel: identical bits."""
+    T, C = 365, 4099
+    x = _field(rng, T, C)
+    q = osdba.equally_spaced_nodes(20)
+    a = K.quantile_series(dev, dev.to_device(x), q).get()
+    monkeypatch.setenv("XH_DIAGNOSTICS", "1")
+    monkeypatch.setenv("XH_SELECT_NOREGSORT", "1")
+    b = K.quantile_series(dev, dev.to_device(x), q).get()
+    monkeypatch.delenv("XH_SELECT_NOREGSORT")
+    monkeypatch.setenv("XH_REGSORT_IRREGULAR", "1")
+    c = K.quantile_series(dev, dev.to_device(x), q).get()
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, c)
+    np.testing.assert_array_equal(a, osdba.quantile(x, q).astype(np.float32))
+
+
 @pytest.mark.parametrize("T,C", [(365, 70001), (500, 33333), (800, 20011), (1500, 9001), (3650, 5003), (10950, 4801)])
 def test_quantile_series_many_columns(dev, rng, T, C):
     """More columns than resident workgroups (grid-stride column loops, ragged last tiles of the staged time-major

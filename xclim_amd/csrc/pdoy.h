@@ -78,3 +78,8 @@ int xh_launch_doy_stats_sets(xh_ctx* ctx, const float* x, int64_t T, int64_t C, 
 int xh_launch_pdoy_top16(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
                          int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int nsub, int rev, double* out,
                          const int32_t* d_vmap, int64_t Tv, const uint8_t* d_reg);
+// COUNT variant (xh_percentile_doy_count, multi-year base period): one percentile, every doy regular; the exceedances
+// of (year y, doy d) are added to period d_period[y * ndoy + d] (atomics: cnt_out / valid_out must be zeroed)
+int xh_launch_pdoy_top16_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
+                               int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int rev, const uint8_t* d_reg,
+                               int op, const int32_t* d_period, int32_t* cnt_out, int32_t* valid_out);

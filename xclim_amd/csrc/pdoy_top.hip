@@ -64,12 +64,41 @@ __device__ __forceinline__ void merge_top16(uint32_t (&t)[16], const uint32_t (&
   }
 }
 
-template <int W, int NYP>
+// Largest float <= r / smallest float >= r: with them the fp64 compare `(double)x OP r` of an fp32 sample against an fp64
+// threshold (numpy promotion of tx90p's compare, gen:301-361) is exactly ONE fp32 compare:
+//   x > r  <=>  x > below(r)      x <= r  <=>  x <= below(r)      x < r  <=>  x < above(r)      x >= r  <=>  x >= above(r)
+// (every float above below(r) is above r).  NaN stays NaN (every compare False).
+__device__ __forceinline__ float f32_step(float f, bool up) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) == 0u) return __uint_as_float(up ? 0x00000001u : 0x80000001u);  // +-0 -> smallest subnormal
+  const bool away = up == !(u >> 31);  // moving away from zero
+  return __uint_as_float(away ? u + 1u : u - 1u);
+}
+__device__ __forceinline__ float f32_threshold(double r, int op) {
+  float f = (float)r;  // round to nearest
+  if (f != f || f == __uint_as_float(0x7F800000u) || f == __uint_as_float(0xFF800000u)) {
+    // overflow of a finite r to +-inf: step back inside when the direction demands it
+    if (r == r && (double)f != r) {
+      const bool want_below = op == XH_OP_GT || op == XH_OP_LE;
+      if (want_below && f > 0.0f) return __uint_as_float(0x7F7FFFFFu);
+      if (!want_below && f < 0.0f) return __uint_as_float(0xFF7FFFFFu);
+    }
+    return f;
+  }
+  if (op == XH_OP_GT || op == XH_OP_LE) return (double)f > r ? f32_step(f, false) : f;  // below(r)
+  return (double)f < r ? f32_step(f, true) : f;                                          // above(r)
+}
+
+// COUNT = true (xh_percentile_doy_count on a multi-year base period): the percentile of doy d is compared with the
+// samples of day d of EVERY year and the exceedances are counted per (year, doy) -> period; the (D, C) fp64 table of the
+// unfused chain is neither written nor re-read once per year.  One percentile (nsub == 1), regular doys only.
+template <int W, int NYP, bool COUNT = false>
 __global__ void __launch_bounds__(64)
 k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
              int ndoy, int chunk, const QTab* __restrict__ qtab, const int32_t* __restrict__ jmap, int nsub,
              double* __restrict__ out, const int32_t* __restrict__ vmap, int64_t Tv, const uint8_t* __restrict__ regular,
-             int rev) {
+             int rev, int op = 0, const int32_t* __restrict__ yd_period = nullptr, int32_t* __restrict__ cnt_out = nullptr,
+             int32_t* __restrict__ valid_out = nullptr) {
   const uint32_t rmask = rev ? 0xFFFFFFFFu : 0u;  // mirrored key order for the bottom-16 case
   const int lane = threadIdx.x;
   int64_t c = (int64_t)blockIdx.x * 64 + lane;
@@ -108,6 +137,42 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
       merge_top16(top, blk);
     }
   };
+  // COUNT: per-year counters; the period of (year y, doy d) is wave-uniform, a year's counters are flushed with one
+  // atomic per lane when its period changes and at the end of the doy chunk
+  int ccnt[COUNT ? NYP : 1], cval[COUNT ? NYP : 1], cper[COUNT ? NYP : 1];
+  if (COUNT) {
+#pragma unroll
+    for (int y = 0; y < NYP; ++y) { ccnt[y] = 0; cval[y] = 0; cper[y] = -1; }
+  }
+  auto flush_year = [&](int y) {
+    if (COUNT) {
+      if (cper[y] >= 0 && active) {
+        if (ccnt[y]) atomicAdd(&cnt_out[(int64_t)cper[y] * C + c], ccnt[y]);
+        if (valid_out && cval[y]) atomicAdd(&valid_out[(int64_t)cper[y] * C + c], cval[y]);
+      }
+      ccnt[y] = 0; cval[y] = 0;
+    }
+  };
+  auto count_day = [&](int d, double r) {
+    if (!COUNT) return;
+    const float thr = f32_threshold(r, op);
+    const int rowc = rows_of(d, 0);  // lane y: row of (year y, doy d)
+    const int perv = (lane < nyears) ? yd_period[(int64_t)lane * ndoy + d] : -1;
+    float xv[NYP];
+    pdoy_gather<NYP>(xv, rowc, x, st, cc);  // rows read W/2 + 1 doys ago by this wave: cache hits
+#pragma unroll
+    for (int y = 0; y < NYP; ++y) {
+      const int pp = __builtin_amdgcn_readlane(perv, y);
+      if (pp != cper[y]) { flush_year(y); cper[y] = pp; }
+      bool hit;
+      if (op == XH_OP_GT) hit = xv[y] > thr;
+      else if (op == XH_OP_GE) hit = xv[y] >= thr;
+      else if (op == XH_OP_LT) hit = xv[y] < thr;
+      else hit = xv[y] <= thr;
+      ccnt[y] += hit ? 1 : 0;         // an absent row was gathered as NaN: never a hit, never valid
+      cval[y] += (xv[y] == xv[y]) ? 1 : 0;
+    }
+  };
   auto select_and_store = [&](int d) {
     uint32_t t16[16];
     int n = cnt[0];
@@ -137,7 +202,8 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
         if (e.gamma >= 0.5) r = (double)right - (double)diff * (1.0 - e.gamma);
         if (r != r && n > 0) r = (double)get(rev ? (n - 1 < 15 ? n - 1 : 15) : 0);  // +-inf: nanmax fallback (utl:552-554)
       }
-      if (active) out[((int64_t)j * ndoy + d) * C + c] = r;
+      if (COUNT) count_day(d, r);
+      else if (active) out[((int64_t)j * ndoy + d) * C + c] = r;
     }
   };
 
@@ -166,6 +232,10 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
       }
       if (regular[d]) select_and_store(d);
     }
+    if (COUNT) {
+#pragma unroll
+      for (int y = 0; y < NYP; ++y) flush_year(y);
+    }
   }
 }
 
@@ -183,6 +253,24 @@ int xh_launch_pdoy_top16(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
     if (window == 3) XH_TOP16(3, 64); else if (window == 5) XH_TOP16(5, 64); else XH_TOP16(7, 64);
   }
 #undef XH_TOP16
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_launch_pdoy_top16_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
+                               int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int rev, const uint8_t* d_reg,
+                               int op, const int32_t* d_period, int32_t* cnt_out, int32_t* valid_out) {
+  const int chunk = 46;  // 8 chunks of a 365-day year: fewer counter flushes (one atomic per year, lane and chunk)
+  const dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
+#define XH_TOP16C(W, NY)                                                                                                       \
+  hipLaunchKernelGGL((k_pdoy_top16<W, NY, true>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, d_tab, \
+                     d_jmap, 1, (double*)nullptr, (const int32_t*)nullptr, T, d_reg, rev, op, d_period, cnt_out, valid_out)
+  if (nyears <= 32) {
+    if (window == 3) XH_TOP16C(3, 32); else if (window == 5) XH_TOP16C(5, 32); else XH_TOP16C(7, 32);
+  } else {
+    if (window == 3) XH_TOP16C(3, 64); else if (window == 5) XH_TOP16C(5, 64); else XH_TOP16C(7, 64);
+  }
+#undef XH_TOP16C
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

@@ -933,6 +933,59 @@ static int pdoy_count_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, in
   return XH_OK;
 }
 
+// tx90p-style fused chain on a multi-year base period that is also the analysed period: every doy regular (no calendar
+// gaps: noleap / 360-day calendars, whole years), the percentile within the 16 largest / smallest samples for every valid
+// count (register top-16 kernel).  Anything else: XH_ERR_NOTIMPL -> the caller runs xh_percentile_doy + xh_threshold_count.
+// doy_period: (nyears, ndoy) period of every (year, doy) day, -1 where tbase is -1.
+static int pdoy_count_multi(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* tbase, int nyears,
+                            int ndoy, int window, double per, double alpha, double beta, int op, const int32_t* doy_period,
+                            int P, int32_t* count_out, int32_t* valid_out) {
+  const int N = nyears * window;
+  if (!(N > 32 && nyears <= 64 && (window == 3 || window == 5 || window == 7))) return XH_ERR_NOTIMPL;
+  if (op != XH_OP_GT && op != XH_OP_GE && op != XH_OP_LT && op != XH_OP_LE) return XH_ERR_NOTIMPL;
+  for (int64_t i = 0; i < (int64_t)nyears * ndoy; ++i) {
+    XH_REQUIRE(tbase[i] >= -1 && tbase[i] < T, XH_ERR_ARG, "xh_percentile_doy_count: tbase entry out of range");
+    XH_REQUIRE(tbase[i] < 0 ? doy_period[i] < 0 : (doy_period[i] >= 0 && doy_period[i] < P), XH_ERR_ARG,
+               "xh_percentile_doy_count: doy_period[%lld] must be in [0, P) for present days and < 0 for absent ones",
+               (long long)i);
+  }
+  uint8_t* regular = (uint8_t*)malloc((size_t)ndoy);
+  int32_t* irregular = (int32_t*)malloc(sizeof(int32_t) * (size_t)ndoy);
+  QTab* tab = (QTab*)malloc(sizeof(QTab) * (size_t)(N + 1));
+  if (!regular || !irregular || !tab) {
+    free(regular); free(irregular); free(tab);
+    xh_set_error("xh_percentile_doy_count: out of host memory");
+    return XH_ERR_ARG;
+  }
+  const int nirr = pdoy_regular_flags(tbase, nyears, ndoy, window, T, nullptr, T, regular, irregular);
+  const double q = per / 100.0;
+  build_qtab(N, &q, 1, alpha, beta, tab);
+  int dt = 0, db = 0;
+  for (int n = 0; n <= N; ++n) {
+    const QTab& e = tab[n];
+    if (e.lo < 0) continue;
+    if (n - e.lo > dt) dt = n - e.lo;
+    if (e.hi + 1 > db) db = e.hi + 1;
+  }
+  const bool top = dt <= 16, bot = !top && db <= 16;
+  int rc = (nirr == 0 && (top || bot)) ? XH_OK : XH_ERR_NOTIMPL;
+  size_t cur = 0;
+  void *d_tb = nullptr, *d_reg = nullptr, *d_tab = nullptr, *d_j = nullptr, *d_dp = nullptr;
+  const int32_t j0 = 0;
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, tbase, sizeof(int32_t) * (size_t)nyears * ndoy, &d_tb);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, regular, (size_t)ndoy, &d_reg);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, tab, sizeof(QTab) * (size_t)(N + 1), &d_tab);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, &j0, sizeof(int32_t), &d_j);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, doy_period, sizeof(int32_t) * (size_t)nyears * ndoy, &d_dp);
+  free(regular); free(irregular); free(tab);
+  if (rc) return rc;
+  XH_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int32_t) * (size_t)P * (size_t)C, ctx->stream));
+  if (valid_out) XH_CHECK_HIP(hipMemsetAsync(valid_out, 0, sizeof(int32_t) * (size_t)P * (size_t)C, ctx->stream));
+  return xh_launch_pdoy_top16_count(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const QTab*)d_tab,
+                                    (const int32_t*)d_j, bot ? 1 : 0, (const uint8_t*)d_reg, op, (const int32_t*)d_dp,
+                                    count_out, valid_out);
+}
+
 extern "C" {
 
 int xh_percentile_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* tbase,
@@ -970,8 +1023,10 @@ int xh_percentile_doy_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, i
   XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_percentile_doy_count: needs a time-major view (sc == 1, st >= C)");
   XH_REQUIRE(per >= 0.0 && per <= 100.0, XH_ERR_ARG, "xh_percentile_doy_count: percentile outside [0, 100]");
   XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
-  if (nyears != 1) return XH_ERR_NOTIMPL;  // multi-year base periods: use xh_percentile_doy + xh_threshold_count
   if (C == 0) return XH_OK;
+  if (nyears != 1)
+    return pdoy_count_multi(ctx, x, T, C, st, tbase, nyears, ndoy, window, per, alpha, beta, op, doy_period, P, count_out,
+                            valid_out);
   return pdoy_count_impl(ctx, x, T, C, st, tbase, ndoy, window, per, alpha, beta, op, doy_period, P, count_out, valid_out);
 }
 

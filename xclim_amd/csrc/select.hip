@@ -588,6 +588,10 @@ static int launch_select_grp(xh_ctx* ctx, const float* x, int64_t T, int64_t nco
 int xh_select_time_major(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq,
                          float* out, int64_t out_cstride, int64_t out_qstride) {
   if (T > 512 || nq > 64) return XH_ERR_NOTIMPL;
+  {  // one-year daily series: register sorting network (select3.hip)
+    const int rc = xh_select_regsort(ctx, x, T, C, st, d_q, nq, out, out_cstride, out_qstride);
+    if (rc != XH_ERR_NOTIMPL) return rc;
+  }
   return launch_select_grp<true>(ctx, x, T, C, st, d_q, nq, out, out_cstride, out_qstride);
 }
 

@@ -410,8 +410,8 @@ def percentile_doy_count(dev: Device, x: DeviceArray, tbase, window: int, per: f
     T, C_ = _tc(x)
     tb = np.ascontiguousarray(tbase, dtype=np.int32)
     nyears, ndoy = tb.shape
-    dp = np.ascontiguousarray(doy_period, dtype=np.int32)
-    assert dp.shape == (ndoy,)
+    dp = np.ascontiguousarray(doy_period, dtype=np.int32).reshape(-1)
+    assert dp.shape == (nyears * ndoy,)  # period of every (year, doy) day, < 0 where the day is absent
     if out is not None:
         cnt, val = out
     else:
