@@ -2,19 +2,21 @@
 """bench.py — the reference's headline workload on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu] [--no-extra] [--no-full]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... [--workload c5]
 
 Workload (BASELINE.json configs[1]): tx90p = percentile_doy(window 5, per 90) + threshold_count(">", per-doy fp64
 threshold, freq "YS") + MissingAny mask on a synthetic 365 x 1440 x 720 fp32 tasmax grid (noleap, time-major), all
 resident in HBM.  One "step" = one full pass of that chain through the C ABI.  With N > 1 every rank owns one
 1440x720 slab of an N-times larger grid (lat split, weak scaling) and the reduced (P, C) outputs are all-gathered
-over RCCL at the end of each step (the only exchange on this path).
+over RCCL at the end of each step (the only exchange on this path) — through the C ABI (xh_comm_*), no torch.
+--workload c5 runs BASELINE configs[4] instead (tx90p + EQM on the 30-year 360x1440 slab one of 8 GPUs owns).
 
 Prints ONE JSON line (rank 0): metric = grid-cells x timesteps / s (whole job), plus
   roofline     — dominant kernel (percentile_doy), algorithmic bytes / HIP-event time on the kernel's own stream
   cpu_baseline — the numpy oracle (a port: the reference stack is not installable) on a bounded lat-band sample
   extra        — the two other north-star workloads at the same grid (cdd run-length, EQM train+adjust)
-torch is imported only for N > 1 (torch.distributed rendezvous + RCCL all_gather); the product path is torch-free.
+Nothing here imports torch: with N > 1 the launcher (torch.distributed.run, or anything that sets RANK / LOCAL_RANK /
+WORLD_SIZE) only starts the ranks; rendezvous and the collective go through xclim_amd.shard.Comm -> libxclimhip.so -> RCCL.
 """
 
 import argparse
@@ -85,6 +87,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=str, default="365x1440x720")
+    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
+                    help="c2 (default): BASELINE configs[1], tx90p on 365x1440x720 per GPU; c5: configs[4], tx90p + EQM on a "
+                         "30-year 360x1440 slab per GPU")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-full", action="store_true", help="skip the 3650-step / 30-year extras (they allocate up to 182 GB)")
@@ -94,22 +99,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
-        sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    dist = torch = None
-    # XH_BENCH_FORCE_DIST=1: go through the torch.distributed / RCCL path even with one rank (single-GPU validation)
+        sys.exit("--gpus N > 1 must be launched with one rank per GPU (python -m torch.distributed.run ... bench.py --gpus N)")
+    # XH_BENCH_FORCE_DIST=1: go through the RCCL path even with one rank (single-GPU validation of the exchange code)
     use_dist = world > 1 or bool(os.environ.get("XH_BENCH_FORCE_DIST"))
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from xclim_amd import kernels as K
     from xclim_amd._capi import Device
     from xclim_amd.timeaxis import TimeAxis
 
     dev = Device(local_rank)
+    comm = None
+    if use_dist:
+        # RCCL through the C ABI (xh_comm_*, include/xclim_hip.h): no torch anywhere in this process.  The launcher only
+        # provides RANK / LOCAL_RANK / WORLD_SIZE; the unique id travels through a node-local file (xclim_amd/shard.py).
+        from xclim_amd.shard import Comm
+
+        comm = Comm.from_env(dev)
+    if args.workload == "c5":
+        return bench_config5(args, dev, K, comm, world, rank)
     T, Y, X = (int(v) for v in args.grid.split("x"))
     C = Y * X
     ta = TimeAxis.daily("2001-01-01", T, "noleap")
@@ -125,29 +132,15 @@ def main():
     res = dev.empty((P, C), np.float64)
     tidx = dev.to_device(tidx_h)
     table = per.reshape(len(doys), C)
-    gathered = None
-    overlap = False
+    overlap = use_dist and not os.environ.get("XH_BENCH_SYNC_GATHER")
     if use_dist:
-        # Two result buffers: the all-gather of step k runs on its own stream while step k + 1 computes (the only
-        # exchange of the path; nothing downstream of it inside a step).  The kernels run on the context's HIP
-        # stream, RCCL is enqueued from a torch stream: events order the two, the host never waits inside a step.
-        res_ts = [torch.empty((P, C), dtype=torch.float64, device="cuda") for _ in range(2)]
-        gathered = [torch.empty((world, P, C), dtype=torch.float64, device="cuda") for _ in range(2)]
-        res_views = [dev.wrap(t.data_ptr(), (P, C), np.float64) for t in res_ts]
-        res = res_views[0]
-        if not os.environ.get("XH_BENCH_SYNC_GATHER"):
-            try:
-                import ctypes
-
-                sp = ctypes.c_void_p()
-                dev.call("xh_stream", ctypes.byref(sp))
-                ext = torch.cuda.ExternalStream(sp.value, device=torch.device("cuda", local_rank))
-                comm = torch.cuda.Stream(device=torch.device("cuda", local_rank))
-                ev_ready = [torch.cuda.Event() for _ in range(2)]
-                ev_done = [torch.cuda.Event() for _ in range(2)]
-                overlap = True
-            except Exception as e:  # pragma: no cover - older torch without ExternalStream
-                print(f"bench: overlapped gather unavailable ({e}); using the synchronous gather", file=sys.stderr)
+        # Two result buffers: the all-gather of step k runs on the communicator's stream while step k + 1 computes (the
+        # only exchange of the path; nothing downstream of it inside a step): xh_comm_allgather(slot) orders
+        # itself after the kernels queued so far, xh_comm_fence(slot) protects the buffer before it is rewritten; the
+        # host never waits inside a step.
+        res_bufs = [dev.empty((P, C), np.float64) for _ in range(2)]
+        gathered = [dev.empty((world, P, C), np.float64) for _ in range(2)]
+        res = res_bufs[0]
 
     def k_pdoy():
         K.percentile_doy(dev, tasmax, tb, 5, [90.0], out=per)
@@ -166,27 +159,16 @@ def main():
         if not use_dist:
             k_pdoy(); k_count(); k_mask()
             return
-        if overlap:
-            if nstep[0] > 2:
-                ext.wait_event(ev_done[b])  # the gather of two steps ago has read res_ts[b]
-            k_pdoy(); k_count(); k_mask(res_views[b])
-            ev_ready[b].record(ext)
-            with torch.cuda.stream(comm):
-                comm.wait_event(ev_ready[b])
-                dist.all_gather_into_tensor(gathered[b].view(world * P, C), res_ts[b])
-                ev_done[b].record(comm)
-            return
-        k_pdoy(); k_count(); k_mask(res_views[b])
-        dev.sync()  # the kernels run on the context's stream, RCCL on torch's: order them explicitly
-        dist.all_gather_into_tensor(gathered[b].view(world * P, C), res_ts[b])
-        torch.cuda.current_stream().synchronize()
+        if overlap and nstep[0] > 2:
+            comm.fence(b)  # the gather of two steps ago has read res_bufs[b]
+        k_pdoy(); k_count(); k_mask(res_bufs[b])
+        comm.all_gather(res_bufs[b], gathered[b], slot=b if overlap else -1)
 
     def fence():
         dev.sync()
         if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+            comm.sync()
+            comm.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -198,11 +180,10 @@ def main():
     dt = time.perf_counter() - t0
     if use_dist:
         lastb = (nstep[0] - 1) % 2  # the slab this rank contributed must have arrived in the gathered field
-        if not torch.allclose(gathered[lastb][rank], res_ts[lastb], rtol=0, atol=0, equal_nan=True):
+        mine = dev.wrap(gathered[lastb].ptr + rank * res_bufs[lastb].nbytes, (P, C), np.float64).get()
+        if not np.array_equal(mine, res_bufs[lastb].get(), equal_nan=True):
             sys.exit("bench: the all-gathered field does not hold this rank's result")
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = float(comm.allreduce([dt], "max")[0])
     units_step = float(T) * C * world
     value = units_step * args.steps / dt
 
@@ -259,15 +240,98 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"tx90p (percentile_doy window 5 per 90 + threshold_count > + MissingAny) on {T}x{Y}x{X} fp32 "
                                    f"per GPU, noleap, freq YS, time-major, resident in HBM",
-                       "grid_per_gpu": [T, Y, X], "sharding": "lat slabs, one per rank; RCCL all_gather of (P,C) fp64" + (", overlapped with the next step" if overlap else "")},
+                       "grid_per_gpu": [T, Y, X], "sharding": "lat slabs, one per rank; RCCL (xh_comm_allgather, C ABI) all_gather of (P,C) fp64" + (", overlapped with the next step" if overlap else "")},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "extra": extra,
         }
         print(json.dumps(line))
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        comm.barrier()
+        comm.close()
+
+
+def bench_config5(args, dev, K, comm, world, rank):
+    """--workload c5: BASELINE configs[4] — tx90p AND EQM train + adjust on 30 noleap years of a 2880 x 1440 grid cut into
+    8 lat slabs of 360 x 1440 cells.  Every rank owns ONE such slab (cells [rank * 518400, ...) of the global counter-based
+    field; with 8 ranks this is exactly config 5, with fewer it is the same per-GPU work on a smaller grid: weak scaling).
+    One step = percentile_doy(window 5, per 90) -> threshold_count(">") -> missing mask, eqm_train(ref, hist, 20 nodes,
+    "+") -> eqm_adjust(sim, nearest, constant), then the ONE exchange: all-gather of the (30, C) masked counts and of the
+    (20, C) af / hist_q nodes (scen stays sharded)."""
+    from xclim_amd.timeaxis import TimeAxis
+
+    T, C = 10950, 360 * 1440
+    cell0 = rank * C
+    ta = TimeAxis.daily("1981-01-01", T, "noleap")
+    tb, years, doys = ta.doy_table()
+    seg, _ = ta.segments("YS")
+    P, D = len(seg) - 1, len(doys)
+    expected = ta.expected_count("YS")
+    base = seasonal_base(T)
+    tas = K.fill_synthetic(dev, T, C, 0, 2, base, 3.0, cell0=cell0)
+    ref = K.fill_synthetic(dev, T, C, 0, 4, base, 3.0, cell0=cell0)
+    hist = K.fill_synthetic(dev, T, C, 0, 5, base + np.float32(1.5), 3.3, cell0=cell0)
+    sim = K.fill_synthetic(dev, T, C, 0, 6, base + np.float32(3.5), 3.3, cell0=cell0)
+    scen = dev.empty((T, C), np.float32)
+    per = dev.empty((1, D, C), np.float64)
+    cnt, val = dev.empty((P, C), np.int32), dev.empty((P, C), np.int32)
+    tidx = dev.to_device(np.searchsorted(doys, ta.doy).astype(np.int32))
+    q = (np.arange(20) + 0.5) / 20
+    # one send buffer: (P, C) float64 counts followed by (2, 20, C) float32 nodes -> a single collective per step
+    nb_res, nb_nodes = P * C * 8, 2 * 20 * C * 4
+    send = dev.empty((nb_res + nb_nodes,), np.uint8)
+    res = dev.wrap(send.ptr, (P, C), np.float64)
+    af = dev.wrap(send.ptr + nb_res, (20, C), np.float32)
+    hq = dev.wrap(send.ptr + nb_res + 20 * C * 4, (20, C), np.float32)
+    recv = dev.empty((world, nb_res + nb_nodes), np.uint8) if comm else None
+
+    def step():
+        K.percentile_doy(dev, tas, tb, 5, [90.0], out=per)
+        K.threshold_count(dev, tas, ">", seg, doy_table=per.reshape(D, C), tidx=tidx, out=(cnt, val))
+        K.apply_missing_mask(dev, cnt, val, expected, out=res)
+        K.eqm_train(dev, ref, hist, q, "+", out=(af, hq))
+        K.eqm_adjust(dev, sim, af, hq, "+", "nearest", "constant", out=scen)
+        if comm:
+            comm.all_gather(send, recv, slot=-1)
+
+    def fence():
+        dev.sync()
+        if comm:
+            comm.sync()
+            comm.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if comm:
+        mine = dev.wrap(recv.ptr + rank * send.nbytes, (send.nbytes,), np.uint8).get()
+        if not np.array_equal(mine, send.get()):
+            sys.exit("bench: the all-gathered field does not hold this rank's result")
+        dt = float(comm.allreduce([dt], "max")[0])
+    E = float(T) * C
+    bytes_step = (2 * (4 * E + 8 * D * C) + 8 * P * C) + 16 * E  # tx90p unfused (SURVEY 8d) + EQM train + adjust
+    if rank == 0:
+        print(json.dumps({
+            "metric": "grid-cells x timesteps / s (tx90p + EQM train + adjust, 30-year daily series)",
+            "value": E * world * args.steps / dt, "unit": "cell-timesteps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: tx90p + EmpiricalQuantileMapping train+adjust on {T} x 360 x 1440 fp32 "
+                                   "per GPU (one of the 8 lat slabs of the 2880 x 1440 grid), noleap, resident in HBM",
+                       "grid_per_gpu": [T, 360, 1440],
+                       "sharding": "lat slabs, one per rank; one RCCL all_gather of (P,C) fp64 counts + (2,20,C) fp32 nodes per step"},
+            "roofline": {"bound": "hbm", "kernel": "whole step (5 kernels chains)", "achieved": bytes_step / (dt / args.steps) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes": bytes_step},
+            "cpu_baseline": None}))
+    if comm:
+        comm.barrier()
+        comm.close()
 
 
 def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D, full_configs=True):

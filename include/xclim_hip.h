@@ -104,12 +104,41 @@ int xh_timer_stop(xh_ctx* ctx, float* elapsed_ms); /* synchronises */
 /* raw hipStream_t of the context, for interop (e.g. ordering against RCCL collectives) */
 int xh_stream(xh_ctx* ctx, void** stream);
 
+/* ---- multi-GPU exchange ------------------------------------------------------------------------------
+ * The path shards over (lat, lon) with no halo; its ONE exchange step is the all-gather of the reduced outputs ((P, C/N)
+ * counts / statistics, (nq, C/N) quantile nodes; scen stays sharded).  RCCL over xGMI, one process per GPU; librccl.so is
+ * dlopen'ed at the first xh_comm_* call (single-GPU users never load it).  The reference has no collectives:
+ * no reference line to match — this is north_star's "RCCL over xGMI only for the final gather".
+ *   rendezvous  rank 0: xh_comm_unique_id -> hands the XH_COMM_ID_BYTES to every rank (file / socket / environment:
+ *               xclim_amd/shard.py uses a node-local file); every rank: xh_comm_init (collective, blocks).
+ *   all-gather  recv holds nranks * bytes_per_rank bytes, rank r's block at r * bytes_per_rank.  slot < 0: enqueued on
+ *               the context's stream, in line with the kernels.  slot in [0, 4): runs on the communicator's own stream
+ *               after everything queued on the context's stream so far, overlapping later kernels; xh_comm_fence(slot)
+ *               makes the context's stream wait for that collective (before its send buffer is overwritten),
+ *               xh_comm_sync waits on the host for both streams.
+ *   scalars     xh_comm_allreduce_f64: 1 or 2 host doubles reduced over the ranks in place (timings, checksums);
+ *               xh_comm_barrier = drain this rank's streams + a one-word all-reduce. */
+typedef struct xh_comm xh_comm;
+#define XH_COMM_ID_BYTES 128
+#define XH_COMM_SUM 0
+#define XH_COMM_MAX 2
+#define XH_COMM_MIN 3
+int xh_comm_unique_id(void* id /* host, XH_COMM_ID_BYTES */);
+int xh_comm_init(xh_ctx* ctx, int nranks, int rank, const void* id /* host */, xh_comm** out);
+int xh_comm_destroy(xh_comm* comm);
+int xh_comm_size(xh_comm* comm, int* nranks, int* rank);
+int xh_comm_allgather(xh_comm* comm, const void* send, void* recv, size_t bytes_per_rank, int slot);
+int xh_comm_fence(xh_comm* comm, int slot);
+int xh_comm_sync(xh_comm* comm);
+int xh_comm_allreduce_f64(xh_comm* comm, double* host_values, int count, int op);
+int xh_comm_barrier(xh_comm* comm);
+
 /* ---- block adapter support (chunked host inputs streamed through the device; the reference's
  * dask / map_blocks layer, indices/helpers.py:898-974, core/indicator.py:865-944) --------------------------------
  * Pinned host memory (xh_host_alloc, or xh_host_register on caller memory) makes the strided copies below asynchronous
  * and full PCIe rate.  Lanes: 0 = the compute stream every xh_* op runs on, 1 = copy-in stream, 2 = copy-out stream.
  * xh_memcpy2d copies `height` rows of `width` bytes (pitches in bytes; a cell slab of a (T, C) host array is
- * width = slab * 4, spitch = C * 4); kind 0 = host -> device, 1 = device -> host; blocking != 0 waits for the copy
+ * width = slab * 4, spitch = C * 4); kind 0 = host -> device, 1 = device -> host, 2 = device -> device; blocking != 0 waits for the copy
  * (required for pageable host memory).  xh_lane_fence(a, b): work queued on lane b from now on waits for everything
  * queued on lane a so far.  xh_lane_sync: the host waits for the lane. */
 int xh_host_alloc(xh_ctx* ctx, size_t bytes, void** hptr);

@@ -64,6 +64,15 @@ SIGNATURES: dict[str, list] = {
     "xh_timer_start": [_vp],
     "xh_timer_stop": [_vp, C.POINTER(_flt)],
     "xh_stream": [_vp, C.POINTER(_vp)],
+    "xh_comm_unique_id": [_vp],
+    "xh_comm_init": [_vp, _int, _int, _vp, C.POINTER(_vp)],
+    "xh_comm_destroy": [_vp],
+    "xh_comm_size": [_vp, C.POINTER(_int), C.POINTER(_int)],
+    "xh_comm_allgather": [_vp, _vp, _vp, _sz, _int],
+    "xh_comm_fence": [_vp, _int],
+    "xh_comm_sync": [_vp],
+    "xh_comm_allreduce_f64": [_vp, C.POINTER(_dbl), _int, _int],
+    "xh_comm_barrier": [_vp],
     "xh_fill_synthetic": [_vp, _vp, _i64, _i64, _i64, _int, _u64, _i64, _vp, _flt, _flt, _u32],
     "xh_transpose_f32": [_vp, _vp, _i64, _i64, _i64, _vp, _i64],
     "xh_threshold_count": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _dbl, _vp, _i64, _vp, _vp, _int, _vp, _vp],
@@ -300,9 +309,9 @@ class Device:
 
     def copy2d(self, dst: int, dpitch: int, src: int, spitch: int, width: int, height: int, kind: str, lane: int = 0,
                blocking: bool = True) -> None:
-        """xh_memcpy2d: `height` rows of `width` bytes; kind "h2d" | "d2h"; lanes 0 compute / 1 copy-in / 2 copy-out."""
+        """xh_memcpy2d: `height` rows of `width` bytes; kind "h2d" | "d2h" | "d2d"; lanes 0 compute / 1 copy-in / 2 copy-out."""
         _check(self.lib, self.lib.xh_memcpy2d(self.ctx, _vp(dst), dpitch, _vp(src), spitch, width, height,
-                                              {"h2d": 0, "d2h": 1}[kind], lane, int(bool(blocking))))
+                                              {"h2d": 0, "d2h": 1, "d2d": 2}[kind], lane, int(bool(blocking))))
 
     def lane_fence(self, from_lane: int, to_lane: int) -> None:
         _check(self.lib, self.lib.xh_lane_fence(self.ctx, from_lane, to_lane))

@@ -202,12 +202,13 @@ int xh_host_unregister(xh_ctx* ctx, void* hptr) {
 int xh_memcpy2d(xh_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int kind,
                 int lane, int blocking) {
   XH_REQUIRE(ctx, XH_ERR_ARG, "xh_memcpy2d: ctx is NULL");
-  XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "xh_memcpy2d: kind must be 0 (host -> device) or 1 (device -> host)");
+  XH_REQUIRE(kind >= 0 && kind <= 2, XH_ERR_ARG,
+             "xh_memcpy2d: kind must be 0 (host -> device), 1 (device -> host) or 2 (device -> device)");
   XH_REQUIRE(lane >= 0 && lane <= 2, XH_ERR_ARG, "xh_memcpy2d: lane must be 0, 1 or 2");
   if (width == 0 || height == 0) return XH_OK;
   XH_REQUIRE(dst && src && dpitch >= width && spitch >= width, XH_ERR_ARG, "xh_memcpy2d: NULL pointer or pitch < width");
   hipStream_t s = lane_stream(ctx, lane);
-  XH_CHECK_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, s));
+  XH_CHECK_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind == 0 ? hipMemcpyHostToDevice : (kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice), s));
   if (blocking) XH_CHECK_HIP(hipStreamSynchronize(s));  // pageable host memory: do not return before it has been consumed
   return XH_OK;
 }

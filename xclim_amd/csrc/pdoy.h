@@ -12,11 +12,16 @@ struct QTab {
 // with ONE vector load chain (tbase -> vmap); the unrolled gather then reads the rows with readlane + unconditional,
 // clamped loads.  (Resolving the rows with per-year scalar loads serialised every gather behind two s_load latencies:
 // ~22k clk per doy, 4x the whole rest of the kernel.)
+// A day-set index outside [0, ndoy) wraps into the neighbouring year: day-set -1 is {(y - 1, ndoy - 1)} — the day before
+// (y, 0) on a calendar without gaps.  With it the windows of the first / last W/2 doys of a multi-year base period
+// decompose into day-sets like every other doy (pdoy_regular_flags verifies exactly that, row by row).
 __device__ __forceinline__ int pdoy_row(int lane, int nyears, int ndoy, int dn, int off, const int32_t* __restrict__ tbase,
                                         const int32_t* __restrict__ vmap, int64_t Tv, int64_t T) {
   int tp = -1;
-  if (lane < nyears && dn >= 0 && dn < ndoy) {
-    const int v = tbase[(int64_t)lane * ndoy + dn];
+  const int yy = dn < 0 ? lane - 1 : (dn >= ndoy ? lane + 1 : lane);
+  const int dd = dn < 0 ? dn + ndoy : (dn >= ndoy ? dn - ndoy : dn);
+  if (lane < nyears && yy >= 0 && yy < nyears && dd >= 0 && dd < ndoy) {
+    const int v = tbase[(int64_t)yy * ndoy + dd];
     const int64_t vv = (int64_t)v + off;
     if (v >= 0 && vv >= 0 && vv < Tv) {
       const int64_t p = vmap ? (int64_t)vmap[vv] : vv;
@@ -54,7 +59,9 @@ static inline int pdoy_regular_flags(const int32_t* tbase, int nyears, int ndoy,
           if (t >= 0 && t < Tv) a = t;
         }
         int dn = d - half + k;
-        int64_t b = (dn >= 0 && dn < ndoy) ? (int64_t)tbase[(int64_t)y * ndoy + dn] : -1;
+        const int yy = dn < 0 ? y - 1 : (dn >= ndoy ? y + 1 : y);              // (same wrap as pdoy_row)
+        const int dd = dn < 0 ? dn + ndoy : (dn >= ndoy ? dn - ndoy : dn);
+        int64_t b = (yy >= 0 && yy < nyears && dd >= 0 && dd < ndoy) ? (int64_t)tbase[(int64_t)yy * ndoy + dd] : -1;
         // compare the PHYSICAL rows (two virtual days may map to the same / to an absent row)
         int64_t pa = a < 0 ? -1 : (vmap ? vmap[a] : a), pb = b < 0 ? -1 : (vmap ? vmap[b] : b);
         if (pa >= T) pa = -1;

@@ -18,10 +18,17 @@
 //      leaves the N smallest samples in A (negated) and the N largest in B, both as "down then up" sequences
 //   4. the same ascending bitonic merge in both lanes                XH_SN_MERGE  (Lang's merge for arbitrary N)
 //      -> rank r of the column sits in A at k[N-1-r] (negated) for r < N and in B at k[r-N] otherwise
-//   5. the 2*nq order statistics are picked in one walk over the registers (static indices; the wanted local index of
-//      the next target is compared with the step number) into a small LDS table, then Hyndman-Fan lerp + coalesced stores
-// Columns whose valid count is neither T nor 0 (some NaN samples) have lane-dependent ranks: such tiles take the
-// "irregular" path (valid count by counting, every target picked by a compare/select chain over the registers).
+//   5. the 2*nq order statistics are picked from the registers (per-lane index -> 5-level select tree over 32 registers
+//      at a time) into a small LDS table, then Hyndman-Fan lerp + coalesced stores
+// Columns whose valid count is neither T nor 0 (some NaN samples) have lane-dependent ranks: in such ("irregular") tiles
+// the valid counts are counted and every lane evaluates its own ranks instead of reading the shared rank table.
+// The tile loop is 46 KB of straight-line code (inside the 64 KB instruction cache).  Measured on MI355X, 365 x 1 036 800
+// (profiles/r02/regsort_anatomy.txt): 0.78 ms per array against 1.27 ms for the histogram kernel, and VALU-bound — with
+// the loads replaced by register fills it still takes 0.75 ms: sort 0.36, split + merge 0.11, picks 0.11, keys / lerp /
+// stores 0.17.  v_min_u32 / v_max_u32 (like v_cmp, v_fma_f32 and every 3-operand op) issue at HALF the rate of
+// v_add / v_xor / v_mov on gfx950 (tools/valu_ubench.hip: 3.7 vs 2.1 clocks per wave64 instruction with two waves per
+// SIMD), so a comparator costs ~8 clocks; delaying one wave of each SIMD pair (to make one load while the other sorts)
+// changes nothing for the same reason.
 #include <stdlib.h>
 
 #include "common.h"
@@ -57,20 +64,23 @@ __device__ __forceinline__ int hf7_rank(uint32_t n, double q, int side) {
 template <int N, int TMIN>
 __global__ void __launch_bounds__(256, 2)
 k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const double* __restrict__ qs, int nq,
-                 float* __restrict__ out, int64_t ocs, int64_t oqs, int force_irregular) {
+                 float* __restrict__ out, int64_t ocs, int64_t oqs, int force_irregular, int abl) {
   static_assert(N == XH_SN_N, "sortnet header generated for another N");
   __shared__ double qS[MAXQ];
-  __shared__ int rkS[2 * MAXQ + 2];             // rkS[j + 1] = rank of target j when every sample is valid (n = T)
+  __shared__ int rkS[2 * MAXQ + 4];             // rkS[j + 2] = rank of target j when every sample is valid (n = T)
   __shared__ uint32_t valsS[4][2 * MAXQ * 32];  // per wave: picked keys, [target][column of the tile]
   __shared__ uint32_t ncolS[4][32];             // per wave: valid count per column of the tile
   const int tid = threadIdx.x, w = tid >> 6;
   const int ntgt = 2 * nq;
   if (tid < nq) qS[tid] = qs[tid];
-  if (tid <= ntgt + 1)
-    rkS[tid] = (tid == 0 || tid == ntgt + 1) ? RK_SENTINEL : hf7_rank((uint32_t)T, qs[(tid - 1) >> 1], (tid - 1) & 1);
+  if (tid < ntgt + 4)
+    rkS[tid] = (tid < 2 || tid >= ntgt + 2) ? RK_SENTINEL : hf7_rank((uint32_t)T, qs[(tid - 2) >> 1], (tid - 2) & 1);
   __syncthreads();
-  int jA = 0;  // targets that live in lane A (rank < N) when n = T
-  for (int j = 0; j < ntgt; ++j) jA += rkS[j + 1] < N ? 1 : 0;
+  // Targets 2k / 2k + 1 are the lower / upper neighbour of quantile k.  Each parity class has non-decreasing ranks (the
+  // whole sequence does not when quantiles lie closer than one rank: lower(k + 1) < upper(k)), so the picks below run
+  // once per parity.  jA[p]: targets of parity p that live in lane A (rank < N) when n = T.
+  int jA[2] = {0, 0};
+  for (int j = 0; j < ntgt; ++j) jA[j & 1] += rkS[j + 2] < N ? 1 : 0;
 
   uint32_t* vals = valsS[w];
   uint32_t* ncol = ncolS[w];
@@ -84,9 +94,13 @@ k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, cons
     // everything computed from them) would stay live across the sort, which needs every register it can get
     uint32_t lane = (uint32_t)tid & 63u;
     asm volatile("" : "+v"(lane));
+    const int64_t col0 = tile * 32;
+#define XH_DECL(i) uint32_t k##i;
+    XH_SN_FOREACH(XH_DECL)
+#undef XH_DECL
+    {
     const uint32_t h = lane & 1u, c32 = lane >> 1;
-    const uint32_t mA = h ? 0u : 0xFFFFFFFFu;  // lane A keeps its keys negated from the split on
-    const int64_t col0 = tile * 32, col = col0 + c32;
+    const int64_t col = col0 + c32;
     const int64_t colc = col < C ? col : C - 1;
     // ---- 1. loads: register i of lane A holds row i, of lane B row T - N + i: one uniform row base per instruction
     //      (scalar address arithmetic) plus ONE per-lane 32-bit byte offset
@@ -95,8 +109,14 @@ k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, cons
     //  tile and made opaque per tile: hoisted out of the tile loop, N loop-invariant offsets would spill)
     uint32_t soff = 0u;
     asm volatile("" : "+s"(soff));
-#define XH_LD(i) uint32_t k##i = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0); soff += strideB;
+#define XH_LD(i) k##i = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0); soff += strideB;
+    if (!(abl & 8)) {
     XH_SN_FOREACH(XH_LD)
+    } else {  // diagnostics: no memory traffic, pseudo-random keys
+#define XH_FK(i) k##i = (voff * 2654435761u + (uint32_t)i * 40503u) >> 9 | 0x40000000u;
+    XH_SN_FOREACH(XH_FK)
+#undef XH_FK
+    }
 #undef XH_LD
     // keys; B's first 2N - T registers repeat rows that lane A holds -> pads (only i < 2N - TMIN can be affected)
     uint32_t bcut = h ? (uint32_t)(2 * N - T) : 0u;
@@ -112,6 +132,7 @@ k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, cons
   }
     XH_SN_FOREACH(XH_CV)
 #undef XH_CV
+    }
     // ---- 2. local sort
 #define XH_CE(i, j)                               \
   {                                               \
@@ -119,7 +140,13 @@ k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, cons
     k##i = a_ < b_ ? a_ : b_;                     \
     k##j = a_ < b_ ? b_ : a_;                     \
   }
+    if (!(abl & 1)) {
     XH_SN_SORT(XH_CE)
+    }
+    // (lane constants are re-derived after each long phase instead of being kept in registers across it)
+    uint32_t lane3 = (uint32_t)tid & 63u;
+    asm volatile("" : "+v"(lane3));
+    const uint32_t mA3 = (lane3 & 1u) ? 0u : 0xFFFFFFFFu;  // lane A keeps its keys negated from the split on
     // ---- 3. lane A negates, bitonic split across the lane pair.  One asm statement per register pair: written with the
     //      DPP builtin, instruction selection parks the DPP moves of ALL pairs in registers long before the v_max that
     //      consumes them and ~140 of them spill.
@@ -132,7 +159,7 @@ k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, cons
         "v_not_b32_dpp %2, %1 " XH_DPP_SWAP1 "\n\tv_not_b32_dpp %3, %0 " XH_DPP_SWAP1 "\n\t"                    \
         "v_max_u32 %0, %0, %2\n\tv_max_u32 %1, %1, %3"                                                           \
         : "+v"(k##i), "+v"(k##j), "=&v"(t0_), "=&v"(t1_)                                                         \
-        : "v"(mA));                                                                                              \
+        : "v"(mA3));                                                                                             \
   }
 #define XH_SM(m)                                                                          \
   {                                                                                       \
@@ -140,16 +167,22 @@ k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, cons
     asm volatile("v_xor_b32 %0, %0, %2\n\ts_nop 1\n\tv_not_b32_dpp %1, %0 " XH_DPP_SWAP1   \
                  "\n\tv_max_u32 %0, %0, %1"                                               \
                  : "+v"(k##m), "=&v"(t0_)                                                 \
-                 : "v"(mA));                                                              \
+                 : "v"(mA3));                                                             \
   }
+    if (!(abl & 2)) {
     XH_SN_SPLIT(XH_SP, XH_SM)
+    }
 #undef XH_SP
 #undef XH_SM
     // ---- 4. merge
-#define XH_CEB(i, j) XH_CE(i, j) __builtin_amdgcn_sched_barrier(0);
-    XH_SN_MERGE(XH_CEB)
-#undef XH_CEB
+    if (!(abl & 2)) {
+    XH_SN_MERGE(XH_CE)
+    }
 #undef XH_CE
+    uint32_t lane4 = (uint32_t)tid & 63u;
+    asm volatile("" : "+v"(lane4));
+    const uint32_t h = lane4 & 1u, c32 = lane4 >> 1;
+    const uint32_t mA = h ? 0u : 0xFFFFFFFFu;
     // ---- valid counts: the largest real sample (rank T-1) is B's k[T-1-N], the smallest (rank 0) A's k[N-1]
     uint32_t top = 0u, low = 0u;
     uint32_t tsel = (uint32_t)(T - 1 - N);
@@ -163,49 +196,59 @@ k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, cons
     const uint32_t both = fl | swap1(fl);  // bit 0: the column has NaN samples, bit 1: it has nothing else
     const bool partial = (both & 1u) && !(both & 2u);
     const bool irregular = __any(partial ? 1 : 0) || force_irregular;
-    if (!irregular) {
-      // ---- 5a. every column has n = T (or 0: then every key is the pad and every pick decodes to NaN)
-      if (h == 0) ncol[c32] = (both & 2u) ? 0u : (uint32_t)T;
-      int jcur = h ? jA : jA - 1;  // B walks its targets upwards, A downwards (its local order is reversed)
-      const int dj = h ? 1 : -1;
-      uint32_t snext;
-      {
-        const int r = rkS[jcur + 1];
-        snext = h ? (uint32_t)(r - N) : (uint32_t)(N - 1 - r);
-      }
-#define XH_WK(i)                                                     \
-  if (snext == (uint32_t)i) {                                        \
-    const uint32_t v_ = k##i ^ mA;                                   \
-    do {                                                             \
-      vals[jcur * 32 + c32] = v_;                                    \
-      jcur += dj;                                                    \
-      const int r_ = rkS[jcur + 1];                                  \
-      snext = h ? (uint32_t)(r_ - N) : (uint32_t)(N - 1 - r_);       \
-    } while (snext == (uint32_t)i);                                  \
-  }
-      XH_SN_FOREACH(XH_WK)
-#undef XH_WK
-    } else {
-      // ---- 5b. some column has NaN samples: per-column valid count, per-lane ranks, compare/select chains
+    // ---- 5. pick the 2*nq order statistics.  Valid count n of my column: T (or 0: every key is the pad then and every
+    //      pick decodes to NaN) unless some column of the tile has NaN samples — then n is counted and every lane
+    //      evaluates its own ranks (utl:395) instead of reading the shared table.
+    uint32_t n = (both & 2u) ? 0u : (uint32_t)T;
+    int myA[2] = {jA[0], jA[1]};  // my column's targets with rank < N, per parity
+    if (irregular) {
       const uint32_t pad_stored = PADK ^ mA;
       uint32_t nv = 0;
 #define XH_CN(i) nv += k##i != pad_stored ? 1u : 0u;
       XH_SN_FOREACH(XH_CN)
 #undef XH_CN
-      const uint32_t n = nv + swap1(nv);
-      if (h == 0) ncol[c32] = n;
+      n = nv + swap1(nv);
+      myA[0] = 0;
+      myA[1] = 0;
 #pragma nounroll
       for (int j = 0; j < ntgt; ++j) {
-        const int r = hf7_rank(n, qS[j >> 1], j & 1);
-        const bool mine = h ? r >= N : r < N;
-        const uint32_t s = mine ? (h ? (uint32_t)(r - N) : (uint32_t)(N - 1 - r)) : 0xFFFFFFFFu;
-        uint32_t ans = 0u;
-#define XH_PK(i) ans = (s == (uint32_t)i) ? k##i : ans;
-        XH_SN_FOREACH(XH_PK)
-#undef XH_PK
-        if (mine) vals[j * 32 + c32] = ans ^ mA;
+        const int below = hf7_rank(n, qS[j >> 1], j & 1) < N ? 1 : 0;
+        myA[0] += (j & 1) ? 0 : below;
+        myA[1] += (j & 1) ? below : 0;
       }
     }
+    if (h == 0) ncol[c32] = n;
+    // register index (in MY lane) of target j's order statistic; a sentinel that matches no index past either end
+    auto local_of = [&](int j) -> uint32_t {
+      int r;
+      if (irregular) r = (j >= 0 && j < ntgt) ? hf7_rank(n, qS[j >> 1], j & 1) : RK_SENTINEL;
+      else r = rkS[j + 2];
+      return h ? (uint32_t)(r - N) : (uint32_t)(N - 1 - r);
+    };
+    // Both lanes meet the targets of one parity in order of INCREASING register index: B walks them upwards, A (whose
+    // local order is reversed) downwards.  32 registers at a time; the wanted one comes out of a 5-level select tree on
+    // the bits of the index (31 v_cndmask, lanes may want different registers) — a compare-and-branch per register costs
+    // 13 KB of code and pushes the kernel out of the instruction cache; a dynamically indexed vector is expanded by the
+    // compiler into 32 compares + 32 selects.
+#define XH_PICK(c)                                                                            \
+  while ((snext >> 5) == (uint32_t)(c)) {                                                     \
+    const bool b0 = snext & 1u, b1 = snext & 2u, b2 = snext & 4u, b3 = snext & 8u, b4 = snext & 16u; \
+    uint32_t v_;                                                                              \
+    XH_SN_SEL_##c(v_, b0, b1, b2, b3, b4)                                                     \
+    vals[jcur * 32 + (int)c32] = v_ ^ mA;                                                     \
+    jcur += dj;                                                                               \
+    snext = local_of(jcur);                                                                   \
+  }
+#pragma nounroll
+    for (int par = (abl & 4) ? 2 : 0; par < 2; ++par) {
+      const int mine = par ? myA[1] : myA[0];
+      int jcur = (h ? 2 * mine : 2 * (mine - 1)) + par;
+      const int dj = h ? 2 : -2;
+      uint32_t snext = local_of(jcur);
+      XH_PICK(0) XH_PICK(1) XH_PICK(2) XH_PICK(3) XH_PICK(4) XH_PICK(5)
+    }
+    static_assert(XH_SN_CHUNKS == 6, "XH_PICK chunks");
+#undef XH_PICK
     wave_fence();
     // ---- Hyndman-Fan lerp (utl:464-491) and stores: 32 columns x nq quantiles spread over the wave
     uint32_t lane2 = (uint32_t)tid & 63u;
@@ -248,12 +291,13 @@ int xh_select_regsort(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t
   if ((unsigned long long)T * (unsigned long long)st * 4ull >= (1ull << 32)) return XH_ERR_NOTIMPL;  // 32-bit lane offsets
   if (xh_diag_env("XH_SELECT_NOREGSORT")) return XH_ERR_NOTIMPL;  // A/B against the histogram kernels
   const char* fi = xh_diag_env("XH_REGSORT_IRREGULAR");  // tests: send clean data through the NaN path as well
+  const char* ea = xh_diag_env("XH_REGSORT_ABL");  // diagnostics: skip phases (1 sort, 2 split + merge, 4 picks, 8 loads; wrong results)
   const int64_t ntiles = (C + 31) / 32;
   int64_t nblk = (ntiles + 3) / 4;
   const int64_t maxblk = (int64_t)ctx->num_cu * 2;  // two 256-thread workgroups per CU (256 VGPRs per lane)
   if (nblk > maxblk) nblk = maxblk;
   hipLaunchKernelGGL((k_select_regsort<N, TMIN>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, x, (int)T, C, st, d_q, nq,
-                     out, out_cstride, out_qstride, fi ? atoi(fi) : 0);
+                     out, out_cstride, out_qstride, fi ? atoi(fi) : 0, ea ? atoi(ea) : 0);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

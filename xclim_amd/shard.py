@@ -2,13 +2,19 @@
 
 Every op on the path is independent per grid cell (only time-axis windows exist), so the flattened cell axis is
 cut into contiguous slabs, each rank runs the single-GPU kernels on its slab, and the ONLY exchange is one
-all-gather of the reduced ``(P, cells)`` outputs — RCCL over xGMI when the tensors are on the GPU (torch.distributed
-backend "nccl" is RCCL on ROCm), gloo for the CPU tests.  ``scen``-sized outputs (EQM adjust) stay sharded.
+all-gather of the reduced ``(P, cells)`` outputs.  ``scen``-sized outputs (EQM adjust) stay sharded.
 
-torch is imported lazily: the single-GPU product path never needs it.
+On the GPU the exchange goes through the C ABI (``xh_comm_*`` in include/xclim_hip.h: RCCL over xGMI, librccl
+dlopen'ed by libxclimhip.so) — :class:`Comm` below, torch-free.  ``gather_cells`` with numpy arrays / CPU tensors uses
+torch.distributed (gloo): that is the CPU test path of the slab arithmetic (tests/test_shard_gloo.py); torch is imported
+lazily and only there.
 """
 
 from __future__ import annotations
+
+import ctypes as C
+import os
+import time
 
 import numpy as np
 
@@ -50,3 +56,119 @@ def gather_cells(local, ncells: int, group=None, align: int = 4):
     dist.all_gather_into_tensor(out.view(world * P, cmax), pad, group=group)
     full = torch.cat([out[r, :, : b - a] for r, (a, b) in enumerate(bounds)], dim=1)
     return full.numpy() if as_numpy else full
+
+
+# ---- RCCL through the C ABI (no torch) ---------------------------------------------------------------------------------
+def _rendezvous_path() -> str:
+    """Node-local file through which rank 0 hands the RCCL unique id to the other ranks of ONE launch.  The name is built
+    from what every rank of a launch shares and consecutive launches do not: the rendezvous endpoint and the PID of
+    the common parent (the torchrun agent / the shell that started the ranks)."""
+    d = os.environ.get("XH_RENDEZVOUS_DIR") or os.environ.get("TMPDIR") or "/tmp"
+    key = os.environ.get("XH_RENDEZVOUS_KEY") or "{}_{}_{}".format(
+        os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"), os.getppid())
+    return os.path.join(d, f"xclim_amd_rccl_{key}.id")
+
+
+class Comm:
+    """One RCCL communicator over the ranks of a launch (one process per GPU), on a Device's context.
+
+    ``Comm.from_env(dev)`` reads RANK / WORLD_SIZE (as set by torch.distributed.run, mpirun wrappers, ...) and does the
+    file rendezvous; ``all_gather`` / ``fence`` / ``sync`` / ``allreduce`` / ``barrier`` map one to one onto xh_comm_*."""
+
+    ID_BYTES = 128
+
+    def __init__(self, dev, world: int, rank: int, unique_id: bytes):
+        if len(unique_id) != self.ID_BYTES:
+            raise ValueError("unique_id must be 128 bytes")
+        self.dev, self.world, self.rank = dev, int(world), int(rank)
+        buf = C.create_string_buffer(unique_id, self.ID_BYTES)
+        h = C.c_void_p()
+        dev.call("xh_comm_init", self.world, self.rank, C.cast(buf, C.c_void_p), C.byref(h))
+        self.handle = h
+
+    @staticmethod
+    def new_unique_id(dev) -> bytes:
+        from ._capi import _check
+
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        _check(dev.lib, dev.lib.xh_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    @classmethod
+    def from_env(cls, dev, timeout_s: float = 300.0) -> "Comm":
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        path = _rendezvous_path()
+        if rank == 0:
+            uid = cls.new_unique_id(dev)
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as f:
+                f.write(uid)
+            os.replace(tmp, path)  # atomic: readers see the whole id or nothing
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    with open(path, "rb") as f:
+                        uid = f.read()
+                    if len(uid) == cls.ID_BYTES:
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > timeout_s:
+                    raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s:.0f} s")
+                time.sleep(0.02)
+        comm = cls(dev, world, rank, uid)  # collective: returns once every rank has joined (and so has read the file)
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        return comm
+
+    def _call(self, name, *args):
+        from ._capi import _check
+
+        with self.dev.lock:
+            _check(self.dev.lib, getattr(self.dev.lib, name)(self.handle, *args))
+
+    def all_gather(self, send, recv, slot: int = -1) -> None:
+        """recv (device, world * send.nbytes) <- every rank's `send` (device); slot >= 0: overlapped (see the header)."""
+        if recv.nbytes != self.world * send.nbytes:
+            raise ValueError("all_gather: recv must hold world * send.nbytes bytes")
+        self._call("xh_comm_allgather", C.c_void_p(send.ptr), C.c_void_p(recv.ptr), send.nbytes, int(slot))
+
+    def fence(self, slot: int) -> None:
+        self._call("xh_comm_fence", int(slot))
+
+    def sync(self) -> None:
+        self._call("xh_comm_sync")
+
+    def barrier(self) -> None:
+        self._call("xh_comm_barrier")
+
+    def allreduce(self, values, op: str = "max"):
+        v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64)
+        self._call("xh_comm_allreduce_f64", v.ctypes.data_as(C.POINTER(C.c_double)), len(v), {"sum": 0, "max": 2, "min": 3}[op])
+        return v
+
+    def gather_cells(self, local, ncells: int, align: int = 4, out=None):
+        """All-gather per-rank (P, c_local) device arrays (slabs of `shard_bounds`) into (world, P, cmax) on every rank:
+        rank r's slab is out[r, :, : c1 - c0].  Slabs are padded to the largest one so that one fixed-size collective
+        suffices; returns (out, bounds)."""
+        bounds = all_bounds(ncells, self.world, align)
+        cmax = max(b - a for a, b in bounds)
+        P, cl = local.shape
+        send = local
+        if cl != cmax:
+            send = self.dev.zeros((P, cmax), local.dtype)
+            isz = np.dtype(local.dtype).itemsize
+            self.dev.copy2d(send.ptr, cmax * isz, local.ptr, cl * isz, cl * isz, P, "d2d", blocking=False)
+        if out is None:
+            out = self.dev.empty((self.world, P, cmax), local.dtype)
+        self.all_gather(send, out)
+        return out, bounds
+
+    def close(self) -> None:
+        if self.handle:
+            self.dev.lib.xh_comm_destroy(self.handle)
+            self.handle = None
