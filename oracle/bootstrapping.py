@@ -49,9 +49,12 @@ def _replace_block(base, bloc_idx, src_idx, time: OTime):
 
 
 def bootstrap_exceedance(da, time: OTime, base_years, freq, op=">", window=5, per=90.0, alpha=1.0 / 3.0, beta=1.0 / 3.0,
-                         index_fn=None):
+                         index_fn=None, per_out=None):
     """tx90p-style index with bootstrap=True.  Returns float64 (P, ...) counts (non-integer inside the base period).
-    `index_fn(x, per, per_doys, time)` replaces the exceedance count (e.g. days_over_precip_thresh)."""
+    `index_fn(x, per, per_doys, time)` replaces the exceedance count (e.g. days_over_precip_thresh).
+    `per_out = (per_da, per_doys)`: the percentile the caller supplied, used for the years outside the overlap of `da`
+    with the base period (bootstrapping.py:196-199); default: percentile_doy of the overlap (the two coincide when the
+    percentile was computed from `da` itself)."""
     da = np.asarray(da)
     y0, y1 = base_years
     in_base = (time.year >= y0) & (time.year <= y1)
@@ -62,7 +65,7 @@ def bootstrap_exceedance(da, time: OTime, base_years, freq, op=">", window=5, pe
         raise KeyError("`bootstrap` is unnecessary when no year overlap between reference and studied periods.")
     base = da[bidx]
     tbase = time.isel(bidx)
-    per_da, per_doys = ocal.percentile_doy(base, tbase, window, per, alpha, beta)
+    per_da, per_doys = per_out if per_out is not None else ocal.percentile_doy(base, tbase, window, per, alpha, beta)
     bfreq = bootstrap_freq(freq)
     base_groups = groups(tbase, bfreq)
     base_year_labels = set(tbase.year.tolist())

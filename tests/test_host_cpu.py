@@ -98,6 +98,36 @@ def test_library_exports_every_header_symbol():
     assert lib.xh_device_count(ctypes.byref(n)) == 0 and n.value >= 0
 
 
+def test_comm_entry_points_validate_arguments(monkeypatch, tmp_path):
+    """xh_comm_* (RCCL behind the C ABI, multi-GPU exchange): argument validation happens before librccl is touched, so
+    it can be driven on a GPU-less host; the rendezvous file name is unique per launch and shared by its ranks."""
+    lib = _capi.load_library()
+    null = ctypes.c_void_p(0)
+    assert lib.xh_comm_unique_id(null) == _capi.XH_ERR_ARG
+    h = ctypes.c_void_p()
+    buf = ctypes.create_string_buffer(128)
+    assert lib.xh_comm_init(null, 2, 0, ctypes.cast(buf, ctypes.c_void_p), ctypes.byref(h)) == _capi.XH_ERR_ARG
+    assert b"NULL" in lib.xh_last_error()
+    assert lib.xh_comm_allgather(null, null, null, 16, -1) == _capi.XH_ERR_ARG
+    assert lib.xh_comm_fence(null, 0) == _capi.XH_ERR_ARG
+    assert lib.xh_comm_sync(null) == _capi.XH_ERR_ARG
+    assert lib.xh_comm_barrier(null) == _capi.XH_ERR_ARG
+    one = ctypes.c_double(1.0)
+    assert lib.xh_comm_allreduce_f64(null, ctypes.byref(one), 1, 2) == _capi.XH_ERR_ARG
+    assert lib.xh_comm_destroy(null) == 0  # destroying nothing is fine (like free(NULL))
+    from xclim_amd import shard
+
+    monkeypatch.setenv("XH_RENDEZVOUS_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    a = shard._rendezvous_path()
+    assert a.startswith(str(tmp_path)) and str(os.getppid()) in a and "29511" in a
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    assert shard._rendezvous_path() != a
+    monkeypatch.setenv("XH_RENDEZVOUS_KEY", "job42")
+    assert shard._rendezvous_path().endswith("xclim_amd_rccl_job42.id")
+
+
 def test_no_cpu_fallback_without_device():
     """The product path fails loudly when no GPU is visible (no silent CPU fallback)."""
     if _capi.device_count() > 0:
@@ -128,6 +158,13 @@ def test_operator_validation():
 
 
 # ---- synthetic generator ---------------------------------------------------------------------------------------------
+def test_get_op_accepts_a_string_constrain():
+    """gen:289-290: `constrain` may be a single operator string; '>=' must not be read as the two operators '>' and '='."""
+    assert generic.get_op(">=", constrain=">=") == ">="
+    with pytest.raises(ValueError, match="not permitted"):
+        generic.get_op(">", constrain=">=")
+
+
 def test_synthetic_generator_is_counter_based():
     base = synth.seasonal_base(50)
     a = synth.fill_synthetic(50, np.arange(100, 140), 0, 7, base, 3.0, nan_per_million=20000)

@@ -32,6 +32,8 @@ def get_op(op: str, constrain=None) -> str:
     else:
         raise ValueError(f"Operation `{op}` not recognized.")
     if constrain:
+        if isinstance(constrain, str):  # gen:289-290 accepts a bare string: do not iterate over its characters
+            constrain = [constrain]
         allowed = list(constrain) + [binary_ops[c] for c in constrain if c in binary_ops]
         if op not in allowed:
             raise ValueError(f"Operation `{op}` not permitted for indice.")

@@ -109,7 +109,6 @@ def _tx90p(tasmax, tasmax_per: DoyPercentile, time: TimeAxis, freq: str = "YS", 
     return _percentile_count(tasmax, tasmax_per, time, freq, op, (">", ">="), device, mask_missing)
 
 
-_tx90p._default_op = ">"
 tx90p = percentile_bootstrap(_tx90p)
 tg90p = tn90p = tx90p
 
@@ -120,7 +119,6 @@ def _tx10p(tasmax, tasmax_per: DoyPercentile, time: TimeAxis, freq: str = "YS", 
     return _percentile_count(tasmax, tasmax_per, time, freq, op, ("<", "<="), device, mask_missing)
 
 
-_tx10p._default_op = "<"
 tx10p = percentile_bootstrap(_tx10p)
 tg10p = tn10p = tx10p
 
@@ -171,17 +169,21 @@ def _percentile_spell(da, per: DoyPercentile, window, time, freq, resample_befor
     return _masked(out, val, time, freq, dev, cell_shape, mask_missing)
 
 
-def warm_spell_duration_index(tasmax, tasmax_per: DoyPercentile, time: TimeAxis, window: int = 6, freq: str = "YS",
-                              resample_before_rl: bool = True, op: str = ">", *, device=None, mask_missing=True):
+def _warm_spell_duration_index(tasmax, tasmax_per: DoyPercentile, time: TimeAxis, window: int = 6, freq: str = "YS",
+                               resample_before_rl: bool = True, op: str = ">", *, device=None, mask_missing=True):
     """indices/_multivariate.py:1693-1793: days that are part of a spell of at least `window` consecutive days with
-    tasmax above its day-of-year percentile."""
+    tasmax above its day-of-year percentile.  ``bootstrap=True`` as in tx90p (decorated at :1718 in the reference)."""
     return _percentile_spell(tasmax, tasmax_per, window, time, freq, resample_before_rl, op, (">", ">="), device, mask_missing)
 
 
-def cold_spell_duration_index(tasmin, tasmin_per: DoyPercentile, time: TimeAxis, window: int = 6, freq: str = "YS",
-                              resample_before_rl: bool = True, op: str = "<", *, device=None, mask_missing=True):
-    """indices/_multivariate.py:66-152: same with tasmin below its day-of-year percentile."""
+def _cold_spell_duration_index(tasmin, tasmin_per: DoyPercentile, time: TimeAxis, window: int = 6, freq: str = "YS",
+                               resample_before_rl: bool = True, op: str = "<", *, device=None, mask_missing=True):
+    """indices/_multivariate.py:66-152: same with tasmin below its day-of-year percentile (``bootstrap=True``: :68)."""
     return _percentile_spell(tasmin, tasmin_per, window, time, freq, resample_before_rl, op, ("<", "<="), device, mask_missing)
+
+
+warm_spell_duration_index = percentile_bootstrap(_warm_spell_duration_index)
+cold_spell_duration_index = percentile_bootstrap(_cold_spell_duration_index)
 
 
 def _precip_over(pr, pr_per, time, freq, thresh, op, want, device, mask_missing):
@@ -219,8 +221,6 @@ def _fraction_over_precip_thresh(pr, pr_per, time: TimeAxis, freq: str = "YS", o
     return _precip_over(pr, pr_per, time, freq, thresh, op, "frac", device, mask_missing)
 
 
-_days_over_precip_thresh._default_op = _fraction_over_precip_thresh._default_op = ">"
-_days_over_precip_thresh._bootstrap_stat, _fraction_over_precip_thresh._bootstrap_stat = "count", "frac"
 days_over_precip_thresh = percentile_bootstrap(_days_over_precip_thresh)
 fraction_over_precip_thresh = percentile_bootstrap(_fraction_over_precip_thresh)
 
