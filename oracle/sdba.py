@@ -23,8 +23,11 @@ from scipy.interpolate import interp1d
 from .quantile import nan_quantile
 
 
-def equally_spaced_nodes(n: int) -> np.ndarray:
-    return (np.arange(n) + 0.5) / n
+def equally_spaced_nodes(n: int, eps=None) -> np.ndarray:
+    """xsdba.utils.equally_spaced_nodes: linspace(1/2n, 1 - 1/2n, n), plus the end points eps / 1 - eps when given."""
+    dq = 1.0 / n / 2.0
+    q = np.linspace(dq, 1.0 - dq, n)
+    return q if eps is None else np.insert(np.append(q, 1.0 - eps), 0, eps)
 
 
 def quantile(da, q, axis=0):

@@ -439,6 +439,33 @@ def test_boundary_run_coord(dev, rng, coord):
         xrl.first_run(x, 3, coord=coord, device=dev)
 
 
+def test_boundary_run_coord_true_returns_dates(dev):
+    """coord=True: the time coordinate itself (rl:586-593 via utils.lazy_indexing).  Known answers of the reference:
+    tests/test_run_length.py:314-353 (first_run -> 2000-01-31, per month -> 2000-01-01 / 2000-02-01),
+    :384-402 (last_run -> 2000-02-09); no run -> NaT."""
+    t = np.zeros((60, 2), np.float32)
+    t[30:40] = 2
+    ta = TimeAxis.daily("2000-01-01", 60)
+    out = xrl.first_run(t > 0, window=1, coord=True, time=ta, device=dev)
+    assert out.dtype == np.dtype("datetime64[ns]")
+    np.testing.assert_array_equal(out, np.array(["2000-01-31"] * 2, dtype="datetime64[ns]"))
+    np.testing.assert_array_equal(xrl.last_run(t > 0, window=1, coord=True, time=ta, device=dev),
+                                  np.array(["2000-02-09"] * 2, dtype="datetime64[ns]"))
+    t[0] = 2
+    out = xrl.first_run(t > 0, window=1, coord=True, freq="MS", time=ta, device=dev)
+    np.testing.assert_array_equal(out, np.array([["2000-01-01"] * 2, ["2000-02-01"] * 2], dtype="datetime64[ns]"))
+    t[:, 1] = 0
+    out = xrl.first_run(t > 0, window=3, coord=True, time=ta, device=dev)
+    assert out[0] == np.datetime64("2000-01-31") and np.isnat(out[1])
+    # season start / end as dates; calendars without datetime64 (360_day has Feb 30) give ISO strings / None
+    c = np.zeros((720, 1), np.float32)
+    c[40:400] = 1
+    t360 = TimeAxis.daily("2001-01-01", 720, "360_day")
+    s = xrl.season(c > 0, 3, coord=True, time=t360, device=dev)
+    assert s["start"][0] == "2001-02-11" and s["end"][0] == "2002-02-11"
+    assert xrl.first_run(np.zeros((720, 1), np.float32), 3, coord=True, time=t360, device=dev)[0] is None
+
+
 def test_device_mask_chaining_and_dtype_guard(dev, rng):
     """compare(..., keep=True) hands a float32 device mask to the run-length mirrors (the drop-in chain
     cond = compare(...); rl.rle_statistics(cond, ...) without leaving the device); a uint8 / float64 device buffer is

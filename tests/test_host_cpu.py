@@ -158,6 +158,16 @@ def test_operator_validation():
 
 
 # ---- synthetic generator ---------------------------------------------------------------------------------------------
+def test_equally_spaced_nodes():
+    """xsdba.utils.equally_spaced_nodes: centres of n equal bins, optionally with the end points eps / 1 - eps."""
+    from xclim_amd.sdba import equally_spaced_nodes
+
+    np.testing.assert_allclose(equally_spaced_nodes(4), [0.125, 0.375, 0.625, 0.875])
+    q = equally_spaced_nodes(20, eps=1e-6)
+    assert len(q) == 22 and q[0] == 1e-6 and q[-1] == 1 - 1e-6
+    np.testing.assert_allclose(q[1:-1], (np.arange(20) + 0.5) / 20)
+
+
 def test_get_op_accepts_a_string_constrain():
     """gen:289-290: `constrain` may be a single operator string; '>=' must not be read as the two operators '>' and '='."""
     assert generic.get_op(">=", constrain=">=") == ">="

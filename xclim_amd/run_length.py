@@ -253,11 +253,7 @@ def season(da, window: int, mid_date: str | None = None, dim="time", stat=None, 
                 mid[p] = idx[0]
     s, e, ln = (a.get() for a in K.season(dev, m, window, seg, mid))
     if coord:
-        table = _coord_table(time, coord)
-        for arr in (s, e):
-            for p in range(P):
-                ok = ~np.isnan(arr[p])
-                arr[p, ok] = table[int(seg[p]) + arr[p, ok].astype(np.int64)]
+        s, e = _to_coord(s, seg, coord, time), _to_coord(e, seg, coord, time)
     shp = (P,) + tuple(cell_shape)
     out = {"start": s.reshape(shp), "end": e.reshape(shp), "length": ln.reshape(shp)}
     if freq is None:
@@ -311,14 +307,24 @@ def _coord_table(time: TimeAxis, coord) -> np.ndarray:
     """The 1-D array that ``coord`` selects on the time axis (rl:690, 740: ``da[dim].dt.<coord>`` looked up at the run's
     index through utils.lazy_indexing).  The lookup itself is host work on (period, cell) results."""
     names = {"dayofyear": "doy", "year": "year", "month": "month", "day": "day"}
-    if coord is True or coord not in names:
-        raise NotImplementedError(f"coord={coord!r}: supported datetime fields are {sorted(names)}")
+    if coord is True:
+        return time.dates()  # rl:589-592: the coordinate itself (dates)
+    if coord not in names:
+        raise NotImplementedError(f"coord={coord!r}: supported are True (dates) and the datetime fields {sorted(names)}")
     return np.asarray(getattr(time, names[coord]))
 
 
 def _to_coord(res, seg, coord, time):
+    """Indices (relative to the period start, NaN = no run) -> coordinate values at those steps.  ``coord=True`` gives the
+    dates themselves: datetime64[ns] with NaT where there is no run (strings / None for calendars without datetime64)."""
     if coord:
         table = _coord_table(time, coord)
+        if coord is True:
+            dates = np.full(res.shape, np.datetime64("NaT") if table.dtype.kind == "M" else None, dtype=table.dtype)
+            for p in range(res.shape[0]):
+                ok = ~np.isnan(res[p])
+                dates[p, ok] = table[int(seg[p]) + res[p, ok].astype(np.int64)]
+            return dates
         for p in range(res.shape[0]):
             ok = ~np.isnan(res[p])
             res[p, ok] = table[int(seg[p]) + res[p, ok].astype(np.int64)]

@@ -20,10 +20,13 @@ ADDITIVE, MULTIPLICATIVE = "+", "*"
 
 
 def equally_spaced_nodes(n: int, eps=None) -> np.ndarray:
-    """xsdba.utils.equally_spaced_nodes: q_i = (i + 1/2) / n (no end points when eps is None)."""
-    if eps is not None:
-        raise NotImplementedError("eps end-point nodes are not supported")
-    return (np.arange(n) + 0.5) / n
+    """xsdba.utils.equally_spaced_nodes: n nodes q_i = (i + 1/2) / n; with ``eps`` the end points eps and 1 - eps are
+    added (n + 2 nodes), so that the adjustment factors are also defined near the ends of the distribution."""
+    dq = 1.0 / n / 2.0
+    q = np.linspace(dq, 1.0 - dq, n)
+    if eps is None:
+        return q
+    return np.insert(np.append(q, 1.0 - eps), 0, eps)
 
 
 def quantile(da, q, dim="time", *, device=None, keep=False):

@@ -110,6 +110,16 @@ class TimeAxis:
                 y += 1
         return cls(years, months, days, calendar)
 
+    def dates(self) -> np.ndarray:
+        """The time coordinate itself (what ``coord=True`` returns in the reference, rl:586-593 -> utils.lazy_indexing):
+        ``datetime64[ns]`` when every date of the calendar is a Gregorian date (standard, proleptic_gregorian, noleap);
+        for all_leap / 360_day calendars — whose Feb 29 / Feb 30 have no datetime64 — ISO ``YYYY-MM-DD`` strings (cftime,
+        the reference's type for them, is not a dependency)."""
+        iso = np.array([f"{y:04d}-{m:02d}-{d:02d}" for y, m, d in zip(self.year, self.month, self.day)])
+        if self.calendar in ("standard", "gregorian", "proleptic_gregorian", "noleap", "365_day"):
+            return iso.astype("datetime64[ns]")
+        return iso.astype(object)
+
     def subset(self, sl) -> "TimeAxis":
         out = TimeAxis.__new__(TimeAxis)
         out.year, out.month, out.day, out.doy = self.year[sl], self.month[sl], self.day[sl], self.doy[sl]
