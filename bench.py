@@ -39,7 +39,7 @@ def pmc_traffic(kernel, grid):
     valid for the grid the profile was taken on (365x1440x720); None otherwise."""
     if tuple(grid) != (365, 1440, 720):
         return None
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic.json")
     try:
         table = json.load(open(path))
     except (OSError, ValueError):

@@ -55,7 +55,23 @@ int xh_create(int device, xh_ctx** out) {
   XH_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   XH_CHECK_HIP(hipEventCreate(&ctx->ev0));
   XH_CHECK_HIP(hipEventCreate(&ctx->ev1));
-  XH_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  {
+    // the helper stream of the transposed-batch pipeline (eqm.hip): optionally at the highest priority, so that its
+    // (memory-bound) transposes are dispatched into the slots the latency-bound selection workgroups free up
+    const char* pr = xh_diag_env("XH_STREAM2_PRIO");
+    const char* cm = xh_diag_env("XH_STREAM2_CUMASK_STRIDE");  // tuning: helper stream restricted to every k-th CU
+    int least = 0, greatest = 0;
+    if (cm && atoi(cm) > 1) {
+      const int k = atoi(cm);
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < 256; ++i)
+        if (i % k == 0) mask[i / 32] |= 1u << (i % 32);
+      XH_CHECK_HIP(hipExtStreamCreateWithCUMask(&ctx->stream2, 8, mask));
+    } else if (pr && atoi(pr) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+      XH_CHECK_HIP(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest));
+    else
+      XH_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  }
   for (int i = 0; i < 2; ++i) {
     XH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_ready[i], hipEventDisableTiming));
     XH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));

@@ -66,13 +66,27 @@ __global__ void __launch_bounds__(256, 2)
 k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const double* __restrict__ qs, int nq,
                  float* __restrict__ out, int64_t ocs, int64_t oqs, int force_irregular, int abl) {
   static_assert(N == XH_SN_N, "sortnet header generated for another N");
-  __shared__ double qS[MAXQ];
-  __shared__ int rkS[2 * MAXQ + 4];             // rkS[j + 2] = rank of target j when every sample is valid (n = T)
-  __shared__ uint32_t valsS[4][2 * MAXQ * 32];  // per wave: picked keys, [target][column of the tile]
-  __shared__ uint32_t ncolS[4][32];             // per wave: valid count per column of the tile
+  // LDS (dynamic, 16-byte aligned carve): per block q / gamma tables and the n = T rank table; per wave the valid counts
+  // of the tile's columns, the picked keys [target][column] and a 32-register hand-over buffer [register][lane]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* qS = reinterpret_cast<double*>(smem);                 // [MAXQ] quantiles
+  double* gS = qS + MAXQ;                                       // [MAXQ] gamma of quantile q when n = T
+  double* g1S = gS + MAXQ;                                      // [MAXQ] 1 - gamma
+  int* modeS = reinterpret_cast<int*>(g1S + MAXQ);              // [MAXQ] 0: left only, 1: left + d*g, 2: right - d*(1-g)
+  int* rkS = modeS + MAXQ;                                      // [2*MAXQ + 4] rkS[j + 2] = rank of target j when n = T
+  uint32_t* wave0 = reinterpret_cast<uint32_t*>(rkS + 2 * MAXQ + 4);
+  const int per_wave = 32 + 2 * nq * 32 + 32 * 64;              // words
   const int tid = threadIdx.x, w = tid >> 6;
   const int ntgt = 2 * nq;
-  if (tid < nq) qS[tid] = qs[tid];
+  if (tid < nq) {
+    const double qq = qs[tid], nn = (double)T;
+    const double vi = nn * qq + (1.0 + qq * (1.0 - 1.0 - 1.0)) - 1.0;  // utl:395, alpha = beta = 1
+    const double gamma = vi - floor(vi);
+    qS[tid] = qq;
+    gS[tid] = gamma;
+    g1S[tid] = 1.0 - gamma;
+    modeS[tid] = (vi >= nn - 1.0 || vi < 0.0) ? 0 : (gamma >= 0.5 ? 2 : 1);  // utl:464-491
+  }
   if (tid < ntgt + 4)
     rkS[tid] = (tid < 2 || tid >= ntgt + 2) ? RK_SENTINEL : hf7_rank((uint32_t)T, qs[(tid - 2) >> 1], (tid - 2) & 1);
   __syncthreads();
@@ -82,8 +96,9 @@ k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, cons
   int jA[2] = {0, 0};
   for (int j = 0; j < ntgt; ++j) jA[j & 1] += rkS[j + 2] < N ? 1 : 0;
 
-  uint32_t* vals = valsS[w];
-  uint32_t* ncol = ncolS[w];
+  uint32_t* ncol = wave0 + w * per_wave;
+  uint32_t* vals = ncol + 32;
+  uint32_t* dump = vals + 2 * nq * 32;
   const int64_t ntiles = (C + 31) / 32;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const uint32_t strideB = (uint32_t)(st * 4);
@@ -226,29 +241,33 @@ k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, cons
       return h ? (uint32_t)(r - N) : (uint32_t)(N - 1 - r);
     };
     // Both lanes meet the targets of one parity in order of INCREASING register index: B walks them upwards, A (whose
-    // local order is reversed) downwards.  32 registers at a time; the wanted one comes out of a 5-level select tree on
-    // the bits of the index (31 v_cndmask, lanes may want different registers) — a compare-and-branch per register costs
-    // 13 KB of code and pushes the kernel out of the instruction cache; a dynamically indexed vector is expanded by the
-    // compiler into 32 compares + 32 selects.
-#define XH_PICK(c)                                                                            \
-  while ((snext >> 5) == (uint32_t)(c)) {                                                     \
-    const bool b0 = snext & 1u, b1 = snext & 2u, b2 = snext & 4u, b3 = snext & 8u, b4 = snext & 16u; \
-    uint32_t v_;                                                                              \
-    XH_SN_SEL_##c(v_, b0, b1, b2, b3, b4)                                                     \
-    vals[jcur * 32 + (int)c32] = v_ ^ mA;                                                     \
-    jcur += dj;                                                                               \
-    snext = local_of(jcur);                                                                   \
+    // local order is reversed) downwards.  The registers are handed to LDS 32 at a time ([register][lane]: conflict-free
+    // stores with immediate offsets) and the wanted one is read back with a per-lane address — no VALU work per
+    // register.  (Earlier forms: a compare-and-branch per register = 13 KB of code, out of the instruction cache; a
+    // 31-v_cndmask select tree per pick = 0.11 of the kernel's 0.78 ms.)
+    int jcur0 = h ? 2 * myA[0] : 2 * (myA[0] - 1), jcur1 = (h ? 2 * myA[1] : 2 * (myA[1] - 1)) + 1;
+    const int dj = h ? 2 : -2;
+    uint32_t snext0 = local_of(jcur0), snext1 = local_of(jcur1);
+    uint32_t* mydump = dump + lane4;
+#define XH_DW(e, reg) mydump[(e) * 64] = reg;
+#define XH_PICK(c)                                                     \
+  if (!(abl & 4)) {                                                    \
+    XH_SN_DUMP_##c(XH_DW)                                              \
+    while ((snext0 >> 5) == (uint32_t)(c)) {                           \
+      vals[jcur0 * 32 + (int)c32] = mydump[(snext0 & 31u) * 64] ^ mA;  \
+      jcur0 += dj;                                                     \
+      snext0 = local_of(jcur0);                                        \
+    }                                                                  \
+    while ((snext1 >> 5) == (uint32_t)(c)) {                           \
+      vals[jcur1 * 32 + (int)c32] = mydump[(snext1 & 31u) * 64] ^ mA;  \
+      jcur1 += dj;                                                     \
+      snext1 = local_of(jcur1);                                        \
+    }                                                                  \
   }
-#pragma nounroll
-    for (int par = (abl & 4) ? 2 : 0; par < 2; ++par) {
-      const int mine = par ? myA[1] : myA[0];
-      int jcur = (h ? 2 * mine : 2 * (mine - 1)) + par;
-      const int dj = h ? 2 : -2;
-      uint32_t snext = local_of(jcur);
-      XH_PICK(0) XH_PICK(1) XH_PICK(2) XH_PICK(3) XH_PICK(4) XH_PICK(5)
-    }
+    XH_PICK(0) XH_PICK(1) XH_PICK(2) XH_PICK(3) XH_PICK(4) XH_PICK(5)
     static_assert(XH_SN_CHUNKS == 6, "XH_PICK chunks");
 #undef XH_PICK
+#undef XH_DW
     wave_fence();
     // ---- Hyndman-Fan lerp (utl:464-491) and stores: 32 columns x nq quantiles spread over the wave
     uint32_t lane2 = (uint32_t)tid & 63u;
@@ -262,7 +281,13 @@ k_select_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, cons
         double r;
         if (n == 0) r = xh_nan64();
         else if (n < 2) r = (double)left;
-        else {
+        else if (n == (uint32_t)T) {  // the usual case: gamma and the branch of utl:464-491 come from the per-q tables
+          const int mode = modeS[q];
+          const float diff = right - left;
+          r = (double)left;
+          if (mode == 1) r = (double)left + (double)diff * gS[q];
+          if (mode == 2) r = (double)right - (double)diff * g1S[q];
+        } else {
           const double nn = (double)n, qq = qS[q];
           const double vi = nn * qq + (1.0 + qq * (1.0 - 1.0 - 1.0)) - 1.0;
           if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
@@ -296,8 +321,12 @@ int xh_select_regsort(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t
   int64_t nblk = (ntiles + 3) / 4;
   const int64_t maxblk = (int64_t)ctx->num_cu * 2;  // two 256-thread workgroups per CU (256 VGPRs per lane)
   if (nblk > maxblk) nblk = maxblk;
-  hipLaunchKernelGGL((k_select_regsort<N, TMIN>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, x, (int)T, C, st, d_q, nq,
-                     out, out_cstride, out_qstride, fi ? atoi(fi) : 0, ea ? atoi(ea) : 0);
+  const size_t lds = 3 * MAXQ * sizeof(double) + (MAXQ + 2 * MAXQ + 4) * sizeof(int) +
+                     4 * (size_t)(32 + 2 * nq * 32 + 32 * 64) * sizeof(uint32_t);
+  auto kern = k_select_regsort<N, TMIN>;
+  if (lds > 64 * 1024) XH_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, x, (int)T, C, st, d_q, nq, out, out_cstride,
+                     out_qstride, fi ? atoi(fi) : 0, ea ? atoi(ea) : 0);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }
