@@ -337,6 +337,14 @@ int xh_suspicious_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t
 int xh_nan_quantile(xh_ctx* ctx, const float* x, int64_t N, int64_t C, int64_t sn, int64_t sc, const double* q,
                     int nq, double alpha, double beta, double* out);
 
+/* Weighted quantiles over the first axis (ensemble_percentiles with `weights`, ensembles/_base.py:346-356, which calls
+ * xarray's DataArrayWeighted.quantile: Kish effective sample size + type-7 weighted estimator, NaN samples and zero
+ * weights dropped).  x (N, C) member-major (sc == 1), weights[N] / q[nq] on the host, out (nq, C) float64; N <= 128.
+ * PARITY UNPINNED (the arithmetic is xarray's, restated from its published form; equal weights reproduce
+ * xh_nan_quantile with alpha = beta = 1). */
+int xh_weighted_quantile(xh_ctx* ctx, const float* x, int64_t N, int64_t C, int64_t sn, int64_t sc,
+                         const double* weights /* host */, const double* q /* host */, int nq, double* out);
+
 /* percentile_doy (core/calendar.py:395-494) before the 366-day adjustment: for each day-of-year row d
  * and year y, tbase[y * ndoy + d] is the time index of that calendar day (or -1 if the year lacks it);
  * the sample set is x[tbase - window/2 .. tbase + window - 1 - window/2] over all years (NaN outside

@@ -511,6 +511,39 @@ def test_percentile_spell_indices(dev, rng, calendar, T, before):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R", [3, 11, 40, 128])
+def test_weighted_ensemble_percentiles(dev, rng, R):
+    """ensembles/_base.py:346-356: with `weights` the reference calls xarray's weighted quantile (PARITY UNPINNED: xarray is
+    not available; oracle and kernel restate its published algorithm).  Pinned analytically: equal weights reproduce the
+    unweighted "linear" (type 7) percentiles; a zero weight removes the member; NaN members are skipped; only "linear"."""
+    from oracle import ensembles as oens
+    from xclim_amd import ensembles as xens
+
+    ens = rng.normal(10, 3, (R, 5, 9)).astype(np.float32)
+    ens[rng.random(ens.shape) < 0.1] = np.nan
+    ens[:, 0, 0] = np.nan
+    vals = [5, 10, 50, 90, 99]
+    w = rng.random(R) + 0.1
+    got = xens.ensemble_percentiles(ens, vals, weights=w, device=dev)
+    np.testing.assert_allclose(got, oens.ensemble_percentiles(ens, vals, weights=w), rtol=1e-12, atol=1e-12, equal_nan=True)
+    assert np.isnan(got[0, 0]).all()
+    # equal weights == the unweighted estimator (both the oracle's calc_perc, pinned to the reference, and the HIP path)
+    eq = xens.ensemble_percentiles(ens, vals, weights=np.full(R, 2.5), device=dev)
+    np.testing.assert_allclose(eq, oens.ensemble_percentiles(ens, vals), rtol=1e-6, equal_nan=True)
+    # a zero weight drops the member
+    w0 = w.copy()
+    w0[0] = 0.0
+    np.testing.assert_allclose(xens.ensemble_percentiles(ens, vals, weights=w0, device=dev),
+                               xens.ensemble_percentiles(ens[1:], vals, weights=w[1:], device=dev), rtol=1e-12, equal_nan=True)
+    mm = xens.ensemble_percentiles(ens, vals, weights=w, min_members=R, device=dev)
+    assert np.isnan(mm[np.isnan(ens).any(axis=0)]).all()
+    with pytest.raises(ValueError, match="Only the 'linear' method"):
+        xens.ensemble_percentiles(ens, vals, weights=w, method="hazen", device=dev)
+    if R == 128:
+        with pytest.raises(Exception):
+            xens.ensemble_percentiles(np.zeros((129, 4), np.float32), vals, weights=np.ones(129), device=dev)
+
+
 @pytest.mark.parametrize("method", ["linear", "median_unbiased", "weibull", "hazen"])
 @pytest.mark.parametrize("R", [5, 21, 60])
 def test_ensemble_percentiles(dev, rng, method, R):
@@ -531,8 +564,9 @@ def test_ensemble_percentiles(dev, rng, method, R):
     lin = np.arange(R, dtype=np.float32)[:, None]
     got = xens.ensemble_percentiles(lin, [0, 50, 100], device=dev)
     np.testing.assert_allclose(got[0], [0, (R - 1) / 2, R - 1], rtol=1e-12)
-    with pytest.raises(NotImplementedError):
-        xens.ensemble_percentiles(ens, weights=np.ones(R), device=dev)
+    if method != "linear":  # _base.py:347-348
+        with pytest.raises(ValueError, match="Only the 'linear' method"):
+            xens.ensemble_percentiles(ens, weights=np.ones(R), method=method, device=dev)
 
 
 @pytest.mark.gpu

@@ -105,3 +105,34 @@ def test_blocks_register_and_errors(dev, rng):
         map_cell_blocks(lambda d, xs: K.transpose(d, xs), [x], block_cells=32, device=dev)  # not (R, slab)
     with pytest.raises(ValueError):
         map_cell_blocks(f, [np.asfortranarray(x)], device=dev)
+
+
+def test_dask_style_map_blocks(dev, rng):
+    """xclim_amd.dask_adapter: index functions as map_blocks callees (the role xr.map_blocks / apply_ufunc(dask=
+    "parallelized") play in the reference, indices/helpers.py:898-974).  dask is not installed here: the numpy walk over
+    a dask-style chunk grid drives the SAME callee that dask.array.map_blocks would call per chunk; ragged chunk edges,
+    one- and two-variable indices, percentile-free thresholds; stitched results equal the unchunked call."""
+    from xclim_amd import dask_adapter as xda
+    from xclim_amd import indices as xi
+    from xclim_amd.timeaxis import TimeAxis
+
+    T, Y, X = 730, 13, 21
+    ta = TimeAxis.daily("2001-01-01", T, "noleap")
+    tas = (285 + 8 * rng.standard_normal((T, Y, X))).astype(np.float32)
+    tas[rng.random(tas.shape) < 0.002] = np.nan
+    tasmax = tas + np.abs(rng.normal(3, 1, tas.shape)).astype(np.float32)
+    for name, args, kw, arrs in (("tx_days_above", (), dict(thresh=290.0, freq="MS"), [tasmax]),
+                                 ("tg_mean", (), dict(freq="YS"), [tas]),
+                                 ("maximum_consecutive_tx_days", (), dict(thresh=288.0, freq="YS"), [tasmax]),
+                                 ("daily_temperature_range", (), dict(freq="QS-DEC"), [tas, tasmax])):
+        full = getattr(xi, name)(*arrs, *args, time=ta, device=dev, **kw)
+        for chunks in ((5, 8), (13, 21), ((4, 9), (10, 10, 1))):
+            got = xda.map_blocks(name, arrs, ta, *args, chunks=chunks, device=dev, **kw)
+            np.testing.assert_array_equal(got, full, err_msg=f"{name} chunks={chunks}")
+    grid = xda.chunk_grid((13, 21), (5, 8))
+    assert len(grid) == 3 * 3 and grid[-1] == (slice(10, 13), slice(16, 21))
+    f = xda.block_function("tg_mean", ta, freq="YS", device=dev)
+    with pytest.raises(ValueError, match="whole time axis"):
+        f(tas[:100])
+    with pytest.raises(ValueError, match="expected 1 data block"):
+        f(tas, tas)

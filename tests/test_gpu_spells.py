@@ -671,6 +671,32 @@ def test_spell_mask_reference_known_answers(dev):
         xgen.spell_mask(d, 3, "mean", "<=", 2, weights=[1, 2], device=dev)
 
 
+@pytest.mark.parametrize("window", [1, 3, 5, 12])
+@pytest.mark.parametrize("red,op", [("min", ">"), ("max", "<="), ("mean", ">="), ("sum", "<"), ("max", ">")])
+def test_spell_mask_per_cell_thresholds_with_a_window(dev, rng, window, red, op):
+    """gen:434-540 with a threshold that has one value per grid cell (in the reference: a DataArray without the time
+    dimension, as in tests/test_generic.py:754-766) and a window > 1: rolling statistic, per-cell compare, then "part of
+    any window that satisfies the condition".  Masks and the spell statistics built on them equal the oracle."""
+    T, shape = 500, (6, 7)
+    x = (rng.normal(0, 1, (T,) + shape)).astype(np.float32)
+    x[rng.random(x.shape) < 0.01] = np.nan
+    x[:, 0, 0] = np.nan
+    thr = rng.normal(0.0 if red != "sum" else 0.0 * window, 0.5, shape)          # float64, like a DataArray of thresholds
+    got = xgen.spell_mask(x, window, red, op, thr, device=dev)
+    exp = ogen.spell_mask(x, window, red, op, thr)
+    np.testing.assert_array_equal(got, exp)
+    assert 0 < got.mean() < 1
+    got_gap = xgen.spell_mask(x, window, red, op, thr, min_gap=3, device=dev)
+    np.testing.assert_array_equal(got_gap, ogen.spell_mask(x, window, red, op, thr, min_gap=3))
+    ta, ot = TimeAxis.daily("2001-01-01", T), OTime.standard("2001-01-01", T)
+    for before in (True, False):
+        st = xgen.spell_length_statistics(x, thr, window, red, op, "max", ta, "YS", resample_before_rl=before, device=dev)
+        np.testing.assert_array_equal(st, ogen.spell_length_statistics(x, thr, window, red, op, "max", ot, "YS", resample_before_rl=before))
+    if window > 1:
+        with pytest.raises(NotImplementedError):
+            xgen.spell_mask(x, window, "mean", op, thr, weights=[1.0] * window, device=dev)
+
+
 def test_thresholded_events_reference_known_answers(dev):
     """tests/test_generic.py:800-905 (TestThresholdedEvents: simple, different stop window, window_stop 3, freq "MS")
     through the HIP path, and the same numbers from the oracle's find_events on the compare masks."""

@@ -107,6 +107,7 @@ SIGNATURES: dict[str, list] = {
     "xh_season": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, _vp],
     "xh_max_run_sum": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _int, _int, _vp],
     "xh_nan_quantile": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _dbl, _dbl, _vp],
+    "xh_weighted_quantile": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp],
     "xh_percentile_doy": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _vp, _int, _dbl, _dbl, _vp],
     "xh_percentile_doy_mapped": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _vp, _int, _dbl, _dbl, _vp, _i64, _vp],
     "xh_doy_interp": [_vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _int, _vp, _vp],

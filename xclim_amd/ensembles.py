@@ -31,11 +31,10 @@ def ensemble_percentiles(ens, values=None, min_members: int | None = 1, weights=
     Elements with fewer than ``min_members`` valid members are NaN (``None``: all members required)."""
     if values is None:
         values = [10, 50, 90]
-    if weights is not None:
-        raise NotImplementedError("weighted ensemble percentiles go through xarray's weighted quantile in the reference; "
-                                  "not implemented on this backend")
     if method not in _quantile_params:
         raise KeyError(method)
+    if weights is not None and method != "linear":
+        raise ValueError("Only the 'linear' method is supported when using weights.")  # _base.py:347-348
     alpha, beta = _quantile_params[method]
     dev = device or get_device()
     if isinstance(ens, DeviceArray):
@@ -48,7 +47,11 @@ def ensemble_percentiles(ens, values=None, min_members: int | None = 1, weights=
     if min_members is None:
         min_members = R
     q = np.array([v / 100.0 for v in values], dtype=np.float64)
-    out = K.nan_quantile(dev, x, q, alpha, beta, sample_axis=0)  # (nper, C) float64
+    if weights is not None:
+        # _base.py:350-356: xarray's weighted quantile (parity unpinned: xarray is not available; see wquantile.hip)
+        out = K.weighted_quantile(dev, x, weights, q)
+    else:
+        out = K.nan_quantile(dev, x, q, alpha, beta, sample_axis=0)  # (nper, C) float64
     if min_members != 1:
         seg = np.array([0, R], dtype=np.int64)
         nvalid, _ = K.resample_reduce(dev, x, "count", seg, want_valid=False)  # (1, C) int32

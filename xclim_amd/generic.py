@@ -60,8 +60,12 @@ def _cell_threshold(dev, threshold, da):
     shape = tuple(da.shape) if isinstance(da, DeviceArray) else np.shape(da)
     if th.ndim == len(shape) and th.shape[0] == 1:
         th = th[0]
-    if th.shape != tuple(shape[1:]) or th.ndim == 0:
+    if th.ndim == 0:
         return None
+    if th.shape != tuple(shape[1:]):
+        # a flattened device view (T, C) of the data: the threshold still has the caller's cell shape
+        if not (isinstance(da, DeviceArray) and len(shape) == 2 and th.size == shape[1]):
+            return None
     table = dev.to_device(np.ascontiguousarray(th, dtype=np.float64).reshape(1, -1))
     return table, np.zeros(shape[0], dtype=np.int32)
 
@@ -396,7 +400,28 @@ def spell_mask(data, window: int, win_reducer: str, op: str, thresh, min_gap: in
             m = K.spell_mask_multi(dev, xs, window, win_reducer, sym, th, var_reducer, weights)
     else:
         x, cell_shape = _flatten(data, dev)
-        if window == 1:
+        cell = _cell_threshold(dev, thresh, data)
+        if cell is not None:
+            # one threshold per grid cell (a DataArray without the time dim in the reference: tests/test_generic.py:754-766).
+            # The compare runs against the one-row float64 table; with a window the three steps of gen:519-535 are kept
+            # apart: rolling statistic (trailing, NaN until the window is full) -> per-cell compare -> "part of ANY window
+            # that satisfies the condition" = trailing rolling max of the condition read w - 1 steps ahead (zeros behind
+            # the end of the series).
+            if weights is not None:
+                raise NotImplementedError("weighted window means with per-cell thresholds are not supported")
+            table, tidx = cell
+            if window == 1:
+                m = K.compare_doy(dev, x, sym, table, tidx)
+            else:
+                T, C_ = x.shape
+                stat = K.rolling_reduce(dev, x, window, win_reducer, center=False)
+                cond = K.compare_doy(dev, stat, sym, table, tidx)
+                pad = dev.zeros((T + window - 1, C_), np.float32)
+                dev.copy_d2d(pad.ptr, cond.ptr, cond.nbytes)
+                anyw = K.rolling_reduce(dev, pad, window, "max", center=False)
+                m = dev.wrap(anyw.ptr + (window - 1) * C_ * 4, (T, C_), np.float32)
+                m._owner = anyw
+        elif window == 1:
             m = K.spell_mask(dev, x, 1, "min", sym, float(thresh))
         else:
             m = K.spell_mask(dev, x, window, win_reducer, sym, float(thresh), weights)

@@ -381,6 +381,18 @@ def nan_quantile(dev: Device, x: DeviceArray, q, alpha=1.0, beta=1.0, sample_axi
     return out
 
 
+def weighted_quantile(dev: Device, x: DeviceArray, weights, q) -> DeviceArray:
+    """xh_weighted_quantile: x (N, C) member-major -> (nq, C) float64."""
+    N, C_ = _tc(x)
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+    if w.shape != (N,):
+        raise ValueError(f"weights must have one value per member ({N}), got shape {w.shape}")
+    out = dev.empty((len(q), C_), np.float64)
+    dev.call("xh_weighted_quantile", _vp(x.ptr), N, C_, C_, 1, np_ptr(w), np_ptr(q), len(q), _vp(out.ptr))
+    return out
+
+
 def percentile_doy(dev: Device, x: DeviceArray, tbase, window: int, per, alpha=1.0 / 3, beta=1.0 / 3,
                    out=None, vmap=None) -> DeviceArray:
     """Returns (nper, ndoy, C) float64 — percentile_doy before the 366-day adjustment.
