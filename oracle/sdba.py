@@ -71,3 +71,46 @@ def eqm_adjust(sim, af, hist_q, kind="+", interp="nearest", extrapolation="const
         with np.errstate(all="ignore"):
             out[:, c] = s2[:, c] + af_t if kind == "+" else s2[:, c] * af_t
     return out.reshape(sim.shape)
+
+
+# ---- sub-groupings (xsdba.base.Grouper: "time.month", "time.dayofyear" with a window) — specified restatement ----------
+def group_values(time, prop):
+    return np.asarray(time.month if prop == "month" else time.doy)
+
+
+def grouped_sample(x, time, prop, window, label):
+    """Training sample of one group: the centred `window` steps around every time step of the group (NaN beyond the ends
+    of the series), flattened — rolling(time=window, center=True).construct("window") + groupby(prop) in xsdba."""
+    x = np.asarray(x)
+    T = x.shape[0]
+    t = np.nonzero(group_values(time, prop) == label)[0]
+    half = window // 2
+    rows = (t[:, None] + np.arange(-half, half + 1)[None, :]).reshape(-1)
+    ok = (rows >= 0) & (rows < T)
+    out = np.full((len(rows),) + x.shape[1:], np.nan, dtype=x.dtype)
+    out[ok] = x[rows[ok]]
+    return out
+
+
+def eqm_train_grouped(ref, hist, time, prop, window=1, nquantiles=20, kind="+"):
+    """(af, hist_q, labels) with shapes (G, nq, ...)."""
+    q = equally_spaced_nodes(nquantiles) if np.isscalar(nquantiles) else np.asarray(nquantiles, dtype=np.float64)
+    labels = np.unique(group_values(time, prop))
+    afs, hqs = [], []
+    for lab in labels:
+        a, h = eqm_train(grouped_sample(ref, time, prop, window, lab), grouped_sample(hist, time, prop, window, lab), q, kind)
+        afs.append(a)
+        hqs.append(h)
+    return np.stack(afs), np.stack(hqs), labels
+
+
+def eqm_adjust_grouped(sim, time, prop, labels, af, hist_q, kind="+", interp="nearest", extrapolation="constant"):
+    """Every time step is mapped with the factors of its own group."""
+    sim = np.asarray(sim)
+    out = np.empty_like(sim)
+    gv = group_values(time, prop)
+    for g, lab in enumerate(labels):
+        rows = np.nonzero(gv == lab)[0]
+        if rows.size:
+            out[rows] = eqm_adjust(sim[rows], af[g], hist_q[g], kind, interp, extrapolation)
+    return out

@@ -3,9 +3,17 @@ reference shim src/xclim/sdba.py:1-28; object API pinned by tests/test_xsdba.py:
 
 Names follow xsdba: ``EmpiricalQuantileMapping.train(ref, hist, nquantiles=20, kind="+", group="time")`` then
 ``.adjust(sim, interp="nearest", extrapolation="constant")``, with ``ds.af`` / ``ds.hist_q`` exposed as ``.af`` /
-``.hist_q``; ``nbutils.quantile`` and ``utils.equally_spaced_nodes`` as module functions.  Only ``group="time"``
-(no sub-grouping) is supported.  Arrays: TIME ON AXIS 0, numpy or device arrays; all arithmetic is in
-``xh_eqm_train`` / ``xh_eqm_adjust``.
+``.hist_q``; ``nbutils.quantile`` and ``utils.equally_spaced_nodes`` as module functions.  Arrays: TIME ON AXIS 0, numpy
+or device arrays; all arithmetic is in ``xh_eqm_train`` / ``xh_eqm_adjust``.
+
+Grouping (first slice): :class:`Grouper` ``"time"``, ``"time.month"`` and ``"time.dayofyear"`` with
+an odd ``window`` (xsdba: the samples of a group are the centred ``window`` days around every time step of the group —
+the same sample sets as ``percentile_doy``).  Training gathers each group's rows (``xh_select_rows``) and runs the
+per-column multi-quantile kernels on them; ``af`` / ``hist_q`` get a leading group axis ``(group, quantiles, *cells)``.
+``adjust`` maps every time step with the factors of ITS group (rows are permuted group-major once, one ``xh_eqm_adjust``
+launch per group on a contiguous row block, one gather back).  Interpolating the factors BETWEEN groups along time (what
+xsdba does for ``interp != "nearest"`` with monthly groups), ``QuantileDeltaMapping`` / ``DetrendedQuantileMapping``
+(they need per-column ranks of every sample) are not built.  PARITY UNPINNED like everything xsdba (oracle/sdba.py).
 """
 
 from __future__ import annotations
@@ -17,6 +25,56 @@ from ._capi import DeviceArray, get_device
 from .calendar import _flatten
 
 ADDITIVE, MULTIPLICATIVE = "+", "*"
+
+
+class Grouper:
+    """xsdba.base.Grouper for the groupings of the quantile-mapping path: ``Grouper("time")``, ``Grouper("time.month")``,
+    ``Grouper("time.dayofyear", window=31)``."""
+
+    def __init__(self, group: str = "time", window: int = 1):
+        if isinstance(group, Grouper):
+            group, window = group.name, group.window
+        if group not in ("time", "time.month", "time.dayofyear"):
+            raise NotImplementedError(f"group={group!r}: supported are 'time', 'time.month', 'time.dayofyear'")
+        if window < 1 or window % 2 == 0:
+            raise ValueError("window must be a positive odd number of time steps")
+        if group == "time" and window != 1:
+            raise ValueError("a window needs a sub-grouping ('time.month' / 'time.dayofyear')")
+        self.name, self.window = group, int(window)
+        self.prop = group.split(".")[1] if "." in group else "group"
+
+    def __repr__(self):
+        return f"Grouper(name={self.name!r}, window={self.window})"
+
+    def labels(self, time) -> np.ndarray:
+        """Group coordinate values present on `time` (months 1..12 / days of year), sorted."""
+        if self.prop == "group":
+            return np.array([0])
+        return np.unique(time.month if self.prop == "month" else time.doy)
+
+    def index(self, time, labels=None) -> np.ndarray:
+        """Position of every time step's group in `labels` (default: the labels of `time`); -1 when absent."""
+        if self.prop == "group":
+            return np.zeros(len(time), dtype=np.int64)
+        lab = self.labels(time) if labels is None else np.asarray(labels)
+        val = time.month if self.prop == "month" else time.doy
+        pos = np.clip(np.searchsorted(lab, val), 0, len(lab) - 1)
+        return np.where(lab[pos] == val, pos, -1)
+
+    def sample_rows(self, time) -> list:
+        """For every group the rows of its training sample: the centred window around each of its time steps, -1 (NaN)
+        beyond the ends of the series — rolling(time=window, center=True).construct + groupby in xsdba."""
+        T = len(time)
+        gi = self.index(time)
+        half = self.window // 2
+        off = np.arange(-half, half + 1)
+        out = []
+        for g in range(len(self.labels(time))):
+            t = np.nonzero(gi == g)[0]
+            rows = (t[:, None] + off[None, :]).reshape(-1)
+            rows[(rows < 0) | (rows >= T)] = -1
+            out.append(rows.astype(np.int64))
+        return out
 
 
 def equally_spaced_nodes(n: int, eps=None) -> np.ndarray:
@@ -42,18 +100,23 @@ def quantile(da, q, dim="time", *, device=None, keep=False):
 class EmpiricalQuantileMapping:
     """Empirical quantile mapping bias adjustment (train on ref/hist quantiles, adjust sim by node search)."""
 
-    def __init__(self, dev, af: DeviceArray, hist_q: DeviceArray, quantiles, kind, cell_shape):
+    def __init__(self, dev, af: DeviceArray, hist_q: DeviceArray, quantiles, kind, cell_shape, group=None, labels=None):
         self._dev = dev
         self._af, self._hist_q = af, hist_q
         self.quantiles = np.asarray(quantiles)
         self.kind = kind
         self.cell_shape = tuple(cell_shape)
-        self.adj_params = {"group": "time", "kind": kind, "nquantiles": len(self.quantiles)}
+        self.group = group or Grouper("time")
+        self.group_labels = np.array([0]) if labels is None else np.asarray(labels)
+        self.adj_params = {"group": self.group.name if self.group.window == 1 else repr(self.group), "kind": kind,
+                           "nquantiles": len(self.quantiles)}
 
     @classmethod
-    def train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group: str = "time", device=None):
-        if group != "time":
-            raise NotImplementedError("only group='time' is supported by the HIP backend")
+    def train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", window: int | None = None, time=None,
+              device=None):
+        """``group``: "time" (default), "time.month", "time.dayofyear" or a :class:`Grouper`; sub-groupings need the
+        common ``time`` axis (TimeAxis) of ref and hist."""
+        grp = group if isinstance(group, Grouper) else Grouper(group, 1 if window is None else window)
         if kind not in (ADDITIVE, MULTIPLICATIVE):
             raise ValueError(f"kind must be '+' or '*', got {kind!r}")
         dev = device or get_device()
@@ -62,22 +125,68 @@ class EmpiricalQuantileMapping:
         if tuple(cell_shape) != tuple(cell_shape_h) or r.shape != h.shape:
             raise ValueError("ref and hist must have the same shape")  # _check_matching_time_sizes analogue
         q = equally_spaced_nodes(nquantiles) if np.isscalar(nquantiles) else np.asarray(nquantiles, dtype=np.float64)
-        af, hq = K.eqm_train(dev, r, h, q, kind)
-        return cls(dev, af, hq, q, kind, cell_shape)
+        if grp.prop == "group":
+            af, hq = K.eqm_train(dev, r, h, q, kind)
+            return cls(dev, af, hq, q, kind, cell_shape, grp)
+        if time is None or len(time) != r.shape[0]:
+            raise ValueError(f"group={grp.name!r} needs time=TimeAxis of the training series")
+        labels = grp.labels(time)
+        G, C_ = len(labels), r.shape[1]
+        af = dev.empty((G, len(q), C_), np.float32)
+        hq = dev.empty((G, len(q), C_), np.float32)
+        plane = len(q) * C_ * 4
+        for g, rows in enumerate(grp.sample_rows(time)):
+            out_g = tuple(dev.wrap(a.ptr + g * plane, (len(q), C_), np.float32) for a in (af, hq))
+            K.eqm_train(dev, K.select_rows(dev, r, rows), K.select_rows(dev, h, rows), q, kind, out=out_g)
+        dev.sync()
+        return cls(dev, af, hq, q, kind, cell_shape, grp, labels)
 
-    def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", keep=False):
+    def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", time=None, keep=False):
         if interp not in ("nearest", "linear", "cubic"):
             raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
         s, cell_shape = _flatten(sim, self._dev)
         if tuple(cell_shape) != self.cell_shape:
             raise ValueError("sim does not match the trained grid")
-        scen = K.eqm_adjust(self._dev, s, self._af, self._hist_q, self.kind, interp, extrapolation)
-        return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
+        dev = self._dev
+        if self.group.prop == "group":
+            scen = K.eqm_adjust(dev, s, self._af, self._hist_q, self.kind, interp, extrapolation)
+            return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
+        if time is None or len(time) != s.shape[0]:
+            raise ValueError(f"group={self.group.name!r} needs time=TimeAxis of sim")
+        gi = self.group.index(time, self.group_labels)
+        if (gi < 0).any():
+            raise ValueError("sim holds time steps whose group was not trained (e.g. day 366 with a 365-day training set)")
+        # group-major permutation of the rows: every group becomes one contiguous block
+        perm = np.argsort(gi, kind="stable")
+        counts = np.bincount(gi, minlength=len(self.group_labels))
+        T, C_ = s.shape
+        nq = len(self.quantiles)
+        s_perm = K.select_rows(dev, s, perm)
+        scen_perm = dev.empty((T, C_), np.float32)
+        off = 0
+        for g, n in enumerate(counts):
+            if n == 0:
+                continue
+            blk = dev.wrap(s_perm.ptr + off * C_ * 4, (int(n), C_), np.float32)
+            out = dev.wrap(scen_perm.ptr + off * C_ * 4, (int(n), C_), np.float32)
+            af_g = dev.wrap(self._af.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
+            hq_g = dev.wrap(self._hist_q.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
+            K.eqm_adjust(dev, blk, af_g, hq_g, self.kind, interp, extrapolation, out=out)
+            off += int(n)
+        inv = np.empty(T, dtype=np.int64)
+        inv[perm] = np.arange(T)
+        scen = K.select_rows(dev, scen_perm, inv)
+        dev.sync()
+        return scen if keep else scen.get().reshape((T,) + self.cell_shape)
+
+    def _shape(self):
+        lead = (len(self.quantiles),) if self.group.prop == "group" else (len(self.group_labels), len(self.quantiles))
+        return lead + self.cell_shape
 
     @property
     def af(self) -> np.ndarray:
-        return self._af.get().reshape((len(self.quantiles),) + self.cell_shape)
+        return self._af.get().reshape(self._shape())
 
     @property
     def hist_q(self) -> np.ndarray:
-        return self._hist_q.get().reshape((len(self.quantiles),) + self.cell_shape)
+        return self._hist_q.get().reshape(self._shape())
