@@ -461,10 +461,13 @@ def test_resample_doy_and_within_bnds_doy(dev, rng, calendar, T):
 @pytest.mark.parametrize("calendar,T,freq,window,per,op", [("noleap", 365, "YS", 5, 90.0, ">"), ("noleap", 365, "MS", 5, 10.0, "<"),
                                                            ("noleap", 365, "QS-DEC", 3, 50.0, ">="), ("standard", 365, "MS", 7, 90.0, ">"),
                                                            ("noleap", 200, "MS", 5, 75.0, ">"), ("noleap", 1095, "YS", 5, 90.0, ">"),
-                                                           ("standard", 366, "YS", 5, 90.0, ">")])
+                                                           ("standard", 366, "YS", 5, 90.0, ">"),
+                                                           ("noleap", 365 * 12, "YS", 5, 95.0, ">"), ("noleap", 365 * 9, "MS", 7, 3.0, "<="),
+                                                           ("360_day", 360 * 8, "QS-DEC", 5, 90.0, ">=")])
 def test_percentile_exceedance_fused(dev, rng, calendar, T, freq, window, per, op):
-    """The fused percentile_doy + threshold_count kernel must reproduce the two-step chain bit for bit (and fall back
-    to it for several years / 366-day years)."""
+    """The fused percentile_doy + threshold_count kernels (one year: sliding window; several years on a calendar without
+    gaps: register top-16 + per-year counters) must reproduce the two-step chain bit for bit, and the wrapper falls back
+    to the chain where they do not apply (366-day years, central percentiles on several years)."""
     x = _temp(rng, T, (7, 9), nan_frac=0.01)
     x[10:13, 0, 0] = np.nan
     start = "2001-01-01" if T != 366 else "2000-01-01"

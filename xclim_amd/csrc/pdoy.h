@@ -36,7 +36,9 @@ __device__ __forceinline__ void pdoy_gather(float (&raw)[NYP], int rowv, const f
   for (int y = 0; y < NYP; ++y) {
     const int tp = __builtin_amdgcn_readlane(rowv, y);
     const float f = x[(int64_t)(tp < 0 ? 0 : tp) * st + cc];
-    raw[y] = tp < 0 ? xh_nan32() : f;
+    // absent day -> NaN by OR-ing the (wave-uniform) mask into the bits: written as `tp < 0 ? NaN : f` the compiler sinks
+    // the load into a scalar branch per sample (s_cmp / s_cbranch around every load of the gather)
+    raw[y] = __uint_as_float(__float_as_uint(f) | (tp < 0 ? 0x7FFFFFFFu : 0u));
   }
 }
 
@@ -86,7 +88,9 @@ int xh_launch_pdoy_top16(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
                          int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int nsub, int rev, double* out,
                          const int32_t* d_vmap, int64_t Tv, const uint8_t* d_reg);
 // COUNT variant (xh_percentile_doy_count, multi-year base period): one percentile, every doy regular; the exceedances
-// of (year y, doy d) are added to period d_period[y * ndoy + d] (atomics: cnt_out / valid_out must be zeroed)
+// of (year y, doy d) are added to period d_period[y * ndoy + d] (atomics: cnt_out / valid_out must be zeroed);
+// d_newseg[d] = 1 where the period of doy d differs from that of doy d - 1 — for EVERY year at once (host-checked)
 int xh_launch_pdoy_top16_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
                                int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int rev, const uint8_t* d_reg,
-                               int op, const int32_t* d_period, int32_t* cnt_out, int32_t* valid_out);
+                               int op, const int32_t* d_period, int32_t* cnt_out, int32_t* valid_out,
+                               const uint8_t* d_newseg);

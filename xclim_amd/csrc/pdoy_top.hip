@@ -1,4 +1,6 @@
 // pdoy_top.hip — percentile_doy on multi-year base periods, register top-16 variant.
+#include <stdlib.h>
+
 #include "pdoy.h"
 
 // ---- multi-year path, register variant: top-16 of the W day-sets by bitonic half-merges ---------------------
@@ -93,12 +95,12 @@ __device__ __forceinline__ float f32_threshold(double r, int op) {
 // samples of day d of EVERY year and the exceedances are counted per (year, doy) -> period; the (D, C) fp64 table of the
 // unfused chain is neither written nor re-read once per year.  One percentile (nsub == 1), regular doys only.
 template <int W, int NYP, bool COUNT = false>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)
 k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
              int ndoy, int chunk, const QTab* __restrict__ qtab, const int32_t* __restrict__ jmap, int nsub,
              double* __restrict__ out, const int32_t* __restrict__ vmap, int64_t Tv, const uint8_t* __restrict__ regular,
              int rev, int op = 0, const int32_t* __restrict__ yd_period = nullptr, int32_t* __restrict__ cnt_out = nullptr,
-             int32_t* __restrict__ valid_out = nullptr) {
+             int32_t* __restrict__ valid_out = nullptr, const uint8_t* __restrict__ newseg = nullptr) {
   const uint32_t rmask = rev ? 0xFFFFFFFFu : 0u;  // mirrored key order for the bottom-16 case
   const int lane = threadIdx.x;
   int64_t c = (int64_t)blockIdx.x * 64 + lane;
@@ -109,9 +111,9 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
   int cnt[W];
   float raw[NYP];
 
-  const int64_t cc = active ? c : C - 1;  // inactive lanes read a valid cell and never store
+  const int64_t cc_ = active ? c : C - 1;  // inactive lanes read a valid cell and never store
   auto rows_of = [&](int dn, int off) { return pdoy_row(lane, nyears, ndoy, dn, off, tbase, vmap, Tv, T); };
-  auto gather = [&](int rowv) { pdoy_gather<NYP>(raw, rowv, x, st, cc); };
+  auto gather = [&](int rowv) { pdoy_gather<NYP>(raw, rowv, x, st, cc_); };
   // sort the gathered day-set and return its top 16 (in the possibly mirrored order) + valid count
   auto finish = [&](uint32_t (&top)[16], int& nv) {
     uint32_t key[NYP];
@@ -137,40 +139,61 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
       merge_top16(top, blk);
     }
   };
-  // COUNT: per-year counters; the period of (year y, doy d) is wave-uniform, a year's counters are flushed with one
-  // atomic per lane when its period changes and at the end of the doy chunk
-  int ccnt[COUNT ? NYP : 1], cval[COUNT ? NYP : 1], cper[COUNT ? NYP : 1];
+  // COUNT: one packed counter per year and lane (low half: exceedances, high half: valid days; a chunk has < 2^16 doys).
+  // Period boundaries fall on the same doy for every year (`newseg[d]`, checked by the host), so ALL years are flushed
+  // together — one atomic per year and lane — when a new segment starts and at the end of the doy chunk; the period of
+  // (year y, doy) comes from the table at flush time.  The samples of day d are re-read (the day-set left the registers
+  // W/2 + 1 doys ago) ONE DOY AHEAD of their use: gathered and used in the same step they cost a full L2 / HBM latency
+  // per doy (the first version of this kernel: 31.8 ms fused against 18.2 + 11.9 ms for the two-step chain).
+  const bool prim_lt = op == XH_OP_LT || op == XH_OP_GE, complement = op == XH_OP_GE || op == XH_OP_LE;
+  const float sgn = prim_lt ? -1.0f : 1.0f;
+  uint32_t cc[COUNT ? NYP : 1];
+  float xv[COUNT ? NYP : 1];
+  // the prefetched samples wait in LDS (lane-private column) while the sort networks need the registers
+  __shared__ float xs[COUNT ? NYP * 64 : 1];
   if (COUNT) {
 #pragma unroll
-    for (int y = 0; y < NYP; ++y) { ccnt[y] = 0; cval[y] = 0; cper[y] = -1; }
+    for (int y = 0; y < NYP; ++y) cc[y] = 0u;
   }
-  auto flush_year = [&](int y) {
+  auto flush_all = [&](int dlast) {  // dlast: a doy of the segment that ends
     if (COUNT) {
-      if (cper[y] >= 0 && active) {
-        if (ccnt[y]) atomicAdd(&cnt_out[(int64_t)cper[y] * C + c], ccnt[y]);
-        if (valid_out && cval[y]) atomicAdd(&valid_out[(int64_t)cper[y] * C + c], cval[y]);
+      const int perv = (lane < nyears) ? yd_period[(int64_t)lane * ndoy + dlast] : -1;
+#pragma unroll
+      for (int y = 0; y < NYP; ++y) {
+        const int pp = __builtin_amdgcn_readlane(perv, y);
+        if (pp >= 0 && active) {
+          const int nvld = (int)(cc[y] >> 16);
+          const int nc = complement ? nvld - (int)(cc[y] & 0xFFFFu) : (int)(cc[y] & 0xFFFFu);
+          if (nc) atomicAdd(&cnt_out[(int64_t)pp * C + c], nc);
+          if (valid_out && nvld) atomicAdd(&valid_out[(int64_t)pp * C + c], nvld);
+        }
+        cc[y] = 0u;
       }
-      ccnt[y] = 0; cval[y] = 0;
     }
   };
-  auto count_day = [&](int d, double r) {
-    if (!COUNT) return;
-    const float thr = f32_threshold(r, op);
-    const int rowc = rows_of(d, 0);  // lane y: row of (year y, doy d)
-    const int perv = (lane < nyears) ? yd_period[(int64_t)lane * ndoy + d] : -1;
-    float xv[NYP];
-    pdoy_gather<NYP>(xv, rowc, x, st, cc);  // rows read W/2 + 1 doys ago by this wave: cache hits
+  auto fetch_day = [&](int d) {  // samples of (year y, doy d) for the count of doy d
+    if constexpr (COUNT) pdoy_gather<NYP>(xv, rows_of(d, 0), x, st, cc_);
+  };
+  auto stash_day = [&]() {  // registers -> LDS at the top of the step that uses them
+    if constexpr (COUNT) {
 #pragma unroll
-    for (int y = 0; y < NYP; ++y) {
-      const int pp = __builtin_amdgcn_readlane(perv, y);
-      if (pp != cper[y]) { flush_year(y); cper[y] = pp; }
-      bool hit;
-      if (op == XH_OP_GT) hit = xv[y] > thr;
-      else if (op == XH_OP_GE) hit = xv[y] >= thr;
-      else if (op == XH_OP_LT) hit = xv[y] < thr;
-      else hit = xv[y] <= thr;
-      ccnt[y] += hit ? 1 : 0;         // an absent row was gathered as NaN: never a hit, never valid
-      cval[y] += (xv[y] == xv[y]) ? 1 : 0;
+      for (int y = 0; y < NYP; ++y) xs[y * 64 + lane] = xv[y];
+    }
+  };
+  // One primitive, "sample > threshold", serves the four operators: < is > on negated values, and >= / <= are the
+  // complements within the valid samples (hits = valid - count(x < r), resp. valid - count(x > r); applied at flush time).
+  auto count_day = [&](int d, double r, bool all_valid) {
+    if (!COUNT) return;
+    const float thr = sgn * f32_threshold(r, prim_lt ? XH_OP_LT : XH_OP_GT);
+    if (all_valid) {  // the day-set holds no NaN / absent day (wave-uniform): one multiply, compare and add-with-carry per sample
+#pragma unroll
+      for (int y = 0; y < NYP; ++y) cc[y] += 0x10000u + ((xs[y * 64 + lane] * sgn > thr) ? 1u : 0u);
+    } else {
+#pragma unroll
+      for (int y = 0; y < NYP; ++y) {  // an absent row was gathered as NaN: never a hit, never valid
+        const float v = xs[y * 64 + lane];
+        cc[y] += ((v * sgn > thr) ? 1u : 0u) + ((v == v) ? 0x10000u : 0u);
+      }
     }
   };
   auto select_and_store = [&](int d) {
@@ -202,7 +225,7 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
         if (e.gamma >= 0.5) r = (double)right - (double)diff * (1.0 - e.gamma);
         if (r != r && n > 0) r = (double)get(rev ? (n - 1 < 15 ? n - 1 : 15) : 0);  // +-inf: nanmax fallback (utl:552-554)
       }
-      if (COUNT) count_day(d, r);
+      if (COUNT) count_day(d, r, __all(cnt[half] == nyears ? 1 : 0) != 0);
       else if (active) out[((int64_t)j * ndoy + d) * C + c] = r;
     }
   };
@@ -218,7 +241,9 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
     }
     gather(rows_of(d0 + half, 0));
     int rows_next = rows_of(d0 + half + 1, 0);
+    fetch_day(d0);
     for (int d = d0; d < d1; ++d) {
+      stash_day();
 #pragma unroll
       for (int w = 0; w < W - 1; ++w) {
 #pragma unroll
@@ -230,12 +255,11 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
         gather(rows_next);
         rows_next = rows_of(d + 2 + half, 0);
       }
+      if (COUNT && d > d0 && newseg[d]) flush_all(d - 1);
       if (regular[d]) select_and_store(d);
+      if (COUNT && d + 1 < d1) fetch_day(d + 1);
     }
-    if (COUNT) {
-#pragma unroll
-      for (int y = 0; y < NYP; ++y) flush_year(y);
-    }
+    if (COUNT) flush_all(d1 - 1);
   }
 }
 
@@ -259,12 +283,14 @@ int xh_launch_pdoy_top16(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
 
 int xh_launch_pdoy_top16_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
                                int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int rev, const uint8_t* d_reg,
-                               int op, const int32_t* d_period, int32_t* cnt_out, int32_t* valid_out) {
-  const int chunk = 46;  // 8 chunks of a 365-day year: fewer counter flushes (one atomic per year, lane and chunk)
+                               int op, const int32_t* d_period, int32_t* cnt_out, int32_t* valid_out,
+                               const uint8_t* d_newseg) {
+  int chunk = 92;  // 4 chunks of a 365-day year (24 / 46 / 92 / 183 / 365: 26.3 / 25.1 / 24.6 / 24.5 / 24.7 ms at 30 yr x 1440 x 720)
+  if (const char* e = xh_diag_env("XH_PDOY_COUNT_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : chunk;
   const dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
 #define XH_TOP16C(W, NY)                                                                                                       \
   hipLaunchKernelGGL((k_pdoy_top16<W, NY, true>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, d_tab, \
-                     d_jmap, 1, (double*)nullptr, (const int32_t*)nullptr, T, d_reg, rev, op, d_period, cnt_out, valid_out)
+                     d_jmap, 1, (double*)nullptr, (const int32_t*)nullptr, T, d_reg, rev, op, d_period, cnt_out, valid_out, d_newseg)
   if (nyears <= 32) {
     if (window == 3) XH_TOP16C(3, 32); else if (window == 5) XH_TOP16C(5, 32); else XH_TOP16C(7, 32);
   } else {

@@ -969,21 +969,36 @@ static int pdoy_count_multi(xh_ctx* ctx, const float* x, int64_t T, int64_t C, i
   }
   const bool top = dt <= 16, bot = !top && db <= 16;
   int rc = (nirr == 0 && (top || bot)) ? XH_OK : XH_ERR_NOTIMPL;
+  // period boundaries must fall on the same doy in every year (the kernel flushes all years' counters together)
+  uint8_t* newseg = (uint8_t*)malloc((size_t)ndoy);
+  if (!newseg) rc = XH_ERR_ARG;
+  for (int d = 0; !rc && d < ndoy; ++d) {
+    int nchg = 0, npres = 0;
+    for (int y = 0; y < nyears; ++y) {
+      const int32_t p1 = doy_period[(int64_t)y * ndoy + d], p0 = d > 0 ? doy_period[(int64_t)y * ndoy + d - 1] : p1;
+      if (p1 < 0 || p0 < 0) continue;
+      npres++;
+      nchg += p1 != p0 ? 1 : 0;
+    }
+    if (nchg != 0 && nchg != npres) rc = XH_ERR_NOTIMPL;
+    newseg[d] = nchg != 0 ? 1 : 0;
+  }
   size_t cur = 0;
-  void *d_tb = nullptr, *d_reg = nullptr, *d_tab = nullptr, *d_j = nullptr, *d_dp = nullptr;
+  void *d_tb = nullptr, *d_reg = nullptr, *d_tab = nullptr, *d_j = nullptr, *d_dp = nullptr, *d_ns = nullptr;
   const int32_t j0 = 0;
   if (!rc) rc = xh_scratch_upload(ctx, &cur, tbase, sizeof(int32_t) * (size_t)nyears * ndoy, &d_tb);
   if (!rc) rc = xh_scratch_upload(ctx, &cur, regular, (size_t)ndoy, &d_reg);
   if (!rc) rc = xh_scratch_upload(ctx, &cur, tab, sizeof(QTab) * (size_t)(N + 1), &d_tab);
   if (!rc) rc = xh_scratch_upload(ctx, &cur, &j0, sizeof(int32_t), &d_j);
   if (!rc) rc = xh_scratch_upload(ctx, &cur, doy_period, sizeof(int32_t) * (size_t)nyears * ndoy, &d_dp);
-  free(regular); free(irregular); free(tab);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, newseg, (size_t)ndoy, &d_ns);
+  free(regular); free(irregular); free(tab); free(newseg);
   if (rc) return rc;
   XH_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int32_t) * (size_t)P * (size_t)C, ctx->stream));
   if (valid_out) XH_CHECK_HIP(hipMemsetAsync(valid_out, 0, sizeof(int32_t) * (size_t)P * (size_t)C, ctx->stream));
   return xh_launch_pdoy_top16_count(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const QTab*)d_tab,
                                     (const int32_t*)d_j, bot ? 1 : 0, (const uint8_t*)d_reg, op, (const int32_t*)d_dp,
-                                    count_out, valid_out);
+                                    count_out, valid_out, (const uint8_t*)d_ns);
 }
 
 extern "C" {

@@ -128,7 +128,8 @@ def percentile_exceedance(da, time: TimeAxis, freq: str = "YS", op: str = ">", w
     """``tx90p(da, percentile_doy(da, window, per), freq)`` in one pass when the percentile base period is the analysed
     series itself (calendar.py:395-494 + indices/_multivariate.py:1534-1650): identical counts, but the
     (dayofyear, lat, lon) float64 percentile field — 2/3 of the chain's HBM traffic — is never materialised.  Falls back
-    to the two-step chain for shapes the fused kernel does not cover (several years, 366-day years, other windows)."""
+    to the two-step chain for shapes the fused kernels do not cover (366-day years, other windows, central percentiles
+    on multi-year series)."""
     from .calendar import _flatten, percentile_doy
 
     dev = device or get_device()
@@ -137,8 +138,11 @@ def percentile_exceedance(da, time: TimeAxis, freq: str = "YS", op: str = ">", w
     tb, years, doys = time.doy_table()
     seg, _ = time.segments(freq)
     res = None
-    if tb.shape[0] == 1 and doys.max() != 366 and len(doys) == len(time):
-        period = (np.searchsorted(seg, tb[0], side="right") - 1).astype(np.int32)  # period of every doy row
+    if doys.max() != 366:
+        # fused kernels: one contiguous year (sliding window) or a multi-year base period on a calendar without gaps
+        # (register top-16 kernel, high / low percentiles); they return None for shapes they do not cover
+        period = (np.searchsorted(seg, tb, side="right") - 1).astype(np.int32)  # period of every (year, doy) day
+        period[tb < 0] = -1
         res = K.percentile_doy_count(dev, x, tb, window, per, sym, period, len(seg) - 1, alpha, beta)
     if res is None:
         p = percentile_doy(x, time, window, per, alpha, beta, device=dev)
