@@ -112,6 +112,36 @@ __device__ __forceinline__ bool xh_cmp_f64(double a, int op, double b) {
   }
 }
 
+// One-compare form of a run-time ordering operator: for > < >= <= against a FINITE float threshold t there are (sgn, t')
+// with   x OP t  <=>  sgn * x > t'   for every x (NaN included: both sides are False):
+//   >: (+1, t)   <: (-1, -t)   >=: (+1, pred(t))   <=: (-1, pred(-t)),   pred = the next float towards -inf.
+// One multiply (full rate) + one v_cmp per element instead of the three compares + mask logic of xh_cmp_f32 (v_cmp
+// issues at half rate on gfx950, tools/valu_ubench.hip).  `ok` = 0 for == / != and non-finite thresholds: use xh_cmp_f32.
+struct XhOneCmp {
+  float sgn, thr;
+  int ok;
+};
+static inline XhOneCmp xh_one_cmp(int op, float t) {
+  XhOneCmp r = {1.0f, t, 0};
+  if (!(t == t) || t > 3.4028234e38f || t < -3.4028234e38f) return r;
+  auto pred = [](float v) -> float {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    if ((u & 0x7FFFFFFFu) == 0u) u = 0x80000001u;  // +-0 -> the smallest negative subnormal
+    else u = (u >> 31) ? u + 1u : u - 1u;           // away from zero for negatives, towards zero for positives
+    memcpy(&v, &u, 4);
+    return v;
+  };
+  switch (op) {
+    case XH_OP_GT: r.sgn = 1.0f; r.thr = t; r.ok = 1; break;
+    case XH_OP_LT: r.sgn = -1.0f; r.thr = -t; r.ok = 1; break;
+    case XH_OP_GE: r.sgn = 1.0f; r.thr = pred(t); r.ok = 1; break;
+    case XH_OP_LE: r.sgn = -1.0f; r.thr = pred(-t); r.ok = 1; break;
+    default: break;
+  }
+  return r;
+}
+
 template <int OP>
 __device__ __forceinline__ bool xh_cmp_t(float a, float b) {
   if (OP == XH_OP_GT) return a > b;

@@ -95,7 +95,9 @@ static int launch_threshold_count(xh_ctx* ctx, int kind, dim3 grid, const float*
 static inline unsigned period_grid(int P) { return (unsigned)(P < 1 ? 1 : (P > 4096 ? 4096 : P)); }
 
 // ---- domain_count ----------------------------------------------------------------------------------
-template <int VEC>
+// FAST: both conditions in the one-compare form of xh_one_cmp (sgn * x > thr): 2 multiplies + 2 compares per element
+// instead of two run-time operators (PMC: 28 VALU per element, 0.39 ms at 365 x 1440 x 720 before).
+template <int VEC, bool FAST = false>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_domain_count(const float* __restrict__ x, int64_t C, int64_t st, int op1, float thr1, int op2, float thr2, int combine,
                const int64_t* __restrict__ seg_off, int P, int32_t* __restrict__ count_out,
@@ -110,7 +112,14 @@ k_domain_count(const float* __restrict__ x, int64_t C, int64_t st, int op1, floa
     xh_march_rows<VEC, 8>(x + c, st, t0, t1, [&](int64_t, const VecF<VEC>& xv) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        bool a = xh_cmp_f32(xv.v[i], op1, thr1), b = xh_cmp_f32(xv.v[i], op2, thr2);
+        bool a, b;
+        if (FAST) {  // op1 / op2 carry the signs here (see the launcher)
+          a = xv.v[i] * __int_as_float(op1) > thr1;
+          b = xv.v[i] * __int_as_float(op2) > thr2;
+        } else {
+          a = xh_cmp_f32(xv.v[i], op1, thr1);
+          b = xh_cmp_f32(xv.v[i], op2, thr2);
+        }
         cnt[i] += ((combine == 1) ? (a && b) : (a || b)) ? 1 : 0;
         val[i] += (xv.v[i] == xv.v[i]) ? 1 : 0;
       }
@@ -380,7 +389,14 @@ int xh_domain_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t s
   if (C == 0) return XH_OK;
   int vec = xh_pick_vec(x, C, st);
   dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), period_grid(P));
-  if (vec == 4)
+  const XhOneCmp c1 = xh_one_cmp(op1, (float)thr1), c2 = xh_one_cmp(op2, (float)thr2);
+  if (vec == 4 && c1.ok && c2.ok) {
+    int s1, s2;
+    memcpy(&s1, &c1.sgn, 4);
+    memcpy(&s2, &c2.sgn, 4);
+    hipLaunchKernelGGL((k_domain_count<4, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, s1, c1.thr, s2, c2.thr, combine,
+                       d_seg, P, count_out, valid_out);
+  } else if (vec == 4)
     hipLaunchKernelGGL((k_domain_count<4>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, op1, (float)thr1, op2,
                        (float)thr2, combine, d_seg, P, count_out, valid_out);
   else

@@ -166,6 +166,66 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
 // Fast path of maximum_consecutive_{dry,wet}_days & friends (gen:543-585 with window == 1, reducer "max", resample
 // before run length): the mask comes from a compare, so it has no NaN and every run is visible; the longest run is
 // max over t of the running length, no run-end bookkeeping at all.  ~6 VALU ops per cell-step -> HBM bound.
+// Run statistics of a 1 / 0 / NaN MASK with the runs cut at the period edges — the common case behind rle_statistics /
+// windowed_run_count / windowed_run_events on a precomputed condition (rl:275-488).  The generic kernel above resolves
+// the index mode, the fused compare and the statistic per element (PMC: 122 VALU + 115 SALU wave-instructions per row of
+// 4 cells, 0.50 ms at 365 x 1440 x 720); here they are template parameters and the state machine is written for the
+// minimum of selects: ~13 VALU per cell-step for the maximum.
+//   IDX 0: index="last" (a run whose NEXT step is NaN is dropped), 1: index="first" (a run that STARTS right after a
+//   NaN step is dropped), 2 / 3: the 1-D ufunc paths (NaN steps only break runs; 3 = statistics_run_1d: NaN result when
+//   the series has NaN steps and no qualifying run) — rl:223-272, 1334-1437 and DESIGN.md "two reference paths".
+//   SG 1: max, 2: sum / count / mean, 0: every field (min, std).
+template <int VEC, int IDX, int SG>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_run_stats_mask(const float* __restrict__ x, int64_t C, int64_t st, int window, int stat, const int64_t* __restrict__ seg_off,
+                 int P, float* __restrict__ out, int32_t* __restrict__ valid_out) {
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    RunAcc acc[VEC];
+    int run[VEC], nnan[VEC];
+    bool vis[VEC], prevnan[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      acc_reset(acc[i]);
+      run[i] = 0; nnan[i] = 0; vis[i] = true; prevnan[i] = false;
+    }
+    xh_march_rows<VEC, 8>(x + c, st, t0, t1, [&](int64_t, const VecF<VEC>& xv) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float v = xv.v[i];
+        const bool isn = v != v, on = v > 0.0f;
+        nnan[i] += isn ? 1 : 0;
+        int len = on ? 0 : run[i];                    // length of the run that ended with the previous step (0: none)
+        if (IDX == 0) len = isn ? 0 : len;            // hidden by the NaN that follows it
+        if (IDX == 1) len = vis[i] ? len : 0;         // hidden by the NaN that preceded it
+        len = len >= window ? len : 0;
+        if (SG == 1) acc[i].mx = len > acc[i].mx ? len : acc[i].mx;
+        else acc_add_if<SG>(acc[i], len);
+        if (IDX == 1) {
+          vis[i] = (on && run[i] == 0) ? !prevnan[i] : vis[i];
+          prevnan[i] = isn;
+        }
+        run[i] = on ? run[i] + 1 : 0;
+      }
+    });
+    const int64_t o = (int64_t)p * C + c;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if (run[i] > 0 && run[i] >= window && (IDX == 1 ? vis[i] : true)) {  // beyond the segment end: shift fill_value 0
+        if (SG == 1) acc[i].mx = run[i] > acc[i].mx ? run[i] : acc[i].mx;
+        else acc_add(acc[i], run[i]);
+      }
+      if (SG == 1) acc[i].cnt = acc[i].mx > 0 ? 1 : 0;
+      float r = acc_result(acc[i], stat, 0);
+      if (IDX == 3 && acc[i].cnt == 0 && nnan[i] > 0 && stat != XH_RUN_COUNT && stat != XH_RUN_SUM) r = xh_nan32();
+      out[o + i] = r;
+      if (valid_out) valid_out[o + i] = (int)(t1 - t0) - nnan[i];
+    }
+  }
+}
+
 template <int VEC, int OP>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_run_max_fused(const float* __restrict__ x, int64_t C, int64_t st, float thr, int window,
@@ -435,6 +495,26 @@ int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, 
         XH_RMF(1, XH_OP_NE) }
     }
 #undef XH_RMF
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+  }
+  if (cut_at_segments && fused_op < 0 && stat != XH_RUN_PLAINSUM && index_first >= 0 && index_first <= 3) {
+    // a mask, runs cut at the period edges: specialised state machine (index mode and statistic group at compile time)
+    dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), py);
+    const int sg = stat == XH_RUN_MAX ? 1 : ((stat == XH_RUN_SUM || stat == XH_RUN_COUNT || stat == XH_RUN_MEAN) ? 2 : 0);
+#define XH_RSM(V, I, G)                                                                                                \
+  hipLaunchKernelGGL((k_run_stats_mask<V, I, G>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, stat, d_seg, P, out, \
+                     valid_out)
+#define XH_RSM_G(V, I) { if (sg == 1) XH_RSM(V, I, 1); else if (sg == 2) XH_RSM(V, I, 2); else XH_RSM(V, I, 0); }
+#define XH_RSM_I(V)                                                                         \
+  {                                                                                         \
+    if (index_first == 0) XH_RSM_G(V, 0) else if (index_first == 1) XH_RSM_G(V, 1)          \
+    else if (index_first == 2) XH_RSM_G(V, 2) else XH_RSM_G(V, 3)                           \
+  }
+    if (vec == 4) XH_RSM_I(4) else XH_RSM_I(1)
+#undef XH_RSM_I
+#undef XH_RSM_G
+#undef XH_RSM
     XH_LAUNCH_CHECK();
     return XH_OK;
   }
