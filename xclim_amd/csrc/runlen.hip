@@ -163,9 +163,6 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
   }
 }
 
-// Fast path of maximum_consecutive_{dry,wet}_days & friends (gen:543-585 with window == 1, reducer "max", resample
-// before run length): the mask comes from a compare, so it has no NaN and every run is visible; the longest run is
-// max over t of the running length, no run-end bookkeeping at all.  ~6 VALU ops per cell-step -> HBM bound.
 // Run statistics of a 1 / 0 / NaN MASK with the runs cut at the period edges — the common case behind rle_statistics /
 // windowed_run_count / windowed_run_events on a precomputed condition (rl:275-488).  The generic kernel above resolves
 // the index mode, the fused compare and the statistic per element (PMC: 122 VALU + 115 SALU wave-instructions per row of
@@ -175,10 +172,12 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
 //   NaN step is dropped), 2 / 3: the 1-D ufunc paths (NaN steps only break runs; 3 = statistics_run_1d: NaN result when
 //   the series has NaN steps and no qualifying run) — rl:223-272, 1334-1437 and DESIGN.md "two reference paths".
 //   SG 1: max, 2: sum / count / mean, 0: every field (min, std).
-template <int VEC, int IDX, int SG>
+//   FUSED: the condition is `sgn * x > thr` on the data itself (xh_one_cmp form of > < >= <=: spell_length, the
+//   *_spell_* indices with window 1, gen:543-585, 1204-1252); a NaN step is then just a False step (IDX 2).
+template <int VEC, int IDX, int SG, bool FUSED = false>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_run_stats_mask(const float* __restrict__ x, int64_t C, int64_t st, int window, int stat, const int64_t* __restrict__ seg_off,
-                 int P, float* __restrict__ out, int32_t* __restrict__ valid_out) {
+                 int P, float* __restrict__ out, int32_t* __restrict__ valid_out, float sgn = 1.0f, float thr = 0.0f) {
   int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
   for (int p = blockIdx.y; p < P; p += gridDim.y) {
@@ -195,7 +194,7 @@ k_run_stats_mask(const float* __restrict__ x, int64_t C, int64_t st, int window,
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float v = xv.v[i];
-        const bool isn = v != v, on = v > 0.0f;
+        const bool isn = v != v, on = FUSED ? (v * sgn > thr) : (v > 0.0f);
         nnan[i] += isn ? 1 : 0;
         int len = on ? 0 : run[i];                    // length of the run that ended with the previous step (0: none)
         if (IDX == 0) len = isn ? 0 : len;            // hidden by the NaN that follows it
@@ -226,6 +225,9 @@ k_run_stats_mask(const float* __restrict__ x, int64_t C, int64_t st, int window,
   }
 }
 
+// Fast path of maximum_consecutive_{dry,wet}_days & friends (gen:543-585 with window == 1, reducer "max", resample
+// before run length): the mask comes from a compare, so it has no NaN and every run is visible; the longest run is
+// max over t of the running length, no run-end bookkeeping at all.  ~6 VALU ops per cell-step -> HBM bound.
 template <int VEC, int OP>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_run_max_fused(const float* __restrict__ x, int64_t C, int64_t st, float thr, int window,
@@ -498,23 +500,32 @@ int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, 
     XH_LAUNCH_CHECK();
     return XH_OK;
   }
-  if (cut_at_segments && fused_op < 0 && stat != XH_RUN_PLAINSUM && index_first >= 0 && index_first <= 3) {
-    // a mask, runs cut at the period edges: specialised state machine (index mode and statistic group at compile time)
+  const XhOneCmp oc = xh_one_cmp(fused_op, (float)thr);
+  if (cut_at_segments && (fused_op < 0 || oc.ok) && stat != XH_RUN_PLAINSUM && index_first >= 0 && index_first <= 3) {
+    // a mask (or a one-compare condition on the data), runs cut at the period edges: specialised state machine (index
+    // mode and statistic group at compile time)
     dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), py);
     const int sg = stat == XH_RUN_MAX ? 1 : ((stat == XH_RUN_SUM || stat == XH_RUN_COUNT || stat == XH_RUN_MEAN) ? 2 : 0);
 #define XH_RSM(V, I, G)                                                                                                \
   hipLaunchKernelGGL((k_run_stats_mask<V, I, G>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, stat, d_seg, P, out, \
-                     valid_out)
+                     valid_out, 1.0f, 0.0f)
+#define XH_RSF(V, I, G)                                                                                                \
+  hipLaunchKernelGGL((k_run_stats_mask<V, I, G, true>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, stat, d_seg, P, \
+                     out, valid_out, oc.sgn, oc.thr)
 #define XH_RSM_G(V, I) { if (sg == 1) XH_RSM(V, I, 1); else if (sg == 2) XH_RSM(V, I, 2); else XH_RSM(V, I, 0); }
+#define XH_RSF_G(V, I) { if (sg == 1) XH_RSF(V, I, 1); else if (sg == 2) XH_RSF(V, I, 2); else XH_RSF(V, I, 0); }
 #define XH_RSM_I(V)                                                                         \
   {                                                                                         \
-    if (index_first == 0) XH_RSM_G(V, 0) else if (index_first == 1) XH_RSM_G(V, 1)          \
+    if (fused_op >= 0) { if (index_first == 3) XH_RSF_G(V, 3) else XH_RSF_G(V, 2) }         \
+    else if (index_first == 0) XH_RSM_G(V, 0) else if (index_first == 1) XH_RSM_G(V, 1)     \
     else if (index_first == 2) XH_RSM_G(V, 2) else XH_RSM_G(V, 3)                           \
   }
     if (vec == 4) XH_RSM_I(4) else XH_RSM_I(1)
 #undef XH_RSM_I
 #undef XH_RSM_G
+#undef XH_RSF_G
 #undef XH_RSM
+#undef XH_RSF
     XH_LAUNCH_CHECK();
     return XH_OK;
   }
