@@ -15,29 +15,40 @@ namespace {
 
 constexpr int WMAX = 8;
 
-template <int VEC>
+// WT > 0: the window length is a compile-time constant (3 and 5 are instantiated: the windows of the spell / rolling
+// indices); the ring then holds exactly WT rows — with the generic 8-slot ring a 3-day window still shifted 8 registers
+// and walked 8 predicated slots per cell-step (PMC: 64 VALU per cell-step for spell_mask w = 3).  WT = 0: run-time w <= 8.
+template <int WT>
+struct RingN {
+  static constexpr int N = WT > 0 ? WT : WMAX;
+};
+
+template <int VEC, int WT = 0>
 struct Ring {
-  float v[VEC][WMAX];
+  static constexpr int N = RingN<WT>::N;
+  float v[VEC][N];
   __device__ __forceinline__ void fill_nan() {
 #pragma unroll
     for (int i = 0; i < VEC; ++i)
 #pragma unroll
-      for (int k = 0; k < WMAX; ++k) v[i][k] = xh_nan32();
+      for (int k = 0; k < N; ++k) v[i][k] = xh_nan32();
   }
   __device__ __forceinline__ void push(const VecF<VEC>& x) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
 #pragma unroll
-      for (int k = 0; k < WMAX - 1; ++k) v[i][k] = v[i][k + 1];
-      v[i][WMAX - 1] = x.v[i];
+      for (int k = 0; k < N - 1; ++k) v[i][k] = v[i][k + 1];
+      v[i][N - 1] = x.v[i];
     }
   }
 };
 
 // statistic of the last `w` ring entries (oldest first).  RED: XH_RED_* ; returns NaN when any entry is NaN (xarray
 // rolling with min_periods = window), except COUNT (number of valid entries).
-template <int RED>
-__device__ __forceinline__ float ring_stat(const float (&r)[WMAX], int w, double inv_w, const float* wts) {
+template <int RED, int WT = 0>
+__device__ __forceinline__ float ring_stat(const float (&r)[RingN<WT>::N], int w, double inv_w, const float* wts) {
+  constexpr int WMAX = RingN<WT>::N;  // (shadows the file constant: the loops below walk this ring's slots)
+  if (WT > 0) w = WT;
   double s = 0.0;
   float e = 0.f;
   bool nan = false, first = true;
@@ -81,10 +92,11 @@ __device__ __forceinline__ void store_vec(float* p, const float (&r)[VEC]) {
   }
 }
 
-template <int VEC, int RED>
+template <int VEC, int RED, int WT = 0>
 __global__ void __launch_bounds__(XH_BLOCK)
-k_rolling_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w, int left, int right,
+k_rolling_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w_, int left, int right,
                float* __restrict__ out, int64_t out_st) {
+  const int w = WT > 0 ? WT : w_;
   const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
   const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
@@ -93,7 +105,7 @@ k_rolling_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, in
   if (tb > T) tb = T;
   if (ta >= tb) return;
   const double inv_w = 1.0 / (double)w;
-  Ring<VEC> ring;
+  Ring<VEC, WT> ring;
   ring.fill_nan();
   // rows needed: [ta - left, tb - 1 + right] clipped to [0, T); a row tp completes the window of t = tp - right
   const int64_t r0 = ta - left < 0 ? 0 : ta - left;
@@ -105,7 +117,7 @@ k_rolling_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, in
     const bool whole = (t - left >= 0) && (t + right < T);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const float s = ring_stat<RED>(ring.v[i], w, inv_w, nullptr);
+      const float s = ring_stat<RED, WT>(ring.v[i], w, inv_w, nullptr);
       r[i] = (RED == XH_RED_COUNT || whole) ? s : xh_nan32();
     }
     store_vec<VEC>(out + t * out_st + c, r);
@@ -125,10 +137,11 @@ k_rolling_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, in
 }
 
 // out[t] = any cond[t'] for t' in [t, t + w - 1], cond[t'] = stat(x[t'-w+1 .. t']) op thr (False for incomplete / NaN windows)
-template <int VEC, int RED>
+template <int VEC, int RED, int WT = 0>
 __global__ void __launch_bounds__(XH_BLOCK)
-k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w, int op, float thr,
+k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w_, int op, float thr,
              const float* __restrict__ weights, float* __restrict__ out, int64_t out_st) {
+  const int w = WT > 0 ? WT : w_;
   const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
   const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
@@ -136,11 +149,12 @@ k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
   int64_t tb = ta + chunk;
   if (tb > T) tb = T;
   if (ta >= tb) return;
-  float wts[WMAX];
+  constexpr int RN = RingN<WT>::N;
+  float wts[RN];
 #pragma unroll
-  for (int k = 0; k < WMAX; ++k) wts[k] = (RED == 100 && k >= WMAX - w) ? weights[k - (WMAX - w)] : 0.f;
+  for (int k = 0; k < RN; ++k) wts[k] = (RED == 100 && k >= RN - w) ? weights[k - (RN - w)] : 0.f;
   const double inv_w = 1.0 / (double)w;
-  Ring<VEC> ring;
+  Ring<VEC, WT> ring;
   ring.fill_nan();
   int64_t last_true[VEC];
 #pragma unroll
@@ -154,7 +168,7 @@ k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
     for (int i = 0; i < VEC; ++i) {
       bool cond = false;
       if (have_row && tp >= w - 1) {
-        const float s = ring_stat<RED>(ring.v[i], w, inv_w, wts);
+        const float s = ring_stat<RED, WT>(ring.v[i], w, inv_w, wts);
         cond = (s == s) && xh_cmp_f32(s, op, thr);
       }
       if (cond) last_true[i] = tp;
@@ -175,20 +189,22 @@ k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
 // directly (rle_statistics with window = 1 on the mask, runs cut at the period edges).  The mask near a period edge
 // depends on the rows of the neighbouring periods (the reference builds it on the whole series first): every period
 // re-reads a (w - 1)-row halo on both sides.  One workgroup row per period.
-template <int VEC, int RED>
+template <int VEC, int RED, int WT = 0>
 __global__ void __launch_bounds__(XH_BLOCK)
-k_spell_runs(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w, int op, float thr,
+k_spell_runs(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w_, int op, float thr,
              const float* __restrict__ weights, int stat, const int64_t* __restrict__ seg_off, int P, float* __restrict__ out,
              int32_t* __restrict__ valid_out) {
+  const int w = WT > 0 ? WT : w_;
   const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
-  float wts[WMAX];
+  constexpr int RN = RingN<WT>::N;
+  float wts[RN];
 #pragma unroll
-  for (int k = 0; k < WMAX; ++k) wts[k] = (RED == 100 && k >= WMAX - w) ? weights[k - (WMAX - w)] : 0.f;
+  for (int k = 0; k < RN; ++k) wts[k] = (RED == 100 && k >= RN - w) ? weights[k - (RN - w)] : 0.f;
   const double inv_w = 1.0 / (double)w;
   for (int p = blockIdx.y; p < P; p += gridDim.y) {
     const int64_t ta = seg_off[p], tb = seg_off[p + 1];
-    Ring<VEC> ring;
+    Ring<VEC, WT> ring;
     ring.fill_nan();
     int64_t last_true[VEC];
     RunAcc acc[VEC];
@@ -204,7 +220,7 @@ k_spell_runs(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
       for (int i = 0; i < VEC; ++i) {
         bool cond = false;
         if (have_row && tp >= w - 1) {
-          const float s = ring_stat<RED>(ring.v[i], w, inv_w, wts);
+          const float s = ring_stat<RED, WT>(ring.v[i], w, inv_w, wts);
           cond = (s == s) && xh_cmp_f32(s, op, thr);
         }
         if (cond) last_true[i] = tp;
@@ -254,7 +270,13 @@ int xh_launch_rolling_ring(xh_ctx* ctx, const float* x, int64_t T, int64_t C, in
   const dim3 grid = window_grid(ctx, T, C, vec);
 #define XH_RR(R)                                                                                                          \
   case R:                                                                                                                 \
-    if (vec == 4)                                                                                                         \
+    if (vec == 4 && window == 3)                                                                                          \
+      hipLaunchKernelGGL((k_rolling_ring<4, R, 3>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, left, right, out, \
+                         out_st);                                                                                         \
+    else if (vec == 4 && window == 5)                                                                                     \
+      hipLaunchKernelGGL((k_rolling_ring<4, R, 5>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, left, right, out, \
+                         out_st);                                                                                         \
+    else if (vec == 4)                                                                                                    \
       hipLaunchKernelGGL((k_rolling_ring<4, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, left, right, out, \
                          out_st);                                                                                         \
     else                                                                                                                  \
@@ -281,7 +303,13 @@ int xh_launch_spell_ring(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
   const int red = win_red == 0 ? XH_RED_SUM : win_red == 1 ? XH_RED_MEAN : win_red == 2 ? XH_RED_MIN : win_red == 3 ? XH_RED_MAX : 100;
 #define XH_SR(R)                                                                                                       \
   case R:                                                                                                              \
-    if (vec == 4)                                                                                                      \
+    if (vec == 4 && window == 3)                                                                                       \
+      hipLaunchKernelGGL((k_spell_ring<4, R, 3>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
+                         out, out_st);                                                                                 \
+    else if (vec == 4 && window == 5)                                                                                  \
+      hipLaunchKernelGGL((k_spell_ring<4, R, 5>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
+                         out, out_st);                                                                                 \
+    else if (vec == 4)                                                                                                 \
       hipLaunchKernelGGL((k_spell_ring<4, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
                          out, out_st);                                                                                 \
     else                                                                                                               \
@@ -310,6 +338,12 @@ int xh_launch_spell_runs(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
   case R:                                                                                                                  \
     if (vec == 4)                                                                                                          \
       hipLaunchKernelGGL((k_spell_runs<4, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
+                         stat, d_seg, P, out, valid_out);                                                                  \
+    else if (window == 3)                                                                                                  \
+      hipLaunchKernelGGL((k_spell_runs<1, R, 3>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
+                         stat, d_seg, P, out, valid_out);                                                                  \
+    else if (window == 5)                                                                                                  \
+      hipLaunchKernelGGL((k_spell_runs<1, R, 5>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
                          stat, d_seg, P, out, valid_out);                                                                  \
     else                                                                                                                   \
       hipLaunchKernelGGL((k_spell_runs<1, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
