@@ -57,8 +57,8 @@ __device__ __forceinline__ float ring_stat(const float (&r)[RingN<WT>::N], int w
   for (int k = 0; k < WMAX; ++k) {
     if (k >= WMAX - w) {  // uniform predicate
       const float x = r[k];
-      nan |= (x != x);
-      n += (x == x) ? 1 : 0;
+      if (RED == XH_RED_MIN || RED == XH_RED_MAX) nan |= (x != x);  // the fp64 sums propagate NaN by themselves
+      if (RED == XH_RED_COUNT) n += (x == x) ? 1 : 0;
       if (RED == XH_RED_MIN) e = (first || x < e) ? x : e;
       else if (RED == XH_RED_MAX) e = (first || x > e) ? x : e;
       else if (RED == 100) s += (double)x * (double)wts[k];  // weighted mean (spell_mask weights)
@@ -139,7 +139,7 @@ k_rolling_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, in
 // out[t] = any cond[t'] for t' in [t, t + w - 1], cond[t'] = stat(x[t'-w+1 .. t']) op thr (False for incomplete / NaN windows)
 template <int VEC, int RED, int WT = 0>
 __global__ void __launch_bounds__(XH_BLOCK)
-k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w_, int op, float thr,
+k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w_, int op, float thr, float sgn,
              const float* __restrict__ weights, float* __restrict__ out, int64_t out_st) {
   const int w = WT > 0 ? WT : w_;
   const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
@@ -156,9 +156,9 @@ k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
   const double inv_w = 1.0 / (double)w;
   Ring<VEC, WT> ring;
   ring.fill_nan();
-  int64_t last_true[VEC];
+  int since[VEC];  // steps since the last window that met the condition (spell_mask: any window covering t)
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) last_true[i] = -1;
+  for (int i = 0; i < VEC; ++i) since[i] = WMAX;
   // outputs t in [ta, tb) need cond[t'] for t' in [ta, tb + w - 2], i.e. rows [ta - (w - 1), tb + w - 2]
   const int64_t r0 = ta - (w - 1) < 0 ? 0 : ta - (w - 1);
   const int64_t r1 = tb + w - 1 > T ? T : tb + w - 1;
@@ -169,10 +169,10 @@ k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
       bool cond = false;
       if (have_row && tp >= w - 1) {
         const float s = ring_stat<RED, WT>(ring.v[i], w, inv_w, wts);
-        cond = (s == s) && xh_cmp_f32(s, op, thr);
+        cond = WT > 0 ? (s * sgn > thr) : ((s == s) && xh_cmp_f32(s, op, thr));  // WT > 0: xh_one_cmp form, NaN -> false
       }
-      if (cond) last_true[i] = tp;
-      r[i] = (last_true[i] >= tp - (w - 1)) ? 1.0f : 0.0f;
+      since[i] = cond ? 0 : since[i] + 1;
+      r[i] = (since[i] < w) ? 1.0f : 0.0f;
     }
     const int64_t t = tp - (w - 1);
     if (t >= ta && t < tb) store_vec<VEC>(out + t * out_st + c, r);
@@ -189,9 +189,9 @@ k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
 // directly (rle_statistics with window = 1 on the mask, runs cut at the period edges).  The mask near a period edge
 // depends on the rows of the neighbouring periods (the reference builds it on the whole series first): every period
 // re-reads a (w - 1)-row halo on both sides.  One workgroup row per period.
-template <int VEC, int RED, int WT = 0>
+template <int VEC, int RED, int WT = 0, int SG = 0>
 __global__ void __launch_bounds__(XH_BLOCK)
-k_spell_runs(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w_, int op, float thr,
+k_spell_runs(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w_, int op, float thr, float sgn,
              const float* __restrict__ weights, int stat, const int64_t* __restrict__ seg_off, int P, float* __restrict__ out,
              int32_t* __restrict__ valid_out) {
   const int w = WT > 0 ? WT : w_;
@@ -206,11 +206,11 @@ k_spell_runs(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
     const int64_t ta = seg_off[p], tb = seg_off[p + 1];
     Ring<VEC, WT> ring;
     ring.fill_nan();
-    int64_t last_true[VEC];
+    int since[VEC];
     RunAcc acc[VEC];
     int run[VEC], nvalid[VEC], days[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { last_true[i] = -1; acc_reset(acc[i]); run[i] = 0; nvalid[i] = 0; days[i] = 0; }
+    for (int i = 0; i < VEC; ++i) { since[i] = WMAX; acc_reset(acc[i]); run[i] = 0; nvalid[i] = 0; days[i] = 0; }
     const int64_t r0 = ta - (w - 1) < 0 ? 0 : ta - (w - 1);
     const int64_t r1 = tb + w - 1 > T ? T : tb + w - 1;
     auto emit = [&](int64_t tp, bool have_row) {
@@ -221,12 +221,12 @@ k_spell_runs(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
         bool cond = false;
         if (have_row && tp >= w - 1) {
           const float s = ring_stat<RED, WT>(ring.v[i], w, inv_w, wts);
-          cond = (s == s) && xh_cmp_f32(s, op, thr);
+          cond = WT > 0 ? (s * sgn > thr) : ((s == s) && xh_cmp_f32(s, op, thr));
         }
-        if (cond) last_true[i] = tp;
-        const bool on = inside && (last_true[i] >= tp - (w - 1));
+        since[i] = cond ? 0 : since[i] + 1;
+        const bool on = inside && (since[i] < w);
         const int len = (inside && !on) ? run[i] : 0;  // a spell ended at t - 1
-        acc_add_if<0>(acc[i], len);
+        acc_add_if<SG>(acc[i], len);
         run[i] = on ? run[i] + 1 : (inside ? 0 : run[i]);
         days[i] += on ? 1 : 0;
       }
@@ -245,7 +245,7 @@ k_spell_runs(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
     const int64_t o = (int64_t)p * C + c;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      if (run[i] > 0) acc_add(acc[i], run[i]);  // spell cut by the period end
+      acc_add_if<SG>(acc[i], run[i]);  // spell cut by the period end
       out[o + i] = acc_result(acc[i], stat, days[i]);
       if (valid_out) valid_out[o + i] = nvalid[i];
     }
@@ -294,34 +294,80 @@ int xh_launch_rolling_ring(xh_ctx* ctx, const float* x, int64_t T, int64_t C, in
   return XH_OK;
 }
 
+namespace {
+
+struct SpellArgs {
+  const float* x;
+  int64_t T, C, st;
+  int window, op;
+  float thr, sgn;
+  const float* d_weights;
+};
+
+template <int VEC, int RED, int WT>
+void launch_spell_ring_t(xh_ctx* ctx, dim3 grid, const SpellArgs& a, float* out, int64_t out_st) {
+  hipLaunchKernelGGL((k_spell_ring<VEC, RED, WT>), grid, dim3(XH_BLOCK), 0, ctx->stream, a.x, a.T, a.C, a.st, a.window, a.op,
+                     a.thr, a.sgn, a.d_weights, out, out_st);
+}
+
+template <int RED>
+void launch_spell_ring_r(xh_ctx* ctx, dim3 grid, int vec, int wt, const SpellArgs& a, float* out, int64_t out_st) {
+  if (vec == 4 && wt == 3) launch_spell_ring_t<4, RED, 3>(ctx, grid, a, out, out_st);
+  else if (vec == 4 && wt == 5) launch_spell_ring_t<4, RED, 5>(ctx, grid, a, out, out_st);
+  else if (vec == 4) launch_spell_ring_t<4, RED, 0>(ctx, grid, a, out, out_st);
+  else launch_spell_ring_t<1, RED, 0>(ctx, grid, a, out, out_st);
+}
+
+template <int VEC, int RED, int WT, int SG>
+void launch_spell_runs_t(xh_ctx* ctx, dim3 grid, const SpellArgs& a, int stat, const int64_t* d_seg, int P, float* out,
+                         int32_t* valid_out) {
+  hipLaunchKernelGGL((k_spell_runs<VEC, RED, WT, SG>), grid, dim3(XH_BLOCK), 0, ctx->stream, a.x, a.T, a.C, a.st, a.window,
+                     a.op, a.thr, a.sgn, a.d_weights, stat, d_seg, P, out, valid_out);
+}
+
+template <int RED>
+void launch_spell_runs_r(xh_ctx* ctx, dim3 grid, int vec, int wt, int sg, const SpellArgs& a, int stat, const int64_t* d_seg,
+                         int P, float* out, int32_t* valid_out) {
+#define XH_SRN(V, W)                                                                      \
+  do {                                                                                    \
+    if (sg == 1) launch_spell_runs_t<V, RED, W, 1>(ctx, grid, a, stat, d_seg, P, out, valid_out);      \
+    else if (sg == 2) launch_spell_runs_t<V, RED, W, 2>(ctx, grid, a, stat, d_seg, P, out, valid_out); \
+    else launch_spell_runs_t<V, RED, W, 0>(ctx, grid, a, stat, d_seg, P, out, valid_out);              \
+  } while (0)
+  if (vec == 1 && wt == 3) XH_SRN(1, 3);
+  else if (vec == 1 && wt == 5) XH_SRN(1, 5);
+  else if (vec == 4) launch_spell_runs_t<4, RED, 0, 0>(ctx, grid, a, stat, d_seg, P, out, valid_out);
+  else launch_spell_runs_t<1, RED, 0, 0>(ctx, grid, a, stat, d_seg, P, out, valid_out);
+#undef XH_SRN
+}
+
+// The compile-time windows (3, 5) take the one-compare form of the condition (xh_one_cmp): ordered op, finite threshold.
+SpellArgs spell_args(const float* x, int64_t T, int64_t C, int64_t st, int window, int op, float thr, const float* d_weights,
+                     bool wt_built, int* wt) {
+  SpellArgs a = {x, T, C, st, window, op, thr, 1.0f, d_weights};
+  const XhOneCmp one = xh_one_cmp(op, thr);
+  *wt = (wt_built && one.ok && (window == 3 || window == 5)) ? window : 0;
+  if (*wt) { a.thr = one.thr; a.sgn = one.sgn; }
+  return a;
+}
+
+}  // namespace
+
 int xh_launch_spell_ring(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int window, int win_red, int op,
                          float thr, const float* d_weights, float* out, int64_t out_st) {
   if (window > WMAX) return XH_ERR_NOTIMPL;
   const int vec = (xh_pick_vec(x, C, st) == 4 && xh_pick_vec(out, C, out_st) == 4) ? 4 : 1;
   const dim3 grid = window_grid(ctx, T, C, vec);
-  // win_red (spell.hip): 0 sum, 1 mean, 2 min, 3 max, 4 weighted mean
-  const int red = win_red == 0 ? XH_RED_SUM : win_red == 1 ? XH_RED_MEAN : win_red == 2 ? XH_RED_MIN : win_red == 3 ? XH_RED_MAX : 100;
-#define XH_SR(R)                                                                                                       \
-  case R:                                                                                                              \
-    if (vec == 4 && window == 3)                                                                                       \
-      hipLaunchKernelGGL((k_spell_ring<4, R, 3>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
-                         out, out_st);                                                                                 \
-    else if (vec == 4 && window == 5)                                                                                  \
-      hipLaunchKernelGGL((k_spell_ring<4, R, 5>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
-                         out, out_st);                                                                                 \
-    else if (vec == 4)                                                                                                 \
-      hipLaunchKernelGGL((k_spell_ring<4, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
-                         out, out_st);                                                                                 \
-    else                                                                                                               \
-      hipLaunchKernelGGL((k_spell_ring<1, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
-                         out, out_st);                                                                                 \
-    break;
-  switch (red) {
-    XH_SR(XH_RED_SUM) XH_SR(XH_RED_MEAN) XH_SR(XH_RED_MIN) XH_SR(XH_RED_MAX) XH_SR(100)
-    default:
-      return XH_ERR_NOTIMPL;
+  int wt;
+  const SpellArgs a = spell_args(x, T, C, st, window, op, thr, d_weights, vec == 4, &wt);
+  switch (win_red) {  // win_red (spell.hip): 0 sum, 1 mean, 2 min, 3 max, 4 weighted mean
+    case 0: launch_spell_ring_r<XH_RED_SUM>(ctx, grid, vec, wt, a, out, out_st); break;
+    case 1: launch_spell_ring_r<XH_RED_MEAN>(ctx, grid, vec, wt, a, out, out_st); break;
+    case 2: launch_spell_ring_r<XH_RED_MIN>(ctx, grid, vec, wt, a, out, out_st); break;
+    case 3: launch_spell_ring_r<XH_RED_MAX>(ctx, grid, vec, wt, a, out, out_st); break;
+    case 4: launch_spell_ring_r<100>(ctx, grid, vec, wt, a, out, out_st); break;
+    default: return XH_ERR_NOTIMPL;
   }
-#undef XH_SR
   XH_LAUNCH_CHECK();
   return XH_OK;
 }
@@ -333,28 +379,18 @@ int xh_launch_spell_runs(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
   // four cells per lane only when that still leaves >= 8 workgroups per CU (a period cannot be cut into time chunks)
   const int vec = (xh_pick_vec(x, C, st) == 4 && cdiv64(cdiv64(C, 4), XH_BLOCK) * py >= 8 * (int64_t)ctx->num_cu) ? 4 : 1;
   const dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), py);
-  const int red = win_red == 0 ? XH_RED_SUM : win_red == 1 ? XH_RED_MEAN : win_red == 2 ? XH_RED_MIN : win_red == 3 ? XH_RED_MAX : 100;
-#define XH_SRN(R)                                                                                                          \
-  case R:                                                                                                                  \
-    if (vec == 4)                                                                                                          \
-      hipLaunchKernelGGL((k_spell_runs<4, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
-                         stat, d_seg, P, out, valid_out);                                                                  \
-    else if (window == 3)                                                                                                  \
-      hipLaunchKernelGGL((k_spell_runs<1, R, 3>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
-                         stat, d_seg, P, out, valid_out);                                                                  \
-    else if (window == 5)                                                                                                  \
-      hipLaunchKernelGGL((k_spell_runs<1, R, 5>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
-                         stat, d_seg, P, out, valid_out);                                                                  \
-    else                                                                                                                   \
-      hipLaunchKernelGGL((k_spell_runs<1, R>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window, op, thr, d_weights, \
-                         stat, d_seg, P, out, valid_out);                                                                  \
-    break;
-  switch (red) {
-    XH_SRN(XH_RED_SUM) XH_SRN(XH_RED_MEAN) XH_SRN(XH_RED_MIN) XH_SRN(XH_RED_MAX) XH_SRN(100)
-    default:
-      return XH_ERR_NOTIMPL;
+  int wt;
+  const SpellArgs a = spell_args(x, T, C, st, window, op, thr, d_weights, vec == 1, &wt);
+  // fields of the run accumulator the statistic reads (runacc.h): 1 max, 2 sum / count / mean / plain sum, 0 all
+  const int sg = stat == XH_RUN_MAX ? 1 : (stat == XH_RUN_SUM || stat == XH_RUN_COUNT || stat == XH_RUN_MEAN || stat == XH_RUN_PLAINSUM) ? 2 : 0;
+  switch (win_red) {
+    case 0: launch_spell_runs_r<XH_RED_SUM>(ctx, grid, vec, wt, sg, a, stat, d_seg, P, out, valid_out); break;
+    case 1: launch_spell_runs_r<XH_RED_MEAN>(ctx, grid, vec, wt, sg, a, stat, d_seg, P, out, valid_out); break;
+    case 2: launch_spell_runs_r<XH_RED_MIN>(ctx, grid, vec, wt, sg, a, stat, d_seg, P, out, valid_out); break;
+    case 3: launch_spell_runs_r<XH_RED_MAX>(ctx, grid, vec, wt, sg, a, stat, d_seg, P, out, valid_out); break;
+    case 4: launch_spell_runs_r<100>(ctx, grid, vec, wt, sg, a, stat, d_seg, P, out, valid_out); break;
+    default: return XH_ERR_NOTIMPL;
   }
-#undef XH_SRN
   XH_LAUNCH_CHECK();
   return XH_OK;
 }
