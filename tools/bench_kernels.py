@@ -62,6 +62,13 @@ run("season w5", lambda: K.season(dev, mask, 5, seg_y, None), 4 * E)
 run("max_run_sum w3", lambda: K.max_run_sum(dev, pr, 3, seg_y), 4 * E)
 tb, years, doys = ta.doy_table()
 run("doy_mean_std w5", lambda: K.doy_mean_std(dev, tas, tb, 5), 4 * E + 8 * len(doys) * C)
+# a climatology is taken over decades: 30 years x (1440 x 72) cells, the same 4.5 GB of samples per year-block
+T30, C30 = 365 * 30, 1440 * 72
+ta30 = TimeAxis.daily("1971-01-01", T30, "noleap")
+tb30, _, doys30 = ta30.doy_table()
+tas30 = K.fill_synthetic(dev, T30, C30, 0, 5, bench.seasonal_base(T30), 3.0)
+run("doy_mean_std w5 30yr", lambda: K.doy_mean_std(dev, tas30, tb30, 5), 4.0 * T30 * C30 + 8 * len(doys30) * C30)
+del tas30
 p = K.percentile_doy(dev, tas, tb, 5, [90.0])
 tidx = np.searchsorted(doys, ta.doy).astype(np.int32)
 run("compare_doy", lambda: K.compare_doy(dev, tas, ">", p.reshape(len(doys), C), tidx), 8 * E + 8 * len(doys) * C)

@@ -93,8 +93,9 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
     }
     int pt = 0;  // period of the current time step (uniform across lanes)
     int64_t tend = seg_off[P];
+    int64_t next_edge = seg_off[1];  // kept in a scalar register: one s_load per period, not per step
     xh_march_rows<VEC, 8>(x + c, st, seg_off[0], tend, [&](int64_t t, const VecF<VEC>& xv) {
-      while (t >= seg_off[pt + 1]) {
+      while (t >= next_edge) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           if (valid_out) valid_out[(int64_t)pt * C + c + i] = nvalid[i];
@@ -102,6 +103,7 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
           nvalid[i] = 0; plainsum[i] = 0;
         }
         pt++;
+        next_edge = seg_off[pt + 1];
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -111,25 +113,25 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
         bool masknan = (!fused) && isn;
         nvalid[i] += isn ? 0 : 1;
         plainsum[i] += on ? 1 : 0;
-        if (on) {
-          if (s[i].run == 0) { s[i].vis = !s[i].prevnan; s[i].startp = pt; }
-          s[i].run++;
-        } else if (s[i].run > 0) {
-          bool visible = index_first >= 2 ? true : (index_first ? s[i].vis : !masknan);
-          if (visible && s[i].run >= window && stat != XH_RUN_PLAINSUM) {
-            // the run ended at t-1; its last element is in period pt unless t is the first step of pt
-            int pa = pt;
-            if (index_first) pa = s[i].startp;
-            else while (pa > 0 && t - 1 < seg_off[pa]) pa--;  // skip empty periods before t
-            while (accp[i] < pa) {
-              out[(int64_t)accp[i] * C + c + i] = acc_result(acc[i], stat, 0);
-              acc_reset(acc[i]);
-              accp[i]++;
-            }
-            acc_add(acc[i], s[i].run);
+        // branch-free step; only a qualifying run that ENDS here takes the (rare, divergent) attribution path
+        const bool visible = index_first >= 2 ? true : (index_first ? s[i].vis : !masknan);
+        const bool qual = !on && visible && s[i].run >= window && stat != XH_RUN_PLAINSUM;  // window >= 1: run > 0
+        if (qual) {
+          // the run ended at t-1; its last element is in period pt unless t is the first step of pt
+          int pa = pt;
+          if (index_first) pa = s[i].startp;
+          else while (pa > 0 && t - 1 < seg_off[pa]) pa--;  // skip empty periods before t
+          while (accp[i] < pa) {
+            out[(int64_t)accp[i] * C + c + i] = acc_result(acc[i], stat, 0);
+            acc_reset(acc[i]);
+            accp[i]++;
           }
-          s[i].run = 0;
+          acc_add(acc[i], s[i].run);
         }
+        const bool starts = on && s[i].run == 0;
+        s[i].vis = starts ? !s[i].prevnan : s[i].vis;
+        s[i].startp = starts ? pt : s[i].startp;
+        s[i].run = on ? s[i].run + 1 : 0;
         s[i].prevnan = masknan;
       }
     });

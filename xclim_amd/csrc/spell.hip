@@ -265,6 +265,69 @@ k_season(const float* __restrict__ x, int64_t C, int64_t st, int window, const i
   }
 }
 
+// window >= 2 (no argmax == argmin quirk): ONE counter per cell and two mode flags instead of the two counters, two
+// True-counts and ~8 compares per cell-step of k_season (v_cmp issues at half rate on gfx950, tools/valu_ubench.hip).
+//   mode 0 (m0): looking for the start, k = consecutive True;   valid while i < limit
+//   mode 1 (m1): looking for the end,   k = consecutive False;  valid from i >= mid, the count restarts at i == mid
+// The end search formally begins at lb = max(start, mid): steps start .. start + window - 1 are True, so counting the
+// False steps from the step the start became known (k = 0 there) is the same count when start >= mid, and the restart
+// at i == mid (uniform) cuts the runs there when mid > start.  2 compares + 6 selects / adds per cell-step; the mode
+// flags live in lane masks (SALU).
+template <int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_season_w(const float* __restrict__ x, int64_t C, int64_t st, int window, const int64_t* __restrict__ seg_off,
+           const int32_t* __restrict__ mid_idx, int has_date, int P, float* __restrict__ start_out,
+           float* __restrict__ end_out, float* __restrict__ len_out) {
+  int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    const int len = (int)(t1 - t0);
+    const int mid = has_date ? mid_idx[p] : 0;
+    const bool nodate = has_date && mid < 0;
+    int limit = has_date ? (mid + window - 1) : len;
+    if (limit > len) limit = len;
+    int k[VEC], beg[VEC], end[VEC];
+    bool m0[VEC], m1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { k[v] = 0; beg[v] = -1; end[v] = -1; m0[v] = true; m1[v] = false; }
+    xh_march_rows<VEC, 8>(x + c, st, t0, t1, [&](int64_t t, const VecF<VEC>& xv) {
+      const int i = (int)(t - t0);
+      const bool a_ok = i < limit, b_ok = i >= mid, at_mid = i == mid;
+      const int pos = i - window + 1;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const bool on = xv.v[v] > 0.0f;
+        const bool hit = on != m1[v];
+        const int kp = (at_mid && m1[v]) ? 0 : k[v];
+        const int kn = hit ? kp + 1 : 0;
+        const bool ge = kn >= window;
+        const bool d0 = ge && m0[v] && a_ok;
+        const bool d1 = ge && m1[v] && b_ok;
+        beg[v] = d0 ? pos : beg[v];
+        end[v] = d1 ? pos : end[v];
+        k[v] = d0 ? 0 : kn;
+        m0[v] = m0[v] && !d0;
+        m1[v] = (m1[v] || d0) && !d1;
+      }
+    });
+    const int64_t o = (int64_t)p * C + c;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float fs = xh_nan32(), fe = xh_nan32(), fl = 0.0f;
+      const int b = beg[v], e = end[v];
+      if (!nodate && b >= 0) {
+        fs = (float)b;
+        fl = e < 0 ? (float)(len - b) : (float)(e - b);
+        fe = e < 0 ? (float)(len - 1) : (float)e;
+      }
+      start_out[o + v] = fs;
+      end_out[o + v] = fe;
+      len_out[o + v] = fl;
+    }
+  }
+}
+
 // ---- windowed_max_run_sum (cut at segments / whole series) ------------------------------------------------------
 // rl:491-540: d_rse = reset-cumsum of the VALUES from the run's first element to the next exact zero (NaN adds 0
 // and does not reset), kept where rle(da > 0) >= window, max over the period.  Backward march.
@@ -594,7 +657,15 @@ int xh_season(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int
     if (rc) return rc;
   }
   if (C == 0) return XH_OK;
-  if (xh_pick_vec(x, C, st) == 4)
+  if (window >= 2 && xh_pick_vec(x, C, st) == 4)
+    hipLaunchKernelGGL((k_season_w<4>), dim3((unsigned)cdiv64(cdiv64(C, 4), XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)),
+                       dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, d_seg, (const int32_t*)d_mid, mid_idx ? 1 : 0, P,
+                       start_out, end_out, len_out);
+  else if (window >= 2)
+    hipLaunchKernelGGL((k_season_w<1>), dim3((unsigned)cdiv64(C, XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)), dim3(XH_BLOCK), 0,
+                       ctx->stream, x, C, st, window, d_seg, (const int32_t*)d_mid, mid_idx ? 1 : 0, P, start_out, end_out,
+                       len_out);
+  else if (xh_pick_vec(x, C, st) == 4)
     hipLaunchKernelGGL((k_season<4>), dim3((unsigned)cdiv64(cdiv64(C, 4), XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P)),
                        dim3(XH_BLOCK), 0, ctx->stream, x, C, st, window, d_seg, (const int32_t*)d_mid, mid_idx ? 1 : 0, P,
                        start_out, end_out, len_out);
