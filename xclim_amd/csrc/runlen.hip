@@ -93,6 +93,7 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
     }
     int pt = 0;  // period of the current time step (uniform across lanes)
     int64_t tend = seg_off[P];
+    int pprev = 0;                   // period of the previous time step
     int64_t next_edge = seg_off[1];  // kept in a scalar register: one s_load per period, not per step
     xh_march_rows<VEC, 8>(x + c, st, seg_off[0], tend, [&](int64_t t, const VecF<VEC>& xv) {
       while (t >= next_edge) {
@@ -104,6 +105,20 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
         }
         pt++;
         next_edge = seg_off[pt + 1];
+        // early flush, all lanes together: a cell that is not inside a run has every period before pt final (any later
+        // run is attributed to pt or later), so the lazy per-run flush below only fires for runs that span an edge
+        if (stat != XH_RUN_PLAINSUM) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            if (s[i].run == 0) {
+              while (accp[i] < pt) {
+                out[(int64_t)accp[i] * C + c + i] = acc_result(acc[i], stat, 0);
+                acc_reset(acc[i]);
+                accp[i]++;
+              }
+            }
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -116,24 +131,23 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
         // branch-free step; only a qualifying run that ENDS here takes the (rare, divergent) attribution path
         const bool visible = index_first >= 2 ? true : (index_first ? s[i].vis : !masknan);
         const bool qual = !on && visible && s[i].run >= window && stat != XH_RUN_PLAINSUM;  // window >= 1: run > 0
-        if (qual) {
-          // the run ended at t-1; its last element is in period pt unless t is the first step of pt
-          int pa = pt;
-          if (index_first) pa = s[i].startp;
-          else while (pa > 0 && t - 1 < seg_off[pa]) pa--;  // skip empty periods before t
-          while (accp[i] < pa) {
+        // the run ended at t-1: index="last" attributes it to the period of step t-1 (pprev), "first" to its start's
+        const int pa = index_first ? s[i].startp : pprev;
+        if (qual && accp[i] < pa) {
+          do {
             out[(int64_t)accp[i] * C + c + i] = acc_result(acc[i], stat, 0);
             acc_reset(acc[i]);
             accp[i]++;
-          }
-          acc_add(acc[i], s[i].run);
+          } while (accp[i] < pa);
         }
+        acc_add_if<SG>(acc[i], qual ? s[i].run : 0);
         const bool starts = on && s[i].run == 0;
         s[i].vis = starts ? !s[i].prevnan : s[i].vis;
         s[i].startp = starts ? pt : s[i].startp;
         s[i].run = on ? s[i].run + 1 : 0;
         s[i].prevnan = masknan;
       }
+      pprev = pt;
     });
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -146,7 +160,7 @@ k_run_stats(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int f
             acc_reset(acc[i]);
             accp[i]++;
           }
-          acc_add(acc[i], s[i].run);
+          acc_add_if<SG>(acc[i], s[i].run);
         }
       }
       if (stat != XH_RUN_PLAINSUM) {
@@ -550,8 +564,14 @@ int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, 
     XH_REQUIRE(seg_off[0] == 0 && seg_off[P] == T, XH_ERR_ARG,
                "xh_run_stats: resample-after mode needs segments covering [0, T)");
     dim3 grid((unsigned)cdiv64(C, XH_BLOCK), 1);
-    hipLaunchKernelGGL((k_run_stats<1, false>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, fused_op, (float)thr,
-                       window, stat, index_first, d_seg, P, out, valid_out);
+    // stat group: 1 max, 2 sum / count / mean, 3 min, 0 all (std)
+    const int sg = stat == XH_RUN_MAX ? 1 : (stat == XH_RUN_SUM || stat == XH_RUN_COUNT || stat == XH_RUN_MEAN || stat == XH_RUN_PLAINSUM) ? 2
+                   : stat == XH_RUN_MIN ? 3 : 0;
+#define XH_RSN(G)                                                                                                          \
+  hipLaunchKernelGGL((k_run_stats<1, false, G>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, fused_op, (float)thr, \
+                     window, stat, index_first, d_seg, P, out, valid_out)
+    if (sg == 1) XH_RSN(1); else if (sg == 2) XH_RSN(2); else if (sg == 3) XH_RSN(3); else XH_RSN(0);
+#undef XH_RSN
   }
   XH_LAUNCH_CHECK();
   return XH_OK;
