@@ -212,7 +212,10 @@ def test_fuzz_eqm_and_two_variable_reductions(dev, seed):
             extrap = str(rng.choice(["constant", "nan"]))
             got = K.eqm_adjust(dev, dev.to_device(sim), dev.to_device(eaf32), dev.to_device(ehq32), kind, interp, extrap).get()
             exp = osdba.eqm_adjust(sim, eaf32, ehq32, kind, interp, extrap)
-            np.testing.assert_allclose(got, exp, rtol=2e-6, atol=0, equal_nan=True, err_msg=f"adjust {interp} {extrap} {kind} T={T} C={C} nq={nq}")
+            # north star: 1e-6 relative for the piecewise-constant / piecewise-linear factors; the cubic spline
+            # (scipy fp64 in the oracle, fp32 Horner on the device) is held to 2e-6
+            np.testing.assert_allclose(got, exp, rtol=2e-6 if interp == "cubic" else 1e-6, atol=0, equal_nan=True,
+                                       err_msg=f"adjust {interp} {extrap} {kind} T={T} C={C} nq={nq}")
         # two-variable range reductions
         lo = ref.reshape((T,) + cells)
         hi = (ref + np.abs(hist)).reshape((T,) + cells)

@@ -269,7 +269,12 @@ static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t 
   // buffers and two streams: batch k+1 is transposed on stream2 while batch k is selected on the main stream (the
   // selection kernels are latency bound and leave the memory pipe mostly idle).
   const int64_t Tp = (T + 63) & ~(int64_t)63;  // padded column stride: every 64-float segment the transpose writes is one aligned 256-byte block (a misaligned segment touches three 128-byte lines instead of two)
-  int64_t batch = (int64_t)((1ull << 29) / (sizeof(float) * (size_t)Tp));
+  size_t batch_bytes = 1ull << 29;
+  if (const char* e = xh_diag_env("XH_SELECT_BATCH_MB")) {  // diagnostics: scratch batch size (MALL residency experiments)
+    const long mb = atol(e);
+    if (mb >= 1 && mb <= 4096) batch_bytes = (size_t)mb << 20;
+  }
+  int64_t batch = (int64_t)(batch_bytes / (sizeof(float) * (size_t)Tp));
   batch = (batch / 64) * 64;
   if (batch < 64) batch = 64;
   if (batch > C) batch = C;
