@@ -537,8 +537,10 @@ def test_synthetic_matches_oracle(dev):
         np.testing.assert_array_equal(g, e)
 
 
-def test_transpose(dev, rng):
-    x = rng.normal(size=(130, 77)).astype(np.float32)
+@pytest.mark.parametrize("shape", [(130, 77), (128, 128), (300, 388), (257, 260), (5, 4), (8, 4), (1000, 132)])
+def test_transpose(dev, rng, shape):
+    """xh_transpose_f32: the 128 x 128 / 16-byte kernel (cols % 4 == 0: full and edge tiles) and the 64 x 64 one."""
+    x = rng.normal(size=shape).astype(np.float32)
     np.testing.assert_array_equal(K.transpose(dev, dev.to_device(x)).get(), x.T)
 
 

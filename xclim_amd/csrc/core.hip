@@ -380,6 +380,50 @@ k_transpose_f32(const float* __restrict__ in, int64_t rows, int64_t cols, int64_
   }
 }
 
+// 128 x 128 tile, 16-byte accesses on both sides: a wave reads two 512-byte row pieces per instruction and writes two
+// 512-byte column pieces (the 64 x 64 tile above moves 256-byte pieces: twice as many DRAM page switches per byte).
+// Interior tiles only (rows / cols multiples of 128 are not required: the edges fall back to clamped scalar stores).
+__global__ void __launch_bounds__(XH_BLOCK)
+k_transpose128_f32(const float* __restrict__ in, int64_t rows, int64_t cols, int64_t in_stride, float* __restrict__ out,
+                   int64_t out_stride) {
+  __shared__ float tile[128][129];
+  const int64_t r0 = (int64_t)blockIdx.y * 128, c0 = (int64_t)blockIdx.x * 128;
+  const int q = threadIdx.x & 31, h = threadIdx.x >> 5;  // 32 lanes x 16 B = one 512-byte row piece; 8 pieces per pass
+  const bool full = r0 + 128 <= rows && c0 + 128 <= cols;
+  if (full) {
+    float4 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const float4*>(in + (r0 + h + 8 * k) * in_stride + c0 + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float* t = &tile[h + 8 * k][4 * q];
+      t[0] = v[k].x; t[1] = v[k].y; t[2] = v[k].z; t[3] = v[k].w;
+    }
+  } else {  // edge tile: element-wise, clamped (values beyond the edge are never stored)
+    const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
+    const int64_t cc = c0 + tx < cols ? c0 + tx : cols - 1;
+    for (int k = 0; k < 64; ++k) {
+      const int64_t r = r0 + ty + 2 * k;
+      tile[ty + 2 * k][tx] = in[(r < rows ? r : rows - 1) * in_stride + cc];
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int c = h + 8 * k;  // output row = input column
+    const int r = 4 * q;
+    const float4 o = make_float4(tile[r][c], tile[r + 1][c], tile[r + 2][c], tile[r + 3][c]);
+    float* dst = out + (c0 + c) * out_stride + r0 + r;
+    if (full) *reinterpret_cast<float4*>(dst) = o;
+    else if (c0 + c < cols) {
+      if (r0 + r < rows) dst[0] = o.x;
+      if (r0 + r + 1 < rows) dst[1] = o.y;
+      if (r0 + r + 2 < rows) dst[2] = o.z;
+      if (r0 + r + 3 < rows) dst[3] = o.w;
+    }
+  }
+}
+
 extern "C" {
 
 int xh_fill_synthetic(xh_ctx* ctx, float* out, int64_t T, int64_t C, int64_t st, int kind, uint64_t seed, int64_t cell0,
@@ -401,6 +445,16 @@ int xh_transpose_f32(xh_ctx* ctx, const float* in, int64_t rows, int64_t cols, i
   XH_REQUIRE(rows >= 0 && cols >= 0 && in_stride >= cols && out_stride >= rows, XH_ERR_ARG,
              "xh_transpose_f32: bad shape/strides");
   if (rows == 0 || cols == 0) return XH_OK;
+  const bool al16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && in_stride % 4 == 0 &&
+                    out_stride % 4 == 0 && cols >= 4;
+  const char* e64 = xh_diag_env("XH_TRANSPOSE_64");  // diagnostics: force the 64 x 64 kernel
+  if (al16 && !(e64 && atoi(e64))) {
+    dim3 grid((unsigned)cdiv64(cols, 128), (unsigned)cdiv64(rows, 128));
+    XH_REQUIRE(grid.y <= 65535u, XH_ERR_LIMIT, "xh_transpose_f32: too many row tiles");
+    hipLaunchKernelGGL(k_transpose128_f32, grid, dim3(XH_BLOCK), 0, ctx->stream, in, rows, cols, in_stride, out, out_stride);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+  }
   dim3 grid((unsigned)cdiv64(cols, 64), (unsigned)cdiv64(rows, 64));
   XH_REQUIRE(grid.y <= 65535u, XH_ERR_LIMIT, "xh_transpose_f32: too many row tiles");
   hipLaunchKernelGGL(k_transpose_f32, grid, dim3(XH_BLOCK), 0, ctx->stream, in, rows, cols, in_stride, out, out_stride);

@@ -268,7 +268,13 @@ static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t 
   // time-major: transpose batches of columns into scratch (not counted as algorithmic bytes).  Two scratch
   // buffers and two streams: batch k+1 is transposed on stream2 while batch k is selected on the main stream (the
   // selection kernels are latency bound and leave the memory pipe mostly idle).
-  const int64_t Tp = (T + 63) & ~(int64_t)63;  // padded column stride: every 64-float segment the transpose writes is one aligned 256-byte block (a misaligned segment touches three 128-byte lines instead of two)
+  // padded column stride: every 64-float segment the transpose writes is one aligned 256-byte block (a misaligned segment
+  // touches three 128-byte lines instead of two), and an ODD number of 256-byte blocks per column: the selection
+  // workgroups stream hundreds of columns in lockstep, and with an even count (11008 floats = 172 blocks at T = 10950)
+  // the same offset of consecutive columns falls onto a quarter of the HBM channels.
+  int64_t Tp = (T + 63) & ~(int64_t)63;
+  if (((Tp / 64) & 1) == 0) Tp += 64;
+  if (const char* e = xh_diag_env("XH_SELECT_TPAD")) Tp = ((T + 63) & ~(int64_t)63) + 64 * (int64_t)atol(e);  // diagnostics
   size_t batch_bytes = 1ull << 29;
   if (const char* e = xh_diag_env("XH_SELECT_BATCH_MB")) {  // diagnostics: scratch batch size (MALL residency experiments)
     const long mb = atol(e);

@@ -404,7 +404,8 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
           if (gamma >= 0.5) r = (double)right - (double)diff * (1.0 - gamma);
         }
       }
-      out[col * out_cstride + (int64_t)j * out_qstride] = (float)r;
+      if (!(abl & 16)) out[col * out_cstride + (int64_t)j * out_qstride] = (float)r;
+      else if (r == 12345.678) out[0] = (float)r;
     }
     lds_barrier();  // vals / tinfo / red are rewritten by the next column
     XH_PHASE(7);
@@ -451,10 +452,11 @@ int xh_select_columns_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t n
                            const double* d_q, int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
   if (T <= 1024 || T > 16384 || nq > 64) return XH_ERR_NOTIMPL;
 #define XH_LEAN(NT, KPL, NB) return launch_lean<NT, KPL, NB>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride)
-  // threads per column: 256 (4 workgroups per CU, 48 keys per thread) beats 512 (2 per CU) on 30-year series — 0.40 vs
-  // 0.43 ms per 12160 columns alone, 100 vs 107 ms for the config-4 train (profiles/r02/eqm_c4_anatomy.txt)
+  // threads per column above 4096 steps: 512 (two workgroups per CU).  Alone, 256 threads (four per CU) are a little
+  // ahead on 30-year series (0.40 vs 0.43 ms per 12160 columns); next to the 128 x 128 transposes of the time-major
+  // pipeline 512 wins: config-4 train 92.7 vs 98.5 ms (profiles/r02/eqm_c4_anatomy.txt).
   const char* ent = xh_diag_env("XH_LEAN_NT");  // tuning only
-  const int nt = ent ? atoi(ent) : (T > 8192 ? 256 : 512);
+  const int nt = ent ? atoi(ent) : 512;
   if (T <= 2048) XH_LEAN(256, 8, 1024);
   if (T <= 3072) XH_LEAN(256, 12, 1024);
   if (T <= 4096) XH_LEAN(256, 16, 1024);
