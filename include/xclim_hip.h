@@ -425,6 +425,14 @@ int xh_eqm_train(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, in
  * 1 nan); scen = sim + af_t (kind 0) or sim * af_t (kind 1).  scen (T, C) row stride scen_st. */
 int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const float* af,
                   const float* hist_q, int nq, int kind, int interp, int extrap, float* scen, int64_t scen_st);
+/* QuantileDeltaMapping.adjust (xsdba._adjustment.qdm_adjust, group "time"): sim_q = rank(sim, pct=True) along time
+ * (average ranks of the valid samples r / n, rescaled mx (r/n - mn) / (mx - mn) as xsdba.utils.rank does);
+ * af_t = interp_on_quantiles(sim_q, q, af) with the nq quantile nodes q (host, strictly increasing) as abscissa
+ * (interp 0 nearest, 1 linear; extrap 0 constant, 1 nan; NaN factors dropped per cell); scen = sim + af_t (kind 0) or
+ * sim * af_t (kind 1).  af (nq, C) float32 as trained by xh_eqm_train.  scen has the layout of sim (st, sc);
+ * 1 <= T <= 16384.  Parity unpinned (xsdba is not in the reference tree). */
+int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const float* af,
+                  const double* q /* host */, int nq, int kind, int interp, int extrap, float* scen);
 
 #ifdef __cplusplus
 }

@@ -48,7 +48,7 @@ def eqm_train(ref, hist, nquantiles=20, kind="+"):
 def _interp_1d(newx, oldx, oldy, method, extrap):
     mask_new = np.isnan(newx)
     mask_old = np.isnan(oldy) | np.isnan(oldx)
-    out = np.full_like(newx, np.nan, dtype=oldy.dtype)
+    out = np.full(np.shape(newx), np.nan, dtype=oldy.dtype)
     if mask_new.all() or mask_old.all() or (~mask_old).sum() < 2:
         return out
     fill = (oldy[~mask_old][0], oldy[~mask_old][-1]) if extrap == "constant" else np.nan
@@ -68,6 +68,42 @@ def eqm_adjust(sim, af, hist_q, kind="+", interp="nearest", extrapolation="const
     out = np.empty_like(s2)
     for c in range(s2.shape[1]):
         af_t = _interp_1d(s2[:, c], h2[:, c], a2[:, c], interp, extrapolation)
+        with np.errstate(all="ignore"):
+            out[:, c] = s2[:, c] + af_t if kind == "+" else s2[:, c] * af_t
+    return out.reshape(sim.shape)
+
+
+# ---- QuantileDeltaMapping (xsdba._adjustment.qdm_adjust, group "time") — specified restatement, parity unpinned ---------
+def rank_pct(x):
+    """xsdba.utils.rank(da, dim="time", pct=True) for one series: average ranks of the valid samples divided by their
+    count (xarray's ``rank(pct=True)``), then rescaled ``mx * (rnk - mn) / (mx - mn)`` so that the smallest sample gets 0
+    (xarray's own percentage ranks start at 1 / n); NaN stays NaN."""
+    from scipy.stats import rankdata
+
+    x = np.asarray(x)
+    out = np.full(x.shape, np.nan, dtype=np.float64)
+    ok = ~np.isnan(x)
+    n = int(ok.sum())
+    if n == 0:
+        return out
+    rnk = rankdata(x[ok], method="average") / n
+    mn, mx = rnk.min(), rnk.max()
+    with np.errstate(all="ignore"):
+        out[ok] = mx * (rnk - mn) / (mx - mn)
+    return out
+
+
+def qdm_adjust(sim, af, quantiles, kind="+", interp="nearest", extrapolation="constant"):
+    """sim (T, C); af (nq, C); quantiles (nq,) — the abscissa of the factors is the quantile node, the same for every
+    cell: sim_q = rank(sim, pct=True); af_t = interp_on_quantiles(sim_q, quantiles, af); scen = sim (+|*) af_t."""
+    sim = np.asarray(sim)
+    T = sim.shape[0]
+    s2 = sim.reshape(T, -1)
+    a2 = np.asarray(af).reshape(af.shape[0], -1)
+    xq = np.asarray(quantiles, dtype=np.float64)
+    out = np.empty_like(s2)
+    for c in range(s2.shape[1]):
+        af_t = _interp_1d(rank_pct(s2[:, c]), xq, a2[:, c], interp, extrapolation)
         with np.errstate(all="ignore"):
             out[:, c] = s2[:, c] + af_t if kind == "+" else s2[:, c] * af_t
     return out.reshape(sim.shape)

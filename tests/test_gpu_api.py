@@ -1198,3 +1198,78 @@ def test_consecutive_day_indices_reference_known_answers(dev):
     b[5:15] += 30
     out = xi.maximum_consecutive_tx_days(b.astype(np.float32)[:, None], 25 + K2C, TimeAxis.daily("2010-01-01", 365), "ME", **kw)
     assert out[0, 0] == 10 and (out[1:] == 0).all()
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("interp", ["nearest", "linear"])
+@pytest.mark.parametrize("T,cells", [(365, (7, 9)), (800, (33,)), (3000, (5,)), (10950, (3,)), (50, (4, 4)), (1, (3,))])
+def test_qdm_adjust_matches_oracle(dev, rng, kind, interp, T, cells):
+    """QuantileDeltaMapping.adjust == rank(pct) + interp_on_quantiles + apply_correction of the oracle (scipy rankdata /
+    interp1d), every kernel variant (T 1 .. 10950), NaN samples, tied samples, both extrapolations.  Parity unpinned."""
+    from xclim_amd import sdba as xsdba
+
+    shape = (T,) + cells
+    ref = rng.normal(10, 3, shape).astype(np.float32)
+    hist = rng.normal(11, 4, shape).astype(np.float32)
+    sim = rng.normal(13, 4, shape).astype(np.float32)
+    if kind == "*":
+        ref, hist, sim = np.abs(ref) + 1, np.abs(hist) + 1, np.abs(sim) + 1
+    sim[rng.random(shape) < 0.03] = np.nan
+    if T > 10:
+        sim[T // 3] = sim[T // 2]          # ties (a whole row repeated)
+        sim[:, ..., 0] = np.round(sim[:, ..., 0])   # a heavily tied cell
+    qdm = xsdba.QuantileDeltaMapping.train(ref, hist, nquantiles=20, kind=kind, device=dev)
+    for extrap in ("constant", "nan"):
+        got = qdm.adjust(sim, interp=interp, extrapolation=extrap)
+        exp = osdba.qdm_adjust(sim, qdm.af, qdm.quantiles, kind, interp, extrap)
+        np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0, equal_nan=True, err_msg=f"{extrap}")
+
+
+def test_qdm_precipitation_and_edge_cases(dev, rng):
+    """Dry days (most samples tied at the minimum, rank 0), an all-NaN cell, a constant cell (0 / 0 ranks -> NaN), NaN
+    factors (dropped nodes), the time-minor layout, argument errors."""
+    from xclim_amd import kernels as K
+    from xclim_amd import sdba as xsdba
+
+    T, C = 730, 64
+    def pr():
+        x = rng.gamma(0.7, 4.0, (T, C)).astype(np.float32)
+        x[rng.random((T, C)) < 0.6] = 0.0
+        return x
+    ref, hist, sim = pr(), pr(), pr()
+    sim[:, 1] = np.nan
+    sim[:, 2] = 3.0
+    sim[5:40, 3] = np.nan
+    qdm = xsdba.QuantileDeltaMapping.train(ref, hist, nquantiles=15, kind="*", device=dev)   # 0 / 0 factors at the dry nodes
+    for interp in ("nearest", "linear"):
+        got = qdm.adjust(sim, interp=interp)
+        exp = osdba.qdm_adjust(sim, qdm.af, qdm.quantiles, "*", interp, "constant")
+        np.testing.assert_allclose(got, exp, rtol=1e-6, equal_nan=True, err_msg=interp)
+    assert np.isnan(got[:, 1]).all() and np.isnan(got[:, 2]).all()
+    # time-minor (cells, time) layout gives the transposed result
+    af = dev.to_device(qdm.af.reshape(15, C))
+    tm = K.qdm_adjust(dev, dev.to_device(np.ascontiguousarray(sim.T)), af, qdm.quantiles, "*", "linear", time_axis=1).get()
+    np.testing.assert_array_equal(tm.T, got)
+    with pytest.raises(NotImplementedError):
+        qdm.adjust(sim, interp="cubic")
+    with pytest.raises(NotImplementedError):
+        xsdba.QuantileDeltaMapping.train(ref, hist, group="time.month", device=dev)
+    with pytest.raises(ValueError):
+        K.qdm_adjust(dev, dev.to_device(sim), af, qdm.quantiles[::-1].copy())
+
+
+def test_qdm_preserves_quantile_deltas(dev, rng):
+    """The defining property (Cannon et al. 2015): with additive factors the change between hist and sim of every quantile
+    is carried over to the adjusted series: q(scen) - q(ref) ~ q(sim) - q(hist)."""
+    from xclim_amd import sdba as xsdba
+
+    T = 6000
+    ref = rng.normal(10, 2, (T, 4)).astype(np.float32)
+    hist = rng.normal(12, 3, (T, 4)).astype(np.float32)
+    sim = (rng.normal(12, 3, (T, 4)) * 1.2 + 2.0).astype(np.float32)   # warmer and more variable future
+    qdm = xsdba.QuantileDeltaMapping.train(ref, hist, nquantiles=50, kind="+", device=dev)
+    scen = qdm.adjust(sim, interp="linear")
+    qs = [0.1, 0.25, 0.5, 0.75, 0.9]
+    d_model = np.quantile(sim, qs, axis=0) - np.quantile(hist, qs, axis=0)
+    d_scen = np.quantile(scen, qs, axis=0) - np.quantile(ref, qs, axis=0)
+    np.testing.assert_allclose(d_scen, d_model, atol=0.25)

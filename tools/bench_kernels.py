@@ -78,3 +78,9 @@ run("precip_over_doy (count+frac)", lambda: K.precip_over_doy(dev, tas, ">", 280
                                                               want=("count", "frac")), 4 * E + 8 * len(doys) * C)
 run("doy_broadcast", lambda: K.doy_broadcast(dev, p.reshape(len(doys), C), tidx), 16 * E)
 run("transpose", lambda: K.transpose(dev, tas), 8 * E)
+# quantile delta mapping: exact per-column ranks + factor lookup (transposed scratch both ways inside)
+qn = (np.arange(20) + 0.5) / 20
+af_q, _ = K.eqm_train(dev, tas, tas2, qn, "+")
+run("qdm_adjust nearest", lambda: K.qdm_adjust(dev, tas, af_q, qn, "+", "nearest"), 8 * E)
+run("qdm_adjust linear", lambda: K.qdm_adjust(dev, tas, af_q, qn, "+", "linear"), 8 * E)
+run("qdm_adjust nearest (precipitation)", lambda: K.qdm_adjust(dev, pr, af_q, qn, "*", "nearest"), 8 * E)

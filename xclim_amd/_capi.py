@@ -114,6 +114,7 @@ SIGNATURES: dict[str, list] = {
     "xh_quantile_series": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp],
     "xh_eqm_train": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _vp, _vp],
     "xh_eqm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64],
+    "xh_qdm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp],
 }
 _RESTYPES = {"xh_last_error": C.c_char_p}
 

@@ -556,3 +556,26 @@ def eqm_adjust(dev: Device, sim: DeviceArray, af: DeviceArray, hist_q: DeviceArr
     dev.call("xh_eqm_adjust", _vp(sim.ptr), T, C_, C_, 1, _vp(af.ptr), _vp(hist_q.ptr), nq, {"+": 0, "*": 1}[kind],
              {"nearest": 0, "linear": 1, "cubic": 2}[interp], {"constant": 0, "nan": 1}[extrapolation], _vp(scen.ptr), C_)
     return scen
+
+
+def qdm_adjust(dev: Device, sim: DeviceArray, af: DeviceArray, q, kind="+", interp="nearest", extrapolation="constant",
+               time_axis=0, out: DeviceArray | None = None) -> DeviceArray:
+    """xh_qdm_adjust: sim (T, C) [time_axis 0] or (C, T) [time_axis 1], af (nq, C), q the nq quantile nodes; scen in the
+    layout of sim."""
+    q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+    if interp not in ("nearest", "linear"):
+        raise NotImplementedError(f"qdm_adjust: interp={interp!r} (nearest and linear are built)")
+    if time_axis == 0:
+        T, C_ = _tc(sim)
+        st, sc = C_, 1
+    else:
+        C_, T = _tc(sim)
+        st, sc = 1, T
+    if int(af.shape[0]) != len(q):
+        raise ValueError("qdm_adjust: af must hold one row per quantile node")
+    if np.any(np.diff(q) <= 0):
+        raise ValueError("qdm_adjust: the quantile nodes must be strictly increasing")
+    scen = out if out is not None else dev.empty(tuple(sim.shape), np.float32)
+    dev.call("xh_qdm_adjust", _vp(sim.ptr), T, C_, st, sc, _vp(af.ptr), np_ptr(q), len(q), {"+": 0, "*": 1}[kind],
+             {"nearest": 0, "linear": 1}[interp], {"constant": 0, "nan": 1}[extrapolation], _vp(scen.ptr))
+    return scen

@@ -12,8 +12,13 @@ the same sample sets as ``percentile_doy``).  Training gathers each group's rows
 per-column multi-quantile kernels on them; ``af`` / ``hist_q`` get a leading group axis ``(group, quantiles, *cells)``.
 ``adjust`` maps every time step with the factors of ITS group (rows are permuted group-major once, one ``xh_eqm_adjust``
 launch per group on a contiguous row block, one gather back).  Interpolating the factors BETWEEN groups along time (what
-xsdba does for ``interp != "nearest"`` with monthly groups), ``QuantileDeltaMapping`` / ``DetrendedQuantileMapping``
-(they need per-column ranks of every sample) are not built.  PARITY UNPINNED like everything xsdba (oracle/sdba.py).
+xsdba does for ``interp != "nearest"`` with monthly groups) and ``DetrendedQuantileMapping`` are not built.
+
+:class:`QuantileDeltaMapping` (``group="time"``): trained like EQM; ``adjust`` looks the factor up at the QUANTILE of every
+sim value within the sim series itself (``rank(sim, pct=True)``), so that the simulated change of every quantile is
+preserved — ``xh_qdm_adjust`` ranks each column exactly (average ranks, NaN skipped) and interpolates in fp64.
+
+PARITY UNPINNED like everything xsdba (oracle/sdba.py).
 """
 
 from __future__ import annotations
@@ -190,3 +195,27 @@ class EmpiricalQuantileMapping:
     @property
     def hist_q(self) -> np.ndarray:
         return self._hist_q.get().reshape(self._shape())
+
+
+class QuantileDeltaMapping(EmpiricalQuantileMapping):
+    """Quantile delta mapping (xsdba.QuantileDeltaMapping): the same training as EQM, the adjustment factor of a sim
+    value is taken at ITS quantile in the sim series: ``sim_q = rank(sim, pct=True)``,
+    ``af = interp_on_quantiles(sim_q, quantiles, af)``, ``scen = sim (+|*) af``.  ``group="time"`` only."""
+
+    @classmethod
+    def train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", window=None, time=None, device=None):
+        grp = group if isinstance(group, Grouper) else Grouper(group, 1 if window is None else window)
+        if grp.prop != "group":
+            raise NotImplementedError("QuantileDeltaMapping: only group='time' is built")
+        return super().train(ref, hist, nquantiles=nquantiles, kind=kind, group=grp, device=device)
+
+    def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", time=None, keep=False):
+        if interp not in ("nearest", "linear", "cubic"):
+            raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
+        if interp == "cubic":
+            raise NotImplementedError("QuantileDeltaMapping.adjust: interp='cubic' is not built (nearest, linear)")
+        s, cell_shape = _flatten(sim, self._dev)
+        if tuple(cell_shape) != self.cell_shape:
+            raise ValueError("sim does not match the trained grid")
+        scen = K.qdm_adjust(self._dev, s, self._af, self.quantiles, self.kind, interp, extrapolation)
+        return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
