@@ -6,7 +6,7 @@ import bench
 from xclim_amd import kernels as K
 from xclim_amd._capi import Device
 
-T = 10950
+T = int(os.environ.get("XH_BENCH_T", "10950"))
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 1440 * 720
 dev = Device(0)
 base = bench.seasonal_base(T)

@@ -64,6 +64,7 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
   __shared__ uint32_t list[LISTCAP + 2 * 8 + 4];  // padded: the in-bin select reads (masked) past a bin's keys
   __shared__ float vals[MAXT];
   __shared__ uint32_t red[5 * NW + 8];
+  __shared__ uint32_t texcl[NT];  // exclusive prefix of the bin counts inside each wave (target search)
   __shared__ int s_slow, s_off, s_nslot;
   const int gt = threadIdx.x;
   const int lane = gt & 63, w = gt >> 6;
@@ -204,78 +205,95 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
       if (lane >= off) incl += o;
     }
     if (lane == 63) red[3 * NW + w] = incl;
+    texcl[gt] = incl - s;  // keys in the bins before mine INSIDE this wave
     const int myr0 = lane < ntgt ? trank[lane] : -1, myr1 = lane + 64 < ntgt ? trank[lane + 64] : -1;
     lds_barrier();
     XH_PHASE(2);
-    {
-      uint32_t add = 0;
+    // Targets: every lane of wave 0 resolves the (up to two) target ranks it holds IN PARALLEL — owner wave from the
+    // eight wave totals, owner thread by a 6-step binary search over that wave's exclusive prefixes, bin from the owner's
+    // BPT counts (one LDS read) — where round 1 walked the targets of each wave one after the other on scalars (~2 K
+    // cycles per target: ballot / readlane / LDS-atomic round trips in a serial loop, 20 % of the kernel).
+    // A bin hit by several targets is allocated once, by its LEADER (the lowest target index with that bin); the ranks
+    // are monotone only up to lo_{j+1} < hi_j, so equal bins need not be neighbours: the leader is found by a uniform
+    // loop over the targets (readlane + compare).
+    if (w == 0 && !(abl & 8)) {
+      uint32_t wp[NW + 1];
+      wp[0] = 0;
 #pragma unroll
-      for (int i = 0; i < NW; ++i) add += (i < w) ? red[3 * NW + i] : 0u;
-      const uint32_t first = incl - s + add;  // keys in the bins before mine
-      // Targets whose rank falls into this WAVE's bins — all on scalars: the owner lane is the last lane whose `first`
-      // is <= r (ballot + popcount), its scan state comes over with readlane, the list region / big-bin slot of a bin
-      // is allocated once (the ranks are sorted up to lo_{j+1} < hi_j, so a bin can only repeat among the last two).
-      // Counts left in cur[] never reach the tag bits, so only the target bins are rewritten.
-      const uint32_t wfirst = __builtin_amdgcn_readfirstlane(add);
-      const uint32_t wend = wfirst + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-      int pb0 = -1, pb1 = -1;
-      uint32_t pt0 = 0, pt1 = 0;
-      // (lane l holds the ranks of targets l and l + 64: one vector compare finds the wave's targets; a scalar loop
-      //  over all 2*nq targets costs ~100 clk per iteration in dependent s_cmp / s_cbranch chains)
-      unsigned long long in0 = __ballot(myr0 >= 0 && (uint32_t)myr0 >= wfirst && (uint32_t)myr0 < wend);
-      unsigned long long in1 = __ballot(myr1 >= 0 && (uint32_t)myr1 >= wfirst && (uint32_t)myr1 < wend);
-      if (abl & 8) { in0 = 0; in1 = 0; }
-      while (in0 | in1) {
-        int t, r;
-        if (in0) {
-          const int l = __ffsll((long long)in0) - 1;
-          in0 &= in0 - 1;
-          t = l; r = __builtin_amdgcn_readlane(myr0, l);
-        } else {
-          const int l = __ffsll((long long)in1) - 1;
-          in1 &= in1 - 1;
-          t = l + 64; r = __builtin_amdgcn_readlane(myr1, l);
-        }
-        const int L = __popcll(__ballot(first <= (uint32_t)r)) - 1;
-        uint32_t st0 = (uint32_t)__builtin_amdgcn_readlane((int)first, L);
-        int bin = 0, m = 0, kth = 0;
-        bool found = false;
+      for (int i = 0; i < NW; ++i) wp[i + 1] = wp[i] + red[3 * NW + i];
+      int tbin[2], tm[2], tkth[2];
 #pragma unroll
-        for (int b = 0; b < BPT; ++b) {
-          const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)loc[b], L);
-          if (!found && (uint32_t)r < st0 + lb) {
-            found = true;
-            bin = (w * 64 + L) * BPT + b; m = (int)lb; kth = (int)((uint32_t)r - st0);
+      for (int h = 0; h < 2; ++h) {
+        const int r = h ? myr1 : myr0;
+        tbin[h] = -1; tm[h] = 0; tkth[h] = 0;
+        if (r >= 0) {
+          int wi = 0;
+          uint32_t base = 0;
+#pragma unroll
+          for (int i = 1; i < NW; ++i) {
+            const bool in = wp[i] <= (uint32_t)r;  // the LAST wave whose first key index is <= r holds rank r
+            wi = in ? i : wi;
+            base = in ? wp[i] : base;
           }
-          st0 += lb;
-        }
-        uint32_t tag;
-        if (bin == pb0) tag = pt0;
-        else if (bin == pb1) tag = pt1;
-        else {
-          int off = LISTCAP + 1;
-          const bool floor_bin = bin == 0;  // the copies of kmin: a constant bin whose keys are never collected
-          if (m <= BIGM && !floor_bin) {
-            if (lane == 0) off = atomicAdd(&s_off, m);
-            off = __builtin_amdgcn_readfirstlane(off);
+          int lo = 0, hi = 63;
+#pragma unroll
+          for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi + 1) >> 1;
+            const bool le = base + texcl[wi * 64 + mid] <= (uint32_t)r;
+            lo = le ? mid : lo;
+            hi = le ? hi : mid - 1;
           }
-          if (m <= BIGM && !floor_bin && off + m <= LISTCAP) tag = F_LIST | (uint32_t)off;
-          else {
-            int slot = 0;
-            if (lane == 0) {
-              slot = atomicAdd(&s_nslot, 1);
-              bmin[slot] = floor_bin ? kmin : 0xFFFFFFFFu; bmax[slot] = floor_bin ? kmin : 0u;
+          const int L = wi * 64 + lo;
+          uint32_t st0 = base + texcl[L];
+          bool found = false;
+#pragma unroll
+          for (int b = 0; b < BPT; ++b) {
+            const uint32_t lb = cur[L * BPT + b];
+            if (!found && (uint32_t)r < st0 + lb) {
+              found = true;
+              tbin[h] = L * BPT + b; tm[h] = (int)lb; tkth[h] = (int)((uint32_t)r - st0);
             }
-            slot = __builtin_amdgcn_readfirstlane(slot);
-            tag = F_BIG | (uint32_t)slot;
+            st0 += lb;
           }
-          if (lane == 0) cur[bin] = tag;  // append cursor / min-max slot of the bin
-          pb1 = pb0; pt1 = pt0; pb0 = bin; pt0 = tag;
         }
-        if (lane == 0) {
+      }
+      // leaders: lowest target index with the same bin
+      int lead[2] = {lane, lane + 64};
+      for (int j = ntgt - 1; j >= 0; --j) {  // descending: the last assignment that sticks is the lowest index
+        const int bj = j < 64 ? __builtin_amdgcn_readlane(tbin[0], j) : __builtin_amdgcn_readlane(tbin[1], j - 64);
+        lead[0] = (bj == tbin[0]) ? j : lead[0];
+        lead[1] = (bj == tbin[1]) ? j : lead[1];
+      }
+      uint32_t tag[2] = {0u, 0u};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int t = lane + 64 * h;
+        if (tbin[h] >= 0 && lead[h] == t) {
+          const int bin = tbin[h], m = tm[h];
+          const bool floor_bin = bin == 0;  // the copies of kmin: a constant bin whose keys are never collected
+          int off = LISTCAP + 1;
+          if (m <= BIGM && !floor_bin) off = atomicAdd(&s_off, m);
+          if (m <= BIGM && !floor_bin && off + m <= LISTCAP) tag[h] = F_LIST | (uint32_t)off;
+          else {
+            const int slot = atomicAdd(&s_nslot, 1);
+            bmin[slot] = floor_bin ? kmin : 0xFFFFFFFFu;
+            bmax[slot] = floor_bin ? kmin : 0u;
+            tag[h] = F_BIG | (uint32_t)slot;
+          }
+          cur[bin] = tag[h];  // append cursor / min-max slot of the bin (the count left in cur[] is not needed any more)
+        }
+      }
+      // followers take the leader's tag
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ld = lead[h];
+        const uint32_t t0 = (uint32_t)__shfl((int)tag[0], ld & 63, 64), t1 = (uint32_t)__shfl((int)tag[1], ld & 63, 64);
+        const uint32_t tg = ld < 64 ? t0 : t1;
+        const int t = lane + 64 * h;
+        if (tbin[h] >= 0 && t < ntgt) {
           TInfo ti;
-          ti.bin = bin; ti.kth = kth; ti.m = m;
-          ti.region = (tag & F_LIST) ? (int)(tag & F_MASK) : -((int)(tag & F_MASK) + 1);
+          ti.bin = tbin[h]; ti.kth = tkth[h]; ti.m = tm[h];
+          ti.region = (tg & F_LIST) ? (int)(tg & F_MASK) : -((int)(tg & F_MASK) + 1);
           tinfo[t] = ti;
         }
       }
@@ -452,11 +470,11 @@ int xh_select_columns_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t n
                            const double* d_q, int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
   if (T <= 1024 || T > 16384 || nq > 64) return XH_ERR_NOTIMPL;
 #define XH_LEAN(NT, KPL, NB) return launch_lean<NT, KPL, NB>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride)
-  // threads per column above 4096 steps: 512 (two workgroups per CU).  Alone, 256 threads (four per CU) are a little
-  // ahead on 30-year series (0.40 vs 0.43 ms per 12160 columns); next to the 128 x 128 transposes of the time-major
-  // pipeline 512 wins: config-4 train 92.7 vs 98.5 ms (profiles/r02/eqm_c4_anatomy.txt).
+  // threads per column above 4096 steps: 256 (four workgroups per CU).  With the parallel target search the config-4
+  // train (T = 10950, time-major pipeline) takes 85.4 ms with 256 threads and 93.2 ms with 512; T = 7300: 59.1 vs 69.0 ms
+  // (with the serial per-wave target loop of round 1 it was 98.5 vs 92.7: four waves walked ten targets each).
   const char* ent = xh_diag_env("XH_LEAN_NT");  // tuning only
-  const int nt = ent ? atoi(ent) : 512;
+  const int nt = ent ? atoi(ent) : 256;
   if (T <= 2048) XH_LEAN(256, 8, 1024);
   if (T <= 3072) XH_LEAN(256, 12, 1024);
   if (T <= 4096) XH_LEAN(256, 16, 1024);
