@@ -126,11 +126,20 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
     // amount); with [kmin, kmax] divided evenly every wet day lands in a quarter of the bins.  The copies of kmin are
     // counted in registers: they skip the histogram atomics (thousands of lanes on one address) and are never collected.
     // Wave level first (shuffles only): wave minimum, smallest key above it, copies of it; one LDS round joins the waves.
+    // (smallest key above kmin = kmin + 1 + min over keys of (key - kmin - 1): the copies of kmin wrap to 0xFFFFFFFF and
+    //  never win — a subtract and a min per key instead of two compares and a select)
     uint32_t wmin2 = 0xFFFFFFFFu, wcnt = 0;
+    {
+      const uint32_t kmin1 = kmin + 1u;
+      uint32_t m2 = 0xFFFFFFFFu;
 #pragma unroll
-    for (int k = 0; k < KPL; ++k) {
-      wmin2 = (key[k] > kmin && key[k] < wmin2) ? key[k] : wmin2;  // NaN keys (0xFFFFFFFF) never pass `< wmin2`
-      wcnt += key[k] == kmin ? 1u : 0u;
+      for (int k = 0; k < KPL; ++k) {
+        const uint32_t d1 = key[k] - kmin1;
+        m2 = d1 < m2 ? d1 : m2;
+        wcnt += key[k] == kmin ? 1u : 0u;
+      }
+      // NaN keys: 0xFFFFFFFF - kmin1 stays below 0xFFFFFFFF unless kmin1 == 0 (an all-NaN wave); keep the old sentinel
+      wmin2 = (m2 == 0xFFFFFFFFu || kmin1 + m2 == 0xFFFFFFFFu) ? 0xFFFFFFFFu : kmin1 + m2;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -157,16 +166,23 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
       kmin2 = c2 < kmin2 ? c2 : kmin2;
       cnt0 += own ? red[4 * NW + i] : 0u;
     }
-    kmin2 = kmin2 == 0xFFFFFFFFu ? kmin : kmin2;  // all valid keys equal
+    const bool alleq = kmin2 == 0xFFFFFFFFu;      // all valid keys equal (or none valid)
+    kmin2 = alleq ? kmin + 1u : kmin2;            // (kmin + 1: the copies of kmin then wrap to the dummy bin like always)
     cnt0 = n > 0 ? cnt0 : 0u;                     // (all NaN: kmin is the NaN key)
-    const uint32_t range = n > 0 ? kmax - kmin2 : 0u;
-    int shift = 32 - __clz((int)range) - (31 - __clz(NB));
-    shift = (range == 0u || shift < 0) ? 0 : shift;
-    // bin of a key: NB (dummy, no tag, no atomics) for NaN and for the copies of kmin; the top value bin is merged into
-    // bin NB - 1 when its index is reached
+    const uint32_t range = (n > 0 && !alleq) ? kmax - kmin2 : 0u;
+    // bins 1 .. NB-1 divide [kmin2, kmax] EVENLY: bin = 1 + floor((key - kmin2) * (NB - 1) / (range + 1)) as one
+    // v_mul_hi_u32 with a 32.32 fixed-point scale (monotone in the key, which is all the selection needs).  A power-of-two
+    // shift used between half and all of the bins (1009 of 2048 on the benchmark series): twice the keys per target
+    // bin, and the in-bin selection is quadratic in that.  Fewer distinct keys than bins: one key value per bin.
+    const bool bexact = range < (uint32_t)(NB - 1);
+    const uint32_t bscale = bexact ? 0u : (uint32_t)((((uint64_t)(NB - 1)) << 32) / ((uint64_t)range + 1ull));
+    // bin of a key: NB (dummy, no tag, no atomics) for NaN and for the copies of kmin — WITHOUT testing for them: a
+    // genuine key has d <= range and lands in 1 .. NB-1; the NaN key and the copies of kmin (d wraps) are at least
+    // 0x7FFFFF beyond the range (valid keys end at 0xFF800000), which puts the scaled value at NB-1 or more
     auto binof = [&](uint32_t kk) -> uint32_t {
-      const uint32_t b = 1u + ((kk - kmin2) >> shift);
-      return (kk == 0xFFFFFFFFu || kk == kmin) ? (uint32_t)NB : (b < (uint32_t)NB ? b : (uint32_t)NB - 1u);
+      const uint32_t d = kk - kmin2;
+      const uint32_t x = bexact ? d : __umulhi(d, bscale);
+      return 1u + (x < (uint32_t)(NB - 1) ? x : (uint32_t)(NB - 1));
     };
     // ---- B: target ranks + histogram
     if (gt < ntgt) {
@@ -337,7 +353,7 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
     // ---- E: select inside the bins: (target, candidate) pairs are spread over the whole workgroup — a candidate key
     //      is the answer iff #(keys < e) <= kth < #(keys <= e); O(m) LDS reads per thread, not O(m^2) per target
     if (!(abl & 4)) {
-      constexpr int CPT = 8;  // candidate lanes per target
+      constexpr int CPT = NT >= 512 ? 8 : NT / 64;  // candidate lanes per target: 64 targets (2 x 32 quantiles) in ONE pass
       for (int t = gt / CPT; t < ntgt; t += NT / CPT) {
         const TInfo ti = tinfo[t];
         const int a0 = gt % CPT;
@@ -359,12 +375,13 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
         // iteration loop waits one LDS latency per key).  Reads past the bin's m keys are masked (list is padded).
         const uint32_t m = (uint32_t)ti.m, kth = (uint32_t)ti.kth;
         const uint32_t* lp = list + ti.region;
+        if (abl & 64) continue;
         for (uint32_t a2 = a0; a2 < m; a2 += 2 * CPT) {
           const uint32_t e0 = lp[a2];
           uint32_t e1 = lp[a2 + CPT];
           e1 = a2 + CPT < m ? e1 : 0u;  // key 0 never wins (valid keys are > 0)
           uint32_t less0 = 0, leq0 = 0, less1 = 0, leq1 = 0;
-          for (uint32_t b2 = 0; b2 < m; b2 += 4) {
+          for (uint32_t b2 = 0; b2 < ((abl & 32) ? 0u : m); b2 += 4) {
             uint32_t k0 = lp[b2], k1 = lp[b2 + 1], k2 = lp[b2 + 2], k3 = lp[b2 + 3];
             k1 = b2 + 1 < m ? k1 : 0xFFFFFFFFu;
             k2 = b2 + 2 < m ? k2 : 0xFFFFFFFFu;
@@ -390,7 +407,7 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
         uint32_t lo = bmin[slot], hi = bmax[slot];
         if (lo == hi) continue;
         // smallest K in [lo, hi] with #(key <= K, key in this bin) >= kth + 1
-        const uint32_t binlo = kmin2 + ((uint32_t)(ti.bin - 1) << shift);  // (bin 0 is constant and never gets here)
+        const uint32_t binlo = lo;  // the smallest key of the bin: every key of a lower bin is below it
         while (lo < hi) {
           const uint32_t mid = lo + ((hi - lo) >> 1);
           uint32_t c = 0;
