@@ -50,11 +50,17 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* red) {
   return s;
 }
 
-template <int NT, int KPL, int NB>
+// DIAG = false (production): the ablation switches and phase timers are compiled out — each of them is a uniform
+// condition held in scalar registers across the column loop, and the kernel already spills SGPRs into VGPR lanes.
+// KSAFE: the first KSAFE key steps are known at compile time to lie inside the series for every T this instantiation
+// is used with (no index test, no clamp on the load).
+template <int NT, int KPL, int NB, int KSAFE = 0, bool DIAG = false>
 __global__ void __launch_bounds__(NT, XH_LEAN_MINB)
 k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col_stride, const double* __restrict__ qs,
-              int nq, float* __restrict__ out, int64_t out_cstride, int64_t out_qstride, int abl,
-              unsigned long long* __restrict__ prof) {
+              int nq, float* __restrict__ out, int64_t out_cstride, int64_t out_qstride, int abl_,
+              unsigned long long* __restrict__ prof_) {
+  const int abl = DIAG ? abl_ : 0;
+  unsigned long long* __restrict__ prof = DIAG ? prof_ : nullptr;
   constexpr int BPT = NB / NT;
   constexpr int NW = NT / 64;
   __shared__ uint32_t cur[NB + 1];  // [NB]: dummy bin of the NaN keys (keeps the histogram atomics branch-free)
@@ -94,28 +100,46 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
       const uint32_t i = g + (uint32_t)(k * NT);
-      key[k] = __float_as_uint(xc[i < Tm1 ? i : Tm1]);
+      key[k] = __float_as_uint(xc[(k < KSAFE || i < Tm1) ? i : Tm1]);
     }
 #pragma unroll
     for (int b = 0; b < BPT; ++b) cur[gt + b * NT] = 0;
     if (gt == 0) { s_slow = 0; s_off = 0; s_nslot = 0; cur[NB] = 0; }
+    // The kernel is VALU-bound (PMC: the VALU is busy 86 % of the time with 4 workgroups per CU), so the per-key work is
+    // counted in instructions.  Key: u ^ ((u >> 31) | 0x80000000) (3 ops); NaN (either sign) and the positions beyond
+    // the series become 0xFFFFFFFF with one compare + one select; the valid and minimum counts are wave-uniform (popcount
+    // of the compare mask on the scalar unit).
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
-      const uint32_t i = g + (uint32_t)(k * NT);
-      const uint32_t kk = xh_f2key(__uint_as_float(key[k]));
-      key[k] = (i <= Tm1) ? kk : 0xFFFFFFFFu;
+      const uint32_t u = key[k];
+      const uint32_t kk = u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+      if (k < KSAFE) {
+        // compare, count and select in one block on VCC: written in C++ the scheduler batches the KPL compares and their
+        // lane masks overflow the scalar registers into VGPR lanes (v_writelane / v_readlane per key)
+        uint32_t o, c;
+        asm volatile("v_cmp_o_f32 vcc, %3, %3\n\ts_bcnt1_i32_b64 %1, vcc\n\tv_cndmask_b32 %0, -1, %2, vcc"
+                     : "=v"(o), "=s"(c)
+                     : "v"(kk), "v"(u)
+                     : "vcc", "scc");
+        key[k] = o;
+        nv += c;  // (wave-uniform)
+      } else {
+        const uint32_t i = g + (uint32_t)(k * NT);
+        const float f = __uint_as_float(u);
+        const bool valid = i <= Tm1 && (f == f);
+        key[k] = valid ? kk : 0xFFFFFFFFu;
+        nv += (uint32_t)__popcll(__ballot(valid));
+      }
     }
     // NaN key = 0xFFFFFFFF never wins a min; kmax is tracked as (key + 1) so that the NaN key wraps to 0
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
       uint32_t kk = key[k];
-      nv += kk != 0xFFFFFFFFu ? 1u : 0u;
       kmin = kk < kmin ? kk : kmin;
       kmax = kk + 1u > kmax ? kk + 1u : kmax;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      nv += __shfl_xor(nv, off, 64);
       uint32_t a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
       kmin = a < kmin ? a : kmin;
       kmax = b > kmax ? b : kmax;
@@ -136,7 +160,9 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
       for (int k = 0; k < KPL; ++k) {
         const uint32_t d1 = key[k] - kmin1;
         m2 = d1 < m2 ? d1 : m2;
-        wcnt += key[k] == kmin ? 1u : 0u;
+        uint32_t c;
+        asm volatile("v_cmp_eq_u32 vcc, %1, %2\n\ts_bcnt1_i32_b64 %0, vcc" : "=s"(c) : "v"(key[k]), "v"(kmin) : "vcc", "scc");
+        wcnt += c;  // (wave-uniform)
       }
       // NaN keys: 0xFFFFFFFF - kmin1 stays below 0xFFFFFFFF unless kmin1 == 0 (an all-NaN wave); keep the old sentinel
       wmin2 = (m2 == 0xFFFFFFFFu || kmin1 + m2 == 0xFFFFFFFFu) ? 0xFFFFFFFFu : kmin1 + m2;
@@ -145,7 +171,6 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
     for (int off = 32; off > 0; off >>= 1) {
       const uint32_t a = __shfl_xor(wmin2, off, 64);
       wmin2 = a < wmin2 ? a : wmin2;
-      wcnt += __shfl_xor(wcnt, off, 64);
     }
     if (lane == 0) { red[w] = nv; red[NW + w] = kmin; red[2 * NW + w] = kmax; red[3 * NW + w] = wmin2; red[4 * NW + w] = wcnt; }
     lds_barrier();
@@ -176,12 +201,13 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
     // bin, and the in-bin selection is quadratic in that.  Fewer distinct keys than bins: one key value per bin.
     const bool bexact = range < (uint32_t)(NB - 1);
     const uint32_t bscale = bexact ? 0u : (uint32_t)((((uint64_t)(NB - 1)) << 32) / ((uint64_t)range + 1ull));
+    const uint32_t bpass = bexact ? 0xFFFFFFFFu : 0u;  // (the scale 1.0 does not fit 0.32 bits: d itself is added instead)
     // bin of a key: NB (dummy, no tag, no atomics) for NaN and for the copies of kmin — WITHOUT testing for them: a
     // genuine key has d <= range and lands in 1 .. NB-1; the NaN key and the copies of kmin (d wraps) are at least
     // 0x7FFFFF beyond the range (valid keys end at 0xFF800000), which puts the scaled value at NB-1 or more
     auto binof = [&](uint32_t kk) -> uint32_t {
       const uint32_t d = kk - kmin2;
-      const uint32_t x = bexact ? d : __umulhi(d, bscale);
+      const uint32_t x = __umulhi(d, bscale) + (d & bpass);
       return 1u + (x < (uint32_t)(NB - 1) ? x : (uint32_t)(NB - 1));
     };
     // ---- B: target ranks + histogram
@@ -322,21 +348,32 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
       constexpr int CH = KPL % 8 == 0 ? 8 : 4;
 #pragma unroll
       for (int k0 = 0; k0 < KPL; k0 += CH) {
-        uint32_t cf[CH], pos[CH];
-        bool anybig = false;
+        uint32_t cf[CH], pos[CH], bidx[CH];
+        uint32_t bigor = 0;
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-          cf[k] = cur[binof(key[k0 + k])];  // cur[NB] (NaN keys, copies of kmin) carries no tag
-          anybig |= (cf[k] & F_BIG) != 0u;
+          bidx[k] = binof(key[k0 + k]);
+          cf[k] = cur[bidx[k]];  // cur[NB] (NaN keys, copies of kmin) carries no tag
+          bigor |= cf[k];
         }
+        const bool anybig = (bigor & F_BIG) != 0u;
+        // branch-free: a lane whose key is not in a listed bin appends to a private dummy word (texcl[gt], free until
+        // the next column's scan) — every atomic of the chunk is in flight before the first result is needed; with a
+        // branch per key the compiler serialised one LDS round trip per key
+        uint32_t* ap[CH];
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-          pos[k] = 0;
-          if (cf[k] & F_LIST) pos[k] = atomicAdd(&cur[binof(key[k0 + k])], 1u) & F_MASK;
+          const bool lst = (cf[k] & F_LIST) != 0u;
+          ap[k] = lst ? &cur[bidx[k]] : &texcl[gt];
         }
 #pragma unroll
-        for (int k = 0; k < CH; ++k)
-          if (cf[k] & F_LIST) list[pos[k]] = key[k0 + k];
+        for (int k = 0; k < CH; ++k) pos[k] = atomicAdd(ap[k], 1u) & F_MASK;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const bool lst = (cf[k] & F_LIST) != 0u;
+          uint32_t* wp = lst ? &list[pos[k]] : &texcl[gt];
+          *wp = key[k0 + k];
+        }
         if (__any(anybig)) {
 #pragma unroll
           for (int k = 0; k < CH; ++k)
@@ -448,7 +485,7 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
 #undef XH_PHASE
 }
 
-template <int NT, int KPL, int NB>
+template <int NT, int KPL, int NB, int KSAFE = 0>
 int launch_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const double* d_q, int nq,
                 float* out, int64_t out_cstride, int64_t out_qstride) {
   int64_t nblk = ncols;
@@ -461,8 +498,12 @@ int launch_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64
     XH_CHECK_HIP(hipMalloc((void**)&d_prof, 16 * sizeof(unsigned long long)));
     XH_CHECK_HIP(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
   }
-  hipLaunchKernelGGL((k_select_lean<NT, KPL, NB>), dim3((unsigned)nblk), dim3(NT), 0, ctx->stream, xcols, T, ncols, col_stride,
-                     d_q, nq, out, out_cstride, out_qstride, ea ? atoi(ea) : 0, d_prof);
+  if ((ea && atoi(ea)) || d_prof)
+    hipLaunchKernelGGL((k_select_lean<NT, KPL, NB, KSAFE, true>), dim3((unsigned)nblk), dim3(NT), 0, ctx->stream, xcols, T, ncols,
+                       col_stride, d_q, nq, out, out_cstride, out_qstride, ea ? atoi(ea) : 0, d_prof);
+  else
+    hipLaunchKernelGGL((k_select_lean<NT, KPL, NB, KSAFE, false>), dim3((unsigned)nblk), dim3(NT), 0, ctx->stream, xcols, T, ncols,
+                       col_stride, d_q, nq, out, out_cstride, out_qstride, 0, nullptr);
   XH_LAUNCH_CHECK();
   if (d_prof) {
     unsigned long long h[16];
@@ -487,21 +528,24 @@ int xh_select_columns_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t n
                            const double* d_q, int nq, float* out, int64_t out_cstride, int64_t out_qstride) {
   if (T <= 1024 || T > 16384 || nq > 64) return XH_ERR_NOTIMPL;
 #define XH_LEAN(NT, KPL, NB) return launch_lean<NT, KPL, NB>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride)
+#define XH_LEANS(NT, KPL, NB, TLOW) \
+  return launch_lean<NT, KPL, NB, (TLOW) / (NT)>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride)
   // threads per column above 4096 steps: 256 (four workgroups per CU).  With the parallel target search the config-4
   // train (T = 10950, time-major pipeline) takes 85.4 ms with 256 threads and 93.2 ms with 512; T = 7300: 59.1 vs 69.0 ms
   // (with the serial per-wave target loop of round 1 it was 98.5 vs 92.7: four waves walked ten targets each).
   const char* ent = xh_diag_env("XH_LEAN_NT");  // tuning only
   const int nt = ent ? atoi(ent) : 256;
-  if (T <= 2048) XH_LEAN(256, 8, 1024);
-  if (T <= 3072) XH_LEAN(256, 12, 1024);
-  if (T <= 4096) XH_LEAN(256, 16, 1024);
+  if (T <= 2048) XH_LEANS(256, 8, 1024, 1024);
+  if (T <= 3072) XH_LEANS(256, 12, 1024, 2048);
+  if (T <= 4096) XH_LEANS(256, 16, 1024, 3072);
   if (nt == 256) {
-    if (T <= 6144) XH_LEAN(256, 24, 2048);
-    if (T <= 8192) XH_LEAN(256, 32, 2048);
-    if (T <= 10240) XH_LEAN(256, 40, 2048);
-    if (T <= 12288) XH_LEAN(256, 48, 2048);
-    if (T <= 14336) XH_LEAN(256, 56, 2048);
-    XH_LEAN(256, 64, 2048);
+    if (T <= 6144) XH_LEANS(256, 24, 2048, 4096);
+    if (T <= 8192) XH_LEANS(256, 32, 2048, 6144);
+    if (T <= 10240) XH_LEANS(256, 40, 2048, 8192);
+    if (T <= 11264) XH_LEANS(256, 44, 2048, 10240);  // 30 years of days: 10950 .. 10958 keys, 3 % idle slots instead of 11 %
+    if (T <= 12288) XH_LEANS(256, 48, 2048, 11264);
+    if (T <= 14336) XH_LEANS(256, 56, 2048, 12288);
+    XH_LEANS(256, 64, 2048, 14336);
   }
   if (nt == 1024) {
     if (T <= 8192) XH_LEAN(1024, 8, 2048);
@@ -515,4 +559,5 @@ int xh_select_columns_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t n
   if (T <= 14336) XH_LEAN(512, 28, 2048);
   XH_LEAN(512, 32, 2048);
 #undef XH_LEAN
+#undef XH_LEANS
 }
