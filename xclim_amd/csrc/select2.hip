@@ -199,15 +199,14 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
     // v_mul_hi_u32 with a 32.32 fixed-point scale (monotone in the key, which is all the selection needs).  A power-of-two
     // shift used between half and all of the bins (1009 of 2048 on the benchmark series): twice the keys per target
     // bin, and the in-bin selection is quadratic in that.  Fewer distinct keys than bins: one key value per bin.
-    const bool bexact = range < (uint32_t)(NB - 1);
-    const uint32_t bscale = bexact ? 0u : (uint32_t)((((uint64_t)(NB - 1)) << 32) / ((uint64_t)range + 1ull));
-    const uint32_t bpass = bexact ? 0xFFFFFFFFu : 0u;  // (the scale 1.0 does not fit 0.32 bits: d itself is added instead)
+    // (fewer distinct key values than bins: the scale saturates at 1 - 2^-32, d -> d - 1: still monotone, still < NB - 1)
+    const uint32_t bscale = range < (uint32_t)(NB - 1) ? 0xFFFFFFFFu : (uint32_t)((((uint64_t)(NB - 1)) << 32) / ((uint64_t)range + 1ull));
     // bin of a key: NB (dummy, no tag, no atomics) for NaN and for the copies of kmin — WITHOUT testing for them: a
     // genuine key has d <= range and lands in 1 .. NB-1; the NaN key and the copies of kmin (d wraps) are at least
     // 0x7FFFFF beyond the range (valid keys end at 0xFF800000), which puts the scaled value at NB-1 or more
     auto binof = [&](uint32_t kk) -> uint32_t {
       const uint32_t d = kk - kmin2;
-      const uint32_t x = __umulhi(d, bscale) + (d & bpass);
+      const uint32_t x = __umulhi(d, bscale);
       return 1u + (x < (uint32_t)(NB - 1) ? x : (uint32_t)(NB - 1));
     };
     // ---- B: target ranks + histogram
@@ -490,6 +489,7 @@ int launch_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64
                 float* out, int64_t out_cstride, int64_t out_qstride) {
   int64_t nblk = ncols;
   int64_t maxblk = (int64_t)ctx->num_cu * 16;
+  if (const char* eg = xh_diag_env("XH_LEAN_GRID_PER_CU")) maxblk = (int64_t)ctx->num_cu * (atoi(eg) > 0 ? atoi(eg) : 16);
   if (nblk > maxblk) nblk = maxblk;
   const char* ea = xh_diag_env("XH_SELECT_ABL");  // diagnostics only: skip phases (results become wrong)
   const char* ep = xh_diag_env("XH_SELECT_PROF");  // diagnostics only: per-phase cycle counts on stderr
@@ -498,11 +498,14 @@ int launch_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64
     XH_CHECK_HIP(hipMalloc((void**)&d_prof, 16 * sizeof(unsigned long long)));
     XH_CHECK_HIP(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
   }
+  const char* epad = xh_diag_env("XH_LEAN_PAD_LDS");  // diagnostics: unused dynamic LDS (KB) to cap the workgroups per CU
+  const size_t pad = epad ? (size_t)atoi(epad) * 1024 : 0;
+  if (pad) XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_select_lean<NT, KPL, NB, KSAFE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
   if ((ea && atoi(ea)) || d_prof)
     hipLaunchKernelGGL((k_select_lean<NT, KPL, NB, KSAFE, true>), dim3((unsigned)nblk), dim3(NT), 0, ctx->stream, xcols, T, ncols,
                        col_stride, d_q, nq, out, out_cstride, out_qstride, ea ? atoi(ea) : 0, d_prof);
   else
-    hipLaunchKernelGGL((k_select_lean<NT, KPL, NB, KSAFE, false>), dim3((unsigned)nblk), dim3(NT), 0, ctx->stream, xcols, T, ncols,
+    hipLaunchKernelGGL((k_select_lean<NT, KPL, NB, KSAFE, false>), dim3((unsigned)nblk), dim3(NT), pad, ctx->stream, xcols, T, ncols,
                        col_stride, d_q, nq, out, out_cstride, out_qstride, 0, nullptr);
   XH_LAUNCH_CHECK();
   if (d_prof) {
