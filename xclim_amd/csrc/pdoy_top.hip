@@ -95,7 +95,7 @@ __device__ __forceinline__ float f32_threshold(double r, int op) {
 // samples of day d of EVERY year and the exceedances are counted per (year, doy) -> period; the (D, C) fp64 table of the
 // unfused chain is neither written nor re-read once per year.  One percentile (nsub == 1), regular doys only.
 template <int W, int NYP, bool COUNT = false>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, (COUNT || W > 5 || NYP > 32) ? 2 : 3)
 k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
              int ndoy, int chunk, const QTab* __restrict__ qtab, const int32_t* __restrict__ jmap, int nsub,
              double* __restrict__ out, const int32_t* __restrict__ vmap, int64_t Tv, const uint8_t* __restrict__ regular,
