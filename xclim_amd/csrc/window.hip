@@ -83,6 +83,19 @@ __device__ __forceinline__ float ring_stat(const float (&r)[RingN<WT>::N], int w
   return nan ? xh_nan32() : out;
 }
 
+// Compile-time windows with a sum / mean reducer: the spell condition `float(sum / w) OP thr` is decided on the fp64 SUM
+// itself, `s * sgn64 > thr64` with the threshold moved into sum space on the host (spell_sum_threshold below: float
+// rounding and the division by w are monotone, so the set of sums that meet the condition is a half line) — three
+// converts, two adds, one multiply and one compare per cell-step instead of the exact division (3 fp64 FMAs), the convert
+// back and the fp32 compare.  NaN anywhere in the window makes the sum NaN and the compare false.
+template <int WT>
+__device__ __forceinline__ bool ring_sum_cond(const float (&r)[RingN<WT>::N], double sgn64, double thr64) {
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < WT; ++k) s += (double)r[k];  // oldest -> newest, as ring_stat
+  return s * sgn64 > thr64;
+}
+
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* p, const float (&r)[VEC]) {
   if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
@@ -140,6 +153,7 @@ k_rolling_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, in
 template <int VEC, int RED, int WT = 0>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w_, int op, float thr, float sgn,
+             double thr64, double sgn64,
              const float* __restrict__ weights, float* __restrict__ out, int64_t out_st) {
   const int w = WT > 0 ? WT : w_;
   const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
@@ -168,8 +182,14 @@ k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
     for (int i = 0; i < VEC; ++i) {
       bool cond = false;
       if (have_row && tp >= w - 1) {
-        const float s = ring_stat<RED, WT>(ring.v[i], w, inv_w, wts);
-        cond = WT > 0 ? (s * sgn > thr) : ((s == s) && xh_cmp_f32(s, op, thr));  // WT > 0: xh_one_cmp form, NaN -> false
+        if (WT > 0 && (RED == XH_RED_SUM || RED == XH_RED_MEAN)) cond = ring_sum_cond<WT>(ring.v[i], sgn64, thr64);
+        else {
+          if (WT > 0 && (RED == XH_RED_SUM || RED == XH_RED_MEAN)) cond = ring_sum_cond<WT>(ring.v[i], sgn64, thr64);
+          else {
+            const float s = ring_stat<RED, WT>(ring.v[i], w, inv_w, wts);
+            cond = WT > 0 ? (s * sgn > thr) : ((s == s) && xh_cmp_f32(s, op, thr));
+          }  // WT > 0: xh_one_cmp form, NaN -> false
+        }
       }
       since[i] = cond ? 0 : since[i] + 1;
       r[i] = (since[i] < w) ? 1.0f : 0.0f;
@@ -192,6 +212,7 @@ k_spell_ring(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
 template <int VEC, int RED, int WT = 0, int SG = 0>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_spell_runs(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int w_, int op, float thr, float sgn,
+             double thr64, double sgn64,
              const float* __restrict__ weights, int stat, const int64_t* __restrict__ seg_off, int P, float* __restrict__ out,
              int32_t* __restrict__ valid_out) {
   const int w = WT > 0 ? WT : w_;
@@ -220,8 +241,11 @@ k_spell_runs(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
       for (int i = 0; i < VEC; ++i) {
         bool cond = false;
         if (have_row && tp >= w - 1) {
-          const float s = ring_stat<RED, WT>(ring.v[i], w, inv_w, wts);
-          cond = WT > 0 ? (s * sgn > thr) : ((s == s) && xh_cmp_f32(s, op, thr));
+          if (WT > 0 && (RED == XH_RED_SUM || RED == XH_RED_MEAN)) cond = ring_sum_cond<WT>(ring.v[i], sgn64, thr64);
+          else {
+            const float s = ring_stat<RED, WT>(ring.v[i], w, inv_w, wts);
+            cond = WT > 0 ? (s * sgn > thr) : ((s == s) && xh_cmp_f32(s, op, thr));
+          }
         }
         since[i] = cond ? 0 : since[i] + 1;
         const bool on = inside && (since[i] < w);
@@ -301,13 +325,14 @@ struct SpellArgs {
   int64_t T, C, st;
   int window, op;
   float thr, sgn;
+  double thr64, sgn64;  // the same condition on the fp64 window sum (sum / mean reducers, compile-time windows)
   const float* d_weights;
 };
 
 template <int VEC, int RED, int WT>
 void launch_spell_ring_t(xh_ctx* ctx, dim3 grid, const SpellArgs& a, float* out, int64_t out_st) {
   hipLaunchKernelGGL((k_spell_ring<VEC, RED, WT>), grid, dim3(XH_BLOCK), 0, ctx->stream, a.x, a.T, a.C, a.st, a.window, a.op,
-                     a.thr, a.sgn, a.d_weights, out, out_st);
+                     a.thr, a.sgn, a.thr64, a.sgn64, a.d_weights, out, out_st);
 }
 
 template <int RED>
@@ -322,7 +347,7 @@ template <int VEC, int RED, int WT, int SG>
 void launch_spell_runs_t(xh_ctx* ctx, dim3 grid, const SpellArgs& a, int stat, const int64_t* d_seg, int P, float* out,
                          int32_t* valid_out) {
   hipLaunchKernelGGL((k_spell_runs<VEC, RED, WT, SG>), grid, dim3(XH_BLOCK), 0, ctx->stream, a.x, a.T, a.C, a.st, a.window,
-                     a.op, a.thr, a.sgn, a.d_weights, stat, d_seg, P, out, valid_out);
+                     a.op, a.thr, a.sgn, a.thr64, a.sgn64, a.d_weights, stat, d_seg, P, out, valid_out);
 }
 
 template <int RED>
@@ -341,13 +366,51 @@ void launch_spell_runs_r(xh_ctx* ctx, dim3 grid, int vec, int wt, int sg, const 
 #undef XH_SRN
 }
 
+// Threshold of the one-compare condition `F(s) * sgn > t` (F(s) = float(s / w) for the mean, float(s) for the sum, s the
+// fp64 window sum) moved into sum space: sgn = +1: F(s) > t  <=>  s > S+,  S+ = the largest double with F(S+) <= t;
+// sgn = -1: F(s) < -t  <=>  s < S-,  S- = the smallest double with F(S-) >= -t.  F is monotone, so a bisection over the
+// ordered doubles (64 steps) finds the boundary; the arithmetic of F is the device's (IEEE division and round-to-nearest
+// conversion: xh_div_int is bit-identical to s / w).  Returns thr64 for `s * sgn > thr64`.
+double spell_sum_threshold(float t, float sgn, int w, bool mean) {
+  auto F = [&](double s) -> float { return (float)(mean ? s / (double)w : s); };
+  auto ord = [](double d) -> int64_t {  // monotone map double -> int64
+    int64_t u;
+    memcpy(&u, &d, 8);
+    return u < 0 ? (int64_t)(0x8000000000000000ull - (uint64_t)u) : u;
+  };
+  auto unord = [](int64_t k) -> double {
+    const int64_t u = k < 0 ? (int64_t)(0x8000000000000000ull - (uint64_t)k) : k;
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+  };
+  int64_t lo = ord(-1.7976931348623157e308), hi = ord(1.7976931348623157e308);
+  if (sgn > 0.0f) {  // largest s with F(s) <= t  (F(lo) = -inf <= t, F(hi) = +inf > t for a finite t)
+    while (lo + 1 < hi) {
+      const int64_t mid = (lo >> 1) + (hi >> 1) + (lo & hi & 1);  // (hi - lo overflows int64 over the whole double range)
+      if (F(unord(mid)) <= t) lo = mid; else hi = mid;
+    }
+    return unord(lo);
+  }
+  const float nt = -t;  // smallest s with F(s) >= -t
+  while (lo + 1 < hi) {
+    const int64_t mid = (lo >> 1) + (hi >> 1) + (lo & hi & 1);
+    if (F(unord(mid)) >= nt) hi = mid; else lo = mid;
+  }
+  return -unord(hi);
+}
+
 // The compile-time windows (3, 5) take the one-compare form of the condition (xh_one_cmp): ordered op, finite threshold.
-SpellArgs spell_args(const float* x, int64_t T, int64_t C, int64_t st, int window, int op, float thr, const float* d_weights,
-                     bool wt_built, int* wt) {
-  SpellArgs a = {x, T, C, st, window, op, thr, 1.0f, d_weights};
+SpellArgs spell_args(const float* x, int64_t T, int64_t C, int64_t st, int window, int win_red, int op, float thr,
+                     const float* d_weights, bool wt_built, int* wt) {
+  SpellArgs a = {x, T, C, st, window, op, thr, 1.0f, 0.0, 1.0, d_weights};
   const XhOneCmp one = xh_one_cmp(op, thr);
   *wt = (wt_built && one.ok && (window == 3 || window == 5)) ? window : 0;
-  if (*wt) { a.thr = one.thr; a.sgn = one.sgn; }
+  if (*wt) {
+    a.thr = one.thr; a.sgn = one.sgn;
+    a.sgn64 = (double)one.sgn;
+    if (win_red == 0 || win_red == 1) a.thr64 = spell_sum_threshold(one.thr, one.sgn, window, win_red == 1);
+  }
   return a;
 }
 
@@ -359,7 +422,7 @@ int xh_launch_spell_ring(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
   const int vec = (xh_pick_vec(x, C, st) == 4 && xh_pick_vec(out, C, out_st) == 4) ? 4 : 1;
   const dim3 grid = window_grid(ctx, T, C, vec);
   int wt;
-  const SpellArgs a = spell_args(x, T, C, st, window, op, thr, d_weights, vec == 4, &wt);
+  const SpellArgs a = spell_args(x, T, C, st, window, win_red, op, thr, d_weights, vec == 4, &wt);
   switch (win_red) {  // win_red (spell.hip): 0 sum, 1 mean, 2 min, 3 max, 4 weighted mean
     case 0: launch_spell_ring_r<XH_RED_SUM>(ctx, grid, vec, wt, a, out, out_st); break;
     case 1: launch_spell_ring_r<XH_RED_MEAN>(ctx, grid, vec, wt, a, out, out_st); break;
@@ -380,7 +443,7 @@ int xh_launch_spell_runs(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
   const int vec = (xh_pick_vec(x, C, st) == 4 && cdiv64(cdiv64(C, 4), XH_BLOCK) * py >= 8 * (int64_t)ctx->num_cu) ? 4 : 1;
   const dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), py);
   int wt;
-  const SpellArgs a = spell_args(x, T, C, st, window, op, thr, d_weights, vec == 1, &wt);
+  const SpellArgs a = spell_args(x, T, C, st, window, win_red, op, thr, d_weights, vec == 1, &wt);
   // fields of the run accumulator the statistic reads (runacc.h): 1 max, 2 sum / count / mean / plain sum, 0 all
   const int sg = stat == XH_RUN_MAX ? 1 : (stat == XH_RUN_SUM || stat == XH_RUN_COUNT || stat == XH_RUN_MEAN || stat == XH_RUN_PLAINSUM) ? 2 : 0;
   switch (win_red) {
