@@ -7,6 +7,8 @@
 // shift keeps the one-pass variance well conditioned: |v - K| is of the order of the spread, not of the magnitude).
 // The generic kernel (reduce2.hip) re-reads every row W times and twice for its two-pass std; it remains the exact path
 // for irregular doys (calendar gaps).
+#include <stdlib.h>
+
 #include "pdoy.h"
 
 namespace {
@@ -90,7 +92,8 @@ k_doy_stats_sets(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, 
 int xh_launch_doy_stats_sets(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
                              int ndoy, int window, const uint8_t* d_reg, float* mean_out, float* std_out) {
   if (!(window == 3 || window == 5 || window == 7) || nyears > 64) return XH_ERR_NOTIMPL;
-  const int chunk = 24;
+  int chunk = 24;
+  if (const char* e = xh_diag_env("XH_DOYSTATS_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : chunk;  // diagnostics
   const dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
 #define XH_DS(W, NY)                                                                                                     \
   hipLaunchKernelGGL((k_doy_stats_sets<W, NY>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, d_reg, \
