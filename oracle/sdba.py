@@ -150,3 +150,15 @@ def eqm_adjust_grouped(sim, time, prop, labels, af, hist_q, kind="+", interp="ne
         if rows.size:
             out[rows] = eqm_adjust(sim[rows], af[g], hist_q[g], kind, interp, extrapolation)
     return out
+
+
+def qdm_adjust_grouped(sim, time, prop, labels, af, quantiles, kind="+", interp="nearest", extrapolation="constant"):
+    """Grouped QDM: ranks inside each group's own time steps (main_only=True), factors of that group."""
+    sim = np.asarray(sim)
+    out = np.empty_like(sim)
+    gv = group_values(time, prop)
+    for g, lab in enumerate(labels):
+        rows = np.nonzero(gv == lab)[0]
+        if rows.size:
+            out[rows] = qdm_adjust(sim[rows], af[g], quantiles, kind, interp, extrapolation)
+    return out

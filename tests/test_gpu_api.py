@@ -1252,8 +1252,6 @@ def test_qdm_precipitation_and_edge_cases(dev, rng):
     np.testing.assert_array_equal(tm.T, got)
     with pytest.raises(NotImplementedError):
         qdm.adjust(sim, interp="cubic")
-    with pytest.raises(NotImplementedError):
-        xsdba.QuantileDeltaMapping.train(ref, hist, group="time.month", device=dev)
     with pytest.raises(ValueError):
         K.qdm_adjust(dev, dev.to_device(sim), af, qdm.quantiles[::-1].copy())
 
@@ -1273,3 +1271,24 @@ def test_qdm_preserves_quantile_deltas(dev, rng):
     d_model = np.quantile(sim, qs, axis=0) - np.quantile(hist, qs, axis=0)
     d_scen = np.quantile(scen, qs, axis=0) - np.quantile(ref, qs, axis=0)
     np.testing.assert_allclose(d_scen, d_model, atol=0.25)
+
+
+@pytest.mark.parametrize("group,window", [("time.month", 1), ("time.dayofyear", 15)])
+def test_qdm_grouped_matches_oracle(dev, rng, group, window):
+    """QDM with a sub-grouping: trained like the grouped EQM, ranks taken inside each group's own time steps, factors of
+    the step's group (oracle restatement; parity unpinned)."""
+    from xclim_amd import sdba as xsdba
+
+    T = 365 * 3
+    ta, ot = _axes("2001-01-01", T, "noleap")
+    shape = (T, 3, 5)
+    ref = rng.normal(10, 3, shape).astype(np.float32)
+    hist = rng.normal(11, 4, shape).astype(np.float32)
+    sim = rng.normal(13, 4, shape).astype(np.float32)
+    sim[rng.random(shape) < 0.02] = np.nan
+    qdm = xsdba.QuantileDeltaMapping.train(ref, hist, nquantiles=10, kind="+", group=group, window=window, time=ta, device=dev)
+    prop = group.split(".")[1]
+    for interp in ("nearest", "linear"):
+        got = qdm.adjust(sim, interp=interp, time=ta)
+        exp = osdba.qdm_adjust_grouped(sim, ot, prop, qdm.group_labels, qdm.af, qdm.quantiles, "+", interp, "constant")
+        np.testing.assert_allclose(got, exp, rtol=1e-6, equal_nan=True, err_msg=f"{group} {interp}")

@@ -198,24 +198,46 @@ class EmpiricalQuantileMapping:
 
 
 class QuantileDeltaMapping(EmpiricalQuantileMapping):
-    """Quantile delta mapping (xsdba.QuantileDeltaMapping): the same training as EQM, the adjustment factor of a sim
-    value is taken at ITS quantile in the sim series: ``sim_q = rank(sim, pct=True)``,
-    ``af = interp_on_quantiles(sim_q, quantiles, af)``, ``scen = sim (+|*) af``.  ``group="time"`` only."""
-
-    @classmethod
-    def train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", window=None, time=None, device=None):
-        grp = group if isinstance(group, Grouper) else Grouper(group, 1 if window is None else window)
-        if grp.prop != "group":
-            raise NotImplementedError("QuantileDeltaMapping: only group='time' is built")
-        return super().train(ref, hist, nquantiles=nquantiles, kind=kind, group=grp, device=device)
+    """Quantile delta mapping (xsdba.QuantileDeltaMapping): the same training as EQM (incl. its groupings), the adjustment
+    factor of a sim value is taken at ITS quantile in the sim series: ``sim_q = rank(sim, pct=True)``,
+    ``af = interp_on_quantiles(sim_q, quantiles, af)``, ``scen = sim (+|*) af``.  With a sub-grouping the ranks are taken
+    inside each group's own time steps (xsdba: ``group.apply(rank, sim, main_only=True)`` — the window only widens the
+    TRAINING sample) and every step uses the factors of its group; factors are not interpolated between groups."""
 
     def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", time=None, keep=False):
         if interp not in ("nearest", "linear", "cubic"):
             raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
         if interp == "cubic":
             raise NotImplementedError("QuantileDeltaMapping.adjust: interp='cubic' is not built (nearest, linear)")
-        s, cell_shape = _flatten(sim, self._dev)
+        dev = self._dev
+        s, cell_shape = _flatten(sim, dev)
         if tuple(cell_shape) != self.cell_shape:
             raise ValueError("sim does not match the trained grid")
-        scen = K.qdm_adjust(self._dev, s, self._af, self.quantiles, self.kind, interp, extrapolation)
-        return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
+        if self.group.prop == "group":
+            scen = K.qdm_adjust(dev, s, self._af, self.quantiles, self.kind, interp, extrapolation)
+            return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
+        if time is None or len(time) != s.shape[0]:
+            raise ValueError(f"group={self.group.name!r} needs time=TimeAxis of sim")
+        gi = self.group.index(time, self.group_labels)
+        if (gi < 0).any():
+            raise ValueError("sim holds time steps whose group was not trained (e.g. day 366 with a 365-day training set)")
+        perm = np.argsort(gi, kind="stable")  # group-major: every group one contiguous row block, ranked on its own
+        counts = np.bincount(gi, minlength=len(self.group_labels))
+        T, C_ = s.shape
+        nq = len(self.quantiles)
+        s_perm = K.select_rows(dev, s, perm)
+        scen_perm = dev.empty((T, C_), np.float32)
+        off = 0
+        for g, n in enumerate(counts):
+            if n == 0:
+                continue
+            blk = dev.wrap(s_perm.ptr + off * C_ * 4, (int(n), C_), np.float32)
+            out = dev.wrap(scen_perm.ptr + off * C_ * 4, (int(n), C_), np.float32)
+            af_g = dev.wrap(self._af.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
+            K.qdm_adjust(dev, blk, af_g, self.quantiles, self.kind, interp, extrapolation, out=out)
+            off += int(n)
+        inv = np.empty(T, dtype=np.int64)
+        inv[perm] = np.arange(T)
+        scen = K.select_rows(dev, scen_perm, inv)
+        dev.sync()
+        return scen if keep else scen.get().reshape((T,) + self.cell_shape)
