@@ -238,7 +238,8 @@ def test_cdd_fused(dev, rng):
         np.testing.assert_array_equal(val.get(), ogen.select_resample_op(pr, "count", ot, "YS"))
 
 
-@pytest.mark.parametrize("N,C", [(1, 10), (2, 10), (5, 300), (8, 64), (13, 70), (30, 129), (150, 200), (365, 40)])
+@pytest.mark.parametrize("N,C", [(1, 10), (2, 10), (5, 300), (8, 64), (13, 70), (30, 129), (150, 200), (365, 40), (600, 70), (1000, 40),
+                                 (2500, 20)])
 @pytest.mark.parametrize("ab", [(1.0, 1.0), (1 / 3, 1 / 3)])
 def test_nan_quantile(dev, rng, N, C, ab):
     x = rng.normal(0, 1, (N, C)).astype(np.float32)
@@ -258,7 +259,7 @@ def test_nan_quantile(dev, rng, N, C, ab):
 
 @pytest.mark.parametrize("nyears,window,C,calendar", [(1, 5, 260, "noleap"), (1, 5, 64, "standard"), (3, 5, 33, "standard"),
                                                      (6, 5, 70, "noleap"), (9, 7, 20, "standard"), (30, 5, 24, "noleap"),
-                                                     (2, 4, 16, "noleap")])
+                                                     (2, 4, 16, "noleap"), (20, 31, 40, "noleap"), (30, 31, 20, "standard")])
 def test_percentile_doy(dev, rng, nyears, window, C, calendar):
     start = "2000-01-01"
     T = 365 * nyears + (nyears + 3) // 4 if calendar == "standard" else 365 * nyears

@@ -14,7 +14,8 @@
 //                                         whose order statistics lie within the 16 largest / smallest samples
 //                                        k_pdoy_merge   per-day sorted lists in a compact LDS ring + W-way tail merge (other
 //                                         percentiles; OFFSET variant: exact window lists for irregular doys, e.g. Feb 29)
-//   anything else (N <= 640)           : k_pdoy_lds     lane-private LDS column, bitonic network in LDS
+//   anything else (N <= 4096)          : k_pdoy_lds     lane-private LDS column, bitonic network in LDS (64 cells per wave
+//                                                         up to 512 samples, 32 / 16 / 8 beyond)
 // Time-major layout, one lane per cell (VEC cells in the sliding kernel).
 #include <stdlib.h>
 
@@ -386,20 +387,23 @@ static void build_qtab(int L, const double* qs, int nper, double alpha, double b
 }
 
 // ---- LDS path -------------------------------------------------------------------------------------
-// One wave (64 lanes) per block; lane l owns column l of an [NP][64] uint32 LDS array (conflict-free: the bank
+// One wave (64 lanes) per block; lane l owns column l of an [NP][cw] uint32 LDS array (conflict-free: the bank
 // is the lane).  All lanes execute the same compare-exchange sequence on their own column, so no barriers.
+// cw = cells per wave: 64 up to 512 samples per cell; 32 / 16 / 8 (the other lanes idle) for 1024 / 2048 / 4096 samples
+// (e.g. window 31 over 30 years = 930): the exact, slow path of last resort.
 __global__ void __launch_bounds__(64)
 k_pdoy_lds(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
-           int ndoy, int window, int NP, const double* __restrict__ qs, int nper, double alpha, double beta,
+           int ndoy, int window, int NP, int cw, const double* __restrict__ qs, int nper, double alpha, double beta,
            double* __restrict__ out, const int32_t* __restrict__ vmap, int64_t Tv, const int32_t* __restrict__ doy_list,
            int ndl) {
   extern __shared__ uint32_t lds[];
   const int lane = threadIdx.x;
-  int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  if (lane >= cw) return;  // (no barriers in this kernel)
+  int64_t c = (int64_t)blockIdx.x * cw + lane;
   const bool active = c < C;
   const int half = window / 2;
   const int N = nyears * window;
-  uint32_t* col = lds + lane;  // element i at col[i * 64]
+  uint32_t* col = lds + lane;  // element i at col[i * cw]
   const int nd = doy_list ? ndl : ndoy;
   for (int di = blockIdx.y; di < nd; di += gridDim.y) {
     const int d = doy_list ? doy_list[di] : di;
@@ -414,10 +418,10 @@ k_pdoy_lds(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const 
           if (active && tp >= 0 && tp < T) v = x[tp * st + c];
         }
         nvalid += (v == v) ? 1 : 0;
-        col[(y * window + k) * 64] = xh_f2key(v);
+        col[(y * window + k) * cw] = xh_f2key(v);
       }
     }
-    for (int i = N; i < NP; ++i) col[i * 64] = 0xFFFFFFFFu;
+    for (int i = N; i < NP; ++i) col[i * cw] = 0xFFFFFFFFu;
     // bitonic sort of NP keys, lane-private
     for (int size = 2; size <= NP; size <<= 1) {
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -425,16 +429,16 @@ k_pdoy_lds(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const 
           int j = i ^ stride;
           if (j > i) {
             bool up = ((i & size) == 0);
-            uint32_t a = col[i * 64], b = col[j * 64];
+            uint32_t a = col[i * cw], b = col[j * cw];
             uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-            col[i * 64] = up ? lo : hi;
-            col[j * 64] = up ? hi : lo;
+            col[i * cw] = up ? lo : hi;
+            col[j * cw] = up ? hi : lo;
           }
         }
       }
     }
     if (active) {
-      auto get = [&](int idx) -> float { return xh_key2f(col[idx * 64]); };
+      auto get = [&](int idx) -> float { return xh_key2f(col[idx * cw]); };
       for (int j = 0; j < nper; ++j) {
         double r = xh_hf_quantile(N, nvalid, qs[j], alpha, beta, get);
         out[((int64_t)j * ndoy + d) * C + c] = r;
@@ -687,14 +691,14 @@ static int launch_pdoy_lds(xh_ctx* ctx, const float* x, int64_t T, int64_t C, in
                            double* out, const int32_t* d_vmap, int64_t Tv, const int32_t* d_doy_list, int ndl) {
   int N = nyears * window;
   int NP = next_pow2(N < 2 ? 2 : N);
-  size_t lds = (size_t)NP * 64 * sizeof(uint32_t);
-  XH_REQUIRE(lds <= 160 * 1024, XH_ERR_LIMIT, "percentile: %d samples per cell exceed the per-wave LDS column capacity (640)",
-             N);
+  XH_REQUIRE(NP <= 4096, XH_ERR_LIMIT, "percentile: %d samples per cell exceed the LDS column capacity (4096)", N);
+  const int cw = NP <= 512 ? 64 : (NP == 1024 ? 32 : (NP == 2048 ? 16 : 8));  // cells per wave: NP * cw * 4 B <= 128 KB
+  size_t lds = (size_t)NP * cw * sizeof(uint32_t);
   if (lds > 64 * 1024)
     XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_pdoy_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int nd = d_doy_list ? ndl : ndoy;
-  dim3 grid((unsigned)cdiv64(C, 64), (unsigned)(nd > 1024 ? 1024 : nd));
-  hipLaunchKernelGGL(k_pdoy_lds, grid, dim3(64), lds, ctx->stream, x, T, C, st, d_tbase, nyears, ndoy, window, NP, d_q, nper,
+  dim3 grid((unsigned)cdiv64(C, cw), (unsigned)(nd > 1024 ? 1024 : nd));
+  hipLaunchKernelGGL(k_pdoy_lds, grid, dim3(64), lds, ctx->stream, x, T, C, st, d_tbase, nyears, ndoy, window, NP, cw, d_q, nper,
                      alpha, beta, out, d_vmap, Tv, d_doy_list, ndl);
   XH_LAUNCH_CHECK();
   return XH_OK;
@@ -1049,7 +1053,7 @@ int xh_nan_quantile(xh_ctx* ctx, const float* x, int64_t N, int64_t C, int64_t s
                     double alpha, double beta, double* out) {
   XH_REQUIRE(ctx && x && q && out, XH_ERR_ARG, "xh_nan_quantile: NULL argument");
   XH_REQUIRE(N >= 1 && C >= 0 && nq >= 1 && nq <= 64, XH_ERR_ARG, "xh_nan_quantile: bad shape (N >= 1, 1 <= nq <= 64)");
-  XH_REQUIRE(N <= 640, XH_ERR_LIMIT, "xh_nan_quantile: N = %lld samples exceed 640 (use xh_quantile_series)",
+  XH_REQUIRE(N <= 4096, XH_ERR_LIMIT, "xh_nan_quantile: N = %lld samples exceed 4096 (use xh_quantile_series)",
              (long long)N);
   if (C == 0) return XH_OK;
   const float* xs = x;
@@ -1066,7 +1070,7 @@ int xh_nan_quantile(xh_ctx* ctx, const float* x, int64_t N, int64_t C, int64_t s
     st = C;
   }
   // one "doy" row, N "years", window 1, tbase[y] = y
-  int32_t tb[640];
+  int32_t tb[4096];
   for (int i = 0; i < (int)N; ++i) tb[i] = i;
   size_t cur = 0;
   void *d_tb = nullptr, *d_q = nullptr;
