@@ -563,14 +563,22 @@ int xh_run_stats(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, 
   } else {
     XH_REQUIRE(seg_off[0] == 0 && seg_off[P] == T, XH_ERR_ARG,
                "xh_run_stats: resample-after mode needs segments covering [0, T)");
-    dim3 grid((unsigned)cdiv64(C, XH_BLOCK), 1);
+    // one cell per lane: four per lane are slower with the early flush as well (0.89 vs 0.50 ms; round 1, lazy flush only:
+    // 1.11 vs 0.57) — one serial march per cell and a quarter of the waves; XH_RUNSTATS_NOCUT_VEC=4 (diagnostics) selects it
+    const char* ev = xh_diag_env("XH_RUNSTATS_NOCUT_VEC");
+    const int nvec = (ev && atoi(ev) == 4 && vec == 4) ? 4 : 1;
+    dim3 grid((unsigned)cdiv64(cdiv64(C, nvec), XH_BLOCK), 1);
     // stat group: 1 max, 2 sum / count / mean, 3 min, 0 all (std)
     const int sg = stat == XH_RUN_MAX ? 1 : (stat == XH_RUN_SUM || stat == XH_RUN_COUNT || stat == XH_RUN_MEAN || stat == XH_RUN_PLAINSUM) ? 2
                    : stat == XH_RUN_MIN ? 3 : 0;
-#define XH_RSN(G)                                                                                                          \
-  hipLaunchKernelGGL((k_run_stats<1, false, G>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, fused_op, (float)thr, \
+#define XH_RSN(V, G)                                                                                                          \
+  hipLaunchKernelGGL((k_run_stats<V, false, G>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, fused_op, (float)thr, \
                      window, stat, index_first, d_seg, P, out, valid_out)
-    if (sg == 1) XH_RSN(1); else if (sg == 2) XH_RSN(2); else if (sg == 3) XH_RSN(3); else XH_RSN(0);
+    if (nvec == 4) {
+      if (sg == 1) XH_RSN(4, 1); else if (sg == 2) XH_RSN(4, 2); else if (sg == 3) XH_RSN(4, 3); else XH_RSN(4, 0);
+    } else {
+      if (sg == 1) XH_RSN(1, 1); else if (sg == 2) XH_RSN(1, 2); else if (sg == 3) XH_RSN(1, 3); else XH_RSN(1, 0);
+    }
 #undef XH_RSN
   }
   XH_LAUNCH_CHECK();
