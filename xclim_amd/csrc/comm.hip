@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <stdlib.h>
+#include <unistd.h>
 
 #include "common.h"
 
@@ -107,7 +108,18 @@ int xh_comm_init(xh_ctx* ctx, int nranks, int rank, const void* id, xh_comm** ou
   c->rank = rank;
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
+  // RCCL prints a version banner on STDOUT when the first communicator comes up; a caller that writes its result there
+  // (bench.py: one JSON line, parsed by whoever launched it) would find the banner after it once the C buffer is flushed
+  // at exit.  File descriptor 1 points at stderr for the duration of the call.
+  fflush(stdout);
+  const int saved_out = dup(1);
+  if (saved_out >= 0) (void)dup2(2, 1);
   ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+  fflush(stdout);
+  if (saved_out >= 0) {
+    (void)dup2(saved_out, 1);
+    (void)close(saved_out);
+  }
   if (r != ncclSuccess) {
     xh_set_error("ncclCommInitRank(nranks=%d, rank=%d) failed: %s", nranks, rank, g_rccl.GetErrorString(r));
     delete c;
