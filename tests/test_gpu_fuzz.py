@@ -216,6 +216,12 @@ def test_fuzz_eqm_and_two_variable_reductions(dev, seed):
             # (scipy fp64 in the oracle, fp32 Horner on the device) is held to 2e-6
             np.testing.assert_allclose(got, exp, rtol=2e-6 if interp == "cubic" else 1e-6, atol=0, equal_nan=True,
                                        err_msg=f"adjust {interp} {extrap} {kind} T={T} C={C} nq={nq}")
+        # quantile delta mapping on the same factors: exact average ranks + fp64 lookup (oracle: scipy rankdata / interp1d)
+        for interp in ("nearest", "linear"):
+            extrap = str(rng.choice(["constant", "nan"]))
+            got = K.qdm_adjust(dev, dev.to_device(sim), dev.to_device(eaf32), osdba.equally_spaced_nodes(nq), kind, interp, extrap).get()
+            exp = osdba.qdm_adjust(sim, eaf32, osdba.equally_spaced_nodes(nq), kind, interp, extrap)
+            np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0, equal_nan=True, err_msg=f"qdm {interp} {extrap} {kind} T={T} C={C} nq={nq}")
         # two-variable range reductions
         lo = ref.reshape((T,) + cells)
         hi = (ref + np.abs(hist)).reshape((T,) + cells)
