@@ -245,3 +245,18 @@ def test_threshold_units():
     for bad in (("1 mm/day", "kg m-2 s-1", None), ("1 mm", "K", None), ("1 furlong", "m", None), ("abc", "K", None)):
         with pytest.raises(ValueError):
             cvt(*bad)
+
+
+def test_float64_inputs_are_flagged():
+    """float64 fields / array thresholds are rounded to float32 — not silently: PrecisionWarning."""
+    import warnings
+
+    from xclim_amd._capi import PrecisionWarning, warn_downcast
+
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        warn_downcast(np.zeros((3, 2), dtype=np.float64), "field")
+        warn_downcast(np.zeros((3, 2), dtype=np.float32), "field")
+        warn_downcast(1.5, "scalar")
+        warn_downcast(np.float64(1.5), "scalar")
+    assert len(w) == 1 and issubclass(w[0].category, PrecisionWarning)

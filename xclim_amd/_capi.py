@@ -24,6 +24,20 @@ REDUCERS = {"sum": 0, "integral": 0, "mean": 1, "min": 2, "max": 3, "std": 4, "v
 RUN_STATS = {"max": 0, "min": 1, "sum": 2, "count": 3, "mean": 4, "std": 5, "first": 6, "last": 7, "plainsum": 8}
 
 
+class PrecisionWarning(UserWarning):
+    """A float64 input was rounded to float32: the kernels compute on float32 fields (xclim keeps the input dtype, so
+    values differ at ~1e-7 relative and comparisons of values that close to a threshold can flip)."""
+
+
+def warn_downcast(a, what: str) -> None:
+    """One PrecisionWarning per call site when `a` is a float64 array (python floats and float32 pass silently)."""
+    import warnings
+
+    if getattr(a, "dtype", None) == np.float64 and getattr(a, "ndim", 0) > 0:
+        warnings.warn(f"{what}: float64 input is rounded to float32 (the HIP kernels compute on float32 fields)",
+                      PrecisionWarning, stacklevel=3)
+
+
 class BackendUnavailable(RuntimeError):
     """libxclimhip.so is not built/loadable or no MI355X device is visible."""
 

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import kernels as K
-from ._capi import DeviceArray, get_device
+from ._capi import DeviceArray, warn_downcast, get_device
 from .timeaxis import TimeAxis
 
 
@@ -62,6 +62,7 @@ def _flatten(arr, dev):
         cell_shape = arr.shape[1:]
         return arr.reshape(arr.shape[0], -1), cell_shape
     a = np.asarray(arr)
+    warn_downcast(a, "field")
     cell_shape = a.shape[1:]
     return dev.to_device(a.reshape(a.shape[0], -1), dtype=np.float32), cell_shape
 

@@ -12,7 +12,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import kernels as K
-from ._capi import OPS, DeviceArray, get_device
+from ._capi import warn_downcast, OPS, DeviceArray, get_device
 from .calendar import DoyPercentile, _flatten, adjust_doy_calendar, resample_doy_index
 from .timeaxis import TimeAxis
 
@@ -157,6 +157,7 @@ def compare(left, op: str, right, constrain=None, *, device=None, keep=False):
     if np.ndim(right) == 0 and not isinstance(right, DeviceArray):
         m = K.compare_map(dev, x, sym, right, kind)
     else:
+        warn_downcast(np.asarray(right), "compare: array threshold")
         b, _ = _flatten(np.broadcast_to(np.asarray(right, dtype=np.float32), np.shape(left))
                         if not isinstance(right, DeviceArray) else right, dev)
         m = K.compare_map(dev, x, sym, b, kind)
@@ -173,6 +174,7 @@ def get_daily_events(da, threshold, op: str, constrain=None, *, device=None, kee
     if np.ndim(threshold) == 0 and not isinstance(threshold, DeviceArray):
         ev = K.compare_map(dev, x, sym, threshold, "events")
     else:
+        warn_downcast(np.asarray(threshold), "compare: array threshold")
         b, _ = _flatten(np.broadcast_to(np.asarray(threshold, dtype=np.float32), np.shape(da))
                         if not isinstance(threshold, DeviceArray) else threshold, dev)
         ev = K.compare_map(dev, x, sym, b, "events")

@@ -9,7 +9,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import kernels as K
-from ._capi import get_device
+from ._capi import get_device, warn_downcast
 
 
 def nan_calc_percentiles(arr, percentiles=None, axis: int = -1, alpha: float = 1.0, beta: float = 1.0, copy: bool = True,
@@ -23,6 +23,7 @@ def nan_calc_percentiles(arr, percentiles=None, axis: int = -1, alpha: float = 1
     lead = a.shape[:-1]
     N = a.shape[-1]
     dev = device or get_device()
+    warn_downcast(a, "calc_perc")
     flat = np.ascontiguousarray(a.reshape(-1, N), dtype=np.float32)  # (C, N) sample-minor
     q = np.array([p / 100.0 for p in pers])
     out = K.nan_quantile(dev, dev.to_device(flat), q, alpha, beta, sample_axis=1).get()  # (nq, C)
