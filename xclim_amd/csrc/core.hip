@@ -61,15 +61,8 @@ int xh_create(int device, xh_ctx** out) {
     // kernel got faster than the transposes next to it, they are the long pole (config-4 train 71.4 -> 67.6 ms);
     // XH_STREAM2_PRIO=0 (diagnostics) restores the default priority
     const char* pr = xh_diag_env("XH_STREAM2_PRIO");
-    const char* cm = xh_diag_env("XH_STREAM2_CUMASK_STRIDE");  // tuning: helper stream restricted to every k-th CU
     int least = 0, greatest = 0;
-    if (cm && atoi(cm) > 1) {
-      const int k = atoi(cm);
-      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < 256; ++i)
-        if (i % k == 0) mask[i / 32] |= 1u << (i % 32);
-      XH_CHECK_HIP(hipExtStreamCreateWithCUMask(&ctx->stream2, 8, mask));
-    } else if (!(pr && !atoi(pr)) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+    if (!(pr && !atoi(pr)) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
       XH_CHECK_HIP(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest));
     else
       XH_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));

@@ -274,13 +274,7 @@ static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t 
   // the same offset of consecutive columns falls onto a quarter of the HBM channels.
   int64_t Tp = (T + 63) & ~(int64_t)63;
   if (((Tp / 64) & 1) == 0) Tp += 64;
-  if (const char* e = xh_diag_env("XH_SELECT_TPAD")) Tp = ((T + 63) & ~(int64_t)63) + 64 * (int64_t)atol(e);  // diagnostics
-  size_t batch_bytes = 1ull << 29;
-  if (const char* e = xh_diag_env("XH_SELECT_BATCH_MB")) {  // diagnostics: scratch batch size (MALL residency experiments)
-    const long mb = atol(e);
-    if (mb >= 1 && mb <= 4096) batch_bytes = (size_t)mb << 20;
-  }
-  int64_t batch = (int64_t)(batch_bytes / (sizeof(float) * (size_t)Tp));
+  int64_t batch = (int64_t)((1ull << 29) / (sizeof(float) * (size_t)Tp));  // 512 MB batches (smaller ones only add tails)
   batch = (batch / 64) * 64;
   if (batch < 64) batch = 64;
   if (batch > C) batch = C;

@@ -411,13 +411,12 @@ k_select_lean(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
         // iteration loop waits one LDS latency per key).  Reads past the bin's m keys are masked (list is padded).
         const uint32_t m = (uint32_t)ti.m, kth = (uint32_t)ti.kth;
         const uint32_t* lp = list + ti.region;
-        if (abl & 64) continue;
         for (uint32_t a2 = a0; a2 < m; a2 += 2 * CPT) {
           const uint32_t e0 = lp[a2];
           uint32_t e1 = lp[a2 + CPT];
           e1 = a2 + CPT < m ? e1 : 0u;  // key 0 never wins (valid keys are > 0)
           uint32_t less0 = 0, leq0 = 0, less1 = 0, leq1 = 0;
-          for (uint32_t b2 = 0; b2 < ((abl & 32) ? 0u : m); b2 += 4) {
+          for (uint32_t b2 = 0; b2 < m; b2 += 4) {
             uint32_t k0 = lp[b2], k1 = lp[b2 + 1], k2 = lp[b2 + 2], k3 = lp[b2 + 3];
             k1 = b2 + 1 < m ? k1 : 0xFFFFFFFFu;
             k2 = b2 + 2 < m ? k2 : 0xFFFFFFFFu;
@@ -489,7 +488,6 @@ int launch_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64
                 float* out, int64_t out_cstride, int64_t out_qstride) {
   int64_t nblk = ncols;
   int64_t maxblk = (int64_t)ctx->num_cu * 16;
-  if (const char* eg = xh_diag_env("XH_LEAN_GRID_PER_CU")) maxblk = (int64_t)ctx->num_cu * (atoi(eg) > 0 ? atoi(eg) : 16);
   if (nblk > maxblk) nblk = maxblk;
   const char* ea = xh_diag_env("XH_SELECT_ABL");  // diagnostics only: skip phases (results become wrong)
   const char* ep = xh_diag_env("XH_SELECT_PROF");  // diagnostics only: per-phase cycle counts on stderr
@@ -498,14 +496,11 @@ int launch_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64
     XH_CHECK_HIP(hipMalloc((void**)&d_prof, 16 * sizeof(unsigned long long)));
     XH_CHECK_HIP(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
   }
-  const char* epad = xh_diag_env("XH_LEAN_PAD_LDS");  // diagnostics: unused dynamic LDS (KB) to cap the workgroups per CU
-  const size_t pad = epad ? (size_t)atoi(epad) * 1024 : 0;
-  if (pad) XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_select_lean<NT, KPL, NB, KSAFE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
   if ((ea && atoi(ea)) || d_prof)
     hipLaunchKernelGGL((k_select_lean<NT, KPL, NB, KSAFE, true>), dim3((unsigned)nblk), dim3(NT), 0, ctx->stream, xcols, T, ncols,
                        col_stride, d_q, nq, out, out_cstride, out_qstride, ea ? atoi(ea) : 0, d_prof);
   else
-    hipLaunchKernelGGL((k_select_lean<NT, KPL, NB, KSAFE, false>), dim3((unsigned)nblk), dim3(NT), pad, ctx->stream, xcols, T, ncols,
+    hipLaunchKernelGGL((k_select_lean<NT, KPL, NB, KSAFE, false>), dim3((unsigned)nblk), dim3(NT), 0, ctx->stream, xcols, T, ncols,
                        col_stride, d_q, nq, out, out_cstride, out_qstride, 0, nullptr);
   XH_LAUNCH_CHECK();
   if (d_prof) {
