@@ -187,6 +187,9 @@ k_qdm_columns(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
     const double mn = ((double)(cnt0 + 1u) / 2.0) / dn;                // rank of the minimum / count
     const double mx = ((double)(2u * n - cntm + 1u) / 2.0) / dn;       // rank of the maximum / count
     const double mxmn = mx - mn;
+    // the two divisions of every key (rank / count, then the rescaling) as exact quotients from reciprocals computed
+    // once per column (xh_div_int: Markstein's correction, bit-identical to the IEEE division)
+    const double inv_dn = 1.0 / dn, inv_mxmn = 1.0 / mxmn;
     float* __restrict__ oc = out + col * out_cstride;
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
@@ -207,8 +210,9 @@ k_qdm_columns(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
           below = cnt0 + s0 + less;
           equal = eq;
         }
-        const double rnk = ((double)(2u * below + equal + 1u) / 2.0) / dn;
-        const double pct = (mx * (rnk - mn)) / mxmn;  // 0 / 0 = NaN when every valid sample is equal
+        const double rnk = xh_div_int((double)(2u * below + equal + 1u) * 0.5, dn, inv_dn);
+        const double pnum = mx * (rnk - mn);
+        const double pct = mxmn == 0.0 ? xh_nan64() : xh_div_int(pnum, mxmn, inv_mxmn);  // 0 / 0 = NaN: all valid samples equal
         if (pct == pct) {
           const double x0 = xs[0], xl = xs[nvn - 1];
           float a;
