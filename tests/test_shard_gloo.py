@@ -63,3 +63,51 @@ def test_two_rank_gloo_gather(tmp_path):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "SHARD-OK (2, 203)" in res.stdout
+
+
+_RDV_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+from xclim_amd.shard import _rendezvous_path, exchange_unique_id
+rank = int(os.environ["RANK"])
+if rank == 0:
+    time.sleep(0.3)            # the other ranks are already polling when the id appears
+uid = exchange_unique_id(_rendezvous_path(), rank, lambda: bytes(range(128)), 128, timeout_s=20.0)
+sys.stdout.write(uid.hex())
+"""
+
+
+def test_unique_id_file_rendezvous_three_ranks(tmp_path):
+    """The only host-side logic of a multi-GPU launch that is not RCCL: rank 0 publishes the 128-byte id atomically, the
+    other ranks (started earlier, polling) read the complete id; the file name is shared inside one launch (same
+    MASTER_ADDR / MASTER_PORT / parent process) and differs between launches."""
+    script = tmp_path / "rdv.py"
+    script.write_text(_RDV_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XH_RENDEZVOUS_DIR=str(tmp_path), MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="3")
+    procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE)
+             for r in (1, 2, 0)]
+    outs = [p.communicate(timeout=60)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    assert outs[0] == outs[1] == outs[2] == bytes(range(128)).hex()
+    # a different port (another launch) uses another file
+    from xclim_amd.shard import _rendezvous_path
+
+    a = _rendezvous_path()
+    os.environ["MASTER_PORT"], old = "29534", os.environ.get("MASTER_PORT")
+    try:
+        os.environ["MASTER_PORT"] = "1"
+        b = _rendezvous_path()
+        os.environ["MASTER_PORT"] = "2"
+        c = _rendezvous_path()
+    finally:
+        if old is None:
+            os.environ.pop("MASTER_PORT", None)
+        else:
+            os.environ["MASTER_PORT"] = old
+    assert b != c and a is not None
+    # a rank that never gets an id gives up with a clear error
+    with pytest.raises(TimeoutError):
+        from xclim_amd.shard import exchange_unique_id
+
+        exchange_unique_id(str(tmp_path / "never.id"), 1, None, 128, timeout_s=0.2)

@@ -69,6 +69,32 @@ def _rendezvous_path() -> str:
     return os.path.join(d, f"xclim_amd_rccl_{key}.id")
 
 
+def exchange_unique_id(path: str, rank: int, make_id, nbytes: int, timeout_s: float = 300.0) -> bytes:
+    """The file rendezvous of a launch: rank 0 creates the id (``make_id()``) and publishes it atomically at `path`, every
+    other rank polls until the complete id is there.  Pure host logic (covered on the CPU by tests/test_shard_gloo.py)."""
+    if rank == 0:
+        uid = make_id()
+        if len(uid) != nbytes:
+            raise ValueError(f"unique id must be {nbytes} bytes")
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)  # atomic: readers see the whole id or nothing
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == nbytes:
+                return uid
+        except OSError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s:.0f} s")
+        time.sleep(0.02)
+
+
 class Comm:
     """One RCCL communicator over the ranks of a launch (one process per GPU), on a Device's context.
 
@@ -98,25 +124,7 @@ class Comm:
     def from_env(cls, dev, timeout_s: float = 300.0) -> "Comm":
         world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
         path = _rendezvous_path()
-        if rank == 0:
-            uid = cls.new_unique_id(dev)
-            tmp = f"{path}.{os.getpid()}.tmp"
-            with open(tmp, "wb") as f:
-                f.write(uid)
-            os.replace(tmp, path)  # atomic: readers see the whole id or nothing
-        else:
-            t0 = time.time()
-            while True:
-                try:
-                    with open(path, "rb") as f:
-                        uid = f.read()
-                    if len(uid) == cls.ID_BYTES:
-                        break
-                except OSError:
-                    pass
-                if time.time() - t0 > timeout_s:
-                    raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s:.0f} s")
-                time.sleep(0.02)
+        uid = exchange_unique_id(path, rank, lambda: cls.new_unique_id(dev), cls.ID_BYTES, timeout_s)
         comm = cls(dev, world, rank, uid)  # collective: returns once every rank has joined (and so has read the file)
         if rank == 0:
             try:
