@@ -434,6 +434,16 @@ int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
 int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const float* af,
                   const double* q /* host */, int nq, int kind, int interp, int extrap, float* scen);
 
+/* DetrendedQuantileMapping pieces (xsdba._adjustment.dqm_train / dqm_adjust, xsdba.detrending.PolyDetrend; parity
+ * unpinned).  xh_poly_trend: per-cell least-squares polynomial of degree 0 (mean) or 1 over the valid samples of the
+ * time-major series, p0[C] + p1[C] * (t - (T - 1) / 2) in float64 (p1 may be NULL for degree 0; nvalid[C] optional).
+ * xh_trend_apply: out = x OP (p0[c] + p1[c] * (t - (T - 1) / 2)), mode 0 "+", 1 "-", 2 "*", 3 "/"; p1 NULL = a per-cell
+ * constant (the scaling / normalisation steps); float64 arithmetic, rounded once to float32. */
+int xh_poly_trend(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int degree, double* p0,
+                  double* p1, int32_t* nvalid);
+int xh_trend_apply(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* p0,
+                   const double* p1, int mode, float* out, int64_t out_st);
+
 #ifdef __cplusplus
 }
 #endif

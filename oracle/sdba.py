@@ -162,3 +162,58 @@ def qdm_adjust_grouped(sim, time, prop, labels, af, quantiles, kind="+", interp=
         if rows.size:
             out[rows] = qdm_adjust(sim[rows], af[g], quantiles, kind, interp, extrapolation)
     return out
+
+
+# ---- DetrendedQuantileMapping (xsdba._adjustment.dqm_train / dqm_adjust, PolyDetrend) — specified restatement, unpinned ------
+def _nanmean0(x):
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return np.nanmean(np.asarray(x, dtype=np.float64), axis=0)
+
+
+def _corr(x, f, kind, inverse=False):
+    """apply_correction(x, f | invert(f)): float64 arithmetic, float32 result (the device's stage boundaries)."""
+    x64 = np.asarray(x, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        if kind == "+":
+            out = x64 - f if inverse else x64 + f
+        else:
+            out = x64 / f if inverse else x64 * f
+    return out.astype(np.float32)
+
+
+def dqm_train(ref, hist, nquantiles=20, kind="+"):
+    """(af, hist_q, scaling): quantiles of the mean-normalised series, scaling = mean(ref) (-|/) mean(hist)."""
+    mu_r, mu_h = _nanmean0(ref), _nanmean0(hist)
+    af, hist_q = eqm_train(_corr(ref, mu_r, kind, True), _corr(hist, mu_h, kind, True), nquantiles, kind)
+    with np.errstate(all="ignore"):
+        scaling = mu_r - mu_h if kind == "+" else mu_r / mu_h
+    return af, hist_q, scaling
+
+
+def poly_trend(x, degree):
+    """Per-cell least-squares polynomial (degree 0 / 1) over the valid steps, evaluated at every step: (T, C) float64."""
+    x = np.asarray(x, dtype=np.float64)
+    T = x.shape[0]
+    x2 = x.reshape(T, -1)
+    t = np.arange(T, dtype=np.float64) - 0.5 * (T - 1)
+    out = np.full(x2.shape, np.nan)
+    for c in range(x2.shape[1]):
+        ok = ~np.isnan(x2[:, c])
+        if not ok.any():
+            continue
+        if degree == 0 or ok.sum() < 2:
+            out[:, c] = x2[ok, c].mean()
+        else:
+            out[:, c] = np.polyval(np.polyfit(t[ok], x2[ok, c], 1), t)
+    return out.reshape(x.shape)
+
+
+def dqm_adjust(sim, af, hist_q, scaling, kind="+", interp="nearest", extrapolation="constant", detrend=1):
+    scaled = _corr(sim, scaling, kind)
+    trend = poly_trend(scaled, detrend)
+    detr = _corr(scaled, trend, kind, True)
+    scen0 = eqm_adjust(detr, af, hist_q, kind, interp, extrapolation)
+    return _corr(scen0, trend, kind)

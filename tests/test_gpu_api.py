@@ -1292,3 +1292,53 @@ def test_qdm_grouped_matches_oracle(dev, rng, group, window):
         got = qdm.adjust(sim, interp=interp, time=ta)
         exp = osdba.qdm_adjust_grouped(sim, ot, prop, qdm.group_labels, qdm.af, qdm.quantiles, "+", interp, "constant")
         np.testing.assert_allclose(got, exp, rtol=1e-6, equal_nan=True, err_msg=f"{group} {interp}")
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("detrend", [0, 1])
+def test_dqm_matches_oracle(dev, rng, kind, detrend):
+    """DetrendedQuantileMapping: train (mean-normalised quantiles + scaling) and adjust (scale, detrend, EQM lookup, retrend)
+    against the oracle restatement; NaN steps, an all-NaN cell.  Parity unpinned (xsdba absent)."""
+    from xclim_amd import sdba as xsdba
+
+    T, cells = 1460, (6, 7)
+    t = np.arange(T, dtype=np.float32)[:, None, None]
+    ref = (rng.normal(10, 3, (T,) + cells) + 0.001 * t).astype(np.float32)
+    hist = (rng.normal(12, 4, (T,) + cells) + 0.001 * t).astype(np.float32)
+    sim = (rng.normal(14, 4, (T,) + cells) + 0.004 * t).astype(np.float32)   # a stronger trend in the future run
+    if kind == "*":
+        ref, hist, sim = np.abs(ref) + 1, np.abs(hist) + 1, np.abs(sim) + 1
+    sim[rng.random(sim.shape) < 0.02] = np.nan
+    ref[rng.random(ref.shape) < 0.01] = np.nan
+    sim[:, 0, 1] = np.nan
+    dqm = xsdba.DetrendedQuantileMapping.train(ref, hist, nquantiles=20, kind=kind, device=dev)
+    eaf, ehq, esc = osdba.dqm_train(ref, hist, 20, kind)
+    np.testing.assert_allclose(dqm.scaling, esc.reshape(cells), rtol=1e-12)
+    np.testing.assert_allclose(dqm.hist_q, ehq, rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(dqm.af, eaf, rtol=2e-5, atol=2e-6, equal_nan=True)   # differences of nearly equal quantiles
+    for interp in ("nearest", "linear"):
+        got = dqm.adjust(sim, interp=interp, detrend=detrend)
+        # the oracle adjusts with the DEVICE's factors: the node lookup is discontinuous in them for "nearest"
+        exp = osdba.dqm_adjust(sim, dqm.af, dqm.hist_q, dqm.scaling, kind, interp, "constant", detrend)
+        np.testing.assert_allclose(got, exp, rtol=2e-6, atol=1e-6, equal_nan=True, err_msg=f"{interp}")
+    assert np.isnan(got[:, 0, 1]).all()
+    with pytest.raises(NotImplementedError):
+        dqm.adjust(sim, detrend=2)
+
+
+def test_dqm_removes_the_bias_and_keeps_the_trend(dev, rng):
+    """What DQM is for: the adjusted series has the distribution of ref around the (scaled) trend of sim — the linear trend
+    of sim survives the adjustment, the mean bias of the model does not."""
+    from xclim_amd import sdba as xsdba
+
+    T = 7300
+    t = np.arange(T, dtype=np.float64)[:, None]
+    ref = rng.normal(10, 2, (T, 3))
+    hist = rng.normal(13, 3, (T, 3))                      # model: +3 bias, too variable
+    sim = rng.normal(13, 3, (T, 3)) + 0.0005 * t         # the same model with a trend of +3.65 over the run
+    dqm = xsdba.DetrendedQuantileMapping.train(ref.astype(np.float32), hist.astype(np.float32), nquantiles=50, kind="+", device=dev)
+    scen = dqm.adjust(sim.astype(np.float32), interp="linear", detrend=1)
+    slope = np.polyfit(t[:, 0], scen, 1)[0]
+    np.testing.assert_allclose(slope, 0.0005, rtol=0.1)
+    np.testing.assert_allclose(scen.mean(axis=0), 10.0 + 0.0005 * (T - 1) / 2, atol=0.15)
+    np.testing.assert_allclose((scen - np.polyval(np.polyfit(t[:, 0], scen, 1), t)).std(axis=0), 2.0, rtol=0.05)

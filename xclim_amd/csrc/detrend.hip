@@ -1,0 +1,137 @@
+// detrend.hip — the two elementwise / reduction pieces DetrendedQuantileMapping adds around the EQM kernels
+// (xsdba._adjustment.dqm_train / dqm_adjust, xsdba.detrending.PolyDetrend).  xsdba is not in the
+// reference tree (src/xclim/sdba.py:10 re-exports it): PARITY UNPINNED, restated in oracle/sdba.py.
+//
+//   xh_poly_trend   per-cell least-squares polynomial of degree 0 or 1 over the valid samples of a series
+//                   (DataArray.polyfit(dim="time", deg) with NaNs skipped): p0 + p1 (t - tc), tc = (T - 1) / 2
+//   xh_trend_apply  out = x OP (p0[c] + p1[c] (t - tc)), OP in {+, -, *, /}: apply_correction with a per-cell constant
+//                   (p1 NULL: the scaling / normalisation of dqm_train) or with the trend (detrend / retrend)
+// Both stream the time-major (T, C) field once: a lane owns VEC cells and marches along time.
+#include "common.h"
+
+namespace {
+
+// sums in fp64 over the valid samples with the CENTRED step index u = t - tc (|u| <= T / 2: u and u^2 are exact):
+// n, Su, Suu, Sx, Sux;  slope = (n Sux - Su Sx) / (n Suu - Su^2), intercept at u = 0: (Sx - slope Su) / n
+template <int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_poly_trend(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int degree, double tc, double* __restrict__ p0,
+             double* __restrict__ p1, int32_t* __restrict__ nvalid) {
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  double n[VEC], su[VEC], suu[VEC], sx[VEC], sux[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) n[i] = su[i] = suu[i] = sx[i] = sux[i] = 0.0;
+  xh_march_rows<VEC, 8>(x + c, st, 0, T, [&](int64_t t, const VecF<VEC>& xv) {
+    const double u = (double)t - tc;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float f = xv.v[i];
+      const bool ok = f == f;
+      const double v = ok ? (double)f : 0.0, w = ok ? 1.0 : 0.0;
+      n[i] += w;
+      su[i] += w * u;
+      suu[i] += w * u * u;
+      sx[i] += v;
+      sux[i] += u * v;
+    }
+  });
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    double a = xh_nan64(), b = 0.0;
+    if (n[i] > 0.0) {
+      if (degree == 0) a = sx[i] / n[i];
+      else {
+        const double den = n[i] * suu[i] - su[i] * su[i];
+        if (den > 0.0) {
+          b = (n[i] * sux[i] - su[i] * sx[i]) / den;
+          a = (sx[i] - b * su[i]) / n[i];
+        } else a = sx[i] / n[i];  // one valid step (or all at the same step): the fit degenerates to the mean, slope 0
+      }
+    }
+    p0[c + i] = a;
+    if (p1) p1[c + i] = (n[i] > 0.0) ? b : xh_nan64();
+    if (nvalid) nvalid[c + i] = (int32_t)n[i];
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_trend_apply(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const double* __restrict__ p0,
+              const double* __restrict__ p1, double tc, int mode, float* __restrict__ out, int64_t out_st) {
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
+  const int64_t ta = (int64_t)blockIdx.y * chunk;
+  int64_t tb = ta + chunk;
+  if (tb > T) tb = T;
+  if (ta >= tb) return;
+  double a[VEC], b[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { a[i] = p0[c + i]; b[i] = p1 ? p1[c + i] : 0.0; }
+  xh_march_rows<VEC, 8>(x + c, st, ta, tb, [&](int64_t t, const VecF<VEC>& xv) {
+    const double u = (double)t - tc;
+    float r[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const double tr = a[i] + b[i] * u, v = (double)xv.v[i];
+      const double o = mode == 0 ? v + tr : (mode == 1 ? v - tr : (mode == 2 ? v * tr : v / tr));
+      r[i] = (float)o;
+    }
+    float* dst = out + t * out_st + c;
+    if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+    else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) dst[i] = r[i];
+    }
+  });
+}
+
+}  // namespace
+
+extern "C" {
+
+int xh_poly_trend(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int degree, double* p0,
+                  double* p1, int32_t* nvalid) {
+  XH_REQUIRE(ctx && x && p0, XH_ERR_ARG, "xh_poly_trend: NULL argument");
+  XH_REQUIRE(T >= 1 && C >= 0, XH_ERR_ARG, "xh_poly_trend: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_poly_trend: needs a time-major view (sc == 1)");
+  XH_REQUIRE(degree == 0 || degree == 1, XH_ERR_NOTIMPL, "xh_poly_trend: degree must be 0 or 1");
+  XH_REQUIRE(degree == 0 || p1, XH_ERR_ARG, "xh_poly_trend: p1 is NULL");
+  if (C == 0) return XH_OK;
+  const double tc = 0.5 * (double)(T - 1);
+  const bool v4 = xh_pick_vec(x, C, st) == 4 && cdiv64(cdiv64(C, 4), XH_BLOCK) >= 2 * (int64_t)ctx->num_cu;
+  if (v4)
+    hipLaunchKernelGGL((k_poly_trend<4>), dim3((unsigned)cdiv64(cdiv64(C, 4), XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st,
+                       degree, tc, p0, p1, nvalid);
+  else
+    hipLaunchKernelGGL((k_poly_trend<1>), dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, degree,
+                       tc, p0, p1, nvalid);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_trend_apply(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* p0,
+                   const double* p1, int mode, float* out, int64_t out_st) {
+  XH_REQUIRE(ctx && x && p0 && out, XH_ERR_ARG, "xh_trend_apply: NULL argument");
+  XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "xh_trend_apply: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C && out_st >= C, XH_ERR_LAYOUT, "xh_trend_apply: needs time-major views (sc == 1)");
+  XH_REQUIRE(mode >= 0 && mode <= 3, XH_ERR_ARG, "xh_trend_apply: mode must be 0 (+), 1 (-), 2 (*) or 3 (/)");
+  if (T == 0 || C == 0) return XH_OK;
+  const double tc = 0.5 * (double)(T - 1);
+  const int vec = (xh_pick_vec(x, C, st) == 4 && xh_pick_vec(out, C, out_st) == 4) ? 4 : 1;
+  const int64_t cblocks = cdiv64(cdiv64(C, vec), XH_BLOCK);
+  int64_t gy = cdiv64((int64_t)ctx->num_cu * 12, cblocks);
+  if (gy < 1) gy = 1;
+  if (gy > cdiv64(T, 32)) gy = cdiv64(T, 32);
+  if (gy < 1) gy = 1;
+  const dim3 grid((unsigned)cblocks, (unsigned)gy);
+  if (vec == 4)
+    hipLaunchKernelGGL((k_trend_apply<4>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, p0, p1, tc, mode, out, out_st);
+  else
+    hipLaunchKernelGGL((k_trend_apply<1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, p0, p1, tc, mode, out, out_st);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+}  // extern "C"

@@ -12,7 +12,7 @@ the same sample sets as ``percentile_doy``).  Training gathers each group's rows
 per-column multi-quantile kernels on them; ``af`` / ``hist_q`` get a leading group axis ``(group, quantiles, *cells)``.
 ``adjust`` maps every time step with the factors of ITS group (rows are permuted group-major once, one ``xh_eqm_adjust``
 launch per group on a contiguous row block, one gather back).  Interpolating the factors BETWEEN groups along time (what
-xsdba does for ``interp != "nearest"`` with monthly groups) and ``DetrendedQuantileMapping`` are not built.
+xsdba does for ``interp != "nearest"`` with monthly groups) is not built.
 
 :class:`QuantileDeltaMapping` (``group="time"``): trained like EQM; ``adjust`` looks the factor up at the QUANTILE of every
 sim value within the sim series itself (``rank(sim, pct=True)``), so that the simulated change of every quantile is
@@ -241,3 +241,62 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
         scen = K.select_rows(dev, scen_perm, inv)
         dev.sync()
         return scen if keep else scen.get().reshape((T,) + self.cell_shape)
+
+
+class DetrendedQuantileMapping(EmpiricalQuantileMapping):
+    """Detrended quantile mapping (xsdba.DetrendedQuantileMapping, ``group="time"``; Cannon et al. 2015).
+
+    train (``dqm_train``): ref and hist are normalised by their time means (``x - mean`` for "+", ``x / mean`` for "*"),
+    ``af`` / ``hist_q`` come from the quantiles of the NORMALISED series, ``scaling = mean(ref) - mean(hist)`` (resp. the
+    ratio).  adjust (``dqm_adjust``): ``sim`` is shifted by ``scaling``, its polynomial trend of degree ``detrend`` (0 or 1,
+    ``PolyDetrend``: least squares over the valid steps) is removed, the detrended series goes through the EQM node
+    lookup, the trend is put back.  Every stage is float32 on the device with float64 arithmetic inside the kernels
+    (means, fit, trend evaluation).  PARITY UNPINNED (oracle/sdba.py: dqm_*)."""
+
+    def __init__(self, *args, scaling=None, **kw):
+        super().__init__(*args, **kw)
+        self._scaling = scaling  # (C,) float64 device array
+
+    @classmethod
+    def train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", window=None, time=None, device=None):
+        grp = group if isinstance(group, Grouper) else Grouper(group, 1 if window is None else window)
+        if grp.prop != "group":
+            raise NotImplementedError("DetrendedQuantileMapping: only group='time' is built")
+        if kind not in (ADDITIVE, MULTIPLICATIVE):
+            raise ValueError(f"kind must be '+' or '*', got {kind!r}")
+        dev = device or get_device()
+        r, cell_shape = _flatten(ref, dev)
+        h, cell_shape_h = _flatten(hist, dev)
+        if tuple(cell_shape) != tuple(cell_shape_h) or r.shape != h.shape:
+            raise ValueError("ref and hist must have the same shape")
+        q = equally_spaced_nodes(nquantiles) if np.isscalar(nquantiles) else np.asarray(nquantiles, dtype=np.float64)
+        inv = "-" if kind == ADDITIVE else "/"
+        mu_r, _ = K.poly_trend(dev, r, 0)
+        mu_h, _ = K.poly_trend(dev, h, 0)
+        af, hq = K.eqm_train(dev, K.trend_apply(dev, r, mu_r, None, inv), K.trend_apply(dev, h, mu_h, None, inv), q, kind)
+        # scaling = get_correction(mu_hist, mu_ref): a (C,) table — O(C) host arithmetic on the two mean vectors
+        mr, mh = mu_r.get(), mu_h.get()
+        with np.errstate(all="ignore"):
+            scaling = mr - mh if kind == ADDITIVE else mr / mh
+        return cls(dev, af, hq, q, kind, cell_shape, grp, scaling=dev.to_device(np.ascontiguousarray(scaling), dtype=np.float64))
+
+    @property
+    def scaling(self) -> np.ndarray:
+        return self._scaling.get().reshape(self.cell_shape)
+
+    def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", detrend: int = 1, time=None, keep=False):
+        if interp not in ("nearest", "linear", "cubic"):
+            raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
+        if detrend not in (0, 1):
+            raise NotImplementedError("DetrendedQuantileMapping.adjust: detrend must be 0 or 1 (polynomial degree)")
+        dev = self._dev
+        s, cell_shape = _flatten(sim, dev)
+        if tuple(cell_shape) != self.cell_shape:
+            raise ValueError("sim does not match the trained grid")
+        fwd, inv = ("+", "-") if self.kind == ADDITIVE else ("*", "/")
+        scaled = K.trend_apply(dev, s, self._scaling, None, fwd)
+        p0, p1 = K.poly_trend(dev, scaled, detrend)
+        detr = K.trend_apply(dev, scaled, p0, p1, inv, out=scaled)  # in place: `scaled` is not needed again
+        scen0 = K.eqm_adjust(dev, detr, self._af, self._hist_q, self.kind, interp, extrapolation)
+        scen = K.trend_apply(dev, scen0, p0, p1, fwd, out=scen0)
+        return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
