@@ -78,6 +78,11 @@ run("precip_over_doy (count+frac)", lambda: K.precip_over_doy(dev, tas, ">", 280
                                                               want=("count", "frac")), 4 * E + 8 * len(doys) * C)
 run("doy_broadcast", lambda: K.doy_broadcast(dev, p.reshape(len(doys), C), tidx), 16 * E)
 run("transpose", lambda: K.transpose(dev, tas), 8 * E)
+# the form the time-major pipelines use: output pitch padded to 64 floats (256-byte aligned column segments, 16-byte stores)
+from xclim_amd._capi import _vp  # noqa: E402
+tpad = dev.empty((C, 384), np.float32)
+run("transpose (pitch 384)", lambda: dev.call("xh_transpose_f32", _vp(tas.ptr), T, C, C, _vp(tpad.ptr), 384), 8 * E)
+del tpad
 # quantile delta mapping: exact per-column ranks + factor lookup (transposed scratch both ways inside)
 qn = (np.arange(20) + 0.5) / 20
 af_q, _ = K.eqm_train(dev, tas, tas2, qn, "+")
