@@ -296,7 +296,8 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         fwd, inv = ("+", "-") if self.kind == ADDITIVE else ("*", "/")
         scaled = K.trend_apply(dev, s, self._scaling, None, fwd)
         p0, p1 = K.poly_trend(dev, scaled, detrend)
-        detr = K.trend_apply(dev, scaled, p0, p1, inv, out=scaled)  # in place: `scaled` is not needed again
+        detr = K.trend_apply(dev, scaled, p0, p1, inv)
+        del scaled
         scen0 = K.eqm_adjust(dev, detr, self._af, self._hist_q, self.kind, interp, extrapolation)
-        scen = K.trend_apply(dev, scen0, p0, p1, fwd, out=scen0)
+        scen = K.trend_apply(dev, scen0, p0, p1, fwd, out=detr)  # (distinct buffers: the kernels' pointers are __restrict__)
         return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
