@@ -60,29 +60,53 @@ k_doy_stats_sets(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, 
   }
   pdoy_gather<NYP>(raw, rows_of(d0 + half), x, st, cc);
   int rows_next = rows_of(d0 + half + 1);
-  for (int d = d0; d < d1; ++d) {
+  // The ring does not shift: the day loop is unrolled by W and the partial of the day-set that enters at step u of a group
+  // lands in the static slot (u + W - 1) % W — the slot of the day-set that leaves (20 64-bit moves per doy before).
+  // Running window sums: RS += entering partial - leaving partial (fp64 drift over a chunk of doys ~1e-15 relative; the
+  // contract is 1e-6).  1 / N is a wave-uniform constant when every lane's window is complete (the usual case), the
+  // standard deviation comes from the hardware fp32 square root: the divide / divide / fp64 sqrt per doy was most of
+  // the VALU work of this (VALU-bound) kernel on short base periods.
 #pragma unroll
-    for (int w = 0; w < W - 1; ++w) { s1[w] = s1[w + 1]; s2[w] = s2[w + 1]; n[w] = n[w + 1]; }
-    reduce_into(s1[W - 1], s2[W - 1], n[W - 1]);
-    if (d + 1 < d1) {
-      pdoy_gather<NYP>(raw, rows_next, x, st, cc);
-      rows_next = rows_of(d + 2 + half);
-    }
-    if (regular[d] && active) {
-      double S1 = 0.0, S2 = 0.0;
-      int N = 0;
+  for (int w = 0; w < W - 1; ++w) { s1[w] = s1[w + 1]; s2[w] = s2[w + 1]; n[w] = n[w + 1]; }  // prologue slots 1..W-1 -> 0..W-2
+  s1[W - 1] = 0.0; s2[W - 1] = 0.0; n[W - 1] = 0;
+  double RS1 = 0.0, RS2 = 0.0;
+  int RN = 0;
 #pragma unroll
-      for (int w = 0; w < W; ++w) { S1 += s1[w]; S2 += s2[w]; N += n[w]; }
-      float m = xh_nan32(), sd = xh_nan32();
-      if (N > 0) {
-        const double mean_s = S1 / (double)N;
-        double var = (S2 - S1 * mean_s) / (double)N;
-        var = var > 0.0 ? var : 0.0;
-        m = (float)((double)K + mean_s);
-        sd = (float)sqrt(var);
+  for (int w = 0; w < W - 1; ++w) { RS1 += s1[w]; RS2 += s2[w]; RN += n[w]; }
+  const int nfull = W * nyears;
+  const double inv_full = 1.0 / (double)nfull;
+  for (int db = d0; db < d1; db += W) {
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+      const int d = db + u;
+      if (d < d1) {
+        const int SLOT = (u + W - 1) % W;  // (compile-time after unrolling)
+        double b1, b2;
+        int bn;
+        reduce_into(b1, b2, bn);
+        RS1 += b1 - s1[SLOT]; RS2 += b2 - s2[SLOT]; RN += bn - n[SLOT];
+        s1[SLOT] = b1; s2[SLOT] = b2; n[SLOT] = bn;
+        if (d + 1 < d1) {
+          pdoy_gather<NYP>(raw, rows_next, x, st, cc);
+          rows_next = rows_of(d + 2 + half);
+        }
+        if (regular[d]) {
+          const bool allfull = __all(RN == nfull ? 1 : 0) != 0;
+          float m = xh_nan32(), sd = xh_nan32();
+          if (allfull || RN > 0) {
+            const double invN = allfull ? inv_full : 1.0 / (double)(RN > 0 ? RN : 1);
+            const double mean_s = RS1 * invN;
+            double var = (RS2 - RS1 * mean_s) * invN;
+            var = var > 0.0 ? var : 0.0;
+            m = (float)((double)K + mean_s);
+            sd = __builtin_amdgcn_sqrtf((float)var);
+          }
+          if (active) {
+            mean_out[(int64_t)d * C + c] = m;
+            std_out[(int64_t)d * C + c] = sd;
+          }
+        }
       }
-      mean_out[(int64_t)d * C + c] = m;
-      std_out[(int64_t)d * C + c] = sd;
     }
   }
 }
@@ -102,7 +126,8 @@ int xh_launch_doy_stats_sets(xh_ctx* ctx, const float* x, int64_t T, int64_t C, 
   do {                                                                               \
     if (window == 3) XH_DS(3, NY); else if (window == 5) XH_DS(5, NY); else XH_DS(7, NY); \
   } while (0)
-  if (nyears <= 2) XH_DSW(2);
+  if (nyears == 1) XH_DSW(1);  // (one sample per day-set: no padded second slot to gather and mask)
+  else if (nyears <= 2) XH_DSW(2);
   else if (nyears <= 8) XH_DSW(8);
   else if (nyears <= 32) XH_DSW(32);
   else XH_DSW(64);
