@@ -111,11 +111,107 @@ k_doy_stats_sets(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, 
   }
 }
 
+// ONE contiguous year (row of doy index i = t0 + i): the day-sets are single rows, the climatology is a centred,
+// NaN-skipping rolling mean / std over consecutive rows.  Four cells per lane, rows in double-buffered batches of 8
+// (xh_march_rows), the window in a register ring with static slots; mean and population std (two passes over the W
+// values in fp64 — exact, no pivot) per doy.  The per-day-set kernel above moves 256 bytes per wave and row.
+template <int W, int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_doy_stats_year(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int64_t t0, int ndoy, int chunk,
+                 const uint8_t* __restrict__ regular, float* __restrict__ mean_out, float* __restrict__ std_out) {
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  constexpr int half = W / 2;
+  const int d0 = blockIdx.y * chunk;
+  int d1 = d0 + chunk;
+  if (d1 > ndoy) d1 = ndoy;
+  if (d0 >= d1) return;
+  float ring[VEC][W];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i)
+#pragma unroll
+    for (int k = 0; k < W; ++k) ring[i][k] = xh_nan32();
+  // rows t0 + d0 - half .. t0 + d1 - 1 + half; rows outside the series are absent days (NaN)
+  const int64_t ta = t0 + d0 - half, tb = t0 + d1 - 1 + half + 1;
+  const int64_t ra = ta < 0 ? 0 : ta, rb = tb > T ? T : tb;
+  auto emit = [&](int64_t tnew) {  // tnew: the row that just entered = the newest of the window of doy d
+    const int64_t d = tnew - half - t0;
+    if (d < d0 || d >= d1 || !regular[d]) return;
+    float m[VEC], sd[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      double sum = 0.0;
+      int n = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const float v = ring[i][k];
+        const bool ok = v == v;
+        sum += ok ? (double)v : 0.0;
+        n += ok ? 1 : 0;
+      }
+      const double inv = 1.0 / (double)(n > 0 ? n : 1);
+      const double mean = sum * inv;
+      double s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const float v = ring[i][k];
+        const double dv = (v == v) ? (double)v - mean : 0.0;
+        s2 += dv * dv;
+      }
+      m[i] = n > 0 ? (float)mean : xh_nan32();
+      sd[i] = n > 0 ? __builtin_amdgcn_sqrtf((float)(s2 * inv)) : xh_nan32();
+    }
+    float* mo = mean_out + d * C + c;
+    float* so = std_out + d * C + c;
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(mo) = make_float4(m[0], m[1 % VEC], m[2 % VEC], m[3 % VEC]);
+      *reinterpret_cast<float4*>(so) = make_float4(sd[0], sd[1 % VEC], sd[2 % VEC], sd[3 % VEC]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { mo[i] = m[i]; so[i] = sd[i]; }
+    }
+  };
+  auto push = [&](const VecF<VEC>& xv) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+#pragma unroll
+      for (int k = 0; k < W - 1; ++k) ring[i][k] = ring[i][k + 1];
+      ring[i][W - 1] = xv.v[i];
+    }
+  };
+  VecF<VEC> nanv;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) nanv.v[i] = xh_nan32();
+  for (int64_t t = ta; t < ra; ++t) { push(nanv); emit(t); }  // absent rows before the series
+  xh_march_rows<VEC, 8>(x + c, st, ra, rb, [&](int64_t t, const VecF<VEC>& xv) {
+    push(xv);
+    emit(t);
+  });
+  for (int64_t t = (rb > ra ? rb : ra); t < tb; ++t) { push(nanv); emit(t); }  // absent rows after it
+}
+
 }  // namespace
 
 int xh_launch_doy_stats_sets(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
-                             int ndoy, int window, const uint8_t* d_reg, float* mean_out, float* std_out) {
+                             int ndoy, int window, const uint8_t* d_reg, float* mean_out, float* std_out, int64_t year_t0) {
   if (!(window == 3 || window == 5 || window == 7) || nyears > 64) return XH_ERR_NOTIMPL;
+  if (nyears == 1 && year_t0 >= 0) {  // one contiguous year: rolling form
+    const int vec = (xh_pick_vec(x, C, st) == 4 && xh_pick_vec(mean_out, C, C) == 4 && xh_pick_vec(std_out, C, C) == 4) ? 4 : 1;
+    const int64_t cblocks = cdiv64(cdiv64(C, vec), XH_BLOCK);
+    int64_t gy = cdiv64((int64_t)ctx->num_cu * 12, cblocks);
+    if (gy < 1) gy = 1;
+    if (gy > cdiv64(ndoy, 32)) gy = cdiv64(ndoy, 32);
+    if (gy < 1) gy = 1;
+    const int ychunk = (int)cdiv64(ndoy, gy);
+    const dim3 ygrid((unsigned)cblocks, (unsigned)cdiv64(ndoy, ychunk));
+#define XH_DY(W, V) \
+  hipLaunchKernelGGL((k_doy_stats_year<W, V>), ygrid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, year_t0, ndoy, ychunk, d_reg, mean_out, std_out)
+    if (vec == 4) { if (window == 3) XH_DY(3, 4); else if (window == 5) XH_DY(5, 4); else XH_DY(7, 4); }
+    else { if (window == 3) XH_DY(3, 1); else if (window == 5) XH_DY(5, 1); else XH_DY(7, 1); }
+#undef XH_DY
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+  }
   int chunk = 24;
   if (const char* e = xh_diag_env("XH_DOYSTATS_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : chunk;  // diagnostics
   const dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));

@@ -79,7 +79,7 @@ static inline int pdoy_regular_flags(const int32_t* tbase, int nyears, int ndoy,
 
 // doystats.hip: climatological mean / std per doy from per-day-set partial sums (regular doys of the chunk grid)
 int xh_launch_doy_stats_sets(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
-                             int ndoy, int window, const uint8_t* d_reg, float* mean_out, float* std_out);
+                             int ndoy, int window, const uint8_t* d_reg, float* mean_out, float* std_out, int64_t year_t0);
 
 // pdoy_top.hip: register top-16 kernel for the percentiles in jmap[0..nsub) (rev = 0: all of them select within the 16
 // largest samples; rev = 1: within the 16 smallest) on the REGULAR doys (d_reg[d] != 0) of the chunk grid; irregular doys

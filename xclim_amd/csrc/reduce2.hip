@@ -290,8 +290,15 @@ int xh_doy_mean_std(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t s
     if (!rc && ndl) rc = xh_scratch_upload(ctx, &cur, irregular, sizeof(int32_t) * (size_t)ndl, &d_irr);
     free(regular); free(irregular);
     if (rc) return rc;
+    // one contiguous year (row of doy index i = tbase[0] + i): the rolling form of doystats.hip
+    int64_t year_t0 = -1;
+    if (nyears == 1 && tbase[0] >= 0) {
+      year_t0 = tbase[0];
+      for (int i = 1; i < ndoy; ++i)
+        if ((int64_t)tbase[i] != year_t0 + i) { year_t0 = -1; break; }
+    }
     rc = xh_launch_doy_stats_sets(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const uint8_t*)d_reg,
-                                  mean_out, std_out);
+                                  mean_out, std_out, year_t0);
     if (rc && rc != XH_ERR_NOTIMPL) return rc;
     if (rc == XH_OK) {
       generic_all = false;
