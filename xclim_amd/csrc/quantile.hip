@@ -920,7 +920,8 @@ static int pdoy_count_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, in
   if (rc) return rc;
   XH_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int32_t) * (size_t)P * (size_t)C, ctx->stream));
   if (valid_out) XH_CHECK_HIP(hipMemsetAsync(valid_out, 0, sizeof(int32_t) * (size_t)P * (size_t)C, ctx->stream));
-  const int chunk = 32;
+  int chunk = 61;  // doys per workgroup (W - 1 halo rows each): 16 / 32 / 46 / 61 / 92 / 183 -> 0.61 / 0.57 / 0.56 / 0.54 / 0.55 / 0.56 ms
+  if (const char* e = xh_diag_env("XH_PDOY_SLIDE_COUNT_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : chunk;  // diagnostics
   const int vec = xh_pick_vec(x, C, st);
   dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), (unsigned)((ndoy + chunk - 1) / chunk));
 #define XH_SLIDEC(W, V)                                                                                                   \
