@@ -761,7 +761,8 @@ static int pdoy_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
     void* d_tab = nullptr;
     int rc = xh_scratch_upload(ctx, &cur, tab, sizeof(QTab) * (size_t)nper * (window + 1), &d_tab);
     if (rc) return rc;
-    const int chunk = 32;
+    int chunk = 32;
+    if (const char* e = xh_diag_env("XH_PDOY_SLIDE_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : chunk;  // diagnostics
     int vec = xh_pick_vec(x, C, st);
     if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) vec = 1;
     dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), (unsigned)((ndoy + chunk - 1) / chunk));
