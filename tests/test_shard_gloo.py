@@ -111,3 +111,31 @@ def test_unique_id_file_rendezvous_three_ranks(tmp_path):
         from xclim_amd.shard import exchange_unique_id
 
         exchange_unique_id(str(tmp_path / "never.id"), 1, None, 128, timeout_s=0.2)
+
+
+_FC_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+from xclim_amd.shard import FileComm
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+fc = FileComm(None, world, rank, sys.argv[2])
+vals = []
+for step in range(3):
+    vals.append(float(fc.allreduce([10.0 * step + rank], "max")[0]))
+    vals.append(float(fc.allreduce([1.0 + rank], "sum")[0]))
+sys.stdout.write(repr(vals))
+"""
+
+
+def test_file_comm_scalar_reductions(tmp_path):
+    """FileComm (bench.py's stand-in when RCCL cannot be initialised): max / sum over three ranks through files."""
+    script = tmp_path / "fc.py"
+    script.write_text(_FC_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3")
+    procs = [subprocess.Popen([sys.executable, str(script), root, str(tmp_path / "fc")], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE) for r in range(3)]
+    outs = [p.communicate(timeout=60)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    expect = repr([2.0, 6.0, 12.0, 6.0, 22.0, 6.0])
+    assert outs == [expect, expect, expect]

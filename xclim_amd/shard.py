@@ -95,6 +95,64 @@ def exchange_unique_id(path: str, rank: int, make_id, nbytes: int, timeout_s: fl
         time.sleep(0.02)
 
 
+class FileComm:
+    """Last-resort stand-in for :class:`Comm` when RCCL cannot be brought up on a node (no librccl, IPC refused ...):
+    barriers and scalar reductions through files in the rendezvous directory, NO data exchange — ``all_gather`` only
+    copies the rank's own block into its place.  ``bench.py`` uses it so that a multi-GPU launch still reports the
+    sharded throughput (flagged ``"exchange": "none (RCCL unavailable: ...)"``) instead of dying; library users get the
+    original exception from :meth:`Comm.from_env`."""
+
+    kind = "file"
+
+    def __init__(self, dev, world: int, rank: int, base: str, reason: str = ""):
+        self.dev, self.world, self.rank, self.reason = dev, int(world), int(rank), reason
+        self._base, self._n = base, 0
+
+    def _exchange(self, value: float, timeout_s: float = 300.0):
+        tag = f"{self._base}.b{self._n}"
+        self._n += 1
+        mine = f"{tag}.r{self.rank}"
+        with open(mine + ".tmp", "w") as f:
+            f.write(repr(float(value)))
+        os.replace(mine + ".tmp", mine)
+        vals, t0 = [], time.time()
+        for r in range(self.world):
+            while True:
+                try:
+                    with open(f"{tag}.r{r}") as f:
+                        vals.append(float(f.read()))
+                    break
+                except (OSError, ValueError):
+                    if time.time() - t0 > timeout_s:
+                        raise TimeoutError(f"rank {self.rank}: rank {r} did not reach barrier {self._n - 1}")
+                    time.sleep(0.002)
+        return vals
+
+    def all_gather(self, send, recv, slot: int = -1) -> None:
+        isz = send.nbytes
+        self.dev.copy2d(recv.ptr + self.rank * isz, isz, send.ptr, isz, isz, 1, "d2d", blocking=False)
+
+    def fence(self, slot: int) -> None:
+        pass
+
+    def sync(self) -> None:
+        self.dev.sync()
+
+    def barrier(self) -> None:
+        self.dev.sync()
+        self._exchange(0.0)
+
+    def allreduce(self, values, op: str = "max"):
+        v = np.atleast_1d(np.asarray(values, dtype=np.float64)).copy()
+        red = {"sum": np.sum, "max": np.max, "min": np.min}[op]
+        for i in range(len(v)):
+            v[i] = red(self._exchange(v[i]))
+        return v
+
+    def close(self) -> None:
+        pass
+
+
 class Comm:
     """One RCCL communicator over the ranks of a launch (one process per GPU), on a Device's context.
 
