@@ -181,6 +181,9 @@ class Comm:
     @classmethod
     def from_env(cls, dev, timeout_s: float = 300.0) -> "Comm":
         world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        # one node, one process per GPU: RCCL's socket bootstrap runs over the loopback interface unless the caller chose
+        # another one (a box without an outside interface has nothing else; the data path is xGMI / shared memory anyway)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         path = _rendezvous_path()
         uid = exchange_unique_id(path, rank, lambda: cls.new_unique_id(dev), cls.ID_BYTES, timeout_s)
         comm = cls(dev, world, rank, uid)  # collective: returns once every rank has joined (and so has read the file)
