@@ -150,7 +150,19 @@ class FileComm:
         return v
 
     def close(self) -> None:
-        pass
+        """Remove this rank's barrier files (after a last barrier: nobody is still polling for them)."""
+        import glob
+
+        try:
+            self._exchange(0.0, timeout_s=30.0)
+        except TimeoutError:
+            pass
+        for f in glob.glob(f"{self._base}.b*.r{self.rank}"):
+            if not f.endswith(f".b{self._n - 1}.r{self.rank}"):  # the last one may still be read by a slower rank
+                try:
+                    os.unlink(f)
+                except OSError:
+                    pass
 
 
 class Comm:
