@@ -1342,3 +1342,18 @@ def test_dqm_removes_the_bias_and_keeps_the_trend(dev, rng):
     np.testing.assert_allclose(slope, 0.0005, rtol=0.1)
     np.testing.assert_allclose(scen.mean(axis=0), 10.0 + 0.0005 * (T - 1) / 2, atol=0.15)
     np.testing.assert_allclose((scen - np.polyval(np.polyfit(t[:, 0], scen, 1), t)).std(axis=0), 2.0, rtol=0.05)
+
+
+@pytest.mark.parametrize("freq", ["W", "W-THU", "7D", "10D"])
+def test_weekly_and_nday_resampling(dev, rng, freq):
+    """threshold_count / select_resample_op / run statistics with weekly and n-day bins (pandas "W" semantics: closed and
+    labelled on the right) against the oracle, which resamples with pandas itself."""
+    T = 400
+    ta, ot = _axes("2003-12-27", T)
+    x = rng.normal(285, 6, (T, 5, 7)).astype(np.float32)
+    x[rng.random(x.shape) < 0.02] = np.nan
+    np.testing.assert_array_equal(xgen.threshold_count(x, ">", 288.0, ta, freq, device=dev), ogen.threshold_count(x, ">", 288.0, ot, freq))
+    np.testing.assert_allclose(xgen.select_resample_op(x, "mean", ta, freq, device=dev), ogen.select_resample_op(x, "mean", ot, freq),
+                               rtol=1e-6, equal_nan=True)
+    got = xgen.spell_length_statistics(x, 284.0, 1, None, ">", "max", ta, freq, device=dev)
+    np.testing.assert_array_equal(got, ogen.spell_length_statistics(x, 284.0, 1, None, ">", "max", ot, freq))

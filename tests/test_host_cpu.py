@@ -63,10 +63,13 @@ def test_doy_table_leap():
 
 def test_parse_freq_errors():
     assert parse_freq("YS-JUL") == ("Y", 7) and parse_freq("QE-NOV") == ("Q", 12) and parse_freq("YE") == ("Y", 1)
+    assert parse_freq("7D") == ("D", 7) and parse_freq("D") == ("D", 1) and parse_freq("W") == ("W", 6) and parse_freq("W-WED") == ("W", 2)
     with pytest.raises(NotImplementedError):
-        parse_freq("7D")
+        parse_freq("2h")
     with pytest.raises(ValueError):
         parse_freq("YS-FOO")
+    with pytest.raises(ValueError):
+        parse_freq("W-FOO")
 
 
 def test_doy_interp_tables():
@@ -260,3 +263,33 @@ def test_float64_inputs_are_flagged():
         warn_downcast(1.5, "scalar")
         warn_downcast(np.float64(1.5), "scalar")
     assert len(w) == 1 and issubclass(w[0].category, PrecisionWarning)
+
+
+@pytest.mark.parametrize("freq", ["W", "W-SUN", "W-WED", "W-MON", "7D", "10D", "D", "30D"])
+def test_weekly_and_day_frequencies_match_pandas(freq):
+    """resample(time="W" / "W-XXX" / "nD"): the segments of TimeAxis equal pandas' bins (weekly: closed and labelled on
+    the right; n days: from the first day on), missing days inside the span included; expected counts are 7 / n."""
+    import pandas as pd
+
+    from xclim_amd.timeaxis import TimeAxis
+
+    idx = pd.date_range("2003-12-27", periods=400, freq="D")
+    keep = np.ones(len(idx), dtype=bool)
+    keep[40:62] = False                       # a gap: empty bins stay
+    idx = idx[keep]
+    ta = TimeAxis.from_pandas(idx)
+    seg, starts = ta.segments(freq)
+    ref = pd.Series(1.0, index=idx).resample(freq).count()
+    np.testing.assert_array_equal(np.diff(seg), ref.values)
+    n = 7 if freq.startswith("W") else int(freq[:-1] or 1)
+    np.testing.assert_array_equal(ta.expected_count(freq), np.full(len(ref), n))
+    assert sum(s is None for s in starts) == int((ref.values == 0).sum())
+
+
+def test_weekly_frequency_needs_weekdays():
+    from xclim_amd.timeaxis import TimeAxis
+
+    with pytest.raises(NotImplementedError):
+        TimeAxis.daily("2001-01-01", 30, "360_day").segments("W")
+    seg, _ = TimeAxis.daily("2001-01-01", 65, "360_day").segments("30D")
+    np.testing.assert_array_equal(seg, [0, 30, 60, 65])

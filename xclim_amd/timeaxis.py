@@ -33,9 +33,24 @@ def _month_len(year: int, month: int, calendar: str) -> int:
     return n
 
 
+_WEEKDAYS = ["MON", "TUE", "WED", "THU", "FRI", "SAT", "SUN"]
+
+
 def parse_freq(freq: str) -> tuple[str, int]:
-    """Return (base, anchor_month) with base in {"Y", "Q", "M"}.  Only start-anchored offsets are supported."""
+    """Return (base, parameter): base "Y" / "Q" / "M" with the anchor month (start-anchored; the end-anchored spellings
+    give the same segments), "W" with the weekday the week ENDS on (0 = Monday; pandas "W" == "W-SUN": bins closed and
+    labelled on the right), "D" with the number of days per bin ("D", "7D", "10D": bins from the first day on)."""
     f = freq.upper()
+    if f == "W" or f.startswith("W-"):
+        day = f.split("-", 1)[1] if "-" in f else "SUN"
+        if day not in _WEEKDAYS:
+            raise ValueError(f"Unknown anchor weekday in frequency {freq!r}")
+        return "W", _WEEKDAYS.index(day)
+    if f.endswith("D") and (f[:-1].isdigit() or f == "D"):
+        n = int(f[:-1]) if f[:-1] else 1
+        if n < 1:
+            raise ValueError(f"Bad day count in frequency {freq!r}")
+        return "D", n
     for old, new in (("AS", "YS"), ("A-", "Y-")):
         if f.startswith(old):
             f = new + f[len(old):]
@@ -126,7 +141,59 @@ class TimeAxis:
         out.calendar = self.calendar
         return out
 
+    def ordinal(self) -> np.ndarray:
+        """Day number of every time step in its own calendar (consecutive days differ by 1); for the Gregorian calendars
+        it is the proleptic Gregorian ordinal (0001-01-01 = 1, a Monday)."""
+        y, m, d = self.year, self.month, self.day
+        if self.calendar == "360_day":
+            return y * 360 + (m - 1) * 30 + d
+        cum = np.concatenate([[0], np.cumsum(_MLEN_NOLEAP)])[:-1]
+        if self.calendar in ("noleap", "365_day"):
+            return y * 365 + cum[m - 1] + d
+        if self.calendar in ("all_leap", "366_day"):
+            return y * 366 + cum[m - 1] + d + (m > 2)
+        y1 = y - 1
+        return y1 * 365 + y1 // 4 - y1 // 100 + y1 // 400 + self.doy
+
     # ---- resample segments ----
+    def _day_segments(self, base: str, par: int):
+        """Weekly / N-day bins: (seg_off, starts) with ``starts`` = (year, month, day) of each bin's first day."""
+        o = self.ordinal()
+        if np.any(np.diff(o) < 0):
+            raise ValueError("time axis must be sorted")
+        if base == "W":
+            if self.calendar not in ("standard", "gregorian", "proleptic_gregorian"):
+                raise NotImplementedError("weekly resampling needs a Gregorian calendar (weekdays)")
+            first = (par + 1) % 7                      # weekday the bins start on (Monday = 0; ordinal 1 is a Monday)
+            key = (o - 1 - first) // 7
+            nd, start_of = 7, lambda k: k * 7 + 1 + first
+        else:
+            key = (o - o[0]) // par
+            nd, start_of = par, lambda k: int(o[0]) + k * par
+        k0, k1 = int(key[0]), int(key[-1])
+        keys = np.arange(k0, k1 + 1)
+        seg_off = np.searchsorted(key, np.concatenate([keys, [k1 + 1]]), side="left").astype(np.int64)
+        # labels: walk from a known (ordinal, date) pair; bins are short, so the first step inside / after the bin start
+        starts = []
+        for k in keys:
+            s0 = start_of(int(k))
+            i = int(np.searchsorted(o, s0, side="left"))
+            if i < len(o) and int(o[i]) - s0 < nd:
+                back = int(o[i]) - s0            # days between the bin start and its first present step
+                yy, mm, dd = int(self.year[i]), int(self.month[i]), int(self.day[i])
+                while back > 0:                  # step the date back inside the calendar
+                    dd -= 1
+                    if dd < 1:
+                        mm -= 1
+                        if mm < 1:
+                            mm, yy = 12, yy - 1
+                        dd = _month_len(yy, mm, self.calendar)
+                    back -= 1
+                starts.append((yy, mm, dd))
+            else:
+                starts.append(None)              # an empty bin inside the span
+        return seg_off, starts, nd
+
     def _period_key(self, freq: str):
         base, anchor = parse_freq(freq)
         m0 = self.year * 12 + (self.month - 1)
@@ -144,6 +211,12 @@ class TimeAxis:
         Returns ``(seg_off, starts)``: ``seg_off`` int64[P+1] offsets into the (sorted) time axis — empty periods
         inside the span are kept, as pandas does — and ``starts`` a list of ``(year, month)`` period start labels.
         """
+        base0, par0 = parse_freq(freq)
+        if len(self) == 0:
+            return np.zeros(1, dtype=np.int64), []
+        if base0 in ("W", "D"):
+            seg_off, starts, _ = self._day_segments(base0, par0)
+            return seg_off, starts
         key, nmon, off = self._period_key(freq)
         if len(key) == 0:
             return np.zeros(1, dtype=np.int64), []
@@ -172,8 +245,11 @@ class TimeAxis:
             mask = select_time_mask(synth, **indexer)
             edges = np.concatenate(([0], np.cumsum(full)))
             return np.array([int(mask[a:b].sum()) for a, b in zip(edges[:-1], edges[1:])], dtype=np.int32)
+        base, par = parse_freq(freq)
+        if base in ("W", "D"):
+            seg_off, _, nd = self._day_segments(base, par)
+            return np.full(len(seg_off) - 1, nd, dtype=np.int32)
         _, starts = self.segments(freq)
-        base, _ = parse_freq(freq)
         nmon = {"M": 1, "Q": 3, "Y": 12}[base]
         out = np.zeros(len(starts), dtype=np.int32)
         for i, (y, m) in enumerate(starts):
