@@ -179,6 +179,12 @@ def test_windowed_max_run_sum(dev, rng, window):
         np.testing.assert_allclose(got, exp, rtol=1e-6)
         np.testing.assert_allclose(xrl.resample_and_rl(x, False, xrl.windowed_max_run_sum, window, freq=freq, time=ta, device=dev),
                                    exp, rtol=1e-6)
+        # index="last": the run counts for the period of its LAST day, its sum is accumulated forward (bit-exact order)
+        exp = orl.windowed_max_run_sum(x, window, ot, freq, index="last")
+        got = xrl.windowed_max_run_sum(x, window, freq=freq, time=ta, device=dev, index="last")
+        np.testing.assert_array_equal(got, exp)
+    np.testing.assert_array_equal(xrl.windowed_max_run_sum(x, window, device=dev, index="last"),
+                                  orl.windowed_max_run_sum(x, window, index="last"))
     f = np.zeros((50, 1), np.float32)
     f[4:6] = 5
     f[25:30] = 5

@@ -185,12 +185,21 @@ def windowed_max_run_sum(da, window: int, dim="time", freq=None, index="first", 
     resamples AFTER (run sums and lengths cross the period edges, a run counts for the period of its first step);
     ``cut=True`` cuts the runs at the period edges instead — what :func:`resample_and_rl` does with
     ``resample_before_rl=True`` (the default of hot_spell_max_magnitude)."""
-    if index != "first" and freq is not None and not cut:
-        raise NotImplementedError("windowed_max_run_sum: resampling after the run length needs index='first' on the HIP path")
+    if index not in ("first", "last"):
+        raise ValueError(f"index must be 'first' or 'last', got {index!r}")
     dev = device or get_device()
     m, cell_shape = _mask(da, dev)
-    seg = _whole(m.shape[0]) if freq is None else time.segments(freq)[0]
+    T = m.shape[0]
+    seg = _whole(T) if freq is None else time.segments(freq)[0]
+    if index == "last":
+        # the reference flips the series (rle / _cumsum_reset with index="last"): the run sum is accumulated FORWARD and
+        # sits on the run's last step.  The kernel marches backward and credits the first step: run it on the reversed
+        # series with the reversed segments (same fp32 summation order), then put the periods back in order.
+        m = K.select_rows(dev, m, np.arange(T - 1, -1, -1, dtype=np.int64))
+        seg = (T - np.asarray(seg)[::-1]).astype(np.int64)
     out = K.max_run_sum(dev, m, window, seg, cut=(cut or freq is None))
+    if index == "last" and out.shape[0] > 1:
+        out = K.select_rows(dev, out, np.arange(out.shape[0] - 1, -1, -1, dtype=np.int64))
     if keep:
         return out
     o = out.get().reshape((out.shape[0],) + tuple(cell_shape))
