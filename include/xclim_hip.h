@@ -389,6 +389,13 @@ int xh_doy_broadcast(xh_ctx* ctx, const double* table, int D, int64_t C, const i
 int xh_within_bnds_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* low,
                        const double* high, int D, const int32_t* tidx, uint8_t* out);
 
+/* select_time(da, doy_bounds=(start, end)) with PER-CELL bounds (mask_between_doys, core/calendar.py:1166-1257, bounds
+ * without a time dimension): out (T, C) = x where doy[t] lies in the cell's [start[c], end[c]] (wrapping over the new
+ * year when start > end), NaN elsewhere.  doy[T] on the host; start / end (C,) float32 on the device, already shifted
+ * by +-1 for exclusive bounds, NaN = open (1 / 366). */
+int xh_mask_doy_cells(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* doy /* host */,
+                      const float* start, const float* end, float* out, int64_t out_st);
+
 /* compare(da, op, resample_doy(per, da)) as a float32 1/0 mask (fp64 compare against the (D, C) per-doy table): the
  * first step of warm_spell_duration_index / cold_spell_duration_index (indices/_multivariate.py:66-152, 1693-1793);
  * xh_run_stats on the mask gives the index. */

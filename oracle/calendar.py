@@ -146,9 +146,34 @@ def select_time_mask(time: OTime, season=None, month=None, doy_bounds=None, date
     return np.isin(cum[mon - 1] + day, get_doys(cum[ms - 1] + ds, cum[me - 1] + de))
 
 
+def mask_between_doys_cells(time: OTime, start, end, cell_shape, include_bounds=(True, True)):
+    """cal:1199-1257, bounds WITHOUT a time dimension: (T, *cells) mask; start > end: the span crosses the new year;
+    NaN bounds default to 1 / 366."""
+    if isinstance(include_bounds, bool):
+        include_bounds = (include_bounds, include_bounds)
+    s = np.broadcast_to(np.asarray(start, dtype=np.float64), cell_shape).copy()
+    e = np.broadcast_to(np.asarray(end, dtype=np.float64), cell_shape).copy()
+    if not include_bounds[0]:
+        s += 1
+    if not include_bounds[1]:
+        e -= 1
+    s = np.where(np.isnan(s), 1.0, s)
+    e = np.where(np.isnan(e), 366.0, e)
+    doys = np.asarray(time.doy, dtype=np.float64).reshape((-1,) + (1,) * len(cell_shape))
+    return np.where(s <= e, (doys >= s) & (doys <= e), ~((doys > e) & (doys < s)))
+
+
 def select_time(da, time: OTime, drop=False, **indexer):
     """da.where(mask, drop=drop): NaN outside the selection, or only the selected steps (+ their time axis)."""
     da = np.asarray(da)
+    db = indexer.get("doy_bounds")
+    if db is not None and not all(isinstance(b, (int, np.integer)) for b in db):
+        if drop:
+            raise ValueError("Passing array-like doy bounds is incompatible with drop=True.")
+        m = mask_between_doys_cells(time, db[0], db[1], da.shape[1:], indexer.get("include_bounds", (True, True)))
+        out = da.astype(np.result_type(da.dtype, np.float32), copy=True)
+        out[~m] = np.nan
+        return out
     mask = select_time_mask(time, **indexer)
     if drop:
         idx = np.nonzero(mask)[0]

@@ -1357,3 +1357,25 @@ def test_weekly_and_nday_resampling(dev, rng, freq):
                                rtol=1e-6, equal_nan=True)
     got = xgen.spell_length_statistics(x, 284.0, 1, None, ">", "max", ta, freq, device=dev)
     np.testing.assert_array_equal(got, ogen.spell_length_statistics(x, 284.0, 1, None, ">", "max", ot, freq))
+
+
+@pytest.mark.parametrize("include", [True, (False, True), (True, False)])
+def test_select_time_with_per_cell_doy_bounds(dev, rng, include):
+    """select_time(doy_bounds=(start, end)) with array bounds (mask_between_doys, cal:1199-1257, no time dimension on the
+    bounds): spans inside the year, spans that cross the new year (start > end), an int against an array, NaN = open
+    bound; drop=True is refused like in the reference."""
+    from xclim_amd.calendar import select_time
+
+    T, cells = 800, (6, 8)
+    ta, ot = _axes("2001-01-01", T)
+    x = rng.normal(280, 5, (T,) + cells).astype(np.float32)
+    start = rng.integers(1, 366, cells).astype(np.float64)
+    end = rng.integers(1, 366, cells).astype(np.float64)
+    start[0, 0], end[0, 1] = np.nan, np.nan
+    for bounds in ((start, end), (100, end), (start, 250)):
+        got = select_time(x, ta, doy_bounds=bounds, include_bounds=include, device=dev)
+        exp = ocal.select_time(x, ot, doy_bounds=bounds, include_bounds=include)
+        np.testing.assert_array_equal(got, exp)
+    assert np.isnan(got).any() and (~np.isnan(got)).any()
+    with pytest.raises(ValueError, match="incompatible with drop=True"):
+        select_time(x, ta, drop=True, doy_bounds=(start, end), device=dev)

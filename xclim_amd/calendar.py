@@ -99,7 +99,7 @@ def select_time_mask(time: TimeAxis, *, season=None, month=None, doy_bounds=None
         return np.isin(time.month, [month] if np.isscalar(month) else list(month))
     if doy_bounds is not None:
         if not all(isinstance(b, (int, np.integer)) for b in doy_bounds):
-            raise NotImplementedError("array-like doy bounds are not supported on the HIP path")
+            raise NotImplementedError("array-like doy bounds give a (time, cells) mask: use select_time()")
         return np.isin(time.doy, _get_doys(int(doy_bounds[0]), int(doy_bounds[1]), include_bounds))
     start, end = date_bounds
     (ms, ds), (me, de) = (tuple(int(v) for v in b.split("-")) for b in (start, end))
@@ -117,9 +117,25 @@ def select_time(da, time: TimeAxis, drop: bool = False, *, season=None, month=No
     """core/calendar.py:1259-1378: ``da.where(mask, drop=drop)`` for the time selections season / month / doy_bounds /
     date_bounds (the ``**indexer`` of select_resample_op & co.).  drop=False: same length, NaN outside the selection;
     drop=True: ``(selected rows, their TimeAxis)``.  keep=True returns the (rows, cells) float32 device array."""
+    dev = device or get_device()
+    if doy_bounds is not None and not all(isinstance(b, (int, np.integer)) for b in doy_bounds):
+        # per-cell bounds (mask_between_doys, cal:1199-1257, bounds without a time dimension)
+        if sum(a is not None for a in (season, month, date_bounds)) > 0:
+            raise ValueError("Only one method of indexing may be given, got 2.")
+        if drop:
+            raise ValueError("Passing array-like doy bounds is incompatible with drop=True.")  # cal:1343-1345
+        x, cell_shape = _flatten(da, dev)
+        inc = (include_bounds, include_bounds) if isinstance(include_bounds, bool) else tuple(include_bounds)
+        start, end = doy_bounds
+        bs, be = (np.broadcast_to(np.asarray(b, dtype=np.float32), cell_shape).reshape(-1).copy() for b in (start, end))
+        if not inc[0]:
+            bs += 1  # (NaN stays NaN: an open bound)
+        if not inc[1]:
+            be -= 1
+        out = K.mask_doy_cells(dev, x, time.doy, dev.to_device(bs), dev.to_device(be))
+        return out if keep else out.get().reshape((out.shape[0],) + tuple(cell_shape))
     mask = select_time_mask(time, season=season, month=month, doy_bounds=doy_bounds, date_bounds=date_bounds,
                             include_bounds=include_bounds)
-    dev = device or get_device()
     x, cell_shape = _flatten(da, dev)
     if mask is None:
         out, sub = x, time

@@ -285,6 +285,45 @@ static int upload_tidx(xh_ctx* ctx, const char* fn, const int32_t* tidx, int64_t
   return XH_OK;
 }
 
+// select_time(doy_bounds=(start, end)) with per-cell bounds (mask_between_doys, core/calendar.py:1244-1257, the
+// "spatial dims only" case): out = x where the day of year of the step lies inside the cell's [start, end] — a span that
+// wraps over the new year when start > end — else NaN.  start / end are float32 (C,), already shifted for exclusive
+// bounds; NaN bounds default to 1 / 366.
+template <int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_mask_doy_cells(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ doy,
+                 const float* __restrict__ start, const float* __restrict__ end, float* __restrict__ out, int64_t out_st) {
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
+  const int64_t ta = (int64_t)blockIdx.y * chunk;
+  int64_t tb = ta + chunk;
+  if (tb > T) tb = T;
+  if (ta >= tb) return;
+  float s[VEC], e[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const float a = start[c + i], b = end[c + i];
+    s[i] = a == a ? a : 1.0f;
+    e[i] = b == b ? b : 366.0f;
+  }
+  xh_march_rows<VEC, 8>(x + c, st, ta, tb, [&](int64_t t, const VecF<VEC>& xv) {
+    const float d = (float)doy[t];
+    float r[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const bool inside = s[i] <= e[i] ? (d >= s[i] && d <= e[i]) : !(d > e[i] && d < s[i]);
+      r[i] = inside ? xv.v[i] : xh_nan32();
+    }
+    float* dst = out + t * out_st + c;
+    if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+    else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) dst[i] = r[i];
+    }
+  });
+}
+
 extern "C" {
 
 int xh_range_reduce(xh_ctx* ctx, const float* low, const float* high, int64_t T, int64_t C, int64_t st_low, int64_t st_high,
@@ -455,6 +494,32 @@ int xh_select_rows(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
     hipLaunchKernelGGL((k_select_rows<4>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, (const int64_t*)d_idx, n, out, st_out);
   else
     hipLaunchKernelGGL((k_select_rows<1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, (const int64_t*)d_idx, n, out, st_out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_mask_doy_cells(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* doy,
+                      const float* start, const float* end, float* out, int64_t out_st) {
+  XH_REQUIRE(ctx && x && doy && start && end && out, XH_ERR_ARG, "xh_mask_doy_cells: NULL argument");
+  XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "xh_mask_doy_cells: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C && out_st >= C, XH_ERR_LAYOUT, "xh_mask_doy_cells: needs time-major views (sc == 1)");
+  if (T == 0 || C == 0) return XH_OK;
+  size_t cur = 0;
+  void* d_doy = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, doy, sizeof(int32_t) * (size_t)T, &d_doy);
+  if (rc) return rc;
+  const int vec = (xh_pick_vec(x, C, st) == 4 && xh_pick_vec(out, C, out_st) == 4 &&
+                   ((reinterpret_cast<uintptr_t>(start) | reinterpret_cast<uintptr_t>(end)) & 15) == 0) ? 4 : 1;
+  const int64_t cblocks = cdiv64(cdiv64(C, vec), XH_BLOCK);
+  int64_t gy = cdiv64((int64_t)ctx->num_cu * 12, cblocks);
+  if (gy < 1) gy = 1;
+  if (gy > cdiv64(T, 32)) gy = cdiv64(T, 32);
+  if (gy < 1) gy = 1;
+  const dim3 grid((unsigned)cblocks, (unsigned)gy);
+  if (vec == 4)
+    hipLaunchKernelGGL((k_mask_doy_cells<4>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, (const int32_t*)d_doy, start, end, out, out_st);
+  else
+    hipLaunchKernelGGL((k_mask_doy_cells<1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, (const int32_t*)d_doy, start, end, out, out_st);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

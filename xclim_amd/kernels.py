@@ -558,6 +558,15 @@ def eqm_adjust(dev: Device, sim: DeviceArray, af: DeviceArray, hist_q: DeviceArr
     return scen
 
 
+def mask_doy_cells(dev: Device, x: DeviceArray, doy, start: DeviceArray, end: DeviceArray) -> DeviceArray:
+    """xh_mask_doy_cells: x where doy[t] is inside the cell's [start, end] (wrapping when start > end), NaN elsewhere."""
+    T, C_ = _tc(x)
+    d = np.ascontiguousarray(doy, dtype=np.int32)
+    out = dev.empty((T, C_), np.float32)
+    dev.call("xh_mask_doy_cells", _vp(x.ptr), T, C_, C_, 1, np_ptr(d), _vp(start.ptr), _vp(end.ptr), _vp(out.ptr), C_)
+    return out
+
+
 def poly_trend(dev: Device, x: DeviceArray, degree: int = 1):
     """xh_poly_trend: (p0, p1) float64 (C,) device arrays of the per-cell trend p0 + p1 (t - (T - 1) / 2); p1 None for degree 0."""
     T, C_ = _tc(x)
