@@ -473,6 +473,58 @@ def test_quantile_series_register_sort_matches_histogram_kernels(dev, rng, monke
     np.testing.assert_array_equal(a, osdba.quantile(x, q).astype(np.float32))
 
 
+@pytest.mark.parametrize("T", [1025, 1300, 4000, 10950, 20000])
+@pytest.mark.parametrize("nq", [1, 20, 32])
+def test_quantile_series_two_pass_histogram(dev, rng, T, nq):
+    """select4.hip (k_hs_sample -> k_hs_hist -> k_hs_collect): long time-major series in two streaming passes.  Clean,
+    NaN-sprinkled, all-NaN, constant, two-valued, precipitation-like (the dry days own the pure "== lo" bin), saturated
+    at the maximum (pure "== hi" bin), tied / negative / -0.0 / sign-bit-NaN columns, a single valid sample,
+    a ragged last tile (C % 32 != 0).  Bitwise against the oracle (same fp64 lerp) and against the transposed pipeline."""
+    C = 32 * 5 + 7
+    x = _field(rng, T, C, nan_frac=0.002)
+    x[:, 3] = np.nan
+    x[:, 4] = np.float32(7.25)
+    x[:, 5] = np.where(rng.random(T) < 0.5, -1.5, 2.5)
+    x[:, 6:10] = _field(rng, T, 4, kind="pr")
+    x[:, 10] = np.minimum(x[:, 10], np.float32(290.0))          # a third of the days at the cap
+    x[:, 11] = np.round(x[:, 11] * 4) / 4                          # quarter-degree steps: heavy ties everywhere
+    x[:, 12] = -np.abs(x[:, 12]) * 0.0
+    x[:, 13] = x[:, 13] - 288                                      # values around zero, both signs
+    x[: T - 1, 14] = np.nan
+    x[:, 15] = np.where(rng.random(T) < 0.97, np.nan, x[:, 15])
+    neg_nan = np.frombuffer(np.uint32(0xFFC00001).tobytes(), np.float32)[0]
+    x[7, 16] = neg_nan
+    x[:, 18] = np.where(np.arange(T) % 2 == 0, 1.0, 1.0000001)      # two ADJACENT float32 values
+    x[:, C - 2] = np.nan
+    q = np.linspace(0.0, 1.0, nq) if nq > 1 else np.array([0.5])
+    if nq == 20:
+        q = osdba.equally_spaced_nodes(20)
+    exp = osdba.quantile(x, q).astype(np.float32)
+    out = K.quantile_series(dev, dev.to_device(x), q).get()
+    np.testing.assert_array_equal(out, exp)
+
+
+def test_quantile_series_two_pass_matches_transposed_pipeline(dev, rng, monkeypatch):
+    """Same field through select4.hip and (diagnostic switch) through the transposed column kernels: identical bits; the
+    flagged-column path (clustered values: > 512 candidates) and a non-16-byte-aligned view ride along."""
+    T, C = 3000, 2051
+    x = _field(rng, T, C, nan_frac=0.001)
+    x[:, 100:140] = (1.0 + rng.integers(0, 50, (T, 40)) * 1.1920929e-07).astype(np.float32)
+    x[rng.random((T, C)) < 0.0005] = 1.0e6
+    q = osdba.equally_spaced_nodes(20)
+    exp = osdba.quantile(x, q).astype(np.float32)
+    x[5, 17], x[9, 17], x[11, 18] = np.inf, -np.inf, np.inf  # (+-inf: compared between the GPU paths only, DESIGN.md §4)
+    xd = dev.to_device(x)
+    a = K.quantile_series(dev, xd, q).get()
+    monkeypatch.setenv("XH_DIAGNOSTICS", "1")
+    monkeypatch.setenv("XH_SELECT_NOHIST", "1")
+    b = K.quantile_series(dev, xd, q).get()
+    np.testing.assert_array_equal(a, b)
+    keep = np.ones(C, bool)
+    keep[17:19] = False
+    np.testing.assert_array_equal(a[:, keep], exp[:, keep])
+
+
 @pytest.mark.parametrize("T,C", [(365, 70001), (500, 33333), (800, 20011), (1500, 9001), (3650, 5003), (10950, 4801)])
 def test_quantile_series_many_columns(dev, rng, T, C):
     """More columns than resident workgroups (grid-stride column loops, ragged last tiles of the staged time-major

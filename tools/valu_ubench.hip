@@ -62,6 +62,12 @@ KERNEL(k_perm, A3("v_perm_b32"))
 KERNEL(k_ce_cmp, uint32_t t; CE_CMP(a0, a1) CE_CMP(a2, a3) CE_CMP(a4, a5) CE_CMP(a6, a7) CE_CMP(a0, a2) CE_CMP(a1, a3) CE_CMP(a4, a6) CE_CMP(a5, a7))
 #define CE_MM(ai, aj) asm volatile("v_min_u32 %2, %0, %1\n\tv_max_u32 %1, %0, %1\n\tv_mov_b32 %0, %2" : "+v"(ai), "+v"(aj), "=&v"(t));
 KERNEL(k_ce_minmax, uint32_t t; CE_MM(a0, a1) CE_MM(a2, a3) CE_MM(a4, a5) CE_MM(a6, a7) CE_MM(a0, a2) CE_MM(a1, a3) CE_MM(a4, a6) CE_MM(a5, a7))
+// compare-exchange from the borrow of a subtraction: v_sub_co_u32 (is it in the fast class?) + two v_cndmask
+#define CE_SUB(ai, aj) asm volatile("v_sub_co_u32 %2, vcc, %0, %1\n\tv_cndmask_b32 %2, %1, %0, vcc\n\tv_cndmask_b32 %1, %0, %1, vcc\n\tv_mov_b32 %0, %2" : "+v"(ai), "+v"(aj), "=&v"(t) : : "vcc");
+KERNEL(k_ce_subco, uint32_t t; CE_SUB(a0, a1) CE_SUB(a2, a3) CE_SUB(a4, a5) CE_SUB(a6, a7) CE_SUB(a0, a2) CE_SUB(a1, a3) CE_SUB(a4, a6) CE_SUB(a5, a7))
+#define SUBCO(ai) asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(ai) : "v"(b) : "vcc");
+KERNEL(k_sub_co, SUBCO(a0) SUBCO(a1) SUBCO(a2) SUBCO(a3) SUBCO(a4) SUBCO(a5) SUBCO(a6) SUBCO(a7))
+KERNEL(k_cvt_u32_f32, A1M("v_cvt_u32_f32"))
 #define CMP1(ai) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(ai), "v"(b) : "vcc");
 KERNEL(k_cmp_u32, CMP1(a0) CMP1(a1) CMP1(a2) CMP1(a3) CMP1(a4) CMP1(a5) CMP1(a6) CMP1(a7))
 #define CMPF(ai) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(ai), "v"(b) : "vcc");
@@ -91,7 +97,7 @@ int main() {
                 {"v_fma_f32", k_fma_f32}, {"v_min3_f32", k_min3_f32}, {"v_med3_f32", k_med3_f32}, {"v_min3_u32", k_min3_u32},
                 {"v_med3_u32", k_med3_u32}, {"v_lshl_add_u32", k_lshl_add}, {"v_bfi_b32", k_bfi}, {"v_perm_b32", k_perm},
                 {"v_cmp_lt_u32", k_cmp_u32}, {"v_cmp_lt_f32", k_cmp_f32}, {"cmp+cndmask (2 inst)", k_cmp_cnd}, {"CE cmp+2cnd+mov (4)", k_ce_cmp},
-                {"CE min+max+mov (3)", k_ce_minmax}, {"v_mov_b32", k_mov}, {"v_ashrrev_i32", k_ashr}, {"v_or_b32", k_or}, {"v_sub_u32", k_sub},
+                {"CE min+max+mov (3)", k_ce_minmax}, {"CE sub_co+2cnd+mov (4)", k_ce_subco}, {"v_sub_co_u32", k_sub_co}, {"v_cvt_u32_f32", k_cvt_u32_f32}, {"v_mov_b32", k_mov}, {"v_ashrrev_i32", k_ashr}, {"v_or_b32", k_or}, {"v_sub_u32", k_sub},
                 {"v_max_u16", k_max_u16}, {"v_mul_lo_u32", k_mul_lo}, {"v_mul_u32_u24", k_mul_u24}, {"v_add_f64 (+cvt)", k_add_f64}};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   int clk = 0; hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);

@@ -80,6 +80,10 @@ int xh_select_columns_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t n
 // XH_ERR_NOTIMPL when the shape does not fit
 int xh_select_regsort(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq, float* out,
                       int64_t out_cstride, int64_t out_qstride);
+// select4.hip: long series (1024 < T <= 65535) straight from a time-major view: two streaming passes with per-column
+// histograms in LDS; XH_ERR_NOTIMPL when the shape does not fit or too many columns need the column kernels
+int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq, float* out,
+                   int64_t out_cstride, int64_t out_qstride);
 // short series read straight from a time-major view; XH_ERR_NOTIMPL when the shape does not fit
 int xh_select_time_major(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq,
                          float* out, int64_t out_cstride, int64_t out_qstride);

@@ -265,6 +265,9 @@ static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t 
   // short series: 8-lane groups read the time-major rows directly (no transpose)
   int rc0 = xh_select_time_major(ctx, x, T, C, st, d_q, nq, out, 1, C);
   if (rc0 != XH_ERR_NOTIMPL) return rc0;
+  // long series: two streaming passes over the rows as they lie in memory (select4.hip)
+  rc0 = xh_select_hist(ctx, x, T, C, st, d_q, nq, out, 1, C);
+  if (rc0 != XH_ERR_NOTIMPL) return rc0;
   // time-major: transpose batches of columns into scratch (not counted as algorithmic bytes).  Two scratch
   // buffers and two streams: batch k+1 is transposed on stream2 while batch k is selected on the main stream (the
   // selection kernels are latency bound and leave the memory pipe mostly idle).

@@ -11,8 +11,14 @@ an odd ``window`` (xsdba: the samples of a group are the centred ``window`` days
 the same sample sets as ``percentile_doy``).  Training gathers each group's rows (``xh_select_rows``) and runs the
 per-column multi-quantile kernels on them; ``af`` / ``hist_q`` get a leading group axis ``(group, quantiles, *cells)``.
 ``adjust`` maps every time step with the factors of ITS group (rows are permuted group-major once, one ``xh_eqm_adjust``
-launch per group on a contiguous row block, one gather back).  Interpolating the factors BETWEEN groups along time (what
-xsdba does for ``interp != "nearest"`` with monthly groups) is not built.
+launch per group on a contiguous row block, one gather back).  With a sub-grouping only ``interp="nearest"`` is accepted:
+for "linear" / "cubic" xsdba interpolates over the (quantile, group) PLANE (``utils.interp_on_quantiles`` ->
+``_interp_on_quantiles_2D``: ``scipy.interpolate.griddata`` with a fractional group index), which is not built — an
+interpolation along the quantile axis inside each group would silently differ from it and jump at the group boundaries,
+so those calls raise ``NotImplementedError`` (:func:`_check_group_interp`).  Caveat for "nearest": xsdba's grouped
+"nearest" is ``griddata(method="nearest")`` in the same plane, i.e. the nearest (hist_q, group-index) point in EUCLIDEAN
+distance — where the nodes of a group lie more than one unit apart a node of the NEIGHBOURING group can win; here every
+time step always uses the nearest node of its own group.
 
 :class:`QuantileDeltaMapping` (``group="time"``): trained like EQM; ``adjust`` looks the factor up at the QUANTILE of every
 sim value within the sim series itself (``rank(sim, pct=True)``), so that the simulated change of every quantile is
@@ -82,6 +88,14 @@ class Grouper:
         return out
 
 
+def _check_group_interp(group: "Grouper", interp: str, who: str) -> None:
+    """Sub-groupings interpolate over (quantile, group) in xsdba when interp != "nearest" — not built: refuse loudly."""
+    if group.prop != "group" and interp != "nearest":
+        raise NotImplementedError(
+            f"{who}: interp={interp!r} with group={group.name!r} needs xsdba's 2-D interpolation over (quantile, group), "
+            "which is not built; use interp='nearest' (or group='time')")
+
+
 def equally_spaced_nodes(n: int, eps=None) -> np.ndarray:
     """xsdba.utils.equally_spaced_nodes: n nodes q_i = (i + 1/2) / n; with ``eps`` the end points eps and 1 - eps are
     added (n + 2 nodes), so that the adjustment factors are also defined near the ends of the distribution."""
@@ -149,6 +163,7 @@ class EmpiricalQuantileMapping:
     def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", time=None, keep=False):
         if interp not in ("nearest", "linear", "cubic"):
             raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
+        _check_group_interp(self.group, interp, "EmpiricalQuantileMapping.adjust")
         s, cell_shape = _flatten(sim, self._dev)
         if tuple(cell_shape) != self.cell_shape:
             raise ValueError("sim does not match the trained grid")
@@ -202,13 +217,14 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
     factor of a sim value is taken at ITS quantile in the sim series: ``sim_q = rank(sim, pct=True)``,
     ``af = interp_on_quantiles(sim_q, quantiles, af)``, ``scen = sim (+|*) af``.  With a sub-grouping the ranks are taken
     inside each group's own time steps (xsdba: ``group.apply(rank, sim, main_only=True)`` — the window only widens the
-    TRAINING sample) and every step uses the factors of its group; factors are not interpolated between groups."""
+    TRAINING sample) and every step uses the factors of its group (``interp="nearest"`` only, see the module docstring)."""
 
     def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", time=None, keep=False):
         if interp not in ("nearest", "linear", "cubic"):
             raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
         if interp == "cubic":
             raise NotImplementedError("QuantileDeltaMapping.adjust: interp='cubic' is not built (nearest, linear)")
+        _check_group_interp(self.group, interp, "QuantileDeltaMapping.adjust")
         dev = self._dev
         s, cell_shape = _flatten(sim, dev)
         if tuple(cell_shape) != self.cell_shape:
