@@ -52,7 +52,7 @@ struct HsStat {
   uint32_t nflag;   // columns handed to the column kernels
   uint32_t maxm;    // largest candidate count of any column
   uint32_t errors;  // pass 2 met a different candidate count than pass 1 announced (must stay 0)
-  uint32_t pad;
+  uint32_t summ;    // candidates of all columns (diagnostics: the mean per column)
 };
 
 // per-column window -> bin arithmetic, identical in pass 1 and pass 2.  Bins are equally wide in VALUE, not in key
@@ -261,6 +261,17 @@ __device__ __forceinline__ void hs_stream(const float* __restrict__ x, int T, in
   }
 }
 
+// Workgroup -> tile map.  The dispatcher places block b on XCD b % 8; with tile = b the workgroups of one XCD touch
+// every 8th 128-byte line of a row.  Optional map (XH_HIST_XCD=1, diagnostics): inside each round of gridDim tiles, XCD
+// x takes the x-th CONTIGUOUS eighth (64 adjacent tiles = 8 KB of every row).  Measured on config 4: no gain (42.8 ms
+// with, 41.3 without), so the identity is the default.  Needs gridDim % 8 == 0, identity otherwise.
+__device__ __forceinline__ int64_t hs_tile_of(int64_t round_base, int64_t ntiles, int xcd_map) {
+  const int64_t G = gridDim.x, b = blockIdx.x;
+  const int64_t local = (xcd_map && (G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
+  const int64_t tile = round_base + local;
+  return tile < ntiles ? tile : -1;
+}
+
 // ---- pass 1: histogram + target bins -----------------------------------------------------------------------------------
 // LDS: hist [512][32] u32 (two u16 counters per word: bins 2d, 2d + 1 of column c at [d][c]) | bm [32][32] target-bin
 // bitmap | part [16][32] partial sums | tgt [2 * MAXQ][32] (bin | rank inside the bin << 16) | mcol [32] | cbase [32]
@@ -270,7 +281,7 @@ __global__ void __launch_bounds__(HS_NT, 4)
 k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2* __restrict__ lohi,
           const double* __restrict__ qs, int nq, uint32_t* __restrict__ meta_n, uint32_t* __restrict__ meta_m,
           uint32_t* __restrict__ meta_base, uint16_t* __restrict__ crank, uint32_t* __restrict__ bitmap_g,
-          uint32_t* __restrict__ flist, HsStat* __restrict__ stat) {
+          uint32_t* __restrict__ flist, HsStat* __restrict__ stat, int xcd_map, int abl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
   uint32_t* bm = hist + (HS_NB / 2) * HS_CW;
@@ -284,14 +295,22 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
   // zero the histogram and the bitmap (again at the end of every tile)
   for (int i = tid; i < (HS_NB / 2) * HS_CW + 32 * HS_CW; i += HS_NT) hist[i] = 0u;
   __syncthreads();
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
+    const int64_t tile = hs_tile_of(round_base, ntiles, xcd_map);
+    if (tile < 0) break;  // (block-uniform; only in the last round)
     const int64_t c = tile * HS_CW + col;
     const bool cvalid = c < C;
     const int64_t cc = cvalid ? c : C - 1;
     const uint2 lh = lohi[cc];
     const HsScale s = hs_scale(lh.x, lh.y);
     uint32_t* mycol = hist + col;
+    uint32_t dummy = 0;
     hs_stream(x, T, st, cc, cvalid, rl, [&](const float (&v)[HS_U], const uint32_t (&k)[HS_U]) {
+      if (abl & 2) {  // diagnostics: loads only
+#pragma unroll
+        for (int u = 0; u < HS_U; ++u) dummy ^= k[u];
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < HS_U; ++u) {
         const uint32_t b = hs_bin(v[u], k[u], s);
@@ -299,6 +318,7 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
         atomicAdd(mycol + (b >> 1) * HS_CW, val);
       }
     });
+    if ((abl & 2) && dummy == 0x12345679u) atomicAdd(&stat->errors, 1u);
     __syncthreads();
     // ---- exclusive prefix sums, in place: thread (col, rl) owns words [rl * 32, rl * 32 + 32) = bins [rl * 64, ...)
     uint32_t ssum = 0;
@@ -405,6 +425,7 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
       meta_m[c] = flagged ? HS_FLAGGED : m;
       meta_base[c] = mybase;
       atomicMax(&stat->maxm, m);
+      atomicAdd(&stat->summ, m);
       if (flagged) flist[atomicAdd(&stat->nflag, 1u)] = (uint32_t)c;
     }
     __syncthreads();  // every reader of bm / hist / part is done
@@ -472,7 +493,7 @@ __global__ void __launch_bounds__(HS_NT, 4)
 k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2* __restrict__ lohi,
              const double* __restrict__ qs, int nq, const uint32_t* __restrict__ meta_n, const uint32_t* __restrict__ meta_m,
              const uint32_t* __restrict__ meta_base, const uint16_t* __restrict__ crank, const uint32_t* __restrict__ bitmap_g, float* __restrict__ out, int64_t ocs,
-             int64_t oqs, HsStat* __restrict__ stat) {
+             int64_t oqs, HsStat* __restrict__ stat, int xcd_map, int abl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* cand = reinterpret_cast<uint32_t*>(smem);
   uint32_t* bm = cand + HS_POOL;
@@ -482,7 +503,9 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
   const int lane = tid & 63, wv = tid >> 6;
   const int ntgt = 2 * nq;
   const int64_t ntiles = (C + HS_CW - 1) / HS_CW;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
+    const int64_t tile = hs_tile_of(round_base, ntiles, xcd_map);
+    if (tile < 0) break;  // (block-uniform; only in the last round)
     const int64_t c = tile * HS_CW + col;
     const bool cvalid = c < C;
     const int64_t cc = cvalid ? c : C - 1;
@@ -526,7 +549,8 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
       const uint32_t m = cursor[k];
       if (m != mm && lane == 0) atomicAdd(&stat->errors, 1u);
       uint32_t* list = cand + meta_base[ck];
-      if (m > 1024u) hs_sort_column<32>(list, m < mm ? m : mm, lane);
+      if (abl & 1) {
+      } else if (m > 1024u) hs_sort_column<32>(list, m < mm ? m : mm, lane);
       else if (m > 512u) hs_sort_column<16>(list, m, lane);
       else if (m > 256u) hs_sort_column<8>(list, m, lane);
       else if (m > 128u) hs_sort_column<4>(list, m, lane);
@@ -635,6 +659,10 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   int64_t nblk = ntiles;
   const int64_t maxblk = (int64_t)ctx->num_cu * 2;
   if (nblk > maxblk) nblk = maxblk;
+  if (nblk >= 8) nblk &= ~(int64_t)7;  // the XCD-aware tile map wants a multiple of 8 (the tile loop is grid-strided)
+  const int xcd_map = xh_diag_env("XH_HIST_XCD") ? 1 : 0;  // measured on config 4: 42.8 ms with the map, 41.3 without -> off
+  const char* eabl = xh_diag_env("XH_HIST_ABL");  // diagnostics: 1 = no candidate sort, 2 = pass 1 loads only (wrong results)
+  const int abl = eabl ? atoi(eabl) : 0;
   {
     const char* g = xh_diag_env("XH_HIST_GRID");  // diagnostics: workgroups per CU
     if (g && atoi(g) > 0 && (int64_t)ctx->num_cu * atoi(g) < ntiles) nblk = (int64_t)ctx->num_cu * atoi(g);
@@ -642,17 +670,17 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_LDS1));
   XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_LDS2));
   hipLaunchKernelGGL(k_hs_hist, dim3((unsigned)nblk), dim3(HS_NT), HS_LDS1, ctx->stream, x, (int)T, C, st, lohi, d_q, nq, meta_n,
-                     meta_m, meta_base, crank, bitmap_g, flist, stat);
+                     meta_m, meta_base, crank, bitmap_g, flist, stat, xcd_map, abl);
   XH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_hs_collect, dim3((unsigned)nblk), dim3(HS_NT), HS_LDS2, ctx->stream, x, (int)T, C, st, lohi, d_q, nq,
-                     meta_n, meta_m, meta_base, crank, bitmap_g, out, out_cstride, out_qstride, stat);
+                     meta_n, meta_m, meta_base, crank, bitmap_g, out, out_cstride, out_qstride, stat, xcd_map, abl);
   XH_LAUNCH_CHECK();
   HsStat h;
   XH_CHECK_HIP(hipMemcpyAsync(&h, stat, sizeof(HsStat), hipMemcpyDeviceToHost, ctx->stream));
   XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   XH_REQUIRE(h.errors == 0, XH_ERR_HIP, "xh_select_hist: %u columns met another candidate count in pass 2 than in pass 1",
              h.errors);
-  if (xh_diag_env("XH_HIST_STATS")) fprintf(stderr, "[xh_select_hist] T=%lld C=%lld flagged=%u max candidates=%u\n", (long long)T, (long long)C, h.nflag, h.maxm);
+  if (xh_diag_env("XH_HIST_STATS")) fprintf(stderr, "[xh_select_hist] T=%lld C=%lld flagged=%u candidates: max %u mean %.1f\n", (long long)T, (long long)C, h.nflag, h.maxm, (double)h.summ / (double)C);
   if (h.nflag == 0) return XH_OK;
   if ((int64_t)h.nflag > nfmax) return XH_ERR_NOTIMPL;  // the caller recomputes everything with the transposed pipeline
   const int64_t nf = h.nflag;
