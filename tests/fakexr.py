@@ -1,0 +1,225 @@
+"""A ~150-line stand-in for the part of ``xarray.DataArray`` that xclim_amd/xr_adapter.py touches (its module docstring
+lists the protocol), so that the xarray-facing wrappers are executed on the GPU box, where xarray cannot be installed.
+TEST INFRASTRUCTURE ONLY — nothing in the product imports it.
+
+Also: stand-in MODULES with the reference's import structure (``make_reference_like_modules``): the index bodies are
+restated from the reference in a few lines each (file:line given) and import ``threshold_count`` / ``compare`` /
+``resample_doy`` BY NAME like the reference does, so that ``patch.install(env, modules)`` is exercised with the same
+resolution rules as on a real installation.
+"""
+import types
+
+import numpy as np
+
+
+class _Dt:
+    def __init__(self, coord):
+        self._c = coord
+
+    def __getattr__(self, name):
+        if name == "calendar":
+            return self._c._cal
+        return DataArray(self._c._fields[name], dims=self._c.dims)
+
+
+class _Resampled:
+    def __init__(self, da, freq):
+        self._da, self._freq = da, freq
+
+    def first(self, **kw):
+        from xclim_amd.timeaxis import TimeAxis
+
+        f = self._da._fields
+        seg, _ = TimeAxis(f["year"], f["month"], f["day"], self._da._cal).segments(self._freq)
+        first = np.asarray(seg[:-1])
+        lab = time_coord_like(self._da, first)
+        return DataArray(self._da.values[first], coords={"time": lab}, dims=("time",))
+
+
+class DataArray:
+    def __init__(self, data, coords=None, dims=None, name=None, attrs=None):
+        self.values = np.asarray(data)
+        self.dims = tuple(dims) if dims is not None else tuple(f"dim_{i}" for i in range(self.values.ndim))
+        assert len(self.dims) == self.values.ndim, (self.dims, self.values.shape)
+        self.name, self.attrs = name, dict(attrs or {})
+        self.coords = {}
+        self._fields, self._cal = None, None
+        for k, v in (coords or {}).items():
+            if not isinstance(v, DataArray):
+                v = DataArray(np.asarray(v), dims=(k,))
+            self.coords[k] = v
+
+    dtype = property(lambda self: self.values.dtype)
+    shape = property(lambda self: self.values.shape)
+    data = property(lambda self: self.values)
+
+    def __getitem__(self, key):
+        return self.coords[key]
+
+    @property
+    def dt(self):
+        return _Dt(self)
+
+    def transpose(self, *dims):
+        if Ellipsis in dims:
+            i = dims.index(Ellipsis)
+            rest = tuple(d for d in self.dims if d not in dims)
+            dims = dims[:i] + rest + dims[i + 1:]
+        perm = [self.dims.index(d) for d in dims]
+        out = DataArray(self.values.transpose(perm), coords=self.coords, dims=dims, name=self.name, attrs=self.attrs)
+        out._fields, out._cal = self._fields, self._cal
+        return out
+
+    def resample(self, time):
+        return _Resampled(self, time)
+
+    def assign_attrs(self, **kw):
+        out = self.copy()
+        out.attrs.update(kw)
+        return out
+
+    def copy(self, data=None):
+        out = DataArray(self.values.copy() if data is None else data, coords=self.coords, dims=self.dims, name=self.name,
+                        attrs=self.attrs)
+        out._fields, out._cal = self._fields, self._cal
+        return out
+
+    def sel(self, **kw):
+        out = self
+        for k, v in kw.items():
+            ax = out.dims.index(k)
+            j = int(np.nonzero(out.coords[k].values == v)[0][0])
+            out = DataArray(np.take(out.values, j, axis=ax), coords={c: x for c, x in out.coords.items() if c != k},
+                            dims=tuple(d for d in out.dims if d != k), name=out.name, attrs=out.attrs)
+        return out
+
+    def _bin(self, other, fn):
+        o = other.transpose(*self.dims).values if isinstance(other, DataArray) else np.asarray(other)
+        out = DataArray(fn(self.values, o), coords=self.coords, dims=self.dims)
+        out._fields, out._cal = self._fields, self._cal
+        return out
+
+    def __gt__(self, o): return self._bin(o, np.greater)
+    def __lt__(self, o): return self._bin(o, np.less)
+    def __ge__(self, o): return self._bin(o, np.greater_equal)
+    def __le__(self, o): return self._bin(o, np.less_equal)
+    def __mul__(self, o): return self._bin(o, np.multiply)
+    def __add__(self, o): return self._bin(o, np.add)
+    def __sub__(self, o): return self._bin(o, np.subtract)
+    __hash__ = object.__hash__
+
+
+def time_coord(ta) -> DataArray:
+    """The ``time`` coordinate of a daily TimeAxis (values = ordinals; ``.dt`` serves year / month / day / dayofyear)."""
+    c = DataArray(np.asarray(ta.ordinal()), dims=("time",))
+    c._fields = {"year": np.asarray(ta.year), "month": np.asarray(ta.month), "day": np.asarray(ta.day), "dayofyear": np.asarray(ta.doy)}
+    c._cal = ta.calendar
+    return c
+
+
+def time_coord_like(c, idx) -> DataArray:
+    out = DataArray(c.values[idx], dims=("time",))
+    out._fields = {k: v[idx] for k, v in c._fields.items()}
+    out._cal = c._cal
+    return out
+
+
+def field(x, ta, dims=("time", "lat", "lon"), attrs=None, name=None) -> DataArray:
+    """A (time, lat, lon)-like DataArray (any dim order) on the TimeAxis ``ta``."""
+    coords = {d: np.arange(n) for d, n in zip(dims, np.shape(x)) if d != "time"}
+    coords["time"] = time_coord(ta)
+    return DataArray(x, coords=coords, dims=dims, attrs=attrs or {"units": "K"}, name=name)
+
+
+def make_env():
+    """xr_adapter.Env of the stand-in: thresholds are plain floats / DataArrays already in the data's units."""
+    from xclim_amd.xr_adapter import Env
+
+    def convert_units_to(thr, data, context=None):
+        return thr
+
+    def to_agg_units(out, orig, op, dim="time", **kw):
+        out.attrs["units"] = {"count": "days", "integral": f"{orig.attrs.get('units', '')} days"}.get(op, orig.attrs.get("units", ""))
+        return out
+
+    return Env(DataArray, convert_units_to, to_agg_units)
+
+
+def make_reference_like_modules(env):
+    """name -> module, wired like the reference: ``generic`` / ``calendar`` / ``run_length`` / ``utils`` define the functions
+    (here: stubs that fail loudly — after ``install`` nothing may reach them), ``_multivariate`` and ``_threshold`` import
+    them BY NAME and hold ``rl`` as a module object (indices/_multivariate.py:13, 22-24; indices/_threshold.py:25-36)."""
+    def stub(name):
+        def f(*a, **k):
+            raise AssertionError(f"the reference's {name} was reached: the wrapper did not replace it")
+        f.__name__ = name
+        return f
+
+    mods = {}
+    for modname, names in {
+        "xclim.indices.generic": ("threshold_count", "count_occurrences", "domain_count", "select_resample_op",
+                                  "spell_length_statistics", "cumulative_difference", "compare"),
+        "xclim.core.calendar": ("percentile_doy", "resample_doy"),
+        "xclim.indices.run_length": ("rle", "rle_statistics", "longest_run", "windowed_run_events", "windowed_run_count",
+                                     "first_run", "last_run", "season_length", "resample_and_rl", "_cumsum_reset_np"),
+        "xclim.core.utils": ("calc_perc",),
+    }.items():
+        m = types.ModuleType(modname)
+        for n in names:
+            setattr(m, n, stub(n))
+        mods[modname] = m
+    gen, cal, rl = mods["xclim.indices.generic"], mods["xclim.core.calendar"], mods["xclim.indices.run_length"]
+
+    mv = types.ModuleType("xclim.indices._multivariate")
+    mv.resample_doy, mv.compare, mv.threshold_count, mv.select_resample_op = cal.resample_doy, gen.compare, gen.threshold_count, gen.select_resample_op
+    mv.rl = rl
+
+    def tx90p(tasmax, tasmax_per, freq="YS", op=">"):  # indices/_multivariate.py:1584-1592
+        tasmax_per = env.convert_units_to(tasmax_per, tasmax)
+        thresh = mv.resample_doy(tasmax_per, tasmax)
+        out = mv.threshold_count(tasmax, op, thresh, freq, constrain=(">", ">="))
+        return env.to_agg_units(out, tasmax, "count", deffreq="D")
+
+    def warm_spell_duration_index(tasmax, tasmax_per, window=6, freq="YS", resample_before_rl=True, op=">"):  # :1779-1793
+        thresh = env.convert_units_to(tasmax_per, tasmax)
+        thresh = mv.resample_doy(thresh, tasmax)
+        above = mv.compare(tasmax, op, thresh, constrain=(">", ">="))
+        out = mv.rl.resample_and_rl(above, resample_before_rl, mv.rl.windowed_run_count, window=window, freq=freq)
+        return env.to_agg_units(out, tasmax, "count", deffreq="D")
+
+    mv.tx90p, mv.warm_spell_duration_index = tx90p, warm_spell_duration_index
+    mods[mv.__name__] = mv
+
+    th = types.ModuleType("xclim.indices._threshold")
+    th.spell_length_statistics, th.threshold_count, th.count_occurrences, th.domain_count = (
+        gen.spell_length_statistics, gen.threshold_count, gen.count_occurrences, gen.domain_count)
+    th.cumulative_difference, th.compare, th.rl = gen.cumulative_difference, gen.compare, rl
+
+    def maximum_consecutive_dry_days(pr, thresh=1.0 / 86400.0, op="<", freq="YS", resample_before_rl=True):  # _threshold.py:2925-2937
+        return th.spell_length_statistics(pr, thresh, 1, win_reducer=None, op=op, spell_reducer="max", freq=freq,
+                                          resample_before_rl=resample_before_rl)
+
+    def frost_days(tasmin, thresh=273.15, freq="YS"):  # _threshold.py: threshold_count(tasmin, "<", frz, freq) + to_agg_units
+        out = th.threshold_count(tasmin, "<", env.convert_units_to(thresh, tasmin), freq)
+        return env.to_agg_units(out, tasmin, "count")
+
+    def hot_spell_frequency(tasmax, thresh=303.15, window=3, freq="YS", op=">", resample_before_rl=True):  # _threshold.py (hot_spell_frequency)
+        cond = th.compare(tasmax, op, thresh, constrain=(">", ">="))
+        return th.rl.resample_and_rl(cond, resample_before_rl, th.rl.windowed_run_events, window=window, freq=freq)
+
+    def growing_degree_days(tas, thresh=277.15, freq="YS"):  # _threshold.py: cumulative_difference(tas, thresh, ">", freq)
+        return th.cumulative_difference(tas, threshold=thresh, op=">", freq=freq)
+
+    th.maximum_consecutive_dry_days, th.frost_days, th.hot_spell_frequency, th.growing_degree_days = (
+        maximum_consecutive_dry_days, frost_days, hot_spell_frequency, growing_degree_days)
+    mods[th.__name__] = th
+
+    sp = types.ModuleType("xclim.indices._simple")
+    sp.select_resample_op = gen.select_resample_op
+
+    def tg_mean(tas, freq="YS"):  # indices/_simple.py:113
+        return sp.select_resample_op(tas, op="mean", freq=freq)
+
+    sp.tg_mean = tg_mean
+    mods[sp.__name__] = sp
+    return mods

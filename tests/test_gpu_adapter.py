@@ -1,0 +1,209 @@
+"""Tier 1 of the drop-in boundary, EXECUTED: ``patch.install(env, modules)`` puts the xarray-facing
+wrappers of xclim_amd/xr_adapter.py into stand-in modules wired like the reference (functions imported BY NAME into the
+index modules, ``rl`` held as a module object — tests/fakexr.py), the reference's index bodies are then called on
+DataArray stand-ins and checked against the oracle.  A launch log (``Device.start_trace``) proves that the wrappers reach
+the kernels the benchmark measures: tx90p -> ``xh_threshold_count`` with the per-doy float64 table (never the (T, Y, X)
+threshold field), maximum_consecutive_dry_days -> the fused ``xh_run_stats`` (never ``xh_cumsum_reset``), the warm spell
+duration index -> ``xh_run_stats_doy``.
+"""
+import numpy as np
+import pytest
+
+import fakexr
+from oracle import calendar as ocal
+from oracle import generic as ogen
+from oracle import indices as oidx
+from oracle import run_length as orl
+from oracle import sdba as osdba
+from oracle.timeutil import OTime
+from xclim_amd import patch
+from xclim_amd._capi import THR_DOY_F64
+from xclim_amd.timeaxis import TimeAxis
+from xclim_amd.xr_adapter import DoyThreshold, LazyCompare, make_wrappers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ref(dev):
+    env = fakexr.make_env()
+    mods = fakexr.make_reference_like_modules(env)
+    import xclim_amd._capi as capi
+
+    old = capi._default_device
+    capi._default_device = dev  # the wrappers run on the test's context
+    names = patch.install(env, mods)
+    yield env, mods, names
+    patch.uninstall()
+    capi._default_device = old
+
+
+def _temp(rng, T, shape, nan_frac=0.0):
+    t = np.arange(T).reshape((T,) + (1,) * len(shape))
+    x = (288 + 12 * np.sin(2 * np.pi * (t - 100) / 365) + rng.normal(0, 3, (T,) + shape)).astype(np.float32)
+    if nan_frac:
+        x[rng.random(x.shape) < nan_frac] = np.nan
+    return x
+
+
+def _calls(trace, name):
+    return [a for n, a in trace if n == name]
+
+
+def test_install_replaces_every_by_name_import(ref):
+    env, mods, names = ref
+    assert "xclim.indices._multivariate.threshold_count" in names and "xclim.indices._multivariate.resample_doy" in names
+    assert "xclim.indices._threshold.spell_length_statistics" in names and "xclim.indices.run_length.resample_and_rl" in names
+    assert mods["xclim.indices._multivariate"].threshold_count is mods["xclim.indices.generic"].threshold_count
+    assert mods["xclim.core.calendar"].percentile_doy.__wrapped__ is mods["xclim.core.calendar"].percentile_doy  # bootstrapping.py:195
+
+
+def test_tx90p_through_the_wrappers_reaches_the_doy_table_kernel(ref, dev, rng):
+    env, mods, _ = ref
+    T = 365 * 3
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    x = _temp(rng, T, (4, 5), nan_frac=0.001)
+    tasmax = fakexr.field(np.ascontiguousarray(np.moveaxis(x, 0, 1)), ta, dims=("lat", "time", "lon"))  # time NOT first
+    per = mods["xclim.core.calendar"].percentile_doy(tasmax, window=5, per=90.0)
+    assert per.dims == ("dayofyear", "lat", "lon", "percentiles") and per.dtype == np.float64 and per.attrs["window"] == 5
+    p_o, doys = ocal.percentile_doy(x, ot, 5, 90.0)
+    np.testing.assert_allclose(per.values[..., 0], p_o[..., 0], rtol=1e-12)
+    trace = dev.start_trace()
+    out = mods["xclim.indices._multivariate"].tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
+    dev.stop_trace()
+    exp = oidx.tx90p(x, p_o[..., 0], doys, ot, "YS")
+    assert out.dims == ("time", "lat", "lon") and out.dtype == np.int64 and out.attrs["units"] == "days"
+    np.testing.assert_array_equal(out.values, exp)
+    tc = _calls(trace, "xh_threshold_count")
+    assert len(tc) == 1 and tc[0][6] == THR_DOY_F64          # thr_kind: the per-doy fp64 table, gathered in the kernel
+    assert not _calls(trace, "xh_doy_broadcast")              # the (T, Y, X) float64 threshold was never formed
+
+
+def test_cdd_through_the_wrappers_is_the_fused_run_length_kernel(ref, dev, rng):
+    env, mods, _ = ref
+    T = 365 * 2
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    pr = np.where(rng.random((T, 6, 7)) < 0.3, rng.gamma(0.8, 8.0, (T, 6, 7)) / 86400.0, 0.0).astype(np.float32)
+    da = fakexr.field(pr, ta, attrs={"units": "kg m-2 s-1"})
+    trace = dev.start_trace()
+    out = mods["xclim.indices._threshold"].maximum_consecutive_dry_days(da, 1.0 / 86400.0, freq="YS")
+    out_after = mods["xclim.indices._threshold"].maximum_consecutive_dry_days(da, 1.0 / 86400.0, freq="YS", resample_before_rl=False)
+    dev.stop_trace()
+    np.testing.assert_array_equal(out.values, oidx.maximum_consecutive_dry_days(pr, 1.0 / 86400.0, ot, "YS"))
+    np.testing.assert_array_equal(out_after.values, oidx.maximum_consecutive_dry_days(pr, 1.0 / 86400.0, ot, "YS", resample_before_rl=False))
+    assert out.attrs["units"] == "days" and out.dims == ("time", "lat", "lon")
+    assert _calls(trace, "xh_run_stats") and not _calls(trace, "xh_cumsum_reset") and not _calls(trace, "xh_rle")
+    assert _calls(trace, "xh_run_stats")[0][5] >= 0           # fused_op: the compare happens inside the run-length kernel
+
+
+def test_wsdi_through_the_wrappers_is_one_fused_launch(ref, dev, rng):
+    env, mods, _ = ref
+    T = 365 * 3
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    x = _temp(rng, T, (3, 4))
+    tasmax = fakexr.field(x, ta)
+    per = mods["xclim.core.calendar"].percentile_doy(tasmax, window=5, per=75.0).sel(percentiles=75.0)
+    p_o, doys = ocal.percentile_doy(x, ot, 5, 75.0)
+    for before in (True, False):
+        trace = dev.start_trace()
+        out = mods["xclim.indices._multivariate"].warm_spell_duration_index(tasmax, per, window=3, freq="YS", resample_before_rl=before)
+        dev.stop_trace()
+        exp = oidx.warm_spell_duration_index(x, p_o[..., 0], doys, ot, 3, "YS", before)
+        np.testing.assert_array_equal(out.values, exp)
+        assert exp.sum() > 0
+        if before:
+            assert len(_calls(trace, "xh_run_stats_doy")) == 1 and not _calls(trace, "xh_doy_broadcast")
+
+
+def test_lazy_threshold_and_mask_turn_into_arrays_for_code_that_was_not_replaced(ref, dev, rng):
+    env, mods, _ = ref
+    T = 365
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    x = _temp(rng, T, (2, 3))
+    da = fakexr.field(x, ta)
+    per = mods["xclim.core.calendar"].percentile_doy(da, window=5, per=50.0).sel(percentiles=50.0)
+    thr = mods["xclim.core.calendar"].resample_doy(per, da)
+    assert isinstance(thr, DoyThreshold)
+    p_o, doys = ocal.percentile_doy(x, ot, 5, 50.0)
+    full = ocal.resample_doy(p_o[..., 0], doys, ot)
+    np.testing.assert_array_equal(np.asarray(thr), full)       # __array__
+    assert thr.dims == ("time", "lat", "lon") and thr.values.dtype == np.float64   # attribute access materialises
+    np.testing.assert_array_equal((da > thr).values, x > full)   # reflected comparison of an un-replaced caller
+    mask = mods["xclim.indices.generic"].compare(da, ">", thr)
+    assert isinstance(mask, LazyCompare)
+    np.testing.assert_array_equal(mask.values, x > full)
+    np.testing.assert_array_equal((mask * 1).values, (x > full) * 1)
+    with pytest.raises(ValueError, match="not recognized"):
+        mods["xclim.indices.generic"].compare(da, "=>", thr)
+
+
+@pytest.mark.parametrize("dims", [("time", "lat", "lon"), ("lon", "lat", "time")])
+def test_generic_wrappers_vs_oracle(ref, dev, rng, dims):
+    env, mods, _ = ref
+    gen = mods["xclim.indices.generic"]
+    T = 800
+    ta, ot = TimeAxis.daily("2000-03-15", T), OTime.standard("2000-03-15", T)
+    x = _temp(rng, T, (3, 4), nan_frac=0.01)
+    arr = np.ascontiguousarray(np.transpose(x, [("time", "lat", "lon").index(d) for d in dims]))
+    da = fakexr.field(arr, ta, dims=dims)
+    order = da.transpose("time", ...).dims                        # results: time first, the other dims in their own order
+    x = np.ascontiguousarray(np.transpose(x, [("time", "lat", "lon").index(d) for d in order]))
+    out = gen.threshold_count(da, ">", 290.0, "MS")
+    assert out.dims == order
+    np.testing.assert_array_equal(out.values, ogen.threshold_count(x, ">", 290.0, ot, "MS"))
+    cell = fakexr.DataArray(np.float32(285) + rng.random((4, 3)).astype(np.float32) * 8, dims=("lon", "lat"))  # per-cell threshold
+    np.testing.assert_array_equal(gen.threshold_count(da, "<", cell, "YS").values,
+                                  ogen.threshold_count(x, "<", cell.transpose(*order[1:]).values[None], ot, "YS"))
+    np.testing.assert_array_equal(gen.count_occurrences(da, 290.0, "QS-DEC", "!=").values, ogen.count_occurrences(x, 290.0, "!=", ot, "QS-DEC"))
+    np.testing.assert_array_equal(gen.domain_count(da, 280.0, 295.0, "YS").values, ogen.domain_count(x, 280.0, 295.0, ot, "YS"))
+    for op in ("mean", "max", "std", "count", "argmax"):
+        np.testing.assert_allclose(gen.select_resample_op(da, op, "MS").values, ogen.select_resample_op(x, op, ot, "MS"), rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(gen.cumulative_difference(da, 283.0, ">", "YS").values, ogen.cumulative_difference(x, 283.0, ">", ot, "YS"), rtol=1e-6)
+    np.testing.assert_array_equal(gen.compare(da, ">=", 290.0).values, x >= np.float32(290.0))  # (time first, like every result)
+    with pytest.raises(ValueError, match="not permitted"):
+        gen.threshold_count(da, "==", 290.0, "YS")
+    with pytest.raises(AssertionError, match="was reached"):   # a callable op is FORWARDED to the reference's function
+        gen.select_resample_op(da, np.nanmax, "YS")
+    # the index bodies of the stand-in modules (by-name imports) on the same field
+    th = mods["xclim.indices._threshold"]
+    np.testing.assert_array_equal(th.frost_days(da, 283.15, "YS").values, ogen.threshold_count(x, "<", 283.15, ot, "YS"))
+    np.testing.assert_allclose(th.growing_degree_days(da, 283.0, "YS").values, ogen.cumulative_difference(x, 283.0, ">", ot, "YS"), rtol=1e-6)
+    np.testing.assert_allclose(mods["xclim.indices._simple"].tg_mean(da, "YS").values, ogen.select_resample_op(x, "mean", ot, "YS"), rtol=1e-6, equal_nan=True)
+    exp = oidx.run_index(x, ">", 292.0, "events", 3, ot, "YS")
+    np.testing.assert_array_equal(th.hot_spell_frequency(da, 292.0, 3, "YS").values, exp)
+
+
+def test_run_length_wrappers_vs_oracle(ref, dev, rng):
+    env, mods, _ = ref
+    rl = mods["xclim.indices.run_length"]
+    T = 730
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    m = (rng.random((T, 96, 100)) < 0.6)                          # > 9000 cells: the N-D semantics of the reference
+    da = fakexr.field(np.ascontiguousarray(np.moveaxis(m, 0, -1)), ta, dims=("lat", "lon", "time"))
+    mf = m.astype(np.float32)
+    np.testing.assert_array_equal(rl.rle_statistics(da, "max", 2).values, orl.rle_statistics(mf, "max", 2))
+    np.testing.assert_array_equal(rl.rle_statistics(da, "sum", 3, freq="YS").values, orl.rle_statistics(mf, "sum", 3, ot, "YS"))
+    np.testing.assert_array_equal(rl.longest_run(da, freq="YS").values, orl.longest_run(mf, ot, "YS"))
+    np.testing.assert_array_equal(rl.windowed_run_count(da, 3).values, orl.windowed_run_count(mf, 3))
+    np.testing.assert_array_equal(rl.windowed_run_events(da, 2, freq="MS").values, orl.windowed_run_events(mf, 2, ot, "MS"))
+    np.testing.assert_array_equal(rl.first_run(da, 4).values, orl.first_run(mf, 4))
+    idx = orl.last_run(mf, 4)
+    np.testing.assert_array_equal(rl.last_run(da, 4, coord="dayofyear").values,
+                                  np.where(np.isnan(idx), np.nan, ot.doy[np.nan_to_num(idx).astype(int)]))
+    np.testing.assert_array_equal(rl.rle(da).values, orl.rle(mf))
+    out = rl.resample_and_rl(da, True, rl.rle_statistics, reducer="max", window=1, freq="YS")
+    np.testing.assert_array_equal(out.values, orl.resample_and_rl(mf, True, orl.rle_statistics, "max", 1, time=ot, freq="YS"))
+    with pytest.raises(AssertionError, match="was reached"):   # other dims than time are the reference's business
+        rl.longest_run(da, dim="lat")
+
+
+def test_sdba_quantile_wrapper(ref, dev, rng):
+    env = ref[0]
+    w = make_wrappers(env, device=dev)
+    T = 1500
+    ta = TimeAxis.daily("2001-01-01", T, "noleap")
+    x = _temp(rng, T, (5, 6), nan_frac=0.01)
+    q = osdba.equally_spaced_nodes(20)
+    out = w["sdba_quantile"](fakexr.field(x, ta), q, "time")
+    assert out.dims == ("lat", "lon", "quantiles")
+    np.testing.assert_allclose(np.moveaxis(out.values, -1, 0), osdba.quantile(x.reshape(T, -1), q).reshape(20, 5, 6), rtol=1e-6, equal_nan=True)

@@ -65,13 +65,3 @@ def test_calc_perc_on_the_stack_dim_view(dev, rng, alpha, beta):
     want_med = oq.nan_quantile(keep, np.array([0.5]), axis=-1, alpha=1.0, beta=1.0)[0]
     assert med.shape == (D, Y, X, 1)
     np.testing.assert_allclose(med[..., 0], want_med, rtol=1e-12, equal_nan=True)
-
-
-def test_percentile_doy_wrapper_keeps_wrapped(dev):
-    """core/bootstrapping.py:195 calls percentile_doy.__wrapped__: the tier-1 wrapper must expose it (checked on the
-    wrapper factory's contract without importing xarray: the attribute is set next to the definition)."""
-    import inspect
-
-    src = inspect.getsource(patch._make_wrappers)
-    assert "percentile_doy.__wrapped__ = percentile_doy" in src
-    assert set(patch.__all__) >= {"cumsum_reset_np", "calc_perc", "install"}

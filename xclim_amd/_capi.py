@@ -247,6 +247,7 @@ class Device:
         self.ctx = ctx
         self.index = device
         self.lock = threading.RLock()
+        self.trace = None  # list of (entry point, args) while start_trace() is active
         # Freed buffers are kept per exact size and handed out again: hipMalloc / hipFree cost ~0.1-0.4 ms each and
         # hipFree synchronises the device, which is as long as a whole kernel of this library.  Re-use is safe because
         # every kernel of a context runs on its one stream (stream order protects a buffer that is still being read).
@@ -387,8 +388,20 @@ class Device:
 
     def call(self, name: str, *args):
         """Invoke an entry point with this context as first argument and raise on error."""
+        if self.trace is not None:  # launch log for the adapter tests: (entry point, arguments as passed)
+            self.trace.append((name, args))
         with self.lock:
             _check(self.lib, getattr(self.lib, name)(self.ctx, *args))
+
+    def start_trace(self) -> list:
+        """Record every C-ABI call made through this context from now on: returns the (growing) list of
+        ``(entry point, args)``; :meth:`stop_trace` ends it.  Test instrumentation (tests/test_gpu_adapter.py asserts that
+        tx90p through the xarray wrappers reaches ``xh_threshold_count`` with the per-doy table, cdd ``xh_run_stats``)."""
+        self.trace = []
+        return self.trace
+
+    def stop_trace(self) -> None:
+        self.trace = None
 
 
 _default_device: Device | None = None

@@ -151,10 +151,12 @@ def percentile_exceedance(da, time: TimeAxis, freq: str = "YS", op: str = ">", w
     return _masked(cnt, val, time, freq, dev, cell_shape, mask_missing)
 
 
-def _percentile_spell(da, per: DoyPercentile, window, time, freq, resample_before_rl, op, constrain, device, mask_missing):
+def _percentile_run(da, per: DoyPercentile, stat, window, time, freq, resample_before_rl, op, constrain, dev):
+    """Run statistic `stat` (sum = windowed_run_count, count = windowed_run_events, max ...) of ``da op per[dayofyear]``
+    per period: (out, valid) device arrays.  resample_before_rl: compare, run lengths and valid counts in ONE pass over x
+    and the per-doy table (xh_run_stats_doy); after: compare mask + run statistics across the period edges."""
     from .calendar import _flatten, adjust_doy_calendar, resample_doy_index
 
-    dev = device or get_device()
     sym = generic.get_op(op, constrain)
     x, cell_shape = _flatten(da, dev)
     doy = adjust_doy_calendar(per, time, dev)
@@ -163,13 +165,30 @@ def _percentile_spell(da, per: DoyPercentile, window, time, freq, resample_befor
     table = doy.data.reshape(doy.data.shape[1], doy.data.shape[2])
     seg, _ = time.segments(freq)
     tidx = resample_doy_index(doy, time)
-    # rl.windowed_run_count: total length of the runs of at least `window` steps (run_length.py:437-488)
-    if resample_before_rl:  # compare, run lengths and valid counts in one pass over x and the table
-        out, val = K.run_stats_doy(dev, x, sym, table, tidx, "sum", window, seg)
+    if resample_before_rl:
+        out, val = K.run_stats_doy(dev, x, sym, table, tidx, stat, window, seg)
     else:
         mask = K.compare_doy(dev, x, sym, table, tidx)
-        out, _ = K.run_stats(dev, mask, "sum", window, seg, cut=False, want_valid=False)
+        out, _ = K.run_stats(dev, mask, stat, window, seg, cut=False, want_valid=False)
         _, val = K.resample_reduce(dev, x, "count", seg)
+    return out, val, cell_shape
+
+
+def percentile_run_stat(da, per: DoyPercentile, op: str, stat: str, window: int, time: TimeAxis, freq: str,
+                        resample_before_rl: bool = True, *, constrain=None, device=None):
+    """``rl.resample_and_rl(compare(da, op, resample_doy(per, da)), resample_before_rl, rl.<stat function>, window, freq)``
+    of the reference (indices/_multivariate.py:137-152, 1778-1793) without the (T, Y, X) float64 threshold and without the
+    mask: numpy (P, *cells) float32, no missing-value mask (the building-block form used by xr_adapter.resample_and_rl)."""
+    dev = device or get_device()
+    out, _, cell_shape = _percentile_run(da, per, stat, window, time, freq, resample_before_rl, op, constrain, dev)
+    o = out.get()
+    return o.reshape((o.shape[0],) + tuple(cell_shape))
+
+
+def _percentile_spell(da, per: DoyPercentile, window, time, freq, resample_before_rl, op, constrain, device, mask_missing):
+    dev = device or get_device()
+    # rl.windowed_run_count: total length of the runs of at least `window` steps (run_length.py:437-488)
+    out, val, cell_shape = _percentile_run(da, per, "sum", window, time, freq, resample_before_rl, op, constrain, dev)
     return _masked(out, val, time, freq, dev, cell_shape, mask_missing)
 
 

@@ -11,11 +11,13 @@ Two tiers, as the reference resolves its own hot path:
   - :func:`calc_perc` replaces ``xclim.core.utils.calc_perc`` (core/utils.py:279-323, imported at call time by
     ``percentile_doy``, core/calendar.py:441, 469-479): ``(…, stack_dim)`` strided view -> ``(…, nper)``.
 
-* **tier 1 — module attributes** (same-signature functions on ``xr.DataArray``): :func:`install` patches them when xarray
-  and xclim are importable.  xarray cannot be installed in the build environment, so this part is exercised only where
-  it is (``python -c "import xclim_amd.patch as p; p.install()"`` then the reference's own test-suite); the wrappers
-  are deliberately thin: unwrap ``.values`` with time first, call the host mirror, re-wrap with the coordinates of the
-  reference's own resample template.
+* **tier 1 — module attributes** (same-signature functions on ``xr.DataArray``, xclim_amd/xr_adapter.py):
+  :func:`install` replaces them in every module that holds them (``rl.*`` through the module object, the generic /
+  calendar functions also in the index modules that imported them by name, ``calc_perc`` at its definition).  xarray is
+  not installable in the build environment, so the wrappers take what they need from xarray / xclim through an ``Env``
+  and are EXECUTED in tests/test_gpu_adapter.py against a small DataArray stand-in (tests/fakexr.py) installed into
+  stand-in modules with the reference's import structure; with the real packages:
+  ``python -c "import xclim_amd.patch as p; print(p.install())"``.
 
 ``percentile_doy`` keeps a ``__wrapped__`` attribute because ``bootstrap_func`` calls ``percentile_doy.__wrapped__``
 (core/bootstrapping.py:195).
@@ -29,7 +31,7 @@ from . import kernels as K
 from . import utils as _hutl
 from ._capi import get_device
 
-__all__ = ["cumsum_reset_np", "calc_perc", "install", "uninstall"]
+__all__ = ["cumsum_reset_np", "calc_perc", "install", "uninstall", "real_env"]
 
 
 # ---- tier 2 --------------------------------------------------------------------------------------------------------
@@ -70,81 +72,104 @@ def calc_perc(arr: np.ndarray, percentiles=None, alpha: float = 1.0, beta: float
 # ---- tier 1 (needs xarray + xclim) ----------------------------------------------------------------------------------
 _saved: dict = {}
 
+# reference module -> names imported BY NAME there (/root/reference/src/xclim/indices/_threshold.py:25-36,
+# _multivariate.py:13, 22-24, _simple.py:10, _hydrology.py:14, _anuclim.py:26, core/bootstrapping.py:17, indices/stats.py:23);
+# a name is only replaced where the module really holds it (hasattr), so the table may list more than a version imports
+_GENERIC_NAMES = ("threshold_count", "count_occurrences", "domain_count", "select_resample_op", "spell_length_statistics",
+                  "cumulative_difference", "compare")
+_BY_NAME = {
+    "xclim.indices.generic": _GENERIC_NAMES,
+    "xclim.indices._threshold": _GENERIC_NAMES,
+    "xclim.indices._multivariate": _GENERIC_NAMES + ("percentile_doy", "resample_doy"),
+    "xclim.indices._simple": _GENERIC_NAMES,
+    "xclim.indices._hydrology": _GENERIC_NAMES,
+    "xclim.indices._anuclim": _GENERIC_NAMES,
+    "xclim.indices._agro": _GENERIC_NAMES + ("percentile_doy", "resample_doy"),
+    "xclim.indices._conversion": _GENERIC_NAMES,
+    "xclim.core.calendar": ("percentile_doy", "resample_doy"),
+    "xclim.core.bootstrapping": ("percentile_doy",),
+    "xclim.indices.stats": ("percentile_doy",),
+    # rl.* is always reached through the module object: patching the module attributes is enough (gen:37, _threshold.py:25)
+    "xclim.indices.run_length": ("rle", "rle_statistics", "longest_run", "windowed_run_events", "windowed_run_count",
+                                 "first_run", "last_run", "season_length", "resample_and_rl"),
+    "xclim.core.utils": ("calc_perc",),
+}
 
-def _time_axis(da):
-    from .timeaxis import TimeAxis
 
-    t = da["time"].dt
-    return TimeAxis(t.year.values, t.month.values, t.day.values, str(t.calendar))
-
-
-def _tfirst_f32(da):
-    return np.ascontiguousarray(da.transpose("time", ...).values, dtype=np.float32)
-
-
-def _make_wrappers():
+def real_env():
+    """The :class:`xr_adapter.Env` of an installation that has xarray and xclim."""
     import xarray as xr
+    from xclim.core.calendar import build_climatology_bounds
+    from xclim.core.units import convert_units_to, pint2cfattrs, to_agg_units, units2pint
 
-    from . import calendar as hcal
-    from . import generic as hgen
+    from .xr_adapter import Env
 
-    def threshold_count(da, op, threshold, freq, constrain=None):  # indices/generic.py:329-361
-        thr = threshold.transpose("time", ...).values if isinstance(threshold, xr.DataArray) else threshold
-        out = hgen.threshold_count(_tfirst_f32(da), op, thr, _time_axis(da), freq, constrain)
-        tmpl = da.transpose("time", ...).resample(time=freq).first(skipna=False)  # period labels / coordinates only
-        return tmpl.copy(data=np.asarray(out).astype("int64").reshape(tmpl.shape))
+    def finish_select_resample_op(out, da, op, out_units):  # the tail of indices/generic.py:118-125
+        if out_units is not None:
+            return out.assign_attrs(units=out_units)
+        if op in ("std", "var"):
+            out.attrs.update(pint2cfattrs(units2pint(out.attrs["units"]), is_difference=True))
+        return to_agg_units(out, da, op)
 
-    def percentile_doy(arr, window=5, per=10.0, alpha=1.0 / 3.0, beta=1.0 / 3.0, copy=True):  # core/calendar.py:395-494
-        from xclim.core.calendar import build_climatology_bounds
-
-        pers = [per] if np.isscalar(per) else list(per)
-        a = arr.transpose("time", ...)
-        p = hcal.percentile_doy(_tfirst_f32(a), _time_axis(a), window=window, per=pers, alpha=alpha, beta=beta)
-        data = p.values()  # (ndoy, *cells, nper): the reference's dim order
-        dims = ("dayofyear",) + tuple(d for d in a.dims if d != "time") + ("percentiles",)
-        coords = {d: a[d] for d in a.dims if d != "time" and d in a.coords}
-        coords.update(dayofyear=np.asarray(p.dayofyear), percentiles=pers)
-        out = xr.DataArray(data, dims=dims, coords=coords, attrs=dict(arr.attrs), name="per")
-        out.attrs.update(climatology_bounds=build_climatology_bounds(arr), window=window, alpha=alpha, beta=beta)
-        return out
-
-    percentile_doy.__wrapped__ = percentile_doy  # bootstrap_func calls percentile_doy.__wrapped__ (bootstrapping.py:195)
-    return {"threshold_count": threshold_count, "percentile_doy": percentile_doy}
+    return Env(xr.DataArray, convert_units_to, to_agg_units, finish_select_resample_op, build_climatology_bounds)
 
 
-def install() -> list[str]:
-    """Patch the reference's module attributes (SURVEY.md §8b resolution rules); returns the patched names.
+def install(env=None, modules=None) -> list[str]:
+    """Replace the reference's hot-path functions (SURVEY.md §8b resolution rules); returns the patched names.
 
-    ``rl.*`` is always reached through the module object, ``threshold_count`` / ``percentile_doy`` are imported BY NAME
-    into the index modules and must be replaced in each of them, ``calc_perc`` is imported at call time."""
+    ``env`` / ``modules``: dependency injection for the tests (tests/test_gpu_adapter.py installs the wrappers into
+    stand-in modules with the reference's import structure, because xarray / xclim are not installable there);
+    by default the real packages are used.  Functions the HIP path does not serve are forwarded to the saved originals."""
     import importlib
 
-    wrappers = _make_wrappers()
+    from .xr_adapter import make_wrappers
+
+    env = env or real_env()
+
+    def resolve(modname):
+        if modules is not None:
+            return modules.get(modname)
+        try:
+            return importlib.import_module(modname)
+        except ImportError:
+            return None
+
+    orig = {}  # the reference's own functions, for the calls the HIP path forwards
+    for modname in ("xclim.indices.generic", "xclim.indices.run_length", "xclim.core.calendar", "xclim.core.utils"):
+        mod = resolve(modname)
+        for name in _BY_NAME[modname]:
+            if mod is not None and hasattr(mod, name):
+                orig.setdefault(name, _saved.get((modname, name), getattr(mod, name)))
+    wrappers = make_wrappers(env, orig)
+    wrappers["_cumsum_reset_np"] = cumsum_reset_np
     done = []
 
     def patch(modname, attr, fn):
-        try:
-            mod = importlib.import_module(modname)
-        except ImportError:
-            return
-        if hasattr(mod, attr):
+        mod = resolve(modname)
+        if mod is not None and hasattr(mod, attr):
             _saved.setdefault((modname, attr), getattr(mod, attr))
             setattr(mod, attr, fn)
             done.append(f"{modname}.{attr}")
 
+    for modname, names in _BY_NAME.items():
+        for name in names:
+            patch(modname, name, wrappers[name])
     patch("xclim.indices.run_length", "_cumsum_reset_np", cumsum_reset_np)
-    patch("xclim.core.utils", "calc_perc", calc_perc)
-    for modname in ("xclim.indices.generic", "xclim.indices._threshold", "xclim.indices._multivariate",
-                    "xclim.indices._simple", "xclim.indices._hydrology", "xclim.indices._anuclim"):
-        patch(modname, "threshold_count", wrappers["threshold_count"])
-    for modname in ("xclim.core.calendar", "xclim.indices._multivariate", "xclim.core.bootstrapping", "xclim.indices.stats"):
-        patch(modname, "percentile_doy", wrappers["percentile_doy"])
+    # xsdba (third party, re-exported by src/xclim/sdba.py:10): the per-cell multi-quantile entry point; xsdba's own
+    # modules reach it through the module object (``nbu.quantile``), so the one attribute is enough
+    patch("xsdba.nbutils", "quantile", wrappers["sdba_quantile"])
+    _saved_modules.update({} if modules is None else modules)
     return done
+
+
+_saved_modules: dict = {}
 
 
 def uninstall() -> None:
     import importlib
 
     for (modname, attr), fn in _saved.items():
-        setattr(importlib.import_module(modname), attr, fn)
+        mod = _saved_modules.get(modname) or importlib.import_module(modname)
+        setattr(mod, attr, fn)
     _saved.clear()
+    _saved_modules.clear()

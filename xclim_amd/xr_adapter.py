@@ -1,0 +1,448 @@
+"""Tier 1 of the drop-in boundary: same-signature replacements of the reference's hot-path functions
+that take and return ``xarray.DataArray`` — unwrap (time first), call the host mirror (-> HIP kernels), re-wrap with the
+coordinates and unit attributes the reference would give.
+
+Nothing here imports xarray or xclim: the few things the wrappers need from them come in through an :class:`Env`
+(``patch.install()`` builds it from the real packages; tests/fakexr.py provides a ~150-line stand-in so that every
+wrapper is EXECUTED on the GPU box, where xarray is not installable).  What a DataArray has to offer (real or fake):
+
+    da.dims, da.dtype, da.attrs, da.name, da.values, da.coords, da[name], da.transpose("time", ...),
+    da["time"].dt.{year, month, day, dayofyear, calendar}, da["time"].resample(time=freq).first()  (period labels),
+    Env.DataArray(data, coords=..., dims=..., name=..., attrs=...), isinstance(x, Env.DataArray)
+
+Reference functions replaced (signatures identical, file:line of the original):
+
+    indices/generic.py      threshold_count :329, count_occurrences :960, domain_count :364, select_resample_op :83,
+                            spell_length_statistics :588, cumulative_difference :1514, compare :301
+    core/calendar.py        percentile_doy :395, resample_doy :763
+    indices/run_length.py   rle :223, rle_statistics :275, longest_run :338, windowed_run_events :381,
+                            windowed_run_count :437, first_run :643, last_run :693, season_length :1113,
+                            resample_and_rl :87, _cumsum_reset_np :143
+    core/utils.py           calc_perc :279
+    xsdba (when importable) nbutils.quantile
+
+The chain of an index stays on the fused kernels the benchmark measures: ``resample_doy`` returns a :class:`DoyThreshold`
+(the per-doy table on the device + the target time axis — NOT the (time, lat, lon) float64 field of the reference),
+``threshold_count`` takes it through ``XH_THR_DOY_F64``; ``compare`` of a DataArray with a DoyThreshold returns a
+:class:`LazyCompare` that ``resample_and_rl`` runs as ONE fused launch (``xh_run_stats_doy``); ``spell_length_statistics``
+with window 1 (maximum_consecutive_dry_days ...) is the fused compare + run-length kernel.  Both lazy objects turn into
+real DataArrays the moment anything else touches them (attribute access / arithmetic), so code that was not replaced
+keeps working.  A call a wrapper cannot serve (callable ``op``, thresholds with unexpected dims, ``dim != "time"``) is
+forwarded to the ORIGINAL function (``orig``), never approximated.
+"""
+
+from __future__ import annotations
+
+import operator
+
+import numpy as np
+
+from . import calendar as hcal
+from . import generic as hgen
+from . import run_length as hrl
+from . import utils as hutl
+from ._capi import get_device
+from .timeaxis import TimeAxis
+
+__all__ = ["Env", "DoyThreshold", "LazyCompare", "make_wrappers", "time_axis_of"]
+
+
+class Env:
+    """What the wrappers need from xarray / xclim.  ``convert_units_to(threshold, data, context=None)`` -> float or
+    DataArray in the units of ``data``; ``to_agg_units(out, orig, op, dim="time")`` -> ``out`` with the units of the
+    aggregation; ``finish_select_resample_op(out, da, op, out_units)`` = the tail of gen:118-125."""
+
+    def __init__(self, DataArray, convert_units_to, to_agg_units, finish_select_resample_op=None,
+                 build_climatology_bounds=None):
+        self.DataArray = DataArray
+        self.convert_units_to = convert_units_to
+        self.to_agg_units = to_agg_units
+        self.finish_select_resample_op = finish_select_resample_op or (lambda out, da, op, out_units: out)
+        self.build_climatology_bounds = build_climatology_bounds
+
+
+def time_axis_of(da) -> TimeAxis:
+    t = da["time"].dt
+    return TimeAxis(np.asarray(t.year.values), np.asarray(t.month.values), np.asarray(t.day.values), str(t.calendar))
+
+
+def _tfirst(da):
+    """The DataArray with time first and its values as a C-contiguous array in the array's OWN dtype."""
+    a = da.transpose("time", ...)
+    return a, np.ascontiguousarray(a.values)
+
+
+def _cell_dims(a):
+    return tuple(d for d in a.dims if d != "time")
+
+
+def _cell_coords(a):
+    return {k: v for k, v in a.coords.items() if "time" not in getattr(v, "dims", ())}
+
+
+class _LazyBase:
+    """Proxy: anything but the wrappers sees the materialised DataArray."""
+
+    _da = None
+
+    def materialize(self):
+        raise NotImplementedError
+
+    def _get(self):
+        if self._da is None:
+            self._da = self.materialize()
+        return self._da
+
+    def __getattr__(self, name):  # only reached for attributes the proxy does not define itself
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return getattr(self._get(), name)
+
+    def __getitem__(self, key):
+        return self._get()[key]
+
+    def __array__(self, dtype=None, copy=None):
+        v = np.asarray(self._get().values)
+        return v.astype(dtype) if dtype is not None else v
+
+
+def _delegate(opname):
+    fn = getattr(operator, opname)
+
+    def method(self, other):
+        return fn(self._get(), other)
+
+    def rmethod(self, other):
+        return fn(other, self._get())
+
+    return method, rmethod
+
+
+for _op, _dunder in (("add", "add"), ("sub", "sub"), ("mul", "mul"), ("truediv", "truediv"), ("gt", "gt"), ("lt", "lt"),
+                     ("ge", "ge"), ("le", "le"), ("eq", "eq"), ("ne", "ne"), ("and_", "and"), ("or_", "or")):
+    _m, _r = _delegate(_op)
+    setattr(_LazyBase, f"__{_dunder}__", _m)
+    if _dunder in ("add", "sub", "mul", "truediv", "and", "or"):
+        setattr(_LazyBase, f"__r{_dunder}__", _r)
+_LazyBase.__hash__ = object.__hash__
+
+
+class DoyThreshold(_LazyBase):
+    """Result of the patched ``resample_doy(doy, arr)`` (cal:763-790): the per-doy table (device, float64) + the time
+    axis and coordinates of ``arr``.  ``threshold_count`` / ``compare`` consume it without the (T, Y, X) float64 field."""
+
+    def __init__(self, env, doy: hcal.DoyPercentile, like, time: TimeAxis, device):
+        self._env, self.doy, self.like, self.time, self._dev = env, doy, like, time, device
+
+    def materialize(self):
+        a = self.like.transpose("time", ...)
+        data = hcal.resample_doy(self.doy, self.time, device=self._dev)
+        coords = dict(_cell_coords(a))
+        coords["time"] = a["time"]
+        return self._env.DataArray(data, coords=coords, dims=a.dims, attrs=dict(self.doy.attrs))
+
+
+class LazyCompare(_LazyBase):
+    """``compare(da, op, DoyThreshold)``: the mask is only formed when something other than ``resample_and_rl`` /
+    ``threshold_count`` asks for it."""
+
+    def __init__(self, env, da, op, thr: DoyThreshold, constrain, device):
+        self._env, self.da, self.op, self.thr, self.constrain, self._dev = env, da, op, thr, constrain, device
+
+    def materialize(self):
+        from . import kernels as K
+
+        a, x = _tfirst(self.da)
+        dev, doy = self._dev, hcal.adjust_doy_calendar(self.thr.doy, self.thr.time, self._dev)
+        xd, _ = hcal._flatten(x, dev)
+        table = doy.data.reshape(doy.data.shape[1], doy.data.shape[2])
+        # x[t] OP table[dayofyear(t)] compared in float64 like numpy does for float32 data against a float64 threshold
+        m = K.compare_doy(dev, xd, hgen.get_op(self.op, self.constrain), table, hcal.resample_doy_index(doy, self.thr.time))
+        coords = dict(_cell_coords(a))
+        coords["time"] = a["time"]
+        return self._env.DataArray(m.get().reshape(x.shape) != 0, coords=coords, dims=a.dims)
+
+
+def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
+    """name -> callable.  ``orig``: the reference's own functions by the same names (fallback for calls the HIP path does
+    not serve; absent in the tests, where such calls raise NotImplementedError)."""
+    orig = orig or {}
+    DA = env.DataArray
+
+    def dev():
+        return device or get_device()
+
+    def fallback(name, *args, **kwargs):
+        if name in orig:
+            return orig[name](*args, **kwargs)
+        raise NotImplementedError(f"{name}: this call is not served by the HIP path and no original function was supplied")
+
+    def wrap_periods(a, data, freq, attrs=None, name=None):
+        """(P, *cells) -> DataArray(time = period labels of the reference's own resample, *cell dims)."""
+        labels = a["time"].resample(time=freq).first()["time"]
+        coords = dict(_cell_coords(a))
+        coords["time"] = labels
+        data = np.asarray(data)
+        return DA(data.reshape((len(labels.values),) + data.shape[1:]), coords=coords, dims=("time",) + _cell_dims(a),
+                  attrs=dict(attrs or {}), name=name)
+
+    def wrap_cells(a, data, attrs=None, name=None):
+        return DA(np.asarray(data), coords=_cell_coords(a), dims=_cell_dims(a), attrs=dict(attrs or {}), name=name)
+
+    def wrap_full(a, data, attrs=None, name=None):
+        coords = dict(_cell_coords(a))
+        coords["time"] = a["time"]
+        return DA(np.asarray(data), coords=coords, dims=a.dims, attrs=dict(attrs or {}), name=name)
+
+    def as_threshold(thr, a):
+        """float | per-cell array (cell dims of `a`) | full array (dims of `a`) | DoyPercentile; None = not servable."""
+        if isinstance(thr, DoyThreshold):
+            return thr.doy
+        if isinstance(thr, _LazyBase):
+            thr = thr._get()
+        if isinstance(thr, DA):
+            if set(thr.dims) == set(a.dims):
+                return np.ascontiguousarray(thr.transpose(*a.dims).values)
+            if set(thr.dims) == set(_cell_dims(a)):
+                return np.ascontiguousarray(thr.transpose(*_cell_dims(a)).values)
+            if len(thr.dims) == 0:
+                return thr.values[()]
+            return None
+        if np.ndim(thr) == 0:
+            return thr
+        return None
+
+    # ---- indices/generic.py ---------------------------------------------------------------------------------------
+    def threshold_count(da, op, threshold, freq, constrain=None):  # gen:329-361
+        if isinstance(threshold, LazyCompare) or not isinstance(da, DA):
+            return fallback("threshold_count", da, op, threshold, freq, constrain)
+        a, x = _tfirst(da)
+        thr = as_threshold(threshold, a)
+        if thr is None:
+            return fallback("threshold_count", da, op, threshold, freq, constrain)
+        out = hgen.threshold_count(x, op, thr, time_axis_of(a), freq, constrain, device=dev())
+        return wrap_periods(a, np.asarray(out).astype(np.int64), freq)  # (bool * 1).resample.sum: int64, no attrs
+
+    def count_occurrences(data, threshold, freq, op, constrain=None):  # gen:960-999
+        a, x = _tfirst(data)
+        thr = as_threshold(env.convert_units_to(threshold, data), a)
+        if thr is None:
+            return fallback("count_occurrences", data, threshold, freq, op, constrain)
+        out = hgen.count_occurrences(x, thr, op, time_axis_of(a), freq, constrain, device=dev())
+        return env.to_agg_units(wrap_periods(a, np.asarray(out).astype(np.int64), freq, data.attrs), data, "count", dim="time")
+
+    def domain_count(da, low, high, freq):  # gen:364-392
+        if np.ndim(low) != 0 or np.ndim(high) != 0 or isinstance(low, DA) or isinstance(high, DA):
+            return fallback("domain_count", da, low, high, freq)
+        a, x = _tfirst(da)
+        out = hgen.domain_count(x, low, high, time_axis_of(a), freq, device=dev())
+        return wrap_periods(a, np.asarray(out).astype(np.int64), freq)
+
+    def select_resample_op(da, op, freq="YS", out_units=None, **indexer):  # gen:83-125
+        if not isinstance(op, str):
+            return fallback("select_resample_op", da, op, freq, out_units, **indexer)
+        a, x = _tfirst(da)
+        out = hgen.select_resample_op(x, op, time_axis_of(a), freq, device=dev(), **indexer)
+        o = wrap_periods(a, out, freq, da.attrs, da.name)
+        return env.finish_select_resample_op(o, da, op, out_units)
+
+    def spell_length_statistics(data, threshold, window, win_reducer, op, spell_reducer, freq, min_gap=1,
+                                resample_before_rl=True, **indexer):  # gen:588-686 -> 543-585
+        if not isinstance(data, DA):
+            return fallback("spell_length_statistics", data, threshold, window, win_reducer, op, spell_reducer, freq,
+                            min_gap=min_gap, resample_before_rl=resample_before_rl, **indexer)
+        a, x = _tfirst(data)
+        thr = as_threshold(env.convert_units_to(threshold, data, context="infer"), a)
+        if thr is None or isinstance(thr, hcal.DoyPercentile):
+            return fallback("spell_length_statistics", data, threshold, window, win_reducer, op, spell_reducer, freq,
+                            min_gap=min_gap, resample_before_rl=resample_before_rl, **indexer)
+        reducers = [spell_reducer] if isinstance(spell_reducer, str) else list(spell_reducer)
+        outs = []
+        for sr in reducers:
+            o = hgen.spell_length_statistics(x, thr, window, win_reducer, op, sr, time_axis_of(a), freq, min_gap,
+                                             resample_before_rl, device=dev(), **indexer)
+            w = wrap_periods(a, o, freq, data.attrs)
+            if sr == "count":
+                w.attrs["units"] = ""
+                outs.append(w)
+            else:
+                outs.append(env.to_agg_units(w, data, "count"))
+        return outs[0] if len(outs) == 1 else tuple(outs)
+
+    def cumulative_difference(data, threshold, op, freq=None):  # gen:1514-1552
+        if freq is None:
+            return fallback("cumulative_difference", data, threshold, op, freq)
+        a, x = _tfirst(data)
+        thr = as_threshold(env.convert_units_to(threshold, data), a)
+        if thr is None or np.ndim(thr) != 0:
+            return fallback("cumulative_difference", data, threshold, op, freq)
+        out = hgen.cumulative_difference(x, float(thr), op, time_axis_of(a), freq, device=dev())
+        return env.to_agg_units(wrap_periods(a, out, freq, data.attrs), data, op="integral")
+
+    def compare(left, op, right, constrain=None):  # gen:301-326
+        if isinstance(right, DoyThreshold) and isinstance(left, DA):
+            hgen.get_op(op, constrain)  # the reference's ValueError for an unknown / constrained operator comes first
+            return LazyCompare(env, left, op, right, constrain, dev())
+        if isinstance(left, _LazyBase):
+            left = left._get()
+        if isinstance(right, _LazyBase):
+            right = right._get()
+        if not isinstance(left, DA):
+            return fallback("compare", left, op, right, constrain)
+        a, x = _tfirst(left) if "time" in left.dims else (left, np.ascontiguousarray(left.values))
+        thr = as_threshold(right, a) if "time" in left.dims else (right if np.ndim(right) == 0 and not isinstance(right, DA) else None)
+        if thr is None:
+            return fallback("compare", left, op, right, constrain)
+        if np.ndim(thr) == x.ndim - 1 and np.ndim(thr) > 0:
+            thr = np.broadcast_to(thr, x.shape)
+        data = hgen.compare(x if x.ndim > 1 else x[:, None], op, thr if np.ndim(thr) == 0 or x.ndim > 1 else thr[:, None],
+                            constrain, device=dev())
+        data = np.asarray(data).astype(bool).reshape(x.shape)
+        return DA(data, coords=dict(a.coords), dims=a.dims)
+
+    # ---- core/calendar.py -----------------------------------------------------------------------------------------
+    def percentile_doy(arr, window=5, per=10.0, alpha=1.0 / 3.0, beta=1.0 / 3.0, copy=True):  # cal:395-494
+        pers = [per] if np.isscalar(per) else list(per)
+        a, x = _tfirst(arr)
+        p = hcal.percentile_doy(x, time_axis_of(a), window=window, per=pers, alpha=alpha, beta=beta, device=dev())
+        coords = dict(_cell_coords(a))
+        coords.update(dayofyear=np.asarray(p.dayofyear), percentiles=np.asarray(pers, dtype=np.float64))
+        out = DA(p.values(), coords=coords, dims=("dayofyear",) + _cell_dims(a) + ("percentiles",), attrs=dict(arr.attrs),
+                 name="per")
+        bounds = env.build_climatology_bounds(arr) if env.build_climatology_bounds else p.attrs["climatology_bounds"]
+        out.attrs.update(climatology_bounds=bounds, window=window, alpha=alpha, beta=beta)
+        return out
+
+    percentile_doy.__wrapped__ = percentile_doy  # bootstrap_func calls percentile_doy.__wrapped__ (bootstrapping.py:195)
+
+    def resample_doy(doy, arr):  # cal:763-790
+        if not isinstance(doy, DA) or "dayofyear" not in doy.dims or "percentiles" in doy.dims or "time" not in arr.dims:
+            return fallback("resample_doy", doy, arr)
+        a = arr.transpose("time", ...)
+        cd = _cell_dims(a)
+        if set(doy.dims) != {"dayofyear", *cd}:
+            return fallback("resample_doy", doy, arr)
+        table = np.ascontiguousarray(doy.transpose("dayofyear", *cd).values, dtype=np.float64)
+        D = table.shape[0]
+        d = dev()
+        data = d.to_device(table.reshape(1, D, -1), dtype=np.float64)
+        dp = hcal.DoyPercentile(data, np.asarray(doy["dayofyear"].values), [np.nan], table.shape[1:], dict(doy.attrs))
+        return DoyThreshold(env, dp, arr, time_axis_of(a), d)
+
+    # ---- indices/run_length.py ------------------------------------------------------------------------------------
+    def _mask_values(da):
+        """(a, values, time axis) of a mask-like DataArray / LazyCompare; LazyCompare stays lazy for resample_and_rl only."""
+        if isinstance(da, _LazyBase):
+            da = da._get()
+        a, x = _tfirst(da)
+        if x.dtype == bool:
+            x = x.astype(np.float32)
+        return a, x, time_axis_of(a)
+
+    def _rl_out(a, out, freq, name=None):
+        return wrap_cells(a, out, name=name) if freq is None else wrap_periods(a, out, freq, name=name)
+
+    def rle(da, dim="time", index="first"):  # rl:223-272
+        if dim != "time":
+            return fallback("rle", da, dim, index)
+        a, x, _ = _mask_values(da)
+        return wrap_full(a, hrl.rle(x, dim, index, device=dev()), da.attrs if isinstance(da, DA) else None)
+
+    def rle_statistics(da, reducer, window, dim="time", freq=None, ufunc_1dim="from_context", index="first"):  # rl:275-335
+        if dim != "time":
+            return fallback("rle_statistics", da, reducer, window, dim, freq, ufunc_1dim, index)
+        a, x, t = _mask_values(da)
+        return _rl_out(a, hrl.rle_statistics(x, reducer, window, dim, freq, ufunc_1dim, index, time=t, device=dev()), freq)
+
+    def longest_run(da, dim="time", freq=None, ufunc_1dim="from_context", index="first"):  # rl:338-378
+        if dim != "time":
+            return fallback("longest_run", da, dim, freq, ufunc_1dim, index)
+        a, x, t = _mask_values(da)
+        return _rl_out(a, hrl.longest_run(x, dim, freq, ufunc_1dim, index, time=t, device=dev()), freq)
+
+    def windowed_run_events(da, window, dim="time", freq=None, ufunc_1dim="from_context", index="first"):  # rl:381-434
+        if dim != "time":
+            return fallback("windowed_run_events", da, window, dim, freq, ufunc_1dim, index)
+        a, x, t = _mask_values(da)
+        return _rl_out(a, hrl.windowed_run_events(x, window, dim, freq, ufunc_1dim, index, time=t, device=dev()), freq)
+
+    def windowed_run_count(da, window, dim="time", freq=None, ufunc_1dim="from_context", index="first"):  # rl:437-488
+        if dim != "time":
+            return fallback("windowed_run_count", da, window, dim, freq, ufunc_1dim, index)
+        a, x, t = _mask_values(da)
+        return _rl_out(a, hrl.windowed_run_count(x, window, dim, freq, ufunc_1dim, index, time=t, device=dev()), freq)
+
+    def _boundary(name, host, da, window, dim, freq, coord, ufunc_1dim):
+        if dim != "time" or coord not in (None, False, "dayofyear", "year", "month", "day"):
+            return fallback(name, da, window, dim, freq, coord, ufunc_1dim)  # coord=True: datetime labels (reference path)
+        a, x, t = _mask_values(da)
+        return _rl_out(a, host(x, window, dim, freq, coord or None, ufunc_1dim, time=t, device=dev()), freq)
+
+    def first_run(da, window, dim="time", freq=None, coord=None, ufunc_1dim="from_context"):  # rl:643-690
+        return _boundary("first_run", hrl.first_run, da, window, dim, freq, coord, ufunc_1dim)
+
+    def last_run(da, window, dim="time", freq=None, coord=None, ufunc_1dim="from_context"):  # rl:693-740
+        return _boundary("last_run", hrl.last_run, da, window, dim, freq, coord, ufunc_1dim)
+
+    def season_length(da, window, mid_date=None, dim="time"):  # rl:1113-1145
+        if dim != "time":
+            return fallback("season_length", da, window, mid_date, dim)
+        a, x, t = _mask_values(da)
+        return wrap_cells(a, hrl.season_length(x, window, mid_date, dim, time=t, device=dev()))
+
+    rl_host = {}  # wrapper -> host mirror, for resample_and_rl (which receives the function OBJECT rl.<name>)
+
+    def resample_and_rl(da, resample_before_rl, compute, *args, freq, dim="time", **kwargs):  # rl:87-132
+        host = rl_host.get(compute)
+        if host is None or dim != "time":
+            return fallback("resample_and_rl", da, resample_before_rl, compute, *args, freq=freq, dim=dim, **kwargs)
+        if isinstance(da, LazyCompare) and compute in (windowed_run_count, windowed_run_events, rle_statistics, longest_run) \
+                and da._da is None and kwargs.get("index", "first") == "first":
+            # compare(da, op, resample_doy(per, da)) -> run statistic: ONE fused launch on the per-doy table
+            # (xh_run_stats_doy; the host mirror is the percentile-spell path of indices.py)
+            from . import indices as hind
+
+            a, x = _tfirst(da.da)
+            params = dict(zip({"rle_statistics": ("reducer", "window"), "longest_run": (), "windowed_run_events": ("window",),
+                               "windowed_run_count": ("window",)}[host.__name__], args))
+            params.update(kwargs)
+            stat = {"rle_statistics": params.get("reducer"), "longest_run": "max", "windowed_run_events": "count",
+                    "windowed_run_count": "sum"}[host.__name__]
+            out = hind.percentile_run_stat(x, da.thr.doy, da.op, stat, int(params.get("window", 1)), time_axis_of(a), freq,
+                                           resample_before_rl, constrain=da.constrain, device=dev())
+            return wrap_periods(a, out, freq)
+        a, x, t = _mask_values(da)
+        out = hrl.resample_and_rl(x, resample_before_rl, host, *args, freq=freq, time=t, dim=dim, device=dev(), **kwargs)
+        return wrap_periods(a, out, freq)
+
+    rl_host.update({rle_statistics: hrl.rle_statistics, longest_run: hrl.longest_run,
+                    windowed_run_events: hrl.windowed_run_events, windowed_run_count: hrl.windowed_run_count,
+                    first_run: hrl.first_run, last_run: hrl.last_run})
+
+    # ---- apply_ufunc callees (tier 2) and xsdba ----------------------------------------------------------------------
+    def calc_perc(arr, percentiles=None, alpha=1.0, beta=1.0, copy=True):  # utl:279-323
+        return hutl.calc_perc(arr, percentiles, alpha, beta, copy, device=dev())
+
+    def sdba_quantile(da, q, dim):  # xsdba.nbutils.quantile(da, q, dim): quantiles along `dim` (a name or a list of names)
+        dims = [dim] if isinstance(dim, str) else list(dim)
+        if dims != ["time"] or not isinstance(da, DA):
+            return fallback("sdba_quantile", da, q, dim)
+        from . import sdba as hsdba
+
+        a, x = _tfirst(da)
+        qs = np.atleast_1d(np.asarray(q, dtype=np.float64))
+        out = hsdba.quantile(x, qs, device=dev())  # (nq, *cells)
+        coords = dict(_cell_coords(a))
+        coords["quantiles"] = qs
+        return DA(np.moveaxis(np.asarray(out), 0, -1), coords=coords, dims=_cell_dims(a) + ("quantiles",), attrs=dict(da.attrs),
+                  name=da.name)
+
+    return {
+        "threshold_count": threshold_count, "count_occurrences": count_occurrences, "domain_count": domain_count,
+        "select_resample_op": select_resample_op, "spell_length_statistics": spell_length_statistics,
+        "cumulative_difference": cumulative_difference, "compare": compare,
+        "percentile_doy": percentile_doy, "resample_doy": resample_doy,
+        "rle": rle, "rle_statistics": rle_statistics, "longest_run": longest_run, "windowed_run_events": windowed_run_events,
+        "windowed_run_count": windowed_run_count, "first_run": first_run, "last_run": last_run, "season_length": season_length,
+        "resample_and_rl": resample_and_rl, "calc_perc": calc_perc, "sdba_quantile": sdba_quantile,
+    }
