@@ -337,6 +337,22 @@ int xh_suspicious_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t
 int xh_nan_quantile(xh_ctx* ctx, const float* x, int64_t N, int64_t C, int64_t sn, int64_t sc, const double* q,
                     int nq, double alpha, double beta, double* out);
 
+/* ---- float64 FIELDS ------------------------------------------------------------------------------------------
+ * The reference computes in the dtype of its input: compare() of a float64 DataArray is a float64 compare
+ * (indices/generic.py:301-326, 360), resample(...).<op>() returns float64 (gen:83-125), _nan_quantile takes `diff` in
+ * float64 (core/utils.py:486).  These three entries take float64 fields as they are (no rounding to float32); same
+ * layouts, segment tables and outputs as their float32 twins, except:
+ *   xh_threshold_count_f64: thr_kind in {XH_THR_SCALAR_F64, XH_THR_DOY_F64, XH_THR_FULL_F64} (float64 tables);
+ *   xh_resample_reduce_f64: float reducers write FLOAT64 `out` (P, C);
+ *   xh_nan_quantile_f64:    N <= 4096 samples per cell, out (nq, C) float64. */
+int xh_threshold_count_f64(xh_ctx* ctx, const double* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, int thr_kind,
+                           double thr_scalar, const double* thr_table, int64_t thr_stride, const int32_t* tidx,
+                           const int64_t* seg_off, int P, int32_t* count_out, int32_t* valid_out);
+int xh_resample_reduce_f64(xh_ctx* ctx, const double* x, int64_t T, int64_t C, int64_t st, int64_t sc, int reducer, int skipna,
+                           const int64_t* seg_off, int P, void* out, int32_t* valid_out);
+int xh_nan_quantile_f64(xh_ctx* ctx, const double* x, int64_t N, int64_t C, int64_t sn, int64_t sc, const double* q, int nq,
+                        double alpha, double beta, double* out);
+
 /* Weighted quantiles over the first axis (ensemble_percentiles with `weights`, ensembles/_base.py:346-356, which calls
  * xarray's DataArrayWeighted.quantile: Kish effective sample size + type-7 weighted estimator, NaN samples and zero
  * weights dropped).  x (N, C) member-major (sc == 1), weights[N] / q[nq] on the host, out (nq, C) float64; N <= 128.

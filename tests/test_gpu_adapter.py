@@ -207,3 +207,22 @@ def test_sdba_quantile_wrapper(ref, dev, rng):
     out = w["sdba_quantile"](fakexr.field(x, ta), q, "time")
     assert out.dims == ("lat", "lon", "quantiles")
     np.testing.assert_allclose(np.moveaxis(out.values, -1, 0), osdba.quantile(x.reshape(T, -1), q).reshape(20, 5, 6), rtol=1e-6, equal_nan=True)
+
+
+def test_float64_dataarrays_keep_their_dtype_or_go_to_the_reference(ref, dev, rng):
+    """threshold_count / count_occurrences / select_resample_op have float64 kernels; every other wrapper forwards a
+    float64 field to the reference's own function (here: the stub that fails loudly) instead of rounding it."""
+    env, mods, _ = ref
+    gen, rl = mods["xclim.indices.generic"], mods["xclim.indices.run_length"]
+    T = 730
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    x = 290.0 + rng.integers(-3, 4, (T, 3, 4)) * 5.684341886080802e-14
+    da = fakexr.field(x, ta)
+    np.testing.assert_array_equal(gen.threshold_count(da, ">", 290.0, "YS").values, ogen.threshold_count(x, ">", 290.0, ot, "YS"))
+    out = gen.select_resample_op(da, "mean", "MS")
+    assert out.dtype == np.float64
+    np.testing.assert_allclose(out.values, ogen.select_resample_op(x, "mean", ot, "MS"), rtol=1e-13)
+    with pytest.raises(AssertionError, match="was reached"):
+        gen.spell_length_statistics(da, 290.0, 1, None, ">", "max", "YS")
+    with pytest.raises(AssertionError, match="was reached"):
+        mods["xclim.core.calendar"].percentile_doy(da)

@@ -491,8 +491,12 @@ def test_device_mask_chaining_and_dtype_guard(dev, rng):
     u8 = K.compare_map(dev, dev.to_device(x.reshape(T, -1)), ">", 0.25, "mask")
     with pytest.raises(TypeError, match="float32"):
         xrl.rle_statistics(u8, "max", 2, device=dev)
+    x64 = dev.to_device(x.astype(np.float64).reshape(T, -1))
     with pytest.raises(TypeError, match="float32"):
-        xgen.threshold_count(dev.to_device(x.astype(np.float64).reshape(T, -1)), ">", 0.0, ta, "YS", device=dev)
+        xgen.spell_length_statistics(x64, 0.0, 1, None, ">", "max", ta, "YS", device=dev)
+    # (threshold_count has a float64 kernel since round 3: the float64 device field is taken as it is)
+    np.testing.assert_array_equal(xgen.threshold_count(x64, ">", 0.0, ta, "YS", device=dev).reshape(-1, 6, 5),
+                                  ogen.threshold_count(x.astype(np.float64), ">", 0.0, ot, "YS"))
 
 
 @pytest.mark.parametrize("shape", [(37, 5, 7), (365, 1003), (1, 3), (50,)])

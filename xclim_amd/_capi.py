@@ -38,6 +38,25 @@ def warn_downcast(a, what: str) -> None:
                       PrecisionWarning, stacklevel=3)
 
 
+class Float64FieldError(TypeError):
+    """A float64 FIELD reached an entry point that only exists for float32 fields.  The reference computes in the input
+    dtype; rounding the field first can flip a count next to a threshold, so it is refused unless asked for."""
+
+
+def handle_float64(a, what: str) -> None:
+    """Policy for float64 fields on float32-only kernels (``XCLIM_AMD_FLOAT64``): "raise" (default) -> Float64FieldError;
+    "round" -> PrecisionWarning and the field is rounded to float32.  threshold_count / count_occurrences /
+    select_resample_op / calc_perc have native float64 kernels (xh_*_f64) and never come here."""
+    if getattr(a, "dtype", None) != np.float64 or getattr(a, "ndim", 0) == 0:
+        return
+    if os.environ.get("XCLIM_AMD_FLOAT64", "raise").lower() == "round":
+        warn_downcast(a, what)
+        return
+    raise Float64FieldError(f"{what}: float64 fields are only served by threshold_count, count_occurrences, select_resample_op and "
+                            "calc_perc (xh_*_f64); cast to float32 yourself, or set XCLIM_AMD_FLOAT64=round to have it "
+                            "rounded with a PrecisionWarning")
+
+
 class BackendUnavailable(RuntimeError):
     """libxclimhip.so is not built/loadable or no MI355X device is visible."""
 
@@ -121,6 +140,9 @@ SIGNATURES: dict[str, list] = {
     "xh_season": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, _vp],
     "xh_max_run_sum": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _int, _int, _vp],
     "xh_nan_quantile": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _dbl, _dbl, _vp],
+    "xh_threshold_count_f64": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _dbl, _vp, _i64, _vp, _vp, _int, _vp, _vp],
+    "xh_resample_reduce_f64": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _int, _vp, _vp],
+    "xh_nan_quantile_f64": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _dbl, _dbl, _vp],
     "xh_weighted_quantile": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp],
     "xh_percentile_doy": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _vp, _int, _dbl, _dbl, _vp],
     "xh_percentile_doy_mapped": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _vp, _int, _dbl, _dbl, _vp, _i64, _vp],

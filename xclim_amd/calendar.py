@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import kernels as K
-from ._capi import DeviceArray, warn_downcast, get_device
+from ._capi import DeviceArray, handle_float64, get_device
 from .timeaxis import TimeAxis
 
 
@@ -53,17 +53,21 @@ def doy_interp_tables(n_src: int, doy_max: int, doy_min: int = 1):
     return lo.astype(np.int32), hi.astype(np.int32), xn - x[lo], x[hi] - x[lo]
 
 
-def _flatten(arr, dev):
-    """(T, *cells) numpy/device array -> (DeviceArray (T, C), cell_shape)."""
+def _flatten(arr, dev, f64: bool = False):
+    """(T, *cells) numpy/device array -> (DeviceArray (T, C), cell_shape).  ``f64``: the caller has a float64 kernel — a
+    float64 field is uploaded as it is; otherwise it is refused (or rounded, ``_capi.handle_float64``)."""
     if isinstance(arr, DeviceArray):
-        if arr.dtype != np.float32:  # the kernels read float32 fields: a uint8 / float64 buffer must not be reinterpreted
+        if arr.dtype != np.float32 and not (f64 and arr.dtype == np.float64):
+            # the kernels read float32 fields: a uint8 / float64 buffer must not be reinterpreted
             raise TypeError(f"device arrays handed to the kernels must be float32, got {np.dtype(arr.dtype).name} "
                             "(masks: use the float mask of compare(..., keep=True))")
         cell_shape = arr.shape[1:]
         return arr.reshape(arr.shape[0], -1), cell_shape
     a = np.asarray(arr)
-    warn_downcast(a, "field")
     cell_shape = a.shape[1:]
+    if f64 and a.dtype == np.float64:
+        return dev.to_device(a.reshape(a.shape[0], -1)), cell_shape
+    handle_float64(a, "field")
     return dev.to_device(a.reshape(a.shape[0], -1), dtype=np.float32), cell_shape
 
 

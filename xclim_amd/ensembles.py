@@ -11,7 +11,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import kernels as K
-from ._capi import DeviceArray, get_device, warn_downcast
+from ._capi import DeviceArray, get_device, handle_float64
 
 # _base.py:21-28
 _quantile_params = {
@@ -42,8 +42,11 @@ def ensemble_percentiles(ens, values=None, min_members: int | None = 1, weights=
     else:
         a = np.asarray(ens)
         lead = a.shape[1:]
-        warn_downcast(a, "ensemble_percentiles")
-        x = dev.to_device(np.ascontiguousarray(a.reshape(a.shape[0], -1), dtype=np.float32))
+        if a.dtype == np.float64 and weights is None:  # float64 members: xh_nan_quantile_f64 (`diff` in float64, utl:486)
+            x = dev.to_device(np.ascontiguousarray(a.reshape(a.shape[0], -1)))
+        else:
+            handle_float64(a, "ensemble_percentiles (weighted)")
+            x = dev.to_device(np.ascontiguousarray(a.reshape(a.shape[0], -1), dtype=np.float32))
     R = x.shape[0]
     if min_members is None:
         min_members = R

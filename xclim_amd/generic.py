@@ -12,7 +12,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import kernels as K
-from ._capi import warn_downcast, OPS, DeviceArray, get_device
+from ._capi import handle_float64, OPS, DeviceArray, get_device
 from .calendar import DoyPercentile, _flatten, adjust_doy_calendar, resample_doy_index
 from .timeaxis import TimeAxis
 
@@ -79,8 +79,13 @@ def threshold_count(da, op: str, threshold, time: TimeAxis, freq: str, constrain
         constrain = (">", "<", ">=", "<=")
     sym = get_op(op, constrain)
     dev = device or get_device()
-    x, cell_shape = _flatten(da, dev)
+    x, cell_shape = _flatten(da, dev, f64=True)  # a float64 field is compared in float64 (xh_threshold_count_f64)
     seg, _ = time.segments(freq)
+    if x.dtype == np.float64 and not isinstance(threshold, (DoyPercentile, DeviceArray)) and np.ndim(threshold) > 0 \
+            and _cell_threshold(dev, threshold, da) is None:
+        full = dev.to_device(np.broadcast_to(np.asarray(threshold), np.shape(da)).reshape(x.shape), dtype=np.float64)
+        cnt, val = K.threshold_count(dev, x, sym, seg, full=full)
+        return _finish(cnt, val, cell_shape, keep, with_valid)
     if isinstance(threshold, DoyPercentile):
         doy = adjust_doy_calendar(threshold, time, dev)
         if doy.data.shape[0] != 1:
@@ -157,7 +162,7 @@ def compare(left, op: str, right, constrain=None, *, device=None, keep=False):
     if np.ndim(right) == 0 and not isinstance(right, DeviceArray):
         m = K.compare_map(dev, x, sym, right, kind)
     else:
-        warn_downcast(np.asarray(right), "compare: array threshold")
+        handle_float64(np.asarray(right), "compare: array threshold")
         b, _ = _flatten(np.broadcast_to(np.asarray(right, dtype=np.float32), np.shape(left))
                         if not isinstance(right, DeviceArray) else right, dev)
         m = K.compare_map(dev, x, sym, b, kind)
@@ -174,7 +179,7 @@ def get_daily_events(da, threshold, op: str, constrain=None, *, device=None, kee
     if np.ndim(threshold) == 0 and not isinstance(threshold, DeviceArray):
         ev = K.compare_map(dev, x, sym, threshold, "events")
     else:
-        warn_downcast(np.asarray(threshold), "compare: array threshold")
+        handle_float64(np.asarray(threshold), "compare: array threshold")
         b, _ = _flatten(np.broadcast_to(np.asarray(threshold, dtype=np.float32), np.shape(da))
                         if not isinstance(threshold, DeviceArray) else threshold, dev)
         ev = K.compare_map(dev, x, sym, b, "events")
@@ -252,7 +257,7 @@ def select_resample_op(da, op: str, time: TimeAxis, freq: str = "YS", *, device=
     """gen:83-125 (string ops): min/max/mean/std/var/count/sum/integral/argmax/argmin per period; ``**indexer``
     (season= / month= / doy_bounds= / date_bounds=) masks the other time steps first (calendar.select_time)."""
     dev = device or get_device()
-    x, cell_shape = _flatten(da, dev)
+    x, cell_shape = _flatten(da, dev, f64=not indexer)  # float64 field -> float64 statistics (xh_resample_reduce_f64)
     if indexer:
         from .calendar import select_time
 

@@ -68,7 +68,8 @@ def transpose(dev: Device, x: DeviceArray) -> DeviceArray:
 def threshold_count(dev: Device, x: DeviceArray, op: str, seg_off, *, scalar=None, scalar_f64=False, doy_table=None,
                     tidx=None, full=None, want_valid=True, out=None):
     """xh_threshold_count.  Exactly one of scalar / (doy_table, tidx) / full.  Returns (count, valid) (P, C) int32."""
-    T, C_ = _tc(x)
+    f64 = x.dtype == np.float64  # float64 field: float64 compare against any threshold (numpy promotion), xh_*_f64
+    T, C_ = _tc(x, np.float64 if f64 else np.float32)
     seg, P = _seg(seg_off)
     if out is not None:
         count, valid = out
@@ -94,8 +95,12 @@ def threshold_count(dev: Device, x: DeviceArray, op: str, seg_off, *, scalar=Non
         table_ptr, tstride = _vp(full.ptr), int(full.shape[-1])
     else:
         raise ValueError("a threshold is required")
-    dev.call("xh_threshold_count", _vp(x.ptr), T, C_, C_, 1, op_code(op), kind, thr, table_ptr, tstride, tidx_ptr,
-             np_ptr(seg), P, _vp(count.ptr), _vp(valid.ptr if valid else 0))
+    if f64:
+        if kind in (capi.THR_DOY_F32, capi.THR_FULL_F32):
+            raise TypeError("a float64 field needs float64 threshold tables (a float32 table widens exactly: upload it as float64)")
+        kind = capi.THR_SCALAR_F64 if kind == capi.THR_SCALAR_F32 else kind
+    dev.call("xh_threshold_count_f64" if f64 else "xh_threshold_count", _vp(x.ptr), T, C_, C_, 1, op_code(op), kind, thr,
+             table_ptr, tstride, tidx_ptr, np_ptr(seg), P, _vp(count.ptr), _vp(valid.ptr if valid else 0))
     if keep:
         dev.sync()
     return count, valid
@@ -112,14 +117,15 @@ def domain_count(dev: Device, x: DeviceArray, op1, thr1, op2, thr2, combine, seg
 
 
 def resample_reduce(dev: Device, x: DeviceArray, reducer: str, seg_off, skipna=True, want_valid=True):
-    T, C_ = _tc(x)
+    f64 = x.dtype == np.float64  # float64 field -> float64 statistics (xh_resample_reduce_f64)
+    T, C_ = _tc(x, np.float64 if f64 else np.float32)
     seg, P = _seg(seg_off)
     if reducer not in REDUCERS:
         raise ValueError(f"Reducer `{reducer}` not recognized.")
-    odt = np.int32 if reducer in ("count", "argmin", "argmax") else np.float32
+    odt = np.int32 if reducer in ("count", "argmin", "argmax") else (np.float64 if f64 else np.float32)
     out = dev.empty((P, C_), odt)
     valid = dev.empty((P, C_), np.int32) if want_valid else None
-    dev.call("xh_resample_reduce", _vp(x.ptr), T, C_, C_, 1, REDUCERS[reducer], int(bool(skipna)), np_ptr(seg), P,
+    dev.call("xh_resample_reduce_f64" if f64 else "xh_resample_reduce", _vp(x.ptr), T, C_, C_, 1, REDUCERS[reducer], int(bool(skipna)), np_ptr(seg), P,
              _vp(out.ptr), _vp(valid.ptr if valid else 0))
     return out, valid
 
@@ -370,14 +376,15 @@ def max_run_sum(dev: Device, x: DeviceArray, window: int, seg_off, cut=True) -> 
 def nan_quantile(dev: Device, x: DeviceArray, q, alpha=1.0, beta=1.0, sample_axis=0) -> DeviceArray:
     """x: (N, C) if sample_axis == 0 else (C, N).  Returns (nq, C) float64."""
     q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+    f64 = x.dtype == np.float64  # float64 samples: `diff` in float64 (utl:486), xh_nan_quantile_f64
     if sample_axis == 0:
-        N, C_ = _tc(x)
+        N, C_ = _tc(x, np.float64 if f64 else np.float32)
         sn, sc = C_, 1
     else:
-        C_, N = _tc(x)
+        C_, N = _tc(x, np.float64 if f64 else np.float32)
         sn, sc = 1, N
     out = dev.empty((len(q), C_), np.float64)
-    dev.call("xh_nan_quantile", _vp(x.ptr), N, C_, sn, sc, np_ptr(q), len(q), float(alpha), float(beta), _vp(out.ptr))
+    dev.call("xh_nan_quantile_f64" if f64 else "xh_nan_quantile", _vp(x.ptr), N, C_, sn, sc, np_ptr(q), len(q), float(alpha), float(beta), _vp(out.ptr))
     return out
 
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import kernels as K
-from ._capi import get_device, warn_downcast
+from ._capi import get_device
 
 
 def nan_calc_percentiles(arr, percentiles=None, axis: int = -1, alpha: float = 1.0, beta: float = 1.0, copy: bool = True,
@@ -23,8 +23,8 @@ def nan_calc_percentiles(arr, percentiles=None, axis: int = -1, alpha: float = 1
     lead = a.shape[:-1]
     N = a.shape[-1]
     dev = device or get_device()
-    warn_downcast(a, "calc_perc")
-    flat = np.ascontiguousarray(a.reshape(-1, N), dtype=np.float32)  # (C, N) sample-minor
+    # (C, N) sample-minor; float64 samples keep their dtype (xh_nan_quantile_f64: `diff` in float64, utl:486)
+    flat = np.ascontiguousarray(a.reshape(-1, N), dtype=np.float64 if a.dtype == np.float64 else np.float32)
     q = np.array([p / 100.0 for p in pers])
     out = K.nan_quantile(dev, dev.to_device(flat), q, alpha, beta, sample_axis=1).get()  # (nq, C)
     return out.reshape((len(pers),) + lead)

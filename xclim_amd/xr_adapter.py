@@ -41,7 +41,7 @@ from . import calendar as hcal
 from . import generic as hgen
 from . import run_length as hrl
 from . import utils as hutl
-from ._capi import get_device
+from ._capi import Float64FieldError, get_device
 from .timeaxis import TimeAxis
 
 __all__ = ["Env", "DoyThreshold", "LazyCompare", "make_wrappers", "time_axis_of"]
@@ -391,13 +391,13 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         return wrap_cells(a, hrl.season_length(x, window, mid_date, dim, time=t, device=dev()))
 
     rl_host = {}  # wrapper -> host mirror, for resample_and_rl (which receives the function OBJECT rl.<name>)
+    lazy_ok = set()  # the run statistics that xh_run_stats_doy fuses with the per-doy compare
 
     def resample_and_rl(da, resample_before_rl, compute, *args, freq, dim="time", **kwargs):  # rl:87-132
         host = rl_host.get(compute)
         if host is None or dim != "time":
             return fallback("resample_and_rl", da, resample_before_rl, compute, *args, freq=freq, dim=dim, **kwargs)
-        if isinstance(da, LazyCompare) and compute in (windowed_run_count, windowed_run_events, rle_statistics, longest_run) \
-                and da._da is None and kwargs.get("index", "first") == "first":
+        if isinstance(da, LazyCompare) and compute in lazy_ok and da._da is None and kwargs.get("index", "first") == "first":
             # compare(da, op, resample_doy(per, da)) -> run statistic: ONE fused launch on the per-doy table
             # (xh_run_stats_doy; the host mirror is the percentile-spell path of indices.py)
             from . import indices as hind
@@ -415,6 +415,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         out = hrl.resample_and_rl(x, resample_before_rl, host, *args, freq=freq, time=t, dim=dim, device=dev(), **kwargs)
         return wrap_periods(a, out, freq)
 
+    lazy_ok.update((windowed_run_count, windowed_run_events, rle_statistics, longest_run))
     rl_host.update({rle_statistics: hrl.rle_statistics, longest_run: hrl.longest_run,
                     windowed_run_events: hrl.windowed_run_events, windowed_run_count: hrl.windowed_run_count,
                     first_run: hrl.first_run, last_run: hrl.last_run})
@@ -437,7 +438,24 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         return DA(np.moveaxis(np.asarray(out), 0, -1), coords=coords, dims=_cell_dims(a) + ("quantiles",), attrs=dict(da.attrs),
                   name=da.name)
 
-    return {
+    def forwarding(name, fn):
+        """A float64 field on a float32-only kernel (Float64FieldError) goes to the reference's own function: the
+        wrappers never round an input behind the caller's back."""
+        import functools
+
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            try:
+                return fn(*args, **kwargs)
+            except Float64FieldError:
+                return fallback(name, *args, **kwargs)
+
+        for attr in ("__wrapped__",):
+            if hasattr(fn, attr):
+                setattr(wrapper, attr, wrapper)
+        return wrapper
+
+    table = {
         "threshold_count": threshold_count, "count_occurrences": count_occurrences, "domain_count": domain_count,
         "select_resample_op": select_resample_op, "spell_length_statistics": spell_length_statistics,
         "cumulative_difference": cumulative_difference, "compare": compare,
@@ -446,3 +464,11 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         "windowed_run_count": windowed_run_count, "first_run": first_run, "last_run": last_run, "season_length": season_length,
         "resample_and_rl": resample_and_rl, "calc_perc": calc_perc, "sdba_quantile": sdba_quantile,
     }
+    out = {name: forwarding(name, fn) for name, fn in table.items()}
+    # resample_and_rl receives the PATCHED rl.<name> objects (the forwarding wrappers): map those to the host mirrors too
+    for inner, host in list(rl_host.items()):
+        for name, fn in table.items():
+            if fn is inner:
+                rl_host[out[name]] = host
+    lazy_ok.update(out[n] for n in ("windowed_run_count", "windowed_run_events", "rle_statistics", "longest_run"))
+    return out
