@@ -33,20 +33,49 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s best measured copy)
 
 
+PMC_TABLES = ("profiles/r03/pmc_hbm_traffic.json", "profiles/r02/pmc_hbm_traffic.json")
+
+
 def pmc_traffic(kernel, grid):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE collected in
-    separate runs by tools/profile_bench.sh, corrected per MI355X_MICROARCH.md by tools/summarize_pmc.py).  Only
-    valid for the grid the profile was taken on (365x1440x720); None otherwise."""
+    """(HBM bytes per launch of `kernel`, source file) from the COMMITTED rocprofv3 PMC passes of this command
+    (FETCH_SIZE / WRITE_SIZE collected in separate runs by tools/profile_bench.sh, corrected per MI355X_MICROARCH.md by
+    tools/summarize_pmc.py) — counters cannot be collected inside a timed run, so this number is replayed from the file
+    named in ``traffic_source``, not measured now.  Only valid for the grid the profile was taken on (365x1440x720)."""
     if tuple(grid) != (365, 1440, 720):
-        return None
-    path = os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic.json")
-    try:
-        table = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    for name in (kernel, kernel[:-1] + ", false>"):  # the kernel gained a trailing COUNT template flag (false = this path)
-        if name in table:
-            return table[name]["hbm_bytes_per_launch"]
+        return None, None
+    for rel in PMC_TABLES:
+        try:
+            table = json.load(open(os.path.join(ROOT, rel)))
+        except (OSError, ValueError):
+            continue
+        for name in (kernel, kernel[:-1] + ", false>"):  # the kernel gained a trailing COUNT template flag (false = this path)
+            if name in table:
+                return table[name]["hbm_bytes_per_launch"], rel
+    return None, None
+
+
+def hbm_roofline(nbytes, ms, kernel=None, **more):
+    """The roofline object of the JSON contract for an HBM-bound launch (or chain): algorithmic bytes / HIP-event time."""
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+         "algorithmic_bytes": nbytes, "ms": ms}
+    if kernel:
+        r["kernel"] = kernel
+    r.update(more)
+    return r
+
+
+def valu_bound(kernel):
+    """{"bound": "valu", "busy": ...} for a kernel the SQ counters show to be VALU-bound (SQ_ACTIVE_INST_VALU /
+    (SQ_WAVE_CYCLES / 4), collected by tools/pmc_bench_sq.sh into profiles/r0x/valu_busy.json); None when not profiled."""
+    for rel in ("profiles/r03/valu_busy.json", "profiles/r02/valu_busy.json"):
+        try:
+            table = json.load(open(os.path.join(ROOT, rel)))
+        except (OSError, ValueError):
+            continue
+        for name, busy in table.items():
+            if name.startswith(kernel):
+                return {"bound": "valu", "busy": busy, "kernel": name, "source": rel}
     return None
 
 
@@ -107,6 +136,9 @@ def main():
     from xclim_amd._capi import Device
     from xclim_amd.timeaxis import TimeAxis
 
+    mock = bool(os.environ.get("XH_BENCH_MOCK_DEVICE"))
+    if mock:  # plumbing test of a multi-rank launch on a box without GPUs (tests/test_shard_gloo.py): no-op kernels
+        from tools.mock_device import MockDevice as Device  # noqa: F811
     dev = Device(local_rank)
     comm = None
     if use_dist:
@@ -210,7 +242,8 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": bytes_pdoy / (ms_pdoy * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "traffic": pmc_traffic("k_pdoy_slide<5, 4>", (T, Y, X)),
+        "traffic": pmc_traffic("k_pdoy_slide<5, 4>", (T, Y, X))[0],
+        "traffic_source": pmc_traffic("k_pdoy_slide<5, 4>", (T, Y, X))[1],
         "algorithmic_bytes": bytes_pdoy,
         "ms": ms_pdoy,
         "chain": {
@@ -243,7 +276,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "mock (no GPU: plumbing test, the numbers mean nothing)" if mock else "synthetic",
             "config": {"workload": f"tx90p (percentile_doy window 5 per 90 + threshold_count > + MissingAny) on {T}x{Y}x{X} fp32 "
                                    f"per GPU, noleap, freq YS, time-major, resident in HBM",
                        "grid_per_gpu": [T, Y, X], "sharding": ("lat slabs, one per rank; RCCL (xh_comm_allgather, C ABI) all_gather of (P,C) fp64" + (", overlapped with the next step" if overlap else ""))
@@ -368,7 +401,8 @@ def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D, full_configs=True)
                                              out=(o, v)), 10)
     b = 4 * E + 8 * P * C
     out["cdd_rle_365"] = {"ms": ms, "GB/s": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS,
-                          "cell-timesteps/s": E / (ms * 1e-3), "algorithmic_bytes": b}
+                          "cell-timesteps/s": E / (ms * 1e-3), "algorithmic_bytes": b,
+                          "roofline": hbm_roofline(b, ms, "k_run_max_fused<4, LT> (xh_run_stats)")}
     del pr
     # --- EQM train + adjust (nquantiles 20, "+", nearest, constant) ---
     base = seasonal_base(T)
@@ -383,12 +417,15 @@ def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D, full_configs=True)
     b_tr = 8 * E + 8 * 20 * C
     b_ad = 8 * E + 8 * 20 * C
     out["eqm_train_365"] = {"ms": ms_tr, "GB/s": b_tr / ms_tr / 1e6, "frac": b_tr / ms_tr / 1e6 / HBM_PEAK_GBS,
-                            "algorithmic_bytes": b_tr, "note": "time-major input: includes the internal transpose"}
+                            "algorithmic_bytes": b_tr, "note": "time-major input, read in place (register sorting network)",
+                            "roofline": hbm_roofline(b_tr, ms_tr, "2 x k_select_regsort<183, 360> + k_correction (xh_eqm_train)"),
+                            "roofline_valu": valu_bound("k_select_regsort")}
     out["eqm_adjust_365"] = {"ms": ms_ad, "GB/s": b_ad / ms_ad / 1e6, "frac": b_ad / ms_ad / 1e6 / HBM_PEAK_GBS,
-                             "algorithmic_bytes": b_ad}
+                             "algorithmic_bytes": b_ad, "roofline": hbm_roofline(b_ad, ms_ad, "k_eqm_adjust<20, 0> (xh_eqm_adjust)")}
     out["eqm_train_adjust_365"] = {"ms": ms_tr + ms_ad, "GB/s": (b_tr + b_ad) / (ms_tr + ms_ad) / 1e6,
                                    "frac": (b_tr + b_ad) / (ms_tr + ms_ad) / 1e6 / HBM_PEAK_GBS,
-                                   "cell-timesteps/s": E / ((ms_tr + ms_ad) * 1e-3)}
+                                   "cell-timesteps/s": E / ((ms_tr + ms_ad) * 1e-3),
+                                   "roofline": hbm_roofline(b_tr + b_ad, ms_tr + ms_ad, "xh_eqm_train + xh_eqm_adjust")}
     for a in (ref, hist, sim, scen, af, hq):
         a.free()
     if full_configs:
@@ -415,7 +452,8 @@ def bench_full_configs(dev, K, C):
     E = float(T) * C
     b = 4 * E + 8 * P * C
     out["cdd_3650"] = {"ms": ms, "GB/s": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS, "cell-timesteps/s": E / ms * 1e3,
-                       "algorithmic_bytes": b}
+                       "algorithmic_bytes": b, "config": "BASELINE configs[2]",
+                       "roofline": hbm_roofline(b, ms, "k_run_max_fused<4, LT> (xh_run_stats)")}
     for a in (pr, o, v):
         a.free()
     # ---- tx90p on 30 years (150 samples per day of year)
@@ -437,7 +475,10 @@ def bench_full_configs(dev, K, C):
     out["tx90p_30yr"] = {"percentile_doy_ms": ms_p, "percentile_doy_GB/s": bp / ms_p / 1e6, "threshold_count_ms": ms_c,
                          "threshold_count_GB/s": bc / ms_c / 1e6, "ms": ms_p + ms_c, "GB/s": (bp + bc) / (ms_p + ms_c) / 1e6,
                          "frac": (bp + bc) / (ms_p + ms_c) / 1e6 / HBM_PEAK_GBS, "cell-timesteps/s": E / (ms_p + ms_c) * 1e3,
-                         "algorithmic_bytes": bp + bc}
+                         "algorithmic_bytes": bp + bc, "config": "BASELINE configs[4], the tx90p half on one GPU's 1440x720 grid",
+                         "roofline": hbm_roofline(bp + bc, ms_p + ms_c, "xh_percentile_doy + xh_threshold_count"),
+                         "roofline_percentile_doy": hbm_roofline(bp, ms_p, "k_pdoy_top16<5, 32, false>"),
+                         "roofline_valu": valu_bound("k_pdoy_top16")}
     period = (np.searchsorted(seg, tb, side="right") - 1).astype(np.int32)
     period[tb < 0] = -1
     fused = K.percentile_doy_count(dev, tas, tb, 5, 90.0, ">", period, P, out=(cnt, val))
@@ -445,7 +486,8 @@ def bench_full_configs(dev, K, C):
         msf = event_time(dev, lambda: K.percentile_doy_count(dev, tas, tb, 5, 90.0, ">", period, P, out=(cnt, val)), 2)
         bf = 4 * E + 8 * P * C
         out["tx90p_30yr_fused"] = {"ms": msf, "GB/s": bf / msf / 1e6, "frac": bf / msf / 1e6 / HBM_PEAK_GBS,
-                                   "cell-timesteps/s": E / msf * 1e3, "algorithmic_bytes": bf}
+                                   "cell-timesteps/s": E / msf * 1e3, "algorithmic_bytes": bf,
+                                   "roofline": hbm_roofline(bf, msf, "k_pdoy_top16<5, 32, true> (xh_percentile_doy_count)")}
     for a in (per, cnt, val):
         a.free()
     # ---- configs[3]: EQM train + adjust on 30 years
@@ -461,7 +503,12 @@ def bench_full_configs(dev, K, C):
     out["eqm_c4"] = {"train_ms": ms_tr, "train_GB/s": 8 * E / ms_tr / 1e6, "train_frac": 8 * E / ms_tr / 1e6 / HBM_PEAK_GBS,
                      "adjust_ms": ms_ad, "adjust_GB/s": 8 * E / ms_ad / 1e6, "ms": ms_tr + ms_ad,
                      "GB/s": 16 * E / (ms_tr + ms_ad) / 1e6, "frac": 16 * E / (ms_tr + ms_ad) / 1e6 / HBM_PEAK_GBS,
-                     "cell-timesteps/s": E / (ms_tr + ms_ad) * 1e3, "algorithmic_bytes": 16 * E}
+                     "cell-timesteps/s": E / (ms_tr + ms_ad) * 1e3, "algorithmic_bytes": 16 * E,
+                     "config": "BASELINE configs[3]",
+                     "roofline": hbm_roofline(16 * E, ms_tr + ms_ad, "xh_eqm_train + xh_eqm_adjust"),
+                     "roofline_train": hbm_roofline(8 * E, ms_tr, "2 x (k_hs_sample + k_hs_hist + k_hs_collect) (select4.hip)",
+                                                    passes="two streaming passes per array: 16E + 0.25E bytes cross HBM for 8E algorithmic"),
+                     "roofline_adjust": hbm_roofline(8 * E, ms_ad, "k_eqm_adjust<20, 0>")}
     for a in (hist, sim, scen, af, hq):
         a.free()
     return out
@@ -501,6 +548,15 @@ def _cpu_worker(job):
 
 
 def cpu_baseline(T, Y, X, budget_s=10.0):
+    """1-core AND N-core figures: ``value`` / ``cores`` are the N-core measurement (the faster one: what the
+    host can do), ``one_core`` the single worker measured first with the same sampling."""
+    one = _cpu_baseline(T, Y, X, budget_s, want=1)
+    many = _cpu_baseline(T, Y, X, budget_s, want=0)
+    many["one_core"] = {k: one[k] for k in ("value", "unit", "cores", "sample")}
+    return many
+
+
+def _cpu_baseline(T, Y, X, budget_s=10.0, want=0):
     """Oracle (numpy restatement of the reference) on a sample of the SAME synthetic field, on the host cores of this box.
 
     One worker PROCESS per core (up to 16: on the MI355X boxes 64 workers gave LESS aggregate throughput, 1.38e8 vs
@@ -515,7 +571,7 @@ def cpu_baseline(T, Y, X, budget_s=10.0):
         avail = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         avail = os.cpu_count() or 1
-    want = int(os.environ.get("XH_BENCH_CPU_CORES", "0")) or min(avail, 16)
+    want = want or int(os.environ.get("XH_BENCH_CPU_CORES", "0")) or min(avail, 16)
     res = []
     if want > 1:
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")

@@ -18,9 +18,25 @@ import os, sys
 import numpy as np
 sys.path.insert(0, {root!r})
 import torch.distributed as dist
+import torch
 from oracle import indices as oidx, synth
 from oracle.timeutil import OTime
-from xclim_amd.shard import shard_bounds, gather_cells
+from xclim_amd.shard import all_bounds, shard_bounds
+
+
+def gather_cells(local, ncells, align=4):
+    # the exchange of Comm.gather_cells (slabs padded to the largest, one fixed-size all-gather) over gloo: torch lives
+    # here, with the test, not in the product package
+    world = dist.get_world_size()
+    bounds = all_bounds(ncells, world, align)
+    cmax = max(b - a for a, b in bounds)
+    t = torch.from_numpy(np.ascontiguousarray(local))
+    pad = torch.zeros((t.shape[0], cmax), dtype=t.dtype)
+    pad[:, : t.shape[1]] = t
+    out = torch.empty((world, t.shape[0], cmax), dtype=t.dtype)
+    dist.all_gather_into_tensor(out.view(world * t.shape[0], cmax), pad)
+    return torch.cat([out[r, :, : b - a] for r, (a, b) in enumerate(bounds)], dim=1).numpy()
+
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -139,3 +155,24 @@ def test_file_comm_scalar_reductions(tmp_path):
     assert all(p.returncode == 0 for p in procs)
     expect = repr([2.0, 6.0, 12.0, 6.0, 22.0, 6.0])
     assert outs == [expect, expect, expect]
+
+
+def test_bench_two_ranks_plumbing_without_gpus(tmp_path):
+    """``bench.py --gpus 2`` exactly as the driver launches it (torch.distributed.run, one rank per GPU), on a machine
+    without GPUs: a host-memory mock device (tools/mock_device.py, no-op kernels) and XH_BENCH_NO_RCCL=1 (file barriers, no
+    exchange) — environment handling, rendezvous fallback, barriers, max-over-ranks timing and the ONE JSON line on
+    rank 0 must work before the first 8-GPU run.  The numbers are meaningless and labelled so."""
+    import json
+
+    env = dict(os.environ, OMP_NUM_THREADS="1", XH_BENCH_MOCK_DEVICE="1", XH_BENCH_NO_RCCL="1", XH_RENDEZVOUS_DIR=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--grid", "365x4x8", "--no-cpu", "--no-extra"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["data"].startswith("mock") and "NO exchange" in rec["config"]["sharding"]
+    assert rec["value"] > 0 and rec["roofline"]["bound"] == "hbm" and rec["unit"] == "cell-timesteps/s"

@@ -125,10 +125,18 @@ int xh_comm_init(xh_ctx* ctx, int nranks, int rank, const void* id, xh_comm** ou
     delete c;
     return XH_ERR_HIP;
   }
-  XH_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  XH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-  for (int i = 0; i < XH_COMM_SLOTS; ++i) XH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
-  XH_CHECK_HIP(hipMalloc((void**)&c->d_word, 2 * sizeof(double)));
+  // resources of the communicator; on any failure everything created so far — the RCCL communicator included — is
+  // released again (xh_comm_destroy tolerates the members that are still zero)
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+  for (int i = 0; i < XH_COMM_SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_word, 2 * sizeof(double));
+  if (e != hipSuccess) {
+    xh_set_error("xh_comm_init: %s while creating the stream / events / scratch of the communicator", hipGetErrorString(e));
+    (void)hipGetLastError();
+    (void)xh_comm_destroy(c);
+    return XH_ERR_HIP;
+  }
   *out = c;
   return XH_OK;
 }
@@ -136,12 +144,13 @@ int xh_comm_init(xh_ctx* ctx, int nranks, int rank, const void* id, xh_comm** ou
 int xh_comm_destroy(xh_comm* c) {
   if (!c) return XH_OK;
   (void)hipSetDevice(c->ctx->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)g_rccl.CommDestroy(c->comm);
-  for (int i = 0; i < XH_COMM_SLOTS; ++i) (void)hipEventDestroy(c->ev_done[i]);
-  (void)hipEventDestroy(c->ev_in);
-  (void)hipStreamDestroy(c->stream);
-  (void)hipFree(c->d_word);
+  for (int i = 0; i < XH_COMM_SLOTS; ++i)
+    if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->d_word) (void)hipFree(c->d_word);
   delete c;
   return XH_OK;
 }

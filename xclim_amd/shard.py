@@ -4,10 +4,9 @@ Every op on the path is independent per grid cell (only time-axis windows exist)
 cut into contiguous slabs, each rank runs the single-GPU kernels on its slab, and the ONLY exchange is one
 all-gather of the reduced ``(P, cells)`` outputs.  ``scen``-sized outputs (EQM adjust) stay sharded.
 
-On the GPU the exchange goes through the C ABI (``xh_comm_*`` in include/xclim_hip.h: RCCL over xGMI, librccl
-dlopen'ed by libxclimhip.so) — :class:`Comm` below, torch-free.  ``gather_cells`` with numpy arrays / CPU tensors uses
-torch.distributed (gloo): that is the CPU test path of the slab arithmetic (tests/test_shard_gloo.py); torch is imported
-lazily and only there.
+The exchange goes through the C ABI (``xh_comm_*`` in include/xclim_hip.h: RCCL over xGMI, librccl dlopen'ed by
+libxclimhip.so) — :class:`Comm` below.  Nothing in this package imports torch: the gloo all-gather that checks the slab
+arithmetic on CPU-only machines lives with its test (tests/test_shard_gloo.py).
 """
 
 from __future__ import annotations
@@ -33,29 +32,6 @@ def shard_bounds(ncells: int, world: int, rank: int, align: int = 4) -> tuple[in
 
 def all_bounds(ncells: int, world: int, align: int = 4):
     return [shard_bounds(ncells, world, r, align) for r in range(world)]
-
-
-def gather_cells(local, ncells: int, group=None, align: int = 4):
-    """All-gather per-rank ``(P, c_local)`` results into the full ``(P, ncells)`` array on every rank.
-
-    `local`: numpy array (-> gloo/CPU tensors) or a torch tensor (CUDA tensors go through RCCL).  Shards are padded
-    to the largest slab so that one fixed-size collective suffices.
-    """
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    bounds = all_bounds(ncells, world, align)
-    cmax = max(b - a for a, b in bounds)
-    as_numpy = isinstance(local, np.ndarray)
-    t = torch.from_numpy(np.ascontiguousarray(local)) if as_numpy else local
-    P = t.shape[0]
-    pad = torch.zeros((P, cmax), dtype=t.dtype, device=t.device)
-    pad[:, : t.shape[1]] = t
-    out = torch.empty((world, P, cmax), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out.view(world * P, cmax), pad, group=group)
-    full = torch.cat([out[r, :, : b - a] for r, (a, b) in enumerate(bounds)], dim=1)
-    return full.numpy() if as_numpy else full
 
 
 # ---- RCCL through the C ABI (no torch) ---------------------------------------------------------------------------------
@@ -193,6 +169,12 @@ class Comm:
     @classmethod
     def from_env(cls, dev, timeout_s: float = 300.0) -> "Comm":
         world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        local_world = os.environ.get("LOCAL_WORLD_SIZE")
+        if local_world is not None and int(local_world) != world:
+            # the unique id travels through a node-LOCAL file: a launch over several nodes would wait for it until the
+            # timeout — say so at once instead
+            raise RuntimeError(f"Comm.from_env: WORLD_SIZE={world} but LOCAL_WORLD_SIZE={local_world}: the file rendezvous "
+                               "of the RCCL id only works inside one node (hand the id over yourself and use Comm(...))")
         # one node, one process per GPU: RCCL's socket bootstrap runs over the loopback interface unless the caller chose
         # another one (a box without an outside interface has nothing else; the data path is xGMI / shared memory anyway)
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
