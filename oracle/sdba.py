@@ -13,6 +13,30 @@ and it is not installed here, so this is a *specified* restatement of the publis
 * ``apply_correction``              scen = sim + af_t | sim * af_t
 
 The only test in the reference that pins numbers at this boundary is tests/test_xsdba.py:113-155 (1 decimal).
+
+Function by function — what each oracle function restates upstream (``xsdba >= 0.4.0``), so that a maintainer WITH xsdba
+can pin it: ``python tests/golden/make_sdba_golden.py`` calls exactly these upstream entry points on seeded inputs and
+writes tests/golden/sdba_vectors.npz; tests/test_gpu_sdba_golden.py then holds the HIP path to those numbers (both skip
+while the file is absent):
+
+    oracle function                restates (xsdba)                                                  fixture keys
+    -----------------------------  ----------------------------------------------------------------  -------------------
+    equally_spaced_nodes           xsdba.utils.equally_spaced_nodes(n, eps)                          nodes_20, nodes_eps
+    quantile                       xsdba.nbutils.quantile(da, q, dim="time")                         quantile
+    eqm_train                      xsdba._adjustment.eqm_train via EmpiricalQuantileMapping.train    eqm_{kind}_af / _hist_q
+                                   (ds.af, ds.hist_q; utils.get_correction)
+    eqm_adjust / _interp_1d        _adjustment.qm_adjust -> utils.interp_on_quantiles (1-D branch,   eqm_{kind}_{interp}_{extrap}
+                                   _interp_on_quantiles_1D: scipy interp1d) + utils.apply_correction
+    rank_pct / qdm_adjust          _adjustment.qdm_adjust: utils.rank(sim, dim="time", pct=True) ->  qdm_{kind}_{interp}
+                                   interp_on_quantiles(sim_q, quantiles, af) -> apply_correction
+    eqm_train_grouped /            the same through base.Grouper("time.month" | "time.dayofyear",   eqmg_{group}_af / _hist_q /
+      eqm_adjust_grouped           window): Grouper.apply / map_groups sample sets; adjust with      _scen  (interp "nearest")
+                                   interp="nearest" (2-D griddata "nearest", see xclim_amd/sdba.py)
+    dqm_train / dqm_adjust /       _adjustment.dqm_train / dqm_adjust, detrending.PolyDetrend        dqm_{kind}_af / _scaling /
+      poly_trend                   (degree 0 / 1), utils.apply_correction / invert                   _scen_d{degree}
+
+    NOT restated (refused by the product): adapt_freq, interpolation over (quantile, group) for "linear" / "cubic",
+    DQM with sub-groupings, QDM cubic, group="time.season".
 """
 
 from __future__ import annotations

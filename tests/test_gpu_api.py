@@ -382,22 +382,26 @@ def test_eqm_object_api(dev, rng, kind, interp):
         xsdba.EmpiricalQuantileMapping.train(ref, hist, group="time.season", device=dev)
 
 
-def test_eqm_uniform_to_normal_like_reference_testqm(dev):
-    """Analytic check modelled on reference tests/test_xsdba.py:113-155 (TestQM.test_quantiles): mapping a uniform
-    `hist` onto a normal `ref` reproduces ppf differences to 1 decimal in the interior."""
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("interp", ["linear", "nearest"])
+def test_eqm_reference_testqm(dev, kind, interp):
+    """The reference's only numeric test at the sdba boundary (tests/test_xsdba.py:113-155, TestQM.test_quantiles), its
+    own data path and tolerances through the HIP kernels: hist = sim ~ U(10, 11), ref ~ N(12, 1) drawn from the SAME
+    10000 uniform numbers, nquantiles = 50, group "time"; ``af[2:-2]`` equals the correction of the theoretical
+    quantiles to 1 decimal and ``adjust(sim)`` reproduces ``ref`` to 1 decimal away from the extremes — for both kinds
+    (the reference adjusts with interp="linear"; "nearest" is held to the same interior bound here)."""
     from scipy.stats import norm, uniform
 
-    rng = np.random.default_rng(0)
-    n = 10000
-    u = rng.random(n)
-    x = uniform.ppf(u, loc=1, scale=1).astype(np.float32)[:, None]
-    y = norm.ppf(u, loc=2, scale=1).astype(np.float32)[:, None]
-    eqm = xsdba.EmpiricalQuantileMapping.train(y, x, nquantiles=50, kind="+", device=dev)
-    q = eqm.quantiles
-    expected = norm.ppf(q, 2, 1) - uniform.ppf(q, 1, 1)
-    np.testing.assert_almost_equal(eqm.af[2:-2, 0], expected[2:-2], 1)
-    p = eqm.adjust(x, interp="linear")
-    np.testing.assert_almost_equal(np.sort(p[:, 0])[n // 2 - 5 : n // 2 + 5], np.sort(y[:, 0])[n // 2 - 5 : n // 2 + 5], 1)
+    u = np.random.default_rng(0).random(10000)
+    xd, yd = uniform(loc=10, scale=1), norm(loc=12, scale=1)
+    x, y = xd.ppf(u).astype(np.float32)[:, None], yd.ppf(u).astype(np.float32)[:, None]
+    qm = xsdba.EmpiricalQuantileMapping.train(y, x, kind=kind, group="time", nquantiles=50, device=dev)
+    q = qm.quantiles
+    expected = yd.ppf(q) - xd.ppf(q) if kind == "+" else yd.ppf(q) / xd.ppf(q)      # sdba.utils.get_correction(x_q, y_q, kind)
+    np.testing.assert_array_almost_equal(qm.af[2:-2, 0], expected[2:-2], 1)
+    p = qm.adjust(x, interp=interp)
+    middle = (u > 1e-2) & (u < 0.99)
+    np.testing.assert_array_almost_equal(p[middle, 0], y[middle, 0], 1)
 
 
 def test_range_reductions_and_daily_events(dev, rng):
