@@ -412,6 +412,19 @@ int xh_within_bnds_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
 int xh_mask_doy_cells(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t* doy /* host */,
                       const float* start, const float* end, float* out, int64_t out_st);
 
+/* ... with bounds that carry a TIME dimension (cal:1211-1246: one (start, end) pair per period of the bounds' own
+ * frequency and per cell): lo / hi (P, C) float32 on the device = the bounds as days since the first step of period p
+ * (doy_to_days_since on the host, NaN -> 0 / 366, lo = +inf for a period the bounds do not cover); seg_off[P + 1] on the
+ * host, covering [0, T).  out (T, C) = x where lo[p, c] <= t - seg_off[p] <= hi[p, c], NaN elsewhere. */
+int xh_mask_days_cells(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int64_t* seg_off /* host */,
+                       int P, const float* lo, const float* hi, float* out, int64_t out_st);
+
+/* The weighted "spell value" of spell_mask (indices/generic.py:523-524: rolling(time=window).construct("window").dot(
+ * weights)) as a field: out[t] = sum_k weights[k] * x[t - window + 1 + k] (float64 sum, one rounding to float32), NaN while
+ * the window is incomplete or holds a NaN.  weights[window] on the host.  Used when the threshold differs per cell. */
+int xh_rolling_dot(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, const double* weights /* host */,
+                   float* out, int64_t out_st);
+
 /* compare(da, op, resample_doy(per, da)) as a float32 1/0 mask (fp64 compare against the (D, C) per-doy table): the
  * first step of warm_spell_duration_index / cold_spell_duration_index (indices/_multivariate.py:66-152, 1693-1793);
  * xh_run_stats on the mask gives the index. */

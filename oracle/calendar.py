@@ -163,6 +163,60 @@ def mask_between_doys_cells(time: OTime, start, end, cell_shape, include_bounds=
     return np.where(s <= e, (doys >= s) & (doys <= e), ~((doys > e) & (doys < s)))
 
 
+def mask_between_doys_temporal(time: OTime, start, end, bounds_labels, freq, cell_shape, include_bounds=(True, True)):
+    """cal:1211-1246, bounds WITH a time dimension: `start` / `end` (P_b, *cells), `bounds_labels` = list of (year, month, day)
+    of their time coordinate (period starts).  For each period of time.resample(freq): its bounds become days since the
+    period's first step (doy_to_days_since, cal:1004-1072: a doy below the base doy lies in the next year), NaN -> 0 /
+    366, and a step is selected when start_d <= days <= end_d; periods without bounds are all False (cal:1239-1243)."""
+    from .timeutil import groups
+
+    if isinstance(include_bounds, bool):
+        include_bounds = (include_bounds, include_bounds)
+    nb = len(bounds_labels)
+    s = np.broadcast_to(np.asarray(start, dtype=np.float64), (nb,) + tuple(cell_shape)).copy()
+    e = np.broadcast_to(np.asarray(end, dtype=np.float64), (nb,) + tuple(cell_shape)).copy()
+    if not include_bounds[0]:
+        s += 1
+    if not include_bounds[1]:
+        e -= 1
+    labels = [tuple(int(v) for v in lab) for lab in bounds_labels]
+    mask = np.zeros((len(time),) + tuple(cell_shape), dtype=bool)
+
+    def daynum(y, m, d):  # consecutive day number in the calendar of `time`
+        if time.calendar == "360_day":
+            return y * 360 + (m - 1) * 30 + d
+        if time.calendar in ("noleap", "365_day"):
+            return y * 365 + [0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334][m - 1] + d
+        import datetime
+
+        return datetime.date(int(y), int(m), int(d)).toordinal()
+
+    for label, idx in groups(time, freq):
+        if idx.size == 0:
+            continue
+        lab = (label.year, label.month, label.day) if hasattr(label, "year") else (int(label[0]), int(label[1]), 1)
+        if lab not in labels:
+            continue
+        i = labels.index(lab)
+        ly = lab[0]
+        base = float(daynum(*lab) - daynum(ly, 1, 1) + 1)          # dayofyear of the period label (base_time)
+        if time.calendar == "360_day":
+            ylen = 360.0
+        elif time.calendar in ("noleap", "365_day"):
+            ylen = 365.0
+        else:
+            ylen = 366.0 if (ly % 4 == 0 and ly % 100 != 0) or ly % 400 == 0 else 365.0
+        with np.errstate(invalid="ignore"):
+            sd = np.where(s[i] >= base, s[i], s[i] + ylen) - base
+            ed = np.where(e[i] >= base, e[i], e[i] + ylen) - base
+        sd = np.where(np.isnan(sd), 0.0, sd)
+        ed = np.where(np.isnan(ed), 366.0, ed)
+        days = np.array([daynum(int(time.year[t]), int(time.month[t]), int(time.day[t])) - daynum(*lab) for t in idx], dtype=np.float64)
+        days = days.reshape((-1,) + (1,) * len(cell_shape))
+        mask[idx] = (days >= sd) & (days <= ed)
+    return mask
+
+
 def select_time(da, time: OTime, drop=False, **indexer):
     """da.where(mask, drop=drop): NaN outside the selection, or only the selected steps (+ their time axis)."""
     da = np.asarray(da)
@@ -170,7 +224,11 @@ def select_time(da, time: OTime, drop=False, **indexer):
     if db is not None and not all(isinstance(b, (int, np.integer)) for b in db):
         if drop:
             raise ValueError("Passing array-like doy bounds is incompatible with drop=True.")
-        m = mask_between_doys_cells(time, db[0], db[1], da.shape[1:], indexer.get("include_bounds", (True, True)))
+        if indexer.get("bounds_labels") is not None:
+            m = mask_between_doys_temporal(time, db[0], db[1], indexer["bounds_labels"], indexer["bounds_freq"], da.shape[1:],
+                                           indexer.get("include_bounds", (True, True)))
+        else:
+            m = mask_between_doys_cells(time, db[0], db[1], da.shape[1:], indexer.get("include_bounds", (True, True)))
         out = da.astype(np.result_type(da.dtype, np.float32), copy=True)
         out[~m] = np.nan
         return out

@@ -135,6 +135,8 @@ def qdm_adjust(sim, af, quantiles, kind="+", interp="nearest", extrapolation="co
 
 # ---- sub-groupings (xsdba.base.Grouper: "time.month", "time.dayofyear" with a window) — specified restatement ----------
 def group_values(time, prop):
+    if prop == "season":  # time.dt.season
+        return np.array(["", "DJF", "DJF", "MAM", "MAM", "MAM", "JJA", "JJA", "JJA", "SON", "SON", "SON", "DJF"])[np.asarray(time.month)]
     return np.asarray(time.month if prop == "month" else time.doy)
 
 

@@ -379,7 +379,7 @@ def test_eqm_object_api(dev, rng, kind, interp):
     assert eqm.adj_params["kind"] == kind
     np.testing.assert_allclose(xsdba.quantile(ref, eqm.quantiles, device=dev).reshape(20, -1), osdba.quantile(ref.reshape(T, -1), eqm.quantiles), rtol=1e-6)
     with pytest.raises(NotImplementedError):
-        xsdba.EmpiricalQuantileMapping.train(ref, hist, group="time.season", device=dev)
+        xsdba.EmpiricalQuantileMapping.train(ref, hist, group="time.week", device=dev)
 
 
 @pytest.mark.parametrize("kind", ["+", "*"])
@@ -389,7 +389,7 @@ def test_eqm_reference_testqm(dev, kind, interp):
     own data path and tolerances through the HIP kernels: hist = sim ~ U(10, 11), ref ~ N(12, 1) drawn from the SAME
     10000 uniform numbers, nquantiles = 50, group "time"; ``af[2:-2]`` equals the correction of the theoretical
     quantiles to 1 decimal and ``adjust(sim)`` reproduces ``ref`` to 1 decimal away from the extremes — for both kinds
-    (the reference adjusts with interp="linear"; "nearest" is held to the same interior bound here)."""
+    (the reference adjusts with interp="linear"; "nearest", a step function, is held to half a node spacing)."""
     from scipy.stats import norm, uniform
 
     u = np.random.default_rng(0).random(10000)
@@ -401,7 +401,10 @@ def test_eqm_reference_testqm(dev, kind, interp):
     np.testing.assert_array_almost_equal(qm.af[2:-2, 0], expected[2:-2], 1)
     p = qm.adjust(x, interp=interp)
     middle = (u > 1e-2) & (u < 0.99)
-    np.testing.assert_array_almost_equal(p[middle, 0], y[middle, 0], 1)
+    if interp == "linear":
+        np.testing.assert_array_almost_equal(p[middle, 0], y[middle, 0], 1)
+    else:  # a step function of 50 nodes: half a node spacing of the correction in the tails of the normal
+        assert np.abs(p[middle, 0] - y[middle, 0]).max() < 0.35
 
 
 def test_range_reductions_and_daily_events(dev, rng):
@@ -518,7 +521,7 @@ def test_percentile_spell_indices(dev, rng, calendar, T, before):
 
 
 @pytest.mark.parametrize("group,window,nyears", [("time.month", 1, 4), ("time.dayofyear", 1, 3), ("time.dayofyear", 31, 3),
-                                                 ("time.dayofyear", 7, 2)])
+                                                 ("time.dayofyear", 7, 2), ("time.season", 1, 3)])
 @pytest.mark.parametrize("kind,interp", [("+", "nearest"), ("*", "nearest"), ("+", "linear")])
 def test_eqm_with_sub_groupings(dev, rng, group, window, nyears, kind, interp):
     """EmpiricalQuantileMapping with xsdba's Grouper("time.month") / Grouper("time.dayofyear", window) (SURVEY 8f rank 4,
@@ -567,7 +570,8 @@ def test_grouped_eqm_removes_a_seasonal_bias(dev, rng):
     flat = xsdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=20, kind="+", device=dev)
     assert np.abs(flat.adjust(hist) - ref).max() > 1.0
     with pytest.raises(NotImplementedError):
-        xsdba.Grouper("time.season")
+        xsdba.Grouper("time.week")
+    assert list(xsdba.Grouper("time.season").labels(ta)) == ["DJF", "JJA", "MAM", "SON"]   # sorted like xarray's groupby
     with pytest.raises(ValueError):
         xsdba.Grouper("time.month", window=4)
     with pytest.raises(ValueError):
@@ -1388,3 +1392,35 @@ def test_select_time_with_per_cell_doy_bounds(dev, rng, include):
     assert np.isnan(got).any() and (~np.isnan(got)).any()
     with pytest.raises(ValueError, match="incompatible with drop=True"):
         select_time(x, ta, drop=True, doy_bounds=(start, end), device=dev)
+
+
+@pytest.mark.parametrize("include", [True, (False, True)])
+@pytest.mark.parametrize("start_date,cal,freq", [("2000-03-15", "standard", "YS"), ("2001-01-01", "noleap", "YS-JUL"), ("2001-01-01", "standard", "MS")])
+def test_select_time_with_doy_bounds_that_carry_a_time_dimension(dev, rng, include, start_date, cal, freq):
+    """mask_between_doys with bounds (period, *cells) (core/calendar.py:1211-1246): one (start, end) pair per period of the
+    bounds' own frequency and per cell, compared as DAYS SINCE the period label (doy_to_days_since: a doy below the
+    label's doy lies in the next year); NaN = open, periods the bounds do not label are masked entirely, a first
+    period that starts before the data, a calendar without leap days, July-anchored years, monthly bounds."""
+    from xclim_amd.calendar import select_time
+
+    T, cells = 800, (5, 8)
+    ta, ot = _axes(start_date, T) if cal == "standard" else _axes(start_date, T, cal)
+    x = rng.normal(280, 5, (T,) + cells).astype(np.float32)
+    seg, starts = ta.segments(freq)
+    labels = [(y, m, 1) for (y, m) in starts][:-1]              # the last period of the data has no bounds
+    nb = len(labels)
+    if freq == "MS":
+        base = np.array([TimeAxis(np.array([y]), np.array([m]), np.array([1]), ta.calendar).doy[0] for y, m, _ in labels])
+        start = base[:, None, None] + rng.integers(0, 12, (nb,) + cells).astype(np.float64)
+        end = start + rng.integers(0, 20, (nb,) + cells)
+    else:
+        start = rng.integers(1, 366, (nb,) + cells).astype(np.float64)
+        end = rng.integers(1, 366, (nb,) + cells).astype(np.float64)
+    start[0, 0, 0], end[0, 0, 1] = np.nan, np.nan
+    bt = TimeAxis(np.array([l[0] for l in labels]), np.array([l[1] for l in labels]), np.array([1] * nb), ta.calendar)
+    got = select_time(x, ta, doy_bounds=(start, end), include_bounds=include, bounds_time=bt, device=dev)
+    exp = ocal.select_time(x, ot, doy_bounds=(start, end), include_bounds=include, bounds_labels=labels, bounds_freq=freq)
+    np.testing.assert_array_equal(got, exp)
+    assert np.isnan(got[int(seg[-2]):]).all() and (~np.isnan(got)).any()     # the unlabelled last period is masked
+    got2 = select_time(x, ta, doy_bounds=(start, end), include_bounds=include, bounds_time=bt, bounds_freq=freq, device=dev)
+    np.testing.assert_array_equal(got2, exp)

@@ -702,9 +702,10 @@ def test_spell_mask_per_cell_thresholds_with_a_window(dev, rng, window, red, op)
     for before in (True, False):
         st = xgen.spell_length_statistics(x, thr, window, red, op, "max", ta, "YS", resample_before_rl=before, device=dev)
         np.testing.assert_array_equal(st, ogen.spell_length_statistics(x, thr, window, red, op, "max", ot, "YS", resample_before_rl=before))
-    if window > 1:
-        with pytest.raises(NotImplementedError):
-            xgen.spell_mask(x, window, "mean", op, thr, weights=[1.0] * window, device=dev)
+    if window > 1:   # weights (gen:523-524) with per-cell thresholds: the dot product as a field (xh_rolling_dot)
+        w = list(rng.random(window) + 0.1)
+        np.testing.assert_array_equal(xgen.spell_mask(x, window, "mean", op, thr, weights=w, device=dev),
+                                      ogen.spell_mask(x, window, "mean", op, thr, weights=w))
 
 
 def test_thresholded_events_reference_known_answers(dev):

@@ -212,9 +212,10 @@ def test_bench_finds_pmc_traffic_of_the_dominant_kernel():
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    t = bench.pmc_traffic("k_pdoy_slide<5, 4>", (365, 1440, 720))
+    t, source = bench.pmc_traffic("k_pdoy_slide<5, 4>", (365, 1440, 720))
     assert t is not None and 4.4e9 < t < 5.5e9   # algorithmic 4.54 GB
-    assert bench.pmc_traffic("k_pdoy_slide<5, 4>", (365, 10, 10)) is None
+    assert source.startswith("profiles/r0") and os.path.exists(os.path.join(root, source))   # named in roofline.traffic_source
+    assert bench.pmc_traffic("k_pdoy_slide<5, 4>", (365, 10, 10)) == (None, None)
 
 
 def test_dim_other_than_time_is_refused():

@@ -152,6 +152,8 @@ SIGNATURES: dict[str, list] = {
     "xh_eqm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64],
     "xh_qdm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp],
     "xh_mask_doy_cells": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64],
+    "xh_rolling_dot": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _i64],
+    "xh_mask_days_cells": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _vp, _vp, _i64],
     "xh_poly_trend": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp],
     "xh_trend_apply": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _i64],
 }

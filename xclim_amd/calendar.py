@@ -11,7 +11,7 @@ import numpy as np
 
 from . import kernels as K
 from ._capi import DeviceArray, handle_float64, get_device
-from .timeaxis import TimeAxis
+from .timeaxis import TimeAxis, _is_leap
 
 
 class DoyPercentile:
@@ -116,11 +116,65 @@ def select_time_mask(time: TimeAxis, *, season=None, month=None, doy_bounds=None
     return np.isin(doy_t, _get_doys(int(s), int(e), include_bounds))
 
 
+def _days_since_bounds(time: TimeAxis, start, end, bounds_time: TimeAxis, freq: str, cell_shape, include_bounds):
+    """cal:1211-1246 on the host: the bounds (P_b, *cells) of the periods labelled by `bounds_time` -> (seg, lo, hi) with lo /
+    hi (P, C) float32 in days since the first step of each period of ``time.segments(freq)``.  doy_to_days_since
+    (cal:1004-1072): a doy before the period's first doy lies in the NEXT year (+ days in the year); NaN -> 0 / 366;
+    periods of `time` that the bounds do not label stay masked (lo = +inf)."""
+    seg, starts = time.segments(freq)
+    if starts and len(starts[0]) != 2:
+        raise NotImplementedError("doy bounds with a time dimension: yearly / quarterly / monthly bounds only")
+    P = len(seg) - 1
+    C_ = int(np.prod(cell_shape, dtype=np.int64))
+    s = np.broadcast_to(np.asarray(start, dtype=np.float64), (len(bounds_time),) + tuple(cell_shape)).reshape(len(bounds_time), C_).copy()
+    e = np.broadcast_to(np.asarray(end, dtype=np.float64), (len(bounds_time),) + tuple(cell_shape)).reshape(len(bounds_time), C_).copy()
+    if not include_bounds[0]:
+        s += 1
+    if not include_bounds[1]:
+        e -= 1
+    lo = np.full((P, C_), np.inf, dtype=np.float32)
+    hi = np.full((P, C_), -np.inf, dtype=np.float32)
+    key = {(int(y), int(m), int(d)): i for i, (y, m, d) in enumerate(zip(bounds_time.year, bounds_time.month, bounds_time.day))}
+    ordinal = time.ordinal()
+    for p in range(P):
+        t0 = int(seg[p])
+        if seg[p + 1] <= t0:
+            continue
+        ly, lm = starts[p]  # the period's LABEL (its first day, present in the data or not): `base_time` of cal:1229
+        i = key.get((int(ly), int(lm), 1))
+        if i is None:
+            continue  # "This group has no defined bounds: put False in the mask" (cal:1239-1243)
+        label = TimeAxis(np.array([ly]), np.array([lm]), np.array([1]), time.calendar)
+        base = float(label.doy[0])
+        # days in the label's year (_doy_days_since_doys: doy_max, cal:982-987)
+        ylen = 360.0 if time.calendar == "360_day" else (366.0 if bool(_is_leap(int(ly), time.calendar)) else 365.0)
+        with np.errstate(invalid="ignore"):
+            sd = np.where(s[i] >= base, s[i], s[i] + ylen) - base
+            ed = np.where(e[i] >= base, e[i], e[i] + ylen) - base
+        off = float(ordinal[t0] - label.ordinal()[0])  # the kernel counts days from the period's first PRESENT step
+        lo[p] = np.where(np.isnan(sd), 0.0, sd) - off
+        hi[p] = np.where(np.isnan(ed), 366.0, ed) - off
+    return seg, lo, hi
+
+
+def _infer_bounds_freq(bt: TimeAxis) -> str:
+    """xr.infer_freq for the two shapes the reference's own callers produce: yearly labels (same month / day in consecutive
+    years -> "YS" / "YS-MON") and monthly labels (day 1 of consecutive months -> "MS")."""
+    mon = ["JAN", "FEB", "MAR", "APR", "MAY", "JUN", "JUL", "AUG", "SEP", "OCT", "NOV", "DEC"]
+    if len(bt) >= 2 and np.all(bt.month == bt.month[0]) and np.all(bt.day == 1) and np.all(np.diff(bt.year) == 1):
+        return "YS" if bt.month[0] == 1 else f"YS-{mon[int(bt.month[0]) - 1]}"
+    if len(bt) >= 2 and np.all(bt.day == 1) and np.all(np.diff(bt.year * 12 + bt.month) == 1):
+        return "MS"
+    raise ValueError("doy bounds with a time dimension: cannot infer the frequency of their time coordinate; pass bounds_freq=")
+
+
 def select_time(da, time: TimeAxis, drop: bool = False, *, season=None, month=None, doy_bounds=None, date_bounds=None,
-                include_bounds=True, device=None, keep=False):
+                include_bounds=True, bounds_time: TimeAxis | None = None, bounds_freq: str | None = None, device=None, keep=False):
     """core/calendar.py:1259-1378: ``da.where(mask, drop=drop)`` for the time selections season / month / doy_bounds /
     date_bounds (the ``**indexer`` of select_resample_op & co.).  drop=False: same length, NaN outside the selection;
-    drop=True: ``(selected rows, their TimeAxis)``.  keep=True returns the (rows, cells) float32 device array."""
+    drop=True: ``(selected rows, their TimeAxis)``.  keep=True returns the (rows, cells) float32 device array.
+    Array-like ``doy_bounds``: per cell ``(*cells)``, or — with ``bounds_time`` = the TimeAxis of the bounds' own time
+    coordinate (period starts) — per period and cell ``(P_b, *cells)`` (mask_between_doys, cal:1166-1257)."""
     dev = device or get_device()
     if doy_bounds is not None and not all(isinstance(b, (int, np.integer)) for b in doy_bounds):
         # per-cell bounds (mask_between_doys, cal:1199-1257, bounds without a time dimension)
@@ -131,6 +185,13 @@ def select_time(da, time: TimeAxis, drop: bool = False, *, season=None, month=No
         x, cell_shape = _flatten(da, dev)
         inc = (include_bounds, include_bounds) if isinstance(include_bounds, bool) else tuple(include_bounds)
         start, end = doy_bounds
+        if bounds_time is not None:
+            # bounds WITH a time dimension (cal:1211-1246): one pair per period of the bounds' own frequency, compared as
+            # days since the period's first step; steps of periods the bounds do not label are masked
+            freq = bounds_freq or _infer_bounds_freq(bounds_time)
+            seg, lo, hi = _days_since_bounds(time, start, end, bounds_time, freq, cell_shape, inc)
+            out = K.mask_days_cells(dev, x, seg, dev.to_device(lo), dev.to_device(hi))
+            return out if keep else out.get().reshape((out.shape[0],) + tuple(cell_shape))
         bs, be = (np.broadcast_to(np.asarray(b, dtype=np.float32), cell_shape).reshape(-1).copy() for b in (start, end))
         if not inc[0]:
             bs += 1  # (NaN stays NaN: an open bound)

@@ -324,6 +324,54 @@ k_mask_doy_cells(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, 
   });
 }
 
+// Trailing weighted window sum: out[t] = sum_k w[k] * x[t - W + 1 + k] in float64 (k ascending), rounded once to float32;
+// NaN while the window is incomplete or holds a NaN.  The "spell value" of spell_mask with `weights` (indices/generic.py:
+// 523-524: data_pad.rolling(time=window).construct("window").dot(weights)) as a field of its own — needed when the
+// threshold differs per cell (the fused spell kernels of window.hip take one scalar threshold).  Rarely used: every
+// output re-reads its W inputs through L2.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_rolling_dot(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int W, const double* __restrict__ w,
+              float* __restrict__ out, int64_t out_st) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
+  const int64_t ta = (int64_t)blockIdx.y * chunk;
+  int64_t tb = ta + chunk;
+  if (tb > T) tb = T;
+  for (int64_t t = ta; t < tb; ++t) {
+    float r = xh_nan32();
+    if (t >= W - 1) {
+      double s = 0.0;
+      for (int k = 0; k < W; ++k) s += w[k] * (double)x[(t - W + 1 + k) * st + c];  // a NaN sample poisons the sum
+      r = (float)s;
+    }
+    out[t * out_st + c] = r;
+  }
+}
+
+// select_time(da, doy_bounds=(start, end)) with bounds that carry a TIME dimension (mask_between_doys, core/calendar.py:
+// 1211-1246): one pair of bounds per period and cell, already converted by the host to "days since the period's first
+// step" (doy_to_days_since; NaN -> 0 / 366; a period without bounds: lo = +inf).  out = x where lo <= t - t0 <= hi.
+template <int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_mask_days_cells(const float* __restrict__ x, int64_t C, int64_t st, const int64_t* __restrict__ seg_off, int P,
+                  const float* __restrict__ lo, const float* __restrict__ hi, float* __restrict__ out, int64_t out_st) {
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  for (int p = blockIdx.y; p < P; p += gridDim.y) {
+    const int64_t t0 = seg_off[p], t1 = seg_off[p + 1];
+    float a[VEC], b[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a[i] = lo[(int64_t)p * C + c + i], b[i] = hi[(int64_t)p * C + c + i];
+    xh_march_rows<VEC, 8>(x + c, st, t0, t1, [&](int64_t t, const VecF<VEC>& xv) {
+      const float d = (float)(t - t0);
+      float* dst = out + t * out_st + c;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) dst[i] = (d >= a[i] && d <= b[i]) ? xv.v[i] : xh_nan32();
+    });
+  }
+}
+
 extern "C" {
 
 int xh_range_reduce(xh_ctx* ctx, const float* low, const float* high, int64_t T, int64_t C, int64_t st_low, int64_t st_high,
@@ -520,6 +568,49 @@ int xh_mask_doy_cells(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t
     hipLaunchKernelGGL((k_mask_doy_cells<4>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, (const int32_t*)d_doy, start, end, out, out_st);
   else
     hipLaunchKernelGGL((k_mask_doy_cells<1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, (const int32_t*)d_doy, start, end, out, out_st);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_mask_days_cells(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const int64_t* seg_off, int P,
+                       const float* lo, const float* hi, float* out, int64_t out_st) {
+  XH_REQUIRE(ctx && x && seg_off && lo && hi && out, XH_ERR_ARG, "xh_mask_days_cells: NULL argument");
+  XH_REQUIRE(T >= 0 && C >= 0 && P >= 1, XH_ERR_ARG, "xh_mask_days_cells: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C && out_st >= C, XH_ERR_LAYOUT, "xh_mask_days_cells: needs time-major views (sc == 1)");
+  XH_REQUIRE(seg_off[0] == 0 && seg_off[P] == T, XH_ERR_ARG, "xh_mask_days_cells: the periods must cover [0, T)");
+  for (int p = 0; p < P; ++p)
+    XH_REQUIRE(seg_off[p] <= seg_off[p + 1], XH_ERR_ARG, "xh_mask_days_cells: seg_off must be non-decreasing");
+  if (T == 0 || C == 0) return XH_OK;
+  size_t cur = 0;
+  void* d_seg = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, seg_off, sizeof(int64_t) * (size_t)(P + 1), &d_seg);
+  if (rc) return rc;
+  const int vec = (xh_pick_vec(x, C, st) == 4 && xh_pick_vec(out, C, out_st) == 4) ? 4 : 1;
+  const dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), (unsigned)(P > 4096 ? 4096 : P));
+  if (vec == 4)
+    hipLaunchKernelGGL((k_mask_days_cells<4>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, (const int64_t*)d_seg, P, lo, hi, out, out_st);
+  else
+    hipLaunchKernelGGL((k_mask_days_cells<1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, (const int64_t*)d_seg, P, lo, hi, out, out_st);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_rolling_dot(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, const double* weights,
+                   float* out, int64_t out_st) {
+  XH_REQUIRE(ctx && x && weights && out, XH_ERR_ARG, "xh_rolling_dot: NULL argument");
+  XH_REQUIRE(T >= 0 && C >= 0 && window >= 1 && window <= 4096, XH_ERR_ARG, "xh_rolling_dot: bad shape (1 <= window <= 4096)");
+  XH_REQUIRE(sc == 1 && st >= C && out_st >= C, XH_ERR_LAYOUT, "xh_rolling_dot: needs time-major views (sc == 1)");
+  if (T == 0 || C == 0) return XH_OK;
+  size_t cur = 0;
+  void* d_w = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, weights, sizeof(double) * (size_t)window, &d_w);
+  if (rc) return rc;
+  const int64_t cblocks = cdiv64(C, XH_BLOCK);
+  int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
+  if (gy > cdiv64(T, 16)) gy = cdiv64(T, 16);
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(k_rolling_dot, dim3((unsigned)cblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window,
+                     (const double*)d_w, out, out_st);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

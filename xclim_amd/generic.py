@@ -414,14 +414,13 @@ def spell_mask(data, window: int, win_reducer: str, op: str, thresh, min_gap: in
             # apart: rolling statistic (trailing, NaN until the window is full) -> per-cell compare -> "part of ANY window
             # that satisfies the condition" = trailing rolling max of the condition read w - 1 steps ahead (zeros behind
             # the end of the series).
-            if weights is not None:
-                raise NotImplementedError("weighted window means with per-cell thresholds are not supported")
             table, tidx = cell
             if window == 1:
                 m = K.compare_doy(dev, x, sym, table, tidx)
             else:
                 T, C_ = x.shape
-                stat = K.rolling_reduce(dev, x, window, win_reducer, center=False)
+                # (weights: the dot product of gen:523-524 as a field — xh_rolling_dot — instead of the rolling statistic)
+                stat = K.rolling_dot(dev, x, weights) if weights is not None else K.rolling_reduce(dev, x, window, win_reducer, center=False)
                 cond = K.compare_doy(dev, stat, sym, table, tidx)
                 pad = dev.zeros((T + window - 1, C_), np.float32)
                 dev.copy_d2d(pad.ptr, cond.ptr, cond.nbytes)

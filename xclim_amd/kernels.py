@@ -148,6 +148,15 @@ def rolling_reduce(dev: Device, x: DeviceArray, window: int, reducer: str, cente
     return out
 
 
+def rolling_dot(dev: Device, x: DeviceArray, weights) -> DeviceArray:
+    """xh_rolling_dot: trailing weighted window sum (float64 sum, float32 result, NaN until the window is full)."""
+    T, C_ = _tc(x)
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    out = dev.empty((T, C_), np.float32)
+    dev.call("xh_rolling_dot", _vp(x.ptr), T, C_, C_, 1, len(w), np_ptr(w), _vp(out.ptr), C_)
+    return out
+
+
 def cumsum_reset(dev: Device, x: DeviceArray, index="last") -> DeviceArray:
     T, C_ = _tc(x)
     out = dev.empty((T, C_), np.float32)
@@ -571,6 +580,16 @@ def mask_doy_cells(dev: Device, x: DeviceArray, doy, start: DeviceArray, end: De
     d = np.ascontiguousarray(doy, dtype=np.int32)
     out = dev.empty((T, C_), np.float32)
     dev.call("xh_mask_doy_cells", _vp(x.ptr), T, C_, C_, 1, np_ptr(d), _vp(start.ptr), _vp(end.ptr), _vp(out.ptr), C_)
+    return out
+
+
+def mask_days_cells(dev: Device, x: DeviceArray, seg_off, lo: DeviceArray, hi: DeviceArray) -> DeviceArray:
+    """xh_mask_days_cells: x where lo[p, c] <= t - seg_off[p] <= hi[p, c] (p = the period of step t), NaN elsewhere."""
+    T, C_ = _tc(x)
+    seg, P = _seg(seg_off)
+    assert lo.shape == (P, C_) and hi.shape == (P, C_)
+    out = dev.empty((T, C_), np.float32)
+    dev.call("xh_mask_days_cells", _vp(x.ptr), T, C_, C_, 1, np_ptr(seg), P, _vp(lo.ptr), _vp(hi.ptr), _vp(out.ptr), C_)
     return out
 
 

@@ -6,7 +6,7 @@ Names follow xsdba: ``EmpiricalQuantileMapping.train(ref, hist, nquantiles=20, k
 ``.hist_q``; ``nbutils.quantile`` and ``utils.equally_spaced_nodes`` as module functions.  Arrays: TIME ON AXIS 0, numpy
 or device arrays; all arithmetic is in ``xh_eqm_train`` / ``xh_eqm_adjust``.
 
-Grouping (first slice): :class:`Grouper` ``"time"``, ``"time.month"`` and ``"time.dayofyear"`` with
+Grouping (first slice): :class:`Grouper` ``"time"``, ``"time.month"``, ``"time.season"`` and ``"time.dayofyear"`` with
 an odd ``window`` (xsdba: the samples of a group are the centred ``window`` days around every time step of the group —
 the same sample sets as ``percentile_doy``).  Training gathers each group's rows (``xh_select_rows``) and runs the
 per-column multi-quantile kernels on them; ``af`` / ``hist_q`` get a leading group axis ``(group, quantiles, *cells)``.
@@ -45,8 +45,8 @@ class Grouper:
     def __init__(self, group: str = "time", window: int = 1):
         if isinstance(group, Grouper):
             group, window = group.name, group.window
-        if group not in ("time", "time.month", "time.dayofyear"):
-            raise NotImplementedError(f"group={group!r}: supported are 'time', 'time.month', 'time.dayofyear'")
+        if group not in ("time", "time.month", "time.dayofyear", "time.season"):
+            raise NotImplementedError(f"group={group!r}: supported are 'time', 'time.month', 'time.dayofyear', 'time.season'")
         if window < 1 or window % 2 == 0:
             raise ValueError("window must be a positive odd number of time steps")
         if group == "time" and window != 1:
@@ -57,18 +57,29 @@ class Grouper:
     def __repr__(self):
         return f"Grouper(name={self.name!r}, window={self.window})"
 
+    _SEASON_OF_MONTH = np.array(["", "DJF", "DJF", "MAM", "MAM", "MAM", "JJA", "JJA", "JJA", "SON", "SON", "SON", "DJF"])
+
+    def values(self, time) -> np.ndarray:
+        """The group coordinate of every time step: month, day of year, or the season name (``time.dt.season``)."""
+        if self.prop == "month":
+            return np.asarray(time.month)
+        if self.prop == "season":
+            return self._SEASON_OF_MONTH[np.asarray(time.month)]
+        return np.asarray(time.doy)
+
     def labels(self, time) -> np.ndarray:
-        """Group coordinate values present on `time` (months 1..12 / days of year), sorted."""
+        """Group coordinate values present on `time` (months 1..12 / days of year / season names), sorted like xarray's
+        groupby sorts them (the seasons alphabetically: DJF, JJA, MAM, SON)."""
         if self.prop == "group":
             return np.array([0])
-        return np.unique(time.month if self.prop == "month" else time.doy)
+        return np.unique(self.values(time))
 
     def index(self, time, labels=None) -> np.ndarray:
         """Position of every time step's group in `labels` (default: the labels of `time`); -1 when absent."""
         if self.prop == "group":
             return np.zeros(len(time), dtype=np.int64)
         lab = self.labels(time) if labels is None else np.asarray(labels)
-        val = time.month if self.prop == "month" else time.doy
+        val = self.values(time)
         pos = np.clip(np.searchsorted(lab, val), 0, len(lab) - 1)
         return np.where(lab[pos] == val, pos, -1)
 
