@@ -226,3 +226,54 @@ def test_float64_dataarrays_keep_their_dtype_or_go_to_the_reference(ref, dev, rn
         gen.spell_length_statistics(da, 290.0, 1, None, ">", "max", "YS")
     with pytest.raises(AssertionError, match="was reached"):
         mods["xclim.core.calendar"].percentile_doy(da)
+
+
+def test_indicator_level_fusion_compute_and_missing_mask_in_one_pass(ref, dev, rng):
+    """core/indicator.py:1522-1549: after the compute the Indicator runs ``MissingAny()(da, freq, src_freq, **indexer)`` on the
+    SAME input and masks the periods that miss a value.  The reducers' kernels return the valid count as a side output, the
+    wrappers remember it per input buffer, the replaced MissingAny.__call__ answers from it: the launch log shows ONE pass
+    over the data for compute + mask.  A buffer that was not seen (or an indexer) costs one counting pass, never the
+    reference's two host passes."""
+    env, mods, names = ref
+    assert "xclim.core.missing.MissingAny.__call__" in names
+    T = 365 * 2
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    x = _temp(rng, T, (5, 6))
+    x[400:403, 1, 2] = np.nan
+    x[10, 3, 3] = np.nan
+    da = fakexr.field(x, ta)
+    misser = mods["xclim.core.missing"].MissingAny()
+
+    def indicator(compute, *args, freq="YS", **kw):  # compute -> missing mask -> out.where(~mask), like Indicator.__call__
+        out = compute(da, *args, freq=freq, **kw)
+        return out.where(~misser(da, freq, "D"))
+
+    trace = dev.start_trace()
+    got = indicator(mods["xclim.indices._simple"].tg_mean)
+    dev.stop_trace()
+    exp = oidx.apply_missing(ogen.select_resample_op(x, "mean", ot, "YS"), x, ot, "YS")
+    np.testing.assert_allclose(got.values, exp, rtol=1e-6, equal_nan=True)
+    assert np.isnan(got.values).sum() == 2
+    assert len(_calls(trace, "xh_resample_reduce")) == 1 and not _calls(trace, "xh_threshold_count")   # ONE pass: mean + valid count
+    trace = dev.start_trace()
+    got = indicator(mods["xclim.indices._threshold"].frost_days, 283.15)
+    dev.stop_trace()
+    np.testing.assert_array_equal(got.values, oidx.apply_missing(ogen.threshold_count(x, "<", 283.15, ot, "YS").astype(np.float64), x, ot, "YS"))
+    assert len(_calls(trace, "xh_threshold_count")) == 1 and not _calls(trace, "xh_resample_reduce")
+    trace = dev.start_trace()
+    got = indicator(mods["xclim.indices._threshold"].maximum_consecutive_dry_days, 285.0)
+    dev.stop_trace()
+    assert len(_calls(trace, "xh_run_stats")) == 1 and not _calls(trace, "xh_resample_reduce")
+    assert np.isnan(got.values[:, 1, 2]).sum() == 1 and np.isnan(got.values[0, 3, 3])
+    # an input the wrappers have not seen: one counting pass on the device
+    other = fakexr.field(x.copy(), ta)
+    trace = dev.start_trace()
+    m = misser(other, "MS", "D")
+    dev.stop_trace()
+    np.testing.assert_array_equal(m.values, oidx.missing_any(x, ot, "MS"))
+    assert len(_calls(trace, "xh_resample_reduce")) == 1
+    # with a time selection the expected count follows the indexer (core/missing.py:118-135)
+    m = misser(other, "YS", "D", month=[6, 7, 8])
+    assert m.values.sum() == 0 and m.values.shape == (2, 5, 6)      # the NaNs lie outside JJA
+    with pytest.raises(AssertionError, match="was reached"):        # a sub-daily / unknown source step is the reference's business
+        misser(other, "YS", "h")

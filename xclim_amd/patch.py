@@ -155,6 +155,16 @@ def install(env=None, modules=None) -> list[str]:
         for name in names:
             patch(modname, name, wrappers[name])
     patch("xclim.indices.run_length", "_cumsum_reset_np", cumsum_reset_np)
+    # the missing-value check of Indicator._postprocess (core/indicator.py:1522-1549): a METHOD of MissingAny
+    miss_mod = resolve("xclim.core.missing")
+    cls = getattr(miss_mod, "MissingAny", None) if miss_mod is not None else None
+    if cls is not None:
+        orig_call = cls.__call__
+        if ("xclim.core.missing", "MissingAny.__call__") not in _saved:
+            _saved[("xclim.core.missing", "MissingAny.__call__")] = orig_call
+        orig["MissingAny.__call__"] = _saved[("xclim.core.missing", "MissingAny.__call__")]
+        cls.__call__ = wrappers["MissingAny.__call__"]
+        done.append("xclim.core.missing.MissingAny.__call__")
     # xsdba (third party, re-exported by src/xclim/sdba.py:10): the per-cell multi-quantile entry point; xsdba's own
     # modules reach it through the module object (``nbu.quantile``), so the one attribute is enough
     patch("xsdba.nbutils", "quantile", wrappers["sdba_quantile"])
@@ -170,6 +180,10 @@ def uninstall() -> None:
 
     for (modname, attr), fn in _saved.items():
         mod = _saved_modules.get(modname) or importlib.import_module(modname)
-        setattr(mod, attr, fn)
+        if "." in attr:  # a method: "Class.name"
+            cname, meth = attr.split(".")
+            setattr(getattr(mod, cname), meth, fn)
+        else:
+            setattr(mod, attr, fn)
     _saved.clear()
     _saved_modules.clear()

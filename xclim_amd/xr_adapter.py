@@ -19,6 +19,7 @@ Reference functions replaced (signatures identical, file:line of the original):
                             windowed_run_count :437, first_run :643, last_run :693, season_length :1113,
                             resample_and_rl :87, _cumsum_reset_np :143
     core/utils.py           calc_perc :279
+    core/missing.py         MissingAny.__call__ (MissingBase.__call__ :253 + is_valid :201 + is_missing :318)
     xsdba (when importable) nbutils.quantile
 
 The chain of an index stays on the fused kernels the benchmark measures: ``resample_doy`` returns a :class:`DoyThreshold`
@@ -27,7 +28,11 @@ The chain of an index stays on the fused kernels the benchmark measures: ``resam
 :class:`LazyCompare` that ``resample_and_rl`` runs as ONE fused launch (``xh_run_stats_doy``); ``spell_length_statistics``
 with window 1 (maximum_consecutive_dry_days ...) is the fused compare + run-length kernel.  Both lazy objects turn into
 real DataArrays the moment anything else touches them (attribute access / arithmetic), so code that was not replaced
-keeps working.  A call a wrapper cannot serve (callable ``op``, thresholds with unexpected dims, ``dim != "time"``) is
+keeps working.  Indicator-level fusion: every reducer's kernel also returns the per-period count of valid steps; the
+wrappers remember it per input buffer and the replaced ``MissingAny.__call__`` (what ``Indicator._postprocess`` runs on
+the same DataArray right after the compute, core/indicator.py:1522-1549) answers from it — compute and missing-value
+mask in ONE pass over the data; unit conversion costs no pass either, because the reference converts the THRESHOLD to
+the data's units (``convert_units_to(thresh, data)``), not the data.  A call a wrapper cannot serve (callable ``op``, thresholds with unexpected dims, ``dim != "time"``) is
 forwarded to the ORIGINAL function (``orig``), never approximated.
 """
 
@@ -166,7 +171,7 @@ class LazyCompare(_LazyBase):
 def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     """name -> callable.  ``orig``: the reference's own functions by the same names (fallback for calls the HIP path does
     not serve; absent in the tests, where such calls raise NotImplementedError)."""
-    orig = orig or {}
+    orig = {} if orig is None else orig  # (the SAME dict: install() adds entries after the wrappers exist)
     DA = env.DataArray
 
     def dev():
@@ -176,6 +181,40 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         if name in orig:
             return orig[name](*args, **kwargs)
         raise NotImplementedError(f"{name}: this call is not served by the HIP path and no original function was supplied")
+
+    # ---- Indicator-level fusion (core/indicator.py:1522-1549 -> core/missing.py:253-298) -------------
+    # Every reducer returns the per-period count of valid (non-NaN) steps as a side output of the SAME kernel launch.  It
+    # is remembered per input buffer, so that the missing-value check the Indicator runs right after the compute
+    # (MissingAny()(da, freq, src_timestep, **indexer) on the same DataArray) costs no second pass over the data.
+    import weakref
+
+    valid_cache = {}
+
+    def _buffer_key(x, freq, indexer):
+        ai = x.__array_interface__
+        idx = tuple(sorted((k, repr(v)) for k, v in indexer.items() if v is not None)) if indexer else ()
+        return (ai["data"][0], x.shape, x.strides, x.dtype.str, freq, idx)
+
+    def remember_valid(da, x, freq, valid, indexer=None):
+        """`x`: the C-contiguous time-first values the kernel read.  Only buffers that ARE the DataArray's own storage can be
+        recognised again (a transposed / non-contiguous input was copied by _tfirst: nothing to remember)."""
+        base = da.values if isinstance(da, DA) else None
+        if base is None or not isinstance(base, np.ndarray) or base.__array_interface__["data"][0] != x.__array_interface__["data"][0]:
+            return
+        owner = base if base.base is None else base.base
+        try:
+            ref = weakref.ref(owner)
+        except TypeError:
+            return
+        if len(valid_cache) > 64:
+            valid_cache.clear()
+        valid_cache[_buffer_key(x, freq, indexer)] = (ref, np.asarray(valid))
+
+    def recall_valid(x, freq, indexer):
+        hit = valid_cache.get(_buffer_key(x, freq, indexer))
+        if hit is None or hit[0]() is None:
+            return None
+        return hit[1]
 
     def wrap_periods(a, data, freq, attrs=None, name=None):
         """(P, *cells) -> DataArray(time = period labels of the reference's own resample, *cell dims)."""
@@ -220,7 +259,8 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         thr = as_threshold(threshold, a)
         if thr is None:
             return fallback("threshold_count", da, op, threshold, freq, constrain)
-        out = hgen.threshold_count(x, op, thr, time_axis_of(a), freq, constrain, device=dev())
+        out, valid = hgen.threshold_count(x, op, thr, time_axis_of(a), freq, constrain, device=dev(), with_valid=True)
+        remember_valid(a, x, freq, valid)
         return wrap_periods(a, np.asarray(out).astype(np.int64), freq)  # (bool * 1).resample.sum: int64, no attrs
 
     def count_occurrences(data, threshold, freq, op, constrain=None):  # gen:960-999
@@ -228,7 +268,8 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         thr = as_threshold(env.convert_units_to(threshold, data), a)
         if thr is None:
             return fallback("count_occurrences", data, threshold, freq, op, constrain)
-        out = hgen.count_occurrences(x, thr, op, time_axis_of(a), freq, constrain, device=dev())
+        out, valid = hgen.count_occurrences(x, thr, op, time_axis_of(a), freq, constrain, device=dev(), with_valid=True)
+        remember_valid(a, x, freq, valid)
         return env.to_agg_units(wrap_periods(a, np.asarray(out).astype(np.int64), freq, data.attrs), data, "count", dim="time")
 
     def domain_count(da, low, high, freq):  # gen:364-392
@@ -242,7 +283,8 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         if not isinstance(op, str):
             return fallback("select_resample_op", da, op, freq, out_units, **indexer)
         a, x = _tfirst(da)
-        out = hgen.select_resample_op(x, op, time_axis_of(a), freq, device=dev(), **indexer)
+        out, valid = hgen.select_resample_op(x, op, time_axis_of(a), freq, device=dev(), with_valid=True, **indexer)
+        remember_valid(a, x, freq, valid, indexer)
         o = wrap_periods(a, out, freq, da.attrs, da.name)
         return env.finish_select_resample_op(o, da, op, out_units)
 
@@ -259,8 +301,10 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         reducers = [spell_reducer] if isinstance(spell_reducer, str) else list(spell_reducer)
         outs = []
         for sr in reducers:
-            o = hgen.spell_length_statistics(x, thr, window, win_reducer, op, sr, time_axis_of(a), freq, min_gap,
-                                             resample_before_rl, device=dev(), **indexer)
+            o, valid = hgen.spell_length_statistics(x, thr, window, win_reducer, op, sr, time_axis_of(a), freq, min_gap,
+                                                    resample_before_rl, device=dev(), with_valid=True, **indexer)
+            if not indexer:  # (with an indexer the count is of the unselected data: not what MissingAny wants)
+                remember_valid(a, x, freq, valid)
             w = wrap_periods(a, o, freq, data.attrs)
             if sr == "count":
                 w.attrs["units"] = ""
@@ -420,6 +464,26 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
                     windowed_run_events: hrl.windowed_run_events, windowed_run_count: hrl.windowed_run_count,
                     first_run: hrl.first_run, last_run: hrl.last_run})
 
+    # ---- core/missing.py --------------------------------------------------------------------------------------------------
+    def missing_any_call(self, da, freq=None, src_timestep=None, **indexer):  # MissingBase.__call__ for MissingAny, :253-298, 318-322
+        if freq is None or not isinstance(da, DA) or "time" not in da.dims or (src_timestep not in (None, "D", "1D")):
+            return fallback("MissingAny.__call__", self, da, freq, src_timestep, **indexer)
+        a, x = _tfirst(da)
+        t = time_axis_of(a)
+        if len(t) > 1 and not np.all(np.diff(t.ordinal()) == 1):  # xr.infer_freq(da.time) must be daily
+            return fallback("MissingAny.__call__", self, da, freq, src_timestep, **indexer)
+        idx = {k: v for k, v in indexer.items() if v is not None}
+        valid = recall_valid(x, freq, idx)
+        if valid is None:
+            try:
+                valid = hgen.select_resample_op(x, "count", t, freq, device=dev(), **idx)
+            except Float64FieldError:  # count of a float64 field with a time selection: the reference's business
+                return fallback("MissingAny.__call__", self, da, freq, src_timestep, **indexer)
+        expected = t.expected_count(freq, **idx)
+        valid = np.asarray(valid)
+        miss = valid != expected.reshape((-1,) + (1,) * (valid.ndim - 1))
+        return wrap_periods(a, miss, freq)
+
     # ---- apply_ufunc callees (tier 2) and xsdba ----------------------------------------------------------------------
     def calc_perc(arr, percentiles=None, alpha=1.0, beta=1.0, copy=True):  # utl:279-323
         return hutl.calc_perc(arr, percentiles, alpha, beta, copy, device=dev())
@@ -463,6 +527,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         "rle": rle, "rle_statistics": rle_statistics, "longest_run": longest_run, "windowed_run_events": windowed_run_events,
         "windowed_run_count": windowed_run_count, "first_run": first_run, "last_run": last_run, "season_length": season_length,
         "resample_and_rl": resample_and_rl, "calc_perc": calc_perc, "sdba_quantile": sdba_quantile,
+        "MissingAny.__call__": missing_any_call,
     }
     out = {name: forwarding(name, fn) for name, fn in table.items()}
     # resample_and_rl receives the PATCHED rl.<name> objects (the forwarding wrappers): map those to the host mirrors too
