@@ -34,14 +34,11 @@
 
 namespace {
 
-constexpr int HS_NT = 512;             // threads per workgroup
-constexpr int HS_CW = 32;              // columns per workgroup
-constexpr int HS_RL = HS_NT / HS_CW;   // row lanes per column
-constexpr int HS_U = 16;               // loads in flight per thread
-constexpr int HS_ROWS = HS_RL * HS_U;  // rows a workgroup covers per batch
+constexpr int HS_RL = 16;              // row lanes per column: a workgroup owns CW columns with CW * 16 threads
+constexpr int HS_NT = 512;             // (threads of the diagnostic streaming kernel)
+constexpr int HS_UDEF = 16;            // loads in flight per thread and register set (two sets: ping-pong)
 constexpr int HS_NB = 1024;            // bins per column
 constexpr int HS_NREG = 1020;          // regular bins 2 .. 1021
-constexpr int HS_POOL = 16384;         // candidate keys of a tile (all 32 columns) kept in LDS: 512 per column on average
 constexpr int HS_CAPMAX = 2048;        // ... and at most this many for one column (the largest register sort)
 constexpr int HS_MAXQ = 32;            // quantiles per call on this path
 constexpr uint32_t HS_NANKEY = 0xFFFFFFFFu;
@@ -190,13 +187,14 @@ k_hs_sample(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int64
 // Thread (col, rl) of a tile visits rows rl, rl + 16, ... in batches of HS_U rows; f(values, keys) is called once per batch
 // with the order-preserving keys of hs_key (NaN patterns fail hs_valid; 0xFFFFFFFF for rows past the end and for the columns
 // past C of a ragged tile).
-template <typename F>
+template <int HS_U, int RLT, typename F>
 __device__ __forceinline__ void hs_stream(const float* __restrict__ x, int T, int64_t st, int64_t cc, bool cvalid, int rl, F&& f) {
+  constexpr int HS_ROWS = RLT * HS_U;  // rows a workgroup covers per batch
   // full batches: every row of the batch exists for every row lane.  Buffer loads: a descriptor re-based per batch
   // (scalar), the row offset of load u as the scalar offset, ONE 32-bit per-lane byte offset — no vector address
   // arithmetic and no 64-bit address registers per load (16 loads in flight would hold 32 of them).
   const uint32_t voff = (uint32_t)(((int64_t)rl * st + cc) * 4);
-  const uint32_t rowstep = (uint32_t)(st * 4 * HS_RL);  // bytes between the rows of loads u and u + 1 (host: 256 rows < 4 GiB)
+  const uint32_t rowstep = (uint32_t)(st * 4 * RLT);  // bytes between the rows of loads u and u + 1 (host: 256 rows < 4 GiB)
   const int nfull = T / HS_ROWS;
   const uint32_t padkey = cvalid ? 0u : HS_NANKEY;  // OR-ed into the key: a column past C only ever shows NaN keys
   auto load = [&](float (&dst)[HS_U], int kb) {
@@ -249,14 +247,14 @@ __device__ __forceinline__ void hs_stream(const float* __restrict__ x, int T, in
     float buf[HS_U];
 #pragma unroll
     for (int u = 0; u < HS_U; ++u) {
-      int r = u * HS_RL + rlo;
+      int r = u * RLT + rlo;
       r = r < rem ? r : rem - 1;
       const uint32_t vo = (uint32_t)r * (uint32_t)(st * 4) + (uint32_t)(cc * 4);
       buf[u] = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, 0, 0));
     }
     uint32_t k[HS_U];
 #pragma unroll
-    for (int u = 0; u < HS_U; ++u) k[u] = u * HS_RL + rlo < rem ? (hs_key(buf[u]) | padkey) : HS_NANKEY;
+    for (int u = 0; u < HS_U; ++u) k[u] = u * RLT + rlo < rem ? (hs_key(buf[u]) | padkey) : HS_NANKEY;
     f(buf, k);
   }
 }
@@ -275,37 +273,39 @@ __device__ __forceinline__ int64_t hs_tile_of(int64_t round_base, int64_t ntiles
 // ---- pass 1: histogram + target bins -----------------------------------------------------------------------------------
 // LDS: hist [512][32] u32 (two u16 counters per word: bins 2d, 2d + 1 of column c at [d][c]) | bm [32][32] target-bin
 // bitmap | part [16][32] partial sums | tgt [2 * MAXQ][32] (bin | rank inside the bin << 16) | mcol [32] | cbase [32]
-constexpr size_t HS_LDS1 = (size_t)(HS_NB / 2) * HS_CW * 4 + 32 * HS_CW * 4 + HS_RL * HS_CW * 4 + 2 * HS_MAXQ * HS_CW * 4 + 2 * HS_CW * 4;
+constexpr size_t hs_lds1(int cw) { return (size_t)(HS_NB / 2) * cw * 4 + 32 * cw * 4 + HS_RL * cw * 4 + 2 * HS_MAXQ * cw * 4 + 2 * cw * 4; }
 
-__global__ void __launch_bounds__(HS_NT, 4)
+template <int HS_U, int CW>
+__global__ void __launch_bounds__(CW * HS_RL, 4)
 k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2* __restrict__ lohi,
           const double* __restrict__ qs, int nq, uint32_t* __restrict__ meta_n, uint32_t* __restrict__ meta_m,
           uint32_t* __restrict__ meta_base, uint16_t* __restrict__ crank, uint32_t* __restrict__ bitmap_g,
           uint32_t* __restrict__ flist, HsStat* __restrict__ stat, int xcd_map, int abl) {
+  constexpr int NT = CW * HS_RL, POOL = CW * 512;  // threads per workgroup; LDS pool of candidate keys in pass 2
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* bm = hist + (HS_NB / 2) * HS_CW;
-  uint32_t* part = bm + 32 * HS_CW;
-  uint32_t* tgt = part + HS_RL * HS_CW;
-  uint32_t* mcol = tgt + 2 * HS_MAXQ * HS_CW;
-  uint32_t* cbase = mcol + HS_CW;
-  const int tid = threadIdx.x, col = tid & (HS_CW - 1), rl = tid >> 5;
+  uint32_t* bm = hist + (HS_NB / 2) * CW;
+  uint32_t* part = bm + 32 * CW;
+  uint32_t* tgt = part + HS_RL * CW;
+  uint32_t* mcol = tgt + 2 * HS_MAXQ * CW;
+  uint32_t* cbase = mcol + CW;
+  const int tid = threadIdx.x, col = tid & (CW - 1), rl = tid / CW;
   const int ntgt = 2 * nq;
-  const int64_t ntiles = (C + HS_CW - 1) / HS_CW;
+  const int64_t ntiles = (C + CW - 1) / CW;
   // zero the histogram and the bitmap (again at the end of every tile)
-  for (int i = tid; i < (HS_NB / 2) * HS_CW + 32 * HS_CW; i += HS_NT) hist[i] = 0u;
+  for (int i = tid; i < (HS_NB / 2) * CW + 32 * CW; i += NT) hist[i] = 0u;
   __syncthreads();
   for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
     const int64_t tile = hs_tile_of(round_base, ntiles, xcd_map);
     if (tile < 0) break;  // (block-uniform; only in the last round)
-    const int64_t c = tile * HS_CW + col;
+    const int64_t c = tile * CW + col;
     const bool cvalid = c < C;
     const int64_t cc = cvalid ? c : C - 1;
     const uint2 lh = lohi[cc];
     const HsScale s = hs_scale(lh.x, lh.y);
     uint32_t* mycol = hist + col;
     uint32_t dummy = 0;
-    hs_stream(x, T, st, cc, cvalid, rl, [&](const float (&v)[HS_U], const uint32_t (&k)[HS_U]) {
+    hs_stream<HS_U, HS_RL>(x, T, st, cc, cvalid, rl, [&](const float (&v)[HS_U], const uint32_t (&k)[HS_U]) {
       if (abl & 2) {  // diagnostics: loads only
 #pragma unroll
         for (int u = 0; u < HS_U; ++u) dummy ^= k[u];
@@ -315,30 +315,31 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
       for (int u = 0; u < HS_U; ++u) {
         const uint32_t b = hs_bin(v[u], k[u], s);
         const uint32_t val = hs_valid(k[u]) ? (1u << ((b & 1u) << 4)) : 0u;
-        atomicAdd(mycol + (b >> 1) * HS_CW, val);
+        atomicAdd(mycol + (b >> 1) * CW, val);
       }
     });
     if ((abl & 2) && dummy == 0x12345679u) atomicAdd(&stat->errors, 1u);
     __syncthreads();
+    if (abl & 4) continue;  // diagnostics: no tile epilogue (wrong results, the histogram is not even cleared)
     // ---- exclusive prefix sums, in place: thread (col, rl) owns words [rl * 32, rl * 32 + 32) = bins [rl * 64, ...)
     uint32_t ssum = 0;
 #pragma unroll 8
     for (int i = 0; i < 32; ++i) {
-      const uint32_t w = hist[(rl * 32 + i) * HS_CW + col];
+      const uint32_t w = hist[(rl * 32 + i) * CW + col];
       ssum += (w & 0xFFFFu) + (w >> 16);
     }
-    part[rl * HS_CW + col] = ssum;
+    part[rl * CW + col] = ssum;
     __syncthreads();
     uint32_t run = 0, n = 0;
 #pragma unroll
     for (int r = 0; r < HS_RL; ++r) {
-      const uint32_t p = part[r * HS_CW + col];
+      const uint32_t p = part[r * CW + col];
       run += r < rl ? p : 0u;
       n += p;
     }
 #pragma unroll 8
     for (int i = 0; i < 32; ++i) {
-      const int idx = (rl * 32 + i) * HS_CW + col;
+      const int idx = (rl * 32 + i) * CW + col;
       const uint32_t w = hist[idx];
       const uint32_t c0 = w & 0xFFFFu, c1 = w >> 16;
       hist[idx] = run | ((run + c0) << 16);  // counts below bin 2d | below bin 2d + 1 (<= n <= T <= 65535)
@@ -347,7 +348,7 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
     __syncthreads();
     auto below = [&](uint32_t b) -> uint32_t {  // keys in bins < b, b in [0, 1024]
       if (b >= (uint32_t)HS_NB) return n;
-      const uint32_t w = hist[(b >> 1) * HS_CW + col];
+      const uint32_t w = hist[(b >> 1) * CW + col];
       return (b & 1u) ? (w >> 16) : (w & 0xFFFFu);
     };
     // ---- the bin and the rank inside it of every target; mark the bins that need a second look
@@ -364,14 +365,14 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
           hi_b = le ? hi_b : mid - 1u;
         }
         e = lo_b | ((r - below(lo_b)) << 16);
-        if (lo_b != 1u && lo_b != s.binH) atomicOr(&bm[(lo_b >> 5) * HS_CW + col], 1u << (lo_b & 31u));
+        if (lo_b != 1u && lo_b != s.binH) atomicOr(&bm[(lo_b >> 5) * CW + col], 1u << (lo_b & 31u));
       }
-      tgt[j * HS_CW + col] = e;
+      tgt[j * CW + col] = e;
     }
     __syncthreads();
     // ---- candidates below each target: keys of the marked bins, words [2 rl, 2 rl + 1] of the bitmap per thread
     auto marked_below = [&](int w, uint32_t limit_bit) -> uint32_t {  // keys of the marked bins of word w below bit `limit_bit`
-      uint32_t bits = bm[w * HS_CW + col];
+      uint32_t bits = bm[w * CW + col];
       if (limit_bit < 32u) bits &= (1u << limit_bit) - 1u;
       uint32_t acc = 0;
       while (bits) {
@@ -381,20 +382,20 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
       }
       return acc;
     };
-    part[rl * HS_CW + col] = marked_below(2 * rl, 32u) + marked_below(2 * rl + 1, 32u);
+    part[rl * CW + col] = marked_below(2 * rl, 32u) + marked_below(2 * rl + 1, 32u);
     __syncthreads();
     uint32_t m = 0;
 #pragma unroll
-    for (int r = 0; r < HS_RL; ++r) m += part[r * HS_CW + col];
+    for (int r = 0; r < HS_RL; ++r) m += part[r * CW + col];
     // the tile's candidate lists share one LDS pool in pass 2: column offsets in column order; a column that does not
     // fit (or exceeds the largest register sort) is flagged for the column kernels
     if (rl == 0) mcol[col] = cvalid ? m : 0u;
     __syncthreads();
     if (tid == 0) {
       uint32_t runp = 0;
-      for (int k = 0; k < HS_CW; ++k) {
+      for (int k = 0; k < CW; ++k) {
         const uint32_t mk = mcol[k];
-        const bool fl = mk > (uint32_t)HS_CAPMAX || runp + mk > (uint32_t)HS_POOL;
+        const bool fl = mk > (uint32_t)HS_CAPMAX || runp + mk > (uint32_t)POOL;
         cbase[k] = fl ? HS_FLAGGED : runp;
         runp += fl ? 0u : mk;
       }
@@ -403,7 +404,7 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
     const uint32_t mybase = cbase[col];
     const bool flagged = mybase == HS_FLAGGED;
     for (int j = rl; j < ntgt; j += HS_RL) {
-      const uint32_t e = tgt[j * HS_CW + col];
+      const uint32_t e = tgt[j * CW + col];
       uint32_t cr = HS_SPEC_NONE;
       if (e != HS_SPEC_NONE) {
         const uint32_t b = e & 0xFFFFu, o = e >> 16;
@@ -412,13 +413,13 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
         else {
           const int w = (int)(b >> 5);
           uint32_t mp = 0;
-          for (int r = 0; r < (w >> 1); ++r) mp += part[r * HS_CW + col];
+          for (int r = 0; r < (w >> 1); ++r) mp += part[r * CW + col];
           if (w & 1) mp += marked_below(w - 1, 32u);
           mp += marked_below(w, b & 31u);
           cr = mp + o;
         }
       }
-      if (cvalid) crank[(tile * ntgt + j) * HS_CW + col] = (uint16_t)cr;
+      if (cvalid) crank[(tile * ntgt + j) * CW + col] = (uint16_t)cr;
     }
     if (rl == 0 && cvalid) {
       meta_n[c] = n;
@@ -430,11 +431,32 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
     }
     __syncthreads();  // every reader of bm / hist / part is done
     // bitmap of the tile (pass 2 turns the keys of flagged columns into NaN keys: nothing is collected there), then clear
-    for (int i = tid; i < 32 * HS_CW; i += HS_NT) bitmap_g[tile * (32 * HS_CW) + i] = bm[i];
+    for (int i = tid; i < 32 * CW; i += NT) bitmap_g[tile * (32 * CW) + i] = bm[i];
     __syncthreads();
-    for (int i = tid; i < (HS_NB / 2) * HS_CW + 32 * HS_CW; i += HS_NT) hist[i] = 0u;
+    for (int i = tid; i < (HS_NB / 2) * CW + 32 * CW; i += NT) hist[i] = 0u;
     __syncthreads();
   }
+}
+
+// diagnostics only (XH_HIST_GEOM): the bare streaming loop with CWT columns x (512 / CWT) row lanes per workgroup — what
+// does the access pattern itself sustain?  (32 columns: one 128-byte line per row and workgroup; 64: two; 128: four)
+template <int CWT, int HS_U>
+__global__ void __launch_bounds__(HS_NT, 4)
+k_hs_stream_test(const float* __restrict__ x, int T, int64_t C, int64_t st, HsStat* __restrict__ stat) {
+  constexpr int RLT = HS_NT / CWT;
+  const int tid = threadIdx.x, col = tid & (CWT - 1), rl = tid / CWT;
+  const int64_t ntiles = (C + CWT - 1) / CWT;
+  uint32_t dummy = 0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t c = tile * CWT + col;
+    const bool cvalid = c < C;
+    const int64_t cc = cvalid ? c : C - 1;
+    hs_stream<HS_U, RLT>(x, T, st, cc, cvalid, rl, [&](const float (&v)[HS_U], const uint32_t (&k)[HS_U]) {
+#pragma unroll
+      for (int u = 0; u < HS_U; ++u) dummy ^= k[u];
+    });
+  }
+  if (dummy == 0x12345679u) atomicAdd(&stat->errors, 1u);
 }
 
 // ---- wave-wide bitonic sort of 64 * K keys held K per lane (element i = lane * K + r), ascending ---------------------
@@ -487,44 +509,46 @@ __device__ __forceinline__ void hs_sort_column(uint32_t* __restrict__ list, uint
 
 // ---- pass 2: collect the keys of the target bins, sort them per column, pick + lerp -----------------------------------
 // LDS: cand [16384] keys (the columns' lists back to back) | bm [32][32] | cursor [32] | tv [8 waves][64] picked keys
-constexpr size_t HS_LDS2 = (size_t)HS_POOL * 4 + 32 * HS_CW * 4 + HS_CW * 4 + (HS_NT / 64) * 64 * 4;
+constexpr size_t hs_lds2(int cw) { return (size_t)cw * 512 * 4 + 32 * cw * 4 + cw * 4 + (size_t)(cw * HS_RL / 64) * 64 * 4; }
 
-__global__ void __launch_bounds__(HS_NT, 4)
+template <int HS_U, int CW>
+__global__ void __launch_bounds__(CW * HS_RL, 4)
 k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2* __restrict__ lohi,
              const double* __restrict__ qs, int nq, const uint32_t* __restrict__ meta_n, const uint32_t* __restrict__ meta_m,
              const uint32_t* __restrict__ meta_base, const uint16_t* __restrict__ crank, const uint32_t* __restrict__ bitmap_g, float* __restrict__ out, int64_t ocs,
              int64_t oqs, HsStat* __restrict__ stat, int xcd_map, int abl) {
+  constexpr int NT = CW * HS_RL, POOL = CW * 512;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* cand = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* bm = cand + HS_POOL;
-  uint32_t* cursor = bm + 32 * HS_CW;
-  uint32_t* tvall = cursor + HS_CW;
-  const int tid = threadIdx.x, col = tid & (HS_CW - 1), rl = tid >> 5;
+  uint32_t* bm = cand + POOL;
+  uint32_t* cursor = bm + 32 * CW;
+  uint32_t* tvall = cursor + CW;
+  const int tid = threadIdx.x, col = tid & (CW - 1), rl = tid / CW;
   const int lane = tid & 63, wv = tid >> 6;
   const int ntgt = 2 * nq;
-  const int64_t ntiles = (C + HS_CW - 1) / HS_CW;
+  const int64_t ntiles = (C + CW - 1) / CW;
   for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
     const int64_t tile = hs_tile_of(round_base, ntiles, xcd_map);
     if (tile < 0) break;  // (block-uniform; only in the last round)
-    const int64_t c = tile * HS_CW + col;
+    const int64_t c = tile * CW + col;
     const bool cvalid = c < C;
     const int64_t cc = cvalid ? c : C - 1;
     const uint2 lh = lohi[cc];
     const HsScale s = hs_scale(lh.x, lh.y);
     const uint32_t mymax = meta_m[cc];
     const bool collect = cvalid && mymax != HS_FLAGGED;
-    for (int i = tid; i < 32 * HS_CW; i += HS_NT) bm[i] = bitmap_g[tile * (32 * HS_CW) + i];
-    if (tid < HS_CW) cursor[tid] = 0u;
+    for (int i = tid; i < 32 * CW; i += NT) bm[i] = bitmap_g[tile * (32 * CW) + i];
+    if (tid < CW) cursor[tid] = 0u;
     __syncthreads();
     uint32_t* mylist = cand + (collect ? meta_base[cc] : 0u);
     const uint32_t* mybm = bm + col;
-    hs_stream(x, T, st, cc, collect, rl, [&](const float (&v)[HS_U], const uint32_t (&k)[HS_U]) {
+    hs_stream<HS_U, HS_RL>(x, T, st, cc, collect, rl, [&](const float (&v)[HS_U], const uint32_t (&k)[HS_U]) {
       // all bins, then all bitmap words (16 LDS reads in flight), then ONE cursor atomic per lane and batch
       uint32_t b[HS_U], w[HS_U];
 #pragma unroll
       for (int u = 0; u < HS_U; ++u) b[u] = hs_bin(v[u], k[u], s);
 #pragma unroll
-      for (int u = 0; u < HS_U; ++u) w[u] = mybm[(b[u] >> 5) * HS_CW];
+      for (int u = 0; u < HS_U; ++u) w[u] = mybm[(b[u] >> 5) * CW];
       uint32_t hit = 0;
 #pragma unroll
       for (int u = 0; u < HS_U; ++u) hit |= (((w[u] >> (b[u] & 31u)) & 1u) & (hs_valid(k[u]) ? 1u : 0u)) << u;
@@ -541,8 +565,8 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
     __syncthreads();
     // ---- one wave per column: sort, pick, lerp (utl:464-491), store
     uint32_t* tv = tvall + wv * 64;
-    for (int k = wv; k < HS_CW; k += HS_NT / 64) {
-      const int64_t ck = tile * HS_CW + k;
+    for (int k = wv; k < CW; k += NT / 64) {
+      const int64_t ck = tile * CW + k;
       if (ck >= C) break;  // (wave-uniform)
       const uint32_t mm = meta_m[ck];
       if (mm == HS_FLAGGED) continue;
@@ -560,7 +584,7 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
       const uint32_t n = meta_n[ck];
       const uint2 lhk = lohi[ck];
       if (lane < ntgt) {
-        const uint32_t cr = crank[(tile * ntgt + lane) * HS_CW + k];
+        const uint32_t cr = crank[(tile * ntgt + lane) * CW + k];
         uint32_t key = HS_NANKEY;
         if (cr == HS_SPEC_LO) key = lhk.x;
         else if (cr == HS_SPEC_HI) key = lhk.y;
@@ -617,16 +641,20 @@ k_hs_scatter(const float* __restrict__ tmp, int64_t nf, int nq, const uint32_t* 
 int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq, float* out,
                    int64_t out_cstride, int64_t out_qstride) {
   if (T <= 1024 || T > 32768 || nq < 1 || nq > HS_MAXQ || C < 1) return XH_ERR_NOTIMPL;  // (32768: the column kernels' limit)
-  if ((unsigned long long)((HS_ROWS + HS_RL) * st + C) * 4ull >= (1ull << 32)) return XH_ERR_NOTIMPL;  // 32-bit offsets inside a batch
+  if ((unsigned long long)((HS_RL * 32 + HS_RL) * st + C) * 4ull >= (1ull << 32)) return XH_ERR_NOTIMPL;  // 32-bit offsets inside a batch (U <= 32)
   if (xh_diag_env("XH_SELECT_NOHIST")) return XH_ERR_NOTIMPL;  // A/B against the transposed pipeline
-  const int64_t ntiles = cdiv64(C, HS_CW);
+  // columns per workgroup: 64 (1024 threads, one workgroup per CU, 256-byte row segments: the bare streaming loop runs
+  // at 6.2 TB/s against 5.3 TB/s with 32 columns / 128-byte segments, profiles/r03/select_hist_geometry.txt)
+  const char* ecw = xh_diag_env("XH_HIST_CW");
+  const int CWH = (ecw && atoi(ecw) == 32) ? 32 : 64;
+  const int64_t ntiles = cdiv64(C, CWH);
   const int ntgt = 2 * nq;
   // fallback capacity: flagged columns are recomputed from a gathered copy; more than that -> everything the old way
   const int64_t Tp = (T + 63) & ~(int64_t)63;
   int64_t nfmax = C < 4096 ? C : 4096;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t b_lohi = al(sizeof(uint2) * (size_t)C), b_n = al(4 * (size_t)C), b_m = al(4 * (size_t)C), b_base = al(4 * (size_t)C);
-  const size_t b_crank = al(2 * (size_t)ntiles * ntgt * HS_CW), b_bm = al(4 * (size_t)ntiles * 32 * HS_CW);
+  const size_t b_crank = al(2 * (size_t)ntiles * ntgt * CWH), b_bm = al(4 * (size_t)ntiles * 32 * CWH);
   const size_t b_flist = al(4 * (size_t)C), b_stat = al(sizeof(HsStat));
   const size_t b_gather = al(4 * (size_t)nfmax * (size_t)Tp), b_tmp = al(4 * (size_t)nfmax * (size_t)nq);
   void* ws = nullptr;
@@ -657,24 +685,44 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
     XH_LAUNCH_CHECK();
   }
   int64_t nblk = ntiles;
-  const int64_t maxblk = (int64_t)ctx->num_cu * 2;
+  const int64_t maxblk = (int64_t)ctx->num_cu * (CWH == 32 ? 2 : 1);  // LDS: two 512-thread or one 1024-thread workgroup per CU
   if (nblk > maxblk) nblk = maxblk;
   if (nblk >= 8) nblk &= ~(int64_t)7;  // the XCD-aware tile map wants a multiple of 8 (the tile loop is grid-strided)
   const int xcd_map = xh_diag_env("XH_HIST_XCD") ? 1 : 0;  // measured on config 4: 42.8 ms with the map, 41.3 without -> off
-  const char* eabl = xh_diag_env("XH_HIST_ABL");  // diagnostics: 1 = no candidate sort, 2 = pass 1 loads only (wrong results)
+  const char* eabl = xh_diag_env("XH_HIST_ABL");  // diagnostics: 1 = no candidate sort, 2 = pass 1 loads only, 4 = no pass-1 tile epilogue (wrong results)
   const int abl = eabl ? atoi(eabl) : 0;
   {
     const char* g = xh_diag_env("XH_HIST_GRID");  // diagnostics: workgroups per CU
     if (g && atoi(g) > 0 && (int64_t)ctx->num_cu * atoi(g) < ntiles) nblk = (int64_t)ctx->num_cu * atoi(g);
   }
-  XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_LDS1));
-  XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_LDS2));
-  hipLaunchKernelGGL(k_hs_hist, dim3((unsigned)nblk), dim3(HS_NT), HS_LDS1, ctx->stream, x, (int)T, C, st, lohi, d_q, nq, meta_n,
-                     meta_m, meta_base, crank, bitmap_g, flist, stat, xcd_map, abl);
-  XH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_hs_collect, dim3((unsigned)nblk), dim3(HS_NT), HS_LDS2, ctx->stream, x, (int)T, C, st, lohi, d_q, nq,
-                     meta_n, meta_m, meta_base, crank, bitmap_g, out, out_cstride, out_qstride, stat, xcd_map, abl);
-  XH_LAUNCH_CHECK();
+  if (const char* eg = xh_diag_env("XH_HIST_GEOM")) {  // diagnostics: time the bare streaming loop in another geometry, then go on
+    const int g = atoi(eg);
+    const int64_t nt = cdiv64(C, g);
+    int64_t nb = nt < maxblk ? nt : maxblk;
+    if (g == 64) hipLaunchKernelGGL((k_hs_stream_test<64, 16>), dim3((unsigned)nb), dim3(HS_NT), 0, ctx->stream, x, (int)T, C, st, stat);
+    else if (g == 128) hipLaunchKernelGGL((k_hs_stream_test<128, 16>), dim3((unsigned)nb), dim3(HS_NT), 0, ctx->stream, x, (int)T, C, st, stat);
+    else if (g == 256) hipLaunchKernelGGL((k_hs_stream_test<256, 16>), dim3((unsigned)nb), dim3(HS_NT), 0, ctx->stream, x, (int)T, C, st, stat);
+    else hipLaunchKernelGGL((k_hs_stream_test<32, 16>), dim3((unsigned)nb), dim3(HS_NT), 0, ctx->stream, x, (int)T, C, st, stat);
+    XH_LAUNCH_CHECK();
+  }
+  const char* eu = xh_diag_env("XH_HIST_U");  // diagnostics: loads in flight per register set (8 | 16)
+  const int U = eu ? atoi(eu) : HS_UDEF;
+#define XH_HS_LAUNCH(UU, CC)                                                                                                          \
+  {                                                                                                                                  \
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist<UU, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds1(CC))); \
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<UU, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2(CC))); \
+    hipLaunchKernelGGL((k_hs_hist<UU, CC>), dim3((unsigned)nblk), dim3(CC * HS_RL), hs_lds1(CC), ctx->stream, x, (int)T, C, st, lohi,  \
+                       d_q, nq, meta_n, meta_m, meta_base, crank, bitmap_g, flist, stat, xcd_map, abl);                              \
+    XH_LAUNCH_CHECK();                                                                                                               \
+    hipLaunchKernelGGL((k_hs_collect<UU, CC>), dim3((unsigned)nblk), dim3(CC * HS_RL), hs_lds2(CC), ctx->stream, x, (int)T, C, st,    \
+                       lohi, d_q, nq, meta_n, meta_m, meta_base, crank, bitmap_g, out, out_cstride, out_qstride, stat, xcd_map, abl); \
+    XH_LAUNCH_CHECK();                                                                                                               \
+  }
+  if (CWH == 32 && U == 8) XH_HS_LAUNCH(8, 32)
+  else if (CWH == 32) XH_HS_LAUNCH(16, 32)
+  else if (U == 8) XH_HS_LAUNCH(8, 64)
+  else XH_HS_LAUNCH(16, 64)
+#undef XH_HS_LAUNCH
   HsStat h;
   XH_CHECK_HIP(hipMemcpyAsync(&h, stat, sizeof(HsStat), hipMemcpyDeviceToHost, ctx->stream));
   XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
