@@ -460,8 +460,28 @@ k_hs_stream_test(const float* __restrict__ x, int T, int64_t C, int64_t st, HsSt
 }
 
 // ---- wave-wide bitonic sort of 64 * K keys held K per lane (element i = lane * K + r), ascending ---------------------
+// value of lane ^ m: DPP inside the VALU for m = 1, 2, 8 (quad_perm / row_ror:8) and two masked DPP moves for m = 4
+// (row_shl:4 into banks 0, 2; row_shr:4 into banks 1, 3) — verified lane by lane on gfx950 by tools/dpp_test.hip;
+// ds_bpermute (the LDS crossbar) only for m = 16, 32.  With every exchange on ds_bpermute the deferred sort kernel was
+// bound by the crossbar (168 of them per 512-key column), not by the VALU.
+__device__ __forceinline__ uint32_t hs_lane_xor(uint32_t v, int m) {
+  switch (m) {
+    case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    case 4: {
+      const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);
+      return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);
+    }
+    case 8: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);
+    default: return (uint32_t)__shfl_xor((int)v, m);
+  }
+}
+
 template <int K>
 __device__ __forceinline__ void hs_wave_sort(uint32_t (&v)[K], int lane) {
+  // Where the direction of a comparator depends on the lane, it is ONE compare + selects (v_cmp, the lane condition folded
+  // into the compare mask by a scalar xnor, v_cndmask) instead of v_min + v_max + v_cndmask: a compare and a min / max
+  // issue at the same (half) rate, so a cross-lane step costs two VALU instructions per key instead of three.
 #pragma unroll
   for (int k = 2; k <= 64 * K; k <<= 1) {
 #pragma unroll
@@ -473,19 +493,25 @@ __device__ __forceinline__ void hs_wave_sort(uint32_t (&v)[K], int lane) {
         const bool takemin = lower == up;
 #pragma unroll
         for (int r = 0; r < K; ++r) {
-          const uint32_t p = (uint32_t)__shfl_xor((int)v[r], mlane);
-          const uint32_t mn = v[r] < p ? v[r] : p, mx = v[r] < p ? p : v[r];
-          v[r] = takemin ? mn : mx;
+          const uint32_t p = hs_lane_xor(v[r], mlane);
+          v[r] = ((v[r] < p) == takemin) ? v[r] : p;  // (equal keys: either copy)
         }
       } else {  // inside the lane: registers r and r ^ j
 #pragma unroll
         for (int r = 0; r < K; ++r) {
           if ((r & j) == 0) {
-            const bool up = ((lane * K + r) & k) == 0;
             const uint32_t a = v[r], b = v[r | j];
-            const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
-            v[r] = up ? mn : mx;
-            v[r | j] = up ? mx : mn;
+            if (k < K) {  // direction known at compile time
+              const bool up = (r & k) == 0;
+              const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
+              v[r] = up ? mn : mx;
+              v[r | j] = up ? mx : mn;
+            } else {
+              const bool up = ((lane * K + r) & k) == 0;
+              const bool keep = (a < b) == up;
+              v[r] = keep ? a : b;
+              v[r | j] = keep ? b : a;
+            }
           }
         }
       }
@@ -507,26 +533,67 @@ __device__ __forceinline__ void hs_sort_column(uint32_t* __restrict__ list, uint
     if ((uint32_t)(lane * K + r) < m) list[lane * K + r] = v[r];  // (the next column's list starts at list + m)
 }
 
-// ---- pass 2: collect the keys of the target bins, sort them per column, pick + lerp -----------------------------------
-// LDS: cand [16384] keys (the columns' lists back to back) | bm [32][32] | cursor [32] | tv [8 waves][64] picked keys
-constexpr size_t hs_lds2(int cw) { return (size_t)cw * 512 * 4 + 32 * cw * 4 + cw * 4 + (size_t)(cw * HS_RL / 64) * 64 * 4; }
+// One column, its candidates sorted in `list` (LDS): pick the 2 nq order statistics by position, Hyndman-Fan lerp
+// (utl:464-491), store the nq quantiles.  One wave; tv = 64 words of LDS scratch.
+template <int CW>
+__device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm, int64_t tile, int k, int64_t ck, int lane, int ntgt,
+                                              int nq, const double* __restrict__ qs, const uint32_t* __restrict__ meta_n,
+                                              const uint2* __restrict__ lohi, const uint16_t* __restrict__ crank, uint32_t* tv,
+                                              float* __restrict__ out, int64_t ocs, int64_t oqs) {
+  const uint32_t n = meta_n[ck];
+  const uint2 lhk = lohi[ck];
+  if (lane < ntgt) {
+    const uint32_t cr = crank[(tile * ntgt + lane) * CW + k];
+    uint32_t key = HS_NANKEY;
+    if (cr == HS_SPEC_LO) key = lhk.x;
+    else if (cr == HS_SPEC_HI) key = lhk.y;
+    else if (cr < mm) key = list[cr];
+    tv[lane] = key;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < nq) {
+    const float left = xh_key2f(tv[2 * lane]), right = xh_key2f(tv[2 * lane + 1]);
+    double r;
+    if (n == 0u) r = xh_nan64();
+    else if (n < 2u) r = (double)left;
+    else {
+      const double nn = (double)n, qq = qs[lane];
+      const double vi = nn * qq + (1.0 + qq * (1.0 - 1.0 - 1.0)) - 1.0;
+      if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
+      else {
+        const double gamma = vi - floor(vi);
+        const float diff = right - left;
+        r = (double)left + (double)diff * gamma;
+        if (gamma >= 0.5) r = (double)right - (double)diff * (1.0 - gamma);
+      }
+    }
+    out[ck * ocs + (int64_t)lane * oqs] = (float)r;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
 
-template <int HS_U, int CW>
+// ---- pass 2: collect the keys of the target bins, sort them per column, pick + lerp -----------------------------------
+// LDS: cand [CW * 512] keys (the columns' lists back to back) | bm [32][CW] | cursor [CW] | tv [waves][64] picked keys | trash
+constexpr size_t hs_lds2(int cw) { return (size_t)cw * 512 * 4 + 32 * cw * 4 + cw * 4 + (size_t)(cw * HS_RL / 64) * 64 * 4 + 16; }
+
+template <int HS_U, int CW, bool DEFER>
 __global__ void __launch_bounds__(CW * HS_RL, 4)
 k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2* __restrict__ lohi,
              const double* __restrict__ qs, int nq, const uint32_t* __restrict__ meta_n, const uint32_t* __restrict__ meta_m,
              const uint32_t* __restrict__ meta_base, const uint16_t* __restrict__ crank, const uint32_t* __restrict__ bitmap_g, float* __restrict__ out, int64_t ocs,
-             int64_t oqs, HsStat* __restrict__ stat, int xcd_map, int abl) {
+             int64_t oqs, HsStat* __restrict__ stat, int xcd_map, int abl, uint32_t* __restrict__ cand_g) {
   constexpr int NT = CW * HS_RL, POOL = CW * 512;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* cand = reinterpret_cast<uint32_t*>(smem);
   uint32_t* bm = cand + POOL;
   uint32_t* cursor = bm + 32 * CW;
   uint32_t* tvall = cursor + CW;
+  uint32_t* trash = tvall + (NT / 64) * 64;
   const int tid = threadIdx.x, col = tid & (CW - 1), rl = tid / CW;
   const int lane = tid & 63, wv = tid >> 6;
   const int ntgt = 2 * nq;
   const int64_t ntiles = (C + CW - 1) / CW;
+  if (tid == 0) tvall[0] = 0u;
   for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
     const int64_t tile = hs_tile_of(round_base, ntiles, xcd_map);
     if (tile < 0) break;  // (block-uniform; only in the last round)
@@ -553,16 +620,40 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
 #pragma unroll
       for (int u = 0; u < HS_U; ++u) hit |= (((w[u] >> (b[u] & 31u)) & 1u) & (hs_valid(k[u]) ? 1u : 0u)) << u;
       if (__any(hit != 0u)) {
+        // one reservation per lane and batch; the stores are unconditional (a key that is no candidate goes to a trash
+        // word) — no exec-mask round trip per key.  pos < the column's count by construction (pass 1 counted the same bins).
         uint32_t pos = atomicAdd(&cursor[col], (uint32_t)__popc(hit));
 #pragma unroll
         for (int u = 0; u < HS_U; ++u) {
           const uint32_t bit = (hit >> u) & 1u;
-          if (bit && pos < mymax) mylist[pos] = k[u];
+          uint32_t* dst = bit ? mylist + pos : trash;
+          *dst = k[u];
           pos += bit;
         }
       }
     });
     __syncthreads();
+    if (DEFER) {
+      // one workgroup per CU (LDS): a sort in here would run with nothing streaming beside it.  The tile's candidate
+      // lists leave for global memory as they lie in the pool (one coalesced copy of ~1 % of the tile's bytes);
+      // k_hs_finish sorts them with the whole chip's VALUs.
+      uint32_t end = 0;
+      if (tid < CW) {
+        const int64_t ck = tile * CW + tid;
+        if (ck < C && meta_m[ck] != HS_FLAGGED) {
+          if (cursor[tid] != meta_m[ck]) atomicAdd(&stat->errors, 1u);
+          end = meta_base[ck] + meta_m[ck];
+        }
+        atomicMax(&tvall[0], end);
+      }
+      __syncthreads();
+      const uint32_t tot = tvall[0];
+      uint32_t* dst = cand_g + tile * (int64_t)POOL;
+      for (uint32_t i = tid; i < tot; i += NT) dst[i] = cand[i];
+      __syncthreads();
+      if (tid == 0) tvall[0] = 0u;
+      continue;
+    }
     // ---- one wave per column: sort, pick, lerp (utl:464-491), store
     uint32_t* tv = tvall + wv * 64;
     for (int k = wv; k < CW; k += NT / 64) {
@@ -581,38 +672,56 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
       else if (m > 64u) hs_sort_column<2>(list, m, lane);
       else if (m > 1u) hs_sort_column<1>(list, m, lane);
       __builtin_amdgcn_wave_barrier();
-      const uint32_t n = meta_n[ck];
-      const uint2 lhk = lohi[ck];
-      if (lane < ntgt) {
-        const uint32_t cr = crank[(tile * ntgt + lane) * CW + k];
-        uint32_t key = HS_NANKEY;
-        if (cr == HS_SPEC_LO) key = lhk.x;
-        else if (cr == HS_SPEC_HI) key = lhk.y;
-        else if (cr < mm) key = list[cr];
-        tv[lane] = key;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < nq) {
-        const float left = xh_key2f(tv[2 * lane]), right = xh_key2f(tv[2 * lane + 1]);
-        double r;
-        if (n == 0u) r = xh_nan64();
-        else if (n < 2u) r = (double)left;
-        else {
-          const double nn = (double)n, qq = qs[lane];
-          const double vi = nn * qq + (1.0 + qq * (1.0 - 1.0 - 1.0)) - 1.0;
-          if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
-          else {
-            const double gamma = vi - floor(vi);
-            const float diff = right - left;
-            r = (double)left + (double)diff * gamma;
-            if (gamma >= 0.5) r = (double)right - (double)diff * (1.0 - gamma);
-          }
-        }
-        out[ck * ocs + (int64_t)lane * oqs] = (float)r;
-      }
-      __builtin_amdgcn_wave_barrier();
+      hs_pick_store<CW>(list, mm, tile, k, ck, lane, ntgt, nq, qs, meta_n, lohi, crank, tv, out, ocs, oqs);
     }
     __syncthreads();  // cand / bm / cursor are rewritten by the next tile
+  }
+}
+
+// ---- pass 3 (deferred form of the epilogue above): one wave per column sorts its candidates in registers ----------------
+template <int K>
+__device__ __forceinline__ void hs_sort_global(const uint32_t* __restrict__ src, uint32_t* buf, uint32_t m, int lane) {
+  uint32_t v[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) {  // element i = r * 64 + lane on the way in (coalesced); the sort does not care
+    const uint32_t i = (uint32_t)(r * 64 + lane);
+    v[r] = i < m ? src[i] : HS_NANKEY;
+  }
+  hs_wave_sort<K>(v, lane);
+#pragma unroll
+  for (int r = 0; r < K; ++r) buf[lane * K + r] = v[r];
+}
+
+// BIG = false: the columns with at most 512 candidates (2 KB of LDS per wave: many waves per CU hide the chain of
+// dependent loads meta -> list -> positions); BIG = true: the few larger ones.
+template <int CW, bool BIG>
+__global__ void __launch_bounds__(256)
+k_hs_finish(const uint32_t* __restrict__ cand_g, int64_t C, const uint2* __restrict__ lohi, const double* __restrict__ qs, int nq,
+            const uint32_t* __restrict__ meta_n, const uint32_t* __restrict__ meta_m, const uint32_t* __restrict__ meta_base,
+            const uint16_t* __restrict__ crank, float* __restrict__ out, int64_t ocs, int64_t oqs) {
+  constexpr int POOL = CW * 512;
+  __shared__ uint32_t sorted[4][BIG ? HS_CAPMAX : 512];
+  __shared__ uint32_t tvs[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ntgt = 2 * nq;
+  for (int64_t ck = (int64_t)blockIdx.x * 4 + wv; ck < C; ck += (int64_t)gridDim.x * 4) {
+    const uint32_t mm = meta_m[ck];
+    if (mm == HS_FLAGGED || (mm > 512u) != BIG) continue;
+    const int64_t tile = ck / CW;
+    const int k = (int)(ck - tile * CW);
+    const uint32_t* src = cand_g + tile * (int64_t)POOL + meta_base[ck];
+    uint32_t* buf = sorted[wv];
+    if (BIG) {
+      if (mm > 1024u) hs_sort_global<32>(src, buf, mm, lane);
+      else hs_sort_global<16>(src, buf, mm, lane);
+    } else {
+      if (mm > 256u) hs_sort_global<8>(src, buf, mm, lane);
+      else if (mm > 128u) hs_sort_global<4>(src, buf, mm, lane);
+      else if (mm > 64u) hs_sort_global<2>(src, buf, mm, lane);
+      else hs_sort_global<1>(src, buf, mm, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+    hs_pick_store<CW>(buf, mm, tile, k, ck, lane, ntgt, nq, qs, meta_n, lohi, crank, tvs[wv], out, ocs, oqs);
   }
 }
 
@@ -657,8 +766,13 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   const size_t b_crank = al(2 * (size_t)ntiles * ntgt * CWH), b_bm = al(4 * (size_t)ntiles * 32 * CWH);
   const size_t b_flist = al(4 * (size_t)C), b_stat = al(sizeof(HsStat));
   const size_t b_gather = al(4 * (size_t)nfmax * (size_t)Tp), b_tmp = al(4 * (size_t)nfmax * (size_t)nq);
+  // diagnostics: XH_HIST_DEFER=1 moves the per-column sort out of pass 2 into k_hs_finish (measured on config 4 with the
+  // DPP sort: 9.27 + 1.29 ms against 10.71 ms inline — no gain, and it needs 2 GB of scratch: off)
+  const char* edf = xh_diag_env("XH_HIST_DEFER");
+  const bool defer = CWH == 64 && edf && atoi(edf) == 1;
+  const size_t b_cand = defer ? al(4 * (size_t)ntiles * (size_t)CWH * 512) : 0;
   void* ws = nullptr;
-  int rc = xh_big_scratch(ctx, b_lohi + b_n + b_m + b_base + b_crank + b_bm + b_flist + b_stat + b_gather + b_tmp, &ws);
+  int rc = xh_big_scratch(ctx, b_lohi + b_n + b_m + b_base + b_crank + b_bm + b_flist + b_stat + b_gather + b_tmp + b_cand, &ws);
   if (rc) return rc;
   char* p = (char*)ws;
   uint2* lohi = (uint2*)p; p += b_lohi;
@@ -670,7 +784,8 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   uint32_t* flist = (uint32_t*)p; p += b_flist;
   HsStat* stat = (HsStat*)p; p += b_stat;
   float* gbuf = (float*)p; p += b_gather;
-  float* gtmp = (float*)p;
+  float* gtmp = (float*)p; p += b_tmp;
+  uint32_t* cand_g = defer ? (uint32_t*)p : nullptr;
   XH_CHECK_HIP(hipMemsetAsync(stat, 0, sizeof(HsStat), ctx->stream));
   // pass 0
   int64_t S = T / 342;
@@ -707,21 +822,34 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   }
   const char* eu = xh_diag_env("XH_HIST_U");  // diagnostics: loads in flight per register set (8 | 16)
   const int U = eu ? atoi(eu) : HS_UDEF;
-#define XH_HS_LAUNCH(UU, CC)                                                                                                          \
+#define XH_HS_LAUNCH(UU, CC, DD)                                                                                                      \
   {                                                                                                                                  \
     XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist<UU, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds1(CC))); \
-    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<UU, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2(CC))); \
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<UU, CC, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2(CC))); \
     hipLaunchKernelGGL((k_hs_hist<UU, CC>), dim3((unsigned)nblk), dim3(CC * HS_RL), hs_lds1(CC), ctx->stream, x, (int)T, C, st, lohi,  \
                        d_q, nq, meta_n, meta_m, meta_base, crank, bitmap_g, flist, stat, xcd_map, abl);                              \
     XH_LAUNCH_CHECK();                                                                                                               \
-    hipLaunchKernelGGL((k_hs_collect<UU, CC>), dim3((unsigned)nblk), dim3(CC * HS_RL), hs_lds2(CC), ctx->stream, x, (int)T, C, st,    \
-                       lohi, d_q, nq, meta_n, meta_m, meta_base, crank, bitmap_g, out, out_cstride, out_qstride, stat, xcd_map, abl); \
+    hipLaunchKernelGGL((k_hs_collect<UU, CC, DD>), dim3((unsigned)nblk), dim3(CC * HS_RL), hs_lds2(CC), ctx->stream, x, (int)T, C, st, \
+                       lohi, d_q, nq, meta_n, meta_m, meta_base, crank, bitmap_g, out, out_cstride, out_qstride, stat, xcd_map, abl,  \
+                       cand_g);                                                                                                      \
     XH_LAUNCH_CHECK();                                                                                                               \
   }
-  if (CWH == 32 && U == 8) XH_HS_LAUNCH(8, 32)
-  else if (CWH == 32) XH_HS_LAUNCH(16, 32)
-  else if (U == 8) XH_HS_LAUNCH(8, 64)
-  else XH_HS_LAUNCH(16, 64)
+  if (CWH == 32 && U == 8) XH_HS_LAUNCH(8, 32, false)
+  else if (CWH == 32) XH_HS_LAUNCH(16, 32, false)
+  else if (U == 8 && defer) XH_HS_LAUNCH(8, 64, true)
+  else if (U == 8) XH_HS_LAUNCH(8, 64, false)
+  else if (defer) XH_HS_LAUNCH(16, 64, true)
+  else XH_HS_LAUNCH(16, 64, false)
+  if (defer) {
+    int64_t fb = cdiv64(C, 4);
+    if (fb > (int64_t)ctx->num_cu * 64) fb = (int64_t)ctx->num_cu * 64;
+    hipLaunchKernelGGL((k_hs_finish<64, false>), dim3((unsigned)fb), dim3(256), 0, ctx->stream, cand_g, C, lohi, d_q, nq, meta_n,
+                       meta_m, meta_base, crank, out, out_cstride, out_qstride);
+    XH_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_hs_finish<64, true>), dim3((unsigned)fb), dim3(256), 0, ctx->stream, cand_g, C, lohi, d_q, nq, meta_n,
+                       meta_m, meta_base, crank, out, out_cstride, out_qstride);
+    XH_LAUNCH_CHECK();
+  }
 #undef XH_HS_LAUNCH
   HsStat h;
   XH_CHECK_HIP(hipMemcpyAsync(&h, stat, sizeof(HsStat), hipMemcpyDeviceToHost, ctx->stream));
