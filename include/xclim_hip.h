@@ -173,6 +173,14 @@ int xh_threshold_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
                        const int32_t* tidx, const int64_t* seg_off, int P, int32_t* count_out,
                        int32_t* valid_out);
 
+/* The DOY_F64 form with the number of table rows stated (ndoy = D): same results as xh_threshold_count(thr_kind =
+ * XH_THR_DOY_F64).  On multi-year series (tx90p over a 30-year period: threshold_count(tasmax, ">", resample_doy(per)),
+ * indices/_threshold.py + core/calendar.py resample_doy) one workgroup keeps its columns' table slice on chip instead of
+ * re-reading the (D, C) table once per year; tidx[t] outside [0, D) compares as a NaN threshold. */
+int xh_threshold_count_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op,
+                           const double* thr_table, int64_t thr_stride, int ndoy, const int32_t* tidx,
+                           const int64_t* seg_off, int P, int32_t* count_out, int32_t* valid_out);
+
 /* domain_count / count_occurrences-style two-sided scalar conditions (indices/generic.py:364-392):
  *   cond = (x op1 thr1) AND|OR (x op2 thr2);  combine: 1 = and, 2 = or.  fp32 compares. */
 int xh_domain_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op1,

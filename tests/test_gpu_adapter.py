@@ -74,8 +74,8 @@ def test_tx90p_through_the_wrappers_reaches_the_doy_table_kernel(ref, dev, rng):
     exp = oidx.tx90p(x, p_o[..., 0], doys, ot, "YS")
     assert out.dims == ("time", "lat", "lon") and out.dtype == np.int64 and out.attrs["units"] == "days"
     np.testing.assert_array_equal(out.values, exp)
-    tc = _calls(trace, "xh_threshold_count")
-    assert len(tc) == 1 and tc[0][6] == THR_DOY_F64          # thr_kind: the per-doy fp64 table, gathered in the kernel
+    tc = _calls(trace, "xh_threshold_count_doy")             # the per-doy fp64 table form (XH_THR_DOY_F64), gathered in the kernel
+    assert len(tc) == 1 and tc[0][8] == per.shape[0] and not _calls(trace, "xh_threshold_count")
     assert not _calls(trace, "xh_doy_broadcast")              # the (T, Y, X) float64 threshold was never formed
 
 
@@ -259,7 +259,7 @@ def test_indicator_level_fusion_compute_and_missing_mask_in_one_pass(ref, dev, r
     got = indicator(mods["xclim.indices._threshold"].frost_days, 283.15)
     dev.stop_trace()
     np.testing.assert_array_equal(got.values, oidx.apply_missing(ogen.threshold_count(x, "<", 283.15, ot, "YS").astype(np.float64), x, ot, "YS"))
-    assert len(_calls(trace, "xh_threshold_count")) == 1 and not _calls(trace, "xh_resample_reduce")
+    assert len(_calls(trace, "xh_threshold_count") + _calls(trace, "xh_threshold_count_doy")) == 1 and not _calls(trace, "xh_resample_reduce")
     trace = dev.start_trace()
     got = indicator(mods["xclim.indices._threshold"].maximum_consecutive_dry_days, 285.0)
     dev.stop_trace()

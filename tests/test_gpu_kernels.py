@@ -93,6 +93,47 @@ def test_threshold_count_doy_and_full(dev, rng, C):
     np.testing.assert_array_equal(c3.get(), ogen.threshold_count(x, ">=", t32[tidx], ot, "YS"))
 
 
+@pytest.mark.parametrize("op", [">", "<", ">=", "<="])
+@pytest.mark.parametrize("C,freq", [(200, "YS"), (64, "MS"), (1031, "QS-DEC")])
+def test_threshold_count_doy_multi_year_tile_kernel(dev, rng, op, C, freq):
+    """tcount.hip (xh_threshold_count_doy on >= 3 years: LDS-resident fp32 thresholds, packed counters): counts and valid
+    counts bit-identical to the float64 compare of the reference (gen:301-361), on a leap calendar, ragged column tiles,
+    NaN samples, NaN thresholds, thresholds that are exactly a sample / between two floats, a step whose doy the table
+    does not hold, and periods that do not cover the whole series."""
+    T = 365 * 9 + 2 + 117  # 9 years and a bit: full batches of 256 rows plus a tail
+    x = _field(rng, T, C, nan_frac=0.004)
+    ta, ot = _times("2001-03-01", T)
+    seg, _ = ta.segments(freq)
+    seg = np.asarray(seg)[1:-1] if freq == "MS" else np.asarray(seg)  # MS: the first and last month belong to no period
+    table = (288 + 12 * np.sin(2 * np.pi * (np.arange(366)[:, None] - 100) / 365) + rng.normal(0, 1, (366, C)))
+    tidx = (ta.doy - 1).astype(np.int32)
+    tt = rng.integers(0, T, 400)
+    cc = rng.integers(0, C, 400)
+    table[tidx[tt], cc] = x[tt, cc].astype(np.float64)                     # ties: the threshold IS a sample
+    tt2 = rng.integers(0, T, 400)
+    cc2 = rng.integers(0, C, 400)
+    table[tidx[tt2], cc2] = x[tt2, cc2].astype(np.float64) * (1 + rng.choice([-1e-12, 1e-12], 400))  # just beside one
+    table[rng.integers(0, 366, 30), rng.integers(0, C, 30)] = np.nan
+    tidx_bad = tidx.copy()
+    tidx_bad[[5, 1000, T - 1]] = [-1, 366, 400]
+    full = np.where(((tidx_bad >= 0) & (tidx_bad < 366))[:, None], table[np.clip(tidx_bad, 0, 365)], np.nan)
+    import operator
+    fn = {">": operator.gt, "<": operator.lt, ">=": operator.ge, "<=": operator.le}[op]
+    with np.errstate(invalid="ignore"):
+        hit = fn(x.astype(np.float64), full)
+    ok = ~np.isnan(x)
+    P = len(seg) - 1
+    exp_c = np.stack([hit[seg[p]:seg[p + 1]].sum(axis=0) for p in range(P)]).astype(np.int32)
+    exp_v = np.stack([ok[seg[p]:seg[p + 1]].sum(axis=0) for p in range(P)]).astype(np.int32)
+    d = dev.to_device(x)
+    trace = dev.start_trace()
+    cnt, val = K.threshold_count(dev, d, op, seg, doy_table=dev.to_device(table), tidx=tidx_bad)
+    dev.stop_trace()
+    assert [n for n, _ in trace if n.startswith("xh_threshold_count")] == ["xh_threshold_count_doy"]
+    np.testing.assert_array_equal(cnt.get(), exp_c)
+    np.testing.assert_array_equal(val.get(), exp_v)
+
+
 def test_domain_count(dev, rng):
     T, C = 730, 300
     x = _field(rng, T, C, nan_frac=0.01)

@@ -140,6 +140,7 @@ SIGNATURES: dict[str, list] = {
     "xh_season": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, _vp],
     "xh_max_run_sum": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _int, _int, _vp],
     "xh_nan_quantile": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _dbl, _dbl, _vp],
+    "xh_threshold_count_doy": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _int, _vp, _vp, _int, _vp, _vp],
     "xh_threshold_count_f64": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _dbl, _vp, _i64, _vp, _vp, _int, _vp, _vp],
     "xh_resample_reduce_f64": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _int, _vp, _vp],
     "xh_nan_quantile_f64": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _dbl, _dbl, _vp],

@@ -70,6 +70,10 @@ const char* xh_diag_env(const char* name);
 // Upload a small host table into the context scratch (bump allocated per call via `*cursor`).
 int xh_scratch_upload(xh_ctx* ctx, size_t* cursor, const void* host, size_t bytes, void** dptr);
 int xh_big_scratch(xh_ctx* ctx, size_t bytes, void** dptr);
+// tcount.hip: XH_OK launched, XH_ERR_NOTIMPL (no error text) = outside the tile kernel's domain
+int xh_launch_tcount_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int op, const double* table,
+                         int64_t tstride, const int32_t* tidx, const int64_t* d_seg, const int64_t* h_seg, int P, int ndoy,
+                         int32_t* count_out, int32_t* valid_out);
 // select.hip: per-column exact multi-quantile selection on a time-minor view (d_q: device pointer)
 int xh_select_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const double* d_q,
                       int nq, float* out, int64_t out_cstride, int64_t out_qstride);

@@ -340,9 +340,9 @@ static int upload_segments(xh_ctx* ctx, size_t* cur, const int64_t* seg_off, int
 
 extern "C" {
 
-int xh_threshold_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, int thr_kind,
-                       double thr_scalar, const void* thr_table, int64_t thr_stride, const int32_t* tidx,
-                       const int64_t* seg_off, int P, int32_t* count_out, int32_t* valid_out) {
+static int threshold_count_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, int thr_kind,
+                                double thr_scalar, const void* thr_table, int64_t thr_stride, const int32_t* tidx,
+                                const int64_t* seg_off, int P, int32_t* count_out, int32_t* valid_out, int ndoy) {
   int rc = check_tc("xh_threshold_count", ctx, x, T, C, st, sc);
   if (rc) return rc;
   XH_REQUIRE(op >= XH_OP_GT && op <= XH_OP_NE, XH_ERR_OP, "Operation `%d` not recognized.", op);
@@ -357,6 +357,12 @@ int xh_threshold_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
   rc = upload_segments(ctx, &cur, seg_off, P, T, "xh_threshold_count", &d_seg);
   if (rc) return rc;
   if (C == 0) return XH_OK;
+  if (thr_kind == XH_THR_DOY_F64 && ndoy > 0 && !xh_diag_env("XH_TCOUNT_LEGACY")) {
+    // multi-year series: one workgroup per column tile with the table slice in LDS (tcount.hip)
+    rc = xh_launch_tcount_doy(ctx, x, T, C, st, op, static_cast<const double*>(thr_table), thr_stride, tidx, d_seg, seg_off, P,
+                              ndoy, count_out, valid_out);
+    if (rc != XH_ERR_NOTIMPL) return rc;
+  }
   int vec = xh_pick_vec(x, C, st);
   if (thr_kind >= XH_THR_DOY_F64) {
     size_t esz = (thr_kind == XH_THR_DOY_F64 || thr_kind == XH_THR_FULL_F64) ? 8 : 4;
@@ -371,6 +377,21 @@ int xh_threshold_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
                                      count_out, valid_out, period_fast);
   return launch_threshold_count<1>(ctx, thr_kind, grid, x, C, st, op, thr_scalar, thr_table, thr_stride, tidx, d_seg, P,
                                    count_out, valid_out, period_fast);
+}
+
+int xh_threshold_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op, int thr_kind,
+                       double thr_scalar, const void* thr_table, int64_t thr_stride, const int32_t* tidx,
+                       const int64_t* seg_off, int P, int32_t* count_out, int32_t* valid_out) {
+  return threshold_count_impl(ctx, x, T, C, st, sc, op, thr_kind, thr_scalar, thr_table, thr_stride, tidx, seg_off, P, count_out,
+                              valid_out, 0);
+}
+
+int xh_threshold_count_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op,
+                           const double* thr_table, int64_t thr_stride, int ndoy, const int32_t* tidx, const int64_t* seg_off,
+                           int P, int32_t* count_out, int32_t* valid_out) {
+  XH_REQUIRE(ndoy >= 1, XH_ERR_ARG, "xh_threshold_count_doy: the table needs at least one row (ndoy = %d)", ndoy);
+  return threshold_count_impl(ctx, x, T, C, st, sc, op, XH_THR_DOY_F64, 0.0, thr_table, thr_stride, tidx, seg_off, P, count_out,
+                              valid_out, ndoy);
 }
 
 int xh_domain_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int op1, double thr1,

@@ -99,8 +99,13 @@ def threshold_count(dev: Device, x: DeviceArray, op: str, seg_off, *, scalar=Non
         if kind in (capi.THR_DOY_F32, capi.THR_FULL_F32):
             raise TypeError("a float64 field needs float64 threshold tables (a float32 table widens exactly: upload it as float64)")
         kind = capi.THR_SCALAR_F64 if kind == capi.THR_SCALAR_F32 else kind
-    dev.call("xh_threshold_count_f64" if f64 else "xh_threshold_count", _vp(x.ptr), T, C_, C_, 1, op_code(op), kind, thr,
-             table_ptr, tstride, tidx_ptr, np_ptr(seg), P, _vp(count.ptr), _vp(valid.ptr if valid else 0))
+    if kind == capi.THR_DOY_F64 and not f64:
+        # the table's row count is known here: the multi-year tile kernel (tcount.hip) needs it to size its LDS slice
+        dev.call("xh_threshold_count_doy", _vp(x.ptr), T, C_, C_, 1, op_code(op), table_ptr, tstride,
+                 int(np.prod(doy_table.shape[:-1])), tidx_ptr, np_ptr(seg), P, _vp(count.ptr), _vp(valid.ptr if valid else 0))
+    else:
+        dev.call("xh_threshold_count_f64" if f64 else "xh_threshold_count", _vp(x.ptr), T, C_, C_, 1, op_code(op), kind, thr,
+                 table_ptr, tstride, tidx_ptr, np_ptr(seg), P, _vp(count.ptr), _vp(valid.ptr if valid else 0))
     if keep:
         dev.sync()
     return count, valid
