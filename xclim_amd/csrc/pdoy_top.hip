@@ -7,9 +7,14 @@
 // ---- multi-year path, register variant: top-16 of the W day-sets by bitonic half-merges ---------------------
 // For high (or, mirrored, low) percentiles only the 16 largest samples of a doy can be selected (e.g. per = 90 over
 // 30 years x 5 days: ranks 134/135 of 150).  Each day-set is sorted once (descending, NaN last) and only its top 16
-// are kept — in REGISTERS: ring[W][16].  The top 16 of the union of W lists come from W-1 bitonic half-merges
-// (C[i] = max(A[i], B[15-i]) is bitonic and holds the 16 largest of A u B; 4 compare-exchange stages re-sort it):
-// static networks, no LDS, no data-dependent loops, lots of independent work per lane.
+// are kept — in REGISTERS.  The top 16 of a union of lists come from bitonic half-merges (C[i] = max(A[i], B[15-i]) is
+// bitonic and holds the 16 largest of A u B; 4 compare-exchange stages re-sort it): static networks, no LDS, no
+// data-dependent loops, lots of independent work per lane.
+// Neighbouring windows share their day-sets, so the merges are shared too: pr[k] = top16(L_{d-h+k} u L_{d-h+k+1}) (the
+// PAIR of two consecutive day-sets, made once, used by two windows), and window_d = pr[0] u pr[2] u ... u L_{d+h}:
+// W/2 + 1 merges per doy instead of W - 1 (W = 5: 3 instead of 4) in the same W x 16 registers.  The last of them need not
+// re-sort when the wave's ranks are the two lowest of the top 16 (per = 90 of 150 samples: ranks 134 / 135 = positions
+// 15 / 14): the two smallest of the bitonic C take 16 comparators instead of 32 compare-exchanges.
 // rev mirrors the key order so that the same code serves low percentiles (bottom-16).  Valid keys are never 0.
 __device__ __forceinline__ void ce_desc(uint32_t& a, uint32_t& b) {
   uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
@@ -67,6 +72,21 @@ __device__ __forceinline__ void merge_top16(uint32_t (&t)[16], const uint32_t (&
   }
 }
 
+// the two smallest of the 16 largest of (t u b): lo16 = 16th largest, hi15 = 15th largest of the union (t, b sorted descending).
+// max(t[i], b[15 - i]) is bitonic; the lower half of a half-cleaner holds the smaller half and is bitonic again.
+__device__ __forceinline__ void merge_low2(const uint32_t (&t)[16], const uint32_t (&b)[16], uint32_t& lo16, uint32_t& hi15) {
+  uint32_t c[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c[i] = t[i] > b[15 - i] ? t[i] : b[15 - i];
+#pragma unroll
+  for (int n = 8; n >= 2; n >>= 1) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) c[i] = c[i] < c[i + n] ? c[i] : c[i + n];
+  }
+  lo16 = c[0] < c[1] ? c[0] : c[1];
+  hi15 = c[0] < c[1] ? c[1] : c[0];
+}
+
 // COUNT = true (xh_percentile_doy_count on a multi-year base period): the percentile of doy d is compared with the
 // samples of day d of EVERY year and the exceedances are counted per (year, doy) -> period; the (D, C) fp64 table of the
 // unfused chain is neither written nor re-read once per year.  One percentile (nsub == 1), regular doys only.
@@ -82,9 +102,11 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
   int64_t c = (int64_t)blockIdx.x * 64 + lane;
   const bool active = c < C;
   constexpr int half = W / 2;
+  constexpr bool FASTSEL = !COUNT;
   const int N = nyears * W;
-  uint32_t ring[W][16];
-  int cnt[W];
+  uint32_t pr[W - 1][16];  // pr[k]: pair of the day-sets of doys d - half + k and d - half + k + 1
+  uint32_t last[16];       // day-set of doy d + half
+  int cnt[W];              // valid samples of the day-sets d - half .. d + half
   float raw[NYP];
 
   const int64_t cc_ = active ? c : C - 1;  // inactive lanes read a valid cell and never store
@@ -176,12 +198,35 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
     uint32_t t16[16];
     int n = cnt[0];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t16[i] = ring[0][i];
+    for (int i = 0; i < 16; ++i) t16[i] = pr[0][i];
 #pragma unroll
-    for (int w = 1; w < W; ++w) {
-      merge_top16(t16, ring[w]);
-      n += cnt[w];
+    for (int k = 2; k <= W - 3; k += 2) merge_top16(t16, pr[k]);
+#pragma unroll
+    for (int w = 1; w < W; ++w) n += cnt[w];
+    const bool all_valid = COUNT && __all(cnt[half] == nyears ? 1 : 0) != 0;
+    // fast path: one percentile, the same sample count in every lane, ranks at positions 14 / 15 of the top 16
+    if (FASTSEL && nsub == 1) {
+      const int n0 = __builtin_amdgcn_readfirstlane(n);
+      if (__all(n == n0 ? 1 : 0)) {
+        const int j = jmap[0];
+        const QTab e = qtab[j * (N + 1) + n0];  // wave-uniform
+        const int plo = rev ? e.lo : (n0 - 1 - e.lo), phi = rev ? e.hi : (n0 - 1 - e.hi);
+        if (e.lo >= 0 && plo >= 14 && plo <= 15 && phi >= 14 && phi <= 15) {
+          uint32_t k16, k15;
+          merge_low2(t16, last, k16, k15);
+          const float left = xh_key2f((plo == 15 ? k16 : k15) ^ rmask), right = xh_key2f((phi == 15 ? k16 : k15) ^ rmask);
+          const float diff = right - left;
+          double r = (double)left + (double)diff * e.gamma;
+          if (e.gamma >= 0.5) r = (double)right - (double)diff * (1.0 - e.gamma);
+          if (!__any(r != r ? 1 : 0)) {  // (+-inf samples: the nanmax rule below needs the whole list)
+            if (COUNT) count_day(d, r, all_valid);
+            else if (active) out[((int64_t)j * ndoy + d) * C + c] = r;
+            return;
+          }
+        }
+      }
     }
+    merge_top16(t16, last);
     auto get = [&](int idx) -> float {
       uint32_t g = 0;
 #pragma unroll
@@ -201,7 +246,7 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
         if (e.gamma >= 0.5) r = (double)right - (double)diff * (1.0 - e.gamma);
         if (r != r && n > 0) r = (double)get(rev ? (n - 1 < 15 ? n - 1 : 15) : 0);  // +-inf: nanmax fallback (utl:552-554)
       }
-      if (COUNT) count_day(d, r, __all(cnt[half] == nyears ? 1 : 0) != 0);
+      if (COUNT) count_day(d, r, all_valid);
       else if (active) out[((int64_t)j * ndoy + d) * C + c] = r;
     }
   };
@@ -209,28 +254,47 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
   {
     int d0 = blockIdx.y * chunk, d1 = d0 + chunk;
     if (d1 > ndoy) d1 = ndoy;
-    // ring[w] holds the day-set of doy (d - half + w); prologue fills slots 1..W-1 for d = d0 - 1
+    // one step: the pairs move up, the old `last` starts the new pair, the gathered day-set becomes `last` and joins it
+    auto advance = [&]() {
+#pragma unroll
+      for (int k = 0; k < W - 2; ++k) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pr[k][i] = pr[k + 1][i];
+      }
+#pragma unroll
+      for (int w = 0; w < W - 1; ++w) cnt[w] = cnt[w + 1];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pr[W - 2][i] = last[i];
+      finish(last, cnt[W - 1]);
+    };
+    // prologue: the state of doy d0 - 1 = day-sets d0 - half .. d0 - 1 + half fed into an empty ring (pr[0] then holds an
+    // incomplete pair; it leaves with the first step)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) last[i] = 0u;
+#pragma unroll
+    for (int k = 0; k < W - 1; ++k) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pr[k][i] = 0u;
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) cnt[w] = 0;
 #pragma unroll
     for (int w = 1; w < W; ++w) {
       gather(rows_of(d0 - 1 - half + w, 0));
-      finish(ring[w], cnt[w]);
+      advance();
+      merge_top16(pr[W - 2], last);
     }
     gather(rows_of(d0 + half, 0));
     int rows_next = rows_of(d0 + half + 1, 0);
     fetch_day(d0);
     for (int d = d0; d < d1; ++d) {
       stash_day();
-#pragma unroll
-      for (int w = 0; w < W - 1; ++w) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ring[w][i] = ring[w + 1][i];
-        cnt[w] = cnt[w + 1];
-      }
-      finish(ring[W - 1], cnt[W - 1]);
+      advance();
       if (d + 1 < d1) {
         gather(rows_next);
         rows_next = rows_of(d + 2 + half, 0);
       }
+      merge_top16(pr[W - 2], last);
       if (COUNT && d > d0 && newseg[d]) flush_all(d - 1);
       if (regular[d]) select_and_store(d);
       if (COUNT && d + 1 < d1) fetch_day(d + 1);
