@@ -74,6 +74,11 @@ int xh_big_scratch(xh_ctx* ctx, size_t bytes, void** dptr);
 int xh_launch_tcount_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int op, const double* table,
                          int64_t tstride, const int32_t* tidx, const int64_t* d_seg, const int64_t* h_seg, int P, int ndoy,
                          int32_t* count_out, int32_t* valid_out);
+int xh_tcount_plan(int64_t T, int64_t C, int64_t st, int op, int P, int ndoy, int64_t longest, size_t* lds, int* narrow);
+int64_t xh_tcount_meta_slots(int64_t T);
+int64_t xh_tcount_slot_of_row(int64_t t);
+int xh_tcount_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int op, const double* table, int64_t tstride,
+                  const uint32_t* meta, int P, int ndoy, int narrow, size_t lds, int32_t* count_out, int32_t* valid_out);
 // select.hip: per-column exact multi-quantile selection on a time-minor view (d_q: device pointer)
 int xh_select_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const double* d_q,
                       int nq, float* out, int64_t out_cstride, int64_t out_qstride);

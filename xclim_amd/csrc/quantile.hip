@@ -974,7 +974,8 @@ static int pdoy_count_multi(xh_ctx* ctx, const float* x, int64_t T, int64_t C, i
     if (e.hi + 1 > db) db = e.hi + 1;
   }
   const bool top = dt <= 16, bot = !top && db <= 16;
-  int rc = (nirr == 0 && (top || bot)) ? XH_OK : XH_ERR_NOTIMPL;
+  const bool table_ok = nirr == 0 && (top || bot);
+  int rc = table_ok ? XH_OK : XH_ERR_NOTIMPL;
   // period boundaries must fall on the same doy in every year (the kernel flushes all years' counters together)
   uint8_t* newseg = (uint8_t*)malloc((size_t)ndoy);
   if (!newseg) rc = XH_ERR_ARG;
@@ -992,6 +993,49 @@ static int pdoy_count_multi(xh_ctx* ctx, const float* x, int64_t T, int64_t C, i
   size_t cur = 0;
   void *d_tb = nullptr, *d_reg = nullptr, *d_tab = nullptr, *d_j = nullptr, *d_dp = nullptr, *d_ns = nullptr;
   const int32_t j0 = 0;
+  // Two kernels beat the fused one since tcount.hip: the (ndoy, C) table goes to scratch (top-16 table kernel, 13.7 ms at
+  // 30 yr x 1440 x 720) and the tile kernel counts against it (8.3 ms) — 22.0 ms against 25.2 ms fused (which re-reads
+  // every sample for the count).  The fused kernel stays for the shapes the tile kernel does not take.
+  // (It does not need the period boundaries on the same doy in every year either.)
+  if (table_ok && newseg && !xh_diag_env("XH_PDOY_COUNT_FUSED")) {
+    int64_t* plen = (int64_t*)calloc((size_t)P, sizeof(int64_t));
+    const int64_t nslots = xh_tcount_meta_slots(T);
+    uint32_t* hmeta = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)nslots);
+    int rc2 = (plen && hmeta) ? XH_OK : XH_ERR_NOTIMPL;
+    size_t lds = 0;
+    int narrow = 0;
+    if (!rc2) {
+      for (int64_t i = 0; i < nslots; ++i) hmeta[i] = (uint32_t)ndoy | ((uint32_t)P << 16);  // a step outside the table / every period
+      for (int y = 0; y < nyears; ++y)
+        for (int d = 0; d < ndoy; ++d) {
+          const int64_t i = (int64_t)y * ndoy + d;
+          if (tbase[i] < 0) continue;
+          hmeta[xh_tcount_slot_of_row(tbase[i])] = (uint32_t)d | ((uint32_t)doy_period[i] << 16);
+          plen[doy_period[i]]++;
+        }
+      int64_t longest = 0;
+      for (int p = 0; p < P; ++p) longest = plen[p] > longest ? plen[p] : longest;
+      rc2 = xh_tcount_plan(T, C, st, op, P, ndoy, longest, &lds, &narrow);
+    }
+    void *ws = nullptr, *d_meta = nullptr;
+    const size_t b_table = sizeof(double) * (size_t)ndoy * (size_t)C;
+    if (!rc2) rc2 = xh_big_scratch(ctx, b_table, &ws);
+    if (!rc2) rc2 = xh_scratch_upload(ctx, &cur, tbase, sizeof(int32_t) * (size_t)nyears * ndoy, &d_tb);
+    if (!rc2) rc2 = xh_scratch_upload(ctx, &cur, regular, (size_t)ndoy, &d_reg);
+    if (!rc2) rc2 = xh_scratch_upload(ctx, &cur, tab, sizeof(QTab) * (size_t)(N + 1), &d_tab);
+    if (!rc2) rc2 = xh_scratch_upload(ctx, &cur, &j0, sizeof(int32_t), &d_j);
+    if (!rc2) rc2 = xh_scratch_upload(ctx, &cur, hmeta, sizeof(uint32_t) * (size_t)nslots, &d_meta);
+    free(plen); free(hmeta);
+    if (!rc2) {
+      free(regular); free(irregular); free(tab); free(newseg);
+      rc2 = xh_launch_pdoy_top16(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const QTab*)d_tab,
+                                 (const int32_t*)d_j, 1, bot ? 1 : 0, (double*)ws, nullptr, T, (const uint8_t*)d_reg);
+      if (rc2) return rc2;
+      return xh_tcount_run(ctx, x, T, C, st, op, (const double*)ws, C, (const uint32_t*)d_meta, P, ndoy, narrow, lds, count_out,
+                           valid_out);
+    }
+    cur = 0;  // not this shape: the fused kernel below
+  }
   if (!rc) rc = xh_scratch_upload(ctx, &cur, tbase, sizeof(int32_t) * (size_t)nyears * ndoy, &d_tb);
   if (!rc) rc = xh_scratch_upload(ctx, &cur, regular, (size_t)ndoy, &d_reg);
   if (!rc) rc = xh_scratch_upload(ctx, &cur, tab, sizeof(QTab) * (size_t)(N + 1), &d_tab);

@@ -147,26 +147,31 @@ k_tc_doy(const float* __restrict__ x, int T, int64_t C, int64_t st, const double
 
 }  // namespace
 
-// XH_OK: launched.  XH_ERR_NOTIMPL (no error text): shape outside this kernel's domain, the caller uses k_threshold_count.
-int xh_launch_tcount_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int op, const double* table,
-                         int64_t tstride, const int32_t* tidx, const int64_t* d_seg, const int64_t* h_seg, int P, int ndoy,
-                         int32_t* count_out, int32_t* valid_out) {
+// ---- host side ---------------------------------------------------------------------------------------------------------
+// xh_tcount_plan: XH_OK and the launch shape, or XH_ERR_NOTIMPL (no error text) = outside the tile kernel's domain (the
+// caller uses k_threshold_count).  longest = steps of the longest period.
+int xh_tcount_plan(int64_t T, int64_t C, int64_t st, int op, int P, int ndoy, int64_t longest, size_t* lds, int* narrow) {
   if (op < XH_OP_GT || op > XH_OP_LE) return XH_ERR_NOTIMPL;
   if (ndoy < 1 || ndoy > 0xFFFE || P < 1 || P > 0xFFFE || T > 0x7FFFFFFF) return XH_ERR_NOTIMPL;
-  int64_t longest = 0;
-  for (int p = 0; p < P; ++p) longest = h_seg[p + 1] - h_seg[p] > longest ? h_seg[p + 1] - h_seg[p] : longest;
   if (longest > 0xFFFF) return XH_ERR_NOTIMPL;  // 16-bit halves of the packed counters
-  const bool narrow = longest <= 0xFF;            // 8-bit halves: two columns per LDS word
-  const size_t lds = (size_t)(ndoy + 1) * TC_CW * 4 + (size_t)(P + 1) * TC_CW * (narrow ? 2 : 4);
-  if (lds > 156 * 1024) return XH_ERR_NOTIMPL;
+  *narrow = longest <= 0xFF ? 1 : 0;            // 8-bit halves: two columns per LDS word
+  *lds = (size_t)(ndoy + 1) * TC_CW * 4 + (size_t)(P + 1) * TC_CW * (*narrow ? 2 : 4);
+  if (*lds > 156 * 1024) return XH_ERR_NOTIMPL;
   if (T < 2048 || T < 3 * (int64_t)ndoy || C < TC_CW) return XH_ERR_NOTIMPL;  // one or two years: the table is read about once anyway
   if ((int64_t)TC_ROWS * st * 4 >= ((int64_t)1 << 32) || C * 4 + (int64_t)TC_RL * st * 4 >= ((int64_t)1 << 32)) return XH_ERR_NOTIMPL;
-  const int64_t nbatch = (T + TC_ROWS - 1) / TC_ROWS, nslots = nbatch * TC_ROWS;
-  void* scratch = nullptr;
-  int rc = xh_big_scratch(ctx, (size_t)nslots * 4, &scratch);
-  if (rc) return rc;
-  uint32_t* meta = static_cast<uint32_t*>(scratch);
-  hipLaunchKernelGGL(k_tc_meta, dim3((unsigned)cdiv64(nslots, 256)), dim3(256), 0, ctx->stream, tidx, d_seg, P, T, nslots, ndoy, meta);
+  return XH_OK;
+}
+
+int64_t xh_tcount_meta_slots(int64_t T) { return (T + TC_ROWS - 1) / TC_ROWS * TC_ROWS; }
+
+// slot of row t in the visiting order of xh_row_stream (host twin of k_tc_meta's index arithmetic)
+int64_t xh_tcount_slot_of_row(int64_t t) {
+  const int64_t kb = t / TC_ROWS, r = t % TC_ROWS;
+  return (kb * TC_RL + r % TC_RL) * TC_U + r / TC_RL;
+}
+
+int xh_tcount_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int op, const double* table, int64_t tstride,
+                  const uint32_t* meta, int P, int ndoy, int narrow, size_t lds, int32_t* count_out, int32_t* valid_out) {
   const int64_t ntiles = cdiv64(C, TC_CW);
   const unsigned grid = (unsigned)(ntiles < ctx->num_cu ? ntiles : ctx->num_cu);  // one 1024-thread workgroup per CU (LDS)
 #define XH_TCD2(OPV, NW)                                                                                                      \
@@ -189,4 +194,22 @@ int xh_launch_tcount_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
 #undef XH_TCD
   XH_LAUNCH_CHECK();
   return XH_OK;
+}
+
+int xh_launch_tcount_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int op, const double* table,
+                         int64_t tstride, const int32_t* tidx, const int64_t* d_seg, const int64_t* h_seg, int P, int ndoy,
+                         int32_t* count_out, int32_t* valid_out) {
+  int64_t longest = 0;
+  for (int p = 0; p < P; ++p) longest = h_seg[p + 1] - h_seg[p] > longest ? h_seg[p + 1] - h_seg[p] : longest;
+  size_t lds = 0;
+  int narrow = 0;
+  int rc = xh_tcount_plan(T, C, st, op, P, ndoy, longest, &lds, &narrow);
+  if (rc) return rc;
+  const int64_t nslots = xh_tcount_meta_slots(T);
+  void* scratch = nullptr;
+  rc = xh_big_scratch(ctx, (size_t)nslots * 4, &scratch);
+  if (rc) return rc;
+  uint32_t* meta = static_cast<uint32_t*>(scratch);
+  hipLaunchKernelGGL(k_tc_meta, dim3((unsigned)cdiv64(nslots, 256)), dim3(256), 0, ctx->stream, tidx, d_seg, P, T, nslots, ndoy, meta);
+  return xh_tcount_run(ctx, x, T, C, st, op, table, tstride, meta, P, ndoy, narrow, lds, count_out, valid_out);
 }
