@@ -76,7 +76,7 @@ k_qdm_columns(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
       const uint32_t i = g + (uint32_t)(k * NT);
-      const uint32_t kk = xh_f2key(raw[k]);
+      const uint32_t kk = xh_f2key(raw[k] + 0.0f);  // -0.0 + 0.0 = +0.0: the two zeros tie, as they do in rankdata
       key[k] = (i <= Tm1) ? kk : 0xFFFFFFFFu;
       nv += key[k] != 0xFFFFFFFFu ? 1u : 0u;
       kmin = key[k] < kmin ? key[k] : kmin;

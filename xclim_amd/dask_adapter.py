@@ -14,7 +14,8 @@ the ``(periods, *chunk cells)`` numpy block.
 
 Each block call uploads its chunk, runs the kernels and downloads the result.  Inside one big host array the slab
 pipeline of :mod:`xclim_amd.blocks` (upload / compute / download overlapped on three streams) is the faster engine;
-dask's own scheduler may call the callee from several threads: calls are serialised per device context (``Device.lock``).
+dask's own scheduler may call the callee from several threads: a block call holds the device's lock (``Device.lock``, an
+RLock) from its first upload to its last download, so the kernels of two blocks never interleave on the one stream.
 """
 
 from __future__ import annotations
@@ -24,6 +25,7 @@ import itertools
 import numpy as np
 
 from . import indices as _indices
+from ._capi import get_device
 from .timeaxis import TimeAxis
 
 __all__ = ["block_function", "map_blocks", "chunk_grid"]
@@ -45,7 +47,9 @@ def block_function(index, time: TimeAxis, *args, nvars: int = 1, **kwargs):
             if a.shape[0] != len(time):
                 raise ValueError("every block must hold the whole time axis (rechunk with time: -1, cal:463-467)")
             arrs.append(a)
-        return np.asarray(fn(*arrs, *args, time=time, **kwargs))
+        dev = kwargs.get("device") or get_device()
+        with dev.lock:  # the whole multi-kernel index, not just each C call
+            return np.asarray(fn(*arrs, *args, time=time, **kwargs))
 
     callee.__name__ = f"xclim_amd_{getattr(fn, '__name__', 'index')}"
     return callee
@@ -73,8 +77,8 @@ def map_blocks(index, arrays, time: TimeAxis, *args, chunks=None, **kwargs):
         if len(arrs[0].chunks[0]) != 1:
             raise ValueError("the time axis must be in one chunk (rechunk({0: -1}))")
         probe = f(*[np.zeros((len(time),) + (1,) * (a.ndim - 1), np.float32) for a in arrs])
-        nper = probe.shape[0]
-        return dsa.map_blocks(f, *arrs, dtype=np.float64, chunks=((nper,),) + tuple(arrs[0].chunks[1:]))
+        nper = probe.shape[0]  # (one single-cell call at graph-construction time: the period count and the result dtype)
+        return dsa.map_blocks(f, *arrs, dtype=probe.dtype, chunks=((nper,),) + tuple(arrs[0].chunks[1:]))
     if chunks is None:
         return f(*arrs)
     a0 = np.asarray(arrs[0])
