@@ -66,17 +66,34 @@ def hbm_roofline(nbytes, ms, kernel=None, **more):
 
 
 def valu_bound(kernel):
-    """{"bound": "valu", "busy": ...} for a kernel the SQ counters show to be VALU-bound (SQ_ACTIVE_INST_VALU /
-    (SQ_WAVE_CYCLES / 4), collected by tools/pmc_bench_sq.sh into profiles/r0x/valu_busy.json); None when not profiled."""
-    for rel in ("profiles/r03/valu_busy.json", "profiles/r02/valu_busy.json"):
-        try:
-            table = json.load(open(os.path.join(ROOT, rel)))
-        except (OSError, ValueError):
-            continue
-        for name, busy in table.items():
-            if name.startswith(kernel):
-                return {"bound": "valu", "busy": busy, "kernel": name, "source": rel}
+    """The VALU-issue view of a kernel from the committed SQ + GRBM PMC passes (tools/gpu_r03_prof.sh ->
+    tools/summarize_sq.py -> profiles/r03/valu_busy.json): VALU instructions per SIMD x the measured issue cost of a
+    wave64 instruction (2.5 cycles of the ~2.4 GHz clock for add / xor / mov, 4.3 for min / max / cmp:
+    profiles/r03/valu_ubench.txt, bank_ubench.txt) over the kernel's cycles.  busy_hi near 1 = no faster without issuing fewer instructions.  None when not profiled."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles/r03/valu_busy.json")))
+    except (OSError, ValueError):
+        return None
+    for name, v in table.items():
+        if name.startswith(kernel):
+            return {"bound": "valu", "kernel": name, "valu_insts_per_simd": v["valu_insts_per_simd"], "cycles": v["cycles"],
+                    "busy_at_2.5_cycles": v["busy_lo"], "busy_at_4.3_cycles": v["busy_hi"], "source": "profiles/r03/valu_busy.json"}
     return None
+
+
+def pmc_traffic_30yr(*kernels):
+    """Sum of the HBM bytes per launch of the 30-year kernels from profiles/r03/pmc_hbm_traffic_30yr.json (PMC passes of
+    the full configurations; only kernels that run at one size there), or None."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles/r03/pmc_hbm_traffic_30yr.json")))
+    except (OSError, ValueError):
+        return None
+    tot = 0.0
+    for k in kernels:
+        if k not in table:
+            return None
+        tot += table[k]["hbm_bytes_per_launch"]
+    return tot
 
 
 def seasonal_base(T, mean=288.0, amp=12.0, phase=100.0, period=365.0):
@@ -113,8 +130,8 @@ def chain_event_times(dev, fns, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--grid", type=str, default="365x1440x720")
     ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
                     help="c2 (default): BASELINE configs[1], tx90p on 365x1440x720 per GPU; c5: configs[4], tx90p + EQM on a "
@@ -478,7 +495,8 @@ def bench_full_configs(dev, K, C):
                          "algorithmic_bytes": bp + bc, "config": "BASELINE configs[4], the tx90p half on one GPU's 1440x720 grid",
                          "roofline": hbm_roofline(bp + bc, ms_p + ms_c, "k_pdoy_top16<5, 32, false> (xh_percentile_doy) + k_tc_doy<0, false> (xh_threshold_count_doy)"),
                          "roofline_percentile_doy": hbm_roofline(bp, ms_p, "k_pdoy_top16<5, 32, false>"),
-                         "roofline_threshold_count": hbm_roofline(bc, ms_c, "k_tc_doy<0, false>"),
+                         "roofline_threshold_count": hbm_roofline(bc, ms_c, "k_tc_doy<0, false>", traffic=pmc_traffic_30yr("k_tc_doy<0, false>"),
+                                                                  traffic_source="profiles/r03/pmc_hbm_traffic_30yr.json"),
                          "roofline_valu": valu_bound("k_pdoy_top16")}
     period = (np.searchsorted(seg, tb, side="right") - 1).astype(np.int32)
     period[tb < 0] = -1
@@ -509,7 +527,10 @@ def bench_full_configs(dev, K, C):
                      "config": "BASELINE configs[3]",
                      "roofline": hbm_roofline(16 * E, ms_tr + ms_ad, "xh_eqm_train + xh_eqm_adjust"),
                      "roofline_train": hbm_roofline(8 * E, ms_tr, "2 x (k_hs_sample + k_hs_hist + k_hs_collect) (select4.hip)",
-                                                    passes="two streaming passes per array: 16E + 0.25E bytes cross HBM for 8E algorithmic"),
+                                                    passes="two streaming passes per array: 16E + 0.25E bytes cross HBM for 8E algorithmic",
+                                                    traffic=(lambda t: None if t is None else 2 * t)(pmc_traffic_30yr(
+                                                        "k_hs_sample<4>", "k_hs_hist<16, 64>", "k_hs_collect<16, 64, false>")),
+                                                    traffic_source="profiles/r03/pmc_hbm_traffic_30yr.json"),
                      "roofline_adjust": hbm_roofline(8 * E, ms_ad, "k_eqm_adjust<20, 0>")}
     for a in (hist, sim, scen, af, hq):
         a.free()

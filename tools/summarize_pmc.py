@@ -9,7 +9,9 @@ FETCH_SIZE*1024*2 = 4.542 GB; k_run_max_fused reads 1.514 GB, FETCH_SIZE*1024*2 
 1.514 GB and WRITE_SIZE*1024 = 1.514 GB, i.e. writes need no correction).  The strided-gather select kernels are
 NOT calibrated and are reported uncorrected.
 
-usage: tools/summarize_pmc.py gpurun_out/prof_<tag> profiles/<tag>
+usage: tools/summarize_pmc.py gpurun_out/prof_<tag> profiles/<tag> [out.json [kernel-prefix,kernel-prefix,...]]
+(the optional prefix list keeps only kernels that run at ONE grid size in that profile run: a mean over launches of
+different sizes says nothing)
 """
 import collections
 import csv
@@ -18,10 +20,10 @@ import json
 import os
 import sys
 
-UNCALIBRATED = ("k_select", "__amd_rocclr")
+UNCALIBRATED = ("k_select", "__amd_rocclr", "k_pdoy_top16")  # strided gathers: FETCH_SIZE x2 not calibrated
 
 
-def main(src, dst):
+def main(src, dst, name="pmc_hbm_traffic.json", only=None):
     out = {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         files = glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)
@@ -31,6 +33,8 @@ def main(src, dst):
                 if r["Counter_Name"] != cname:
                     continue
                 k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+                if only and not k.startswith(only):
+                    continue
                 agg[k][0] += 1
                 agg[k][1] += float(r["Counter_Value"])
         for k, (n, v) in agg.items():
@@ -45,10 +49,11 @@ def main(src, dst):
         d["hbm_write_bytes_per_launch"] = w
         d["hbm_bytes_per_launch"] = f + w
     os.makedirs(dst, exist_ok=True)
-    json.dump(out, open(os.path.join(dst, "pmc_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
+    json.dump(out, open(os.path.join(dst, name), "w"), indent=1, sort_keys=True)
     for k, d in sorted(out.items()):
         print(f"{k:40s} read {d['hbm_read_bytes_per_launch'] / 1e9:7.3f} GB  write {d['hbm_write_bytes_per_launch'] / 1e9:7.3f} GB")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], *(sys.argv[3:4] or ["pmc_hbm_traffic.json"]),
+         only=tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else None)
