@@ -1237,6 +1237,58 @@ def test_qdm_adjust_matches_oracle(dev, rng, kind, interp, T, cells):
         np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0, equal_nan=True, err_msg=f"{extrap}")
 
 
+@pytest.mark.parametrize("T", [360, 365, 366])
+@pytest.mark.parametrize("kind,nq", [("+", 20), ("*", 15), ("*", 36), ("+", 48)])
+def test_qdm_nearest_one_year_cut_value_kernel(dev, rng, monkeypatch, T, kind, nq):
+    """qdm2.hip (one-year series, interp="nearest": sort in registers, class boundaries as order statistics, samples
+    classified against cut values) == the oracle AND bit-identical to the exact-rank kernel it replaces, on: continuous
+    columns, NaN samples, dry-day series (copies of the minimum: the exact path inside the kernel), signed zeros, columns
+    with ties (the list handed to the exact-rank kernel), constant and all-NaN columns, NaN factors (dropped nodes), both
+    extrapolations, a ragged last tile."""
+    from xclim_amd import kernels as K
+
+    C = 203
+    sim = rng.normal(13, 4, (T, C)).astype(np.float32)
+    if kind == "*":
+        sim = np.abs(sim) + 1
+    sim[rng.random((T, C)) < 0.02] = np.nan
+    dry = rng.random((T, 40)) < 0.6                                  # columns 0 .. 39: precipitation-like, 60 % dry
+    sim[:, :40] = np.where(dry, 0.0, rng.gamma(0.7, 4.0, (T, 40))).astype(np.float32)
+    z = np.flatnonzero(sim[:, 3] == 0.0)
+    sim[z[::2], 3] = -0.0                                            # signed zeros tie
+    sim[5:60, 4] = np.nan                                            # dry days and NaN samples together
+    sim[:, 50] = np.round(sim[:, 50])                                # heavily tied column -> exact-rank kernel
+    sim[10, 51] = sim[200, 51]                                       # one tie
+    sim[:, 52] = 7.5                                                 # constant: 0 / 0 ranks -> NaN
+    sim[:, 53] = np.nan
+    sim[1:, 54] = np.nan                                             # a single valid sample
+    sim[:, 55] = np.sort(sim[:, 55])                                 # sorted input (NaN last)
+    sim[100, 56] = np.inf
+    sim[101, 56] = -np.inf
+    sim[[7, 300], 57] = np.nanmax(sim[:, 57]) + 1                    # two copies of the maximum: mx changes for every sample
+    sim[[9, 301], 58] = np.nanmin(sim[:, 58]) - 1                    # two copies of the minimum of a continuous column
+    q = (np.arange(nq) + 0.5) / nq
+    af = rng.normal(1.0, 0.3, (nq, C)).astype(np.float32)
+    af[rng.random((nq, C)) < 0.02] = np.nan                          # dropped nodes
+    af[:, 60] = np.nan                                               # no node at all
+    af[1:, 61] = np.nan                                              # one node: nothing to interpolate on
+    d_sim, d_af = dev.to_device(sim), dev.to_device(af)
+    for extrap in ("constant", "nan"):
+        trace = dev.start_trace()
+        got = K.qdm_adjust(dev, d_sim, d_af, q, kind, "nearest", extrap).get()
+        dev.stop_trace()
+        exp = osdba.qdm_adjust(sim, af, q, kind, "nearest", extrap)
+        with np.errstate(invalid="ignore"):
+            bad = np.argwhere(~(np.isclose(got, exp, rtol=1e-6, atol=0) | (np.isnan(got) & np.isnan(exp))))
+        np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0, equal_nan=True, err_msg=f"{extrap}: first mismatches (row, column) {bad[:5].tolist()}")
+        with monkeypatch.context() as m:
+            m.setenv("XH_DIAGNOSTICS", "1")
+            m.setenv("XH_QDM_NOREGSORT", "1")
+            legacy = K.qdm_adjust(dev, d_sim, d_af, q, kind, "nearest", extrap).get()
+        np.testing.assert_array_equal(got, legacy)
+    assert np.isnan(got[:, [52, 53, 54, 60, 61]]).all()
+
+
 def test_qdm_precipitation_and_edge_cases(dev, rng):
     """Dry days (most samples tied at the minimum, rank 0), an all-NaN cell, a constant cell (0 / 0 ranks -> NaN), NaN
     factors (dropped nodes), the time-minor layout, argument errors."""

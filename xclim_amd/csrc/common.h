@@ -74,6 +74,11 @@ int xh_big_scratch(xh_ctx* ctx, size_t bytes, void** dptr);
 int xh_launch_tcount_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int op, const double* table,
                          int64_t tstride, const int32_t* tidx, const int64_t* d_seg, const int64_t* h_seg, int P, int ndoy,
                          int32_t* count_out, int32_t* valid_out);
+// qdm.hip / qdm2.hip
+int xh_qdm_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const float* af, int64_t af_qs,
+                   const double* d_q, int nq, int kind, int interp, int extrap, float* out, int64_t out_cs);
+int xh_qdm_regsort(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, const float* af, int64_t af_qs,
+                   const double* d_q, int nq, int kind, int extrap, float* scen, int64_t ost);
 int xh_tcount_plan(int64_t T, int64_t C, int64_t st, int op, int P, int ndoy, int64_t longest, size_t* lds, int* narrow);
 int64_t xh_tcount_meta_slots(int64_t T);
 int64_t xh_tcount_slot_of_row(int64_t t);

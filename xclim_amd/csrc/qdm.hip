@@ -262,8 +262,12 @@ int launch_qdm(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_
   return XH_OK;
 }
 
-int qdm_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const float* af, int64_t af_qs,
-                const double* d_q, int nq, int kind, int interp, int extrap, float* out, int64_t out_cs) {
+}  // namespace
+
+// exact-rank kernel on time-minor columns (column c at xcols + c * col_stride, factors af[j * af_qs + c]); also the
+// fallback of qdm2.hip for columns with ties
+int xh_qdm_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const float* af, int64_t af_qs,
+                   const double* d_q, int nq, int kind, int interp, int extrap, float* out, int64_t out_cs) {
 #define XH_QDM(NT, KPL, NB) return launch_qdm<NT, KPL, NB>(ctx, xcols, T, ncols, col_stride, af, af_qs, d_q, nq, kind, interp, extrap, out, out_cs)
   if (T <= 512) XH_QDM(64, 8, 256);
   if (T <= 2048) XH_QDM(256, 8, 1024);
@@ -273,8 +277,6 @@ int qdm_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64
   XH_QDM(512, 32, 2048);
 #undef XH_QDM
 }
-
-}  // namespace
 
 extern "C" {
 
@@ -294,9 +296,13 @@ int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   int rc = xh_scratch_upload(ctx, &cur, q, sizeof(double) * nq, &d_q);
   if (rc) return rc;
   if (st == 1 && sc >= T)  // time-minor: columns in place, scen in the same layout
-    return qdm_columns(ctx, sim, T, C, sc, af, C, (const double*)d_q, nq, kind, interp, extrap, scen, sc);
+    return xh_qdm_columns(ctx, sim, T, C, sc, af, C, (const double*)d_q, nq, kind, interp, extrap, scen, sc);
   XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_qdm_adjust: one of the strides must be 1 (st=%lld sc=%lld)", (long long)st,
              (long long)sc);
+  if (interp == 0) {  // one-year series, nearest: sort in registers + classify by cut values, in place (qdm2.hip)
+    rc = xh_qdm_regsort(ctx, sim, T, C, st, af, C, (const double*)d_q, nq, kind, extrap, scen, st);
+    if (rc != XH_ERR_NOTIMPL) return rc;
+  }
   // time-major: batches of columns through a transposed scratch, both ways (padded pitch: 256-byte aligned segments)
   int64_t Tp = (T + 63) & ~(int64_t)63;
   int64_t batch = (int64_t)((1ull << 28) / (sizeof(float) * (size_t)Tp));
@@ -312,7 +318,7 @@ int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
     const int64_t nb = C - c0 < batch ? C - c0 : batch;
     rc = xh_transpose_f32(ctx, sim + c0, T, nb, st, bin, Tp);
     if (rc) return rc;
-    rc = qdm_columns(ctx, bin, T, nb, Tp, af + c0, C, (const double*)d_q, nq, kind, interp, extrap, bout, Tp);
+    rc = xh_qdm_columns(ctx, bin, T, nb, Tp, af + c0, C, (const double*)d_q, nq, kind, interp, extrap, bout, Tp);
     if (rc) return rc;
     rc = xh_transpose_f32(ctx, bout, nb, T, Tp, scen + c0, st);
     if (rc) return rc;

@@ -1,0 +1,525 @@
+// qdm2.hip — QuantileDeltaMapping.adjust, interp = "nearest", on ONE-YEAR daily series (360 <= T <= 366), time-major, read and
+// written in place (xsdba._adjustment.qdm_adjust: rank(sim, pct=True) -> interp_on_quantiles(nearest) -> apply_correction;
+// not in the reference tree: PARITY UNPINNED, oracle/sdba.py qdm_adjust restates it with scipy.stats.rankdata + interp1d).
+//
+// With nearest-node interpolation the factor of a sample depends only on which of <= nq + 2 classes its percentage rank
+// falls in (below the first node | nearest to node j | above the last node), the percentage rank is a non-decreasing
+// function of the sample's doubled average rank r2 = 2·below + equal + 1, and r2 is a non-decreasing function of the VALUE.
+// So a column needs no rank per sample: per class boundary the smallest r2 that passes (fp64, the operation order of
+// qdm.hip / numpy), the order statistic that first reaches it, and then every sample is classified by <= 6 compares against
+// the column's <= nq + 1 cut values.
+//
+//   1    the column in REGISTERS (two lanes per column, 183 keys each, as select3.hip); valid count n, smallest key and
+//        its copies cnt0 (dry days: exact) from the unsorted keys
+//   2    per (column, boundary): R = min { r2 : test(pct(r2)) } by an analytic guess + exact verification, then the rank
+//        p = ceil((R - 2) / 2) (inside the minimum's run: rank 0 if its r2 = cnt0 + 1 passes, else rank cnt0).  32 of the
+//        183 registers wait in LDS meanwhile: the fp64 arithmetic needs the room.
+//   3-5  sort by the comparator networks of select3.hip (local sort, split across the lane pair, merge)
+//   6    adjacent equal keys in the sorted column: any tie that is not a copy of the minimum puts the column on a list for
+//        the exact-rank kernel of qdm.hip (k_qdm_columns) — ties decide average ranks, and following them needs counts
+//        this kernel does not have.  Without ties the run of sorted[p] is [p, p + 1): r2 = 2p + 2.
+//   7    the <= nq + 1 order statistics leave the registers through the LDS hand-over of select3.hip (one monotone pass)
+//   8    the tile's rows are read again (L2 / Infinity Cache), classified by a branch-free binary search over the cut
+//        values in LDS, corrected and stored.
+// HBM traffic: sim once, scen once.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.h"
+#include "sortnet_183.h"
+
+namespace {
+
+constexpr uint32_t PADK = 0xFFFFFFFFu;
+constexpr int QR_MAXQ = 36;          // quantile nodes (LDS budget of two workgroups per CU)
+constexpr uint32_t QR_SENT = 0x7FFFu;  // rank that no register index ever matches (stored as u16)
+constexpr uint32_t QR_OK = 0u, QR_NAN = 1u, QR_TIES = 2u;
+
+__device__ __forceinline__ uint32_t qr_swap1(uint32_t v) {  // partner lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void qr_fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// LDS words per wave for nq nodes: status arrays [4][32] | idx bytes [nq][32] | factor table [nq + 2][32] (its start holds
+// the u16 ranks [nq + 1][32] until the picks are done) | cut values [nq + 2][32] (row nq + 1 = NaN) | hand-over buffer [32][64]
+__host__ __device__ constexpr int qr_words_per_wave(int nq) {
+  return 4 * 32 + (nq * 32 + 3) / 4 + 2 * (nq + 2) * 32 + 32 * 64;
+}
+
+template <int N, int TMIN>
+__global__ void __launch_bounds__(256, 2)
+k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const float* __restrict__ af, int64_t af_qs,
+              const double* __restrict__ qnodes, int nq, int kind, int extrap, float* __restrict__ out, int64_t ost,
+              uint32_t* __restrict__ flist, uint32_t* __restrict__ nflag, int abl) {
+  static_assert(N == XH_SN_N, "sortnet header generated for another N");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* qS = reinterpret_cast<double*>(smem);  // [QR_MAXQ] quantile nodes
+  uint32_t* wave0 = reinterpret_cast<uint32_t*>(qS + QR_MAXQ);
+  const int tid = threadIdx.x, w = tid >> 6;
+  const int ntmax = nq + 1;  // tests per column at most
+  if (tid < nq) qS[tid] = qnodes[tid];
+  __syncthreads();
+  uint32_t* ncol = wave0 + w * qr_words_per_wave(nq);
+  uint32_t* c0col = ncol + 32;
+  uint32_t* stcol = c0col + 32;
+  uint32_t* nvcol = stcol + 32;
+  uint8_t* idx = reinterpret_cast<uint8_t*>(nvcol + 32);                                  // [nq][32] node index of the j-th valid node
+  float* FS = reinterpret_cast<float*>(reinterpret_cast<uint32_t*>(idx) + (nq * 32 + 3) / 4);  // [ntmax + 1][32], after the picks
+  uint16_t* rkT = reinterpret_cast<uint16_t*>(FS);                                        // [ntmax][32] until then
+  uint32_t* vals = reinterpret_cast<uint32_t*>(FS) + (ntmax + 1) * 32;                    // [ntmax + 1][32] keys, then float cuts
+  uint32_t* dump = vals + (ntmax + 1) * 32;                                               // [32][64]
+  const int64_t ntiles = (C + 31) / 32;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const uint32_t strideB = (uint32_t)(st * 4), strideO = (uint32_t)(ost * 4);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)0xFFFFFFFFu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)0xFFFFFFFFu, 0x00020000);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += nwaves) {
+    uint32_t lane = (uint32_t)tid & 63u;
+    asm volatile("" : "+v"(lane));
+    const int64_t col0 = tile * 32;
+#define XH_DECL(i) uint32_t k##i;
+    XH_SN_FOREACH(XH_DECL)
+#undef XH_DECL
+    {
+      const uint32_t h = lane & 1u, c32 = lane >> 1;
+      const int64_t col = col0 + c32;
+      const int64_t colc = col < C ? col : C - 1;
+      // ---- 1. loads (as select3.hip): lane A rows 0 .. N-1, lane B rows T-N .. T-1
+      const uint32_t voff = (uint32_t)(colc * 4) + (h ? (uint32_t)(T - N) * strideB : 0u);
+      uint32_t soff = 0u;
+      asm volatile("" : "+s"(soff));
+#define XH_LD(i) k##i = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0); soff += strideB;
+      XH_SN_FOREACH(XH_LD)
+#undef XH_LD
+      uint32_t bcut = h ? (uint32_t)(2 * N - T) : 0u;
+      asm volatile("" : "+v"(bcut));
+      // keys of x + 0.0f: -0.0 and +0.0 tie (rankdata); NaN / the rows lane A holds too -> pad
+#define XH_CV(i)                                                           \
+  {                                                                        \
+    const float f_ = __uint_as_float(k##i) + 0.0f;                         \
+    const uint32_t u_ = __float_as_uint(f_);                               \
+    uint32_t kk_ = u_ ^ ((uint32_t)((int32_t)u_ >> 31) | 0x80000000u);    \
+    kk_ = (f_ != f_) ? PADK : kk_;                                         \
+    if (i < 2 * N - TMIN) kk_ = ((uint32_t)i < bcut) ? PADK : kk_;         \
+    k##i = kk_;                                                            \
+  }
+      XH_SN_FOREACH(XH_CV)
+#undef XH_CV
+    }
+    uint32_t lane1 = (uint32_t)tid & 63u;
+    asm volatile("" : "+v"(lane1));
+    uint32_t* mydump = dump + lane1;
+#define XH_DW(e, reg) mydump[(e) * 64] = reg;
+#define QR_DUMP_CHUNK(ci)                   \
+  switch (ci) {                             \
+    case 0: XH_SN_DUMP_0(XH_DW) break;      \
+    case 1: XH_SN_DUMP_1(XH_DW) break;      \
+    case 2: XH_SN_DUMP_2(XH_DW) break;      \
+    case 3: XH_SN_DUMP_3(XH_DW) break;      \
+    case 4: XH_SN_DUMP_4(XH_DW) break;      \
+    default: XH_SN_DUMP_5(XH_DW) break;     \
+  }
+    static_assert(XH_SN_CHUNKS == 6 && N > 160 && N <= 192, "six hand-over chunks of 32 registers");
+    // ---- 1b. valid count, smallest key and its copies, from the unsorted keys (pads and NaN are 0xFFFFFFFF: never the
+    //      minimum of a column that holds a sample).  The registers pass through the hand-over buffer and are counted in a
+    //      ROLLED loop: unrolled over 183 registers the three counters were 7 KB of code, and the kernel has to stay inside
+    //      the 64 KB instruction cache (sort networks: 32 KB).
+    if (!(abl & 1)) {
+      const uint32_t h = lane1 & 1u, c32 = lane1 >> 1;
+      uint32_t nvl = 0u, kml = PADK, cml = 0u;
+#pragma nounroll
+      for (int ci = 0; ci < 6; ++ci) {
+        QR_DUMP_CHUNK(ci)
+        const int cnt = ci < 5 ? 32 : N - 160;
+#pragma unroll 4
+        for (int e = 0; e < cnt; ++e) {
+          const uint32_t v = mydump[e * 64];
+          nvl += v != PADK ? 1u : 0u;
+          const bool lt = v < kml;
+          cml = lt ? 1u : cml + (v == kml ? 1u : 0u);
+          kml = lt ? v : kml;
+        }
+      }
+      const uint32_t pk = qr_swap1(kml), pc = qr_swap1(cml);
+      const uint32_t kmin = pk < kml ? pk : kml;
+      const uint32_t n = nvl + qr_swap1(nvl), cnt0 = (kml == kmin ? cml : 0u) + (pk == kmin ? pc : 0u);
+      // nothing valid / all valid samples equal: 0 / 0 ranks -> NaN (qdm.hip)
+      if (h == 0) { ncol[c32] = n; c0col[c32] = cnt0; stcol[c32] = (n == 0u || cnt0 >= n) ? QR_NAN : QR_OK; }
+    }
+    if (abl & 3) {  // diagnostics only: sane tables for the phases that still run
+      if (abl & 1) { if (lane1 < 32u) { ncol[lane1] = (uint32_t)T; c0col[lane1] = 1u; stcol[lane1] = QR_OK; } }
+      if (abl & 2) {
+        for (int i = (int)lane1; i < (ntmax + 1) * 32; i += 64) { rkT[i] = (uint16_t)QR_SENT; vals[i] = PADK; }
+        if (lane1 < 32u) nvcol[lane1] = 2u;
+        for (int i = (int)lane1; i < nq * 32; i += 64) idx[i] = 0;
+      }
+      qr_fence();
+    }
+    // ---- 2. ranks of the class boundaries.  k0 .. k31 wait in the hand-over buffer while the fp64 arithmetic runs.
+    if (!(abl & 2)) {
+      QR_DUMP_CHUNK(0)
+      qr_fence();
+      // ---- 2a. nodes of the column: drop the NaN factors (interp_on_quantiles masks them); lane c < 32 owns column c
+      if (lane1 < 32u) {
+        const int64_t cc = col0 + lane1 < C ? col0 + lane1 : C - 1;
+        uint32_t cnt = 0;
+        // 8 factors in flight (one load per iteration would pay a full memory latency nq times)
+#pragma nounroll
+        for (int j0 = 0; j0 < nq; j0 += 8) {
+          float a[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = af[(int64_t)(j0 + u < nq ? j0 + u : nq - 1) * af_qs + cc];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (j0 + u < nq && a[u] == a[u]) { idx[cnt * 32 + lane1] = (uint8_t)(j0 + u); ++cnt; }
+        }
+        nvcol[lane1] = cnt;
+        if (cnt < 2u && stcol[lane1] == QR_OK) stcol[lane1] = QR_NAN;  // fewer than two nodes: nothing to interpolate on
+      }
+      qr_fence();
+      // ---- 2b. per (column, boundary) the rank of the order statistic that opens the class.  Lane: column lane & 31, the
+      //      even (lanes < 32) or odd boundaries.
+      {
+        const uint32_t c = lane1 & 31u;
+        const uint32_t nn = ncol[c], c0 = c0col[c], nvn = nvcol[c];
+        const bool ok = stcol[c] == QR_OK;
+        const double dn = (double)nn;
+        const double mn = ((double)(c0 + 1u) / 2.0) / dn;           // rank of the minimum / count
+        const double mx = ((double)(2u * nn - 1u + 1u) / 2.0) / dn;  // rank of the (single) maximum / count
+        const double mxmn = mx - mn;
+        const double inv_dn = 1.0 / dn, inv_mxmn = 1.0 / mxmn;
+        const double slope = 2.0 * dn * (mxmn / mx);                 // d r2 / d pct
+#pragma nounroll
+        for (uint32_t t = lane1 >> 5; t < (uint32_t)ntmax; t += 2u) {
+          uint32_t rank = QR_SENT;
+          if (ok && t <= nvn) {
+            // t = 0: pct >= x0 (not below the first node); 0 < t < nvn: pct > (x[t-1] / 2 + x[t] / 2), scipy's nearest
+            // bounds; t = nvn: pct > the last node
+            double thr;
+            if (t == 0u) thr = qS[idx[c]];
+            else if (t == nvn) thr = qS[idx[(nvn - 1u) * 32 + c]];
+            else thr = qS[idx[(t - 1u) * 32 + c]] / 2.0 + qS[idx[t * 32 + c]] / 2.0;
+            // pct ~ mx (r2 / 2n - mn) / mxmn  =>  r2 ~ 2n mn + thr slope; then exactly: down while R - 1 passes, up while R fails
+            const double g = 2.0 * dn * mn + thr * slope;
+            uint32_t R = g < 1.0 ? 1u : (g > 2.0 * dn ? 2u * nn : (uint32_t)g);
+            bool down = true;
+            for (;;) {
+              const uint32_t probe = down ? R - 1u : R;
+              const bool valid = down ? R > 1u : R <= 2u * nn;
+              bool pass = false;
+              if (valid) {
+                const double rnk = xh_div_int((double)probe * 0.5, dn, inv_dn);
+                const double p = xh_div_int(mx * (rnk - mn), mxmn, inv_mxmn);
+                pass = t == 0u ? !(p < thr) : p > thr;
+              }
+              if (down) {
+                if (pass) --R; else down = false;
+              } else {
+                if (!valid || pass) break;
+                ++R;
+              }
+            }
+            if (R <= 2u * nn) {
+              const uint32_t p = R <= 2u ? 0u : (R - 1u) >> 1;  // ceil((R - 2) / 2): first position whose r2 = 2p + 2 reaches R
+              if (p < c0) rank = (c0 + 1u >= R) ? 0u : c0;      // inside the minimum's run [0, c0): its r2 is c0 + 1
+              else rank = p;
+              if (rank >= nn) rank = QR_SENT;
+            }
+          }
+          rkT[t * 32 + c] = (uint16_t)rank;
+          vals[t * 32 + c] = PADK;  // a boundary nobody reaches decodes to NaN: every compare fails
+        }
+        // one more target, for the tie test only: the maximum (rank n - 1).  Copies of the maximum change mx, i.e. the
+        // percentage rank of EVERY sample, wherever the class boundaries lie.
+        if (lane1 < 32u) {
+          vals[ntmax * 32 + lane1] = PADK;
+          rkT[ntmax * 32 + lane1] = (uint16_t)(ok && nn >= 1u ? nn - 1u : QR_SENT);
+        }
+      }
+      qr_fence();
+#define XH_UP(e, reg) reg = mydump[(e) * 64];
+      XH_SN_DUMP_0(XH_UP)
+#undef XH_UP
+    }
+    // ---- 3. local sort
+#define XH_CE(i, j)                               \
+  {                                               \
+    const uint32_t a_ = k##i, b_ = k##j;          \
+    k##i = a_ < b_ ? a_ : b_;                     \
+    k##j = a_ < b_ ? b_ : a_;                     \
+  }
+    if (!(abl & 4)) {
+    XH_SN_SORT(XH_CE)
+    }
+    uint32_t lane3 = (uint32_t)tid & 63u;
+    asm volatile("" : "+v"(lane3));
+    const uint32_t mA3 = (lane3 & 1u) ? 0u : 0xFFFFFFFFu;
+    // ---- 4. lane A negates, bitonic split across the lane pair (one asm statement per register pair, see select3.hip)
+#define XH_DPP_SWAP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define XH_SP(i, j)                                                                                              \
+  {                                                                                                              \
+    uint32_t t0_, t1_;                                                                                           \
+    asm volatile(                                                                                                \
+        "v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %4\n\ts_nop 1\n\t"                                            \
+        "v_not_b32_dpp %2, %1 " XH_DPP_SWAP1 "\n\tv_not_b32_dpp %3, %0 " XH_DPP_SWAP1 "\n\t"                    \
+        "v_max_u32 %0, %0, %2\n\tv_max_u32 %1, %1, %3"                                                           \
+        : "+v"(k##i), "+v"(k##j), "=&v"(t0_), "=&v"(t1_)                                                         \
+        : "v"(mA3));                                                                                             \
+  }
+#define XH_SM(m)                                                                          \
+  {                                                                                       \
+    uint32_t t0_;                                                                         \
+    asm volatile("v_xor_b32 %0, %0, %2\n\ts_nop 1\n\tv_not_b32_dpp %1, %0 " XH_DPP_SWAP1   \
+                 "\n\tv_max_u32 %0, %0, %1"                                               \
+                 : "+v"(k##m), "=&v"(t0_)                                                 \
+                 : "v"(mA3));                                                             \
+  }
+    if (!(abl & 4)) {
+    XH_SN_SPLIT(XH_SP, XH_SM)
+    }
+#undef XH_SP
+#undef XH_SM
+    // ---- 5. merge: rank r of the column sits in A at k[N-1-r] (negated) for r < N, in B at k[r-N] otherwise
+    if (!(abl & 4)) {
+    XH_SN_MERGE(XH_CE)
+    }
+#undef XH_CE
+    uint32_t lane4 = (uint32_t)tid & 63u;
+    asm volatile("" : "+v"(lane4));
+    const uint32_t h = lane4 & 1u, c32 = lane4 >> 1;
+    const uint32_t mA = h ? 0u : 0xFFFFFFFFu;
+    const int64_t mycol = col0 + c32;
+    // ---- 6 + 7. picks: one monotone sequence of targets — B (ranks >= N) walks its targets upwards, A downwards — and the
+    //      tie test: a picked key that equals one of its two neighbours in the sorted column belongs to a run the kernel
+    //      knows nothing about (unless it is the minimum's: rank < cnt0) -> the column goes on the list.  The neighbours are
+    //      the hand-over entries next to it, at a chunk's edges the adjacent register, across the lane pair the partner's k0.
+    if (!(abl & 16)) {
+      const uint32_t c0 = c0col[c32];
+      // my targets: ranks < N live in lane A, ranks in [N, 2N) in lane B; unreachable boundaries carry the sentinel and are
+      // skipped (they may lie between the last boundary and the maximum's target)
+      const int dj = h ? 1 : -1;
+      auto next_mine = [&](int j) -> int {
+        while (j >= 0 && j <= ntmax) {
+          const uint32_t r = rkT[j * 32 + c32];
+          if (h ? (r >= (uint32_t)N && r != QR_SENT) : r < (uint32_t)N) break;
+          j += dj;
+        }
+        return j;
+      };
+      auto local_of = [&](int j) -> uint32_t {
+        if (j < 0 || j > ntmax) return 0xFFFFFFFFu;
+        const uint32_t r = rkT[j * 32 + c32];
+        return h ? r - (uint32_t)N : (uint32_t)(N - 1) - r;
+      };
+      int jcur = next_mine(h ? 0 : ntmax);
+      uint32_t snext = local_of(jcur);
+      uint32_t tied = 0u;
+      const uint32_t partner0 = qr_swap1(k0 ^ mA);  // the partner lane's k0 as a real key: my local index -1
+#define XH_PICK(c, LO, HI)                                                        \
+  {                                                                               \
+    const uint32_t lo_edge_ = (LO), hi_edge_ = (HI);                              \
+    XH_SN_DUMP_##c(XH_DW)                                                         \
+    constexpr uint32_t cnt_ = (c) < 5 ? 32u : (uint32_t)(N - 160);                \
+    while ((snext >> 5) == (uint32_t)(c)) {                                       \
+      const uint32_t e_ = snext & 31u;                                            \
+      const uint32_t v_ = mydump[e_ * 64] ^ mA;                                   \
+      const uint32_t lo_ = e_ > 0u ? mydump[(e_ - 1u) * 64] ^ mA : lo_edge_;      \
+      const uint32_t hi_ = e_ + 1u < cnt_ ? mydump[(e_ + 1u) * 64] ^ mA : hi_edge_; \
+      vals[jcur * 32 + (int)c32] = v_;                                            \
+      tied |= ((lo_ == v_ || hi_ == v_) && rkT[jcur * 32 + c32] >= c0) ? 1u : 0u;  \
+      jcur = next_mine(jcur + dj);                                                \
+      snext = local_of(jcur);                                                     \
+    }                                                                             \
+  }
+      XH_PICK(0, partner0, k32 ^ mA)
+      XH_PICK(1, k31 ^ mA, k64 ^ mA)
+      XH_PICK(2, k63 ^ mA, k96 ^ mA)
+      XH_PICK(3, k95 ^ mA, k128 ^ mA)
+      XH_PICK(4, k127 ^ mA, k160 ^ mA)
+      XH_PICK(5, k159 ^ mA, PADK)
+#undef XH_PICK
+      if (tied && stcol[c32] == QR_OK) stcol[c32] = QR_TIES;
+    }
+    qr_fence();
+    // ---- 8a. the tile's rows once more, all in flight (the sorted keys are dead: same registers, same loads as step 1; L2 /
+    //      Infinity Cache serve most of them) — issued before the tables below are built
+    const int64_t colc8 = mycol < C ? mycol : C - 1;
+    if (!(abl & 32)) {
+      const uint32_t voff = (uint32_t)(colc8 * 4) + (h ? (uint32_t)(T - N) * strideB : 0u);
+      uint32_t soff = 0u;
+      asm volatile("" : "+s"(soff));
+#define XH_LD(i) k##i = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0); soff += strideB;
+      XH_SN_FOREACH(XH_LD)
+#undef XH_LD
+    }
+    // ---- 8b. cut values as floats; factor table of the column's classes: [0] below the first node, [k] node k - 1,
+    //      [nvn + 1] above the last node; columns that are all-NaN or on the tie list get NaN everywhere
+    for (int i = (int)lane4; i < (ntmax + 1) * 32; i += 64) vals[i] = __float_as_uint(xh_key2f(vals[i]));
+    {
+      // lane: column lane & 31, the even (lanes < 32) or odd classes; 8 factor loads in flight
+      const uint32_t c = lane4 & 31u, hf = lane4 >> 5;
+      const int64_t cc = col0 + c < C ? col0 + c : C - 1;
+      const uint32_t nvn = nvcol[c], stt = stcol[c];
+      const float nanv = xh_nan32();
+#pragma nounroll
+      for (uint32_t k0_ = hf; k0_ <= (uint32_t)ntmax; k0_ += 16u) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t k = k0_ + 2u * (uint32_t)u;  // class k: node min(max(k, 1), nvn) - 1
+          uint32_t node = k < 1u ? 0u : k - 1u;
+          node = node < nvn ? node : (nvn > 0u ? nvn - 1u : 0u);
+          const uint32_t jn = nvn > 0u ? idx[node * 32 + c] : 0u;  // (no valid node: the table entry is never read as one)
+          a[u] = af[(int64_t)jn * af_qs + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t k = k0_ + 2u * (uint32_t)u;
+          if (k <= (uint32_t)ntmax) {
+            const bool inner = k >= 1u && k <= nvn;  // below the first / above the last node: the end factor or NaN
+            FS[k * 32 + c] = (stt == QR_OK && k <= nvn + 1u && (inner || extrap == 0)) ? a[u] : nanv;
+          }
+        }
+      }
+      if (lane4 < 32u && stt == QR_TIES && col0 + c < C) flist[atomicAdd(nflag, 1u)] = (uint32_t)(col0 + c);
+    }
+    qr_fence();
+    // ---- 8c. classify, correct, store.  The rows leave the registers through the hand-over buffer (a rolled loop needs a
+    //      run-time row index); class = number of cuts <= x (cuts non-decreasing, unreachable ones NaN at the end): a
+    //      branch-free lower bound, 8 rows level by level (8 independent LDS reads in flight instead of one dependent
+    //      chain per sample)
+    if (!(abl & 32)) {
+      const uint32_t voffO = (uint32_t)(colc8 * 4) + (h ? (uint32_t)(T - N) * strideO : 0u);
+      const uint32_t bc = h ? (uint32_t)(2 * N - T) : 0u;  // B's first rows are A's
+      const float* cuts = reinterpret_cast<const float*>(vals) + c32;
+      const float* fac = FS + c32;
+      const bool colok = mycol < C;
+      constexpr int QB = 8;
+#pragma nounroll
+      for (int ci = 0; ci < 6; ++ci) {
+        QR_DUMP_CHUNK(ci)
+        const int cnt = ci < 5 ? 32 : N - 160;
+#pragma nounroll
+        for (int e0 = 0; e0 < cnt; e0 += QB) {
+          float v[QB];
+#pragma unroll
+          for (int u = 0; u < QB; ++u) v[u] = __uint_as_float(mydump[(e0 + u < cnt ? e0 + u : cnt - 1) * 64]);
+          uint32_t base[QB];
+#pragma unroll
+          for (int u = 0; u < QB; ++u) base[u] = 0u;
+          int len = ntmax;
+#pragma nounroll
+          while (len > 1) {
+            const int half = len >> 1;
+            float cv[QB];
+#pragma unroll
+            for (int u = 0; u < QB; ++u) cv[u] = cuts[(base[u] + (uint32_t)half - 1u) * 32];
+            asm volatile("" ::: "memory");  // (all QB reads issued before the first compare waits)
+#pragma unroll
+            for (int u = 0; u < QB; ++u) base[u] += (v[u] >= cv[u]) ? (uint32_t)half : 0u;
+            len -= half;
+          }
+          {
+            float cv[QB];
+#pragma unroll
+            for (int u = 0; u < QB; ++u) cv[u] = cuts[base[u] * 32];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < QB; ++u) base[u] += (v[u] >= cv[u]) ? 1u : 0u;
+          }
+          float a[QB];
+#pragma unroll
+          for (int u = 0; u < QB; ++u) a[u] = fac[base[u] * 32];
+#pragma unroll
+          for (int u = 0; u < QB; ++u) {
+            const int i = ci * 32 + e0 + u;
+            const float r = kind == 0 ? v[u] + a[u] : v[u] * a[u];
+            if (e0 + u < cnt && (uint32_t)i >= bc && colok)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rsrcO, (int)voffO, (int)((uint32_t)i * strideO), 0);
+          }
+        }
+      }
+    }
+#undef QR_DUMP_CHUNK
+#undef XH_DW
+    qr_fence();  // the per-wave tables are rewritten by the next tile
+  }
+}
+
+// flagged columns -> time-minor scratch (column f at buf + f * Tp), their factors -> (nq, nf)
+__global__ void __launch_bounds__(XH_BLOCK)
+k_qr_gather(const float* __restrict__ x, int64_t T, int64_t st, const uint32_t* __restrict__ flist, float* __restrict__ buf,
+            int64_t Tp, const float* __restrict__ af, int64_t af_qs, int nq, int64_t nf, float* __restrict__ gaf) {
+  const int64_t c = flist[blockIdx.x];
+  float* dst = buf + (int64_t)blockIdx.x * Tp;
+  for (int64_t t = threadIdx.x; t < T; t += XH_BLOCK) dst[t] = x[t * st + c];
+  if (threadIdx.x < nq) gaf[(int64_t)threadIdx.x * nf + blockIdx.x] = af[(int64_t)threadIdx.x * af_qs + c];
+}
+
+__global__ void __launch_bounds__(XH_BLOCK)
+k_qr_scatter(const float* __restrict__ buf, int64_t T, int64_t Tp, const uint32_t* __restrict__ flist, float* __restrict__ out,
+             int64_t ost) {
+  const int64_t c = flist[blockIdx.x];
+  const float* src = buf + (int64_t)blockIdx.x * Tp;
+  for (int64_t t = threadIdx.x; t < T; t += XH_BLOCK) out[t * ost + c] = src[t];
+}
+
+}  // namespace
+
+// XH_OK: scen written.  XH_ERR_NOTIMPL (no error text): not this kernel's shape, the caller runs the exact-rank pipeline.
+int xh_qdm_regsort(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, const float* af, int64_t af_qs,
+                   const double* d_q, int nq, int kind, int extrap, float* scen, int64_t ost) {
+  constexpr int N = XH_SN_N, TMIN = 360;
+  if (T < TMIN || T > 2 * N || nq < 2 || nq > QR_MAXQ || C < 1) return XH_ERR_NOTIMPL;
+  if (scen == sim) return XH_ERR_NOTIMPL;  // (the tied columns are re-read from sim after scen has been written)
+  if ((unsigned long long)T * (unsigned long long)st * 4ull >= (1ull << 32) ||
+      (unsigned long long)T * (unsigned long long)ost * 4ull >= (1ull << 32) || C >= ((int64_t)1 << 32))
+    return XH_ERR_NOTIMPL;
+  if (xh_diag_env("XH_QDM_NOREGSORT")) return XH_ERR_NOTIMPL;  // A/B against the exact-rank kernel
+  const size_t lds = sizeof(double) * QR_MAXQ + 4 * sizeof(uint32_t) * (size_t)qr_words_per_wave(nq);
+  if (lds > 79 * 1024) return XH_ERR_NOTIMPL;  // two workgroups per CU
+  const int64_t ntiles = (C + 31) / 32;
+  int64_t nblk = (ntiles + 3) / 4;
+  const int64_t maxblk = (int64_t)ctx->num_cu * 2;
+  if (nblk > maxblk) nblk = maxblk;
+  // scratch: counter | tie list (at most C entries) | room for the tied columns' detour through the exact-rank kernel
+  // (time-minor copies in and out + their factors), capped at C / 8 columns — more ties than that: exact ranks for everything
+  const int64_t Tp = (T + 63) & ~(int64_t)63;
+  int64_t nfmax = C / 8 > 4096 ? C / 8 : 4096;
+  if (nfmax > C) nfmax = C;
+  const size_t b_list = sizeof(uint32_t) * (((size_t)C + 4 + 63) & ~(size_t)63);
+  const size_t b_cols = sizeof(float) * (size_t)nfmax * (size_t)Tp;
+  void* ws = nullptr;
+  int rc = xh_big_scratch(ctx, b_list + 2 * b_cols + sizeof(float) * (size_t)nq * (size_t)nfmax, &ws);
+  if (rc) return rc;
+  uint32_t* nflag = static_cast<uint32_t*>(ws);
+  uint32_t* flist = nflag + 4;
+  float* gbuf = reinterpret_cast<float*>(static_cast<char*>(ws) + b_list);
+  float* gout = gbuf + (size_t)nfmax * (size_t)Tp;
+  float* gaf = gout + (size_t)nfmax * (size_t)Tp;
+  XH_CHECK_HIP(hipMemsetAsync(nflag, 0, 16, ctx->stream));
+  const char* ea = xh_diag_env("XH_QDM_ABL");  // diagnostics: skip phases (1 stats, 2 ranks, 4 sort, 16 picks, 32 apply; wrong results)
+  const int abl = ea ? atoi(ea) : 0;
+  auto kern = k_qdm_regsort<N, TMIN>;
+  if (lds > 48 * 1024) XH_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, sim, (int)T, C, st, af, af_qs, d_q, nq, kind, extrap,
+                     scen, ost, flist, nflag, abl);
+  XH_LAUNCH_CHECK();
+  uint32_t nf = 0;
+  XH_CHECK_HIP(hipMemcpyAsync(&nf, nflag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (xh_diag_env("XH_QDM_STATS")) fprintf(stderr, "[xh_qdm_regsort] T=%lld C=%lld nq=%d: %u columns with ties -> exact-rank kernel\n", (long long)T, (long long)C, nq, nf);
+  if (nf == 0 || abl) return XH_OK;
+  if ((int64_t)nf > nfmax) return XH_ERR_NOTIMPL;  // a quantised field: the caller ranks every column exactly
+  // columns with ties: exact average ranks (k_qdm_columns, time-minor input: it does not touch the big scratch) on a copy
+  hipLaunchKernelGGL(k_qr_gather, dim3(nf), dim3(XH_BLOCK), 0, ctx->stream, sim, T, st, flist, gbuf, Tp, af, af_qs, nq, (int64_t)nf, gaf);
+  rc = xh_qdm_columns(ctx, gbuf, T, (int64_t)nf, Tp, gaf, (int64_t)nf, d_q, nq, kind, 0, extrap, gout, Tp);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_qr_scatter, dim3(nf), dim3(XH_BLOCK), 0, ctx->stream, gout, T, Tp, flist, scen, ost);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
