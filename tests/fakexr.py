@@ -166,7 +166,8 @@ def make_reference_like_modules(env):
     mods = {}
     for modname, names in {
         "xclim.indices.generic": ("threshold_count", "count_occurrences", "domain_count", "select_resample_op",
-                                  "spell_length_statistics", "cumulative_difference", "compare"),
+                                  "spell_length_statistics", "cumulative_difference", "compare", "season",
+                                  "first_day_threshold_reached"),
         "xclim.core.calendar": ("percentile_doy", "resample_doy"),
         "xclim.indices.run_length": ("rle", "rle_statistics", "longest_run", "windowed_run_events", "windowed_run_count",
                                      "first_run", "last_run", "season_length", "resample_and_rl", "_cumsum_reset_np"),
@@ -218,6 +219,20 @@ def make_reference_like_modules(env):
     def growing_degree_days(tas, thresh=277.15, freq="YS"):  # _threshold.py: cumulative_difference(tas, thresh, ">", freq)
         return th.cumulative_difference(tas, threshold=thresh, op=">", freq=freq)
 
+    th.season, th.first_day_threshold_reached = gen.season, gen.first_day_threshold_reached
+
+    def growing_season_length(tas, thresh=278.15, window=6, mid_date="07-01", freq="YS", op=">="):  # _threshold.py (growing_season_length)
+        return th.season(tas, thresh=thresh, window=window, op=op, stat="length", freq=freq, mid_date=mid_date, constrain=(">=", ">"))
+
+    def growing_season_start(tas, thresh=278.15, mid_date="07-01", window=5, freq="YS", op=">="):
+        return th.season(tas, thresh=thresh, window=window, op=op, stat="start", freq=freq, mid_date=mid_date, constrain=(">=", ">"))
+
+    def first_day_temperature_above(tas, thresh=273.15, op=">", after_date="01-01", window=1, freq="YS"):  # _threshold.py
+        return th.first_day_threshold_reached(tas, threshold=thresh, op=op, after_date=after_date, window=window, freq=freq,
+                                              constrain=(">", ">="))
+
+    th.growing_season_length, th.growing_season_start, th.first_day_temperature_above = (
+        growing_season_length, growing_season_start, first_day_temperature_above)
     th.maximum_consecutive_dry_days, th.frost_days, th.hot_spell_frequency, th.growing_degree_days = (
         maximum_consecutive_dry_days, frost_days, hot_spell_frequency, growing_degree_days)
     mods[th.__name__] = th

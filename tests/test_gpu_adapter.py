@@ -277,3 +277,40 @@ def test_indicator_level_fusion_compute_and_missing_mask_in_one_pass(ref, dev, r
     assert m.values.sum() == 0 and m.values.shape == (2, 5, 6)      # the NaNs lie outside JJA
     with pytest.raises(AssertionError, match="was reached"):        # a sub-daily / unknown source step is the reference's business
         misser(other, "YS", "h")
+
+
+def test_season_and_first_day_threshold_reached_through_the_wrappers(ref, dev, rng):
+    """generic.season / first_day_threshold_reached (gen:770-853, 1556-1608) as imported BY NAME into _threshold.py: the
+    growing season length / start and the first day above a threshold, against the oracle's season and first-run
+    functions applied per period."""
+    env, mods, names = ref
+    assert "xclim.indices._threshold.season" in names and "xclim.indices._threshold.first_day_threshold_reached" in names
+    T = 365 * 3
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    x = (_temp(rng, T, (5, 6)) - 12.0).astype(np.float32)          # seasons that start in spring and end in autumn
+    x[400:405, 0, 0] = np.nan
+    da = fakexr.field(x, ta, attrs={"units": "K"})
+    th = mods["xclim.indices._threshold"]
+    cond = x >= np.float32(278.15)
+    beg, end, length = orl.season_per_period(cond, 6, "07-01", ot, "YS")
+    got = th.growing_season_length(da, thresh=278.15, window=6, mid_date="07-01", freq="YS")
+    assert got.dims == ("time", "lat", "lon") and got.attrs["units"] == "days"
+    np.testing.assert_array_equal(got.values, length)
+    seg, _ = ta.segments("YS")
+    beg5, _, _ = orl.season_per_period(cond, 5, "07-01", ot, "YS")
+    start = th.growing_season_start(da, thresh=278.15, mid_date="07-01", window=5, freq="YS")
+    exp = np.full(beg5.shape, np.nan)
+    for p in range(beg5.shape[0]):
+        ok = ~np.isnan(beg5[p])
+        exp[p][ok] = ta.doy[int(seg[p]) + beg5[p][ok].astype(int)]
+    np.testing.assert_array_equal(start.values, exp)
+    assert start.attrs["is_dayofyear"] == 1 and start.attrs["calendar"] == "noleap" and start.attrs["units"] == ""
+    first = th.first_day_temperature_above(da, thresh=283.15, after_date="03-01", window=3, freq="YS")
+    exp = np.stack([orl.first_run_after_date((x[idx] > np.float32(283.15)), 3, "03-01", ot.isel(idx)) for _, idx in orl.groups(ot, "YS")])
+    expd = np.full(exp.shape, np.nan)
+    for p in range(exp.shape[0]):
+        ok = ~np.isnan(exp[p])
+        expd[p][ok] = ta.doy[int(seg[p]) + exp[p][ok].astype(int)]
+    np.testing.assert_array_equal(first.values, expd)
+    with pytest.raises(ValueError):
+        th.season(da, thresh=278.15, window=6, op="<", stat="length", freq="YS", constrain=(">=", ">"))

@@ -13,7 +13,8 @@ wrapper is EXECUTED on the GPU box, where xarray is not installable).  What a Da
 Reference functions replaced (signatures identical, file:line of the original):
 
     indices/generic.py      threshold_count :329, count_occurrences :960, domain_count :364, select_resample_op :83,
-                            spell_length_statistics :588, cumulative_difference :1514, compare :301
+                            spell_length_statistics :588, cumulative_difference :1514, compare :301, season :770,
+                            first_day_threshold_reached :1556
     core/calendar.py        percentile_doy :395, resample_doy :763
     indices/run_length.py   rle :223, rle_statistics :275, longest_run :338, windowed_run_events :381,
                             windowed_run_count :437, first_run :643, last_run :693, season_length :1113,
@@ -323,6 +324,31 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         out = hgen.cumulative_difference(x, float(thr), op, time_axis_of(a), freq, device=dev())
         return env.to_agg_units(wrap_periods(a, out, freq, data.attrs), data, op="integral")
 
+    def season(data, thresh, window, op, stat, freq, mid_date=None, constrain=None):  # gen:770-853
+        a, x = _tfirst(data)
+        thr = as_threshold(env.convert_units_to(thresh, data, context="infer"), a)
+        if thr is None or np.ndim(thr) != 0 or stat not in ("start", "end", "length"):
+            return fallback("season", data, thresh, window, op, stat, freq, mid_date=mid_date, constrain=constrain)
+        hgen.get_op(op, constrain)
+        res = hgen.season(x, float(thr), window, op, time_axis_of(a), freq, mid_date, device=dev())[stat]
+        out = wrap_periods(a, res, freq, data.attrs)
+        if stat == "length":
+            return env.to_agg_units(out, data, "count")
+        out.attrs.update(units="", is_dayofyear=np.int32(1), calendar=str(a["time"].dt.calendar))
+        return out
+
+    def first_day_threshold_reached(data, *, threshold, op, after_date, window=1, freq="YS", constrain=None):  # gen:1556-1608
+        a, x = _tfirst(data)
+        thr = as_threshold(env.convert_units_to(threshold, data), a)
+        if thr is None or np.ndim(thr) != 0:
+            return fallback("first_day_threshold_reached", data, threshold=threshold, op=op, after_date=after_date, window=window,
+                            freq=freq, constrain=constrain)
+        res = hgen.first_day_threshold_reached(x, threshold=float(thr), op=op, after_date=after_date, time=time_axis_of(a),
+                                               window=window, freq=freq, constrain=constrain, device=dev())
+        out = wrap_periods(a, res, freq, data.attrs)
+        out.attrs.update(units="", is_dayofyear=np.int32(1), calendar=str(a["time"].dt.calendar))
+        return out
+
     def compare(left, op, right, constrain=None):  # gen:301-326
         if isinstance(right, DoyThreshold) and isinstance(left, DA):
             hgen.get_op(op, constrain)  # the reference's ValueError for an unknown / constrained operator comes first
@@ -522,7 +548,8 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     table = {
         "threshold_count": threshold_count, "count_occurrences": count_occurrences, "domain_count": domain_count,
         "select_resample_op": select_resample_op, "spell_length_statistics": spell_length_statistics,
-        "cumulative_difference": cumulative_difference, "compare": compare,
+        "cumulative_difference": cumulative_difference, "compare": compare, "season": season,
+        "first_day_threshold_reached": first_day_threshold_reached,
         "percentile_doy": percentile_doy, "resample_doy": resample_doy,
         "rle": rle, "rle_statistics": rle_statistics, "longest_run": longest_run, "windowed_run_events": windowed_run_events,
         "windowed_run_count": windowed_run_count, "first_run": first_run, "last_run": last_run, "season_length": season_length,
