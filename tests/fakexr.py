@@ -167,7 +167,7 @@ def make_reference_like_modules(env):
     for modname, names in {
         "xclim.indices.generic": ("threshold_count", "count_occurrences", "domain_count", "select_resample_op",
                                   "spell_length_statistics", "cumulative_difference", "compare", "season",
-                                  "first_day_threshold_reached"),
+                                  "first_day_threshold_reached", "bivariate_count_occurrences"),
         "xclim.core.calendar": ("percentile_doy", "resample_doy"),
         "xclim.indices.run_length": ("rle", "rle_statistics", "longest_run", "windowed_run_events", "windowed_run_count",
                                      "first_run", "last_run", "season_length", "resample_and_rl", "_cumsum_reset_np"),
@@ -220,6 +220,14 @@ def make_reference_like_modules(env):
         return th.cumulative_difference(tas, threshold=thresh, op=">", freq=freq)
 
     th.season, th.first_day_threshold_reached = gen.season, gen.first_day_threshold_reached
+    th.bivariate_count_occurrences = gen.bivariate_count_occurrences
+
+    def tx_tn_days_above(tasmin, tasmax, thresh_tasmin=295.15, thresh_tasmax=303.15, freq="YS", op=">"):  # _threshold.py (tx_tn_days_above)
+        return th.bivariate_count_occurrences(data_var1=tasmin, data_var2=tasmax, threshold_var1=thresh_tasmin, threshold_var2=thresh_tasmax,
+                                              freq=freq, op_var1=op, op_var2=op, var_reducer="all", constrain_var1=(">", ">="),
+                                              constrain_var2=(">", ">="))
+
+    th.tx_tn_days_above = tx_tn_days_above
 
     def growing_season_length(tas, thresh=278.15, window=6, mid_date="07-01", freq="YS", op=">="):  # _threshold.py (growing_season_length)
         return th.season(tas, thresh=thresh, window=window, op=op, stat="length", freq=freq, mid_date=mid_date, constrain=(">=", ">"))

@@ -314,3 +314,18 @@ def test_season_and_first_day_threshold_reached_through_the_wrappers(ref, dev, r
     np.testing.assert_array_equal(first.values, expd)
     with pytest.raises(ValueError):
         th.season(da, thresh=278.15, window=6, op="<", stat="length", freq="YS", constrain=(">=", ">"))
+
+
+def test_bivariate_count_occurrences_through_the_wrappers(ref, dev, rng):
+    """tx_tn_days_above (_threshold.py) = bivariate_count_occurrences(..., var_reducer="all") imported by name."""
+    env, mods, names = ref
+    assert "xclim.indices._threshold.bivariate_count_occurrences" in names
+    T = 730
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    tn, tx = _temp(rng, T, (4, 3), 0.01), _temp(rng, T, (4, 3), 0.01) + 6
+    out = mods["xclim.indices._threshold"].tx_tn_days_above(fakexr.field(tn, ta, attrs={"units": "K"}), fakexr.field(tx, ta, attrs={"units": "K"}),
+                                                             thresh_tasmin=292.0, thresh_tasmax=299.0, freq="MS")
+    cond = (tn > np.float32(292.0)) & (tx > np.float32(299.0))
+    exp = np.stack([cond[idx].sum(axis=0) for _, idx in orl.groups(ot, "MS")])
+    np.testing.assert_array_equal(out.values, exp)
+    assert out.dims == ("time", "lat", "lon") and out.attrs["units"] == "days" and exp.sum() > 0

@@ -76,7 +76,7 @@ _saved: dict = {}
 # _multivariate.py:13, 22-24, _simple.py:10, _hydrology.py:14, _anuclim.py:26, core/bootstrapping.py:17, indices/stats.py:23);
 # a name is only replaced where the module really holds it (hasattr), so the table may list more than a version imports
 _GENERIC_NAMES = ("threshold_count", "count_occurrences", "domain_count", "select_resample_op", "spell_length_statistics",
-                  "cumulative_difference", "compare", "season", "first_day_threshold_reached")
+                  "cumulative_difference", "compare", "season", "first_day_threshold_reached", "bivariate_count_occurrences")
 _BY_NAME = {
     "xclim.indices.generic": _GENERIC_NAMES,
     "xclim.indices._threshold": _GENERIC_NAMES,

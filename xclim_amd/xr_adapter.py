@@ -13,7 +13,7 @@ wrapper is EXECUTED on the GPU box, where xarray is not installable).  What a Da
 Reference functions replaced (signatures identical, file:line of the original):
 
     indices/generic.py      threshold_count :329, count_occurrences :960, domain_count :364, select_resample_op :83,
-                            spell_length_statistics :588, cumulative_difference :1514, compare :301, season :770,
+                            spell_length_statistics :588, cumulative_difference :1514, compare :301, season :770, bivariate_count_occurrences :1003,
                             first_day_threshold_reached :1556
     core/calendar.py        percentile_doy :395, resample_doy :763
     indices/run_length.py   rle :223, rle_statistics :275, longest_run :338, windowed_run_events :381,
@@ -324,6 +324,25 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         out = hgen.cumulative_difference(x, float(thr), op, time_axis_of(a), freq, device=dev())
         return env.to_agg_units(wrap_periods(a, out, freq, data.attrs), data, op="integral")
 
+    def bivariate_count_occurrences(*, data_var1, data_var2, threshold_var1, threshold_var2, freq, op_var1, op_var2,
+                                    var_reducer, constrain_var1=None, constrain_var2=None):  # gen:1003-1073
+        kw = dict(data_var1=data_var1, data_var2=data_var2, threshold_var1=threshold_var1, threshold_var2=threshold_var2,
+                  freq=freq, op_var1=op_var1, op_var2=op_var2, var_reducer=var_reducer, constrain_var1=constrain_var1,
+                  constrain_var2=constrain_var2)
+        if not (isinstance(data_var1, DA) and isinstance(data_var2, DA)) or tuple(data_var1.dims) != tuple(data_var2.dims):
+            return fallback("bivariate_count_occurrences", **kw)
+        a, x1 = _tfirst(data_var1)
+        b, x2 = _tfirst(data_var2)
+        t1 = as_threshold(env.convert_units_to(threshold_var1, data_var1), a)
+        t2 = as_threshold(env.convert_units_to(threshold_var2, data_var2), b)
+        if t1 is None or t2 is None or np.ndim(t1) != 0 or np.ndim(t2) != 0 or x1.shape != x2.shape:
+            return fallback("bivariate_count_occurrences", **kw)
+        out = hgen.bivariate_count_occurrences(data_var1=x1, data_var2=x2, threshold_var1=float(t1), threshold_var2=float(t2),
+                                               time=time_axis_of(a), freq=freq, op_var1=op_var1, op_var2=op_var2,
+                                               var_reducer=var_reducer, constrain_var1=constrain_var1,
+                                               constrain_var2=constrain_var2, device=dev())
+        return env.to_agg_units(wrap_periods(a, np.asarray(out).astype(np.int64), freq, data_var1.attrs), data_var1, "count", dim="time")
+
     def season(data, thresh, window, op, stat, freq, mid_date=None, constrain=None):  # gen:770-853
         a, x = _tfirst(data)
         thr = as_threshold(env.convert_units_to(thresh, data, context="infer"), a)
@@ -549,6 +568,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         "threshold_count": threshold_count, "count_occurrences": count_occurrences, "domain_count": domain_count,
         "select_resample_op": select_resample_op, "spell_length_statistics": spell_length_statistics,
         "cumulative_difference": cumulative_difference, "compare": compare, "season": season,
+        "bivariate_count_occurrences": bivariate_count_occurrences,
         "first_day_threshold_reached": first_day_threshold_reached,
         "percentile_doy": percentile_doy, "resample_doy": resample_doy,
         "rle": rle, "rle_statistics": rle_statistics, "longest_run": longest_run, "windowed_run_events": windowed_run_events,
