@@ -134,6 +134,28 @@ def test_threshold_count_doy_multi_year_tile_kernel(dev, rng, op, C, freq):
     np.testing.assert_array_equal(val.get(), exp_v)
 
 
+def test_threshold_count_doy_tile_kernel_empty_periods_and_narrow_counters(dev, rng):
+    """tcount.hip: periods without a step (equal consecutive offsets) count 0 / 0; 8-bit counter halves (every period
+    shorter than 256 steps) and 16-bit ones (a period of 400 steps) give the same counts as the per-period kernel."""
+    T, C = 4000, 130
+    x = _field(rng, T, C, nan_frac=0.01)
+    table = 288 + rng.normal(0, 4, (366, C))
+    tidx = (np.arange(T) % 366).astype(np.int32)
+    for seg in (np.array([0, 200, 200, 200, 431, 600, 855, 1000, 1000, 1255, T - 7], dtype=np.int64),     # narrow, gaps at both ends
+                np.array([3, 403, 500, 900, 1300, 1300, 1700, 2100, 2500, 2900, 3300, 3700, T], dtype=np.int64)):  # a 400-step period
+        hit = x.astype(np.float64) <= table[tidx]
+        ok = ~np.isnan(x)
+        P = len(seg) - 1
+        exp_c = np.stack([hit[seg[p]:seg[p + 1]].sum(axis=0) for p in range(P)]).astype(np.int32)
+        exp_v = np.stack([ok[seg[p]:seg[p + 1]].sum(axis=0) for p in range(P)]).astype(np.int32)
+        trace = dev.start_trace()
+        cnt, val = K.threshold_count(dev, dev.to_device(x), "<=", seg, doy_table=dev.to_device(table), tidx=tidx)
+        dev.stop_trace()
+        assert [n for n, _ in trace if n.startswith("xh_threshold_count")] == ["xh_threshold_count_doy"]
+        np.testing.assert_array_equal(cnt.get(), exp_c)
+        np.testing.assert_array_equal(val.get(), exp_v)
+
+
 def test_domain_count(dev, rng):
     T, C = 730, 300
     x = _field(rng, T, C, nan_frac=0.01)
