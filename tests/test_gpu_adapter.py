@@ -55,7 +55,11 @@ def test_install_replaces_every_by_name_import(ref):
     assert "xclim.indices._multivariate.threshold_count" in names and "xclim.indices._multivariate.resample_doy" in names
     assert "xclim.indices._threshold.spell_length_statistics" in names and "xclim.indices.run_length.resample_and_rl" in names
     assert mods["xclim.indices._multivariate"].threshold_count is mods["xclim.indices.generic"].threshold_count
-    assert mods["xclim.core.calendar"].percentile_doy.__wrapped__ is mods["xclim.core.calendar"].percentile_doy  # bootstrapping.py:195
+    import inspect
+
+    pd = mods["xclim.core.calendar"].percentile_doy
+    assert callable(pd.__wrapped__)  # bootstrapping.py:195 calls percentile_doy.__wrapped__(...)
+    assert list(inspect.signature(pd).parameters) == ["arr", "window", "per", "alpha", "beta", "copy"]  # cal:395-402
 
 
 def test_tx90p_through_the_wrappers_reaches_the_doy_table_kernel(ref, dev, rng):

@@ -294,3 +294,47 @@ def test_weekly_frequency_needs_weekdays():
         TimeAxis.daily("2001-01-01", 30, "360_day").segments("W")
     seg, _ = TimeAxis.daily("2001-01-01", 65, "360_day").segments("30D")
     np.testing.assert_array_equal(seg, [0, 30, 60, 65])
+
+
+def test_adapter_wrappers_have_the_reference_signatures():
+    """Every DataArray-level wrapper of xr_adapter.py takes exactly the parameters of the reference function it replaces
+    (names, order, keyword-only and variadic parts) — read from the reference sources with ast; skipped where the reference
+    tree is not present (the GPU box)."""
+    import ast
+    import inspect
+    import os
+    import sys
+
+    root = "/root/reference/src/xclim"
+    if not os.path.isdir(root):
+        pytest.skip("reference tree not present")
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__)))
+    import fakexr
+    from xclim_amd.xr_adapter import make_wrappers
+
+    wrappers = make_wrappers(fakexr.make_env(), orig={}, device=None)
+    where = {"indices/generic.py": ("threshold_count", "count_occurrences", "domain_count", "select_resample_op",
+                                    "spell_length_statistics", "cumulative_difference", "compare", "season",
+                                    "first_day_threshold_reached", "bivariate_count_occurrences"),
+             "core/calendar.py": ("percentile_doy", "resample_doy"),
+             "indices/run_length.py": ("rle", "rle_statistics", "longest_run", "windowed_run_events", "windowed_run_count",
+                                       "first_run", "last_run", "season_length", "resample_and_rl"),
+             "core/utils.py": ("calc_perc",)}
+    P = inspect.Parameter
+    checked = 0
+    for rel, names in where.items():
+        tree = ast.parse(open(os.path.join(root, rel)).read())
+        defs = {n.name: n.args for n in tree.body if isinstance(n, ast.FunctionDef)}
+        for name in names:
+            a = defs[name]
+            ref = ([x.arg for x in a.posonlyargs + a.args], [x.arg for x in a.kwonlyargs], a.vararg.arg if a.vararg else None,
+                   a.kwarg.arg if a.kwarg else None)
+            sig = inspect.signature(wrappers[name])  # (follows __wrapped__ to the wrapper's own function)
+            ps = list(sig.parameters.values())
+            ours = ([p.name for p in ps if p.kind in (P.POSITIONAL_ONLY, P.POSITIONAL_OR_KEYWORD)],
+                    [p.name for p in ps if p.kind == P.KEYWORD_ONLY],
+                    next((p.name for p in ps if p.kind == P.VAR_POSITIONAL), None),
+                    next((p.name for p in ps if p.kind == P.VAR_KEYWORD), None))
+            assert ours == ref, (name, ours, ref)
+            checked += 1
+    assert checked == 22

@@ -402,7 +402,6 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         out.attrs.update(climatology_bounds=bounds, window=window, alpha=alpha, beta=beta)
         return out
 
-    percentile_doy.__wrapped__ = percentile_doy  # bootstrap_func calls percentile_doy.__wrapped__ (bootstrapping.py:195)
 
     def resample_doy(doy, arr):  # cal:763-790
         if not isinstance(doy, DA) or "dayofyear" not in doy.dims or "percentiles" in doy.dims or "time" not in arr.dims:
@@ -559,9 +558,8 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
             except Float64FieldError:
                 return fallback(name, *args, **kwargs)
 
-        for attr in ("__wrapped__",):
-            if hasattr(fn, attr):
-                setattr(wrapper, attr, wrapper)
+        # functools.wraps leaves wrapper.__wrapped__ = fn: what bootstrap_func calls as percentile_doy.__wrapped__
+        # (bootstrapping.py:195) — a plain function with the reference's signature, no loop for inspect.unwrap
         return wrapper
 
     table = {
