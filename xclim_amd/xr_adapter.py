@@ -281,7 +281,9 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         return wrap_periods(a, np.asarray(out).astype(np.int64), freq)
 
     def select_resample_op(da, op, freq="YS", out_units=None, **indexer):  # gen:83-125
-        if not isinstance(op, str):
+        # callables and the names gen:221 maps to callables (doymin / doymax: resample_map of a DataArray function) stay with
+        # the reference
+        if not isinstance(op, str) or op not in ("min", "max", "mean", "std", "var", "count", "sum", "integral", "argmax", "argmin"):
             return fallback("select_resample_op", da, op, freq, out_units, **indexer)
         a, x = _tfirst(da)
         out, valid = hgen.select_resample_op(x, op, time_axis_of(a), freq, device=dev(), with_valid=True, **indexer)
