@@ -7,7 +7,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out/prof_r03; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B=$GRAFT_REPO_ROOT/bench.py
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python $B --no-cpu > $O/stats.log 2>&1
-tail -1 $O/stats.log > $O/bench_line_under_rocprof.json
+grep -h "^{\"metric\"" $O/stats.log | tail -1 > $O/bench_line_under_rocprof.json
 SMALL="python $B --steps 5 --warmup 1 --no-cpu --no-full"
 FULL="python $B --steps 2 --warmup 1 --no-cpu"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/small/pmc_fetch -o f -- $SMALL > $O/small_fetch.log 2>&1
