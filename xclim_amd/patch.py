@@ -140,6 +140,9 @@ def install(env=None, modules=None) -> list[str]:
         for name in _BY_NAME[modname]:
             if mod is not None and hasattr(mod, name):
                 orig.setdefault(name, _saved.get((modname, name), getattr(mod, name)))
+    nbu = resolve("xsdba.nbutils")
+    if nbu is not None and hasattr(nbu, "quantile"):  # the original behind the wrapper's forwards (other dims, float64 fields)
+        orig["sdba_quantile"] = _saved.get(("xsdba.nbutils", "quantile"), nbu.quantile)
     wrappers = make_wrappers(env, orig)
     wrappers["_cumsum_reset_np"] = cumsum_reset_np
     done = []
