@@ -33,6 +33,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s best measured copy)
 
 
+# untimed steps before the W warm-up steps of the contract: the first steps after a process start (or after the box sat
+# idle) ran up to 40 % slower on one of ~10 boxes of the pool; they are not part of the measurement either way
+WAKEUP_STEPS = 30
+
 PMC_TABLES = ("profiles/r03/pmc_hbm_traffic.json", "profiles/r02/pmc_hbm_traffic.json")
 
 
@@ -225,7 +229,7 @@ def main():
             comm.sync()
             comm.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(WAKEUP_STEPS + args.warmup):  # (clocks / caches / pools settle; all untimed)
         step()
     fence()
     t0 = time.perf_counter()
@@ -296,7 +300,7 @@ def main():
             "data": "mock (no GPU: plumbing test, the numbers mean nothing)" if mock else "synthetic",
             "config": {"workload": f"tx90p (percentile_doy window 5 per 90 + threshold_count > + MissingAny) on {T}x{Y}x{X} fp32 "
                                    f"per GPU, noleap, freq YS, time-major, resident in HBM",
-                       "grid_per_gpu": [T, Y, X], "sharding": ("lat slabs, one per rank; RCCL (xh_comm_allgather, C ABI) all_gather of (P,C) fp64" + (", overlapped with the next step" if overlap else ""))
+                       "grid_per_gpu": [T, Y, X], "untimed_wakeup_steps": WAKEUP_STEPS, "sharding": ("lat slabs, one per rank; RCCL (xh_comm_allgather, C ABI) all_gather of (P,C) fp64" + (", overlapped with the next step" if overlap else ""))
                        if getattr(comm, "kind", "rccl") != "file" else f"lat slabs, one per rank; NO exchange (RCCL unavailable: {comm.reason})"},
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -357,7 +361,7 @@ def bench_config5(args, dev, K, comm, world, rank):
             comm.sync()
             comm.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(WAKEUP_STEPS + args.warmup):  # (clocks / caches / pools settle; all untimed)
         step()
     fence()
     t0 = time.perf_counter()
