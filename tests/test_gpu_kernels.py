@@ -141,7 +141,8 @@ def test_threshold_count_doy_tile_kernel_empty_periods_and_narrow_counters(dev, 
     x = _field(rng, T, C, nan_frac=0.01)
     table = 288 + rng.normal(0, 4, (366, C))
     tidx = (np.arange(T) % 366).astype(np.int32)
-    for seg in (np.array([0, 200, 200, 200, 431, 600, 855, 1000, 1000, 1255, T - 7], dtype=np.int64),     # narrow, gaps at both ends
+    for seg in (np.array([1455, 1488], dtype=np.int64),   # ONE short period inside the 256 rows a batch spans, no period around it
+                np.array([0, 200, 200, 200, 431, 600, 855, 1000, 1000, 1255, T - 7], dtype=np.int64),     # narrow, gaps at both ends
                 np.array([3, 403, 500, 900, 1300, 1300, 1700, 2100, 2500, 2900, 3300, 3700, T], dtype=np.int64)):  # a 400-step period
         hit = x.astype(np.float64) <= table[tidx]
         ok = ~np.isnan(x)

@@ -109,8 +109,13 @@ k_tc_doy(const float* __restrict__ x, int T, int64_t C, int64_t st, const double
       uint32_t h[TC_U];
 #pragma unroll
       for (int u = 0; u < TC_U; ++u) h[u] = (tc_cmp<OP>(v[u], thr[u]) ? 1u : 0u) + (v[u] == v[u] ? VONE : 0u);
-      // rows ascend with u, periods with rows: first and last in the current period = all of them (wave-uniform test)
-      if ((m[0] >> 16) == cur && (m[TC_U - 1] >> 16) == cur) {
+      // all 16 rows in the current period (wave-uniform, scalar xor / or of the 16 words).  Testing only the first and the
+      // last row is not enough: rows before the first and after the last period share one dummy period, and a period
+      // shorter than the 256 rows a batch spans can lie between two of them.
+      uint32_t pdiff = 0u;
+#pragma unroll
+      for (int u = 1; u < TC_U; ++u) pdiff |= m[u] ^ m[0];
+      if ((pdiff >> 16) == 0u && (m[0] >> 16) == cur) {
         uint32_t sum = 0u;
 #pragma unroll
         for (int u = 0; u < TC_U; ++u) sum += h[u];
