@@ -1214,7 +1214,7 @@ def test_consecutive_day_indices_reference_known_answers(dev):
 
 @pytest.mark.parametrize("kind", ["+", "*"])
 @pytest.mark.parametrize("interp", ["nearest", "linear"])
-@pytest.mark.parametrize("T,cells", [(365, (7, 9)), (800, (33,)), (3000, (5,)), (10950, (3,)), (50, (4, 4)), (1, (3,))])
+@pytest.mark.parametrize("T,cells", [(365, (7, 9)), (800, (33,)), (3000, (5,)), (10950, (3,)), (50, (4, 4)), (1, (3,)), (20000, (2,)), (32768, (2,))])
 def test_qdm_adjust_matches_oracle(dev, rng, kind, interp, T, cells):
     """QuantileDeltaMapping.adjust == rank(pct) + interp_on_quantiles + apply_correction of the oracle (scipy rankdata /
     interp1d), every kernel variant (T 1 .. 10950), NaN samples, tied samples, both extrapolations.  Parity unpinned."""

@@ -274,7 +274,8 @@ int xh_qdm_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, in
   if (T <= 4096) XH_QDM(256, 16, 1024);
   if (T <= 8192) XH_QDM(512, 16, 2048);
   if (T <= 12288) XH_QDM(512, 24, 2048);
-  XH_QDM(512, 32, 2048);
+  if (T <= 16384) XH_QDM(512, 32, 2048);
+  XH_QDM(512, 64, 2048);  // up to 32768 steps (~90 years of daily data): 144 KB of LDS, one workgroup per CU
 #undef XH_QDM
 }
 
@@ -283,8 +284,8 @@ extern "C" {
 int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const float* af,
                   const double* q, int nq, int kind, int interp, int extrap, float* scen) {
   XH_REQUIRE(ctx && sim && af && q && scen, XH_ERR_ARG, "xh_qdm_adjust: NULL argument");
-  XH_REQUIRE(T >= 1 && T <= 16384 && C >= 0 && nq >= 1 && nq <= QDM_MAXQ, XH_ERR_ARG,
-             "xh_qdm_adjust: bad shape (1 <= T <= 16384, 1 <= nq <= 64)");
+  XH_REQUIRE(T >= 1 && T <= 32768 && C >= 0 && nq >= 1 && nq <= QDM_MAXQ, XH_ERR_ARG,
+             "xh_qdm_adjust: bad shape (1 <= T <= 32768, 1 <= nq <= 64)");
   XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "xh_qdm_adjust: kind must be 0 (+) or 1 (*)");
   XH_REQUIRE(interp == 0 || interp == 1, XH_ERR_NOTIMPL, "xh_qdm_adjust: interp must be 0 (nearest) or 1 (linear)");
   XH_REQUIRE(extrap == 0 || extrap == 1, XH_ERR_ARG, "xh_qdm_adjust: extrap must be 0 (constant) or 1 (nan)");

@@ -230,8 +230,8 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
     inside each group's own time steps (xsdba: ``group.apply(rank, sim, main_only=True)`` — the window only widens the
     TRAINING sample) and every step uses the factors of its group (``interp="nearest"`` only, see the module docstring).
 
-    Limits: a ranked series (the whole sim series for ``group="time"``, one group's steps otherwise) holds at most 16384
-    steps (``xh_qdm_adjust`` keeps a column's keys in the registers of one workgroup; about 45 years of daily data —
+    Limits: a ranked series (the whole sim series for ``group="time"``, one group's steps otherwise) holds at most 32768
+    steps (``xh_qdm_adjust`` keeps a column's keys in the registers of one workgroup; about 90 years of daily data —
     longer series raise ``ValueError``, rank them per period or use a sub-grouping).  -0.0 and +0.0 tie, as in
     ``scipy.stats.rankdata``."""
 
