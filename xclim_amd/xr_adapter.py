@@ -252,6 +252,17 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
             return thr
         return None
 
+    def plain_scalar(thr, x):
+        """True when `thr` compares with the field `x` in x's own dtype under NumPy's promotion rules: a python number (weak
+        scalar) or a numpy scalar that casts safely to x.dtype.  A 0-d float64 DataArray against a float32 field is a
+        float64 compare in the reference (0-d arrays are not weak): the kernels that only compare in the field's dtype leave
+        such calls to the original function."""
+        if np.ndim(thr) != 0:
+            return False
+        if isinstance(thr, np.generic):
+            return np.can_cast(thr.dtype, x.dtype, "safe")
+        return isinstance(thr, (int, float))
+
     # ---- indices/generic.py ---------------------------------------------------------------------------------------
     def threshold_count(da, op, threshold, freq, constrain=None):  # gen:329-361
         if isinstance(threshold, LazyCompare) or not isinstance(da, DA):
@@ -277,6 +288,8 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         if np.ndim(low) != 0 or np.ndim(high) != 0 or isinstance(low, DA) or isinstance(high, DA):
             return fallback("domain_count", da, low, high, freq)
         a, x = _tfirst(da)
+        if not plain_scalar(low, x) or not plain_scalar(high, x):
+            return fallback("domain_count", da, low, high, freq)
         out = hgen.domain_count(x, low, high, time_axis_of(a), freq, device=dev())
         return wrap_periods(a, np.asarray(out).astype(np.int64), freq)
 
@@ -298,7 +311,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
                             min_gap=min_gap, resample_before_rl=resample_before_rl, **indexer)
         a, x = _tfirst(data)
         thr = as_threshold(env.convert_units_to(threshold, data, context="infer"), a)
-        if thr is None or isinstance(thr, hcal.DoyPercentile):
+        if thr is None or isinstance(thr, hcal.DoyPercentile) or (np.ndim(thr) == 0 and not plain_scalar(thr, x)):
             return fallback("spell_length_statistics", data, threshold, window, win_reducer, op, spell_reducer, freq,
                             min_gap=min_gap, resample_before_rl=resample_before_rl, **indexer)
         reducers = [spell_reducer] if isinstance(spell_reducer, str) else list(spell_reducer)
@@ -321,7 +334,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
             return fallback("cumulative_difference", data, threshold, op, freq)
         a, x = _tfirst(data)
         thr = as_threshold(env.convert_units_to(threshold, data), a)
-        if thr is None or np.ndim(thr) != 0:
+        if thr is None or not plain_scalar(thr, x):
             return fallback("cumulative_difference", data, threshold, op, freq)
         out = hgen.cumulative_difference(x, float(thr), op, time_axis_of(a), freq, device=dev())
         return env.to_agg_units(wrap_periods(a, out, freq, data.attrs), data, op="integral")
@@ -337,7 +350,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         b, x2 = _tfirst(data_var2)
         t1 = as_threshold(env.convert_units_to(threshold_var1, data_var1), a)
         t2 = as_threshold(env.convert_units_to(threshold_var2, data_var2), b)
-        if t1 is None or t2 is None or np.ndim(t1) != 0 or np.ndim(t2) != 0 or x1.shape != x2.shape:
+        if t1 is None or t2 is None or not plain_scalar(t1, x1) or not plain_scalar(t2, x2) or x1.shape != x2.shape:
             return fallback("bivariate_count_occurrences", **kw)
         out = hgen.bivariate_count_occurrences(data_var1=x1, data_var2=x2, threshold_var1=float(t1), threshold_var2=float(t2),
                                                time=time_axis_of(a), freq=freq, op_var1=op_var1, op_var2=op_var2,
@@ -348,7 +361,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     def season(data, thresh, window, op, stat, freq, mid_date=None, constrain=None):  # gen:770-853
         a, x = _tfirst(data)
         thr = as_threshold(env.convert_units_to(thresh, data, context="infer"), a)
-        if thr is None or np.ndim(thr) != 0 or stat not in ("start", "end", "length"):
+        if thr is None or not plain_scalar(thr, x) or stat not in ("start", "end", "length"):
             return fallback("season", data, thresh, window, op, stat, freq, mid_date=mid_date, constrain=constrain)
         hgen.get_op(op, constrain)
         res = hgen.season(x, float(thr), window, op, time_axis_of(a), freq, mid_date, device=dev())[stat]
@@ -361,7 +374,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     def first_day_threshold_reached(data, *, threshold, op, after_date, window=1, freq="YS", constrain=None):  # gen:1556-1608
         a, x = _tfirst(data)
         thr = as_threshold(env.convert_units_to(threshold, data), a)
-        if thr is None or np.ndim(thr) != 0:
+        if thr is None or not plain_scalar(thr, x):
             return fallback("first_day_threshold_reached", data, threshold=threshold, op=op, after_date=after_date, window=window,
                             freq=freq, constrain=constrain)
         res = hgen.first_day_threshold_reached(x, threshold=float(thr), op=op, after_date=after_date, time=time_axis_of(a),
