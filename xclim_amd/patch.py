@@ -111,7 +111,8 @@ def real_env():
             out.attrs.update(pint2cfattrs(units2pint(out.attrs["units"]), is_difference=True))
         return to_agg_units(out, da, op)
 
-    return Env(xr.DataArray, convert_units_to, to_agg_units, finish_select_resample_op, build_climatology_bounds)
+    return Env(xr.DataArray, convert_units_to, to_agg_units, finish_select_resample_op, build_climatology_bounds,
+               difference_attrs=lambda u: pint2cfattrs(units2pint(u), is_difference=True))
 
 
 def install(env=None, modules=None) -> list[str]:

@@ -59,7 +59,8 @@ class Env:
     aggregation; ``finish_select_resample_op(out, da, op, out_units)`` = the tail of gen:118-125."""
 
     def __init__(self, DataArray, convert_units_to, to_agg_units, finish_select_resample_op=None,
-                 build_climatology_bounds=None):
+                 build_climatology_bounds=None, difference_attrs=None):
+        self.difference_attrs = difference_attrs  # units string -> CF attrs of a DIFFERENCE in these units (gen:1550)
         self.DataArray = DataArray
         self.convert_units_to = convert_units_to
         self.to_agg_units = to_agg_units
@@ -336,8 +337,10 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         thr = as_threshold(env.convert_units_to(threshold, data), a)
         if thr is None or not plain_scalar(thr, x):
             return fallback("cumulative_difference", data, threshold, op, freq)
-        out = hgen.cumulative_difference(x, float(thr), op, time_axis_of(a), freq, device=dev())
-        return env.to_agg_units(wrap_periods(a, out, freq, data.attrs), data, op="integral")
+        out = wrap_periods(a, hgen.cumulative_difference(x, float(thr), op, time_axis_of(a), freq, device=dev()), freq, data.attrs)
+        if env.difference_attrs is not None and "units" in data.attrs:  # a sum of differences: delta units (gen:1550)
+            out.attrs.update(env.difference_attrs(data.attrs["units"]))
+        return env.to_agg_units(out, data, op="integral")
 
     def bivariate_count_occurrences(*, data_var1, data_var2, threshold_var1, threshold_var2, freq, op_var1, op_var2,
                                     var_reducer, constrain_var1=None, constrain_var2=None):  # gen:1003-1073
