@@ -46,6 +46,11 @@ def _temp(rng, T, shape, nan_frac=0.0):
     return x
 
 
+def _tf(o):
+    """values of a result with time first (the wrappers return the dimension order of their input, as xarray does)"""
+    return o.transpose("time", ...).values if "time" in o.dims else o.values
+
+
 def _calls(trace, name):
     return [a for n, a in trace if n == name]
 
@@ -76,8 +81,8 @@ def test_tx90p_through_the_wrappers_reaches_the_doy_table_kernel(ref, dev, rng):
     out = mods["xclim.indices._multivariate"].tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
     dev.stop_trace()
     exp = oidx.tx90p(x, p_o[..., 0], doys, ot, "YS")
-    assert out.dims == ("time", "lat", "lon") and out.dtype == np.int64 and out.attrs["units"] == "days"
-    np.testing.assert_array_equal(out.values, exp)
+    assert out.dims == ("lat", "time", "lon") and out.dtype == np.int64 and out.attrs["units"] == "days"   # the input's order
+    np.testing.assert_array_equal(_tf(out), exp)
     tc = _calls(trace, "xh_threshold_count_doy")             # the per-doy fp64 table form (XH_THR_DOY_F64), gathered in the kernel
     assert len(tc) == 1 and tc[0][8] == per.shape[0] and not _calls(trace, "xh_threshold_count")
     assert not _calls(trace, "xh_doy_broadcast")              # the (T, Y, X) float64 threshold was never formed
@@ -153,28 +158,28 @@ def test_generic_wrappers_vs_oracle(ref, dev, rng, dims):
     order = da.transpose("time", ...).dims                        # results: time first, the other dims in their own order
     x = np.ascontiguousarray(np.transpose(x, [("time", "lat", "lon").index(d) for d in order]))
     out = gen.threshold_count(da, ">", 290.0, "MS")
-    assert out.dims == order
-    np.testing.assert_array_equal(out.values, ogen.threshold_count(x, ">", 290.0, ot, "MS"))
+    assert out.dims == dims                                      # the input's order, as xarray's resample gives
+    np.testing.assert_array_equal(_tf(out), ogen.threshold_count(x, ">", 290.0, ot, "MS"))
     cell = fakexr.DataArray(np.float32(285) + rng.random((4, 3)).astype(np.float32) * 8, dims=("lon", "lat"))  # per-cell threshold
-    np.testing.assert_array_equal(gen.threshold_count(da, "<", cell, "YS").values,
+    np.testing.assert_array_equal(_tf(gen.threshold_count(da, "<", cell, "YS")),
                                   ogen.threshold_count(x, "<", cell.transpose(*order[1:]).values[None], ot, "YS"))
-    np.testing.assert_array_equal(gen.count_occurrences(da, 290.0, "QS-DEC", "!=").values, ogen.count_occurrences(x, 290.0, "!=", ot, "QS-DEC"))
-    np.testing.assert_array_equal(gen.domain_count(da, 280.0, 295.0, "YS").values, ogen.domain_count(x, 280.0, 295.0, ot, "YS"))
+    np.testing.assert_array_equal(_tf(gen.count_occurrences(da, 290.0, "QS-DEC", "!=")), ogen.count_occurrences(x, 290.0, "!=", ot, "QS-DEC"))
+    np.testing.assert_array_equal(_tf(gen.domain_count(da, 280.0, 295.0, "YS")), ogen.domain_count(x, 280.0, 295.0, ot, "YS"))
     for op in ("mean", "max", "std", "count", "argmax"):
-        np.testing.assert_allclose(gen.select_resample_op(da, op, "MS").values, ogen.select_resample_op(x, op, ot, "MS"), rtol=1e-6, equal_nan=True)
-    np.testing.assert_allclose(gen.cumulative_difference(da, 283.0, ">", "YS").values, ogen.cumulative_difference(x, 283.0, ">", ot, "YS"), rtol=1e-6)
-    np.testing.assert_array_equal(gen.compare(da, ">=", 290.0).values, x >= np.float32(290.0))  # (time first, like every result)
+        np.testing.assert_allclose(_tf(gen.select_resample_op(da, op, "MS")), ogen.select_resample_op(x, op, ot, "MS"), rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(_tf(gen.cumulative_difference(da, 283.0, ">", "YS")), ogen.cumulative_difference(x, 283.0, ">", ot, "YS"), rtol=1e-6)
+    np.testing.assert_array_equal(_tf(gen.compare(da, ">=", 290.0)), x >= np.float32(290.0))  # (time first, like every result)
     with pytest.raises(ValueError, match="not permitted"):
         gen.threshold_count(da, "==", 290.0, "YS")
     with pytest.raises(AssertionError, match="was reached"):   # a callable op is FORWARDED to the reference's function
         gen.select_resample_op(da, np.nanmax, "YS")
     # the index bodies of the stand-in modules (by-name imports) on the same field
     th = mods["xclim.indices._threshold"]
-    np.testing.assert_array_equal(th.frost_days(da, 283.15, "YS").values, ogen.threshold_count(x, "<", 283.15, ot, "YS"))
-    np.testing.assert_allclose(th.growing_degree_days(da, 283.0, "YS").values, ogen.cumulative_difference(x, 283.0, ">", ot, "YS"), rtol=1e-6)
-    np.testing.assert_allclose(mods["xclim.indices._simple"].tg_mean(da, "YS").values, ogen.select_resample_op(x, "mean", ot, "YS"), rtol=1e-6, equal_nan=True)
+    np.testing.assert_array_equal(_tf(th.frost_days(da, 283.15, "YS")), ogen.threshold_count(x, "<", 283.15, ot, "YS"))
+    np.testing.assert_allclose(_tf(th.growing_degree_days(da, 283.0, "YS")), ogen.cumulative_difference(x, 283.0, ">", ot, "YS"), rtol=1e-6)
+    np.testing.assert_allclose(_tf(mods["xclim.indices._simple"].tg_mean(da, "YS")), ogen.select_resample_op(x, "mean", ot, "YS"), rtol=1e-6, equal_nan=True)
     exp = oidx.run_index(x, ">", 292.0, "events", 3, ot, "YS")
-    np.testing.assert_array_equal(th.hot_spell_frequency(da, 292.0, 3, "YS").values, exp)
+    np.testing.assert_array_equal(_tf(th.hot_spell_frequency(da, 292.0, 3, "YS")), exp)
 
 
 def test_run_length_wrappers_vs_oracle(ref, dev, rng):
@@ -185,18 +190,18 @@ def test_run_length_wrappers_vs_oracle(ref, dev, rng):
     m = (rng.random((T, 96, 100)) < 0.6)                          # > 9000 cells: the N-D semantics of the reference
     da = fakexr.field(np.ascontiguousarray(np.moveaxis(m, 0, -1)), ta, dims=("lat", "lon", "time"))
     mf = m.astype(np.float32)
-    np.testing.assert_array_equal(rl.rle_statistics(da, "max", 2).values, orl.rle_statistics(mf, "max", 2))
-    np.testing.assert_array_equal(rl.rle_statistics(da, "sum", 3, freq="YS").values, orl.rle_statistics(mf, "sum", 3, ot, "YS"))
-    np.testing.assert_array_equal(rl.longest_run(da, freq="YS").values, orl.longest_run(mf, ot, "YS"))
-    np.testing.assert_array_equal(rl.windowed_run_count(da, 3).values, orl.windowed_run_count(mf, 3))
-    np.testing.assert_array_equal(rl.windowed_run_events(da, 2, freq="MS").values, orl.windowed_run_events(mf, 2, ot, "MS"))
-    np.testing.assert_array_equal(rl.first_run(da, 4).values, orl.first_run(mf, 4))
+    np.testing.assert_array_equal(_tf(rl.rle_statistics(da, "max", 2)), orl.rle_statistics(mf, "max", 2))
+    np.testing.assert_array_equal(_tf(rl.rle_statistics(da, "sum", 3, freq="YS")), orl.rle_statistics(mf, "sum", 3, ot, "YS"))
+    np.testing.assert_array_equal(_tf(rl.longest_run(da, freq="YS")), orl.longest_run(mf, ot, "YS"))
+    np.testing.assert_array_equal(_tf(rl.windowed_run_count(da, 3)), orl.windowed_run_count(mf, 3))
+    np.testing.assert_array_equal(_tf(rl.windowed_run_events(da, 2, freq="MS")), orl.windowed_run_events(mf, 2, ot, "MS"))
+    np.testing.assert_array_equal(_tf(rl.first_run(da, 4)), orl.first_run(mf, 4))
     idx = orl.last_run(mf, 4)
-    np.testing.assert_array_equal(rl.last_run(da, 4, coord="dayofyear").values,
+    np.testing.assert_array_equal(_tf(rl.last_run(da, 4, coord="dayofyear")),
                                   np.where(np.isnan(idx), np.nan, ot.doy[np.nan_to_num(idx).astype(int)]))
-    np.testing.assert_array_equal(rl.rle(da).values, orl.rle(mf))
+    np.testing.assert_array_equal(_tf(rl.rle(da)), orl.rle(mf))
     out = rl.resample_and_rl(da, True, rl.rle_statistics, reducer="max", window=1, freq="YS")
-    np.testing.assert_array_equal(out.values, orl.resample_and_rl(mf, True, orl.rle_statistics, "max", 1, time=ot, freq="YS"))
+    np.testing.assert_array_equal(_tf(out), orl.resample_and_rl(mf, True, orl.rle_statistics, "max", 1, time=ot, freq="YS"))
     with pytest.raises(AssertionError, match="was reached"):   # other dims than time are the reference's business
         rl.longest_run(da, dim="lat")
 

@@ -569,10 +569,25 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         wrappers never round an input behind the caller's back."""
         import functools
 
+        def restore_order(out, args, kwargs):
+            """xarray's resample / groupby reductions and element-wise results keep the dimension ORDER of their input
+            (GroupBy._restore_dim_order); the wrappers work time-first.  A result with the same dimensions as the first
+            DataArray argument that has a time dimension is put back into that argument's order."""
+            src = next((v for v in list(args) + list(kwargs.values()) if isinstance(v, DA) and "time" in v.dims), None)
+            if src is None:
+                return out
+
+            def fix(o):
+                if isinstance(o, DA) and set(o.dims) == set(src.dims) and tuple(o.dims) != tuple(src.dims):
+                    return o.transpose(*src.dims)
+                return o
+
+            return tuple(fix(o) for o in out) if isinstance(out, tuple) else fix(out)
+
         @functools.wraps(fn)
         def wrapper(*args, **kwargs):
             try:
-                return fn(*args, **kwargs)
+                return restore_order(fn(*args, **kwargs), args, kwargs)
             except Float64FieldError:
                 return fallback(name, *args, **kwargs)
 
