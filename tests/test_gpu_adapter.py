@@ -74,9 +74,9 @@ def test_tx90p_through_the_wrappers_reaches_the_doy_table_kernel(ref, dev, rng):
     x = _temp(rng, T, (4, 5), nan_frac=0.001)
     tasmax = fakexr.field(np.ascontiguousarray(np.moveaxis(x, 0, 1)), ta, dims=("lat", "time", "lon"))  # time NOT first
     per = mods["xclim.core.calendar"].percentile_doy(tasmax, window=5, per=90.0)
-    assert per.dims == ("dayofyear", "lat", "lon", "percentiles") and per.dtype == np.float64 and per.attrs["window"] == 5
+    assert per.dims == ("lat", "lon", "dayofyear", "percentiles") and per.dtype == np.float64 and per.attrs["window"] == 5  # cal:448-480
     p_o, doys = ocal.percentile_doy(x, ot, 5, 90.0)
-    np.testing.assert_allclose(per.values[..., 0], p_o[..., 0], rtol=1e-12)
+    np.testing.assert_allclose(per.transpose("dayofyear", "lat", "lon", "percentiles").values[..., 0], p_o[..., 0], rtol=1e-12)
     trace = dev.start_trace()
     out = mods["xclim.indices._multivariate"].tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
     dev.stop_trace()
@@ -84,7 +84,7 @@ def test_tx90p_through_the_wrappers_reaches_the_doy_table_kernel(ref, dev, rng):
     assert out.dims == ("lat", "time", "lon") and out.dtype == np.int64 and out.attrs["units"] == "days"   # the input's order
     np.testing.assert_array_equal(_tf(out), exp)
     tc = _calls(trace, "xh_threshold_count_doy")             # the per-doy fp64 table form (XH_THR_DOY_F64), gathered in the kernel
-    assert len(tc) == 1 and tc[0][8] == per.shape[0] and not _calls(trace, "xh_threshold_count")
+    assert len(tc) == 1 and tc[0][8] == len(doys) and not _calls(trace, "xh_threshold_count")
     assert not _calls(trace, "xh_doy_broadcast")              # the (T, Y, X) float64 threshold was never formed
 
 

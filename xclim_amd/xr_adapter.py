@@ -416,6 +416,9 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         coords.update(dayofyear=np.asarray(p.dayofyear), percentiles=np.asarray(pers, dtype=np.float64))
         out = DA(p.values(), coords=coords, dims=("dayofyear",) + _cell_dims(a) + ("percentiles",), attrs=dict(arr.attrs),
                  name="per")
+        # the reference's order: unstack("time") appends (year, dayofyear) after the cell dimensions, apply_ufunc appends
+        # the percentile dimension (cal:448-480) -> (*cells, dayofyear, percentiles)
+        out = out.transpose(*(_cell_dims(a) + ("dayofyear", "percentiles")))
         bounds = env.build_climatology_bounds(arr) if env.build_climatology_bounds else p.attrs["climatology_bounds"]
         out.attrs.update(climatology_bounds=bounds, window=window, alpha=alpha, beta=beta)
         return out
