@@ -466,7 +466,8 @@ int xh_eqm_train(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, in
                  const double* q /* host */, int nq, int kind, float* af, float* hist_q);
 /* qm_adjust: af_t = interp_on_quantiles(sim, hist_q, af) (interp 0 nearest, 1 linear, 2 cubic [not-a-knot spline as
  * scipy interp1d(kind="cubic"), nq <= 32, >= 4 valid nodes per cell else NaN]; extrap 0 constant,
- * 1 nan); scen = sim + af_t (kind 0) or sim * af_t (kind 1).  scen (T, C) row stride scen_st. */
+ * 1 nan); scen = sim + af_t (kind 0) or sim * af_t (kind 1); kind 2: scen = af_t, the interpolated factor itself
+ * (what xsdba.utils.interp_on_quantiles returns for group="time").  scen (T, C) row stride scen_st. */
 int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const float* af,
                   const float* hist_q, int nq, int kind, int interp, int extrap, float* scen, int64_t scen_st);
 /* QuantileDeltaMapping.adjust (xsdba._adjustment.qdm_adjust, group "time"): sim_q = rank(sim, pct=True) along time

@@ -262,4 +262,17 @@ def make_reference_like_modules(env):
 
     sp.tg_mean = tg_mean
     mods[sp.__name__] = sp
+
+    su = types.ModuleType("xsdba.utils")
+    su.interp_on_quantiles = stub("interp_on_quantiles")
+    mods[su.__name__] = su
+    sa = types.ModuleType("xsdba._adjustment")
+    sa.u = su
+
+    def qm_adjust(sim, af, hist_q, kind="+", interp="nearest", extrapolation="constant"):  # xsdba._adjustment.qm_adjust, group="time"
+        af_t = sa.u.interp_on_quantiles(sim, hist_q, af, group="time", method=interp, extrapolation=extrapolation)
+        return sim._bin(af_t, np.add if kind == "+" else np.multiply)              # utils.apply_correction
+
+    sa.qm_adjust = qm_adjust
+    mods[sa.__name__] = sa
     return mods

@@ -338,3 +338,31 @@ def test_bivariate_count_occurrences_through_the_wrappers(ref, dev, rng):
     exp = np.stack([cond[idx].sum(axis=0) for _, idx in orl.groups(ot, "MS")])
     np.testing.assert_array_equal(out.values, exp)
     assert out.dims == ("time", "lat", "lon") and out.attrs["units"] == "days" and exp.sum() > 0
+
+
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic"])
+def test_xsdba_interp_on_quantiles_through_the_wrappers(ref, dev, rng, interp):
+    """xsdba._adjustment.qm_adjust reaches the factor interpolation as ``u.interp_on_quantiles`` (module attribute):
+    group="time" -> xh_eqm_adjust with kind "factor"; the corrected series equals the oracle's eqm_adjust; a sub-grouping
+    is forwarded to the original."""
+    env, mods, names = ref
+    assert "xsdba.utils.interp_on_quantiles" in names
+    T, cells, nq = 500, (4, 5), 15
+    ta = TimeAxis.daily("2001-01-01", T, "noleap")
+    sim = _temp(rng, T, cells, 0.01)
+    hq = np.sort(rng.normal(288, 9, (nq,) + cells), axis=0).astype(np.float32)
+    af = rng.normal(1.0, 0.3, (nq,) + cells).astype(np.float32)
+    af[3, 0, 0] = np.nan
+    d_sim = fakexr.field(sim, ta)
+    qdim = fakexr.DataArray((np.arange(nq) + 0.5) / nq, dims=("quantiles",))
+    coords = {"quantiles": qdim, "lat": d_sim.coords["lat"], "lon": d_sim.coords["lon"]}
+    d_hq = fakexr.DataArray(hq, coords=coords, dims=("quantiles", "lat", "lon"))
+    d_af = fakexr.DataArray(np.moveaxis(af, 0, -1).copy(), coords=coords, dims=("lat", "lon", "quantiles"))   # another order
+    trace = dev.start_trace()
+    scen = mods["xsdba._adjustment"].qm_adjust(d_sim, d_af, d_hq, "+", interp, "constant")
+    dev.stop_trace()
+    assert len(_calls(trace, "xh_eqm_adjust")) == 1
+    exp = osdba.eqm_adjust(sim.reshape(T, -1), af.reshape(nq, -1), hq.reshape(nq, -1), "+", interp, "constant").reshape(sim.shape)
+    np.testing.assert_allclose(_tf(scen), exp, rtol=2e-6 if interp == "cubic" else 1e-6, equal_nan=True)
+    with pytest.raises(AssertionError, match="was reached"):
+        mods["xsdba.utils"].interp_on_quantiles(d_sim, d_hq, d_af, group="time.month", method=interp)

@@ -102,7 +102,7 @@ k_eqm_adjust(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, co
       if (below) a = extrap == 0 ? firsty : xh_nan32();
       if (above) a = extrap == 0 ? lasty : xh_nan32();
     }
-    scen[t * scen_st + c] = kind == 0 ? (x + a) : (x * a);
+    scen[t * scen_st + c] = kind == 0 ? (x + a) : (kind == 1 ? (x * a) : a);  // kind 2: the interpolated factor itself
   };
   int64_t t = ta;
   for (; t + 8 <= tb; t += 8) {
@@ -242,7 +242,7 @@ k_eqm_adjust_cubic(const float* __restrict__ sim, int64_t T, int64_t C, int64_t 
       if (xs > xlast) S = extrap == 0 ? ylast : xh_nan64();
       a = (float)S;
     }
-    scen[t * scen_st + c] = kind == 0 ? (xs + a) : (xs * a);
+    scen[t * scen_st + c] = kind == 0 ? (xs + a) : (kind == 1 ? (xs * a) : a);
   };
   int64_t t = ta;
   for (; t + 8 <= tb; t += 8) {  // 8 rows in flight per lane
@@ -358,7 +358,7 @@ int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   XH_REQUIRE(ctx && sim && af && hist_q && scen, XH_ERR_ARG, "xh_eqm_adjust: NULL argument");
   XH_REQUIRE(T >= 0 && C >= 0 && nq >= 1 && nq <= 64, XH_ERR_ARG, "xh_eqm_adjust: bad shape (1 <= nq <= 64)");
   XH_REQUIRE(sc == 1 && st >= C && scen_st >= C, XH_ERR_LAYOUT, "xh_eqm_adjust: needs time-major views (sc == 1)");
-  XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "xh_eqm_adjust: kind must be 0 (+) or 1 (*)");
+  XH_REQUIRE(kind >= 0 && kind <= 2, XH_ERR_ARG, "xh_eqm_adjust: kind must be 0 (+), 1 (*) or 2 (the interpolated factor only)");
   XH_REQUIRE(interp >= 0 && interp <= 2, XH_ERR_ARG, "xh_eqm_adjust: interp must be 0 (nearest), 1 (linear) or 2 (cubic)");
   XH_REQUIRE(extrap == 0 || extrap == 1, XH_ERR_ARG, "xh_eqm_adjust: extrap must be 0 (constant) or 1 (nan)");
   if (T == 0 || C == 0) return XH_OK;

@@ -574,7 +574,7 @@ def eqm_adjust(dev: Device, sim: DeviceArray, af: DeviceArray, hist_q: DeviceArr
     T, C_ = _tc(sim)
     nq = int(af.shape[0])
     scen = out if out is not None else dev.empty((T, C_), np.float32)
-    dev.call("xh_eqm_adjust", _vp(sim.ptr), T, C_, C_, 1, _vp(af.ptr), _vp(hist_q.ptr), nq, {"+": 0, "*": 1}[kind],
+    dev.call("xh_eqm_adjust", _vp(sim.ptr), T, C_, C_, 1, _vp(af.ptr), _vp(hist_q.ptr), nq, {"+": 0, "*": 1, "factor": 2}[kind],
              {"nearest": 0, "linear": 1, "cubic": 2}[interp], {"constant": 0, "nan": 1}[extrapolation], _vp(scen.ptr), C_)
     return scen
 

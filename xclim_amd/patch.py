@@ -144,6 +144,9 @@ def install(env=None, modules=None) -> list[str]:
     nbu = resolve("xsdba.nbutils")
     if nbu is not None and hasattr(nbu, "quantile"):  # the original behind the wrapper's forwards (other dims, float64 fields)
         orig["sdba_quantile"] = _saved.get(("xsdba.nbutils", "quantile"), nbu.quantile)
+    sut = resolve("xsdba.utils")
+    if sut is not None and hasattr(sut, "interp_on_quantiles"):
+        orig["sdba_interp_on_quantiles"] = _saved.get(("xsdba.utils", "interp_on_quantiles"), sut.interp_on_quantiles)
     wrappers = make_wrappers(env, orig)
     wrappers["_cumsum_reset_np"] = cumsum_reset_np
     done = []
@@ -172,6 +175,8 @@ def install(env=None, modules=None) -> list[str]:
     # xsdba (third party, re-exported by src/xclim/sdba.py:10): the per-cell multi-quantile entry point; xsdba's own
     # modules reach it through the module object (``nbu.quantile``), so the one attribute is enough
     patch("xsdba.nbutils", "quantile", wrappers["sdba_quantile"])
+    # qm_adjust / qdm_adjust reach the factor interpolation as ``u.interp_on_quantiles`` (module object): group="time" -> xh_eqm_adjust
+    patch("xsdba.utils", "interp_on_quantiles", wrappers["sdba_interp_on_quantiles"])
     _saved_modules.update({} if modules is None else modules)
     return done
 

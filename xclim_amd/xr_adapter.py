@@ -567,6 +567,45 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         return DA(np.moveaxis(np.asarray(out), 0, -1), coords=coords, dims=_cell_dims(a) + ("quantiles",), attrs=dict(da.attrs),
                   name=da.name)
 
+    def sdba_interp_on_quantiles(newx, xq, yq, *, group="time", method="linear", extrapolation="constant"):
+        """xsdba.utils.interp_on_quantiles for group="time" (no sub-grouping): the 1-D interpolation of the factors `yq`
+        given at the quantile values `xq`, evaluated at `newx`, per cell (scipy interp1d semantics on the non-NaN nodes,
+        constant or NaN extrapolation) -> xh_eqm_adjust with kind "factor".  Sub-groupings (the 2-D interpolation over
+        quantile and group) and anything unexpected go to the original."""
+        kw = dict(group=group, method=method, extrapolation=extrapolation)
+        prop = "group"
+        gdim = "time"
+        if isinstance(group, str):
+            if "." in group:
+                gdim, prop = group.split(".", 1)
+            else:
+                gdim = group
+        else:
+            gdim, prop = getattr(group, "dim", None), getattr(group, "prop", None)
+        if (prop != "group" or gdim != "time" or method not in ("nearest", "linear", "cubic")
+                or extrapolation not in ("constant", "nan") or not all(isinstance(v, DA) for v in (newx, xq, yq))):
+            return fallback("sdba_interp_on_quantiles", newx, xq, yq, **kw)
+        if "time" not in newx.dims or "quantiles" not in xq.dims or set(xq.dims) != set(yq.dims):
+            return fallback("sdba_interp_on_quantiles", newx, xq, yq, **kw)
+        a, x = _tfirst(newx)
+        cd = _cell_dims(a)
+        if set(xq.dims) != {"quantiles", *cd} or x.dtype != np.float32:
+            return fallback("sdba_interp_on_quantiles", newx, xq, yq, **kw)
+        from . import kernels as K_
+
+        d = dev()
+        hq = np.ascontiguousarray(xq.transpose("quantiles", *cd).values, dtype=np.float32)
+        af = np.ascontiguousarray(yq.transpose("quantiles", *cd).values, dtype=np.float32)
+        nq = hq.shape[0]
+        if nq > (32 if method == "cubic" else 64):
+            return fallback("sdba_interp_on_quantiles", newx, xq, yq, **kw)
+        T = x.shape[0]
+        out = K_.eqm_adjust(d, d.to_device(x.reshape(T, -1)), d.to_device(af.reshape(nq, -1)), d.to_device(hq.reshape(nq, -1)),
+                            "factor", method, extrapolation).get().reshape(x.shape)
+        coords = dict(_cell_coords(a))
+        coords["time"] = a["time"]
+        return DA(out.astype(yq.dtype, copy=False), coords=coords, dims=a.dims, attrs=dict(newx.attrs), name=newx.name)
+
     def forwarding(name, fn):
         """A float64 field on a float32-only kernel (Float64FieldError) goes to the reference's own function: the
         wrappers never round an input behind the caller's back."""
@@ -608,6 +647,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         "rle": rle, "rle_statistics": rle_statistics, "longest_run": longest_run, "windowed_run_events": windowed_run_events,
         "windowed_run_count": windowed_run_count, "first_run": first_run, "last_run": last_run, "season_length": season_length,
         "resample_and_rl": resample_and_rl, "calc_perc": calc_perc, "sdba_quantile": sdba_quantile,
+        "sdba_interp_on_quantiles": sdba_interp_on_quantiles,
         "MissingAny.__call__": missing_any_call,
     }
     out = {name: forwarding(name, fn) for name, fn in table.items()}
