@@ -36,7 +36,15 @@ while the file is absent):
       poly_trend                   (degree 0 / 1), utils.apply_correction / invert                   _scen_d{degree}
 
     NOT restated (refused by the product): adapt_freq, interpolation over (quantile, group) for "linear" / "cubic",
-    DQM with sub-groupings, QDM cubic, group="time.season".
+    DQM with sub-groupings, QDM cubic.
+
+Where a difference is most likely once the fixtures exist (from memory of the upstream sources, not verified here): (1)
+``nbutils.quantile`` casts the probabilities to the dtype of the data before it calls numpy's nanquantile, so float32
+series see float32 probabilities and numpy's float32 interpolation arithmetic — this restatement (and the kernels) keep
+the probabilities and the interpolation weight in float64 and round once: differences of the order of 1e-7 relative are
+expected, inside the 1e-6 bar; (2) the 2-D ``griddata(method="nearest")`` of grouped adjustments measures distance in
+(value, group index) space, so a node of a NEIGHBOURING group can be the nearest one where the quantile values of a
+group are more than one unit apart — this restatement takes the nearest node of the step's own group.
 """
 
 from __future__ import annotations
