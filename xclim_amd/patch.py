@@ -86,6 +86,8 @@ _BY_NAME = {
     "xclim.indices._anuclim": _GENERIC_NAMES,
     "xclim.indices._agro": _GENERIC_NAMES + ("percentile_doy", "resample_doy"),
     "xclim.indices._conversion": _GENERIC_NAMES,
+    "xclim.indicators.generic._stats": ("select_resample_op",),   # indicators/generic/_stats.py:6
+    "xclim.ensembles._robustness": ("compare",),                  # ensembles/_robustness.py:24
     "xclim.core.calendar": ("percentile_doy", "resample_doy"),
     "xclim.core.bootstrapping": ("percentile_doy",),
     "xclim.indices.stats": ("percentile_doy",),
