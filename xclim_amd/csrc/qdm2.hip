@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "rowstream.h"
 #include "sortnet_183.h"
 
 namespace {
@@ -54,7 +55,11 @@ template <int N, int TMIN>
 __global__ void __launch_bounds__(256, 2)
 k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const float* __restrict__ af, int64_t af_qs,
               const double* __restrict__ qnodes, int nq, int kind, int extrap, float* __restrict__ out, int64_t ost,
-              uint32_t* __restrict__ flist, uint32_t* __restrict__ nflag, int abl) {
+              uint32_t* __restrict__ flist, uint32_t* __restrict__ nflag, int abl, float* __restrict__ gcut,
+              float* __restrict__ gfac) {
+  // gcut != nullptr: the tables leave for k_cut_classify (cut values [nq + 1][C], class factors [nq + 2][C]) and this kernel
+  // neither re-reads nor writes the series
+  const bool split = gcut != nullptr;
   static_assert(N == XH_SN_N, "sortnet header generated for another N");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* qS = reinterpret_cast<double*>(smem);  // [QR_MAXQ] quantile nodes
@@ -348,7 +353,7 @@ k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const f
     // ---- 8a. the tile's rows once more, all in flight (the sorted keys are dead: same registers, same loads as step 1; L2 /
     //      Infinity Cache serve most of them) — issued before the tables below are built
     const int64_t colc8 = mycol < C ? mycol : C - 1;
-    if (!(abl & 32)) {
+    if (!(abl & 32) && !split) {
       const uint32_t voff = (uint32_t)(colc8 * 4) + (h ? (uint32_t)(T - N) * strideB : 0u);
       uint32_t soff = 0u;
       asm volatile("" : "+s"(soff));
@@ -388,11 +393,21 @@ k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const f
       if (lane4 < 32u && stt == QR_TIES && col0 + c < C) flist[atomicAdd(nflag, 1u)] = (uint32_t)(col0 + c);
     }
     qr_fence();
+    if (split) {  // tables -> global, 32 columns x 4 bytes per row
+      for (int i = (int)lane4; i < ntmax * 32; i += 64) {
+        const int64_t cg = col0 + (i & 31);
+        if (cg < C) gcut[(int64_t)(i >> 5) * C + cg] = __uint_as_float(vals[i]);
+      }
+      for (int i = (int)lane4; i < (ntmax + 1) * 32; i += 64) {
+        const int64_t cg = col0 + (i & 31);
+        if (cg < C) gfac[(int64_t)(i >> 5) * C + cg] = FS[i];
+      }
+    }
     // ---- 8c. classify, correct, store.  The rows leave the registers through the hand-over buffer (a rolled loop needs a
     //      run-time row index); class = number of cuts <= x (cuts non-decreasing, unreachable ones NaN at the end): a
     //      branch-free lower bound, 8 rows level by level (8 independent LDS reads in flight instead of one dependent
     //      chain per sample)
-    if (!(abl & 32)) {
+    if (!(abl & 32) && !split) {
       const uint32_t voffO = (uint32_t)(colc8 * 4) + (h ? (uint32_t)(T - N) * strideO : 0u);
       const uint32_t bc = h ? (uint32_t)(2 * N - T) : 0u;  // B's first rows are A's
       const float* cuts = reinterpret_cast<const float*>(vals) + c32;
@@ -450,6 +465,74 @@ k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const f
   }
 }
 
+// ---- classification against per-column cut values (the second half of the QDM path when it is split in two kernels) ----
+// scen[t, c] = sim[t, c] (+|*) fac[#{k : cut[k, c] <= sim[t, c]}, c]; cut (ntest, C) non-decreasing per column with NaN for the
+// boundaries no sample reaches (every compare fails), fac (ntest + 1, C).  A workgroup = 64 columns x 4 row lanes; the
+// tile's two tables sit in LDS; 16 rows per lane in flight (xh_row_stream), their searches run level by level.
+constexpr int CC_CW = 64, CC_RL = 4, CC_U = 16, CC_NT = CC_CW * CC_RL;
+__global__ void __launch_bounds__(CC_NT)
+k_cut_classify(const float* __restrict__ x, int T, int64_t C, int64_t st, const float* __restrict__ gcut,
+               const float* __restrict__ gfac, int ntest, int kind, float* __restrict__ out, int64_t ost) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* cutS = reinterpret_cast<float*>(smem);  // [ntest][64]
+  float* facS = cutS + ntest * CC_CW;            // [ntest + 1][64]
+  const int tid = threadIdx.x, col = tid & (CC_CW - 1), rl = tid / CC_CW;
+  const int64_t ntiles = (C + CC_CW - 1) / CC_CW;
+  const uint32_t rowstepO = (uint32_t)(ost * 4 * CC_RL);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t c = tile * CC_CW + col;
+    const bool cvalid = c < C;
+    const int64_t cc = cvalid ? c : C - 1;
+    for (int k = rl; k <= ntest; k += CC_RL) {
+      if (k < ntest) cutS[k * CC_CW + col] = gcut[(int64_t)k * C + cc];
+      facS[k * CC_CW + col] = gfac[(int64_t)k * C + cc];
+    }
+    __syncthreads();
+    const float* cuts = cutS + col;
+    const float* fac = facS + col;
+    const uint32_t voffO = (uint32_t)(((int64_t)rl * ost + cc) * 4);
+    xh_row_stream<CC_U, CC_RL>(x, T, st, cc, rl, [&](const float (&v)[CC_U], int kb) {
+      uint32_t base[CC_U];
+#pragma unroll
+      for (int u = 0; u < CC_U; ++u) base[u] = 0u;
+      int len = ntest;
+#pragma nounroll
+      while (len > 1) {
+        const int half = len >> 1;
+        float cv[CC_U];
+#pragma unroll
+        for (int u = 0; u < CC_U; ++u) cv[u] = cuts[(base[u] + (uint32_t)half - 1u) * CC_CW];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < CC_U; ++u) base[u] += (v[u] >= cv[u]) ? (uint32_t)half : 0u;
+        len -= half;
+      }
+      {
+        float cv[CC_U];
+#pragma unroll
+        for (int u = 0; u < CC_U; ++u) cv[u] = cuts[base[u] * CC_CW];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < CC_U; ++u) base[u] += (v[u] >= cv[u]) ? 1u : 0u;
+      }
+      float a[CC_U];
+#pragma unroll
+      for (int u = 0; u < CC_U; ++u) a[u] = fac[base[u] * CC_CW];
+      float* ob = out + (int64_t)kb * (CC_RL * CC_U) * ost;
+      const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)0xFFFFFFFFu, 0x00020000);
+      uint32_t soff = 0u;
+#pragma unroll
+      for (int u = 0; u < CC_U; ++u) {
+        const float r = kind == 0 ? v[u] + a[u] : v[u] * a[u];
+        if (cvalid && kb * (CC_RL * CC_U) + u * CC_RL + rl < T)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rsrcO, (int)voffO, (int)soff, 0);
+        soff += rowstepO;
+      }
+    });
+    __syncthreads();  // the tables are rewritten by the next tile
+  }
+}
+
 // flagged columns -> time-minor scratch (column f at buf + f * Tp), their factors -> (nq, nf)
 __global__ void __launch_bounds__(XH_BLOCK)
 k_qr_gather(const float* __restrict__ x, int64_t T, int64_t st, const uint32_t* __restrict__ flist, float* __restrict__ buf,
@@ -494,21 +577,34 @@ int xh_qdm_regsort(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t 
   const size_t b_list = sizeof(uint32_t) * (((size_t)C + 4 + 63) & ~(size_t)63);
   const size_t b_cols = sizeof(float) * (size_t)nfmax * (size_t)Tp;
   void* ws = nullptr;
-  int rc = xh_big_scratch(ctx, b_list + 2 * b_cols + sizeof(float) * (size_t)nq * (size_t)nfmax, &ws);
+  const char* esp = xh_diag_env("XH_QDM_SPLIT");  // diagnostics: 0 = one kernel that also classifies and writes (re-reads its tile)
+  const bool split = !(esp && atoi(esp) == 0);
+  const size_t b_tab = split ? sizeof(float) * (size_t)(2 * nq + 3) * (size_t)C : 0;
+  int rc = xh_big_scratch(ctx, b_list + 2 * b_cols + sizeof(float) * (size_t)nq * (size_t)nfmax + b_tab, &ws);
   if (rc) return rc;
   uint32_t* nflag = static_cast<uint32_t*>(ws);
   uint32_t* flist = nflag + 4;
   float* gbuf = reinterpret_cast<float*>(static_cast<char*>(ws) + b_list);
   float* gout = gbuf + (size_t)nfmax * (size_t)Tp;
   float* gaf = gout + (size_t)nfmax * (size_t)Tp;
+  float* gcut = split ? gaf + (size_t)nq * (size_t)nfmax : nullptr;  // (nq + 1, C)
+  float* gfac = split ? gcut + (size_t)(nq + 1) * (size_t)C : nullptr;  // (nq + 2, C)
   XH_CHECK_HIP(hipMemsetAsync(nflag, 0, 16, ctx->stream));
   const char* ea = xh_diag_env("XH_QDM_ABL");  // diagnostics: skip phases (1 stats, 2 ranks, 4 sort, 16 picks, 32 apply; wrong results)
   const int abl = ea ? atoi(ea) : 0;
   auto kern = k_qdm_regsort<N, TMIN>;
   if (lds > 48 * 1024) XH_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, sim, (int)T, C, st, af, af_qs, d_q, nq, kind, extrap,
-                     scen, ost, flist, nflag, abl);
+                     scen, ost, flist, nflag, abl, gcut, gfac);
   XH_LAUNCH_CHECK();
+  if (split && !(abl & 32)) {
+    const size_t lds2 = sizeof(float) * (size_t)(2 * (nq + 1) + 1) * CC_CW;
+    const int64_t ct = cdiv64(C, CC_CW);
+    const int64_t cg = ct < (int64_t)ctx->num_cu * 8 ? ct : (int64_t)ctx->num_cu * 8;
+    hipLaunchKernelGGL(k_cut_classify, dim3((unsigned)cg), dim3(CC_NT), lds2, ctx->stream, sim, (int)T, C, st, gcut, gfac, nq + 1, kind, scen,
+                       ost);
+    XH_LAUNCH_CHECK();
+  }
   uint32_t nf = 0;
   XH_CHECK_HIP(hipMemcpyAsync(&nf, nflag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
