@@ -66,7 +66,10 @@ while time.time() < t_end:
         b = with_env("XH_QDM_NOREGSORT", lambda: K.qdm_adjust(dev, d_s, d_a, q, kind, "nearest", extrap).get())
         if not np.array_equal(a, b, equal_nan=True):
             bad = np.argwhere(~((a == b) | (np.isnan(a) & np.isnan(b))))
-            print(json.dumps({"FAIL": "qdm", "T": T, "C": C, "nq": nq, "kind": kind, "extrap": extrap, "first": bad[:4].tolist(), "it": it}))
+            cols = np.unique(bad[:, 1])
+            info = [{"col": int(c_), "nbad": int((bad[:, 1] == c_).sum()), "n": int(np.isfinite(sim[:, c_]).sum()), "nmin": int((sim[:, c_] == np.nanmin(sim[:, c_])).sum()) if np.isfinite(sim[:, c_]).any() else 0,
+                     "nvn": int(np.isfinite(af[:, c_]).sum()), "ndistinct": int(len(np.unique(sim[:, c_][np.isfinite(sim[:, c_])])))} for c_ in cols[:6]]
+            print(json.dumps({"FAIL": "qdm", "T": T, "C": C, "nq": nq, "kind": kind, "extrap": extrap, "first": bad[:4].tolist(), "it": it, "ncols_bad": int(len(cols)), "cols": info}))
             sys.exit(1)
         stats["qdm"] += 1
     elif which == 1:  # threshold_count, per-doy table, multi-year
