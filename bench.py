@@ -451,7 +451,7 @@ def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D, full_configs=True)
     ms_qd = event_time(dev, lambda: K.qdm_adjust(dev, sim, af, q, "+", "nearest", "constant", out=scen), 5)
     out["qdm_adjust_365"] = {"ms": ms_qd, "GB/s": 8 * E / ms_qd / 1e6, "frac": 8 * E / ms_qd / 1e6 / HBM_PEAK_GBS,
                              "algorithmic_bytes": 8 * E,
-                             "roofline": hbm_roofline(8 * E, ms_qd, "k_qdm_regsort<183, 360> (xh_qdm_adjust) + k_qdm_columns for columns with ties"),
+                             "roofline": hbm_roofline(8 * E, ms_qd, "k_qdm_regsort<183, 360> + k_cut_classify (xh_qdm_adjust) + k_qdm_columns for columns with ties"),
                              "roofline_valu": valu_bound("k_qdm_regsort")}
     for a in (ref, hist, sim, scen, af, hq):
         a.free()
