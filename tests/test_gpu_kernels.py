@@ -589,6 +589,72 @@ def test_quantile_series_two_pass_matches_transposed_pipeline(dev, rng, monkeypa
     np.testing.assert_array_equal(a[:, keep], exp[:, keep])
 
 
+@pytest.mark.parametrize("T", [40000, 55152])
+def test_quantile_series_beyond_32768_steps(dev, rng, T):
+    """1950-2100 daily = 55 152 steps: the streaming passes of select4.hip take any T <= 65535 (u16 counters), and what
+    they hand back (heavily tied columns) goes to the radix select of select5.hip — round 3 refused T > 32768.  Bitwise
+    against the oracle; the time-minor layout (radix select for every column) and nq > 32 (two radix sweeps) ride along."""
+    C = 64 * 3 + 5
+    x = _field(rng, T, C, nan_frac=0.002)
+    x[:, 3] = np.nan
+    x[:, 4] = np.float32(7.25)
+    x[:, 5] = np.where(rng.random(T) < 0.5, -1.5, 2.5)
+    x[:, 6:10] = _field(rng, T, 4, kind="pr")
+    x[:, 10] = np.minimum(x[:, 10], np.float32(290.0))
+    x[:, 11] = np.round(x[:, 11] * 4) / 4                          # ~350 ties per value: > 2048 candidates, flagged
+    x[:, 12] = np.round(x[:, 12])                                  # whole degrees
+    x[:, 13] = x[:, 13] - 288
+    x[: T - 1, 14] = np.nan
+    x[:, 15] = np.where(rng.random(T) < 0.97, np.nan, x[:, 15])
+    r16 = rng.random(T)
+    x[:, 16] = np.where(r16 < 0.3, 0.0, np.where(r16 < 0.6, -0.0, x[:, 16] - 288))   # zeros of both signs
+    x[:, C - 2] = np.nan
+    q = osdba.equally_spaced_nodes(20)
+    exp = osdba.quantile(x, q).astype(np.float32)
+    out = K.quantile_series(dev, dev.to_device(x), q).get()
+    np.testing.assert_array_equal(out, exp)
+    xt = np.ascontiguousarray(x[:, :40].T)
+    out2 = K.quantile_series(dev, dev.to_device(xt), q, time_axis=1).get()
+    np.testing.assert_array_equal(out2, exp[:, :40])
+    q40 = np.linspace(0.0, 1.0, 40)
+    out3 = K.quantile_series(dev, dev.to_device(xt), q40, time_axis=1).get()
+    np.testing.assert_array_equal(out3, osdba.quantile(x[:, :40], q40).astype(np.float32))
+
+
+def test_quantile_series_two_pass_value_classes(dev, rng, monkeypatch):
+    """The bins of select4.hip come from float differences against the window's ends (round 4): zeros of both signs,
+    samples at +-FLT_MAX and +-inf (the window is clamped to finite ends), columns whose window has denormal width or
+    overflows (scale 0), windows [x, nextafter(x)], a column of +inf.  Compared with the transposed column kernels
+    (diagnostic switch: both are exact selections) and, for the finite columns, with the oracle."""
+    T, C = 5000, 64 + 9
+    x = _field(rng, T, C, nan_frac=0.001)
+    fmax = np.finfo(np.float32).max
+    x[:, 0] = np.where(rng.random(T) < 0.5, 0.0, -0.0)
+    x[:, 1] = np.where(rng.random(T) < 0.4, -0.0, x[:, 1] - 288)
+    x[:, 2] = np.where(rng.random(T) < 0.4, 0.0, x[:, 2] - 288)
+    x[:, 3] = np.where(rng.random(T) < 0.1, -np.inf, x[:, 3])
+    x[:, 4] = np.where(rng.random(T) < 0.1, np.inf, x[:, 4])
+    x[:, 5] = np.where(rng.random(T) < 0.3, fmax, np.where(rng.random(T) < 0.3, -fmax, x[:, 5]))
+    x[:, 6] = rng.choice(np.array([1e-45, 2.8e-45, 4.2e-45, 0.0], np.float32), T)
+    x[:, 7] = np.where(rng.random(T) < 0.5, np.float32(1.0), np.nextafter(np.float32(1.0), np.float32(2.0)))
+    x[:, 8] = np.inf
+    x[:, 9] = np.where(rng.random(T) < 0.5, -fmax, fmax)
+    x[:, 10] = (x[:, 10] - 288) * np.float32(1e-40)
+    x[:, 11] = (x[:, 11] - 288) * np.float32(1e36)
+    q = osdba.equally_spaced_nodes(20)
+    xd = dev.to_device(x)
+    a = K.quantile_series(dev, xd, q).get()
+    monkeypatch.setenv("XH_DIAGNOSTICS", "1")
+    monkeypatch.setenv("XH_SELECT_NOHIST", "1")
+    b = K.quantile_series(dev, xd, q).get()
+    np.testing.assert_array_equal(a, b)
+    fin = np.ones(C, bool)
+    fin[[3, 4, 8]] = False
+    with np.errstate(all="ignore"):
+        exp = osdba.quantile(x, q).astype(np.float32)
+    np.testing.assert_array_equal(a[:, fin], exp[:, fin])
+
+
 @pytest.mark.parametrize("T,C", [(365, 70001), (500, 33333), (800, 20011), (1500, 9001), (3650, 5003), (10950, 4801)])
 def test_quantile_series_many_columns(dev, rng, T, C):
     """More columns than resident workgroups (grid-stride column loops, ragged last tiles of the staged time-major

@@ -90,6 +90,9 @@ int xh_select_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols,
 // select2.hip: long series (1024 < T <= 16384) without a per-column LDS copy; XH_ERR_NOTIMPL outside that range
 int xh_select_columns_lean(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride,
                            const double* d_q, int nq, float* out, int64_t out_cstride, int64_t out_qstride);
+// select5.hip: radix select, one workgroup per column, any T < 2^31 (the fallback above 32768 samples per column)
+int xh_select_columns_radix(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const double* d_q,
+                            int nq, float* out, int64_t out_cstride, int64_t out_qstride);
 // select3.hip: one-year daily series (360 <= T <= 366) from a time-major view, column in registers + sorting network;
 // XH_ERR_NOTIMPL when the shape does not fit
 int xh_select_regsort(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq, float* out,

@@ -629,6 +629,7 @@ int xh_select_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols,
     if (rc_lean != XH_ERR_NOTIMPL) return rc_lean;
   }
   // T > 16384: the whole column lives in LDS (sorted[T]), 1024-thread workgroups
-  XH_REQUIRE(T <= 32768, XH_ERR_LIMIT, "quantile_series: T = %lld exceeds the 32768-sample column limit", (long long)T);
+  // beyond 32768 samples (1950-2100 daily = 55 152): the radix select of select5.hip, any length
+  if (T > 32768) return xh_select_columns_radix(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
   return launch_select<1024, 32, 2048>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
 }

@@ -8,40 +8,60 @@
 // memory, like the run-length kernels do, and the per-column state is a histogram in LDS:
 //
 //   pass 0  k_hs_sample   every S-th row (~342 rows, 3 % of the bytes): per column the 4th smallest / 4th largest sampled
-//                          key -> a value window [lo, hi] that holds ~97.5 % of the column (keys = order-preserving uint32)
-//   pass 1  k_hs_hist     all rows: 1024-bin histogram per column over that window (packed u16 counters in LDS,
-//                          [bin / 2][column], LDS atomics).  Bins: 0 keys < lo | 1 keys == lo | 2..1021 regular, equally wide in value
-//                          | binH keys == hi | binH + 1 keys > hi.  Bins 1 and binH hold ONE value each ("pure": the dry
-//                          days of a precipitation series, a saturated maximum) and never need a second look.  At the
-//                          end of a tile: prefix sums, the bin and the rank inside its bin of each of the 2 nq order
-//                          statistics (Hyndman-Fan, utl:395, 417-461), a bitmap of those target bins, and the position
-//                          every target will have among the column's sorted CANDIDATES (= the keys of the target bins).
-//   pass 2  k_hs_collect  all rows again: keys whose bin is a target bin (~3 % of them) are appended to the column's
+//                          value -> a FINITE value window [lo, hi] that holds ~97.5 % of the column
+//   pass 1  k_hs_hist     all rows: 1024-bin histogram per column over that window (u16 counters in LDS, [bin][column],
+//                          two adjacent columns per 32-bit word, LDS atomics).  Bins (hs_bin): 0 x < lo | 1 x == lo |
+//                          2 + f regular, f = floor((x - lo) * scale) clamped to [0, 1019] | 3 + f(hi) x == hi |
+//                          4 + f x > hi.  The bins of lo and of hi hold ONE value each ("pure": the dry days of a
+//                          precipitation series, a saturated maximum) and never need a second look.  At the end of a
+//                          tile: prefix sums, the bin and the rank inside its bin of each of the 2 nq order statistics
+//                          (Hyndman-Fan, utl:395, 417-461), a bitmap of those target bins, and the position every
+//                          target will have among the column's sorted CANDIDATES (= the keys of the target bins).
+//   pass 2  k_hs_collect  all rows again: values whose bin is a target bin (~3 % of them) are appended to the column's
 //                          list in LDS; at the end of a tile one wave per column sorts its candidates (<= 2048) in registers
-//                          (bitonic, ds_bpermute exchanges), picks the 2 nq order statistics by position, lerps
+//                          (bitonic, DPP / ds_bpermute exchanges), picks the 2 nq order statistics by position, lerps
 //                          (utl:464-491) and stores the nq quantiles.
 //
-// Geometry: a 512-thread workgroup owns 32 adjacent columns (one 128-byte line per row) and 16 "row lanes" per column;
-// thread (column c, row lane r) loads rows r, r + 16, r + 32 ... with 16 loads in flight, double buffered; a wave
-// instruction reads two full 128-byte row segments.  64 KB of histogram (or candidate list) per workgroup, two
-// workgroups per CU.  Algorithmic bytes per pass: 4E; nothing else crosses HBM except ~230 bytes of per-column tables.
+// Round 4: the per-sample instruction diet.  Both passes were VALU-issue bound next to a 6 TB/s stream (profiles/r03/
+// valu_busy.txt: 22 + 1 and ~30 instructions per sample).  Now
+//   * the bin comes from the VALUE alone: f from sub / mul / med3 / cvt, the five classes from the SIGNS of x - lo and
+//     x - hi (v_med3_i32 of the float's bits against -1 / +1; a float difference is zero iff the operands are equal) —
+//     no order-preserving integer key, no saturating key arithmetic, no validity compare: 8 instructions;
+//   * NaN samples (and the rows past the end of the series, which the loader turns into NaN) are found per 16-row batch
+//     by ONE float sum per sample (NaN propagates); only a batch with a NaN in the wave takes the path that tests
+//     every sample;
+//   * the histogram word of a sample is [bin][column / 2]: its address is one v_lshl_add of the bin, the increment
+//     (1 or 1 << 16) is a per-lane constant — the bin-pair layout of round 3 needed five instructions for both;
+//   * pass 2 looks the sample's REGULAR index f up in a table of bit pairs (candidate | needs the exact classes) built
+//     by pass 1: 4 instructions for f, 5 for the lookup; only batches that touch a flagged f (the window's ends when
+//     they are targets) or hold a NaN recompute the exact bin.  Candidates are appended as raw floats under the
+//     execution mask and become keys when they are sorted.
 //
-// Columns whose target bins hold more than 2048 keys, or that do not fit the tile's 16384-key LDS pool (heavily tied or
-// clustered values away from the window's ends), are flagged in pass 1 and recomputed by the column kernels of select.hip / select2.hip from a gathered copy.
+// Geometry: a 1024-thread workgroup owns 64 adjacent columns (256-byte row segments) and 16 "row lanes" per column;
+// thread (column c, row lane r) loads rows r, r + 16, r + 32 ... with 16 loads in flight, double buffered.  One
+// workgroup per CU (LDS).  Algorithmic bytes per pass: 4E; nothing else crosses HBM except ~600 bytes of per-column
+// tables.
+//
+// Columns whose target bins hold more than 2048 keys, or that do not fit the tile's 32768-key LDS pool (heavily tied or
+// clustered values away from the window's ends), are flagged in pass 1 and recomputed by the column kernels of
+// select.hip / select2.hip / select5.hip from a gathered copy.
 #include <stdlib.h>
 
 #include "common.h"
 
 namespace {
 
-constexpr int HS_RL = 16;              // row lanes per column: a workgroup owns CW columns with CW * 16 threads
-constexpr int HS_NT = 512;             // (threads of the diagnostic streaming kernel)
-constexpr int HS_UDEF = 16;            // loads in flight per thread and register set (two sets: ping-pong)
+constexpr int HS_RL = 16;              // row lanes per column
+constexpr int HS_CW = 64;              // columns per workgroup
+constexpr int HS_NT = HS_CW * HS_RL;   // threads per workgroup
+constexpr int HS_U = 16;               // loads in flight per thread and register set (two sets: ping-pong)
 constexpr int HS_NB = 1024;            // bins per column
-constexpr int HS_NREG = 1020;          // regular bins 2 .. 1021
+constexpr int HS_NREG = 1020;          // regular indices f = 0 .. 1019
+constexpr int HS_POOL = HS_CW * 512;   // candidate keys of one tile in LDS
 constexpr int HS_CAPMAX = 2048;        // ... and at most this many for one column (the largest register sort)
 constexpr int HS_MAXQ = 32;            // quantiles per call on this path
 constexpr uint32_t HS_NANKEY = 0xFFFFFFFFu;
+constexpr uint32_t HS_KEY_MINF = 0x00800000u, HS_KEY_MAXF = 0xFF7FFFFFu;  // keys of -FLT_MAX / +FLT_MAX
 constexpr uint32_t HS_SPEC_LO = 0xFFFEu, HS_SPEC_HI = 0xFFFDu, HS_SPEC_NONE = 0xFFFFu;
 constexpr uint32_t HS_FLAGGED = 0xFFFFFFFFu;
 
@@ -55,49 +75,50 @@ struct HsStat {
 // per-column window -> bin arithmetic, identical in pass 1 and pass 2.  Bins are equally wide in VALUE, not in key
 // space: keys are logarithmic in |x| (a series that straddles zero — degrees Celsius, anomalies — would put all of its
 // samples into a handful of key-space bins around the huge key range of the tiny values).  fp32 subtract, multiply and
-// floor are monotone, and monotone + identical in both passes is all the selection needs:
-//   key < lo -> bin 0 | key == lo -> 1 | otherwise 2 + min(floor((x - lo) * scale), 1019) | key == hi -> binH | key > hi -> binH + 1
-// The class offsets come from saturating key arithmetic (no compares: v_cmp + v_cndmask pairs serialise on VCC).
+// floor are monotone, and monotone + identical in both passes + pure bins for lo and hi is all the selection needs:
+//   bin(x) = f(x) + 2 + sgn(x - lo) + sgn(x - hi),   f(x) = floor(med3((x - lo) * scale, 0, 1019))
+//   x < lo -> 0 | x == lo -> 1 | lo < x < hi -> 2 + f | x == hi -> 3 + f(hi) | x > hi -> 4 + f        (lo < hi)
+// x - lo is +0 iff x == lo (IEEE: a difference of finite floats never rounds to zero; denormals are kept, the kernel
+// descriptor says float_denorm_mode_32 = 3), so the classes are exact whatever the rounding of f.  lo and hi are finite
+// (k_hs_sample clamps them to +-FLT_MAX: x = -inf then is "below lo", inf - inf never happens for a non-NaN sample).
+// Zeros of both signs are ONE value here (x - lo = +0 for either); the integer keys of round 3 ordered -0 below +0.
+// NaN samples do not pass through hs_bin in pass 1 (see the NaN sum) and land on f = 0 in pass 2's table look-up.
 struct HsScale {
-  uint32_t lo1, hi1, binH;
-  float lof, scale;
+  float lof, hif, scale;
 };
-
-__device__ __forceinline__ uint32_t hs_usub_sat(uint32_t a, uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }
-__device__ __forceinline__ uint32_t hs_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
-
-__device__ __forceinline__ uint32_t hs_regular(float x, float lof, float scale) {
-  // median of (t, 0, 1019): NaN (inf * 0, inf - inf) and negative t give 0, large t the top regular bin
-  return (uint32_t)__builtin_amdgcn_fmed3f((x - lof) * scale, 0.0f, (float)(HS_NREG - 1));
-}
 
 __device__ __forceinline__ HsScale hs_scale(uint32_t lo, uint32_t hi) {
   HsScale s;
-  s.lo1 = lo + 1u;  // lo is a sampled (non-NaN) key: <= 0xFF800000
   s.lof = xh_key2f(lo);
-  const float hif = xh_key2f(hi);
-  const float d = hif - s.lof;
+  s.hif = xh_key2f(hi);
+  const float d = s.hif - s.lof;
   float sc = 0.0f;
-  if (d > 0.0f) sc = (float)((double)HS_NREG * 1.000001 / (double)d);  // (hi - lo) * scale >= 1020: hi lands in the top regular bin
+  if (d > 0.0f) sc = (float)((double)HS_NREG * 1.000001 / (double)d);  // (hi - lo) * scale >= 1020: hi lands on f = 1019
   if (!(sc <= 3.0e38f)) sc = 0.0f;                                       // d = inf, or a window of denormal width
   s.scale = sc;
-  s.hi1 = hi > lo ? hi - 1u : HS_NANKEY;  // one-valued window: no "== hi" class (bin 1 holds the value)
-  s.binH = hi > lo ? 3u + hs_regular(hif, s.lof, sc) : HS_SPEC_NONE;
   return s;
 }
 
-// order-preserving key WITHOUT the NaN test of xh_f2key: NaN bit patterns land above key(+inf) = 0xFF800000 or below
-// key(-inf) = 0x007FFFFF and are recognised by hs_valid
+__device__ __forceinline__ int hs_sgn(float z) {  // -1 | 0 | +1 from the bits of a float difference (one v_med3_i32)
+  int r;  // (the compiler turns min / max of the float's bits into two v_cmp + two v_cndmask)
+  asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(z));
+  return r;
+}
+__device__ __forceinline__ uint32_t hs_findex(float z, float scale) {
+  // median of (t, 0, 1019): NaN (inf * 0, NaN samples) and negative t give 0, large t the top index
+  return (uint32_t)__builtin_amdgcn_fmed3f(z * scale, 0.0f, (float)(HS_NREG - 1));
+}
+// the bin MINUS 2 (a signed number >= -2): the callers fold the 2 into their table base
+__device__ __forceinline__ int hs_bin_m2(float x, const HsScale& s) {
+  const float z = x - s.lof;
+  return (int)hs_findex(z, s.scale) + hs_sgn(z) + hs_sgn(x - s.hif);
+}
+__device__ __forceinline__ uint32_t hs_bin(float x, const HsScale& s) { return (uint32_t)(hs_bin_m2(x, s) + 2); }
+
+// order-preserving key of a non-NaN float (candidates are never NaN)
 __device__ __forceinline__ uint32_t hs_key(float f) {
   const uint32_t u = __float_as_uint(f);
   return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
-}
-__device__ __forceinline__ bool hs_valid(uint32_t k) { return k - 0x007FFFFFu <= 0xFF000001u; }
-
-__device__ __forceinline__ uint32_t hs_bin(float x, uint32_t k, const HsScale& s) {
-  const uint32_t up = hs_min(hs_usub_sat(k, s.hi1), 2u);  // 0 | 1 (key == hi) | 2 (above)
-  const uint32_t dn = hs_min(hs_usub_sat(s.lo1, k), 2u);  // 0 | 1 (key == lo) | 2 (below)
-  return hs_regular(x, s.lof, s.scale) + (2u + up) - dn;
 }
 
 // rank of target (quantile q, side 0 = lower / 1 = upper neighbour) among n valid samples: utl:395, 417-461 (type 7)
@@ -179,24 +200,25 @@ k_hs_sample(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int64
       lo = 0x80000000u;
       hi = 0x80000000u;
     }
+    // a finite window: hs_bin takes float differences against lo and hi
+    lo = lo < HS_KEY_MINF ? HS_KEY_MINF : (lo > HS_KEY_MAXF ? HS_KEY_MAXF : lo);
+    hi = hi < HS_KEY_MINF ? HS_KEY_MINF : (hi > HS_KEY_MAXF ? HS_KEY_MAXF : hi);
     lohi[c0 + v] = make_uint2(lo, hi);
   }
 }
 
 // ---- the streaming loop shared by pass 1 and pass 2 ------------------------------------------------------------------
-// Thread (col, rl) of a tile visits rows rl, rl + 16, ... in batches of HS_U rows; f(values, keys) is called once per batch
-// with the order-preserving keys of hs_key (NaN patterns fail hs_valid; 0xFFFFFFFF for rows past the end and for the columns
-// past C of a ragged tile).
-template <int HS_U, int RLT, typename F>
-__device__ __forceinline__ void hs_stream(const float* __restrict__ x, int T, int64_t st, int64_t cc, bool cvalid, int rl, F&& f) {
-  constexpr int HS_ROWS = RLT * HS_U;  // rows a workgroup covers per batch
+// Thread (col, rl) of a tile visits rows rl, rl + 16, ... in batches of HS_U rows; f(values) is called once per batch.
+// Rows past the end of the series arrive as NaN (the callers skip NaN samples anyway).
+template <typename F>
+__device__ __forceinline__ void hs_stream(const float* __restrict__ x, int T, int64_t st, int64_t cc, int rl, F&& f) {
+  constexpr int HS_ROWS = HS_RL * HS_U;  // rows a workgroup covers per batch
   // full batches: every row of the batch exists for every row lane.  Buffer loads: a descriptor re-based per batch
   // (scalar), the row offset of load u as the scalar offset, ONE 32-bit per-lane byte offset — no vector address
   // arithmetic and no 64-bit address registers per load (16 loads in flight would hold 32 of them).
   const uint32_t voff = (uint32_t)(((int64_t)rl * st + cc) * 4);
-  const uint32_t rowstep = (uint32_t)(st * 4 * RLT);  // bytes between the rows of loads u and u + 1 (host: 256 rows < 4 GiB)
+  const uint32_t rowstep = (uint32_t)(st * 4 * HS_RL);  // bytes between the rows of loads u and u + 1 (host: 256 rows < 4 GiB)
   const int nfull = T / HS_ROWS;
-  const uint32_t padkey = cvalid ? 0u : HS_NANKEY;  // OR-ed into the key: a column past C only ever shows NaN keys
   auto load = [&](float (&dst)[HS_U], int kb) {
     const float* base = x + (int64_t)kb * HS_ROWS * st;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)0xFFFFFFFFu, 0x00020000);
@@ -207,12 +229,6 @@ __device__ __forceinline__ void hs_stream(const float* __restrict__ x, int T, in
       soff += rowstep;
     }
   };
-  auto proc = [&](const float (&src)[HS_U]) {
-    uint32_t k[HS_U];
-#pragma unroll
-    for (int u = 0; u < HS_U; ++u) k[u] = hs_key(src[u]) | padkey;
-    f(src, k);
-  };
   if (nfull > 0) {
     // two register sets, ping-pong (no copies: a copy of set B into set A right after element u is consumed would make
     // element u wait for the load that was issued a moment ago): the loads of one batch fly while the other is consumed
@@ -221,17 +237,17 @@ __device__ __forceinline__ void hs_stream(const float* __restrict__ x, int T, in
     int kb = 0;
     while (kb + 2 < nfull) {  // no conditional loads in here: the compiler counts the outstanding loads exactly
       load(B, kb + 1);
-      proc(A);
+      f(A);
       load(A, kb + 2);
-      proc(B);
+      f(B);
       kb += 2;
     }
     if (kb + 1 < nfull) {
       load(B, kb + 1);
-      proc(A);
-      proc(B);
+      f(A);
+      f(B);
     } else {
-      proc(A);
+      f(A);
     }
   }
   // tail rows (fewer than 256): same buffer loads from CLAMPED per-lane rows, validity applied afterwards (a conditional
@@ -247,110 +263,135 @@ __device__ __forceinline__ void hs_stream(const float* __restrict__ x, int T, in
     float buf[HS_U];
 #pragma unroll
     for (int u = 0; u < HS_U; ++u) {
-      int r = u * RLT + rlo;
+      int r = u * HS_RL + rlo;
       r = r < rem ? r : rem - 1;
       const uint32_t vo = (uint32_t)r * (uint32_t)(st * 4) + (uint32_t)(cc * 4);
       buf[u] = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, 0, 0));
     }
-    uint32_t k[HS_U];
 #pragma unroll
-    for (int u = 0; u < HS_U; ++u) k[u] = u * RLT + rlo < rem ? (hs_key(buf[u]) | padkey) : HS_NANKEY;
-    f(buf, k);
+    for (int u = 0; u < HS_U; ++u) buf[u] = u * HS_RL + rlo < rem ? buf[u] : xh_nan32();
+    f(buf);
   }
 }
 
-// Workgroup -> tile map.  The dispatcher places block b on XCD b % 8; with tile = b the workgroups of one XCD touch
-// every 8th 128-byte line of a row.  Optional map (XH_HIST_XCD=1, diagnostics): inside each round of gridDim tiles, XCD
-// x takes the x-th CONTIGUOUS eighth (64 adjacent tiles = 8 KB of every row).  Measured on config 4: no gain (42.8 ms
-// with, 41.3 without), so the identity is the default.  Needs gridDim % 8 == 0, identity otherwise.
-__device__ __forceinline__ int64_t hs_tile_of(int64_t round_base, int64_t ntiles, int xcd_map) {
-  const int64_t G = gridDim.x, b = blockIdx.x;
-  const int64_t local = (xcd_map && (G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
-  const int64_t tile = round_base + local;
+// NaN anywhere in the batch of this WAVE?  One float add per sample (NaN propagates; +inf and -inf in one lane's batch
+// give a false alarm, which only costs the exact path).
+__device__ __forceinline__ bool hs_wave_has_nan(const float (&v)[HS_U]) {
+  // two sequential chains: a tree makes the compiler pair the operands for v_pk_add_f32 (16 v_mov to line them up)
+  float a = v[0], b = v[1];
+#pragma unroll
+  for (int u = 2; u < HS_U; u += 2) {
+    a += v[u];
+    b += v[u + 1];
+  }
+  a += b;
+  return __any(a != a) != 0;
+}
+
+// Workgroup -> tile map: grid-strided, the identity inside a round (an XCD-aware map was measured in round 3: no gain).
+__device__ __forceinline__ int64_t hs_tile_of(int64_t round_base, int64_t ntiles) {
+  const int64_t tile = round_base + blockIdx.x;
   return tile < ntiles ? tile : -1;
 }
 
 // ---- pass 1: histogram + target bins -----------------------------------------------------------------------------------
-// LDS: hist [512][32] u32 (two u16 counters per word: bins 2d, 2d + 1 of column c at [d][c]) | bm [32][32] target-bin
-// bitmap | part [16][32] partial sums | tgt [2 * MAXQ][32] (bin | rank inside the bin << 16) | mcol [32] | cbase [32]
-constexpr size_t hs_lds1(int cw) { return (size_t)(HS_NB / 2) * cw * 4 + 32 * cw * 4 + HS_RL * cw * 4 + 2 * HS_MAXQ * cw * 4 + 2 * cw * 4; }
+// LDS: h32 [1024 bins][32 column pairs] u32 (two u16 counters per word: columns 2p, 2p + 1 of bin b at [b][p]) | bm [32][64]
+// target-bin bitmap | part [32][32] packed partial sums (later [16][64] candidate counts) | tgt [2 * MAXQ][64] (bin | rank
+// inside the bin << 16) | mcol [64] | cbase [64] | ntot [32] packed column totals
+constexpr size_t hs_lds1() {
+  return (size_t)HS_NB * 32 * 4 + 32 * HS_CW * 4 + 1024 * 4 + 2 * HS_MAXQ * HS_CW * 4 + 2 * HS_CW * 4 + 32 * 4;
+}
 
-template <int HS_U, int CW>
-__global__ void __launch_bounds__(CW * HS_RL, 4)
+// 16 bits -> the even bit positions of a word
+__device__ __forceinline__ uint32_t hs_spread16(uint32_t x) {
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+
+__global__ void __launch_bounds__(HS_NT, 4)
 k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2* __restrict__ lohi,
           const double* __restrict__ qs, int nq, uint32_t* __restrict__ meta_n, uint32_t* __restrict__ meta_m,
           uint32_t* __restrict__ meta_base, uint16_t* __restrict__ crank, uint32_t* __restrict__ bitmap_g,
-          uint32_t* __restrict__ flist, HsStat* __restrict__ stat, int xcd_map, int abl) {
-  constexpr int NT = CW * HS_RL, POOL = CW * 512;  // threads per workgroup; LDS pool of candidate keys in pass 2
+          uint32_t* __restrict__ tab_g, uint32_t* __restrict__ flist, HsStat* __restrict__ stat, int abl) {
+  constexpr int CW = HS_CW, NT = HS_NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* bm = hist + (HS_NB / 2) * CW;
+  uint32_t* h32 = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* bm = h32 + HS_NB * 32;
   uint32_t* part = bm + 32 * CW;
-  uint32_t* tgt = part + HS_RL * CW;
+  uint32_t* tgt = part + 1024;
   uint32_t* mcol = tgt + 2 * HS_MAXQ * CW;
   uint32_t* cbase = mcol + CW;
+  uint32_t* ntot = cbase + CW;
   const int tid = threadIdx.x, col = tid & (CW - 1), rl = tid / CW;
+  const int pw = tid & 31, prt = tid >> 5;  // epilogue: column-pair word and 32-bin part of the prefix sums
+  const uint32_t sh16 = (uint32_t)(col & 1) << 4;
   const int ntgt = 2 * nq;
   const int64_t ntiles = (C + CW - 1) / CW;
   // zero the histogram and the bitmap (again at the end of every tile)
-  for (int i = tid; i < (HS_NB / 2) * CW + 32 * CW; i += NT) hist[i] = 0u;
+  for (int i = tid; i < HS_NB * 32 + 32 * CW; i += NT) h32[i] = 0u;
   __syncthreads();
   for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
-    const int64_t tile = hs_tile_of(round_base, ntiles, xcd_map);
+    const int64_t tile = hs_tile_of(round_base, ntiles);
     if (tile < 0) break;  // (block-uniform; only in the last round)
     const int64_t c = tile * CW + col;
     const bool cvalid = c < C;
     const int64_t cc = cvalid ? c : C - 1;
     const uint2 lh = lohi[cc];
     const HsScale s = hs_scale(lh.x, lh.y);
-    uint32_t* mycol = hist + col;
-    uint32_t dummy = 0;
-    hs_stream<HS_U, HS_RL>(x, T, st, cc, cvalid, rl, [&](const float (&v)[HS_U], const uint32_t (&k)[HS_U]) {
+    // this lane's counter of bin b is the half `col & 1` of word [b][col >> 1]; a column past C adds zeros.  Row 2 of
+    // the table is bin 0 of hs_bin_m2.
+    uint32_t* mycol = h32 + 2 * 32 + (col >> 1);
+    const uint32_t one = cvalid ? (1u << sh16) : 0u;
+    float dummy = 0.0f;
+    hs_stream(x, T, st, cc, rl, [&](const float (&v)[HS_U]) {
       if (abl & 2) {  // diagnostics: loads only
 #pragma unroll
-        for (int u = 0; u < HS_U; ++u) dummy ^= k[u];
+        for (int u = 0; u < HS_U; ++u) dummy += v[u];
         return;
       }
+      if (!hs_wave_has_nan(v)) {
 #pragma unroll
-      for (int u = 0; u < HS_U; ++u) {
-        const uint32_t b = hs_bin(v[u], k[u], s);
-        const uint32_t val = hs_valid(k[u]) ? (1u << ((b & 1u) << 4)) : 0u;
-        atomicAdd(mycol + (b >> 1) * CW, val);
+        for (int u = 0; u < HS_U; ++u) atomicAdd(mycol + hs_bin_m2(v[u], s) * 32, one);
+      } else {
+#pragma unroll
+        for (int u = 0; u < HS_U; ++u) atomicAdd(mycol + hs_bin_m2(v[u], s) * 32, v[u] == v[u] ? one : 0u);
       }
     });
-    if ((abl & 2) && dummy == 0x12345679u) atomicAdd(&stat->errors, 1u);
+    if ((abl & 2) && dummy == 0.12345f) atomicAdd(&stat->errors, 1u);
     __syncthreads();
     if (abl & 4) continue;  // diagnostics: no tile epilogue (wrong results, the histogram is not even cleared)
-    // ---- exclusive prefix sums, in place: thread (col, rl) owns words [rl * 32, rl * 32 + 32) = bins [rl * 64, ...)
+    // ---- exclusive prefix sums over the bins, in place and PACKED (two columns per word; every half stays <= T <= 65535):
+    // thread (pw, prt) owns the words of bins [prt * 32, prt * 32 + 32) of column pair pw
     uint32_t ssum = 0;
 #pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-      const uint32_t w = hist[(rl * 32 + i) * CW + col];
-      ssum += (w & 0xFFFFu) + (w >> 16);
-    }
-    part[rl * CW + col] = ssum;
+    for (int i = 0; i < 32; ++i) ssum += h32[(prt * 32 + i) * 32 + pw];
+    part[prt * 32 + pw] = ssum;
     __syncthreads();
-    uint32_t run = 0, n = 0;
+    uint32_t run = 0;
 #pragma unroll
-    for (int r = 0; r < HS_RL; ++r) {
-      const uint32_t p = part[r * CW + col];
-      run += r < rl ? p : 0u;
-      n += p;
+    for (int r = 0; r < 32; ++r) {
+      const uint32_t p = part[r * 32 + pw];
+      run += r < prt ? p : 0u;
     }
 #pragma unroll 8
     for (int i = 0; i < 32; ++i) {
-      const int idx = (rl * 32 + i) * CW + col;
-      const uint32_t w = hist[idx];
-      const uint32_t c0 = w & 0xFFFFu, c1 = w >> 16;
-      hist[idx] = run | ((run + c0) << 16);  // counts below bin 2d | below bin 2d + 1 (<= n <= T <= 65535)
-      run += c0 + c1;
+      const int idx = (prt * 32 + i) * 32 + pw;
+      const uint32_t w = h32[idx];
+      h32[idx] = run;  // samples in the bins below this one
+      run += w;
     }
+    if (prt == 31) ntot[pw] = run;
     __syncthreads();
-    auto below = [&](uint32_t b) -> uint32_t {  // keys in bins < b, b in [0, 1024]
+    const uint32_t n = (ntot[col >> 1] >> sh16) & 0xFFFFu;
+    const uint32_t* myh = h32 + (col >> 1);
+    auto below = [&](uint32_t b) -> uint32_t {  // samples in bins < b, b in [0, 1024]
       if (b >= (uint32_t)HS_NB) return n;
-      const uint32_t w = hist[(b >> 1) * CW + col];
-      return (b & 1u) ? (w >> 16) : (w & 0xFFFFu);
+      return (myh[b * 32] >> sh16) & 0xFFFFu;
     };
+    const uint32_t binL = hs_bin(s.lof, s), binH = hs_bin(s.hif, s);  // the pure bins
     // ---- the bin and the rank inside it of every target; mark the bins that need a second look
     for (int j = rl; j < ntgt; j += HS_RL) {
       uint32_t e = HS_SPEC_NONE;
@@ -365,7 +406,7 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
           hi_b = le ? hi_b : mid - 1u;
         }
         e = lo_b | ((r - below(lo_b)) << 16);
-        if (lo_b != 1u && lo_b != s.binH) atomicOr(&bm[(lo_b >> 5) * CW + col], 1u << (lo_b & 31u));
+        if (lo_b != binL && lo_b != binH) atomicOr(&bm[(lo_b >> 5) * CW + col], 1u << (lo_b & 31u));
       }
       tgt[j * CW + col] = e;
     }
@@ -387,18 +428,21 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
     uint32_t m = 0;
 #pragma unroll
     for (int r = 0; r < HS_RL; ++r) m += part[r * CW + col];
-    // the tile's candidate lists share one LDS pool in pass 2: column offsets in column order; a column that does not
-    // fit (or exceeds the largest register sort) is flagged for the column kernels
-    if (rl == 0) mcol[col] = cvalid ? m : 0u;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t runp = 0;
-      for (int k = 0; k < CW; ++k) {
-        const uint32_t mk = mcol[k];
-        const bool fl = mk > (uint32_t)HS_CAPMAX || runp + mk > (uint32_t)POOL;
-        cbase[k] = fl ? HS_FLAGGED : runp;
-        runp += fl ? 0u : mk;
+    // the tile's candidate lists share one LDS pool in pass 2: column offsets in column order (one wave, shuffle scan); a
+    // column with more candidates than the largest register sort, and every column from the one that overflows the
+    // pool on, is flagged for the column kernels
+    if (rl == 0) {  // wave 0: lane = column
+      const uint32_t mk = cvalid ? m : 0u;
+      const bool big = mk > (uint32_t)HS_CAPMAX;
+      const uint32_t val = big ? 0u : mk;
+      uint32_t incl = val;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        incl += col >= d ? o : 0u;
       }
+      const bool fl = big || incl > (uint32_t)HS_POOL;
+      cbase[col] = fl ? HS_FLAGGED : incl - val;
     }
     __syncthreads();
     const uint32_t mybase = cbase[col];
@@ -408,8 +452,8 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
       uint32_t cr = HS_SPEC_NONE;
       if (e != HS_SPEC_NONE) {
         const uint32_t b = e & 0xFFFFu, o = e >> 16;
-        if (b == 1u) cr = HS_SPEC_LO;
-        else if (b == s.binH) cr = HS_SPEC_HI;
+        if (b == binL) cr = HS_SPEC_LO;
+        else if (b == binH) cr = HS_SPEC_HI;
         else {
           const int w = (int)(b >> 5);
           uint32_t mp = 0;
@@ -429,34 +473,43 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
       atomicAdd(&stat->summ, m);
       if (flagged) flist[atomicAdd(&stat->nflag, 1u)] = (uint32_t)c;
     }
-    __syncthreads();  // every reader of bm / hist / part is done
-    // bitmap of the tile (pass 2 turns the keys of flagged columns into NaN keys: nothing is collected there), then clear
+    // ---- pass 2's look-up table: one bit pair per regular index f (word f >> 4, bits 2 (f & 15)): bit 0 = "a sample
+    // with this f is a candidate" (interior f: 0 < f < f(hi), where the bin is f + 2 whatever the sample), bit 1 =
+    // "decide with the exact bin" (f = 0 and f >= f(hi), where one f covers several bins and one of them is marked)
+    {
+      const uint32_t fH = hs_findex(s.hif - s.lof, s.scale);
+      auto bmbit = [&](uint32_t b) -> uint32_t { return (bm[(b >> 5) * CW + col] >> (b & 31u)) & 1u; };
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        const int wq = rl * 4 + i;
+        const uint32_t bin0 = (uint32_t)wq * 16u + 2u;
+        const int wi = (int)(bin0 >> 5);
+        const uint32_t lo32 = bm[wi * CW + col];
+        const uint32_t hi32 = wi + 1 < 32 ? bm[(wi + 1) * CW + col] : 0u;
+        const uint64_t both = ((uint64_t)hi32 << 32) | lo32;
+        uint32_t word = hs_spread16((uint32_t)(both >> (bin0 & 31u)) & 0xFFFFu);
+        if (wq == 0 || (uint32_t)wq * 16u + 15u >= fH) {
+#pragma unroll 1
+          for (uint32_t e = 0; e < 16u; ++e) {
+            const uint32_t f = (uint32_t)wq * 16u + e;
+            const bool first = f == 0u, top = f >= fH && f < (uint32_t)HS_NREG;
+            if (!first && !top) continue;
+            uint32_t fl = 0u;
+            if (first) fl |= bmbit(0u) | bmbit(2u);
+            if (top) fl |= bmbit(f + 4u) | (f == fH ? bmbit(f + 2u) : 0u);
+            word = (word & ~(3u << (2u * e))) | (fl << (2u * e + 1u));
+          }
+        }
+        if (cvalid) tab_g[(tile * 64 + wq) * CW + col] = word;
+      }
+    }
+    __syncthreads();  // every reader of bm / h32 / part is done
+    // bitmap of the tile, then clear
     for (int i = tid; i < 32 * CW; i += NT) bitmap_g[tile * (32 * CW) + i] = bm[i];
     __syncthreads();
-    for (int i = tid; i < (HS_NB / 2) * CW + 32 * CW; i += NT) hist[i] = 0u;
+    for (int i = tid; i < HS_NB * 32 + 32 * CW; i += NT) h32[i] = 0u;
     __syncthreads();
   }
-}
-
-// diagnostics only (XH_HIST_GEOM): the bare streaming loop with CWT columns x (512 / CWT) row lanes per workgroup — what
-// does the access pattern itself sustain?  (32 columns: one 128-byte line per row and workgroup; 64: two; 128: four)
-template <int CWT, int HS_U>
-__global__ void __launch_bounds__(HS_NT, 4)
-k_hs_stream_test(const float* __restrict__ x, int T, int64_t C, int64_t st, HsStat* __restrict__ stat) {
-  constexpr int RLT = HS_NT / CWT;
-  const int tid = threadIdx.x, col = tid & (CWT - 1), rl = tid / CWT;
-  const int64_t ntiles = (C + CWT - 1) / CWT;
-  uint32_t dummy = 0;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t c = tile * CWT + col;
-    const bool cvalid = c < C;
-    const int64_t cc = cvalid ? c : C - 1;
-    hs_stream<HS_U, RLT>(x, T, st, cc, cvalid, rl, [&](const float (&v)[HS_U], const uint32_t (&k)[HS_U]) {
-#pragma unroll
-      for (int u = 0; u < HS_U; ++u) dummy ^= k[u];
-    });
-  }
-  if (dummy == 0x12345679u) atomicAdd(&stat->errors, 1u);
 }
 
 // ---- wave-wide bitonic sort of 64 * K keys held K per lane (element i = lane * K + r), ascending ---------------------
@@ -525,7 +578,7 @@ __device__ __forceinline__ void hs_sort_column(uint32_t* __restrict__ list, uint
 #pragma unroll
   for (int r = 0; r < K; ++r) {
     const uint32_t i = (uint32_t)(lane * K + r);
-    v[r] = i < m ? list[i] : HS_NANKEY;
+    v[r] = i < m ? hs_key(__uint_as_float(list[i])) : HS_NANKEY;  // the list holds the raw floats of pass 2
   }
   hs_wave_sort<K>(v, lane);
 #pragma unroll
@@ -572,88 +625,118 @@ __device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm,
   __builtin_amdgcn_wave_barrier();
 }
 
-// ---- pass 2: collect the keys of the target bins, sort them per column, pick + lerp -----------------------------------
-// LDS: cand [CW * 512] keys (the columns' lists back to back) | bm [32][CW] | cursor [CW] | tv [waves][64] picked keys | trash
-constexpr size_t hs_lds2(int cw) { return (size_t)cw * 512 * 4 + 32 * cw * 4 + cw * 4 + (size_t)(cw * HS_RL / 64) * 64 * 4 + 16; }
+// ---- pass 2: collect the samples of the target bins, sort them per column, pick + lerp ---------------------------------
+// LDS: cand [64 * 512] candidates (the columns' lists back to back) | tab [64][64] bit pairs per regular index | bm [32][64]
+// bin bitmap (exact path) | cursor [64] | colok [64] | tv [waves][64] picked keys
+constexpr size_t hs_lds2() {
+  return (size_t)HS_POOL * 4 + 64 * HS_CW * 4 + 32 * HS_CW * 4 + 2 * HS_CW * 4 + (size_t)(HS_NT / 64) * 64 * 4;
+}
 
-template <int HS_U, int CW, bool DEFER>
-__global__ void __launch_bounds__(CW * HS_RL, 4)
+// APPEND: how a batch's candidates reach the column's list — 0 = unconditional stores (a sample that is no candidate goes to
+// a trash word), 1 = `if` per sample (the compiler's exec-mask branches), 2 = v_cmpx + masked ds_write, no branch
+template <int APPEND>
+__global__ void __launch_bounds__(HS_NT, 4)
 k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2* __restrict__ lohi,
              const double* __restrict__ qs, int nq, const uint32_t* __restrict__ meta_n, const uint32_t* __restrict__ meta_m,
-             const uint32_t* __restrict__ meta_base, const uint16_t* __restrict__ crank, const uint32_t* __restrict__ bitmap_g, float* __restrict__ out, int64_t ocs,
-             int64_t oqs, HsStat* __restrict__ stat, int xcd_map, int abl, uint32_t* __restrict__ cand_g) {
-  constexpr int NT = CW * HS_RL, POOL = CW * 512;
+             const uint32_t* __restrict__ meta_base, const uint16_t* __restrict__ crank, const uint32_t* __restrict__ bitmap_g,
+             const uint32_t* __restrict__ tab_g, float* __restrict__ out, int64_t ocs, int64_t oqs, HsStat* __restrict__ stat,
+             int abl) {
+  constexpr int CW = HS_CW, NT = HS_NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* cand = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* bm = cand + POOL;
+  uint32_t* tab = cand + HS_POOL;
+  uint32_t* bm = tab + 64 * CW;
   uint32_t* cursor = bm + 32 * CW;
-  uint32_t* tvall = cursor + CW;
-  uint32_t* trash = tvall + (NT / 64) * 64;
+  uint32_t* colok = cursor + CW;
+  uint32_t* tvall = colok + CW;
   const int tid = threadIdx.x, col = tid & (CW - 1), rl = tid / CW;
   const int lane = tid & 63, wv = tid >> 6;
   const int ntgt = 2 * nq;
   const int64_t ntiles = (C + CW - 1) / CW;
-  if (tid == 0) tvall[0] = 0u;
   for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
-    const int64_t tile = hs_tile_of(round_base, ntiles, xcd_map);
+    const int64_t tile = hs_tile_of(round_base, ntiles);
     if (tile < 0) break;  // (block-uniform; only in the last round)
     const int64_t c = tile * CW + col;
     const bool cvalid = c < C;
     const int64_t cc = cvalid ? c : C - 1;
     const uint2 lh = lohi[cc];
     const HsScale s = hs_scale(lh.x, lh.y);
-    const uint32_t mymax = meta_m[cc];
-    const bool collect = cvalid && mymax != HS_FLAGGED;
-    for (int i = tid; i < 32 * CW; i += NT) bm[i] = bitmap_g[tile * (32 * CW) + i];
-    if (tid < CW) cursor[tid] = 0u;
+    const bool collect = cvalid && meta_m[cc] != HS_FLAGGED;
+    if (tid < CW) {
+      cursor[tid] = 0u;
+      colok[tid] = collect ? 0xFFFFFFFFu : 0u;  // (tid < CW: col == tid)
+    }
+    __syncthreads();
+    // the tile's tables; the columns nothing is collected for (flagged, past C) read all-zero tables
+    for (int i = tid; i < 64 * CW; i += NT) tab[i] = tab_g[tile * (64 * CW) + i] & colok[i & (CW - 1)];
+    for (int i = tid; i < 32 * CW; i += NT) bm[i] = bitmap_g[tile * (32 * CW) + i] & colok[i & (CW - 1)];
     __syncthreads();
     uint32_t* mylist = cand + (collect ? meta_base[cc] : 0u);
+    const uint32_t* mytab = tab + col;
     const uint32_t* mybm = bm + col;
-    hs_stream<HS_U, HS_RL>(x, T, st, cc, collect, rl, [&](const float (&v)[HS_U], const uint32_t (&k)[HS_U]) {
-      // all bins, then all bitmap words (16 LDS reads in flight), then ONE cursor atomic per lane and batch
-      uint32_t b[HS_U], w[HS_U];
+    hs_stream(x, T, st, cc, rl, [&](const float (&v)[HS_U]) {
+      // the regular index of every sample and its bit pair (16 LDS reads in flight); bit 1 anywhere in the wave: this
+      // batch is decided by the exact bins (NaN samples: f = 0, whose candidate bit is never set)
+      uint32_t sb[HS_U];
+      uint32_t acc = 0u;
 #pragma unroll
-      for (int u = 0; u < HS_U; ++u) b[u] = hs_bin(v[u], k[u], s);
-#pragma unroll
-      for (int u = 0; u < HS_U; ++u) w[u] = mybm[(b[u] >> 5) * CW];
-      uint32_t hit = 0;
-#pragma unroll
-      for (int u = 0; u < HS_U; ++u) hit |= (((w[u] >> (b[u] & 31u)) & 1u) & (hs_valid(k[u]) ? 1u : 0u)) << u;
-      if (__any(hit != 0u)) {
-        // one reservation per lane and batch; the stores are unconditional (a key that is no candidate goes to a trash
-        // word) — no exec-mask round trip per key.  pos < the column's count by construction (pass 1 counted the same bins).
-        uint32_t pos = atomicAdd(&cursor[col], (uint32_t)__popc(hit));
+      for (int u = 0; u < HS_U; ++u) {
+        const uint32_t f = hs_findex(v[u] - s.lof, s.scale);
+        sb[u] = mytab[(f >> 4) * CW] >> ((f << 1) & 31u);
+        acc |= sb[u];
+      }
+      if (__any((acc & 2u) != 0u)) {
 #pragma unroll
         for (int u = 0; u < HS_U; ++u) {
-          const uint32_t bit = (hit >> u) & 1u;
-          uint32_t* dst = bit ? mylist + pos : trash;
-          *dst = k[u];
-          pos += bit;
+          const uint32_t b = hs_bin(v[u], s);
+          const uint32_t w = mybm[(b >> 5) * CW] >> (b & 31u);
+          sb[u] = v[u] == v[u] ? w : 0u;
+        }
+      }
+      uint32_t cnt = 0u;
+#pragma unroll
+      for (int u = 0; u < HS_U; ++u) {
+        sb[u] &= 1u;
+        cnt += sb[u];
+      }
+      if (__any(cnt != 0u)) {
+        // one reservation per lane and batch.  pos < the column's count by construction (pass 1 counted the same bins).
+        uint32_t pos = atomicAdd(&cursor[col], cnt);
+        if (APPEND == 2) {
+          typedef __attribute__((address_space(3))) uint32_t lds_u32;
+          uint32_t addr = (uint32_t)(uintptr_t)(lds_u32*)(mylist + pos);
+#pragma unroll
+          for (int u = 0; u < HS_U; ++u) {
+            uint64_t sv;
+            asm volatile(
+                "s_mov_b64 %[sv], exec\n\t"
+                "v_cmpx_ne_u32_e32 0, %[bit]\n\t"
+                "ds_write_b32 %[addr], %[val]\n\t"
+                "v_add_u32_e32 %[addr], 4, %[addr]\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [addr] "+v"(addr), [sv] "=&s"(sv)
+                : [bit] "v"(sb[u]), [val] "v"(v[u])
+                : "vcc", "memory");
+          }
+        } else if (APPEND == 1) {
+#pragma unroll
+          for (int u = 0; u < HS_U; ++u) {
+            if (sb[u]) {
+              mylist[pos] = __float_as_uint(v[u]);
+              ++pos;
+            }
+          }
+        } else {  // unconditional stores: a sample that is no candidate goes to a trash word (tvall[0])
+#pragma unroll
+          for (int u = 0; u < HS_U; ++u) {
+            uint32_t* dst = sb[u] ? mylist + pos : tvall;
+            *dst = __float_as_uint(v[u]);
+            pos += sb[u];
+          }
         }
       }
     });
     __syncthreads();
-    if (DEFER) {
-      // one workgroup per CU (LDS): a sort in here would run with nothing streaming beside it.  The tile's candidate
-      // lists leave for global memory as they lie in the pool (one coalesced copy of ~1 % of the tile's bytes);
-      // k_hs_finish sorts them with the whole chip's VALUs.
-      uint32_t end = 0;
-      if (tid < CW) {
-        const int64_t ck = tile * CW + tid;
-        if (ck < C && meta_m[ck] != HS_FLAGGED) {
-          if (cursor[tid] != meta_m[ck]) atomicAdd(&stat->errors, 1u);
-          end = meta_base[ck] + meta_m[ck];
-        }
-        atomicMax(&tvall[0], end);
-      }
-      __syncthreads();
-      const uint32_t tot = tvall[0];
-      uint32_t* dst = cand_g + tile * (int64_t)POOL;
-      for (uint32_t i = tid; i < tot; i += NT) dst[i] = cand[i];
-      __syncthreads();
-      if (tid == 0) tvall[0] = 0u;
-      continue;
-    }
     // ---- one wave per column: sort, pick, lerp (utl:464-491), store
     uint32_t* tv = tvall + wv * 64;
     for (int k = wv; k < CW; k += NT / 64) {
@@ -664,64 +747,18 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
       const uint32_t m = cursor[k];
       if (m != mm && lane == 0) atomicAdd(&stat->errors, 1u);
       uint32_t* list = cand + meta_base[ck];
+      const uint32_t ms = m < mm ? m : mm;
       if (abl & 1) {
-      } else if (m > 1024u) hs_sort_column<32>(list, m < mm ? m : mm, lane);
-      else if (m > 512u) hs_sort_column<16>(list, m, lane);
-      else if (m > 256u) hs_sort_column<8>(list, m, lane);
-      else if (m > 128u) hs_sort_column<4>(list, m, lane);
-      else if (m > 64u) hs_sort_column<2>(list, m, lane);
-      else if (m > 1u) hs_sort_column<1>(list, m, lane);
+      } else if (ms > 1024u) hs_sort_column<32>(list, ms, lane);
+      else if (ms > 512u) hs_sort_column<16>(list, ms, lane);
+      else if (ms > 256u) hs_sort_column<8>(list, ms, lane);
+      else if (ms > 128u) hs_sort_column<4>(list, ms, lane);
+      else if (ms > 64u) hs_sort_column<2>(list, ms, lane);
+      else if (ms > 0u) hs_sort_column<1>(list, ms, lane);  // (one candidate: only turned into its key)
       __builtin_amdgcn_wave_barrier();
       hs_pick_store<CW>(list, mm, tile, k, ck, lane, ntgt, nq, qs, meta_n, lohi, crank, tv, out, ocs, oqs);
     }
-    __syncthreads();  // cand / bm / cursor are rewritten by the next tile
-  }
-}
-
-// ---- pass 3 (deferred form of the epilogue above): one wave per column sorts its candidates in registers ----------------
-template <int K>
-__device__ __forceinline__ void hs_sort_global(const uint32_t* __restrict__ src, uint32_t* buf, uint32_t m, int lane) {
-  uint32_t v[K];
-#pragma unroll
-  for (int r = 0; r < K; ++r) {  // element i = r * 64 + lane on the way in (coalesced); the sort does not care
-    const uint32_t i = (uint32_t)(r * 64 + lane);
-    v[r] = i < m ? src[i] : HS_NANKEY;
-  }
-  hs_wave_sort<K>(v, lane);
-#pragma unroll
-  for (int r = 0; r < K; ++r) buf[lane * K + r] = v[r];
-}
-
-// BIG = false: the columns with at most 512 candidates (2 KB of LDS per wave: many waves per CU hide the chain of
-// dependent loads meta -> list -> positions); BIG = true: the few larger ones.
-template <int CW, bool BIG>
-__global__ void __launch_bounds__(256)
-k_hs_finish(const uint32_t* __restrict__ cand_g, int64_t C, const uint2* __restrict__ lohi, const double* __restrict__ qs, int nq,
-            const uint32_t* __restrict__ meta_n, const uint32_t* __restrict__ meta_m, const uint32_t* __restrict__ meta_base,
-            const uint16_t* __restrict__ crank, float* __restrict__ out, int64_t ocs, int64_t oqs) {
-  constexpr int POOL = CW * 512;
-  __shared__ uint32_t sorted[4][BIG ? HS_CAPMAX : 512];
-  __shared__ uint32_t tvs[4][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int ntgt = 2 * nq;
-  for (int64_t ck = (int64_t)blockIdx.x * 4 + wv; ck < C; ck += (int64_t)gridDim.x * 4) {
-    const uint32_t mm = meta_m[ck];
-    if (mm == HS_FLAGGED || (mm > 512u) != BIG) continue;
-    const int64_t tile = ck / CW;
-    const int k = (int)(ck - tile * CW);
-    const uint32_t* src = cand_g + tile * (int64_t)POOL + meta_base[ck];
-    uint32_t* buf = sorted[wv];
-    if (BIG) {
-      if (mm > 1024u) hs_sort_global<32>(src, buf, mm, lane);
-      else hs_sort_global<16>(src, buf, mm, lane);
-    } else {
-      if (mm > 256u) hs_sort_global<8>(src, buf, mm, lane);
-      else if (mm > 128u) hs_sort_global<4>(src, buf, mm, lane);
-      else if (mm > 64u) hs_sort_global<2>(src, buf, mm, lane);
-      else hs_sort_global<1>(src, buf, mm, lane);
-    }
-    __builtin_amdgcn_wave_barrier();
-    hs_pick_store<CW>(buf, mm, tile, k, ck, lane, ntgt, nq, qs, meta_n, lohi, crank, tvs[wv], out, ocs, oqs);
+    __syncthreads();  // cand / tab / bm / cursor are rewritten by the next tile
   }
 }
 
@@ -749,30 +786,23 @@ k_hs_scatter(const float* __restrict__ tmp, int64_t nf, int nq, const uint32_t* 
 // many columns would need the column kernels (the caller then takes the transposed pipeline of eqm.hip for everything).
 int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq, float* out,
                    int64_t out_cstride, int64_t out_qstride) {
-  if (T <= 1024 || T > 32768 || nq < 1 || nq > HS_MAXQ || C < 1) return XH_ERR_NOTIMPL;  // (32768: the column kernels' limit)
-  if ((unsigned long long)((HS_RL * 32 + HS_RL) * st + C) * 4ull >= (1ull << 32)) return XH_ERR_NOTIMPL;  // 32-bit offsets inside a batch (U <= 32)
+  if (T <= 1024 || T > 65535 || nq < 1 || nq > HS_MAXQ || C < 1) return XH_ERR_NOTIMPL;  // (65535: u16 counters)
+  if ((unsigned long long)((HS_RL * 32 + HS_RL) * st + C) * 4ull >= (1ull << 32)) return XH_ERR_NOTIMPL;  // 32-bit offsets inside a batch
   if (xh_diag_env("XH_SELECT_NOHIST")) return XH_ERR_NOTIMPL;  // A/B against the transposed pipeline
-  // columns per workgroup: 64 (1024 threads, one workgroup per CU, 256-byte row segments: the bare streaming loop runs
-  // at 6.2 TB/s against 5.3 TB/s with 32 columns / 128-byte segments, profiles/r03/select_hist_geometry.txt)
-  const char* ecw = xh_diag_env("XH_HIST_CW");
-  const int CWH = (ecw && atoi(ecw) == 32) ? 32 : 64;
-  const int64_t ntiles = cdiv64(C, CWH);
+  const int64_t ntiles = cdiv64(C, HS_CW);
   const int ntgt = 2 * nq;
-  // fallback capacity: flagged columns are recomputed from a gathered copy; more than that -> everything the old way
+  // fallback capacity: flagged columns are recomputed from a gathered copy, at most `nfmax` of them at a time
   const int64_t Tp = (T + 63) & ~(int64_t)63;
-  int64_t nfmax = C < 4096 ? C : 4096;
+  int64_t nfmax = T > 32768 ? 1024 : 4096;
+  if (nfmax > C) nfmax = C;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t b_lohi = al(sizeof(uint2) * (size_t)C), b_n = al(4 * (size_t)C), b_m = al(4 * (size_t)C), b_base = al(4 * (size_t)C);
-  const size_t b_crank = al(2 * (size_t)ntiles * ntgt * CWH), b_bm = al(4 * (size_t)ntiles * 32 * CWH);
+  const size_t b_crank = al(2 * (size_t)ntiles * ntgt * HS_CW), b_bm = al(4 * (size_t)ntiles * 32 * HS_CW);
+  const size_t b_tab = al(4 * (size_t)ntiles * 64 * HS_CW);
   const size_t b_flist = al(4 * (size_t)C), b_stat = al(sizeof(HsStat));
   const size_t b_gather = al(4 * (size_t)nfmax * (size_t)Tp), b_tmp = al(4 * (size_t)nfmax * (size_t)nq);
-  // diagnostics: XH_HIST_DEFER=1 moves the per-column sort out of pass 2 into k_hs_finish (measured on config 4 with the
-  // DPP sort: 9.27 + 1.29 ms against 10.71 ms inline — no gain, and it needs 2 GB of scratch: off)
-  const char* edf = xh_diag_env("XH_HIST_DEFER");
-  const bool defer = CWH == 64 && edf && atoi(edf) == 1;
-  const size_t b_cand = defer ? al(4 * (size_t)ntiles * (size_t)CWH * 512) : 0;
   void* ws = nullptr;
-  int rc = xh_big_scratch(ctx, b_lohi + b_n + b_m + b_base + b_crank + b_bm + b_flist + b_stat + b_gather + b_tmp + b_cand, &ws);
+  int rc = xh_big_scratch(ctx, b_lohi + b_n + b_m + b_base + b_crank + b_bm + b_tab + b_flist + b_stat + b_gather + b_tmp, &ws);
   if (rc) return rc;
   char* p = (char*)ws;
   uint2* lohi = (uint2*)p; p += b_lohi;
@@ -781,11 +811,11 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   uint32_t* meta_base = (uint32_t*)p; p += b_base;
   uint16_t* crank = (uint16_t*)p; p += b_crank;
   uint32_t* bitmap_g = (uint32_t*)p; p += b_bm;
+  uint32_t* tab_g = (uint32_t*)p; p += b_tab;
   uint32_t* flist = (uint32_t*)p; p += b_flist;
   HsStat* stat = (HsStat*)p; p += b_stat;
   float* gbuf = (float*)p; p += b_gather;
   float* gtmp = (float*)p; p += b_tmp;
-  uint32_t* cand_g = defer ? (uint32_t*)p : nullptr;
   XH_CHECK_HIP(hipMemsetAsync(stat, 0, sizeof(HsStat), ctx->stream));
   // pass 0
   int64_t S = T / 342;
@@ -800,57 +830,27 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
     XH_LAUNCH_CHECK();
   }
   int64_t nblk = ntiles;
-  const int64_t maxblk = (int64_t)ctx->num_cu * (CWH == 32 ? 2 : 1);  // LDS: two 512-thread or one 1024-thread workgroup per CU
+  const int64_t maxblk = (int64_t)ctx->num_cu;  // LDS: one 1024-thread workgroup per CU
   if (nblk > maxblk) nblk = maxblk;
-  if (nblk >= 8) nblk &= ~(int64_t)7;  // the XCD-aware tile map wants a multiple of 8 (the tile loop is grid-strided)
-  const int xcd_map = xh_diag_env("XH_HIST_XCD") ? 1 : 0;  // measured on config 4: 42.8 ms with the map, 41.3 without -> off
   const char* eabl = xh_diag_env("XH_HIST_ABL");  // diagnostics: 1 = no candidate sort, 2 = pass 1 loads only, 4 = no pass-1 tile epilogue (wrong results)
   const int abl = eabl ? atoi(eabl) : 0;
-  {
-    const char* g = xh_diag_env("XH_HIST_GRID");  // diagnostics: workgroups per CU
-    if (g && atoi(g) > 0 && (int64_t)ctx->num_cu * atoi(g) < ntiles) nblk = (int64_t)ctx->num_cu * atoi(g);
+  const char* eap = xh_diag_env("XH_HIST_APPEND");  // diagnostics: 0 | 1 | 2, see k_hs_collect
+  const int append = eap ? atoi(eap) : 2;
+  XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds1()));
+  hipLaunchKernelGGL(k_hs_hist, dim3((unsigned)nblk), dim3(HS_NT), hs_lds1(), ctx->stream, x, (int)T, C, st, lohi, d_q, nq, meta_n,
+                     meta_m, meta_base, crank, bitmap_g, tab_g, flist, stat, abl);
+  XH_LAUNCH_CHECK();
+#define XH_HS_COLLECT(AP)                                                                                                        \
+  {                                                                                                                             \
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<AP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2())); \
+    hipLaunchKernelGGL((k_hs_collect<AP>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds2(), ctx->stream, x, (int)T, C, st, lohi, d_q,  \
+                       nq, meta_n, meta_m, meta_base, crank, bitmap_g, tab_g, out, out_cstride, out_qstride, stat, abl);         \
   }
-  if (const char* eg = xh_diag_env("XH_HIST_GEOM")) {  // diagnostics: time the bare streaming loop in another geometry, then go on
-    const int g = atoi(eg);
-    const int64_t nt = cdiv64(C, g);
-    int64_t nb = nt < maxblk ? nt : maxblk;
-    if (g == 64) hipLaunchKernelGGL((k_hs_stream_test<64, 16>), dim3((unsigned)nb), dim3(HS_NT), 0, ctx->stream, x, (int)T, C, st, stat);
-    else if (g == 128) hipLaunchKernelGGL((k_hs_stream_test<128, 16>), dim3((unsigned)nb), dim3(HS_NT), 0, ctx->stream, x, (int)T, C, st, stat);
-    else if (g == 256) hipLaunchKernelGGL((k_hs_stream_test<256, 16>), dim3((unsigned)nb), dim3(HS_NT), 0, ctx->stream, x, (int)T, C, st, stat);
-    else hipLaunchKernelGGL((k_hs_stream_test<32, 16>), dim3((unsigned)nb), dim3(HS_NT), 0, ctx->stream, x, (int)T, C, st, stat);
-    XH_LAUNCH_CHECK();
-  }
-  const char* eu = xh_diag_env("XH_HIST_U");  // diagnostics: loads in flight per register set (8 | 16)
-  const int U = eu ? atoi(eu) : HS_UDEF;
-#define XH_HS_LAUNCH(UU, CC, DD)                                                                                                      \
-  {                                                                                                                                  \
-    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist<UU, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds1(CC))); \
-    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<UU, CC, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2(CC))); \
-    hipLaunchKernelGGL((k_hs_hist<UU, CC>), dim3((unsigned)nblk), dim3(CC * HS_RL), hs_lds1(CC), ctx->stream, x, (int)T, C, st, lohi,  \
-                       d_q, nq, meta_n, meta_m, meta_base, crank, bitmap_g, flist, stat, xcd_map, abl);                              \
-    XH_LAUNCH_CHECK();                                                                                                               \
-    hipLaunchKernelGGL((k_hs_collect<UU, CC, DD>), dim3((unsigned)nblk), dim3(CC * HS_RL), hs_lds2(CC), ctx->stream, x, (int)T, C, st, \
-                       lohi, d_q, nq, meta_n, meta_m, meta_base, crank, bitmap_g, out, out_cstride, out_qstride, stat, xcd_map, abl,  \
-                       cand_g);                                                                                                      \
-    XH_LAUNCH_CHECK();                                                                                                               \
-  }
-  if (CWH == 32 && U == 8) XH_HS_LAUNCH(8, 32, false)
-  else if (CWH == 32) XH_HS_LAUNCH(16, 32, false)
-  else if (U == 8 && defer) XH_HS_LAUNCH(8, 64, true)
-  else if (U == 8) XH_HS_LAUNCH(8, 64, false)
-  else if (defer) XH_HS_LAUNCH(16, 64, true)
-  else XH_HS_LAUNCH(16, 64, false)
-  if (defer) {
-    int64_t fb = cdiv64(C, 4);
-    if (fb > (int64_t)ctx->num_cu * 64) fb = (int64_t)ctx->num_cu * 64;
-    hipLaunchKernelGGL((k_hs_finish<64, false>), dim3((unsigned)fb), dim3(256), 0, ctx->stream, cand_g, C, lohi, d_q, nq, meta_n,
-                       meta_m, meta_base, crank, out, out_cstride, out_qstride);
-    XH_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_hs_finish<64, true>), dim3((unsigned)fb), dim3(256), 0, ctx->stream, cand_g, C, lohi, d_q, nq, meta_n,
-                       meta_m, meta_base, crank, out, out_cstride, out_qstride);
-    XH_LAUNCH_CHECK();
-  }
-#undef XH_HS_LAUNCH
+  if (append == 0) XH_HS_COLLECT(0)
+  else if (append == 1) XH_HS_COLLECT(1)
+  else XH_HS_COLLECT(2)
+#undef XH_HS_COLLECT
+  XH_LAUNCH_CHECK();
   HsStat h;
   XH_CHECK_HIP(hipMemcpyAsync(&h, stat, sizeof(HsStat), hipMemcpyDeviceToHost, ctx->stream));
   XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -858,14 +858,17 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
              h.errors);
   if (xh_diag_env("XH_HIST_STATS")) fprintf(stderr, "[xh_select_hist] T=%lld C=%lld flagged=%u candidates: max %u mean %.1f\n", (long long)T, (long long)C, h.nflag, h.maxm, (double)h.summ / (double)C);
   if (h.nflag == 0) return XH_OK;
-  if ((int64_t)h.nflag > nfmax) return XH_ERR_NOTIMPL;  // the caller recomputes everything with the transposed pipeline
-  const int64_t nf = h.nflag;
-  hipLaunchKernelGGL(k_hs_gather, dim3((unsigned)nf), dim3(XH_BLOCK), 0, ctx->stream, x, T, st, flist, gbuf, Tp);
-  XH_LAUNCH_CHECK();
-  rc = xh_select_columns(ctx, gbuf, T, nf, Tp, d_q, nq, gtmp, 1, nf);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_hs_scatter, dim3((unsigned)cdiv64(nf * nq, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, gtmp, nf, nq, flist,
-                     out, out_cstride, out_qstride);
-  XH_LAUNCH_CHECK();
+  // up to 32768 steps the transposed pipeline is the better answer when MANY columns are flagged (heavily tied fields)
+  if (T <= 32768 && (int64_t)h.nflag > nfmax) return XH_ERR_NOTIMPL;
+  for (int64_t f0 = 0; f0 < (int64_t)h.nflag; f0 += nfmax) {
+    const int64_t nf = (int64_t)h.nflag - f0 < nfmax ? (int64_t)h.nflag - f0 : nfmax;
+    hipLaunchKernelGGL(k_hs_gather, dim3((unsigned)nf), dim3(XH_BLOCK), 0, ctx->stream, x, T, st, flist + f0, gbuf, Tp);
+    XH_LAUNCH_CHECK();
+    rc = xh_select_columns(ctx, gbuf, T, nf, Tp, d_q, nq, gtmp, 1, nf);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_hs_scatter, dim3((unsigned)cdiv64(nf * nq, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, gtmp, nf, nq,
+                       flist + f0, out, out_cstride, out_qstride);
+    XH_LAUNCH_CHECK();
+  }
   return XH_OK;
 }
