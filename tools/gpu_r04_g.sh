@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round 4, call G: granularity of the streaming ring (loads per set x sets), same box.
+set -u
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04h; rm -rf $O; mkdir -p $O
+export XH_DIAGNOSTICS=1
+cd /tmp && export TMPDIR=/tmp
+run() {  # tag, env...
+  tag=$1; shift
+  env "$@" timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/$tag -o s -- python $GRAFT_REPO_ROOT/tools/bench_c4.py > $GRAFT_REPO_ROOT/$O/$tag.log 2>&1
+  echo "$tag: $(python $GRAFT_REPO_ROOT/tools/kstats.py $GRAFT_REPO_ROOT/$O/$tag 5 | grep -E 'k_hs_' | grep -v sample | awk '{n=$1; if (n=="void") n=$2" "$3; print substr(n,20,24), $(NF-1)}' | tr '\n' '|') $(grep -h train_ms $GRAFT_REPO_ROOT/$O/$tag.log | cut -c27-50)" | tee -a $GRAFT_REPO_ROOT/$O/summary.txt
+  find $GRAFT_REPO_ROOT/$O/$tag -type f ! -name "*kernel_stats.csv" -delete
+}
+for r in 162 85 86 87 48 410 412 85; do
+  run full_$r XH_HIST_RING=$r
+  run loads_$r XH_HIST_RING=$r XH_HIST_ABL=70
+done

@@ -38,8 +38,8 @@
 //     execution mask and become keys when they are sorted.
 //
 // Geometry: a 1024-thread workgroup owns 64 adjacent columns (256-byte row segments) and 16 "row lanes" per column;
-// thread (column c, row lane r) loads rows r, r + 16, r + 32 ... with 16 loads in flight, double buffered.  One
-// workgroup per CU (LDS).  Algorithmic bytes per pass: 4E; nothing else crosses HBM except ~600 bytes of per-column
+// thread (column c, row lane r) loads rows r, r + 16, r + 32 ... through a ring of 5 register sets of 8 loads (32 to 40
+// in flight per lane).  One workgroup per CU (LDS).  Algorithmic bytes per pass: 4E; nothing else crosses HBM except ~600 bytes of per-column
 // tables.
 //
 // Columns whose target bins hold more than 2048 keys, or that do not fit the tile's 32768-key LDS pool (heavily tied or
@@ -54,7 +54,7 @@ namespace {
 constexpr int HS_RL = 16;              // row lanes per column
 constexpr int HS_CW = 64;              // columns per workgroup
 constexpr int HS_NT = HS_CW * HS_RL;   // threads per workgroup
-constexpr int HS_U = 16;               // loads in flight per thread and register set (two sets: ping-pong)
+constexpr int HS_UMAX = 16;            // loads per register set of the streaming ring (template parameter U: 8 | 16)
 constexpr int HS_NB = 1024;            // bins per column
 constexpr int HS_NREG = 1020;          // regular indices f = 0 .. 1019
 constexpr int HS_POOL = HS_CW * 512;   // candidate keys of one tile in LDS
@@ -210,72 +210,93 @@ k_hs_sample(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int64
 // ---- the streaming loop shared by pass 1 and pass 2 ------------------------------------------------------------------
 // Thread (col, rl) of a tile visits rows rl, rl + 16, ... in batches of HS_U rows; f(values) is called once per batch.
 // Rows past the end of the series arrive as NaN (the callers skip NaN samples anyway).
-template <typename F>
-__device__ __forceinline__ void hs_stream(const float* __restrict__ x, int T, int64_t st, int64_t cc, int rl, F&& f) {
-  constexpr int HS_ROWS = HS_RL * HS_U;  // rows a workgroup covers per batch
-  // full batches: every row of the batch exists for every row lane.  Buffer loads: a descriptor re-based per batch
-  // (scalar), the row offset of load u as the scalar offset, ONE 32-bit per-lane byte offset — no vector address
-  // arithmetic and no 64-bit address registers per load (16 loads in flight would hold 32 of them).
-  const uint32_t voff = (uint32_t)(((int64_t)rl * st + cc) * 4);
-  const uint32_t rowstep = (uint32_t)(st * 4 * HS_RL);  // bytes between the rows of loads u and u + 1 (host: 256 rows < 4 GiB)
-  const int nfull = T / HS_ROWS;
-  auto load = [&](float (&dst)[HS_U], int kb) {
-    const float* base = x + (int64_t)kb * HS_ROWS * st;
+//
+// A RING of NSET register sets (no copies: a copy of one set into another right after element u is consumed would make
+// element u wait for the load that was issued a moment ago): while one set is consumed, the loads of NSET - 1 batches
+// fly.  Round 4 measurements on config 4 (profiles/r04/select4_anatomy.txt): the bare loop streams at 6.0 TB/s whatever
+// the occupancy, but every microsecond a wave spends away from it (LDS latency chains, the tile epilogues) comes on top —
+// one workgroup per CU, nothing else to run.  5 sets of 8 (32 to 40 loads per lane in flight, re-requested every 8
+// samples) against round 3's 2 sets of 16: config-4 train 40.5 -> 37 ms.  prime() requests the first NSET - 1 batches
+// of a tile; the kernels CAN call it for the next tile before they start a tile's epilogue (template flag EARLY), so
+// that the epilogue runs under flying loads — measured: no gain, off.
+template <int HS_U, int NSET, int RLT = HS_RL>
+struct HsRing {
+  static constexpr int ROWS = RLT * HS_U;  // rows a workgroup covers per batch
+  float S[NSET][HS_U];
+
+  // Buffer loads: a descriptor re-based per batch (scalar), the row offset of load u as the scalar offset, ONE 32-bit
+  // per-lane byte offset — no vector address arithmetic and no 64-bit address registers per load.
+  __device__ __forceinline__ void load(float (&dst)[HS_U], const float* __restrict__ x, int64_t st, uint32_t voff, int kb) {
+    const float* base = x + (int64_t)kb * ROWS * st;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)0xFFFFFFFFu, 0x00020000);
+    const uint32_t rowstep = (uint32_t)(st * 4 * RLT);  // bytes between the rows of loads u and u + 1 (host: 256 rows < 4 GiB)
     uint32_t soff = 0u;
 #pragma unroll
     for (int u = 0; u < HS_U; ++u) {
       dst[u] = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
       soff += rowstep;
     }
-  };
-  if (nfull > 0) {
-    // two register sets, ping-pong (no copies: a copy of set B into set A right after element u is consumed would make
-    // element u wait for the load that was issued a moment ago): the loads of one batch fly while the other is consumed
-    float A[HS_U], B[HS_U];
-    load(A, 0);
-    int kb = 0;
-    while (kb + 2 < nfull) {  // no conditional loads in here: the compiler counts the outstanding loads exactly
-      load(B, kb + 1);
-      f(A);
-      load(A, kb + 2);
-      f(B);
-      kb += 2;
+  }
+
+  __device__ __forceinline__ void prime(const float* __restrict__ x, int T, int64_t st, int64_t cc, int rl) {
+    const uint32_t voff = (uint32_t)(((int64_t)rl * st + cc) * 4);
+    const int nfull = T / ROWS;
+#pragma unroll
+    for (int i = 0; i < NSET - 1; ++i)
+      if (i < nfull) load(S[i], x, st, voff, i);
+  }
+
+  // (prime() with the same arguments came first)
+  template <typename F>
+  __device__ __forceinline__ void run(const float* __restrict__ x, int T, int64_t st, int64_t cc, int rl, F&& f) {
+    const uint32_t voff = (uint32_t)(((int64_t)rl * st + cc) * 4);
+    const int nfull = T / ROWS;
+    int done = 0;
+    // steady state: no conditional loads (the compiler counts the outstanding loads exactly)
+    while (done + 2 * NSET - 1 <= nfull) {
+#pragma unroll
+      for (int i = 0; i < NSET; ++i) {
+        load(S[(i + NSET - 1) % NSET], x, st, voff, done + i + NSET - 1);
+        f(S[i]);
+      }
+      done += NSET;
     }
-    if (kb + 1 < nfull) {
-      load(B, kb + 1);
-      f(A);
-      f(B);
-    } else {
-      f(A);
+    // drain: at most 2 NSET - 2 batches are left, NSET - 1 of them already requested (done % NSET == 0: static sets)
+#pragma unroll
+    for (int i = 0; i < 2 * NSET - 2; ++i) {
+      if (done + i < nfull) {
+        if (done + i + NSET - 1 < nfull) load(S[(i + NSET - 1) % NSET], x, st, voff, done + i + NSET - 1);
+        f(S[i % NSET]);
+      }
+    }
+    // tail rows (fewer than a batch): same buffer loads from CLAMPED per-lane rows, validity applied afterwards (a
+    // conditional load costs a full s_waitcnt vmcnt(0)).  rl passes through an opaque copy: hoisted out of the tile
+    // loop, the clamped offsets would stay live (and spill) across the whole kernel.
+    const int t0 = nfull * ROWS;
+    if (t0 < T) {
+      int rlo = rl;
+      asm volatile("" : "+v"(rlo));
+      const int rem = T - t0;
+      const float* base = x + (int64_t)t0 * st;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)0xFFFFFFFFu, 0x00020000);
+      float buf[HS_U];
+#pragma unroll
+      for (int u = 0; u < HS_U; ++u) {
+        int r = u * RLT + rlo;
+        r = r < rem ? r : rem - 1;
+        const uint32_t vo = (uint32_t)r * (uint32_t)(st * 4) + (uint32_t)(cc * 4);
+        buf[u] = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, 0, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < HS_U; ++u) buf[u] = u * RLT + rlo < rem ? buf[u] : xh_nan32();
+      f(buf);
     }
   }
-  // tail rows (fewer than 256): same buffer loads from CLAMPED per-lane rows, validity applied afterwards (a conditional
-  // load costs a full s_waitcnt vmcnt(0)).  rl passes through an opaque copy: hoisted out of the tile loop, the 16
-  // clamped offsets would stay live (and spill) across the whole kernel.
-  const int t0 = nfull * HS_ROWS;
-  if (t0 < T) {
-    int rlo = rl;
-    asm volatile("" : "+v"(rlo));
-    const int rem = T - t0;
-    const float* base = x + (int64_t)t0 * st;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)0xFFFFFFFFu, 0x00020000);
-    float buf[HS_U];
-#pragma unroll
-    for (int u = 0; u < HS_U; ++u) {
-      int r = u * HS_RL + rlo;
-      r = r < rem ? r : rem - 1;
-      const uint32_t vo = (uint32_t)r * (uint32_t)(st * 4) + (uint32_t)(cc * 4);
-      buf[u] = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo, 0, 0));
-    }
-#pragma unroll
-    for (int u = 0; u < HS_U; ++u) buf[u] = u * HS_RL + rlo < rem ? buf[u] : xh_nan32();
-    f(buf);
-  }
-}
+};
 
 // NaN anywhere in the batch of this WAVE?  One float add per sample (NaN propagates; +inf and -inf in one lane's batch
 // give a false alarm, which only costs the exact path).
+template <int HS_U>
 __device__ __forceinline__ bool hs_wave_has_nan(const float (&v)[HS_U]) {
   // two sequential chains: a tree makes the compiler pair the operands for v_pk_add_f32 (16 v_mov to line them up)
   float a = v[0], b = v[1];
@@ -292,6 +313,31 @@ __device__ __forceinline__ bool hs_wave_has_nan(const float (&v)[HS_U]) {
 __device__ __forceinline__ int64_t hs_tile_of(int64_t round_base, int64_t ntiles) {
   const int64_t tile = round_base + blockIdx.x;
   return tile < ntiles ? tile : -1;
+}
+
+// diagnostics only (XH_HIST_GEOM): the bare streaming loop with 64 columns x RLT row lanes per workgroup and `lds` bytes of
+// dynamic LDS (= how many workgroups a CU holds): what does the access pattern itself sustain at which occupancy?
+template <int RLT, int NSET, int HS_U = 16>
+__global__ void __launch_bounds__(HS_CW * RLT)
+k_hs_stream_test(const float* __restrict__ x, int T, int64_t C, int64_t st, HsStat* __restrict__ stat) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, col = tid & (HS_CW - 1), rl = tid / HS_CW;
+  const int64_t ntiles = (C + HS_CW - 1) / HS_CW;
+  float dummy = 0.0f;
+  HsRing<HS_U, NSET, RLT> ring;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t c = tile * HS_CW + col;
+    const int64_t cc = c < C ? c : C - 1;
+    ring.prime(x, T, st, cc, rl);
+    ring.run(x, T, st, cc, rl, [&](const float (&v)[HS_U]) {
+#pragma unroll
+      for (int u = 0; u < HS_U; ++u) dummy += v[u];
+    });
+  }
+  if (dummy == 0.12345f) {
+    atomicAdd(&stat->errors, 1u);
+    smem[tid] = 1;
+  }
 }
 
 // ---- pass 1: histogram + target bins -----------------------------------------------------------------------------------
@@ -311,6 +357,7 @@ __device__ __forceinline__ uint32_t hs_spread16(uint32_t x) {
   return x;
 }
 
+template <int HS_U, int NSET, bool EARLY>
 __global__ void __launch_bounds__(HS_NT, 4)
 k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2* __restrict__ lohi,
           const double* __restrict__ qs, int nq, uint32_t* __restrict__ meta_n, uint32_t* __restrict__ meta_m,
@@ -333,12 +380,20 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
   // zero the histogram and the bitmap (again at the end of every tile)
   for (int i = tid; i < HS_NB * 32 + 32 * CW; i += NT) h32[i] = 0u;
   __syncthreads();
+  HsRing<HS_U, NSET> ring;
+  auto col_of = [&](int64_t t) -> int64_t {  // the column this thread reads in tile t (the last one for a column past C)
+    const int64_t c_ = t * CW + col;
+    return c_ < C ? c_ : C - 1;
+  };
+  constexpr bool early = EARLY;  // request a tile's first batches before the PREVIOUS tile's epilogue (or when its turn comes)
+  if (early && (int64_t)blockIdx.x < ntiles) ring.prime(x, T, st, col_of(blockIdx.x), rl);
   for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
     const int64_t tile = hs_tile_of(round_base, ntiles);
     if (tile < 0) break;  // (block-uniform; only in the last round)
     const int64_t c = tile * CW + col;
     const bool cvalid = c < C;
     const int64_t cc = cvalid ? c : C - 1;
+    if (!early) ring.prime(x, T, st, cc, rl);
     const uint2 lh = lohi[cc];
     const HsScale s = hs_scale(lh.x, lh.y);
     // this lane's counter of bin b is the half `col & 1` of word [b][col >> 1]; a column past C adds zeros.  Row 2 of
@@ -346,28 +401,39 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
     uint32_t* mycol = h32 + 2 * 32 + (col >> 1);
     const uint32_t one = cvalid ? (1u << sh16) : 0u;
     float dummy = 0.0f;
-    hs_stream(x, T, st, cc, rl, [&](const float (&v)[HS_U]) {
+    ring.run(x, T, st, cc, rl, [&](const float (&v)[HS_U]) {
       if (abl & 2) {  // diagnostics: loads only
 #pragma unroll
         for (int u = 0; u < HS_U; ++u) dummy += v[u];
         return;
       }
-      if (!hs_wave_has_nan(v)) {
+      // (groups of four samples between scheduling barriers: with all 16 in flight at once the temporaries of the bin
+      // arithmetic push the register sets of the streaming ring out into scratch)
+      if (!hs_wave_has_nan<HS_U>(v)) {
 #pragma unroll
-        for (int u = 0; u < HS_U; ++u) atomicAdd(mycol + hs_bin_m2(v[u], s) * 32, one);
+        for (int u = 0; u < HS_U; ++u) {
+          atomicAdd(mycol + hs_bin_m2(v[u], s) * 32, one);
+          if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
       } else {
 #pragma unroll
-        for (int u = 0; u < HS_U; ++u) atomicAdd(mycol + hs_bin_m2(v[u], s) * 32, v[u] == v[u] ? one : 0u);
+        for (int u = 0; u < HS_U; ++u) {
+          atomicAdd(mycol + hs_bin_m2(v[u], s) * 32, v[u] == v[u] ? one : 0u);
+          if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
       }
     });
     if ((abl & 2) && dummy == 0.12345f) atomicAdd(&stat->errors, 1u);
+    if (early && tile + (int64_t)gridDim.x < ntiles) ring.prime(x, T, st, col_of(tile + gridDim.x), rl);  // the epilogue runs under these loads
     __syncthreads();
     if (abl & 4) continue;  // diagnostics: no tile epilogue (wrong results, the histogram is not even cleared)
     // ---- exclusive prefix sums over the bins, in place and PACKED (two columns per word; every half stays <= T <= 65535):
     // thread (pw, prt) owns the words of bins [prt * 32, prt * 32 + 32) of column pair pw
     uint32_t ssum = 0;
+    if (!(abl & 1024)) {
 #pragma unroll 8
     for (int i = 0; i < 32; ++i) ssum += h32[(prt * 32 + i) * 32 + pw];
+    }
     part[prt * 32 + pw] = ssum;
     __syncthreads();
     uint32_t run = 0;
@@ -376,12 +442,14 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
       const uint32_t p = part[r * 32 + pw];
       run += r < prt ? p : 0u;
     }
+    if (!(abl & 1024)) {
 #pragma unroll 8
     for (int i = 0; i < 32; ++i) {
       const int idx = (prt * 32 + i) * 32 + pw;
       const uint32_t w = h32[idx];
       h32[idx] = run;  // samples in the bins below this one
       run += w;
+    }
     }
     if (prt == 31) ntot[pw] = run;
     __syncthreads();
@@ -395,7 +463,7 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
     // ---- the bin and the rank inside it of every target; mark the bins that need a second look
     for (int j = rl; j < ntgt; j += HS_RL) {
       uint32_t e = HS_SPEC_NONE;
-      if (n > 0u) {
+      if (n > 0u && !(abl & 128)) {
         const uint32_t r = hs_rank(n, qs[j >> 1], j & 1);
         uint32_t lo_b = 0u, hi_b = HS_NB - 1;  // largest b with below(b) <= r: that bin holds rank r
 #pragma unroll 1
@@ -450,7 +518,7 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
     for (int j = rl; j < ntgt; j += HS_RL) {
       const uint32_t e = tgt[j * CW + col];
       uint32_t cr = HS_SPEC_NONE;
-      if (e != HS_SPEC_NONE) {
+      if (e != HS_SPEC_NONE && !(abl & 256)) {
         const uint32_t b = e & 0xFFFFu, o = e >> 16;
         if (b == binL) cr = HS_SPEC_LO;
         else if (b == binH) cr = HS_SPEC_HI;
@@ -476,7 +544,7 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
     // ---- pass 2's look-up table: one bit pair per regular index f (word f >> 4, bits 2 (f & 15)): bit 0 = "a sample
     // with this f is a candidate" (interior f: 0 < f < f(hi), where the bin is f + 2 whatever the sample), bit 1 =
     // "decide with the exact bin" (f = 0 and f >= f(hi), where one f covers several bins and one of them is marked)
-    {
+    if (!(abl & 512)) {
       const uint32_t fH = hs_findex(s.hif - s.lof, s.scale);
       auto bmbit = [&](uint32_t b) -> uint32_t { return (bm[(b >> 5) * CW + col] >> (b & 31u)) & 1u; };
 #pragma unroll 1
@@ -627,14 +695,12 @@ __device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm,
 
 // ---- pass 2: collect the samples of the target bins, sort them per column, pick + lerp ---------------------------------
 // LDS: cand [64 * 512] candidates (the columns' lists back to back) | tab [64][64] bit pairs per regular index | bm [32][64]
-// bin bitmap (exact path) | cursor [64] | colok [64] | tv [waves][64] picked keys
+// bin bitmap (exact path) | cursor [64] | colok [64] | lbase [64] list offsets | tv [waves][64] picked keys
 constexpr size_t hs_lds2() {
-  return (size_t)HS_POOL * 4 + 64 * HS_CW * 4 + 32 * HS_CW * 4 + 2 * HS_CW * 4 + (size_t)(HS_NT / 64) * 64 * 4;
+  return (size_t)HS_POOL * 4 + 64 * HS_CW * 4 + 32 * HS_CW * 4 + 3 * HS_CW * 4 + (size_t)(HS_NT / 64) * 64 * 4;
 }
 
-// APPEND: how a batch's candidates reach the column's list — 0 = unconditional stores (a sample that is no candidate goes to
-// a trash word), 1 = `if` per sample (the compiler's exec-mask branches), 2 = v_cmpx + masked ds_write, no branch
-template <int APPEND>
+template <int HS_U, int NSET, bool EARLY>
 __global__ void __launch_bounds__(HS_NT, 4)
 k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2* __restrict__ lohi,
              const double* __restrict__ qs, int nq, const uint32_t* __restrict__ meta_n, const uint32_t* __restrict__ meta_m,
@@ -648,95 +714,103 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
   uint32_t* bm = tab + 64 * CW;
   uint32_t* cursor = bm + 32 * CW;
   uint32_t* colok = cursor + CW;
-  uint32_t* tvall = colok + CW;
+  uint32_t* lbase = colok + CW;
+  uint32_t* tvall = lbase + CW;
   const int tid = threadIdx.x, col = tid & (CW - 1), rl = tid / CW;
   const int lane = tid & 63, wv = tid >> 6;
   const int ntgt = 2 * nq;
   const int64_t ntiles = (C + CW - 1) / CW;
+  HsRing<HS_U, NSET> ring;
+  auto col_of = [&](int64_t t) -> int64_t {
+    const int64_t c_ = t * CW + col;
+    return c_ < C ? c_ : C - 1;
+  };
+  constexpr bool early = EARLY;
+  if (early && (int64_t)blockIdx.x < ntiles) ring.prime(x, T, st, col_of(blockIdx.x), rl);
   for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
     const int64_t tile = hs_tile_of(round_base, ntiles);
     if (tile < 0) break;  // (block-uniform; only in the last round)
     const int64_t c = tile * CW + col;
     const bool cvalid = c < C;
     const int64_t cc = cvalid ? c : C - 1;
+    if (!early) ring.prime(x, T, st, cc, rl);
     const uint2 lh = lohi[cc];
     const HsScale s = hs_scale(lh.x, lh.y);
     const bool collect = cvalid && meta_m[cc] != HS_FLAGGED;
     if (tid < CW) {
       cursor[tid] = 0u;
       colok[tid] = collect ? 0xFFFFFFFFu : 0u;  // (tid < CW: col == tid)
+      lbase[tid] = collect ? meta_base[cc] : 0u;
     }
     __syncthreads();
     // the tile's tables; the columns nothing is collected for (flagged, past C) read all-zero tables
     for (int i = tid; i < 64 * CW; i += NT) tab[i] = tab_g[tile * (64 * CW) + i] & colok[i & (CW - 1)];
     for (int i = tid; i < 32 * CW; i += NT) bm[i] = bitmap_g[tile * (32 * CW) + i] & colok[i & (CW - 1)];
     __syncthreads();
-    uint32_t* mylist = cand + (collect ? meta_base[cc] : 0u);
     const uint32_t* mytab = tab + col;
     const uint32_t* mybm = bm + col;
-    hs_stream(x, T, st, cc, rl, [&](const float (&v)[HS_U]) {
-      // the regular index of every sample and its bit pair (16 LDS reads in flight); bit 1 anywhere in the wave: this
-      // batch is decided by the exact bins (NaN samples: f = 0, whose candidate bit is never set)
-      uint32_t sb[HS_U];
-      uint32_t acc = 0u;
+    uint32_t dummy = 0u;
+    ring.run(x, T, st, cc, rl, [&](const float (&v)[HS_U]) {
+      // the regular index of every sample and its bit pair (8 LDS reads in flight); bit 1 anywhere in the wave: this
+      // batch is decided by the exact bins (NaN samples: f = 0, whose candidate bit is never set).  The hits of the batch
+      // are ONE register (bit u = sample u): sixteen 0 / 1 registers next to the ring's register sets spill, and a spill
+      // reload inside this loop is an s_waitcnt vmcnt(0) — it waits for the prefetched batch as well (round 4: +1.7 ms).
+      uint32_t hit = 0u, flags = 0u;
+      if (abl & 64) {  // diagnostics: loads only
+#pragma unroll
+        for (int u = 0; u < HS_U; ++u) dummy += __float_as_uint(v[u]);
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < HS_U; ++u) {
         const uint32_t f = hs_findex(v[u] - s.lof, s.scale);
-        sb[u] = mytab[(f >> 4) * CW] >> ((f << 1) & 31u);
-        acc |= sb[u];
+        const uint32_t pair = mytab[(f >> 4) * CW] >> ((f << 1) & 31u);
+        flags |= pair;
+        hit |= (pair & 1u) << u;
+        if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
-      if (__any((acc & 2u) != 0u)) {
+      if (__any((flags & 2u) != 0u)) {
+        hit = 0u;
 #pragma unroll
         for (int u = 0; u < HS_U; ++u) {
           const uint32_t b = hs_bin(v[u], s);
-          const uint32_t w = mybm[(b >> 5) * CW] >> (b & 31u);
-          sb[u] = v[u] == v[u] ? w : 0u;
+          const uint32_t w = (mybm[(b >> 5) * CW] >> (b & 31u)) & 1u;
+          hit |= (v[u] == v[u] ? w : 0u) << u;
         }
       }
-      uint32_t cnt = 0u;
-#pragma unroll
-      for (int u = 0; u < HS_U; ++u) {
-        sb[u] &= 1u;
-        cnt += sb[u];
+      if (abl & 32) {  // diagnostics: no appends
+        dummy += hit;
+        return;
       }
-      if (__any(cnt != 0u)) {
-        // one reservation per lane and batch.  pos < the column's count by construction (pass 1 counted the same bins).
-        uint32_t pos = atomicAdd(&cursor[col], cnt);
-        if (APPEND == 2) {
-          typedef __attribute__((address_space(3))) uint32_t lds_u32;
-          uint32_t addr = (uint32_t)(uintptr_t)(lds_u32*)(mylist + pos);
+      if (__any(hit != 0u)) {
+        // one reservation per lane and batch (pos < the column's count by construction: pass 1 counted the same bins), then
+        // sixteen ds_write under the execution mask (v_cmpx, no branch).  The cursor's and the list's LDS addresses are
+        // rebuilt from the column here (opaque copy): kept live across the loop they are the values the allocator spills.
+        int colo = col;
+        asm volatile("" : "+v"(colo));
+        typedef __attribute__((address_space(3))) uint32_t lds_u32;
+        const uint32_t pos = atomicAdd(&cursor[colo], (uint32_t)__popc(hit));
+        uint32_t addr = (uint32_t)(uintptr_t)(lds_u32*)(cand + lbase[colo]) + pos * 4u;
 #pragma unroll
-          for (int u = 0; u < HS_U; ++u) {
-            uint64_t sv;
-            asm volatile(
-                "s_mov_b64 %[sv], exec\n\t"
-                "v_cmpx_ne_u32_e32 0, %[bit]\n\t"
-                "ds_write_b32 %[addr], %[val]\n\t"
-                "v_add_u32_e32 %[addr], 4, %[addr]\n\t"
-                "s_mov_b64 exec, %[sv]"
-                : [addr] "+v"(addr), [sv] "=&s"(sv)
-                : [bit] "v"(sb[u]), [val] "v"(v[u])
-                : "vcc", "memory");
-          }
-        } else if (APPEND == 1) {
-#pragma unroll
-          for (int u = 0; u < HS_U; ++u) {
-            if (sb[u]) {
-              mylist[pos] = __float_as_uint(v[u]);
-              ++pos;
-            }
-          }
-        } else {  // unconditional stores: a sample that is no candidate goes to a trash word (tvall[0])
-#pragma unroll
-          for (int u = 0; u < HS_U; ++u) {
-            uint32_t* dst = sb[u] ? mylist + pos : tvall;
-            *dst = __float_as_uint(v[u]);
-            pos += sb[u];
-          }
+        for (int u = 0; u < HS_U; ++u) {
+          uint64_t sv;
+          uint32_t bit = hit & (1u << u);
+          asm volatile(
+              "s_mov_b64 %[sv], exec\n\t"
+              "v_cmpx_ne_u32_e32 0, %[bit]\n\t"
+              "ds_write_b32 %[addr], %[val]\n\t"
+              "v_add_u32_e32 %[addr], 4, %[addr]\n\t"
+              "s_mov_b64 exec, %[sv]"
+              : [addr] "+v"(addr), [sv] "=&s"(sv)
+              : [bit] "v"(bit), [val] "v"(v[u])
+              : "vcc", "memory");
         }
       }
     });
+    if ((abl & 96) && dummy == 0x12345679u) atomicAdd(&stat->errors, 1u);
+    if (early && tile + (int64_t)gridDim.x < ntiles) ring.prime(x, T, st, col_of(tile + gridDim.x), rl);  // the sorts run under these loads
     __syncthreads();
+    if (abl & 96) continue;
     // ---- one wave per column: sort, pick, lerp (utl:464-491), store
     uint32_t* tv = tvall + wv * 64;
     for (int k = wv; k < CW; k += NT / 64) {
@@ -832,29 +906,55 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   int64_t nblk = ntiles;
   const int64_t maxblk = (int64_t)ctx->num_cu;  // LDS: one 1024-thread workgroup per CU
   if (nblk > maxblk) nblk = maxblk;
+  if (const char* eg = xh_diag_env("XH_HIST_GEOM")) {  // diagnostics: "<row lanes>,<sets>,<lds bytes>,<workgroups per CU>": time the bare loop, then go on
+    int grl = 16, gns = 2, glds = 0, gwg = 1;
+    sscanf(eg, "%d,%d,%d,%d", &grl, &gns, &glds, &gwg);
+    int64_t nb = ntiles < (int64_t)ctx->num_cu * gwg ? ntiles : (int64_t)ctx->num_cu * gwg;
+#define XH_HS_GEOM(RL, NS)                                                                                                       \
+  {                                                                                                                             \
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_stream_test<RL, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    hipLaunchKernelGGL((k_hs_stream_test<RL, NS>), dim3((unsigned)nb), dim3(HS_CW * RL), (size_t)glds, ctx->stream, x, (int)T, C, st, stat); \
+  }
+    if (grl == 16 && gns == 2) XH_HS_GEOM(16, 2)
+    else if (grl == 8 && gns == 2) XH_HS_GEOM(8, 2)
+    else if (grl == 4 && gns == 2) XH_HS_GEOM(4, 2)
+#undef XH_HS_GEOM
+    XH_LAUNCH_CHECK();
+  }
   const char* eabl = xh_diag_env("XH_HIST_ABL");  // diagnostics: 1 = no candidate sort, 2 = pass 1 loads only, 4 = no pass-1 tile epilogue (wrong results)
   const int abl = eabl ? atoi(eabl) : 0;
-  const char* eap = xh_diag_env("XH_HIST_APPEND");  // diagnostics: 0 | 1 | 2, see k_hs_collect
-  const int append = eap ? atoi(eap) : 2;
-  XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds1()));
-  hipLaunchKernelGGL(k_hs_hist, dim3((unsigned)nblk), dim3(HS_NT), hs_lds1(), ctx->stream, x, (int)T, C, st, lohi, d_q, nq, meta_n,
-                     meta_m, meta_base, crank, bitmap_g, tab_g, flist, stat, abl);
-  XH_LAUNCH_CHECK();
-#define XH_HS_COLLECT(AP)                                                                                                        \
+  // the streaming ring: 5 sets of 8 loads (32 to 40 loads per lane in flight).  Diagnostics: XH_HIST_RING=162 = two sets of 16
+  // (round 3's ping-pong: 16 to 32 in flight; config-4 train 40.5 against 36.7-38.2 ms on the same box, profiles/r04/)
+  const char* ens = xh_diag_env("XH_HIST_RING");
+  const int ring = ens ? atoi(ens) : 85;
+#define XH_HS_HIST(UU, NS, EH)                                                                                                      \
   {                                                                                                                             \
-    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<AP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2())); \
-    hipLaunchKernelGGL((k_hs_collect<AP>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds2(), ctx->stream, x, (int)T, C, st, lohi, d_q,  \
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist<UU, NS, EH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds1())); \
+    hipLaunchKernelGGL((k_hs_hist<UU, NS, EH>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds1(), ctx->stream, x, (int)T, C, st, lohi, d_q, nq, \
+                       meta_n, meta_m, meta_base, crank, bitmap_g, tab_g, flist, stat, abl);                                     \
+  }
+#define XH_HS_COLLECT(UU, NS, EC)                                                                                                    \
+  {                                                                                                                             \
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<UU, NS, EC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2())); \
+    hipLaunchKernelGGL((k_hs_collect<UU, NS, EC>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds2(), ctx->stream, x, (int)T, C, st, lohi, d_q, \
                        nq, meta_n, meta_m, meta_base, crank, bitmap_g, tab_g, out, out_cstride, out_qstride, stat, abl);         \
   }
-  if (append == 0) XH_HS_COLLECT(0)
-  else if (append == 1) XH_HS_COLLECT(1)
-  else XH_HS_COLLECT(2)
+#define XH_HS_BOTH(UU, NS, EH, EC) { XH_HS_HIST(UU, NS, EH) XH_LAUNCH_CHECK(); XH_HS_COLLECT(UU, NS, EC) }
+  const char* eea = xh_diag_env("XH_HIST_EARLY");  // diagnostics: early priming in pass 1 / pass 2: "00" | "10" | "01" | "11"
+  const int eh = eea ? eea[0] == '1' : 0, ec = eea ? eea[1] == '1' : 0;  // measured: no gain (38.0 / 38.2 / 38.6 / 38.8 ms for 00 / 10 / 01 / 11)
+  if (ring == 162) XH_HS_BOTH(16, 2, false, false)
+  else if (eh && ec) XH_HS_BOTH(8, 5, true, true)
+  else if (eh) XH_HS_BOTH(8, 5, true, false)
+  else if (ec) XH_HS_BOTH(8, 5, false, true)
+  else XH_HS_BOTH(8, 5, false, false)
+#undef XH_HS_BOTH
+#undef XH_HS_HIST
 #undef XH_HS_COLLECT
   XH_LAUNCH_CHECK();
   HsStat h;
   XH_CHECK_HIP(hipMemcpyAsync(&h, stat, sizeof(HsStat), hipMemcpyDeviceToHost, ctx->stream));
   XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  XH_REQUIRE(h.errors == 0, XH_ERR_HIP, "xh_select_hist: %u columns met another candidate count in pass 2 than in pass 1",
+  XH_REQUIRE(h.errors == 0 || abl != 0, XH_ERR_HIP, "xh_select_hist: %u columns met another candidate count in pass 2 than in pass 1",
              h.errors);
   if (xh_diag_env("XH_HIST_STATS")) fprintf(stderr, "[xh_select_hist] T=%lld C=%lld flagged=%u candidates: max %u mean %.1f\n", (long long)T, (long long)C, h.nflag, h.maxm, (double)h.summ / (double)C);
   if (h.nflag == 0) return XH_OK;
