@@ -475,7 +475,9 @@ int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
  * af_t = interp_on_quantiles(sim_q, q, af) with the nq quantile nodes q (host, strictly increasing) as abscissa
  * (interp 0 nearest, 1 linear; extrap 0 constant, 1 nan; NaN factors dropped per cell); scen = sim + af_t (kind 0) or
  * sim * af_t (kind 1).  af (nq, C) float32 as trained by xh_eqm_train.  scen has the layout of sim (st, sc);
- * 1 <= T <= 32768.  Parity unpinned (xsdba is not in the reference tree). */
+ * 1 <= T < 2^27: up to 32768 steps a column's keys stay in one workgroup (qdm.hip, qdm2.hip), longer series (1950-2100
+ * daily = 55 152) are ranked through a global sort in column batches (qdm3.hip).  Parity unpinned (xsdba is not in the
+ * reference tree). */
 int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const float* af,
                   const double* q /* host */, int nq, int kind, int interp, int extrap, float* scen);
 

@@ -36,11 +36,61 @@ class _Resampled:
         return DataArray(self._da.values[first], coords={"time": lab}, dims=("time",))
 
 
+class ChunkedArray:
+    """Stand-in for a dask array behind a DataArray (``da.data``): ``.chunks`` / ``.dask`` / ``.shape`` / ``.dtype``, lazy
+    ``transpose`` and slicing; turning it into numpy (``np.asarray``: what ``DataArray.values`` does) is RECORDED in
+    ``loads`` (number of elements per materialisation), so a test can assert that a wrapper never pulled more than one
+    block of a chunked field into host memory (xr_adapter.reduce_blocks; the reference: core/calendar.py:460-479)."""
+
+    def __init__(self, array, chunks, loads=None, index=None, perm=None):
+        self._a = array                      # the backing numpy array, original axis order
+        self._index = index or tuple(slice(0, n) for n in array.shape)   # one slice per ORIGINAL axis
+        self._perm = tuple(perm) if perm is not None else tuple(range(array.ndim))
+        self._chunks0 = tuple(tuple(int(c) for c in ch) for ch in chunks)  # per ORIGINAL axis, of the full array
+        self.loads = loads if loads is not None else []
+        self.dask = {"stand-in": True}
+
+    dtype = property(lambda self: self._a.dtype)
+    ndim = property(lambda self: self._a.ndim)
+
+    @property
+    def shape(self):
+        return tuple(self._index[ax].stop - self._index[ax].start for ax in self._perm)
+
+    @property
+    def chunks(self):
+        out = []
+        for ax in self._perm:
+            sl, edges = self._index[ax], np.concatenate([[0], np.cumsum(self._chunks0[ax])])
+            sizes = [min(e1, sl.stop) - max(e0, sl.start) for e0, e1 in zip(edges[:-1], edges[1:])]
+            out.append(tuple(int(n) for n in sizes if n > 0))
+        return tuple(out)
+
+    def transpose(self, *perm):
+        return ChunkedArray(self._a, self._chunks0, self.loads, self._index, tuple(self._perm[i] for i in perm))
+
+    def __getitem__(self, key):
+        key = key if isinstance(key, tuple) else (key,)
+        key = key + (slice(None),) * (self.ndim - len(key))
+        idx = list(self._index)
+        for pos, k in enumerate(key):
+            ax = self._perm[pos]
+            start, stop, step = k.indices(self._index[ax].stop - self._index[ax].start)
+            assert step == 1
+            idx[ax] = slice(self._index[ax].start + start, self._index[ax].start + stop)
+        return ChunkedArray(self._a, self._chunks0, self.loads, tuple(idx), self._perm)
+
+    def __array__(self, dtype=None, copy=None):
+        v = self._a[self._index].transpose(self._perm)
+        self.loads.append(int(v.size))
+        return v.astype(dtype) if dtype is not None else v
+
+
 class DataArray:
     def __init__(self, data, coords=None, dims=None, name=None, attrs=None):
-        self.values = np.asarray(data)
-        self.dims = tuple(dims) if dims is not None else tuple(f"dim_{i}" for i in range(self.values.ndim))
-        assert len(self.dims) == self.values.ndim, (self.dims, self.values.shape)
+        self._data = data if isinstance(data, ChunkedArray) else np.asarray(data)
+        self.dims = tuple(dims) if dims is not None else tuple(f"dim_{i}" for i in range(self._data.ndim))
+        assert len(self.dims) == self._data.ndim, (self.dims, self._data.shape)
         self.name, self.attrs = name, dict(attrs or {})
         self.coords = {}
         self._fields, self._cal = None, None
@@ -49,9 +99,34 @@ class DataArray:
                 v = DataArray(np.asarray(v), dims=(k,))
             self.coords[k] = v
 
-    dtype = property(lambda self: self.values.dtype)
-    shape = property(lambda self: self.values.shape)
-    data = property(lambda self: self.values)
+    dtype = property(lambda self: self._data.dtype)
+    shape = property(lambda self: tuple(self._data.shape))
+    data = property(lambda self: self._data)
+
+    @property
+    def values(self):
+        return np.asarray(self._data)
+
+    @values.setter
+    def values(self, v):
+        self._data = np.asarray(v)
+
+    def isel(self, indexers=None, **kw):
+        """Positional slices per dimension (slices only: what xr_adapter.block_values asks for)."""
+        sel = dict(indexers or {}, **kw)
+        key = tuple(sel.get(d, slice(None)) for d in self.dims)
+        coords = {}
+        for k, c in self.coords.items():
+            if c.dims == (k,) and k in sel:
+                cc = DataArray(c.values[sel[k]], dims=(k,))
+                cc._fields = None if c._fields is None else {f: v[sel[k]] for f, v in c._fields.items()}
+                cc._cal = c._cal
+                coords[k] = cc
+            else:
+                coords[k] = c
+        out = DataArray(self._data[key], coords=coords, dims=self.dims, name=self.name, attrs=self.attrs)
+        out._fields, out._cal = self._fields, self._cal
+        return out
 
     def __getitem__(self, key):
         return self.coords[key]
@@ -66,7 +141,7 @@ class DataArray:
             rest = tuple(d for d in self.dims if d not in dims)
             dims = dims[:i] + rest + dims[i + 1:]
         perm = [self.dims.index(d) for d in dims]
-        out = DataArray(self.values.transpose(perm), coords=self.coords, dims=dims, name=self.name, attrs=self.attrs)
+        out = DataArray(self._data.transpose(*perm), coords=self.coords, dims=dims, name=self.name, attrs=self.attrs)
         out._fields, out._cal = self._fields, self._cal
         return out
 
@@ -132,10 +207,18 @@ def time_coord_like(c, idx) -> DataArray:
     return out
 
 
-def field(x, ta, dims=("time", "lat", "lon"), attrs=None, name=None) -> DataArray:
-    """A (time, lat, lon)-like DataArray (any dim order) on the TimeAxis ``ta``."""
+def field(x, ta, dims=("time", "lat", "lon"), attrs=None, name=None, chunks=None) -> DataArray:
+    """A (time, lat, lon)-like DataArray (any dim order) on the TimeAxis ``ta``.  ``chunks``: {dim: chunk length} makes it
+    "dask-backed" (a :class:`ChunkedArray` behind ``.data``; dimensions not named are one chunk)."""
     coords = {d: np.arange(n) for d, n in zip(dims, np.shape(x)) if d != "time"}
     coords["time"] = time_coord(ta)
+    if chunks is not None:
+        x = np.asarray(x)
+        cks = []
+        for d, n in zip(dims, x.shape):
+            c = int(chunks.get(d, n))
+            cks.append(tuple([c] * (n // c) + ([n % c] if n % c else [])))
+        x = ChunkedArray(x, cks)
     return DataArray(x, coords=coords, dims=dims, attrs=attrs or {"units": "K"}, name=name)
 
 

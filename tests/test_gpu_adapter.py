@@ -366,3 +366,142 @@ def test_xsdba_interp_on_quantiles_through_the_wrappers(ref, dev, rng, interp):
     np.testing.assert_allclose(_tf(scen), exp, rtol=2e-6 if interp == "cubic" else 1e-6, equal_nan=True)
     with pytest.raises(AssertionError, match="was reached"):
         mods["xsdba.utils"].interp_on_quantiles(d_sim, d_hq, d_af, group="time.month", method=interp)
+
+
+def test_chunked_fields_go_through_the_wrappers_block_by_block(ref, dev, rng):
+    """dask-backed DataArrays (the reference's chunked path: core/calendar.py:460-479, indices/helpers.py:898-974,
+    core/indicator.py:865-944): round 3's wrappers called ``.values`` on everything.  Now a chunked field is walked block by
+    block over its cell dimensions — the stand-in's ``ChunkedArray`` records every materialisation: never more than one
+    block on the host, one upload per block and pass — and the stitched results equal the in-memory ones.  tx90p chain,
+    cdd, WSDI (fused per-doy run statistic), tg_mean, run-length reducers, MissingAny, percentile_doy; a float64 chunk is
+    forwarded like an in-memory float64 field; full-shape results (rle, masks) of chunked inputs go to the reference."""
+    env, mods, _ = ref
+    T, Y, X = 365 * 3, 7, 10
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    x = _temp(rng, T, (Y, X), nan_frac=0.001)
+    mem = fakexr.field(x, ta)
+    chk = fakexr.field(x, ta, chunks={"lat": 3, "lon": 4})
+    nblocks, biggest = 3 * 3, T * 3 * 4
+    loads = chk.data.loads
+    cal, mv, th, sp, rl, gen = (mods[m] for m in ("xclim.core.calendar", "xclim.indices._multivariate", "xclim.indices._threshold",
+                                                  "xclim.indices._simple", "xclim.indices.run_length", "xclim.indices.generic"))
+
+    def check(fn, passes=1):
+        del loads[:]
+        trace = dev.start_trace()
+        got = fn(chk)
+        dev.stop_trace()
+        exp = fn(mem)
+        np.testing.assert_array_equal(_tf(got), _tf(exp))
+        assert got.dims == exp.dims
+        assert len(loads) == passes * nblocks and max(loads) <= biggest, (len(loads), max(loads))
+        return trace
+
+    per = cal.percentile_doy(mem, window=5, per=80.0).sel(percentiles=80.0)
+    check(lambda da: cal.percentile_doy(da, window=5, per=80.0))
+    tr = check(lambda da: mv.tx90p(da, per, freq="YS"))
+    assert len(_calls(tr, "xh_threshold_count_doy")) == nblocks and not _calls(tr, "xh_doy_broadcast")
+    tr = check(lambda da: mv.warm_spell_duration_index(da, per, window=3, freq="YS"))
+    assert len(_calls(tr, "xh_run_stats_doy")) == nblocks
+    check(lambda da: th.maximum_consecutive_dry_days(da, 285.0, freq="YS"))
+    check(lambda da: th.frost_days(da, 283.15, freq="MS"))
+    check(lambda da: sp.tg_mean(da, freq="QS-DEC"))
+    check(lambda da: th.growing_season_length(da, thresh=283.15, freq="YS"))
+    check(lambda da: th.growing_degree_days(da, thresh=283.15, freq="YS"))
+    check(lambda da: mods["xclim.core.missing"].MissingAny()(da, "YS", "D"))
+    # a chunked MASK through the run-length reducers (float mask, as spell_mask's astype(float32) gives, gen:557)
+    mask = (x > 290).astype(np.float32)
+    m_mem, m_chk = fakexr.field(mask, ta), fakexr.field(mask, ta, chunks={"lat": 3, "lon": 4})
+    for fn in (lambda m: rl.longest_run(m, freq="YS"), lambda m: rl.windowed_run_count(m, 3, freq="YS"),
+               lambda m: rl.first_run(m, 3, coord="dayofyear"), lambda m: rl.resample_and_rl(m, True, rl.windowed_run_events, window=2, freq="YS")):
+        del m_chk.data.loads[:]
+        np.testing.assert_array_equal(_tf(fn(m_chk)), _tf(fn(m_mem)))
+        assert len(m_chk.data.loads) == nblocks and max(m_chk.data.loads) <= biggest
+    # dimension order other than time-first, chunked along one dimension only
+    y = np.ascontiguousarray(np.moveaxis(x, 0, 2))
+    a_mem, a_chk = fakexr.field(y, ta, dims=("lat", "lon", "time")), fakexr.field(y, ta, dims=("lat", "lon", "time"), chunks={"lon": 5})
+    got, exp = th.frost_days(a_chk, 283.15, freq="YS"), th.frost_days(a_mem, 283.15, freq="YS")
+    assert got.dims == exp.dims == ("lat", "lon", "time")
+    np.testing.assert_array_equal(got.values, exp.values)
+    assert len(a_chk.data.loads) == 2 and max(a_chk.data.loads) == T * Y * 5
+    # float64 chunks: the float64 kernels where they exist, the reference elsewhere — never rounded
+    c64 = fakexr.field(x.astype(np.float64), ta, chunks={"lat": 3, "lon": 4})
+    np.testing.assert_array_equal(gen.threshold_count(c64, ">", 290.0, "YS").values, ogen.threshold_count(x.astype(np.float64), ">", 290.0, ot, "YS"))
+    with pytest.raises(AssertionError, match="was reached"):
+        gen.spell_length_statistics(c64, 290.0, 1, None, ">", "max", "YS")
+    # full-shape results of chunked inputs are the reference's own dask business
+    with pytest.raises(AssertionError, match="rle was reached"):
+        rl.rle(m_chk)
+    with pytest.raises(AssertionError, match="compare was reached"):
+        gen.compare(chk, ">", 290.0)
+
+
+def test_float64_field_against_a_doy_threshold_is_forwarded_not_refused(dev, rng):
+    """compare(float64 da, op, DoyThreshold) returned a LazyCompare whose fused path AND whose materialisation
+    both refuse float64 fields — cold_spell_duration_index on float64 data died with a TypeError.  The wrapper now hands
+    the call to the reference's compare with the materialised (time, ...) threshold (here: a working stand-in for
+    gen:301-326 put into the modules BEFORE install, so that it is what install() saves as the original)."""
+    import xclim_amd._capi as capi
+
+    env = fakexr.make_env()
+    mods = fakexr.make_reference_like_modules(env)
+    seen = {}
+
+    def ref_compare(left, op, right, constrain=None):
+        seen["right"] = right
+        return left._bin(right, {"<": np.less, ">": np.greater}[op])
+
+    for m in ("xclim.indices.generic", "xclim.indices._multivariate", "xclim.indices._threshold"):
+        mods[m].compare = ref_compare
+    old = capi._default_device
+    capi._default_device = dev
+    patch.install(env, mods)
+    try:
+        T = 365 * 2
+        ta = TimeAxis.daily("2001-01-01", T, "noleap")
+        x32 = _temp(rng, T, (2, 3))
+        cal, gen, rl = mods["xclim.core.calendar"], mods["xclim.indices.generic"], mods["xclim.indices.run_length"]
+        per = cal.percentile_doy(fakexr.field(x32, ta), window=5, per=20.0).sel(percentiles=20.0)
+        da64 = fakexr.field(x32.astype(np.float64), ta)
+        thr = cal.resample_doy(per, da64)
+        below = gen.compare(da64, "<", thr, constrain=("<", "<="))
+        assert isinstance(seen["right"], fakexr.DataArray) and seen["right"].dims == da64.dims and seen["right"].dtype == np.float64
+        assert below.dtype == bool and not isinstance(below, LazyCompare)
+        out = rl.resample_and_rl(below, True, rl.windowed_run_count, window=2, freq="YS")
+        exp = orl.resample_and_rl(below.values.astype(np.float32), True, orl.windowed_run_count, 2, time=OTime.noleap(2001, T), freq="YS")
+        np.testing.assert_array_equal(out.values, exp)
+        assert isinstance(gen.compare(fakexr.field(x32, ta), "<", thr), LazyCompare)  # a float32 field keeps the fused path
+    finally:
+        patch.uninstall()
+        capi._default_device = old
+
+
+def test_dataarray_indexers_and_the_valid_cache(ref, dev, rng):
+    """(1) DataArray-valued ``doy_bounds`` carry their own dimension order (cal:1199-1246, missing.py:140-146) —
+    such calls go to the reference instead of being broadcast in the wrong order; (2) the valid-count cache is one-shot
+    and guarded by a fingerprint: a buffer modified in place between the reducer and the missing-value check is counted
+    again, and a second MissingAny call recounts."""
+    env, mods, _ = ref
+    T = 365 * 2
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    x = _temp(rng, T, (3, 4))
+    da = fakexr.field(x, ta)
+    gen, misser = mods["xclim.indices.generic"], mods["xclim.core.missing"].MissingAny()
+    start = fakexr.DataArray(np.full((4, 3), 100), dims=("lon", "lat"))   # per-cell bounds in ANOTHER dimension order
+    with pytest.raises(AssertionError, match="select_resample_op was reached"):
+        gen.select_resample_op(da, "mean", "YS", doy_bounds=(start, 200))
+    with pytest.raises(AssertionError, match="was reached"):
+        misser(da, "YS", "D", doy_bounds=(start, 200))
+    gen.select_resample_op(da, "mean", "YS")
+    trace = dev.start_trace()
+    m1 = misser(da, "YS", "D")       # answered from the reducer's valid counts
+    m2 = misser(da, "YS", "D")       # one-shot: counted again
+    dev.stop_trace()
+    assert len(_calls(trace, "xh_resample_reduce")) == 1 and not m1.values.any() and not m2.values.any()
+    gen.select_resample_op(da, "mean", "YS")
+    da.values[0, 1, 1] = np.nan      # modified in place after the reducer ran
+    trace = dev.start_trace()
+    m3 = misser(da, "YS", "D")
+    dev.stop_trace()
+    assert len(_calls(trace, "xh_resample_reduce")) == 1 and m3.values[0, 1, 1] and m3.values.sum() == 1
+    np.testing.assert_array_equal(m3.values, oidx.missing_any(da.values, ot, "YS"))

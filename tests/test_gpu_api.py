@@ -1237,6 +1237,37 @@ def test_qdm_adjust_matches_oracle(dev, rng, kind, interp, T, cells):
         np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0, equal_nan=True, err_msg=f"{extrap}")
 
 
+@pytest.mark.parametrize("kind,interp", [("+", "nearest"), ("*", "linear")])
+def test_qdm_adjust_beyond_32768_steps(dev, rng, kind, interp):
+    """1950-2100 daily (55 152 steps): round 3 refused series longer than 32768 steps.  qdm3.hip ranks them through a
+    global sort of (key, time index) pairs; NaN samples, tied rows, a heavily tied cell, dry days, signed zeros, an
+    all-NaN and a constant cell, NaN factors; both layouts.  Against the oracle (scipy rankdata / interp1d)."""
+    from xclim_amd import kernels as K
+
+    T, C, nq = 55152, 37, 20
+    sim = rng.normal(13, 4, (T, C)).astype(np.float32)
+    if kind == "*":
+        sim = np.abs(sim) + 1
+    sim[rng.random((T, C)) < 0.01] = np.nan
+    sim[T // 3] = sim[T // 2]
+    sim[:, 0] = np.round(sim[:, 0])
+    sim[:, 1] = np.where(rng.random(T) < 0.6, 0.0, rng.gamma(0.7, 4.0, T)).astype(np.float32)
+    z = np.flatnonzero(sim[:, 1] == 0.0)
+    sim[z[::2], 1] = -0.0
+    sim[:, 2] = np.nan
+    sim[:, 3] = 7.5
+    sim[1:, 4] = np.nan
+    q = (np.arange(nq) + 0.5) / nq
+    af = rng.normal(1.0, 0.3, (nq, C)).astype(np.float32)
+    af[rng.random((nq, C)) < 0.02] = np.nan
+    af[:, 6] = np.nan
+    exp = osdba.qdm_adjust(sim, af, q, kind, interp, "constant")
+    got = K.qdm_adjust(dev, dev.to_device(sim), dev.to_device(af), q, kind, interp, "constant").get()
+    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0, equal_nan=True)
+    tm = K.qdm_adjust(dev, dev.to_device(np.ascontiguousarray(sim.T)), dev.to_device(af), q, kind, interp, "constant", time_axis=1).get()
+    np.testing.assert_array_equal(tm.T, got)
+
+
 @pytest.mark.parametrize("T", [360, 365, 366])
 @pytest.mark.parametrize("kind,nq", [("+", 20), ("*", 15), ("*", 36), ("+", 48)])
 def test_qdm_nearest_one_year_cut_value_kernel(dev, rng, monkeypatch, T, kind, nq):

@@ -20,12 +20,31 @@ class DoyPercentile:
     Carries what the reference stores in DataArray attrs (cal:487-494): climatology_bounds, window, alpha, beta.
     """
 
-    def __init__(self, data: DeviceArray, doys, percentiles, cell_shape, attrs):
-        self.data = data
+    def __init__(self, data: DeviceArray | None, doys, percentiles, cell_shape, attrs, host=None, device=None):
+        """``host``: the same table on the host, (nper, ndoy, *cells) float64 — what the xarray adapter holds when the table
+        came in as a DataArray; with it the device copy is made on first use (``data``) and cell blocks of a chunked field
+        get their own slab (:meth:`block`)."""
+        self._data = data
+        self.host = host
+        self._dev = device
         self.dayofyear = np.asarray(doys)
         self.percentiles = np.asarray(percentiles, dtype=np.float64)
         self.cell_shape = tuple(cell_shape)
         self.attrs = dict(attrs)
+
+    @property
+    def data(self) -> DeviceArray:
+        if self._data is None:
+            h = np.ascontiguousarray(self.host, dtype=np.float64)
+            self._data = (self._dev or get_device()).to_device(h.reshape(h.shape[0], h.shape[1], -1), dtype=np.float64)
+        return self._data
+
+    def block(self, idx) -> "DoyPercentile":
+        """The table of one cell block (``idx``: one slice per cell dimension), uploaded from the host copy."""
+        if self.host is None:
+            raise ValueError("DoyPercentile.block needs the host table (tables made on the device cover the whole grid)")
+        h = np.ascontiguousarray(self.host[(slice(None), slice(None)) + tuple(idx)], dtype=np.float64)
+        return DoyPercentile(None, self.dayofyear, self.percentiles, h.shape[2:], self.attrs, host=h, device=self._dev)
 
     def sel(self, percentiles) -> "DoyPercentile":
         j = int(np.nonzero(self.percentiles == percentiles)[0][0])

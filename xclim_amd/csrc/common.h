@@ -77,6 +77,10 @@ int xh_launch_tcount_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
 // qdm.hip / qdm2.hip
 int xh_qdm_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const float* af, int64_t af_qs,
                    const double* d_q, int nq, int kind, int interp, int extrap, float* out, int64_t out_cs);
+// qdm3.hip: exact ranks through a global (rocPRIM) sort, any T; workspace query + run on time-minor columns
+int xh_qdm_sorted_ws(int64_t T, int64_t ncols, size_t* bytes);
+int xh_qdm_sorted(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_t col_stride, const float* af, int64_t af_qs,
+                  const double* d_q, int nq, int kind, int interp, int extrap, float* out, int64_t out_cs, void* ws);
 int xh_qdm_regsort(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, const float* af, int64_t af_qs,
                    const double* d_q, int nq, int kind, int extrap, float* scen, int64_t ost);
 int xh_tcount_plan(int64_t T, int64_t C, int64_t st, int op, int P, int ndoy, int64_t longest, size_t* lds, int* narrow);

@@ -284,8 +284,8 @@ extern "C" {
 int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const float* af,
                   const double* q, int nq, int kind, int interp, int extrap, float* scen) {
   XH_REQUIRE(ctx && sim && af && q && scen, XH_ERR_ARG, "xh_qdm_adjust: NULL argument");
-  XH_REQUIRE(T >= 1 && T <= 32768 && C >= 0 && nq >= 1 && nq <= QDM_MAXQ, XH_ERR_ARG,
-             "xh_qdm_adjust: bad shape (1 <= T <= 32768, 1 <= nq <= 64)");
+  XH_REQUIRE(T >= 1 && T < (1ll << 27) && C >= 0 && nq >= 1 && nq <= QDM_MAXQ, XH_ERR_ARG,
+             "xh_qdm_adjust: bad shape (1 <= T < 2^27, 1 <= nq <= 64)");
   XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "xh_qdm_adjust: kind must be 0 (+) or 1 (*)");
   XH_REQUIRE(interp == 0 || interp == 1, XH_ERR_NOTIMPL, "xh_qdm_adjust: interp must be 0 (nearest) or 1 (linear)");
   XH_REQUIRE(extrap == 0 || extrap == 1, XH_ERR_ARG, "xh_qdm_adjust: extrap must be 0 (constant) or 1 (nan)");
@@ -296,8 +296,24 @@ int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   void* d_q = nullptr;
   int rc = xh_scratch_upload(ctx, &cur, q, sizeof(double) * nq, &d_q);
   if (rc) return rc;
-  if (st == 1 && sc >= T)  // time-minor: columns in place, scen in the same layout
-    return xh_qdm_columns(ctx, sim, T, C, sc, af, C, (const double*)d_q, nq, kind, interp, extrap, scen, sc);
+  const bool longs = T > 32768;  // beyond the exact-rank kernel's LDS list: ranks through a global sort (qdm3.hip), in batches
+  if (st == 1 && sc >= T) {  // time-minor: columns in place, scen in the same layout
+    if (!longs) return xh_qdm_columns(ctx, sim, T, C, sc, af, C, (const double*)d_q, nq, kind, interp, extrap, scen, sc);
+    int64_t chunk = (1ll << 27) / T;
+    chunk = chunk < 1 ? 1 : (chunk > C ? C : chunk);
+    size_t wsb = 0;
+    rc = xh_qdm_sorted_ws(T, chunk, &wsb);
+    if (rc) return rc;
+    void* ws = nullptr;
+    rc = xh_big_scratch(ctx, wsb, &ws);
+    if (rc) return rc;
+    for (int64_t c0 = 0; c0 < C; c0 += chunk) {
+      const int64_t nb = C - c0 < chunk ? C - c0 : chunk;
+      rc = xh_qdm_sorted(ctx, sim + c0 * sc, T, nb, sc, af + c0, C, (const double*)d_q, nq, kind, interp, extrap, scen + c0 * sc, sc, ws);
+      if (rc) return rc;
+    }
+    return XH_OK;
+  }
   XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_qdm_adjust: one of the strides must be 1 (st=%lld sc=%lld)", (long long)st,
              (long long)sc);
   if (interp == 0) {  // one-year series, nearest: sort in registers + classify by cut values, in place (qdm2.hip)
@@ -311,15 +327,23 @@ int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   if (batch < 128) batch = 128;
   if (batch > C) batch = C;
   void* tmp = nullptr;
-  rc = xh_big_scratch(ctx, 2 * sizeof(float) * (size_t)batch * (size_t)Tp, &tmp);
+  size_t wsb = 0;
+  if (longs) {
+    rc = xh_qdm_sorted_ws(T, batch, &wsb);
+    if (rc) return rc;
+  }
+  const size_t bufb = 2 * sizeof(float) * (size_t)batch * (size_t)Tp;
+  rc = xh_big_scratch(ctx, bufb + wsb, &tmp);
   if (rc) return rc;
   float* bin = (float*)tmp;
   float* bout = bin + (size_t)batch * (size_t)Tp;
+  void* ws = (char*)tmp + bufb;
   for (int64_t c0 = 0; c0 < C; c0 += batch) {
     const int64_t nb = C - c0 < batch ? C - c0 : batch;
     rc = xh_transpose_f32(ctx, sim + c0, T, nb, st, bin, Tp);
     if (rc) return rc;
-    rc = xh_qdm_columns(ctx, bin, T, nb, Tp, af + c0, C, (const double*)d_q, nq, kind, interp, extrap, bout, Tp);
+    rc = longs ? xh_qdm_sorted(ctx, bin, T, nb, Tp, af + c0, C, (const double*)d_q, nq, kind, interp, extrap, bout, Tp, ws)
+               : xh_qdm_columns(ctx, bin, T, nb, Tp, af + c0, C, (const double*)d_q, nq, kind, interp, extrap, bout, Tp);
     if (rc) return rc;
     rc = xh_transpose_f32(ctx, bout, nb, T, Tp, scen + c0, st);
     if (rc) return rc;

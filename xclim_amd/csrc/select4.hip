@@ -54,7 +54,7 @@ namespace {
 constexpr int HS_RL = 16;              // row lanes per column
 constexpr int HS_CW = 64;              // columns per workgroup
 constexpr int HS_NT = HS_CW * HS_RL;   // threads per workgroup
-constexpr int HS_UMAX = 16;            // loads per register set of the streaming ring (template parameter U: 8 | 16)
+
 constexpr int HS_NB = 1024;            // bins per column
 constexpr int HS_NREG = 1020;          // regular indices f = 0 .. 1019
 constexpr int HS_POOL = HS_CW * 512;   // candidate keys of one tile in LDS

@@ -43,7 +43,9 @@ def block_function(index, time: TimeAxis, *args, nvars: int = 1, **kwargs):
             raise ValueError(f"expected {nvars} data block(s), got {len(blocks)}")
         arrs = []
         for b in blocks:
-            a = np.ascontiguousarray(b, dtype=np.float32)
+            # the block in its OWN dtype: a float64 chunk takes the float64 kernels where they exist and raises
+            # Float64FieldError elsewhere (_capi.handle_float64) — never rounded to float32 behind the caller's back
+            a = np.ascontiguousarray(b)
             if a.shape[0] != len(time):
                 raise ValueError("every block must hold the whole time axis (rechunk with time: -1, cal:463-467)")
             arrs.append(a)
@@ -76,7 +78,7 @@ def map_blocks(index, arrays, time: TimeAxis, *args, chunks=None, **kwargs):
 
         if len(arrs[0].chunks[0]) != 1:
             raise ValueError("the time axis must be in one chunk (rechunk({0: -1}))")
-        probe = f(*[np.zeros((len(time),) + (1,) * (a.ndim - 1), np.float32) for a in arrs])
+        probe = f(*[np.zeros((len(time),) + (1,) * (a.ndim - 1), a.dtype) for a in arrs])  # (a float64 input may raise HERE)
         nper = probe.shape[0]  # (one single-cell call at graph-construction time: the period count and the result dtype)
         return dsa.map_blocks(f, *arrs, dtype=probe.dtype, chunks=((nper,),) + tuple(arrs[0].chunks[1:]))
     if chunks is None:

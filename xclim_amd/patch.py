@@ -150,6 +150,7 @@ def install(env=None, modules=None) -> list[str]:
     if sut is not None and hasattr(sut, "interp_on_quantiles"):
         orig["sdba_interp_on_quantiles"] = _saved.get(("xsdba.utils", "interp_on_quantiles"), sut.interp_on_quantiles)
     wrappers = make_wrappers(env, orig)
+    _cleanups.append(wrappers.pop("_clear_valid_cache"))
     wrappers["_cumsum_reset_np"] = cumsum_reset_np
     done = []
 
@@ -184,6 +185,7 @@ def install(env=None, modules=None) -> list[str]:
 
 
 _saved_modules: dict = {}
+_cleanups: list = []  # per install(): drops the valid-count cache of its wrappers
 
 
 def uninstall() -> None:
@@ -198,3 +200,6 @@ def uninstall() -> None:
             setattr(mod, attr, fn)
     _saved.clear()
     _saved_modules.clear()
+    for fn in _cleanups:
+        fn()
+    _cleanups.clear()

@@ -230,9 +230,9 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
     inside each group's own time steps (xsdba: ``group.apply(rank, sim, main_only=True)`` — the window only widens the
     TRAINING sample) and every step uses the factors of its group (``interp="nearest"`` only, see the module docstring).
 
-    Limits: a ranked series (the whole sim series for ``group="time"``, one group's steps otherwise) holds at most 32768
-    steps (``xh_qdm_adjust`` keeps a column's keys in the registers of one workgroup; about 90 years of daily data —
-    longer series raise ``ValueError``, rank them per period or use a sub-grouping).  -0.0 and +0.0 tie, as in
+    Series of up to 32768 steps are ranked inside one workgroup (``xh_qdm_adjust``: keys in registers); longer ones
+    (1950-2100 daily = 55 152 steps) go through a global sort in column batches (qdm3.hip) — exact, not tuned.  -0.0
+    and +0.0 tie, as in
     ``scipy.stats.rankdata``."""
 
     def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", time=None, keep=False):

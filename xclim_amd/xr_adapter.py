@@ -39,6 +39,7 @@ forwarded to the ORIGINAL function (``orig``), never approximated.
 
 from __future__ import annotations
 
+import itertools
 import operator
 
 import numpy as np
@@ -73,10 +74,74 @@ def time_axis_of(da) -> TimeAxis:
     return TimeAxis(np.asarray(t.year.values), np.asarray(t.month.values), np.asarray(t.day.values), str(t.calendar))
 
 
+def is_chunked(da) -> bool:
+    """dask-backed (the reference's chunked path: core/calendar.py:460-479 ``dask="parallelized"``, indices/helpers.py:898-974,
+    core/indicator.py:865-944)?  Such a field is NEVER pulled into host memory in one piece (``.values``): the wrappers
+    walk its chunk grid over the cell dimensions, one block with the whole time axis at a time."""
+    d = getattr(da, "data", None)
+    return d is not None and hasattr(d, "dask") and hasattr(d, "chunks")
+
+
 def _tfirst(da):
-    """The DataArray with time first and its values as a C-contiguous array in the array's OWN dtype."""
+    """The DataArray with time first and its values as a C-contiguous array in the array's OWN dtype — ``None`` for a
+    chunked (dask-backed) field, whose values only ever exist block by block (:func:`chunk_index`, :func:`block_values`)."""
     a = da.transpose("time", ...)
+    if is_chunked(a):
+        return a, None
     return a, np.ascontiguousarray(a.values)
+
+
+def chunk_index(a):
+    """Index tuples (one slice per cell dimension) of the dask chunk grid of a time-first DataArray.  The time axis is
+    taken whole whatever its chunking (the reference re-chunks to ``time: -1`` itself, cal:463-467)."""
+    spans = []
+    for dim, c in zip(a.dims, a.data.chunks):
+        if dim == "time":
+            continue
+        edges = np.concatenate([[0], np.cumsum(c)])
+        spans.append([slice(int(e0), int(e1)) for e0, e1 in zip(edges[:-1], edges[1:])])
+    return list(itertools.product(*spans))
+
+
+def block_values(a, idx):
+    """The values of one cell block (whole time axis) of a time-first DataArray, C-contiguous, own dtype: the only part of
+    a chunked field that is on the host at any time."""
+    sub = a.isel({d: sl for d, sl in zip(_cell_dims(a), idx)})
+    return np.ascontiguousarray(sub.values)
+
+
+def reduce_blocks(a, x, compute):
+    """``compute(x_block, idx) -> array (R, *block cells)`` or a tuple of such.  In-memory field: one call with ``idx =
+    None``; chunked field: one call per block of :func:`chunk_index`, results stitched into ``(R, *cells)`` arrays (the
+    role ``xr.map_blocks`` / ``apply_ufunc(dask="parallelized")`` play in the reference; every op on the path is
+    independent per cell)."""
+    if x is not None:
+        return compute(x, None)
+    cells = tuple(a.shape[1:])
+    outs, was_tuple = None, False
+    for idx in chunk_index(a):
+        r = compute(block_values(a, idx), idx)
+        was_tuple = isinstance(r, tuple)
+        rt = r if was_tuple else (r,)
+        if outs is None:
+            outs = [None if o is None else np.empty((np.shape(o)[0],) + cells, np.asarray(o).dtype) for o in rt]
+        for o, dst in zip(rt, outs):
+            if dst is not None:
+                dst[(slice(None),) + tuple(idx)] = np.asarray(o)
+    return tuple(outs) if was_tuple else outs[0]
+
+
+def threshold_block(thr, idx, a):
+    """The part of a threshold that belongs to a cell block: scalars as they are, per-cell and full arrays sliced,
+    per-doy tables as the block's own slab (``DoyPercentile.block``)."""
+    if idx is None or isinstance(thr, (int, float)) or (np.ndim(thr) == 0 and not isinstance(thr, hcal.DoyPercentile)):
+        return thr
+    if isinstance(thr, hcal.DoyPercentile):
+        return thr.block(idx)
+    thr = np.asarray(thr)
+    if thr.ndim == len(_cell_dims(a)):
+        return np.ascontiguousarray(thr[tuple(idx)])
+    return np.ascontiguousarray(thr[(slice(None),) + tuple(idx)])
 
 
 def _cell_dims(a):
@@ -160,14 +225,21 @@ class LazyCompare(_LazyBase):
         from . import kernels as K
 
         a, x = _tfirst(self.da)
-        dev, doy = self._dev, hcal.adjust_doy_calendar(self.thr.doy, self.thr.time, self._dev)
-        xd, _ = hcal._flatten(x, dev)
-        table = doy.data.reshape(doy.data.shape[1], doy.data.shape[2])
-        # x[t] OP table[dayofyear(t)] compared in float64 like numpy does for float32 data against a float64 threshold
-        m = K.compare_doy(dev, xd, hgen.get_op(self.op, self.constrain), table, hcal.resample_doy_index(doy, self.thr.time))
+        dev = self._dev
+
+        def one(xb, idx):
+            doy = hcal.adjust_doy_calendar(threshold_block(self.thr.doy, idx, a), self.thr.time, dev)
+            xd, _ = hcal._flatten(xb, dev)
+            table = doy.data.reshape(doy.data.shape[1], doy.data.shape[2])
+            # x[t] OP table[dayofyear(t)] compared in float64 like numpy does for float32 data against a float64 threshold
+            m = K.compare_doy(dev, xd, hgen.get_op(self.op, self.constrain), table, hcal.resample_doy_index(doy, self.thr.time))
+            return m.get().reshape(xb.shape) != 0
+
+        # (a chunked field: the mask is assembled block by block — whoever touches a LazyCompare asked for the full mask)
+        mask = reduce_blocks(a, x, one)
         coords = dict(_cell_coords(a))
         coords["time"] = a["time"]
-        return self._env.DataArray(m.get().reshape(x.shape) != 0, coords=coords, dims=a.dims)
+        return self._env.DataArray(mask, coords=coords, dims=a.dims)
 
 
 def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
@@ -197,6 +269,18 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         idx = tuple(sorted((k, repr(v)) for k, v in indexer.items() if v is not None)) if indexer else ()
         return (ai["data"][0], x.shape, x.strides, x.dtype.str, freq, idx)
 
+    def _fingerprint(x):
+        """A cheap guard against a buffer that was modified in place between the reducer and the missing-value check
+        (``da.values[...] = nan``): the NaN count of the first, a middle and the last time step."""
+        T = x.shape[0]
+        return tuple(int(np.isnan(x[t]).sum()) for t in sorted({0, T // 2, T - 1})) if T and x.dtype.kind == "f" else ()
+
+    def plain_indexer(indexer):
+        """Indexers whose values are plain python / numpy values.  DataArray-valued ``doy_bounds`` (per cell, or with a time
+        dimension: cal:1199-1246, missing.py:140-146) carry their own dimension order: such calls go to the reference."""
+        return not any(isinstance(v, (DA, _LazyBase)) or (isinstance(v, (tuple, list)) and any(isinstance(e, (DA, _LazyBase)) for e in v))
+                       for v in (indexer or {}).values())
+
     def remember_valid(da, x, freq, valid, indexer=None):
         """`x`: the C-contiguous time-first values the kernel read.  Only buffers that ARE the DataArray's own storage can be
         recognised again (a transposed / non-contiguous input was copied by _tfirst: nothing to remember)."""
@@ -210,11 +294,13 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
             return
         if len(valid_cache) > 64:
             valid_cache.clear()
-        valid_cache[_buffer_key(x, freq, indexer)] = (ref, np.asarray(valid))
+        valid_cache[_buffer_key(x, freq, indexer)] = (ref, np.asarray(valid), _fingerprint(x))
 
     def recall_valid(x, freq, indexer):
-        hit = valid_cache.get(_buffer_key(x, freq, indexer))
-        if hit is None or hit[0]() is None:
+        """ONE-SHOT: the Indicator runs the missing-value check right after the compute (core/indicator.py:1522-1549); an
+        entry that was used, or whose buffer no longer looks the same, is gone."""
+        hit = valid_cache.pop(_buffer_key(x, freq, indexer), None)
+        if hit is None or hit[0]() is None or hit[2] != _fingerprint(x):
             return None
         return hit[1]
 
@@ -261,7 +347,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         if np.ndim(thr) != 0:
             return False
         if isinstance(thr, np.generic):
-            return np.can_cast(thr.dtype, x.dtype, "safe")
+            return np.can_cast(thr.dtype, x.dtype, "safe")  # (x: the values or the DataArray — only its dtype is used)
         return isinstance(thr, (int, float))
 
     # ---- indices/generic.py ---------------------------------------------------------------------------------------
@@ -272,8 +358,11 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         thr = as_threshold(threshold, a)
         if thr is None:
             return fallback("threshold_count", da, op, threshold, freq, constrain)
-        out, valid = hgen.threshold_count(x, op, thr, time_axis_of(a), freq, constrain, device=dev(), with_valid=True)
-        remember_valid(a, x, freq, valid)
+        t = time_axis_of(a)
+        out, valid = reduce_blocks(a, x, lambda xb, idx: hgen.threshold_count(xb, op, threshold_block(thr, idx, a), t, freq, constrain,
+                                                                              device=dev(), with_valid=True))
+        if x is not None:
+            remember_valid(a, x, freq, valid)
         return wrap_periods(a, np.asarray(out).astype(np.int64), freq)  # (bool * 1).resample.sum: int64, no attrs
 
     def count_occurrences(data, threshold, freq, op, constrain=None):  # gen:960-999
@@ -281,27 +370,34 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         thr = as_threshold(env.convert_units_to(threshold, data), a)
         if thr is None:
             return fallback("count_occurrences", data, threshold, freq, op, constrain)
-        out, valid = hgen.count_occurrences(x, thr, op, time_axis_of(a), freq, constrain, device=dev(), with_valid=True)
-        remember_valid(a, x, freq, valid)
+        t = time_axis_of(a)
+        out, valid = reduce_blocks(a, x, lambda xb, idx: hgen.count_occurrences(xb, threshold_block(thr, idx, a), op, t, freq, constrain,
+                                                                                device=dev(), with_valid=True))
+        if x is not None:
+            remember_valid(a, x, freq, valid)
         return env.to_agg_units(wrap_periods(a, np.asarray(out).astype(np.int64), freq, data.attrs), data, "count", dim="time")
 
     def domain_count(da, low, high, freq):  # gen:364-392
         if np.ndim(low) != 0 or np.ndim(high) != 0 or isinstance(low, DA) or isinstance(high, DA):
             return fallback("domain_count", da, low, high, freq)
         a, x = _tfirst(da)
-        if not plain_scalar(low, x) or not plain_scalar(high, x):
+        if not plain_scalar(low, a) or not plain_scalar(high, a):
             return fallback("domain_count", da, low, high, freq)
-        out = hgen.domain_count(x, low, high, time_axis_of(a), freq, device=dev())
+        t = time_axis_of(a)
+        out = reduce_blocks(a, x, lambda xb, idx: hgen.domain_count(xb, low, high, t, freq, device=dev()))
         return wrap_periods(a, np.asarray(out).astype(np.int64), freq)
 
     def select_resample_op(da, op, freq="YS", out_units=None, **indexer):  # gen:83-125
         # callables and the names gen:221 maps to callables (doymin / doymax: resample_map of a DataArray function) stay with
         # the reference
-        if not isinstance(op, str) or op not in ("min", "max", "mean", "std", "var", "count", "sum", "integral", "argmax", "argmin"):
+        if (not isinstance(op, str) or op not in ("min", "max", "mean", "std", "var", "count", "sum", "integral", "argmax", "argmin")
+                or not plain_indexer(indexer)):
             return fallback("select_resample_op", da, op, freq, out_units, **indexer)
         a, x = _tfirst(da)
-        out, valid = hgen.select_resample_op(x, op, time_axis_of(a), freq, device=dev(), with_valid=True, **indexer)
-        remember_valid(a, x, freq, valid, indexer)
+        t = time_axis_of(a)
+        out, valid = reduce_blocks(a, x, lambda xb, idx: hgen.select_resample_op(xb, op, t, freq, device=dev(), with_valid=True, **indexer))
+        if x is not None:
+            remember_valid(a, x, freq, valid, indexer)
         o = wrap_periods(a, out, freq, da.attrs, da.name)
         return env.finish_select_resample_op(o, da, op, out_units)
 
@@ -312,15 +408,18 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
                             min_gap=min_gap, resample_before_rl=resample_before_rl, **indexer)
         a, x = _tfirst(data)
         thr = as_threshold(env.convert_units_to(threshold, data, context="infer"), a)
-        if thr is None or isinstance(thr, hcal.DoyPercentile) or (np.ndim(thr) == 0 and not plain_scalar(thr, x)):
+        if (thr is None or isinstance(thr, hcal.DoyPercentile) or (np.ndim(thr) == 0 and not plain_scalar(thr, a))
+                or not plain_indexer(indexer)):
             return fallback("spell_length_statistics", data, threshold, window, win_reducer, op, spell_reducer, freq,
                             min_gap=min_gap, resample_before_rl=resample_before_rl, **indexer)
         reducers = [spell_reducer] if isinstance(spell_reducer, str) else list(spell_reducer)
         outs = []
+        t = time_axis_of(a)
         for sr in reducers:
-            o, valid = hgen.spell_length_statistics(x, thr, window, win_reducer, op, sr, time_axis_of(a), freq, min_gap,
-                                                    resample_before_rl, device=dev(), with_valid=True, **indexer)
-            if not indexer:  # (with an indexer the count is of the unselected data: not what MissingAny wants)
+            o, valid = reduce_blocks(a, x, lambda xb, idx: hgen.spell_length_statistics(
+                xb, threshold_block(thr, idx, a), window, win_reducer, op, sr, t, freq, min_gap, resample_before_rl, device=dev(),
+                with_valid=True, **indexer))
+            if not indexer and x is not None:  # (with an indexer the count is of the unselected data: not what MissingAny wants)
                 remember_valid(a, x, freq, valid)
             w = wrap_periods(a, o, freq, data.attrs)
             if sr == "count":
@@ -335,9 +434,11 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
             return fallback("cumulative_difference", data, threshold, op, freq)
         a, x = _tfirst(data)
         thr = as_threshold(env.convert_units_to(threshold, data), a)
-        if thr is None or not plain_scalar(thr, x):
+        if thr is None or not plain_scalar(thr, a):
             return fallback("cumulative_difference", data, threshold, op, freq)
-        out = wrap_periods(a, hgen.cumulative_difference(x, float(thr), op, time_axis_of(a), freq, device=dev()), freq, data.attrs)
+        t = time_axis_of(a)
+        out = wrap_periods(a, reduce_blocks(a, x, lambda xb, idx: hgen.cumulative_difference(xb, float(thr), op, t, freq, device=dev())),
+                           freq, data.attrs)
         if env.difference_attrs is not None and "units" in data.attrs:  # a sum of differences: delta units (gen:1550)
             out.attrs.update(env.difference_attrs(data.attrs["units"]))
         return env.to_agg_units(out, data, op="integral")
@@ -353,21 +454,24 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         b, x2 = _tfirst(data_var2)
         t1 = as_threshold(env.convert_units_to(threshold_var1, data_var1), a)
         t2 = as_threshold(env.convert_units_to(threshold_var2, data_var2), b)
-        if t1 is None or t2 is None or not plain_scalar(t1, x1) or not plain_scalar(t2, x2) or x1.shape != x2.shape:
+        if (t1 is None or t2 is None or not plain_scalar(t1, a) or not plain_scalar(t2, b) or tuple(a.shape) != tuple(b.shape)
+                or (x1 is None) != (x2 is None)):
             return fallback("bivariate_count_occurrences", **kw)
-        out = hgen.bivariate_count_occurrences(data_var1=x1, data_var2=x2, threshold_var1=float(t1), threshold_var2=float(t2),
-                                               time=time_axis_of(a), freq=freq, op_var1=op_var1, op_var2=op_var2,
-                                               var_reducer=var_reducer, constrain_var1=constrain_var1,
-                                               constrain_var2=constrain_var2, device=dev())
+        t = time_axis_of(a)
+        out = reduce_blocks(a, x1, lambda xb, idx: hgen.bivariate_count_occurrences(
+            data_var1=xb, data_var2=x2 if idx is None else block_values(b, idx), threshold_var1=float(t1), threshold_var2=float(t2),
+            time=t, freq=freq, op_var1=op_var1, op_var2=op_var2, var_reducer=var_reducer, constrain_var1=constrain_var1,
+            constrain_var2=constrain_var2, device=dev()))
         return env.to_agg_units(wrap_periods(a, np.asarray(out).astype(np.int64), freq, data_var1.attrs), data_var1, "count", dim="time")
 
     def season(data, thresh, window, op, stat, freq, mid_date=None, constrain=None):  # gen:770-853
         a, x = _tfirst(data)
         thr = as_threshold(env.convert_units_to(thresh, data, context="infer"), a)
-        if thr is None or not plain_scalar(thr, x) or stat not in ("start", "end", "length"):
+        if thr is None or not plain_scalar(thr, a) or stat not in ("start", "end", "length"):
             return fallback("season", data, thresh, window, op, stat, freq, mid_date=mid_date, constrain=constrain)
         hgen.get_op(op, constrain)
-        res = hgen.season(x, float(thr), window, op, time_axis_of(a), freq, mid_date, device=dev())[stat]
+        t = time_axis_of(a)
+        res = reduce_blocks(a, x, lambda xb, idx: hgen.season(xb, float(thr), window, op, t, freq, mid_date, device=dev())[stat])
         out = wrap_periods(a, res, freq, data.attrs)
         if stat == "length":
             return env.to_agg_units(out, data, "count")
@@ -377,11 +481,12 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     def first_day_threshold_reached(data, *, threshold, op, after_date, window=1, freq="YS", constrain=None):  # gen:1556-1608
         a, x = _tfirst(data)
         thr = as_threshold(env.convert_units_to(threshold, data), a)
-        if thr is None or not plain_scalar(thr, x):
+        if thr is None or not plain_scalar(thr, a):
             return fallback("first_day_threshold_reached", data, threshold=threshold, op=op, after_date=after_date, window=window,
                             freq=freq, constrain=constrain)
-        res = hgen.first_day_threshold_reached(x, threshold=float(thr), op=op, after_date=after_date, time=time_axis_of(a),
-                                               window=window, freq=freq, constrain=constrain, device=dev())
+        t = time_axis_of(a)
+        res = reduce_blocks(a, x, lambda xb, idx: hgen.first_day_threshold_reached(
+            xb, threshold=float(thr), op=op, after_date=after_date, time=t, window=window, freq=freq, constrain=constrain, device=dev()))
         out = wrap_periods(a, res, freq, data.attrs)
         out.attrs.update(units="", is_dayofyear=np.int32(1), calendar=str(a["time"].dt.calendar))
         return out
@@ -389,12 +494,16 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     def compare(left, op, right, constrain=None):  # gen:301-326
         if isinstance(right, DoyThreshold) and isinstance(left, DA):
             hgen.get_op(op, constrain)  # the reference's ValueError for an unknown / constrained operator comes first
+            if left.dtype != np.float32:
+                # the fused kernels behind a LazyCompare read float32 fields; a float64 (or integer) field is compared by
+                # the reference itself against the materialised (time, ...) threshold — forwarded, never refused later
+                return fallback("compare", left, op, right._get(), constrain)
             return LazyCompare(env, left, op, right, constrain, dev())
         if isinstance(left, _LazyBase):
             left = left._get()
         if isinstance(right, _LazyBase):
             right = right._get()
-        if not isinstance(left, DA):
+        if not isinstance(left, DA) or is_chunked(left):  # (a chunked full-shape mask is the reference's own dask business)
             return fallback("compare", left, op, right, constrain)
         a, x = _tfirst(left) if "time" in left.dims else (left, np.ascontiguousarray(left.values))
         thr = as_threshold(right, a) if "time" in left.dims else (right if np.ndim(right) == 0 and not isinstance(right, DA) else None)
@@ -411,10 +520,27 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     def percentile_doy(arr, window=5, per=10.0, alpha=1.0 / 3.0, beta=1.0 / 3.0, copy=True):  # cal:395-494
         pers = [per] if np.isscalar(per) else list(per)
         a, x = _tfirst(arr)
-        p = hcal.percentile_doy(x, time_axis_of(a), window=window, per=pers, alpha=alpha, beta=beta, device=dev())
+        t = time_axis_of(a)
+        meta = {}
+
+        def one(xb, idx):
+            p = hcal.percentile_doy(xb, t, window=window, per=pers, alpha=alpha, beta=beta, device=dev())
+            meta.setdefault("p", p)
+            return p.values()  # (ndoy, *cells, nper)
+
+        if x is not None:
+            vals = one(x, None)
+        else:  # chunked: block by block (the reference: apply_ufunc(dask="parallelized") after time: -1, cal:460-479)
+            vals = None
+            for idx in chunk_index(a):
+                v = one(block_values(a, idx), idx)
+                if vals is None:
+                    vals = np.empty((v.shape[0],) + tuple(a.shape[1:]) + (v.shape[-1],), v.dtype)
+                vals[(slice(None),) + tuple(idx)] = v
+        p = meta["p"]
         coords = dict(_cell_coords(a))
         coords.update(dayofyear=np.asarray(p.dayofyear), percentiles=np.asarray(pers, dtype=np.float64))
-        out = DA(p.values(), coords=coords, dims=("dayofyear",) + _cell_dims(a) + ("percentiles",), attrs=dict(arr.attrs),
+        out = DA(vals, coords=coords, dims=("dayofyear",) + _cell_dims(a) + ("percentiles",), attrs=dict(arr.attrs),
                  name="per")
         # the reference's order: unstack("time") appends (year, dayofyear) after the cell dimensions, apply_ufunc appends
         # the percentile dimension (cal:448-480) -> (*cells, dayofyear, percentiles)
@@ -432,10 +558,10 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         if set(doy.dims) != {"dayofyear", *cd}:
             return fallback("resample_doy", doy, arr)
         table = np.ascontiguousarray(doy.transpose("dayofyear", *cd).values, dtype=np.float64)
-        D = table.shape[0]
         d = dev()
-        data = d.to_device(table.reshape(1, D, -1), dtype=np.float64)
-        dp = hcal.DoyPercentile(data, np.asarray(doy["dayofyear"].values), [np.nan], table.shape[1:], dict(doy.attrs))
+        # the table stays on the host until a kernel wants it: whole (in-memory field) or slab by slab (chunked field)
+        dp = hcal.DoyPercentile(None, np.asarray(doy["dayofyear"].values), [np.nan], table.shape[1:], dict(doy.attrs),
+                                host=table[None], device=d)
         return DoyThreshold(env, dp, arr, time_axis_of(a), d)
 
     # ---- indices/run_length.py ------------------------------------------------------------------------------------
@@ -444,15 +570,31 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         if isinstance(da, _LazyBase):
             da = da._get()
         a, x = _tfirst(da)
-        if x.dtype == bool:
+        if x is not None and x.dtype == bool:
             x = x.astype(np.float32)
         return a, x, time_axis_of(a)
+
+    def mask_block(xb):
+        return xb.astype(np.float32) if xb.dtype == bool else xb
+
+    def rl_blocks(a, x, fn):
+        """fn(mask values) -> (P, *cells) or (*cells) [freq=None]; chunked masks block by block"""
+        if x is not None:
+            return fn(x)
+        out = None
+        for idx in chunk_index(a):
+            r = np.asarray(fn(mask_block(block_values(a, idx))))
+            lead = r.ndim - len(idx)  # 1 with a period axis, 0 for one value per cell
+            if out is None:
+                out = np.empty(r.shape[:lead] + tuple(a.shape[1:]), r.dtype)
+            out[(slice(None),) * lead + tuple(idx)] = r
+        return out
 
     def _rl_out(a, out, freq, name=None):
         return wrap_cells(a, out, name=name) if freq is None else wrap_periods(a, out, freq, name=name)
 
     def rle(da, dim="time", index="first"):  # rl:223-272
-        if dim != "time":
+        if dim != "time" or (isinstance(da, DA) and is_chunked(da)):  # (a chunked full-shape result: the reference's dask path)
             return fallback("rle", da, dim, index)
         a, x, _ = _mask_values(da)
         return wrap_full(a, hrl.rle(x, dim, index, device=dev()), da.attrs if isinstance(da, DA) else None)
@@ -461,31 +603,31 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         if dim != "time":
             return fallback("rle_statistics", da, reducer, window, dim, freq, ufunc_1dim, index)
         a, x, t = _mask_values(da)
-        return _rl_out(a, hrl.rle_statistics(x, reducer, window, dim, freq, ufunc_1dim, index, time=t, device=dev()), freq)
+        return _rl_out(a, rl_blocks(a, x, lambda xb: hrl.rle_statistics(xb, reducer, window, dim, freq, ufunc_1dim, index, time=t, device=dev())), freq)
 
     def longest_run(da, dim="time", freq=None, ufunc_1dim="from_context", index="first"):  # rl:338-378
         if dim != "time":
             return fallback("longest_run", da, dim, freq, ufunc_1dim, index)
         a, x, t = _mask_values(da)
-        return _rl_out(a, hrl.longest_run(x, dim, freq, ufunc_1dim, index, time=t, device=dev()), freq)
+        return _rl_out(a, rl_blocks(a, x, lambda xb: hrl.longest_run(xb, dim, freq, ufunc_1dim, index, time=t, device=dev())), freq)
 
     def windowed_run_events(da, window, dim="time", freq=None, ufunc_1dim="from_context", index="first"):  # rl:381-434
         if dim != "time":
             return fallback("windowed_run_events", da, window, dim, freq, ufunc_1dim, index)
         a, x, t = _mask_values(da)
-        return _rl_out(a, hrl.windowed_run_events(x, window, dim, freq, ufunc_1dim, index, time=t, device=dev()), freq)
+        return _rl_out(a, rl_blocks(a, x, lambda xb: hrl.windowed_run_events(xb, window, dim, freq, ufunc_1dim, index, time=t, device=dev())), freq)
 
     def windowed_run_count(da, window, dim="time", freq=None, ufunc_1dim="from_context", index="first"):  # rl:437-488
         if dim != "time":
             return fallback("windowed_run_count", da, window, dim, freq, ufunc_1dim, index)
         a, x, t = _mask_values(da)
-        return _rl_out(a, hrl.windowed_run_count(x, window, dim, freq, ufunc_1dim, index, time=t, device=dev()), freq)
+        return _rl_out(a, rl_blocks(a, x, lambda xb: hrl.windowed_run_count(xb, window, dim, freq, ufunc_1dim, index, time=t, device=dev())), freq)
 
     def _boundary(name, host, da, window, dim, freq, coord, ufunc_1dim):
         if dim != "time" or coord not in (None, False, "dayofyear", "year", "month", "day"):
             return fallback(name, da, window, dim, freq, coord, ufunc_1dim)  # coord=True: datetime labels (reference path)
         a, x, t = _mask_values(da)
-        return _rl_out(a, host(x, window, dim, freq, coord or None, ufunc_1dim, time=t, device=dev()), freq)
+        return _rl_out(a, rl_blocks(a, x, lambda xb: host(xb, window, dim, freq, coord or None, ufunc_1dim, time=t, device=dev())), freq)
 
     def first_run(da, window, dim="time", freq=None, coord=None, ufunc_1dim="from_context"):  # rl:643-690
         return _boundary("first_run", hrl.first_run, da, window, dim, freq, coord, ufunc_1dim)
@@ -497,7 +639,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         if dim != "time":
             return fallback("season_length", da, window, mid_date, dim)
         a, x, t = _mask_values(da)
-        return wrap_cells(a, hrl.season_length(x, window, mid_date, dim, time=t, device=dev()))
+        return wrap_cells(a, rl_blocks(a, x, lambda xb: hrl.season_length(xb, window, mid_date, dim, time=t, device=dev())))
 
     rl_host = {}  # wrapper -> host mirror, for resample_and_rl (which receives the function OBJECT rl.<name>)
     lazy_ok = set()  # the run statistics that xh_run_stats_doy fuses with the per-doy compare
@@ -512,16 +654,19 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
             from . import indices as hind
 
             a, x = _tfirst(da.da)
+            t = time_axis_of(a)
             params = dict(zip({"rle_statistics": ("reducer", "window"), "longest_run": (), "windowed_run_events": ("window",),
                                "windowed_run_count": ("window",)}[host.__name__], args))
             params.update(kwargs)
             stat = {"rle_statistics": params.get("reducer"), "longest_run": "max", "windowed_run_events": "count",
                     "windowed_run_count": "sum"}[host.__name__]
-            out = hind.percentile_run_stat(x, da.thr.doy, da.op, stat, int(params.get("window", 1)), time_axis_of(a), freq,
-                                           resample_before_rl, constrain=da.constrain, device=dev())
+            out = reduce_blocks(a, x, lambda xb, idx: hind.percentile_run_stat(
+                xb, threshold_block(da.thr.doy, idx, a), da.op, stat, int(params.get("window", 1)), t, freq, resample_before_rl,
+                constrain=da.constrain, device=dev()))
             return wrap_periods(a, out, freq)
         a, x, t = _mask_values(da)
-        out = hrl.resample_and_rl(x, resample_before_rl, host, *args, freq=freq, time=t, dim=dim, device=dev(), **kwargs)
+        out = rl_blocks(a, x, lambda xb: hrl.resample_and_rl(xb, resample_before_rl, host, *args, freq=freq, time=t, dim=dim,
+                                                              device=dev(), **kwargs))
         return wrap_periods(a, out, freq)
 
     lazy_ok.update((windowed_run_count, windowed_run_events, rle_statistics, longest_run))
@@ -533,15 +678,17 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     def missing_any_call(self, da, freq=None, src_timestep=None, **indexer):  # MissingBase.__call__ for MissingAny, :253-298, 318-322
         if freq is None or not isinstance(da, DA) or "time" not in da.dims or (src_timestep not in (None, "D", "1D")):
             return fallback("MissingAny.__call__", self, da, freq, src_timestep, **indexer)
+        if not plain_indexer(indexer):
+            return fallback("MissingAny.__call__", self, da, freq, src_timestep, **indexer)
         a, x = _tfirst(da)
         t = time_axis_of(a)
         if len(t) > 1 and not np.all(np.diff(t.ordinal()) == 1):  # xr.infer_freq(da.time) must be daily
             return fallback("MissingAny.__call__", self, da, freq, src_timestep, **indexer)
         idx = {k: v for k, v in indexer.items() if v is not None}
-        valid = recall_valid(x, freq, idx)
+        valid = recall_valid(x, freq, idx) if x is not None else None
         if valid is None:
             try:
-                valid = hgen.select_resample_op(x, "count", t, freq, device=dev(), **idx)
+                valid = reduce_blocks(a, x, lambda xb, bi: hgen.select_resample_op(xb, "count", t, freq, device=dev(), **idx))
             except Float64FieldError:  # count of a float64 field with a time selection: the reference's business
                 return fallback("MissingAny.__call__", self, da, freq, src_timestep, **indexer)
         expected = t.expected_count(freq, **idx)
@@ -561,7 +708,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
 
         a, x = _tfirst(da)
         qs = np.atleast_1d(np.asarray(q, dtype=np.float64))
-        out = hsdba.quantile(x, qs, device=dev())  # (nq, *cells)
+        out = reduce_blocks(a, x, lambda xb, idx: np.asarray(hsdba.quantile(xb, qs, device=dev())))  # (nq, *cells)
         coords = dict(_cell_coords(a))
         coords["quantiles"] = qs
         return DA(np.moveaxis(np.asarray(out), 0, -1), coords=coords, dims=_cell_dims(a) + ("quantiles",), attrs=dict(da.attrs),
@@ -587,9 +734,12 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
             return fallback("sdba_interp_on_quantiles", newx, xq, yq, **kw)
         if "time" not in newx.dims or "quantiles" not in xq.dims or set(xq.dims) != set(yq.dims):
             return fallback("sdba_interp_on_quantiles", newx, xq, yq, **kw)
+        if is_chunked(newx) or not (newx.dtype == xq.dtype == yq.dtype == np.float32):
+            # a chunked full-shape result is the reference's dask path; float64 nodes or factors are never rounded here
+            return fallback("sdba_interp_on_quantiles", newx, xq, yq, **kw)
         a, x = _tfirst(newx)
         cd = _cell_dims(a)
-        if set(xq.dims) != {"quantiles", *cd} or x.dtype != np.float32:
+        if set(xq.dims) != {"quantiles", *cd}:
             return fallback("sdba_interp_on_quantiles", newx, xq, yq, **kw)
         from . import kernels as K_
 
@@ -604,7 +754,9 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
                             "factor", method, extrapolation).get().reshape(x.shape)
         coords = dict(_cell_coords(a))
         coords["time"] = a["time"]
-        return DA(out.astype(yq.dtype, copy=False), coords=coords, dims=a.dims, attrs=dict(newx.attrs), name=newx.name)
+        # xsdba: apply_ufunc(..., output_core_dims=[[dim]]) puts the core dimension LAST
+        res = DA(out, coords=coords, dims=a.dims, attrs=dict(newx.attrs), name=newx.name)
+        return res.transpose(*(cd + ("time",)))
 
     def forwarding(name, fn):
         """A float64 field on a float32-only kernel (Float64FieldError) goes to the reference's own function: the
@@ -626,10 +778,13 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
 
             return tuple(fix(o) for o in out) if isinstance(out, tuple) else fix(out)
 
+        keep_order = name in ("sdba_interp_on_quantiles",)  # (apply_ufunc results: core dimension last, not the input's order)
+
         @functools.wraps(fn)
         def wrapper(*args, **kwargs):
             try:
-                return restore_order(fn(*args, **kwargs), args, kwargs)
+                out = fn(*args, **kwargs)
+                return out if keep_order else restore_order(out, args, kwargs)
             except Float64FieldError:
                 return fallback(name, *args, **kwargs)
 
@@ -651,6 +806,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         "MissingAny.__call__": missing_any_call,
     }
     out = {name: forwarding(name, fn) for name, fn in table.items()}
+    out["_clear_valid_cache"] = valid_cache.clear  # (patch.uninstall)
     # resample_and_rl receives the PATCHED rl.<name> objects (the forwarding wrappers): map those to the host mirrors too
     for inner, host in list(rl_host.items()):
         for name, fn in table.items():
