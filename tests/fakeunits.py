@@ -1,4 +1,6 @@
-"""Threshold units on the hot path (reference: core/units.py:334-420 ``convert_units_to`` with the "hydro" context).
+"""TEST INFRASTRUCTURE (the stand-in's ``convert_units_to``; units are OUT OF SCOPE for the product, SURVEY.md §2 — round 3
+shipped this file as xclim_amd/units.py).  Threshold units on the hot path (reference: core/units.py:334-420
+``convert_units_to`` with the "hydro" context).
 
 The reference parses quantities with pint.  The index functions of this backend take thresholds as floats in the units
 of the data; this module is the small, dependency-free piece of ``convert_units_to`` an adapter needs for the threshold

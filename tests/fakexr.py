@@ -1,11 +1,14 @@
-"""A ~150-line stand-in for the part of ``xarray.DataArray`` that xclim_amd/xr_adapter.py touches (its module docstring
+"""A small stand-in for the part of ``xarray.DataArray`` that xclim_amd/xr_adapter.py touches (its module docstring
 lists the protocol), so that the xarray-facing wrappers are executed on the GPU box, where xarray cannot be installed.
 TEST INFRASTRUCTURE ONLY — nothing in the product imports it.
 
-Also: stand-in MODULES with the reference's import structure (``make_reference_like_modules``): the index bodies are
-restated from the reference in a few lines each (file:line given) and import ``threshold_count`` / ``compare`` /
-``resample_doy`` BY NAME like the reference does, so that ``patch.install(env, modules)`` is exercised with the same
-resolution rules as on a real installation.
+Also: stand-in MODULES with the reference's import structure (``make_reference_like_modules``).  Their index functions are
+NOT re-typed: each one replays the call program that tests/golden/make_call_programs.py recorded by executing the
+reference's own body (tests/callprog.py), inside the stand-in module's namespace, where ``threshold_count`` / ``compare``
+/ ``resample_doy`` are held BY NAME and ``rl`` as a module object like in the reference — so ``patch.install(env,
+modules)`` is exercised with the reference's resolution rules AND the reference's call sequences.  What
+the DataArray stand-in offers beyond the adapter's protocol (``where(cond, other)``, ``&``, ``resample().sum()``,
+``attrs[...] = ``) is there because a recorded reference line uses it.
 """
 import types
 
@@ -34,6 +37,29 @@ class _Resampled:
         first = np.asarray(seg[:-1])
         lab = time_coord_like(self._da, first)
         return DataArray(self._da.values[first], coords={"time": lab}, dims=("time",))
+
+    def _reduce(self, fn, dim="time"):
+        """resample(time=freq).<sum|max|min|mean>(dim="time") of a data array (host numpy: not a replaced function)."""
+        from xclim_amd.timeaxis import TimeAxis
+
+        da = self._da
+        c = da.coords["time"]
+        seg, _ = TimeAxis(c._fields["year"], c._fields["month"], c._fields["day"], c._cal).segments(self._freq)
+        ax = da.dims.index("time")
+        v = np.moveaxis(da.values, ax, 0)
+        out = np.stack([fn(v[a:b], axis=0) for a, b in zip(seg[:-1], seg[1:])])
+        coords = dict(da.coords)
+        coords["time"] = time_coord_like(c, np.asarray(seg[:-1]))
+        return DataArray(np.moveaxis(out, 0, ax), coords=coords, dims=da.dims, attrs=da.attrs)
+
+    def sum(self, dim="time"):
+        return self._reduce(np.sum, dim)
+
+    def max(self, dim="time"):
+        return self._reduce(np.max, dim)
+
+    def min(self, dim="time"):
+        return self._reduce(np.min, dim)
 
 
 class ChunkedArray:
@@ -174,10 +200,16 @@ class DataArray:
         out._fields, out._cal = self._fields, self._cal
         return out
 
-    def where(self, cond):
+    def where(self, cond, other=None):
         c = cond.transpose(*self.dims).values if isinstance(cond, DataArray) else np.asarray(cond)
-        out = self.copy(np.where(c, self.values.astype(np.result_type(self.values.dtype, np.float32)), np.nan))
-        return out
+        if other is None:
+            return self.copy(np.where(c, self.values.astype(np.result_type(self.values.dtype, np.float32)), np.nan))
+        o = other.transpose(*self.dims).values if isinstance(other, DataArray) else other
+        return self.copy(np.where(c, self.values, o))
+
+    def __and__(self, o): return self._bin(o, np.logical_and)
+    def __or__(self, o): return self._bin(o, np.logical_or)
+    def __truediv__(self, o): return self._bin(o, np.divide)
 
     def __invert__(self):
         return self.copy(~self.values)
@@ -227,6 +259,13 @@ def make_env():
     from xclim_amd.xr_adapter import Env
 
     def convert_units_to(thr, data, context=None):
+        """core/units.py:334-420 as far as the recorded index bodies need it: threshold STRINGS ("1 mm/day", "30 degC") in
+        the units of ``data`` (tests/fakeunits.py, the hydro context is the bodies' ``units.context("hydro")``); numbers and
+        DataArrays are taken to be in the data's units already."""
+        if isinstance(thr, str):
+            import fakeunits
+
+            return fakeunits.convert_units_to(thr, data.attrs["units"], context="hydro")
         return thr
 
     def to_agg_units(out, orig, op, dim="time", **kw):
@@ -238,19 +277,24 @@ def make_env():
 
 def make_reference_like_modules(env):
     """name -> module, wired like the reference: ``generic`` / ``calendar`` / ``run_length`` / ``utils`` define the functions
-    (here: stubs that fail loudly — after ``install`` nothing may reach them), ``_multivariate`` and ``_threshold`` import
-    them BY NAME and hold ``rl`` as a module object (indices/_multivariate.py:13, 22-24; indices/_threshold.py:25-36)."""
+    (here: stubs that fail loudly — after ``install`` nothing may reach them), ``_multivariate`` / ``_threshold`` / ``_simple``
+    import them BY NAME and hold ``rl`` as a module object (indices/_multivariate.py:13, 22-24; indices/_threshold.py:25-36;
+    indices/_simple.py:10).  Their index functions replay the reference's recorded call programs (tests/callprog.py)."""
+    import contextlib
+
+    import callprog
+
     def stub(name):
         def f(*a, **k):
             raise AssertionError(f"the reference's {name} was reached: the wrapper did not replace it")
         f.__name__ = name
         return f
 
+    generic_names = ("threshold_count", "count_occurrences", "domain_count", "select_resample_op", "spell_length_statistics",
+                     "cumulative_difference", "compare", "season", "first_day_threshold_reached", "bivariate_count_occurrences")
     mods = {}
     for modname, names in {
-        "xclim.indices.generic": ("threshold_count", "count_occurrences", "domain_count", "select_resample_op",
-                                  "spell_length_statistics", "cumulative_difference", "compare", "season",
-                                  "first_day_threshold_reached", "bivariate_count_occurrences"),
+        "xclim.indices.generic": generic_names,
         "xclim.core.calendar": ("percentile_doy", "resample_doy"),
         "xclim.indices.run_length": ("rle", "rle_statistics", "longest_run", "windowed_run_events", "windowed_run_count",
                                      "first_run", "last_run", "season_length", "resample_and_rl", "_cumsum_reset_np"),
@@ -262,71 +306,19 @@ def make_reference_like_modules(env):
         mods[modname] = m
     gen, cal, rl = mods["xclim.indices.generic"], mods["xclim.core.calendar"], mods["xclim.indices.run_length"]
 
-    mv = types.ModuleType("xclim.indices._multivariate")
-    mv.resample_doy, mv.compare, mv.threshold_count, mv.select_resample_op = cal.resample_doy, gen.compare, gen.threshold_count, gen.select_resample_op
-    mv.rl = rl
-
-    def tx90p(tasmax, tasmax_per, freq="YS", op=">"):  # indices/_multivariate.py:1584-1592
-        tasmax_per = env.convert_units_to(tasmax_per, tasmax)
-        thresh = mv.resample_doy(tasmax_per, tasmax)
-        out = mv.threshold_count(tasmax, op, thresh, freq, constrain=(">", ">="))
-        return env.to_agg_units(out, tasmax, "count", deffreq="D")
-
-    def warm_spell_duration_index(tasmax, tasmax_per, window=6, freq="YS", resample_before_rl=True, op=">"):  # :1779-1793
-        thresh = env.convert_units_to(tasmax_per, tasmax)
-        thresh = mv.resample_doy(thresh, tasmax)
-        above = mv.compare(tasmax, op, thresh, constrain=(">", ">="))
-        out = mv.rl.resample_and_rl(above, resample_before_rl, mv.rl.windowed_run_count, window=window, freq=freq)
-        return env.to_agg_units(out, tasmax, "count", deffreq="D")
-
-    mv.tx90p, mv.warm_spell_duration_index = tx90p, warm_spell_duration_index
-    mods[mv.__name__] = mv
-
-    th = types.ModuleType("xclim.indices._threshold")
-    th.spell_length_statistics, th.threshold_count, th.count_occurrences, th.domain_count = (
-        gen.spell_length_statistics, gen.threshold_count, gen.count_occurrences, gen.domain_count)
-    th.cumulative_difference, th.compare, th.rl = gen.cumulative_difference, gen.compare, rl
-
-    def maximum_consecutive_dry_days(pr, thresh=1.0 / 86400.0, op="<", freq="YS", resample_before_rl=True):  # _threshold.py:2925-2937
-        return th.spell_length_statistics(pr, thresh, 1, win_reducer=None, op=op, spell_reducer="max", freq=freq,
-                                          resample_before_rl=resample_before_rl)
-
-    def frost_days(tasmin, thresh=273.15, freq="YS"):  # _threshold.py: threshold_count(tasmin, "<", frz, freq) + to_agg_units
-        out = th.threshold_count(tasmin, "<", env.convert_units_to(thresh, tasmin), freq)
-        return env.to_agg_units(out, tasmin, "count")
-
-    def hot_spell_frequency(tasmax, thresh=303.15, window=3, freq="YS", op=">", resample_before_rl=True):  # _threshold.py (hot_spell_frequency)
-        cond = th.compare(tasmax, op, thresh, constrain=(">", ">="))
-        return th.rl.resample_and_rl(cond, resample_before_rl, th.rl.windowed_run_events, window=window, freq=freq)
-
-    def growing_degree_days(tas, thresh=277.15, freq="YS"):  # _threshold.py: cumulative_difference(tas, thresh, ">", freq)
-        return th.cumulative_difference(tas, threshold=thresh, op=">", freq=freq)
-
-    th.season, th.first_day_threshold_reached = gen.season, gen.first_day_threshold_reached
-    th.bivariate_count_occurrences = gen.bivariate_count_occurrences
-
-    def tx_tn_days_above(tasmin, tasmax, thresh_tasmin=295.15, thresh_tasmax=303.15, freq="YS", op=">"):  # _threshold.py (tx_tn_days_above)
-        return th.bivariate_count_occurrences(data_var1=tasmin, data_var2=tasmax, threshold_var1=thresh_tasmin, threshold_var2=thresh_tasmax,
-                                              freq=freq, op_var1=op, op_var2=op, var_reducer="all", constrain_var1=(">", ">="),
-                                              constrain_var2=(">", ">="))
-
-    th.tx_tn_days_above = tx_tn_days_above
-
-    def growing_season_length(tas, thresh=278.15, window=6, mid_date="07-01", freq="YS", op=">="):  # _threshold.py (growing_season_length)
-        return th.season(tas, thresh=thresh, window=window, op=op, stat="length", freq=freq, mid_date=mid_date, constrain=(">=", ">"))
-
-    def growing_season_start(tas, thresh=278.15, mid_date="07-01", window=5, freq="YS", op=">="):
-        return th.season(tas, thresh=thresh, window=window, op=op, stat="start", freq=freq, mid_date=mid_date, constrain=(">=", ">"))
-
-    def first_day_temperature_above(tas, thresh=273.15, op=">", after_date="01-01", window=1, freq="YS"):  # _threshold.py
-        return th.first_day_threshold_reached(tas, threshold=thresh, op=op, after_date=after_date, window=window, freq=freq,
-                                              constrain=(">", ">="))
-
-    th.growing_season_length, th.growing_season_start, th.first_day_temperature_above = (
-        growing_season_length, growing_season_start, first_day_temperature_above)
-    th.maximum_consecutive_dry_days, th.frost_days, th.hot_spell_frequency, th.growing_degree_days = (
-        maximum_consecutive_dry_days, frost_days, hot_spell_frequency, growing_degree_days)
-    mods[th.__name__] = th
+    # what the index modules import (by name) or hold besides the replaced functions: the unit helpers of core/units.py —
+    # here the Env's stand-ins — and the ``units`` registry whose "hydro" context some bodies enter
+    units = types.SimpleNamespace(context=lambda name: contextlib.nullcontext())
+    for modname in ("xclim.indices._multivariate", "xclim.indices._threshold", "xclim.indices._simple"):
+        m = types.ModuleType(modname)
+        for n in generic_names:
+            setattr(m, n, getattr(gen, n))
+        m.percentile_doy, m.resample_doy, m.rl = cal.percentile_doy, cal.resample_doy, rl
+        m.convert_units_to, m.to_agg_units, m.units = env.convert_units_to, env.to_agg_units, units
+        mods[modname] = m
+    for name, prog in callprog.load_programs().items():
+        m = mods[prog["module"]]
+        setattr(m, name, callprog.make_index(name, prog, m.__dict__))
 
     ms = types.ModuleType("xclim.core.missing")
 
@@ -337,22 +329,15 @@ def make_reference_like_modules(env):
     ms.MissingAny = MissingAny
     mods[ms.__name__] = ms
 
-    sp = types.ModuleType("xclim.indices._simple")
-    sp.select_resample_op = gen.select_resample_op
-
-    def tg_mean(tas, freq="YS"):  # indices/_simple.py:113
-        return sp.select_resample_op(tas, op="mean", freq=freq)
-
-    sp.tg_mean = tg_mean
-    mods[sp.__name__] = sp
-
+    # xsdba is not in the reference tree (src/xclim/sdba.py:10 re-exports the installed package): nothing to record —
+    # qm_adjust below restates xsdba._adjustment.qm_adjust for group="time" (interp_on_quantiles + apply_correction)
     su = types.ModuleType("xsdba.utils")
     su.interp_on_quantiles = stub("interp_on_quantiles")
     mods[su.__name__] = su
     sa = types.ModuleType("xsdba._adjustment")
     sa.u = su
 
-    def qm_adjust(sim, af, hist_q, kind="+", interp="nearest", extrapolation="constant"):  # xsdba._adjustment.qm_adjust, group="time"
+    def qm_adjust(sim, af, hist_q, kind="+", interp="nearest", extrapolation="constant"):
         af_t = sa.u.interp_on_quantiles(sim, hist_q, af, group="time", method=interp, extrapolation=extrapolation)
         return sim._bin(af_t, np.add if kind == "+" else np.multiply)              # utils.apply_correction
 

@@ -174,8 +174,8 @@ def test_generic_wrappers_vs_oracle(ref, dev, rng, dims):
     with pytest.raises(AssertionError, match="was reached"):   # a callable op is FORWARDED to the reference's function
         gen.select_resample_op(da, np.nanmax, "YS")
     # the index bodies of the stand-in modules (by-name imports) on the same field
-    th = mods["xclim.indices._threshold"]
-    np.testing.assert_array_equal(_tf(th.frost_days(da, 283.15, "YS")), ogen.threshold_count(x, "<", 283.15, ot, "YS"))
+    th, sp = mods["xclim.indices._threshold"], mods["xclim.indices._simple"]
+    np.testing.assert_array_equal(_tf(sp.frost_days(da, 283.15, "YS")), ogen.threshold_count(x, "<", 283.15, ot, "YS"))
     np.testing.assert_allclose(_tf(th.growing_degree_days(da, 283.0, "YS")), ogen.cumulative_difference(x, 283.0, ">", ot, "YS"), rtol=1e-6)
     np.testing.assert_allclose(_tf(mods["xclim.indices._simple"].tg_mean(da, "YS")), ogen.select_resample_op(x, "mean", ot, "YS"), rtol=1e-6, equal_nan=True)
     exp = oidx.run_index(x, ">", 292.0, "events", 3, ot, "YS")
@@ -265,7 +265,7 @@ def test_indicator_level_fusion_compute_and_missing_mask_in_one_pass(ref, dev, r
     assert np.isnan(got.values).sum() == 2
     assert len(_calls(trace, "xh_resample_reduce")) == 1 and not _calls(trace, "xh_threshold_count")   # ONE pass: mean + valid count
     trace = dev.start_trace()
-    got = indicator(mods["xclim.indices._threshold"].frost_days, 283.15)
+    got = indicator(mods["xclim.indices._simple"].frost_days, 283.15)
     dev.stop_trace()
     np.testing.assert_array_equal(got.values, oidx.apply_missing(ogen.threshold_count(x, "<", 283.15, ot, "YS").astype(np.float64), x, ot, "YS"))
     assert len(_calls(trace, "xh_threshold_count") + _calls(trace, "xh_threshold_count_doy")) == 1 and not _calls(trace, "xh_resample_reduce")
@@ -326,18 +326,97 @@ def test_season_and_first_day_threshold_reached_through_the_wrappers(ref, dev, r
 
 
 def test_bivariate_count_occurrences_through_the_wrappers(ref, dev, rng):
-    """tx_tn_days_above (_threshold.py) = bivariate_count_occurrences(..., var_reducer="all") imported by name."""
+    """generic.bivariate_count_occurrences (gen:1003-1073) called the way its one reference caller does
+    (indices/_threshold.py:3858-3870: keyword arguments, ``constrain_var*`` as LISTS)."""
     env, mods, names = ref
     assert "xclim.indices._threshold.bivariate_count_occurrences" in names
     T = 730
     ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
     tn, tx = _temp(rng, T, (4, 3), 0.01), _temp(rng, T, (4, 3), 0.01) + 6
-    out = mods["xclim.indices._threshold"].tx_tn_days_above(fakexr.field(tn, ta, attrs={"units": "K"}), fakexr.field(tx, ta, attrs={"units": "K"}),
-                                                             thresh_tasmin=292.0, thresh_tasmax=299.0, freq="MS")
+    d1, d2 = fakexr.field(tn, ta, attrs={"units": "K"}), fakexr.field(tx, ta, attrs={"units": "K"})
+    out = mods["xclim.indices._threshold"].bivariate_count_occurrences(
+        data_var1=d1, data_var2=d2, threshold_var1=292.0, threshold_var2=299.0, op_var1=">", op_var2=">", freq="MS", var_reducer="all",
+        constrain_var1=[">=", ">"], constrain_var2=[">=", ">"])
     cond = (tn > np.float32(292.0)) & (tx > np.float32(299.0))
     exp = np.stack([cond[idx].sum(axis=0) for _, idx in orl.groups(ot, "MS")])
     np.testing.assert_array_equal(out.values, exp)
     assert out.dims == ("time", "lat", "lon") and out.attrs["units"] == "days" and exp.sum() > 0
+
+
+def test_reference_call_programs_through_the_wrappers(ref, dev, rng):
+    """Every index of tests/golden/call_programs.json — the calls the REFERENCE's own bodies make, recorded by executing
+    them (tests/golden/make_call_programs.py) — replayed on the stand-in with the wrappers installed, against the
+    oracle.  This is where a wrapper that does not take what the reference hands it shows: unit STRINGS as default
+    thresholds ("30 degC", "1 mm/day" under the hydro context), ``to_agg_units(..., deffreq="D")``, positional
+    ``constrain``, masks combined with ``&`` before ``rl.resample_and_rl``, ``.where(cond, 0)`` on a wrapper's result,
+    ``out.attrs["units"] = ""``, a per-doy threshold floored with ``pr_per.where(pr_per > thresh, thresh)``."""
+    import callprog
+
+    env, mods, _ = ref
+    progs = callprog.load_programs()
+    T = 365 * 3
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    tg = _temp(rng, T, (3, 4), nan_frac=0.002)
+    tn, tx = (tg - 4).astype(np.float32), (tg + 5).astype(np.float32)
+    tas, tasmin, tasmax = (fakexr.field(v, ta, attrs={"units": "K"}) for v in (tg, tn, tx))
+    prv = np.where(rng.random((T, 3, 4)) < 0.35, rng.gamma(0.8, 8.0, (T, 3, 4)) / 86400.0, 0.0).astype(np.float32)
+    pr = fakexr.field(prv, ta, attrs={"units": "kg m-2 s-1"})
+    mv, th, sp, cal = (mods[m] for m in ("xclim.indices._multivariate", "xclim.indices._threshold", "xclim.indices._simple", "xclim.core.calendar"))
+    K0 = 273.15
+    mm = 1.0 / 86400.0
+    run = lambda x, op, thr, stat, w, freq="YS", before=True: oidx.run_index(x, op, thr, stat, w, ot, freq, before)  # noqa: E731
+    spell_max = lambda x, op, thr, before: ogen.spell_length_statistics(x, float(thr), 1, None, op, "max", ot, "YS", before)  # noqa: E731
+    # -- _simple / _threshold: defaults are unit strings
+    np.testing.assert_array_equal(sp.frost_days(tasmin).values, ogen.threshold_count(tn, "<", np.float32(K0), ot, "YS"))
+    np.testing.assert_allclose(sp.tg_mean(tas, freq="MS").values, ogen.select_resample_op(tg, "mean", ot, "MS"), rtol=1e-6, equal_nan=True)
+    np.testing.assert_array_equal(sp.tx_max(tasmax).values, ogen.select_resample_op(tx, "max", ot, "YS"))
+    np.testing.assert_array_equal(sp.tn_min(tasmin).values, ogen.select_resample_op(tn, "min", ot, "YS"))
+    np.testing.assert_array_equal(th.tx_days_above(tasmax, thresh="25 degC").values, ogen.threshold_count(tx, ">", np.float32(K0 + 25), ot, "YS"))
+    np.testing.assert_array_equal(th.tn_days_below(tasmin, thresh="-10 degC", freq="MS").values,
+                                  ogen.threshold_count(tn, "<", np.float32(K0 - 10), ot, "MS"))
+    np.testing.assert_array_equal(th.dry_days(pr, thresh="0.2 mm/day").values, ogen.threshold_count(prv, "<", np.float32(0.2 * mm), ot, "YS"))
+    np.testing.assert_array_equal(th.wetdays(pr).values, ogen.threshold_count(prv, ">=", np.float32(mm), ot, "YS"))
+    for name, op in (("maximum_consecutive_dry_days", "<"), ("maximum_consecutive_wet_days", ">")):
+        for before in (True, False):
+            got = getattr(th, name)(pr, resample_before_rl=before)
+            np.testing.assert_array_equal(got.values, spell_max(prv, op, np.float32(mm), before), err_msg=name)
+            assert got.attrs["units"] == "days"
+    np.testing.assert_allclose(th.growing_degree_days(tas, thresh="4 degC").values, ogen.cumulative_difference(tg, np.float32(K0 + 4), ">", ot, "YS"), rtol=1e-6)
+    np.testing.assert_allclose(th.cooling_degree_days(tas, thresh="18 degC").values, ogen.cumulative_difference(tg, np.float32(K0 + 18), ">", ot, "YS"), rtol=1e-6)
+    got = th.hot_spell_frequency(tasmax, thresh="22 degC", window=2)
+    np.testing.assert_array_equal(got.values, run(tx, ">", np.float32(K0 + 22), "events", 2))
+    assert got.attrs["units"] == ""
+    np.testing.assert_array_equal(th.hot_spell_max_length(tasmax, thresh="22 degC", window=3).values,
+                                  oidx.longest_run_index(tx, ">", np.float32(K0 + 22), 3, ot, "YS"))
+    np.testing.assert_array_equal(th.cold_spell_days(tas, thresh="8 degC", window=3).values,
+                                  run(tg, "<", np.float32(K0 + 8), "count", 3, freq="YS-JUL"))          # (its default freq)
+    gsl = th.growing_season_length(tas, thresh="10 degC", window=4)        # (start / first day: test_season_and_first_day_...)
+    np.testing.assert_array_equal(gsl.values, orl.season_per_period(tg >= np.float32(K0 + 10), 4, "07-01", ot, "YS")[2])
+    # -- _multivariate: two masks and-ed (host) before the run length; compare(...) * 1 -> resample().sum()
+    cond = ((tn > np.float32(K0 + 10)) & (tx > np.float32(K0 + 24))).astype(np.float32)
+    got = mv.heat_wave_frequency(tasmin, tasmax, thresh_tasmin="10 degC", thresh_tasmax="24 degC", window=2)
+    np.testing.assert_array_equal(got.values, orl.resample_and_rl(cond, True, orl.windowed_run_events, 2, time=ot, freq="YS"))
+    got = mv.tx_tn_days_above(tasmin, tasmax, thresh_tasmin="10 degC", thresh_tasmax="24 degC", freq="MS")
+    np.testing.assert_array_equal(got.values, np.stack([cond[idx].sum(axis=0) for _, idx in orl.groups(ot, "MS")]))
+    assert got.attrs["units"] == "days"
+    # -- percentile indices: per-doy thresholds
+    per_x = cal.percentile_doy(tasmax, window=5, per=85.0).sel(percentiles=85.0)
+    per_n = cal.percentile_doy(tasmin, window=5, per=15.0).sel(percentiles=15.0)
+    px, doys = ocal.percentile_doy(tx, ot, 5, 85.0)
+    pn, _ = ocal.percentile_doy(tn, ot, 5, 15.0)
+    np.testing.assert_array_equal(mv.tx90p(tasmax, per_x).values, oidx.tx90p(tx, px[..., 0], doys, ot, "YS"))
+    np.testing.assert_array_equal(mv.tn10p(tasmin, per_n, freq="MS").values, oidx.tx10p(tn, pn[..., 0], doys, ot, "MS"))
+    np.testing.assert_array_equal(mv.warm_spell_duration_index(tasmax, per_x, window=3).values,
+                                  oidx.warm_spell_duration_index(tx, px[..., 0], doys, ot, 3, "YS", True))
+    np.testing.assert_array_equal(mv.cold_spell_duration_index(tasmin, per_n, window=3).values,
+                                  oidx.cold_spell_duration_index(tn, pn[..., 0], doys, ot, 3, "YS", True))
+    per_p = cal.percentile_doy(pr, window=5, per=70.0).sel(percentiles=70.0)
+    pp, _ = ocal.percentile_doy(prv, ot, 5, 70.0)
+    got = mv.days_over_precip_thresh(pr, per_p)                   # pr_per.where(pr_per > thresh, thresh): float64 table, python-float floor
+    np.testing.assert_array_equal(got.values, oidx.days_over_precip_thresh(prv, pp[..., 0], doys, ot, mm, "YS"))
+    assert len(progs) >= 25 and all(hasattr(mods[p["module"]], n) for n, p in progs.items())
+    with pytest.raises(NotImplementedError, match="recorded program holds"):
+        mv.days_over_precip_thresh(pr, per_p, bootstrap=True)       # the body is recorded for bootstrap=False (percentile_bootstrap stripped)
 
 
 @pytest.mark.parametrize("interp", ["nearest", "linear", "cubic"])
@@ -404,7 +483,7 @@ def test_chunked_fields_go_through_the_wrappers_block_by_block(ref, dev, rng):
     tr = check(lambda da: mv.warm_spell_duration_index(da, per, window=3, freq="YS"))
     assert len(_calls(tr, "xh_run_stats_doy")) == nblocks
     check(lambda da: th.maximum_consecutive_dry_days(da, 285.0, freq="YS"))
-    check(lambda da: th.frost_days(da, 283.15, freq="MS"))
+    check(lambda da: sp.frost_days(da, 283.15, freq="MS"))
     check(lambda da: sp.tg_mean(da, freq="QS-DEC"))
     check(lambda da: th.growing_season_length(da, thresh=283.15, freq="YS"))
     check(lambda da: th.growing_degree_days(da, thresh=283.15, freq="YS"))
@@ -420,7 +499,7 @@ def test_chunked_fields_go_through_the_wrappers_block_by_block(ref, dev, rng):
     # dimension order other than time-first, chunked along one dimension only
     y = np.ascontiguousarray(np.moveaxis(x, 0, 2))
     a_mem, a_chk = fakexr.field(y, ta, dims=("lat", "lon", "time")), fakexr.field(y, ta, dims=("lat", "lon", "time"), chunks={"lon": 5})
-    got, exp = th.frost_days(a_chk, 283.15, freq="YS"), th.frost_days(a_mem, 283.15, freq="YS")
+    got, exp = sp.frost_days(a_chk, 283.15, freq="YS"), sp.frost_days(a_mem, 283.15, freq="YS")
     assert got.dims == exp.dims == ("lat", "lon", "time")
     np.testing.assert_array_equal(got.values, exp.values)
     assert len(a_chk.data.loads) == 2 and max(a_chk.data.loads) == T * Y * 5
