@@ -136,7 +136,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--grid", type=str, default="365x1440x720")
+    ap.add_argument("--grid", type=str, default=None,
+                    help="TxYxX per GPU; default 365x1440x720 (c2) / 10950x360x1440 (c5, the slab config 5 gives one of 8 GPUs)")
     ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
                     help="c2 (default): BASELINE configs[1], tx90p on 365x1440x720 per GPU; c5: configs[4], tx90p + EQM on a "
                          "30-year 360x1440 slab per GPU")
@@ -176,7 +177,7 @@ def main():
             comm = FileComm(dev, world, rank, _rendezvous_path() + ".fc", reason=str(exc)[:200])
     if args.workload == "c5":
         return bench_config5(args, dev, K, comm, world, rank)
-    T, Y, X = (int(v) for v in args.grid.split("x"))
+    T, Y, X = (int(v) for v in (args.grid or "365x1440x720").split("x"))
     C = Y * X
     ta = TimeAxis.daily("2001-01-01", T, "noleap")
     tb, years, doys = ta.doy_table()
@@ -321,7 +322,8 @@ def bench_config5(args, dev, K, comm, world, rank):
     (20, C) af / hist_q nodes (scen stays sharded)."""
     from xclim_amd.timeaxis import TimeAxis
 
-    T, C = 10950, 360 * 1440
+    T, Y, X = (int(v) for v in (args.grid or "10950x360x1440").split("x"))  # (--grid: plumbing tests on small slabs)
+    C = Y * X
     cell0 = rank * C
     ta = TimeAxis.daily("1981-01-01", T, "noleap")
     tb, years, doys = ta.doy_table()
@@ -381,10 +383,11 @@ def bench_config5(args, dev, K, comm, world, rank):
             "metric": "grid-cells x timesteps / s (tx90p + EQM train + adjust, 30-year daily series)",
             "value": E * world * args.steps / dt, "unit": "cell-timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[4]: tx90p + EmpiricalQuantileMapping train+adjust on {T} x 360 x 1440 fp32 "
+            "vs_baseline": None, "dtype": "f32",
+            "data": "mock (no GPU: plumbing test, the numbers mean nothing)" if os.environ.get("XH_BENCH_MOCK_DEVICE") else "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: tx90p + EmpiricalQuantileMapping train+adjust on {T} x {Y} x {X} fp32 "
                                    "per GPU (one of the 8 lat slabs of the 2880 x 1440 grid), noleap, resident in HBM",
-                       "grid_per_gpu": [T, 360, 1440],
+                       "grid_per_gpu": [T, Y, X],
                        "sharding": "lat slabs, one per rank; one RCCL all_gather of (P,C) fp64 counts + (2,20,C) fp32 nodes per step"
                        if getattr(comm, "kind", "rccl") != "file" else f"lat slabs, one per rank; NO exchange (RCCL unavailable: {comm.reason})"},
             "roofline": {"bound": "hbm", "kernel": "whole step (5 kernels chains)", "achieved": bytes_step / (dt / args.steps) / 1e9,

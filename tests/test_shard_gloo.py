@@ -157,7 +157,8 @@ def test_file_comm_scalar_reductions(tmp_path):
     assert outs == [expect, expect, expect]
 
 
-def test_bench_two_ranks_plumbing_without_gpus(tmp_path):
+@pytest.mark.parametrize("workload", ["c2", "c5"])
+def test_bench_two_ranks_plumbing_without_gpus(tmp_path, workload):
     """``bench.py --gpus 2`` exactly as the driver launches it (torch.distributed.run, one rank per GPU), on a machine
     without GPUs: a host-memory mock device (tools/mock_device.py, no-op kernels) and XH_BENCH_NO_RCCL=1 (file barriers, no
     exchange) — environment handling, rendezvous fallback, barriers, max-over-ranks timing and the ONE JSON line on
@@ -166,8 +167,8 @@ def test_bench_two_ranks_plumbing_without_gpus(tmp_path):
 
     env = dict(os.environ, OMP_NUM_THREADS="1", XH_BENCH_MOCK_DEVICE="1", XH_BENCH_NO_RCCL="1", XH_RENDEZVOUS_DIR=str(tmp_path))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--grid", "365x4x8", "--no-cpu", "--no-extra"]
+           "--master-port", "29541" if workload == "c2" else "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--grid", "365x4x8" if workload == "c2" else "1095x4x8", "--no-cpu", "--no-extra", "--workload", workload]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -176,3 +177,5 @@ def test_bench_two_ranks_plumbing_without_gpus(tmp_path):
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
     assert rec["data"].startswith("mock") and "NO exchange" in rec["config"]["sharding"]
     assert rec["value"] > 0 and rec["roofline"]["bound"] == "hbm" and rec["unit"] == "cell-timesteps/s"
+    if workload == "c5":  # config 5's per-GPU slab flow: tx90p + EQM train + adjust, one gather buffer per step
+        assert rec["config"]["grid_per_gpu"] == [1095, 4, 8] and "configs[4]" in rec["config"]["workload"]
