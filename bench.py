@@ -458,9 +458,48 @@ def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D, full_configs=True)
                              "roofline_valu": valu_bound("k_qdm_regsort")}
     for a in (ref, hist, sim, scen, af, hq):
         a.free()
+    out["adapter_e2e"] = bench_adapter_e2e(dev, K, ta, T, C, tasmax)
     if full_configs:
         out.update(bench_full_configs(dev, K, C))
     return out
+
+
+def bench_adapter_e2e(dev, K, ta, T, C, tasmax):
+    """What the drop-in layer costs END TO END when the field lives in host memory (reported beside, never
+    instead of, the HBM roofline): numpy in -> numpy out through the host mirrors the xarray wrappers call after
+    unwrapping (xr_adapter._tfirst -> xclim_amd.calendar / indices), i.e. upload + kernels + download, wall clock, best of
+    3; once from pageable memory (what ``DataArray.values`` is) and once from page-locked memory."""
+    from xclim_amd import indices as xi
+    from xclim_amd.calendar import percentile_doy
+
+    host = tasmax.get()                                   # pageable
+    pinned = dev.pinned_empty(host.shape, np.float32)
+    pinned[...] = host
+    pr_host = K.fill_synthetic(dev, T, C, 1, 3, np.zeros(T, np.float32), 40.0 / 86400.0, 0.3).get()
+    E = float(T) * C
+
+    def best(fn, n=3):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            dev.sync()
+            ts.append(time.perf_counter() - t0)
+        return min(ts) * 1e3
+
+    def tx90p(x):
+        per = percentile_doy(x, ta, window=5, per=90.0, device=dev)
+        return xi.tx90p(x, per, ta, freq="YS", device=dev)
+
+    res = {"note": "host-resident float32 field -> numpy result through the host mirrors (H2D + kernels + D2H); PCIe-inclusive, "
+                   "NOT the headline value", "field_GB": host.nbytes / 1e9}
+    for label, x in (("pageable", host), ("pinned", pinned)):
+        ms = best(lambda: tx90p(x))
+        res[f"tx90p_{label}"] = {"ms": ms, "cell-timesteps/s": E / (ms * 1e-3), "uploads": 2,
+                                 "host_link_GB/s": 2 * host.nbytes / ms / 1e6}
+    ms = best(lambda: xi.maximum_consecutive_dry_days(pr_host, 1.0 / 86400.0, ta, freq="YS", device=dev))
+    res["cdd_pageable"] = {"ms": ms, "cell-timesteps/s": E / (ms * 1e-3), "uploads": 1, "host_link_GB/s": pr_host.nbytes / ms / 1e6}
+    return res
 
 
 def bench_full_configs(dev, K, C):
@@ -546,6 +585,27 @@ def bench_full_configs(dev, K, C):
                                                     traffic_source="profiles/r03/pmc_hbm_traffic_30yr.json"),
                      "roofline_adjust": hbm_roofline(8 * E, ms_ad, "k_eqm_adjust<20, 0>")}
     for a in (hist, sim, scen, af, hq):
+        a.free()
+    # ---- 1950-2100 daily (55 152 steps: beyond the 32768-step column kernels) on a 1440 x 90 band of the grid: EQM train
+    #      (select4.hip streams any T <= 65535) and QDM adjust (qdm3.hip: ranks through a global sort) — round 3 refused both
+    T, Cb = 55152, C // 8
+    base = seasonal_base(T)
+    ref = K.fill_synthetic(dev, T, Cb, 0, 4, base, 3.0)
+    hist = K.fill_synthetic(dev, T, Cb, 0, 5, base + np.float32(1.5), 3.3)
+    af, hq = dev.empty((20, Cb), np.float32), dev.empty((20, Cb), np.float32)
+    ms_tr = event_time(dev, lambda: K.eqm_train(dev, ref, hist, q, "+", out=(af, hq)), 2)
+    E = float(T) * Cb
+    out["eqm_55k"] = {"train_ms": ms_tr, "GB/s": 8 * E / ms_tr / 1e6, "frac": 8 * E / ms_tr / 1e6 / HBM_PEAK_GBS,
+                      "grid": [T, 1440, 90], "algorithmic_bytes": 8 * E,
+                      "roofline": hbm_roofline(8 * E, ms_tr, "2 x (k_hs_sample + k_hs_hist + k_hs_collect) (select4.hip, T = 55152)")}
+    ref.free()
+    scen = dev.empty((T, Cb), np.float32)
+    ms_qd = event_time(dev, lambda: K.qdm_adjust(dev, hist, af, q, "+", "nearest", "constant", out=scen), 1)
+    out["qdm_55k"] = {"ms": ms_qd, "GB/s": 8 * E / ms_qd / 1e6, "frac": 8 * E / ms_qd / 1e6 / HBM_PEAK_GBS, "grid": [T, 1440, 90],
+                      "algorithmic_bytes": 8 * E,
+                      "roofline": hbm_roofline(8 * E, ms_qd, "transposes + k_q3_keys + rocprim segmented radix sort + k_q3_ranks (qdm3.hip)",
+                                               passes="exact ranks through a global sort of (key, time index) pairs in column batches: not tuned")}
+    for a in (hist, scen, af, hq):
         a.free()
     return out
 

@@ -7,7 +7,7 @@ FETCH_SIZE reports exactly 1/2 of the bytes of a coalesced streaming read, so it
 kernels (calibration on this code: k_threshold_count reads x (1.514 GB) + the fp64 table (3.028 GB) = 4.542 GB and
 FETCH_SIZE*1024*2 = 4.542 GB; k_run_max_fused reads 1.514 GB, FETCH_SIZE*1024*2 = 1.514 GB; k_fill_synthetic writes
 1.514 GB and WRITE_SIZE*1024 = 1.514 GB, i.e. writes need no correction).  The strided-gather select kernels are
-NOT calibrated and are reported uncorrected.
+NOT calibrated: their derived byte figures are written as null (the raw counter means stay).
 
 usage: tools/summarize_pmc.py gpurun_out/prof_<tag> profiles/<tag> [out.json [kernel-prefix,kernel-prefix,...]]
 (the optional prefix list keeps only kernels that run at ONE grid size in that profile run: a mean over launches of
@@ -41,17 +41,25 @@ def main(src, dst, name="pmc_hbm_traffic.json", only=None):
             out.setdefault(k, {})[cname + "_KiB_mean"] = v / n
             out[k]["launches"] = n
     for k, d in out.items():
-        x2 = not k.startswith(UNCALIBRATED)
-        f = d.get("FETCH_SIZE_KiB_mean", 0.0) * 1024 * (2 if x2 else 1)
         w = d.get("WRITE_SIZE_KiB_mean", 0.0) * 1024
-        d["fetch_x2_correction"] = x2
-        d["hbm_read_bytes_per_launch"] = f
         d["hbm_write_bytes_per_launch"] = w
+        if k.startswith(UNCALIBRATED):
+            # no figure that is known to be wrong: the raw counter stays, the derived bytes do not
+            d["fetch_x2_correction"] = None
+            d["hbm_read_bytes_per_launch"] = None
+            d["hbm_bytes_per_launch"] = None
+            d["reason"] = ("FETCH_SIZE is not calibrated for this kernel's strided 256-byte gathers (neither x1 nor x2 "
+                           "reproduces its known input bytes)")
+            continue
+        f = d.get("FETCH_SIZE_KiB_mean", 0.0) * 1024 * 2
+        d["fetch_x2_correction"] = True
+        d["hbm_read_bytes_per_launch"] = f
         d["hbm_bytes_per_launch"] = f + w
     os.makedirs(dst, exist_ok=True)
     json.dump(out, open(os.path.join(dst, name), "w"), indent=1, sort_keys=True)
     for k, d in sorted(out.items()):
-        print(f"{k:40s} read {d['hbm_read_bytes_per_launch'] / 1e9:7.3f} GB  write {d['hbm_write_bytes_per_launch'] / 1e9:7.3f} GB")
+        rd = "   n/a " if d["hbm_read_bytes_per_launch"] is None else f"{d['hbm_read_bytes_per_launch'] / 1e9:7.3f}"
+        print(f"{k:40s} read {rd} GB  write {d['hbm_write_bytes_per_launch'] / 1e9:7.3f} GB")
 
 
 if __name__ == "__main__":

@@ -70,6 +70,7 @@ struct HsStat {
   uint32_t maxm;    // largest candidate count of any column
   uint32_t errors;  // pass 2 met a different candidate count than pass 1 announced (must stay 0)
   uint32_t summ;    // candidates of all columns (diagnostics: the mean per column)
+  uint32_t rounds;  // highest collect round any column was put in (pass 2 runs rounds + 1 times)
 };
 
 // per-column window -> bin arithmetic, identical in pass 1 and pass 2.  Bins are equally wide in VALUE, not in key
@@ -496,9 +497,11 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
     uint32_t m = 0;
 #pragma unroll
     for (int r = 0; r < HS_RL; ++r) m += part[r * CW + col];
-    // the tile's candidate lists share one LDS pool in pass 2: column offsets in column order (one wave, shuffle scan); a
-    // column with more candidates than the largest register sort, and every column from the one that overflows the
-    // pool on, is flagged for the column kernels
+    // the tile's candidate lists share one LDS pool in pass 2: column offsets in column order (one wave, shuffle scan).  A
+    // column with more candidates than the largest register sort is flagged for the column kernels.  A tile whose lists do
+    // not fit the pool together (long series: the candidates grow with T, ~1400 per column at 55 152 steps) is collected in
+    // several ROUNDS of pass 2, each round the columns of one pool-full: round = (inclusive prefix - 1) / (POOL - CAPMAX)
+    // — the round's first list may start below the boundary by less than CAPMAX, so a round never overflows the pool.
     if (rl == 0) {  // wave 0: lane = column
       const uint32_t mk = cvalid ? m : 0u;
       const bool big = mk > (uint32_t)HS_CAPMAX;
@@ -509,8 +512,19 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
         const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
         incl += col >= d ? o : 0u;
       }
-      const bool fl = big || incl > (uint32_t)HS_POOL;
-      cbase[col] = fl ? HS_FLAGGED : incl - val;
+      const uint32_t excl = incl - val;
+      const uint32_t round = val > 0u ? (incl - 1u) / (uint32_t)(HS_POOL - HS_CAPMAX) : 0u;
+      unsigned long long mine = 0ull;  // the lanes (columns) of my round
+#pragma unroll 1
+      for (uint32_t r = 0; r <= 3u; ++r) {  // at most CW * CAPMAX / (POOL - CAPMAX) + 1 = 5 rounds; 4 handled here, more are flagged
+        const unsigned long long mr = __ballot(round == r && val > 0u);
+        if (round == r) mine = mr;
+      }
+      const int first = mine ? __ffsll((long long)mine) - 1 : col;
+      const uint32_t start = (uint32_t)__shfl((int)excl, first);
+      const bool fl = big || round > 3u;
+      cbase[col] = fl ? HS_FLAGGED : ((excl - start) | (round << 16));
+      if (!fl && val > 0u) atomicMax(&stat->rounds, round);
     }
     __syncthreads();
     const uint32_t mybase = cbase[col];
@@ -706,7 +720,7 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
              const double* __restrict__ qs, int nq, const uint32_t* __restrict__ meta_n, const uint32_t* __restrict__ meta_m,
              const uint32_t* __restrict__ meta_base, const uint16_t* __restrict__ crank, const uint32_t* __restrict__ bitmap_g,
              const uint32_t* __restrict__ tab_g, float* __restrict__ out, int64_t ocs, int64_t oqs, HsStat* __restrict__ stat,
-             int abl) {
+             int abl, int round) {
   constexpr int CW = HS_CW, NT = HS_NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* cand = reinterpret_cast<uint32_t*>(smem);
@@ -733,17 +747,18 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
     const int64_t c = tile * CW + col;
     const bool cvalid = c < C;
     const int64_t cc = cvalid ? c : C - 1;
-    if (!early) ring.prime(x, T, st, cc, rl);
     const uint2 lh = lohi[cc];
     const HsScale s = hs_scale(lh.x, lh.y);
-    const bool collect = cvalid && meta_m[cc] != HS_FLAGGED;
+    const uint32_t mbase = meta_base[cc];
+    const bool collect = cvalid && meta_m[cc] != HS_FLAGGED && (mbase >> 16) == (uint32_t)round;
     if (tid < CW) {
       cursor[tid] = 0u;
       colok[tid] = collect ? 0xFFFFFFFFu : 0u;  // (tid < CW: col == tid)
-      lbase[tid] = collect ? meta_base[cc] : 0u;
+      lbase[tid] = collect ? (mbase & 0xFFFFu) : 0u;
     }
-    __syncthreads();
-    // the tile's tables; the columns nothing is collected for (flagged, past C) read all-zero tables
+    if (!__syncthreads_or(collect ? 1 : 0)) continue;  // no column of this tile belongs to this round (block-uniform)
+    if (!early) ring.prime(x, T, st, cc, rl);
+    // the tile's tables; the columns nothing is collected for (flagged, other rounds, past C) read all-zero tables
     for (int i = tid; i < 64 * CW; i += NT) tab[i] = tab_g[tile * (64 * CW) + i] & colok[i & (CW - 1)];
     for (int i = tid; i < 32 * CW; i += NT) bm[i] = bitmap_g[tile * (32 * CW) + i] & colok[i & (CW - 1)];
     __syncthreads();
@@ -817,10 +832,10 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
       const int64_t ck = tile * CW + k;
       if (ck >= C) break;  // (wave-uniform)
       const uint32_t mm = meta_m[ck];
-      if (mm == HS_FLAGGED) continue;
+      if (mm == HS_FLAGGED || (meta_base[ck] >> 16) != (uint32_t)round) continue;
       const uint32_t m = cursor[k];
       if (m != mm && lane == 0) atomicAdd(&stat->errors, 1u);
-      uint32_t* list = cand + meta_base[ck];
+      uint32_t* list = cand + (meta_base[ck] & 0xFFFFu);
       const uint32_t ms = m < mm ? m : mm;
       if (abl & 1) {
       } else if (ms > 1024u) hs_sort_column<32>(list, ms, lane);
@@ -937,26 +952,29 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   {                                                                                                                             \
     XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<UU, NS, EC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2())); \
     hipLaunchKernelGGL((k_hs_collect<UU, NS, EC>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds2(), ctx->stream, x, (int)T, C, st, lohi, d_q, \
-                       nq, meta_n, meta_m, meta_base, crank, bitmap_g, tab_g, out, out_cstride, out_qstride, stat, abl);         \
+                       nq, meta_n, meta_m, meta_base, crank, bitmap_g, tab_g, out, out_cstride, out_qstride, stat, abl, round);  \
   }
-#define XH_HS_BOTH(UU, NS, EH, EC) { XH_HS_HIST(UU, NS, EH) XH_LAUNCH_CHECK(); XH_HS_COLLECT(UU, NS, EC) }
+#define XH_HS_BOTH(UU, NS, EH, EC) { if (round == 0) { XH_HS_HIST(UU, NS, EH) XH_LAUNCH_CHECK(); } XH_HS_COLLECT(UU, NS, EC) }
   const char* eea = xh_diag_env("XH_HIST_EARLY");  // diagnostics: early priming in pass 1 / pass 2: "00" | "10" | "01" | "11"
   const int eh = eea ? eea[0] == '1' : 0, ec = eea ? eea[1] == '1' : 0;  // measured: no gain (38.0 / 38.2 / 38.6 / 38.8 ms for 00 / 10 / 01 / 11)
-  if (ring == 162) XH_HS_BOTH(16, 2, false, false)
-  else if (eh && ec) XH_HS_BOTH(8, 5, true, true)
-  else if (eh) XH_HS_BOTH(8, 5, true, false)
-  else if (ec) XH_HS_BOTH(8, 5, false, true)
-  else XH_HS_BOTH(8, 5, false, false)
+  HsStat h;
+  for (int round = 0;; ++round) {  // round 0: pass 1 + pass 2; further rounds of pass 2 for tiles whose lists overflow the pool
+    if (ring == 162) XH_HS_BOTH(16, 2, false, false)
+    else if (eh && ec) XH_HS_BOTH(8, 5, true, true)
+    else if (eh) XH_HS_BOTH(8, 5, true, false)
+    else if (ec) XH_HS_BOTH(8, 5, false, true)
+    else XH_HS_BOTH(8, 5, false, false)
+    XH_LAUNCH_CHECK();
+    XH_CHECK_HIP(hipMemcpyAsync(&h, stat, sizeof(HsStat), hipMemcpyDeviceToHost, ctx->stream));
+    XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (round >= (int)h.rounds) break;
+  }
 #undef XH_HS_BOTH
 #undef XH_HS_HIST
 #undef XH_HS_COLLECT
-  XH_LAUNCH_CHECK();
-  HsStat h;
-  XH_CHECK_HIP(hipMemcpyAsync(&h, stat, sizeof(HsStat), hipMemcpyDeviceToHost, ctx->stream));
-  XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   XH_REQUIRE(h.errors == 0 || abl != 0, XH_ERR_HIP, "xh_select_hist: %u columns met another candidate count in pass 2 than in pass 1",
              h.errors);
-  if (xh_diag_env("XH_HIST_STATS")) fprintf(stderr, "[xh_select_hist] T=%lld C=%lld flagged=%u candidates: max %u mean %.1f\n", (long long)T, (long long)C, h.nflag, h.maxm, (double)h.summ / (double)C);
+  if (xh_diag_env("XH_HIST_STATS")) fprintf(stderr, "[xh_select_hist] T=%lld C=%lld flagged=%u candidates: max %u mean %.1f, %u collect rounds\n", (long long)T, (long long)C, h.nflag, h.maxm, (double)h.summ / (double)C, h.rounds + 1u);
   if (h.nflag == 0) return XH_OK;
   // up to 32768 steps the transposed pipeline is the better answer when MANY columns are flagged (heavily tied fields)
   if (T <= 32768 && (int64_t)h.nflag > nfmax) return XH_ERR_NOTIMPL;
