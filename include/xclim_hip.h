@@ -480,6 +480,23 @@ int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
  * reference tree). */
 int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const float* af,
                   const double* q /* host */, int nq, int kind, int interp, int extrap, float* scen);
+/* xsdba.nbutils.vecquantiles(da, rnk, dim) (upstream xsdba, re-exported by /root/reference/src/xclim/sdba.py:10): ONE
+ * quantile per cell at that cell's own probability q_cell[c] (DEVICE float64, NaN -> NaN), Hyndman-Fan type 7 over the
+ * valid samples (= /root/reference/src/xclim/core/utils.py:370-491 with alpha = beta = 1).  x (T, C) with element strides
+ * (st, sc), one of them 1; out (C) float32.  Any T < 2^31 (radix select per column).  Parity unpinned. */
+int xh_quantile_cells(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* q_cell, float* out);
+/* The value-replacement step of xsdba.processing.adapt_freq (upstream _processing._adapt_freq; precipitation
+ * pre-processing before a multiplicative quantile mapping):
+ *   sim_ad = sim.where(dP0 < 0, sim.where((rank < P0_ref) | (rank > P0_sim) | isnull(sim), (pth - thresh) * U + thresh))
+ * rank = sim.rank(dim, pct=True): average ranks of the valid samples / their count (exact, through a sort of (key, time
+ * index) pairs); per cell p0_ref / p0_sim / dp0 (DEVICE float64) and pth (DEVICE float32) come from the caller
+ * (xh_threshold_count with "<=", xh_quantile_cells).  U in [0, 1) is a counter-based uniform keyed by (seed, tindex[t] or
+ * t, cell0 + c) — upstream draws from numpy's global generator; oracle/sdba.py restates this one bit for bit.  tindex:
+ * DEVICE int64 (T) global time index of every row, or NULL.  sim / scen (T, C) strides (st, sc), one of them 1.
+ * Parity unpinned. */
+int xh_adapt_freq(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const double* p0_ref,
+                  const double* p0_sim, const double* dp0, const float* pth, double thresh, uint64_t seed, const int64_t* tindex,
+                  int64_t cell0, float* scen);
 
 /* DetrendedQuantileMapping pieces (xsdba._adjustment.dqm_train / dqm_adjust, xsdba.detrending.PolyDetrend; parity
  * unpinned).  xh_poly_trend: per-cell least-squares polynomial of degree 0 (mean) or 1 over the valid samples of the

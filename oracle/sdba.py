@@ -35,8 +35,13 @@ while the file is absent):
     dqm_train / dqm_adjust /       _adjustment.dqm_train / dqm_adjust, detrending.PolyDetrend        dqm_{kind}_af / _scaling /
       poly_trend                   (degree 0 / 1), utils.apply_correction / invert                   _scen_d{degree}
 
-    NOT restated (refused by the product): adapt_freq, interpolation over (quantile, group) for "linear" / "cubic",
-    DQM with sub-groupings, QDM cubic.
+    adapt_freq / adapt_uniform     processing.adapt_freq -> _processing._adapt_freq (ecdf,           adapt_{group}_sim_ad / _pth /
+                                   nbutils.vecquantiles, DataArray.rank(pct=True)); the random       _dP0 (sim_ad only where no
+                                   fill values come from a counter-based uniform, not from numpy's   value was replaced: upstream's
+                                   global generator                                                  draws are not reproducible)
+
+    NOT restated (refused by the product): interpolation over (quantile, group) for "linear" / "cubic", DQM with
+    sub-groupings, QDM cubic.
 
 Where a difference is most likely once the fixtures exist (from memory of the upstream sources, not verified here): (1)
 ``nbutils.quantile`` casts the probabilities to the dtype of the data before it calls numpy's nanquantile, so float32
@@ -251,3 +256,76 @@ def dqm_adjust(sim, af, hist_q, scaling, kind="+", interp="nearest", extrapolati
     detr = _corr(scaled, trend, kind, True)
     scen0 = eqm_adjust(detr, af, hist_q, kind, interp, extrapolation)
     return _corr(scen0, trend, kind)
+
+
+# ---- adapt_freq (xsdba.processing.adapt_freq -> _processing._adapt_freq) ------------------------------------------------
+_K0, _K1, _K2 = np.uint64(0xD1342543DE82EF95), np.uint64(0x9E3779B97F4A7C15), np.uint64(0xC2B2AE3D27D4EB4F)
+
+
+def adapt_uniform(seed, tindex, cells):
+    """The uniform numbers of xh_adapt_freq (xclim_amd/csrc/qdm3.hip k_q3_adapt), bit for bit: U(seed, t, cell) =
+    (mix64(seed K0 + t K1 + cell K2) >> 11) / 2^53, float64 in [0, 1).  Stands where upstream calls
+    ``np.random.random_sample(size=sim.shape)``."""
+    from .synth import _mix64
+
+    t = np.asarray(tindex, dtype=np.uint64)[:, None]
+    c = np.asarray(cells, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        z = _mix64(np.uint64(seed) * _K0 + t * _K1 + c * _K2)
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def rank_avg_pct(x):
+    """DataArray.rank(dim, pct=True) along axis 0: average ranks of the valid samples (bottleneck.nanrankdata) / their
+    count; NaN stays NaN.  (utils.rank, used by QDM, rescales on top of this: rank_pct above.)"""
+    from scipy.stats import rankdata
+
+    x = np.asarray(x)
+    out = np.full(x.shape, np.nan)
+    for c in range(x.shape[1]):
+        ok = ~np.isnan(x[:, c])
+        n = int(ok.sum())
+        if n:
+            out[ok, c] = rankdata(x[ok, c] + x.dtype.type(0), method="average") / n   # (+0: the two zeros tie)
+    return out
+
+
+def _adapt_one(ref_sample, sim_sample, sim_main, thresh, u):
+    """One group: samples (N, C) for the frequencies and pth, the group's own steps (n, C) for the ranks; u (n, C)."""
+    f32 = np.float32
+    with np.errstate(all="ignore"):
+        p0_sim = (sim_sample <= f32(thresh)).sum(axis=0) / (~np.isnan(sim_sample)).sum(axis=0)      # utils.ecdf
+        p0_ref = (ref_sample <= f32(thresh)).sum(axis=0) / (~np.isnan(ref_sample)).sum(axis=0)
+        dp0 = (p0_sim - p0_ref) / p0_sim
+    pth = np.full(ref_sample.shape[1], np.nan, f32)                                                   # nbutils.vecquantiles
+    for c in range(ref_sample.shape[1]):
+        if dp0[c] > 0:
+            pth[c] = nan_quantile(ref_sample[:, c], np.array([p0_sim[c]]), axis=0, alpha=1.0, beta=1.0)[0].astype(f32)
+    rank = rank_avg_pct(sim_main)
+    with np.errstate(invalid="ignore"):
+        keep = (rank < p0_ref[None]) | (rank > p0_sim[None]) | np.isnan(sim_main)
+        fill = (pth[None].astype(np.float64) - float(thresh)) * u + float(thresh)
+        inner = np.where(keep, sim_main, fill.astype(f32))
+        sim_ad = np.where((dp0 < 0)[None], sim_main, inner).astype(f32)
+    return sim_ad, pth, dp0
+
+
+def adapt_freq(ref, sim, thresh, seed=0, time=None, prop="group", window=1, cell0=0):
+    """sim_ad (T, C) float32, pth, dP0 — group "time" (prop "group") or a sub-grouping on the common `time` (OTime)."""
+    ref, sim = np.asarray(ref), np.asarray(sim)
+    T, C = sim.shape
+    cells = cell0 + np.arange(C)
+    if prop == "group":
+        return _adapt_one(ref, sim, sim, thresh, adapt_uniform(seed, np.arange(T), cells))
+    vals = group_values(time, prop)
+    labels = np.unique(vals)
+    out = sim.copy()
+    pths, dp0s = [], []
+    for lab in labels:
+        main = np.nonzero(vals == lab)[0]
+        ad, pth, dp0 = _adapt_one(grouped_sample(ref, time, prop, window, lab), grouped_sample(sim, time, prop, window, lab), sim[main],
+                                  thresh, adapt_uniform(seed, main, cells))
+        out[main] = ad
+        pths.append(pth)
+        dp0s.append(dp0)
+    return out, np.stack(pths), np.stack(dp0s)

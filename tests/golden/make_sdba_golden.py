@@ -86,6 +86,22 @@ def main() -> int:
         out[f"eqmg_{tag}_hist_q"] = eqm.ds.hist_q.transpose(gdim, "quantiles", "lat", "lon").values
         out[f"eqmg_{tag}_scen"] = eqm.adjust(da(sim, "K"), interp="nearest").transpose("time", "lat", "lon").values
 
+    # adapt_freq (xsdba.processing.adapt_freq): pth and dP0 are deterministic; sim_ad draws its fill values from numpy's
+    # global generator, so only the UNCHANGED samples of sim_ad (and which samples changed) can be pinned
+    from xsdba.processing import adapt_freq
+
+    dry = rng.random((T, Y, X))
+    ad_ref = np.where(dry < 0.4, rng.random((T, Y, X)) * 0.3, rng.gamma(0.7, 5.0, (T, Y, X))).astype(np.float32)
+    ad_sim = np.where(dry[::-1] < 0.7, rng.random((T, Y, X)) * 0.3, rng.gamma(0.7, 4.0, (T, Y, X))).astype(np.float32)
+    out.update(adapt_ref=ad_ref, adapt_sim=ad_sim, adapt_thresh=np.array(0.5))
+    for group, window in (("time", 1), ("time.month", 1)):
+        tag = group.split(".")[-1]
+        sim_ad, pth, dP0 = adapt_freq(da(ad_ref, "mm/d"), da(ad_sim, "mm/d"), thresh="0.5 mm/d", group=xsdba.Grouper(group, window=window))
+        lead = [d for d in pth.dims if d not in ("lat", "lon")]
+        out[f"adapt_{tag}_pth"] = pth.transpose(*lead, "lat", "lon").values
+        out[f"adapt_{tag}_dP0"] = dP0.transpose(*lead, "lat", "lon").values
+        out[f"adapt_{tag}_sim_ad"] = sim_ad.transpose("time", "lat", "lon").values
+
     path = os.path.join(HERE, "sdba_vectors.npz")
     np.savez_compressed(path, **out)
     print(f"make_sdba_golden: wrote {path} ({len(out)} arrays, xsdba {xsdba.__version__})")

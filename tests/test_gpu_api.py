@@ -1237,6 +1237,71 @@ def test_qdm_adjust_matches_oracle(dev, rng, kind, interp, T, cells):
         np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0, equal_nan=True, err_msg=f"{extrap}")
 
 
+def _pr_field(rng, T, C, p_dry, scale):
+    x = rng.gamma(0.7, scale, (T, C)).astype(np.float32)
+    x[rng.random((T, C)) < p_dry] = 0.0
+    return x
+
+
+@pytest.mark.parametrize("group,window", [("time", 1), ("time.month", 1), ("time.dayofyear", 31)])
+def test_adapt_freq_matches_oracle(dev, rng, group, window):
+    """xsdba.processing.adapt_freq (round 3: not built): frequencies P0 / dP0, pth = vecquantiles(ref, P0_sim), the
+    values whose percentage rank lies in [P0_ref, P0_sim] replaced by U[thresh, pth) — against the oracle's restatement
+    with the SAME counter-based uniforms (upstream draws from numpy's global generator).  Cells: sim too dry (the case
+    the method is for), sim wetter than ref (dP0 < 0: untouched), equal frequencies, no dry day at all (P0_sim = 0:
+    dP0 NaN), NaN samples, all-NaN sim / ref, drizzle below the threshold (distinct ranks inside the band), -0.0."""
+    from xclim_amd import sdba as xsdba
+
+    T = 365 * 4
+    ta, ot = _axes("2001-01-01", T, "noleap")
+    C = 12
+    ref, sim = _pr_field(rng, T, C, 0.4, 5.0), _pr_field(rng, T, C, 0.65, 4.0)
+    sim[:, 1] = _pr_field(rng, T, 1, 0.2, 4.0)[:, 0]                 # wetter than ref
+    sim[:, 2] = np.where(ref[:, 2] == 0, 0.0, sim[:, 2] + 0.5)       # the same dry days
+    sim[:, 3] = np.abs(sim[:, 3]) + 1.5                               # never below the threshold
+    sim[rng.random((T, C)) < 0.01] = np.nan
+    ref[rng.random((T, C)) < 0.01] = np.nan
+    sim[:, 4] = np.nan
+    ref[:, 5] = np.nan
+    dz = sim[:, 6] == 0
+    sim[dz, 6] = rng.random(int(dz.sum())).astype(np.float32) * 0.9  # drizzle: distinct values below the threshold
+    z = np.flatnonzero(sim[:, 7] == 0)
+    sim[z[::2], 7] = -0.0
+    thresh, seed = 1.0, 77
+    prop = "group" if group == "time" else group.split(".")[1]
+    got, pth, dp0 = xsdba.adapt_freq(ref, sim, thresh, group=group, window=window, time=ta, seed=seed, device=dev)
+    exp, epth, edp0 = osdba.adapt_freq(ref, sim, thresh, seed=seed, time=ot, prop=prop, window=window)
+    np.testing.assert_allclose(dp0, edp0, rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(pth, epth, rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0, equal_nan=True)
+    changed = ~((got == sim) | (np.isnan(got) & np.isnan(sim)))
+    assert changed[:, 0].sum() > 50 and not changed[:, 1].any() and not changed[:, 3].any() and not changed[:, 4].any()
+    if group == "time":
+        # the defining property: the frequency of values <= thresh in sim_ad matches ref's (up to the ties of exact zeros)
+        p0 = lambda x: np.nanmean(np.where(np.isnan(x), np.nan, x <= thresh), axis=0)  # noqa: E731
+        assert abs(p0(got)[6] - p0(ref)[6]) < 0.01 and p0(sim)[6] - p0(ref)[6] > 0.15
+        assert np.all(got[changed[:, 6], 6] >= thresh) and np.all(got[changed[:, 6], 6] < pth[6])
+
+
+def test_eqm_train_with_adapt_freq_thresh(dev, rng):
+    """EmpiricalQuantileMapping.train(adapt_freq_thresh=...) (xsdba: eqm_train -> _adapt_freq_hist): hist is frequency-
+    adapted against ref before the quantiles are taken, multiplicative factors stay finite at the dry nodes."""
+    from xclim_amd import sdba as xsdba
+
+    T, C = 3000, 9
+    ref, hist = _pr_field(rng, T, C, 0.4, 5.0), _pr_field(rng, T, C, 0.7, 4.0)
+    dz = hist == 0
+    hist[dz] = rng.random(int(dz.sum())).astype(np.float32) * 0.4     # drizzle instead of tied zeros (xsdba: jitter_under_thresh first)
+    eqm = xsdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=15, kind="*", adapt_freq_thresh=0.5, adapt_freq_seed=3, device=dev)
+    hist_ad, _, _ = osdba.adapt_freq(ref, hist, 0.5, seed=3)
+    eaf, ehq = osdba.eqm_train(ref, hist_ad, 15, "*")
+    np.testing.assert_allclose(eqm.hist_q, ehq, rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(eqm.af, eaf, rtol=1e-5, equal_nan=True)
+    plain = xsdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=15, kind="*", device=dev)
+    # node 9 (q = 0.633) lies between the frequencies of values <= 0.5 in ref (~0.53) and hist (~0.78): drizzle before, wet after
+    assert (plain.hist_q[9] < 0.5).all() and (eqm.hist_q[9] >= 0.5).all()
+
+
 @pytest.mark.parametrize("kind,interp", [("+", "nearest"), ("*", "linear")])
 def test_qdm_adjust_beyond_32768_steps(dev, rng, kind, interp):
     """1950-2100 daily (55 152 steps): round 3 refused series longer than 32768 steps.  qdm3.hip ranks them through a

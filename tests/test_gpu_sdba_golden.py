@@ -60,3 +60,23 @@ def test_grouped_eqm_against_xsdba(dev, G, group, window):
     np.testing.assert_allclose(eqm.hist_q, G[f"eqmg_{tag}_hist_q"], rtol=RTOL, equal_nan=True)
     np.testing.assert_allclose(eqm.af, G[f"eqmg_{tag}_af"], rtol=RTOL, atol=1e-6, equal_nan=True)
     np.testing.assert_allclose(eqm.adjust(G["sim"], interp="nearest", time=ta), G[f"eqmg_{tag}_scen"], rtol=RTOL, equal_nan=True)
+
+
+@needs_fixture
+@pytest.mark.parametrize("group", ["time", "time.month"])
+def test_adapt_freq_against_xsdba(dev, G, group):
+    """xsdba.processing.adapt_freq: pth and dP0 exactly, sim_ad where upstream left the value alone, and the SAME samples
+    replaced (the fill values themselves come from different random generators)."""
+    from xclim_amd import sdba as xsdba
+    from xclim_amd.timeaxis import TimeAxis
+
+    tag = group.split(".")[-1]
+    ref, sim, thresh = G["adapt_ref"], G["adapt_sim"], float(G["adapt_thresh"])
+    ta = TimeAxis.daily("2001-01-01", ref.shape[0], "noleap")
+    got, pth, dp0 = xsdba.adapt_freq(ref, sim, thresh, group=group, time=ta, device=dev)
+    np.testing.assert_allclose(dp0, G[f"adapt_{tag}_dP0"].reshape(dp0.shape), rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(pth, G[f"adapt_{tag}_pth"].reshape(pth.shape), rtol=1e-6, equal_nan=True)
+    up = G[f"adapt_{tag}_sim_ad"]
+    same_up = (up == sim) | (np.isnan(up) & np.isnan(sim))
+    same_me = (got == sim) | (np.isnan(got) & np.isnan(sim))
+    np.testing.assert_array_equal(same_me, same_up)

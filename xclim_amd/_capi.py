@@ -152,6 +152,8 @@ SIGNATURES: dict[str, list] = {
     "xh_eqm_train": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _vp, _vp],
     "xh_eqm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64],
     "xh_qdm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp],
+    "xh_quantile_cells": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp],
+    "xh_adapt_freq": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _dbl, _u64, _vp, _i64, _vp],
     "xh_mask_doy_cells": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64],
     "xh_rolling_dot": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _i64],
     "xh_mask_days_cells": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _vp, _vp, _i64],

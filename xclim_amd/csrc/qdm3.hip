@@ -137,6 +137,66 @@ k_q3_ranks(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col_st
   }
 }
 
+// ---- adapt_freq (xsdba.processing.adapt_freq -> _processing._adapt_freq) ------------------------------------------------
+// sim_ad = sim.where(dP0 < 0, sim.where((rank < P0_ref) | (rank > P0_sim) | sim.isnull(), (pth - thresh) * U + thresh))
+// with rank = sim.rank(dim, pct=True) (average ranks / valid count) from the sorted pairs, per column the float64 P0_ref,
+// P0_sim, dP0 and the float32 pth.  U replaces upstream's np.random.random_sample (not reproducible across runs there
+// either): a counter-based uniform in [0, 1) keyed by (seed, global time index, global cell), 53 bits, restated bit for
+// bit in oracle/sdba.py.  tindex: global time index of every row of the columns (a group's rows), nullptr = row number.
+__device__ __forceinline__ uint64_t q3_mix64(uint64_t z) {
+  z ^= z >> 30;
+  z *= 0xBF58476D1CE4E5B9ULL;
+  z ^= z >> 27;
+  z *= 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return z;
+}
+
+__global__ void __launch_bounds__(Q3_NT)
+k_q3_adapt(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col_stride, const uint32_t* __restrict__ keys,
+           const uint32_t* __restrict__ idx, const double* __restrict__ p0_ref, const double* __restrict__ p0_sim,
+           const double* __restrict__ dp0, const float* __restrict__ pth, double thresh, uint64_t seed,
+           const int64_t* __restrict__ tindex, int64_t cell0, float* __restrict__ out, int64_t out_cstride) {
+  __shared__ uint32_t s_n;
+  const int gt = threadIdx.x;
+  for (int64_t col = blockIdx.x; col < ncols; col += gridDim.x) {
+    const uint32_t* __restrict__ ks = keys + col * T;
+    const uint32_t* __restrict__ ix = idx + col * T;
+    const float* __restrict__ xc = x + col * col_stride;
+    float* __restrict__ oc = out + col * out_cstride;
+    if (gt == 0) s_n = q3_lower(ks, (uint32_t)T, Q3_NANKEY);
+    __syncthreads();
+    const uint32_t n = s_n;
+    const double dn = (double)n, inv_dn = 1.0 / dn;
+    const double pr = p0_ref[col], ps = p0_sim[col], d = dp0[col];
+    const double span = (double)pth[col] - thresh;
+    const uint64_t cell = (uint64_t)(cell0 + col);
+    for (uint32_t p = (uint32_t)gt; p < (uint32_t)T; p += Q3_NT) {
+      const uint32_t t = ix[p];
+      const float raw = xc[t];
+      float res = raw;  // NaN samples (p >= n) and everything that keeps its value
+      if (p < n && !(d < 0.0)) {
+        const uint32_t kk = ks[p];
+        uint32_t below = p, equal = 1u;
+        const bool tl = p > 0u && ks[p - 1u] == kk, tr = p + 1u < n && ks[p + 1u] == kk;
+        if (tl || tr) {
+          below = tl ? q3_lower(ks, n, kk) : p;
+          equal = (tr ? q3_upper(ks, n, kk) : p + 1u) - below;
+        }
+        const double rnk = xh_div_int((double)(2u * below + equal + 1u) * 0.5, dn, inv_dn);
+        if (!((rnk < pr) || (rnk > ps))) {
+          const uint64_t tg = (uint64_t)(tindex ? tindex[t] : (int64_t)t);
+          const uint64_t z = q3_mix64(seed * 0xD1342543DE82EF95ULL + tg * 0x9E3779B97F4A7C15ULL + cell * 0xC2B2AE3D27D4EB4FULL);
+          const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+          res = (float)(span * u + thresh);
+        }
+      }
+      oc[t] = res;
+    }
+    __syncthreads();
+  }
+}
+
 size_t q3_al(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -186,3 +246,73 @@ int xh_qdm_sorted(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int
   XH_LAUNCH_CHECK();
   return XH_OK;
 }
+
+extern "C" {
+
+// The value-replacement step of xsdba.processing.adapt_freq on sim (T, C), element strides (st, sc), one of them 1; per
+// cell: p0_ref, p0_sim, dp0 (float64) and pth (float32), device arrays of C; scen in the layout of sim.  The counts
+// behind P0 and the quantile behind pth are the caller's (xh_threshold_count, xh_quantile_cells: xclim_amd/sdba.py).
+int xh_adapt_freq(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const double* p0_ref,
+                  const double* p0_sim, const double* dp0, const float* pth, double thresh, uint64_t seed, const int64_t* tindex,
+                  int64_t cell0, float* scen) {
+  XH_REQUIRE(ctx && sim && p0_ref && p0_sim && dp0 && pth && scen, XH_ERR_ARG, "xh_adapt_freq: NULL argument");
+  XH_REQUIRE(T >= 1 && T < (1ll << 27) && C >= 0, XH_ERR_ARG, "xh_adapt_freq: bad shape (1 <= T < 2^27)");
+  if (C == 0) return XH_OK;
+  auto run = [&](const float* cols, int64_t n, int64_t cs, int64_t c0, float* o, int64_t ocs, void* ws) -> int {
+    const size_t ne = (size_t)(n * T);
+    char* p = (char*)ws;
+    uint32_t* kin = (uint32_t*)p; p += q3_al(4 * ne);
+    uint32_t* kout = (uint32_t*)p; p += q3_al(4 * ne);
+    uint32_t* iin = (uint32_t*)p; p += q3_al(4 * ne);
+    uint32_t* iout = (uint32_t*)p; p += q3_al(4 * ne);
+    uint32_t* offs = (uint32_t*)p; p += q3_al(4 * (size_t)(n + 1));
+    size_t tmp = 0;
+    XH_CHECK_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tmp, kin, kout, iin, iout, (unsigned)ne, (unsigned)n, offs, offs + 1, 0, 32,
+                                                     ctx->stream));
+    hipLaunchKernelGGL(k_q3_keys, dim3((unsigned)cdiv64((int64_t)ne + 1, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, cols, T, n, cs, kin,
+                       iin, offs);
+    XH_LAUNCH_CHECK();
+    XH_CHECK_HIP(rocprim::segmented_radix_sort_pairs((void*)p, tmp, kin, kout, iin, iout, (unsigned)ne, (unsigned)n, offs, offs + 1, 0, 32,
+                                                     ctx->stream));
+    int64_t nblk = n < (int64_t)ctx->num_cu * 8 ? n : (int64_t)ctx->num_cu * 8;
+    hipLaunchKernelGGL(k_q3_adapt, dim3((unsigned)nblk), dim3(Q3_NT), 0, ctx->stream, cols, T, n, cs, kout, iout, p0_ref + c0, p0_sim + c0,
+                       dp0 + c0, pth + c0, thresh, seed, tindex, cell0 + c0, o, ocs);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+  };
+  const bool minor = st == 1 && sc >= T;
+  XH_REQUIRE(minor || (sc == 1 && st >= C), XH_ERR_LAYOUT, "xh_adapt_freq: one of the strides must be 1 (st=%lld sc=%lld)",
+             (long long)st, (long long)sc);
+  const int64_t Tp = (T + 63) & ~(int64_t)63;
+  int64_t batch = (1ll << 26) / Tp;  // 64 M samples per batch: ~1.3 GB of sort workspace
+  batch = (batch / 128) * 128;
+  if (batch < 128) batch = 128;
+  if (batch > C) batch = C;
+  size_t wsb = 0;
+  int rc = xh_qdm_sorted_ws(T, batch, &wsb);
+  if (rc) return rc;
+  const size_t bufb = minor ? 0 : 2 * sizeof(float) * (size_t)batch * (size_t)Tp;
+  void* tmp = nullptr;
+  rc = xh_big_scratch(ctx, bufb + wsb, &tmp);
+  if (rc) return rc;
+  float* bin = (float*)tmp;
+  float* bout = bin + (size_t)batch * (size_t)Tp;
+  void* ws = (char*)tmp + bufb;
+  for (int64_t c0 = 0; c0 < C; c0 += batch) {
+    const int64_t nb = C - c0 < batch ? C - c0 : batch;
+    if (minor) {
+      rc = run(sim + c0 * sc, nb, sc, c0, scen + c0 * sc, sc, ws);
+      if (rc) return rc;
+      continue;
+    }
+    rc = xh_transpose_f32(ctx, sim + c0, T, nb, st, bin, Tp);
+    if (rc) return rc;
+    rc = run(bin, nb, Tp, c0, bout, Tp, ws);
+    if (rc) return rc;
+    rc = xh_transpose_f32(ctx, bout, nb, T, Tp, scen + c0, st);
+    if (rc) return rc;
+  }
+  return XH_OK;
+}
+
+}  // extern "C"

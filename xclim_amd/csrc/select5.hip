@@ -37,7 +37,8 @@ __device__ __forceinline__ uint32_t rs_rank(uint32_t n, double q, int side) {  /
 
 __global__ void __launch_bounds__(RS_NT)
 k_radix_select(const float* __restrict__ xcols, int64_t T, int64_t ncols, int64_t col_stride, const double* __restrict__ qs,
-               int nq, float* __restrict__ out, int64_t ocs, int64_t oqs) {
+               int nq, float* __restrict__ out, int64_t ocs, int64_t oqs, const double* __restrict__ qcol) {
+  // qcol != nullptr: ONE quantile per column, its probability qcol[column] (xsdba.nbutils.vecquantiles; nq = 1)
   // LDS (dynamic: 112.8 KB, one workgroup per CU): hist [64][256] u32 | map [3][64][256] u8: (slot, digit) of round r -> slot
   // of round r + 1 (0xFF: none) | per target: rank inside its current slot, digits found so far, slot
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -79,7 +80,8 @@ k_radix_select(const float* __restrict__ xcols, int64_t T, int64_t ncols, int64_
           }
           __syncthreads();
           if (tid < ntgt) {
-            t_rank[tid] = rs_rank(s_misc[0], qs[q0 + (tid >> 1)], tid & 1);
+            const double qq = qcol ? qcol[c] : qs[q0 + (tid >> 1)];
+            t_rank[tid] = qq == qq ? rs_rank(s_misc[0], qq, tid & 1) : 0u;
             t_key[tid] = 0u;
             t_slot[tid] = 0u;
           }
@@ -129,9 +131,10 @@ k_radix_select(const float* __restrict__ xcols, int64_t T, int64_t ncols, int64_
         if (n == 0u) r = xh_nan64();
         else if (n < 2u) r = (double)left;
         else {
-          const double nn = (double)n, qq = qs[q0 + tid];
+          const double nn = (double)n, qq = qcol ? qcol[c] : qs[q0 + tid];
           const double vi = nn * qq + (1.0 + qq * (1.0 - 1.0 - 1.0)) - 1.0;
-          if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
+          if (qq != qq) r = xh_nan64();  // (a NaN probability: vecquantiles of a cell without valid sim samples)
+          else if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
           else {
             const double gamma = vi - floor(vi);
             const float diff = right - left;
@@ -158,7 +161,48 @@ int xh_select_columns_radix(xh_ctx* ctx, const float* xcols, int64_t T, int64_t 
   constexpr size_t lds = (size_t)RS_MAXS * 256 * 4 + 3 * RS_MAXS * 256 + 3 * RS_MAXS * 4 + 16;
   XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_radix_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_radix_select, dim3((unsigned)nblk), dim3(RS_NT), lds, ctx->stream, xcols, T, ncols, col_stride, d_q, nq, out,
-                     out_cstride, out_qstride);
+                     out_cstride, out_qstride, (const double*)nullptr);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }
+
+extern "C" {
+
+// xsdba.nbutils.vecquantiles(da, rnk, dim): ONE quantile per cell, at that cell's own probability q_cell[c] (device,
+// float64; NaN -> NaN) — Hyndman-Fan type 7 over the valid samples.  x (T, C) with element strides (st, sc), one of them
+// 1; out (C) float32.  Used by adapt_freq (pth = the value of ref at the dry-day frequency of sim).  Time-major input
+// goes through transposed column batches (the radix select reads a column five times).
+int xh_quantile_cells(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* q_cell, float* out) {
+  XH_REQUIRE(ctx && x && q_cell && out, XH_ERR_ARG, "xh_quantile_cells: NULL argument");
+  XH_REQUIRE(T >= 1 && T < (1ll << 31) && C >= 0, XH_ERR_ARG, "xh_quantile_cells: bad shape");
+  if (C == 0) return XH_OK;
+  constexpr size_t lds = (size_t)RS_MAXS * 256 * 4 + 3 * RS_MAXS * 256 + 3 * RS_MAXS * 4 + 16;
+  XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_radix_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto run = [&](const float* cols, int64_t n, int64_t cs, const double* qc, float* o) -> int {
+    int64_t nblk = n < (int64_t)ctx->num_cu ? n : (int64_t)ctx->num_cu;
+    hipLaunchKernelGGL(k_radix_select, dim3((unsigned)nblk), dim3(RS_NT), lds, ctx->stream, cols, T, n, cs, qc, 1, o, (int64_t)1, (int64_t)0, qc);
+    XH_LAUNCH_CHECK();
+    return XH_OK;
+  };
+  if (st == 1 && sc >= T) return run(x, C, sc, q_cell, out);
+  XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_quantile_cells: one of the strides must be 1 (st=%lld sc=%lld)", (long long)st,
+             (long long)sc);
+  const int64_t Tp = (T + 63) & ~(int64_t)63;
+  int64_t batch = (int64_t)((1ull << 28) / (sizeof(float) * (size_t)Tp));
+  batch = (batch / 128) * 128;
+  if (batch < 128) batch = 128;
+  if (batch > C) batch = C;
+  void* tmp = nullptr;
+  int rc = xh_big_scratch(ctx, sizeof(float) * (size_t)batch * (size_t)Tp, &tmp);
+  if (rc) return rc;
+  for (int64_t c0 = 0; c0 < C; c0 += batch) {
+    const int64_t nb = C - c0 < batch ? C - c0 : batch;
+    rc = xh_transpose_f32(ctx, x + c0, T, nb, st, (float*)tmp, Tp);
+    if (rc) return rc;
+    rc = run((const float*)tmp, nb, Tp, q_cell + c0, out + c0);
+    if (rc) return rc;
+  }
+  return XH_OK;
+}
+
+}  // extern "C"

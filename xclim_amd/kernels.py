@@ -637,3 +637,35 @@ def qdm_adjust(dev: Device, sim: DeviceArray, af: DeviceArray, q, kind="+", inte
     dev.call("xh_qdm_adjust", _vp(sim.ptr), T, C_, st, sc, _vp(af.ptr), np_ptr(q), len(q), {"+": 0, "*": 1}[kind],
              {"nearest": 0, "linear": 1}[interp], {"constant": 0, "nan": 1}[extrapolation], _vp(scen.ptr))
     return scen
+
+
+def quantile_cells(dev: Device, x: DeviceArray, q_cell, time_axis=0) -> DeviceArray:
+    """xh_quantile_cells (xsdba.nbutils.vecquantiles): one quantile per cell at its own probability `q_cell` (C float64,
+    host or device); x (T, C) [time_axis 0] or (C, T)."""
+    if time_axis == 0:
+        T, C_ = _tc(x)
+        st, sc = C_, 1
+    else:
+        C_, T = _tc(x)
+        st, sc = 1, T
+    qd = q_cell if isinstance(q_cell, DeviceArray) else dev.to_device(np.ascontiguousarray(q_cell, dtype=np.float64))
+    out = dev.empty((C_,), np.float32)
+    dev.call("xh_quantile_cells", _vp(x.ptr), T, C_, st, sc, _vp(qd.ptr), _vp(out.ptr))
+    return out
+
+
+def adapt_freq(dev: Device, sim: DeviceArray, p0_ref, p0_sim, dp0, pth, thresh: float, seed: int = 0, tindex=None, cell0: int = 0,
+               out: DeviceArray | None = None) -> DeviceArray:
+    """xh_adapt_freq: the value-replacement step of xsdba.processing.adapt_freq on sim (T, C); per-cell P0_ref / P0_sim /
+    dP0 (float64) and pth (float32), host or device arrays of C."""
+    T, C_ = _tc(sim)
+
+    def up(a, dt):
+        return a if isinstance(a, DeviceArray) else dev.to_device(np.ascontiguousarray(a, dtype=dt))
+
+    pr, ps, dp, pt = up(p0_ref, np.float64), up(p0_sim, np.float64), up(dp0, np.float64), up(pth, np.float32)
+    ti = None if tindex is None else dev.to_device(np.ascontiguousarray(tindex, dtype=np.int64))
+    scen = out if out is not None else dev.empty(tuple(sim.shape), np.float32)
+    dev.call("xh_adapt_freq", _vp(sim.ptr), T, C_, C_, 1, _vp(pr.ptr), _vp(ps.ptr), _vp(dp.ptr), _vp(pt.ptr), float(thresh),
+             int(seed) & 0xFFFFFFFFFFFFFFFF, _vp(ti.ptr) if ti is not None else None, int(cell0), _vp(scen.ptr))
+    return scen

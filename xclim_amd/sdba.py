@@ -127,6 +127,82 @@ def quantile(da, q, dim="time", *, device=None, keep=False):
     return out if keep else out.get().reshape((out.shape[0],) + tuple(cell_shape))
 
 
+def adapt_freq(ref, sim, thresh: float, *, group="time", window: int | None = None, time=None, seed: int = 0, device=None,
+               keep=False):
+    """xsdba.processing.adapt_freq (``_processing._adapt_freq``, Themeßl et al. 2012): adapt the frequency of values
+    ``<= thresh`` in ``sim`` to that of ``ref`` — the pre-processing a multiplicative quantile mapping of precipitation
+    needs when the model has too many dry days.  Per cell and group:
+
+        P0 = count(x <= thresh) / count(valid)   for sim and ref (over the group's windowed sample)
+        dP0 = (P0_sim - P0_ref) / P0_sim         the share of sim's values <= thresh that has to become wet
+        pth = quantile(ref, P0_sim)  where dP0 > 0  (``nbutils.vecquantiles``: the value of ref at sim's dry-day rank)
+        sim_ad = sim, except: where dP0 >= 0 the samples whose percentage rank (average ranks over the group's own time
+                 steps) lies in [P0_ref, P0_sim] get a uniform random value in [thresh, pth)
+
+    Returns ``(sim_ad, pth, dP0)``: sim_ad float32 in the shape of sim, pth / dP0 per cell (``(groups, *cells)`` with a
+    sub-grouping).  ``thresh`` in the units of the data.  The random numbers: upstream draws from numpy's global
+    generator (not reproducible across runs); here a counter-based uniform keyed by ``(seed, time step, cell)`` —
+    ``xh_adapt_freq``, restated in oracle/sdba.py.  ``ref`` and ``sim`` need the same number of time steps only with a
+    sub-grouping (one ``time`` axis for both).  Parity unpinned (xsdba is not in the reference tree)."""
+    grp = group if isinstance(group, Grouper) else Grouper(group, 1 if window is None else window)
+    dev = device or get_device()
+    r, cell_shape = _flatten(ref, dev)
+    s_, cell_shape_s = _flatten(sim, dev)
+    if tuple(cell_shape) != tuple(cell_shape_s):
+        raise ValueError("ref and sim must have the same grid")
+    C_ = s_.shape[1]
+    thresh = float(thresh)
+
+    def one_group(ref_sample, sim_sample, sim_main, tindex, out):
+        """P0 / dP0 / pth from the (windowed) samples, the replacement on the group's own steps"""
+        def p0(x):
+            seg = np.array([0, x.shape[0]], dtype=np.int64)
+            cnt, val = K.threshold_count(dev, x, "<=", seg, scalar=thresh)
+            cnt, val = cnt.get()[0].astype(np.float64), val.get()[0].astype(np.float64)
+            with np.errstate(all="ignore"):
+                return cnt / val
+        p0_sim, p0_ref = p0(sim_sample), p0(ref_sample)
+        with np.errstate(all="ignore"):
+            dp0 = (p0_sim - p0_ref) / p0_sim
+        pth = K.quantile_cells(dev, ref_sample, p0_sim).get()
+        pth = np.where(dp0 > 0, pth, np.float32(np.nan)).astype(np.float32)
+        K.adapt_freq(dev, sim_main, p0_ref, p0_sim, dp0, pth, thresh, seed, tindex=tindex, out=out)
+        return pth, dp0
+
+    if grp.prop == "group":
+        out = dev.empty(tuple(s_.shape), np.float32)
+        pth, dp0 = one_group(r, s_, s_, None, out)
+        res = out if keep else out.get().reshape((s_.shape[0],) + tuple(cell_shape))
+        return res, pth.reshape(cell_shape), dp0.reshape(cell_shape)
+    if time is None or len(time) != s_.shape[0] or r.shape[0] != s_.shape[0]:
+        raise ValueError(f"group={grp.name!r} needs time=TimeAxis common to ref and sim")
+    gi = grp.index(time)
+    labels = grp.labels(time)
+    T = s_.shape[0]
+    # group-major blocks (every group's own steps contiguous), one gather back at the end — like the grouped adjust
+    perm = np.argsort(gi, kind="stable")
+    counts = np.bincount(gi, minlength=len(labels))
+    s_perm = K.select_rows(dev, s_, perm)
+    ad_perm = dev.empty((T, C_), np.float32)
+    pths, dp0s, off = [], [], 0
+    for g, rows in enumerate(grp.sample_rows(time)):
+        n = int(counts[g])
+        main = perm[off:off + n]
+        sim_main = dev.wrap(s_perm.ptr + off * C_ * 4, (n, C_), np.float32)
+        blk = dev.wrap(ad_perm.ptr + off * C_ * 4, (n, C_), np.float32)
+        pth, dp0 = one_group(K.select_rows(dev, r, rows), K.select_rows(dev, s_, rows), sim_main, main, blk)
+        pths.append(pth)
+        dp0s.append(dp0)
+        off += n
+    inv = np.empty(T, dtype=np.int64)
+    inv[perm] = np.arange(T)
+    out = K.select_rows(dev, ad_perm, inv)
+    dev.sync()
+    res = out if keep else out.get().reshape((T,) + tuple(cell_shape))
+    G = len(labels)
+    return res, np.stack(pths).reshape((G,) + tuple(cell_shape)), np.stack(dp0s).reshape((G,) + tuple(cell_shape))
+
+
 class EmpiricalQuantileMapping:
     """Empirical quantile mapping bias adjustment (train on ref/hist quantiles, adjust sim by node search)."""
 
@@ -143,9 +219,11 @@ class EmpiricalQuantileMapping:
 
     @classmethod
     def train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", window: int | None = None, time=None,
-              device=None):
+              device=None, adapt_freq_thresh: float | None = None, adapt_freq_seed: int = 0):
         """``group``: "time" (default), "time.month", "time.dayofyear" or a :class:`Grouper`; sub-groupings need the
-        common ``time`` axis (TimeAxis) of ref and hist."""
+        common ``time`` axis (TimeAxis) of ref and hist.  ``adapt_freq_thresh`` (in the units of the data): hist goes
+        through :func:`adapt_freq` against ref (same grouping) before the quantiles are taken — xsdba's
+        ``EmpiricalQuantileMapping.train(adapt_freq_thresh=...)`` (``_adjustment.eqm_train`` -> ``_adapt_freq_hist``)."""
         grp = group if isinstance(group, Grouper) else Grouper(group, 1 if window is None else window)
         if kind not in (ADDITIVE, MULTIPLICATIVE):
             raise ValueError(f"kind must be '+' or '*', got {kind!r}")
@@ -154,6 +232,8 @@ class EmpiricalQuantileMapping:
         h, cell_shape_h = _flatten(hist, dev)
         if tuple(cell_shape) != tuple(cell_shape_h) or r.shape != h.shape:
             raise ValueError("ref and hist must have the same shape")  # _check_matching_time_sizes analogue
+        if adapt_freq_thresh is not None:
+            h, _, _ = adapt_freq(r, h, adapt_freq_thresh, group=grp, time=time, seed=adapt_freq_seed, device=dev, keep=True)
         q = equally_spaced_nodes(nquantiles) if np.isscalar(nquantiles) else np.asarray(nquantiles, dtype=np.float64)
         if grp.prop == "group":
             af, hq = K.eqm_train(dev, r, h, q, kind)
