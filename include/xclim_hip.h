@@ -507,6 +507,13 @@ int xh_poly_trend(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st,
                   double* p1, int32_t* nvalid);
 int xh_trend_apply(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* p0,
                    const double* p1, int mode, float* out, int64_t out_st);
+/* The same two with the rows' own time coordinate u[t] (DEVICE float64, T) in place of the centred row number: the
+ * per-group fit / trend of PolyDetrend with a sub-grouping (xsdba.detrending.PolyDetrend(group=...): DataArray.polyfit over
+ * the time coordinate of the group's steps) on a gathered block of rows.  Parity unpinned. */
+int xh_poly_trend_u(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int degree, const double* u,
+                    double* p0, double* p1, int32_t* nvalid);
+int xh_trend_apply_u(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* u, const double* p0,
+                     const double* p1, int mode, float* out, int64_t out_st);
 
 #ifdef __cplusplus
 }

@@ -40,8 +40,11 @@ while the file is absent):
                                    fill values come from a counter-based uniform, not from numpy's   value was replaced: upstream's
                                    global generator                                                  draws are not reproducible)
 
-    NOT restated (refused by the product): interpolation over (quantile, group) for "linear" / "cubic", DQM with
-    sub-groupings, QDM cubic.
+    dqm_train_grouped /            dqm_train / dqm_adjust through Grouper("time.month" | "time.season")  dqmg_{group}_af / _hist_q /
+      dqm_adjust_grouped           (window 1): u.broadcast of the scaling, PolyDetrend(group=...)         _scaling / _scen
+
+    NOT restated (refused by the product): interpolation over (quantile, group) for "linear" / "cubic", DQM with a
+    windowed sub-grouping (the trend is fitted on the window mean there), QDM cubic.
 
 Where a difference is most likely once the fixtures exist (from memory of the upstream sources, not verified here): (1)
 ``nbutils.quantile`` casts the probabilities to the dtype of the data before it calls numpy's nanquantile, so float32
@@ -256,6 +259,53 @@ def dqm_adjust(sim, af, hist_q, scaling, kind="+", interp="nearest", extrapolati
     detr = _corr(scaled, trend, kind, True)
     scen0 = eqm_adjust(detr, af, hist_q, kind, interp, extrapolation)
     return _corr(scen0, trend, kind)
+
+
+def poly_trend_u(x, u, degree):
+    """The same on an explicit coordinate `u` (one value per row): DataArray.polyfit over the time coordinate of a
+    group's steps; evaluated at the same rows."""
+    x = np.asarray(x, dtype=np.float64)
+    x2 = x.reshape(x.shape[0], -1)
+    u = np.asarray(u, dtype=np.float64)
+    out = np.full(x2.shape, np.nan)
+    for c in range(x2.shape[1]):
+        ok = ~np.isnan(x2[:, c])
+        if not ok.any():
+            continue
+        if degree == 0 or ok.sum() < 2 or np.ptp(u[ok]) == 0:
+            out[:, c] = x2[ok, c].mean()
+        else:
+            out[:, c] = np.polyval(np.polyfit(u[ok], x2[ok, c], 1), u)
+    return out.reshape(x.shape)
+
+
+def dqm_train_grouped(ref, hist, time, prop, nquantiles=20, kind="+"):
+    """dqm_train per group (window 1): (labels, af (G, nq, ...), hist_q, scaling (G, ...))."""
+    labels = np.unique(group_values(time, prop))
+    res = [dqm_train(grouped_sample(ref, time, prop, 1, lab), grouped_sample(hist, time, prop, 1, lab), nquantiles, kind) for lab in labels]
+    return labels, np.stack([r[0] for r in res]), np.stack([r[1] for r in res]), np.stack([r[2] for r in res])
+
+
+def dqm_adjust_grouped(sim, time, prop, labels, af, hist_q, scaling, kind="+", extrapolation="constant", detrend=1):
+    """dqm_adjust with a sub-grouping, interp="nearest": every step takes the scaling of its group (u.broadcast), the
+    polynomial trend is fitted PER GROUP over the group's own steps on the time coordinate (PolyDetrend(group=...):
+    polyfit along time — here days since the group's mean date; a linear fit does not depend on the origin), the
+    detrended steps go through their group's nodes, the trend is put back."""
+    sim = np.asarray(sim)
+    out = np.full(sim.shape, np.nan, dtype=np.float32)
+    gv = group_values(time, prop)
+    days = np.arange(sim.shape[0], dtype=np.float64)  # (a DAILY series: the day number up to an origin)
+    for g, lab in enumerate(labels):
+        rows = np.nonzero(gv == lab)[0]
+        if not rows.size:
+            continue
+        scaled = _corr(sim[rows], scaling[g], kind)
+        u = days[rows] - days[rows].mean()
+        trend = poly_trend_u(scaled, u, detrend)
+        detr = _corr(scaled, trend, kind, True)
+        scen0 = eqm_adjust(detr, af[g], hist_q[g], kind, "nearest", extrapolation)
+        out[rows] = _corr(scen0, trend, kind)
+    return out
 
 
 # ---- adapt_freq (xsdba.processing.adapt_freq -> _processing._adapt_freq) ------------------------------------------------

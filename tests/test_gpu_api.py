@@ -1237,6 +1237,44 @@ def test_qdm_adjust_matches_oracle(dev, rng, kind, interp, T, cells):
         np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0, equal_nan=True, err_msg=f"{extrap}")
 
 
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("group", ["time.month", "time.season"])
+def test_dqm_grouped_matches_oracle(dev, rng, kind, group):
+    """DetrendedQuantileMapping with a sub-grouping (round 3: group="time" only): per group the normalised quantiles and
+    the scaling; adjust = the group's scaling, a trend fitted over the group's OWN steps on their time coordinate, the
+    group's nodes, the trend put back.  A warming sim (trend 3 K over the series) keeps its trend; parity unpinned."""
+    from xclim_amd import sdba as xsdba
+
+    T = 365 * 6
+    ta, ot = _axes("2001-01-01", T, "noleap")
+    shape = (T, 3, 4)
+    t = np.arange(T)[:, None, None]
+    seas = 8 * np.sin(2 * np.pi * (t - 100) / 365)
+    base = 0.0 if kind == "+" else 25.0
+    ref = (base + 10 + seas + rng.normal(0, 3, shape)).astype(np.float32)
+    hist = (base + 11.5 + 1.2 * seas + rng.normal(0, 4, shape)).astype(np.float32)
+    sim = (base + 12 + 1.2 * seas + 3.0 * t / T + rng.normal(0, 4, shape)).astype(np.float32)
+    sim[rng.random(shape) < 0.01] = np.nan
+    hist[:50, 0, 0] = np.nan
+    prop = group.split(".")[1]
+    dqm = xsdba.DetrendedQuantileMapping.train(ref, hist, nquantiles=15, kind=kind, group=group, time=ta, device=dev)
+    labels, eaf, ehq, escal = osdba.dqm_train_grouped(ref, hist, ot, prop, 15, kind)
+    np.testing.assert_array_equal(dqm.group_labels, labels)
+    np.testing.assert_allclose(dqm.scaling, escal, rtol=1e-6)
+    np.testing.assert_allclose(dqm.hist_q, ehq, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(dqm.af, eaf, rtol=1e-5, atol=1e-5)
+    for deg in (0, 1):
+        got = dqm.adjust(sim, detrend=deg, time=ta)
+        exp = osdba.dqm_adjust_grouped(sim, ot, prop, labels, dqm.af, dqm.hist_q, dqm.scaling, kind, "constant", deg)
+        np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5, equal_nan=True)
+    first, last = np.nanmean(got[:365]), np.nanmean(got[-365:])
+    assert 1.5 < last - first < 4.0                                     # the simulated trend survives the adjustment
+    with pytest.raises(NotImplementedError):
+        xsdba.DetrendedQuantileMapping.train(ref, hist, group="time.dayofyear", window=31, time=ta, device=dev)
+    with pytest.raises(NotImplementedError):
+        dqm.adjust(sim, interp="linear", time=ta)
+
+
 def _pr_field(rng, T, C, p_dry, scale):
     x = rng.gamma(0.7, scale, (T, C)).astype(np.float32)
     x[rng.random((T, C)) < p_dry] = 0.0

@@ -16,14 +16,14 @@ namespace {
 template <int VEC>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_poly_trend(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int degree, double tc, double* __restrict__ p0,
-             double* __restrict__ p1, int32_t* __restrict__ nvalid) {
+             double* __restrict__ p1, int32_t* __restrict__ nvalid, const double* __restrict__ ucoord) {
   const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
   double n[VEC], su[VEC], suu[VEC], sx[VEC], sux[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) n[i] = su[i] = suu[i] = sx[i] = sux[i] = 0.0;
   xh_march_rows<VEC, 8>(x + c, st, 0, T, [&](int64_t t, const VecF<VEC>& xv) {
-    const double u = (double)t - tc;
+    const double u = ucoord ? ucoord[t] : (double)t - tc;  // (ucoord: the rows' own time coordinate, e.g. a group's steps)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float f = xv.v[i];
@@ -58,7 +58,8 @@ k_poly_trend(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int 
 template <int VEC>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_trend_apply(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const double* __restrict__ p0,
-              const double* __restrict__ p1, double tc, int mode, float* __restrict__ out, int64_t out_st) {
+              const double* __restrict__ p1, double tc, int mode, float* __restrict__ out, int64_t out_st,
+              const double* __restrict__ ucoord) {
   const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
   if (c >= C) return;
   const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
@@ -70,7 +71,7 @@ k_trend_apply(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, con
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { a[i] = p0[c + i]; b[i] = p1 ? p1[c + i] : 0.0; }
   xh_march_rows<VEC, 8>(x + c, st, ta, tb, [&](int64_t t, const VecF<VEC>& xv) {
-    const double u = (double)t - tc;
+    const double u = ucoord ? ucoord[t] : (double)t - tc;
     float r[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -91,8 +92,8 @@ k_trend_apply(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, con
 
 extern "C" {
 
-int xh_poly_trend(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int degree, double* p0,
-                  double* p1, int32_t* nvalid) {
+static int poly_trend_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int degree, double* p0,
+                           double* p1, int32_t* nvalid, const double* ucoord) {
   XH_REQUIRE(ctx && x && p0, XH_ERR_ARG, "xh_poly_trend: NULL argument");
   XH_REQUIRE(T >= 1 && C >= 0, XH_ERR_ARG, "xh_poly_trend: bad shape");
   XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_poly_trend: needs a time-major view (sc == 1)");
@@ -103,16 +104,30 @@ int xh_poly_trend(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st,
   const bool v4 = xh_pick_vec(x, C, st) == 4 && cdiv64(cdiv64(C, 4), XH_BLOCK) >= 2 * (int64_t)ctx->num_cu;
   if (v4)
     hipLaunchKernelGGL((k_poly_trend<4>), dim3((unsigned)cdiv64(cdiv64(C, 4), XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st,
-                       degree, tc, p0, p1, nvalid);
+                       degree, tc, p0, p1, nvalid, ucoord);
   else
     hipLaunchKernelGGL((k_poly_trend<1>), dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, degree,
-                       tc, p0, p1, nvalid);
+                       tc, p0, p1, nvalid, ucoord);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }
 
-int xh_trend_apply(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* p0,
-                   const double* p1, int mode, float* out, int64_t out_st) {
+int xh_poly_trend(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int degree, double* p0,
+                  double* p1, int32_t* nvalid) {
+  return poly_trend_impl(ctx, x, T, C, st, sc, degree, p0, p1, nvalid, nullptr);
+}
+
+// the same with the rows' own coordinate u[t] (DEVICE float64, T; e.g. days since the mean date of a group's steps) instead
+// of the centred row number: PolyDetrend fitted per group on a gathered block of rows (xsdba.detrending.PolyDetrend with a
+// sub-grouping: DataArray.polyfit over the group's time coordinate)
+int xh_poly_trend_u(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int degree, const double* u,
+                    double* p0, double* p1, int32_t* nvalid) {
+  XH_REQUIRE(u, XH_ERR_ARG, "xh_poly_trend_u: NULL coordinate");
+  return poly_trend_impl(ctx, x, T, C, st, sc, degree, p0, p1, nvalid, u);
+}
+
+static int trend_apply_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* p0,
+                            const double* p1, int mode, float* out, int64_t out_st, const double* ucoord) {
   XH_REQUIRE(ctx && x && p0 && out, XH_ERR_ARG, "xh_trend_apply: NULL argument");
   XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "xh_trend_apply: bad shape");
   XH_REQUIRE(sc == 1 && st >= C && out_st >= C, XH_ERR_LAYOUT, "xh_trend_apply: needs time-major views (sc == 1)");
@@ -127,11 +142,22 @@ int xh_trend_apply(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   if (gy < 1) gy = 1;
   const dim3 grid((unsigned)cblocks, (unsigned)gy);
   if (vec == 4)
-    hipLaunchKernelGGL((k_trend_apply<4>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, p0, p1, tc, mode, out, out_st);
+    hipLaunchKernelGGL((k_trend_apply<4>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, p0, p1, tc, mode, out, out_st, ucoord);
   else
-    hipLaunchKernelGGL((k_trend_apply<1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, p0, p1, tc, mode, out, out_st);
+    hipLaunchKernelGGL((k_trend_apply<1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, p0, p1, tc, mode, out, out_st, ucoord);
   XH_LAUNCH_CHECK();
   return XH_OK;
+}
+
+int xh_trend_apply(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* p0,
+                   const double* p1, int mode, float* out, int64_t out_st) {
+  return trend_apply_impl(ctx, x, T, C, st, sc, p0, p1, mode, out, out_st, nullptr);
+}
+
+int xh_trend_apply_u(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* u, const double* p0,
+                     const double* p1, int mode, float* out, int64_t out_st) {
+  XH_REQUIRE(u, XH_ERR_ARG, "xh_trend_apply_u: NULL coordinate");
+  return trend_apply_impl(ctx, x, T, C, st, sc, p0, p1, mode, out, out_st, u);
 }
 
 }  // extern "C"

@@ -598,21 +598,31 @@ def mask_days_cells(dev: Device, x: DeviceArray, seg_off, lo: DeviceArray, hi: D
     return out
 
 
-def poly_trend(dev: Device, x: DeviceArray, degree: int = 1):
-    """xh_poly_trend: (p0, p1) float64 (C,) device arrays of the per-cell trend p0 + p1 (t - (T - 1) / 2); p1 None for degree 0."""
+def poly_trend(dev: Device, x: DeviceArray, degree: int = 1, u: DeviceArray | None = None):
+    """xh_poly_trend: (p0, p1) float64 (C,) device arrays of the per-cell trend p0 + p1 (t - (T - 1) / 2); p1 None for degree 0.
+    ``u`` (device float64, T): the rows' own coordinate instead of the centred row number (xh_poly_trend_u)."""
     T, C_ = _tc(x)
     p0 = dev.empty((C_,), np.float64)
     p1 = dev.empty((C_,), np.float64) if degree >= 1 else None
-    dev.call("xh_poly_trend", _vp(x.ptr), T, C_, C_, 1, int(degree), _vp(p0.ptr), _vp(p1.ptr if p1 else 0), _vp(0))
+    if u is None:
+        dev.call("xh_poly_trend", _vp(x.ptr), T, C_, C_, 1, int(degree), _vp(p0.ptr), _vp(p1.ptr if p1 else 0), _vp(0))
+    else:
+        dev.call("xh_poly_trend_u", _vp(x.ptr), T, C_, C_, 1, int(degree), _vp(u.ptr), _vp(p0.ptr), _vp(p1.ptr if p1 else 0), _vp(0))
     return p0, p1
 
 
-def trend_apply(dev: Device, x: DeviceArray, p0: DeviceArray, p1, op: str, out: DeviceArray | None = None) -> DeviceArray:
-    """xh_trend_apply: x OP (p0[c] + p1[c] (t - (T - 1) / 2)), op in "+", "-", "*", "/"; p1 None: per-cell constant."""
+def trend_apply(dev: Device, x: DeviceArray, p0: DeviceArray, p1, op: str, out: DeviceArray | None = None,
+                u: DeviceArray | None = None) -> DeviceArray:
+    """xh_trend_apply: x OP (p0[c] + p1[c] (t - (T - 1) / 2)), op in "+", "-", "*", "/"; p1 None: per-cell constant.
+    ``u``: the rows' own coordinate (xh_trend_apply_u)."""
     T, C_ = _tc(x)
     out = out if out is not None else dev.empty((T, C_), np.float32)
-    dev.call("xh_trend_apply", _vp(x.ptr), T, C_, C_, 1, _vp(p0.ptr), _vp(p1.ptr if p1 is not None else 0),
-             {"+": 0, "-": 1, "*": 2, "/": 3}[op], _vp(out.ptr), C_)
+    mode = {"+": 0, "-": 1, "*": 2, "/": 3}[op]
+    if u is None:
+        dev.call("xh_trend_apply", _vp(x.ptr), T, C_, C_, 1, _vp(p0.ptr), _vp(p1.ptr if p1 is not None else 0), mode, _vp(out.ptr), C_)
+    else:
+        dev.call("xh_trend_apply_u", _vp(x.ptr), T, C_, C_, 1, _vp(u.ptr), _vp(p0.ptr), _vp(p1.ptr if p1 is not None else 0), mode,
+                 _vp(out.ptr), C_)
     return out
 
 

@@ -356,7 +356,9 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
 
 
 class DetrendedQuantileMapping(EmpiricalQuantileMapping):
-    """Detrended quantile mapping (xsdba.DetrendedQuantileMapping, ``group="time"``; Cannon et al. 2015).
+    """Detrended quantile mapping (xsdba.DetrendedQuantileMapping; Cannon et al. 2015).  ``group="time"``, or a
+    sub-grouping without a window ("time.month", "time.season": everything below happens per group, the trend is fitted
+    over the group's own steps on their time coordinate).
 
     train (``dqm_train``): ref and hist are normalised by their time means (``x - mean`` for "+", ``x / mean`` for "*"),
     ``af`` / ``hist_q`` come from the quantiles of the NORMALISED series, ``scaling = mean(ref) - mean(hist)`` (resp. the
@@ -372,8 +374,10 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
     @classmethod
     def train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", window=None, time=None, device=None):
         grp = group if isinstance(group, Grouper) else Grouper(group, 1 if window is None else window)
-        if grp.prop != "group":
-            raise NotImplementedError("DetrendedQuantileMapping: only group='time' is built")
+        if grp.prop != "group" and grp.window != 1:
+            # with a window xsdba fits the trend on the WINDOW MEAN of every step (PolyDetrend: da.mean over the window
+            # dimension before polyfit) — not built
+            raise NotImplementedError("DetrendedQuantileMapping: sub-groupings are built for window=1 (time.month, time.season)")
         if kind not in (ADDITIVE, MULTIPLICATIVE):
             raise ValueError(f"kind must be '+' or '*', got {kind!r}")
         dev = device or get_device()
@@ -383,18 +387,37 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             raise ValueError("ref and hist must have the same shape")
         q = equally_spaced_nodes(nquantiles) if np.isscalar(nquantiles) else np.asarray(nquantiles, dtype=np.float64)
         inv = "-" if kind == ADDITIVE else "/"
-        mu_r, _ = K.poly_trend(dev, r, 0)
-        mu_h, _ = K.poly_trend(dev, h, 0)
-        af, hq = K.eqm_train(dev, K.trend_apply(dev, r, mu_r, None, inv), K.trend_apply(dev, h, mu_h, None, inv), q, kind)
-        # scaling = get_correction(mu_hist, mu_ref): a (C,) table — O(C) host arithmetic on the two mean vectors
-        mr, mh = mu_r.get(), mu_h.get()
-        with np.errstate(all="ignore"):
-            scaling = mr - mh if kind == ADDITIVE else mr / mh
-        return cls(dev, af, hq, q, kind, cell_shape, grp, scaling=dev.to_device(np.ascontiguousarray(scaling), dtype=np.float64))
+
+        def one(rg, hg, out=None):
+            mu_r, _ = K.poly_trend(dev, rg, 0)
+            mu_h, _ = K.poly_trend(dev, hg, 0)
+            af, hq = K.eqm_train(dev, K.trend_apply(dev, rg, mu_r, None, inv), K.trend_apply(dev, hg, mu_h, None, inv), q, kind, out=out)
+            # scaling = get_correction(mu_hist, mu_ref): a (C,) table — O(C) host arithmetic on the two mean vectors
+            mr, mh = mu_r.get(), mu_h.get()
+            with np.errstate(all="ignore"):
+                return af, hq, (mr - mh if kind == ADDITIVE else mr / mh)
+
+        if grp.prop == "group":
+            af, hq, scaling = one(r, h)
+            return cls(dev, af, hq, q, kind, cell_shape, grp, scaling=dev.to_device(np.ascontiguousarray(scaling), dtype=np.float64))
+        if time is None or len(time) != r.shape[0]:
+            raise ValueError(f"group={grp.name!r} needs time=TimeAxis of the training series")
+        labels = grp.labels(time)
+        G, C_ = len(labels), r.shape[1]
+        af = dev.empty((G, len(q), C_), np.float32)
+        hq = dev.empty((G, len(q), C_), np.float32)
+        plane = len(q) * C_ * 4
+        scal = np.empty((G, C_), np.float64)
+        for g, rows in enumerate(grp.sample_rows(time)):
+            out_g = tuple(dev.wrap(a.ptr + g * plane, (len(q), C_), np.float32) for a in (af, hq))
+            _, _, scal[g] = one(K.select_rows(dev, r, rows), K.select_rows(dev, h, rows), out=out_g)
+        dev.sync()
+        return cls(dev, af, hq, q, kind, cell_shape, grp, labels, scaling=dev.to_device(scal, dtype=np.float64))
 
     @property
     def scaling(self) -> np.ndarray:
-        return self._scaling.get().reshape(self.cell_shape)
+        lead = () if self.group.prop == "group" else (len(self.group_labels),)
+        return self._scaling.get().reshape(lead + self.cell_shape)
 
     def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", detrend: int = 1, time=None, keep=False):
         if interp not in ("nearest", "linear", "cubic"):
@@ -406,6 +429,8 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         if tuple(cell_shape) != self.cell_shape:
             raise ValueError("sim does not match the trained grid")
         fwd, inv = ("+", "-") if self.kind == ADDITIVE else ("*", "/")
+        if self.group.prop != "group":
+            return self._adjust_grouped(s, interp, extrapolation, detrend, time, keep, fwd, inv)
         scaled = K.trend_apply(dev, s, self._scaling, None, fwd)
         p0, p1 = K.poly_trend(dev, scaled, detrend)
         detr = K.trend_apply(dev, scaled, p0, p1, inv)
@@ -413,3 +438,45 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         scen0 = K.eqm_adjust(dev, detr, self._af, self._hist_q, self.kind, interp, extrapolation)
         scen = K.trend_apply(dev, scen0, p0, p1, fwd, out=detr)  # (distinct buffers: the kernels' pointers are __restrict__)
         return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
+
+    def _adjust_grouped(self, s, interp, extrapolation, detrend, time, keep, fwd, inv):
+        """dqm_adjust with a sub-grouping (window 1): group-major row blocks like the grouped EQM; per block the group's
+        scaling (``u.broadcast``), the trend fitted over the group's OWN steps on their time coordinate (days since the
+        group's mean date: ``PolyDetrend(group=...)`` -> polyfit along time), the group's nodes, the trend put back."""
+        _check_group_interp(self.group, interp, "DetrendedQuantileMapping.adjust")
+        dev = self._dev
+        if time is None or len(time) != s.shape[0]:
+            raise ValueError(f"group={self.group.name!r} needs time=TimeAxis of sim")
+        gi = self.group.index(time, self.group_labels)
+        if (gi < 0).any():
+            raise ValueError("sim holds time steps whose group was not trained")
+        perm = np.argsort(gi, kind="stable")
+        counts = np.bincount(gi, minlength=len(self.group_labels))
+        T, C_ = s.shape
+        nq = len(self.quantiles)
+        days = np.asarray(time.ordinal(), dtype=np.float64)
+        s_perm = K.select_rows(dev, s, perm)
+        scen_perm = dev.empty((T, C_), np.float32)
+        off = 0
+        for g, n in enumerate(counts):
+            n = int(n)
+            if n == 0:
+                continue
+            rows = perm[off:off + n]
+            u = dev.to_device(np.ascontiguousarray(days[rows] - days[rows].mean()), dtype=np.float64)
+            blk = dev.wrap(s_perm.ptr + off * C_ * 4, (n, C_), np.float32)
+            out = dev.wrap(scen_perm.ptr + off * C_ * 4, (n, C_), np.float32)
+            sc_g = dev.wrap(self._scaling.ptr + g * C_ * 8, (C_,), np.float64)
+            af_g = dev.wrap(self._af.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
+            hq_g = dev.wrap(self._hist_q.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
+            scaled = K.trend_apply(dev, blk, sc_g, None, fwd)
+            p0, p1 = K.poly_trend(dev, scaled, detrend, u=u)
+            detr = K.trend_apply(dev, scaled, p0, p1, inv, u=u)
+            scen0 = K.eqm_adjust(dev, detr, af_g, hq_g, self.kind, interp, extrapolation)
+            K.trend_apply(dev, scen0, p0, p1, fwd, out=out, u=u)
+            off += n
+        inv_perm = np.empty(T, dtype=np.int64)
+        inv_perm[perm] = np.arange(T)
+        scen = K.select_rows(dev, scen_perm, inv_perm)
+        dev.sync()
+        return scen if keep else scen.get().reshape((T,) + self.cell_shape)
