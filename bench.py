@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s best meas
 # idle) ran up to 40 % slower on one of ~10 boxes of the pool; they are not part of the measurement either way
 WAKEUP_STEPS = 30
 
-PMC_TABLES = ("profiles/r03/pmc_hbm_traffic.json", "profiles/r02/pmc_hbm_traffic.json")
+PMC_TABLES = ("profiles/r04/pmc_hbm_traffic.json", "profiles/r03/pmc_hbm_traffic.json", "profiles/r02/pmc_hbm_traffic.json")
 
 
 def pmc_traffic(kernel, grid):
@@ -74,27 +74,31 @@ def valu_bound(kernel):
     tools/summarize_sq.py -> profiles/r03/valu_busy.json): VALU instructions per SIMD x the measured issue cost of a
     wave64 instruction (2.5 cycles of the ~2.4 GHz clock for add / xor / mov, 4.3 for min / max / cmp:
     profiles/r03/valu_ubench.txt, bank_ubench.txt) over the kernel's cycles.  busy_hi near 1 = no faster without issuing fewer instructions.  None when not profiled."""
-    try:
-        table = json.load(open(os.path.join(ROOT, "profiles/r03/valu_busy.json")))
-    except (OSError, ValueError):
-        return None
-    for name, v in table.items():
-        if name.startswith(kernel):
-            return {"bound": "valu", "kernel": name, "valu_insts_per_simd": v["valu_insts_per_simd"], "cycles": v["cycles"],
-                    "busy_at_2.5_cycles": v["busy_lo"], "busy_at_4.3_cycles": v["busy_hi"], "source": "profiles/r03/valu_busy.json"}
+    for rel in ("profiles/r04/valu_busy.json", "profiles/r03/valu_busy.json"):
+        try:
+            table = json.load(open(os.path.join(ROOT, rel)))
+        except (OSError, ValueError):
+            continue
+        for name, v in table.items():
+            if name.startswith(kernel):
+                return {"bound": "valu", "kernel": name, "valu_insts_per_simd": v["valu_insts_per_simd"], "cycles": v["cycles"],
+                        "busy_at_2.5_cycles": v["busy_lo"], "busy_at_4.3_cycles": v["busy_hi"], "source": rel}
     return None
 
 
+PMC_30YR = "profiles/r04/pmc_hbm_traffic_30yr.json"
+
+
 def pmc_traffic_30yr(*kernels):
-    """Sum of the HBM bytes per launch of the 30-year kernels from profiles/r03/pmc_hbm_traffic_30yr.json (PMC passes of
-    the full configurations; only kernels that run at one size there), or None."""
+    """Sum of the HBM bytes per launch of the 30-year kernels from the committed PMC passes of the full configurations
+    (PMC_30YR; only kernels that run at one size there), or None (a kernel that is absent or not calibrated)."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles/r03/pmc_hbm_traffic_30yr.json")))
+        table = json.load(open(os.path.join(ROOT, PMC_30YR)))
     except (OSError, ValueError):
         return None
     tot = 0.0
     for k in kernels:
-        if k not in table:
+        if k not in table or table[k].get("hbm_bytes_per_launch") is None:
             return None
         tot += table[k]["hbm_bytes_per_launch"]
     return tot
@@ -144,6 +148,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-full", action="store_true", help="skip the 3650-step / 30-year extras (they allocate up to 182 GB)")
+    ap.add_argument("--no-long", action="store_true", help="skip the 55 152-step extras (PMC passes: per-kernel means must not mix sizes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -279,7 +284,7 @@ def main():
 
     extra = {}
     if not args.no_extra and rank == 0 and world == 1:
-        extra = bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, len(doys), full_configs=not args.no_full)
+        extra = bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, len(doys), full_configs=not args.no_full, long_series=not args.no_long)
 
     cpu = None
     if not args.no_cpu and rank == 0 and world == 1:
@@ -399,7 +404,7 @@ def bench_config5(args, dev, K, comm, world, rank):
         comm.close()
 
 
-def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D, full_configs=True):
+def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D, full_configs=True, long_series=True):
     """The other two north-star workloads on the same 365 x 1440 x 720 grid (HIP-event times, one GPU)."""
     out = {}
     E = float(T) * C
@@ -460,7 +465,7 @@ def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D, full_configs=True)
         a.free()
     out["adapter_e2e"] = bench_adapter_e2e(dev, K, ta, T, C, tasmax)
     if full_configs:
-        out.update(bench_full_configs(dev, K, C))
+        out.update(bench_full_configs(dev, K, C, long_series))
     return out
 
 
@@ -502,7 +507,7 @@ def bench_adapter_e2e(dev, K, ta, T, C, tasmax):
     return res
 
 
-def bench_full_configs(dev, K, C):
+def bench_full_configs(dev, K, C, long_series=True):
     """BASELINE configs[2] (cdd on 3650 steps), the 30-year tx90p of configs[4] and configs[3] (EQM on 30 years) at
     their own size on this GPU's grid (same byte formulas as SURVEY 8d / tools/bench_configs.py), inputs generated on the
     device.  Up to four 45.4 GB arrays are resident at once."""
@@ -548,7 +553,7 @@ def bench_full_configs(dev, K, C):
                          "roofline": hbm_roofline(bp + bc, ms_p + ms_c, "k_pdoy_top16<5, 32, false> (xh_percentile_doy) + k_tc_doy<0, false> (xh_threshold_count_doy)"),
                          "roofline_percentile_doy": hbm_roofline(bp, ms_p, "k_pdoy_top16<5, 32, false>"),
                          "roofline_threshold_count": hbm_roofline(bc, ms_c, "k_tc_doy<0, false>", traffic=pmc_traffic_30yr("k_tc_doy<0, false>"),
-                                                                  traffic_source="profiles/r03/pmc_hbm_traffic_30yr.json"),
+                                                                  traffic_source=PMC_30YR),
                          "roofline_valu": valu_bound("k_pdoy_top16")}
     period = (np.searchsorted(seg, tb, side="right") - 1).astype(np.int32)
     period[tb < 0] = -1
@@ -581,11 +586,13 @@ def bench_full_configs(dev, K, C):
                      "roofline_train": hbm_roofline(8 * E, ms_tr, "2 x (k_hs_sample + k_hs_hist + k_hs_collect) (select4.hip)",
                                                     passes="two streaming passes per array: 16E + 0.25E bytes cross HBM for 8E algorithmic",
                                                     traffic=(lambda t: None if t is None else 2 * t)(pmc_traffic_30yr(
-                                                        "k_hs_sample<4>", "k_hs_hist<16, 64>", "k_hs_collect<16, 64, false>")),
-                                                    traffic_source="profiles/r03/pmc_hbm_traffic_30yr.json"),
+                                                        "k_hs_sample<4>", "k_hs_hist<8, 5, false>", "k_hs_collect<8, 5, false>")),
+                                                    traffic_source=PMC_30YR),
                      "roofline_adjust": hbm_roofline(8 * E, ms_ad, "k_eqm_adjust<20, 0>")}
     for a in (hist, sim, scen, af, hq):
         a.free()
+    if not long_series:
+        return out
     # ---- 1950-2100 daily (55 152 steps: beyond the 32768-step column kernels) on a 1440 x 90 band of the grid: EQM train
     #      (select4.hip streams any T <= 65535) and QDM adjust (qdm3.hip: ranks through a global sort) — round 3 refused both
     T, Cb = 55152, C // 8
