@@ -470,6 +470,14 @@ int xh_eqm_train(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, in
  * (what xsdba.utils.interp_on_quantiles returns for group="time").  scen (T, C) row stride scen_st. */
 int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const float* af,
                   const float* hist_q, int nq, int kind, int interp, int extrap, float* scen, int64_t scen_st);
+/* The same for the steps of ONE group of a month / day-of-year grouping with interp "nearest" the way
+ * xsdba.utils.interp_on_quantiles does it with a sub-grouping (upstream xsdba, re-exported by
+ * /root/reference/src/xclim/sdba.py:10): _interp_on_quantiles_2D = scipy griddata(method="nearest") over the nodes of ALL
+ * groups in the (hist_q, group coordinate) plane (cyclic copies of the last / first group at coordinates 0 / G + 1), then
+ * _extrapolate_on_quantiles with the step's own group (constant | nan).  sim / scen (n, C): the group's rows; af_all /
+ * hq_all (G, nq, C); gcoord in 1 .. G; kind 0 (+) | 1 (*) | 2 (factor only).  Parity unpinned. */
+int xh_eqm_adjust_g2d(xh_ctx* ctx, const float* sim, int64_t n, int64_t C, int64_t st, const float* af_all, const float* hq_all,
+                      int G, int nq, int gcoord, int kind, int extrap, float* scen, int64_t scen_st);
 /* QuantileDeltaMapping.adjust (xsdba._adjustment.qdm_adjust, group "time"): sim_q = rank(sim, pct=True) along time
  * (average ranks of the valid samples r / n, rescaled mx (r/n - mn) / (mx - mn) as xsdba.utils.rank does);
  * af_t = interp_on_quantiles(sim_q, q, af) with the nq quantile nodes q (host, strictly increasing) as abscissa

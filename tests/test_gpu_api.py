@@ -545,14 +545,54 @@ def test_eqm_with_sub_groupings(dev, rng, group, window, nyears, kind, interp):
         with pytest.raises(NotImplementedError, match="2-D interpolation"):
             eqm.adjust(sim, interp=interp, extrapolation="constant", time=ta)
         return
-    scen = eqm.adjust(sim, interp=interp, extrapolation="constant", time=ta)
+    scen = eqm.adjust(sim, interp=interp, extrapolation="constant", time=ta, grouped_nearest="group")
     exp = osdba.eqm_adjust_grouped(sim, ot, prop, labels, eqm.af, eqm.hist_q, kind, interp, "constant")
     np.testing.assert_allclose(scen, exp, rtol=1e-6, equal_nan=True)
+    if prop != "season":  # the default since round 4: xsdba's nearest node in the (hist_q, group) plane (scipy griddata in the oracle)
+        for extrap in ("constant", "nan"):
+            scen2 = eqm.adjust(sim, interp=interp, extrapolation=extrap, time=ta)
+            exp2 = osdba.eqm_adjust_grouped(sim, ot, prop, labels, eqm.af, eqm.hist_q, kind, interp, extrap, mode="griddata")
+            np.testing.assert_allclose(scen2, exp2, rtol=1e-6, equal_nan=True)
+    else:
+        np.testing.assert_array_equal(eqm.adjust(sim, time=ta), scen)   # seasons keep the own-group rule
     assert "Grouper" in str(eqm.adj_params["group"]) or eqm.adj_params["group"] == group
     with pytest.raises(ValueError, match="needs time"):
         eqm.adjust(sim)
     with pytest.raises(ValueError, match="needs time"):
         xsdba.EmpiricalQuantileMapping.train(ref, hist, group=group, window=window, device=dev)
+
+
+def test_grouped_nearest_in_the_value_group_plane(dev, rng):
+    """xsdba's grouped "nearest" = scipy griddata in the (hist_q, group coordinate) plane: with precipitation-like values
+    (nodes tens of mm/day apart in the upper tail) a node of a NEIGHBOURING month is often nearer than the own month's —
+    round 3 always took the own month's node (its documented deviation).  GPU == the oracle's restatement with the real
+    griddata, for both kinds and extrapolations, incl. the cyclic December <-> January neighbourhood and NaN nodes; the
+    two rules do differ on this field."""
+    T = 365 * 5
+    ta, ot = _axes("2001-01-01", T, "noleap")
+    shape = (2, 4)
+    seas = 1.0 + 0.6 * np.sin(2 * np.pi * (np.arange(T) - 30) / 365)[:, None, None]
+
+    def pr(scale):
+        x = rng.gamma(0.6, scale, (T,) + shape) * seas
+        x[rng.random(x.shape) < 0.5] = 0.0
+        return x.astype(np.float32)
+
+    ref, hist, sim = pr(9.0), pr(7.0), pr(8.0)
+    sim[rng.random(sim.shape) < 0.01] = np.nan
+    eqm = xsdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=20, kind="*", group="time.month", time=ta, device=dev)
+    labels = eqm.group_labels
+    a_plane = eqm.adjust(sim, time=ta)
+    a_group = eqm.adjust(sim, time=ta, grouped_nearest="group")
+    exp = osdba.eqm_adjust_grouped(sim, ot, "month", labels, eqm.af, eqm.hist_q, "*", "nearest", "constant", mode="griddata")
+    np.testing.assert_allclose(a_plane, exp, rtol=1e-6, equal_nan=True)
+    differ = ~np.isclose(a_plane, a_group, rtol=1e-6, equal_nan=True)
+    assert differ.mean() > 0.01                                       # the deviation of rounds 2-3 was not a corner case here
+    jan, dec = ta.month == 1, ta.month == 12
+    assert differ[jan].any() and differ[dec].any()                    # (the cyclic copies at coordinates 0 and 13 take part)
+    np.testing.assert_allclose(eqm.adjust(sim, time=ta, extrapolation="nan"),
+                               osdba.eqm_adjust_grouped(sim, ot, "month", labels, eqm.af, eqm.hist_q, "*", "nearest", "nan", mode="griddata"),
+                               rtol=1e-6, equal_nan=True)
 
 
 def test_grouped_eqm_removes_a_seasonal_bias(dev, rng):
@@ -566,7 +606,10 @@ def test_grouped_eqm_removes_a_seasonal_bias(dev, rng):
     hist = (ref + bias).astype(np.float32)
     by_month = xsdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=20, kind="+", group="time.month", time=ta, device=dev)
     np.testing.assert_allclose(by_month.af, np.broadcast_to(-np.linspace(-3.0, 3.0, 12)[:, None, None], by_month.af.shape), atol=2e-4)
-    np.testing.assert_allclose(by_month.adjust(hist, time=ta), ref, atol=5e-4)
+    # (own-group nearest: with xsdba's nearest node in the (value, group) plane a neighbouring month's node wins at a few
+    # steps in the tails and the removal is no longer exact)
+    np.testing.assert_allclose(by_month.adjust(hist, time=ta, grouped_nearest="group"), ref, atol=5e-4)
+    assert (np.abs(by_month.adjust(hist, time=ta) - ref) > 5e-4).mean() < 0.01
     flat = xsdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=20, kind="+", device=dev)
     assert np.abs(flat.adjust(hist) - ref).max() > 1.0
     with pytest.raises(NotImplementedError):
@@ -1264,9 +1307,11 @@ def test_dqm_grouped_matches_oracle(dev, rng, kind, group):
     np.testing.assert_allclose(dqm.hist_q, ehq, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(dqm.af, eaf, rtol=1e-5, atol=1e-5)
     for deg in (0, 1):
-        got = dqm.adjust(sim, detrend=deg, time=ta)
-        exp = osdba.dqm_adjust_grouped(sim, ot, prop, labels, dqm.af, dqm.hist_q, dqm.scaling, kind, "constant", deg)
-        np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5, equal_nan=True)
+        for mode in ("griddata", "group"):
+            got = dqm.adjust(sim, detrend=deg, time=ta, grouped_nearest=mode)
+            exp = osdba.dqm_adjust_grouped(sim, ot, prop, labels, dqm.af, dqm.hist_q, dqm.scaling, kind, "constant", deg,
+                                           mode=mode if prop == "month" else "group")
+            np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5, equal_nan=True)
     first, last = np.nanmean(got[:365]), np.nanmean(got[-365:])
     assert 1.5 < last - first < 4.0                                     # the simulated trend survives the adjustment
     with pytest.raises(NotImplementedError):

@@ -115,6 +115,92 @@ k_eqm_adjust(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, co
   for (; t < tb; ++t) adjust_one(t, sim[t * st + c]);
 }
 
+// ---- adjust with a sub-grouping, interp = "nearest" the way xsdba does it ----------------------------------------------
+// xsdba.utils.interp_on_quantiles with a month / day-of-year Grouper does NOT interpolate inside the step's own group: it
+// calls _interp_on_quantiles_2D -> scipy.interpolate.griddata((hist_q, group coordinate), af, (sim, group of the step),
+// method="nearest") on the nodes of ALL groups (after add_cyclic_bounds: coordinates 0 .. G + 1, 0 = a copy of the last
+// group, G + 1 = a copy of the first), then _extrapolate_on_quantiles puts the step's OWN group's first / last factor
+// (or NaN) where the value lies outside that group's nodes.  The nearest point in the (value, group) plane is a node of
+// the own group unless that node is more than one unit away — then a neighbouring group's node at distance
+// sqrt(dx^2 + dg^2) can win (precipitation in mm/day, temperature tails).  Round 3 always took the own group's node.
+// One lane per cell over the rows of ONE group's block: the own nodes in registers, the neighbours' nodes read on demand
+// (group distance k while k^2 < the best squared distance so far); distances in float64 like the cKDTree's.
+template <int NQMAX>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_eqm_adjust_g2d(const float* __restrict__ sim, int64_t n, int64_t C, int64_t st, const float* __restrict__ af_all,
+                 const float* __restrict__ hq_all, int G, int nq, int gcoord, int kind, int extrap, float* __restrict__ scen,
+                 int64_t scen_st) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  const int64_t plane = (int64_t)nq * C;
+  const float* __restrict__ hq = hq_all + (int64_t)(gcoord - 1) * plane;
+  const float* __restrict__ af = af_all + (int64_t)(gcoord - 1) * plane;
+  float nx[NQMAX], ny[NQMAX];
+  float firstx = 0.f, firsty = xh_nan32(), lastx = 0.f, lasty = xh_nan32();
+  int m = 0;
+#pragma unroll
+  for (int j = 0; j < NQMAX; ++j) {
+    float xj = xh_nan32(), yj = xh_nan32();
+    if (j < nq) { xj = hq[(int64_t)j * C + c]; yj = af[(int64_t)j * C + c]; }
+    const bool valid = (xj == xj) && (yj == yj);
+    nx[j] = valid ? xj : xh_nan32();
+    ny[j] = yj;
+    // utils._first_and_last_nonnull works on hist_q and on af SEPARATELY: the bounds are the first / last non-null node
+    // VALUE, the constants the first / last non-null FACTOR (a 0 / 0 factor at a dry node does not move the bound)
+    if (xj == xj) {
+      if (m == 0) firstx = xj;
+      lastx = xj;
+      m++;
+    }
+    if (yj == yj) {
+      if (firsty != firsty) firsty = yj;
+      lasty = yj;
+    }
+  }
+  const int64_t chunk = cdiv64(n, (int64_t)gridDim.y);
+  const int64_t ta = (int64_t)blockIdx.y * chunk;
+  int64_t tb = ta + chunk;
+  if (tb > n) tb = n;
+  for (int64_t t = ta; t < tb; ++t) {
+    const float x = sim[t * st + c];
+    float a = xh_nan32();
+    if (x == x) {
+      const double xd = (double)x;
+      double best = __longlong_as_double(0x7FF0000000000000LL);  // +inf
+#pragma unroll
+      for (int j = 0; j < NQMAX; ++j) {
+        const double dx = xd - (double)nx[j];
+        const double d2 = dx * dx;  // (NaN node: the compare is false)
+        if (d2 < best) { best = d2; a = ny[j]; }
+      }
+      for (int k = 1; (double)k * (double)k < best && k <= G + 1; ++k) {
+#pragma unroll 1
+        for (int sgn = -1; sgn <= 1; sgn += 2) {
+          const int gg = gcoord + sgn * k;  // coordinate 0 .. G + 1 (cyclic copies at the ends)
+          if (gg < 0 || gg > G + 1) continue;
+          const int ti = gg == 0 ? G - 1 : (gg == G + 1 ? 0 : gg - 1);
+          const float* __restrict__ hx = hq_all + (int64_t)ti * plane + c;
+          const float* __restrict__ hy = af_all + (int64_t)ti * plane + c;
+          for (int j = 0; j < nq; ++j) {
+            const float xj = hx[(int64_t)j * C], yj = hy[(int64_t)j * C];
+            if (xj == xj && yj == yj) {
+              const double dx = xd - (double)xj;
+              const double d2 = dx * dx + (double)k * (double)k;
+              if (d2 < best) { best = d2; a = yj; }
+            }
+          }
+        }
+      }
+      // _extrapolate_on_quantiles: outside the OWN group's nodes -> its first / last factor, or NaN
+      if (m > 0) {
+        if (x < firstx) a = extrap == 0 ? firsty : xh_nan32();
+        if (x > lastx) a = extrap == 0 ? lasty : xh_nan32();
+      }
+    }
+    scen[t * scen_st + c] = kind == 0 ? (x + a) : (kind == 1 ? (x * a) : a);
+  }
+}
+
 // ---- adjust, interp = "cubic" ----------------------------------------------------------------------------------
 // scipy.interpolate.interp1d(kind="cubic") = interpolating cubic spline with not-a-knot end conditions
 // (make_interp_spline(k=3)).  Restated in its classical form: second derivatives M_i from the tridiagonal system
@@ -349,6 +435,33 @@ int xh_eqm_train(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, in
   int64_t n = (int64_t)nq * C;
   hipLaunchKernelGGL(k_correction, dim3((unsigned)cdiv64(n, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, af, hist_q, n, kind,
                      af);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+// Grouped adjustment with xsdba's 2-D "nearest" (see k_eqm_adjust_g2d): sim (n, C) = the steps of ONE group (coordinate
+// gcoord in 1 .. G, the g-th label of a contiguous month / day-of-year grouping), af_all / hq_all (G, nq, C).
+int xh_eqm_adjust_g2d(xh_ctx* ctx, const float* sim, int64_t n, int64_t C, int64_t st, const float* af_all, const float* hq_all,
+                      int G, int nq, int gcoord, int kind, int extrap, float* scen, int64_t scen_st) {
+  XH_REQUIRE(ctx && sim && af_all && hq_all && scen, XH_ERR_ARG, "xh_eqm_adjust_g2d: NULL argument");
+  XH_REQUIRE(n >= 0 && C >= 0 && nq >= 1 && nq <= 32 && G >= 1 && gcoord >= 1 && gcoord <= G, XH_ERR_ARG,
+             "xh_eqm_adjust_g2d: bad shape (1 <= nq <= 32, 1 <= gcoord <= G)");
+  XH_REQUIRE(st >= C && scen_st >= C, XH_ERR_LAYOUT, "xh_eqm_adjust_g2d: needs time-major views");
+  XH_REQUIRE(kind >= 0 && kind <= 2, XH_ERR_ARG, "xh_eqm_adjust_g2d: kind must be 0 (+), 1 (*) or 2 (the factor only)");
+  XH_REQUIRE(extrap == 0 || extrap == 1, XH_ERR_ARG, "xh_eqm_adjust_g2d: extrap must be 0 (constant) or 1 (nan)");
+  if (n == 0 || C == 0) return XH_OK;
+  const int64_t cblocks = cdiv64(C, XH_BLOCK);
+  int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
+  if (gy < 1) gy = 1;
+  if (gy > n) gy = n;
+  if (gy > 1024) gy = 1024;
+  const dim3 grid((unsigned)cblocks, (unsigned)gy);
+  if (nq <= 20)
+    hipLaunchKernelGGL((k_eqm_adjust_g2d<20>), grid, dim3(XH_BLOCK), 0, ctx->stream, sim, n, C, st, af_all, hq_all, G, nq, gcoord, kind,
+                       extrap, scen, scen_st);
+  else
+    hipLaunchKernelGGL((k_eqm_adjust_g2d<32>), grid, dim3(XH_BLOCK), 0, ctx->stream, sim, n, C, st, af_all, hq_all, G, nq, gcoord, kind,
+                       extrap, scen, scen_st);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

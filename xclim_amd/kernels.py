@@ -679,3 +679,15 @@ def adapt_freq(dev: Device, sim: DeviceArray, p0_ref, p0_sim, dp0, pth, thresh: 
     dev.call("xh_adapt_freq", _vp(sim.ptr), T, C_, C_, 1, _vp(pr.ptr), _vp(ps.ptr), _vp(dp.ptr), _vp(pt.ptr), float(thresh),
              int(seed) & 0xFFFFFFFFFFFFFFFF, _vp(ti.ptr) if ti is not None else None, int(cell0), _vp(scen.ptr))
     return scen
+
+
+def eqm_adjust_g2d(dev: Device, sim: DeviceArray, af_all: DeviceArray, hq_all: DeviceArray, gcoord: int, kind="+",
+                   extrapolation="constant", out: DeviceArray | None = None) -> DeviceArray:
+    """xh_eqm_adjust_g2d: the rows of ONE group (coordinate `gcoord` in 1 .. G) adjusted with xsdba's 2-D "nearest" over the
+    nodes of all groups; af_all / hq_all (G, nq, C)."""
+    n, C_ = _tc(sim)
+    G, nq = int(af_all.shape[0]), int(af_all.shape[1])
+    scen = out if out is not None else dev.empty((n, C_), np.float32)
+    dev.call("xh_eqm_adjust_g2d", _vp(sim.ptr), n, C_, C_, _vp(af_all.ptr), _vp(hq_all.ptr), G, nq, int(gcoord),
+             {"+": 0, "*": 1, "factor": 2}[kind], {"constant": 0, "nan": 1}[extrapolation], _vp(scen.ptr), C_)
+    return scen

@@ -15,10 +15,11 @@ launch per group on a contiguous row block, one gather back).  With a sub-groupi
 for "linear" / "cubic" xsdba interpolates over the (quantile, group) PLANE (``utils.interp_on_quantiles`` ->
 ``_interp_on_quantiles_2D``: ``scipy.interpolate.griddata`` with a fractional group index), which is not built — an
 interpolation along the quantile axis inside each group would silently differ from it and jump at the group boundaries,
-so those calls raise ``NotImplementedError`` (:func:`_check_group_interp`).  Caveat for "nearest": xsdba's grouped
-"nearest" is ``griddata(method="nearest")`` in the same plane, i.e. the nearest (hist_q, group-index) point in EUCLIDEAN
-distance — where the nodes of a group lie more than one unit apart a node of the NEIGHBOURING group can win; here every
-time step always uses the nearest node of its own group.
+so those calls raise ``NotImplementedError`` (:func:`_check_group_interp`).  "nearest" with a month / day-of-year grouping
+follows xsdba since round 4: ``griddata(method="nearest")`` in the (hist_q, group coordinate) plane over the nodes of ALL
+groups — where the own group's nearest node is more than one unit away a node of a NEIGHBOURING group can win — and the
+own group's end factors outside its nodes (``xh_eqm_adjust_g2d``; ``grouped_nearest="group"`` restores the own-group rule of
+rounds 2-3, which "time.season" still uses).
 
 :class:`QuantileDeltaMapping` (``group="time"``): trained like EQM; ``adjust`` looks the factor up at the QUANTILE of every
 sim value within the sim series itself (``rank(sim, pct=True)``), so that the simulated change of every quantile is
@@ -251,9 +252,17 @@ class EmpiricalQuantileMapping:
         dev.sync()
         return cls(dev, af, hq, q, kind, cell_shape, grp, labels)
 
-    def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", time=None, keep=False):
+    def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", time=None, keep=False,
+               grouped_nearest: str = "griddata"):
+        """``grouped_nearest`` (sub-groupings only): "griddata" (default) = what xsdba does — the nearest node in the (hist_q,
+        group) PLANE over the nodes of all groups (``_interp_on_quantiles_2D``: a neighbouring group's node wins where the own
+        group's nearest node is more than one unit away), own-group factors outside the own group's nodes; "group" = always
+        the nearest node of the step's own group (rounds 2-3).  "time.season" and groupings whose labels are not 1 .. G take
+        "group" (upstream's season coordinate is not restated)."""
         if interp not in ("nearest", "linear", "cubic"):
             raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
+        if grouped_nearest not in ("griddata", "group"):
+            raise ValueError("grouped_nearest must be 'griddata' or 'group'")
         _check_group_interp(self.group, interp, "EmpiricalQuantileMapping.adjust")
         s, cell_shape = _flatten(sim, self._dev)
         if tuple(cell_shape) != self.cell_shape:
@@ -274,21 +283,32 @@ class EmpiricalQuantileMapping:
         nq = len(self.quantiles)
         s_perm = K.select_rows(dev, s, perm)
         scen_perm = dev.empty((T, C_), np.float32)
+        plane2d = self._plane_nearest(grouped_nearest)
         off = 0
         for g, n in enumerate(counts):
             if n == 0:
                 continue
             blk = dev.wrap(s_perm.ptr + off * C_ * 4, (int(n), C_), np.float32)
             out = dev.wrap(scen_perm.ptr + off * C_ * 4, (int(n), C_), np.float32)
-            af_g = dev.wrap(self._af.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
-            hq_g = dev.wrap(self._hist_q.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
-            K.eqm_adjust(dev, blk, af_g, hq_g, self.kind, interp, extrapolation, out=out)
+            if plane2d:
+                K.eqm_adjust_g2d(dev, blk, self._af, self._hist_q, g + 1, self.kind, extrapolation, out=out)
+            else:
+                af_g = dev.wrap(self._af.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
+                hq_g = dev.wrap(self._hist_q.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
+                K.eqm_adjust(dev, blk, af_g, hq_g, self.kind, interp, extrapolation, out=out)
             off += int(n)
         inv = np.empty(T, dtype=np.int64)
         inv[perm] = np.arange(T)
         scen = K.select_rows(dev, scen_perm, inv)
         dev.sync()
         return scen if keep else scen.get().reshape((T,) + self.cell_shape)
+
+    def _plane_nearest(self, grouped_nearest: str) -> bool:
+        """xsdba's 2-D nearest applies: a month / day-of-year grouping whose labels are 1 .. G (the coordinates upstream's
+        add_cyclic_bounds extends to 0 and G + 1) and at most 32 nodes."""
+        lab = self.group_labels
+        return (grouped_nearest == "griddata" and self.group.prop in ("month", "dayofyear") and len(self.quantiles) <= 32
+                and np.array_equal(lab, np.arange(1, len(lab) + 1)))
 
     def _shape(self):
         lead = (len(self.quantiles),) if self.group.prop == "group" else (len(self.group_labels), len(self.quantiles))
@@ -419,7 +439,8 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         lead = () if self.group.prop == "group" else (len(self.group_labels),)
         return self._scaling.get().reshape(lead + self.cell_shape)
 
-    def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", detrend: int = 1, time=None, keep=False):
+    def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", detrend: int = 1, time=None, keep=False,
+               grouped_nearest: str = "griddata"):
         if interp not in ("nearest", "linear", "cubic"):
             raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
         if detrend not in (0, 1):
@@ -430,7 +451,7 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             raise ValueError("sim does not match the trained grid")
         fwd, inv = ("+", "-") if self.kind == ADDITIVE else ("*", "/")
         if self.group.prop != "group":
-            return self._adjust_grouped(s, interp, extrapolation, detrend, time, keep, fwd, inv)
+            return self._adjust_grouped(s, interp, extrapolation, detrend, time, keep, fwd, inv, grouped_nearest)
         scaled = K.trend_apply(dev, s, self._scaling, None, fwd)
         p0, p1 = K.poly_trend(dev, scaled, detrend)
         detr = K.trend_apply(dev, scaled, p0, p1, inv)
@@ -439,7 +460,7 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         scen = K.trend_apply(dev, scen0, p0, p1, fwd, out=detr)  # (distinct buffers: the kernels' pointers are __restrict__)
         return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
 
-    def _adjust_grouped(self, s, interp, extrapolation, detrend, time, keep, fwd, inv):
+    def _adjust_grouped(self, s, interp, extrapolation, detrend, time, keep, fwd, inv, grouped_nearest="griddata"):
         """dqm_adjust with a sub-grouping (window 1): group-major row blocks like the grouped EQM; per block the group's
         scaling (``u.broadcast``), the trend fitted over the group's OWN steps on their time coordinate (days since the
         group's mean date: ``PolyDetrend(group=...)`` -> polyfit along time), the group's nodes, the trend put back."""
@@ -472,7 +493,10 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             scaled = K.trend_apply(dev, blk, sc_g, None, fwd)
             p0, p1 = K.poly_trend(dev, scaled, detrend, u=u)
             detr = K.trend_apply(dev, scaled, p0, p1, inv, u=u)
-            scen0 = K.eqm_adjust(dev, detr, af_g, hq_g, self.kind, interp, extrapolation)
+            if self._plane_nearest(grouped_nearest):
+                scen0 = K.eqm_adjust_g2d(dev, detr, self._af, self._hist_q, g + 1, self.kind, extrapolation)
+            else:
+                scen0 = K.eqm_adjust(dev, detr, af_g, hq_g, self.kind, interp, extrapolation)
             K.trend_apply(dev, scen0, p0, p1, fwd, out=out, u=u)
             off += n
         inv_perm = np.empty(T, dtype=np.int64)
