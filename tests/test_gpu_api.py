@@ -1320,6 +1320,27 @@ def test_dqm_grouped_matches_oracle(dev, rng, kind, group):
         dqm.adjust(sim, interp="linear", time=ta)
 
 
+@pytest.mark.parametrize("T", [1, 2, 700, 40000])
+def test_quantile_cells_per_cell_probabilities(dev, rng, T):
+    """xh_quantile_cells = xsdba.nbutils.vecquantiles: one quantile per cell at its own probability; NaN probabilities
+    (also with a single valid sample: found by tools/fuzz_r04.py), 0 and 1, all-NaN cells, both layouts."""
+    from xclim_amd import kernels as K
+
+    C = 37
+    x = rng.normal(5, 3, (T, C)).astype(np.float32)
+    x[rng.random((T, C)) < 0.05] = np.nan
+    x[:, 2] = np.nan
+    qc = rng.random(C)
+    qc[[0, 5]], qc[7], qc[8] = np.nan, 0.0, 1.0
+    with np.errstate(all="ignore"):
+        exp = np.array([np.nanquantile(x[:, c].astype(np.float64), qc[c]) if qc[c] == qc[c] and not np.isnan(x[:, c]).all() else np.nan
+                        for c in range(C)])
+    got = K.quantile_cells(dev, dev.to_device(x), qc).get()
+    np.testing.assert_allclose(got, exp, rtol=1e-6, equal_nan=True)
+    got_t = K.quantile_cells(dev, dev.to_device(np.ascontiguousarray(x.T)), qc, time_axis=1).get()
+    np.testing.assert_array_equal(got_t, got)
+
+
 def _pr_field(rng, T, C, p_dry, scale):
     x = rng.gamma(0.7, scale, (T, C)).astype(np.float32)
     x[rng.random((T, C)) < p_dry] = 0.0

@@ -296,7 +296,9 @@ int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   void* d_q = nullptr;
   int rc = xh_scratch_upload(ctx, &cur, q, sizeof(double) * nq, &d_q);
   if (rc) return rc;
-  const bool longs = T > 32768;  // beyond the exact-rank kernel's LDS list: ranks through a global sort (qdm3.hip), in batches
+  // beyond the exact-rank kernel's LDS list: ranks through a global sort (qdm3.hip), in batches (diagnostics:
+  // XH_QDM_FORCE_SORTED sends every length there — the differential test against the exact-rank kernel)
+  const bool longs = T > 32768 || xh_diag_env("XH_QDM_FORCE_SORTED") != nullptr;
   if (st == 1 && sc >= T) {  // time-minor: columns in place, scen in the same layout
     if (!longs) return xh_qdm_columns(ctx, sim, T, C, sc, af, C, (const double*)d_q, nq, kind, interp, extrap, scen, sc);
     int64_t chunk = (1ll << 27) / T;
@@ -316,7 +318,7 @@ int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   }
   XH_REQUIRE(sc == 1 && st >= C, XH_ERR_LAYOUT, "xh_qdm_adjust: one of the strides must be 1 (st=%lld sc=%lld)", (long long)st,
              (long long)sc);
-  if (interp == 0) {  // one-year series, nearest: sort in registers + classify by cut values, in place (qdm2.hip)
+  if (interp == 0 && !longs) {  // one-year series, nearest: sort in registers + classify by cut values, in place (qdm2.hip)
     rc = xh_qdm_regsort(ctx, sim, T, C, st, af, C, (const double*)d_q, nq, kind, extrap, scen, st);
     if (rc != XH_ERR_NOTIMPL) return rc;
   }

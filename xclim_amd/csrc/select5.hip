@@ -128,13 +128,13 @@ k_radix_select(const float* __restrict__ xcols, int64_t T, int64_t ncols, int64_
         const uint32_t n = s_misc[0];
         const float left = xh_key2f(t_key[2 * tid]), right = xh_key2f(t_key[2 * tid + 1]);
         double r;
-        if (n == 0u) r = xh_nan64();
+        const double qq = qcol ? qcol[c] : qs[q0 + tid];
+        if (n == 0u || qq != qq) r = xh_nan64();  // (a NaN probability: vecquantiles of a cell without valid sim samples)
         else if (n < 2u) r = (double)left;
         else {
-          const double nn = (double)n, qq = qcol ? qcol[c] : qs[q0 + tid];
+          const double nn = (double)n;
           const double vi = nn * qq + (1.0 + qq * (1.0 - 1.0 - 1.0)) - 1.0;
-          if (qq != qq) r = xh_nan64();  // (a NaN probability: vecquantiles of a cell without valid sim samples)
-          else if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
+          if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
           else {
             const double gamma = vi - floor(vi);
             const float diff = right - left;
