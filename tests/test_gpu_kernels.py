@@ -367,6 +367,44 @@ def test_percentile_doy_merge_path(dev, rng, nyears, window, calendar, nan_frac)
     np.testing.assert_allclose(out, np.moveaxis(exp, -1, 0), rtol=1e-12, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("nyears,calendar,per,nan_frac", [(30, "noleap", 90.0, 0.0), (30, "noleap", 10.0, 0.0), (30, "standard", 90.0, 0.0),
+                                                         (7, "noleap", 90.0, 0.0), (7, "noleap", 5.0, 0.0), (33, "noleap", 95.0, 0.0),
+                                                         (30, "noleap", 90.0, 0.02), (31, "standard", 10.0, 0.3), (12, "noleap", 99.0, 0.0)])
+def test_percentile_doy_quad_kernel(dev, rng, monkeypatch, nyears, calendar, per, nan_frac):
+    """One percentile on a window of 5 over a multi-year base period = k_pdoy_quad's fast path (pdoy_quad.hip: quad sharing,
+    NaN-free day-sets skip the conversion, padding / absent days read from constant rows): against the oracle, and
+    bit-identical to k_pdoy_top16 (XH_PDOY_QUAD=0), on a column count that is no multiple of 64, with the special values."""
+    C, window = 150, 5
+    T = 365 * nyears + (nyears + 3) // 4 if calendar == "standard" else 365 * nyears
+    x = _field(rng, T, C, nan_frac=nan_frac)
+    x[:, 0] = np.nan           # a cell without data
+    x[:, 1] = 280.0            # ties everywhere
+    x[::7, 2] = np.inf         # infinities of both signs in one day-set window
+    x[3::11, 2] = -np.inf
+    x[: 365 * 2, 3] = np.nan   # two years missing: another valid count than the neighbours
+    x[100:160, 4] = np.nan     # a gap in one year
+    x[:, 5] = -x[:, 6]
+    ta, ot = _times("2000-01-01", T, calendar)
+    tb, years, doys = ta.doy_table()
+    d_x = dev.to_device(x)
+    out = K.percentile_doy(dev, d_x, tb, window, [per]).get()
+    rr = ocal.rolling_construct_center(x, window)  # (the kernel's table has no 366 -> 365 adjustment: stacked calc_perc)
+    stack = np.full((len(doys), len(years), C, window), np.nan, dtype=np.float32)
+    stack[np.searchsorted(doys, ot.doy), np.searchsorted(years, ot.year)] = rr
+    stack = np.moveaxis(stack, 1, -2).reshape(len(doys), C, len(years) * window)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = oq.calc_perc(stack, [per], 1 / 3, 1 / 3)
+    np.testing.assert_allclose(out, np.moveaxis(exp, -1, 0), rtol=1e-12, atol=0, equal_nan=True)
+    monkeypatch.setenv("XH_DIAGNOSTICS", "1")
+    monkeypatch.setenv("XH_PDOY_QUAD", "0")
+    ref = K.percentile_doy(dev, d_x, tb, window, [per]).get()
+    np.testing.assert_array_equal(out, ref)
+    monkeypatch.setenv("XH_PDOY_QUAD", "1")
+    monkeypatch.setenv("XH_PDOY_CHUNK", "10")  # other chunk boundaries, same numbers
+    np.testing.assert_array_equal(K.percentile_doy(dev, d_x, tb, window, [per]).get(), out)
+
+
 @pytest.mark.parametrize("nyears", [4, 12])
 def test_percentile_doy_virtual_time_map(dev, rng, nyears):
     """vmap: percentile_doy of a series in which one year was replaced by another, without copying the data."""

@@ -30,6 +30,11 @@ struct xh_ctx {
   // large scratch (transposes), grown on demand
   void* big;
   size_t big_bytes;
+  // three constant rows (NaN | -inf | +inf), grown on demand and never written afterwards: the gather kernels of
+  // pdoy_top.hip / pdoy_quad.hip read absent days and padding slots from them, which keeps the mask arithmetic out of
+  // their loops (xh_const_rows)
+  void* nanrow;
+  size_t nanrow_bytes;  // of ONE row
   int num_cu;
 };
 
@@ -70,6 +75,8 @@ const char* xh_diag_env(const char* name);
 // Upload a small host table into the context scratch (bump allocated per call via `*cursor`).
 int xh_scratch_upload(xh_ctx* ctx, size_t* cursor, const void* host, size_t bytes, void** dptr);
 int xh_big_scratch(xh_ctx* ctx, size_t bytes, void** dptr);
+// >= elems floats each of NaN, -inf, +inf (persistent; any of the three pointers may be NULL)
+int xh_const_rows(xh_ctx* ctx, int64_t elems, const float** nan_row, const float** ninf_row, const float** pinf_row);
 // tcount.hip: XH_OK launched, XH_ERR_NOTIMPL (no error text) = outside the tile kernel's domain
 int xh_launch_tcount_doy(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int op, const double* table,
                          int64_t tstride, const int32_t* tidx, const int64_t* d_seg, const int64_t* h_seg, int P, int ndoy,

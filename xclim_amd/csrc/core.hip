@@ -96,6 +96,7 @@ int xh_destroy(xh_ctx* ctx) {
     (void)hipHostFree(ctx->retired_host[i]);
   }
   if (ctx->big) (void)hipFree(ctx->big);
+  if (ctx->nanrow) (void)hipFree(ctx->nanrow);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   (void)hipStreamSynchronize(ctx->stream2);
@@ -307,6 +308,27 @@ int xh_big_scratch(xh_ctx* ctx, size_t bytes, void** dptr) {
     ctx->big_bytes = bytes;
   }
   *dptr = ctx->big;
+  return XH_OK;
+}
+
+int xh_const_rows(xh_ctx* ctx, int64_t elems, const float** nan_row, const float** ninf_row, const float** pinf_row) {
+  const size_t bytes = ((size_t)elems * sizeof(float) + 255) & ~(size_t)255;
+  if (bytes > ctx->nanrow_bytes) {
+    XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // (a kernel in flight may still read the old rows)
+    if (ctx->nanrow) XH_CHECK_HIP(hipFree(ctx->nanrow));
+    ctx->nanrow = nullptr;
+    ctx->nanrow_bytes = 0;
+    XH_CHECK_HIP(hipMalloc(&ctx->nanrow, 3 * bytes));
+    ctx->nanrow_bytes = bytes;
+    char* p = (char*)ctx->nanrow;
+    XH_CHECK_HIP(hipMemsetAsync(p, 0xFF, bytes, ctx->stream));  // 0xFFFFFFFF is a NaN
+    XH_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(p + bytes), (int)0xFF800000u, bytes / 4, ctx->stream));
+    XH_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(p + 2 * bytes), (int)0x7F800000u, bytes / 4, ctx->stream));
+  }
+  const char* p = (const char*)ctx->nanrow;
+  if (nan_row) *nan_row = (const float*)p;
+  if (ninf_row) *ninf_row = (const float*)(p + ctx->nanrow_bytes);
+  if (pinf_row) *pinf_row = (const float*)(p + 2 * ctx->nanrow_bytes);
   return XH_OK;
 }
 

@@ -3,6 +3,7 @@
 
 #include "f32thr.h"
 #include "pdoy.h"
+#include "topnet.h"
 
 // ---- multi-year path, register variant: top-16 of the W day-sets by bitonic half-merges ---------------------
 // For high (or, mirrored, low) percentiles only the 16 largest samples of a doy can be selected (e.g. per = 90 over
@@ -15,126 +16,63 @@
 // W/2 + 1 merges per doy instead of W - 1 (W = 5: 3 instead of 4) in the same W x 16 registers.  The last of them need not
 // re-sort when the wave's ranks are the two lowest of the top 16 (per = 90 of 150 samples: ranks 134 / 135 = positions
 // 15 / 14): the two smallest of the bitonic C take 16 comparators instead of 32 compare-exchanges.
-// rev mirrors the key order so that the same code serves low percentiles (bottom-16).  Valid keys are never 0.
-__device__ __forceinline__ void ce_desc(uint32_t& a, uint32_t& b) {
-  uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
-  a = hi;
-  b = lo;
-}
-
-template <int NP>
-__device__ __forceinline__ void bitonic_desc(uint32_t (&k)[NP]) {  // full sort, descending
-#pragma unroll
-  for (int size = 2; size <= NP; size <<= 1) {
-#pragma unroll
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-#pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        int j = i ^ stride;
-        if (j > i) {
-          bool desc = ((i & size) == 0);
-          uint32_t a = k[i], b = k[j];
-          uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
-          k[i] = desc ? hi : lo;
-          k[j] = desc ? lo : hi;
-        }
-      }
-    }
-  }
-}
-
-// 16 keys sorted descending with the 60-comparator, 10-layer optimal network (verified exhaustively with the 0-1
-// principle; the bitonic sorter needs 80)
-__device__ __forceinline__ void sort16_desc(uint32_t (&k)[16]) {
-#define XH_C(i, j) ce_desc(k[i], k[j]);
-  XH_C(0, 13) XH_C(1, 12) XH_C(2, 15) XH_C(3, 14) XH_C(4, 8) XH_C(5, 6) XH_C(7, 11) XH_C(9, 10)
-  XH_C(0, 5) XH_C(1, 7) XH_C(2, 9) XH_C(3, 4) XH_C(6, 13) XH_C(8, 14) XH_C(10, 15) XH_C(11, 12)
-  XH_C(0, 1) XH_C(2, 3) XH_C(4, 5) XH_C(6, 8) XH_C(7, 9) XH_C(10, 11) XH_C(12, 13) XH_C(14, 15)
-  XH_C(0, 2) XH_C(1, 3) XH_C(4, 10) XH_C(5, 11) XH_C(6, 7) XH_C(8, 9) XH_C(12, 14) XH_C(13, 15)
-  XH_C(1, 2) XH_C(3, 12) XH_C(4, 6) XH_C(5, 7) XH_C(8, 10) XH_C(9, 11) XH_C(13, 14)
-  XH_C(1, 4) XH_C(2, 6) XH_C(5, 8) XH_C(7, 10) XH_C(9, 13) XH_C(11, 14)
-  XH_C(2, 4) XH_C(3, 6) XH_C(9, 12) XH_C(11, 13)
-  XH_C(3, 5) XH_C(6, 8) XH_C(7, 9) XH_C(10, 12)
-  XH_C(3, 4) XH_C(5, 6) XH_C(7, 8) XH_C(9, 10) XH_C(11, 12)
-  XH_C(6, 7) XH_C(8, 9)
-#undef XH_C
-}
-
-// t <- the 16 largest of (t u b), sorted descending; t and b sorted descending
-__device__ __forceinline__ void merge_top16(uint32_t (&t)[16], const uint32_t (&b)[16]) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) t[i] = t[i] > b[15 - i] ? t[i] : b[15 - i];
-#pragma unroll
-  for (int stride = 8; stride > 0; stride >>= 1) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if ((i & stride) == 0) ce_desc(t[i], t[i + stride]);
-  }
-}
-
-// the two smallest of the 16 largest of (t u b): lo16 = 16th largest, hi15 = 15th largest of the union (t, b sorted descending).
-// max(t[i], b[15 - i]) is bitonic; the lower half of a half-cleaner holds the smaller half and is bitonic again.
-__device__ __forceinline__ void merge_low2(const uint32_t (&t)[16], const uint32_t (&b)[16], uint32_t& lo16, uint32_t& hi15) {
-  uint32_t c[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) c[i] = t[i] > b[15 - i] ? t[i] : b[15 - i];
-#pragma unroll
-  for (int n = 8; n >= 2; n >>= 1) {
-#pragma unroll
-    for (int i = 0; i < n; ++i) c[i] = c[i] < c[i + n] ? c[i] : c[i + n];
-  }
-  lo16 = c[0] < c[1] ? c[0] : c[1];
-  hi15 = c[0] < c[1] ? c[1] : c[0];
-}
+// REV selects within the 16 SMALLEST instead (low percentiles): the same networks with v_max / v_min swapped (topnet.h).
+// Round 4: the networks run on the FLOATS themselves, NaN and absent days mapped to the innermost value (-inf / +inf) and
+// counted: 3 VALU instructions per sample (compare, select, add-with-carry) instead of the ~11 of the ordered-integer key
+// (sign test, two bit operations, select, NaN test, select, validity test, count, mirror, mask), which was a third of the
+// kernel's instructions.  An infinity that stands for a NaN and a sample that IS that infinity are the same value, and only
+// the positions below the valid count are ever read.
 
 // COUNT = true (xh_percentile_doy_count on a multi-year base period): the percentile of doy d is compared with the
 // samples of day d of EVERY year and the exceedances are counted per (year, doy) -> period; the (D, C) fp64 table of the
 // unfused chain is neither written nor re-read once per year.  One percentile (nsub == 1), regular doys only.
-template <int W, int NYP, bool COUNT = false>
+template <int W, int NYP, bool COUNT = false, bool REV = false>
 __global__ void __launch_bounds__(64, (COUNT || W > 5 || NYP > 32) ? 2 : 3)
 k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ tbase, int nyears,
              int ndoy, int chunk, const QTab* __restrict__ qtab, const int32_t* __restrict__ jmap, int nsub,
              double* __restrict__ out, const int32_t* __restrict__ vmap, int64_t Tv, const uint8_t* __restrict__ regular,
-             int rev, int op = 0, const int32_t* __restrict__ yd_period = nullptr, int32_t* __restrict__ cnt_out = nullptr,
-             int32_t* __restrict__ valid_out = nullptr, const uint8_t* __restrict__ newseg = nullptr) {
-  const uint32_t rmask = rev ? 0xFFFFFFFFu : 0u;  // mirrored key order for the bottom-16 case
+             const float* __restrict__ nanrow, int op = 0, const int32_t* __restrict__ yd_period = nullptr,
+             int32_t* __restrict__ cnt_out = nullptr, int32_t* __restrict__ valid_out = nullptr,
+             const uint8_t* __restrict__ newseg = nullptr) {
+  constexpr bool rev = REV;
+  float SENT = tn_sentinel<REV>();
+  asm volatile("" : "+v"(SENT));  // one VGPR, not a literal per use
   const int lane = threadIdx.x;
   int64_t c = (int64_t)blockIdx.x * 64 + lane;
   const bool active = c < C;
   constexpr int half = W / 2;
   constexpr bool FASTSEL = !COUNT;
   const int N = nyears * W;
-  uint32_t pr[W - 1][16];  // pr[k]: pair of the day-sets of doys d - half + k and d - half + k + 1
-  uint32_t last[16];       // day-set of doy d + half
+  float pr[W - 1][16];  // pr[k]: pair of the day-sets of doys d - half + k and d - half + k + 1
+  float last[16];       // day-set of doy d + half
   int cnt[W];              // valid samples of the day-sets d - half .. d + half
   float raw[NYP];
 
   const int64_t cc_ = active ? c : C - 1;  // inactive lanes read a valid cell and never store
   auto rows_of = [&](int dn, int off) { return pdoy_row(lane, nyears, ndoy, dn, off, tbase, vmap, Tv, T); };
-  auto gather = [&](int rowv) { pdoy_gather<NYP>(raw, rowv, x, st, cc_); };
-  // sort the gathered day-set and return its top 16 (in the possibly mirrored order) + valid count
-  auto finish = [&](uint32_t (&top)[16], int& nv) {
-    uint32_t key[NYP];
-    nv = 0;
+  auto gather = [&](int rowv) { pdoy_gather<NYP, true>(raw, rowv, x, st, cc_, nanrow); };
+  // a gathered day-set -> values with NaN / absent day / padding mapped to the innermost value, + the valid count
+  auto convert = [&](float (&key)[NYP], int& nv) {
+    int nn = 0;
 #pragma unroll
     for (int y = 0; y < NYP; ++y) {
-      uint32_t kk = xh_f2key(raw[y]);
-      bool ok = kk != 0xFFFFFFFFu;
-      nv += ok ? 1 : 0;
-      key[y] = ok ? (kk ^ rmask) : 0u;  // NaN / padding -> 0 = smallest
+      tn_denan(key[y], nn, raw[y], SENT);
     }
-    // top 16 of the NYP keys: sort blocks of 16 with the optimal network, combine with half-merges
-    // (NYP = 32: 60 + 60 + 16 + 32 = 168 comparator-equivalents instead of 240 for a full bitonic-32)
-    uint32_t blk[16];
+    nv = NYP - nn;
+  };
+  // top 16 of the NYP values, sorted (in the possibly mirrored order): blocks of 16 through the optimal network, combined
+  // with half-merges (NYP = 32: 60 + 60 + 16 + 32 = 168 comparator-equivalents instead of 240 for a full bitonic-32)
+  auto sort_top = [&](const float (&key)[NYP], float (&top)[16]) {
+    float blk[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) top[i] = key[i];
-    sort16_desc(top);
+    tn_sort16<REV>(top);
 #pragma unroll
     for (int b = 1; b < NYP / 16; ++b) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) blk[i] = key[b * 16 + i];
-      sort16_desc(blk);
-      merge_top16(top, blk);
+      tn_sort16<REV>(blk);
+      tn_merge16<REV>(top, top, blk);
     }
   };
   // COUNT: one packed counter per year and lane (low half: exceedances, high half: valid days; a chunk has < 2^16 doys).
@@ -170,7 +108,7 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
     }
   };
   auto fetch_day = [&](int d) {  // samples of (year y, doy d) for the count of doy d
-    if constexpr (COUNT) pdoy_gather<NYP>(xv, rows_of(d, 0), x, st, cc_);
+    if constexpr (COUNT) pdoy_gather<NYP, true>(xv, rows_of(d, 0), x, st, cc_, nanrow);
   };
   auto stash_day = [&]() {  // registers -> LDS at the top of the step that uses them
     if constexpr (COUNT) {
@@ -195,12 +133,12 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
     }
   };
   auto select_and_store = [&](int d) {
-    uint32_t t16[16];
+    float t16[16];
     int n = cnt[0];
 #pragma unroll
     for (int i = 0; i < 16; ++i) t16[i] = pr[0][i];
 #pragma unroll
-    for (int k = 2; k <= W - 3; k += 2) merge_top16(t16, pr[k]);
+    for (int k = 2; k <= W - 3; k += 2) tn_merge16<REV>(t16, t16, pr[k]);
 #pragma unroll
     for (int w = 1; w < W; ++w) n += cnt[w];
     const bool all_valid = COUNT && __all(cnt[half] == nyears ? 1 : 0) != 0;
@@ -212,9 +150,9 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
         const QTab e = qtab[j * (N + 1) + n0];  // wave-uniform
         const int plo = rev ? e.lo : (n0 - 1 - e.lo), phi = rev ? e.hi : (n0 - 1 - e.hi);
         if (e.lo >= 0 && plo >= 14 && plo <= 15 && phi >= 14 && phi <= 15) {
-          uint32_t k16, k15;
-          merge_low2(t16, last, k16, k15);
-          const float left = xh_key2f((plo == 15 ? k16 : k15) ^ rmask), right = xh_key2f((phi == 15 ? k16 : k15) ^ rmask);
+          float k16, k15;
+          tn_last2<REV>(t16, last, k16, k15);
+          const float left = plo == 15 ? k16 : k15, right = phi == 15 ? k16 : k15;
           const float diff = right - left;
           double r = (double)left + (double)diff * e.gamma;
           if (e.gamma >= 0.5) r = (double)right - (double)diff * (1.0 - e.gamma);
@@ -226,17 +164,18 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
         }
       }
     }
-    merge_top16(t16, last);
+    tn_merge16<REV>(t16, t16, last);
     auto get = [&](int idx) -> float {
       uint32_t g = 0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) g |= (i == idx) ? t16[i] : 0u;
-      return xh_key2f(g ^ rmask);
+      for (int i = 0; i < 16; ++i) g |= (i == idx) ? __float_as_uint(t16[i]) : 0u;
+      return __uint_as_float(g);
     };
     for (int jj = 0; jj < nsub; ++jj) {
       const int j = jmap[jj];
       const QTab e = qtab[j * (N + 1) + n];
       double r = xh_nan64();
+      bool needmax = false;
       if (e.lo >= 0) {
         // position in the (mirrored) descending top-16: rev -> rank from the bottom, else rank from the top
         const int plo = rev ? e.lo : (n - 1 - e.lo), phi = rev ? e.hi : (n - 1 - e.hi);
@@ -244,7 +183,15 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
         float diff = right - left;
         r = (double)left + (double)diff * e.gamma;
         if (e.gamma >= 0.5) r = (double)right - (double)diff * (1.0 - e.gamma);
-        if (r != r && n > 0) r = (double)get(rev ? (n - 1 < 15 ? n - 1 : 15) : 0);  // +-inf: nanmax fallback (utl:552-554)
+        if (r != r && n > 0) {  // +-inf samples: nanmax fallback (utl:552-554)
+          if (!rev) r = (double)get(0);
+          else if (n <= 16) r = (double)get(n - 1);
+          else needmax = true;  // -inf at the selected ranks: the largest sample is not among the 16 smallest
+        }
+      }
+      if (rev && __any(needmax ? 1 : 0)) {
+        const float wm = pdoy_window_nanmax(d, W, lane, nyears, ndoy, tbase, vmap, Tv, T, x, st, cc_);
+        if (needmax) r = (double)wm;
       }
       if (COUNT) count_day(d, r, all_valid);
       else if (active) out[((int64_t)j * ndoy + d) * C + c] = r;
@@ -254,8 +201,14 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
   {
     int d0 = blockIdx.y * chunk, d1 = d0 + chunk;
     if (d1 > ndoy) d1 = ndoy;
-    // one step: the pairs move up, the old `last` starts the new pair, the gathered day-set becomes `last` and joins it
-    auto advance = [&]() {
+    // one step: the pairs move up, the old `last` starts the new pair, the gathered day-set becomes `last` and joins it.
+    // The next day-set is requested as soon as the registers of the current one are free (after the conversion, before
+    // the sorting networks), so that its loads are in flight for a whole step.  The table load behind the rows of the one
+    // after that is issued right AFTER the gather and consumed one step later: its s_waitcnt vmcnt(0) placed behind a fresh
+    // gather drained the 32 gather loads every step (first versions), placed before it cost a full round trip of its own.
+    int rows_next = 0, tbv = -1;  // tbv: table entry behind the rows of day-set d + 2 + half, fetched one step earlier
+    auto advance = [&](int d) {
+      float key[NYP];
 #pragma unroll
       for (int k = 0; k < W - 2; ++k) {
 #pragma unroll
@@ -265,40 +218,41 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
       for (int w = 0; w < W - 1; ++w) cnt[w] = cnt[w + 1];
 #pragma unroll
       for (int i = 0; i < 16; ++i) pr[W - 2][i] = last[i];
-      finish(last, cnt[W - 1]);
+      convert(key, cnt[W - 1]);
+      const int rows_nn = pdoy_row_finish(tbv, 0, vmap, Tv, T);
+      gather(rows_next);  // (one day-set beyond the chunk's last: a valid or the NaN row, never used)
+      rows_next = rows_nn;
+      tbv = pdoy_row_fetch(lane, nyears, ndoy, d + 3 + half, tbase);  // arrives behind the gather, used in the next step
+      sort_top(key, last);
     };
-    // prologue: the state of doy d0 - 1 = day-sets d0 - half .. d0 - 1 + half fed into an empty ring (pr[0] then holds an
-    // incomplete pair; it leaves with the first step)
+    // The ring starts empty W - 1 steps before the chunk: those warm-up steps feed the day-sets d0 - half .. d0 + half - 1
+    // (pr[0] then holds an incomplete pair; it leaves with the first live step) and select nothing.
 #pragma unroll
-    for (int i = 0; i < 16; ++i) last[i] = 0u;
+    for (int i = 0; i < 16; ++i) last[i] = SENT;
 #pragma unroll
     for (int k = 0; k < W - 1; ++k) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pr[k][i] = 0u;
+      for (int i = 0; i < 16; ++i) pr[k][i] = SENT;
     }
 #pragma unroll
     for (int w = 0; w < W; ++w) cnt[w] = 0;
-#pragma unroll
-    for (int w = 1; w < W; ++w) {
-      gather(rows_of(d0 - 1 - half + w, 0));
-      advance();
-      merge_top16(pr[W - 2], last);
-    }
-    gather(rows_of(d0 + half, 0));
-    int rows_next = rows_of(d0 + half + 1, 0);
-    fetch_day(d0);
-    for (int d = d0; d < d1; ++d) {
-      stash_day();
-      advance();
-      if (d + 1 < d1) {
-        gather(rows_next);
-        rows_next = rows_of(d + 2 + half, 0);
+    const int dstart = d0 - (W - 1);
+    gather(rows_of(dstart + half, 0));
+    rows_next = rows_of(dstart + half + 1, 0);
+    tbv = pdoy_row_fetch(lane, nyears, ndoy, dstart + half + 2, tbase);
+    auto step = [&](int d) {
+      const bool live = d >= d0;  // wave-uniform
+      if (live) stash_day();
+      advance(d);
+      tn_merge16<REV>(pr[W - 2], pr[W - 2], last);
+      if (live) {
+        if (COUNT && d > d0 && pdoy_flag(newseg, d)) flush_all(d - 1);
+        if (pdoy_flag(regular, d)) select_and_store(d);
       }
-      merge_top16(pr[W - 2], last);
-      if (COUNT && d > d0 && newseg[d]) flush_all(d - 1);
-      if (regular[d]) select_and_store(d);
-      if (COUNT && d + 1 < d1) fetch_day(d + 1);
-    }
+      if (COUNT && d + 1 >= d0 && d + 1 < d1) fetch_day(d + 1);
+    };
+    int d = dstart;
+    for (; d < d1; ++d) step(d);
     if (COUNT) flush_all(d1 - 1);
   }
 }
@@ -306,16 +260,30 @@ k_pdoy_top16(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, cons
 int xh_launch_pdoy_top16(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
                          int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int nsub, int rev, double* out,
                          const int32_t* d_vmap, int64_t Tv, const uint8_t* d_reg) {
-  const int chunk = 24;
+  {
+    const int rq = xh_launch_pdoy_quad(ctx, x, T, C, st, d_tb, nyears, ndoy, window, d_tab, d_jmap, nsub, rev, out, d_vmap, Tv, d_reg);
+    if (rq != XH_ERR_NOTIMPL) return rq;
+  }
+  XH_REQUIRE(C < ((int64_t)1 << 29), XH_ERR_LIMIT, "percentile_doy: more than 2^29 columns per call");
+  const float* nanrow = nullptr;
+  if (int rc = xh_const_rows(ctx, C, &nanrow, nullptr, nullptr)) return rc;
+  int chunk = 24;
+  if (const char* e = xh_diag_env("XH_PDOY_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : chunk;
   const dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
-#define XH_TOP16(W, NY)                                                                                                   \
-  hipLaunchKernelGGL((k_pdoy_top16<W, NY>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, d_tab,  \
-                     d_jmap, nsub, out, d_vmap, Tv, d_reg, rev)
+#define XH_TOP16_(W, NY, R)                                                                                                 \
+  hipLaunchKernelGGL((k_pdoy_top16<W, NY, false, R>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, \
+                     d_tab, d_jmap, nsub, out, d_vmap, Tv, d_reg, nanrow)
+#define XH_TOP16(W, NY)                \
+  do {                                 \
+    if (rev) XH_TOP16_(W, NY, true);   \
+    else XH_TOP16_(W, NY, false);      \
+  } while (0)
   if (nyears <= 32) {
     if (window == 3) XH_TOP16(3, 32); else if (window == 5) XH_TOP16(5, 32); else XH_TOP16(7, 32);
   } else {
     if (window == 3) XH_TOP16(3, 64); else if (window == 5) XH_TOP16(5, 64); else XH_TOP16(7, 64);
   }
+#undef XH_TOP16_
 #undef XH_TOP16
   XH_LAUNCH_CHECK();
   return XH_OK;
@@ -325,17 +293,26 @@ int xh_launch_pdoy_top16_count(xh_ctx* ctx, const float* x, int64_t T, int64_t C
                                int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int rev, const uint8_t* d_reg,
                                int op, const int32_t* d_period, int32_t* cnt_out, int32_t* valid_out,
                                const uint8_t* d_newseg) {
+  XH_REQUIRE(C < ((int64_t)1 << 29), XH_ERR_LIMIT, "percentile_doy_count: more than 2^29 columns per call");
+  const float* nanrow = nullptr;
+  if (int rc = xh_const_rows(ctx, C, &nanrow, nullptr, nullptr)) return rc;
   int chunk = 92;  // 4 chunks of a 365-day year (24 / 46 / 92 / 183 / 365: 26.3 / 25.1 / 24.6 / 24.5 / 24.7 ms at 30 yr x 1440 x 720)
   if (const char* e = xh_diag_env("XH_PDOY_COUNT_CHUNK")) chunk = atoi(e) > 0 ? atoi(e) : chunk;
   const dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
-#define XH_TOP16C(W, NY)                                                                                                       \
-  hipLaunchKernelGGL((k_pdoy_top16<W, NY, true>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, d_tab, \
-                     d_jmap, 1, (double*)nullptr, (const int32_t*)nullptr, T, d_reg, rev, op, d_period, cnt_out, valid_out, d_newseg)
+#define XH_TOP16C_(W, NY, R)                                                                                                     \
+  hipLaunchKernelGGL((k_pdoy_top16<W, NY, true, R>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, d_tab, \
+                     d_jmap, 1, (double*)nullptr, (const int32_t*)nullptr, T, d_reg, nanrow, op, d_period, cnt_out, valid_out, d_newseg)
+#define XH_TOP16C(W, NY)               \
+  do {                                 \
+    if (rev) XH_TOP16C_(W, NY, true);  \
+    else XH_TOP16C_(W, NY, false);     \
+  } while (0)
   if (nyears <= 32) {
     if (window == 3) XH_TOP16C(3, 32); else if (window == 5) XH_TOP16C(5, 32); else XH_TOP16C(7, 32);
   } else {
     if (window == 3) XH_TOP16C(3, 64); else if (window == 5) XH_TOP16C(5, 64); else XH_TOP16C(7, 64);
   }
+#undef XH_TOP16C_
 #undef XH_TOP16C
   XH_LAUNCH_CHECK();
   return XH_OK;
