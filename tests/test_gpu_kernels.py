@@ -405,6 +405,48 @@ def test_percentile_doy_quad_kernel(dev, rng, monkeypatch, nyears, calendar, per
     np.testing.assert_array_equal(K.percentile_doy(dev, d_x, tb, window, [per]).get(), out)
 
 
+def test_infinities_follow_the_nanmax_rule(dev, rng):
+    """utl:552-554: a NaN interpolation (inf - inf between two order statistics) becomes the slice's nanmax — in the one-shot
+    quantile (also where the virtual index is below 0 and both neighbours are slot 0), in the series quantiles of every
+    length class, and in the one-year percentile_doy kernel's minimum short-cut (found by tools/fuzz_inf.py)."""
+    def field(T, C):
+        x = np.round(rng.normal(10, 4, (T, C)), 1).astype(np.float32)
+        r = rng.random((T, C))
+        x[r < 0.02] = np.inf
+        x[(r >= 0.02) & (r < 0.04)] = -np.inf
+        x[:, 0] = np.inf
+        x[:, 1] = -np.inf
+        x[::2, 2], x[1::2, 2] = np.inf, -np.inf
+        x[: T // 2, 3] = -np.inf
+        x[:, 4] = np.nan
+        return x
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for n in (3, 17, 150):
+            x = field(n, 40)
+            q = np.array([0.01, 0.3, 0.5, 0.99])
+            for ab in ((1.0, 1.0), (1 / 3, 1 / 3)):
+                np.testing.assert_allclose(K.nan_quantile(dev, dev.to_device(x), q, *ab).get(), oq.nan_quantile(x, q, 0, *ab),
+                                           rtol=1e-12, equal_nan=True, err_msg=f"nan_quantile n={n} {ab}")
+        for T in (365, 800, 3650, 5000, 33000):
+            x = field(T, 40)
+            q = osdba.equally_spaced_nodes(20)
+            exp = oq.nan_quantile(x, q, axis=0, alpha=1.0, beta=1.0).astype(np.float32)
+            np.testing.assert_array_equal(K.quantile_series(dev, dev.to_device(x), q).get(), exp, err_msg=f"quantile_series T={T}")
+        x = field(365, 40)
+        ta, ot = _times("2001-01-01", 365, "noleap")
+        tb, years, doys = ta.doy_table()
+        for per in ([10.0], [90.0], [10.0, 50.0, 90.0]):
+            got = K.percentile_doy(dev, dev.to_device(x), tb, 5, per).get()
+            rr = ocal.rolling_construct_center(x, 5)
+            stack = np.full((len(doys), 1, 40, 5), np.nan, dtype=np.float32)
+            stack[np.searchsorted(doys, ot.doy), 0] = rr
+            stack = np.moveaxis(stack, 1, -2).reshape(len(doys), 40, 5)
+            exp = np.moveaxis(oq.calc_perc(stack, per, 1 / 3, 1 / 3), -1, 0)
+            np.testing.assert_allclose(got, exp, rtol=1e-12, equal_nan=True, err_msg=f"percentile_doy one year {per}")
+
+
 @pytest.mark.parametrize("nyears", [4, 12])
 def test_percentile_doy_virtual_time_map(dev, rng, nyears):
     """vmap: percentile_doy of a series in which one year was replaced by another, without copying the data."""

@@ -341,7 +341,50 @@ k_eqm_adjust_cubic(const float* __restrict__ sim, int64_t T, int64_t C, int64_t 
   for (; t < tb; ++t) adjust_one(t, sim[t * st + c]);
 }
 
+// utl:552-554 — "when an interpolation is in NaN range ... clip to the array max value": a NaN node of a column that has
+// valid samples becomes the column's largest valid sample.  The selection kernels produce such NaNs only from infinities
+// (inf - inf in the lerp between two order statistics), so this is a pass over the (nq, C) nodes — 1/18 of the series'
+// bytes at nq = 20, T = 365 — plus one scan of each column that actually holds one; columns without valid samples keep
+// their NaN.  out: (nq, C) with unit column stride.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_nanmax_fix(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int64_t sc, int nq, float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  bool bad = false;
+  for (int j = 0; j < nq; ++j) {
+    const float v = out[(int64_t)j * C + c];
+    bad |= v != v;
+  }
+  if (!bad) return;
+  float m = __uint_as_float(0xFF800000u);
+  bool any = false;
+  for (int64_t t = 0; t < T; ++t) {
+    const float v = x[t * st + c * sc];
+    if (v == v) {
+      any = true;
+      m = v > m ? v : m;
+    }
+  }
+  if (!any) return;
+  for (int j = 0; j < nq; ++j) {
+    const float v = out[(int64_t)j * C + c];
+    if (v != v) out[(int64_t)j * C + c] = m;
+  }
+}
+
+static int quantile_series_core(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                const double* d_q, int nq, float* out);
+
 static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                const double* d_q, int nq, float* out) {
+  const int rc = quantile_series_core(ctx, x, T, C, st, sc, d_q, nq, out);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_nanmax_fix, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, sc, nq, out);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+static int quantile_series_core(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
                                 const double* d_q, int nq, float* out) {
   if (st == 1 && sc >= T) {
     return xh_select_columns(ctx, x, T, C, sc, d_q, nq, out, 1, C);

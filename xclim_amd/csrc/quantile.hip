@@ -35,7 +35,10 @@ __device__ __forceinline__ double xh_hf_quantile(int L, int n, double q, double 
   // utl:395  n * quantiles + (alpha + quantiles * (1 - alpha - beta)) - 1   (no FMA: built with -ffp-contract=off)
   double vi = nn * q + (alpha + q * (1.0 - alpha - beta)) - 1.0;
   if (vi >= nn - 1.0) return (double)get(n - 1);  // utl:443-447 + nanmax fallback
-  if (vi < 0.0) return (double)get(0);            // utl:449-452
+  if (vi < 0.0) {  // utl:449-452: both neighbours = slot 0, then the lerp of utl:486: inf - inf = NaN -> nanmax (utl:552-554)
+    const float v0 = get(0);
+    return (v0 - v0 != 0.0f) ? (double)get(n - 1) : (double)v0;
+  }
   double prev = floor(vi);
   int ip = (int)prev;
   double gamma = vi - prev;                // utl:412
@@ -279,20 +282,30 @@ k_pdoy_slide(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int6
         rf[v] = xh_key2f(m);
         r[v] = (double)rf[v];
       }
-      if (COUNT) {
-        // the percentile IS a float32 sample here, so the fp64 compare of the general path is exactly an fp32 compare
-        // (no conversions, mask-form operator); the window is full: every value is valid
-        const int p = doy_period[d];
-        if (p != cper) { flush_counts(); cper = p; }
+      // An infinite MINIMUM is not the answer: the lerp between slot 0 and itself is inf - inf = NaN and the reference
+      // then takes the window's nanmax (utl:552-554) — the general path below does that (an infinite maximum is its own
+      // nanmax).
+      bool odd = false;
+      if (fast == 2) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          ccnt[v] += xh_cmp_f32(xh_key2f(centre[v]), op, rf[v]) ? 1 : 0;
-          cval[v] += 1;
+        for (int v = 0; v < VEC; ++v) odd |= (rf[v] - rf[v]) != 0.0f;
+      }
+      if (!(fast == 2 && __any(odd ? 1 : 0))) {
+        if (COUNT) {
+          // the percentile IS a float32 sample here, so the fp64 compare of the general path is exactly an fp32 compare
+          // (no conversions, mask-form operator); the window is full: every value is valid
+          const int p = doy_period[d];
+          if (p != cper) { flush_counts(); cper = p; }
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            ccnt[v] += xh_cmp_f32(xh_key2f(centre[v]), op, rf[v]) ? 1 : 0;
+            cval[v] += 1;
+          }
+          return;
         }
+        for (int j = 0; j < nper; ++j) emit(d, j, r, centre);
         return;
       }
-      for (int j = 0; j < nper; ++j) emit(d, j, r, centre);
-      return;
     }
     uint32_t s[VEC][W];
 #pragma unroll
