@@ -10,13 +10,45 @@
 
 // Per-column quantiles: exact multi-select kernels in select.hip (xh_select_columns).
 
-// af from ref_q / hist_q  (get_correction)
+// af from ref_q / hist_q  (get_correction), one thread per COLUMN, with the nanmax rule of utl:552-554 folded in (see
+// k_nanmax_fix below): a NaN node of a series that has valid samples is that series' largest valid sample.  The thread
+// reads the column's 2 * nq nodes — the bytes an elementwise correction reads anyway — so that EQM training pays no separate
+// pass for the rule; the series themselves are scanned only for columns that hold such a node (infinities in the data).
 __global__ void __launch_bounds__(XH_BLOCK)
-k_correction(const float* __restrict__ ref_q, const float* __restrict__ hist_q, int64_t n, int kind,
-             float* __restrict__ af) {
-  int64_t i = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  af[i] = kind == 0 ? (ref_q[i] - hist_q[i]) : (ref_q[i] / hist_q[i]);
+k_correction_fix(const float* __restrict__ ref, const float* __restrict__ hist, int64_t T, int64_t C, int64_t st, int64_t sc,
+                 int nq, int kind, float* __restrict__ af, float* __restrict__ hist_q) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  bool badr = false, badh = false;
+  for (int j = 0; j < nq; ++j) {
+    const float r = af[(int64_t)j * C + c], h = hist_q[(int64_t)j * C + c];
+    badr |= r != r;
+    badh |= h != h;
+  }
+  auto colmax = [&](const float* __restrict__ x, bool& any) {
+    float m = __uint_as_float(0xFF800000u);
+    any = false;
+    for (int64_t t = 0; t < T; ++t) {
+      const float v = x[t * st + c * sc];
+      if (v == v) {
+        any = true;
+        m = v > m ? v : m;
+      }
+    }
+    return m;
+  };
+  float mr = 0.f, mh = 0.f;
+  if (badr) mr = colmax(ref, badr);  // (badr / badh stay set only when the series has a valid sample)
+  if (badh) mh = colmax(hist, badh);
+  for (int j = 0; j < nq; ++j) {
+    float r = af[(int64_t)j * C + c], h = hist_q[(int64_t)j * C + c];
+    if (badr && r != r) r = mr;
+    if (badh && h != h) {
+      h = mh;
+      hist_q[(int64_t)j * C + c] = h;
+    }
+    af[(int64_t)j * C + c] = kind == 0 ? (r - h) : (r / h);
+  }
 }
 
 // ---- adjust -------------------------------------------------------------------------------------------------
@@ -471,13 +503,12 @@ int xh_eqm_train(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, in
   int rc = xh_scratch_upload(ctx, &cur, q, sizeof(double) * nq, &d_q);
   if (rc) return rc;
   // ref_q goes to `af` first, then af = correction(ref_q, hist_q) in place
-  rc = quantile_series_impl(ctx, ref, T, C, st, sc, (const double*)d_q, nq, af);
+  rc = quantile_series_core(ctx, ref, T, C, st, sc, (const double*)d_q, nq, af);
   if (rc) return rc;
-  rc = quantile_series_impl(ctx, hist, T, C, st, sc, (const double*)d_q, nq, hist_q);
+  rc = quantile_series_core(ctx, hist, T, C, st, sc, (const double*)d_q, nq, hist_q);
   if (rc) return rc;
-  int64_t n = (int64_t)nq * C;
-  hipLaunchKernelGGL(k_correction, dim3((unsigned)cdiv64(n, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, af, hist_q, n, kind,
-                     af);
+  hipLaunchKernelGGL(k_correction_fix, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, ref, hist, T, C, st, sc,
+                     nq, kind, af, hist_q);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }
