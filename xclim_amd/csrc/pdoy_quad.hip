@@ -228,9 +228,11 @@ int xh_launch_pdoy_quad(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64
   chunk += chunk & 1;  // the pairs live on the even grid
   const char* ea = xh_diag_env("XH_PDOY_ABL");  // diagnostics only (results become wrong)
   const int abl = ea ? atoi(ea) : 0;
+  const char* el = xh_diag_env("XH_PDOY_LDSPAD");  // diagnostics: unused dynamic LDS per wave, caps the waves per CU
+  const size_t ldspad = el ? (size_t)atoi(el) : 0;
   const dim3 grid((unsigned)cdiv64(C, 64), (unsigned)((ndoy + chunk - 1) / chunk));
 #define XH_QUAD_(NY, B, A)                                                                                                   \
-  hipLaunchKernelGGL((k_pdoy_quad<NY, B, A>), grid, dim3(64), 0, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, d_tab, \
+  hipLaunchKernelGGL((k_pdoy_quad<NY, B, A>), grid, dim3(64), ldspad, ctx->stream, x, T, C, st, d_tb, nyears, ndoy, chunk, d_tab, \
                      d_jmap, nsub, out, d_vmap, Tv, d_reg, nanrow, B ? pinf : ninf)
 #define XH_QUAD(NY, B) XH_QUAD_(NY, B, 0)
   if (abl && nyears <= 32 && !bot) {
