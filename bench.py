@@ -550,11 +550,11 @@ def bench_full_configs(dev, K, C, long_series=True):
                          "threshold_count_GB/s": bc / ms_c / 1e6, "ms": ms_p + ms_c, "GB/s": (bp + bc) / (ms_p + ms_c) / 1e6,
                          "frac": (bp + bc) / (ms_p + ms_c) / 1e6 / HBM_PEAK_GBS, "cell-timesteps/s": E / (ms_p + ms_c) * 1e3,
                          "algorithmic_bytes": bp + bc, "config": "BASELINE configs[4], the tx90p half on one GPU's 1440x720 grid",
-                         "roofline": hbm_roofline(bp + bc, ms_p + ms_c, "k_pdoy_top16<5, 32, false> (xh_percentile_doy) + k_tc_doy<0, false> (xh_threshold_count_doy)"),
-                         "roofline_percentile_doy": hbm_roofline(bp, ms_p, "k_pdoy_top16<5, 32, false>"),
+                         "roofline": hbm_roofline(bp + bc, ms_p + ms_c, "k_pdoy_quad<32, false> (xh_percentile_doy) + k_tc_doy<0, false> (xh_threshold_count_doy)"),
+                         "roofline_percentile_doy": hbm_roofline(bp, ms_p, "k_pdoy_quad<32, false>"),
                          "roofline_threshold_count": hbm_roofline(bc, ms_c, "k_tc_doy<0, false>", traffic=pmc_traffic_30yr("k_tc_doy<0, false>"),
                                                                   traffic_source=PMC_30YR),
-                         "roofline_valu": valu_bound("k_pdoy_top16")}
+                         "roofline_valu": valu_bound("k_pdoy_quad")}
     period = (np.searchsorted(seg, tb, side="right") - 1).astype(np.int32)
     period[tb < 0] = -1
     fused = K.percentile_doy_count(dev, tas, tb, 5, 90.0, ">", period, P, out=(cnt, val))
@@ -563,7 +563,7 @@ def bench_full_configs(dev, K, C, long_series=True):
         bf = 4 * E + 8 * P * C
         out["tx90p_30yr_fused"] = {"ms": msf, "GB/s": bf / msf / 1e6, "frac": bf / msf / 1e6 / HBM_PEAK_GBS,
                                    "cell-timesteps/s": E / msf * 1e3, "algorithmic_bytes": bf,
-                                   "roofline": hbm_roofline(bf, msf, "xh_percentile_doy_count = k_pdoy_top16<5, 32, false> into scratch + k_tc_doy<0, false>",
+                                   "roofline": hbm_roofline(bf, msf, "xh_percentile_doy_count = k_pdoy_quad<32, false> into scratch + k_tc_doy<0, false>",
                                                             passes="the samples cross HBM twice (table kernel, count kernel) + the (D, C) fp64 scratch table once each way: 8E + 16DC bytes for 4E algorithmic")}
     for a in (per, cnt, val):
         a.free()

@@ -20,7 +20,7 @@ import json
 import os
 import sys
 
-UNCALIBRATED = ("k_select", "__amd_rocclr", "k_pdoy_top16")  # strided gathers: FETCH_SIZE x2 not calibrated
+UNCALIBRATED = ("k_select", "__amd_rocclr", "k_pdoy_top16", "k_pdoy_quad")  # strided gathers: FETCH_SIZE x2 not calibrated
 
 
 def main(src, dst, name="pmc_hbm_traffic.json", only=None):
