@@ -550,8 +550,10 @@ def bench_full_configs(dev, K, C, long_series=True):
                          "threshold_count_GB/s": bc / ms_c / 1e6, "ms": ms_p + ms_c, "GB/s": (bp + bc) / (ms_p + ms_c) / 1e6,
                          "frac": (bp + bc) / (ms_p + ms_c) / 1e6 / HBM_PEAK_GBS, "cell-timesteps/s": E / (ms_p + ms_c) * 1e3,
                          "algorithmic_bytes": bp + bc, "config": "BASELINE configs[4], the tx90p half on one GPU's 1440x720 grid",
-                         "roofline": hbm_roofline(bp + bc, ms_p + ms_c, "k_pdoy_quad<32, false> (xh_percentile_doy) + k_tc_doy<0, false> (xh_threshold_count_doy)"),
-                         "roofline_percentile_doy": hbm_roofline(bp, ms_p, "k_pdoy_quad<32, false>"),
+                         "roofline": hbm_roofline(bp + bc, ms_p + ms_c, "k_pdoy_quad<32, false> (xh_percentile_doy) + k_tc_doy<0, false> (xh_threshold_count_doy)",
+                                                  traffic=pmc_traffic_30yr("k_pdoy_quad<32, false, 0>", "k_tc_doy<0, false>"), traffic_source=PMC_30YR),
+                         "roofline_percentile_doy": hbm_roofline(bp, ms_p, "k_pdoy_quad<32, false>", traffic=pmc_traffic_30yr("k_pdoy_quad<32, false, 0>"),
+                                                                 traffic_source=PMC_30YR),
                          "roofline_threshold_count": hbm_roofline(bc, ms_c, "k_tc_doy<0, false>", traffic=pmc_traffic_30yr("k_tc_doy<0, false>"),
                                                                   traffic_source=PMC_30YR),
                          "roofline_valu": valu_bound("k_pdoy_quad")}

@@ -6,8 +6,11 @@ Units/corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: both coun
 FETCH_SIZE reports exactly 1/2 of the bytes of a coalesced streaming read, so it is doubled for the streaming
 kernels (calibration on this code: k_threshold_count reads x (1.514 GB) + the fp64 table (3.028 GB) = 4.542 GB and
 FETCH_SIZE*1024*2 = 4.542 GB; k_run_max_fused reads 1.514 GB, FETCH_SIZE*1024*2 = 1.514 GB; k_fill_synthetic writes
-1.514 GB and WRITE_SIZE*1024 = 1.514 GB, i.e. writes need no correction).  The strided-gather select kernels are
-NOT calibrated: their derived byte figures are written as null (the raw counter means stay).
+1.514 GB and WRITE_SIZE*1024 = 1.514 GB, i.e. writes need no correction).  The multi-year gather of k_pdoy_quad (256 bytes
+per row and wave from rows 365 rows apart) is calibrated by tools/gather_ubench.hip, the same pattern without
+arithmetic: it reads 45.41 GB and FETCH_SIZE*1024*2 = 45.41 - 45.50 GB for every variant (tools/gpu_r04_p7.sh,
+profiles/r04/pdoy_anatomy.txt #9).  The strided-gather select kernels and k_pdoy_top16 are NOT calibrated: their derived
+byte figures are written as null (the raw counter means stay).
 
 usage: tools/summarize_pmc.py gpurun_out/prof_<tag> profiles/<tag> [out.json [kernel-prefix,kernel-prefix,...]]
 (the optional prefix list keeps only kernels that run at ONE grid size in that profile run: a mean over launches of
@@ -20,7 +23,7 @@ import json
 import os
 import sys
 
-UNCALIBRATED = ("k_select", "__amd_rocclr", "k_pdoy_top16", "k_pdoy_quad")  # strided gathers: FETCH_SIZE x2 not calibrated
+UNCALIBRATED = ("k_select", "__amd_rocclr", "k_pdoy_top16")  # strided gathers: FETCH_SIZE x2 not calibrated
 
 
 def main(src, dst, name="pmc_hbm_traffic.json", only=None):
