@@ -405,6 +405,42 @@ def test_percentile_doy_quad_kernel(dev, rng, monkeypatch, nyears, calendar, per
     np.testing.assert_array_equal(K.percentile_doy(dev, d_x, tb, window, [per]).get(), out)
 
 
+@pytest.mark.parametrize("nyears,window,calendar,nan_frac", [(30, 5, "noleap", 0.0), (30, 5, "standard", 0.02), (12, 7, "noleap", 0.3),
+                                                           (20, 3, "standard", 0.0), (9, 5, "noleap", 0.9)])
+def test_percentile_doy_walk_kernel(dev, rng, monkeypatch, nyears, window, calendar, nan_frac):
+    """Central percentiles on a multi-year base period = k_pdoy_walk (pdoy_walk.hip: sorted day-set lists in LDS, a split
+    per percentile that walks from day to day): against the oracle and bit-identical to the pop-from-one-end kernel it
+    replaces (k_pdoy_merge, XH_PDOY_WALK=0); more percentiles than one launch holds; the special values."""
+    C = 130
+    T = 365 * nyears + (nyears + 3) // 4 if calendar == "standard" else 365 * nyears
+    x = _field(rng, T, C, nan_frac=nan_frac)
+    x[:, 0] = np.nan
+    x[:, 1] = 280.0
+    x[::7, 2] = np.inf
+    x[3::11, 2] = -np.inf
+    x[: 365 * 2, 3] = np.nan
+    x[:, 4] = np.round(x[:, 4])  # ties
+    ta, ot = _times("2000-01-01", T, calendar)
+    tb, years, doys = ta.doy_table()
+    per = [20.0, 33.0, 50.0, 66.6, 75.0, 40.0]
+    d_x = dev.to_device(x)
+    out = K.percentile_doy(dev, d_x, tb, window, per).get()
+    rr = ocal.rolling_construct_center(x, window)
+    stack = np.full((len(doys), len(years), C, window), np.nan, dtype=np.float32)
+    stack[np.searchsorted(doys, ot.doy), np.searchsorted(years, ot.year)] = rr
+    stack = np.moveaxis(stack, 1, -2).reshape(len(doys), C, len(years) * window)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = oq.calc_perc(stack, per, 1 / 3, 1 / 3)
+    np.testing.assert_allclose(out, np.moveaxis(exp, -1, 0), rtol=1e-12, atol=0, equal_nan=True)
+    monkeypatch.setenv("XH_DIAGNOSTICS", "1")
+    monkeypatch.setenv("XH_PDOY_WALK", "0")
+    np.testing.assert_array_equal(K.percentile_doy(dev, d_x, tb, window, per).get(), out)
+    monkeypatch.setenv("XH_PDOY_WALK", "1")
+    monkeypatch.setenv("XH_PDOY_CHUNK", "11")
+    np.testing.assert_array_equal(K.percentile_doy(dev, d_x, tb, window, per).get(), out)
+
+
 def test_infinities_follow_the_nanmax_rule(dev, rng):
     """utl:552-554: a NaN interpolation (inf - inf between two order statistics) becomes the slice's nanmax — in the one-shot
     quantile (also where the virtual index is below 0 and both neighbours are slot 0), in the series quantiles of every

@@ -136,6 +136,11 @@ int xh_launch_pdoy_top16(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int6
 int xh_launch_pdoy_quad(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
                         int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int nsub, int bot, double* out,
                         const int32_t* d_vmap, int64_t Tv, const uint8_t* d_reg);
+// pdoy_walk.hip: percentiles anywhere in the distribution on the regular doys (sorted day-set lists in LDS, a split that
+// walks from day to day); XH_ERR_NOTIMPL without an error text = not its shape, take k_pdoy_merge
+int xh_launch_pdoy_walk(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* d_tb, int nyears,
+                        int ndoy, int window, const QTab* d_tab, const int32_t* d_jmap, int nsub, double* out,
+                        const int32_t* d_vmap, int64_t Tv, const uint8_t* d_reg);
 // COUNT variant (xh_percentile_doy_count, multi-year base period): one percentile, every doy regular; the exceedances
 // of (year y, doy d) are added to period d_period[y * ndoy + d] (atomics: cnt_out / valid_out must be zeroed);
 // d_newseg[d] = 1 where the period of doy d differs from that of doy d - 1 — for EVERY year at once (host-checked)

@@ -883,7 +883,15 @@ static int pdoy_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
     if (rc) return rc;
   }
   if (nrest == 0 && nirr == 0) return XH_OK;
-  // ---- LDS-ring kernel: the remaining percentiles on the regular doys, every percentile on the irregular doys
+  // ---- the remaining percentiles on the regular doys: the split-walk kernel (pdoy_walk.hip) where it applies
+  if (nrest) {
+    const int rw = xh_launch_pdoy_walk(ctx, x, T, C, st, (const int32_t*)d_tb, nyears, ndoy, window, (const QTab*)d_tab,
+                                       (const int32_t*)d_jrest, nrest, out, (const int32_t*)d_vmap, Tv, (const uint8_t*)d_reg);
+    if (rw == XH_OK) nrest = 0;
+    else if (rw != XH_ERR_NOTIMPL) return rw;
+    if (nrest == 0 && nirr == 0) return XH_OK;
+  }
+  // ---- LDS-ring kernel: what is left of them, and every percentile on the irregular doys
   const size_t lds = ((size_t)window * (KT + KB) * 64 + (size_t)window * 64) * sizeof(uint32_t);
   const size_t lds_a = ((size_t)window * (KTa + KBa) * 64 + (size_t)window * 64) * sizeof(uint32_t);
 #define XH_MERGE(W, NY)                                                                                                    \

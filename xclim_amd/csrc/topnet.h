@@ -63,6 +63,37 @@ __device__ __forceinline__ void tn_merge16(float (&o)[16], const float (&a)[16],
   }
 }
 
+// 32 values sorted outer-first: two sort-16 blocks + a full bitonic merge (60 + 60 + 80 comparators)
+template <bool BOT>
+__device__ __forceinline__ void tn_sort32(float (&k)[32]) {
+  float a[16], b[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    a[i] = k[i];
+    b[i] = k[16 + i];
+  }
+  tn_sort16<BOT>(a);
+  tn_sort16<BOT>(b);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    tn_ce<BOT>(a[i], b[15 - i]);  // a: the 16 outermost of all 32, b: the rest — both bitonic
+  }
+#pragma unroll
+  for (int stride = 8; stride > 0; stride >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if ((i & stride) == 0) {
+        tn_ce<BOT>(a[i], a[i + stride]);
+        tn_ce<BOT>(b[i], b[i + stride]);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    k[i] = a[i];
+    k[16 + i] = b[i];
+  }
+}
+
 // positions 15 and 14 of the 16 outermost of (a u b) without sorting them: the inner half of a half-cleaner holds the
 // inner half of a bitonic sequence and is bitonic again (16 + 8 + 4 + 2 + 2 single instructions instead of 16 + 64)
 template <bool BOT>
