@@ -10,10 +10,13 @@
 //   one contiguous year, window 3/5/7  : k_pdoy_slide   sliding register ring, every row read once (the tx90p benchmark);
 //                                         COUNT variant fuses the exceedance count (xh_percentile_doy_count)
 //   N <= 32 samples                    : k_pdoy_reg     gather into registers, bitonic network on uint32 keys
-//   multi-year, regular doys           : k_pdoy_top16   (pdoy_top.hip) register top-16 of the W day-sets, for percentiles
-//                                         whose order statistics lie within the 16 largest / smallest samples
-//                                        k_pdoy_merge   per-day sorted lists in a compact LDS ring + W-way tail merge (other
-//                                         percentiles; OFFSET variant: exact window lists for irregular doys, e.g. Feb 29)
+//   multi-year, regular doys           : k_pdoy_quad    (pdoy_quad.hip, window 5) / k_pdoy_top16 (pdoy_top.hip, windows 3, 7):
+//                                         register top-16 of the W day-sets, for percentiles whose order statistics lie
+//                                         within the 16 largest / smallest samples
+//                                        k_pdoy_walk    (pdoy_walk.hip) the other percentiles up to 32 years: sorted day-set
+//                                         lists in LDS and a split that walks from day to day
+//                                        k_pdoy_merge   per-day sorted lists in a compact LDS ring + W-way tail merge (more
+//                                         than 32 years; OFFSET variant: exact window lists for irregular doys, e.g. Feb 29)
 //   anything else (N <= 4096)          : k_pdoy_lds     lane-private LDS column, bitonic network in LDS (64 cells per wave
 //                                                         up to 512 samples, 32 / 16 / 8 beyond)
 // Time-major layout, one lane per cell (VEC cells in the sliding kernel).
