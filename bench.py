@@ -557,6 +557,12 @@ def bench_full_configs(dev, K, C, long_series=True):
                          "roofline_threshold_count": hbm_roofline(bc, ms_c, "k_tc_doy<0, false>", traffic=pmc_traffic_30yr("k_tc_doy<0, false>"),
                                                                   traffic_source=PMC_30YR),
                          "roofline_valu": valu_bound("k_pdoy_quad")}
+    # a percentile in the MIDDLE of the distribution on the same field (the register top-16 kernels do not apply)
+    ms50 = event_time(dev, lambda: K.percentile_doy(dev, tas, tb, 5, [50.0], out=per), 2)
+    out["percentile_doy_30yr_median"] = {"ms": ms50, "GB/s": bp / ms50 / 1e6, "frac": bp / ms50 / 1e6 / HBM_PEAK_GBS,
+                                          "cell-timesteps/s": E / ms50 * 1e3, "algorithmic_bytes": bp,
+                                          "roofline": hbm_roofline(bp, ms50, "k_pdoy_walk<5> (xh_percentile_doy, per = 50)"),
+                                          "note": "sorted day-set lists in LDS, a split that walks from day to day; latency-bound (one wave per SIMD)"}
     period = (np.searchsorted(seg, tb, side="right") - 1).astype(np.int32)
     period[tb < 0] = -1
     fused = K.percentile_doy_count(dev, tas, tb, 5, 90.0, ">", period, P, out=(cnt, val))
