@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of an experiment: the XH_HIST_CW switch left the tree with it, profiles/r04/select4_anatomy.txt #9)
 # round 4, select4 with 32-column tiles (two 512-thread workgroups per CU, XH_HIST_CW=32) against 64-column tiles: the
 # selection tests + fuzz under CW=32, then config-4 training time for both (same box)
 set -u
