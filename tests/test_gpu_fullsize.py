@@ -187,6 +187,31 @@ def test_tx90p_30yr_full_grid(dev, rng):
     x.free()
 
 
+def test_percentile_doy_30yr_central_percentiles_full_grid(dev, rng):
+    """The 30-year field at its own size through the kernels for percentiles in the middle of the distribution
+    (k_pdoy_walk): size-independent properties on every (doy, cell) — p25 <= p50 <= p75, all finite, all inside the
+    field's range, the median within a degree of the seasonal mean — and sampled cells against the oracle."""
+    T = 10950
+    ta, ot = TimeAxis.daily("1981-01-01", T, "noleap"), OTime.noleap(1981, T)
+    tb, years, doys = ta.doy_table()
+    base = synth.seasonal_base(T)
+    x = K.fill_synthetic(dev, T, C, 0, 2, base, 3.0, nan_per_million=50)
+    per = [25.0, 50.0, 75.0]
+    p = K.percentile_doy(dev, x, tb, 5, per)
+    ph = p.get()  # (3, 365, C) fp64: 9 GB on the host
+    assert ph.shape == (3, len(doys), C) and np.isfinite(ph).all()
+    assert (ph[0] <= ph[1]).all() and (ph[1] <= ph[2]).all()
+    clim = base[:365].astype(np.float64)[:, None]
+    assert np.abs(ph[1] - clim).max() < 1.5  # 150 samples of noise with amplitude 3 around the seasonal cycle
+    assert 1.5 < (ph[2] - ph[0]).mean() < 5.0  # the interquartile range of the synthetic noise (amplitude 3)
+    cells = np.sort(rng.choice(C, size=128, replace=False))
+    xs = synth.fill_synthetic(T, cells, 0, 2, base, 3.0, nan_per_million=50)
+    exp_p, _ = ocal.percentile_doy(xs, ot, 5, per)  # (365, cells, 3)
+    np.testing.assert_allclose(ph[:, :, cells], np.moveaxis(exp_p, -1, 0), rtol=1e-12)
+    x.free()
+    p.free()
+
+
 def _eqm_30yr(dev, rng, ncells, cell0, nsample):
     T = 10950
     base = synth.seasonal_base(T)
