@@ -8,7 +8,7 @@ kernels (calibration on this code: k_threshold_count reads x (1.514 GB) + the fp
 FETCH_SIZE*1024*2 = 4.542 GB; k_run_max_fused reads 1.514 GB, FETCH_SIZE*1024*2 = 1.514 GB; k_fill_synthetic writes
 1.514 GB and WRITE_SIZE*1024 = 1.514 GB, i.e. writes need no correction).  The multi-year gather of k_pdoy_quad (256 bytes
 per row and wave from rows 365 rows apart) is calibrated by tools/gather_ubench.hip, the same pattern without
-arithmetic: it reads 45.41 GB and FETCH_SIZE*1024*2 = 45.41 - 45.50 GB for every variant (tools/gpu_r04_p7.sh,
+arithmetic: it reads 45.41 GB and FETCH_SIZE*1024*2 = 45.41 - 45.50 GB for every variant (tools/experiments/r04/gpu_r04_p7.sh,
 profiles/r04/pdoy_anatomy.txt #9).  The strided-gather select kernels and k_pdoy_top16 are NOT calibrated: their derived
 byte figures are written as null (the raw counter means stay).
 
