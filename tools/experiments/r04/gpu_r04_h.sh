@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of an experiment: the XH_PDOY_NONP1 switch and the NP1 instance left the tree with it)
 # round 4, headline kernel k_pdoy_slide<5,4>: the single-percentile instance (stores left in flight across the step's join)
 # against the generic one (XH_PDOY_NONP1=1), alternating in one call; then the one-year percentile tests
 set -u
