@@ -191,9 +191,12 @@ def eqm_adjust_grouped(sim, time, prop, labels, af, hist_q, kind="+", interp="ne
     out = np.empty_like(sim)
     gv = group_values(time, prop)
     if mode == "griddata":
-        af_t = interp_on_quantiles_2d_nearest(sim, gv, labels, hist_q, af, extrapolation)
+        newg = gv if interp == "nearest" else group_index(time, prop, True)
+        af_t = interp_on_quantiles_2d(sim, newg, labels, hist_q, af, interp, extrapolation)
         with np.errstate(all="ignore"):
             return (sim + af_t if kind == "+" else sim * af_t).astype(sim.dtype)
+    if interp != "nearest":
+        raise ValueError("mode='group' is the own-group NEAREST rule; linear goes through mode='griddata'")
     for g, lab in enumerate(labels):
         rows = np.nonzero(gv == lab)[0]
         if rows.size:
@@ -201,25 +204,62 @@ def eqm_adjust_grouped(sim, time, prop, labels, af, hist_q, kind="+", interp="ne
     return out
 
 
-def interp_on_quantiles_2d_nearest(newx, newg, labels, xq, yq, extrapolation="constant"):
-    """xsdba.utils.interp_on_quantiles for a month / day-of-year grouping and method="nearest", per cell:
+def group_index(time, prop, interp):
+    """xsdba.base.Grouper.get_index(da, interp=...): the group coordinate of every time step.  Integer month / day of year;
+    with ``interp=True`` (every method but "nearest") the month becomes FRACTIONAL — ``month - 0.5 + day / days_in_month``
+    (the middle of a month sits on its integer) — and the day of year stays an integer."""
+    if prop == "dayofyear":
+        return np.asarray(time.doy, dtype=np.float64)
+    if prop != "month":
+        raise NotImplementedError(prop)
+    month = np.asarray(time.month)
+    if not interp:
+        return month.astype(np.float64)
+    if time.index is not None:
+        dim = np.asarray(time.index.days_in_month)
+    elif time.calendar == "360_day":
+        dim = np.full(len(month), 30)
+    else:
+        dim = np.array([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])[month - 1]
+    return month - 0.5 + np.asarray(time.day) / dim
+
+
+def interp_on_quantiles_2d(newx, newg, labels, xq, yq, method="nearest", extrapolation="constant"):
+    """xsdba.utils.interp_on_quantiles for a month / day-of-year grouping, per cell:
     add_cyclic_bounds (the last group copied to coordinate 0, the first to G + 1; labels 1 .. G) ->
-    _interp_on_quantiles_2D = scipy.interpolate.griddata((oldx, oldg), oldy, (newx, newg), method="nearest") on the
-    non-NaN nodes of ALL groups (the REAL scipy routine: a cKDTree query in the (value, group) plane, no rescaling) ->
-    _extrapolate_on_quantiles: where newx lies outside the first / last non-null node of ITS OWN group, that group's
-    first / last factor ("constant") or NaN.  newx (T, ...), newg (T,) group label per step, xq / yq (G, nq, ...)."""
+    _interp_on_quantiles_2D = scipy.interpolate.griddata((oldx, oldg), oldy, (newx, newg), method=method) on the
+    non-NaN nodes of ALL groups — the REAL scipy routine, no rescaling: "nearest" = a cKDTree query in the (value, group)
+    plane, "linear" = barycentric interpolation on Qhull's Delaunay triangulation of the nodes (NaN outside their convex
+    hull) -> _extrapolate_on_quantiles (for "nearest" always, otherwise unless extrapolation="nan"): where newx lies outside
+    the first / last non-null node — np.interp(newg, rows, bounds): of ITS OWN group for an integer newg, between the two
+    neighbouring groups for a fractional one — that bound's first / last factor ("constant") or NaN.
+    newx (T, ...), newg (T,) group coordinate per step (group_index), xq / yq (G, nq, ...); xq may be (nq,) (QDM: the
+    quantile nodes themselves are the abscissa, the same for every group and cell)."""
     from scipy.interpolate import griddata
 
     newx = np.asarray(newx)
     shape = newx.shape
     x2 = newx.reshape(shape[0], -1)
-    G, nq = xq.shape[:2]
-    xq2, yq2 = np.asarray(xq, dtype=np.float64).reshape(G, nq, -1), np.asarray(yq, dtype=np.float64).reshape(G, nq, -1)
+    yq = np.asarray(yq)
+    G, nq = yq.shape[:2]
+    yq2 = np.asarray(yq, dtype=np.float64).reshape(G, nq, -1)
+    xq = np.asarray(xq, dtype=np.float64)
+    xq2 = np.broadcast_to(xq[None, :, None], yq2.shape) if xq.ndim == 1 else xq.reshape(G, nq, -1)
     assert np.array_equal(labels, np.arange(1, G + 1))
     ext = np.concatenate([[G - 1], np.arange(G), [0]])          # rows of the padded tables: coordinates 0 .. G + 1
     oldg = np.repeat(np.arange(G + 2, dtype=np.float64)[:, None], nq, axis=1)
+    rows = np.arange(G + 2, dtype=np.float64)
     out = np.full(x2.shape, np.nan)
     g = np.asarray(newg, dtype=np.float64)
+
+    def first_last(a):  # utils._first_and_last_nonnull: per group row, on THIS array alone (x and y independently)
+        res = np.full((a.shape[0], 2), np.nan)
+        for r, row in enumerate(a):
+            ok = np.nonzero(~np.isnan(row))[0]
+            if ok.size:
+                res[r] = row[ok[0]], row[ok[-1]]
+        return res
+
     for c in range(x2.shape[1]):
         oldx, oldy = xq2[ext, :, c], yq2[ext, :, c]
         x = x2[:, c].astype(np.float64)
@@ -227,27 +267,21 @@ def interp_on_quantiles_2d_nearest(newx, newg, labels, xq, yq, extrapolation="co
         if m_new.all() or m_old.all():
             continue
         res = np.full(x.shape, np.nan)
-        res[~m_new] = griddata((oldx[~m_old], oldg[~m_old]), oldy[~m_old], (x[~m_new], g[~m_new]), method="nearest")
-        # _extrapolate_on_quantiles (newg is an integer coordinate: np.interp picks the row of the own group)
-        def first_last(a):  # utils._first_and_last_nonnull: per group row, on THIS array alone (x and y independently)
-            out = np.full((a.shape[0], 2), np.nan)
-            for r, row in enumerate(a):
-                ok = np.nonzero(~np.isnan(row))[0]
-                if ok.size:
-                    out[r] = row[ok[0]], row[ok[-1]]
-            return out
-
-        bx, by = first_last(oldx), first_last(oldy)
-        gi = g.astype(int)
-        lo_x, hi_x, lo_y, hi_y = bx[gi, 0], bx[gi, 1], by[gi, 0], by[gi, 1]
-        with np.errstate(invalid="ignore"):
-            toolow, toohigh = x < lo_x, x > hi_x
-        if extrapolation == "constant":
-            res[toolow], res[toohigh] = lo_y[toolow], hi_y[toohigh]
-        else:
-            res[toolow | toohigh] = np.nan
+        res[~m_new] = griddata((oldx[~m_old], oldg[~m_old]), oldy[~m_old], (x[~m_new], g[~m_new]), method=method)
+        if method == "nearest" or extrapolation != "nan":       # _extrapolate_on_quantiles
+            bx, by = first_last(oldx), first_last(oldy)
+            with np.errstate(invalid="ignore"):
+                toolow, toohigh = x < np.interp(g, rows, bx[:, 0]), x > np.interp(g, rows, bx[:, 1])
+            if extrapolation == "constant":
+                res[toolow], res[toohigh] = np.interp(g, rows, by[:, 0])[toolow], np.interp(g, rows, by[:, 1])[toohigh]
+            else:
+                res[toolow | toohigh] = np.nan
         out[:, c] = res
     return out.reshape(shape).astype(np.float32)
+
+
+def interp_on_quantiles_2d_nearest(newx, newg, labels, xq, yq, extrapolation="constant"):
+    return interp_on_quantiles_2d(newx, newg, labels, xq, yq, "nearest", extrapolation)
 
 
 def qdm_adjust_grouped(sim, time, prop, labels, af, quantiles, kind="+", interp="nearest", extrapolation="constant"):

@@ -218,16 +218,23 @@ k_hs_sample(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int64
 // the occupancy, but every microsecond a wave spends away from it (LDS latency chains, the tile epilogues) comes on top —
 // one workgroup per CU, nothing else to run.  5 sets of 8 (32 to 40 loads per lane in flight, re-requested every 8
 // samples) against round 3's 2 sets of 16: config-4 train 40.5 -> 37 ms.  prime() requests the first NSET - 1 batches
-// of a tile; the kernels CAN call it for the next tile before they start a tile's epilogue (template flag EARLY), so
+// of a tile; calling it for the NEXT tile before a tile's epilogue (round 4: template flag EARLY, removed in round 5), so
 // that the epilogue runs under flying loads — measured: no gain, off.
+//
+// Round 5: `rev` walks the full batches from the LAST one down to the first.  The fused kernel reads a tile twice in a row
+// (histogram pass, then collect pass); with 256 tiles of 2.8 MB in flight the 256 MiB Infinity Cache still holds roughly
+// the last third of what the first pass read, and only a second pass that STARTS there finds it (tools/mall_ubench.hip,
+// profiles/r05/mall_ubench.txt: second pass 6.46 ms forward, 5.52 ms in reverse, 7.5 ms cold, per 45.4 GB array).
 template <int HS_U, int NSET, int RLT = HS_RL>
 struct HsRing {
   static constexpr int ROWS = RLT * HS_U;  // rows a workgroup covers per batch
   float S[NSET][HS_U];
+  int kb_last = -1;  // >= 0: batch k of the ring is batch kb_last - k of the series (reverse order)
 
   // Buffer loads: a descriptor re-based per batch (scalar), the row offset of load u as the scalar offset, ONE 32-bit
   // per-lane byte offset — no vector address arithmetic and no 64-bit address registers per load.
   __device__ __forceinline__ void load(float (&dst)[HS_U], const float* __restrict__ x, int64_t st, uint32_t voff, int kb) {
+    if (kb_last >= 0) kb = kb_last - kb;
     const float* base = x + (int64_t)kb * ROWS * st;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)0xFFFFFFFFu, 0x00020000);
     const uint32_t rowstep = (uint32_t)(st * 4 * RLT);  // bytes between the rows of loads u and u + 1 (host: 256 rows < 4 GiB)
@@ -239,9 +246,10 @@ struct HsRing {
     }
   }
 
-  __device__ __forceinline__ void prime(const float* __restrict__ x, int T, int64_t st, int64_t cc, int rl) {
+  __device__ __forceinline__ void prime(const float* __restrict__ x, int T, int64_t st, int64_t cc, int rl, bool rev = false) {
     const uint32_t voff = (uint32_t)(((int64_t)rl * st + cc) * 4);
     const int nfull = T / ROWS;
+    kb_last = rev ? nfull - 1 : -1;
 #pragma unroll
     for (int i = 0; i < NSET - 1; ++i)
       if (i < nfull) load(S[i], x, st, voff, i);
@@ -358,14 +366,52 @@ __device__ __forceinline__ uint32_t hs_spread16(uint32_t x) {
   return x;
 }
 
-template <int HS_U, int NSET, bool EARLY>
-__global__ void __launch_bounds__(HS_NT, 4)
-k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2* __restrict__ lohi,
-          const double* __restrict__ qs, int nq, uint32_t* __restrict__ meta_n, uint32_t* __restrict__ meta_m,
-          uint32_t* __restrict__ meta_base, uint16_t* __restrict__ crank, uint32_t* __restrict__ bitmap_g,
-          uint32_t* __restrict__ tab_g, uint32_t* __restrict__ flist, HsStat* __restrict__ stat, int abl) {
+// everything the two passes share (kernel arguments of the round-3/4 kernels, now one struct: the fused kernel runs both)
+struct HsArgs {
+  const float* __restrict__ x;
+  int T;
+  int64_t C, st;
+  const uint2* __restrict__ lohi;
+  const double* __restrict__ qs;
+  int nq;
+  uint32_t* __restrict__ meta_n;
+  uint32_t* __restrict__ meta_m;
+  uint32_t* __restrict__ meta_base;
+  uint16_t* __restrict__ crank;
+  uint32_t* __restrict__ bitmap_g;
+  uint32_t* __restrict__ tab_g;
+  uint32_t* __restrict__ flist;
+  float* __restrict__ out;
+  int64_t ocs, oqs;
+  HsStat* __restrict__ stat;
+  int abl;
+};
+
+// 128-bit clears of n words (n a multiple of 4 * NT is not required)
+__device__ __forceinline__ void hs_clear(uint32_t* p, int n, int tid) {
+  uint4* p4 = reinterpret_cast<uint4*>(p);
+  for (int i = tid; i < n / 4; i += HS_NT) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// One tile of pass 1.  The caller primed the ring for this tile (rows forward); the histogram and the bitmap are zero on
+// entry (cleared at the end of the previous tile, or by the caller) and zero again on return when `clear_after`.
+template <int HS_U, int NSET>
+__device__ __forceinline__ void hs_hist_tile(const HsArgs& A, HsRing<HS_U, NSET>& ring, unsigned char* smem, int64_t tile, bool clear_after) {
   constexpr int CW = HS_CW, NT = HS_NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const float* __restrict__ x = A.x;
+  const int T = A.T;
+  const int64_t C = A.C, st = A.st;
+  const uint2* __restrict__ lohi = A.lohi;
+  const double* __restrict__ qs = A.qs;
+  const int nq = A.nq, abl = A.abl;
+  uint32_t* __restrict__ meta_n = A.meta_n;
+  uint32_t* __restrict__ meta_m = A.meta_m;
+  uint32_t* __restrict__ meta_base = A.meta_base;
+  uint16_t* __restrict__ crank = A.crank;
+  uint32_t* __restrict__ bitmap_g = A.bitmap_g;
+  uint32_t* __restrict__ tab_g = A.tab_g;
+  uint32_t* __restrict__ flist = A.flist;
+  HsStat* __restrict__ stat = A.stat;
   uint32_t* h32 = reinterpret_cast<uint32_t*>(smem);
   uint32_t* bm = h32 + HS_NB * 32;
   uint32_t* part = bm + 32 * CW;
@@ -377,24 +423,10 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
   const int pw = tid & 31, prt = tid >> 5;  // epilogue: column-pair word and 32-bin part of the prefix sums
   const uint32_t sh16 = (uint32_t)(col & 1) << 4;
   const int ntgt = 2 * nq;
-  const int64_t ntiles = (C + CW - 1) / CW;
-  // zero the histogram and the bitmap (again at the end of every tile)
-  for (int i = tid; i < HS_NB * 32 + 32 * CW; i += NT) h32[i] = 0u;
-  __syncthreads();
-  HsRing<HS_U, NSET> ring;
-  auto col_of = [&](int64_t t) -> int64_t {  // the column this thread reads in tile t (the last one for a column past C)
-    const int64_t c_ = t * CW + col;
-    return c_ < C ? c_ : C - 1;
-  };
-  constexpr bool early = EARLY;  // request a tile's first batches before the PREVIOUS tile's epilogue (or when its turn comes)
-  if (early && (int64_t)blockIdx.x < ntiles) ring.prime(x, T, st, col_of(blockIdx.x), rl);
-  for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
-    const int64_t tile = hs_tile_of(round_base, ntiles);
-    if (tile < 0) break;  // (block-uniform; only in the last round)
+  {
     const int64_t c = tile * CW + col;
     const bool cvalid = c < C;
     const int64_t cc = cvalid ? c : C - 1;
-    if (!early) ring.prime(x, T, st, cc, rl);
     const uint2 lh = lohi[cc];
     const HsScale s = hs_scale(lh.x, lh.y);
     // this lane's counter of bin b is the half `col & 1` of word [b][col >> 1]; a column past C adds zeros.  Row 2 of
@@ -425,9 +457,8 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
       }
     });
     if ((abl & 2) && dummy == 0.12345f) atomicAdd(&stat->errors, 1u);
-    if (early && tile + (int64_t)gridDim.x < ntiles) ring.prime(x, T, st, col_of(tile + gridDim.x), rl);  // the epilogue runs under these loads
     __syncthreads();
-    if (abl & 4) continue;  // diagnostics: no tile epilogue (wrong results, the histogram is not even cleared)
+    if (abl & 4) return;  // diagnostics: no tile epilogue (wrong results, the histogram is not even cleared)
     // ---- exclusive prefix sums over the bins, in place and PACKED (two columns per word; every half stays <= T <= 65535):
     // thread (pw, prt) owns the words of bins [prt * 32, prt * 32 + 32) of column pair pw
     uint32_t ssum = 0;
@@ -589,8 +620,28 @@ k_hs_hist(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2
     // bitmap of the tile, then clear
     for (int i = tid; i < 32 * CW; i += NT) bitmap_g[tile * (32 * CW) + i] = bm[i];
     __syncthreads();
-    for (int i = tid; i < HS_NB * 32 + 32 * CW; i += NT) h32[i] = 0u;
-    __syncthreads();
+    if (clear_after) {
+      hs_clear(h32, HS_NB * 32 + 32 * CW, tid);
+      __syncthreads();
+    }
+  }
+}
+
+template <int HS_U, int NSET>
+__global__ void __launch_bounds__(HS_NT, 4)
+k_hs_hist(HsArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, col = tid & (HS_CW - 1), rl = tid / HS_CW;
+  const int64_t ntiles = (A.C + HS_CW - 1) / HS_CW;
+  hs_clear(reinterpret_cast<uint32_t*>(smem), HS_NB * 32 + 32 * HS_CW, tid);
+  __syncthreads();
+  HsRing<HS_U, NSET> ring;
+  for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
+    const int64_t tile = hs_tile_of(round_base, ntiles);
+    if (tile < 0) break;  // (block-uniform; only in the last round)
+    const int64_t c = tile * HS_CW + col;
+    ring.prime(A.x, A.T, A.st, c < A.C ? c : A.C - 1, rl);
+    hs_hist_tile<HS_U, NSET>(A, ring, smem, tile, true);
   }
 }
 
@@ -714,15 +765,26 @@ constexpr size_t hs_lds2() {
   return (size_t)HS_POOL * 4 + 64 * HS_CW * 4 + 32 * HS_CW * 4 + 3 * HS_CW * 4 + (size_t)(HS_NT / 64) * 64 * 4;
 }
 
-template <int HS_U, int NSET, bool EARLY>
-__global__ void __launch_bounds__(HS_NT, 4)
-k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const uint2* __restrict__ lohi,
-             const double* __restrict__ qs, int nq, const uint32_t* __restrict__ meta_n, const uint32_t* __restrict__ meta_m,
-             const uint32_t* __restrict__ meta_base, const uint16_t* __restrict__ crank, const uint32_t* __restrict__ bitmap_g,
-             const uint32_t* __restrict__ tab_g, float* __restrict__ out, int64_t ocs, int64_t oqs, HsStat* __restrict__ stat,
-             int abl, int round) {
+// One tile of pass 2 (collect round `round`).  `rev`: the full batches are streamed from the last one down (fused kernel).
+// The ring is primed here.  Returns without streaming when no column of the tile belongs to this round.
+template <int HS_U, int NSET>
+__device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NSET>& ring, unsigned char* smem, int64_t tile, int round, bool rev) {
   constexpr int CW = HS_CW, NT = HS_NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const float* __restrict__ x = A.x;
+  const int T = A.T;
+  const int64_t C = A.C, st = A.st;
+  const uint2* __restrict__ lohi = A.lohi;
+  const double* __restrict__ qs = A.qs;
+  const int nq = A.nq, abl = A.abl;
+  const uint32_t* __restrict__ meta_n = A.meta_n;
+  const uint32_t* __restrict__ meta_m = A.meta_m;
+  const uint32_t* __restrict__ meta_base = A.meta_base;
+  const uint16_t* __restrict__ crank = A.crank;
+  const uint32_t* __restrict__ bitmap_g = A.bitmap_g;
+  const uint32_t* __restrict__ tab_g = A.tab_g;
+  float* __restrict__ out = A.out;
+  const int64_t ocs = A.ocs, oqs = A.oqs;
+  HsStat* __restrict__ stat = A.stat;
   uint32_t* cand = reinterpret_cast<uint32_t*>(smem);
   uint32_t* tab = cand + HS_POOL;
   uint32_t* bm = tab + 64 * CW;
@@ -733,17 +795,7 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
   const int tid = threadIdx.x, col = tid & (CW - 1), rl = tid / CW;
   const int lane = tid & 63, wv = tid >> 6;
   const int ntgt = 2 * nq;
-  const int64_t ntiles = (C + CW - 1) / CW;
-  HsRing<HS_U, NSET> ring;
-  auto col_of = [&](int64_t t) -> int64_t {
-    const int64_t c_ = t * CW + col;
-    return c_ < C ? c_ : C - 1;
-  };
-  constexpr bool early = EARLY;
-  if (early && (int64_t)blockIdx.x < ntiles) ring.prime(x, T, st, col_of(blockIdx.x), rl);
-  for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
-    const int64_t tile = hs_tile_of(round_base, ntiles);
-    if (tile < 0) break;  // (block-uniform; only in the last round)
+  {
     const int64_t c = tile * CW + col;
     const bool cvalid = c < C;
     const int64_t cc = cvalid ? c : C - 1;
@@ -756,8 +808,8 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
       colok[tid] = collect ? 0xFFFFFFFFu : 0u;  // (tid < CW: col == tid)
       lbase[tid] = collect ? (mbase & 0xFFFFu) : 0u;
     }
-    if (!__syncthreads_or(collect ? 1 : 0)) continue;  // no column of this tile belongs to this round (block-uniform)
-    if (!early) ring.prime(x, T, st, cc, rl);
+    if (!__syncthreads_or(collect ? 1 : 0)) return;  // no column of this tile belongs to this round (block-uniform)
+    ring.prime(x, T, st, cc, rl, rev);
     // the tile's tables; the columns nothing is collected for (flagged, other rounds, past C) read all-zero tables
     for (int i = tid; i < 64 * CW; i += NT) tab[i] = tab_g[tile * (64 * CW) + i] & colok[i & (CW - 1)];
     for (int i = tid; i < 32 * CW; i += NT) bm[i] = bitmap_g[tile * (32 * CW) + i] & colok[i & (CW - 1)];
@@ -823,9 +875,8 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
       }
     });
     if ((abl & 96) && dummy == 0x12345679u) atomicAdd(&stat->errors, 1u);
-    if (early && tile + (int64_t)gridDim.x < ntiles) ring.prime(x, T, st, col_of(tile + gridDim.x), rl);  // the sorts run under these loads
     __syncthreads();
-    if (abl & 96) continue;
+    if (abl & 96) return;
     // ---- one wave per column: sort, pick, lerp (utl:464-491), store
     uint32_t* tv = tvall + wv * 64;
     for (int k = wv; k < CW; k += NT / 64) {
@@ -848,6 +899,50 @@ k_hs_collect(const float* __restrict__ x, int T, int64_t C, int64_t st, const ui
       hs_pick_store<CW>(list, mm, tile, k, ck, lane, ntgt, nq, qs, meta_n, lohi, crank, tv, out, ocs, oqs);
     }
     __syncthreads();  // cand / tab / bm / cursor are rewritten by the next tile
+  }
+}
+
+template <int HS_U, int NSET>
+__global__ void __launch_bounds__(HS_NT, 4)
+k_hs_collect(HsArgs A, int round) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int64_t ntiles = (A.C + HS_CW - 1) / HS_CW;
+  HsRing<HS_U, NSET> ring;
+  for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
+    const int64_t tile = hs_tile_of(round_base, ntiles);
+    if (tile < 0) break;  // (block-uniform; only in the last round)
+    hs_collect_tile<HS_U, NSET>(A, ring, smem, tile, round, false);
+  }
+}
+
+// Round 5 EXPERIMENT (diagnostics, XH_HIST_FUSED=1 | 2; bit-identical, tools/fuzz_r05.py): both passes of a tile back to back
+// in ONE kernel, the second one in reverse row order (see HsRing), so that what pass 1 read last is still in the Infinity
+// Cache when pass 2 starts there.  The micro-benchmark of the access pattern alone promised 7.5 -> 5.5 ms for the second pass
+// (profiles/r05/mall_ubench.txt); the kernel LOSES 1.4-1.7 ms per training (39.57 two kernels, 41.25 fused, 40.97 fused +
+// reverse, alternating in one process): with every workgroup in its own phase the workgroups of neighbouring tiles no
+// longer walk the same rows at the same time (a row of 256 adjacent tiles is one contiguous 64 KB stretch of DRAM), each
+// tile epilogue ages the tile's lines in the cache by what the other 255 workgroups stream meanwhile, and the re-read
+// gains 0.3 ms.  The tables pass 1 writes for pass 2 (tab_g, bitmap_g, crank, meta_*) go through global memory as before —
+// the same workgroup reads them back (__syncthreads orders a workgroup's own global writes and reads); the two LDS
+// layouts alias.  Collect rounds > 0 (series beyond 32768 steps) still run k_hs_collect.
+template <int HS_U, int NSET>
+__global__ void __launch_bounds__(HS_NT, 4)
+k_hs_fused(HsArgs A, int rev) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, col = tid & (HS_CW - 1), rl = tid / HS_CW;
+  const int64_t ntiles = (A.C + HS_CW - 1) / HS_CW;
+  HsRing<HS_U, NSET> ring;
+  for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
+    const int64_t tile = hs_tile_of(round_base, ntiles);
+    if (tile < 0) break;  // (block-uniform; only in the last round)
+    const int64_t c = tile * HS_CW + col;
+    ring.prime(A.x, A.T, A.st, c < A.C ? c : A.C - 1, rl);
+    hs_clear(reinterpret_cast<uint32_t*>(smem), HS_NB * 32 + 32 * HS_CW, tid);  // (under the first loads)
+    __syncthreads();
+    hs_hist_tile<HS_U, NSET>(A, ring, smem, tile, false);
+    __threadfence_block();
+    __syncthreads();  // pass 1's tables are in global memory, its LDS is free
+    hs_collect_tile<HS_U, NSET>(A, ring, smem, tile, 0, rev != 0);
   }
 }
 
@@ -942,36 +1037,41 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   // (round 3's ping-pong: 16 to 32 in flight; config-4 train 40.5 against 36.7-38.2 ms on the same box, profiles/r04/)
   const char* ens = xh_diag_env("XH_HIST_RING");
   const int ring = ens ? atoi(ens) : 85;
-#define XH_HS_HIST(UU, NS, EH)                                                                                                      \
+  HsArgs A;
+  A.x = x; A.T = (int)T; A.C = C; A.st = st; A.lohi = lohi; A.qs = d_q; A.nq = nq;
+  A.meta_n = meta_n; A.meta_m = meta_m; A.meta_base = meta_base; A.crank = crank; A.bitmap_g = bitmap_g; A.tab_g = tab_g;
+  A.flist = flist; A.out = out; A.ocs = out_cstride; A.oqs = out_qstride; A.stat = stat; A.abl = abl;
+  // XH_HIST_FUSED (diagnostics): "1" = both passes of a tile in one kernel, second pass forward, "2" = ... in reverse row
+  // order.  Default 0 = two kernels: measured in one process at config 4 (profiles/r05/select4_fused_ab.txt) 39.57 ms against
+  // 41.25 (fused) and 40.97 (fused + reverse) per training — see k_hs_fused.
+  const char* efu = xh_diag_env("XH_HIST_FUSED");
+  const int fused = efu ? atoi(efu) : 0;
+  const size_t lds_f = hs_lds1() > hs_lds2() ? hs_lds1() : hs_lds2();
+#define XH_HS_LAUNCH(UU, NS)                                                                                                     \
   {                                                                                                                             \
-    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist<UU, NS, EH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds1())); \
-    hipLaunchKernelGGL((k_hs_hist<UU, NS, EH>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds1(), ctx->stream, x, (int)T, C, st, lohi, d_q, nq, \
-                       meta_n, meta_m, meta_base, crank, bitmap_g, tab_g, flist, stat, abl);                                     \
+    if (round == 0 && fused) {                                                                                                  \
+      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_fused<UU, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f)); \
+      hipLaunchKernelGGL((k_hs_fused<UU, NS>), dim3((unsigned)nblk), dim3(HS_NT), lds_f, ctx->stream, A, fused == 2 ? 1 : 0);   \
+    } else {                                                                                                                    \
+      if (round == 0) {                                                                                                         \
+        XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist<UU, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds1())); \
+        hipLaunchKernelGGL((k_hs_hist<UU, NS>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds1(), ctx->stream, A);                  \
+        XH_LAUNCH_CHECK();                                                                                                      \
+      }                                                                                                                         \
+      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<UU, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2())); \
+      hipLaunchKernelGGL((k_hs_collect<UU, NS>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds2(), ctx->stream, A, round);          \
+    }                                                                                                                           \
   }
-#define XH_HS_COLLECT(UU, NS, EC)                                                                                                    \
-  {                                                                                                                             \
-    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<UU, NS, EC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2())); \
-    hipLaunchKernelGGL((k_hs_collect<UU, NS, EC>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds2(), ctx->stream, x, (int)T, C, st, lohi, d_q, \
-                       nq, meta_n, meta_m, meta_base, crank, bitmap_g, tab_g, out, out_cstride, out_qstride, stat, abl, round);  \
-  }
-#define XH_HS_BOTH(UU, NS, EH, EC) { if (round == 0) { XH_HS_HIST(UU, NS, EH) XH_LAUNCH_CHECK(); } XH_HS_COLLECT(UU, NS, EC) }
-  const char* eea = xh_diag_env("XH_HIST_EARLY");  // diagnostics: early priming in pass 1 / pass 2: "00" | "10" | "01" | "11"
-  const int eh = eea ? eea[0] == '1' : 0, ec = eea ? eea[1] == '1' : 0;  // measured: no gain (38.0 / 38.2 / 38.6 / 38.8 ms for 00 / 10 / 01 / 11)
   HsStat h;
   for (int round = 0;; ++round) {  // round 0: pass 1 + pass 2; further rounds of pass 2 for tiles whose lists overflow the pool
-    if (ring == 162) XH_HS_BOTH(16, 2, false, false)
-    else if (eh && ec) XH_HS_BOTH(8, 5, true, true)
-    else if (eh) XH_HS_BOTH(8, 5, true, false)
-    else if (ec) XH_HS_BOTH(8, 5, false, true)
-    else XH_HS_BOTH(8, 5, false, false)
+    if (ring == 162) XH_HS_LAUNCH(16, 2)
+    else XH_HS_LAUNCH(8, 5)
     XH_LAUNCH_CHECK();
     XH_CHECK_HIP(hipMemcpyAsync(&h, stat, sizeof(HsStat), hipMemcpyDeviceToHost, ctx->stream));
     XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     if (round >= (int)h.rounds) break;
   }
-#undef XH_HS_BOTH
-#undef XH_HS_HIST
-#undef XH_HS_COLLECT
+#undef XH_HS_LAUNCH
   XH_REQUIRE(h.errors == 0 || abl != 0, XH_ERR_HIP, "xh_select_hist: %u columns met another candidate count in pass 2 than in pass 1",
              h.errors);
   if (xh_diag_env("XH_HIST_STATS")) fprintf(stderr, "[xh_select_hist] T=%lld C=%lld flagged=%u candidates: max %u mean %.1f, %u collect rounds\n", (long long)T, (long long)C, h.nflag, h.maxm, (double)h.summ / (double)C, h.rounds + 1u);
