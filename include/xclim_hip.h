@@ -478,11 +478,26 @@ int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
  * hq_all (G, nq, C); gcoord in 1 .. G; kind 0 (+) | 1 (*) | 2 (factor only).  Parity unpinned. */
 int xh_eqm_adjust_g2d(xh_ctx* ctx, const float* sim, int64_t n, int64_t C, int64_t st, const float* af_all, const float* hq_all,
                       int G, int nq, int gcoord, int kind, int extrap, float* scen, int64_t scen_st);
+/* interp = "linear" with a month / day-of-year Grouper: xsdba.utils.interp_on_quantiles' 2-D branch (upstream xsdba,
+ * re-exported by /root/reference/src/xclim/sdba.py:10; the documented standard use, /root/reference/docs/sdba.rst:64-65,
+ * /root/reference/CHANGELOG.rst:338): scipy griddata(method="linear") = barycentric interpolation on the Delaunay
+ * triangulation of the nodes of ALL groups in the (abscissa, group coordinate) plane (cyclic copies of the last / first
+ * group at coordinates 0 / G + 1), then _extrapolate_on_quantiles "constant" (first / last factor, np.interp'ed between the
+ * two neighbouring groups for a fractional coordinate).  xnew (T, C) row stride st: the abscissa of every step (EQM / DQM:
+ * sim itself; QDM: its percentage rank); base (T, C) or NULL: the values the factor is applied to (NULL: xnew); gnew (T)
+ * DEVICE float64: the group coordinate of every step (Grouper.get_index(interp=True): month - 0.5 + day / days_in_month, or
+ * the day of year); node abscissae xq_all (G, nq, C) device float32 OR xq_common (nq) HOST float64 (QDM: the quantiles);
+ * factors yq_all (G, nq, C); kind 0 (+) | 1 (*) | 2 (factor only); scen (T, C) row stride scen_st.  The Delaunay
+ * triangle of a query is found by a dual-simplex walk from a starting triangle (plane.hip), no triangulation is stored;
+ * cocircular node sets (regular grids) have no unique answer — see plane.hip.  Parity unpinned. */
+int xh_plane_linear(xh_ctx* ctx, const float* xnew, const float* base, int64_t T, int64_t C, int64_t st, const double* gnew,
+                    const float* xq_all, const double* xq_common, const float* yq_all, int G, int nq, int kind, float* scen,
+                    int64_t scen_st);
 /* QuantileDeltaMapping.adjust (xsdba._adjustment.qdm_adjust, group "time"): sim_q = rank(sim, pct=True) along time
  * (average ranks of the valid samples r / n, rescaled mx (r/n - mn) / (mx - mn) as xsdba.utils.rank does);
  * af_t = interp_on_quantiles(sim_q, q, af) with the nq quantile nodes q (host, strictly increasing) as abscissa
  * (interp 0 nearest, 1 linear; extrap 0 constant, 1 nan; NaN factors dropped per cell); scen = sim + af_t (kind 0) or
- * sim * af_t (kind 1).  af (nq, C) float32 as trained by xh_eqm_train.  scen has the layout of sim (st, sc);
+ * sim * af_t (kind 1); kind 2: scen = af_t alone.  af (nq, C) float32 as trained by xh_eqm_train.  scen has the layout of sim (st, sc);
  * 1 <= T < 2^27: up to 32768 steps a column's keys stay in one workgroup (qdm.hip, qdm2.hip), longer series (1950-2100
  * daily = 55 152) are ranked through a global sort in column batches (qdm3.hip).  Parity unpinned (xsdba is not in the
  * reference tree). */

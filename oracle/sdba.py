@@ -43,8 +43,13 @@ while the file is absent):
     dqm_train_grouped /            dqm_train / dqm_adjust through Grouper("time.month" | "time.season")  dqmg_{group}_af / _hist_q /
       dqm_adjust_grouped           (window 1): u.broadcast of the scaling, PolyDetrend(group=...)         _scaling / _scen
 
-    NOT restated (refused by the product): interpolation over (quantile, group) for "linear" / "cubic", DQM with a
-    windowed sub-grouping (the trend is fitted on the window mean there), QDM cubic.
+    interp_on_quantiles_2d /       utils.interp_on_quantiles, 2-D branch (add_cyclic_bounds, _interp_on_quantiles_2D =     eqmg_{group}_scen_linear,
+      group_index                  scipy griddata "nearest" | "linear" — the REAL scipy routine —, _extrapolate_on_quantiles);  qdmg_{group}_scen_linear
+                                   Grouper.get_index(interp=True): fractional months, integer days of year
+
+    NOT restated (refused by the product): interpolation over (quantile, group) for "cubic" (griddata's Clough-Tocher
+    scheme), "linear" with extrapolation="nan" or a season grouping, DQM with a windowed sub-grouping (the trend is fitted
+    on the window mean there), QDM cubic.
 
 Where a difference is most likely once the fixtures exist (from memory of the upstream sources, not verified here): (1)
 ``nbutils.quantile`` casts the probabilities to the dtype of the data before it calls numpy's nanquantile, so float32
@@ -284,11 +289,25 @@ def interp_on_quantiles_2d_nearest(newx, newg, labels, xq, yq, extrapolation="co
     return interp_on_quantiles_2d(newx, newg, labels, xq, yq, "nearest", extrapolation)
 
 
-def qdm_adjust_grouped(sim, time, prop, labels, af, quantiles, kind="+", interp="nearest", extrapolation="constant"):
-    """Grouped QDM: ranks inside each group's own time steps (main_only=True), factors of that group."""
+def qdm_adjust_grouped(sim, time, prop, labels, af, quantiles, kind="+", interp="nearest", extrapolation="constant", mode="group"):
+    """Grouped QDM: ranks inside each group's own time steps (main_only=True), factors of that group ("group"); mode
+    "griddata": the factors interpolated over the (quantile, group) plane as xsdba does for interp != "nearest" —
+    interp_on_quantiles(sim_q, quantiles, af) with the quantile nodes themselves as abscissa in every group."""
     sim = np.asarray(sim)
     out = np.empty_like(sim)
     gv = group_values(time, prop)
+    if mode == "griddata":
+        T = sim.shape[0]
+        s2 = sim.reshape(T, -1)
+        sim_q = np.full(s2.shape, np.nan)
+        for lab in labels:
+            rows = np.nonzero(gv == lab)[0]
+            for c in range(s2.shape[1]):
+                sim_q[rows, c] = rank_pct(s2[rows, c])
+        af_t = interp_on_quantiles_2d(sim_q.reshape(sim.shape), group_index(time, prop, interp != "nearest"), labels,
+                                      np.asarray(quantiles, dtype=np.float64), af, interp, extrapolation)
+        with np.errstate(all="ignore"):
+            return (sim + af_t if kind == "+" else sim * af_t).astype(sim.dtype)
     for g, lab in enumerate(labels):
         rows = np.nonzero(gv == lab)[0]
         if rows.size:
@@ -376,7 +395,8 @@ def dqm_train_grouped(ref, hist, time, prop, nquantiles=20, kind="+"):
     return labels, np.stack([r[0] for r in res]), np.stack([r[1] for r in res]), np.stack([r[2] for r in res])
 
 
-def dqm_adjust_grouped(sim, time, prop, labels, af, hist_q, scaling, kind="+", extrapolation="constant", detrend=1, mode="group"):
+def dqm_adjust_grouped(sim, time, prop, labels, af, hist_q, scaling, kind="+", extrapolation="constant", detrend=1, mode="group",
+                       interp="nearest"):
     """dqm_adjust with a sub-grouping, interp="nearest": every step takes the scaling of its group (u.broadcast), the
     polynomial trend is fitted PER GROUP over the group's own steps on the time coordinate (PolyDetrend(group=...):
     polyfit along time — here days since the group's mean date; a linear fit does not depend on the origin), the
@@ -394,7 +414,8 @@ def dqm_adjust_grouped(sim, time, prop, labels, af, hist_q, scaling, kind="+", e
         trend = poly_trend_u(scaled, u, detrend)
         detr = _corr(scaled, trend, kind, True)
         if mode == "griddata":
-            af_t = interp_on_quantiles_2d_nearest(detr, gv[rows], labels, hist_q, af, extrapolation)
+            newg = gv[rows] if interp == "nearest" else group_index(time, prop, True)[rows]
+            af_t = interp_on_quantiles_2d(detr, newg, labels, hist_q, af, interp, extrapolation)
             with np.errstate(all="ignore"):
                 scen0 = (detr + af_t if kind == "+" else detr * af_t).astype(np.float32)
         else:

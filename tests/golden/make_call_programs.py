@@ -42,6 +42,7 @@ INDICES = {
         "heat_wave_frequency": {"args": {"tasmin": "*", "tasmax": "*"}},
         "tx_tn_days_above": {"args": {"tasmin": "*", "tasmax": "*"}},
         "days_over_precip_thresh": {"args": {"pr": "*", "pr_per": "*"}, "assume": {"contains": True}},
+        "heat_wave_max_length": {"args": {"tasmin": "*", "tasmax": "*"}},     # rl.resample_and_rl(..., window, reducer)
     },
     "_threshold.py": {
         "maximum_consecutive_dry_days": {"args": {"pr": "*"}},
@@ -58,6 +59,14 @@ INDICES = {
         "tn_days_below": {"args": {"tasmin": "*"}},
         "dry_days": {"args": {"pr": "*"}},
         "wetdays": {"args": {"pr": "*"}},
+        # round 5: the call shapes of replaced functions no recorded body had used yet (tests/test_host_cpu.py walks the
+        # three index modules and lists every shape)
+        "holiday_snow_and_snowfall_days": {"args": {"snd": "*", "prsn": "*"}},  # bivariate_count_occurrences(keywords only)
+        "rprctot": {"args": {"pr": "*", "prc": "*"}},                            # compare without constrain
+        "holiday_snow_days": {"args": {"snd": "*"}},                             # count_occurrences
+        "days_with_snow": {"args": {"prsn": "*"}},                               # domain_count
+        "snd_season_end": {"args": {"snd": "*"}},                                # season(2 positional)
+        "dry_spell_frequency": {"args": {"pr": "*"}},                            # spell_length_statistics(**indexer)
     },
     "_simple.py": {
         "tg_mean": {"args": {"tas": "*"}},

@@ -541,9 +541,18 @@ def test_eqm_with_sub_groupings(dev, rng, group, window, nyears, kind, interp):
     np.testing.assert_array_equal(eqm.group_labels, labels)
     np.testing.assert_allclose(eqm.hist_q, ohq, rtol=1e-6, equal_nan=True)
     np.testing.assert_allclose(eqm.af, oaf, rtol=1e-6, atol=1e-5, equal_nan=True)
-    if interp != "nearest":  # xsdba interpolates over (quantile, group) there: refused, not approximated
-        with pytest.raises(NotImplementedError, match="2-D interpolation"):
-            eqm.adjust(sim, interp=interp, extrapolation="constant", time=ta)
+    if interp != "nearest":  # xsdba interpolates over the (quantile, group) PLANE there (round 5: xh_plane_linear)
+        if prop == "season":  # upstream's season coordinate is not restated: refused, not approximated
+            with pytest.raises(NotImplementedError, match="plane"):
+                eqm.adjust(sim, interp=interp, extrapolation="constant", time=ta)
+            return
+        scen = eqm.adjust(sim, interp=interp, extrapolation="constant", time=ta)
+        exp = osdba.eqm_adjust_grouped(sim, ot, prop, labels, eqm.af, eqm.hist_q, kind, interp, "constant", mode="griddata")
+        np.testing.assert_allclose(scen, exp, rtol=1e-6, atol=1e-6, equal_nan=True)
+        with pytest.raises(NotImplementedError, match="Clough-Tocher"):
+            eqm.adjust(sim, interp="cubic", time=ta)
+        with pytest.raises(NotImplementedError, match="convex hull"):
+            eqm.adjust(sim, interp=interp, extrapolation="nan", time=ta)
         return
     scen = eqm.adjust(sim, interp=interp, extrapolation="constant", time=ta, grouped_nearest="group")
     exp = osdba.eqm_adjust_grouped(sim, ot, prop, labels, eqm.af, eqm.hist_q, kind, interp, "constant")
@@ -1316,8 +1325,14 @@ def test_dqm_grouped_matches_oracle(dev, rng, kind, group):
     assert 1.5 < last - first < 4.0                                     # the simulated trend survives the adjustment
     with pytest.raises(NotImplementedError):
         xsdba.DetrendedQuantileMapping.train(ref, hist, group="time.dayofyear", window=31, time=ta, device=dev)
-    with pytest.raises(NotImplementedError):
-        dqm.adjust(sim, interp="linear", time=ta)
+    if prop == "month":   # interp="linear": the detrended steps interpolated over the (quantile, group) plane (round 5)
+        got = dqm.adjust(sim, interp="linear", detrend=1, time=ta)
+        exp = osdba.dqm_adjust_grouped(sim, ot, prop, labels, dqm.af, dqm.hist_q, dqm.scaling, kind, "constant", 1, mode="griddata",
+                                       interp="linear")
+        np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5, equal_nan=True)
+    else:
+        with pytest.raises(NotImplementedError):
+            dqm.adjust(sim, interp="linear", time=ta)
 
 
 @pytest.mark.parametrize("T", [1, 2, 700, 40000])
@@ -1557,8 +1572,25 @@ def test_qdm_grouped_matches_oracle(dev, rng, group, window):
     got = qdm.adjust(sim, interp="nearest", time=ta)
     exp = osdba.qdm_adjust_grouped(sim, ot, prop, qdm.group_labels, qdm.af, qdm.quantiles, "+", "nearest", "constant")
     np.testing.assert_allclose(got, exp, rtol=1e-6, equal_nan=True, err_msg=f"{group}")
-    with pytest.raises(NotImplementedError, match="2-D interpolation"):
-        qdm.adjust(sim, interp="linear", time=ta)
+    # interp="linear": xsdba interpolates the factors over the (quantile, group) plane with the quantile nodes themselves as
+    # abscissa — a regular grid.  Day of year: every query lies on its group's row, where the answer is unique (and equals
+    # the 1-D interpolation inside the group).  Month (fractional coordinate): every grid cell is a cocircular quadruple,
+    # its Delaunay diagonal is Qhull's arbitrary choice — ours may take the other one: bounded by the cell's twist
+    got = qdm.adjust(sim, interp="linear", time=ta)
+    exp = osdba.qdm_adjust_grouped(sim, ot, prop, qdm.group_labels, qdm.af, qdm.quantiles, "+", "linear", "constant", mode="griddata")
+    if prop == "dayofyear":
+        np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-6, equal_nan=True)
+    else:
+        af = qdm.af
+        ext = np.concatenate([af[-1:], af, af[:1]])                      # cyclic rows 0 .. G + 1
+        twist = np.abs(ext[1:, 1:] + ext[:-1, :-1] - ext[1:, :-1] - ext[:-1, 1:]).max(axis=(0, 1))   # per cell: max |mixed difference|
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        assert (np.abs(got - exp) <= 0.5 * twist[None] + 1e-5)[~np.isnan(exp)].all()
+        on_row = np.isclose(xsdba.Grouper(group).coordinate(ta, True) % 1.0, 0.0)      # the 15th / 16th of a month: on the row
+        if on_row.any():
+            np.testing.assert_allclose(got[on_row], exp[on_row], rtol=1e-6, atol=1e-6, equal_nan=True)
+    with pytest.raises(NotImplementedError):
+        qdm.adjust(sim, interp="cubic", time=ta)
 
 
 @pytest.mark.parametrize("kind", ["+", "*"])

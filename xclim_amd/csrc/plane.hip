@@ -1,0 +1,345 @@
+// plane.hip — interp="linear" over the (quantile, group) PLANE: what xsdba.utils.interp_on_quantiles does for a month /
+// day-of-year Grouper when the method is not "nearest" (upstream xsdba >= 0.4, re-exported by
+// /root/reference/src/xclim/sdba.py:10; documented as the standard configuration: /root/reference/docs/sdba.rst:64-65,
+// /root/reference/CHANGELOG.rst:338).  Upstream, per cell:
+//   add_cyclic_bounds            the G group rows get coordinates 1 .. G, the last row is copied to 0, the first to G + 1
+//   _interp_on_quantiles_2D      scipy.interpolate.griddata((oldx, oldg), oldy, (newx, newg), method="linear") on the non-NaN
+//                                nodes: barycentric interpolation on Qhull's DELAUNAY triangulation of the nodes, no rescaling
+//                                of the axes (a temperature in K and a month number are the same unit)
+//   _extrapolate_on_quantiles    newx below / above np.interp(newg, rows, first / last non-null node): the (row-interpolated)
+//                                first / last factor
+// newg = Grouper.get_index(interp=True): month - 0.5 + day / days_in_month (fractional), or the integer day of year.
+//
+// No triangulation is built.  The nodes lie on G + 2 horizontal lines, sorted along each: for a query q
+//   1. two non-empty rows around q give a starting triangle that contains q (two neighbours of one row + one of the other);
+//   2. the Delaunay triangle that contains q is the optimum of a tiny linear programme — over all convex combinations of
+//      sites that reproduce q, minimise sum lambda_i |p_i - q|^2 (the lower hull of the lifted sites) — solved by the dual
+//      simplex method: while some site lies INSIDE the circumcircle of the current triangle, bring in the one deepest
+//      inside (per row that is the node nearest to the circle's centre: one binary search per row the circle crosses), drop
+//      the vertex the ratio test names (barycentric coordinates of q and of the entering site); the new triangle still
+//      contains q and the objective falls, so the walk ends at the empty-circle triangle.  0.5-6 pivots per query
+//      (tools/experiments/r05/proto_plane.py: agrees with scipy.griddata to 3e-15 on 40 random node sets, value ranges from 0.05
+//      to 30 units per group step, i.e. triangles spanning one to a dozen rows);
+//   3. the factor is the barycentric combination of the three node factors (fp64), rounded to fp32 like upstream's output.
+// What cannot be reproduced: node sets with four or more COCIRCULAR nodes (a regular grid: QDM, whose abscissa is the
+// quantile itself in every group) have no unique Delaunay triangulation — scipy's answer there depends on the order Qhull
+// happens to visit facets in; this walk keeps the triangle it holds when no site is strictly inside (tolerance 1e-10 R^2).
+// On a group row itself (every day-of-year query) both diagonals give the same value.  Duplicated nodes of one row (tied
+// quantiles) collapse to the first of them (Qhull keeps one it chooses).
+//
+// Precision: fp64 throughout (Qhull and LinearNDInterpolator are fp64).  One lane per (time step, cell); node tables packed
+// per cell by k_plane_pack (NaN nodes dropped, strictly increasing abscissa) — gathers that hit L2; functional, not tuned.
+#include "common.h"
+
+namespace {
+
+struct PlaneTabs {
+  const float* __restrict__ px;   // (G, nq, C) packed abscissa of the valid nodes of every row
+  const float* __restrict__ py;   // (G, nq, C) their factors
+  const uint8_t* __restrict__ cnt;  // (G, C) valid nodes per row
+  const float* __restrict__ fx;   // (G, C) first / last non-null ABSCISSA (utils._first_and_last_nonnull on oldx alone)
+  const float* __restrict__ lx;
+  const float* __restrict__ fy;   // (G, C) first / last non-null FACTOR (... on oldy alone)
+  const float* __restrict__ ly;
+  int G, nq;
+  int64_t C;
+};
+
+// one thread per (group row, cell): drop the nodes whose abscissa or factor is NaN, collapse runs of equal abscissae
+__global__ void __launch_bounds__(XH_BLOCK)
+k_plane_pack(const float* __restrict__ xq_all, const double* __restrict__ xq_common, const float* __restrict__ yq_all, int G, int nq,
+             int64_t C, float* __restrict__ px, float* __restrict__ py, uint8_t* __restrict__ cnt, float* __restrict__ fx,
+             float* __restrict__ lx, float* __restrict__ fy, float* __restrict__ ly) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  const int g = blockIdx.y;
+  if (c >= C) return;
+  const int64_t base = (int64_t)g * nq * C + c;
+  int m = 0;
+  float last = 0.f, firstx = xh_nan32(), lastx = xh_nan32(), firsty = xh_nan32(), lasty = xh_nan32();
+  for (int k = 0; k < nq; ++k) {
+    const float x = xq_all ? xq_all[base + (int64_t)k * C] : (float)xq_common[k];
+    const float y = yq_all[base + (int64_t)k * C];
+    if (x == x) {
+      if (firstx != firstx) firstx = x;
+      lastx = x;
+    }
+    if (y == y) {
+      if (firsty != firsty) firsty = y;
+      lasty = y;
+    }
+    if (x == x && y == y && (m == 0 || x > last)) {
+      px[base + (int64_t)m * C] = x;
+      py[base + (int64_t)m * C] = y;
+      last = x;
+      ++m;
+    }
+  }
+  cnt[(int64_t)g * C + c] = (uint8_t)m;
+  fx[(int64_t)g * C + c] = firstx;
+  lx[(int64_t)g * C + c] = lastx;
+  fy[(int64_t)g * C + c] = firsty;
+  ly[(int64_t)g * C + c] = lasty;
+}
+
+// row coordinate r in 0 .. G + 1 -> table row (cyclic copies at both ends)
+__device__ __forceinline__ int plane_row(int r, int G) { return r == 0 ? G - 1 : (r == G + 1 ? 0 : r - 1); }
+
+struct PlaneCell {
+  const PlaneTabs& t;
+  int64_t c;
+  __device__ __forceinline__ int count(int r) const { return (int)t.cnt[(int64_t)plane_row(r, t.G) * t.C + c]; }
+  __device__ __forceinline__ double x(int r, int k) const { return (double)t.px[((int64_t)plane_row(r, t.G) * t.nq + k) * t.C + c]; }
+  __device__ __forceinline__ double y(int r, int k) const { return (double)t.py[((int64_t)plane_row(r, t.G) * t.nq + k) * t.C + c]; }
+  // number of nodes of row r with abscissa <= v (searchsorted side="right"), n = count(r)
+  __device__ __forceinline__ int upper(int r, int n, double v) const {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (x(r, mid) <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  }
+  // ... with abscissa < v (side="left")
+  __device__ __forceinline__ int lower(int r, int n, double v) const {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (x(r, mid) < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  }
+};
+
+// np.interp between two rows at fraction f in [0, 1): the node value itself on a row (numpy: xp[j] == x short-cut)
+__device__ __forceinline__ double plane_lerp(double v0, double v1, double f) {
+  if (f == 0.0) return v0;
+  const double slope = v1 - v0;
+  double r = slope * f + v0;
+  if (r != r) {  // numpy's repair of a non-finite product
+    r = slope * (f - 1.0) + v1;
+    if (r != r && v0 == v1) r = v0;
+  }
+  return r;
+}
+
+struct PlaneTri {
+  int r[3], k[3];
+  double x[3];
+};
+
+// barycentric coordinates of (qx, qy) in the triangle
+__device__ __forceinline__ void plane_bary(const PlaneTri& T, double qx, double qy, double (&lam)[3]) {
+  const double x0 = T.x[0], y0 = (double)T.r[0];
+  const double ax = T.x[1] - x0, ay = (double)T.r[1] - y0, bx = T.x[2] - x0, by = (double)T.r[2] - y0;
+  const double d = ax * by - bx * ay;
+  const double l1 = ((qx - x0) * by - bx * (qy - y0)) / d;
+  const double l2 = (ax * (qy - y0) - (qx - x0) * ay) / d;
+  lam[0] = 1.0 - l1 - l2;
+  lam[1] = l1;
+  lam[2] = l2;
+}
+
+__device__ __forceinline__ bool plane_try(const PlaneCell& P, PlaneTri& T, int ra, int ka, int rb, int kb, int rc, int kc, double qx,
+                                          double qy) {
+  T.r[0] = ra; T.k[0] = ka; T.x[0] = P.x(ra, ka);
+  T.r[1] = rb; T.k[1] = kb; T.x[1] = P.x(rb, kb);
+  T.r[2] = rc; T.k[2] = kc; T.x[2] = P.x(rc, kc);
+  double lam[3];
+  plane_bary(T, qx, qy, lam);
+  const double mn = fmin(lam[0], fmin(lam[1], lam[2]));
+  return mn >= -1e-12;
+}
+
+// The factor at (qx, qy), qy in [0, G + 1]; NaN when q lies outside the strip polygon of its two rows (the caller's bounds
+// test catches those first) or no two non-empty rows surround it.
+__device__ double plane_locate(const PlaneCell& P, double qx, double qy) {
+  const int R = P.t.G + 2;
+  int r0 = (int)floor(qy);
+  r0 = r0 < 0 ? 0 : (r0 > R - 1 ? R - 1 : r0);
+  const bool onrow = (double)r0 == qy;
+  int r1 = r0 + 1;
+  while (r0 >= 0 && P.count(r0) == 0) --r0;
+  if (r0 < 0) return xh_nan64();
+  while (r1 < R && P.count(r1) == 0) ++r1;
+  if (r1 >= R) {  // nothing above: only a query ON row r0 can still be served, by an apex row below
+    if (!(onrow && (double)r0 == qy)) return xh_nan64();
+    r1 = r0 - 1;
+    while (r1 >= 0 && P.count(r1) == 0) --r1;
+    if (r1 < 0) return xh_nan64();
+  }
+  const int nA = P.count(r0), nB = P.count(r1);
+  const double f = (qy - (double)r0) / (double)(r1 - r0);
+  // s(i, j) = (1 - f) A_i + f B_j: the abscissa of segment A_i - B_j at the height of q
+  const double A0 = P.x(r0, 0), B0 = P.x(r1, 0), AL = P.x(r0, nA - 1), BL = P.x(r1, nB - 1);
+  if (qx < (1.0 - f) * A0 + f * B0 || qx > (1.0 - f) * AL + f * BL) return xh_nan64();
+  PlaneTri T;
+  bool have = false;
+  {
+    int i = P.upper(r0, nA, qx) - 1, j = P.upper(r1, nB, qx) - 1;
+    const int imax = nA >= 2 ? nA - 2 : 0, jmax = nB >= 2 ? nB - 2 : 0;
+    i = i < 0 ? 0 : (i > imax ? imax : i);
+    j = j < 0 ? 0 : (j > jmax ? jmax : j);
+    if (nA >= 2) have = plane_try(P, T, r0, i, r0, i + 1, r1, j, qx, qy);
+    if (!have && nA >= 2 && nB >= 2) have = plane_try(P, T, r0, i, r0, i + 1, r1, j + 1, qx, qy);
+    if (!have && nB >= 2) have = plane_try(P, T, r0, i, r1, j, r1, j + 1, qx, qy);
+    if (!have && nA >= 2 && nB >= 2) have = plane_try(P, T, r0, i + 1, r1, j, r1, j + 1, qx, qy);
+  }
+  if (!have) {
+    // the fan from A_0 over B, then from B_last over A: j = last index with s(0, j) <= qx
+    int lo = 0, hi = nB;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((1.0 - f) * A0 + f * P.x(r1, mid) <= qx) lo = mid + 1; else hi = mid;
+    }
+    const int jj = lo - 1;
+    if (jj < nB - 1) {
+      plane_try(P, T, r0, 0, r1, jj < 0 ? 0 : jj, r1, (jj < 0 ? 0 : jj) + 1, qx, qy);
+    } else {
+      lo = 0; hi = nA;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((1.0 - f) * P.x(r0, mid) + f * BL <= qx) lo = mid + 1; else hi = mid;
+      }
+      int ii = lo - 1;
+      ii = ii < 0 ? 0 : (ii > nA - 2 ? nA - 2 : ii);
+      if (nA < 2) return xh_nan64();  // (one node in each row and q not on their segment's end: caught by the bounds)
+      plane_try(P, T, r0, ii, r0, ii + 1, r1, nB - 1, qx, qy);
+    }
+  }
+  // ---- dual simplex walk to the empty-circle triangle
+  double lam[3];
+#pragma unroll 1
+  for (int it = 0; it < 96; ++it) {
+    const double x0 = T.x[0], y0 = (double)T.r[0];
+    const double ax = T.x[1] - x0, ay = (double)T.r[1] - y0, bx = T.x[2] - x0, by = (double)T.r[2] - y0;
+    const double d = 2.0 * (ax * by - ay * bx);
+    const double a2 = ax * ax + ay * ay, b2 = bx * bx + by * by;
+    const double ux = (by * a2 - ay * b2) / d, uy = (ax * b2 - bx * a2) / d;
+    const double cx = x0 + ux, cy = y0 + uy, R2 = ux * ux + uy * uy;
+    if (!(R2 < 1e300)) break;  // degenerate start (collinear): keep it
+    const double Rr = sqrt(R2);
+    int ra = (int)ceil(cy - Rr), rb = (int)floor(cy + Rr);
+    ra = ra < 0 ? 0 : ra;
+    rb = rb > R - 1 ? R - 1 : rb;
+    double bestp = -1e-10 * fmax(R2, 1.0);
+    int br = -1, bk = 0;
+    double bxv = 0.0;
+#pragma unroll 1
+    for (int r = ra; r <= rb; ++r) {
+      const int n = P.count(r);
+      if (n == 0) continue;
+      const double h = (double)r - cy;
+      const double w2 = R2 - h * h;
+      if (!(w2 > 0.0)) continue;
+      const int kk = P.lower(r, n, cx);
+#pragma unroll 1
+      for (int k = kk - 1; k <= kk; ++k) {
+        if (k < 0 || k >= n) continue;
+        if ((r == T.r[0] && k == T.k[0]) || (r == T.r[1] && k == T.k[1]) || (r == T.r[2] && k == T.k[2])) continue;
+        const double xv = P.x(r, k);
+        const double pw = (xv - cx) * (xv - cx) - w2;
+        if (pw < bestp) { bestp = pw; br = r; bk = k; bxv = xv; }
+      }
+    }
+    if (br < 0) break;
+    double mu[3];
+    plane_bary(T, qx, qy, lam);
+    plane_bary(T, bxv, (double)br, mu);
+    int kout = -1;
+    double best = 0.0;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      if (mu[v] > 1e-14) {
+        const double ratio = lam[v] / mu[v];
+        if (kout < 0 || ratio < best) { kout = v; best = ratio; }
+      }
+    }
+    if (kout < 0) break;
+    // (static indexing: a dynamic index into the register arrays becomes a select chain anyway)
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+      if (v == kout) { T.r[v] = br; T.k[v] = bk; T.x[v] = bxv; }
+  }
+  plane_bary(T, qx, qy, lam);
+  return lam[0] * P.y(T.r[0], T.k[0]) + lam[1] * P.y(T.r[1], T.k[1]) + lam[2] * P.y(T.r[2], T.k[2]);
+}
+
+__global__ void __launch_bounds__(XH_BLOCK)
+k_plane_linear(const float* __restrict__ xnew, const float* __restrict__ base, int64_t T, int64_t st, const double* __restrict__ gnew,
+               PlaneTabs tabs, int kind, float* __restrict__ scen, int64_t scen_st) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= tabs.C) return;
+  const PlaneCell P{tabs, c};
+  const int G = tabs.G;
+  const int64_t chunk = cdiv64(T, (int64_t)gridDim.y);
+  const int64_t ta = (int64_t)blockIdx.y * chunk;
+  int64_t tb = ta + chunk;
+  if (tb > T) tb = T;
+  for (int64_t t = ta; t < tb; ++t) {
+    const float xf = xnew[t * st + c];
+    const float bf = base ? base[t * st + c] : xf;
+    float a = xh_nan32();
+    if (xf == xf) {
+      const double x = (double)xf;
+      double g = gnew[t];
+      g = g < 0.0 ? 0.0 : (g > (double)(G + 1) ? (double)(G + 1) : g);
+      int r0 = (int)floor(g);
+      if (r0 > G) r0 = G;  // (g == G + 1: the last interval, f = 1 — np.interp returns the end value)
+      const double f = g - (double)r0;
+      const int64_t i0 = (int64_t)plane_row(r0, G) * tabs.C + c, i1 = (int64_t)plane_row(r0 + 1, G) * tabs.C + c;
+      const double lo = f == 1.0 ? (double)tabs.fx[i1] : plane_lerp((double)tabs.fx[i0], (double)tabs.fx[i1], f);
+      const double hi = f == 1.0 ? (double)tabs.lx[i1] : plane_lerp((double)tabs.lx[i0], (double)tabs.lx[i1], f);
+      double ad;
+      if (x < lo) ad = f == 1.0 ? (double)tabs.fy[i1] : plane_lerp((double)tabs.fy[i0], (double)tabs.fy[i1], f);
+      else if (x > hi) ad = f == 1.0 ? (double)tabs.ly[i1] : plane_lerp((double)tabs.ly[i0], (double)tabs.ly[i1], f);
+      else ad = plane_locate(P, x, g);
+      a = (float)ad;
+    }
+    scen[t * scen_st + c] = kind == 0 ? (bf + a) : (kind == 1 ? (bf * a) : a);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int xh_plane_linear(xh_ctx* ctx, const float* xnew, const float* base, int64_t T, int64_t C, int64_t st, const double* gnew,
+                    const float* xq_all, const double* xq_common, const float* yq_all, int G, int nq, int kind, float* scen,
+                    int64_t scen_st) {
+  XH_REQUIRE(ctx && xnew && gnew && yq_all && scen, XH_ERR_ARG, "xh_plane_linear: NULL argument");
+  XH_REQUIRE((xq_all != nullptr) != (xq_common != nullptr), XH_ERR_ARG, "xh_plane_linear: give xq_all (G, nq, C) OR xq_common (nq)");
+  XH_REQUIRE(T >= 0 && C >= 0 && nq >= 1 && nq <= 255 && G >= 1, XH_ERR_ARG, "xh_plane_linear: bad shape (1 <= nq <= 255, G >= 1)");
+  XH_REQUIRE(st >= C && scen_st >= C, XH_ERR_LAYOUT, "xh_plane_linear: needs time-major views");
+  XH_REQUIRE(kind >= 0 && kind <= 2, XH_ERR_ARG, "xh_plane_linear: kind must be 0 (+), 1 (*) or 2 (the factor only)");
+  if (T == 0 || C == 0) return XH_OK;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t b_tab = al(4 * (size_t)G * nq * C), b_cnt = al((size_t)G * C), b_row = al(4 * (size_t)G * C), b_q = al(8 * (size_t)nq);
+  void* ws = nullptr;
+  int rc = xh_big_scratch(ctx, 2 * b_tab + b_cnt + 4 * b_row + b_q, &ws);
+  if (rc) return rc;
+  char* p = (char*)ws;
+  float* px = (float*)p; p += b_tab;
+  float* py = (float*)p; p += b_tab;
+  uint8_t* cnt = (uint8_t*)p; p += b_cnt;
+  float* fx = (float*)p; p += b_row;
+  float* lx = (float*)p; p += b_row;
+  float* fy = (float*)p; p += b_row;
+  float* ly = (float*)p; p += b_row;
+  double* dq = (double*)p;
+  if (xq_common) XH_CHECK_HIP(hipMemcpyAsync(dq, xq_common, 8 * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+  const int64_t cblocks = cdiv64(C, XH_BLOCK);
+  hipLaunchKernelGGL(k_plane_pack, dim3((unsigned)cblocks, (unsigned)G), dim3(XH_BLOCK), 0, ctx->stream, xq_all, xq_common ? dq : nullptr,
+                     yq_all, G, nq, C, px, py, cnt, fx, lx, fy, ly);
+  XH_LAUNCH_CHECK();
+  PlaneTabs tabs{px, py, cnt, fx, lx, fy, ly, G, nq, C};
+  int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
+  if (gy < 1) gy = 1;
+  if (gy > T) gy = T;
+  if (gy > 4096) gy = 4096;
+  hipLaunchKernelGGL(k_plane_linear, dim3((unsigned)cblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, xnew, base, T, st, gnew, tabs,
+                     kind, scen, scen_st);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+}  // extern "C"

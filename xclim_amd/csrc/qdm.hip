@@ -236,7 +236,7 @@ k_qdm_columns(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
             const double slope = (double)(yhi - ylo) / (xs[lo] - xs[lo - 1]);
             a = (float)(slope * (pct - xs[lo - 1]) + (double)ylo);
           }
-          res = kind == 0 ? raw[k] + a : raw[k] * a;
+          res = kind == 0 ? raw[k] + a : (kind == 1 ? raw[k] * a : a);
         }
       }
       if (i <= Tm1) oc[i] = res;
@@ -286,7 +286,7 @@ int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   XH_REQUIRE(ctx && sim && af && q && scen, XH_ERR_ARG, "xh_qdm_adjust: NULL argument");
   XH_REQUIRE(T >= 1 && T < (1ll << 27) && C >= 0 && nq >= 1 && nq <= QDM_MAXQ, XH_ERR_ARG,
              "xh_qdm_adjust: bad shape (1 <= T < 2^27, 1 <= nq <= 64)");
-  XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "xh_qdm_adjust: kind must be 0 (+) or 1 (*)");
+  XH_REQUIRE(kind >= 0 && kind <= 2, XH_ERR_ARG, "xh_qdm_adjust: kind must be 0 (+), 1 (*) or 2 (the interpolated factor only)");
   XH_REQUIRE(interp == 0 || interp == 1, XH_ERR_NOTIMPL, "xh_qdm_adjust: interp must be 0 (nearest) or 1 (linear)");
   XH_REQUIRE(extrap == 0 || extrap == 1, XH_ERR_ARG, "xh_qdm_adjust: extrap must be 0 (constant) or 1 (nan)");
   for (int j = 1; j < nq; ++j)

@@ -452,7 +452,7 @@ k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const f
 #pragma unroll
           for (int u = 0; u < QB; ++u) {
             const int i = ci * 32 + e0 + u;
-            const float r = kind == 0 ? v[u] + a[u] : v[u] * a[u];
+            const float r = kind == 0 ? v[u] + a[u] : (kind == 1 ? v[u] * a[u] : a[u]);
             if (e0 + u < cnt && (uint32_t)i >= bc && colok)
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rsrcO, (int)voffO, (int)((uint32_t)i * strideO), 0);
           }
@@ -523,7 +523,7 @@ k_cut_classify(const float* __restrict__ x, int T, int64_t C, int64_t st, const 
       uint32_t soff = 0u;
 #pragma unroll
       for (int u = 0; u < CC_U; ++u) {
-        const float r = kind == 0 ? v[u] + a[u] : v[u] * a[u];
+        const float r = kind == 0 ? v[u] + a[u] : (kind == 1 ? v[u] * a[u] : a[u]);
         if (cvalid && kb * (CC_RL * CC_U) + u * CC_RL + rl < T)
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rsrcO, (int)voffO, (int)soff, 0);
         soff += rowstepO;

@@ -128,7 +128,7 @@ k_q3_ranks(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col_st
             a = (float)(slope * (pct - xs[lo - 1]) + (double)ylo);
           }
           const float raw = xc[t];
-          res = kind == 0 ? raw + a : raw * a;
+          res = kind == 0 ? raw + a : (kind == 1 ? raw * a : a);
         }
       }
       oc[t] = res;

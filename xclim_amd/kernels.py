@@ -644,7 +644,7 @@ def qdm_adjust(dev: Device, sim: DeviceArray, af: DeviceArray, q, kind="+", inte
     if np.any(np.diff(q) <= 0):
         raise ValueError("qdm_adjust: the quantile nodes must be strictly increasing")
     scen = out if out is not None else dev.empty(tuple(sim.shape), np.float32)
-    dev.call("xh_qdm_adjust", _vp(sim.ptr), T, C_, st, sc, _vp(af.ptr), np_ptr(q), len(q), {"+": 0, "*": 1}[kind],
+    dev.call("xh_qdm_adjust", _vp(sim.ptr), T, C_, st, sc, _vp(af.ptr), np_ptr(q), len(q), {"+": 0, "*": 1, "factor": 2}[kind],
              {"nearest": 0, "linear": 1}[interp], {"constant": 0, "nan": 1}[extrapolation], _vp(scen.ptr))
     return scen
 
@@ -690,4 +690,27 @@ def eqm_adjust_g2d(dev: Device, sim: DeviceArray, af_all: DeviceArray, hq_all: D
     scen = out if out is not None else dev.empty((n, C_), np.float32)
     dev.call("xh_eqm_adjust_g2d", _vp(sim.ptr), n, C_, C_, _vp(af_all.ptr), _vp(hq_all.ptr), G, nq, int(gcoord),
              {"+": 0, "*": 1, "factor": 2}[kind], {"constant": 0, "nan": 1}[extrapolation], _vp(scen.ptr), C_)
+    return scen
+
+
+def plane_linear(dev: Device, xnew: DeviceArray, gnew, yq_all: DeviceArray, *, xq_all: DeviceArray | None = None, xq_common=None,
+                 base: DeviceArray | None = None, kind="+", out: DeviceArray | None = None) -> DeviceArray:
+    """xh_plane_linear: xsdba's 2-D ``interp_on_quantiles(method="linear")`` (Delaunay interpolation over the nodes of all
+    groups, constant extrapolation).  xnew (T, C) abscissa of every step, gnew (T) float64 group coordinate (host or
+    device), yq_all (G, nq, C) factors, node abscissae ``xq_all`` (G, nq, C) or ``xq_common`` (nq, host: QDM's quantiles);
+    ``base`` (T, C): the values the factor is applied to (default xnew); kind "+" | "*" | "factor"."""
+    T, C_ = _tc(xnew)
+    G, nq = int(yq_all.shape[0]), int(yq_all.shape[1])
+    if (xq_all is None) == (xq_common is None):
+        raise ValueError("plane_linear: give xq_all or xq_common")
+    gd = gnew if isinstance(gnew, DeviceArray) else dev.to_device(np.ascontiguousarray(gnew, dtype=np.float64))
+    if int(gd.shape[0]) != T:
+        raise ValueError("plane_linear: one group coordinate per time step")
+    qc = None if xq_common is None else np.ascontiguousarray(xq_common, dtype=np.float64)
+    if qc is not None and len(qc) != nq:
+        raise ValueError("plane_linear: xq_common must hold one abscissa per node")
+    scen = out if out is not None else dev.empty((T, C_), np.float32)
+    dev.call("xh_plane_linear", _vp(xnew.ptr), _vp(base.ptr) if base is not None else None, T, C_, C_, _vp(gd.ptr),
+             _vp(xq_all.ptr) if xq_all is not None else None, np_ptr(qc) if qc is not None else None, _vp(yq_all.ptr), G, nq,
+             {"+": 0, "*": 1, "factor": 2}[kind], _vp(scen.ptr), C_)
     return scen

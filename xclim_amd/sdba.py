@@ -68,6 +68,16 @@ class Grouper:
             return self._SEASON_OF_MONTH[np.asarray(time.month)]
         return np.asarray(time.doy)
 
+    def coordinate(self, time, interp: bool = False) -> np.ndarray:
+        """xsdba ``Grouper.get_index(da, interp=...)``: the group coordinate of every time step as float64.  With
+        ``interp=True`` (every interpolation but "nearest") the month becomes fractional — ``month - 0.5 + day /
+        days_in_month``, the middle of a month on its integer — and the day of year stays an integer."""
+        if self.prop == "month" and interp:
+            return time.month - 0.5 + time.day / time.days_in_month()
+        if self.prop in ("month", "dayofyear"):
+            return np.asarray(self.values(time), dtype=np.float64)
+        raise NotImplementedError(f"group coordinate of {self.name!r}")
+
     def labels(self, time) -> np.ndarray:
         """Group coordinate values present on `time` (months 1..12 / days of year / season names), sorted like xarray's
         groupby sorts them (the seasons alphabetically: DJF, JJA, MAM, SON)."""
@@ -100,12 +110,29 @@ class Grouper:
         return out
 
 
-def _check_group_interp(group: "Grouper", interp: str, who: str) -> None:
-    """Sub-groupings interpolate over (quantile, group) in xsdba when interp != "nearest" — not built: refuse loudly."""
-    if group.prop != "group" and interp != "nearest":
+def _check_group_interp(group: "Grouper", interp: str, who: str, labels=None, extrapolation: str = "constant") -> None:
+    """Sub-groupings interpolate over the (quantile, group) PLANE in xsdba when interp != "nearest"
+    (``utils.interp_on_quantiles`` -> ``_interp_on_quantiles_2D`` = ``scipy.interpolate.griddata``).  Built: "linear"
+    (Delaunay interpolation, ``xh_plane_linear``) for month / day-of-year groupings whose labels are 1 .. G, with
+    ``extrapolation="constant"``.  Refused loudly: "cubic" (griddata's Clough-Tocher scheme estimates gradients by a global
+    iteration over the whole triangulation), "time.season" (upstream's season coordinate is not restated),
+    ``extrapolation="nan"`` with "linear" (upstream then skips its extrapolation step and keeps griddata's own NaN outside
+    the convex hull of ALL nodes — a different region than the per-group bounds)."""
+    if group.prop == "group" or interp == "nearest":
+        return
+    if interp == "cubic":
         raise NotImplementedError(
-            f"{who}: interp={interp!r} with group={group.name!r} needs xsdba's 2-D interpolation over (quantile, group), "
-            "which is not built; use interp='nearest' (or group='time')")
+            f"{who}: interp='cubic' with group={group.name!r} is scipy griddata's Clough-Tocher interpolation over the "
+            "(quantile, group) plane in xsdba — not built; use 'linear' or 'nearest' (or group='time')")
+    lab = None if labels is None else np.asarray(labels)
+    if group.prop not in ("month", "dayofyear") or lab is None or not np.array_equal(lab, np.arange(1, len(lab) + 1)):
+        raise NotImplementedError(
+            f"{who}: interp={interp!r} over the (quantile, group) plane is built for 'time.month' / 'time.dayofyear' groupings "
+            f"whose labels are 1 .. G (got group={group.name!r})")
+    if extrapolation != "constant":
+        raise NotImplementedError(
+            f"{who}: interp={interp!r} with a sub-grouping is built for extrapolation='constant' (with 'nan' xsdba keeps "
+            "griddata's NaN outside the convex hull of all nodes)")
 
 
 def equally_spaced_nodes(n: int, eps=None) -> np.ndarray:
@@ -257,13 +284,17 @@ class EmpiricalQuantileMapping:
         """``grouped_nearest`` (sub-groupings only): "griddata" (default) = what xsdba does — the nearest node in the (hist_q,
         group) PLANE over the nodes of all groups (``_interp_on_quantiles_2D``: a neighbouring group's node wins where the own
         group's nearest node is more than one unit away), own-group factors outside the own group's nodes; "group" = always
-        the nearest node of the step's own group (rounds 2-3).  "time.season" and groupings whose labels are not 1 .. G take
-        "group" (upstream's season coordinate is not restated)."""
+        the nearest node of the step's own group (rounds 2-3).  "time.season", groupings whose labels are not 1 .. G and
+        models with more than 32 quantile nodes (a warning is raised) take "group" (upstream's season coordinate is not
+        restated; the plane kernel keeps a group's nodes in registers).
+
+        ``interp="linear"`` with a month / day-of-year grouping is xsdba's interpolation over the (quantile, group) plane
+        (``xh_plane_linear``; :func:`_check_group_interp`): months at their fractional coordinate, days of year on their row."""
         if interp not in ("nearest", "linear", "cubic"):
             raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
         if grouped_nearest not in ("griddata", "group"):
             raise ValueError("grouped_nearest must be 'griddata' or 'group'")
-        _check_group_interp(self.group, interp, "EmpiricalQuantileMapping.adjust")
+        _check_group_interp(self.group, interp, "EmpiricalQuantileMapping.adjust", self.group_labels, extrapolation)
         s, cell_shape = _flatten(sim, self._dev)
         if tuple(cell_shape) != self.cell_shape:
             raise ValueError("sim does not match the trained grid")
@@ -276,6 +307,11 @@ class EmpiricalQuantileMapping:
         gi = self.group.index(time, self.group_labels)
         if (gi < 0).any():
             raise ValueError("sim holds time steps whose group was not trained (e.g. day 366 with a 365-day training set)")
+        if interp == "linear":
+            # xsdba's 2-D branch: ONE launch over the whole series, every step at its (fractional) group coordinate
+            scen = K.plane_linear(dev, s, self.group.coordinate(time, interp=True), self._af, xq_all=self._hist_q, kind=self.kind)
+            dev.sync()
+            return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
         # group-major permutation of the rows: every group becomes one contiguous block
         perm = np.argsort(gi, kind="stable")
         counts = np.bincount(gi, minlength=len(self.group_labels))
@@ -307,8 +343,17 @@ class EmpiricalQuantileMapping:
         """xsdba's 2-D nearest applies: a month / day-of-year grouping whose labels are 1 .. G (the coordinates upstream's
         add_cyclic_bounds extends to 0 and G + 1) and at most 32 nodes."""
         lab = self.group_labels
-        return (grouped_nearest == "griddata" and self.group.prop in ("month", "dayofyear") and len(self.quantiles) <= 32
-                and np.array_equal(lab, np.arange(1, len(lab) + 1)))
+        ok = (grouped_nearest == "griddata" and self.group.prop in ("month", "dayofyear")
+              and np.array_equal(lab, np.arange(1, len(lab) + 1)))
+        if ok and len(self.quantiles) > 32:
+            import warnings
+
+            warnings.warn(f"grouped interp='nearest' with {len(self.quantiles)} > 32 quantile nodes: xh_eqm_adjust_g2d keeps a "
+                          "group's nodes in registers (<= 32), so every step takes the nearest node of its OWN group "
+                          "(grouped_nearest='group') instead of xsdba's nearest node in the (quantile, group) plane",
+                          stacklevel=3)
+            return False
+        return ok
 
     def _shape(self):
         lead = (len(self.quantiles),) if self.group.prop == "group" else (len(self.group_labels), len(self.quantiles))
@@ -328,7 +373,8 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
     factor of a sim value is taken at ITS quantile in the sim series: ``sim_q = rank(sim, pct=True)``,
     ``af = interp_on_quantiles(sim_q, quantiles, af)``, ``scen = sim (+|*) af``.  With a sub-grouping the ranks are taken
     inside each group's own time steps (xsdba: ``group.apply(rank, sim, main_only=True)`` — the window only widens the
-    TRAINING sample) and every step uses the factors of its group (``interp="nearest"`` only, see the module docstring).
+    TRAINING sample) and every step uses the factors of its group ("nearest"), or the factors interpolated over the
+    (quantile, group) plane ("linear": see :meth:`adjust`).  ``interp="cubic"`` is not built.
 
     Series of up to 32768 steps are ranked inside one workgroup (``xh_qdm_adjust``: keys in registers); longer ones
     (1950-2100 daily = 55 152 steps) go through a global sort in column batches (qdm3.hip) — exact, not tuned.  -0.0
@@ -340,7 +386,7 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
             raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
         if interp == "cubic":
             raise NotImplementedError("QuantileDeltaMapping.adjust: interp='cubic' is not built (nearest, linear)")
-        _check_group_interp(self.group, interp, "QuantileDeltaMapping.adjust")
+        _check_group_interp(self.group, interp, "QuantileDeltaMapping.adjust", self.group_labels, extrapolation)
         dev = self._dev
         s, cell_shape = _flatten(sim, dev)
         if tuple(cell_shape) != self.cell_shape:
@@ -359,18 +405,35 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
         nq = len(self.quantiles)
         s_perm = K.select_rows(dev, s, perm)
         scen_perm = dev.empty((T, C_), np.float32)
+        # "linear" over the (quantile, group) plane (xsdba: interp_on_quantiles(sim_q, quantiles, af) with the quantile
+        # nodes THEMSELVES as abscissa, the same in every group: a regular grid).  Day of year: the group coordinate is an
+        # integer, every query lies ON its group's row, and the row's edges belong to every Delaunay triangulation of a grid
+        # whose node spacing (1 / nq) is below the row spacing (1) — the plane interpolation IS the 1-D linear interpolation
+        # inside the own group: the loop below.  Month: the coordinate is fractional; the percentage ranks come from the
+        # same rank kernels (kind "factor" on a table whose "factors" are the nodes themselves: sim_q clamped to the node
+        # range, which is all the plane needs — outside it the row-interpolated end factor applies), then one plane launch.
+        plane = interp == "linear" and self.group.prop == "month"
+        qrows = None
+        if plane:
+            qrows = dev.to_device(np.repeat(self.quantiles.astype(np.float32)[:, None], C_, axis=1))
         off = 0
         for g, n in enumerate(counts):
             if n == 0:
                 continue
             blk = dev.wrap(s_perm.ptr + off * C_ * 4, (int(n), C_), np.float32)
             out = dev.wrap(scen_perm.ptr + off * C_ * 4, (int(n), C_), np.float32)
-            af_g = dev.wrap(self._af.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
-            K.qdm_adjust(dev, blk, af_g, self.quantiles, self.kind, interp, extrapolation, out=out)
+            if plane:
+                K.qdm_adjust(dev, blk, qrows, self.quantiles, "factor", "linear", "constant", out=out)
+            else:
+                af_g = dev.wrap(self._af.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
+                K.qdm_adjust(dev, blk, af_g, self.quantiles, self.kind, interp, extrapolation, out=out)
             off += int(n)
         inv = np.empty(T, dtype=np.int64)
         inv[perm] = np.arange(T)
         scen = K.select_rows(dev, scen_perm, inv)
+        if plane:  # scen holds sim_q so far
+            scen = K.plane_linear(dev, scen, self.group.coordinate(time, interp=True), self._af, xq_common=self.quantiles, base=s,
+                                  kind=self.kind)
         dev.sync()
         return scen if keep else scen.get().reshape((T,) + self.cell_shape)
 
@@ -464,7 +527,7 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         """dqm_adjust with a sub-grouping (window 1): group-major row blocks like the grouped EQM; per block the group's
         scaling (``u.broadcast``), the trend fitted over the group's OWN steps on their time coordinate (days since the
         group's mean date: ``PolyDetrend(group=...)`` -> polyfit along time), the group's nodes, the trend put back."""
-        _check_group_interp(self.group, interp, "DetrendedQuantileMapping.adjust")
+        _check_group_interp(self.group, interp, "DetrendedQuantileMapping.adjust", self.group_labels, extrapolation)
         dev = self._dev
         if time is None or len(time) != s.shape[0]:
             raise ValueError(f"group={self.group.name!r} needs time=TimeAxis of sim")
@@ -476,6 +539,7 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         T, C_ = s.shape
         nq = len(self.quantiles)
         days = np.asarray(time.ordinal(), dtype=np.float64)
+        gcoord = self.group.coordinate(time, interp=True) if interp == "linear" else None
         s_perm = K.select_rows(dev, s, perm)
         scen_perm = dev.empty((T, C_), np.float32)
         off = 0
@@ -493,7 +557,9 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             scaled = K.trend_apply(dev, blk, sc_g, None, fwd)
             p0, p1 = K.poly_trend(dev, scaled, detrend, u=u)
             detr = K.trend_apply(dev, scaled, p0, p1, inv, u=u)
-            if self._plane_nearest(grouped_nearest):
+            if interp == "linear":
+                scen0 = K.plane_linear(dev, detr, gcoord[rows], self._af, xq_all=self._hist_q, kind=self.kind)
+            elif self._plane_nearest(grouped_nearest):
                 scen0 = K.eqm_adjust_g2d(dev, detr, self._af, self._hist_q, g + 1, self.kind, extrapolation)
             else:
                 scen0 = K.eqm_adjust(dev, detr, af_g, hq_g, self.kind, interp, extrapolation)

@@ -125,6 +125,13 @@ class TimeAxis:
                 y += 1
         return cls(years, months, days, calendar)
 
+    def days_in_month(self) -> np.ndarray:
+        """Length of every step's month (``DatetimeIndex.days_in_month``; cftime's ``daysinmonth``)."""
+        if self.calendar == "360_day":
+            return np.full(len(self), 30, dtype=np.int64)
+        n = _MLEN_NOLEAP[self.month - 1].astype(np.int64)
+        return n + ((self.month == 2) & _is_leap(self.year, self.calendar))
+
     def dates(self) -> np.ndarray:
         """The time coordinate itself (what ``coord=True`` returns in the reference, rl:586-593 -> utils.lazy_indexing):
         ``datetime64[ns]`` when every date of the calendar is a Gregorian date (standard, proleptic_gregorian, noleap);
