@@ -262,10 +262,14 @@ def make_env():
         """core/units.py:334-420 as far as the recorded index bodies need it: threshold STRINGS ("1 mm/day", "30 degC") in
         the units of ``data`` (tests/fakeunits.py, the hydro context is the bodies' ``units.context("hydro")``); numbers and
         DataArrays are taken to be in the data's units already."""
-        if isinstance(thr, str):
-            import fakeunits
+        import fakeunits
 
+        if isinstance(thr, str):
             return fakeunits.convert_units_to(thr, data.attrs["units"], context="hydro")
+        if isinstance(thr, DataArray) and isinstance(data, str):   # a FIELD into other units: convert_units_to(pr, "mm/d")
+            out = thr * np.float32(fakeunits.convert_units_to("1 " + thr.attrs["units"], data, context="hydro"))
+            out.attrs = dict(thr.attrs, units=data)
+            return out
         return thr
 
     def to_agg_units(out, orig, op, dim="time", **kw):
@@ -315,6 +319,16 @@ def make_reference_like_modules(env):
             setattr(m, n, getattr(gen, n))
         m.percentile_doy, m.resample_doy, m.rl = cal.percentile_doy, cal.resample_doy, rl
         m.convert_units_to, m.to_agg_units, m.units = env.convert_units_to, env.to_agg_units, units
+
+        def rate2amount(da, out_units=None):
+            """core/units.py rate2amount for DAILY fields: a rate per day times one day (the magnitude stays, the unit
+            loses its time part)"""
+            assert da.attrs["units"] in ("mm/d", "mm/day") and out_units == "mm"
+            out = da.copy()
+            out.attrs = dict(da.attrs, units="mm")
+            return out
+
+        m.rate2amount = rate2amount
         mods[modname] = m
     for name, prog in callprog.load_programs().items():
         m = mods[prog["module"]]

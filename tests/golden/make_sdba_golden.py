@@ -85,6 +85,14 @@ def main() -> int:
         out[f"eqmg_{tag}_af"] = eqm.ds.af.transpose(gdim, "quantiles", "lat", "lon").values
         out[f"eqmg_{tag}_hist_q"] = eqm.ds.hist_q.transpose(gdim, "quantiles", "lat", "lon").values
         out[f"eqmg_{tag}_scen"] = eqm.adjust(da(sim, "K"), interp="nearest").transpose("time", "lat", "lon").values
+        # round 5: interp="linear" = griddata over the (quantile, group) plane (utils.interp_on_quantiles, 2-D branch)
+        out[f"eqmg_{tag}_scen_linear"] = eqm.adjust(da(sim, "K"), interp="linear").transpose("time", "lat", "lon").values
+        qdm = QuantileDeltaMapping.train(da(ref, "K"), da(hist, "K"), nquantiles=15, kind="+", group=g)
+        out[f"qdmg_{tag}_scen_linear"] = qdm.adjust(da(sim, "K"), interp="linear").transpose("time", "lat", "lon").values
+    # precipitation in mm/d with a month grouping: node spacings of many group steps (triangles spanning several months)
+    g = xsdba.Grouper("time.month")
+    eqm = EmpiricalQuantileMapping.train(da(pr_ref, "mm/d"), da(pr_hist, "mm/d"), nquantiles=15, kind="*", group=g)
+    out["eqmg_month_pr_scen_linear"] = eqm.adjust(da(pr_sim, "mm/d"), interp="linear").transpose("time", "lat", "lon").values
 
     # adapt_freq (xsdba.processing.adapt_freq): pth and dP0 are deterministic; sim_ad draws its fill values from numpy's
     # global generator, so only the UNCHANGED samples of sim_ad (and which samples changed) can be pinned

@@ -414,7 +414,26 @@ def test_reference_call_programs_through_the_wrappers(ref, dev, rng):
     pp, _ = ocal.percentile_doy(prv, ot, 5, 70.0)
     got = mv.days_over_precip_thresh(pr, per_p)                   # pr_per.where(pr_per > thresh, thresh): float64 table, python-float floor
     np.testing.assert_array_equal(got.values, oidx.days_over_precip_thresh(prv, pp[..., 0], doys, ot, mm, "YS"))
-    assert len(progs) >= 25 and all(hasattr(mods[p["module"]], n) for n, p in progs.items())
+    # -- round 5: the call shapes no recorded body had used (tests/test_host_cpu.py lists all 19 of the reference)
+    np.testing.assert_array_equal(th.days_with_snow(pr, low="1 mm/day", high="20 mm/day", freq="YS").values,       # domain_count
+                                  ogen.domain_count(prv, np.float32(mm), np.float32(20 * mm), ot, "YS"))
+    got = mv.heat_wave_max_length(tasmin, tasmax, thresh_tasmin="10 degC", thresh_tasmax="24 degC", window=2)   # resample_and_rl(reducer=, window=)
+    np.testing.assert_array_equal(got.values, oidx.heat_wave_max_length(tn, tx, ot, np.float32(K0 + 10), np.float32(K0 + 24), 2))
+    for before in (True, False):                                         # spell_length_statistics, keywords only (+ **indexer)
+        got = th.dry_spell_frequency(pr, thresh="3 mm", window=3, resample_before_rl=before)
+        amount = (prv * np.float32(86400.0)).astype(np.float32)
+        np.testing.assert_array_equal(got.values, ogen.spell_length_statistics(amount, 3.0, 3, "sum", "<", "count", ot, "YS", before))
+    # recorded, checked for their call shapes on the CPU, NOT replayed here: their bodies also call functions of xarray /
+    # xclim the wrappers do not replace and the stand-in does not have (select_time, at_least_n_valid, DataArray.resample)
+    not_replayed = {"holiday_snow_and_snowfall_days", "holiday_snow_days", "snd_season_end", "rprctot",
+                    "growing_season_start", "first_day_temperature_above"}   # (the last two: test_season_and_first_day_...)
+    replayed = {"frost_days", "tg_mean", "tx_max", "tn_min", "tx_days_above", "tn_days_below", "dry_days", "wetdays",
+                "maximum_consecutive_dry_days", "maximum_consecutive_wet_days", "growing_degree_days", "cooling_degree_days",
+                "hot_spell_frequency", "hot_spell_max_length", "cold_spell_days", "growing_season_length", "heat_wave_frequency",
+                "tx_tn_days_above", "tx90p", "tn10p", "warm_spell_duration_index", "cold_spell_duration_index",
+                "days_over_precip_thresh", "days_with_snow", "heat_wave_max_length", "dry_spell_frequency"}
+    assert replayed | not_replayed == set(progs) and not (replayed & not_replayed)
+    assert len(progs) >= 32 and all(hasattr(mods[p["module"]], n) for n, p in progs.items())
     with pytest.raises(NotImplementedError, match="recorded program holds"):
         mv.days_over_precip_thresh(pr, per_p, bootstrap=True)       # the body is recorded for bootstrap=False (percentile_bootstrap stripped)
 

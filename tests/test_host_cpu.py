@@ -356,3 +356,59 @@ def test_call_programs_are_what_the_reference_bodies_do():
         stored = json.load(f)
     assert fresh == stored
     assert len(stored) >= 25 and all(p["source"].startswith("src/xclim/indices/") for p in stored.values())
+
+
+def _shape_key(name, npos, kws):
+    return f"{name}({npos}; {', '.join(sorted(k for k in kws if k != '**'))})" + (" + **indexer" if "**" in kws else "")
+
+
+def test_every_call_shape_of_a_replaced_function_is_recorded():
+    """which distinct (function, positional count, keyword set) shapes do the reference's index modules use
+    when they call a function ``patch.install`` replaces — and is each one exercised by a recorded call program (replayed
+    through the wrappers on the GPU box, tests/test_gpu_adapter.py) or explicitly listed as forwarded?  Walks
+    /root/reference/src/xclim/indices/{_threshold,_multivariate,_simple}.py with ``ast`` (128 call sites, 19 shapes)."""
+    import ast
+    import json
+
+    from xclim_amd.patch import _BY_NAME
+
+    ref = "/root/reference/src/xclim/indices"
+    if not os.path.isdir(ref):
+        pytest.skip("the reference tree only exists in the build container")
+    generic, rlnames = set(_BY_NAME["xclim.indices._multivariate"]), set(_BY_NAME["xclim.indices.run_length"])
+    sites = {}
+    for f in ("_threshold.py", "_multivariate.py", "_simple.py"):
+        with open(os.path.join(ref, f)) as fh:
+            tree = ast.parse(fh.read())
+        for fn in (n for n in tree.body if isinstance(n, ast.FunctionDef)):
+            for node in (n for n in ast.walk(fn) if isinstance(n, ast.Call)):
+                name = None
+                if isinstance(node.func, ast.Name) and node.func.id in generic:
+                    name = node.func.id
+                elif (isinstance(node.func, ast.Attribute) and isinstance(node.func.value, ast.Name) and node.func.value.id == "rl"
+                      and node.func.attr in rlnames):
+                    name = "rl." + node.func.attr
+                if name:
+                    key = _shape_key(name, len(node.args), [k.arg or "**" for k in node.keywords])
+                    sites.setdefault(key.replace(" + **indexer", ""), []).append(f"{f}:{fn.name}:{node.lineno}")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "call_programs.json")) as fh:
+        progs = json.load(fh)
+    recorded = {}
+    for idx, prog in progs.items():
+        vals = []
+        for op in prog["ops"]:
+            res = None
+            if op["op"] == "getattr" and op["obj"].get("g") == "rl":
+                res = "rl." + op["name"]
+            elif op["op"] == "call":
+                fn = op["fn"]
+                name = fn["g"] if fn.get("g") in generic else (vals[fn["v"]] if "v" in fn and isinstance(vals[fn["v"]], str) else None)
+                if name and (name in generic or name[3:] in rlnames):
+                    recorded.setdefault(_shape_key(name, len(op["args"]), list(op["kwargs"])), []).append(idx)
+            vals.append(res)
+    # shapes no recorded program exercises and the wrappers hand to the original instead (none at present)
+    forwarded = set()
+    missing = sorted(k for k in sites if k not in recorded and k not in forwarded)
+    assert not missing, {k: sites[k][:3] for k in missing}
+    assert len(sites) == 19 and sum(len(v) for v in sites.values()) == 128      # (the walk itself: a new reference version moves these)
+    assert not [k for k in recorded if k not in sites]

@@ -78,3 +78,27 @@ def test_rle_1d_matches_reference_njit_body():
     v, l, p = orl.rle_1d([0, 0, 1, 1, 1, 0, 0, 1, 1, 1, 1])  # fmt: skip
     np.testing.assert_array_equal(l, [2, 3, 2, 4])
     np.testing.assert_array_equal(p, [0, 2, 5, 7])
+
+
+def test_numba_quantile_mode_stays_within_the_bar():
+    """xsdba's jitted ``nbutils._quantile`` runs numba's np.nanquantile, whose lerp is
+    ``lower (1 - m) + upper m`` on ``rank = 1 + (n - 1) q`` — not numpy's ``_lerp`` that the oracle's contract mode (and the
+    kernels, bit for bit) follow.  Same order statistics, other rounding: on fields of the fixtures' size
+    (tests/golden/make_sdba_golden.py: 4 years x 3 x 4, temperature in K and precipitation in mm/d, 0.2 % NaN) the two
+    modes differ by at most a few float32 ulps — documented bound 2e-7 relative, a fifth of north_star's 1e-6."""
+    from oracle import sdba as osdba
+
+    rng = np.random.default_rng(20260926)
+    T, Y, X = 365 * 4, 3, 4
+    t = np.arange(T)[:, None, None]
+    temp = (288 + 12 * np.sin(2 * np.pi * (t - 100) / 365) + rng.normal(0, 3.0, (T, Y, X))).astype(np.float32)
+    temp[rng.random(temp.shape) < 0.002] = np.nan
+    pr = np.where(rng.random((T, Y, X)) < 0.3, rng.gamma(0.8, 8.0, (T, Y, X)), 0.0).astype(np.float32) + np.float32(1e-3)
+    worst = 0.0
+    for x in (temp, pr, temp[:365], pr[:31]):
+        for q in (osdba.equally_spaced_nodes(20), osdba.equally_spaced_nodes(15, eps=1e-6), np.array([0.0, 0.5, 1.0])):
+            a, b = osdba.quantile(x, q), osdba.quantile(x, q, mode="numba")
+            assert a.dtype == b.dtype == np.float32 and a.shape == b.shape
+            rel = np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(a), 1e-30)
+            worst = max(worst, float(rel.max()))
+    assert 0.0 < worst < 2e-7, worst   # (they DO differ: the bitwise GPU == oracle claim says nothing about upstream's last ulp)
