@@ -190,7 +190,8 @@ class DataArray:
         for k, v in kw.items():
             ax = out.dims.index(k)
             j = int(np.nonzero(out.coords[k].values == v)[0][0])
-            out = DataArray(np.take(out.values, j, axis=ax), coords={c: x for c, x in out.coords.items() if c != k},
+            # (a VIEW, like xarray's own basic indexing for a scalar label)
+            out = DataArray(out.values[(slice(None),) * ax + (j,)], coords={c: x for c, x in out.coords.items() if c != k},
                             dims=tuple(d for d in out.dims if d != k), name=out.name, attrs=out.attrs)
         return out
 

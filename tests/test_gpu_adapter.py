@@ -88,6 +88,58 @@ def test_tx90p_through_the_wrappers_reaches_the_doy_table_kernel(ref, dev, rng):
     assert not _calls(trace, "xh_doy_broadcast")              # the (T, Y, X) float64 threshold was never formed
 
 
+def test_inputs_and_tables_stay_on_the_device_across_wrapper_calls(ref, dev, rng):
+    """VERDICT r4 #5 (caller: the Indicator chain, /root/reference/src/xclim/core/indicator.py:865-944): percentile_doy and
+    the index that consumes its table read the SAME field — ONE PCIe transfer of the field (Device.resident: address +
+    owner + content fingerprint), and the per-doy table is taken from the device copy percentile_doy left behind instead
+    of being transposed and uploaded again (xr_adapter.remember_table).  Asserted on the launch log: one "h2d" of the
+    field, no "h2d" of the table, one "d2h" of the table (the DataArray percentile_doy must return)."""
+    env, mods, _ = ref
+    T = 365 * 3
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    x = _temp(rng, T, (24, 40), nan_frac=0.001)
+    tasmax = fakexr.field(x, ta)
+    cal, mv = mods["xclim.core.calendar"], mods["xclim.indices._multivariate"]
+    keep_min = dev._inputs_min
+    dev._inputs_min = 1 << 16          # (the default only remembers inputs of 32 MiB and more)
+    dev.forget_inputs()
+    try:
+        trace = dev.start_trace()
+        per = cal.percentile_doy(tasmax, window=5, per=[10.0, 90.0])
+        out90 = mv.tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
+        out10 = mv.tn10p(tasmax, per.sel(percentiles=10.0), freq="YS")
+        dev.stop_trace()
+        p_o, doys = ocal.percentile_doy(x, ot, 5, [10.0, 90.0])
+        np.testing.assert_array_equal(out90.values, oidx.tx90p(x, p_o[..., 1], doys, ot, "YS"))
+        np.testing.assert_array_equal(out10.values, oidx.tx10p(x, p_o[..., 0], doys, ot, "YS"))
+        table = 365 * 24 * 40 * 8
+        h2d = [a[0] for n, a in trace if n == "h2d"]
+        assert h2d.count(x.nbytes) == 1 and len([n for n, _ in trace if n == "resident_hit"]) == 2     # the field: once
+        assert table not in h2d and 2 * table not in h2d                                                # the tables: never
+        assert [a[0] for n, a in trace if n == "d2h"].count(2 * table) == 1
+        assert len(_calls(trace, "xh_threshold_count_doy")) == 2
+        # an edit in place is seen (every element of a field this small is sampled) -> a fresh upload, the right answer
+        x2 = tasmax.values
+        x2[100:130] += np.float32(15.0)
+        trace = dev.start_trace()
+        out = mv.tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
+        dev.stop_trace()
+        np.testing.assert_array_equal(out.values, oidx.tx90p(x2, p_o[..., 1], doys, ot, "YS"))
+        assert [a[0] for n, a in trace if n == "h2d"].count(x.nbytes) == 1
+        # ... and so is an edit of the percentile table the user holds: the device copy is not used for it
+        per.values[:, :, 180:200, 1] -= 5.0
+        trace = dev.start_trace()
+        out = mv.tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
+        dev.stop_trace()
+        pe = p_o[..., 1].copy()
+        pe[180:200] -= 5.0
+        np.testing.assert_array_equal(out.values, oidx.tx90p(x2, pe, doys, ot, "YS"))
+        assert table in [a[0] for n, a in trace if n == "h2d"]
+    finally:
+        dev._inputs_min = keep_min
+        dev.forget_inputs()
+
+
 def test_cdd_through_the_wrappers_is_the_fused_run_length_kernel(ref, dev, rng):
     env, mods, _ = ref
     T = 365 * 2

@@ -252,6 +252,8 @@ class DeviceArray:
         out = np.empty(self.shape, dtype=self.dtype)
         if out.size:
             lib = self.dev.lib
+            if self.dev.trace is not None:
+                self.dev.trace.append(("d2h", (out.nbytes,)))
             _check(lib, lib.xh_memcpy_d2h(self.dev.ctx, out.ctypes.data_as(_vp), _vp(self.ptr), out.nbytes))
         return out
 
@@ -286,6 +288,11 @@ class Device:
         self._pool_bytes = 0
         self._pool_cap = int(os.environ.get("XCLIM_AMD_POOL_BYTES", str(32 << 30)))
         self._pinned: dict[int, int] = {}  # page-locked host ranges we own or registered: address -> bytes
+        # device copies of large host inputs, recognised again across calls (resident())
+        self._inputs: dict = {}
+        self._inputs_bytes = 0
+        self._inputs_cap = int(os.environ.get("XCLIM_AMD_INPUT_CACHE_BYTES", str(64 << 30)))
+        self._inputs_min = int(os.environ.get("XCLIM_AMD_INPUT_CACHE_MIN", str(32 << 20)))
 
     # ---- memory ----
     def empty(self, shape, dtype) -> DeviceArray:
@@ -383,8 +390,85 @@ class Device:
         arr = np.ascontiguousarray(arr, dtype=dtype)
         d = self.empty(arr.shape, arr.dtype)
         if arr.nbytes:
+            if self.trace is not None:
+                self.trace.append(("h2d", (arr.nbytes,)))
             _check(self.lib, self.lib.xh_memcpy_h2d(self.ctx, _vp(d.ptr), arr.ctypes.data_as(_vp), arr.nbytes))
         return d
+
+    # ---- device-resident inputs across calls (the caller of the wrappers is the Indicator chain,
+    # /root/reference/src/xclim/core/indicator.py:865-944: percentile_doy and the index that consumes its table read the
+    # SAME field, and so do an index and the missing-value check after it) ----
+    @staticmethod
+    def _host_fingerprint(flat: np.ndarray):
+        """Guard against a buffer edited in place between two calls: the bit patterns of ~2^16 evenly spaced samples plus
+        the first and last 4096 elements, summed as integers (every element of arrays up to 2^16 elements; ~0.5 ms on a
+        1.5 GB field against 27 ms for its upload — 2^20 samples cost 4-5 ms per call, a page miss each).  An
+        edit that touches none of the samples is NOT seen: after writing into a field in place call
+        :meth:`forget_inputs` (or set XCLIM_AMD_INPUT_CACHE_BYTES=0)."""
+        n = flat.size
+        step = max(1, n >> 16)
+        u = flat.view(np.uint32 if flat.dtype.itemsize == 4 else np.uint64)
+        return (n, int(u[::step].sum(dtype=np.uint64)), int(u[:4096].sum(dtype=np.uint64)), int(u[-4096:].sum(dtype=np.uint64)))
+
+    def resident(self, arr: np.ndarray) -> DeviceArray:
+        """Device copy of a C-contiguous float32 / float64 host array.  Large arrays (>= XCLIM_AMD_INPUT_CACHE_MIN bytes,
+        default 32 MiB) are remembered by (address, shape, dtype) together with a weak reference to the object that owns
+        the memory and a content fingerprint; the next call with the same buffer gets the SAME device memory (a view: the
+        kernels only read their inputs) instead of another PCIe transfer.  The cache holds at most
+        XCLIM_AMD_INPUT_CACHE_BYTES (default 64 GiB, 0 = off), least recently used first out, and an entry dies with its
+        host array."""
+        import weakref
+
+        if (not isinstance(arr, np.ndarray) or not arr.flags.c_contiguous or arr.nbytes < self._inputs_min
+                or arr.nbytes > self._inputs_cap or arr.dtype not in (np.float32, np.float64)):
+            return self.to_device(arr)
+        owner = arr
+        while isinstance(owner.base, np.ndarray):
+            owner = owner.base
+        if owner.base is not None:
+            owner = owner.base  # (a buffer object under the outermost ndarray: pinned memory of pinned_empty)
+        key = (arr.ctypes.data, arr.nbytes, arr.dtype.str)
+        fp = self._host_fingerprint(arr.reshape(-1))
+        with self.lock:
+            hit = self._inputs.get(key)
+            if hit is not None and hit[0]() is owner and hit[2] == fp:
+                self._inputs[key] = self._inputs.pop(key)  # most recently used last
+                if self.trace is not None:
+                    self.trace.append(("resident_hit", (arr.nbytes,)))
+                view = DeviceArray(self, hit[1].ptr, arr.shape, arr.dtype, owner=False)
+                view._owner = hit[1]
+                return view
+            if hit is not None:
+                self._drop_input(key)
+        try:
+            ref = weakref.ref(owner)
+        except TypeError:
+            return self.to_device(arr)
+        d = self.to_device(arr)
+        with self.lock:
+            while self._inputs and self._inputs_bytes + arr.nbytes > self._inputs_cap:
+                self._drop_input(next(iter(self._inputs)))
+            self._inputs[key] = (ref, d, fp)
+            self._inputs_bytes += arr.nbytes
+        weakref.finalize(owner, self._drop_input, key, id(d))
+        view = DeviceArray(self, d.ptr, arr.shape, arr.dtype, owner=False)
+        view._owner = d
+        return view
+
+    def _drop_input(self, key, only_id=None) -> None:
+        with self.lock:
+            hit = self._inputs.get(key)
+            if hit is None or (only_id is not None and id(hit[1]) != only_id):
+                return
+            del self._inputs[key]
+            self._inputs_bytes -= hit[1].nbytes
+        # (the device memory goes back to the pool when the last view of it is gone)
+
+    def forget_inputs(self) -> None:
+        """Drop every remembered input copy (after editing a field in place, or to give the memory back)."""
+        with self.lock:
+            self._inputs.clear()
+            self._inputs_bytes = 0
 
     def wrap(self, ptr: int, shape, dtype) -> DeviceArray:
         """Wrap foreign device memory (e.g. a torch tensor's data_ptr()) without taking ownership."""
@@ -413,6 +497,7 @@ class Device:
 
     def close(self):
         if self.ctx:
+            self.forget_inputs()
             self.trim()
             self.lib.xh_destroy(self.ctx)
             self.ctx = None

@@ -23,14 +23,21 @@ class DoyPercentile:
     def __init__(self, data: DeviceArray | None, doys, percentiles, cell_shape, attrs, host=None, device=None):
         """``host``: the same table on the host, (nper, ndoy, *cells) float64 — what the xarray adapter holds when the table
         came in as a DataArray; with it the device copy is made on first use (``data``) and cell blocks of a chunked field
-        get their own slab (:meth:`block`)."""
+        get their own slab (:meth:`block`).  A callable is evaluated on first use (the adapter recognised the table of an
+        earlier ``percentile_doy`` call on the device: its host form is only needed for chunked fields)."""
         self._data = data
-        self.host = host
+        self._host = host
         self._dev = device
         self.dayofyear = np.asarray(doys)
         self.percentiles = np.asarray(percentiles, dtype=np.float64)
         self.cell_shape = tuple(cell_shape)
         self.attrs = dict(attrs)
+
+    @property
+    def host(self):
+        if callable(self._host):
+            self._host = self._host()
+        return self._host
 
     @property
     def data(self) -> DeviceArray:
@@ -84,9 +91,13 @@ def _flatten(arr, dev, f64: bool = False):
         return arr.reshape(arr.shape[0], -1), cell_shape
     a = np.asarray(arr)
     cell_shape = a.shape[1:]
+    # large float32 / float64 fields are recognised again across calls (Device.resident): percentile_doy and the index that
+    # consumes its table, an index and the missing-value check after it read the same buffer — one PCIe transfer, not two
     if f64 and a.dtype == np.float64:
-        return dev.to_device(a.reshape(a.shape[0], -1)), cell_shape
+        return dev.resident(a.reshape(a.shape[0], -1)) if a.flags.c_contiguous else dev.to_device(a.reshape(a.shape[0], -1)), cell_shape
     handle_float64(a, "field")
+    if a.dtype == np.float32 and a.flags.c_contiguous:
+        return dev.resident(a.reshape(a.shape[0], -1)), cell_shape
     return dev.to_device(a.reshape(a.shape[0], -1), dtype=np.float32), cell_shape
 
 

@@ -304,6 +304,50 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
             return None
         return hit[1]
 
+    # ---- per-doy tables stay on the device between percentile_doy and the index that consumes them ------------------------
+    # percentile_doy must hand back a real DataArray (anything may touch it), so its table is downloaded once — but the
+    # device copy is remembered under the host array the DataArray holds.  ``resample_doy(per.sel(percentiles=90), tasmax)``
+    # (what tx90p / tn10p / the spell-duration indices do with it, indices/_multivariate.py) receives a VIEW of that array:
+    # same owner object, the offset and strides of one percentile -> the table is taken from the device instead of being
+    # transposed and uploaded again (3 GB for a 1440 x 720 grid).  Guarded like the input cache: weak reference to the
+    # owner + the bit patterns of three day-of-year rows.
+    table_cache = {}
+
+    def _owner_of(v):
+        while isinstance(getattr(v, "base", None), np.ndarray):
+            v = v.base
+        return v
+
+    def _rows_fingerprint(tv):
+        n = tv.shape[0]
+        rows = np.ascontiguousarray(tv[sorted({0, n // 2, n - 1})])
+        return int(rows.view(np.uint64).sum(dtype=np.uint64)) if rows.dtype == np.float64 else None
+
+    def remember_table(vals, p):
+        """vals: the host array (ndoy, *cells, nper) the returned DataArray is built on; p: the device DoyPercentile."""
+        owner = _owner_of(vals)
+        try:
+            ref = weakref.ref(owner)
+        except TypeError:
+            return
+        if len(table_cache) > 8:
+            table_cache.clear()
+        table_cache[id(owner)] = (ref, vals, p, [_rows_fingerprint(vals[..., j]) for j in range(vals.shape[-1])])
+
+    def recall_table(tv):
+        """tv: (ndoy, *cells) float64 view.  -> device DoyPercentile of that one percentile, or None."""
+        owner = _owner_of(tv)
+        hit = table_cache.get(id(owner))
+        if hit is None or hit[0]() is not owner:
+            return None
+        _, vals, p, fps = hit
+        for j in range(vals.shape[-1]):
+            cand = vals[..., j]
+            if (cand.shape == tv.shape and cand.strides == tv.strides and cand.ctypes.data == tv.ctypes.data
+                    and fps[j] is not None and fps[j] == _rows_fingerprint(tv)):
+                return p.sel(p.percentiles[j])
+        return None
+
     def wrap_periods(a, data, freq, attrs=None, name=None):
         """(P, *cells) -> DataArray(time = period labels of the reference's own resample, *cell dims)."""
         labels = a["time"].resample(time=freq).first()["time"]
@@ -530,6 +574,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
 
         if x is not None:
             vals = one(x, None)
+            remember_table(vals, meta["p"])
         else:  # chunked: block by block (the reference: apply_ufunc(dask="parallelized") after time: -1, cal:460-479)
             vals = None
             for idx in chunk_index(a):
@@ -557,8 +602,16 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         cd = _cell_dims(a)
         if set(doy.dims) != {"dayofyear", *cd}:
             return fallback("resample_doy", doy, arr)
-        table = np.ascontiguousarray(doy.transpose("dayofyear", *cd).values, dtype=np.float64)
+        tv = doy.transpose("dayofyear", *cd).values
         d = dev()
+        known = recall_table(tv) if isinstance(tv, np.ndarray) and tv.dtype == np.float64 else None
+        if known is not None:
+            # the table of an earlier percentile_doy call, still on the device; its host form (a copy when the view is not
+            # contiguous) is only made if a chunked field asks for slabs
+            dp = hcal.DoyPercentile(known.data, np.asarray(doy["dayofyear"].values), [np.nan], tv.shape[1:], dict(doy.attrs),
+                                    host=lambda: np.ascontiguousarray(tv, dtype=np.float64)[None], device=d)
+            return DoyThreshold(env, dp, arr, time_axis_of(a), d)
+        table = np.ascontiguousarray(tv, dtype=np.float64)
         # the table stays on the host until a kernel wants it: whole (in-memory field) or slab by slab (chunked field)
         dp = hcal.DoyPercentile(None, np.asarray(doy["dayofyear"].values), [np.nan], table.shape[1:], dict(doy.attrs),
                                 host=table[None], device=d)
