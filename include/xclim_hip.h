@@ -478,6 +478,11 @@ int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
  * hq_all (G, nq, C); gcoord in 1 .. G; kind 0 (+) | 1 (*) | 2 (factor only).  Parity unpinned. */
 int xh_eqm_adjust_g2d(xh_ctx* ctx, const float* sim, int64_t n, int64_t C, int64_t st, const float* af_all, const float* hq_all,
                       int G, int nq, int gcoord, int kind, int extrap, float* scen, int64_t scen_st);
+/* xsdba.utils.apply_correction(base, fac, kind) on two fields of one shape (upstream xsdba, re-exported by
+ * /root/reference/src/xclim/sdba.py:10): out = base + fac (kind 0) | base * fac (kind 1); (T, C) views with row strides st,
+ * fst, out_st.  Used where the factor was interpolated on another abscissa than the field itself (QDM "cubic"). */
+int xh_apply_factor(xh_ctx* ctx, const float* base, const float* fac, int64_t T, int64_t C, int64_t st, int64_t fst, int kind,
+                    float* out, int64_t out_st);
 /* interp = "linear" with a month / day-of-year Grouper: xsdba.utils.interp_on_quantiles' 2-D branch (upstream xsdba,
  * re-exported by /root/reference/src/xclim/sdba.py:10; the documented standard use, /root/reference/docs/sdba.rst:64-65,
  * /root/reference/CHANGELOG.rst:338): scipy griddata(method="linear") = barycentric interpolation on the Delaunay

@@ -450,11 +450,23 @@ def dqm_adjust_grouped(sim, time, prop, labels, af, hist_q, scaling, kind="+", e
     out = np.full(sim.shape, np.nan, dtype=np.float32)
     gv = group_values(time, prop)
     days = np.arange(sim.shape[0], dtype=np.float64)  # (a DAILY series: the day number up to an origin)
+    scaled_all = None
+    if interp != "nearest" and prop != "dayofyear":
+        # u.broadcast(scaling, sim, group=group, interp=interp): the scaling interpolated over the group coordinate
+        # (add_cyclic_bounds, DataArray.interp "linear"); "nearest" and day-of-year groupings take the group's own value
+        G = len(labels)
+        gc = group_index(time, prop, True)
+        ext = np.concatenate([[G - 1], np.arange(G), [0]])
+        sc = np.asarray(scaling, dtype=np.float64).reshape(G, -1)[ext]
+        r0 = np.clip(np.floor(gc).astype(int), 0, G)
+        f = (gc - r0)[:, None]
+        sc_t = (sc[r0] + (sc[r0 + 1] - sc[r0]) * f).reshape(sim.shape)
+        scaled_all = _corr(sim, sc_t, kind)
     for g, lab in enumerate(labels):
         rows = np.nonzero(gv == lab)[0]
         if not rows.size:
             continue
-        scaled = _corr(sim[rows], scaling[g], kind)
+        scaled = _corr(sim[rows], scaling[g], kind) if scaled_all is None else scaled_all[rows]
         u = days[rows] - days[rows].mean()
         trend = poly_trend_u(scaled, u, detrend)
         detr = _corr(scaled, trend, kind, True)

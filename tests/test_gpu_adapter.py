@@ -118,7 +118,7 @@ def test_inputs_and_tables_stay_on_the_device_across_wrapper_calls(ref, dev, rng
         assert table not in h2d and 2 * table not in h2d                                                # the tables: never
         assert [a[0] for n, a in trace if n == "d2h"].count(2 * table) == 1
         assert len(_calls(trace, "xh_threshold_count_doy")) == 2
-        # an edit in place is seen (every element of a field this small is sampled) -> a fresh upload, the right answer
+        # an edit in place is seen (30 whole rows: one element in 16 of a field this size is sampled) -> a fresh upload, the right answer
         x2 = tasmax.values
         x2[100:130] += np.float32(15.0)
         trace = dev.start_trace()

@@ -478,6 +478,19 @@ static int quantile_series_core(xh_ctx* ctx, const float* x, int64_t T, int64_t 
   return XH_OK;
 }
 
+// utils.apply_correction on two fields of one shape: out = base + fac | base * fac (the factor came out of an interpolation
+// whose abscissa is not the field itself: QDM "cubic", where it is the percentage rank)
+__global__ void __launch_bounds__(XH_BLOCK)
+k_apply_factor(const float* __restrict__ base, const float* __restrict__ fac, int64_t T, int64_t C, int64_t st, int64_t fst, int kind,
+               float* __restrict__ out, int64_t ost) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  for (int64_t t = blockIdx.y; t < T; t += gridDim.y) {
+    const float b = base[t * st + c], a = fac[t * fst + c];
+    out[t * ost + c] = kind == 0 ? b + a : b * a;
+  }
+}
+
 extern "C" {
 
 int xh_quantile_series(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* q, int nq,
@@ -590,6 +603,22 @@ int xh_eqm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
     if (interp == 0) XH_ADJ(64, 0); else XH_ADJ(64, 1);
   }
 #undef XH_ADJ
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+// apply_correction(base, fac, kind) for two (T, C) fields (row strides st, fst, out_st)
+int xh_apply_factor(xh_ctx* ctx, const float* base, const float* fac, int64_t T, int64_t C, int64_t st, int64_t fst, int kind,
+                    float* out, int64_t out_st) {
+  XH_REQUIRE(ctx && base && fac && out, XH_ERR_ARG, "xh_apply_factor: NULL argument");
+  XH_REQUIRE(T >= 0 && C >= 0 && st >= C && fst >= C && out_st >= C, XH_ERR_LAYOUT, "xh_apply_factor: needs time-major views");
+  XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "xh_apply_factor: kind must be 0 (+) or 1 (*)");
+  if (T == 0 || C == 0) return XH_OK;
+  const int64_t cblocks = cdiv64(C, XH_BLOCK);
+  int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
+  gy = gy < 1 ? 1 : (gy > T ? T : (gy > 4096 ? 4096 : gy));
+  hipLaunchKernelGGL(k_apply_factor, dim3((unsigned)cblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, base, fac, T, C, st, fst, kind,
+                     out, out_st);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

@@ -714,3 +714,11 @@ def plane_linear(dev: Device, xnew: DeviceArray, gnew, yq_all: DeviceArray, *, x
              _vp(xq_all.ptr) if xq_all is not None else None, np_ptr(qc) if qc is not None else None, _vp(yq_all.ptr), G, nq,
              {"+": 0, "*": 1, "factor": 2}[kind], _vp(scen.ptr), C_)
     return scen
+
+
+def apply_factor(dev: Device, base: DeviceArray, fac: DeviceArray, kind="+", out: DeviceArray | None = None) -> DeviceArray:
+    """xh_apply_factor: base (+|*) fac, two (T, C) float32 fields."""
+    T, C_ = _tc(base)
+    out = out if out is not None else dev.empty((T, C_), np.float32)
+    dev.call("xh_apply_factor", _vp(base.ptr), _vp(fac.ptr), T, C_, C_, C_, {"+": 0, "*": 1}[kind], _vp(out.ptr), C_)
+    return out

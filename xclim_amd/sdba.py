@@ -11,19 +11,25 @@ an odd ``window`` (xsdba: the samples of a group are the centred ``window`` days
 the same sample sets as ``percentile_doy``).  Training gathers each group's rows (``xh_select_rows``) and runs the
 per-column multi-quantile kernels on them; ``af`` / ``hist_q`` get a leading group axis ``(group, quantiles, *cells)``.
 ``adjust`` maps every time step with the factors of ITS group (rows are permuted group-major once, one ``xh_eqm_adjust``
-launch per group on a contiguous row block, one gather back).  With a sub-grouping only ``interp="nearest"`` is accepted:
-for "linear" / "cubic" xsdba interpolates over the (quantile, group) PLANE (``utils.interp_on_quantiles`` ->
-``_interp_on_quantiles_2D``: ``scipy.interpolate.griddata`` with a fractional group index), which is not built — an
-interpolation along the quantile axis inside each group would silently differ from it and jump at the group boundaries,
-so those calls raise ``NotImplementedError`` (:func:`_check_group_interp`).  "nearest" with a month / day-of-year grouping
+launch per group on a contiguous row block, one gather back).  For "linear" xsdba interpolates over the (quantile, group)
+PLANE (``utils.interp_on_quantiles`` -> ``_interp_on_quantiles_2D``: ``scipy.interpolate.griddata`` with a fractional group
+index — the documented standard use, docs/sdba.rst:64-65, CHANGELOG.rst:338): built since round 5 for month / day-of-year
+groupings (``xh_plane_linear``: the Delaunay triangle of every step is located by a walk, no triangulation is stored; one
+launch over the whole series); "cubic" with a sub-grouping (griddata's Clough-Tocher scheme) raises
+``NotImplementedError`` (:func:`_check_group_interp`) — an interpolation along the quantile axis inside each group would
+silently differ from it.  "nearest" with a month / day-of-year grouping
 follows xsdba since round 4: ``griddata(method="nearest")`` in the (hist_q, group coordinate) plane over the nodes of ALL
 groups — where the own group's nearest node is more than one unit away a node of a NEIGHBOURING group can win — and the
 own group's end factors outside its nodes (``xh_eqm_adjust_g2d``; ``grouped_nearest="group"`` restores the own-group rule of
 rounds 2-3, which "time.season" still uses).
 
-:class:`QuantileDeltaMapping` (``group="time"``): trained like EQM; ``adjust`` looks the factor up at the QUANTILE of every
-sim value within the sim series itself (``rank(sim, pct=True)``), so that the simulated change of every quantile is
-preserved — ``xh_qdm_adjust`` ranks each column exactly (average ranks, NaN skipped) and interpolates in fp64.
+:class:`QuantileDeltaMapping` (``group="time"`` or a sub-grouping: the ranks are then taken inside each group's own steps):
+trained like EQM; ``adjust`` looks the factor up at the QUANTILE of every sim value within the sim series itself
+(``rank(sim, pct=True)``), so that the simulated change of every quantile is preserved — ``xh_qdm_adjust`` ranks each column
+exactly (average ranks, NaN skipped) and interpolates in fp64 ("nearest", "linear"; "cubic" for ``group="time"``: the
+not-a-knot spline of the EQM path over the quantile nodes).  :class:`DetrendedQuantileMapping`: ``group="time"`` or a
+sub-grouping without a window; with "linear" and a month grouping the scaling is interpolated over the group coordinate
+like xsdba's ``u.broadcast`` does.
 
 PARITY UNPINNED like everything xsdba (oracle/sdba.py).
 """
@@ -374,7 +380,8 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
     ``af = interp_on_quantiles(sim_q, quantiles, af)``, ``scen = sim (+|*) af``.  With a sub-grouping the ranks are taken
     inside each group's own time steps (xsdba: ``group.apply(rank, sim, main_only=True)`` — the window only widens the
     TRAINING sample) and every step uses the factors of its group ("nearest"), or the factors interpolated over the
-    (quantile, group) plane ("linear": see :meth:`adjust`).  ``interp="cubic"`` is not built.
+    (quantile, group) plane ("linear": see :meth:`adjust`).  ``interp="cubic"`` is built for ``group="time"`` (a spline
+    over the quantile nodes, <= 32 of them); with a sub-grouping it is xsdba's 2-D griddata "cubic": refused.
 
     Series of up to 32768 steps are ranked inside one workgroup (``xh_qdm_adjust``: keys in registers); longer ones
     (1950-2100 daily = 55 152 steps) go through a global sort in column batches (qdm3.hip) — exact, not tuned.  -0.0
@@ -384,13 +391,24 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
     def adjust(self, sim, *, interp: str = "nearest", extrapolation: str = "constant", time=None, keep=False):
         if interp not in ("nearest", "linear", "cubic"):
             raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
-        if interp == "cubic":
-            raise NotImplementedError("QuantileDeltaMapping.adjust: interp='cubic' is not built (nearest, linear)")
         _check_group_interp(self.group, interp, "QuantileDeltaMapping.adjust", self.group_labels, extrapolation)
         dev = self._dev
         s, cell_shape = _flatten(sim, dev)
         if tuple(cell_shape) != self.cell_shape:
             raise ValueError("sim does not match the trained grid")
+        if self.group.prop == "group" and interp == "cubic":
+            # interp_on_quantiles(sim_q, quantiles, af, method="cubic"): scipy interp1d(kind="cubic") over the quantile nodes —
+            # the rank kernels give sim_q (kind "factor" on a table whose factors are the nodes themselves, "linear": the
+            # rank itself inside the node range; outside it the first / last node for "constant" — where the spline returns
+            # the end factor exactly as interp1d's fill_value does — or NaN), the not-a-knot spline of the EQM path
+            # (xh_eqm_adjust, interp 2) evaluates the factor there, xh_apply_factor puts it onto sim
+            if len(self.quantiles) > 32:
+                raise NotImplementedError("QuantileDeltaMapping.adjust: interp='cubic' supports at most 32 quantile nodes")
+            qrows = dev.to_device(np.repeat(self.quantiles.astype(np.float32)[:, None], s.shape[1], axis=1))
+            sim_q = K.qdm_adjust(dev, s, qrows, self.quantiles, "factor", "linear", extrapolation)
+            af_t = K.eqm_adjust(dev, sim_q, self._af, qrows, "factor", "cubic", extrapolation)
+            scen = K.apply_factor(dev, s, af_t, self.kind, out=sim_q)
+            return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
         if self.group.prop == "group":
             scen = K.qdm_adjust(dev, s, self._af, self.quantiles, self.kind, interp, extrapolation)
             return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
@@ -540,7 +558,38 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         nq = len(self.quantiles)
         days = np.asarray(time.ordinal(), dtype=np.float64)
         gcoord = self.group.coordinate(time, interp=True) if interp == "linear" else None
-        s_perm = K.select_rows(dev, s, perm)
+        src = s
+        prescaled = interp == "linear" and self.group.prop == "month"
+        if prescaled:
+            # xsdba: u.broadcast(scaling, sim, group=group, interp=interp) — for every interpolation but "nearest" (and every
+            # grouping but the day of year) the scaling of a step is INTERPOLATED over the group coordinate (cyclic copies at
+            # 0 and G + 1, DataArray.interp "linear"): scaling_t = S[r0] + (S[r0 + 1] - S[r0]) (g_t - r0).  Steps are handled
+            # interval by interval of the coordinate (G + 1 of them): x OP (p0 + p1 u) is xh_trend_apply_u.
+            G = len(self.group_labels)
+            S = self._scaling.get().reshape(G, C_)
+            r0 = np.clip(np.floor(gcoord).astype(np.int64), 0, G)
+            row = lambda r: (r - 1) % G                                  # coordinate 0 .. G + 1 -> group (cyclic)
+            perm2 = np.argsort(r0, kind="stable")
+            cnt2 = np.bincount(r0, minlength=G + 1)
+            s_p2 = K.select_rows(dev, s, perm2)
+            sc_p2 = dev.empty((T, C_), np.float32)
+            o2 = 0
+            for r in range(G + 1):
+                n2 = int(cnt2[r])
+                if n2 == 0:
+                    continue
+                rows2 = perm2[o2:o2 + n2]
+                a0, a1 = S[row(r)], S[row(r + 1)]
+                p0 = dev.to_device(np.ascontiguousarray(a0), dtype=np.float64)
+                p1 = dev.to_device(np.ascontiguousarray(a1 - a0), dtype=np.float64)
+                uf = dev.to_device(np.ascontiguousarray(gcoord[rows2] - r), dtype=np.float64)
+                K.trend_apply(dev, dev.wrap(s_p2.ptr + o2 * C_ * 4, (n2, C_), np.float32), p0, p1, fwd,
+                              out=dev.wrap(sc_p2.ptr + o2 * C_ * 4, (n2, C_), np.float32), u=uf)
+                o2 += n2
+            inv2 = np.empty(T, dtype=np.int64)
+            inv2[perm2] = np.arange(T)
+            src = K.select_rows(dev, sc_p2, inv2)
+        s_perm = K.select_rows(dev, src, perm)
         scen_perm = dev.empty((T, C_), np.float32)
         off = 0
         for g, n in enumerate(counts):
@@ -554,7 +603,7 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             sc_g = dev.wrap(self._scaling.ptr + g * C_ * 8, (C_,), np.float64)
             af_g = dev.wrap(self._af.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
             hq_g = dev.wrap(self._hist_q.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
-            scaled = K.trend_apply(dev, blk, sc_g, None, fwd)
+            scaled = blk if prescaled else K.trend_apply(dev, blk, sc_g, None, fwd)
             p0, p1 = K.poly_trend(dev, scaled, detrend, u=u)
             detr = K.trend_apply(dev, scaled, p0, p1, inv, u=u)
             if interp == "linear":
