@@ -203,6 +203,8 @@ size_t q3_al(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // bytes of workspace for `ncols` columns of T steps (ncols * T < 2^31)
 int xh_qdm_sorted_ws(int64_t T, int64_t ncols, size_t* bytes) {
+  XH_REQUIRE(T >= 1 && ncols >= 1 && ncols * T < (1ll << 31), XH_ERR_LIMIT, "xh_qdm_sorted_ws: batch of %lld x %lld samples too large",
+             (long long)ncols, (long long)T);
   size_t tmp = 0;
   const uint32_t* k = nullptr;
   uint32_t* ko = nullptr;
@@ -259,6 +261,7 @@ int xh_adapt_freq(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   XH_REQUIRE(T >= 1 && T < (1ll << 27) && C >= 0, XH_ERR_ARG, "xh_adapt_freq: bad shape (1 <= T < 2^27)");
   if (C == 0) return XH_OK;
   auto run = [&](const float* cols, int64_t n, int64_t cs, int64_t c0, float* o, int64_t ocs, void* ws) -> int {
+    XH_REQUIRE(n * T < (1ll << 31), XH_ERR_LIMIT, "xh_adapt_freq: batch of %lld x %lld samples too large", (long long)n, (long long)T);
     const size_t ne = (size_t)(n * T);
     char* p = (char*)ws;
     uint32_t* kin = (uint32_t*)p; p += q3_al(4 * ne);
@@ -287,6 +290,8 @@ int xh_adapt_freq(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
   int64_t batch = (1ll << 26) / Tp;  // 64 M samples per batch: ~1.3 GB of sort workspace
   batch = (batch / 128) * 128;
   if (batch < 128) batch = 128;
+  // the sort and the rank kernel index a batch with 32-bit offsets: very long series get fewer than 128 columns per batch
+  while (batch > 1 && batch * Tp >= (1ll << 31)) batch >>= 1;
   if (batch > C) batch = C;
   size_t wsb = 0;
   int rc = xh_qdm_sorted_ws(T, batch, &wsb);
