@@ -579,8 +579,11 @@ def bench_full_configs(dev, K, C, long_series=True):
     if fused is not None:
         msf = event_time(dev, lambda: K.percentile_doy_count(dev, tas, tb, 5, 90.0, ">", period, P, out=(cnt, val)), 2)
         bf = 4 * E + 8 * P * C
-        out["tx90p_30yr_fused"] = {"ms": msf, "GB/s": bf / msf / 1e6, "frac": bf / msf / 1e6 / HBM_PEAK_GBS,
+        out["tx90p_30yr_one_call"] = {"ms": msf, "GB/s": bf / msf / 1e6, "frac": bf / msf / 1e6 / HBM_PEAK_GBS,
                                    "cell-timesteps/s": E / msf * 1e3, "algorithmic_bytes": bf,
+                                   "note": "xh_percentile_doy_count on a multi-year base period is ONE CALL, not one fused kernel (the 1-year "
+                                           "form, extra.tx90p_fused, is): table kernel into scratch, then the count kernel (key renamed in round 5: "
+                                           "was tx90p_30yr_fused)",
                                    "roofline": hbm_roofline(bf, msf, "xh_percentile_doy_count = k_pdoy_quad<32, false> into scratch + k_tc_doy<0, false>",
                                                             passes="the samples cross HBM twice (table kernel, count kernel) + the (D, C) fp64 scratch table once each way: 8E + 16DC bytes for 4E algorithmic")}
     for a in (per, cnt, val):
@@ -607,8 +610,18 @@ def bench_full_configs(dev, K, C, long_series=True):
                                                         "k_hs_sample<4>", "k_hs_hist<8, 5, false>", "k_hs_collect<8, 5, false>")),
                                                     traffic_source=PMC_30YR),
                      "roofline_adjust": hbm_roofline(8 * E, ms_ad, "k_eqm_adjust<20, 0>")}
+    # ---- QDM adjust at the realistic size (VERDICT r4 #3c): 30 years, full grid, "nearest" — the exact-rank kernel that keeps a
+    #      column in one workgroup (k_qdm_columns, T <= 32768) behind 128 x 128 transposes
+    ms_q4 = event_time(dev, lambda: K.qdm_adjust(dev, sim, af, q, "+", "nearest", "constant", out=scen), 1)
+    out["qdm_c4"] = {"ms": ms_q4, "GB/s": 8 * E / ms_q4 / 1e6, "frac": 8 * E / ms_q4 / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes": 8 * E,
+                     "cell-timesteps/s": E / ms_q4 * 1e3, "config": "QuantileDeltaMapping.adjust on the grid of BASELINE configs[3]",
+                     "roofline": hbm_roofline(8 * E, ms_q4, "transposes + k_qdm_columns (qdm.hip: exact average ranks, column in registers + LDS)",
+                                              passes="sim is transposed to time-minor batches, ranked and mapped per column, transposed back: "
+                                                     "~24E bytes cross HBM for 8E algorithmic")}
     for a in (hist, sim, scen, af, hq):
         a.free()
+    out["eqm_doy_linear"] = bench_plane_linear(dev, K, C // 8)
+    out["c5_slab"] = bench_c5_slab(dev, K)
     if not long_series:
         return out
     # ---- 1950-2100 daily (55 152 steps: beyond the 32768-step column kernels) on a 1440 x 90 band of the grid: EQM train
@@ -631,6 +644,81 @@ def bench_full_configs(dev, K, C, long_series=True):
                       "roofline": hbm_roofline(8 * E, ms_qd, "transposes + k_q3_keys + rocprim segmented radix sort + k_q3_ranks (qdm3.hip)",
                                                passes="exact ranks through a global sort of (key, time index) pairs in column batches: not tuned")}
     for a in (hist, scen, af, hq):
+        a.free()
+    return out
+
+
+def bench_plane_linear(dev, K, Cb):
+    """EmpiricalQuantileMapping(group="time.dayofyear").adjust(interp="linear") — the documented standard configuration
+    (docs/sdba.rst:64-65): factors interpolated over the (quantile, day-of-year) plane, xh_plane_linear, on a 1440 x 90 band,
+    30 years.  Synthetic node tables (365 groups x 20 nodes per cell, a seasonal cycle + a per-cell offset), one launch
+    over the whole series.  Functional, not tuned: reported so that its speed is a number."""
+    from xclim_amd.timeaxis import TimeAxis
+
+    T, G, nq = 10950, 365, 20
+    ta = TimeAxis.daily("1981-01-01", T, "noleap")
+    g = np.asarray(ta.doy, dtype=np.float64)
+    rng = np.random.default_rng(5)
+    node = (288.0 + 12.0 * np.sin(2 * np.pi * (np.arange(G) - 100) / 365))[:, None] + 3.0 * np.sort(rng.normal(0, 1, (G, nq)), axis=1)
+    hq = (node[:, :, None] + rng.normal(0, 0.2, Cb)[None, None, :]).astype(np.float32)
+    af = (1.5 + 0.3 * rng.normal(0, 1, (G, nq)))[:, :, None].astype(np.float32) + np.zeros((1, 1, Cb), np.float32)
+    d_hq, d_af = dev.to_device(hq), dev.to_device(af)
+    del hq, af
+    sim = K.fill_synthetic(dev, T, Cb, 0, 6, seasonal_base(T), 3.3)
+    scen = dev.empty((T, Cb), np.float32)
+    gd = dev.to_device(g)
+    ms = event_time(dev, lambda: K.plane_linear(dev, sim, gd, d_af, xq_all=d_hq, kind="+", out=scen), 1)
+    E = float(T) * Cb
+    b = 8 * E + 2 * 4.0 * G * nq * Cb
+    res = {"ms": ms, "GB/s": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS, "cell-timesteps/s": E / ms * 1e3, "grid": [T, 1440, 90],
+           "algorithmic_bytes": b, "groups": G, "nodes": nq,
+           "roofline": hbm_roofline(b, ms, "k_plane_pack + k_plane_linear (plane.hip)",
+                                    passes="one lane per (step, cell): binary searches in the packed node tables (gathers from L2), "
+                                           "a Delaunay walk in fp64 — latency- and fp64-bound, not a streaming kernel")}
+    for a in (d_hq, d_af, sim, scen, gd):
+        a.free()
+    return res
+
+
+def bench_c5_slab(dev, K):
+    """The per-GPU work of BASELINE configs[4] (`--workload c5 --gpus 1`: tx90p + EQM train + adjust on ONE 360 x 1440 slab of
+    the 2880 x 1440 grid, 30 years) inside the default line — the N = 1 anchor of a future 8-GPU SCALE run lives in the
+    same file (VERDICT r4 #8).  No exchange (one rank)."""
+    from xclim_amd.timeaxis import TimeAxis
+
+    T, C = 10950, 360 * 1440
+    ta = TimeAxis.daily("1981-01-01", T, "noleap")
+    tb, years, doys = ta.doy_table()
+    seg, _ = ta.segments("YS")
+    P, D = len(seg) - 1, len(doys)
+    expected = ta.expected_count("YS")
+    base = seasonal_base(T)
+    tas = K.fill_synthetic(dev, T, C, 0, 2, base, 3.0)
+    ref = K.fill_synthetic(dev, T, C, 0, 4, base, 3.0)
+    hist = K.fill_synthetic(dev, T, C, 0, 5, base + np.float32(1.5), 3.3)
+    sim = K.fill_synthetic(dev, T, C, 0, 6, base + np.float32(3.5), 3.3)
+    scen = dev.empty((T, C), np.float32)
+    per = dev.empty((1, D, C), np.float64)
+    cnt, val = dev.empty((P, C), np.int32), dev.empty((P, C), np.int32)
+    res = dev.empty((P, C), np.float64)
+    af, hq = dev.empty((20, C), np.float32), dev.empty((20, C), np.float32)
+    tidx = dev.to_device(np.searchsorted(doys, ta.doy).astype(np.int32))
+    q = (np.arange(20) + 0.5) / 20
+
+    def step():
+        K.percentile_doy(dev, tas, tb, 5, [90.0], out=per)
+        K.threshold_count(dev, tas, ">", seg, doy_table=per.reshape(D, C), tidx=tidx, out=(cnt, val))
+        K.apply_missing_mask(dev, cnt, val, expected, out=res)
+        K.eqm_train(dev, ref, hist, q, "+", out=(af, hq))
+        K.eqm_adjust(dev, sim, af, hq, "+", "nearest", "constant", out=scen)
+
+    ms = event_time(dev, step, 3)
+    E = float(T) * C
+    b = (2 * (4 * E + 8 * D * C) + 8 * P * C) + 16 * E
+    out = {"ms": ms, "GB/s": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS, "cell-timesteps/s": E / ms * 1e3, "grid_per_gpu": [T, 360, 1440],
+           "algorithmic_bytes": b, "config": "BASELINE configs[4], one of the 8 slabs (= `bench.py --workload c5 --gpus 1`), no exchange",
+           "roofline": hbm_roofline(b, ms, "percentile_doy + threshold_count + missing mask + eqm_train + eqm_adjust")}
+    for a in (tas, ref, hist, sim, scen, per, cnt, val, res, af, hq, tidx):
         a.free()
     return out
 

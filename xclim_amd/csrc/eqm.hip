@@ -264,6 +264,25 @@ k_cubic_setup(const float* __restrict__ af, const float* __restrict__ hq, int nq
   for (int j = 0; j < nq; ++j) { wc[(int64_t)j * C + c] = 0.0; wd[(int64_t)j * C + c] = 0.0; }
   if (m < 4) { wm[c] = 0; return; }
   wm[c] = m;
+  {
+    // a non-finite factor among the nodes (x / 0 of a multiplicative mapping): scipy's banded solve spreads inf / NaN over the
+    // spline coefficients in a pattern that depends on LAPACK's elimination order and on the dtype it is handed (float64: NaN
+    // everywhere inside the node range).  Rule here: NaN everywhere inside the node range, the end factors outside it
+    // (interp1d's fill_value) — deterministic, and what scipy answers for float64 factors
+    bool finite = true;
+    for (int j = 0; j < m; ++j) {
+      const double yj = wy[(int64_t)j * C + c];
+      finite = finite && (yj - yj == 0.0);
+    }
+    if (!finite) {
+      for (int j = 0; j < m; ++j) {
+        wM[(int64_t)j * C + c] = xh_nan64();
+        wc[(int64_t)j * C + c] = xh_nan64();
+        wd[(int64_t)j * C + c] = xh_nan64();
+      }
+      return;
+    }
+  }
   auto X = [&](int i) { return wx[(int64_t)i * C + c]; };
   auto Y = [&](int i) { return wy[(int64_t)i * C + c]; };
   auto H = [&](int i) { return X(i + 1) - X(i); };
