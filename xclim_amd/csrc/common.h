@@ -90,6 +90,12 @@ int xh_qdm_sorted(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int
                   const double* d_q, int nq, int kind, int interp, int extrap, float* out, int64_t out_cs, void* ws);
 int xh_qdm_regsort(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, const float* af, int64_t af_qs,
                    const double* d_q, int nq, int kind, int extrap, float* scen, int64_t ost);
+int xh_cut_classify(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, const float* gcut, const float* gfac, int ntest,
+                    int kind, float* scen, int64_t ost);
+// select4.hip: QDM "nearest" on long time-major series (1024 < T <= 65535): class boundaries as order statistics from the
+// two-pass histogram selection, then one streaming classification pass; XH_ERR_NOTIMPL when the shape does not fit
+int xh_qdm_hist(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, const float* af, int64_t af_qs, const double* d_q,
+                int nq, int kind, int extrap, float* scen, int64_t ost);
 int xh_tcount_plan(int64_t T, int64_t C, int64_t st, int op, int P, int ndoy, int64_t longest, size_t* lds, int* narrow);
 int64_t xh_tcount_meta_slots(int64_t T);
 int64_t xh_tcount_slot_of_row(int64_t t);

@@ -322,6 +322,12 @@ int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
     rc = xh_qdm_regsort(ctx, sim, T, C, st, af, C, (const double*)d_q, nq, kind, extrap, scen, st);
     if (rc != XH_ERR_NOTIMPL) return rc;
   }
+  if (interp == 0 && !xh_diag_env("XH_QDM_FORCE_SORTED")) {
+    // long series (1024 < T <= 65535), nearest: class boundaries as order statistics from the two-pass histogram selection,
+    // then one streaming classification pass (select4.hip) — nothing transposed, nothing sorted globally
+    rc = xh_qdm_hist(ctx, sim, T, C, st, af, C, (const double*)d_q, nq, kind, extrap, scen, st);
+    if (rc != XH_ERR_NOTIMPL) return rc;
+  }
   // time-major: batches of columns through a transposed scratch, both ways (padded pitch: 256-byte aligned segments)
   int64_t Tp = (T + 63) & ~(int64_t)63;
   int64_t batch = (int64_t)((1ull << 28) / (sizeof(float) * (size_t)Tp));

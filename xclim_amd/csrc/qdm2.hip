@@ -553,6 +553,19 @@ k_qr_scatter(const float* __restrict__ buf, int64_t T, int64_t Tp, const uint32_
 
 }  // namespace
 
+// scen = sim (+|*) fac[class], class = number of cut values <= sim: the streaming second half of the QDM "nearest" path, also
+// behind the two-pass histogram selection of select4.hip (xh_qdm_hist).  gcut (ntest, C), gfac (ntest + 1, C).
+int xh_cut_classify(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, const float* gcut, const float* gfac, int ntest,
+                    int kind, float* scen, int64_t ost) {
+  const size_t lds2 = sizeof(float) * (size_t)(2 * ntest + 1) * CC_CW;
+  const int64_t ct = cdiv64(C, CC_CW);
+  const int64_t cg = ct < (int64_t)ctx->num_cu * 8 ? ct : (int64_t)ctx->num_cu * 8;
+  hipLaunchKernelGGL(k_cut_classify, dim3((unsigned)cg), dim3(CC_NT), lds2, ctx->stream, sim, (int)T, C, st, gcut, gfac, ntest, kind, scen,
+                     ost);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
 // XH_OK: scen written.  XH_ERR_NOTIMPL (no error text): not this kernel's shape, the caller runs the exact-rank pipeline.
 int xh_qdm_regsort(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, const float* af, int64_t af_qs,
                    const double* d_q, int nq, int kind, int extrap, float* scen, int64_t ost) {
@@ -598,12 +611,8 @@ int xh_qdm_regsort(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t 
                      scen, ost, flist, nflag, abl, gcut, gfac);
   XH_LAUNCH_CHECK();
   if (split && !(abl & 32)) {
-    const size_t lds2 = sizeof(float) * (size_t)(2 * (nq + 1) + 1) * CC_CW;
-    const int64_t ct = cdiv64(C, CC_CW);
-    const int64_t cg = ct < (int64_t)ctx->num_cu * 8 ? ct : (int64_t)ctx->num_cu * 8;
-    hipLaunchKernelGGL(k_cut_classify, dim3((unsigned)cg), dim3(CC_NT), lds2, ctx->stream, sim, (int)T, C, st, gcut, gfac, nq + 1, kind, scen,
-                       ost);
-    XH_LAUNCH_CHECK();
+    rc = xh_cut_classify(ctx, sim, T, C, st, gcut, gfac, nq + 1, kind, scen, ost);
+    if (rc) return rc;
   }
   uint32_t nf = 0;
   XH_CHECK_HIP(hipMemcpyAsync(&nf, nflag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

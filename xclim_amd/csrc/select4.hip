@@ -48,6 +48,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "qdmrank.h"
 
 namespace {
 
@@ -82,7 +83,8 @@ struct HsStat {
 // x - lo is +0 iff x == lo (IEEE: a difference of finite floats never rounds to zero; denormals are kept, the kernel
 // descriptor says float_denorm_mode_32 = 3), so the classes are exact whatever the rounding of f.  lo and hi are finite
 // (k_hs_sample clamps them to +-FLT_MAX: x = -inf then is "below lo", inf - inf never happens for a non-NaN sample).
-// Zeros of both signs are ONE value here (x - lo = +0 for either); the integer keys of round 3 ordered -0 below +0.
+// Zeros of both signs are ONE value here (hs_scale turns a zero window end into -0.0: x - (-0.0) = +0 for either zero); the
+// integer keys of round 3 ordered -0 below +0.
 // NaN samples do not pass through hs_bin in pass 1 (see the NaN sum) and land on f = 0 in pass 2's table look-up.
 struct HsScale {
   float lof, hif, scale;
@@ -92,6 +94,11 @@ __device__ __forceinline__ HsScale hs_scale(uint32_t lo, uint32_t hi) {
   HsScale s;
   s.lof = xh_key2f(lo);
   s.hif = xh_key2f(hi);
+  // a window end that is a zero becomes NEGATIVE zero: x - (-0.0) = x + (+0.0) is +0 for both zeros, whereas -0.0 - (+0.0)
+  // is -0.0, whose bits read as "negative" in hs_sgn — the two zeros of a column would land in different bins (harmless for
+  // a quantile, wrong for the runs of equal values the QDM boundaries follow; found by tools/fuzz_r05.py, round 5)
+  if (s.lof == 0.0f) s.lof = -0.0f;
+  if (s.hif == 0.0f) s.hif = -0.0f;
   const float d = s.hif - s.lof;
   float sc = 0.0f;
   if (d > 0.0f) sc = (float)((double)HS_NREG * 1.000001 / (double)d);  // (hi - lo) * scale >= 1020: hi lands on f = 1019
@@ -385,7 +392,24 @@ struct HsArgs {
   int64_t ocs, oqs;
   HsStat* __restrict__ stat;
   int abl;
+  // QDM mode (xh_qdm_hist): the targets are the class boundaries of QuantileDeltaMapping "nearest" (qdmrank.h); pass 1 also
+  // tracks the column's minimum and maximum (two VALU per sample), pass 2 counts their copies (four) — the ranks of the
+  // boundaries depend on them, and collecting the open-ended tail bins instead (1.2 % of the samples each) doubled the
+  // candidates and cost a second collect round; pass 1 leaves two RECORDS per target (its bin and the next non-empty bin: global rank of the
+  // bin's first sample | samples in the bin, offset of the bin's keys in the candidate list | kind), pass 2's epilogue turns
+  // them into cut values (gcut) and class factors (gfac)
+  int qdm;
+  const float* __restrict__ af;   // (nq, C) factors, row stride af_qs; a NaN factor drops its node
+  int64_t af_qs;
+  int extrap;
+  uint32_t* __restrict__ qrec;    // [tile][2 * (nq + 1)][2][64]
+  float* __restrict__ colmin;     // (C) smallest / largest valid sample of the column (pass 1); pass 2 counts their copies
+  float* __restrict__ colmax;
+  float* __restrict__ gcut;       // (nq + 1, C)
+  float* __restrict__ gfac;       // (nq + 2, C)
 };
+
+constexpr uint32_t HS_REC_REG = 0u, HS_REC_LO = 1u, HS_REC_HI = 2u, HS_REC_NONE = 0xFFFFu;
 
 // 128-bit clears of n words (n a multiple of 4 * NT is not required)
 __device__ __forceinline__ void hs_clear(uint32_t* p, int n, int tid) {
@@ -395,7 +419,7 @@ __device__ __forceinline__ void hs_clear(uint32_t* p, int n, int tid) {
 
 // One tile of pass 1.  The caller primed the ring for this tile (rows forward); the histogram and the bitmap are zero on
 // entry (cleared at the end of the previous tile, or by the caller) and zero again on return when `clear_after`.
-template <int HS_U, int NSET>
+template <int HS_U, int NSET, bool QDM>
 __device__ __forceinline__ void hs_hist_tile(const HsArgs& A, HsRing<HS_U, NSET>& ring, unsigned char* smem, int64_t tile, bool clear_after) {
   constexpr int CW = HS_CW, NT = HS_NT;
   const float* __restrict__ x = A.x;
@@ -434,11 +458,20 @@ __device__ __forceinline__ void hs_hist_tile(const HsArgs& A, HsRing<HS_U, NSET>
     uint32_t* mycol = h32 + 2 * 32 + (col >> 1);
     const uint32_t one = cvalid ? (1u << sh16) : 0u;
     float dummy = 0.0f;
+    float vmn = __uint_as_float(0x7F800000u), vmx = __uint_as_float(0xFF800000u);  // QDM: the column's extremes (NaN ignored)
+    constexpr bool qdm = QDM;  // (a template parameter: the quantile kernels do not carry the extra code in their loops)
     ring.run(x, T, st, cc, rl, [&](const float (&v)[HS_U]) {
       if (abl & 2) {  // diagnostics: loads only
 #pragma unroll
         for (int u = 0; u < HS_U; ++u) dummy += v[u];
         return;
+      }
+      if (qdm) {  // (block-uniform) v_min / v_max return the other operand for a NaN one; inline asm: fminf canonicalises both inputs first
+#pragma unroll
+        for (int u = 0; u < HS_U; ++u) {
+          asm("v_min_f32 %0, %0, %1" : "+v"(vmn) : "v"(v[u]));
+          asm("v_max_f32 %0, %0, %1" : "+v"(vmx) : "v"(v[u]));
+        }
       }
       // (groups of four samples between scheduling barriers: with all 16 in flight at once the temporaries of the bin
       // arithmetic push the register sets of the streaming ring out into scratch)
@@ -459,6 +492,23 @@ __device__ __forceinline__ void hs_hist_tile(const HsArgs& A, HsRing<HS_U, NSET>
     if ((abl & 2) && dummy == 0.12345f) atomicAdd(&stat->errors, 1u);
     __syncthreads();
     if (abl & 4) return;  // diagnostics: no tile epilogue (wrong results, the histogram is not even cleared)
+    if (qdm) {  // the extremes of the 16 row lanes of a column -> colmin / colmax (through `part`, which the prefix sums use next)
+      float* pf = reinterpret_cast<float*>(part);
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        pf[rl * CW + col] = h ? vmx : vmn;
+        __syncthreads();
+        if (rl == 0 && cvalid) {
+          float m = pf[col];
+          for (int r = 1; r < HS_RL; ++r) {
+            const float o = pf[r * CW + col];
+            m = h ? (o > m ? o : m) : (o < m ? o : m);
+          }
+          (h ? A.colmax : A.colmin)[c] = m;
+        }
+        __syncthreads();
+      }
+    }
     // ---- exclusive prefix sums over the bins, in place and PACKED (two columns per word; every half stays <= T <= 65535):
     // thread (pw, prt) owns the words of bins [prt * 32, prt * 32 + 32) of column pair pw
     uint32_t ssum = 0;
@@ -492,23 +542,90 @@ __device__ __forceinline__ void hs_hist_tile(const HsArgs& A, HsRing<HS_U, NSET>
       return (myh[b * 32] >> sh16) & 0xFFFFu;
     };
     const uint32_t binL = hs_bin(s.lof, s), binH = hs_bin(s.hif, s);  // the pure bins
-    // ---- the bin and the rank inside it of every target; mark the bins that need a second look
-    for (int j = rl; j < ntgt; j += HS_RL) {
-      uint32_t e = HS_SPEC_NONE;
-      if (n > 0u && !(abl & 128)) {
-        const uint32_t r = hs_rank(n, qs[j >> 1], j & 1);
-        uint32_t lo_b = 0u, hi_b = HS_NB - 1;  // largest b with below(b) <= r: that bin holds rank r
+    auto bin_of_rank = [&](uint32_t r) -> uint32_t {  // largest b with below(b) <= r: that bin holds rank r
+      uint32_t lo_b = 0u, hi_b = HS_NB - 1;
 #pragma unroll 1
-        for (int it = 0; it < 10; ++it) {
-          const uint32_t mid = (lo_b + hi_b + 1u) >> 1;
-          const bool le = below(mid) <= r;
-          lo_b = le ? mid : lo_b;
-          hi_b = le ? hi_b : mid - 1u;
-        }
-        e = lo_b | ((r - below(lo_b)) << 16);
-        if (lo_b != binL && lo_b != binH) atomicOr(&bm[(lo_b >> 5) * CW + col], 1u << (lo_b & 31u));
+      for (int it = 0; it < 10; ++it) {
+        const uint32_t mid = (lo_b + hi_b + 1u) >> 1;
+        const bool le = below(mid) <= r;
+        lo_b = le ? mid : lo_b;
+        hi_b = le ? hi_b : mid - 1u;
       }
-      tgt[j * CW + col] = e;
+      return lo_b;
+    };
+    auto mark = [&](uint32_t b) {
+      if (b != binL && b != binH) atomicOr(&bm[(b >> 5) * CW + col], 1u << (b & 31u));
+    };
+    // ---- the bin and the rank inside it of every target; mark the bins that need a second look
+    if (!QDM) {
+      for (int j = rl; j < ntgt; j += HS_RL) {
+        uint32_t e = HS_SPEC_NONE;
+        if (n > 0u && !(abl & 128)) {
+          const uint32_t r = hs_rank(n, qs[j >> 1], j & 1);
+          const uint32_t lo_b = bin_of_rank(r);
+          e = lo_b | ((r - below(lo_b)) << 16);
+          mark(lo_b);
+        }
+        tgt[j * CW + col] = e;
+      }
+    } else {
+      // QDM: targets 0 .. nq = the class boundaries (rank from qdm_min_r2 with the copies of the minimum / maximum ESTIMATED
+      // from the histogram: exact when the extreme value has a pure bin to itself — the dry days —, 1 otherwise; pass 2
+      // counts them, recomputes, and flags the column if a rank then leaves the collected bins).
+      // tgt = bin | successor bin << 16: the next non-empty bin is collected too when the
+      // target's bin is pure or the target is its last sample (the cut may be the next distinct value, qdmrank.h).
+      uint8_t* idx = reinterpret_cast<uint8_t*>(tgt + 40 * CW);  // [nq][CW] node index of the j-th valid node
+      uint32_t* nvc = tgt + 50 * CW;                             // [CW] valid nodes of the column
+      if (rl == 0) {
+        uint32_t cnt = 0;
+#pragma unroll 1
+        for (int j0 = 0; j0 < nq; j0 += 8) {
+          float a[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = A.af[(int64_t)(j0 + u < nq ? j0 + u : nq - 1) * A.af_qs + cc];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (j0 + u < nq && a[u] == a[u]) { idx[cnt * CW + col] = (uint8_t)(j0 + u); ++cnt; }
+        }
+        nvc[col] = cnt;
+      }
+      __syncthreads();
+      const uint32_t nvn = nvc[col];
+      uint32_t c0e = 1u, cme = 1u;
+      if (n > 0u) {
+        const uint32_t fb = bin_of_rank(0u), lb = bin_of_rank(n - 1u);
+        if (fb == binL || fb == binH) c0e = below(fb + 1u) - below(fb);
+        if (lb == binL || lb == binH) cme = below(lb + 1u) - below(lb);
+      }
+      const bool stok = n > 0u && nvn >= 2u && c0e < n;
+      const int ntest = nq + 1;
+      for (int j = rl; j < ntest; j += HS_RL) {
+        uint32_t r = 0xFFFFFFFFu;
+        if (n > 0u) {
+          if (stok && (uint32_t)j <= nvn) {
+            double thr;
+            if (j == 0) thr = qs[idx[col]];
+            else if ((uint32_t)j == nvn) thr = qs[idx[(nvn - 1u) * CW + col]];
+            else thr = qs[idx[(j - 1) * CW + col]] / 2.0 + qs[idx[j * CW + col]] / 2.0;
+            const uint32_t R = qdm_min_r2(j == 0, thr, n, c0e, cme);
+            if (R <= 2u * n) r = qdm_pos_of_r2(R);
+            if (r >= n) r = 0xFFFFFFFFu;
+          }
+        }
+        uint32_t e = HS_SPEC_NONE | (HS_SPEC_NONE << 16);
+        if (r != 0xFFFFFFFFu) {
+          const uint32_t b = bin_of_rank(r);
+          mark(b);
+          uint32_t sb = HS_SPEC_NONE;
+          const uint32_t endb = below(b + 1u);
+          if ((b == binL || b == binH || r + 1u == endb) && endb < n) {
+            sb = bin_of_rank(endb);
+            mark(sb);
+          }
+          e = b | (sb << 16);
+        }
+        tgt[j * CW + col] = e;
+      }
     }
     __syncthreads();
     // ---- candidates below each target: keys of the marked bins, words [2 rl, 2 rl + 1] of the bitmap per thread
@@ -560,23 +677,46 @@ __device__ __forceinline__ void hs_hist_tile(const HsArgs& A, HsRing<HS_U, NSET>
     __syncthreads();
     const uint32_t mybase = cbase[col];
     const bool flagged = mybase == HS_FLAGGED;
-    for (int j = rl; j < ntgt; j += HS_RL) {
-      const uint32_t e = tgt[j * CW + col];
-      uint32_t cr = HS_SPEC_NONE;
-      if (e != HS_SPEC_NONE && !(abl & 256)) {
-        const uint32_t b = e & 0xFFFFu, o = e >> 16;
-        if (b == binL) cr = HS_SPEC_LO;
-        else if (b == binH) cr = HS_SPEC_HI;
-        else {
-          const int w = (int)(b >> 5);
-          uint32_t mp = 0;
-          for (int r = 0; r < (w >> 1); ++r) mp += part[r * CW + col];
-          if (w & 1) mp += marked_below(w - 1, 32u);
-          mp += marked_below(w, b & 31u);
-          cr = mp + o;
+    auto list_offset_of = [&](uint32_t b) -> uint32_t {  // keys of the marked bins below bin b
+      const int w = (int)(b >> 5);
+      uint32_t mp = 0;
+      for (int r = 0; r < (w >> 1); ++r) mp += part[r * CW + col];
+      if (w & 1) mp += marked_below(w - 1, 32u);
+      mp += marked_below(w, b & 31u);
+      return mp;
+    };
+    if (!QDM) {
+      for (int j = rl; j < ntgt; j += HS_RL) {
+        const uint32_t e = tgt[j * CW + col];
+        uint32_t cr = HS_SPEC_NONE;
+        if (e != HS_SPEC_NONE && !(abl & 256)) {
+          const uint32_t b = e & 0xFFFFu, o = e >> 16;
+          if (b == binL) cr = HS_SPEC_LO;
+          else if (b == binH) cr = HS_SPEC_HI;
+          else cr = list_offset_of(b) + o;
+        }
+        if (cvalid) crank[(tile * ntgt + j) * CW + col] = (uint16_t)cr;
+      }
+    } else {
+      const int nrec = 2 * (nq + 1);
+      for (int j = rl; j < nq + 1; j += HS_RL) {
+        const uint32_t e = tgt[j * CW + col];
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t b = h ? e >> 16 : e & 0xFFFFu;
+          uint32_t w0 = 0u, w1 = HS_REC_NONE << 16;
+          if (b != HS_SPEC_NONE) {
+            w0 = below(b) | ((below(b + 1u) - below(b)) << 16);
+            if (b == binL) w1 = HS_REC_LO << 16;
+            else if (b == binH) w1 = HS_REC_HI << 16;
+            else w1 = list_offset_of(b) | (HS_REC_REG << 16);
+          }
+          if (cvalid) {
+            A.qrec[((tile * nrec + 2 * j + h) * 2 + 0) * CW + col] = w0;
+            A.qrec[((tile * nrec + 2 * j + h) * 2 + 1) * CW + col] = w1;
+          }
         }
       }
-      if (cvalid) crank[(tile * ntgt + j) * CW + col] = (uint16_t)cr;
     }
     if (rl == 0 && cvalid) {
       meta_n[c] = n;
@@ -627,7 +767,7 @@ __device__ __forceinline__ void hs_hist_tile(const HsArgs& A, HsRing<HS_U, NSET>
   }
 }
 
-template <int HS_U, int NSET>
+template <int HS_U, int NSET, bool QDM>
 __global__ void __launch_bounds__(HS_NT, 4)
 k_hs_hist(HsArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -641,7 +781,7 @@ k_hs_hist(HsArgs A) {
     if (tile < 0) break;  // (block-uniform; only in the last round)
     const int64_t c = tile * HS_CW + col;
     ring.prime(A.x, A.T, A.st, c < A.C ? c : A.C - 1, rl);
-    hs_hist_tile<HS_U, NSET>(A, ring, smem, tile, true);
+    hs_hist_tile<HS_U, NSET, QDM>(A, ring, smem, tile, true);
   }
 }
 
@@ -706,12 +846,14 @@ __device__ __forceinline__ void hs_wave_sort(uint32_t (&v)[K], int lane) {
 }
 
 template <int K>
-__device__ __forceinline__ void hs_sort_column(uint32_t* __restrict__ list, uint32_t m, int lane) {
+__device__ __forceinline__ void hs_sort_column(uint32_t* __restrict__ list, uint32_t m, int lane, float zero) {
   uint32_t v[K];
 #pragma unroll
   for (int r = 0; r < K; ++r) {
     const uint32_t i = (uint32_t)(lane * K + r);
-    v[r] = i < m ? hs_key(__uint_as_float(list[i])) : HS_NANKEY;  // the list holds the raw floats of pass 2
+    // the list holds the raw floats of pass 2.  `zero` = +0.0 (QDM: -0.0 + 0.0 = +0.0, the two zeros are ONE value when
+    // ranks are counted, scipy.stats.rankdata) or -0.0 (quantiles: x + -0.0 = x bit for bit)
+    v[r] = i < m ? hs_key(__uint_as_float(list[i]) + zero) : HS_NANKEY;
   }
   hs_wave_sort<K>(v, lane);
 #pragma unroll
@@ -758,16 +900,96 @@ __device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm,
   __builtin_amdgcn_wave_barrier();
 }
 
+// QDM epilogue of one column (one wave; its candidates sorted in `list`, keys; c0 / cmax = the copies of the column's minimum
+// / maximum counted by pass 2): per class boundary the rank that decides it (qdmrank.h), its run of equal values among the candidates (or a pure bin),
+// the cut value -> gcut; the class factors -> gfac.  A rank outside the collected bins, or a run longer than the scan cap,
+// puts the column on the list for the exact-rank kernels (returns true).  tv: 64 words of LDS scratch.
+template <int CW>
+__device__ __forceinline__ bool hs_qdm_pick(const HsArgs& A, const uint32_t* list, int64_t tile, int k, int64_t ck, int lane, uint32_t* tv,
+                                            uint32_t c0, uint32_t cmax) {
+  const int nq = A.nq, ntest = nq + 1, nrec = 2 * (nq + 1);
+  const uint32_t n = A.meta_n[ck];
+  const uint2 lh = A.lohi[ck];
+  const uint32_t* __restrict__ rec = A.qrec + (tile * nrec) * 2 * CW + k;
+  auto R0 = [&](int r) -> uint32_t { return rec[(r * 2 + 0) * CW]; };
+  auto R1 = [&](int r) -> uint32_t { return rec[(r * 2 + 1) * CW]; };
+  constexpr uint32_t CAP = 256u;
+  // the column's valid nodes (NaN factors dropped), compacted through the wave: tv[pos] = node index
+  const float myaf = lane < nq ? A.af[(int64_t)lane * A.af_qs + ck] : xh_nan32();
+  const unsigned long long vmask = __ballot(myaf == myaf);
+  const uint32_t nvn = (uint32_t)__popcll(vmask);
+  if (myaf == myaf) tv[__popcll(vmask & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+  __builtin_amdgcn_wave_barrier();
+  // a record that holds global rank r: value + run [a, b) of equal values around it.  found: 1 ok | 0 not collected / cap
+  auto run_at = [&](uint32_t r, uint32_t& key, uint32_t& a, uint32_t& b) -> bool {
+    for (int i = 0; i < nrec; ++i) {
+      const uint32_t w1 = R1(i), kind = w1 >> 16;
+      if (kind == HS_REC_NONE) continue;
+      const uint32_t w0 = R0(i), bel = w0 & 0xFFFFu, cnt = w0 >> 16;
+      if (r < bel || r >= bel + cnt) continue;
+      if (kind != HS_REC_REG) {  // a pure bin: one value (as the canonical key the sorted candidates carry: -0.0 -> +0.0)
+        key = hs_key(xh_key2f(kind == HS_REC_LO ? lh.x : lh.y) + 0.0f);
+        a = bel;
+        b = bel + cnt;
+        return true;
+      }
+      const uint32_t cs = w1 & 0xFFFFu, pos = cs + (r - bel);
+      key = list[pos];
+      uint32_t l = pos, h = pos + 1u, steps = 0u;
+      while (l > cs && list[l - 1u] == key && steps < CAP) { --l; ++steps; }
+      while (h < cs + cnt && list[h] == key && steps < CAP) { ++h; ++steps; }
+      a = bel + (l - cs);
+      b = bel + (h - cs);
+      return steps < CAP;
+    }
+    return false;
+  };
+  bool flag = false;
+  const bool ok = n > 0u && nvn >= 2u && c0 < n;
+  if (lane < ntest) {
+    uint32_t cut = HS_NANKEY;
+    if (ok && (uint32_t)lane <= nvn && !flag) {
+      double thr;
+      if (lane == 0) thr = A.qs[tv[0]];
+      else if ((uint32_t)lane == nvn) thr = A.qs[tv[nvn - 1u]];
+      else thr = A.qs[tv[lane - 1]] / 2.0 + A.qs[tv[lane]] / 2.0;
+      const uint32_t R = qdm_min_r2(lane == 0, thr, n, c0, cmax);
+      if (R <= 2u * n - cmax + 1u) {  // (the largest doubled rank a sample has: beyond it no sample passes)
+        const uint32_t p = qdm_pos_of_r2(R);
+        uint32_t key, a, b;
+        if (p < n && run_at(p, key, a, b)) {
+          if (a + b + 1u >= R) cut = key;
+          else if (b < n) {
+            uint32_t k2, a2, b2;
+            if (run_at(b, k2, a2, b2)) cut = k2; else flag = true;
+          }
+        } else if (p < n) flag = true;
+      }
+    }
+    A.gcut[(int64_t)lane * A.C + ck] = xh_key2f(cut);
+  }
+  if (lane <= ntest) {  // class factors: [0] below the first node, [k] node k - 1, [nvn + 1] above the last node
+    uint32_t node = lane < 1 ? 0u : (uint32_t)lane - 1u;
+    node = node < nvn ? node : (nvn > 0u ? nvn - 1u : 0u);
+    const uint32_t jn = nvn > 0u ? tv[node] : 0u;
+    const float a = A.af[(int64_t)jn * A.af_qs + ck];
+    const bool inner = lane >= 1 && (uint32_t)lane <= nvn;
+    A.gfac[(int64_t)lane * A.C + ck] = (ok && (uint32_t)lane <= nvn + 1u && (inner || A.extrap == 0)) ? a : xh_nan32();
+  }
+  __builtin_amdgcn_wave_barrier();
+  return __any(flag ? 1 : 0) != 0;
+}
+
 // ---- pass 2: collect the samples of the target bins, sort them per column, pick + lerp ---------------------------------
 // LDS: cand [64 * 512] candidates (the columns' lists back to back) | tab [64][64] bit pairs per regular index | bm [32][64]
-// bin bitmap (exact path) | cursor [64] | colok [64] | lbase [64] list offsets | tv [waves][64] picked keys
+// bin bitmap (exact path) | cursor [64] | colok [64] | lbase [64] list offsets | cntmn / cntmx / valmn / valmx [64] (QDM) | tv [waves][64] picked keys
 constexpr size_t hs_lds2() {
-  return (size_t)HS_POOL * 4 + 64 * HS_CW * 4 + 32 * HS_CW * 4 + 3 * HS_CW * 4 + (size_t)(HS_NT / 64) * 64 * 4;
+  return (size_t)HS_POOL * 4 + 64 * HS_CW * 4 + 32 * HS_CW * 4 + 7 * HS_CW * 4 + (size_t)(HS_NT / 64) * 64 * 4;
 }
 
 // One tile of pass 2 (collect round `round`).  `rev`: the full batches are streamed from the last one down (fused kernel).
 // The ring is primed here.  Returns without streaming when no column of the tile belongs to this round.
-template <int HS_U, int NSET>
+template <int HS_U, int NSET, bool QDM>
 __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NSET>& ring, unsigned char* smem, int64_t tile, int round, bool rev) {
   constexpr int CW = HS_CW, NT = HS_NT;
   const float* __restrict__ x = A.x;
@@ -791,7 +1013,11 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
   uint32_t* cursor = bm + 32 * CW;
   uint32_t* colok = cursor + CW;
   uint32_t* lbase = colok + CW;
-  uint32_t* tvall = lbase + CW;
+  uint32_t* cntmn = lbase + CW;   // QDM: copies of the column's minimum / maximum ...
+  uint32_t* cntmx = cntmn + CW;
+  float* valmn = reinterpret_cast<float*>(cntmx + CW);  // ... and the two values (read per batch: they must not live in registers)
+  float* valmx = valmn + CW;
+  uint32_t* tvall = reinterpret_cast<uint32_t*>(valmx + CW);
   const int tid = threadIdx.x, col = tid & (CW - 1), rl = tid / CW;
   const int lane = tid & 63, wv = tid >> 6;
   const int ntgt = 2 * nq;
@@ -807,6 +1033,12 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
       cursor[tid] = 0u;
       colok[tid] = collect ? 0xFFFFFFFFu : 0u;  // (tid < CW: col == tid)
       lbase[tid] = collect ? (mbase & 0xFFFFu) : 0u;
+      cntmn[tid] = 0u;
+      cntmx[tid] = 0u;
+      if (QDM) {
+        valmn[tid] = A.colmin[cc];
+        valmx[tid] = A.colmax[cc];
+      }
     }
     if (!__syncthreads_or(collect ? 1 : 0)) return;  // no column of this tile belongs to this round (block-uniform)
     ring.prime(x, T, st, cc, rl, rev);
@@ -817,7 +1049,36 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
     const uint32_t* mytab = tab + col;
     const uint32_t* mybm = bm + col;
     uint32_t dummy = 0u;
+    // QDM: the copies of the column's minimum / maximum (pass 1 found the values).  Nothing of this may live in registers
+    // across the streaming loop: with two values and two counters per lane (at the 128-VGPR cap) the allocator copied the ring
+    // of register sets at the loop's back edge behind an s_waitcnt vmcnt(0) — every iteration drained the loads in flight
+    // (tools/isa_loops.py).  So: the values are read from LDS per batch, the batch's own minimum / maximum (v_min3 / v_max3)
+    // decides whether any lane of the wave holds a copy at all, and only then the copies are counted into LDS.
+    constexpr bool qdm = QDM;
     ring.run(x, T, st, cc, rl, [&](const float (&v)[HS_U]) {
+      if (qdm) {
+        const float vmn = valmn[col], vmx = valmx[col];
+        float m = v[0], M = v[0];
+#pragma unroll
+        for (int u = 1; u + 1 < HS_U; u += 2) {
+          asm("v_min3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(v[u]), "v"(v[u + 1]));
+          asm("v_max3_f32 %0, %0, %1, %2" : "+v"(M) : "v"(v[u]), "v"(v[u + 1]));
+        }
+        if (HS_U % 2 == 0) {
+          asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(v[HS_U - 1]));
+          asm("v_max_f32 %0, %0, %1" : "+v"(M) : "v"(v[HS_U - 1]));
+        }
+        if (__any((m <= vmn || M >= vmx) ? 1 : 0)) {
+          uint32_t cn = 0u, cx = 0u;
+#pragma unroll
+          for (int u = 0; u < HS_U; ++u) {
+            cn += v[u] == vmn ? 1u : 0u;
+            cx += v[u] == vmx ? 1u : 0u;
+          }
+          if (cn) atomicAdd(&cntmn[col], cn);
+          if (cx) atomicAdd(&cntmx[col], cx);
+        }
+      }
       // the regular index of every sample and its bit pair (8 LDS reads in flight); bit 1 anywhere in the wave: this
       // batch is decided by the exact bins (NaN samples: f = 0, whose candidate bit is never set).  The hits of the batch
       // are ONE register (bit u = sample u): sixteen 0 / 1 registers next to the ring's register sets spill, and a spill
@@ -888,21 +1149,24 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
       if (m != mm && lane == 0) atomicAdd(&stat->errors, 1u);
       uint32_t* list = cand + (meta_base[ck] & 0xFFFFu);
       const uint32_t ms = m < mm ? m : mm;
+      const float zero = QDM ? 0.0f : -0.0f;
       if (abl & 1) {
-      } else if (ms > 1024u) hs_sort_column<32>(list, ms, lane);
-      else if (ms > 512u) hs_sort_column<16>(list, ms, lane);
-      else if (ms > 256u) hs_sort_column<8>(list, ms, lane);
-      else if (ms > 128u) hs_sort_column<4>(list, ms, lane);
-      else if (ms > 64u) hs_sort_column<2>(list, ms, lane);
-      else if (ms > 0u) hs_sort_column<1>(list, ms, lane);  // (one candidate: only turned into its key)
+      } else if (ms > 1024u) hs_sort_column<32>(list, ms, lane, zero);
+      else if (ms > 512u) hs_sort_column<16>(list, ms, lane, zero);
+      else if (ms > 256u) hs_sort_column<8>(list, ms, lane, zero);
+      else if (ms > 128u) hs_sort_column<4>(list, ms, lane, zero);
+      else if (ms > 64u) hs_sort_column<2>(list, ms, lane, zero);
+      else if (ms > 0u) hs_sort_column<1>(list, ms, lane, zero);  // (one candidate: only turned into its key)
       __builtin_amdgcn_wave_barrier();
-      hs_pick_store<CW>(list, mm, tile, k, ck, lane, ntgt, nq, qs, meta_n, lohi, crank, tv, out, ocs, oqs);
+      if (!QDM) hs_pick_store<CW>(list, mm, tile, k, ck, lane, ntgt, nq, qs, meta_n, lohi, crank, tv, out, ocs, oqs);
+      else if (hs_qdm_pick<CW>(A, list, tile, k, ck, lane, tv, cntmn[k], cntmx[k]) && lane == 0)
+        A.flist[atomicAdd(&stat->nflag, 1u)] = (uint32_t)ck;  // (behind pass 1's own entries: the host reads the count afterwards)
     }
     __syncthreads();  // cand / tab / bm / cursor are rewritten by the next tile
   }
 }
 
-template <int HS_U, int NSET>
+template <int HS_U, int NSET, bool QDM>
 __global__ void __launch_bounds__(HS_NT, 4)
 k_hs_collect(HsArgs A, int round) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -911,7 +1175,7 @@ k_hs_collect(HsArgs A, int round) {
   for (int64_t round_base = 0; round_base < ntiles; round_base += gridDim.x) {
     const int64_t tile = hs_tile_of(round_base, ntiles);
     if (tile < 0) break;  // (block-uniform; only in the last round)
-    hs_collect_tile<HS_U, NSET>(A, ring, smem, tile, round, false);
+    hs_collect_tile<HS_U, NSET, QDM>(A, ring, smem, tile, round, false);
   }
 }
 
@@ -939,10 +1203,10 @@ k_hs_fused(HsArgs A, int rev) {
     ring.prime(A.x, A.T, A.st, c < A.C ? c : A.C - 1, rl);
     hs_clear(reinterpret_cast<uint32_t*>(smem), HS_NB * 32 + 32 * HS_CW, tid);  // (under the first loads)
     __syncthreads();
-    hs_hist_tile<HS_U, NSET>(A, ring, smem, tile, false);
+    hs_hist_tile<HS_U, NSET, false>(A, ring, smem, tile, false);
     __threadfence_block();
     __syncthreads();  // pass 1's tables are in global memory, its LDS is free
-    hs_collect_tile<HS_U, NSET>(A, ring, smem, tile, 0, rev != 0);
+    hs_collect_tile<HS_U, NSET, false>(A, ring, smem, tile, 0, rev != 0);
   }
 }
 
@@ -964,12 +1228,60 @@ k_hs_scatter(const float* __restrict__ tmp, int64_t nf, int nq, const uint32_t* 
   out[(int64_t)flist[f] * ocs + q * oqs] = tmp[i];
 }
 
+// QDM fallback: the flagged columns' factors (nq, nf) and their adjusted series back into the time-major field
+__global__ void __launch_bounds__(XH_BLOCK)
+k_hs_gather_af(const float* __restrict__ af, int64_t af_qs, int nq, const uint32_t* __restrict__ flist, int64_t nf, float* __restrict__ gaf) {
+  const int64_t i = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (i >= nf * nq) return;
+  const int64_t q = i / nf, f = i - q * nf;
+  gaf[i] = af[q * af_qs + flist[f]];
+}
+
+__global__ void __launch_bounds__(XH_BLOCK)
+k_hs_scatter_rows(const float* __restrict__ buf, int64_t T, int64_t Tp, const uint32_t* __restrict__ flist, float* __restrict__ out,
+                  int64_t ost) {
+  const int64_t c = flist[blockIdx.x];
+  const float* src = buf + (int64_t)blockIdx.x * Tp;
+  for (int64_t t = threadIdx.x; t < T; t += XH_BLOCK) out[t * ost + c] = src[t];
+}
+
+struct HsQdm {  // xh_qdm_hist's part of the call
+  const float* af;
+  int64_t af_qs;
+  int kind, extrap;
+  float* scen;
+  int64_t ost;
+};
+
+int hs_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq, float* out, int64_t out_cstride,
+           int64_t out_qstride, const HsQdm* qd);
+
 }  // namespace
 
 // Quantiles of long series straight from the time-major (T, C) view.  XH_ERR_NOTIMPL when the shape does not fit or too
 // many columns would need the column kernels (the caller then takes the transposed pipeline of eqm.hip for everything).
 int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq, float* out,
                    int64_t out_cstride, int64_t out_qstride) {
+  return hs_run(ctx, x, T, C, st, d_q, nq, out, out_cstride, out_qstride, nullptr);
+}
+
+// QuantileDeltaMapping.adjust, interp = "nearest", on long time-major series: three streaming passes — histogram, collect
+// (class boundaries as order statistics, ties followed exactly through the runs of equal candidates: qdmrank.h) and
+// classification against the cut values (k_cut_classify) — instead of two transposes around a per-column exact ranking
+// (T <= 32768: 228 ms at 10950 x 1440 x 720) or a global sort (T > 32768: 779 ms at 55152 x 1440 x 90).  Columns whose
+// boundary ranks leave the collected bins go through the exact-rank kernels afterwards.
+int xh_qdm_hist(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, const float* af, int64_t af_qs, const double* d_q,
+                int nq, int kind, int extrap, float* scen, int64_t ost) {
+  if (nq < 2 || scen == sim) return XH_ERR_NOTIMPL;
+  if (xh_diag_env("XH_QDM_NOHIST")) return XH_ERR_NOTIMPL;  // A/B against the exact-rank kernels
+  const HsQdm qd{af, af_qs, kind, extrap, scen, ost};
+  return hs_run(ctx, sim, T, C, st, d_q, nq, nullptr, 0, 0, &qd);
+}
+
+namespace {
+
+int hs_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const double* d_q, int nq, float* out, int64_t out_cstride,
+           int64_t out_qstride, const HsQdm* qd) {
   if (T <= 1024 || T > 65535 || nq < 1 || nq > HS_MAXQ || C < 1) return XH_ERR_NOTIMPL;  // (65535: u16 counters)
   if ((unsigned long long)((HS_RL * 32 + HS_RL) * st + C) * 4ull >= (1ull << 32)) return XH_ERR_NOTIMPL;  // 32-bit offsets inside a batch
   if (xh_diag_env("XH_SELECT_NOHIST")) return XH_ERR_NOTIMPL;  // A/B against the transposed pipeline
@@ -985,8 +1297,20 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   const size_t b_tab = al(4 * (size_t)ntiles * 64 * HS_CW);
   const size_t b_flist = al(4 * (size_t)C), b_stat = al(sizeof(HsStat));
   const size_t b_gather = al(4 * (size_t)nfmax * (size_t)Tp), b_tmp = al(4 * (size_t)nfmax * (size_t)nq);
+  // QDM: records, cut values, class factors, the fallback's output columns (+ the global sort's workspace beyond 32768 steps)
+  const int nrec = 2 * (nq + 1);
+  const size_t b_qrec = qd ? al(4 * (size_t)ntiles * nrec * 2 * HS_CW) + 2 * al(4 * (size_t)C) : 0;
+  const size_t b_gcut = qd ? al(4 * (size_t)(nq + 1) * (size_t)C) : 0, b_gfac = qd ? al(4 * (size_t)(nq + 2) * (size_t)C) : 0;
+  const size_t b_gout = qd ? b_gather : 0;
+  size_t b_sorted = 0;
+  if (qd && T > 32768) {
+    const int rcw = xh_qdm_sorted_ws(T, nfmax, &b_sorted);
+    if (rcw) return rcw;
+    b_sorted = al(b_sorted);
+  }
   void* ws = nullptr;
-  int rc = xh_big_scratch(ctx, b_lohi + b_n + b_m + b_base + b_crank + b_bm + b_tab + b_flist + b_stat + b_gather + b_tmp, &ws);
+  int rc = xh_big_scratch(ctx, b_lohi + b_n + b_m + b_base + b_crank + b_bm + b_tab + b_flist + b_stat + b_gather + b_tmp + b_qrec + b_gcut +
+                                   b_gfac + b_gout + b_sorted, &ws);
   if (rc) return rc;
   char* p = (char*)ws;
   uint2* lohi = (uint2*)p; p += b_lohi;
@@ -1000,6 +1324,13 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   HsStat* stat = (HsStat*)p; p += b_stat;
   float* gbuf = (float*)p; p += b_gather;
   float* gtmp = (float*)p; p += b_tmp;
+  uint32_t* qrec = (uint32_t*)p; p += b_qrec;
+  float* colmin = qd ? (float*)((char*)qrec + al(4 * (size_t)ntiles * nrec * 2 * HS_CW)) : nullptr;
+  float* colmax = qd ? (float*)((char*)colmin + al(4 * (size_t)C)) : nullptr;
+  float* gcut = (float*)p; p += b_gcut;
+  float* gfac = (float*)p; p += b_gfac;
+  float* gout = (float*)p; p += b_gout;
+  void* sws = (void*)p; p += b_sorted;
   XH_CHECK_HIP(hipMemsetAsync(stat, 0, sizeof(HsStat), ctx->stream));
   // pass 0
   int64_t S = T / 342;
@@ -1041,40 +1372,66 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   A.x = x; A.T = (int)T; A.C = C; A.st = st; A.lohi = lohi; A.qs = d_q; A.nq = nq;
   A.meta_n = meta_n; A.meta_m = meta_m; A.meta_base = meta_base; A.crank = crank; A.bitmap_g = bitmap_g; A.tab_g = tab_g;
   A.flist = flist; A.out = out; A.ocs = out_cstride; A.oqs = out_qstride; A.stat = stat; A.abl = abl;
+  A.qdm = qd ? 1 : 0; A.af = qd ? qd->af : nullptr; A.af_qs = qd ? qd->af_qs : 0; A.extrap = qd ? qd->extrap : 0;
+  A.qrec = qrec; A.gcut = gcut; A.gfac = gfac; A.colmin = colmin; A.colmax = colmax;
   // XH_HIST_FUSED (diagnostics): "1" = both passes of a tile in one kernel, second pass forward, "2" = ... in reverse row
   // order.  Default 0 = two kernels: measured in one process at config 4 (profiles/r05/select4_fused_ab.txt) 39.57 ms against
   // 41.25 (fused) and 40.97 (fused + reverse) per training — see k_hs_fused.
   const char* efu = xh_diag_env("XH_HIST_FUSED");
   const int fused = efu ? atoi(efu) : 0;
   const size_t lds_f = hs_lds1() > hs_lds2() ? hs_lds1() : hs_lds2();
+#define XH_HS_TWO(UU, NS, QD)                                                                                                    \
+  {                                                                                                                             \
+    if (round == 0) {                                                                                                           \
+      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist<UU, NS, QD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds1())); \
+      hipLaunchKernelGGL((k_hs_hist<UU, NS, QD>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds1(), ctx->stream, A);                \
+      XH_LAUNCH_CHECK();                                                                                                        \
+    }                                                                                                                           \
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<UU, NS, QD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2())); \
+    hipLaunchKernelGGL((k_hs_collect<UU, NS, QD>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds2(), ctx->stream, A, round);        \
+  }
 #define XH_HS_LAUNCH(UU, NS)                                                                                                     \
   {                                                                                                                             \
-    if (round == 0 && fused) {                                                                                                  \
+    if (round == 0 && fused && !qd) {                                                                                           \
       XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_fused<UU, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f)); \
       hipLaunchKernelGGL((k_hs_fused<UU, NS>), dim3((unsigned)nblk), dim3(HS_NT), lds_f, ctx->stream, A, fused == 2 ? 1 : 0);   \
-    } else {                                                                                                                    \
-      if (round == 0) {                                                                                                         \
-        XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_hist<UU, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds1())); \
-        hipLaunchKernelGGL((k_hs_hist<UU, NS>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds1(), ctx->stream, A);                  \
-        XH_LAUNCH_CHECK();                                                                                                      \
-      }                                                                                                                         \
-      XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_hs_collect<UU, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds2())); \
-      hipLaunchKernelGGL((k_hs_collect<UU, NS>), dim3((unsigned)nblk), dim3(HS_NT), hs_lds2(), ctx->stream, A, round);          \
-    }                                                                                                                           \
+    } else if (qd) XH_HS_TWO(UU, NS, true)                                                                                      \
+    else XH_HS_TWO(UU, NS, false)                                                                                               \
   }
   HsStat h;
   for (int round = 0;; ++round) {  // round 0: pass 1 + pass 2; further rounds of pass 2 for tiles whose lists overflow the pool
-    if (ring == 162) XH_HS_LAUNCH(16, 2)
+    if (ring == 162 && !qd) XH_HS_LAUNCH(16, 2)
     else XH_HS_LAUNCH(8, 5)
     XH_LAUNCH_CHECK();
     XH_CHECK_HIP(hipMemcpyAsync(&h, stat, sizeof(HsStat), hipMemcpyDeviceToHost, ctx->stream));
     XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     if (round >= (int)h.rounds) break;
   }
+#undef XH_HS_TWO
 #undef XH_HS_LAUNCH
   XH_REQUIRE(h.errors == 0 || abl != 0, XH_ERR_HIP, "xh_select_hist: %u columns met another candidate count in pass 2 than in pass 1",
              h.errors);
   if (xh_diag_env("XH_HIST_STATS")) fprintf(stderr, "[xh_select_hist] T=%lld C=%lld flagged=%u candidates: max %u mean %.1f, %u collect rounds\n", (long long)T, (long long)C, h.nflag, h.maxm, (double)h.summ / (double)C, h.rounds + 1u);
+  if (qd) {
+    // more than an eighth of the grid on the list (a heavily quantised field): the exact-rank pipeline for everything
+    if ((int64_t)h.nflag > C / 8 && (int64_t)h.nflag > 4096) return XH_ERR_NOTIMPL;
+    rc = xh_cut_classify(ctx, x, T, C, st, gcut, gfac, nq + 1, qd->kind, qd->scen, qd->ost);
+    if (rc) return rc;
+    if (xh_diag_env("XH_HIST_STATS")) fprintf(stderr, "[xh_qdm_hist] %u of %lld columns go through the exact-rank kernels\n", h.nflag, (long long)C);
+    for (int64_t f0 = 0; f0 < (int64_t)h.nflag; f0 += nfmax) {
+      const int64_t nf = (int64_t)h.nflag - f0 < nfmax ? (int64_t)h.nflag - f0 : nfmax;
+      hipLaunchKernelGGL(k_hs_gather, dim3((unsigned)nf), dim3(XH_BLOCK), 0, ctx->stream, x, T, st, flist + f0, gbuf, Tp);
+      hipLaunchKernelGGL(k_hs_gather_af, dim3((unsigned)cdiv64(nf * nq, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, qd->af, qd->af_qs, nq,
+                         flist + f0, nf, gtmp);
+      XH_LAUNCH_CHECK();
+      rc = T > 32768 ? xh_qdm_sorted(ctx, gbuf, T, nf, Tp, gtmp, nf, d_q, nq, qd->kind, 0, qd->extrap, gout, Tp, sws)
+                     : xh_qdm_columns(ctx, gbuf, T, nf, Tp, gtmp, nf, d_q, nq, qd->kind, 0, qd->extrap, gout, Tp);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_hs_scatter_rows, dim3((unsigned)nf), dim3(XH_BLOCK), 0, ctx->stream, gout, T, Tp, flist + f0, qd->scen, qd->ost);
+      XH_LAUNCH_CHECK();
+    }
+    return XH_OK;
+  }
   if (h.nflag == 0) return XH_OK;
   // up to 32768 steps the transposed pipeline is the better answer when MANY columns are flagged (heavily tied fields)
   if (T <= 32768 && (int64_t)h.nflag > nfmax) return XH_ERR_NOTIMPL;
@@ -1090,3 +1447,5 @@ int xh_select_hist(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st
   }
   return XH_OK;
 }
+
+}  // namespace
