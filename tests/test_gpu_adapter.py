@@ -579,6 +579,19 @@ def test_chunked_fields_go_through_the_wrappers_block_by_block(ref, dev, rng):
     np.testing.assert_array_equal(gen.threshold_count(c64, ">", 290.0, "YS").values, ogen.threshold_count(x.astype(np.float64), ">", 290.0, ot, "YS"))
     with pytest.raises(AssertionError, match="was reached"):
         gen.spell_length_statistics(c64, 290.0, 1, None, ">", "max", "YS")
+    # a CHUNKED full-shape (time, lat, lon) threshold is sliced block by block too — never `.values` in one piece
+    thr_v = (x - rng.normal(0.0, 2.0, x.shape)).astype(np.float32)
+    t_mem, t_chk = fakexr.field(thr_v, ta), fakexr.field(thr_v, ta, chunks={"lat": 3, "lon": 4})
+    del loads[:]
+    got = gen.threshold_count(chk, ">", t_chk, "YS")
+    np.testing.assert_array_equal(got.values, gen.threshold_count(mem, ">", t_mem, "YS").values)
+    np.testing.assert_array_equal(got.values, ogen.threshold_count(x, ">", thr_v, ot, "YS"))
+    assert len(t_chk.data.loads) == nblocks and max(t_chk.data.loads) <= biggest and len(loads) == nblocks
+    np.testing.assert_array_equal(gen.threshold_count(mem, ">", t_chk, "YS").values, got.values)   # in-memory field, chunked threshold
+    # ... and a chunk grid with a zero-length cell dimension gives correctly shaped empty results (was a TypeError)
+    empty = fakexr.field(x[:, :0, :], ta, chunks={"lat": 3, "lon": 4})
+    e = sp.frost_days(empty, 283.15, freq="YS")
+    assert e.values.shape == (3, 0, X)
     # full-shape results of chunked inputs are the reference's own dask business
     with pytest.raises(AssertionError, match="rle was reached"):
         rl.rle(m_chk)
@@ -655,3 +668,12 @@ def test_dataarray_indexers_and_the_valid_cache(ref, dev, rng):
     dev.stop_trace()
     assert len(_calls(trace, "xh_resample_reduce")) == 1 and m3.values[0, 1, 1] and m3.values.sum() == 1
     np.testing.assert_array_equal(m3.values, oidx.missing_any(da.values, ot, "YS"))
+    # an edit of a step that is neither the first, a middle nor the last one (round 4 compared the NaN counts of
+    # those three steps only) is seen too — the fingerprint samples every row
+    gen.select_resample_op(da, "mean", "YS")
+    da.values[500, 2, 3] = np.nan
+    trace = dev.start_trace()
+    m4 = misser(da, "YS", "D")
+    dev.stop_trace()
+    assert len(_calls(trace, "xh_resample_reduce")) == 1 and m4.values[1, 2, 3]
+    np.testing.assert_array_equal(m4.values, oidx.missing_any(da.values, ot, "YS"))
