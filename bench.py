@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s best meas
 # idle) ran up to 40 % slower on one of ~10 boxes of the pool; they are not part of the measurement either way
 WAKEUP_STEPS = 30
 
-PMC_TABLES = ("profiles/r04/pmc_hbm_traffic.json", "profiles/r03/pmc_hbm_traffic.json", "profiles/r02/pmc_hbm_traffic.json")
+PMC_TABLES = ("profiles/r05/pmc_hbm_traffic.json", "profiles/r04/pmc_hbm_traffic.json", "profiles/r03/pmc_hbm_traffic.json", "profiles/r02/pmc_hbm_traffic.json")
 
 
 def pmc_traffic(kernel, grid):
@@ -56,6 +56,14 @@ def pmc_traffic(kernel, grid):
             if name in table:
                 return table[name]["hbm_bytes_per_launch"], rel
     return None, None
+
+
+def train365_traffic(grid):
+    """HBM bytes of one xh_eqm_train at 365 steps: two register-sort launches + the correction kernel (round 5: FETCH_SIZE
+    is calibrated on the register sort's load pattern, tools/regsort_ubench.hip)."""
+    a, _ = pmc_traffic("k_select_regsort<183, 360>", (grid[0], 1440, grid[1] // 1440) if grid[1] == 1440 * 720 else (0, 0, 0))
+    b, _ = pmc_traffic("k_correction_fix", (grid[0], 1440, grid[1] // 1440) if grid[1] == 1440 * 720 else (0, 0, 0))
+    return None if a is None or b is None else 2 * a + b
 
 
 def hbm_roofline(nbytes, ms, kernel=None, **more):
@@ -86,7 +94,7 @@ def valu_bound(kernel):
     return None
 
 
-PMC_30YR = "profiles/r04/pmc_hbm_traffic_30yr.json"
+PMC_30YR = "profiles/r05/pmc_hbm_traffic_30yr.json"
 
 
 def pmc_traffic_30yr(*kernels):
@@ -447,8 +455,13 @@ def bench_extra(dev, K, ta, T, C, seg, P, tasmax, tb, per, D, full_configs=True,
     b_ad = 8 * E + 8 * 20 * C
     out["eqm_train_365"] = {"ms": ms_tr, "GB/s": b_tr / ms_tr / 1e6, "frac": b_tr / ms_tr / 1e6 / HBM_PEAK_GBS,
                             "algorithmic_bytes": b_tr, "note": "time-major input, read in place (register sorting network)",
-                            "roofline": hbm_roofline(b_tr, ms_tr, "2 x k_select_regsort<183, 360> + k_correction (xh_eqm_train)"),
-                            "roofline_valu": valu_bound("k_select_regsort")}
+                            "roofline": hbm_roofline(b_tr, ms_tr, "2 x k_select_regsort<183, 360> + k_correction (xh_eqm_train)",
+                                                     traffic=train365_traffic((T, C)), traffic_source=PMC_TABLES[0]),
+                            "roofline_valu": dict(valu_bound("k_select_regsort") or {}, note=(
+                                "VERDICT r4 #1d: the 50 % target of this leg is RETIRED with the instruction-count bound — 275 K VALU per "
+                                "SIMD and launch, almost all v_min_u32 / v_max_u32 at 4.3 cycles: >= 0.46 ms per array at 100 % issue, with "
+                                "the adjust kernel <= 0.48 of the HBM peak for train + adjust (DESIGN.md 7 item 3); a v_min3 / v_med3 / "
+                                "v_max3 network was priced at <= 1.25x fewer sort instructions (-> <= 0.40) and not built")) or None}
     out["eqm_adjust_365"] = {"ms": ms_ad, "GB/s": b_ad / ms_ad / 1e6, "frac": b_ad / ms_ad / 1e6 / HBM_PEAK_GBS,
                              "algorithmic_bytes": b_ad, "roofline": hbm_roofline(b_ad, ms_ad, "k_eqm_adjust<20, 0> (xh_eqm_adjust)")}
     out["eqm_train_adjust_365"] = {"ms": ms_tr + ms_ad, "GB/s": (b_tr + b_ad) / (ms_tr + ms_ad) / 1e6,

@@ -23,14 +23,21 @@ import json
 import os
 import sys
 
-UNCALIBRATED = ("k_select", "__amd_rocclr", "k_pdoy_top16")  # strided gathers: FETCH_SIZE x2 not calibrated
+UNCALIBRATED = ("k_select_grp", "k_select_lean", "k_select_tm", "__amd_rocclr", "k_pdoy_top16", "k_plane_linear")  # strided gathers: FETCH_SIZE x2 not calibrated
+# (round 5: k_select_regsort / k_qdm_regsort ARE calibrated — tools/regsort_ubench.hip reads 1.518 GB by construction in their
+#  load pattern and FETCH_SIZE x 1024 x 2 = 1.518 GB, profiles/r05/fetch_calibration_regsort.txt)
 
 
-def main(src, dst, name="pmc_hbm_traffic.json", only=None):
+def main(src, dst, name="pmc_hbm_traffic.json", only=None, largest=False):
+    """largest: a run that launches a kernel at several grid sizes (round 5: the 30-year configurations AND the c5 slab AND the
+    365-step grid in one bench run) — keep, per kernel, only the launches of the largest problem (the dispatches of the FETCH
+    pass whose value is within 10 % of the kernel's largest one; the same dispatch positions in the WRITE pass)."""
     out = {}
+    keep = {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         files = glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)
         agg = collections.defaultdict(lambda: [0, 0.0])
+        per = collections.defaultdict(list)
         for f in files:
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] != cname:
@@ -38,8 +45,14 @@ def main(src, dst, name="pmc_hbm_traffic.json", only=None):
                 k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
                 if only and not k.startswith(only):
                     continue
-                agg[k][0] += 1
-                agg[k][1] += float(r["Counter_Value"])
+                per[k].append(float(r["Counter_Value"]))
+        for k, vals in per.items():
+            if largest:
+                if cname == "FETCH_SIZE":
+                    keep[k] = [i for i, v in enumerate(vals) if v >= 0.9 * max(vals)]
+                vals = [vals[i] for i in keep.get(k, range(len(vals))) if i < len(vals)]
+            agg[k][0] = len(vals)
+            agg[k][1] = sum(vals)
         for k, (n, v) in agg.items():
             out.setdefault(k, {})[cname + "_KiB_mean"] = v / n
             out[k]["launches"] = n
@@ -67,4 +80,4 @@ def main(src, dst, name="pmc_hbm_traffic.json", only=None):
 
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2], *(sys.argv[3:4] or ["pmc_hbm_traffic.json"]),
-         only=tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else None)
+         only=tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 and sys.argv[4] else None, largest=len(sys.argv) > 5 and sys.argv[5] == "largest")
