@@ -29,6 +29,11 @@
 //
 // Precision: fp64 throughout (Qhull and LinearNDInterpolator are fp64).  One lane per (time step, cell); node tables packed
 // per cell by k_plane_pack (NaN nodes dropped, strictly increasing abscissa) — gathers that hit L2; functional, not tuned.
+#include <math.h>
+#include <stdlib.h>
+
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -299,6 +304,124 @@ k_plane_linear(const float* __restrict__ xnew, const float* __restrict__ base, i
   }
 }
 
+// Integer group coordinates (the day-of-year grouping: every query lies ON its group's row).  One lane per cell walks the
+// rows of its chunk; a row's packed nodes (abscissae + factors) are loaded ONCE into registers — coalesced across the lanes,
+// all loads in flight together — and serve every time step of that row (30 of them for 30 years).  Between two neighbouring
+// nodes less than 2 group steps apart the row's own edge belongs to every Delaunay triangulation (its diametral circle
+// reaches no other row: Gabriel edge), so the plane interpolation is the linear interpolation along the row; wider gaps
+// (temperature tails, precipitation in mm/day) take the walk of plane_locate.  rows: CSR by row coordinate 1 .. G
+// (roff[r - 1] .. roff[r]) of the time steps with that coordinate.
+template <int NQMAX>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_plane_rows(const float* __restrict__ xnew, const float* __restrict__ base, int64_t st, const int32_t* __restrict__ roff,
+             const int32_t* __restrict__ rsteps, PlaneTabs tabs, int kind, float* __restrict__ scen, int64_t scen_st, int r_first,
+             int r_end, uint2* __restrict__ work, unsigned int* __restrict__ nwork, unsigned long long segcap, int abl) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= tabs.C) return;
+  // this workgroup's own stretch of the work list and its own counter: one counter for the whole grid was an atomic on ONE
+  // address per wave and step
+  const unsigned long long seg = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+  uint2* __restrict__ mywork = work + seg * segcap;
+  unsigned int* __restrict__ mycount = nwork + seg;
+  const int nq = tabs.nq;
+  const int rchunk = (r_end - r_first + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int ra = r_first + (int)blockIdx.y * rchunk;
+  int rb = ra + rchunk;
+  if (rb > r_end) rb = r_end;
+  for (int r = ra; r < rb; ++r) {
+    const int32_t t0 = roff[r - 1], t1 = roff[r];
+    if (t0 == t1) continue;
+    const int64_t rowi = (int64_t)(r - 1) * tabs.C + c;
+    const int n = (int)tabs.cnt[rowi];
+    float nx[NQMAX], ny[NQMAX];
+#pragma unroll
+    for (int j = 0; j < NQMAX; ++j) {
+      const bool in = j < nq;
+      nx[j] = in ? tabs.px[((int64_t)(r - 1) * nq + j) * tabs.C + c] : 0.f;
+      ny[j] = in ? tabs.py[((int64_t)(r - 1) * nq + j) * tabs.C + c] : 0.f;
+    }
+    const float PINF = __uint_as_float(0x7F800000u);
+#pragma unroll
+    for (int j = 0; j < NQMAX; ++j) nx[j] = j < n ? nx[j] : PINF;  // (padding never counts as "<= x")
+    const float lo = tabs.fx[rowi], hi = tabs.lx[rowi], flo = tabs.fy[rowi], fhi = tabs.ly[rowi];
+    for (int32_t i = t0; i < t1; ++i) {
+      const int64_t t = rsteps[i];
+      const float xf = xnew[t * st + c];
+      const float bf = base ? base[t * st + c] : xf;
+      float a = xh_nan32();
+      if (xf == xf) {
+        if (xf < lo) a = flo;
+        else if (xf > hi) a = fhi;
+        else {
+          int idx = 0;  // nodes <= x, by counting (the nodes ascend)
+#pragma unroll
+          for (int j = 0; j < NQMAX; ++j) idx += xf >= nx[j] ? 1 : 0;
+          bool fast = false;
+          if (idx >= 1 && idx < n) {
+            float x0 = nx[0], x1 = nx[1], y0 = ny[0], y1 = ny[1];
+#pragma unroll
+            for (int j = 1; j < NQMAX - 1; ++j) {
+              const bool s = j == idx - 1;
+              x0 = s ? nx[j] : x0; x1 = s ? nx[j + 1] : x1;
+              y0 = s ? ny[j] : y0; y1 = s ? ny[j + 1] : y1;
+            }
+            if ((double)x1 - (double)x0 < 2.0) {
+              const double l = ((double)xf - (double)x0) / ((double)x1 - (double)x0);
+              a = (float)((1.0 - l) * (double)y0 + l * (double)y1);
+              fast = true;
+            }
+          } else if (idx >= 1 && idx == n) {  // x on the row's last valid node (beyond it: the walk decides)
+            float xl = nx[0], yl = ny[0];
+#pragma unroll
+            for (int j = 1; j < NQMAX; ++j) {
+              xl = j == n - 1 ? nx[j] : xl;
+              yl = j == n - 1 ? ny[j] : yl;
+            }
+            if (xf == xl) {
+              a = yl;
+              fast = true;
+            }
+          }
+          if (!fast) {
+            // the walk is a chain of dependent gathers: done here, a handful of lanes would hold the whole wave for tens of
+            // microseconds at EVERY step (measured: 211 ms against 442 for the walk alone) — the query goes on a list that
+            // k_plane_work runs through with full waves (one atomic per wave: the lanes' slots by ballot)
+            if (abl & 1) continue;  // diagnostics: the row kernel alone (unresolved queries stay unwritten)
+            const unsigned long long m = __ballot(1);
+            const int lane = threadIdx.x & 63;
+            unsigned int b0 = 0;
+            if (lane == __ffsll((long long)m) - 1) b0 = atomicAdd(mycount, (unsigned int)__popcll(m));
+            b0 = __shfl(b0, __ffsll((long long)m) - 1);
+            mywork[b0 + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)t, (uint32_t)c);
+            continue;
+          }
+        }
+      }
+      scen[t * scen_st + c] = kind == 0 ? (bf + a) : (kind == 1 ? (bf * a) : a);
+    }
+  }
+}
+
+// the queries the row kernel could not decide from the row alone: every workgroup runs through the stretch of the list its
+// twin of the row kernel filled, one lane per entry, the Delaunay walk of plane_locate
+__global__ void __launch_bounds__(XH_BLOCK)
+k_plane_work(const float* __restrict__ xnew, const float* __restrict__ base, int64_t st, const double* __restrict__ gnew, PlaneTabs tabs,
+             int kind, float* __restrict__ scen, int64_t scen_st, const uint2* __restrict__ work, const unsigned int* __restrict__ nwork,
+             unsigned long long segcap) {
+  const unsigned long long seg = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned int n = nwork[seg];
+  const uint2* __restrict__ mywork = work + seg * segcap;
+  for (unsigned int i = threadIdx.x; i < n; i += XH_BLOCK) {
+    const uint2 e = mywork[i];
+    const int64_t t = e.x, c = e.y;
+    const PlaneCell P{tabs, c};
+    const float xf = xnew[t * st + c];
+    const float bf = base ? base[t * st + c] : xf;
+    const float a = (float)plane_locate(P, (double)xf, gnew[t]);
+    scen[t * scen_st + c] = kind == 0 ? (bf + a) : (kind == 1 ? (bf * a) : a);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -314,8 +437,15 @@ int xh_plane_linear(xh_ctx* ctx, const float* xnew, const float* base, int64_t T
   if (T == 0 || C == 0) return XH_OK;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t b_tab = al(4 * (size_t)G * nq * C), b_cnt = al((size_t)G * C), b_row = al(4 * (size_t)G * C), b_q = al(8 * (size_t)nq);
+  // work list of the row kernel: (step, cell) pairs, at most 2^27 of them (1 GiB) or every query of the call
+  size_t wcap = (size_t)1 << 27;
+  {
+    const unsigned long long all = (unsigned long long)T * XH_BLOCK * (unsigned long long)cdiv64(C, XH_BLOCK);  // every query, cells padded to whole workgroups
+    if (all < wcap) wcap = (size_t)all;
+  }
+  const size_t b_work = al(8 * wcap) + 4 * 65536;
   void* ws = nullptr;
-  int rc = xh_big_scratch(ctx, 2 * b_tab + b_cnt + 4 * b_row + b_q, &ws);
+  int rc = xh_big_scratch(ctx, 2 * b_tab + b_cnt + 4 * b_row + b_q + b_work, &ws);
   if (rc) return rc;
   char* p = (char*)ws;
   float* px = (float*)p; p += b_tab;
@@ -325,13 +455,75 @@ int xh_plane_linear(xh_ctx* ctx, const float* xnew, const float* base, int64_t T
   float* lx = (float*)p; p += b_row;
   float* fy = (float*)p; p += b_row;
   float* ly = (float*)p; p += b_row;
-  double* dq = (double*)p;
+  double* dq = (double*)p; p += b_q;
+  unsigned int* nwork = (unsigned int*)p;   // one counter per workgroup of the row kernel (<= 65536)
+  uint2* work = (uint2*)(p + 4 * 65536);
   if (xq_common) XH_CHECK_HIP(hipMemcpyAsync(dq, xq_common, 8 * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
   const int64_t cblocks = cdiv64(C, XH_BLOCK);
   hipLaunchKernelGGL(k_plane_pack, dim3((unsigned)cblocks, (unsigned)G), dim3(XH_BLOCK), 0, ctx->stream, xq_all, xq_common ? dq : nullptr,
                      yq_all, G, nq, C, px, py, cnt, fx, lx, fy, ly);
   XH_LAUNCH_CHECK();
   PlaneTabs tabs{px, py, cnt, fx, lx, fy, ly, G, nq, C};
+  // integer group coordinates in 1 .. G (day-of-year groupings): the row kernel.  gnew is a device array: T doubles come
+  // back once per call (one synchronisation per adjust); the CSR by row goes up through the context's table scratch.
+  if (nq <= 32 && T < ((int64_t)1 << 31) && !xh_diag_env("XH_PLANE_NOROWS")) {
+    std::vector<double> g((size_t)T);
+    XH_CHECK_HIP(hipMemcpyAsync(g.data(), gnew, 8 * (size_t)T, hipMemcpyDeviceToHost, ctx->stream));
+    XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    bool integral = true;
+    for (int64_t t = 0; t < T && integral; ++t) integral = g[t] >= 1.0 && g[t] <= (double)G && g[t] == floor(g[t]);
+    if (integral) {
+      std::vector<int32_t> off((size_t)G + 1, 0), steps((size_t)T);
+      for (int64_t t = 0; t < T; ++t) off[(size_t)g[t]]++;
+      for (int r = 1; r <= G; ++r) off[r] += off[r - 1];
+      std::vector<int32_t> cur(off.begin(), off.end() - 1);
+      for (int64_t t = 0; t < T; ++t) steps[(size_t)cur[(size_t)g[t] - 1]++] = (int32_t)t;
+      size_t cursor = 0;
+      void *d_off = nullptr, *d_steps = nullptr;
+      rc = xh_scratch_upload(ctx, &cursor, off.data(), 4 * off.size(), &d_off);
+      if (rc) return rc;
+      rc = xh_scratch_upload(ctx, &cursor, steps.data(), 4 * steps.size(), &d_steps);
+      if (rc) return rc;
+      // rows in chunks whose queries fit the work list even if every one of them needs the walk; every workgroup of the row
+      // kernel owns a stretch of the list (rows of its chunk x the longest row x 256 cells)
+      int maxsteps = 1;
+      for (int r = 1; r <= G; ++r) maxsteps = off[r] - off[r - 1] > maxsteps ? off[r] - off[r - 1] : maxsteps;
+      const char* eab = xh_diag_env("XH_PLANE_ABL");  // diagnostics: 1 = row kernel alone, 2 = no work kernel
+      const int abl = eab ? atoi(eab) : 0;
+      int r0 = 1;
+      while (r0 <= G) {
+        // rows per launch: gy row chunks of rchunk rows each, gy * cblocks stretches of rchunk * maxsteps * 256 entries
+        const unsigned long long per_row = (unsigned long long)maxsteps * XH_BLOCK * (unsigned long long)cblocks;
+        const int64_t slots = (int64_t)((unsigned long long)wcap / per_row);
+        XH_REQUIRE(slots >= 1 && cblocks <= 65536, XH_ERR_LIMIT,
+                   "xh_plane_linear: the work list (%llu entries) is too small for one group row of this grid (%llu)",
+                   (unsigned long long)wcap, per_row);
+        int64_t gy = cdiv64((int64_t)ctx->num_cu * 8, cblocks);
+        gy = gy < 1 ? 1 : gy;
+        if (gy > slots) gy = slots;
+        if (gy > G + 1 - r0) gy = G + 1 - r0;
+        if (gy * cblocks > 65536) gy = 65536 / cblocks;
+        int64_t rchunk = cdiv64((int64_t)(G + 1 - r0), gy);
+        if (rchunk > slots / gy) rchunk = slots / gy;
+        int r1 = r0 + (int)(rchunk * gy);
+        if (r1 > G + 1) r1 = G + 1;
+        const unsigned long long segcap = (unsigned long long)rchunk * (unsigned long long)maxsteps * XH_BLOCK;
+        XH_CHECK_HIP(hipMemsetAsync(nwork, 0, 4 * (size_t)(gy * cblocks), ctx->stream));
+        if (nq <= 20)
+          hipLaunchKernelGGL((k_plane_rows<20>), dim3((unsigned)cblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, xnew, base, st,
+                             (const int32_t*)d_off, (const int32_t*)d_steps, tabs, kind, scen, scen_st, r0, r1, work, nwork, segcap, abl);
+        else
+          hipLaunchKernelGGL((k_plane_rows<32>), dim3((unsigned)cblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, xnew, base, st,
+                             (const int32_t*)d_off, (const int32_t*)d_steps, tabs, kind, scen, scen_st, r0, r1, work, nwork, segcap, abl);
+        if (!(abl & 3))
+          hipLaunchKernelGGL(k_plane_work, dim3((unsigned)cblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, xnew, base, st, gnew, tabs,
+                             kind, scen, scen_st, work, nwork, segcap);
+        r0 = r1;
+      }
+      XH_LAUNCH_CHECK();
+      return XH_OK;
+    }
+  }
   int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, cblocks);
   if (gy < 1) gy = 1;
   if (gy > T) gy = T;
