@@ -668,7 +668,7 @@ def bench_plane_linear(dev, K, Cb):
     (docs/sdba.rst:64-65): factors interpolated over the (quantile, day-of-year) plane, xh_plane_linear, on a 1440 x 90 band,
     30 years.  Synthetic node tables (365 groups x 20 nodes per cell, a seasonal cycle + a per-cell offset).  Integer group
     coordinates take the row kernel (a row's nodes in registers, serving its 30 steps; gaps under 2 group steps are decided
-    there) + the Delaunay walk for the listed rest: 301 ms with the walk for everything -> 57 ms."""
+    there) + the Delaunay walk for the listed rest: 301 ms with the walk for everything -> 42 ms."""
     from xclim_amd.timeaxis import TimeAxis
 
     T, G, nq = 10950, 365, 20
@@ -690,7 +690,7 @@ def bench_plane_linear(dev, K, Cb):
            "algorithmic_bytes": b, "groups": G, "nodes": nq,
            "roofline": hbm_roofline(b, ms, "k_plane_pack + k_plane_rows<20> + k_plane_work (plane.hip)",
                                     passes="row kernel 12 ms (streams sim / scen + the node tables once), appends 2 ms, the Delaunay walk of the "
-                                           "listed queries (node gaps >= 2 group steps) 43 ms: gathers + fp64, not a streaming kernel")}
+                                           "listed queries (node gaps >= 2 group steps) 28 ms: gathers + fp64, not a streaming kernel")}
     for a in (d_hq, d_af, sim, scen, gd):
         a.free()
     return res

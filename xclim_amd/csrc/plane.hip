@@ -180,6 +180,37 @@ __device__ double plane_locate(const PlaneCell& P, double qx, double qy) {
   PlaneTri T;
   bool have = false;
   {
+    // A good start matters more than a fast step: neighbouring rows are shifted against each other by several node gaps
+    // (the seasonal cycle between two months), and from a fan triangle the walk needs many pivots, each scanning every row
+    // its huge circle crosses.  The Delaunay triangulation of the TWO rows alone is known in closed form — the apex of a
+    // row's gap is the other row's node nearest to the gap's midpoint — and one of its triangles contains q; it is looked
+    // for among the gaps around q's brackets (alternating sides, both base rows), and it usually IS the answer.
+    auto nearest = [&](int r, int n, double m) -> int {
+      int k = P.lower(r, n, m);
+      if (k >= n) return n - 1;
+      if (k > 0 && m - P.x(r, k - 1) <= P.x(r, k) - m) --k;
+      return k;
+    };
+    const int iA = P.upper(r0, nA, qx) - 1, jB = P.upper(r1, nB, qx) - 1;
+#pragma unroll 1
+    for (int k = 0; k <= 16 && !have; ++k) {
+      const int dk = (k & 1) ? (k + 1) / 2 : -(k / 2);   // 0, +1, -1, +2, -2 ...
+      const int i = iA + dk, j = jB + dk;
+      if (nA >= 2 && i >= 0 && i <= nA - 2) {
+        const double a0 = P.x(r0, i), a1 = P.x(r0, i + 1);
+        const int jj = nearest(r1, nB, 0.5 * (a0 + a1));
+        const double b = P.x(r1, jj);
+        if ((1.0 - f) * a0 + f * b <= qx && qx <= (1.0 - f) * a1 + f * b) have = plane_try(P, T, r0, i, r0, i + 1, r1, jj, qx, qy);
+      }
+      if (!have && nB >= 2 && j >= 0 && j <= nB - 2) {
+        const double b0 = P.x(r1, j), b1 = P.x(r1, j + 1);
+        const int ii = nearest(r0, nA, 0.5 * (b0 + b1));
+        const double a = P.x(r0, ii);
+        if ((1.0 - f) * a + f * b0 <= qx && qx <= (1.0 - f) * a + f * b1) have = plane_try(P, T, r0, ii, r1, j, r1, j + 1, qx, qy);
+      }
+    }
+  }
+  if (!have) {
     int i = P.upper(r0, nA, qx) - 1, j = P.upper(r1, nB, qx) - 1;
     const int imax = nA >= 2 ? nA - 2 : 0, jmax = nB >= 2 ? nB - 2 : 0;
     i = i < 0 ? 0 : (i > imax ? imax : i);
