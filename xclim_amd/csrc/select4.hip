@@ -910,9 +910,19 @@ __device__ __forceinline__ bool hs_qdm_pick(const HsArgs& A, const uint32_t* lis
   const int nq = A.nq, ntest = nq + 1, nrec = 2 * (nq + 1);
   const uint32_t n = A.meta_n[ck];
   const uint2 lh = A.lohi[ck];
+  // the column's records: one (or two) per lane, read back with v_readlane inside the searches below — fetched from memory
+  // one by one, every probe of run_at was a dependent L2 round trip (k_hs_collect in QDM mode: 19.9 ms against 11.1 for the
+  // quantile mode at config 4)
   const uint32_t* __restrict__ rec = A.qrec + (tile * nrec) * 2 * CW + k;
-  auto R0 = [&](int r) -> uint32_t { return rec[(r * 2 + 0) * CW]; };
-  auto R1 = [&](int r) -> uint32_t { return rec[(r * 2 + 1) * CW]; };
+  uint32_t rw0a = 0u, rw1a = HS_REC_NONE << 16, rw0b = 0u, rw1b = HS_REC_NONE << 16;
+  if (lane < nrec) { rw0a = rec[(lane * 2 + 0) * CW]; rw1a = rec[(lane * 2 + 1) * CW]; }
+  if (lane + 64 < nrec) { rw0b = rec[((lane + 64) * 2 + 0) * CW]; rw1b = rec[((lane + 64) * 2 + 1) * CW]; }
+  auto R0 = [&](int r) -> uint32_t {  // (r is wave-uniform; v_readlane reads lanes outside the execution mask too)
+    return (uint32_t)(r < 64 ? __builtin_amdgcn_readlane((int)rw0a, r) : __builtin_amdgcn_readlane((int)rw0b, r - 64));
+  };
+  auto R1 = [&](int r) -> uint32_t {
+    return (uint32_t)(r < 64 ? __builtin_amdgcn_readlane((int)rw1a, r) : __builtin_amdgcn_readlane((int)rw1b, r - 64));
+  };
   constexpr uint32_t CAP = 256u;
   // the column's valid nodes (NaN factors dropped), compacted through the wave: tv[pos] = node index
   const float myaf = lane < nq ? A.af[(int64_t)lane * A.af_qs + ck] : xh_nan32();
