@@ -59,7 +59,8 @@ constexpr int HS_NT = HS_CW * HS_RL;   // threads per workgroup
 constexpr int HS_NB = 1024;            // bins per column
 constexpr int HS_NREG = 1020;          // regular indices f = 0 .. 1019
 constexpr int HS_POOL = HS_CW * 512;   // candidate keys of one tile in LDS
-constexpr int HS_CAPMAX = 2048;        // ... and at most this many for one column (the largest register sort)
+constexpr int HS_CAPMAX = 2048;        // ... at most this many for one column in the register sort
+constexpr int HS_CAPBIG = 8192;        // ... and this many at all (2049 .. 8192: a bitonic sort in LDS, in place in the column's list)
 constexpr int HS_MAXQ = 32;            // quantiles per call on this path
 constexpr uint32_t HS_NANKEY = 0xFFFFFFFFu;
 constexpr uint32_t HS_KEY_MINF = 0x00800000u, HS_KEY_MAXF = 0xFF7FFFFFu;  // keys of -FLT_MAX / +FLT_MAX
@@ -648,11 +649,11 @@ __device__ __forceinline__ void hs_hist_tile(const HsArgs& A, HsRing<HS_U, NSET>
     // the tile's candidate lists share one LDS pool in pass 2: column offsets in column order (one wave, shuffle scan).  A
     // column with more candidates than the largest register sort is flagged for the column kernels.  A tile whose lists do
     // not fit the pool together (long series: the candidates grow with T, ~1400 per column at 55 152 steps) is collected in
-    // several ROUNDS of pass 2, each round the columns of one pool-full: round = (inclusive prefix - 1) / (POOL - CAPMAX)
-    // — the round's first list may start below the boundary by less than CAPMAX, so a round never overflows the pool.
+    // several ROUNDS of pass 2, each round the columns of one pool-full: round = (inclusive prefix - 1) / (POOL - CAPBIG)
+    // — the round's first list may start below the boundary by less than CAPBIG, so a round never overflows the pool.
     if (rl == 0) {  // wave 0: lane = column
       const uint32_t mk = cvalid ? m : 0u;
-      const bool big = mk > (uint32_t)HS_CAPMAX;
+      const bool big = mk > (uint32_t)HS_CAPBIG;
       const uint32_t val = big ? 0u : mk;
       uint32_t incl = val;
 #pragma unroll
@@ -661,16 +662,16 @@ __device__ __forceinline__ void hs_hist_tile(const HsArgs& A, HsRing<HS_U, NSET>
         incl += col >= d ? o : 0u;
       }
       const uint32_t excl = incl - val;
-      const uint32_t round = val > 0u ? (incl - 1u) / (uint32_t)(HS_POOL - HS_CAPMAX) : 0u;
+      const uint32_t round = val > 0u ? (incl - 1u) / (uint32_t)(HS_POOL - HS_CAPBIG) : 0u;
       unsigned long long mine = 0ull;  // the lanes (columns) of my round
 #pragma unroll 1
-      for (uint32_t r = 0; r <= 3u; ++r) {  // at most CW * CAPMAX / (POOL - CAPMAX) + 1 = 5 rounds; 4 handled here, more are flagged
+      for (uint32_t r = 0; r <= 7u; ++r) {  // 8 rounds handled here (55 152 steps need 4), columns beyond are flagged
         const unsigned long long mr = __ballot(round == r && val > 0u);
         if (round == r) mine = mr;
       }
       const int first = mine ? __ffsll((long long)mine) - 1 : col;
       const uint32_t start = (uint32_t)__shfl((int)excl, first);
-      const bool fl = big || round > 3u;
+      const bool fl = big || round > 7u;
       cbase[col] = fl ? HS_FLAGGED : ((excl - start) | (round << 16));
       if (!fl && val > 0u) atomicMax(&stat->rounds, round);
     }
@@ -859,6 +860,43 @@ __device__ __forceinline__ void hs_sort_column(uint32_t* __restrict__ list, uint
 #pragma unroll
   for (int r = 0; r < K; ++r)
     if ((uint32_t)(lane * K + r) < m) list[lane * K + r] = v[r];  // (the next column's list starts at list + m)
+}
+
+// Lists beyond the register sort (2049 .. HS_CAPBIG keys: clustered or tied values, series of 55 152 steps): one wave sorts
+// the list IN PLACE in LDS.  Bitonic network with every comparator pointing up (the first step of a merge mirrors, i ^ (k - 1),
+// the others compare i with i + j): indices past the list's end stand for +inf, a comparator that touches one is a no-op,
+// so no padding is stored — the next column's list starts right behind this one.  ~90 stages of m / 128 compare-exchanges per
+// lane; rare, and it replaces the detour through the radix select / the global sort of whole columns (eqm_55k: 62 of 85 ms).
+__device__ __forceinline__ void hs_sort_lds(uint32_t* __restrict__ list, uint32_t m, int lane, float zero) {
+  for (uint32_t i = (uint32_t)lane; i < m; i += 64u) list[i] = hs_key(__uint_as_float(list[i]) + zero);
+  __builtin_amdgcn_wave_barrier();
+  uint32_t P = 1u;
+  while (P < m) P <<= 1;
+#pragma unroll 1
+  for (uint32_t k = 2u; k <= P; k <<= 1) {
+    const uint32_t hk = k >> 1;
+#pragma unroll 1
+    for (uint32_t idx = (uint32_t)lane; idx < (P >> 1); idx += 64u) {  // mirror step: i in the lower half of its block
+      const uint32_t i = (idx / hk) * k + (idx % hk), p = i ^ (k - 1u);
+      if (p < m) {
+        const uint32_t a = list[i], b = list[p];
+        if (a > b) { list[i] = b; list[p] = a; }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (uint32_t j = hk >> 1; j >= 1u; j >>= 1) {
+#pragma unroll 1
+      for (uint32_t idx = (uint32_t)lane; idx < (P >> 1); idx += 64u) {
+        const uint32_t i = (idx / j) * (2u * j) + (idx % j), p = i + j;
+        if (p < m) {
+          const uint32_t a = list[i], b = list[p];
+          if (a > b) { list[i] = b; list[p] = a; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
 }
 
 // One column, its candidates sorted in `list` (LDS): pick the 2 nq order statistics by position, Hyndman-Fan lerp
@@ -1161,7 +1199,8 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
       const uint32_t ms = m < mm ? m : mm;
       const float zero = QDM ? 0.0f : -0.0f;
       if (abl & 1) {
-      } else if (ms > 1024u) hs_sort_column<32>(list, ms, lane, zero);
+      } else if (ms > (uint32_t)HS_CAPMAX) hs_sort_lds(list, ms, lane, zero);
+      else if (ms > 1024u) hs_sort_column<32>(list, ms, lane, zero);
       else if (ms > 512u) hs_sort_column<16>(list, ms, lane, zero);
       else if (ms > 256u) hs_sort_column<8>(list, ms, lane, zero);
       else if (ms > 128u) hs_sort_column<4>(list, ms, lane, zero);
