@@ -649,15 +649,18 @@ def bench_full_configs(dev, K, C, long_series=True):
     E = float(T) * Cb
     out["eqm_55k"] = {"train_ms": ms_tr, "GB/s": 8 * E / ms_tr / 1e6, "frac": 8 * E / ms_tr / 1e6 / HBM_PEAK_GBS,
                       "grid": [T, 1440, 90], "algorithmic_bytes": 8 * E,
-                      "roofline": hbm_roofline(8 * E, ms_tr, "2 x (k_hs_sample + k_hs_hist + k_hs_collect) (select4.hip, T = 55152)")}
+                      "roofline": hbm_roofline(8 * E, ms_tr, "2 x (k_hs_sample + k_hs_hist + 4 x k_hs_collect) (select4.hip, T = 55152)",
+                                               passes="the candidates of a 64-column tile (~81 K keys) fill the 32768-key LDS pool 4 times: 5 reads per array; "
+                                                      "round 5: lists of 2049 .. 8192 keys are sorted in LDS instead of sending their columns (4 %) through the "
+                                                      "radix select: 85 -> 67 ms")}
     ref.free()
     scen = dev.empty((T, Cb), np.float32)
     ms_qd = event_time(dev, lambda: K.qdm_adjust(dev, hist, af, q, "+", "nearest", "constant", out=scen), 1)
     out["qdm_55k"] = {"ms": ms_qd, "GB/s": 8 * E / ms_qd / 1e6, "frac": 8 * E / ms_qd / 1e6 / HBM_PEAK_GBS, "grid": [T, 1440, 90],
                       "algorithmic_bytes": 8 * E,
-                      "roofline": hbm_roofline(8 * E, ms_qd, "k_hs_hist / k_hs_collect (QDM mode, 3 collect rounds) + k_cut_classify; ~4 % of the columns (more than "
-                                                              "2048 candidates) through rocprim's segmented sort + k_q3_ranks (qdm3.hip)",
-                                               passes="round 5: the streaming path of qdm_c4; round 4 ranked every column through a global sort: 779 ms")}
+                      "roofline": hbm_roofline(8 * E, ms_qd, "k_hs_hist / k_hs_collect (QDM mode, 4 collect rounds; lists beyond 2048 keys sorted in LDS) + k_cut_classify",
+                                               passes="round 5: the streaming path of qdm_c4 (histogram + 4 collect rounds + classification = 6 reads, 1 write); "
+                                                      "round 4 ranked every column through a global sort: 779 ms")}
     for a in (hist, scen, af, hq):
         a.free()
     return out
