@@ -53,10 +53,39 @@ def locate(rows_x, rows_v, xq, yq, stats=None):
     s = lambda i, j: (1 - f) * A[i] + f * B[j]
     if xq < s(0, 0) or xq > s(len(A) - 1, len(B) - 1):
         return None
-    # a good start: bracket in both rows
+    pt = lambda rk: (rows_x[rk[0]][rk[1]], float(rk[0]))
+    tri = None
+    # the start of the kernel (plane.hip): the Delaunay triangulation of the TWO rows alone is known in closed form — the apex
+    # of a row's gap is the other row's node nearest to the gap's midpoint — and one of its triangles contains q
+    def nearest(X, m):
+        k = int(np.searchsorted(X, m, side="left"))
+        if k >= len(X):
+            return len(X) - 1
+        if k > 0 and m - X[k - 1] <= X[k] - m:
+            k -= 1
+        return k
+    iA = int(np.searchsorted(A, xq, side="right") - 1)
+    jB = int(np.searchsorted(B, xq, side="right") - 1)
+    for k in range(17):
+        dk = (k + 1) // 2 if k & 1 else -(k // 2)
+        i, j = iA + dk, jB + dk
+        if len(A) >= 2 and 0 <= i <= len(A) - 2:
+            jj = nearest(B, 0.5 * (A[i] + A[i + 1]))
+            if (1 - f) * A[i] + f * B[jj] <= xq <= (1 - f) * A[i + 1] + f * B[jj]:
+                cnd = [(r0, i), (r0, i + 1), (r1, jj)]
+                if bary([pt(v) for v in cnd], (xq, yq)).min() >= -1e-12:
+                    tri = cnd
+                    break
+        if len(B) >= 2 and 0 <= j <= len(B) - 2:
+            ii = nearest(A, 0.5 * (B[j] + B[j + 1]))
+            if (1 - f) * A[ii] + f * B[j] <= xq <= (1 - f) * A[ii] + f * B[j + 1]:
+                cnd = [(r0, ii), (r1, j), (r1, j + 1)]
+                if bary([pt(v) for v in cnd], (xq, yq)).min() >= -1e-12:
+                    tri = cnd
+                    break
+    # else: bracket in both rows
     i = int(np.clip(np.searchsorted(A, xq, side="right") - 1, 0, max(len(A) - 2, 0)))
     j = int(np.clip(np.searchsorted(B, xq, side="right") - 1, 0, max(len(B) - 2, 0)))
-    tri = None
     cands = []
     if len(A) >= 2:
         cands += [((r0, i), (r0, i + 1), (r1, j))]
@@ -66,8 +95,9 @@ def locate(rows_x, rows_v, xq, yq, stats=None):
         cands += [((r0, i), (r1, j), (r1, j + 1))]
         if len(A) >= 2:
             cands += [((r0, i + 1), (r1, j), (r1, j + 1))]
-    pt = lambda rk: (rows_x[rk[0]][rk[1]], float(rk[0]))
     for cnd in cands:
+        if tri is not None:
+            break
         lam = bary([pt(v) for v in cnd], (xq, yq))
         if lam.min() >= -1e-12:
             tri = list(cnd)
