@@ -42,9 +42,17 @@
 // in flight per lane).  One workgroup per CU (LDS).  Algorithmic bytes per pass: 4E; nothing else crosses HBM except ~600 bytes of per-column
 // tables.
 //
-// Columns whose target bins hold more than 2048 keys, or that do not fit the tile's 32768-key LDS pool (heavily tied or
-// clustered values away from the window's ends), are flagged in pass 1 and recomputed by the column kernels of
-// select.hip / select2.hip / select5.hip from a gathered copy.
+// Columns whose target bins hold more than 8192 keys (heavily tied or clustered values away from the window's ends) are
+// flagged in pass 1 and recomputed by the column kernels of select.hip / select2.hip / select5.hip from a gathered copy;
+// lists of 2049 .. 8192 keys are sorted in place in LDS (hs_sort_lds, round 5), tiles whose lists do not fit the 32768-key
+// pool together are collected in up to 8 rounds of pass 2.
+//
+// Round 5: (1) QDM mode (template flag of the tile functions; xh_qdm_hist): QuantileDeltaMapping "nearest" needs no rank per
+// sample, only the <= nq + 1 class boundaries as order statistics — the targets become the boundary ranks of qdmrank.h, pass
+// 1 also tracks the column's extremes, pass 2 counts their copies and its epilogue follows ties through the runs of equal
+// candidates; a streaming classification (k_cut_classify, qdm2.hip) finishes.  (2) k_hs_fused: both passes of a tile in one
+// kernel, the second in reverse row order, to catch the tile's tail in the Infinity Cache — built, bit-identical, slower
+// than the two kernels (profiles/r05/select4_fused_ab.txt): diagnostic only.
 #include <stdlib.h>
 
 #include "common.h"
