@@ -498,6 +498,16 @@ int xh_apply_factor(xh_ctx* ctx, const float* base, const float* fac, int64_t T,
 int xh_plane_linear(xh_ctx* ctx, const float* xnew, const float* base, int64_t T, int64_t C, int64_t st, const double* gnew,
                     const float* xq_all, const double* xq_common, const float* yq_all, int G, int nq, int kind, float* scen,
                     int64_t scen_st);
+/* interp = "nearest" with a month / day-of-year Grouper over the WHOLE series in one call (the per-group form is
+ * xh_eqm_adjust_g2d above; same rule: upstream xsdba's _interp_on_quantiles_2D = scipy griddata(method="nearest") over the
+ * nodes of all groups, then _extrapolate_on_quantiles with the step's own group; re-exported by
+ * /root/reference/src/xclim/sdba.py:10).  Arguments as xh_plane_linear; gnew (T) DEVICE float64 must hold INTEGER group
+ * coordinates 1 .. G (upstream passes the integer group index for "nearest"); nq <= 32; extrap 0 constant | 1 nan.  A row
+ * kernel keeps a group's nodes in registers for all of its steps: the own row's nearest node stands when it is at most one
+ * group step away, the rest is listed and searched over the neighbouring rows.  Parity unpinned. */
+int xh_plane_nearest(xh_ctx* ctx, const float* xnew, const float* base, int64_t T, int64_t C, int64_t st, const double* gnew,
+                     const float* xq_all, const double* xq_common, const float* yq_all, int G, int nq, int kind, int extrap, float* scen,
+                     int64_t scen_st);
 /* QuantileDeltaMapping.adjust (xsdba._adjustment.qdm_adjust, group "time"): sim_q = rank(sim, pct=True) along time
  * (average ranks of the valid samples r / n, rescaled mx (r/n - mn) / (mx - mn) as xsdba.utils.rank does);
  * af_t = interp_on_quantiles(sim_q, q, af) with the nq quantile nodes q (host, strictly increasing) as abscissa

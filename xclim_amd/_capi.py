@@ -153,6 +153,7 @@ SIGNATURES: dict[str, list] = {
     "xh_eqm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64],
     "xh_eqm_adjust_g2d": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _int, _vp, _i64],
     "xh_apply_factor": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64],
+    "xh_plane_nearest": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _i64],
     "xh_plane_linear": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _vp, _i64],
     "xh_qdm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp],
     "xh_quantile_cells": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp],

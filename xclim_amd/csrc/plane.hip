@@ -300,6 +300,32 @@ __device__ double plane_locate(const PlaneCell& P, double qx, double qy) {
   return lam[0] * P.y(T.r[0], T.k[0]) + lam[1] * P.y(T.r[1], T.k[1]) + lam[2] * P.y(T.r[2], T.k[2]);
 }
 
+// method "nearest" (scipy griddata over the nodes of all groups: a cKDTree query in the (abscissa, group coordinate) plane, no
+// rescaling): the own row first, then the rows k = 1, 2 ... away (below before above) while a node there could still be
+// nearer (k^2 < best squared distance), the first of equally near nodes wins — the order of k_eqm_adjust_g2d (eqm.hip).
+__device__ double plane_nearest(const PlaneCell& P, double x, int r) {
+  const int G = P.t.G;
+  double best = __longlong_as_double(0x7FF0000000000000LL), a = xh_nan64();
+  const int n = P.count(r);
+  for (int j = 0; j < n; ++j) {
+    const double dx = x - P.x(r, j), d2 = dx * dx;
+    if (d2 < best) { best = d2; a = P.y(r, j); }
+  }
+  for (int k = 1; (double)k * (double)k < best && k <= G + 1; ++k) {
+#pragma unroll 1
+    for (int sgn = -1; sgn <= 1; sgn += 2) {
+      const int gg = r + sgn * k;
+      if (gg < 0 || gg > G + 1) continue;
+      const int m = P.count(gg);
+      for (int j = 0; j < m; ++j) {
+        const double dx = x - P.x(gg, j), d2 = dx * dx + (double)k * (double)k;
+        if (d2 < best) { best = d2; a = P.y(gg, j); }
+      }
+    }
+  }
+  return a;
+}
+
 __global__ void __launch_bounds__(XH_BLOCK)
 k_plane_linear(const float* __restrict__ xnew, const float* __restrict__ base, int64_t T, int64_t st, const double* __restrict__ gnew,
                PlaneTabs tabs, int kind, float* __restrict__ scen, int64_t scen_st) {
@@ -342,11 +368,13 @@ k_plane_linear(const float* __restrict__ xnew, const float* __restrict__ base, i
 // reaches no other row: Gabriel edge), so the plane interpolation is the linear interpolation along the row; wider gaps
 // (temperature tails, precipitation in mm/day) take the walk of plane_locate.  rows: CSR by row coordinate 1 .. G
 // (roff[r - 1] .. roff[r]) of the time steps with that coordinate.
-template <int NQMAX>
+// NEAREST: the nearest node of the plane instead — the own row's nearest node stands whenever it is at most one group step away
+// (any node of another row is at least that far), else the query is listed; bounds: the own row's, constant or NaN.
+template <int NQMAX, bool NEAREST>
 __global__ void __launch_bounds__(XH_BLOCK)
 k_plane_rows(const float* __restrict__ xnew, const float* __restrict__ base, int64_t st, const int32_t* __restrict__ roff,
              const int32_t* __restrict__ rsteps, PlaneTabs tabs, int kind, float* __restrict__ scen, int64_t scen_st, int r_first,
-             int r_end, uint2* __restrict__ work, unsigned int* __restrict__ nwork, unsigned long long segcap, int abl) {
+             int r_end, uint2* __restrict__ work, unsigned int* __restrict__ nwork, unsigned long long segcap, int abl, int extrap) {
   const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
   if (c >= tabs.C) return;
   // this workgroup's own stretch of the work list and its own counter: one counter for the whole grid was an atomic on ONE
@@ -381,13 +409,27 @@ k_plane_rows(const float* __restrict__ xnew, const float* __restrict__ base, int
       const float bf = base ? base[t * st + c] : xf;
       float a = xh_nan32();
       if (xf == xf) {
-        if (xf < lo) a = flo;
-        else if (xf > hi) a = fhi;
+        bool fast = false;
+        if (NEAREST) {
+          // (the bounds come AFTER the search upstream, _extrapolate_on_quantiles, but decide alone: outside them the search's
+          // result is overwritten)
+          if (xf < lo) { a = extrap == 0 ? flo : xh_nan32(); fast = true; }
+          else if (xf > hi) { a = extrap == 0 ? fhi : xh_nan32(); fast = true; }
+          else {
+            double best = __longlong_as_double(0x7FF0000000000000LL);
+#pragma unroll
+            for (int j = 0; j < NQMAX; ++j) {
+              const double dx = (double)xf - (double)nx[j], d2 = dx * dx;  // (padding: +inf, never the minimum)
+              if (d2 < best) { best = d2; a = ny[j]; }
+            }
+            fast = best <= 1.0;
+          }
+        } else if (xf < lo) { a = flo; fast = true; }
+        else if (xf > hi) { a = fhi; fast = true; }
         else {
           int idx = 0;  // nodes <= x, by counting (the nodes ascend)
 #pragma unroll
           for (int j = 0; j < NQMAX; ++j) idx += xf >= nx[j] ? 1 : 0;
-          bool fast = false;
           if (idx >= 1 && idx < n) {
             float x0 = nx[0], x1 = nx[1], y0 = ny[0], y1 = ny[1];
 #pragma unroll
@@ -413,6 +455,8 @@ k_plane_rows(const float* __restrict__ xnew, const float* __restrict__ base, int
               fast = true;
             }
           }
+        }
+        {
           if (!fast) {
             // the walk is a chain of dependent gathers: done here, a handful of lanes would hold the whole wave for tens of
             // microseconds at EVERY step (measured: 211 ms against 442 for the walk alone) — the query goes on a list that
@@ -438,7 +482,7 @@ k_plane_rows(const float* __restrict__ xnew, const float* __restrict__ base, int
 __global__ void __launch_bounds__(XH_BLOCK)
 k_plane_work(const float* __restrict__ xnew, const float* __restrict__ base, int64_t st, const double* __restrict__ gnew, PlaneTabs tabs,
              int kind, float* __restrict__ scen, int64_t scen_st, const uint2* __restrict__ work, const unsigned int* __restrict__ nwork,
-             unsigned long long segcap) {
+             unsigned long long segcap, int nearest) {
   const unsigned long long seg = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
   const unsigned int n = nwork[seg];
   const uint2* __restrict__ mywork = work + seg * segcap;
@@ -448,18 +492,16 @@ k_plane_work(const float* __restrict__ xnew, const float* __restrict__ base, int
     const PlaneCell P{tabs, c};
     const float xf = xnew[t * st + c];
     const float bf = base ? base[t * st + c] : xf;
-    const float a = (float)plane_locate(P, (double)xf, gnew[t]);
+    // (listed queries lie inside their row's bounds: the row kernel decided the others)
+    const float a = (float)(nearest ? plane_nearest(P, (double)xf, (int)gnew[t]) : plane_locate(P, (double)xf, gnew[t]));
     scen[t * scen_st + c] = kind == 0 ? (bf + a) : (kind == 1 ? (bf * a) : a);
   }
 }
 
-}  // namespace
-
-extern "C" {
-
-int xh_plane_linear(xh_ctx* ctx, const float* xnew, const float* base, int64_t T, int64_t C, int64_t st, const double* gnew,
-                    const float* xq_all, const double* xq_common, const float* yq_all, int G, int nq, int kind, float* scen,
-                    int64_t scen_st) {
+// method 1 = "linear" (Delaunay interpolation), 0 = "nearest" (integer coordinates only; extrap 0 constant | 1 nan)
+int plane_run(xh_ctx* ctx, const float* xnew, const float* base, int64_t T, int64_t C, int64_t st, const double* gnew,
+              const float* xq_all, const double* xq_common, const float* yq_all, int G, int nq, int kind, float* scen,
+              int64_t scen_st, int method, int extrap) {
   XH_REQUIRE(ctx && xnew && gnew && yq_all && scen, XH_ERR_ARG, "xh_plane_linear: NULL argument");
   XH_REQUIRE((xq_all != nullptr) != (xq_common != nullptr), XH_ERR_ARG, "xh_plane_linear: give xq_all (G, nq, C) OR xq_common (nq)");
   XH_REQUIRE(T >= 0 && C >= 0 && nq >= 1 && nq <= 255 && G >= 1, XH_ERR_ARG, "xh_plane_linear: bad shape (1 <= nq <= 255, G >= 1)");
@@ -497,12 +539,14 @@ int xh_plane_linear(xh_ctx* ctx, const float* xnew, const float* base, int64_t T
   PlaneTabs tabs{px, py, cnt, fx, lx, fy, ly, G, nq, C};
   // integer group coordinates in 1 .. G (day-of-year groupings): the row kernel.  gnew is a device array: T doubles come
   // back once per call (one synchronisation per adjust); the CSR by row goes up through the context's table scratch.
-  if (nq <= 32 && T < ((int64_t)1 << 31) && !xh_diag_env("XH_PLANE_NOROWS")) {
+  XH_REQUIRE(method == 1 || (nq <= 32 && T < ((int64_t)1 << 31)), XH_ERR_LIMIT, "xh_plane_nearest: at most 32 nodes per group");
+  if (nq <= 32 && T < ((int64_t)1 << 31) && (method == 0 || !xh_diag_env("XH_PLANE_NOROWS"))) {
     std::vector<double> g((size_t)T);
     XH_CHECK_HIP(hipMemcpyAsync(g.data(), gnew, 8 * (size_t)T, hipMemcpyDeviceToHost, ctx->stream));
     XH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     bool integral = true;
     for (int64_t t = 0; t < T && integral; ++t) integral = g[t] >= 1.0 && g[t] <= (double)G && g[t] == floor(g[t]);
+    XH_REQUIRE(integral || method == 1, XH_ERR_ARG, "xh_plane_nearest: the group coordinates must be integers in 1 .. G");
     if (integral) {
       std::vector<int32_t> off((size_t)G + 1, 0), steps((size_t)T);
       for (int64_t t = 0; t < T; ++t) off[(size_t)g[t]]++;
@@ -540,15 +584,18 @@ int xh_plane_linear(xh_ctx* ctx, const float* xnew, const float* base, int64_t T
         if (r1 > G + 1) r1 = G + 1;
         const unsigned long long segcap = (unsigned long long)rchunk * (unsigned long long)maxsteps * XH_BLOCK;
         XH_CHECK_HIP(hipMemsetAsync(nwork, 0, 4 * (size_t)(gy * cblocks), ctx->stream));
-        if (nq <= 20)
-          hipLaunchKernelGGL((k_plane_rows<20>), dim3((unsigned)cblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, xnew, base, st,
-                             (const int32_t*)d_off, (const int32_t*)d_steps, tabs, kind, scen, scen_st, r0, r1, work, nwork, segcap, abl);
-        else
-          hipLaunchKernelGGL((k_plane_rows<32>), dim3((unsigned)cblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, xnew, base, st,
-                             (const int32_t*)d_off, (const int32_t*)d_steps, tabs, kind, scen, scen_st, r0, r1, work, nwork, segcap, abl);
+#define XH_PLANE_ROWS(NQM, NEAR)                                                                                                  \
+  hipLaunchKernelGGL((k_plane_rows<NQM, NEAR>), dim3((unsigned)cblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, xnew, base, st, \
+                     (const int32_t*)d_off, (const int32_t*)d_steps, tabs, kind, scen, scen_st, r0, r1, work, nwork, segcap, abl, extrap)
+        if (method == 1) {
+          if (nq <= 20) XH_PLANE_ROWS(20, false); else XH_PLANE_ROWS(32, false);
+        } else {
+          if (nq <= 20) XH_PLANE_ROWS(20, true); else XH_PLANE_ROWS(32, true);
+        }
+#undef XH_PLANE_ROWS
         if (!(abl & 3))
           hipLaunchKernelGGL(k_plane_work, dim3((unsigned)cblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, xnew, base, st, gnew, tabs,
-                             kind, scen, scen_st, work, nwork, segcap);
+                             kind, scen, scen_st, work, nwork, segcap, method == 0 ? 1 : 0);
         r0 = r1;
       }
       XH_LAUNCH_CHECK();
@@ -563,6 +610,23 @@ int xh_plane_linear(xh_ctx* ctx, const float* xnew, const float* base, int64_t T
                      kind, scen, scen_st);
   XH_LAUNCH_CHECK();
   return XH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xh_plane_linear(xh_ctx* ctx, const float* xnew, const float* base, int64_t T, int64_t C, int64_t st, const double* gnew,
+                    const float* xq_all, const double* xq_common, const float* yq_all, int G, int nq, int kind, float* scen,
+                    int64_t scen_st) {
+  return plane_run(ctx, xnew, base, T, C, st, gnew, xq_all, xq_common, yq_all, G, nq, kind, scen, scen_st, 1, 0);
+}
+
+int xh_plane_nearest(xh_ctx* ctx, const float* xnew, const float* base, int64_t T, int64_t C, int64_t st, const double* gnew,
+                     const float* xq_all, const double* xq_common, const float* yq_all, int G, int nq, int kind, int extrap, float* scen,
+                     int64_t scen_st) {
+  XH_REQUIRE(extrap == 0 || extrap == 1, XH_ERR_ARG, "xh_plane_nearest: extrap must be 0 (constant) or 1 (nan)");
+  return plane_run(ctx, xnew, base, T, C, st, gnew, xq_all, xq_common, yq_all, G, nq, kind, scen, scen_st, 0, extrap);
 }
 
 }  // extern "C"

@@ -716,6 +716,21 @@ def plane_linear(dev: Device, xnew: DeviceArray, gnew, yq_all: DeviceArray, *, x
     return scen
 
 
+def plane_nearest(dev: Device, xnew: DeviceArray, gnew, yq_all: DeviceArray, xq_all: DeviceArray, kind="+", extrapolation="constant",
+                  out: DeviceArray | None = None) -> DeviceArray:
+    """xh_plane_nearest: xsdba's 2-D ``interp_on_quantiles(method="nearest")`` for a month / day-of-year grouping over the
+    whole series in one call; gnew (T): the INTEGER group coordinate 1 .. G of every step; yq_all / xq_all (G, nq <= 32, C)."""
+    T, C_ = _tc(xnew)
+    G, nq = int(yq_all.shape[0]), int(yq_all.shape[1])
+    gd = gnew if isinstance(gnew, DeviceArray) else dev.to_device(np.ascontiguousarray(gnew, dtype=np.float64))
+    if int(gd.shape[0]) != T:
+        raise ValueError("plane_nearest: one group coordinate per time step")
+    scen = out if out is not None else dev.empty((T, C_), np.float32)
+    dev.call("xh_plane_nearest", _vp(xnew.ptr), None, T, C_, C_, _vp(gd.ptr), _vp(xq_all.ptr), None, _vp(yq_all.ptr), G, nq,
+             {"+": 0, "*": 1, "factor": 2}[kind], {"constant": 0, "nan": 1}[extrapolation], _vp(scen.ptr), C_)
+    return scen
+
+
 def apply_factor(dev: Device, base: DeviceArray, fac: DeviceArray, kind="+", out: DeviceArray | None = None) -> DeviceArray:
     """xh_apply_factor: base (+|*) fac, two (T, C) float32 fields."""
     T, C_ = _tc(base)

@@ -318,6 +318,14 @@ class EmpiricalQuantileMapping:
             scen = K.plane_linear(dev, s, self.group.coordinate(time, interp=True), self._af, xq_all=self._hist_q, kind=self.kind)
             dev.sync()
             return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
+        plane2d = self._plane_nearest(grouped_nearest)
+        if plane2d:
+            # xsdba's nearest node in the (hist_q, group) plane: ONE launch over the whole series (round 5; rounds 3-4 permuted
+            # the rows group-major and launched xh_eqm_adjust_g2d per group: 145 ms against 15 for a 30-year 1440 x 90 band
+            # with 365 groups)
+            scen = K.plane_nearest(dev, s, gi + 1.0, self._af, self._hist_q, self.kind, extrapolation)
+            dev.sync()
+            return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
         # group-major permutation of the rows: every group becomes one contiguous block
         perm = np.argsort(gi, kind="stable")
         counts = np.bincount(gi, minlength=len(self.group_labels))
@@ -325,7 +333,6 @@ class EmpiricalQuantileMapping:
         nq = len(self.quantiles)
         s_perm = K.select_rows(dev, s, perm)
         scen_perm = dev.empty((T, C_), np.float32)
-        plane2d = self._plane_nearest(grouped_nearest)
         off = 0
         for g, n in enumerate(counts):
             if n == 0:
