@@ -9,24 +9,28 @@
 // qdm.hip / numpy), the order statistic that first reaches it, and then every sample is classified by <= 6 compares against
 // the column's <= nq + 1 cut values.
 //
-//   1    the column in REGISTERS (two lanes per column, 183 keys each, as select3.hip); valid count n, smallest key and
-//        its copies cnt0 (dry days: exact) from the unsorted keys
-//   2    per (column, boundary): R = min { r2 : test(pct(r2)) } by an analytic guess + exact verification, then the rank
-//        p = ceil((R - 2) / 2) (inside the minimum's run: rank 0 if its r2 = cnt0 + 1 passes, else rank cnt0).  32 of the
-//        183 registers wait in LDS meanwhile: the fp64 arithmetic needs the room.
+//   1    the column in REGISTERS (two lanes per column, 183 keys each, as select3.hip); the valid count n = T - #NaN falls
+//        out of the key conversion
 //   3-5  sort by the comparator networks of select3.hip (local sort, split across the lane pair, merge)
-//   6    adjacent equal keys in the sorted column: any tie that is not a copy of the minimum puts the column on a list for
-//        the exact-rank kernel of qdm.hip (k_qdm_columns) — ties decide average ranks, and following them needs counts
-//        this kernel does not have.  Without ties the run of sorted[p] is [p, p + 1): r2 = 2p + 2.
-//   7    the <= nq + 1 order statistics leave the registers through the LDS hand-over of select3.hip (one monotone pass)
-//   8    the tile's rows are read again (L2 / Infinity Cache), classified by a branch-free binary search over the cut
-//        values in LDS, corrected and stored.
-// HBM traffic: sim once, scen once.
+//   1b   smallest key = rank 0, its copies cnt0 (dry days: exact): 1 when rank 1 differs, else counted
+//   2    per (column, boundary): R = min { r2 : test(pct(r2)) } (qdmrank.h) — looked up in a table by cnt0 when the column has
+//        T valid samples and all nq nodes (k_qdm_rank_table, round 5), else an analytic guess + exact verification in fp64
+//        (32 of the 183 registers wait in LDS meanwhile) — then the rank p = ceil((R - 2) / 2) (inside the minimum's run:
+//        rank 0 if its r2 = cnt0 + 1 passes, else rank cnt0)
+//   6-7  the <= nq + 1 order statistics leave the registers through the LDS hand-over of select3.hip (one monotone pass).
+//        A pick with an equal neighbour sits in a run [a, b) of equal keys: the cut is that value if a + b + 1 >= R, else
+//        the value at rank b (round 5; until then every such column went to the exact-rank kernel).  Runs that cross a
+//        hand-over chunk and copies of the MAXIMUM (they change the rank scale of the whole column) still put the column
+//        on a list for k_qdm_columns.
+//   8    the cut values and class factors leave for k_cut_classify (one streaming pass: read, classify by a branch-free
+//        binary search, correct, store); XH_QDM_SPLIT=0: this kernel re-reads its tile and classifies itself.
+// HBM traffic: sim twice, scen once, the tables (2 nq + 3 floats per column) once each way.
 #include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
 #include "rowstream.h"
+#include "qdmrank.h"
 #include "sortnet_183.h"
 
 namespace {
@@ -56,7 +60,10 @@ __global__ void __launch_bounds__(256, 2)
 k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const float* __restrict__ af, int64_t af_qs,
               const double* __restrict__ qnodes, int nq, int kind, int extrap, float* __restrict__ out, int64_t ost,
               uint32_t* __restrict__ flist, uint32_t* __restrict__ nflag, int abl, float* __restrict__ gcut,
-              float* __restrict__ gfac) {
+              float* __restrict__ gfac, const uint16_t* __restrict__ rtab, int rtab_lds) {
+  // rtab_lds: the rank table fits in LDS behind the waves' regions
+  // rtab != nullptr: the boundary ranks R of a column with T valid samples, a single maximum and nq valid nodes, by the copies
+  // of its minimum ([T][nq + 1], k_qdm_rank_table): a wave whose 32 columns are all of that kind looks them up
   // gcut != nullptr: the tables leave for k_cut_classify (cut values [nq + 1][C], class factors [nq + 2][C]) and this kernel
   // neither re-reads nor writes the series
   const bool split = gcut != nullptr;
@@ -67,6 +74,9 @@ k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const f
   const int tid = threadIdx.x, w = tid >> 6;
   const int ntmax = nq + 1;  // tests per column at most
   if (tid < nq) qS[tid] = qnodes[tid];
+  uint16_t* rtabS = reinterpret_cast<uint16_t*>(wave0 + 4 * qr_words_per_wave(nq));
+  if (rtab_lds)
+    for (int i = tid; i < T * ntmax; i += 256) rtabS[i] = rtab[i];
   __syncthreads();
   uint32_t* ncol = wave0 + w * qr_words_per_wave(nq);
   uint32_t* c0col = ncol + 32;
@@ -74,7 +84,8 @@ k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const f
   uint32_t* nvcol = stcol + 32;
   uint8_t* idx = reinterpret_cast<uint8_t*>(nvcol + 32);                                  // [nq][32] node index of the j-th valid node
   float* FS = reinterpret_cast<float*>(reinterpret_cast<uint32_t*>(idx) + (nq * 32 + 3) / 4);  // [ntmax + 1][32], after the picks
-  uint16_t* rkT = reinterpret_cast<uint16_t*>(FS);                                        // [ntmax][32] until then
+  uint16_t* rkT = reinterpret_cast<uint16_t*>(FS);                                        // [ntmax + 1][32] until then
+  uint16_t* rRT = rkT + (ntmax + 1) * 32;                                                 // [ntmax + 1][32] the boundaries' R (0: the maximum's target)
   uint32_t* vals = reinterpret_cast<uint32_t*>(FS) + (ntmax + 1) * 32;                    // [ntmax + 1][32] keys, then float cuts
   uint32_t* dump = vals + (ntmax + 1) * 32;                                               // [32][64]
   const int64_t ntiles = (C + 31) / 32;
@@ -103,152 +114,30 @@ k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const f
       uint32_t bcut = h ? (uint32_t)(2 * N - T) : 0u;
       asm volatile("" : "+v"(bcut));
       // keys of x + 0.0f: -0.0 and +0.0 tie (rankdata); NaN / the rows lane A holds too -> pad
+      uint32_t nanc = 0u;  // NaN among my rows (lane B: not those lane A holds too)
 #define XH_CV(i)                                                           \
   {                                                                        \
     const float f_ = __uint_as_float(k##i) + 0.0f;                         \
     const uint32_t u_ = __float_as_uint(f_);                               \
     uint32_t kk_ = u_ ^ ((uint32_t)((int32_t)u_ >> 31) | 0x80000000u);    \
-    kk_ = (f_ != f_) ? PADK : kk_;                                         \
-    if (i < 2 * N - TMIN) kk_ = ((uint32_t)i < bcut) ? PADK : kk_;         \
+    if (i < 2 * N - TMIN) {                                                \
+      kk_ = (f_ != f_) ? PADK : kk_;                                       \
+      kk_ = ((uint32_t)i < bcut) ? PADK : kk_;                             \
+      nanc += (f_ != f_ && !((uint32_t)i < bcut)) ? 1u : 0u;               \
+    } else {                                                               \
+      /* NaN -> pad, counted by the same compare (the mask is consumed at once: no SGPR pair lives on) */ \
+      asm volatile("v_cmp_u_f32 vcc, %2, %2\n\tv_cndmask_b32_e64 %0, %0, -1, vcc\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" \
+                   : "+v"(kk_), "+v"(nanc) : "v"(f_) : "vcc");            \
+    }                                                                      \
     k##i = kk_;                                                            \
   }
       XH_SN_FOREACH(XH_CV)
 #undef XH_CV
-    }
-    uint32_t lane1 = (uint32_t)tid & 63u;
-    asm volatile("" : "+v"(lane1));
-    uint32_t* mydump = dump + lane1;
-#define XH_DW(e, reg) mydump[(e) * 64] = reg;
-#define QR_DUMP_CHUNK(ci)                   \
-  switch (ci) {                             \
-    case 0: XH_SN_DUMP_0(XH_DW) break;      \
-    case 1: XH_SN_DUMP_1(XH_DW) break;      \
-    case 2: XH_SN_DUMP_2(XH_DW) break;      \
-    case 3: XH_SN_DUMP_3(XH_DW) break;      \
-    case 4: XH_SN_DUMP_4(XH_DW) break;      \
-    default: XH_SN_DUMP_5(XH_DW) break;     \
-  }
-    static_assert(XH_SN_CHUNKS == 6 && N > 160 && N <= 192, "six hand-over chunks of 32 registers");
-    // ---- 1b. valid count, smallest key and its copies, from the unsorted keys (pads and NaN are 0xFFFFFFFF: never the
-    //      minimum of a column that holds a sample).  The registers pass through the hand-over buffer and are counted in a
-    //      ROLLED loop: unrolled over 183 registers the three counters were 7 KB of code, and the kernel has to stay inside
-    //      the 64 KB instruction cache (sort networks: 32 KB).
-    if (!(abl & 1)) {
-      const uint32_t h = lane1 & 1u, c32 = lane1 >> 1;
-      uint32_t nvl = 0u, kml = PADK, cml = 0u;
-#pragma nounroll
-      for (int ci = 0; ci < 6; ++ci) {
-        QR_DUMP_CHUNK(ci)
-        const int cnt = ci < 5 ? 32 : N - 160;
-#pragma unroll 4
-        for (int e = 0; e < cnt; ++e) {
-          const uint32_t v = mydump[e * 64];
-          nvl += v != PADK ? 1u : 0u;
-          const bool lt = v < kml;
-          cml = lt ? 1u : cml + (v == kml ? 1u : 0u);
-          kml = lt ? v : kml;
-        }
-      }
-      const uint32_t pk = qr_swap1(kml), pc = qr_swap1(cml);
-      const uint32_t kmin = pk < kml ? pk : kml;
-      const uint32_t n = nvl + qr_swap1(nvl), cnt0 = (kml == kmin ? cml : 0u) + (pk == kmin ? pc : 0u);
-      // nothing valid / all valid samples equal: 0 / 0 ranks -> NaN (qdm.hip)
-      if (h == 0) { ncol[c32] = n; c0col[c32] = cnt0; stcol[c32] = (n == 0u || cnt0 >= n) ? QR_NAN : QR_OK; }
-    }
-    if (abl & 3) {  // diagnostics only: sane tables for the phases that still run
-      if (abl & 1) { if (lane1 < 32u) { ncol[lane1] = (uint32_t)T; c0col[lane1] = 1u; stcol[lane1] = QR_OK; } }
-      if (abl & 2) {
-        for (int i = (int)lane1; i < (ntmax + 1) * 32; i += 64) { rkT[i] = (uint16_t)QR_SENT; vals[i] = PADK; }
-        if (lane1 < 32u) nvcol[lane1] = 2u;
-        for (int i = (int)lane1; i < nq * 32; i += 64) idx[i] = 0;
-      }
-      qr_fence();
-    }
-    // ---- 2. ranks of the class boundaries.  k0 .. k31 wait in the hand-over buffer while the fp64 arithmetic runs.
-    if (!(abl & 2)) {
-      QR_DUMP_CHUNK(0)
-      qr_fence();
-      // ---- 2a. nodes of the column: drop the NaN factors (interp_on_quantiles masks them); lane c < 32 owns column c
-      if (lane1 < 32u) {
-        const int64_t cc = col0 + lane1 < C ? col0 + lane1 : C - 1;
-        uint32_t cnt = 0;
-        // 8 factors in flight (one load per iteration would pay a full memory latency nq times)
-#pragma nounroll
-        for (int j0 = 0; j0 < nq; j0 += 8) {
-          float a[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) a[u] = af[(int64_t)(j0 + u < nq ? j0 + u : nq - 1) * af_qs + cc];
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (j0 + u < nq && a[u] == a[u]) { idx[cnt * 32 + lane1] = (uint8_t)(j0 + u); ++cnt; }
-        }
-        nvcol[lane1] = cnt;
-        if (cnt < 2u && stcol[lane1] == QR_OK) stcol[lane1] = QR_NAN;  // fewer than two nodes: nothing to interpolate on
-      }
-      qr_fence();
-      // ---- 2b. per (column, boundary) the rank of the order statistic that opens the class.  Lane: column lane & 31, the
-      //      even (lanes < 32) or odd boundaries.
+      // valid count of the column: leaves for LDS now (no register lives through the sort for it)
       {
-        const uint32_t c = lane1 & 31u;
-        const uint32_t nn = ncol[c], c0 = c0col[c], nvn = nvcol[c];
-        const bool ok = stcol[c] == QR_OK;
-        const double dn = (double)nn;
-        const double mn = ((double)(c0 + 1u) / 2.0) / dn;           // rank of the minimum / count
-        const double mx = ((double)(2u * nn - 1u + 1u) / 2.0) / dn;  // rank of the (single) maximum / count
-        const double mxmn = mx - mn;
-        const double inv_dn = 1.0 / dn, inv_mxmn = 1.0 / mxmn;
-        const double slope = 2.0 * dn * (mxmn / mx);                 // d r2 / d pct
-#pragma nounroll
-        for (uint32_t t = lane1 >> 5; t < (uint32_t)ntmax; t += 2u) {
-          uint32_t rank = QR_SENT;
-          if (ok && t <= nvn) {
-            // t = 0: pct >= x0 (not below the first node); 0 < t < nvn: pct > (x[t-1] / 2 + x[t] / 2), scipy's nearest
-            // bounds; t = nvn: pct > the last node
-            double thr;
-            if (t == 0u) thr = qS[idx[c]];
-            else if (t == nvn) thr = qS[idx[(nvn - 1u) * 32 + c]];
-            else thr = qS[idx[(t - 1u) * 32 + c]] / 2.0 + qS[idx[t * 32 + c]] / 2.0;
-            // pct ~ mx (r2 / 2n - mn) / mxmn  =>  r2 ~ 2n mn + thr slope; then exactly: down while R - 1 passes, up while R fails
-            const double g = 2.0 * dn * mn + thr * slope;
-            uint32_t R = g < 1.0 ? 1u : (g > 2.0 * dn ? 2u * nn : (uint32_t)g);
-            bool down = true;
-            for (;;) {
-              const uint32_t probe = down ? R - 1u : R;
-              const bool valid = down ? R > 1u : R <= 2u * nn;
-              bool pass = false;
-              if (valid) {
-                const double rnk = xh_div_int((double)probe * 0.5, dn, inv_dn);
-                const double p = xh_div_int(mx * (rnk - mn), mxmn, inv_mxmn);
-                pass = t == 0u ? !(p < thr) : p > thr;
-              }
-              if (down) {
-                if (pass) --R; else down = false;
-              } else {
-                if (!valid || pass) break;
-                ++R;
-              }
-            }
-            if (R <= 2u * nn) {
-              const uint32_t p = R <= 2u ? 0u : (R - 1u) >> 1;  // ceil((R - 2) / 2): first position whose r2 = 2p + 2 reaches R
-              if (p < c0) rank = (c0 + 1u >= R) ? 0u : c0;      // inside the minimum's run [0, c0): its r2 is c0 + 1
-              else rank = p;
-              if (rank >= nn) rank = QR_SENT;
-            }
-          }
-          rkT[t * 32 + c] = (uint16_t)rank;
-          vals[t * 32 + c] = PADK;  // a boundary nobody reaches decodes to NaN: every compare fails
-        }
-        // one more target, for the tie test only: the maximum (rank n - 1).  Copies of the maximum change mx, i.e. the
-        // percentage rank of EVERY sample, wherever the class boundaries lie.
-        if (lane1 < 32u) {
-          vals[ntmax * 32 + lane1] = PADK;
-          rkT[ntmax * 32 + lane1] = (uint16_t)(ok && nn >= 1u ? nn - 1u : QR_SENT);
-        }
+        const uint32_t nn_ = (uint32_t)T - (nanc + qr_swap1(nanc));
+        if (h == 0u) ncol[c32] = nn_;
       }
-      qr_fence();
-#define XH_UP(e, reg) reg = mydump[(e) * 64];
-      XH_SN_DUMP_0(XH_UP)
-#undef XH_UP
     }
     // ---- 3. local sort
 #define XH_CE(i, j)                               \
@@ -293,6 +182,153 @@ k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const f
     XH_SN_MERGE(XH_CE)
     }
 #undef XH_CE
+    uint32_t lane1 = (uint32_t)tid & 63u;
+    asm volatile("" : "+v"(lane1));
+    uint32_t* mydump = dump + lane1;
+#define XH_DW(e, reg) mydump[(e) * 64] = reg;
+#define QR_DUMP_CHUNK(ci)                   \
+  switch (ci) {                             \
+    case 0: XH_SN_DUMP_0(XH_DW) break;      \
+    case 1: XH_SN_DUMP_1(XH_DW) break;      \
+    case 2: XH_SN_DUMP_2(XH_DW) break;      \
+    case 3: XH_SN_DUMP_3(XH_DW) break;      \
+    case 4: XH_SN_DUMP_4(XH_DW) break;      \
+    default: XH_SN_DUMP_5(XH_DW) break;     \
+  }
+    static_assert(XH_SN_CHUNKS == 6 && N > 160 && N <= 192, "six hand-over chunks of 32 registers");
+    // ---- 1b. smallest key and its copies, from the SORTED column: rank 0 is lane A's k[N-1]; a column whose rank 1 differs has
+    //      one copy (every column of a continuous field), else the copies are counted through the hand-over buffer in a
+    //      ROLLED loop (dry days; the kernel has to stay inside the 64 KB instruction cache: sort networks 32 KB)
+    if (!(abl & 1)) {
+      const uint32_t h = lane1 & 1u, c32 = lane1 >> 1;
+      const uint32_t mAs = h ? 0u : 0xFFFFFFFFu;
+      const uint32_t n = ncol[c32];
+      uint32_t kmin = k182 ^ mAs;
+      const uint32_t pk = qr_swap1(kmin);
+      kmin = h ? pk : kmin;
+      static_assert(N == 183, "rank 0 / rank 1 of the column: k182 / k181 of lane A");
+      const bool more = !h && (k181 ^ mAs) == kmin && kmin != PADK;
+      uint32_t cml = h ? 0u : 1u;
+      if (__any(more ? 1 : 0)) {
+        cml = 0u;
+#pragma nounroll
+        for (int ci = 0; ci < 6; ++ci) {
+          QR_DUMP_CHUNK(ci)
+          const int cnt = ci < 5 ? 32 : N - 160;
+#pragma unroll 8
+          for (int e = 0; e < cnt; ++e) cml += ((mydump[e * 64] ^ mAs) == kmin) ? 1u : 0u;
+        }
+      }
+      const uint32_t cnt0 = cml + qr_swap1(cml);
+      // nothing valid / all valid samples equal: 0 / 0 ranks -> NaN (qdm.hip)
+      if (h == 0) { c0col[c32] = cnt0; stcol[c32] = (n == 0u || cnt0 >= n) ? QR_NAN : QR_OK; }
+    }
+    if (abl & 3) {  // diagnostics only: sane tables for the phases that still run
+      if (abl & 1) { if (lane1 < 32u) { ncol[lane1] = (uint32_t)T; c0col[lane1] = 1u; stcol[lane1] = QR_OK; } }
+      if (abl & 2) {
+        for (int i = (int)lane1; i < (ntmax + 1) * 32; i += 64) { rkT[i] = (uint16_t)QR_SENT; vals[i] = PADK; }
+        if (lane1 < 32u) nvcol[lane1] = 2u;
+        for (int i = (int)lane1; i < nq * 32; i += 64) idx[i] = 0;
+      }
+      qr_fence();
+    }
+    // ---- 2. ranks of the class boundaries.  k0 .. k31 wait in the hand-over buffer while the fp64 arithmetic runs.
+    if (!(abl & 2)) {
+      QR_DUMP_CHUNK(0)
+      qr_fence();
+      // ---- 2a. nodes of the column: drop the NaN factors (interp_on_quantiles masks them); lane c < 32 owns column c
+      if (lane1 < 32u) {
+        const int64_t cc = col0 + lane1 < C ? col0 + lane1 : C - 1;
+        uint32_t cnt = 0;
+        // 8 factors in flight (one load per iteration would pay a full memory latency nq times)
+#pragma nounroll
+        for (int j0 = 0; j0 < nq; j0 += 8) {
+          float a[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = af[(int64_t)(j0 + u < nq ? j0 + u : nq - 1) * af_qs + cc];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (j0 + u < nq && a[u] == a[u]) { idx[cnt * 32 + lane1] = (uint8_t)(j0 + u); ++cnt; }
+        }
+        nvcol[lane1] = cnt;
+        if (cnt < 2u && stcol[lane1] == QR_OK) stcol[lane1] = QR_NAN;  // fewer than two nodes: nothing to interpolate on
+      }
+      qr_fence();
+      // ---- 2b. per (column, boundary) the rank of the order statistic that opens the class.  Lane: column lane & 31, the
+      //      even (lanes < 32) or odd boundaries.
+      {
+        const uint32_t c = lane1 & 31u;
+        const uint32_t nn = ncol[c], c0 = c0col[c], nvn = nvcol[c];
+        const bool ok = stcol[c] == QR_OK;
+        const bool lut = rtab != nullptr && __all((!ok || (nn == (uint32_t)T && nvn == (uint32_t)nq)) ? 1 : 0);
+        if (lut) {
+          auto put = [&](uint32_t t, uint32_t R) {
+            uint32_t rank = QR_SENT;
+            if (ok && R <= 2u * nn) {
+              const uint32_t p = qdm_pos_of_r2(R);
+              rank = p < c0 ? ((c0 + 1u >= R) ? 0u : c0) : p;
+              if (rank >= nn) rank = QR_SENT;
+            }
+            rkT[t * 32 + c] = (uint16_t)rank;
+            rRT[t * 32 + c] = (uint16_t)R;
+            vals[t * 32 + c] = PADK;
+          };
+          const uint32_t roff = (ok ? c0 - 1u : 0u) * (uint32_t)ntmax;
+          if (rtab_lds) {
+#pragma nounroll
+            for (uint32_t t = lane1 >> 5; t < (uint32_t)ntmax; t += 2u) put(t, rtabS[roff + t]);
+          } else {
+            // 8 table entries in flight per round
+            const uint16_t* row = rtab + roff;
+#pragma nounroll
+            for (uint32_t t0 = lane1 >> 5; t0 < (uint32_t)ntmax; t0 += 16u) {
+              uint32_t Rr[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) { const uint32_t t = t0 + 2u * (uint32_t)u; Rr[u] = row[t < (uint32_t)ntmax ? t : (uint32_t)ntmax - 1u]; }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const uint32_t t = t0 + 2u * (uint32_t)u;
+                if (t < (uint32_t)ntmax) put(t, Rr[u]);
+              }
+            }
+          }
+        } else {
+#pragma nounroll
+        for (uint32_t t = lane1 >> 5; t < (uint32_t)ntmax; t += 2u) {
+          uint32_t rank = QR_SENT, R = 0u;
+          if (ok && t <= nvn) {
+            // t = 0: pct >= x0 (not below the first node); 0 < t < nvn: pct > (x[t-1] / 2 + x[t] / 2), scipy's nearest
+            // bounds; t = nvn: pct > the last node
+            double thr;
+            if (t == 0u) thr = qS[idx[c]];
+            else if (t == nvn) thr = qS[idx[(nvn - 1u) * 32 + c]];
+            else thr = qS[idx[(t - 1u) * 32 + c]] / 2.0 + qS[idx[t * 32 + c]] / 2.0;
+            R = qdm_min_r2(t == 0u, thr, nn, c0, 1u);  // (a single maximum: copies of it put the column on the list)
+            if (R <= 2u * nn) {
+              const uint32_t p = qdm_pos_of_r2(R);  // first position whose r2 = 2p + 2 reaches R
+              if (p < c0) rank = (c0 + 1u >= R) ? 0u : c0;      // inside the minimum's run [0, c0): its r2 is c0 + 1
+              else rank = p;
+              if (rank >= nn) rank = QR_SENT;
+            }
+          }
+          rkT[t * 32 + c] = (uint16_t)rank;
+          rRT[t * 32 + c] = (uint16_t)R;
+          vals[t * 32 + c] = PADK;  // a boundary nobody reaches decodes to NaN: every compare fails
+        }
+        }
+        // one more target, for the tie test only: the maximum (rank n - 1).  Copies of the maximum change mx, i.e. the
+        // percentage rank of EVERY sample, wherever the class boundaries lie.
+        if (lane1 < 32u) {
+          vals[ntmax * 32 + lane1] = PADK;
+          rkT[ntmax * 32 + lane1] = (uint16_t)(ok && nn >= 1u ? nn - 1u : QR_SENT);
+          rRT[ntmax * 32 + lane1] = 0;
+        }
+      }
+      qr_fence();
+#define XH_UP(e, reg) reg = mydump[(e) * 64];
+      XH_SN_DUMP_0(XH_UP)
+#undef XH_UP
+    }
     uint32_t lane4 = (uint32_t)tid & 63u;
     asm volatile("" : "+v"(lane4));
     const uint32_t h = lane4 & 1u, c32 = lane4 >> 1;
@@ -324,29 +360,40 @@ k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const f
       uint32_t snext = local_of(jcur);
       uint32_t tied = 0u;
       const uint32_t partner0 = qr_swap1(k0 ^ mA);  // the partner lane's k0 as a real key: my local index -1
-#define XH_PICK(c, LO, HI)                                                        \
-  {                                                                               \
-    const uint32_t lo_edge_ = (LO), hi_edge_ = (HI);                              \
-    XH_SN_DUMP_##c(XH_DW)                                                         \
-    constexpr uint32_t cnt_ = (c) < 5 ? 32u : (uint32_t)(N - 160);                \
-    while ((snext >> 5) == (uint32_t)(c)) {                                       \
-      const uint32_t e_ = snext & 31u;                                            \
-      const uint32_t v_ = mydump[e_ * 64] ^ mA;                                   \
-      const uint32_t lo_ = e_ > 0u ? mydump[(e_ - 1u) * 64] ^ mA : lo_edge_;      \
-      const uint32_t hi_ = e_ + 1u < cnt_ ? mydump[(e_ + 1u) * 64] ^ mA : hi_edge_; \
-      vals[jcur * 32 + (int)c32] = v_;                                            \
-      tied |= ((lo_ == v_ || hi_ == v_) && rkT[jcur * 32 + c32] >= c0) ? 1u : 0u;  \
-      jcur = next_mine(jcur + dj);                                                \
-      snext = local_of(jcur);                                                     \
-    }                                                                             \
-  }
-      XH_PICK(0, partner0, k32 ^ mA)
-      XH_PICK(1, k31 ^ mA, k64 ^ mA)
-      XH_PICK(2, k63 ^ mA, k96 ^ mA)
-      XH_PICK(3, k95 ^ mA, k128 ^ mA)
-      XH_PICK(4, k127 ^ mA, k160 ^ mA)
-      XH_PICK(5, k159 ^ mA, PADK)
-#undef XH_PICK
+#pragma nounroll
+      for (uint32_t ci = 0; ci < 6u; ++ci) {
+        QR_DUMP_CHUNK(ci)
+        const uint32_t cnt_ = ci < 5u ? 32u : (uint32_t)(N - 160);
+        // lane-local neighbours of the chunk's edges (real keys)
+        const uint32_t lo_edge_ = ci == 0u ? partner0 : (ci == 1u ? k31 : ci == 2u ? k63 : ci == 3u ? k95 : ci == 4u ? k127 : k159) ^ mA;
+        const uint32_t hi_edge_ = ci == 5u ? PADK : (ci == 0u ? k32 : ci == 1u ? k64 : ci == 2u ? k96 : ci == 3u ? k128 : k160) ^ mA;
+        while ((snext >> 5) == ci) {
+          const uint32_t e_ = snext & 31u;
+          uint32_t v_ = mydump[e_ * 64] ^ mA;
+          const uint32_t lo_ = e_ > 0u ? mydump[(e_ - 1u) * 64] ^ mA : lo_edge_;
+          const uint32_t hi_ = e_ + 1u < cnt_ ? mydump[(e_ + 1u) * 64] ^ mA : hi_edge_;
+          if ((lo_ == v_ || hi_ == v_) && rkT[jcur * 32 + c32] >= c0) {
+            // a run of equal keys [a, b) around the pick: the cut is this value if its r2 = a + b + 1 reaches R, else the
+            // value at rank b (qdmrank.h).  Runs that leave the chunk and copies of the maximum (which change the ranks of
+            // every sample) go to the exact-rank kernel.
+            const uint32_t R_ = rRT[jcur * 32 + c32];
+            uint32_t s_lo = e_, s_hi = e_ + 1u;
+            while (s_lo > 0u && (mydump[(s_lo - 1u) * 64] ^ mA) == v_) --s_lo;
+            while (s_hi < cnt_ && (mydump[s_hi * 64] ^ mA) == v_) ++s_hi;
+            const uint32_t below_ = s_lo > 0u ? mydump[(s_lo - 1u) * 64] ^ mA : lo_edge_;
+            const uint32_t above_ = s_hi < cnt_ ? mydump[s_hi * 64] ^ mA : hi_edge_;
+            if (R_ == 0u || below_ == v_ || above_ == v_ || (abl & 64)) tied = 1u;
+            else {
+              const uint32_t L0 = ci * 32u + s_lo, L1 = ci * 32u + s_hi;  // local [L0, L1): ranks N + L (lane B), N - 1 - L (lane A)
+              const uint32_t a_ = h ? (uint32_t)N + L0 : (uint32_t)N - L1, b_ = h ? (uint32_t)N + L1 : (uint32_t)N - L0;
+              if (a_ + b_ + 1u < R_) v_ = h ? above_ : below_;
+            }
+          }
+          vals[jcur * 32 + (int)c32] = v_;
+          jcur = next_mine(jcur + dj);
+          snext = local_of(jcur);
+        }
+      }
       if (tied && stcol[c32] == QR_OK) stcol[c32] = QR_TIES;
     }
     qr_fence();
@@ -465,6 +512,22 @@ k_qdm_regsort(const float* __restrict__ x, int T, int64_t C, int64_t st, const f
   }
 }
 
+// Boundary ranks of a column with n = T valid samples, a single maximum and all nq nodes valid, by the copies c0 of its minimum:
+// tab[(c0 - 1) * (nq + 1) + t] = R (qdmrank.h; 2 T + 1 when no rank passes).  Nearly every column of a field without missing
+// values is of that kind, and the fp64 search per (column, boundary) was a third of k_qdm_regsort.
+__global__ void __launch_bounds__(XH_BLOCK)
+k_qdm_rank_table(int T, int nq, const double* __restrict__ qnodes, uint16_t* __restrict__ tab) {
+  const int ntmax = nq + 1;
+  const int64_t i = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (i >= (int64_t)T * ntmax) return;
+  const uint32_t c0 = (uint32_t)(i / ntmax) + 1u, t = (uint32_t)(i % ntmax);
+  double thr;
+  if (t == 0u) thr = qnodes[0];
+  else if (t == (uint32_t)nq) thr = qnodes[nq - 1];
+  else thr = qnodes[t - 1u] / 2.0 + qnodes[t] / 2.0;
+  tab[i] = (uint16_t)qdm_min_r2(t == 0u, thr, (uint32_t)T, c0, 1u);
+}
+
 // ---- classification against per-column cut values (the second half of the QDM path when it is split in two kernels) ----
 // scen[t, c] = sim[t, c] (+|*) fac[#{k : cut[k, c] <= sim[t, c]}, c]; cut (ntest, C) non-decreasing per column with NaN for the
 // boundaries no sample reaches (every compare fails), fac (ntest + 1, C).  A workgroup = 64 columns x 4 row lanes; the
@@ -576,7 +639,7 @@ int xh_qdm_regsort(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t 
       (unsigned long long)T * (unsigned long long)ost * 4ull >= (1ull << 32) || C >= ((int64_t)1 << 32))
     return XH_ERR_NOTIMPL;
   if (xh_diag_env("XH_QDM_NOREGSORT")) return XH_ERR_NOTIMPL;  // A/B against the exact-rank kernel
-  const size_t lds = sizeof(double) * QR_MAXQ + 4 * sizeof(uint32_t) * (size_t)qr_words_per_wave(nq);
+  size_t lds = sizeof(double) * QR_MAXQ + 4 * sizeof(uint32_t) * (size_t)qr_words_per_wave(nq);
   if (lds > 79 * 1024) return XH_ERR_NOTIMPL;  // two workgroups per CU
   const int64_t ntiles = (C + 31) / 32;
   int64_t nblk = (ntiles + 3) / 4;
@@ -593,11 +656,13 @@ int xh_qdm_regsort(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t 
   const char* esp = xh_diag_env("XH_QDM_SPLIT");  // diagnostics: 0 = one kernel that also classifies and writes (re-reads its tile)
   const bool split = !(esp && atoi(esp) == 0);
   const size_t b_tab = split ? sizeof(float) * (size_t)(2 * nq + 3) * (size_t)C : 0;
-  int rc = xh_big_scratch(ctx, b_list + 2 * b_cols + sizeof(float) * (size_t)nq * (size_t)nfmax + b_tab, &ws);
+  const size_t b_rtab = (sizeof(uint16_t) * (size_t)T * (size_t)(nq + 1) + 63) & ~(size_t)63;
+  int rc = xh_big_scratch(ctx, b_rtab + b_list + 2 * b_cols + sizeof(float) * (size_t)nq * (size_t)nfmax + b_tab, &ws);
   if (rc) return rc;
-  uint32_t* nflag = static_cast<uint32_t*>(ws);
+  uint16_t* rtab = static_cast<uint16_t*>(ws);
+  uint32_t* nflag = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + b_rtab);
   uint32_t* flist = nflag + 4;
-  float* gbuf = reinterpret_cast<float*>(static_cast<char*>(ws) + b_list);
+  float* gbuf = reinterpret_cast<float*>(static_cast<char*>(ws) + b_rtab + b_list);
   float* gout = gbuf + (size_t)nfmax * (size_t)Tp;
   float* gaf = gout + (size_t)nfmax * (size_t)Tp;
   float* gcut = split ? gaf + (size_t)nq * (size_t)nfmax : nullptr;  // (nq + 1, C)
@@ -605,10 +670,18 @@ int xh_qdm_regsort(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t 
   XH_CHECK_HIP(hipMemsetAsync(nflag, 0, 16, ctx->stream));
   const char* ea = xh_diag_env("XH_QDM_ABL");  // diagnostics: skip phases (1 stats, 2 ranks, 4 sort, 16 picks, 32 apply; wrong results)
   const int abl = ea ? atoi(ea) : 0;
+  const bool nolut = xh_diag_env("XH_QDM_NOLUT") != nullptr, norun = xh_diag_env("XH_QDM_NORUN") != nullptr;  // A/B of round 5
+  if (!nolut) {
+    const int64_t ne = T * (int64_t)(nq + 1);
+    hipLaunchKernelGGL(k_qdm_rank_table, dim3((unsigned)cdiv64(ne, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, (int)T, nq, d_q, rtab);
+  }
   auto kern = k_qdm_regsort<N, TMIN>;
+  const size_t b_lut = sizeof(uint16_t) * (size_t)T * (size_t)(nq + 1);
+  const int rtab_lds = (!nolut && lds + b_lut <= 79 * 1024 && !xh_diag_env("XH_QDM_LUT_GLOBAL")) ? 1 : 0;
+  if (rtab_lds) lds += b_lut;
   if (lds > 48 * 1024) XH_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, sim, (int)T, C, st, af, af_qs, d_q, nq, kind, extrap,
-                     scen, ost, flist, nflag, abl, gcut, gfac);
+                     scen, ost, flist, nflag, abl | (norun ? 64 : 0), gcut, gfac, nolut ? (const uint16_t*)nullptr : rtab, rtab_lds);
   XH_LAUNCH_CHECK();
   if (split && !(abl & 32)) {
     rc = xh_cut_classify(ctx, sim, T, C, st, gcut, gfac, nq + 1, kind, scen, ost);
