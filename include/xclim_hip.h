@@ -552,6 +552,12 @@ int xh_poly_trend_u(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t s
                     double* p0, double* p1, int32_t* nvalid);
 int xh_trend_apply_u(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, const double* u, const double* p0,
                      const double* p1, int mode, float* out, int64_t out_st);
+/* out[t, c] = mean of the valid samples among x[t - window / 2 .. t + window / 2, c] (rows outside the series do not exist),
+ * NaN when there is none: the series PolyDetrend fits when the Grouper has a window (xsdba.detrending
+ * _polydetrend_get_trend: rolling(center=True).construct("window") then da.mean over the window dimension — upstream
+ * xsdba, re-exported by /root/reference/src/xclim/sdba.py:10; parity unpinned).  float64 running sum, float32 result. */
+int xh_window_nanmean(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, float* out,
+                      int64_t out_st);
 
 #ifdef __cplusplus
 }

@@ -433,15 +433,32 @@ def poly_trend_u(x, u, degree):
     return out.reshape(x.shape)
 
 
-def dqm_train_grouped(ref, hist, time, prop, nquantiles=20, kind="+"):
-    """dqm_train per group (window 1): (labels, af (G, nq, ...), hist_q, scaling (G, ...))."""
+def dqm_train_grouped(ref, hist, time, prop, nquantiles=20, kind="+", window=1):
+    """dqm_train per group on its (windowed) sample — the means run over time AND window (``ds.ref.mean(dim)`` with
+    dim = [time, window]): (labels, af (G, nq, ...), hist_q, scaling (G, ...))."""
     labels = np.unique(group_values(time, prop))
-    res = [dqm_train(grouped_sample(ref, time, prop, 1, lab), grouped_sample(hist, time, prop, 1, lab), nquantiles, kind) for lab in labels]
+    res = [dqm_train(grouped_sample(ref, time, prop, window, lab), grouped_sample(hist, time, prop, window, lab), nquantiles, kind)
+           for lab in labels]
     return labels, np.stack([r[0] for r in res]), np.stack([r[1] for r in res]), np.stack([r[2] for r in res])
 
 
+def window_nanmean(x, window):
+    """rolling(time=window, center=True).construct("window").mean("window"): the mean over the valid samples of the centred
+    window (rows beyond the ends of the series are NaN padding), float64 sums, float32 result (a stage boundary)."""
+    import warnings
+
+    x = np.asarray(x)
+    T, half = x.shape[0], window // 2
+    pad = np.full((half,) + x.shape[1:], np.nan, dtype=np.float64)
+    xp = np.concatenate([pad, x.astype(np.float64), pad])
+    stack = np.stack([xp[k:k + T] for k in range(window)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return np.nanmean(stack, axis=0).astype(np.float32)
+
+
 def dqm_adjust_grouped(sim, time, prop, labels, af, hist_q, scaling, kind="+", extrapolation="constant", detrend=1, mode="group",
-                       interp="nearest"):
+                       interp="nearest", window=1):
     """dqm_adjust with a sub-grouping, interp="nearest": every step takes the scaling of its group (u.broadcast), the
     polynomial trend is fitted PER GROUP over the group's own steps on the time coordinate (PolyDetrend(group=...):
     polyfit along time — here days since the group's mean date; a linear fit does not depend on the origin), the
@@ -462,13 +479,21 @@ def dqm_adjust_grouped(sim, time, prop, labels, af, hist_q, scaling, kind="+", e
         f = (gc - r0)[:, None]
         sc_t = (sc[r0] + (sc[r0 + 1] - sc[r0]) * f).reshape(sim.shape)
         scaled_all = _corr(sim, sc_t, kind)
+    wmean = None
+    if window > 1:
+        # PolyDetrend with a windowed Grouper (xsdba.detrending._polydetrend_get_trend: ``if len(dim) > 1: da = da.mean(dim[1:])``
+        # ahead of polyfit): the trend of a group is fitted on the window mean of the SCALED series at the group's steps
+        if scaled_all is None:
+            gidx = np.searchsorted(labels, gv)
+            scaled_all = _corr(sim, np.asarray(scaling, dtype=np.float64).reshape((len(labels),) + sim.shape[1:])[gidx], kind)
+        wmean = window_nanmean(scaled_all, window)
     for g, lab in enumerate(labels):
         rows = np.nonzero(gv == lab)[0]
         if not rows.size:
             continue
         scaled = _corr(sim[rows], scaling[g], kind) if scaled_all is None else scaled_all[rows]
         u = days[rows] - days[rows].mean()
-        trend = poly_trend_u(scaled, u, detrend)
+        trend = poly_trend_u(scaled if wmean is None else wmean[rows], u, detrend)
         detr = _corr(scaled, trend, kind, True)
         if mode == "griddata":
             newg = gv[rows] if interp == "nearest" else group_index(time, prop, True)[rows]

@@ -66,7 +66,7 @@ def main() -> int:
                 out[f"eqm_{k}_{interp}_{extrap}"] = scen.transpose("time", "lat", "lon").values
         qdm = QuantileDeltaMapping.train(da(r, un), da(h, un), nquantiles=20, kind=kind, group="time")
         out[f"qdm_{k}_af"] = qdm.ds.af.transpose("quantiles", "lat", "lon").values
-        for interp in ("nearest", "linear"):
+        for interp in ("nearest", "linear", "cubic"):   # (cubic: round 5)
             out[f"qdm_{k}_{interp}"] = qdm.adjust(da(s, un), interp=interp).transpose("time", "lat", "lon").values
         dqm = DetrendedQuantileMapping.train(da(r, un), da(h, un), nquantiles=20, kind=kind, group="time")
         out[f"dqm_{k}_af"] = dqm.ds.af.transpose("quantiles", "lat", "lon").values
@@ -89,6 +89,12 @@ def main() -> int:
         out[f"eqmg_{tag}_scen_linear"] = eqm.adjust(da(sim, "K"), interp="linear").transpose("time", "lat", "lon").values
         qdm = QuantileDeltaMapping.train(da(ref, "K"), da(hist, "K"), nquantiles=15, kind="+", group=g)
         out[f"qdmg_{tag}_scen_linear"] = qdm.adjust(da(sim, "K"), interp="linear").transpose("time", "lat", "lon").values
+        # round 5: DetrendedQuantileMapping with the same (windowed) Grouper — PolyDetrend fits on the window mean
+        dqm = DetrendedQuantileMapping.train(da(ref, "K"), da(hist, "K"), nquantiles=15, kind="+", group=g)
+        out[f"dqmg_{tag}_af"] = dqm.ds.af.transpose(gdim, "quantiles", "lat", "lon").values
+        out[f"dqmg_{tag}_scaling"] = dqm.ds.scaling.transpose(gdim, "lat", "lon").values
+        for interp in ("nearest", "linear"):
+            out[f"dqmg_{tag}_scen_{interp}"] = dqm.adjust(da(sim, "K"), interp=interp, detrend=1).transpose("time", "lat", "lon").values
     # precipitation in mm/d with a month grouping: node spacings of many group steps (triangles spanning several months)
     g = xsdba.Grouper("time.month")
     eqm = EmpiricalQuantileMapping.train(da(pr_ref, "mm/d"), da(pr_hist, "mm/d"), nquantiles=15, kind="*", group=g)

@@ -1325,8 +1325,6 @@ def test_dqm_grouped_matches_oracle(dev, rng, kind, group):
             np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5, equal_nan=True)
     first, last = np.nanmean(got[:365]), np.nanmean(got[-365:])
     assert 1.5 < last - first < 4.0                                     # the simulated trend survives the adjustment
-    with pytest.raises(NotImplementedError):
-        xsdba.DetrendedQuantileMapping.train(ref, hist, group="time.dayofyear", window=31, time=ta, device=dev)
     if prop == "month":   # interp="linear": the detrended steps interpolated over the (quantile, group) plane (round 5)
         got = dqm.adjust(sim, interp="linear", detrend=1, time=ta)
         exp = osdba.dqm_adjust_grouped(sim, ot, prop, labels, dqm.af, dqm.hist_q, dqm.scaling, kind, "constant", 1, mode="griddata",
@@ -1335,6 +1333,57 @@ def test_dqm_grouped_matches_oracle(dev, rng, kind, group):
     else:
         with pytest.raises(NotImplementedError):
             dqm.adjust(sim, interp="linear", time=ta)
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("group,window", [("time.dayofyear", 31), ("time.month", 5)])
+def test_dqm_windowed_sub_grouping_matches_oracle(dev, rng, kind, group, window):
+    """DetrendedQuantileMapping with a WINDOWED sub-grouping (round 5; the documented standard Grouper("time.dayofyear",
+    window=31)): the training sample of a group is the windowed one (means over time and window), and PolyDetrend fits the
+    group's trend on the centred window mean of the scaled series (xh_window_nanmean).  nearest (own group + plane) and
+    linear over the (quantile, group) plane; parity unpinned."""
+    from xclim_amd import kernels as K
+    from xclim_amd import sdba as xsdba
+
+    # the window mean itself: NaN samples, windows cut by the ends of the series, a window without any valid sample
+    x = rng.normal(5, 3, (300, 70)).astype(np.float32)
+    x[rng.random(x.shape) < 0.1] = np.nan
+    x[100:140, 3] = np.nan
+    x[:, 4] = np.nan
+    for w in (1, 3, 31):
+        got = K.window_nanmean(dev, dev.to_device(x), w).get()
+        np.testing.assert_allclose(got, osdba.window_nanmean(x, w), rtol=3e-7, atol=1e-7, equal_nan=True)
+
+    T = 365 * 4   # (the CPU oracle runs scipy.griddata once per group: 365 of them for the day of the year)
+    ta, ot = _axes("2001-01-01", T, "noleap")
+    shape = (T, 1, 3)
+    t = np.arange(T)[:, None, None]
+    seas = 8 * np.sin(2 * np.pi * (t - 100) / 365)
+    base = 0.0 if kind == "+" else 25.0
+    ref = (base + 10 + seas + rng.normal(0, 3, shape)).astype(np.float32)
+    hist = (base + 11.5 + 1.2 * seas + rng.normal(0, 4, shape)).astype(np.float32)
+    sim = (base + 12 + 1.2 * seas + 3.0 * t / T + rng.normal(0, 4, shape)).astype(np.float32)
+    sim[rng.random(shape) < 0.01] = np.nan
+    hist[:50, 0, 0] = np.nan
+    prop = group.split(".")[1]
+    dqm = xsdba.DetrendedQuantileMapping.train(ref, hist, nquantiles=15, kind=kind, group=group, window=window, time=ta, device=dev)
+    labels, eaf, ehq, escal = osdba.dqm_train_grouped(ref, hist, ot, prop, 15, kind, window=window)
+    np.testing.assert_array_equal(dqm.group_labels, labels)
+    np.testing.assert_allclose(dqm.scaling, escal, rtol=1e-6)
+    np.testing.assert_allclose(dqm.hist_q, ehq, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(dqm.af, eaf, rtol=1e-5, atol=1e-5)
+    for deg, mode in ((0, "group"), (1, "group"), (1, "griddata")):
+        if True:
+            got = dqm.adjust(sim, detrend=deg, time=ta, grouped_nearest=mode)
+            exp = osdba.dqm_adjust_grouped(sim, ot, prop, labels, dqm.af, dqm.hist_q, dqm.scaling, kind, "constant", deg, mode=mode,
+                                           window=window)
+            np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5, equal_nan=True, err_msg=f"{deg} {mode}")
+    first, last = np.nanmean(got[:365]), np.nanmean(got[-365:])
+    assert 1.5 < last - first < 4.0                                     # the simulated trend survives the adjustment
+    got = dqm.adjust(sim, interp="linear", detrend=1, time=ta)
+    exp = osdba.dqm_adjust_grouped(sim, ot, prop, labels, dqm.af, dqm.hist_q, dqm.scaling, kind, "constant", 1, mode="griddata",
+                                   interp="linear", window=window)
+    np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5, equal_nan=True)
 
 
 @pytest.mark.parametrize("T", [1, 2, 700, 40000])

@@ -165,6 +165,7 @@ SIGNATURES: dict[str, list] = {
     "xh_trend_apply": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _i64],
     "xh_poly_trend_u": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp],
     "xh_trend_apply_u": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _i64],
+    "xh_window_nanmean": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64],
 }
 _RESTYPES = {"xh_last_error": C.c_char_p}
 

@@ -90,6 +90,41 @@ k_trend_apply(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, con
 
 }  // namespace
 
+// Centred window mean over the valid samples (xsdba.detrending._polydetrend_get_trend with a windowed Grouper:
+// rolling(time=window, center=True).construct("window") pads the ends with NaN, then da.mean over the window dimension skips
+// NaN): out[t, c] = mean { x[s, c] : |s - t| <= window / 2, 0 <= s < T, x[s, c] valid }, NaN when the window holds no valid
+// sample.  A thread = one column x one stretch of WM_ROWS output rows: a running float64 sum and count (float32 samples: every
+// add / subtract is exact to 2^-53 of the sum), the window's first rows summed up front.
+constexpr int WM_ROWS = 128;
+__global__ void __launch_bounds__(XH_BLOCK)
+k_window_nanmean(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int half, float* __restrict__ out, int64_t ost) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  const int64_t t0 = (int64_t)blockIdx.y * WM_ROWS;
+  int64_t t1 = t0 + WM_ROWS;
+  if (t1 > T) t1 = T;
+  double sum = 0.0;
+  int cnt = 0;
+  for (int64_t s = t0 - half < 0 ? 0 : t0 - half; s < t0 + half && s < T; ++s) {  // rows [t0 - half, t0 + half): the next one enters in the loop
+    const float v = x[s * st + c];
+    if (v == v) { sum += (double)v; ++cnt; }
+  }
+  for (int64_t t = t0; t < t1; ++t) {
+    const int64_t sin = t + half, sout = t - half - 1;
+    if (sin < T) {
+      const float v = x[sin * st + c];
+      if (v == v) { sum += (double)v; ++cnt; }
+    }
+    if (sout >= 0 && sout >= t0 - half) {
+      const float v = x[sout * st + c];
+      if (v == v) { sum -= (double)v; --cnt; }
+    }
+    // (a window that lost all its samples: the running sum is rounding residue, not data)
+    if (cnt == 0) sum = 0.0;
+    out[t * ost + c] = cnt > 0 ? (float)(sum / (double)cnt) : xh_nan32();
+  }
+}
+
 extern "C" {
 
 static int poly_trend_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int degree, double* p0,
@@ -158,6 +193,20 @@ int xh_trend_apply_u(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
                      const double* p1, int mode, float* out, int64_t out_st) {
   XH_REQUIRE(u, XH_ERR_ARG, "xh_trend_apply_u: NULL coordinate");
   return trend_apply_impl(ctx, x, T, C, st, sc, p0, p1, mode, out, out_st, u);
+}
+
+// PolyDetrend with a windowed sub-grouping fits the trend on the WINDOW MEAN of every step (see k_window_nanmean)
+int xh_window_nanmean(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, float* out, int64_t out_st) {
+  XH_REQUIRE(ctx && x && out, XH_ERR_ARG, "xh_window_nanmean: NULL argument");
+  XH_REQUIRE(T >= 0 && C >= 0, XH_ERR_ARG, "xh_window_nanmean: bad shape");
+  XH_REQUIRE(sc == 1 && st >= C && out_st >= C, XH_ERR_LAYOUT, "xh_window_nanmean: needs time-major views (sc == 1)");
+  XH_REQUIRE(window >= 1 && (window & 1), XH_ERR_ARG, "xh_window_nanmean: window must be a positive odd number of steps");
+  XH_REQUIRE(x != out, XH_ERR_ARG, "xh_window_nanmean: not in place");
+  if (T == 0 || C == 0) return XH_OK;
+  const dim3 grid((unsigned)cdiv64(C, XH_BLOCK), (unsigned)cdiv64(T, WM_ROWS));
+  hipLaunchKernelGGL(k_window_nanmean, grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window / 2, out, out_st);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
 }
 
 }  // extern "C"

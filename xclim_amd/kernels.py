@@ -611,6 +611,14 @@ def poly_trend(dev: Device, x: DeviceArray, degree: int = 1, u: DeviceArray | No
     return p0, p1
 
 
+def window_nanmean(dev: Device, x: DeviceArray, window: int, out: DeviceArray | None = None) -> DeviceArray:
+    """xh_window_nanmean: the centred ``window``-step mean over the valid samples (the ends of the series see fewer rows)."""
+    T, C_ = _tc(x)
+    out = out if out is not None else dev.empty((T, C_), np.float32)
+    dev.call("xh_window_nanmean", _vp(x.ptr), T, C_, C_, 1, int(window), _vp(out.ptr), C_)
+    return out
+
+
 def trend_apply(dev: Device, x: DeviceArray, p0: DeviceArray, p1, op: str, out: DeviceArray | None = None,
                 u: DeviceArray | None = None) -> DeviceArray:
     """xh_trend_apply: x OP (p0[c] + p1[c] (t - (T - 1) / 2)), op in "+", "-", "*", "/"; p1 None: per-cell constant.

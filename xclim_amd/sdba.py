@@ -28,8 +28,8 @@ trained like EQM; ``adjust`` looks the factor up at the QUANTILE of every sim va
 (``rank(sim, pct=True)``), so that the simulated change of every quantile is preserved — ``xh_qdm_adjust`` ranks each column
 exactly (average ranks, NaN skipped) and interpolates in fp64 ("nearest", "linear"; "cubic" for ``group="time"``: the
 not-a-knot spline of the EQM path over the quantile nodes).  :class:`DetrendedQuantileMapping`: ``group="time"`` or a
-sub-grouping without a window; with "linear" and a month grouping the scaling is interpolated over the group coordinate
-like xsdba's ``u.broadcast`` does.
+sub-grouping, with or without a window (with one, the trend is fitted on the centred window mean: ``xh_window_nanmean``);
+with "linear" and a month grouping the scaling is interpolated over the group coordinate like xsdba's ``u.broadcast`` does.
 
 PARITY UNPINNED like everything xsdba (oracle/sdba.py).
 """
@@ -465,8 +465,9 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
 
 class DetrendedQuantileMapping(EmpiricalQuantileMapping):
     """Detrended quantile mapping (xsdba.DetrendedQuantileMapping; Cannon et al. 2015).  ``group="time"``, or a
-    sub-grouping without a window ("time.month", "time.season": everything below happens per group, the trend is fitted
-    over the group's own steps on their time coordinate).
+    sub-grouping ("time.month", "time.season", "time.dayofyear": everything below happens per group, the trend is fitted
+    over the group's own steps on their time coordinate; with a ``window`` the training sample of a group is the windowed
+    one and the trend is fitted on the centred window mean of the scaled series, as ``PolyDetrend`` does).
 
     train (``dqm_train``): ref and hist are normalised by their time means (``x - mean`` for "+", ``x / mean`` for "*"),
     ``af`` / ``hist_q`` come from the quantiles of the NORMALISED series, ``scaling = mean(ref) - mean(hist)`` (resp. the
@@ -482,10 +483,6 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
     @classmethod
     def train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", window=None, time=None, device=None):
         grp = group if isinstance(group, Grouper) else Grouper(group, 1 if window is None else window)
-        if grp.prop != "group" and grp.window != 1:
-            # with a window xsdba fits the trend on the WINDOW MEAN of every step (PolyDetrend: da.mean over the window
-            # dimension before polyfit) — not built
-            raise NotImplementedError("DetrendedQuantileMapping: sub-groupings are built for window=1 (time.month, time.season)")
         if kind not in (ADDITIVE, MULTIPLICATIVE):
             raise ValueError(f"kind must be '+' or '*', got {kind!r}")
         dev = device or get_device()
@@ -549,7 +546,7 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
 
     def _adjust_grouped(self, s, interp, extrapolation, detrend, time, keep, fwd, inv, grouped_nearest="griddata"):
-        """dqm_adjust with a sub-grouping (window 1): group-major row blocks like the grouped EQM; per block the group's
+        """dqm_adjust with a sub-grouping: group-major row blocks like the grouped EQM; per block the group's
         scaling (``u.broadcast``), the trend fitted over the group's OWN steps on their time coordinate (days since the
         group's mean date: ``PolyDetrend(group=...)`` -> polyfit along time), the group's nodes, the trend put back."""
         _check_group_interp(self.group, interp, "DetrendedQuantileMapping.adjust", self.group_labels, extrapolation)
@@ -598,6 +595,27 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             src = K.select_rows(dev, sc_p2, inv2)
         s_perm = K.select_rows(dev, src, perm)
         scen_perm = dev.empty((T, C_), np.float32)
+        inv_perm = np.empty(T, dtype=np.int64)
+        inv_perm[perm] = np.arange(T)
+        windowed = self.group.window > 1
+        wm_perm = None
+        if windowed:
+            # PolyDetrend with a windowed Grouper (xsdba.detrending._polydetrend_get_trend: ``da.mean(dim[1:])`` before polyfit):
+            # the trend of a group is fitted on the centred WINDOW MEAN of the scaled series at the group's steps — neighbours
+            # carry the scaling of their own groups, so the whole series is scaled first (group-major blocks), brought back to
+            # time order, averaged, and permuted again
+            if not prescaled:
+                off = 0
+                for g, n in enumerate(counts):
+                    n = int(n)
+                    if n:
+                        sc_g = dev.wrap(self._scaling.ptr + g * C_ * 8, (C_,), np.float64)
+                        blk = dev.wrap(s_perm.ptr + off * C_ * 4, (n, C_), np.float32)
+                        K.trend_apply(dev, blk, sc_g, None, fwd, out=dev.wrap(scen_perm.ptr + off * C_ * 4, (n, C_), np.float32))
+                    off += n
+                s_perm, scen_perm = scen_perm, s_perm          # s_perm: the scaled series, group-major
+                src = K.select_rows(dev, s_perm, inv_perm)     # ... and in time order
+            wm_perm = K.select_rows(dev, K.window_nanmean(dev, src, self.group.window), perm)
         off = 0
         for g, n in enumerate(counts):
             n = int(n)
@@ -610,8 +628,9 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             sc_g = dev.wrap(self._scaling.ptr + g * C_ * 8, (C_,), np.float64)
             af_g = dev.wrap(self._af.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
             hq_g = dev.wrap(self._hist_q.ptr + g * nq * C_ * 4, (nq, C_), np.float32)
-            scaled = blk if prescaled else K.trend_apply(dev, blk, sc_g, None, fwd)
-            p0, p1 = K.poly_trend(dev, scaled, detrend, u=u)
+            scaled = blk if (prescaled or windowed) else K.trend_apply(dev, blk, sc_g, None, fwd)
+            fit_on = scaled if not windowed else dev.wrap(wm_perm.ptr + off * C_ * 4, (n, C_), np.float32)
+            p0, p1 = K.poly_trend(dev, fit_on, detrend, u=u)
             detr = K.trend_apply(dev, scaled, p0, p1, inv, u=u)
             if interp == "linear":
                 scen0 = K.plane_linear(dev, detr, gcoord[rows], self._af, xq_all=self._hist_q, kind=self.kind)
@@ -621,8 +640,6 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
                 scen0 = K.eqm_adjust(dev, detr, af_g, hq_g, self.kind, interp, extrapolation)
             K.trend_apply(dev, scen0, p0, p1, fwd, out=out, u=u)
             off += n
-        inv_perm = np.empty(T, dtype=np.int64)
-        inv_perm[perm] = np.arange(T)
         scen = K.select_rows(dev, scen_perm, inv_perm)
         dev.sync()
         return scen if keep else scen.get().reshape((T,) + self.cell_shape)
