@@ -1,0 +1,128 @@
+"""Differential fuzzing of xh_plane_linear / xh_plane_nearest (plane.hip) against the oracle's scipy.interpolate.griddata over
+the cyclically padded (quantile, group) node plane: random group counts, node counts, node spacings from a fiftieth of a
+group step to twenty steps, temperature- and precipitation-like node sets, fractional and integer group coordinates,
+queries inside / outside / NaN, NaN nodes.  usage: python tools/fuzz_plane.py [seconds]   (FUZZ_SEED=...)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import sdba as osdba  # noqa: E402
+from xclim_amd import kernels as K  # noqa: E402
+from xclim_amd._capi import get_device  # noqa: E402
+
+dev = get_device()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed0 = int(os.environ.get("FUZZ_SEED", "777"))
+t_end = time.time() + budget
+stats = {"linear": 0, "nearest": 0, "nearest_ties": 0, "elements": 0}
+it = 0
+while time.time() < t_end:
+    it += 1
+    rng = np.random.default_rng(seed0 * 100003 + it)
+    G = int(rng.choice([2, 3, 4, 5, 12, 12, 12, 13, 40, 73, 365]))
+    nq = int(rng.integers(2, 33))
+    C = int(rng.integers(1, 24))
+    T = int(rng.integers(20, 400 if G < 100 else 120))
+    scale = float(np.exp(rng.uniform(np.log(0.02), np.log(20.0))))
+    kind = str(rng.choice(["t", "p"]))
+    cyc = np.sin(2 * np.pi * (np.arange(G) + 0.5) / G)[:, None, None]
+    if kind == "p":
+        xq = np.sort(rng.gamma(0.7, scale * 3.0, (G, nq, C)), axis=1) * (1.0 + 0.5 * cyc)
+    else:
+        xq = np.sort(rng.normal(0.0, scale, (G, nq, C)), axis=1) + rng.uniform(0, 10) * scale * cyc + float(rng.choice([280.0, 0.0]))
+    yq = rng.normal(0.0, 1.0, (G, nq, C)) + 2.0 * cyc
+    xq, yq = xq.astype(np.float32), yq.astype(np.float32)
+    # float32 abscissae near 280 tie by rounding.  Tied nodes of one row with DIFFERENT factors are the documented
+    # unreproducible case (Qhull keeps one of the coincident points: the first in 59 %, the last in 28 % of 1 668 queries where
+    # the choice mattered, /tmp experiment of round 5; the kernel keeps the first): give ties the same factor
+    for _ in range(nq):
+        tie = np.zeros(xq.shape, bool)
+        tie[:, 1:] = xq[:, 1:] == xq[:, :-1]
+        if not tie.any():
+            break
+        yq[:, 1:][tie[:, 1:]] = yq[:, :-1][tie[:, 1:]]
+    nan_nodes = rng.random() < 0.25
+    if nan_nodes:
+        yq[rng.random(yq.shape) < 0.03] = np.nan
+    lo, hi = float(np.nanmin(xq)), float(np.nanmax(xq))
+    x = rng.uniform(lo - 0.1 * (hi - lo) - 1e-3, hi + 0.1 * (hi - lo) + 1e-3, (T, C)).astype(np.float32)
+    x[rng.random((T, C)) < 0.03] = np.nan
+    if rng.random() < 0.3:   # queries ON nodes
+        sel = rng.integers(0, T, 10)
+        x[sel, rng.integers(0, C, 10)] = xq[rng.integers(0, G, 10), rng.integers(0, nq, 10), rng.integers(0, C, 10)]
+    fractional = rng.random() < 0.6
+    g = rng.uniform(0.5, G + 0.5, T) if fractional else rng.integers(1, G + 1, T).astype(np.float64)
+    labels = np.arange(1, G + 1)
+    method = "linear" if it % 2 else "nearest"
+    if method == "nearest" and fractional:
+        g = np.round(g).clip(1, G)   # (upstream: the group INDEX of the step, integer, for "nearest")
+    d_x, d_y, d_q = dev.to_device(x), dev.to_device(yq), dev.to_device(xq)
+    extrap = str(rng.choice(["constant", "nan"])) if method == "nearest" else "constant"
+    if method == "linear":
+        got = K.plane_linear(dev, d_x, g, d_y, xq_all=d_q, kind="factor").get()
+    else:
+        got = K.plane_nearest(dev, d_x, g, d_y, d_q, "factor", extrap).get()
+    exp = osdba.interp_on_quantiles_2d(x, g, labels, xq, yq, method, extrap)
+    ysc = max(1.0, float(np.nanmax(np.abs(yq))))
+    both = ~np.isnan(got) & ~np.isnan(exp)
+    bad = both & ~(np.abs(got - exp) <= 1e-5 * np.abs(exp) + 1e-5 * ysc)
+    nanbad = np.isnan(got) != np.isnan(exp)
+    if nan_nodes:
+        nanbad[:] = False          # (bounds next to NaN nodes: see test_plane_linear_nan_nodes_and_ties)
+    nbad = int(bad.sum())
+    if method == "linear" and nbad:
+        # float32 abscissae are a grid (2^-15 K at 280 K): x_a + x_b == x_c + x_d happens EXACTLY, four nodes on one circle,
+        # two valid Delaunay triangulations — scipy's choice depends on Qhull's facet order (plane.hip, header).  A mismatch
+        # whose scipy triangle has a fourth node ON its circumcircle is that case: tolerated, counted.
+        from scipy.spatial import Delaunay
+
+        ext = np.concatenate([[G - 1], np.arange(G), [0]])
+        for t_, c_ in np.argwhere(bad):
+            pts = np.array([(float(xq[r, k, c_]), float(i)) for i, r in enumerate(ext) for k in range(nq) if not np.isnan(yq[r, k, c_])])
+            pts = np.unique(pts, axis=0)
+            tri = Delaunay(pts)
+            sidx = int(tri.find_simplex(np.array([float(x[t_, c_]), float(g[t_])])))
+            P3 = pts[tri.simplices[sidx]]
+            ax, ay = P3[1] - P3[0]
+            bx, by = P3[2] - P3[0]
+            d = 2 * (ax * by - ay * bx)
+            ux, uy = (by * (ax * ax + ay * ay) - ay * (bx * bx + by * by)) / d, (ax * (bx * bx + by * by) - bx * (ax * ax + ay * ay)) / d
+            pw = ((pts - (P3[0] + [ux, uy])) ** 2).sum(1) - (ux * ux + uy * uy)
+            if (np.abs(pw) < 1e-9 * max(1.0, ux * ux + uy * uy)).sum() >= 4:
+                bad[t_, c_] = False
+                stats["cocircular"] = stats.get("cocircular", 0) + 1
+        nbad = int(bad.sum())
+    if method == "nearest":
+        # equidistant nodes: either is a nearest node (cKDTree's pick is its traversal order).  A mismatch is accepted only when
+        # the kernel's value IS the factor of a node as near as the nearest one — verified here, counted
+        ext = np.concatenate([[G - 1], np.arange(G), [0]])
+        for t_, c_ in np.argwhere(bad):
+            nx_ = np.array([float(xq[r, k, c_]) for r in ext for k in range(nq)])
+            ny_ = np.array([float(yq[r, k, c_]) for r in ext for k in range(nq)])
+            ng_ = np.repeat(np.arange(G + 2.0), nq)
+            ok_ = ~np.isnan(nx_) & ~np.isnan(ny_)
+            d2 = (nx_ - float(x[t_, c_])) ** 2 + (ng_ - float(g[t_])) ** 2
+            dmin = d2[ok_].min()
+            mine = ok_ & (ny_.astype(np.float32) == got[t_, c_])
+            if mine.any() and d2[mine].min() <= dmin * (1 + 1e-6) + 1e-12:
+                bad[t_, c_] = False
+                stats["nearest_ties"] += 1
+        nbad = int(bad.sum())
+        fail = nbad > 0 or bool(nanbad.any())
+    else:
+        fail = nbad > 0 or bool(nanbad.any())
+    if fail:
+        w = np.argwhere(bad | nanbad)
+        print(json.dumps({"FAIL": method, "it": it, "seed": seed0, "G": G, "nq": nq, "C": C, "T": T, "scale": scale, "kind": kind,
+                          "fractional": bool(fractional), "nan_nodes": bool(nan_nodes), "extrap": extrap, "nbad": nbad,
+                          "nnanbad": int(nanbad.sum()), "first": w[:5].tolist(),
+                          "got": [float(got[tuple(i)]) for i in w[:5]], "exp": [float(exp[tuple(i)]) for i in w[:5]],
+                          "x": [float(x[tuple(i)]) for i in w[:5]], "g": [float(g[i[0]]) for i in w[:5]]}))
+        sys.exit(1)
+    stats[method] += 1
+    stats["elements"] += int(got.size)
+print(json.dumps({"ok": True, **stats}))
