@@ -303,6 +303,9 @@ __device__ double plane_locate(const PlaneCell& P, double qx, double qy) {
 // method "nearest" (scipy griddata over the nodes of all groups: a cKDTree query in the (abscissa, group coordinate) plane, no
 // rescaling): the own row first, then the rows k = 1, 2 ... away (below before above) while a node there could still be
 // nearer (k^2 < best squared distance), the first of equally near nodes wins — the order of k_eqm_adjust_g2d (eqm.hip).
+// Exact ties are NOT rare with windowed day-of-year groups: the groups d - 1 and d + 1 share most of their samples, so their
+// extreme nodes are often the same value, equally far from a query on row d; scipy's cKDTree returns either of them (230 : 170
+// in 400 constructed ties, tests/test_gpu_api.py::test_grouper_add_dims_pools_the_members) — not reproducible, documented.
 __device__ double plane_nearest(const PlaneCell& P, double x, int r) {
   const int G = P.t.G;
   double best = __longlong_as_double(0x7FF0000000000000LL), a = xh_nan64();

@@ -47,11 +47,18 @@ ADDITIVE, MULTIPLICATIVE = "+", "*"
 
 class Grouper:
     """xsdba.base.Grouper for the groupings of the quantile-mapping path: ``Grouper("time")``, ``Grouper("time.month")``,
-    ``Grouper("time.dayofyear", window=31)``."""
+    ``Grouper("time.dayofyear", window=31)``.
 
-    def __init__(self, group: str = "time", window: int = 1):
+    ``add_dims`` (xsdba: "additional dimensions that should be reduced in grouping operations", e.g. the realizations of an
+    ensemble — /root/reference/docs/sdba.rst:64-66): the host mirrors take numpy arrays, so the dimensions are AXIS NUMBERS of
+    the training arrays and must be the axes right behind time (``add_dims=1`` or ``(1, 2)``): their samples are pooled with
+    the time steps of a group when the quantiles are taken (``nbutils.quantile(ds.ref, quantiles, dim)`` with
+    ``dim = [time, (window), *add_dims]``), the factors have no such axis, and ``adjust`` maps every member of a ``sim`` that
+    still has it with the same factors."""
+
+    def __init__(self, group: str = "time", window: int = 1, add_dims=None):
         if isinstance(group, Grouper):
-            group, window = group.name, group.window
+            group, window, add_dims = group.name, group.window, group.add_dims if add_dims is None else add_dims
         if group not in ("time", "time.month", "time.dayofyear", "time.season"):
             raise NotImplementedError(f"group={group!r}: supported are 'time', 'time.month', 'time.dayofyear', 'time.season'")
         if window < 1 or window % 2 == 0:
@@ -60,9 +67,37 @@ class Grouper:
             raise ValueError("a window needs a sub-grouping ('time.month' / 'time.dayofyear')")
         self.name, self.window = group, int(window)
         self.prop = group.split(".")[1] if "." in group else "group"
+        dims = () if add_dims is None else tuple(int(a) for a in np.atleast_1d(add_dims))
+        if dims != tuple(range(1, len(dims) + 1)):
+            raise NotImplementedError(f"add_dims={add_dims!r}: the pooled axes must be the ones right behind time (1, 2, ...): "
+                                      "move them there (np.moveaxis) first")
+        self.add_dims = dims
 
     def __repr__(self):
-        return f"Grouper(name={self.name!r}, window={self.window})"
+        extra = f", add_dims={self.add_dims}" if self.add_dims else ""
+        return f"Grouper(name={self.name!r}, window={self.window}{extra})"
+
+    def pool(self, dev, x: DeviceArray, cell_shape):
+        """(T, R * C) field whose leading cell axes are ``add_dims`` -> ((T * R, C) view, R, cell shape without them): row
+        ``t * R + r`` is member ``r`` of step ``t`` — the C-contiguous layout already is that matrix."""
+        k = len(self.add_dims)
+        if k == 0:
+            return x, 1, tuple(cell_shape)
+        if len(cell_shape) < k:
+            raise ValueError(f"add_dims={self.add_dims}: the array has no such axes (shape behind time: {tuple(cell_shape)})")
+        R = int(np.prod(cell_shape[:k]))
+        cells = tuple(cell_shape[k:])
+        C_ = int(np.prod(cells)) if cells else 1
+        return dev.wrap(x.ptr, (x.shape[0] * R, C_), np.float32), R, cells
+
+    @staticmethod
+    def pooled_rows(rows: np.ndarray, R: int) -> np.ndarray:
+        """Sample rows of the time axis -> rows of the pooled (T * R, C) matrix (-1 stays -1, R times)."""
+        if R == 1:
+            return rows
+        out = rows[:, None] * R + np.arange(R)[None, :]
+        out[rows < 0] = -1
+        return out.reshape(-1)
 
     _SEASON_OF_MONTH = np.array(["", "DJF", "DJF", "MAM", "MAM", "MAM", "JJA", "JJA", "JJA", "SON", "SON", "SON", "DJF"])
 
@@ -179,6 +214,8 @@ def adapt_freq(ref, sim, thresh: float, *, group="time", window: int | None = No
     ``xh_adapt_freq``, restated in oracle/sdba.py.  ``ref`` and ``sim`` need the same number of time steps only with a
     sub-grouping (one ``time`` axis for both).  Parity unpinned (xsdba is not in the reference tree)."""
     grp = group if isinstance(group, Grouper) else Grouper(group, 1 if window is None else window)
+    if grp.add_dims:
+        raise NotImplementedError("adapt_freq with Grouper(add_dims=...) is not built")
     dev = device or get_device()
     r, cell_shape = _flatten(ref, dev)
     s_, cell_shape_s = _flatten(sim, dev)
@@ -251,6 +288,30 @@ class EmpiricalQuantileMapping:
         self.adj_params = {"group": self.group.name if self.group.window == 1 else repr(self.group), "kind": kind,
                            "nquantiles": len(self.quantiles)}
 
+    def _for_members(self, sim):
+        """A ``sim`` with extra axes right behind time — the members that ``Grouper(add_dims=...)`` pooled in training, or any
+        other axis the factors do not have (xsdba: the factors broadcast against it in ``interp_on_quantiles``): the model
+        whose tables are repeated for every member, so that the (time, members x cells) matrix goes through the same
+        kernels.  None when sim has the trained shape."""
+        shp = tuple(sim.shape[1:])
+        n = len(self.cell_shape)
+        if shp == self.cell_shape or len(shp) <= n or (n and shp[len(shp) - n:] != self.cell_shape):
+            return None
+        extra = shp[:len(shp) - n]
+        E = int(np.prod(extra))
+        cache = self.__dict__.setdefault("_member_models", {})
+        if extra not in cache:
+            dev = self._dev
+
+            def tile(tab):  # (..., C) -> (..., E * C): row i of the (rows, C) view repeated E times IS row i of (rows, E * C)
+                lead, C_ = int(np.prod(tab.shape[:-1])), tab.shape[-1]
+                out = K.select_rows(dev, tab.reshape(lead, C_), np.repeat(np.arange(lead), E))
+                return out.reshape(*(tuple(tab.shape[:-1]) + (E * C_,)))
+
+            cache[extra] = type(self)(dev, tile(self._af), tile(self._hist_q), self.quantiles, self.kind, extra + self.cell_shape,
+                                      self.group, None if self.group.prop == "group" else self.group_labels)
+        return cache[extra]
+
     @classmethod
     def train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", window: int | None = None, time=None,
               device=None, adapt_freq_thresh: float | None = None, adapt_freq_seed: int = 0):
@@ -267,12 +328,18 @@ class EmpiricalQuantileMapping:
         if tuple(cell_shape) != tuple(cell_shape_h) or r.shape != h.shape:
             raise ValueError("ref and hist must have the same shape")  # _check_matching_time_sizes analogue
         if adapt_freq_thresh is not None:
+            if grp.add_dims:
+                raise NotImplementedError("adapt_freq_thresh with Grouper(add_dims=...) is not built")
             h, _, _ = adapt_freq(r, h, adapt_freq_thresh, group=grp, time=time, seed=adapt_freq_seed, device=dev, keep=True)
         q = equally_spaced_nodes(nquantiles) if np.isscalar(nquantiles) else np.asarray(nquantiles, dtype=np.float64)
+        T = r.shape[0]
+        # Grouper(add_dims=...): the members' samples are pooled with the time steps (rows t * R + r of a (T * R, C) view)
+        r, R, cell_shape = grp.pool(dev, r, cell_shape)
+        h, _, _ = grp.pool(dev, h, cell_shape_h)
         if grp.prop == "group":
             af, hq = K.eqm_train(dev, r, h, q, kind)
             return cls(dev, af, hq, q, kind, cell_shape, grp)
-        if time is None or len(time) != r.shape[0]:
+        if time is None or len(time) != T:
             raise ValueError(f"group={grp.name!r} needs time=TimeAxis of the training series")
         labels = grp.labels(time)
         G, C_ = len(labels), r.shape[1]
@@ -280,6 +347,7 @@ class EmpiricalQuantileMapping:
         hq = dev.empty((G, len(q), C_), np.float32)
         plane = len(q) * C_ * 4
         for g, rows in enumerate(grp.sample_rows(time)):
+            rows = grp.pooled_rows(rows, R)
             out_g = tuple(dev.wrap(a.ptr + g * plane, (len(q), C_), np.float32) for a in (af, hq))
             K.eqm_train(dev, K.select_rows(dev, r, rows), K.select_rows(dev, h, rows), q, kind, out=out_g)
         dev.sync()
@@ -301,6 +369,9 @@ class EmpiricalQuantileMapping:
         if grouped_nearest not in ("griddata", "group"):
             raise ValueError("grouped_nearest must be 'griddata' or 'group'")
         _check_group_interp(self.group, interp, "EmpiricalQuantileMapping.adjust", self.group_labels, extrapolation)
+        members = self._for_members(sim)
+        if members is not None:
+            return members.adjust(sim, interp=interp, extrapolation=extrapolation, time=time, keep=keep, grouped_nearest=grouped_nearest)
         s, cell_shape = _flatten(sim, self._dev)
         if tuple(cell_shape) != self.cell_shape:
             raise ValueError("sim does not match the trained grid")
@@ -399,6 +470,9 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
         if interp not in ("nearest", "linear", "cubic"):
             raise ValueError(f"interp={interp!r} not in ('nearest', 'linear', 'cubic')")
         _check_group_interp(self.group, interp, "QuantileDeltaMapping.adjust", self.group_labels, extrapolation)
+        members = self._for_members(sim)
+        if members is not None:   # (the ranks are taken along time only — group.apply(rank, sim, main_only=True): per member)
+            return members.adjust(sim, interp=interp, extrapolation=extrapolation, time=time, keep=keep)
         dev = self._dev
         s, cell_shape = _flatten(sim, dev)
         if tuple(cell_shape) != self.cell_shape:
@@ -483,6 +557,9 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
     @classmethod
     def train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", window=None, time=None, device=None):
         grp = group if isinstance(group, Grouper) else Grouper(group, 1 if window is None else window)
+        if grp.add_dims:
+            # (PolyDetrend then fits ONE trend on the mean over the pooled members — _polydetrend_get_trend: da.mean(dim[1:]))
+            raise NotImplementedError("DetrendedQuantileMapping with Grouper(add_dims=...) is not built")
         if kind not in (ADDITIVE, MULTIPLICATIVE):
             raise ValueError(f"kind must be '+' or '*', got {kind!r}")
         dev = device or get_device()
