@@ -635,6 +635,7 @@ def bench_full_configs(dev, K, C, long_series=True):
     for a in (hist, sim, scen, af, hq):
         a.free()
     out["eqm_doy_linear"] = bench_plane_linear(dev, K, C // 8)
+    out["eqm_month_linear"] = bench_plane_month(dev, K, C // 8)
     out["c5_slab"] = bench_c5_slab(dev, K)
     if not long_series:
         return out
@@ -694,6 +695,40 @@ def bench_plane_linear(dev, K, Cb):
            "roofline": hbm_roofline(b, ms, "k_plane_pack + k_plane_rows<20> + k_plane_work (plane.hip)",
                                     passes="row kernel 12 ms (streams sim / scen + the node tables once), appends 2 ms, the Delaunay walk of the "
                                            "listed queries (node gaps >= 2 group steps) 28 ms: gathers + fp64, not a streaming kernel")}
+    for a in (d_hq, d_af, sim, scen, gd):
+        a.free()
+    return res
+
+
+def bench_plane_month(dev, K, Cb):
+    """EmpiricalQuantileMapping(group="time.month").adjust(interp="linear"): FRACTIONAL group coordinates (month - 0.5 + day /
+    days_in_month), 12 groups x 20 nodes, 30 years on a 1440 x 90 band.  k_plane_pair (round 5): the two rows around a step
+    in registers + lane-private LDS, the triangle of the two-row tiling by a count over the cuts, accepted when its
+    circumcircle reaches no third row; the rest (a seasonal cycle of 12 K shifts neighbouring months by several kelvin = several
+    units of the plane: ~30 % of the queries) takes the Delaunay walk from the work list."""
+    from xclim_amd.timeaxis import TimeAxis
+
+    T, G, nq = 10950, 12, 20
+    ta = TimeAxis.daily("1981-01-01", T, "noleap")
+    g = np.asarray(ta.month - 0.5 + ta.day / ta.days_in_month(), dtype=np.float64)
+    rng = np.random.default_rng(6)
+    mid = (np.arange(G) + 0.5) * 365.0 / 12.0
+    node = (288.0 + 12.0 * np.sin(2 * np.pi * (mid - 100) / 365))[:, None] + 3.0 * np.sort(rng.normal(0, 1, (G, nq)), axis=1)
+    hq = (node[:, :, None] + rng.normal(0, 0.2, Cb)[None, None, :]).astype(np.float32)
+    af = (1.5 + 0.3 * rng.normal(0, 1, (G, nq)))[:, :, None].astype(np.float32) + np.zeros((1, 1, Cb), np.float32)
+    d_hq, d_af = dev.to_device(hq), dev.to_device(af)
+    del hq, af
+    sim = K.fill_synthetic(dev, T, Cb, 0, 6, seasonal_base(T), 3.3)
+    scen = dev.empty((T, Cb), np.float32)
+    gd = dev.to_device(g)
+    ms = event_time(dev, lambda: K.plane_linear(dev, sim, gd, d_af, xq_all=d_hq, kind="+", out=scen), 1)
+    E = float(T) * Cb
+    b = 8 * E + 2 * 4.0 * G * nq * Cb
+    res = {"ms": ms, "GB/s": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS, "cell-timesteps/s": E / ms * 1e3, "grid": [T, 1440, 90],
+           "algorithmic_bytes": b, "groups": G, "nodes": nq,
+           "roofline": hbm_roofline(b, ms, "k_plane_pack + k_plane_pair<20> + k_plane_work (plane.hip)",
+                                    passes="pair kernel 35 ms (fp64 issue-bound: ~1 000 VALU instructions per query incl. the apex search "
+                                           "per pair of rows), the Delaunay walk of the listed queries 85 ms: gathers + fp64")}
     for a in (d_hq, d_af, sim, scen, gd):
         a.free()
     return res

@@ -480,6 +480,211 @@ k_plane_rows(const float* __restrict__ xnew, const float* __restrict__ base, int
   }
 }
 
+// Fractional group coordinates (the month grouping: newg = month - 0.5 + day / days_in_month).  One lane per cell walks the
+// steps of its chunk in time order; the coordinate is the same for every cell of a step, so the two rows around it (r0 =
+// floor(g), r0 + 1) are the same for the ~15 consecutive days of half a month: their packed nodes are loaded ONCE — abscissae
+// into registers, abscissae and factors into lane-private LDS columns (20 KB per wave: 2 waves per SIMD; with the rows and
+// the apex tables all in LDS or all in registers it was one wave per SIMD and 3.2 x slower: the fp64 chains of a single wave
+// issue an instruction every 7 cycles).  The Delaunay triangulation of two rows ALONE is known in closed form — every gap of
+// a row is the base of exactly one triangle, whose apex is the other row's node nearest to the gap's midpoint (its
+// circumcentre lies on the gap's bisector, so that apex leaves the circle empty of both rows' nodes) — and these triangles
+// tile the strip.  Per pair of rows the apex of every gap is found once (38 binary searches over the LDS columns in lockstep,
+// fp64, the tie rule of plane_locate's start) and kept as its abscissa (registers) + its 5-bit index (packed); per query the
+// cuts of the triangles at the query's height, [(1 - f) a_i + f b, (1 - f) a_{i+1} + f b], ascend with the gap's index, so the
+// triangle is the LAST one whose cut starts at or left of x: a count over registers, then 8 reads of the LDS columns for its
+// vertices.  That triangle is a Delaunay triangle of the WHOLE node set iff its circumcircle reaches no third row
+// (ceil(cy - R) >= r0 and floor(cy + R) <= r0 + 1); else — wide gaps (precipitation in mm/day, the tails of a temperature
+// distribution) or neighbouring months shifted by several kelvin (a seasonal cycle: ~30 % of the queries of bench.py's
+// extra.eqm_month_linear) — the query goes on the work list for the walk of plane_locate.
+// 30 years x 1440 x 90, 12 groups x 20 nodes: 300 ms through k_plane_linear -> 125 ms (pair kernel 35 + walk 85 + lists).
+constexpr int PP_BLOCK = 64;  // (20 KB of LDS per wave at 20 nodes: 8 waves per CU)
+template <int NQMAX>
+__global__ void __launch_bounds__(PP_BLOCK)
+k_plane_pair(const float* __restrict__ xnew, const float* __restrict__ base, int64_t st, const double* __restrict__ gnew, int64_t t_first,
+             int64_t t_end, PlaneTabs tabs, int kind, float* __restrict__ scen, int64_t scen_st, uint2* __restrict__ work,
+             unsigned int* __restrict__ nwork, unsigned long long segcap, int abl) {
+  const int64_t c = (int64_t)blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (c >= tabs.C) return;
+  const unsigned long long seg = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+  uint2* __restrict__ mywork = work + seg * segcap;
+  unsigned int* __restrict__ mycount = nwork + seg;
+  const int nq = tabs.nq, G = tabs.G;
+  const int64_t chunk = cdiv64(t_end - t_first, (int64_t)gridDim.y);
+  const int64_t ta = t_first + (int64_t)blockIdx.y * chunk;
+  int64_t tb = ta + chunk;
+  if (tb > t_end) tb = t_end;
+  const float PINF = __uint_as_float(0x7F800000u);
+  // lane-private LDS columns: the two rows ([0] = r0, [1] = r0 + 1) — whatever needs a run-time index; the abscissae the cut
+  // test runs over also sit in registers, the apex of a gap as its 5-bit index into the other row (5 gaps per word)
+  __shared__ float sx_[2][NQMAX][PP_BLOCK], sy_[2][NQMAX][PP_BLOCK];
+  static_assert(NQMAX <= 32 && (NQMAX - 1 + 4) / 5 <= 4, "apex indices: 5 bits each, four words per row");
+  float ax[NQMAX], bx[NQMAX];
+  float pbx[NQMAX - 1], pax[NQMAX - 1];  // apex abscissa of A's gap i (a node of B), of B's gap j (a node of A)
+  uint32_t kA[4] = {0u, 0u, 0u, 0u}, kB[4] = {0u, 0u, 0u, 0u};
+  int nA = 0, nB = 0, cur = -1;
+  float fxA = 0.f, lxA = 0.f, fyA = 0.f, lyA = 0.f, fxB = 0.f, lxB = 0.f, fyB = 0.f, lyB = 0.f;
+  float xf_next = ta < tb ? xnew[ta * st + c] : 0.f, bf_next = (base && ta < tb) ? base[ta * st + c] : 0.f;
+  for (int64_t t = ta; t < tb; ++t) {
+    double g = gnew[t];
+    g = g < 0.0 ? 0.0 : (g > (double)(G + 1) ? (double)(G + 1) : g);
+    int r0 = (int)floor(g);
+    if (r0 > G) r0 = G;  // (g == G + 1: the last interval, f = 1)
+    const double f = g - (double)r0;
+    if (r0 != cur) {  // (the same for every lane: the coordinate belongs to the step)
+      cur = r0;
+      const int rowA = plane_row(r0, G), rowB = plane_row(r0 + 1, G);
+      const int64_t iA = (int64_t)rowA * tabs.C + c, iB = (int64_t)rowB * tabs.C + c;
+      nA = (int)tabs.cnt[iA];
+      nB = (int)tabs.cnt[iB];
+      // (entries past nq re-read the last one: the counts below pad them; a select on `j < nq` per entry made the compiler keep
+      //  80 uniform masks alive across the whole kernel)
+      const float* __restrict__ pxa = tabs.px + (int64_t)rowA * nq * tabs.C + c;
+      const float* __restrict__ pya = tabs.py + (int64_t)rowA * nq * tabs.C + c;
+      const float* __restrict__ pxb = tabs.px + (int64_t)rowB * nq * tabs.C + c;
+      const float* __restrict__ pyb = tabs.py + (int64_t)rowB * nq * tabs.C + c;
+#pragma unroll
+      for (int j = 0; j < NQMAX; ++j) {
+        const int64_t o = (int64_t)(j < nq ? j : nq - 1) * tabs.C;
+        ax[j] = pxa[o];
+        bx[j] = pxb[o];
+        sy_[0][j][threadIdx.x] = pya[o];
+        sy_[1][j][threadIdx.x] = pyb[o];
+      }
+#pragma unroll
+      for (int j = 0; j < NQMAX; ++j) {
+        ax[j] = j < nA ? ax[j] : PINF;
+        bx[j] = j < nB ? bx[j] : PINF;
+        sx_[0][j][threadIdx.x] = ax[j];
+        sx_[1][j][threadIdx.x] = bx[j];
+      }
+      fxA = tabs.fx[iA]; lxA = tabs.lx[iA]; fyA = tabs.fy[iA]; lyA = tabs.ly[iA];
+      fxB = tabs.fx[iB]; lxB = tabs.lx[iB]; fyB = tabs.fy[iB]; lyB = tabs.ly[iB];
+      // apex of every gap: the other row's node nearest to the gap's midpoint, the lower one of two equally near (the rule of
+      // plane_locate's start); NaN for a gap past the row's last node: every comparison with its cut fails.
+      // all 38 searches in lockstep (5 halvings, the reads of one level in flight together): lo = nodes of the other row < the
+      // gap's midpoint; then plane_locate's rule: the lower of two equally near nodes
+      int la[NQMAX - 1], ha[NQMAX - 1], lb[NQMAX - 1], hb[NQMAX - 1];
+#pragma unroll
+      for (int i = 0; i < NQMAX - 1; ++i) { la[i] = 0; ha[i] = nB; lb[i] = 0; hb[i] = nA; }
+#pragma unroll 1
+      for (int it = 0; it < 5; ++it) {
+#pragma unroll
+        for (int i = 0; i < NQMAX - 1; ++i) {
+          const double mA = 0.5 * ((double)ax[i] + (double)ax[i + 1]), mB = 0.5 * ((double)bx[i] + (double)bx[i + 1]);
+          const int ma = (la[i] + ha[i]) >> 1, mb = (lb[i] + hb[i]) >> 1;
+          const float va = sx_[1][ma < NQMAX ? ma : NQMAX - 1][threadIdx.x], vb = sx_[0][mb < NQMAX ? mb : NQMAX - 1][threadIdx.x];
+          const bool oa = la[i] < ha[i], ob = lb[i] < hb[i];
+          const bool ga = oa && (double)va < mA, gb = ob && (double)vb < mB;
+          la[i] = ga ? ma + 1 : la[i];
+          ha[i] = (oa && !ga) ? ma : ha[i];
+          lb[i] = gb ? mb + 1 : lb[i];
+          hb[i] = (ob && !gb) ? mb : hb[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NQMAX - 1; ++i) {
+        const double mA = 0.5 * ((double)ax[i] + (double)ax[i + 1]), mB = 0.5 * ((double)bx[i] + (double)bx[i + 1]);
+        auto pick = [&](int row, int lo, int n, double m, float& vx) -> uint32_t {
+          const int l1 = lo > 0 ? lo - 1 : 0, l0 = lo < NQMAX ? lo : NQMAX - 1;
+          const double below = (double)sx_[row][l1][threadIdx.x], at = (double)sx_[row][l0][threadIdx.x];
+          int k = lo >= n ? n - 1 : lo;
+          if (lo < n && lo > 0 && m - below <= at - m) k = lo - 1;
+          k = k < 0 ? 0 : k;
+          vx = sx_[row][k][threadIdx.x];
+          return (uint32_t)k;
+        };
+        float vx, wx;
+        const uint32_t ka = pick(1, la[i], nB, mA, vx), kb = pick(0, lb[i], nA, mB, wx);
+        pbx[i] = (i + 1 < nA && nB >= 1) ? vx : xh_nan32();
+        pax[i] = (i + 1 < nB && nA >= 1) ? wx : xh_nan32();
+        if (i % 5 == 0) { kA[i / 5] = 0u; kB[i / 5] = 0u; }
+        kA[i / 5] |= ka << ((i % 5) * 5);
+        kB[i / 5] |= kb << ((i % 5) * 5);
+      }
+    }
+    const float xf = xf_next;
+    const float bf = base ? bf_next : xf;
+    if (t + 1 < tb) {  // (one wave per SIMD: the next step's sample is on its way while this one is located)
+      xf_next = xnew[(t + 1) * st + c];
+      if (base) bf_next = base[(t + 1) * st + c];
+    }
+    float a = xh_nan32();
+    if (xf == xf) {
+      const double x = (double)xf;
+      const double lo = f == 1.0 ? (double)fxB : plane_lerp((double)fxA, (double)fxB, f);
+      const double hi = f == 1.0 ? (double)lxB : plane_lerp((double)lxA, (double)lxB, f);
+      bool done = false;
+      if (x < lo) { a = (float)(f == 1.0 ? (double)fyB : plane_lerp((double)fyA, (double)fyB, f)); done = true; }
+      else if (x > hi) { a = (float)(f == 1.0 ? (double)lyB : plane_lerp((double)lyA, (double)lyB, f)); done = true; }
+      else if (nA >= 1 && nB >= 1 && f < 1.0) {
+        // the triangle of the two-row tiling whose cut at height f holds x.  The left ends of the cuts ascend with the gap's
+        // index (the nodes ascend and so do the apexes), so the candidate is the LAST gap whose cut starts at or left of x: a
+        // count over the registers; its vertices come from the LDS columns.
+        const double w0 = 1.0 - f;
+        int cA = 0, cB = 0;
+#pragma unroll
+        for (int i = 0; i < NQMAX - 1; ++i) {
+          cA += (w0 * (double)ax[i] + f * (double)pbx[i] <= x) ? 1 : 0;   // (NaN apex: a gap that does not exist)
+          cB += (w0 * (double)pax[i] + f * (double)bx[i] <= x) ? 1 : 0;
+        }
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+        float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+        int typ = 0;  // 1: base on A (P0, P1 on row r0, P2 on r0 + 1), 2: base on B (P0 on r0, P1, P2 on r0 + 1)
+        auto apex_of = [&](const uint32_t (&kw)[4], int i) -> int {
+          const int w = i / 5;
+          const uint32_t word = w == 0 ? kw[0] : (w == 1 ? kw[1] : (w == 2 ? kw[2] : kw[3]));
+          return (int)((word >> (uint32_t)((i - w * 5) * 5)) & 31u);
+        };
+        if (cA >= 1) {
+          const int i = cA - 1, k = apex_of(kA, i);
+          const double a1 = (double)sx_[0][i + 1][threadIdx.x], pb = (double)sx_[1][k][threadIdx.x];
+          if (x <= w0 * a1 + f * pb) {
+            typ = 1;
+            x0 = (double)sx_[0][i][threadIdx.x]; x1 = a1; x2 = pb;
+            y0 = sy_[0][i][threadIdx.x]; y1 = sy_[0][i + 1][threadIdx.x]; y2 = sy_[1][k][threadIdx.x];
+          }
+        }
+        if (typ == 0 && cB >= 1) {
+          const int j = cB - 1, k = apex_of(kB, j);
+          const double b1 = (double)sx_[1][j + 1][threadIdx.x], pa = (double)sx_[0][k][threadIdx.x];
+          if (x <= w0 * pa + f * b1) {
+            typ = 2;
+            x0 = pa; x1 = (double)sx_[1][j][threadIdx.x]; x2 = b1;
+            y0 = sy_[0][k][threadIdx.x]; y1 = sy_[1][j][threadIdx.x]; y2 = sy_[1][j + 1][threadIdx.x];
+          }
+        }
+        if (typ != 0) {
+          // circumcircle (the formulas of plane_locate); rows are r0 (y = 0) and r0 + 1 (y = 1) here
+          const double yy1 = typ == 1 ? 0.0 : 1.0;  // P1's row; P0 on row 0, P2 on row 1
+          const double ax_ = x1 - x0, ay_ = yy1, bx_ = x2 - x0, by_ = 1.0;
+          const double d = 2.0 * (ax_ * by_ - ay_ * bx_);
+          const double a2 = ax_ * ax_ + ay_ * ay_, b2 = bx_ * bx_ + by_ * by_;
+          const double ux = (by_ * a2 - ay_ * b2) / d, uy = (ax_ * b2 - bx_ * a2) / d;
+          const double R2 = ux * ux + uy * uy;
+          const double Rr = sqrt(R2);
+          if (R2 < 1e300 && ceil(uy - Rr) >= 0.0 && floor(uy + Rr) <= 1.0) {
+            const double l1 = ((x - x0) * by_ - bx_ * f) / (0.5 * d);
+            const double l2 = (ax_ * f - (x - x0) * ay_) / (0.5 * d);
+            a = (float)((1.0 - l1 - l2) * (double)y0 + l1 * (double)y1 + l2 * (double)y2);
+            done = true;
+          }
+        }
+      }
+      if (!done) {
+        if (abl & 1) continue;  // diagnostics: the pair kernel alone
+        const unsigned long long m = __ballot(1);
+        const int lane = threadIdx.x & 63;
+        unsigned int b0 = 0;
+        if (lane == __ffsll((long long)m) - 1) b0 = atomicAdd(mycount, (unsigned int)__popcll(m));
+        b0 = __shfl(b0, __ffsll((long long)m) - 1);
+        mywork[b0 + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)t, (uint32_t)c);
+        continue;
+      }
+    }
+    scen[t * scen_st + c] = kind == 0 ? (bf + a) : (kind == 1 ? (bf * a) : a);
+  }
+}
+
 // the queries the row kernel could not decide from the row alone: every workgroup runs through the stretch of the list its
 // twin of the row kernel filled, one lane per entry, the Delaunay walk of plane_locate
 __global__ void __launch_bounds__(XH_BLOCK)
@@ -600,6 +805,36 @@ int plane_run(xh_ctx* ctx, const float* xnew, const float* base, int64_t T, int6
           hipLaunchKernelGGL(k_plane_work, dim3((unsigned)cblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, xnew, base, st, gnew, tabs,
                              kind, scen, scen_st, work, nwork, segcap, method == 0 ? 1 : 0);
         r0 = r1;
+      }
+      XH_LAUNCH_CHECK();
+      return XH_OK;
+    }
+    // fractional coordinates (month groupings), <= 20 nodes per group: the two rows around a step in registers (k_plane_pair),
+    // the queries whose triangle is not decided by those two rows alone through the work list.  Steps in stretches whose
+    // queries fit the list even if every one of them is listed.
+    const int64_t pblocks = cdiv64(C, PP_BLOCK);
+    if (method == 1 && nq <= 20 && pblocks <= 65536 && !xh_diag_env("XH_PLANE_NOPAIR")) {
+      const char* eab = xh_diag_env("XH_PLANE_ABL");  // diagnostics: 1 = pair kernel alone, 2 = no work kernel
+      const int abl = eab ? atoi(eab) : 0;
+      const int64_t len_cap = (int64_t)((unsigned long long)wcap / ((unsigned long long)PP_BLOCK * (unsigned long long)pblocks));
+      XH_REQUIRE(len_cap >= 1, XH_ERR_LIMIT, "xh_plane_linear: the work list is too small for one time step of this grid");
+      int64_t t0 = 0;
+      while (t0 < T) {
+        int64_t len = T - t0 < len_cap ? T - t0 : len_cap;
+        int64_t gy = cdiv64((int64_t)ctx->num_cu * 16, pblocks);
+        if (gy > len / 64) gy = len / 64;   // (a chunk reloads its two rows at its start: keep chunks long)
+        if (gy < 1) gy = 1;
+        if (gy * pblocks > 65536) gy = 65536 / pblocks;
+        int64_t chunk = cdiv64(len, gy);
+        if (chunk * gy > len_cap) { chunk = len_cap / gy; len = chunk * gy; }
+        const unsigned long long segcap = (unsigned long long)chunk * PP_BLOCK;
+        XH_CHECK_HIP(hipMemsetAsync(nwork, 0, 4 * (size_t)(gy * pblocks), ctx->stream));
+        hipLaunchKernelGGL((k_plane_pair<20>), dim3((unsigned)pblocks, (unsigned)gy), dim3(PP_BLOCK), 0, ctx->stream, xnew, base, st, gnew, t0,
+                           t0 + len, tabs, kind, scen, scen_st, work, nwork, segcap, abl);
+        if (!(abl & 3))
+          hipLaunchKernelGGL(k_plane_work, dim3((unsigned)pblocks, (unsigned)gy), dim3(XH_BLOCK), 0, ctx->stream, xnew, base, st, gnew, tabs,
+                             kind, scen, scen_st, work, nwork, segcap, 0);
+        t0 += len;
       }
       XH_LAUNCH_CHECK();
       return XH_OK;
