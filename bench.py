@@ -82,7 +82,7 @@ def valu_bound(kernel):
     tools/summarize_sq.py -> profiles/r03/valu_busy.json): VALU instructions per SIMD x the measured issue cost of a
     wave64 instruction (2.5 cycles of the ~2.4 GHz clock for add / xor / mov, 4.3 for min / max / cmp:
     profiles/r03/valu_ubench.txt, bank_ubench.txt) over the kernel's cycles.  busy_hi near 1 = no faster without issuing fewer instructions.  None when not profiled."""
-    for rel in ("profiles/r04/valu_busy.json", "profiles/r03/valu_busy.json"):
+    for rel in ("profiles/r05/valu_busy.json", "profiles/r04/valu_busy.json", "profiles/r03/valu_busy.json"):
         try:
             table = json.load(open(os.path.join(ROOT, rel)))
         except (OSError, ValueError):

@@ -487,6 +487,8 @@ def dqm_adjust_grouped(sim, time, prop, labels, af, hist_q, scaling, kind="+", e
             gidx = np.searchsorted(labels, gv)
             scaled_all = _corr(sim, np.asarray(scaling, dtype=np.float64).reshape((len(labels),) + sim.shape[1:])[gidx], kind)
         wmean = window_nanmean(scaled_all, window)
+    detr_all = np.full(sim.shape, np.nan, dtype=np.float32)
+    trend_all = np.full(sim.shape, np.nan, dtype=np.float64)
     for g, lab in enumerate(labels):
         rows = np.nonzero(gv == lab)[0]
         if not rows.size:
@@ -496,13 +498,17 @@ def dqm_adjust_grouped(sim, time, prop, labels, af, hist_q, scaling, kind="+", e
         trend = poly_trend_u(scaled if wmean is None else wmean[rows], u, detrend)
         detr = _corr(scaled, trend, kind, True)
         if mode == "griddata":
-            newg = gv[rows] if interp == "nearest" else group_index(time, prop, True)[rows]
-            af_t = interp_on_quantiles_2d(detr, newg, labels, hist_q, af, interp, extrapolation)
-            with np.errstate(all="ignore"):
-                scen0 = (detr + af_t if kind == "+" else detr * af_t).astype(np.float32)
+            detr_all[rows], trend_all[rows] = detr, trend
         else:
-            scen0 = eqm_adjust(detr, af[g], hist_q[g], kind, "nearest", extrapolation)
-        out[rows] = _corr(scen0, trend, kind)
+            out[rows] = _corr(eqm_adjust(detr, af[g], hist_q[g], kind, "nearest", extrapolation), trend, kind)
+    if mode == "griddata":
+        # one interpolation over the (quantile, group) plane for the whole series (the same per step as group by group; a
+        # triangulation per group and cell made the day-of-year case take minutes)
+        newg = gv if interp == "nearest" else group_index(time, prop, True)
+        af_t = interp_on_quantiles_2d(detr_all, newg, labels, hist_q, af, interp, extrapolation)
+        with np.errstate(all="ignore"):
+            scen0 = (detr_all + af_t if kind == "+" else detr_all * af_t).astype(np.float32)
+        out = _corr(scen0, trend_all, kind)
     return out
 
 

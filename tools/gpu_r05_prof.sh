@@ -15,6 +15,10 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/small/pmc_write
 timeout 1200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/full/pmc_fetch -o f -- $FULL > $O/full_fetch.log 2>&1
 timeout 1200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/full/pmc_write -o w -- $FULL > $O/full_write.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/calib/pmc_fetch -o f -- $GRAFT_REPO_ROOT/tools/regsort_ubench > $O/calib_regsort.log 2>&1
+if [ "${XH_PROF_SQ:-0}" = "small" ]; then  # the VALU-issue view of the 365-step kernels only (k_qdm_regsort changed in round 5)
+timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/sq -o s -- $SMALL > $O/sq.log 2>&1
+timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/grbm -o g -- $SMALL > $O/grbm.log 2>&1
+fi
 if [ "${XH_PROF_SQ:-0}" = "1" ]; then  # the VALU-issue view (tools/summarize_sq.py); the sort kernels did not change since profiles/r04/valu_busy.json
 timeout 1200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/sq -o s -- $FULL > $O/sq.log 2>&1
 timeout 1200 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/grbm -o g -- $FULL > $O/grbm.log 2>&1
