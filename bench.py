@@ -711,9 +711,15 @@ def bench_plane_month(dev, K, Cb):
     T, G, nq = 10950, 12, 20
     ta = TimeAxis.daily("1981-01-01", T, "noleap")
     g = np.asarray(ta.month - 0.5 + ta.day / ta.days_in_month(), dtype=np.float64)
+    from statistics import NormalDist
+
     rng = np.random.default_rng(6)
     mid = (np.arange(G) + 0.5) * 365.0 / 12.0
-    node = (288.0 + 12.0 * np.sin(2 * np.pi * (mid - 100) / 365))[:, None] + 3.0 * np.sort(rng.normal(0, 1, (G, nq)), axis=1)
+    # the nodes a trained model has: the quantiles (i + 1/2) / nq of a normal distribution around the month's mean (+ a little
+    # noise per month), not 20 random draws (whose tail gaps of 2-3 K send more queries to the walk)
+    z = np.array([NormalDist().inv_cdf((i + 0.5) / nq) for i in range(nq)])
+    node = (288.0 + 12.0 * np.sin(2 * np.pi * (mid - 100) / 365))[:, None] + 3.3 * z[None, :] + rng.normal(0, 0.05, (G, nq))
+    node = np.sort(node, axis=1)
     hq = (node[:, :, None] + rng.normal(0, 0.2, Cb)[None, None, :]).astype(np.float32)
     af = (1.5 + 0.3 * rng.normal(0, 1, (G, nq)))[:, :, None].astype(np.float32) + np.zeros((1, 1, Cb), np.float32)
     d_hq, d_af = dev.to_device(hq), dev.to_device(af)

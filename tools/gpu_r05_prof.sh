@@ -12,8 +12,10 @@ SMALL="python $B --steps 5 --warmup 1 --no-cpu --no-full"
 FULL="python $B --steps 2 --warmup 1 --no-cpu --no-long"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/small/pmc_fetch -o f -- $SMALL > $O/small_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/small/pmc_write -o w -- $SMALL > $O/small_write.log 2>&1
+if [ "${XH_PROF_SKIP_FULL:-0}" != "1" ]; then  # (the 30-year kernels did not change since the committed profiles/r05/pmc_hbm_traffic_30yr.json)
 timeout 1200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/full/pmc_fetch -o f -- $FULL > $O/full_fetch.log 2>&1
 timeout 1200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/full/pmc_write -o w -- $FULL > $O/full_write.log 2>&1
+fi
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/calib/pmc_fetch -o f -- $GRAFT_REPO_ROOT/tools/regsort_ubench > $O/calib_regsort.log 2>&1
 if [ "${XH_PROF_SQ:-0}" = "small" ]; then  # the VALU-issue view of the 365-step kernels only (k_qdm_regsort changed in round 5)
 timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/sq -o s -- $SMALL > $O/sq.log 2>&1
