@@ -412,3 +412,49 @@ def test_every_call_shape_of_a_replaced_function_is_recorded():
     assert not missing, {k: sites[k][:3] for k in missing}
     assert len(sites) == 19 and sum(len(v) for v in sites.values()) == 128      # (the walk itself: a new reference version moves these)
     assert not [k for k in recorded if k not in sites]
+
+
+@pytest.mark.parametrize("calendar,start,T,window", [("noleap", "2001-01-01", 365 * 4, 31), ("noleap", "2001-01-01", 365 * 3, 5),
+                                                     ("360_day", "2001-01-01", 360 * 3, 15), ("standard", "2001-01-01", 1461, 7),
+                                                     ("noleap", "2001-03-01", 365 * 3, 7)])
+def test_group_samples_ring_holds_the_rows_of_sample_rows(monkeypatch, calendar, start, T, window):
+    """Grouper.group_samples keeps the windowed sample of day-of-year groups as a ring (one row per year replaced from one
+    day to the next) when every year holds every day; whatever the route, the matrix of a group must hold exactly the rows
+    that sample_rows lists (as a multiset: the order of a sample does not matter) — here with numpy standing in for the
+    device (rows carry their own index as value)."""
+    from xclim_amd import kernels as K
+    from xclim_amd import sdba
+
+    class FakeArr:
+        def __init__(self, a):
+            self.a, self.shape = a, a.shape
+
+    class FakeDev:
+        def empty(self, shape, dtype):
+            return FakeArr(np.full(shape, -7.0, dtype=np.float32))
+
+    calls = {"rows": 0}
+
+    def fake_select_rows(dev, x, idx, out=None, out_row=0, out_stride_rows=1):
+        idx = np.asarray(idx)
+        vals = np.where(idx[:, None] < 0, np.nan, x.a[np.clip(idx, 0, None)])
+        calls["rows"] += len(idx)
+        if out is None:
+            return FakeArr(vals.astype(np.float32))
+        out.a[out_row + np.arange(len(idx)) * out_stride_rows] = vals
+        return out
+
+    monkeypatch.setattr(K, "select_rows", fake_select_rows)
+    ta = TimeAxis.daily(start, T, calendar) if calendar != "standard" else TimeAxis.daily(start, T)
+    grp = sdba.Grouper("time.dayofyear", window)
+    field = FakeArr(np.arange(T, dtype=np.float32)[:, None])
+    expected = grp.sample_rows(ta)
+    ngroups = 0
+    for g, (smp,) in grp.group_samples(FakeDev(), (field,), ta):
+        got = np.sort(np.where(np.isnan(smp.a[:, 0]), -1, smp.a[:, 0]).astype(np.int64))
+        np.testing.assert_array_equal(got, np.sort(expected[g]), err_msg=f"group {g}")
+        ngroups += 1
+    assert ngroups == len(expected)
+    full = sum(len(e) for e in expected)
+    regular = calendar != "standard" and start.endswith("01-01")
+    assert (calls["rows"] < full / 3) == regular      # the ring gathers a fraction; irregular calendars / partial years gather all

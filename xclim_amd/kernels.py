@@ -233,12 +233,19 @@ def compare_map(dev: Device, a: DeviceArray, op, thr, kind: str = "mask") -> Dev
     return out
 
 
-def select_rows(dev: Device, x: DeviceArray, idx) -> DeviceArray:
-    """out row i = x row idx[i], NaN where idx[i] < 0 (xh_select_rows)."""
+def select_rows(dev: Device, x: DeviceArray, idx, out: DeviceArray | None = None, out_row: int = 0, out_stride_rows: int = 1) -> DeviceArray:
+    """out row i = x row idx[i], NaN where idx[i] < 0 (xh_select_rows).  With ``out`` (rows, C): row i goes to row
+    ``out_row + i * out_stride_rows`` of it (a strided scatter into an existing sample matrix)."""
     T, C_ = _tc(x)
     idx = np.ascontiguousarray(idx, dtype=np.int64)
-    out = dev.empty((len(idx), C_), np.float32)
-    dev.call("xh_select_rows", _vp(x.ptr), T, C_, C_, 1, np_ptr(idx), len(idx), _vp(out.ptr), C_)
+    if out is None:
+        out = dev.empty((len(idx), C_), np.float32)
+        dev.call("xh_select_rows", _vp(x.ptr), T, C_, C_, 1, np_ptr(idx), len(idx), _vp(out.ptr), C_)
+        return out
+    rows, Co = _tc(out)
+    if Co != C_ or out_row < 0 or (len(idx) and out_row + (len(idx) - 1) * out_stride_rows >= rows) or out_stride_rows < 1:
+        raise ValueError("select_rows: the strided destination does not fit `out`")
+    dev.call("xh_select_rows", _vp(x.ptr), T, C_, C_, 1, np_ptr(idx), len(idx), _vp(out.ptr + out_row * C_ * 4), out_stride_rows * C_)
     return out
 
 

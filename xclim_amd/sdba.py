@@ -90,6 +90,44 @@ class Grouper:
         C_ = int(np.prod(cells)) if cells else 1
         return dev.wrap(x.ptr, (x.shape[0] * R, C_), np.float32), R, cells
 
+    def group_samples(self, dev, fields, time, R: int = 1):
+        """For every group (in label order) the training sample of each field of ``fields`` ((T * R, C) device matrices) as a
+        (rows, C) device matrix: the gathered rows of :meth:`sample_rows`.  The matrices of one group are only valid until the
+        next one is asked for.
+
+        Day-of-year groups with a window on a series where every year holds every day (noleap, 360_day ...): the sample of
+        day d + 1 is the sample of day d with ONE row per year replaced (the order of a sample's rows does not matter), so
+        the matrix is kept as a ring — ``window`` slots per year — and 1 / window of it is gathered per group (30 years,
+        window 31: 930 rows -> 30)."""
+        rows_of = self.sample_rows(time)
+        ring = False
+        if self.prop == "dayofyear" and self.window > 1 and R == 1 and len(rows_of) > 1:
+            tb = np.asarray(time.doy_table()[0], dtype=np.int64)      # (years, doys) -> time index
+            ring = tb.shape[1] == len(rows_of) and tb.min() >= 0 and bool((tb[:, 1:] == tb[:, :-1] + 1).all())
+        if not ring:
+            for g, rows in enumerate(rows_of):
+                rows = self.pooled_rows(rows, R)
+                yield g, [K.select_rows(dev, f, rows) for f in fields]
+            return
+        T, W, half, ny = len(time), self.window, self.window // 2, tb.shape[0]
+        bufs = [dev.empty((ny * W, f.shape[1]), np.float32) for f in fields]
+
+        def rows_at(d, off):  # the rows tb[:, d] + off of every year, -1 beyond the series
+            r = tb[:, d] + off
+            return np.where((r < 0) | (r >= T), -1, r)
+
+        first = np.full(ny * W, -1, dtype=np.int64)
+        for off in range(-half, half + 1):
+            first[np.arange(ny) * W + (off % W)] = rows_at(0, off)       # slot of day d + off: (d + off) mod W, d = 0
+        for f, b in zip(fields, bufs):
+            K.select_rows(dev, f, first, out=b)
+        yield 0, bufs
+        for d in range(1, tb.shape[1]):
+            new = rows_at(d, half)                                        # day d + half enters, day d - 1 - half leaves: same slot
+            for f, b in zip(fields, bufs):
+                K.select_rows(dev, f, new, out=b, out_row=(d + half) % W, out_stride_rows=W)
+            yield d, bufs
+
     @staticmethod
     def pooled_rows(rows: np.ndarray, R: int) -> np.ndarray:
         """Sample rows of the time axis -> rows of the pooled (T * R, C) matrix (-1 stays -1, R times)."""
@@ -346,10 +384,9 @@ class EmpiricalQuantileMapping:
         af = dev.empty((G, len(q), C_), np.float32)
         hq = dev.empty((G, len(q), C_), np.float32)
         plane = len(q) * C_ * 4
-        for g, rows in enumerate(grp.sample_rows(time)):
-            rows = grp.pooled_rows(rows, R)
+        for g, (rg, hg) in grp.group_samples(dev, (r, h), time, R):
             out_g = tuple(dev.wrap(a.ptr + g * plane, (len(q), C_), np.float32) for a in (af, hq))
-            K.eqm_train(dev, K.select_rows(dev, r, rows), K.select_rows(dev, h, rows), q, kind, out=out_g)
+            K.eqm_train(dev, rg, hg, q, kind, out=out_g)
         dev.sync()
         return cls(dev, af, hq, q, kind, cell_shape, grp, labels)
 
@@ -590,9 +627,9 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         hq = dev.empty((G, len(q), C_), np.float32)
         plane = len(q) * C_ * 4
         scal = np.empty((G, C_), np.float64)
-        for g, rows in enumerate(grp.sample_rows(time)):
+        for g, (rg, hg) in grp.group_samples(dev, (r, h), time):
             out_g = tuple(dev.wrap(a.ptr + g * plane, (len(q), C_), np.float32) for a in (af, hq))
-            _, _, scal[g] = one(K.select_rows(dev, r, rows), K.select_rows(dev, h, rows), out=out_g)
+            _, _, scal[g] = one(rg, hg, out=out_g)
         dev.sync()
         return cls(dev, af, hq, q, kind, cell_shape, grp, labels, scaling=dev.to_device(scal, dtype=np.float64))
 
