@@ -636,6 +636,7 @@ def bench_full_configs(dev, K, C, long_series=True):
         a.free()
     out["eqm_doy_linear"] = bench_plane_linear(dev, K, C // 8)
     out["eqm_month_linear"] = bench_plane_month(dev, K, C // 8)
+    out["tx90p_bootstrap_band"] = bench_bootstrap(dev, K, C // 8)
     out["c5_slab"] = bench_c5_slab(dev, K)
     if not long_series:
         return out
@@ -733,10 +734,46 @@ def bench_plane_month(dev, K, Cb):
     res = {"ms": ms, "GB/s": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS, "cell-timesteps/s": E / ms * 1e3, "grid": [T, 1440, 90],
            "algorithmic_bytes": b, "groups": G, "nodes": nq,
            "roofline": hbm_roofline(b, ms, "k_plane_pack + k_plane_pair<20> + k_plane_work (plane.hip)",
-                                    passes="pair kernel 35 ms (fp64 issue-bound: ~1 000 VALU instructions per query incl. the apex search "
-                                           "per pair of rows), the Delaunay walk of the listed queries 85 ms: gathers + fp64")}
+                                    passes="pair kernel ~35 ms (fp64 issue-bound: ~1 000 VALU instructions per query incl. the apex search per "
+                                           "pair of rows) + the Delaunay walk of the listed queries (gathers + fp64): ~28 ms on these nodes, 85 ms "
+                                           "on the noisier nodes of a model trained on the synthetic field (tools/experiments/r05/gpu_r05_p.sh)")}
     for a in (d_hq, d_af, sim, scen, gd):
         a.free()
+    return res
+
+
+def bench_bootstrap(dev, K, Cb):
+    """tx90p with the percentile bootstrap of Zhang et al. 2005 (core/bootstrapping.py:81-282: every in-base year is
+    evaluated against the n - 1 percentile tables in which it is replaced by another base year): 31 years on a 1440 x 90
+    band, base period = the first 30 -> 30 x 29 = 870 thirty-year percentile tables.  The reference deep-copies the base
+    period per replica; here a replica is an index table (`vmap`) over the resident series.  Wall clock of the host
+    mirror, device-resident input, result on the device."""
+    import time as _time
+
+    from xclim_amd import indices as xi
+    from xclim_amd.calendar import percentile_doy
+    from xclim_amd.timeaxis import TimeAxis
+
+    nyears, nbase = 31, 30
+    T = 365 * nyears
+    ta = TimeAxis.daily("1961-01-01", T, "noleap")
+    tas = K.fill_synthetic(dev, T, Cb, 0, 2, seasonal_base(T), 3.0)
+    nb = 365 * nbase
+    p90 = percentile_doy(dev.wrap(tas.ptr, (nb, Cb), np.float32), ta.subset(slice(0, nb)), 5, 90.0, device=dev)
+    run = lambda: xi.tx90p(tas, p90, ta, freq="YS", device=dev, bootstrap=True)  # noqa: E731
+    run()
+    dev.sync()
+    t0 = _time.perf_counter()
+    run()
+    dev.sync()
+    ms = (_time.perf_counter() - t0) * 1e3
+    nrep = nbase * (nbase - 1)
+    E = float(T) * Cb
+    res = {"ms": ms, "replicas": nrep, "ms_per_replica": ms / nrep, "grid": [T, 1440, 90], "cell-timesteps/s": E / ms * 1e3,
+           "replica-cell-timesteps/s": float(nb) * Cb * nrep / ms * 1e3,
+           "note": "870 percentile tables over 30 years (k_pdoy_quad through a virtual time map) + the year's exceedance count "
+                   "against each; wall clock incl. the host loop; the reference copies the base period once per replica"}
+    tas.free()
     return res
 
 
