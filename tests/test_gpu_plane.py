@@ -22,7 +22,37 @@ def _nodes(rng, G, nq, C, scale, kind):
     else:
         x = np.sort(rng.normal(0.0, scale, (G, nq, C)), axis=1) + 10.0 * scale * cyc + 280.0
     y = rng.normal(0.0, 1.0, (G, nq, C)) + 2.0 * cyc
-    return x.astype(np.float32), y.astype(np.float32)
+    x, y = x.astype(np.float32), y.astype(np.float32)
+    # float32 abscissae near 280 K tie by rounding (spacing 3e-5 K against node gaps of 0.01 K at scale 0.05).  Tied nodes of one
+    # row with DIFFERENT factors are the documented unreproducible case (Qhull keeps one of two coincident points — the first in
+    # 59 %, the last in 28 % of the queries where it matters; the kernel keeps the first): ties get the same factor here
+    for _ in range(nq):
+        tie = x[:, 1:] == x[:, :-1]
+        if not tie.any():
+            break
+        y[:, 1:][tie] = y[:, :-1][tie]
+    return x, y
+
+
+def _cocircular(x, g, xq, yq, t, c):
+    """Is the query's scipy triangle degenerate — a fourth node EXACTLY on its circumcircle?  float32 abscissae are a grid
+    (2^-15 K at 280 K): x_a + x_b == x_c + x_d happens, two valid Delaunay triangulations exist and scipy's choice follows
+    Qhull's facet order (plane.hip, header; tools/fuzz_plane.py counts these)."""
+    from scipy.spatial import Delaunay
+
+    G, nq = xq.shape[0], xq.shape[1]
+    ext = np.concatenate([[G - 1], np.arange(G), [0]])
+    pts = np.array([(float(xq[r, k, c]), float(i)) for i, r in enumerate(ext) for k in range(nq)
+                    if not (np.isnan(xq[r, k, c]) or np.isnan(yq[r, k, c]))])
+    pts = np.unique(pts, axis=0)
+    tri = Delaunay(pts)
+    P3 = pts[tri.simplices[int(tri.find_simplex(np.array([float(x[t, c]), float(g[t])])))]]
+    ax, ay = P3[1] - P3[0]
+    bx, by = P3[2] - P3[0]
+    d = 2 * (ax * by - ay * bx)
+    ux, uy = (by * (ax * ax + ay * ay) - ay * (bx * bx + by * by)) / d, (ax * (bx * bx + by * by) - bx * (ax * ax + ay * ay)) / d
+    pw = ((pts - (P3[0] + [ux, uy])) ** 2).sum(1) - (ux * ux + uy * uy)
+    return int((np.abs(pw) < 1e-9 * max(1.0, ux * ux + uy * uy)).sum()) >= 4
 
 
 def _check(dev, x, g, xq, yq, rtol=1e-6, atol=1e-6):
@@ -30,7 +60,11 @@ def _check(dev, x, g, xq, yq, rtol=1e-6, atol=1e-6):
     got = K.plane_linear(dev, dev.to_device(x), g, dev.to_device(yq), xq_all=dev.to_device(xq), kind="factor").get()
     exp = osdba.interp_on_quantiles_2d(x, g, np.arange(1, G + 1), xq, yq, "linear", "constant")
     assert np.array_equal(np.isnan(got), np.isnan(exp))
-    np.testing.assert_allclose(got, exp, rtol=rtol, atol=atol * max(1.0, float(np.nanmax(np.abs(yq)))), equal_nan=True)
+    bad = ~np.isclose(got, exp, rtol=rtol, atol=atol * max(1.0, float(np.nanmax(np.abs(yq)))), equal_nan=True)
+    # (whatever the seed of the inputs: a mismatch is accepted only as a verified exact degeneracy, and only a handful)
+    assert bad.sum() <= 4, f"{int(bad.sum())} mismatches"
+    for t, c in np.argwhere(bad):
+        assert _cocircular(x, g, xq, yq, t, c), f"query ({t}, {c}): got {got[t, c]}, scipy {exp[t, c]}"
     return got
 
 
