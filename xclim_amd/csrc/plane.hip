@@ -86,6 +86,8 @@ k_plane_pack(const float* __restrict__ xq_all, const double* __restrict__ xq_com
   ly[(int64_t)g * C + c] = lasty;
 }
 
+// [host-testable: begin] — plain C++ up to the matching end marker: tests/test_plane_host_build.py compiles this stretch with g++
+// (no GPU) and checks plane_locate / plane_nearest against scipy.griddata
 // row coordinate r in 0 .. G + 1 -> table row (cyclic copies at both ends)
 __device__ __forceinline__ int plane_row(int r, int G) { return r == 0 ? G - 1 : (r == G + 1 ? 0 : r - 1); }
 
@@ -329,6 +331,7 @@ __device__ double plane_nearest(const PlaneCell& P, double x, int r) {
   return a;
 }
 
+// [host-testable: end]
 __global__ void __launch_bounds__(XH_BLOCK)
 k_plane_linear(const float* __restrict__ xnew, const float* __restrict__ base, int64_t T, int64_t st, const double* __restrict__ gnew,
                PlaneTabs tabs, int kind, float* __restrict__ scen, int64_t scen_st) {
