@@ -1,0 +1,79 @@
+"""A Device whose C ABI is the HOST SIMULATION build of the translation units that need neither LDS nor wave intrinsics
+(tests/hostsim/hip/hip_runtime.h: every kernel runs thread by thread on the CPU).  Test infrastructure for the `-m "not gpu"`
+tier only — it pins kernel arithmetic and entry-point dispatch against the oracle on machines without a GPU; entry points
+that are not simulated raise (never a silent no-op), and nothing of this is reachable from the product package."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import sys
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.join(HERE, "..", "..")
+CSRC = os.path.join(ROOT, "xclim_amd", "csrc")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from mock_device import MockDevice, _MockLib  # noqa: E402
+from xclim_amd import _capi  # noqa: E402
+
+SIMULATED_UNITS = ("detrend", "window", "runlen", "reduce", "reduce2", "spell", "elemwise")
+WAVE_ENTRY_POINTS = ("xh_doy_mean_std",)   # compiled (reduce2.hip) but its kernel reads through the wave: refused
+
+
+def build(workdir: str) -> str:
+    """g++ the simulated translation units (unchanged sources) + sim_runtime.cpp into workdir/libxclimhip_hostsim.so."""
+    if shutil.which("g++") is None:
+        raise RuntimeError("no g++")
+    flags = ["-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC]
+    objs = []
+    for unit in SIMULATED_UNITS:
+        obj = os.path.join(workdir, unit + ".o")
+        subprocess.run(["g++", "-x", "c++", *flags, "-c", os.path.join(CSRC, unit + ".hip"), "-o", obj], check=True)
+        objs.append(obj)
+    obj = os.path.join(workdir, "sim_runtime.o")
+    subprocess.run(["g++", *flags, "-c", os.path.join(HERE, "sim_runtime.cpp"), "-o", obj], check=True)
+    out = os.path.join(workdir, "libxclimhip_hostsim.so")
+    subprocess.run(["g++", "-shared", "-o", out, *objs, obj], check=True)
+    return out
+
+
+class _SimLib:
+    """The simulated entry points with the prototypes of xclim_amd._capi; memory entry points on host buffers (MockDevice's);
+    anything else raises."""
+
+    def __init__(self, path: str):
+        self._dll = C.CDLL(path)
+        self._mock = _MockLib()
+
+    def __getattr__(self, name):
+        if not name.startswith("xh_"):
+            raise AttributeError(name)
+        try:
+            if name in WAVE_ENTRY_POINTS:
+                raise AttributeError(name)
+            fn = getattr(self._dll, name)
+        except AttributeError:
+            if name in _MockLib._SPECIAL or name in ("xh_malloc", "xh_free", "xh_timer_start"):
+                return getattr(self._mock, name)
+            raise NotImplementedError(f"{name}: its kernels use LDS / wave intrinsics and are not simulated on the host") from None
+        fn.argtypes = _capi.SIGNATURES.get(name)
+        fn.restype = _capi._RESTYPES.get(name, C.c_int)
+        setattr(self, name, fn)
+        return fn
+
+
+class SimDevice(MockDevice):
+    def __init__(self, path: str):
+        super().__init__(0)
+        self.lib = _SimLib(path)
+        ctx = C.c_void_p()
+        self.lib._dll.xh_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        assert self.lib._dll.xh_create(0, C.byref(ctx)) == 0
+        self.ctx = ctx
+        self.lock = threading.RLock()
+
+    def sync(self):
+        return None

@@ -1,0 +1,129 @@
+"""Kernel parity WITHOUT a GPU: the translation units of xclim_amd/csrc that use neither LDS nor wave intrinsics (detrend,
+window, runlen, reduce, spell, elemwise: 33 compute entry points) are compiled unchanged with g++ against a stand-in for the
+HIP runtime that runs every kernel thread by thread (tests/hostsim), and the SAME parity tests the GPU runs — the functions of
+tests/test_gpu_kernels.py / test_gpu_spells.py, which compare the entry points and host mirrors with the oracle — are called
+with the simulated device on a subset of their parameters.  This is the CPU tier's view of the kernels' arithmetic and of the
+entry points' dispatch; the `-m gpu` runs remain the parity tests proper (the real kernels on the real device), and the product
+has no CPU path: the simulation library is built into a temporary directory by this module only, and entry points whose
+kernels use LDS or wave intrinsics raise instead of pretending."""
+import numpy as np
+import pytest
+
+from oracle import sdba as osdba
+from xclim_amd import kernels as K
+
+
+@pytest.fixture(scope="module")
+def sim(tmp_path_factory):
+    from tests.hostsim import simdevice
+
+    try:
+        path = simdevice.build(str(tmp_path_factory.mktemp("hostsim")))
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    return simdevice.SimDevice(path)
+
+
+@pytest.fixture(scope="module")
+def tk():
+    import tests.test_gpu_kernels as mod
+
+    return mod
+
+
+def test_unsimulated_entry_points_raise(sim):
+    with pytest.raises(NotImplementedError, match="not simulated"):
+        K.quantile_series(sim, sim.to_device(np.zeros((10, 4), np.float32)), [0.5])
+
+
+@pytest.mark.parametrize("op", [">", "<", ">=", "<=", "==", "!="])
+def test_threshold_count(sim, rng, tk, op):
+    tk.test_threshold_count_scalar(sim, rng, 7, op)
+
+
+def test_threshold_count_other_forms(sim, rng, tk):
+    tk.test_threshold_count_scalar_promotion(sim, rng)
+    tk.test_threshold_count_doy_and_full(sim, rng, 3)      # (the multi-year tile kernel is not simulated: its documented fall-back runs)
+    tk.test_domain_count(sim, rng)
+
+
+@pytest.mark.parametrize("reducer", ["sum", "mean", "min", "max", "std", "var", "count", "argmin", "argmax"])
+def test_resample_reduce(sim, rng, tk, reducer):
+    tk.test_resample_reduce(sim, rng, reducer, 5)
+
+
+@pytest.mark.parametrize("window,center,reducer", [(5, True, "sum"), (3, False, "mean"), (14, True, "max"), (4, True, "min"), (5, True, "std")])
+def test_rolling_reduce(sim, rng, tk, window, center, reducer):
+    tk.test_rolling_reduce(sim, rng, window, center, reducer)
+
+
+@pytest.mark.parametrize("index", ["first", "last"])
+def test_run_length_family(sim, rng, tk, index):
+    tk.test_cumsum_reset_and_rle(sim, rng, index, 0.05)
+    for stat in ("max", "min", "sum", "count", "mean", "std"):
+        tk.test_run_stats_mask(sim, rng, stat, index, True)
+    tk.test_run_stats_mask(sim, rng, "max", index, False)
+    tk.test_windowed_run_count_events(sim, rng, 2, index)
+
+
+def test_boundary_runs_and_fused_threshold(sim, rng, tk):
+    tk.test_first_last_run(sim, rng, 3, True)
+    tk.test_first_last_run(sim, rng, 7, False)
+    tk.test_cdd_fused(sim, rng)
+
+
+def test_detrend_pieces(sim):
+    rng = np.random.default_rng(9)
+    T = 500
+    x = (283 + rng.normal(0, 4, (T, 7)) + 0.01 * np.arange(T)[:, None]).astype(np.float32)
+    x[rng.random(x.shape) < 0.05] = np.nan
+    x[:, 3] = np.nan
+    d = sim.to_device(x)
+    for w in (1, 5, 31):
+        np.testing.assert_allclose(K.window_nanmean(sim, d, w).get(), osdba.window_nanmean(x, w), rtol=3e-7, atol=1e-6, equal_nan=True)
+    p0, p1 = K.poly_trend(sim, d, 1)
+    trend = osdba.poly_trend(x, 1)
+    t = np.arange(T)[:, None] - 0.5 * (T - 1)
+    np.testing.assert_allclose(p0.get()[None, :] + p1.get()[None, :] * t, trend, rtol=1e-9, atol=1e-9, equal_nan=True)
+    detr = K.trend_apply(sim, d, p0, p1, "-").get()
+    np.testing.assert_allclose(detr, (x.astype(np.float64) - trend).astype(np.float32), rtol=1e-6, atol=1e-5, equal_nan=True)
+
+
+@pytest.fixture(scope="module")
+def ts():
+    import tests.test_gpu_spells as mod
+
+    return mod
+
+
+@pytest.mark.parametrize("window,red,op", [(3, "min", ">"), (3, "max", "<="), (4, "sum", ">="), (5, "mean", ">")])
+def test_spell_mask(sim, rng, ts, window, red, op):
+    ts.test_spell_mask(sim, rng, window, red, op, 0.02)
+
+
+def test_spells_and_seasons(sim, rng, ts):
+    ts.test_spell_mask_weights_and_gap(sim, rng)
+    ts.test_spell_length_statistics_general(sim, rng, 3, "min", "max", True)
+    ts.test_spell_length_statistics_general(sim, rng, 2, "max", "sum", False)
+    ts.test_reference_spell_length_statistics_answer(sim)
+    ts.test_runs_with_holes(sim, rng, 2, 3)
+    ts.test_keep_longest_run(sim, rng)
+    ts.test_season(sim, rng, 3, "07-01")
+    ts.test_season(sim, rng, 1, None)
+    ts.test_reference_season_answers(sim)
+    ts.test_date_bounded_runs(sim, rng, 2, "07-01")
+    ts.test_windowed_max_run_sum(sim, rng, 3)
+    ts.test_run_bounds(sim, rng)
+    ts.test_find_events(sim, rng, 2, 1, "MS")
+    ts.test_suspicious_run(sim, rng, 3, ">", None)
+    ts.test_suspicious_run(sim, rng, 1, "==", 2.0)
+
+
+def test_spells_of_two_variables_and_doy_thresholds(sim, rng, ts):
+    ts.test_spell_mask_two_variables(sim, rng, 3, "min", ">=", "all")
+    ts.test_spell_mask_two_variables(sim, rng, 2, "sum", "<=", "any")
+    ts.test_bivariate_spell_length_statistics_and_thresholded_events(sim, rng)
+    ts.test_run_stats_doy_fused(sim, rng, 730, 37, ">")
+    ts.test_run_stats_doy_fused(sim, rng, 1461, 5, "!=")
+    ts.test_spell_length(sim, rng, "max", ">")
+    ts.test_1d_variants_and_season_end(sim, rng)
