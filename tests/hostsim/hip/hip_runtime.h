@@ -34,6 +34,10 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+template <typename F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 
 template <typename K, typename... A>
 static inline void hipLaunchKernelGGL(K kern, dim3 grid, dim3 block, size_t /*lds*/, hipStream_t, A... args) {

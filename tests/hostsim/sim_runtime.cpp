@@ -37,6 +37,14 @@ int xh_launch_tcount_doy(xh_ctx*, const float*, int64_t, int64_t, int64_t, int, 
 
 int xh_launch_doy_stats_sets(xh_ctx*, const float*, int64_t, int64_t, int64_t, const int32_t*, int, int, int, const uint8_t*, float*, float*, int64_t) { return XH_ERR_NOTIMPL; }
 int xh_const_rows(xh_ctx*, int64_t, const float**, const float**, const float**) { return XH_ERR_NOTIMPL; }
+// eqm.hip's quantile dispatch ends in the selection kernels (LDS, wave intrinsics): xh_eqm_train / xh_quantile_series are refused by
+// the simulated device; these only satisfy the linker
+int xh_select_time_major(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
+int xh_select_hist(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
+int xh_select_columns(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) {
+  xh_set_error("host simulation: the selection kernels are not simulated");
+  return XH_ERR_LIMIT;
+}
 
 extern "C" {
 const char* xh_last_error(void) { return g_err; }
@@ -51,4 +59,8 @@ int xh_create(int device, xh_ctx** out) {
 }
 int xh_destroy(xh_ctx* c) { if (c) { free(c->scratch); free(c->big); free(c); } return XH_OK; }
 int xh_sync(xh_ctx*) { return XH_OK; }
+int xh_transpose_f32(xh_ctx*, const float*, int64_t, int64_t, int64_t, float*, int64_t) {
+  xh_set_error("host simulation: xh_transpose_f32 is not simulated");
+  return XH_ERR_LIMIT;
+}
 }

@@ -19,8 +19,11 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from mock_device import MockDevice, _MockLib  # noqa: E402
 from xclim_amd import _capi  # noqa: E402
 
-SIMULATED_UNITS = ("detrend", "window", "runlen", "reduce", "reduce2", "spell", "elemwise")
-WAVE_ENTRY_POINTS = ("xh_doy_mean_std",)   # compiled (reduce2.hip) but its kernel reads through the wave: refused
+SIMULATED_UNITS = ("detrend", "window", "runlen", "reduce", "reduce2", "spell", "elemwise", "eqm")
+# compiled, but their kernels (or the selection kernels behind them) speak to the wave: refused
+WAVE_ENTRY_POINTS = ("xh_doy_mean_std", "xh_eqm_train", "xh_quantile_series", "xh_transpose_f32")
+# eqm.hip votes `__all(m == nq)` only to pick between two forms that are each right for the lane that takes them
+UNIT_DEFINES = {"eqm": ["-D__all(x)=((x)!=0)"]}
 
 
 def build(workdir: str) -> str:
@@ -31,7 +34,7 @@ def build(workdir: str) -> str:
     objs = []
     for unit in SIMULATED_UNITS:
         obj = os.path.join(workdir, unit + ".o")
-        subprocess.run(["g++", "-x", "c++", *flags, "-c", os.path.join(CSRC, unit + ".hip"), "-o", obj], check=True)
+        subprocess.run(["g++", "-x", "c++", *flags, *UNIT_DEFINES.get(unit, []), "-c", os.path.join(CSRC, unit + ".hip"), "-o", obj], check=True)
         objs.append(obj)
     obj = os.path.join(workdir, "sim_runtime.o")
     subprocess.run(["g++", *flags, "-c", os.path.join(HERE, "sim_runtime.cpp"), "-o", obj], check=True)

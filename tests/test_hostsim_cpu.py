@@ -1,5 +1,5 @@
 """Kernel parity WITHOUT a GPU: the translation units of xclim_amd/csrc that use neither LDS nor wave intrinsics (detrend,
-window, runlen, reduce, spell, elemwise: 33 compute entry points) are compiled unchanged with g++ against a stand-in for the
+window, runlen, reduce, reduce2, spell, elemwise, eqm: 40 compute entry points) are compiled unchanged with g++ against a stand-in for the
 HIP runtime that runs every kernel thread by thread (tests/hostsim), and the SAME parity tests the GPU runs — the functions of
 tests/test_gpu_kernels.py / test_gpu_spells.py, which compare the entry points and host mirrors with the oracle — are called
 with the simulated device on a subset of their parameters.  This is the CPU tier's view of the kernels' arithmetic and of the
@@ -127,3 +127,32 @@ def test_spells_of_two_variables_and_doy_thresholds(sim, rng, ts):
     ts.test_run_stats_doy_fused(sim, rng, 1461, 5, "!=")
     ts.test_spell_length(sim, rng, "max", ">")
     ts.test_1d_variants_and_season_end(sim, rng)
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic"])
+def test_eqm_adjust(sim, rng, tk, kind, interp):
+    """E2 of the hot path (xh_eqm_adjust): the node search / interpolation kernels against scipy's interp1d, from the ORACLE's
+    node tables (training ends in the selection kernels, which are not simulated), incl. NaN nodes and NaN samples."""
+    T, C = 400, 40
+    ref, hist = tk._field(rng, T, C), (tk._field(rng, T, C) + 1.5).astype(np.float32)
+    sim_x = (tk._field(rng, T, C, nan_frac=0.01) + 2.0).astype(np.float32)
+    hist[:, 0] = np.nan
+    eaf, ehq = osdba.eqm_train(ref, hist, 20, kind)
+    eaf, ehq = eaf.astype(np.float32), ehq.astype(np.float32)
+    eaf[1, 3] = np.nan
+    ehq[18, 5] = np.nan
+    for extrap in ("constant", "nan"):
+        got = K.eqm_adjust(sim, sim.to_device(sim_x), sim.to_device(eaf), sim.to_device(ehq), kind, interp, extrap).get()
+        exp = osdba.eqm_adjust(sim_x, eaf, ehq, kind, interp, extrap)
+        np.testing.assert_allclose(got, exp, rtol=2e-6 if interp == "cubic" else 1e-6, atol=0, equal_nan=True, err_msg=extrap)
+    with pytest.raises(NotImplementedError, match="not simulated"):
+        K.eqm_train(sim, sim.to_device(ref), sim.to_device(hist), osdba.equally_spaced_nodes(20), kind)
+
+
+def test_apply_factor(sim, rng, tk):
+    """utils.apply_correction on two fields (QDM "cubic": the factor comes out of an interpolation over the ranks)"""
+    x = tk._field(rng, 50, 9)
+    f = rng.normal(1.0, 0.1, (50, 9)).astype(np.float32)
+    np.testing.assert_array_equal(K.apply_factor(sim, sim.to_device(x), sim.to_device(f), "*").get(), x * f)
+    np.testing.assert_array_equal(K.apply_factor(sim, sim.to_device(x), sim.to_device(f), "+").get(), x + f)
