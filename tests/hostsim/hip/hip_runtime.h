@@ -56,6 +56,8 @@ static inline void hipLaunchKernelGGL(K kern, dim3 grid, dim3 block, size_t /*ld
       }
 }
 
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct double2 { double x, y; };
@@ -77,3 +79,8 @@ static inline int __builtin_amdgcn_readfirstlane(int) { abort(); }
 static inline int __builtin_amdgcn_readlane(int, int) { abort(); }
 static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void*, short, int, int) { abort(); }
 static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t, int, int, int) { abort(); }
+
+// plane.hip: the work list is filled by wave-aggregated appends (ballot + one atomic per wave + shuffle).  One thread at a time IS a
+// wave whose only active lane is that thread: the stand-ins below (selected per unit by -D in tests/hostsim/simdevice.py) make the
+// same code append one entry per call; lane-private LDS columns become static arrays.
+static inline unsigned sim_atomic_add(unsigned* p, unsigned v) { const unsigned old = *p; *p = old + v; return old; }

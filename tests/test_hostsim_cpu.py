@@ -1,5 +1,6 @@
 """Kernel parity WITHOUT a GPU: the translation units of xclim_amd/csrc that use neither LDS nor wave intrinsics (detrend,
-window, runlen, reduce, reduce2, spell, elemwise, eqm: 40 compute entry points) are compiled unchanged with g++ against a stand-in for the
+window, runlen, reduce, reduce2, spell, elemwise, eqm — and plane.hip, whose wave-aggregated work-list appends run as waves of one
+lane: 42 compute entry points) are compiled unchanged with g++ against a stand-in for the
 HIP runtime that runs every kernel thread by thread (tests/hostsim), and the SAME parity tests the GPU runs — the functions of
 tests/test_gpu_kernels.py / test_gpu_spells.py, which compare the entry points and host mirrors with the oracle — are called
 with the simulated device on a subset of their parameters.  This is the CPU tier's view of the kernels' arithmetic and of the
@@ -156,3 +157,36 @@ def test_apply_factor(sim, rng, tk):
     f = rng.normal(1.0, 0.1, (50, 9)).astype(np.float32)
     np.testing.assert_array_equal(K.apply_factor(sim, sim.to_device(x), sim.to_device(f), "*").get(), x * f)
     np.testing.assert_array_equal(K.apply_factor(sim, sim.to_device(x), sim.to_device(f), "+").get(), x + f)
+
+
+@pytest.fixture(scope="module")
+def tp():
+    import tests.test_gpu_plane as mod
+
+    return mod
+
+
+@pytest.mark.parametrize("G,nq", [(12, 20), (12, 5), (40, 8), (365, 6)])
+@pytest.mark.parametrize("fractional", [True, False])
+def test_plane_linear_all_routes(sim, rng, tp, G, nq, fractional):
+    """xh_plane_linear through ALL of its kernels — the row kernel (integer coordinates), the pair kernel (fractional ones, <= 20
+    nodes), their work lists and the Delaunay walk — against the real scipy.griddata, for narrow and wide node spacings."""
+    for scale, kind in ((0.05, "t"), (6.0, "t"), (12.0, "p")):
+        tp.test_plane_linear_matches_griddata(sim, rng, G, nq, scale, kind, fractional)
+
+
+def test_plane_linear_special_nodes_and_nearest(sim, rng, tp):
+    tp.test_plane_linear_nan_nodes_and_ties(sim, rng)
+    tp.test_plane_linear_kinds_and_base(sim, rng)
+    # xh_plane_nearest (the row kernel's NEAREST form + the listed neighbours) against griddata "nearest"
+    G, nq, C, T = 12, 9, 4, 300
+    xq = np.sort(rng.gamma(0.7, 12.0, (G, nq, C)), axis=1).astype(np.float32)
+    yq = rng.normal(0, 1, (G, nq, C)).astype(np.float32)
+    x = rng.uniform(0, float(xq.max()) * 1.05, (T, C)).astype(np.float32)
+    x[rng.random((T, C)) < 0.03] = np.nan
+    g = rng.integers(1, G + 1, T).astype(np.float64)
+    for extrap in ("constant", "nan"):
+        got = K.plane_nearest(sim, sim.to_device(x), g, sim.to_device(yq), sim.to_device(xq), "factor", extrap).get()
+        exp = osdba.interp_on_quantiles_2d(x, g, np.arange(1, G + 1), xq, yq, "nearest", extrap)
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        assert (~np.isclose(got, exp, rtol=1e-6, equal_nan=True)).sum() <= 2   # (an exact tie between two rows may go either way)

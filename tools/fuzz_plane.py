@@ -1,7 +1,8 @@
 """Differential fuzzing of xh_plane_linear / xh_plane_nearest (plane.hip) against the oracle's scipy.interpolate.griddata over
 the cyclically padded (quantile, group) node plane: random group counts, node counts, node spacings from a fiftieth of a
 group step to twenty steps, temperature- and precipitation-like node sets, fractional and integer group coordinates,
-queries inside / outside / NaN, NaN nodes.  usage: python tools/fuzz_plane.py [seconds]   (FUZZ_SEED=...)"""
+queries inside / outside / NaN, NaN nodes.  usage: python tools/fuzz_plane.py [seconds]   (FUZZ_SEED=...; FUZZ_DEVICE=hostsim runs
+the same kernels on the CPU simulation of tests/hostsim when there is no GPU)"""
 import json
 import os
 import sys
@@ -14,7 +15,14 @@ from oracle import sdba as osdba  # noqa: E402
 from xclim_amd import kernels as K  # noqa: E402
 from xclim_amd._capi import get_device  # noqa: E402
 
-dev = get_device()
+if os.environ.get("FUZZ_DEVICE") == "hostsim":   # no GPU: the kernels of plane.hip thread by thread on the CPU (tests/hostsim)
+    import tempfile
+
+    from tests.hostsim import simdevice
+
+    dev = simdevice.SimDevice(simdevice.build(tempfile.mkdtemp(prefix="hostsim_")))
+else:
+    dev = get_device()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(os.environ.get("FUZZ_SEED", "777"))
 t_end = time.time() + budget
