@@ -19,13 +19,15 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from mock_device import MockDevice, _MockLib  # noqa: E402
 from xclim_amd import _capi  # noqa: E402
 
-SIMULATED_UNITS = ("detrend", "window", "runlen", "reduce", "reduce2", "spell", "elemwise", "eqm", "plane")
+SIMULATED_UNITS = ("detrend", "window", "runlen", "reduce", "reduce2", "spell", "elemwise", "eqm", "plane", "wquantile")
 # compiled, but their kernels (or the selection kernels behind them) speak to the wave: refused
 WAVE_ENTRY_POINTS = ("xh_doy_mean_std", "xh_eqm_train", "xh_quantile_series", "xh_transpose_f32")
 # eqm.hip votes `__all(m == nq)` only to pick between two forms that are each right for the lane that takes them
 UNIT_DEFINES = {"eqm": ["-D__all(x)=((x)!=0)"],
                 # plane.hip appends to its work lists wave by wave and keeps lane-private LDS columns: see wave_of_one.h
-                "plane": ["-include", os.path.join(HERE, "wave_of_one.h")]}
+                "plane": ["-include", os.path.join(HERE, "wave_of_one.h")],
+                # wquantile.hip's LDS arrays are lane-private columns ([i * 64 + lane]): static arrays do
+                "wquantile": ["-D__shared__=static"]}
 
 
 def build(workdir: str) -> str:

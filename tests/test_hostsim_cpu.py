@@ -190,3 +190,11 @@ def test_plane_linear_special_nodes_and_nearest(sim, rng, tp):
         exp = osdba.interp_on_quantiles_2d(x, g, np.arange(1, G + 1), xq, yq, "nearest", extrap)
         assert np.array_equal(np.isnan(got), np.isnan(exp))
         assert (~np.isclose(got, exp, rtol=1e-6, equal_nan=True)).sum() <= 2   # (an exact tie between two rows may go either way)
+
+
+@pytest.mark.parametrize("R", [3, 40])
+def test_weighted_ensemble_percentiles(sim, rng, R):
+    """xh_weighted_quantile (wquantile.hip: insertion sort in lane-private LDS columns) against the restated xarray estimator."""
+    import tests.test_gpu_api as ta
+
+    ta.test_weighted_ensemble_percentiles(sim, rng, R)
