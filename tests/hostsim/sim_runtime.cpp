@@ -3,11 +3,101 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <sys/mman.h>
+
 #include <vector>
 
+#define SIM_FIBERS 1
 #include "common.h"
 
 thread_local SimIdx blockIdx, threadIdx, gridDim, blockDim;
+
+// ---- SIMT on fibers (simt.h) -------------------------------------------------------------------------------------------------
+thread_local SimBlockState g_sim;
+static constexpr size_t SIM_STACK = (size_t)1 << 20;   // per fiber; reserved, committed on touch
+
+static void sim_trampoline() {
+  g_sim.entry();
+  g_sim.fibers[g_sim.cur].state = 3;
+  swapcontext(&g_sim.fibers[g_sim.cur].ctx, &g_sim.sched);
+}
+
+void sim_run_block(size_t nthreads, const SimIdx& bdim) {
+  if (g_sim.fibers.size() < nthreads) g_sim.fibers.resize(nthreads);
+  if (!g_sim.dyn_lds) g_sim.dyn_lds = (unsigned char*)calloc(1, 160 * 1024);
+  g_sim.slots.assign(((nthreads + 63) / 64) * 64, 0);
+  for (size_t i = 0; i < nthreads; ++i) {
+    SimFiber& f = g_sim.fibers[i];
+    if (!f.stack) {
+      f.stack = (char*)mmap(nullptr, SIM_STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+      if (f.stack == MAP_FAILED) { fprintf(stderr, "host simulation: no stack for fiber %zu\n", i); abort(); }
+    }
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = SIM_STACK;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, sim_trampoline, 0);
+    f.state = 0;
+    f.site = nullptr;
+    f.tid = {(unsigned)(i % bdim.x), (unsigned)((i / bdim.x) % bdim.y), (unsigned)(i / ((size_t)bdim.x * bdim.y))};
+  }
+  const size_t nwaves = (nthreads + 63) / 64;
+  for (;;) {
+    bool ran = false;
+    size_t done = 0;
+    for (size_t i = 0; i < nthreads; ++i) {
+      SimFiber& f = g_sim.fibers[i];
+      if (f.state == 3) { ++done; continue; }
+      if (f.state != 0) continue;
+      g_sim.cur = (int)i;
+      threadIdx = f.tid;
+      swapcontext(&g_sim.sched, &f.ctx);
+      ran = true;
+      if (f.state == 3) ++done;
+    }
+    if (done == nthreads) break;
+    bool released = false;
+    // wave exchanges: all live lanes of a wave at the SAME call
+    for (size_t w = 0; w < nwaves; ++w) {
+      const size_t a = w * 64, b = a + 64 < nthreads ? a + 64 : nthreads;
+      const void* site = nullptr;
+      bool all = true, any = false, mixed = false;
+      for (size_t i = a; i < b; ++i) {
+        const SimFiber& f = g_sim.fibers[i];
+        if (f.state == 3) continue;
+        if (f.state != 2) { all = false; continue; }
+        if (any && f.site != site) mixed = true;
+        site = f.site;
+        any = true;
+      }
+      if (any && all && !mixed) {
+        for (size_t i = a; i < b; ++i)
+          if (g_sim.fibers[i].state == 2) g_sim.fibers[i].state = 0;
+        released = true;
+      } else if (any && all && mixed) {
+        fprintf(stderr, "host simulation: the live lanes of wave %zu wait in different wave exchanges (a collective under divergent "
+                        "control flow): this kernel cannot be simulated on fibers\n", w);
+        abort();
+      }
+    }
+    // workgroup barrier: every live thread arrived
+    bool all_bar = true, any_bar = false;
+    for (size_t i = 0; i < nthreads; ++i) {
+      const int st = g_sim.fibers[i].state;
+      if (st == 3) continue;
+      if (st == 1) any_bar = true; else all_bar = false;
+    }
+    if (any_bar && all_bar) {
+      for (size_t i = 0; i < nthreads; ++i)
+        if (g_sim.fibers[i].state == 1) g_sim.fibers[i].state = 0;
+      released = true;
+    }
+    if (!ran && !released) {
+      fprintf(stderr, "host simulation: deadlock (threads wait at a barrier / exchange that the others never reach)\n");
+      abort();
+    }
+  }
+}
 static char g_err[1024];
 
 void xh_set_error(const char* fmt, ...) {
@@ -31,20 +121,43 @@ int xh_big_scratch(xh_ctx* ctx, size_t bytes, void** dptr) {
   *dptr = ctx->big;
   return XH_OK;
 }
-// kernels with LDS / wave intrinsics are not simulated: the callers' documented fall-backs take over
-int xh_launch_tcount_doy(xh_ctx*, const float*, int64_t, int64_t, int64_t, int, const double*, int64_t, const int32_t*, const int64_t*,
-                         const int64_t*, int, int, int32_t*, int32_t*) { return XH_ERR_NOTIMPL; }
-
-int xh_launch_doy_stats_sets(xh_ctx*, const float*, int64_t, int64_t, int64_t, const int32_t*, int, int, int, const uint8_t*, float*, float*, int64_t) { return XH_ERR_NOTIMPL; }
-int xh_const_rows(xh_ctx*, int64_t, const float**, const float**, const float**) { return XH_ERR_NOTIMPL; }
+int xh_const_rows(xh_ctx* ctx, int64_t elems, const float** nan_row, const float** ninf_row, const float** pinf_row) {
+  const size_t bytes = ((size_t)elems * 4 + 255) & ~(size_t)255;
+  if (bytes > ctx->nanrow_bytes) {
+    free(ctx->nanrow);
+    ctx->nanrow = malloc(3 * bytes);
+    ctx->nanrow_bytes = bytes;
+    float* p = (float*)ctx->nanrow;
+    const size_t n = bytes / 4;
+    for (size_t i = 0; i < n; ++i) { p[i] = NAN; p[n + i] = -INFINITY; p[2 * n + i] = INFINITY; }
+  }
+  const char* p = (const char*)ctx->nanrow;
+  if (nan_row) *nan_row = (const float*)p;
+  if (ninf_row) *ninf_row = (const float*)(p + ctx->nanrow_bytes);
+  if (pinf_row) *pinf_row = (const float*)(p + 2 * ctx->nanrow_bytes);
+  return XH_OK;
+}
 // eqm.hip's quantile dispatch ends in the selection kernels (LDS, wave intrinsics): xh_eqm_train / xh_quantile_series are refused by
 // the simulated device; these only satisfy the linker
-int xh_select_time_major(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
 int xh_select_hist(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
-int xh_select_columns(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) {
-  xh_set_error("host simulation: the selection kernels are not simulated");
+int xh_select_regsort(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
+int xh_select_columns_lean(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
+// the kernels behind these are ISA-level (register sorting networks, DPP, buffer loads with LDS staging ...): every caller treats
+// XH_ERR_NOTIMPL as "not this kernel's shape" and takes its general kernel, which IS simulated
+struct QTab;
+int xh_qdm_hist(xh_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const double*, int, int, int, float*, int64_t) { return XH_ERR_NOTIMPL; }
+int xh_qdm_regsort(xh_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const double*, int, int, int, float*, int64_t) { return XH_ERR_NOTIMPL; }
+int xh_qdm_sorted_ws(int64_t, int64_t, size_t* bytes) { *bytes = 0; return XH_ERR_NOTIMPL; }
+int xh_qdm_sorted(xh_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const double*, int, int, int, int, float*, int64_t, void*) {
+  xh_set_error("host simulation: the global-sort rank kernels (rocPRIM) are not simulated");
   return XH_ERR_LIMIT;
 }
+int xh_launch_pdoy_walk(xh_ctx*, const float*, int64_t, int64_t, int64_t, const int32_t*, int, int, int, const QTab*, const int32_t*, int, double*,
+                        const int32_t*, int64_t, const uint8_t*) { return XH_ERR_NOTIMPL; }
+int xh_launch_pdoy_top16(xh_ctx*, const float*, int64_t, int64_t, int64_t, const int32_t*, int, int, int, const QTab*, const int32_t*, int, int, double*,
+                         const int32_t*, int64_t, const uint8_t*) { return XH_ERR_NOTIMPL; }
+int xh_launch_pdoy_top16_count(xh_ctx*, const float*, int64_t, int64_t, int64_t, const int32_t*, int, int, int, const QTab*, const int32_t*, int,
+                               const uint8_t*, int, const int32_t*, int32_t*, int32_t*, const uint8_t*) { return XH_ERR_NOTIMPL; }
 
 extern "C" {
 const char* xh_last_error(void) { return g_err; }
@@ -59,8 +172,4 @@ int xh_create(int device, xh_ctx** out) {
 }
 int xh_destroy(xh_ctx* c) { if (c) { free(c->scratch); free(c->big); free(c); } return XH_OK; }
 int xh_sync(xh_ctx*) { return XH_OK; }
-int xh_transpose_f32(xh_ctx*, const float*, int64_t, int64_t, int64_t, float*, int64_t) {
-  xh_set_error("host simulation: xh_transpose_f32 is not simulated");
-  return XH_ERR_LIMIT;
-}
 }

@@ -4,6 +4,7 @@ tier only — it pins kernel arithmetic and entry-point dispatch against the ora
 that are not simulated raise (never a silent no-op), and nothing of this is reachable from the product package."""
 import ctypes as C
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -21,7 +22,7 @@ from xclim_amd import _capi  # noqa: E402
 
 SIMULATED_UNITS = ("detrend", "window", "runlen", "reduce", "reduce2", "spell", "elemwise", "eqm", "plane", "wquantile")
 # compiled, but their kernels (or the selection kernels behind them) speak to the wave: refused
-WAVE_ENTRY_POINTS = ("xh_doy_mean_std", "xh_eqm_train", "xh_quantile_series", "xh_transpose_f32")
+WAVE_ENTRY_POINTS = ("xh_doy_mean_std",)
 # eqm.hip votes `__all(m == nq)` only to pick between two forms that are each right for the lane that takes them
 UNIT_DEFINES = {"eqm": ["-D__all(x)=((x)!=0)"],
                 # plane.hip appends to its work lists wave by wave and keeps lane-private LDS columns: see wave_of_one.h
@@ -30,15 +31,35 @@ UNIT_DEFINES = {"eqm": ["-D__all(x)=((x)!=0)"],
                 "wquantile": ["-D__shared__=static"]}
 
 
+# units whose kernels talk through LDS / the wave in WAVE-UNIFORM control flow: every workgroup as a set of fibers (simt.h)
+FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core")   # (select2.hip counts through the wave in ISA asm: not simulated)
+_DYN_LDS = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([\w ]+?)\s+(\w+)\[\];")
+
+
 def build(workdir: str) -> str:
-    """g++ the simulated translation units (unchanged sources) + sim_runtime.cpp into workdir/libxclimhip_hostsim.so."""
+    """g++ the simulated translation units (sources unchanged, except that an `extern __shared__ T name[];` of a fiber unit
+    becomes a pointer to the workgroup's LDS buffer) + sim_runtime.cpp into workdir/libxclimhip_hostsim.so."""
     if shutil.which("g++") is None:
         raise RuntimeError("no g++")
     flags = ["-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC]
     objs = []
-    for unit in SIMULATED_UNITS:
+    for unit in SIMULATED_UNITS + FIBER_UNITS:
         obj = os.path.join(workdir, unit + ".o")
-        subprocess.run(["g++", "-x", "c++", *flags, *UNIT_DEFINES.get(unit, []), "-c", os.path.join(CSRC, unit + ".hip"), "-o", obj], check=True)
+        src = os.path.join(CSRC, unit + ".hip")
+        extra = list(UNIT_DEFINES.get(unit, []))
+        if unit in FIBER_UNITS:
+            text = open(src).read()
+            if unit == "core":   # the runtime half of core.hip is sim_runtime.cpp's job: only its kernels (synthetic fields, transposes)
+                text = '#include "common.h"\n' + text[text.index("// ---- synthetic generator"):]
+            text = _DYN_LDS.sub(lambda m: f"{m.group(1)}* {m.group(2)} = ({m.group(1)}*)sim_dynamic_lds();", text)
+            # the LDS-only workgroup barrier (s_waitcnt lgkmcnt(0); s_barrier) is a workgroup barrier; empty asm statements are
+            # compiler fences whose operand class "v" / "s" (a VGPR / SGPR) becomes "r"
+            text = text.replace('asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory")', "__syncthreads()")
+            text = re.sub(r'asm volatile\(""\s*:\s*"\+[vs]"', 'asm volatile("" : "+r"', text)
+            src = os.path.join(workdir, unit + ".sim.cpp")
+            open(src, "w").write(text)
+            extra += ["-DSIM_FIBERS=1", "-D__shared__=static"]
+        subprocess.run(["g++", "-x", "c++", *flags, *extra, "-c", src, "-o", obj], check=True)
         objs.append(obj)
     obj = os.path.join(workdir, "sim_runtime.o")
     subprocess.run(["g++", *flags, "-c", os.path.join(HERE, "sim_runtime.cpp"), "-o", obj], check=True)

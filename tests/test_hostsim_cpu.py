@@ -1,12 +1,17 @@
-"""Kernel parity WITHOUT a GPU: the translation units of xclim_amd/csrc that use neither LDS nor wave intrinsics (detrend,
-window, runlen, reduce, reduce2, spell, elemwise, eqm — and plane.hip, whose wave-aggregated work-list appends run as waves of one
-lane: 42 compute entry points) are compiled unchanged with g++ against a stand-in for the
-HIP runtime that runs every kernel thread by thread (tests/hostsim), and the SAME parity tests the GPU runs — the functions of
-tests/test_gpu_kernels.py / test_gpu_spells.py, which compare the entry points and host mirrors with the oracle — are called
-with the simulated device on a subset of their parameters.  This is the CPU tier's view of the kernels' arithmetic and of the
-entry points' dispatch; the `-m gpu` runs remain the parity tests proper (the real kernels on the real device), and the product
-has no CPU path: the simulation library is built into a temporary directory by this module only, and entry points whose
-kernels use LDS or wave intrinsics raise instead of pretending."""
+"""Kernel parity WITHOUT a GPU (tests/hostsim — test infrastructure only).  The translation units of xclim_amd/csrc are compiled
+with g++ against a stand-in for the HIP runtime and run on the CPU:
+  * thread by thread — detrend, window, runlen, reduce, reduce2, spell, elemwise, eqm, wquantile (no LDS traffic between threads),
+    and plane.hip with its wave-aggregated work-list appends as waves of one lane;
+  * every workgroup as a set of FIBERS (simt.h: __syncthreads, wave-uniform shuffles / votes / readlane, atomics) — f64, select,
+    select5, tcount, qdm, quantile, doystats and the kernels of core.hip (transposes, synthetic fields).
+63 of the 93 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
+other 30 are runtime services (memory, streams, RCCL).  The kernels written at ISA level (register sorting networks, DPP, the
+streaming selection of select4.hip, the register top-16 percentile kernels) are NOT simulated: their launchers answer "not this
+kernel's shape" and the callers' general kernels run — exactly the fall-back the product takes for shapes those kernels decline.
+The SAME parity tests the GPU runs (the functions of tests/test_gpu_kernels.py, test_gpu_spells.py, test_gpu_plane.py, ...) are
+called with the simulated device on a subset of their parameters.  The `-m gpu` runs remain the parity tests proper (the real
+kernels on the real device, the ISA-level ones included); the product has no CPU path: the simulation library is built into a
+temporary directory by this module only, and what is not simulated raises instead of pretending."""
 import numpy as np
 import pytest
 
@@ -34,7 +39,7 @@ def tk():
 
 def test_unsimulated_entry_points_raise(sim):
     with pytest.raises(NotImplementedError, match="not simulated"):
-        K.quantile_series(sim, sim.to_device(np.zeros((10, 4), np.float32)), [0.5])
+        K.doy_mean_std(sim, sim.to_device(np.zeros((730, 4), np.float32)), np.arange(730, dtype=np.int32).reshape(2, 365), 5)
 
 
 @pytest.mark.parametrize("op", [">", "<", ">=", "<=", "==", "!="])
@@ -134,7 +139,7 @@ def test_spells_of_two_variables_and_doy_thresholds(sim, rng, ts):
 @pytest.mark.parametrize("interp", ["nearest", "linear", "cubic"])
 def test_eqm_adjust(sim, rng, tk, kind, interp):
     """E2 of the hot path (xh_eqm_adjust): the node search / interpolation kernels against scipy's interp1d, from the ORACLE's
-    node tables (training ends in the selection kernels, which are not simulated), incl. NaN nodes and NaN samples."""
+    node tables, incl. NaN nodes and NaN samples."""
     T, C = 400, 40
     ref, hist = tk._field(rng, T, C), (tk._field(rng, T, C) + 1.5).astype(np.float32)
     sim_x = (tk._field(rng, T, C, nan_frac=0.01) + 2.0).astype(np.float32)
@@ -147,8 +152,6 @@ def test_eqm_adjust(sim, rng, tk, kind, interp):
         got = K.eqm_adjust(sim, sim.to_device(sim_x), sim.to_device(eaf), sim.to_device(ehq), kind, interp, extrap).get()
         exp = osdba.eqm_adjust(sim_x, eaf, ehq, kind, interp, extrap)
         np.testing.assert_allclose(got, exp, rtol=2e-6 if interp == "cubic" else 1e-6, atol=0, equal_nan=True, err_msg=extrap)
-    with pytest.raises(NotImplementedError, match="not simulated"):
-        K.eqm_train(sim, sim.to_device(ref), sim.to_device(hist), osdba.equally_spaced_nodes(20), kind)
 
 
 def test_apply_factor(sim, rng, tk):
@@ -198,3 +201,86 @@ def test_weighted_ensemble_percentiles(sim, rng, R):
     import tests.test_gpu_api as ta
 
     ta.test_weighted_ensemble_percentiles(sim, rng, R)
+
+
+# ---- kernels that talk through LDS and the wave, on fibers (tests/hostsim/simt.h) --------------------------------------------------
+@pytest.fixture(scope="module")
+def tf():
+    import tests.test_gpu_f64 as mod
+
+    return mod
+
+
+@pytest.mark.parametrize("N", [1, 7, 150, 930])
+def test_float64_quantiles_on_fibers(sim, rng, tf, N):
+    """xh_nan_quantile_f64 (f64.hip: a workgroup per column, LDS, __syncthreads, __shfl_xor) — every thread a fiber."""
+    tf.test_calc_perc_float64_vs_oracle(sim, rng, N)
+
+
+def test_float64_counts_and_reductions(sim, rng, tf):
+    tf.test_calc_perc_float64_matches_the_reference_bitwise(sim)
+    tf.test_threshold_count_float64_counts_exactly(sim, rng)
+    tf.test_select_resample_op_float64(sim, rng)
+
+
+@pytest.fixture(scope="module")
+def tapi():
+    import tests.test_gpu_api as mod
+
+    return mod
+
+
+@pytest.mark.parametrize("T,C", [(40, 7), (365, 100), (1000, 33), (5000, 6)])
+def test_quantile_series_on_fibers(sim, rng, tk, T, C):
+    """xh_quantile_series (E1): 8-lane groups on time-major rows (T <= 512), transposes + one wave per column with the column in
+    LDS (<= 1024), 1024-thread workgroups beyond (the register-sort, two-pass-histogram and lean kernels are ISA-level: their
+    callers' general kernels run instead)."""
+    tk.test_quantile_series(sim, rng, T, C)
+
+
+def test_quantile_series_hard_distributions_on_fibers(sim, rng, tk):
+    for T in (40, 365, 600):
+        for kind in ("pr", "pr_skewed", "two_values", "negative_floor", "clustered", "constant", "nan_heavy"):
+            tk.test_quantile_series_hard_distributions(sim, rng, T, kind)
+    tk.test_quantile_series_beyond_32768_steps(sim, rng, 40000)        # the radix select of select5.hip
+
+
+@pytest.mark.parametrize("kind,interp,extrap", [("+", "nearest", "constant"), ("*", "linear", "nan")])
+def test_eqm_train_and_adjust_on_fibers(sim, rng, tk, kind, interp, extrap):
+    tk.test_eqm_train_adjust(sim, rng, kind, interp, extrap)
+    tk.test_eqm_precipitation_tied_nodes(sim, rng, kind, interp, extrap)
+
+
+def test_percentiles_on_fibers(sim, rng, tk):
+    """calc_perc (xh_nan_quantile: register bitonic, lane-private LDS columns), percentile_doy on one year (sliding window) and on
+    three (sorted day-set lists in an LDS ring), through a virtual time map, the 366-day re-gridding, +-inf samples."""
+    for N, C in ((1, 10), (2, 10), (5, 300), (13, 70), (30, 129), (150, 200), (365, 40)):
+        tk.test_nan_quantile(sim, rng, N, C, (1.0, 1.0))
+    tk.test_nan_quantile(sim, rng, 600, 70, (1 / 3, 1 / 3))
+    tk.test_percentile_doy(sim, rng, 1, 5, 260, "noleap")
+    tk.test_percentile_doy(sim, rng, 3, 5, 33, "standard")
+    tk.test_percentile_doy_virtual_time_map(sim, rng, 4)
+    tk.test_doy_interp(sim, rng)
+    tk.test_infinities_follow_the_nanmax_rule(sim, rng)
+
+
+def test_threshold_count_doy_tile_kernel_on_fibers(sim, rng, tk):
+    """xh_threshold_count_doy on multi-year series: the LDS tile kernel of tcount.hip (the 30-year tx90p count of the headline)."""
+    tk.test_threshold_count_doy_multi_year_tile_kernel(sim, rng, ">", 200, "YS")
+    tk.test_threshold_count_doy_multi_year_tile_kernel(sim, rng, "<=", 64, "MS")
+    tk.test_threshold_count_doy_tile_kernel_empty_periods_and_narrow_counters(sim, rng)
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic"])
+def test_qdm_adjust_on_fibers(sim, rng, tapi, kind, interp):
+    """QuantileDeltaMapping.adjust through the exact-rank kernel (qdm.hip: a column per workgroup, average ranks through LDS); the
+    one-year cut-value kernel and the streaming kernels are ISA-level and decline in the simulation."""
+    for T, cells in ((365, (7, 9)), (800, (33,)), (50, (4, 4)), (1, (3,))):
+        tapi.test_qdm_adjust_matches_oracle(sim, rng, kind, interp, T, cells)
+
+
+def test_synthetic_fields_and_transposes_on_fibers(sim, rng, tk):
+    tk.test_synthetic_matches_oracle(sim)
+    for shape in ((130, 77), (128, 128), (300, 388), (257, 260), (5, 4), (8, 4)):
+        tk.test_transpose(sim, rng, shape)
