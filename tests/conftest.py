@@ -14,8 +14,17 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def dev():
-    """The HIP context.  GPU tests must FAIL (not skip) when the library or the device is missing."""
+def dev(tmp_path_factory):
+    """The HIP context.  GPU tests must FAIL (not skip) when the library or the device is missing.
+
+    XH_TEST_DEVICE=hostsim (an AUDIT switch, never the default): the `-m gpu` tests run against the host simulation of
+    tests/hostsim instead — `XH_TEST_DEVICE=hostsim pytest -m gpu -n 8 --timeout 300 --deselect tests/test_gpu_fullsize.py`
+    shows which of them the simulation can serve (kernels written at ISA level decline there; a collective under divergent
+    control flow aborts the worker)."""
+    if os.environ.get("XH_TEST_DEVICE") == "hostsim":
+        from tests.hostsim import simdevice
+
+        return simdevice.SimDevice(simdevice.build(str(tmp_path_factory.mktemp("hostsim"))))
     from xclim_amd._capi import get_device
 
     return get_device(0)

@@ -88,7 +88,7 @@ class Grouper:
         R = int(np.prod(cell_shape[:k]))
         cells = tuple(cell_shape[k:])
         C_ = int(np.prod(cells)) if cells else 1
-        return dev.wrap(x.ptr, (x.shape[0] * R, C_), np.float32), R, cells
+        return x.reshape(x.shape[0] * R, C_), R, cells   # (a view that keeps its parent alive: the caller drops `x`)
 
     def group_samples(self, dev, fields, time, R: int = 1):
         """For every group (in label order) the training sample of each field of ``fields`` ((T * R, C) device matrices) as a
