@@ -16,17 +16,18 @@ import warnings
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import calendar as ocal  # noqa: E402
 from oracle import quantile as oq  # noqa: E402
 from oracle import sdba as osdba  # noqa: E402
 from oracle.timeutil import OTime  # noqa: E402
 from xclim_amd import kernels as K  # noqa: E402
-from xclim_amd._capi import get_device  # noqa: E402
+from fuzzdev import get_fuzz_device  # noqa: E402
 from xclim_amd.timeaxis import TimeAxis  # noqa: E402
 
 warnings.simplefilter("ignore")
 np.seterr(all="ignore")
-dev = get_device()
+dev = get_fuzz_device()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "777")))
 stats = {"nan_quantile": 0, "quantile_series": 0, "percentile_doy": 0, "eqm": 0, "qdm": 0}
@@ -95,7 +96,15 @@ while time.time() < t_end:
         tb, years, doys = ta.doy_table()
         w = int(rng.choice([3, 5, 5, 7]))
         per = sorted(float(v) for v in rng.choice([1.0, 5.0, 10.0, 50.0, 90.0, 95.0, 99.0], size=int(rng.integers(1, 3)), replace=False))
-        got = K.percentile_doy(dev, dev.to_device(x), tb, w, per).get()
+        try:
+            got = K.percentile_doy(dev, dev.to_device(x), tb, w, per).get()
+        except Exception as e:  # noqa: BLE001
+            # (FUZZ_DEVICE=hostsim: extreme percentiles of a multi-year period belong to the register top-16 kernels, which
+            #  are ISA-level and have no general kernel behind them: not simulated)
+            if os.environ.get("FUZZ_DEVICE") == "hostsim" and getattr(e, "code", None) == -5:
+                stats["not_simulated"] = stats.get("not_simulated", 0) + 1
+                continue
+            raise
         rr = ocal.rolling_construct_center(x, w)
         stack = np.full((len(doys), len(years), C, w), np.nan, dtype=np.float32)
         stack[np.searchsorted(doys, ot.doy), np.searchsorted(years, ot.year)] = rr

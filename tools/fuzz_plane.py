@@ -15,14 +15,10 @@ from oracle import sdba as osdba  # noqa: E402
 from xclim_amd import kernels as K  # noqa: E402
 from xclim_amd._capi import get_device  # noqa: E402
 
-if os.environ.get("FUZZ_DEVICE") == "hostsim":   # no GPU: the kernels of plane.hip thread by thread on the CPU (tests/hostsim)
-    import tempfile
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fuzzdev import get_fuzz_device  # noqa: E402
 
-    from tests.hostsim import simdevice
-
-    dev = simdevice.SimDevice(simdevice.build(tempfile.mkdtemp(prefix="hostsim_")))
-else:
-    dev = get_device()
+dev = get_fuzz_device()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(os.environ.get("FUZZ_SEED", "777"))
 t_end = time.time() + budget
