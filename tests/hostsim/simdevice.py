@@ -42,6 +42,11 @@ def build(workdir: str) -> str:
     if shutil.which("g++") is None:
         raise RuntimeError("no g++")
     flags = ["-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC]
+    # HOSTSIM_SANITIZE=undefined (or address,undefined with LD_PRELOAD=libasan.so): an audit build of the kernels under the
+    # compiler's sanitizers — out-of-bounds LDS / scratch accesses, shifts, signed overflow
+    san = os.environ.get("HOSTSIM_SANITIZE")
+    if san:
+        flags += ["-g", f"-fsanitize={san}", "-fno-sanitize-recover=all" if os.environ.get("HOSTSIM_SANITIZE_FATAL") else "-fsanitize-recover=all"]
     objs = []
     for unit in SIMULATED_UNITS + FIBER_UNITS:
         obj = os.path.join(workdir, unit + ".o")
@@ -64,7 +69,7 @@ def build(workdir: str) -> str:
     obj = os.path.join(workdir, "sim_runtime.o")
     subprocess.run(["g++", *flags, "-c", os.path.join(HERE, "sim_runtime.cpp"), "-o", obj], check=True)
     out = os.path.join(workdir, "libxclimhip_hostsim.so")
-    subprocess.run(["g++", "-shared", "-o", out, *objs, obj], check=True)
+    subprocess.run(["g++", "-shared", *([f"-fsanitize={san}"] if san else []), "-o", out, *objs, obj], check=True)
     return out
 
 
