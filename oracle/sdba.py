@@ -415,6 +415,27 @@ def dqm_adjust(sim, af, hist_q, scaling, kind="+", interp="nearest", extrapolati
     return _corr(scen0, trend, kind)
 
 
+def dqm_adjust_members(sim, af, hist_q, scaling, kind="+", interp="nearest", extrapolation="constant", detrend=1, pooled=True):
+    """dqm_adjust for a sim with a member axis behind time ((T, R, *cells)); af / hist_q / scaling have none.  pooled=True — the model
+    was trained with Grouper(add_dims=[member]): PolyDetrend(group=that grouper) fits ONE trend on the mean over the members
+    (_polydetrend_get_trend: ``if len(dim) > 1: da = da.mean(dim[1:])``) and every member is detrended with it; pooled=False: the
+    member axis is an ordinary one, every series has its own trend."""
+    sim = np.asarray(sim)
+    scaled = _corr(sim, np.asarray(scaling)[None, None], kind)
+    if pooled:
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mean = np.nanmean(scaled.astype(np.float64), axis=1).astype(np.float32)
+        trend = np.broadcast_to(poly_trend(mean, detrend)[:, None], sim.shape)
+    else:
+        trend = poly_trend(scaled, detrend)
+    detr = _corr(scaled, trend, kind, True)
+    scen0 = np.stack([eqm_adjust(detr[:, r], af, hist_q, kind, interp, extrapolation) for r in range(sim.shape[1])], axis=1)
+    return _corr(scen0, trend, kind)
+
+
 def poly_trend_u(x, u, degree):
     """The same on an explicit coordinate `u` (one value per row): DataArray.polyfit over the time coordinate of a
     group's steps; evaluated at the same rows."""

@@ -1470,8 +1470,24 @@ def test_grouper_add_dims_pools_the_members(dev, rng, kind, group, window):
         np.testing.assert_array_equal(mdl.adjust(sim[:, 1], time=ta), got[:, 1])
     with pytest.raises(NotImplementedError):
         xsdba.Grouper("time.month", add_dims=2)            # not the axis right behind time
-    with pytest.raises(NotImplementedError):
-        xsdba.DetrendedQuantileMapping.train(ref, hist, group=grp, time=ta, device=dev)
+    # DetrendedQuantileMapping with the pooled members: group="time" (the trend is fitted on the member mean), refused for sub-groupings
+    if prop == "group":
+        dqm = xsdba.DetrendedQuantileMapping.train(ref, hist, nquantiles=12, kind=kind, group=grp, device=dev)
+        eaf, ehq, escal = osdba.dqm_train(ref.reshape((-1,) + ref.shape[2:]), hist.reshape((-1,) + hist.shape[2:]), q, kind)
+        np.testing.assert_allclose(dqm.scaling, escal, rtol=1e-6)
+        np.testing.assert_allclose(dqm.hist_q, ehq, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(dqm.af, eaf, rtol=1e-5, atol=1e-5)
+        for deg in (0, 1):
+            got = dqm.adjust(sim, detrend=deg)
+            exp = osdba.dqm_adjust_members(sim, dqm.af, dqm.hist_q, dqm.scaling, kind, "nearest", "constant", deg, pooled=True)
+            np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5, equal_nan=True, err_msg=f"detrend {deg}")
+        plain = xsdba.DetrendedQuantileMapping.train(ref[:, 0], hist[:, 0], nquantiles=12, kind=kind, device=dev)
+        got = plain.adjust(sim, interp="linear")      # an ordinary extra axis: every series keeps its own trend
+        exp = osdba.dqm_adjust_members(sim, plain.af, plain.hist_q, plain.scaling, kind, "linear", "constant", 1, pooled=False)
+        np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5, equal_nan=True)
+    else:
+        with pytest.raises(NotImplementedError):
+            xsdba.DetrendedQuantileMapping.train(ref, hist, group=grp, time=ta, device=dev)
 
 
 @pytest.mark.parametrize("T", [1, 2, 700, 40000])

@@ -28,7 +28,8 @@ trained like EQM; ``adjust`` looks the factor up at the QUANTILE of every sim va
 (``rank(sim, pct=True)``), so that the simulated change of every quantile is preserved — ``xh_qdm_adjust`` ranks each column
 exactly (average ranks, NaN skipped) and interpolates in fp64 ("nearest", "linear"; "cubic" for ``group="time"``: the
 not-a-knot spline of the EQM path over the quantile nodes).  :class:`DetrendedQuantileMapping`: ``group="time"`` or a
-sub-grouping, with or without a window (with one, the trend is fitted on the centred window mean: ``xh_window_nanmean``);
+sub-grouping, with or without a window (with one, the trend is fitted on the centred window mean: ``xh_window_nanmean``),
+``Grouper("time", add_dims=...)`` (one trend, fitted on the mean over the pooled members);
 with "linear" and a month grouping the scaling is interpolated over the group coordinate like xsdba's ``u.broadcast`` does.
 
 PARITY UNPINNED like everything xsdba (oracle/sdba.py).
@@ -594,9 +595,8 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
     @classmethod
     def train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", window=None, time=None, device=None):
         grp = group if isinstance(group, Grouper) else Grouper(group, 1 if window is None else window)
-        if grp.add_dims:
-            # (PolyDetrend then fits ONE trend on the mean over the pooled members — _polydetrend_get_trend: da.mean(dim[1:]))
-            raise NotImplementedError("DetrendedQuantileMapping with Grouper(add_dims=...) is not built")
+        if grp.add_dims and grp.prop != "group":
+            raise NotImplementedError("DetrendedQuantileMapping with Grouper(add_dims=...) is built for group='time' only")
         if kind not in (ADDITIVE, MULTIPLICATIVE):
             raise ValueError(f"kind must be '+' or '*', got {kind!r}")
         dev = device or get_device()
@@ -606,6 +606,9 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             raise ValueError("ref and hist must have the same shape")
         q = equally_spaced_nodes(nquantiles) if np.isscalar(nquantiles) else np.asarray(nquantiles, dtype=np.float64)
         inv = "-" if kind == ADDITIVE else "/"
+        # Grouper(add_dims=...): means and quantiles over the time steps AND the members (ds.ref.mean(dim), dim = [time, *add_dims])
+        r, _, cell_shape = grp.pool(dev, r, cell_shape)
+        h, _, _ = grp.pool(dev, h, cell_shape_h)
 
         def one(rg, hg, out=None):
             mu_r, _ = K.poly_trend(dev, rg, 0)
@@ -646,9 +649,13 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             raise NotImplementedError("DetrendedQuantileMapping.adjust: detrend must be 0 or 1 (polynomial degree)")
         dev = self._dev
         s, cell_shape = _flatten(sim, dev)
+        fwd, inv = ("+", "-") if self.kind == ADDITIVE else ("*", "/")
+        n = len(self.cell_shape)
+        if tuple(cell_shape) != self.cell_shape and self.group.prop == "group" and len(cell_shape) > n and \
+                (n == 0 or tuple(cell_shape[len(cell_shape) - n:]) == self.cell_shape):
+            return self._adjust_members(s, tuple(cell_shape[:len(cell_shape) - n]), interp, extrapolation, detrend, keep, fwd, inv)
         if tuple(cell_shape) != self.cell_shape:
             raise ValueError("sim does not match the trained grid")
-        fwd, inv = ("+", "-") if self.kind == ADDITIVE else ("*", "/")
         if self.group.prop != "group":
             return self._adjust_grouped(s, interp, extrapolation, detrend, time, keep, fwd, inv, grouped_nearest)
         scaled = K.trend_apply(dev, s, self._scaling, None, fwd)
@@ -658,6 +665,37 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         scen0 = K.eqm_adjust(dev, detr, self._af, self._hist_q, self.kind, interp, extrapolation)
         scen = K.trend_apply(dev, scen0, p0, p1, fwd, out=detr)  # (distinct buffers: the kernels' pointers are __restrict__)
         return scen if keep else scen.get().reshape((s.shape[0],) + self.cell_shape)
+
+    def _adjust_members(self, s, extra, interp, extrapolation, detrend, keep, fwd, inv):
+        """group="time", a sim with member axes right behind time ((T, members x cells) here).  Every member is scaled and mapped
+        with the same tables (repeated per member).  The trend: a model trained with ``Grouper(add_dims=...)`` detrends with
+        ``PolyDetrend(group=that grouper)``, which fits ONE polynomial on the mean over the pooled members
+        (``_polydetrend_get_trend``: ``da.mean(dim[1:])`` ahead of polyfit) and removes it from every member; without
+        ``add_dims`` the extra axes are ordinary ones and every series has its own trend."""
+        dev = self._dev
+        T = s.shape[0]
+        E, C_ = int(np.prod(extra)), int(np.prod(self.cell_shape)) if self.cell_shape else 1
+
+        def tile64(a):   # (C,) float64 table -> (E * C,)
+            return dev.to_device(np.tile(a.get().reshape(-1), E), dtype=np.float64)
+
+        def tile32(tab):  # (nq, C) -> (nq, E * C)
+            lead = tab.shape[0]
+            return K.select_rows(dev, tab.reshape(lead, C_), np.repeat(np.arange(lead), E)).reshape(lead, E * C_)
+
+        scaled = K.trend_apply(dev, s, tile64(self._scaling), None, fwd)
+        if self.group.add_dims:
+            # the mean over the members of every step: the (T, E x C) matrix is (T x E, C) with E rows per step
+            mean, _ = K.resample_reduce(dev, scaled.reshape(T * E, C_), "mean", np.arange(0, T * E + 1, E, dtype=np.int64), want_valid=False)
+            p0, p1 = K.poly_trend(dev, mean, detrend)
+            p0, p1 = tile64(p0), (tile64(p1) if p1 is not None else None)
+        else:
+            p0, p1 = K.poly_trend(dev, scaled, detrend)
+        detr = K.trend_apply(dev, scaled, p0, p1, inv)
+        del scaled
+        scen0 = K.eqm_adjust(dev, detr, tile32(self._af), tile32(self._hist_q), self.kind, interp, extrapolation)
+        scen = K.trend_apply(dev, scen0, p0, p1, fwd, out=detr)
+        return scen if keep else scen.get().reshape((T,) + tuple(extra) + self.cell_shape)
 
     def _adjust_grouped(self, s, interp, extrapolation, detrend, time, keep, fwd, inv, grouped_nearest="griddata"):
         """dqm_adjust with a sub-grouping: group-major row blocks like the grouped EQM; per block the group's
