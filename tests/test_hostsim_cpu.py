@@ -23,10 +23,12 @@ from xclim_amd import kernels as K
 def sim(tmp_path_factory):
     from tests.hostsim import simdevice
 
+    import subprocess
+
     try:
         path = simdevice.build(str(tmp_path_factory.mktemp("hostsim")))
-    except RuntimeError as e:
-        pytest.skip(str(e))
+    except (RuntimeError, subprocess.CalledProcessError) as e:   # (no g++ / a g++ that does not take the stand-in: not a product failure)
+        pytest.skip(f"host simulation not built here: {e}")
     return simdevice.SimDevice(path)
 
 
