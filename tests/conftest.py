@@ -24,7 +24,8 @@ def dev(tmp_path_factory):
     if os.environ.get("XH_TEST_DEVICE") == "hostsim":
         from tests.hostsim import simdevice
 
-        return simdevice.SimDevice(simdevice.build(str(tmp_path_factory.mktemp("hostsim"))))
+        lib = os.environ.get("HOSTSIM_LIB")   # (a library some caller built already: tests/test_hostsim_cpu.py)
+        return simdevice.SimDevice(lib if lib and os.path.exists(lib) else simdevice.build(str(tmp_path_factory.mktemp("hostsim"))))
     from xclim_amd._capi import get_device
 
     return get_device(0)

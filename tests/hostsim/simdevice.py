@@ -101,6 +101,7 @@ class _SimLib:
 class SimDevice(MockDevice):
     def __init__(self, path: str):
         super().__init__(0)
+        self.path = path
         self.lib = _SimLib(path)
         ctx = C.c_void_p()
         self.lib._dll.xh_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]

@@ -8,8 +8,9 @@ with g++ against a stand-in for the HIP runtime and run on the CPU:
 other 30 are runtime services (memory, streams, RCCL).  The kernels written at ISA level (register sorting networks, DPP, the
 streaming selection of select4.hip, the register top-16 percentile kernels) are NOT simulated: their launchers answer "not this
 kernel's shape" and the callers' general kernels run — exactly the fall-back the product takes for shapes those kernels decline.
-The SAME parity tests the GPU runs (the functions of tests/test_gpu_kernels.py, test_gpu_spells.py, test_gpu_plane.py, ...) are
-called with the simulated device on a subset of their parameters.  The `-m gpu` runs remain the parity tests proper (the real
+The SAME parity tests the GPU runs are re-run here: whole modules of the `-m gpu` suite (edges, patch, api, spells, f64, kernels,
+plane: ~740 tests, minus what forces or needs an ISA-level kernel) in two child pytest runs against the simulation library, plus a
+few direct calls.  The `-m gpu` runs remain the parity tests proper (the real
 kernels on the real device, the ISA-level ones included); the product has no CPU path: the simulation library is built into a
 temporary directory by this module only, and what is not simulated raises instead of pretending."""
 import numpy as np
@@ -44,42 +45,6 @@ def test_unsimulated_entry_points_raise(sim):
         K.doy_mean_std(sim, sim.to_device(np.zeros((730, 4), np.float32)), np.arange(730, dtype=np.int32).reshape(2, 365), 5)
 
 
-@pytest.mark.parametrize("op", [">", "<", ">=", "<=", "==", "!="])
-def test_threshold_count(sim, rng, tk, op):
-    tk.test_threshold_count_scalar(sim, rng, 7, op)
-
-
-def test_threshold_count_other_forms(sim, rng, tk):
-    tk.test_threshold_count_scalar_promotion(sim, rng)
-    tk.test_threshold_count_doy_and_full(sim, rng, 3)      # (the multi-year tile kernel is not simulated: its documented fall-back runs)
-    tk.test_domain_count(sim, rng)
-
-
-@pytest.mark.parametrize("reducer", ["sum", "mean", "min", "max", "std", "var", "count", "argmin", "argmax"])
-def test_resample_reduce(sim, rng, tk, reducer):
-    tk.test_resample_reduce(sim, rng, reducer, 5)
-
-
-@pytest.mark.parametrize("window,center,reducer", [(5, True, "sum"), (3, False, "mean"), (14, True, "max"), (4, True, "min"), (5, True, "std")])
-def test_rolling_reduce(sim, rng, tk, window, center, reducer):
-    tk.test_rolling_reduce(sim, rng, window, center, reducer)
-
-
-@pytest.mark.parametrize("index", ["first", "last"])
-def test_run_length_family(sim, rng, tk, index):
-    tk.test_cumsum_reset_and_rle(sim, rng, index, 0.05)
-    for stat in ("max", "min", "sum", "count", "mean", "std"):
-        tk.test_run_stats_mask(sim, rng, stat, index, True)
-    tk.test_run_stats_mask(sim, rng, "max", index, False)
-    tk.test_windowed_run_count_events(sim, rng, 2, index)
-
-
-def test_boundary_runs_and_fused_threshold(sim, rng, tk):
-    tk.test_first_last_run(sim, rng, 3, True)
-    tk.test_first_last_run(sim, rng, 7, False)
-    tk.test_cdd_fused(sim, rng)
-
-
 def test_detrend_pieces(sim):
     rng = np.random.default_rng(9)
     T = 500
@@ -95,46 +60,6 @@ def test_detrend_pieces(sim):
     np.testing.assert_allclose(p0.get()[None, :] + p1.get()[None, :] * t, trend, rtol=1e-9, atol=1e-9, equal_nan=True)
     detr = K.trend_apply(sim, d, p0, p1, "-").get()
     np.testing.assert_allclose(detr, (x.astype(np.float64) - trend).astype(np.float32), rtol=1e-6, atol=1e-5, equal_nan=True)
-
-
-@pytest.fixture(scope="module")
-def ts():
-    import tests.test_gpu_spells as mod
-
-    return mod
-
-
-@pytest.mark.parametrize("window,red,op", [(3, "min", ">"), (3, "max", "<="), (4, "sum", ">="), (5, "mean", ">")])
-def test_spell_mask(sim, rng, ts, window, red, op):
-    ts.test_spell_mask(sim, rng, window, red, op, 0.02)
-
-
-def test_spells_and_seasons(sim, rng, ts):
-    ts.test_spell_mask_weights_and_gap(sim, rng)
-    ts.test_spell_length_statistics_general(sim, rng, 3, "min", "max", True)
-    ts.test_spell_length_statistics_general(sim, rng, 2, "max", "sum", False)
-    ts.test_reference_spell_length_statistics_answer(sim)
-    ts.test_runs_with_holes(sim, rng, 2, 3)
-    ts.test_keep_longest_run(sim, rng)
-    ts.test_season(sim, rng, 3, "07-01")
-    ts.test_season(sim, rng, 1, None)
-    ts.test_reference_season_answers(sim)
-    ts.test_date_bounded_runs(sim, rng, 2, "07-01")
-    ts.test_windowed_max_run_sum(sim, rng, 3)
-    ts.test_run_bounds(sim, rng)
-    ts.test_find_events(sim, rng, 2, 1, "MS")
-    ts.test_suspicious_run(sim, rng, 3, ">", None)
-    ts.test_suspicious_run(sim, rng, 1, "==", 2.0)
-
-
-def test_spells_of_two_variables_and_doy_thresholds(sim, rng, ts):
-    ts.test_spell_mask_two_variables(sim, rng, 3, "min", ">=", "all")
-    ts.test_spell_mask_two_variables(sim, rng, 2, "sum", "<=", "any")
-    ts.test_bivariate_spell_length_statistics_and_thresholded_events(sim, rng)
-    ts.test_run_stats_doy_fused(sim, rng, 730, 37, ">")
-    ts.test_run_stats_doy_fused(sim, rng, 1461, 5, "!=")
-    ts.test_spell_length(sim, rng, "max", ">")
-    ts.test_1d_variants_and_season_end(sim, rng)
 
 
 @pytest.mark.parametrize("kind", ["+", "*"])
@@ -171,15 +96,6 @@ def tp():
     return mod
 
 
-@pytest.mark.parametrize("G,nq", [(12, 20), (12, 5), (40, 8), (365, 6)])
-@pytest.mark.parametrize("fractional", [True, False])
-def test_plane_linear_all_routes(sim, rng, tp, G, nq, fractional):
-    """xh_plane_linear through ALL of its kernels — the row kernel (integer coordinates), the pair kernel (fractional ones, <= 20
-    nodes), their work lists and the Delaunay walk — against the real scipy.griddata, for narrow and wide node spacings."""
-    for scale, kind in ((0.05, "t"), (6.0, "t"), (12.0, "p")):
-        tp.test_plane_linear_matches_griddata(sim, rng, G, nq, scale, kind, fractional)
-
-
 def test_plane_linear_special_nodes_and_nearest(sim, rng, tp):
     tp.test_plane_linear_nan_nodes_and_ties(sim, rng)
     tp.test_plane_linear_kinds_and_base(sim, rng)
@@ -197,80 +113,11 @@ def test_plane_linear_special_nodes_and_nearest(sim, rng, tp):
         assert (~np.isclose(got, exp, rtol=1e-6, equal_nan=True)).sum() <= 2   # (an exact tie between two rows may go either way)
 
 
-@pytest.mark.parametrize("R", [3, 40])
-def test_weighted_ensemble_percentiles(sim, rng, R):
-    """xh_weighted_quantile (wquantile.hip: insertion sort in lane-private LDS columns) against the restated xarray estimator."""
-    import tests.test_gpu_api as ta
-
-    ta.test_weighted_ensemble_percentiles(sim, rng, R)
-
-
-# ---- kernels that talk through LDS and the wave, on fibers (tests/hostsim/simt.h) --------------------------------------------------
-@pytest.fixture(scope="module")
-def tf():
-    import tests.test_gpu_f64 as mod
-
-    return mod
-
-
-@pytest.mark.parametrize("N", [1, 7, 150, 930])
-def test_float64_quantiles_on_fibers(sim, rng, tf, N):
-    """xh_nan_quantile_f64 (f64.hip: a workgroup per column, LDS, __syncthreads, __shfl_xor) — every thread a fiber."""
-    tf.test_calc_perc_float64_vs_oracle(sim, rng, N)
-
-
-def test_float64_counts_and_reductions(sim, rng, tf):
-    tf.test_calc_perc_float64_matches_the_reference_bitwise(sim)
-    tf.test_threshold_count_float64_counts_exactly(sim, rng)
-    tf.test_select_resample_op_float64(sim, rng)
-
-
 @pytest.fixture(scope="module")
 def tapi():
     import tests.test_gpu_api as mod
 
     return mod
-
-
-@pytest.mark.parametrize("T,C", [(40, 7), (365, 100), (1000, 33), (5000, 6)])
-def test_quantile_series_on_fibers(sim, rng, tk, T, C):
-    """xh_quantile_series (E1): 8-lane groups on time-major rows (T <= 512), transposes + one wave per column with the column in
-    LDS (<= 1024), 1024-thread workgroups beyond (the register-sort, two-pass-histogram and lean kernels are ISA-level: their
-    callers' general kernels run instead)."""
-    tk.test_quantile_series(sim, rng, T, C)
-
-
-def test_quantile_series_hard_distributions_on_fibers(sim, rng, tk):
-    for T in (40, 365, 600):
-        for kind in ("pr", "pr_skewed", "two_values", "negative_floor", "clustered", "constant", "nan_heavy"):
-            tk.test_quantile_series_hard_distributions(sim, rng, T, kind)
-    tk.test_quantile_series_beyond_32768_steps(sim, rng, 40000)        # the radix select of select5.hip
-
-
-@pytest.mark.parametrize("kind,interp,extrap", [("+", "nearest", "constant"), ("*", "linear", "nan")])
-def test_eqm_train_and_adjust_on_fibers(sim, rng, tk, kind, interp, extrap):
-    tk.test_eqm_train_adjust(sim, rng, kind, interp, extrap)
-    tk.test_eqm_precipitation_tied_nodes(sim, rng, kind, interp, extrap)
-
-
-def test_percentiles_on_fibers(sim, rng, tk):
-    """calc_perc (xh_nan_quantile: register bitonic, lane-private LDS columns), percentile_doy on one year (sliding window) and on
-    three (sorted day-set lists in an LDS ring), through a virtual time map, the 366-day re-gridding, +-inf samples."""
-    for N, C in ((1, 10), (2, 10), (5, 300), (13, 70), (30, 129), (150, 200), (365, 40)):
-        tk.test_nan_quantile(sim, rng, N, C, (1.0, 1.0))
-    tk.test_nan_quantile(sim, rng, 600, 70, (1 / 3, 1 / 3))
-    tk.test_percentile_doy(sim, rng, 1, 5, 260, "noleap")
-    tk.test_percentile_doy(sim, rng, 3, 5, 33, "standard")
-    tk.test_percentile_doy_virtual_time_map(sim, rng, 4)
-    tk.test_doy_interp(sim, rng)
-    tk.test_infinities_follow_the_nanmax_rule(sim, rng)
-
-
-def test_threshold_count_doy_tile_kernel_on_fibers(sim, rng, tk):
-    """xh_threshold_count_doy on multi-year series: the LDS tile kernel of tcount.hip (the 30-year tx90p count of the headline)."""
-    tk.test_threshold_count_doy_multi_year_tile_kernel(sim, rng, ">", 200, "YS")
-    tk.test_threshold_count_doy_multi_year_tile_kernel(sim, rng, "<=", 64, "MS")
-    tk.test_threshold_count_doy_tile_kernel_empty_periods_and_narrow_counters(sim, rng)
 
 
 @pytest.mark.parametrize("kind", ["+", "*"])
@@ -282,7 +129,44 @@ def test_qdm_adjust_on_fibers(sim, rng, tapi, kind, interp):
         tapi.test_qdm_adjust_matches_oracle(sim, rng, kind, interp, T, cells)
 
 
-def test_synthetic_fields_and_transposes_on_fibers(sim, rng, tk):
-    tk.test_synthetic_matches_oracle(sim)
-    for shape in ((130, 77), (128, 128), (300, 388), (257, 260), (5, 4), (8, 4)):
-        tk.test_transpose(sim, rng, shape)
+def _child_run(sim, files, skip, deselect=(), at_least=1):
+    """The given modules of the `-m gpu` suite in a child pytest against the simulation library built for this module."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, XH_TEST_DEVICE="hostsim", HOSTSIM_LIB=sim.path)
+    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--timeout", "600", *files, "-k", f"not ({skip})"]
+    for d in deselect:
+        cmd += ["--deselect", d]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True)
+    tail = res.stdout.strip().splitlines()[-1] if res.stdout.strip() else res.stderr[-500:]
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert " passed" in tail and "failed" not in tail, tail
+    assert int(tail.split(" passed")[0].split()[-1]) >= at_least, tail
+
+
+def test_whole_gpu_modules_on_the_simulation(sim):
+    """The host mirrors of the index functions — the Python the GPU path runs: indices.py, calendar.py, run_length.py, generic.py,
+    missing.py, the xarray-facing adapter and patch — through the simulated kernels: whole modules of the `-m gpu` suite (edge
+    cases: ragged / empty grids, single steps, all-NaN, error codes; the apply_ufunc views; the index-level API incl. the reference's
+    known answers, tx90p / tx10p at Indicator level, percentile_doy with the 366-day re-gridding; every spell / season / run-length
+    test; the float64 kernels).  What needs the ISA-level kernels is deselected."""
+    skip = ("qdm or eqm or dqm or sdba or bootstrap or adapt or add_dims or sub_groupings or exceedance_fused or climatological or "
+            "beyond or grouped or plane or quantile_cells or tx90p_on_a_float64 or refused_elsewhere")
+    _child_run(sim, ["tests/test_gpu_edges.py", "tests/test_gpu_patch.py", "tests/test_gpu_api.py", "tests/test_gpu_spells.py",
+                     "tests/test_gpu_f64.py"], skip, at_least=250)
+
+
+def test_selection_percentile_and_plane_modules_on_the_simulation(sim):
+    """tests/test_gpu_kernels.py and tests/test_gpu_plane.py: every entry point against the oracle — counts, reductions, rolling,
+    run lengths, calc_perc, percentile_doy (one year; multi-year through the LDS ring for the middle of the distribution), quantile
+    series of 40 ... 55 152 steps incl. the hard distributions, EQM train / adjust (nearest, linear, cubic), the plane kernels.
+    Deselected: what forces or needs an ISA-level kernel (register sorts, two-pass histogram, register top-16 / quad / walk
+    percentile kernels) and the many-column sizes."""
+    skip = ("many_columns or percentile_doy_quad or percentile_doy_count_multi_year or percentile_doy_merge_path or walk_kernel or "
+            "virtual_time_map or register_sort or two_pass")
+    _child_run(sim, ["tests/test_gpu_kernels.py", "tests/test_gpu_plane.py"], skip, at_least=300,
+               deselect=["tests/test_gpu_kernels.py::test_percentile_doy[9-7-20-standard]",
+                         "tests/test_gpu_kernels.py::test_percentile_doy[30-5-24-noleap]"])
