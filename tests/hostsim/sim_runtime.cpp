@@ -172,4 +172,6 @@ int xh_create(int device, xh_ctx** out) {
 }
 int xh_destroy(xh_ctx* c) { if (c) { free(c->scratch); free(c->big); free(c); } return XH_OK; }
 int xh_sync(xh_ctx*) { return XH_OK; }
+int xh_host_alloc(xh_ctx*, size_t bytes, void** out) { *out = malloc(bytes ? bytes : 1); return *out ? XH_OK : XH_ERR_HIP; }
+int xh_host_free(xh_ctx*, void* p) { free(p); return XH_OK; }
 }

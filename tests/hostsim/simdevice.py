@@ -89,9 +89,13 @@ class _SimLib:
                 raise AttributeError(name)
             fn = getattr(self._dll, name)
         except AttributeError:
-            if name in _MockLib._SPECIAL or name in ("xh_malloc", "xh_free", "xh_timer_start"):
+            # memory entry points on host buffers; fences between the copy lanes and page-locking are no-ops here (one thread,
+            # everything in order, host memory)
+            if name in _MockLib._SPECIAL or name in ("xh_malloc", "xh_free", "xh_timer_start", "xh_lane_fence", "xh_lane_sync",
+                                                      "xh_host_register", "xh_host_unregister"):
                 return getattr(self._mock, name)
-            raise NotImplementedError(f"{name}: its kernels use LDS / wave intrinsics and are not simulated on the host") from None
+            raise NotImplementedError(f"{name}: not simulated on the host (kernels written at ISA level, or a runtime service the "
+                                      "simulation does not provide)") from None
         fn.argtypes = _capi.SIGNATURES.get(name)
         fn.restype = _capi._RESTYPES.get(name, C.c_int)
         setattr(self, name, fn)

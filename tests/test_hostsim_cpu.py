@@ -152,11 +152,13 @@ def test_whole_gpu_modules_on_the_simulation(sim):
     missing.py, the xarray-facing adapter and patch — through the simulated kernels: whole modules of the `-m gpu` suite (edge
     cases: ragged / empty grids, single steps, all-NaN, error codes; the apply_ufunc views; the index-level API incl. the reference's
     known answers, tx90p / tx10p at Indicator level, percentile_doy with the 366-day re-gridding; every spell / season / run-length
-    test; the float64 kernels).  What needs the ISA-level kernels is deselected."""
+    test; the float64 kernels; the xarray-facing adapter on the duck-typed DataArray; the block adapter's slab pipeline).  What needs the ISA-level kernels is deselected."""
     skip = ("qdm or eqm or dqm or sdba or bootstrap or adapt or add_dims or sub_groupings or exceedance_fused or climatological or "
             "beyond or grouped or plane or quantile_cells or tx90p_on_a_float64 or refused_elsewhere")
     _child_run(sim, ["tests/test_gpu_edges.py", "tests/test_gpu_patch.py", "tests/test_gpu_api.py", "tests/test_gpu_spells.py",
-                     "tests/test_gpu_f64.py"], skip, at_least=250)
+                     "tests/test_gpu_f64.py", "tests/test_gpu_adapter.py", "tests/test_gpu_blocks.py"], skip, at_least=270,
+               # (the device-resident input cache is the real Device's; the simulation's buffers are host memory)
+               deselect=["tests/test_gpu_adapter.py::test_inputs_and_tables_stay_on_the_device_across_wrapper_calls"])
 
 
 def test_selection_percentile_and_plane_modules_on_the_simulation(sim):
