@@ -86,9 +86,8 @@ static inline long long __double_as_longlong(double d) { long long v; memcpy(&v,
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 #define __builtin_readcyclecounter() 0ull
 
-// pdoy.h speaks to the wave (readlane, buffer loads).  Thread by thread: stand-ins that let the header PARSE (reduce2.hip includes
-// it for xh_doy_mean_std only; that entry point is refused by tests/hostsim/simdevice.py, and the stand-ins abort if anything
-// reaches them).  On fibers (simt.h): real exchanges, and the buffer loads are plain loads.
+// pdoy.h speaks to the wave (readlane, buffer loads): every unit that includes it is built on fibers (simt.h: real exchanges, the
+// buffer loads are plain loads); thread by thread these stand-ins only let a header parse and abort if anything reaches them.
 typedef struct { const void* p; } __amdgpu_buffer_rsrc_t;
 #ifndef SIM_FIBERS
 static inline int __builtin_amdgcn_readfirstlane(int) { abort(); }

@@ -20,9 +20,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from mock_device import MockDevice, _MockLib  # noqa: E402
 from xclim_amd import _capi  # noqa: E402
 
-SIMULATED_UNITS = ("detrend", "window", "runlen", "reduce", "reduce2", "spell", "elemwise", "eqm", "plane", "wquantile")
+SIMULATED_UNITS = ("detrend", "window", "runlen", "reduce", "spell", "elemwise", "eqm", "plane", "wquantile")
 # compiled, but their kernels (or the selection kernels behind them) speak to the wave: refused
-WAVE_ENTRY_POINTS = ("xh_doy_mean_std",)
+WAVE_ENTRY_POINTS = ()
 # eqm.hip votes `__all(m == nq)` only to pick between two forms that are each right for the lane that takes them
 UNIT_DEFINES = {"eqm": ["-D__all(x)=((x)!=0)"],
                 # plane.hip appends to its work lists wave by wave and keeps lane-private LDS columns: see wave_of_one.h
@@ -32,7 +32,7 @@ UNIT_DEFINES = {"eqm": ["-D__all(x)=((x)!=0)"],
 
 
 # units whose kernels talk through LDS / the wave in WAVE-UNIFORM control flow: every workgroup as a set of fibers (simt.h)
-FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core")   # (select2.hip counts through the wave in ISA asm: not simulated)
+FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core", "reduce2")   # (select2.hip counts through the wave in ISA asm: not simulated)
 _DYN_LDS = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([\w ]+?)\s+(\w+)\[\];")
 
 

@@ -1,9 +1,9 @@
 """Kernel parity WITHOUT a GPU (tests/hostsim — test infrastructure only).  The translation units of xclim_amd/csrc are compiled
 with g++ against a stand-in for the HIP runtime and run on the CPU:
-  * thread by thread — detrend, window, runlen, reduce, reduce2, spell, elemwise, eqm, wquantile (no LDS traffic between threads),
+  * thread by thread — detrend, window, runlen, reduce, spell, elemwise, eqm, wquantile (no LDS traffic between threads),
     and plane.hip with its wave-aggregated work-list appends as waves of one lane;
   * every workgroup as a set of FIBERS (simt.h: __syncthreads, wave-uniform shuffles / votes / readlane, atomics) — f64, select,
-    select5, tcount, qdm, quantile, doystats and the kernels of core.hip (transposes, synthetic fields).
+    select5, tcount, qdm, quantile, doystats, reduce2 and the kernels of core.hip (transposes, synthetic fields).
 63 of the 93 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
 other 30 are runtime services (memory, streams, RCCL).  The kernels written at ISA level (register sorting networks, DPP, the
 streaming selection of select4.hip, the register top-16 percentile kernels) are NOT simulated: their launchers answer "not this
@@ -41,8 +41,10 @@ def tk():
 
 
 def test_unsimulated_entry_points_raise(sim):
-    with pytest.raises(NotImplementedError, match="not simulated"):
-        K.doy_mean_std(sim, sim.to_device(np.zeros((730, 4), np.float32)), np.arange(730, dtype=np.int32).reshape(2, 365), 5)
+    """(xh_adapt_freq ranks through rocPRIM's segmented sort; the RCCL entry points are runtime services)"""
+    for name in ("xh_adapt_freq", "xh_comm_allgather"):
+        with pytest.raises(NotImplementedError, match="not simulated"):
+            getattr(sim.lib, name)
 
 
 def test_detrend_pieces(sim):
@@ -153,7 +155,7 @@ def test_whole_gpu_modules_on_the_simulation(sim):
     cases: ragged / empty grids, single steps, all-NaN, error codes; the apply_ufunc views; the index-level API incl. the reference's
     known answers, tx90p / tx10p at Indicator level, percentile_doy with the 366-day re-gridding; every spell / season / run-length
     test; the float64 kernels; the xarray-facing adapter on the duck-typed DataArray; the block adapter's slab pipeline).  What needs the ISA-level kernels is deselected."""
-    skip = ("qdm or eqm or dqm or sdba or bootstrap or adapt or add_dims or sub_groupings or exceedance_fused or climatological or "
+    skip = ("qdm or eqm or dqm or sdba or bootstrap or adapt or add_dims or sub_groupings or exceedance_fused or "
             "beyond or grouped or plane or quantile_cells or tx90p_on_a_float64 or refused_elsewhere")
     _child_run(sim, ["tests/test_gpu_edges.py", "tests/test_gpu_patch.py", "tests/test_gpu_api.py", "tests/test_gpu_spells.py",
                      "tests/test_gpu_f64.py", "tests/test_gpu_adapter.py", "tests/test_gpu_blocks.py"], skip, at_least=270,
