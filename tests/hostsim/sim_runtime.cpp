@@ -152,12 +152,7 @@ int xh_qdm_sorted(xh_ctx*, const float*, int64_t, int64_t, int64_t, const float*
   xh_set_error("host simulation: the global-sort rank kernels (rocPRIM) are not simulated");
   return XH_ERR_LIMIT;
 }
-int xh_launch_pdoy_walk(xh_ctx*, const float*, int64_t, int64_t, int64_t, const int32_t*, int, int, int, const QTab*, const int32_t*, int, double*,
-                        const int32_t*, int64_t, const uint8_t*) { return XH_ERR_NOTIMPL; }
-int xh_launch_pdoy_top16(xh_ctx*, const float*, int64_t, int64_t, int64_t, const int32_t*, int, int, int, const QTab*, const int32_t*, int, int, double*,
-                         const int32_t*, int64_t, const uint8_t*) { return XH_ERR_NOTIMPL; }
-int xh_launch_pdoy_top16_count(xh_ctx*, const float*, int64_t, int64_t, int64_t, const int32_t*, int, int, int, const QTab*, const int32_t*, int,
-                               const uint8_t*, int, const int32_t*, int32_t*, int32_t*, const uint8_t*) { return XH_ERR_NOTIMPL; }
+
 
 extern "C" {
 const char* xh_last_error(void) { return g_err; }

@@ -32,7 +32,22 @@ UNIT_DEFINES = {"eqm": ["-D__all(x)=((x)!=0)"],
 
 
 # units whose kernels talk through LDS / the wave in WAVE-UNIFORM control flow: every workgroup as a set of fibers (simt.h)
-FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core", "reduce2")   # (select2.hip counts through the wave in ISA asm: not simulated)
+FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core", "reduce2", "pdoy_top", "pdoy_quad", "pdoy_walk")   # (select2.hip counts through the wave in ISA asm: not simulated)
+# topnet.h (the comparator networks of the register percentile kernels) issues v_min_f32 / v_max_f32 and a NaN-replace-and-count
+# triple as inline ISA: four statements, rewritten to the C++ they stand for (NaN never enters the min / max: the callers replace
+# it first), in a copy of the header that the fiber units include instead
+HEADER_REWRITES = {"topnet.h": [
+    ('asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));', "r = a < b ? a : b;"),
+    ('asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));', "r = a > b ? a : b;"),
+    ('''  asm("v_cmp_u_f32 vcc, %2, %2\\n\\tv_cndmask_b32 %0, %2, %3, vcc\\n\\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "=&v"(key), "+v"(nn)
+      : "v"(raw), "v"(sentinel)
+      : "vcc");''', "  { const bool n_ = raw != raw; key = n_ ? sentinel : raw; nn += n_ ? 1 : 0; }"),
+    ('''  asm("v_cmp_u_f32 vcc, %0, %0\\n\\tv_cndmask_b32 %0, %0, %2, vcc\\n\\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(v), "+v"(nn)
+      : "v"(sentinel)
+      : "vcc");''', "  { const bool n_ = v != v; v = n_ ? sentinel : v; nn += n_ ? 1 : 0; }"),
+]}
 _DYN_LDS = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([\w ]+?)\s+(\w+)\[\];")
 
 
@@ -41,7 +56,14 @@ def build(workdir: str) -> str:
     becomes a pointer to the workgroup's LDS buffer) + sim_runtime.cpp into workdir/libxclimhip_hostsim.so."""
     if shutil.which("g++") is None:
         raise RuntimeError("no g++")
-    flags = ["-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-I", HERE, "-I", CSRC]
+    for header, rules in HEADER_REWRITES.items():
+        text = open(os.path.join(CSRC, header)).read()
+        for old, new in rules:
+            if old not in text:
+                raise RuntimeError(f"{header}: the statement the simulation rewrites has changed: {old[:60]!r}")
+            text = text.replace(old, new)
+        open(os.path.join(workdir, header), "w").write(text)
+    flags = ["-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-I", workdir, "-I", HERE, "-I", CSRC]
     # HOSTSIM_SANITIZE=undefined (or address,undefined with LD_PRELOAD=libasan.so): an audit build of the kernels under the
     # compiler's sanitizers — out-of-bounds LDS / scratch accesses, shifts, signed overflow
     san = os.environ.get("HOSTSIM_SANITIZE")

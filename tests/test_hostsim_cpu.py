@@ -3,16 +3,21 @@ with g++ against a stand-in for the HIP runtime and run on the CPU:
   * thread by thread — detrend, window, runlen, reduce, spell, elemwise, eqm, wquantile (no LDS traffic between threads),
     and plane.hip with its wave-aggregated work-list appends as waves of one lane;
   * every workgroup as a set of FIBERS (simt.h: __syncthreads, wave-uniform shuffles / votes / readlane, atomics) — f64, select,
-    select5, tcount, qdm, quantile, doystats, reduce2 and the kernels of core.hip (transposes, synthetic fields).
+    select5, tcount, qdm, quantile, doystats, reduce2, pdoy_top, pdoy_quad, pdoy_walk and the kernels of core.hip (transposes,
+    synthetic fields).
 63 of the 93 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
-other 30 are runtime services (memory, streams, RCCL).  The kernels written at ISA level (register sorting networks, DPP, the
-streaming selection of select4.hip, the register top-16 percentile kernels) are NOT simulated: their launchers answer "not this
-kernel's shape" and the callers' general kernels run — exactly the fall-back the product takes for shapes those kernels decline.
+other 30 are runtime services (memory, streams, RCCL).  The register percentile kernels (pdoy_top / pdoy_quad / pdoy_walk) run on
+fibers too, with the four ISA statements of topnet.h rewritten to the C++ they stand for.  The kernels written in ISA throughout
+(the register sorting networks of select3 / qdm2 with their DPP exchanges, select2's wave counts, the streaming selection of
+select4.hip) are NOT simulated: their launchers answer "not this kernel's shape" and the callers' general kernels run — exactly the
+fall-back the product takes for shapes those kernels decline.
 The SAME parity tests the GPU runs are re-run here: whole modules of the `-m gpu` suite (edges, patch, api, spells, f64, kernels,
 plane: ~740 tests, minus what forces or needs an ISA-level kernel) in two child pytest runs against the simulation library, plus a
 few direct calls.  The `-m gpu` runs remain the parity tests proper (the real
 kernels on the real device, the ISA-level ones included); the product has no CPU path: the simulation library is built into a
 temporary directory by this module only, and what is not simulated raises instead of pretending."""
+import os
+
 import numpy as np
 import pytest
 
@@ -131,7 +136,7 @@ def test_qdm_adjust_on_fibers(sim, rng, tapi, kind, interp):
         tapi.test_qdm_adjust_matches_oracle(sim, rng, kind, interp, T, cells)
 
 
-def _child_run(sim, files, skip, deselect=(), at_least=1):
+def _child_run(sim, files, skip="nothing_is_skipped", deselect=(), at_least=1):
     """The given modules of the `-m gpu` suite in a child pytest against the simulation library built for this module."""
     import os
     import subprocess
@@ -174,3 +179,20 @@ def test_selection_percentile_and_plane_modules_on_the_simulation(sim):
     _child_run(sim, ["tests/test_gpu_kernels.py", "tests/test_gpu_plane.py"], skip, at_least=300,
                deselect=["tests/test_gpu_kernels.py::test_percentile_doy[9-7-20-standard]",
                          "tests/test_gpu_kernels.py::test_percentile_doy[30-5-24-noleap]"])
+
+
+def test_register_percentile_kernels_on_the_simulation(sim):
+    """The multi-year percentile kernels of the headline chain — the register top-16 kernel (pdoy_top.hip), the quad kernel of the
+    30-year tx90p (pdoy_quad.hip), the split-walk kernel for the middle of the distribution (pdoy_walk.hip), the fused count, the
+    LDS-ring merge — on fibers: readlane row fetches, buffer loads and the comparator networks of topnet.h (whose four ISA
+    statements — v_min_f32, v_max_f32, the NaN-replace-and-count triples — are rewritten to the C++ they stand for).  A few
+    parameter sets of each GPU test; bootstrap and the fused exceedance count ride on the same kernels."""
+    k = "tests/test_gpu_kernels.py::"
+    a = "tests/test_gpu_api.py::"
+    ids = [k + "test_percentile_doy[9-7-20-standard]", k + "test_percentile_doy[30-5-24-noleap]",
+           k + "test_percentile_doy_merge_path[12-7-standard-0.05]", k + "test_percentile_doy_quad_kernel[30-noleap-90.0-0.0]",
+           k + "test_percentile_doy_count_multi_year[YS-90.0->]", k + "test_percentile_doy_virtual_time_map[12]",
+           a + "test_percentile_bootstrap[noleap-2000-01-01-7-base0-YS]", a + "test_percentile_exceedance_fused[noleap-4380-YS-5-95.0->]"]
+    if os.environ.get("HOSTSIM_SLOW"):   # (the walk kernel exchanges through the wave at every step of every day: 50 s here)
+        ids += [k + "test_percentile_doy_walk_kernel[9-5-noleap-0.9]", k + "test_percentile_doy_quad_kernel[7-noleap-5.0-0.0]"]
+    _child_run(sim, ids, at_least=len(ids))
