@@ -101,6 +101,9 @@ static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc
   memcpy(&v, (const char*)r.p + (unsigned)voff + (unsigned)soff, 4);
   return v;
 }
+static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  memcpy((char*)const_cast<void*>(r.p) + (unsigned)voff + (unsigned)soff, &v, 4);
+}
 #endif
 
 // plane.hip: the work list is filled by wave-aggregated appends (ballot + one atomic per wave + shuffle).  One thread at a time IS a

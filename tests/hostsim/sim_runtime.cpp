@@ -106,7 +106,11 @@ void xh_set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
 }
-const char* xh_diag_env(const char*) { return nullptr; }
+const char* xh_diag_env(const char* name) {   // (as core.hip: diagnostic switches count only under XH_DIAGNOSTICS=1)
+  const char* on = getenv("XH_DIAGNOSTICS");
+  if (!on || on[0] != '1') return nullptr;
+  return getenv(name);
+}
 
 int xh_scratch_upload(xh_ctx* ctx, size_t* cursor, const void* host, size_t bytes, void** dptr) {
   const size_t off = (*cursor + 255) & ~(size_t)255;
@@ -140,13 +144,11 @@ int xh_const_rows(xh_ctx* ctx, int64_t elems, const float** nan_row, const float
 // eqm.hip's quantile dispatch ends in the selection kernels (LDS, wave intrinsics): xh_eqm_train / xh_quantile_series are refused by
 // the simulated device; these only satisfy the linker
 int xh_select_hist(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
-int xh_select_regsort(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
 int xh_select_columns_lean(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
 // the kernels behind these are ISA-level (register sorting networks, DPP, buffer loads with LDS staging ...): every caller treats
 // XH_ERR_NOTIMPL as "not this kernel's shape" and takes its general kernel, which IS simulated
 struct QTab;
 int xh_qdm_hist(xh_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const double*, int, int, int, float*, int64_t) { return XH_ERR_NOTIMPL; }
-int xh_qdm_regsort(xh_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const double*, int, int, int, float*, int64_t) { return XH_ERR_NOTIMPL; }
 int xh_qdm_sorted_ws(int64_t, int64_t, size_t* bytes) { *bytes = 0; return XH_ERR_NOTIMPL; }
 int xh_qdm_sorted(xh_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const double*, int, int, int, int, float*, int64_t, void*) {
   xh_set_error("host simulation: the global-sort rank kernels (rocPRIM) are not simulated");

@@ -32,7 +32,7 @@ UNIT_DEFINES = {"eqm": ["-D__all(x)=((x)!=0)"],
 
 
 # units whose kernels talk through LDS / the wave in WAVE-UNIFORM control flow: every workgroup as a set of fibers (simt.h)
-FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core", "reduce2", "pdoy_top", "pdoy_quad", "pdoy_walk")   # (select2.hip counts through the wave in ISA asm: not simulated)
+FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core", "reduce2", "pdoy_top", "pdoy_quad", "pdoy_walk", "select3", "qdm2")   # (select2.hip counts through the wave in ISA asm: not simulated)
 # topnet.h (the comparator networks of the register percentile kernels) issues v_min_f32 / v_max_f32 and a NaN-replace-and-count
 # triple as inline ISA: four statements, rewritten to the C++ they stand for (NaN never enters the min / max: the callers replace
 # it first), in a copy of the header that the fiber units include instead
@@ -48,6 +48,20 @@ HEADER_REWRITES = {"topnet.h": [
       : "v"(sentinel)
       : "vcc");''', "  { const bool n_ = v != v; v = n_ ? sentinel : v; nn += n_ ? 1 : 0; }"),
 ]}
+# The register sorting networks (select3.hip, qdm2.hip) split a sorted column across the lane pair with DPP moves written as ISA:
+# xor with the lane's sign mask, take the partner's complement (v_not_b32_dpp quad_perm [1,0,3,2]), keep the larger — the same in C++
+# with a shuffle; qdm2.hip's key conversion counts NaN with a compare / select / add-with-carry triple.
+_SPLIT_PAIR = (r"#define XH_SP\(i, j\).*?\n  \}\n",
+               "#define XH_SP(i, j) { k##i ^= mA3; k##j ^= mA3; const uint32_t t0_ = ~__shfl_xor(k##j, 1), t1_ = ~__shfl_xor(k##i, 1); "
+               "k##i = k##i > t0_ ? k##i : t0_; k##j = k##j > t1_ ? k##j : t1_; }\n")
+_SPLIT_ONE = (r"#define XH_SM\(m\).*?\n  \}\n",
+              "#define XH_SM(m) { k##m ^= mA3; const uint32_t t0_ = ~__shfl_xor(k##m, 1); k##m = k##m > t0_ ? k##m : t0_; }\n")
+UNIT_REWRITES = {
+    "select3": [_SPLIT_PAIR, _SPLIT_ONE],
+    "qdm2": [_SPLIT_PAIR, _SPLIT_ONE,
+             (r'asm volatile\("v_cmp_u_f32 vcc, %2, %2\\n\\tv_cndmask_b32_e64 %0, %0, -1, vcc\\n\\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" \\\n\s*: "\+v"\(kk_\), "\+v"\(nanc\) : "v"\(f_\) : "vcc"\);',
+              "{ const bool n_ = f_ != f_; kk_ = n_ ? 0xFFFFFFFFu : kk_; nanc += n_ ? 1u : 0u; }")],
+}
 _DYN_LDS = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([\w ]+?)\s+(\w+)\[\];")
 
 
@@ -69,8 +83,7 @@ def build(workdir: str) -> str:
     san = os.environ.get("HOSTSIM_SANITIZE")
     if san:
         flags += ["-g", f"-fsanitize={san}", "-fno-sanitize-recover=all" if os.environ.get("HOSTSIM_SANITIZE_FATAL") else "-fsanitize-recover=all"]
-    objs = []
-    for unit in SIMULATED_UNITS + FIBER_UNITS:
+    def compile_unit(unit):
         obj = os.path.join(workdir, unit + ".o")
         src = os.path.join(CSRC, unit + ".hip")
         extra = list(UNIT_DEFINES.get(unit, []))
@@ -83,11 +96,20 @@ def build(workdir: str) -> str:
             # compiler fences whose operand class "v" / "s" (a VGPR / SGPR) becomes "r"
             text = text.replace('asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory")', "__syncthreads()")
             text = re.sub(r'asm volatile\(""\s*:\s*"\+[vs]"', 'asm volatile("" : "+r"', text)
+            for pat, rep in UNIT_REWRITES.get(unit, []):
+                text, nsub = re.subn(pat, rep, text, flags=re.S)
+                if nsub == 0:
+                    raise RuntimeError(f"{unit}.hip: the statement the simulation rewrites has changed: {pat[:50]!r}")
             src = os.path.join(workdir, unit + ".sim.cpp")
             open(src, "w").write(text)
             extra += ["-DSIM_FIBERS=1", "-D__shared__=static"]
         subprocess.run(["g++", "-x", "c++", *flags, *extra, "-c", src, "-o", obj], check=True)
-        objs.append(obj)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:   # (g++ runs outside the GIL)
+        objs = list(pool.map(compile_unit, SIMULATED_UNITS + FIBER_UNITS))
     obj = os.path.join(workdir, "sim_runtime.o")
     subprocess.run(["g++", *flags, "-c", os.path.join(HERE, "sim_runtime.cpp"), "-o", obj], check=True)
     out = os.path.join(workdir, "libxclimhip_hostsim.so")

@@ -97,6 +97,14 @@ template <typename T> static inline T sim_readfirstlane(T v, const void* s) {
   const unsigned first = live ? (unsigned)__builtin_ctzll(live) : 0u;
   return sim_exchange(v, s, [=](uint64_t* w) { return w[first]; });
 }
+// DPP moves (v_mov_b32_dpp through __builtin_amdgcn_update_dpp): quad_perm selections — the lane pair swap [1,0,3,2] of the register
+// sorting networks among them; anything else aborts rather than guess
+static inline int sim_update_dpp(int src, int ctrl, const void* s) {
+  if (ctrl < 0 || ctrl > 0xFF) { fprintf(stderr, "host simulation: DPP control 0x%x is not emulated\n", ctrl); abort(); }
+  const unsigned me = sim_lane(), sel = ((unsigned)ctrl >> (2u * (me & 3u))) & 3u;
+  return sim_exchange(src, s, [=](uint64_t* x) { return x[(me & ~3u) | sel]; });
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rowmask, bankmask, boundctrl) sim_update_dpp((src), (ctrl), SIM_SITE)
 #define __shfl(v, src, ...) sim_shfl((v), (src), SIM_SITE, ##__VA_ARGS__)
 #define __shfl_xor(v, mask, ...) sim_shfl_xor((v), (mask), SIM_SITE, ##__VA_ARGS__)
 #define __shfl_up(v, d, ...) sim_shfl_up((v), (d), SIM_SITE, ##__VA_ARGS__)

@@ -7,9 +7,9 @@ with g++ against a stand-in for the HIP runtime and run on the CPU:
     synthetic fields).
 63 of the 93 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
 other 30 are runtime services (memory, streams, RCCL).  The register percentile kernels (pdoy_top / pdoy_quad / pdoy_walk) run on
-fibers too, with the four ISA statements of topnet.h rewritten to the C++ they stand for.  The kernels written in ISA throughout
-(the register sorting networks of select3 / qdm2 with their DPP exchanges, select2's wave counts, the streaming selection of
-select4.hip) are NOT simulated: their launchers answer "not this kernel's shape" and the callers' general kernels run — exactly the
+fibers too, with the four ISA statements of topnet.h rewritten to the C++ they stand for, and so do the register sorting networks
+(select3 / qdm2: the DPP split across the lane pair as a shuffle).  select2's wave counts, the streaming selection of select4.hip
+and rocPRIM are NOT simulated: their launchers answer "not this kernel's shape" and the callers' general kernels run — exactly the
 fall-back the product takes for shapes those kernels decline.
 The SAME parity tests the GPU runs are re-run here: whole modules of the `-m gpu` suite (edges, patch, api, spells, f64, kernels,
 plane: ~740 tests, minus what forces or needs an ISA-level kernel) in two child pytest runs against the simulation library, plus a
@@ -196,3 +196,14 @@ def test_register_percentile_kernels_on_the_simulation(sim):
     if os.environ.get("HOSTSIM_SLOW"):   # (the walk kernel exchanges through the wave at every step of every day: 50 s here)
         ids += [k + "test_percentile_doy_walk_kernel[9-5-noleap-0.9]", k + "test_percentile_doy_quad_kernel[7-noleap-5.0-0.0]"]
     _child_run(sim, ids, at_least=len(ids))
+
+
+def test_register_sorting_network_kernels_on_the_simulation(sim):
+    """The one-year kernels of the headline's EQM / QDM legs — select3.hip (k_select_regsort) and qdm2.hip (k_qdm_regsort +
+    k_cut_classify): a column in the registers of a lane pair, the comparator networks of sortnet_183.h, the split across the pair
+    by DPP.  On fibers, with the two DPP macros (xor with the lane's sign mask, the partner's complement, keep the larger) and qdm2's
+    NaN-count triple rewritten to the C++ they stand for.  The GPU tests of these kernels, incl. bit-equality with the histogram /
+    exact-rank kernels under the diagnostic switches."""
+    k, a = "tests/test_gpu_kernels.py::", "tests/test_gpu_api.py::"
+    _child_run(sim, [k + "test_quantile_series_one_year_register_sort", k + "test_quantile_series_register_sort_matches_histogram_kernels",
+                     a + "test_qdm_nearest_one_year_cut_value_kernel", a + "test_qdm_precipitation_and_edge_cases"], at_least=30)

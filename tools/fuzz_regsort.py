@@ -8,10 +8,11 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from xclim_amd import kernels as K  # noqa: E402
-from xclim_amd._capi import get_device  # noqa: E402
+from fuzzdev import get_fuzz_device  # noqa: E402
 
-dev = get_device()
+dev = get_fuzz_device()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "5150")))
 os.environ["XH_DIAGNOSTICS"] = "1"
