@@ -144,7 +144,6 @@ int xh_const_rows(xh_ctx* ctx, int64_t elems, const float** nan_row, const float
 // eqm.hip's quantile dispatch ends in the selection kernels (LDS, wave intrinsics): xh_eqm_train / xh_quantile_series are refused by
 // the simulated device; these only satisfy the linker
 int xh_select_hist(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
-int xh_select_columns_lean(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
 // the kernels behind these are ISA-level (register sorting networks, DPP, buffer loads with LDS staging ...): every caller treats
 // XH_ERR_NOTIMPL as "not this kernel's shape" and takes its general kernel, which IS simulated
 struct QTab;

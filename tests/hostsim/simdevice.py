@@ -32,7 +32,7 @@ UNIT_DEFINES = {"eqm": ["-D__all(x)=((x)!=0)"],
 
 
 # units whose kernels talk through LDS / the wave in WAVE-UNIFORM control flow: every workgroup as a set of fibers (simt.h)
-FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core", "reduce2", "pdoy_top", "pdoy_quad", "pdoy_walk", "select3", "qdm2")   # (select2.hip counts through the wave in ISA asm: not simulated)
+FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core", "reduce2", "pdoy_top", "pdoy_quad", "pdoy_walk", "select3", "qdm2", "select2")
 # topnet.h (the comparator networks of the register percentile kernels) issues v_min_f32 / v_max_f32 and a NaN-replace-and-count
 # triple as inline ISA: four statements, rewritten to the C++ they stand for (NaN never enters the min / max: the callers replace
 # it first), in a copy of the header that the fiber units include instead
@@ -57,6 +57,11 @@ _SPLIT_PAIR = (r"#define XH_SP\(i, j\).*?\n  \}\n",
 _SPLIT_ONE = (r"#define XH_SM\(m\).*?\n  \}\n",
               "#define XH_SM(m) { k##m ^= mA3; const uint32_t t0_ = ~__shfl_xor(k##m, 1); k##m = k##m > t0_ ? k##m : t0_; }\n")
 UNIT_REWRITES = {
+    # select2.hip counts through the wave on VCC (v_cmp + s_bcnt1_i32_b64): a vote + a population count
+    "select2": [(r'asm volatile\("v_cmp_o_f32 vcc, %3, %3\\n\\ts_bcnt1_i32_b64 %1, vcc\\n\\tv_cndmask_b32 %0, -1, %2, vcc"\s*: "=v"\(o\), "=s"\(c\)\s*: "v"\(kk\), "v"\(u\)\s*: "vcc", "scc"\);',
+                 "{ const bool o_ = __uint_as_float(u) == __uint_as_float(u); c = (uint32_t)__popcll(__ballot(o_)); o = o_ ? kk : 0xFFFFFFFFu; }"),
+                (r'asm volatile\("v_cmp_eq_u32 vcc, %1, %2\\n\\ts_bcnt1_i32_b64 %0, vcc" : "=s"\(c\) : "v"\(key\[k\]\), "v"\(kmin\) : "vcc", "scc"\);',
+                 "c = (uint32_t)__popcll(__ballot(key[k] == kmin));")],
     "select3": [_SPLIT_PAIR, _SPLIT_ONE],
     "qdm2": [_SPLIT_PAIR, _SPLIT_ONE,
              (r'asm volatile\("v_cmp_u_f32 vcc, %2, %2\\n\\tv_cndmask_b32_e64 %0, %0, -1, vcc\\n\\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" \\\n\s*: "\+v"\(kk_\), "\+v"\(nanc\) : "v"\(f_\) : "vcc"\);',
