@@ -39,6 +39,7 @@ void sim_run_block(size_t nthreads, const SimIdx& bdim) {
     makecontext(&f.ctx, sim_trampoline, 0);
     f.state = 0;
     f.site = nullptr;
+    f.orgen = 0;
     f.tid = {(unsigned)(i % bdim.x), (unsigned)((i / bdim.x) % bdim.y), (unsigned)(i / ((size_t)bdim.x * bdim.y))};
   }
   const size_t nwaves = (nthreads + 63) / 64;
@@ -143,11 +144,9 @@ int xh_const_rows(xh_ctx* ctx, int64_t elems, const float** nan_row, const float
 }
 // eqm.hip's quantile dispatch ends in the selection kernels (LDS, wave intrinsics): xh_eqm_train / xh_quantile_series are refused by
 // the simulated device; these only satisfy the linker
-int xh_select_hist(xh_ctx*, const float*, int64_t, int64_t, int64_t, const double*, int, float*, int64_t, int64_t) { return XH_ERR_NOTIMPL; }
 // the kernels behind these are ISA-level (register sorting networks, DPP, buffer loads with LDS staging ...): every caller treats
 // XH_ERR_NOTIMPL as "not this kernel's shape" and takes its general kernel, which IS simulated
 struct QTab;
-int xh_qdm_hist(xh_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const double*, int, int, int, float*, int64_t) { return XH_ERR_NOTIMPL; }
 int xh_qdm_sorted_ws(int64_t, int64_t, size_t* bytes) { *bytes = 0; return XH_ERR_NOTIMPL; }
 int xh_qdm_sorted(xh_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const double*, int, int, int, int, float*, int64_t, void*) {
   xh_set_error("host simulation: the global-sort rank kernels (rocPRIM) are not simulated");

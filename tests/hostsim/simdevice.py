@@ -32,7 +32,7 @@ UNIT_DEFINES = {"eqm": ["-D__all(x)=((x)!=0)"],
 
 
 # units whose kernels talk through LDS / the wave in WAVE-UNIFORM control flow: every workgroup as a set of fibers (simt.h)
-FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core", "reduce2", "pdoy_top", "pdoy_quad", "pdoy_walk", "select3", "qdm2", "select2")
+FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core", "reduce2", "pdoy_top", "pdoy_quad", "pdoy_walk", "select3", "qdm2", "select2", "select4")
 # topnet.h (the comparator networks of the register percentile kernels) issues v_min_f32 / v_max_f32 and a NaN-replace-and-count
 # triple as inline ISA: four statements, rewritten to the C++ they stand for (NaN never enters the min / max: the callers replace
 # it first), in a copy of the header that the fiber units include instead
@@ -63,6 +63,25 @@ UNIT_REWRITES = {
                 (r'asm volatile\("v_cmp_eq_u32 vcc, %1, %2\\n\\ts_bcnt1_i32_b64 %0, vcc" : "=s"\(c\) : "v"\(key\[k\]\), "v"\(kmin\) : "vcc", "scc"\);',
                  "c = (uint32_t)__popcll(__ballot(key[k] == kmin));")],
     "select3": [_SPLIT_PAIR, _SPLIT_ONE],
+    # select4.hip (the streaming two-pass selection): the lane-xor exchanges of its wave-wide bitonic sort are DPP moves (quad_perm,
+    # row_shl / row_shr / row_ror) = the value of lane ^ m; the sign of a float difference is one v_med3_i32 on its bits; column
+    # extremes through v_min / v_max (which return the other operand for a NaN one, like fminf / fmaxf); the candidate appends are
+    # sixteen LDS writes under the execution mask (v_cmpx) at an address kept as a 32-bit LDS offset
+    "select4": [
+        (r"(__device__ __forceinline__ uint32_t hs_lane_xor\(uint32_t v, int m\) \{).*?\n\}\n", r"\1 return (uint32_t)__shfl_xor((int)v, m); }\n"),
+        (r'asm\("v_med3_i32 %0, %1, -1, 1" : "=v"\(r\) : "v"\(z\)\);', "{ int zi_; memcpy(&zi_, &z, 4); r = zi_ < -1 ? -1 : (zi_ > 1 ? 1 : zi_); }"),
+        (r'asm\("v_min_f32 %0, %0, %1" : "\+v"\((\w+)\) : "v"\(([^;]+?)\)\);', r"\1 = fminf(\1, \2);"),
+        (r'asm\("v_max_f32 %0, %0, %1" : "\+v"\((\w+)\) : "v"\(([^;]+?)\)\);', r"\1 = fmaxf(\1, \2);"),
+        (r'asm\("v_min3_f32 %0, %0, %1, %2" : "\+v"\((\w+)\) : "v"\(([^;]+?)\), "v"\(([^;]+?)\)\);', r"\1 = fminf(fminf(\1, \2), \3);"),
+        (r'asm\("v_max3_f32 %0, %0, %1, %2" : "\+v"\((\w+)\) : "v"\(([^;]+?)\), "v"\(([^;]+?)\)\);', r"\1 = fmaxf(fmaxf(\1, \2), \3);"),
+        # hs_qdm_pick reads the column's records with v_readlane from per-lane searches (divergent): published once, peeked after
+        (r"(if \(lane \+ 64 < nrec\) \{ rw0b = [^\n]*\n)", r"\1  sim_publish(0, rw0a); sim_publish(1, rw1a); sim_publish(2, rw0b); sim_publish(3, rw1b);\n"),
+        (r"__builtin_amdgcn_readlane\(\(int\)rw0a, r\)", "sim_peek(0, r)"), (r"__builtin_amdgcn_readlane\(\(int\)rw1a, r\)", "sim_peek(1, r)"),
+        (r"__builtin_amdgcn_readlane\(\(int\)rw0b, r - 64\)", "sim_peek(2, r - 64)"), (r"__builtin_amdgcn_readlane\(\(int\)rw1b, r - 64\)", "sim_peek(3, r - 64)"),
+        (r"typedef __attribute__\(\(address_space\(3\)\)\) uint32_t lds_u32;", ""),
+        (r"uint32_t addr = \(uint32_t\)\(uintptr_t\)\(lds_u32\*\)\(cand \+ lbase\[colo\]\) \+ pos \* 4u;", "uint32_t* addr = (uint32_t*)(cand + lbase[colo]) + pos;"),
+        (r'asm volatile\(\s*"s_mov_b64 %\[sv\], exec\\n\\t".*?: "vcc", "memory"\);', "(void)sv; if (bit) { uint32_t b_; memcpy(&b_, &v[u], 4); *addr++ = b_; }"),
+    ],
     "qdm2": [_SPLIT_PAIR, _SPLIT_ONE,
              (r'asm volatile\("v_cmp_u_f32 vcc, %2, %2\\n\\tv_cndmask_b32_e64 %0, %0, -1, vcc\\n\\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" \\\n\s*: "\+v"\(kk_\), "\+v"\(nanc\) : "v"\(f_\) : "vcc"\);',
               "{ const bool n_ = f_ != f_; kk_ = n_ ? 0xFFFFFFFFu : kk_; nanc += n_ ? 1u : 0u; }")],

@@ -23,6 +23,7 @@ struct SimFiber {
   int state = 0;  // 0 runnable, 1 at the workgroup barrier, 2 at a wave exchange, 3 done
   SimIdx tid{0, 0, 0};
   const void* site = nullptr;
+  int orgen = 0;  // calls of __syncthreads_or so far (selects one of two flags)
 };
 
 struct SimBlockState {
@@ -32,6 +33,8 @@ struct SimBlockState {
   std::vector<uint64_t> slots;  // [wave][64] exchange values
   std::function<void()> entry;
   unsigned char* dyn_lds = nullptr;
+  int or_acc[2] = {0, 0};
+  std::vector<uint32_t> pub[4];  // registers a wave made readable for v_readlane from divergent code (sim_publish / sim_peek)
 };
 extern thread_local SimBlockState g_sim;
 
@@ -45,7 +48,28 @@ static inline unsigned sim_lane() { return (unsigned)g_sim.cur & 63u; }
 static inline uint64_t* sim_wave_slots() { return g_sim.slots.data() + ((size_t)g_sim.cur >> 6) * 64; }
 static inline unsigned char* sim_dynamic_lds() { return g_sim.dyn_lds; }
 
+// v_readlane from DIVERGENT code (hardware: a scalar read of another lane's register, whatever the execution mask): the register
+// is published once at a point where the wave is together, then peeked without an exchange (select4.hip's hs_qdm_pick, rewritten
+// by simdevice.py)
+static inline void sim_publish(int slot, uint32_t v) {
+  if (g_sim.pub[slot].size() < g_sim.fibers.size()) g_sim.pub[slot].resize(g_sim.fibers.size());
+  g_sim.pub[slot][g_sim.cur] = v;
+}
+static inline uint32_t sim_peek(int slot, int lane) { return g_sim.pub[slot][((size_t)g_sim.cur & ~(size_t)63) + (size_t)lane]; }
+
 static inline void __syncthreads() { sim_yield(1, nullptr); }
+// the workgroup barrier that also ORs a predicate: deposit, barrier, read, barrier; two flags used alternately (a thread that leaves
+// clears the flag of THIS call while the quick ones already deposit into the other one for the next call)
+static inline int __syncthreads_or(int pred) {
+  SimFiber& f = g_sim.fibers[g_sim.cur];
+  const int g = f.orgen++ & 1;
+  if (pred) g_sim.or_acc[g] = 1;
+  sim_yield(1, nullptr);
+  const int r = g_sim.or_acc[g];
+  sim_yield(1, nullptr);
+  g_sim.or_acc[g] = 0;
+  return r;
+}
 
 // every live lane deposits `v`, all wait, every lane reads what it needs, all wait again (the slots are reused by the next call)
 template <typename T, typename Pick>
@@ -119,11 +143,21 @@ static inline int sim_update_dpp(int src, int ctrl, const void* s) {
 #define __popcll(x) __builtin_popcountll(x)
 #define __popc(x) __builtin_popcount(x)
 #define __ffsll(x) __builtin_ffsll(x)
+#define __ffs(x) __builtin_ffs(x)
+#define __threadfence_block() ((void)0)
 #define __clz(x) ((x) ? __builtin_clz(x) : 32)
 
 template <typename T> static inline T atomicAdd(T* p, T v) { const T old = *p; *p = old + v; return old; }
 template <typename T> static inline T atomicMax(T* p, T v) { const T old = *p; *p = old > v ? old : v; return old; }
 template <typename T> static inline T atomicMin(T* p, T v) { const T old = *p; *p = old < v ? old : v; return old; }
+template <typename T> static inline T atomicOr(T* p, T v) { const T old = *p; *p = old | v; return old; }
+// v_med3_f32: the median of three; with a NaN among them the hardware returns min3, which skips NaN
+static inline float sim_fmed3f(float a, float b, float c) {
+  if (a != a || b != b || c != c) return fminf(fminf(a, b), c);
+  return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+}
+#define __builtin_amdgcn_fmed3f(a, b, c) sim_fmed3f((a), (b), (c))
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 
 void sim_run_block(size_t nthreads, const SimIdx& bdim);
 

@@ -3,17 +3,18 @@ with g++ against a stand-in for the HIP runtime and run on the CPU:
   * thread by thread — detrend, window, runlen, reduce, spell, elemwise, eqm, wquantile (no LDS traffic between threads),
     and plane.hip with its wave-aggregated work-list appends as waves of one lane;
   * every workgroup as a set of FIBERS (simt.h: __syncthreads, wave-uniform shuffles / votes / readlane, atomics) — f64, select,
-    select5, tcount, qdm, quantile, doystats, reduce2, pdoy_top, pdoy_quad, pdoy_walk and the kernels of core.hip (transposes,
-    synthetic fields).
+    select2, select3, select4, select5, tcount, qdm, qdm2, quantile, doystats, reduce2, pdoy_top, pdoy_quad, pdoy_walk and the
+    kernels of core.hip (transposes, synthetic fields).
 63 of the 93 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
 other 30 are runtime services (memory, streams, RCCL).  The register percentile kernels (pdoy_top / pdoy_quad / pdoy_walk) run on
 fibers too, with the four ISA statements of topnet.h rewritten to the C++ they stand for, and so do the register sorting networks
-(select3 / qdm2: the DPP split across the lane pair as a shuffle).  select2's wave counts, the streaming selection of select4.hip
-and rocPRIM are NOT simulated: their launchers answer "not this kernel's shape" and the callers' general kernels run — exactly the
-fall-back the product takes for shapes those kernels decline.
+(select3 / qdm2: the DPP split across the lane pair as a shuffle), select2's wave counts on VCC and the streaming two-pass selection
+of select4.hip (DPP lane exchanges as shuffles, the execution-masked LDS appends as conditional stores, v_readlane from divergent
+code as publish + peek).  rocPRIM (qdm3.hip: the global sort behind xh_adapt_freq and the exact-rank fall-back of series beyond
+32768 steps) and RCCL are NOT simulated: those launchers answer "not built" and the tests that need them stay GPU-only.
 The SAME parity tests the GPU runs are re-run here: whole modules of the `-m gpu` suite (edges, patch, api, spells, f64, kernels,
-plane: ~740 tests, minus what forces or needs an ISA-level kernel) in two child pytest runs against the simulation library, plus a
-few direct calls.  The `-m gpu` runs remain the parity tests proper (the real
+plane: ~740 tests, minus the slow sizes) in two child pytest runs against the simulation library, selected tests of the
+ISA-level kernels in three more, plus a few direct calls.  The `-m gpu` runs remain the parity tests proper (the real
 kernels on the real device, the ISA-level ones included); the product has no CPU path: the simulation library is built into a
 temporary directory by this module only, and what is not simulated raises instead of pretending."""
 import os
@@ -130,8 +131,8 @@ def tapi():
 @pytest.mark.parametrize("kind", ["+", "*"])
 @pytest.mark.parametrize("interp", ["nearest", "linear", "cubic"])
 def test_qdm_adjust_on_fibers(sim, rng, tapi, kind, interp):
-    """QuantileDeltaMapping.adjust through the exact-rank kernel (qdm.hip: a column per workgroup, average ranks through LDS); the
-    one-year cut-value kernel and the streaming kernels are ISA-level and decline in the simulation."""
+    """QuantileDeltaMapping.adjust: the one-year cut-value kernel (qdm2.hip) for "nearest", the exact-rank kernel (qdm.hip: a column
+    per workgroup, average ranks through LDS) for the interpolating modes."""
     for T, cells in ((365, (7, 9)), (800, (33,)), (50, (4, 4)), (1, (3,))):
         tapi.test_qdm_adjust_matches_oracle(sim, rng, kind, interp, T, cells)
 
@@ -145,6 +146,12 @@ def _child_run(sim, files, skip="nothing_is_skipped", deselect=(), at_least=1):
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     env = dict(os.environ, XH_TEST_DEVICE="hostsim", HOSTSIM_LIB=sim.path)
     cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--timeout", "600", *files, "-k", f"not ({skip})"]
+    try:   # (the tests are independent and seeded one by one: four workers where pytest-xdist is installed)
+        import xdist  # noqa: F401
+
+        cmd += ["-n", str(min(4, os.cpu_count() or 1))]
+    except ImportError:
+        pass
     for d in deselect:
         cmd += ["--deselect", d]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True)
@@ -172,11 +179,13 @@ def test_selection_percentile_and_plane_modules_on_the_simulation(sim):
     """tests/test_gpu_kernels.py and tests/test_gpu_plane.py: every entry point against the oracle — counts, reductions, rolling,
     run lengths, calc_perc, percentile_doy (one year; multi-year through the LDS ring for the middle of the distribution), quantile
     series of 40 ... 55 152 steps incl. the hard distributions, EQM train / adjust (nearest, linear, cubic), the plane kernels.
-    Deselected: what forces or needs an ISA-level kernel (register sorts, two-pass histogram, register top-16 / quad / walk
-    percentile kernels) and the many-column sizes."""
+    Deselected here (and run, a few parameter sets each, by the three tests below): the tests of the register sorts, the two-pass
+    histogram, the register top-16 / quad / walk percentile kernels; and the many-column sizes."""
     skip = ("many_columns or percentile_doy_quad or percentile_doy_count_multi_year or percentile_doy_merge_path or walk_kernel or "
             "virtual_time_map or register_sort or two_pass")
-    _child_run(sim, ["tests/test_gpu_kernels.py", "tests/test_gpu_plane.py"], skip, at_least=300,
+    if not os.environ.get("HOSTSIM_SLOW"):   # (40 000 / 55 152 steps through select4's collect rounds + the radix select: 60 s here)
+        skip += " or beyond_32768"
+    _child_run(sim, ["tests/test_gpu_kernels.py", "tests/test_gpu_plane.py"], skip, at_least=290,
                deselect=["tests/test_gpu_kernels.py::test_percentile_doy[9-7-20-standard]",
                          "tests/test_gpu_kernels.py::test_percentile_doy[30-5-24-noleap]"])
 
@@ -207,3 +216,28 @@ def test_register_sorting_network_kernels_on_the_simulation(sim):
     k, a = "tests/test_gpu_kernels.py::", "tests/test_gpu_api.py::"
     _child_run(sim, [k + "test_quantile_series_one_year_register_sort", k + "test_quantile_series_register_sort_matches_histogram_kernels",
                      a + "test_qdm_nearest_one_year_cut_value_kernel", a + "test_qdm_precipitation_and_edge_cases"], at_least=30)
+
+
+def test_streaming_selection_kernels_on_the_simulation(sim):
+    """select4.hip — the two streaming passes behind the 30-year EQM training and the long-series QDM "nearest" (k_hs_sample,
+    k_hs_hist, k_hs_collect in both modes, the wave-wide bitonic sort of the candidates, k_cut_classify) — and select2.hip's lean
+    kernel, on fibers.  Rewritten for the host (simdevice.py, UNIT_REWRITES): the DPP lane exchanges of the bitonic network
+    (a shuffle), v_med3_i32 on the bits of a float difference (a clamp), v_min / v_max / v_min3 / v_max3 (fminf / fmaxf), the
+    sixteen LDS writes under the execution mask (conditional stores), the records hs_qdm_pick reads with v_readlane from
+    per-lane searches (published once, peeked after).  Small T of each GPU test; test_quantile_series_register_sort_matches_
+    histogram_kernels (other child run) now compares the register sort with THESE kernels bit for bit."""
+    k, a = "tests/test_gpu_kernels.py::", "tests/test_gpu_api.py::"
+    ids = [k + f"test_quantile_series_two_pass_histogram[{nq}-{T}]" for nq in (1, 20, 32) for T in (1025, 1300, 4000)]
+    ids += [k + "test_quantile_series_two_pass_value_classes"]
+    ids += [a + f"test_qdm_adjust_matches_oracle[{T}-cells{i}-nearest-{kind}]" for T, i in ((3000, 2), (10950, 3)) for kind in "+*"]
+    _child_run(sim, ids, at_least=len(ids))
+
+
+def test_quantile_mapping_api_on_the_simulation(sim):
+    """The sdba half of tests/test_gpu_api.py — EmpiricalQuantileMapping / QuantileDeltaMapping / DetrendedQuantileMapping through
+    the host mirror (xclim_amd/sdba.py: Grouper, month / season groupings, detrending, the 2-D interpolation over the
+    (quantile, group) plane) and every kernel behind it, the ISA-level ones included.  Left to the GPU: adapt_freq (rocPRIM),
+    series beyond 32768 steps (rocPRIM for the flagged columns), and the slow ones here (day-of-year groupings, bootstrap,
+    20 000+ steps)."""
+    _child_run(sim, ["tests/test_gpu_api.py"], at_least=60,
+               skip="not (qdm or eqm or dqm or sdba) or bootstrap or adapt or sub_groupings or beyond or dayofyear or 32768 or 20000")

@@ -1,6 +1,6 @@
 """The device a fuzzer runs on: the GPU (default), or — FUZZ_DEVICE=hostsim — the host simulation of tests/hostsim, where the
-kernels that are not written at ISA level run on the CPU (thread by thread / on fibers).  On the simulation the fuzzers exercise
-the GENERAL kernels (the ISA-level fast paths decline there), i.e. the fall-backs the GPU runs rarely reach."""
+kernels run on the CPU (thread by thread / on fibers; the ISA-level ones with their few ISA statements rewritten to C++, see
+tests/hostsim/simdevice.py).  Only what needs rocPRIM is missing there (xh_adapt_freq, QDM's exact-rank path beyond 32768 steps)."""
 import os
 import sys
 
