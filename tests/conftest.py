@@ -19,8 +19,8 @@ def dev(tmp_path_factory):
 
     XH_TEST_DEVICE=hostsim (an AUDIT switch, never the default): the `-m gpu` tests run against the host simulation of
     tests/hostsim instead — `XH_TEST_DEVICE=hostsim pytest -m gpu -n 8 --timeout 300 --deselect tests/test_gpu_fullsize.py`
-    shows which of them the simulation can serve (kernels written at ISA level decline there; a collective under divergent
-    control flow aborts the worker)."""
+    shows which of them the simulation can serve (all but those that need rocPRIM, RCCL or the real device's input cache; a
+    collective under divergent control flow would abort the worker)."""
     if os.environ.get("XH_TEST_DEVICE") == "hostsim":
         from tests.hostsim import simdevice
 

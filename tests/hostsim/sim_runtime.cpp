@@ -142,10 +142,8 @@ int xh_const_rows(xh_ctx* ctx, int64_t elems, const float** nan_row, const float
   if (pinf_row) *pinf_row = (const float*)(p + 2 * ctx->nanrow_bytes);
   return XH_OK;
 }
-// eqm.hip's quantile dispatch ends in the selection kernels (LDS, wave intrinsics): xh_eqm_train / xh_quantile_series are refused by
-// the simulated device; these only satisfy the linker
-// the kernels behind these are ISA-level (register sorting networks, DPP, buffer loads with LDS staging ...): every caller treats
-// XH_ERR_NOTIMPL as "not this kernel's shape" and takes its general kernel, which IS simulated
+// qdm3.hip (rocPRIM's segmented sort + the rank kernels behind it) is the one compute unit that is not simulated: its two entry
+// points exist for the linker and refuse
 struct QTab;
 int xh_qdm_sorted_ws(int64_t, int64_t, size_t* bytes) { *bytes = 0; return XH_ERR_NOTIMPL; }
 int xh_qdm_sorted(xh_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const double*, int, int, int, int, float*, int64_t, void*) {

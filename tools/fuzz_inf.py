@@ -99,8 +99,8 @@ while time.time() < t_end:
         try:
             got = K.percentile_doy(dev, dev.to_device(x), tb, w, per).get()
         except Exception as e:  # noqa: BLE001
-            # (FUZZ_DEVICE=hostsim: extreme percentiles of a multi-year period belong to the register top-16 kernels, which
-            #  are ISA-level and have no general kernel behind them: not simulated)
+            # (FUZZ_DEVICE=hostsim: an entry point the simulation lacks — none of this fuzzer's since the register percentile
+            #  kernels run on fibers; kept as a guard)
             if os.environ.get("FUZZ_DEVICE") == "hostsim" and getattr(e, "code", None) == -5:
                 stats["not_simulated"] = stats.get("not_simulated", 0) + 1
                 continue
