@@ -344,6 +344,20 @@ def make_reference_like_modules(env):
     ms.MissingAny = MissingAny
     mods[ms.__name__] = ms
 
+    im = types.ModuleType("xclim.core.indicator")
+
+    class Indicator:  # the data flow of core/indicator.py:865-944 + :1522-1549: compute, then the missing-value mask
+        def __init__(self, compute, src_freq="D"):
+            self.compute, self.src_freq = compute, src_freq
+
+        def __call__(self, da, *args, freq="YS", **kw):
+            out = self.compute(da, *args, freq=freq, **kw)
+            miss = ms.MissingAny()(da, freq, self.src_freq)
+            return out.where(~miss)
+
+    im.Indicator = Indicator
+    mods[im.__name__] = im
+
     # xsdba is not in the reference tree (src/xclim/sdba.py:10 re-exports the installed package): nothing to record —
     # qm_adjust below restates xsdba._adjustment.qm_adjust for group="time" (interp_on_quantiles + apply_correction)
     su = types.ModuleType("xsdba.utils")

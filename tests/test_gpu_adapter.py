@@ -90,10 +90,14 @@ def test_tx90p_through_the_wrappers_reaches_the_doy_table_kernel(ref, dev, rng):
 
 def test_inputs_and_tables_stay_on_the_device_across_wrapper_calls(ref, dev, rng):
     """VERDICT r4 #5 (caller: the Indicator chain, /root/reference/src/xclim/core/indicator.py:865-944): percentile_doy and
-    the index that consumes its table read the SAME field — ONE PCIe transfer of the field (Device.resident: address +
-    owner + content fingerprint), and the per-doy table is taken from the device copy percentile_doy left behind instead
-    of being transposed and uploaded again (xr_adapter.remember_table).  Asserted on the launch log: one "h2d" of the
-    field, no "h2d" of the table, one "d2h" of the table (the DataArray percentile_doy must return)."""
+    the index that consumes its table read the SAME field — inside a ``keep_inputs`` scope ONE PCIe transfer of the field
+    (Device.resident: address + owner + content fingerprint), and the per-doy table is taken from the device copy
+    percentile_doy left behind instead of being transposed and uploaded again (xr_adapter.remember_table).  Asserted on the
+    launch log: one "h2d" of the field, no "h2d" of the table, one "d2h" of the table (the DataArray percentile_doy must
+    return).  ADVICE r5: OUTSIDE a scope nothing is remembered — every call uploads its field, an in-place edit between
+    two calls can never be missed; the scope ends with every copy dropped."""
+    import xclim_amd
+
     env, mods, _ = ref
     T = 365 * 3
     ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
@@ -103,38 +107,62 @@ def test_inputs_and_tables_stay_on_the_device_across_wrapper_calls(ref, dev, rng
     keep_min = dev._inputs_min
     dev._inputs_min = 1 << 16          # (the default only remembers inputs of 32 MiB and more)
     dev.forget_inputs()
+    table = 365 * 24 * 40 * 8
     try:
+        assert dev._inputs_mode == "scope" and dev._keep_depth == 0
+        with xclim_amd.keep_inputs(dev):
+            trace = dev.start_trace()
+            per = cal.percentile_doy(tasmax, window=5, per=[10.0, 90.0])
+            out90 = mv.tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
+            out10 = mv.tn10p(tasmax, per.sel(percentiles=10.0), freq="YS")
+            dev.stop_trace()
+            p_o, doys = ocal.percentile_doy(x, ot, 5, [10.0, 90.0])
+            np.testing.assert_array_equal(out90.values, oidx.tx90p(x, p_o[..., 1], doys, ot, "YS"))
+            np.testing.assert_array_equal(out10.values, oidx.tx10p(x, p_o[..., 0], doys, ot, "YS"))
+            h2d = [a[0] for n, a in trace if n == "h2d"]
+            assert h2d.count(x.nbytes) == 1 and len([n for n, _ in trace if n == "resident_hit"]) == 2     # the field: once
+            assert table not in h2d and 2 * table not in h2d                                                # the tables: never
+            assert [a[0] for n, a in trace if n == "d2h"].count(2 * table) == 1
+            assert len(_calls(trace, "xh_threshold_count_doy")) == 2
+            # an edit in place is seen (30 whole rows: one element in 16 of a field this size is sampled) -> a fresh upload, the right answer
+            x2 = tasmax.values
+            x2[100:130] += np.float32(15.0)
+            trace = dev.start_trace()
+            out = mv.tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
+            dev.stop_trace()
+            np.testing.assert_array_equal(out.values, oidx.tx90p(x2, p_o[..., 1], doys, ot, "YS"))
+            assert [a[0] for n, a in trace if n == "h2d"].count(x.nbytes) == 1
+            # ... and so is an edit of the percentile table the user holds: the device copy is not used for it
+            per.values[:, :, 180:200, 1] -= 5.0
+            trace = dev.start_trace()
+            out = mv.tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
+            dev.stop_trace()
+            pe = p_o[..., 1].copy()
+            pe[180:200] -= 5.0
+            np.testing.assert_array_equal(out.values, oidx.tx90p(x2, pe, doys, ot, "YS"))
+            assert table in [a[0] for n, a in trace if n == "h2d"]
+            assert dev._inputs
+        assert not dev._inputs and dev._inputs_bytes == 0          # the scope is over: nothing stays behind
+        # outside a scope: a SPARSE edit (one cell, one step — no sample of the fingerprint touches it) between two calls.
+        # Round 5's process-wide cache would have answered from the stale device copy; now each call uploads the field.
+        x2[500, 7, 11] = np.float32(400.0)
         trace = dev.start_trace()
-        per = cal.percentile_doy(tasmax, window=5, per=[10.0, 90.0])
-        out90 = mv.tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
-        out10 = mv.tn10p(tasmax, per.sel(percentiles=10.0), freq="YS")
+        out_a = mv.tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
+        x2[501, 7, 11] = np.float32(400.0)
+        out_b = mv.tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
         dev.stop_trace()
-        p_o, doys = ocal.percentile_doy(x, ot, 5, [10.0, 90.0])
-        np.testing.assert_array_equal(out90.values, oidx.tx90p(x, p_o[..., 1], doys, ot, "YS"))
-        np.testing.assert_array_equal(out10.values, oidx.tx10p(x, p_o[..., 0], doys, ot, "YS"))
-        table = 365 * 24 * 40 * 8
-        h2d = [a[0] for n, a in trace if n == "h2d"]
-        assert h2d.count(x.nbytes) == 1 and len([n for n, _ in trace if n == "resident_hit"]) == 2     # the field: once
-        assert table not in h2d and 2 * table not in h2d                                                # the tables: never
-        assert [a[0] for n, a in trace if n == "d2h"].count(2 * table) == 1
-        assert len(_calls(trace, "xh_threshold_count_doy")) == 2
-        # an edit in place is seen (30 whole rows: one element in 16 of a field this size is sampled) -> a fresh upload, the right answer
-        x2 = tasmax.values
-        x2[100:130] += np.float32(15.0)
+        assert [a[0] for n, a in trace if n == "h2d"].count(x.nbytes) == 2 and not [n for n, _ in trace if n == "resident_hit"]
+        assert out_b.values[1, 7, 11] == out_a.values[1, 7, 11] + 1
+        np.testing.assert_array_equal(out_b.values, oidx.tx90p(x2, pe, doys, ot, "YS"))
+        # the Indicator call chain opens its own scope (patch.install wraps Indicator.__call__): compute + missing-value
+        # check on a field the valid-count cache does not know (an indexer forces the counting pass) -> one upload
+        ind = mods["xclim.core.indicator"].Indicator(lambda da, freq: mv.tx90p(da, per.sel(percentiles=90.0), freq=freq))
         trace = dev.start_trace()
-        out = mv.tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
+        got = ind(tasmax, freq="YS")
         dev.stop_trace()
-        np.testing.assert_array_equal(out.values, oidx.tx90p(x2, p_o[..., 1], doys, ot, "YS"))
         assert [a[0] for n, a in trace if n == "h2d"].count(x.nbytes) == 1
-        # ... and so is an edit of the percentile table the user holds: the device copy is not used for it
-        per.values[:, :, 180:200, 1] -= 5.0
-        trace = dev.start_trace()
-        out = mv.tx90p(tasmax, per.sel(percentiles=90.0), freq="YS")
-        dev.stop_trace()
-        pe = p_o[..., 1].copy()
-        pe[180:200] -= 5.0
-        np.testing.assert_array_equal(out.values, oidx.tx90p(x2, pe, doys, ot, "YS"))
-        assert table in [a[0] for n, a in trace if n == "h2d"]
+        np.testing.assert_array_equal(got.values, oidx.apply_missing(oidx.tx90p(x2, pe, doys, ot, "YS").astype(np.float64), x2, ot, "YS"))
+        assert not dev._inputs
     finally:
         dev._inputs_min = keep_min
         dev.forget_inputs()
@@ -304,10 +332,12 @@ def test_indicator_level_fusion_compute_and_missing_mask_in_one_pass(ref, dev, r
     x[10, 3, 3] = np.nan
     da = fakexr.field(x, ta)
     misser = mods["xclim.core.missing"].MissingAny()
+    assert "xclim.core.indicator.Indicator.__call__" in names
+    Ind = mods["xclim.core.indicator"].Indicator   # compute -> missing mask -> out.where(~mask); install() runs every call inside
+                                                   # a keep_inputs scope (nothing is remembered outside one)
 
-    def indicator(compute, *args, freq="YS", **kw):  # compute -> missing mask -> out.where(~mask), like Indicator.__call__
-        out = compute(da, *args, freq=freq, **kw)
-        return out.where(~misser(da, freq, "D"))
+    def indicator(compute, *args, freq="YS", **kw):
+        return Ind(lambda d, freq: compute(d, *args, freq=freq, **kw))(da, freq=freq)
 
     trace = dev.start_trace()
     got = indicator(mods["xclim.indices._simple"].tg_mean)
@@ -326,6 +356,14 @@ def test_indicator_level_fusion_compute_and_missing_mask_in_one_pass(ref, dev, r
     dev.stop_trace()
     assert len(_calls(trace, "xh_run_stats")) == 1 and not _calls(trace, "xh_resample_reduce")
     assert np.isnan(got.values[:, 1, 2]).sum() == 1 and np.isnan(got.values[0, 3, 3])
+    # outside a scope nothing is remembered: compute, a sparse in-place edit, then the check -> the check counts for itself
+    d2 = fakexr.field(x.copy(), ta)
+    mods["xclim.indices._simple"].tg_mean(d2, freq="YS")
+    d2.values[200, 0, 0] = np.nan
+    trace = dev.start_trace()
+    m = misser(d2, "YS", "D")
+    dev.stop_trace()
+    assert m.values[0, 0, 0] and len(_calls(trace, "xh_resample_reduce")) == 1
     # an input the wrappers have not seen: one counting pass on the device
     other = fakexr.field(x.copy(), ta)
     trace = dev.start_trace()
@@ -655,25 +693,27 @@ def test_dataarray_indexers_and_the_valid_cache(ref, dev, rng):
         gen.select_resample_op(da, "mean", "YS", doy_bounds=(start, 200))
     with pytest.raises(AssertionError, match="was reached"):
         misser(da, "YS", "D", doy_bounds=(start, 200))
-    gen.select_resample_op(da, "mean", "YS")
-    trace = dev.start_trace()
-    m1 = misser(da, "YS", "D")       # answered from the reducer's valid counts
-    m2 = misser(da, "YS", "D")       # one-shot: counted again
-    dev.stop_trace()
-    assert len(_calls(trace, "xh_resample_reduce")) == 1 and not m1.values.any() and not m2.values.any()
-    gen.select_resample_op(da, "mean", "YS")
-    da.values[0, 1, 1] = np.nan      # modified in place after the reducer ran
-    trace = dev.start_trace()
-    m3 = misser(da, "YS", "D")
-    dev.stop_trace()
-    assert len(_calls(trace, "xh_resample_reduce")) == 1 and m3.values[0, 1, 1] and m3.values.sum() == 1
-    np.testing.assert_array_equal(m3.values, oidx.missing_any(da.values, ot, "YS"))
-    # an edit of a step that is neither the first, a middle nor the last one (round 4 compared the NaN counts of
-    # those three steps only) is seen too — the fingerprint samples every row
-    gen.select_resample_op(da, "mean", "YS")
-    da.values[500, 2, 3] = np.nan
-    trace = dev.start_trace()
-    m4 = misser(da, "YS", "D")
-    dev.stop_trace()
-    assert len(_calls(trace, "xh_resample_reduce")) == 1 and m4.values[1, 2, 3]
-    np.testing.assert_array_equal(m4.values, oidx.missing_any(da.values, ot, "YS"))
+    # (the valid counts are only remembered inside a keep_inputs scope — what install() opens around an Indicator call)
+    with dev.keep_inputs():
+        gen.select_resample_op(da, "mean", "YS")
+        trace = dev.start_trace()
+        m1 = misser(da, "YS", "D")       # answered from the reducer's valid counts
+        m2 = misser(da, "YS", "D")       # one-shot: counted again
+        dev.stop_trace()
+        assert len(_calls(trace, "xh_resample_reduce")) == 1 and not m1.values.any() and not m2.values.any()
+        gen.select_resample_op(da, "mean", "YS")
+        da.values[0, 1, 1] = np.nan      # modified in place after the reducer ran
+        trace = dev.start_trace()
+        m3 = misser(da, "YS", "D")
+        dev.stop_trace()
+        assert len(_calls(trace, "xh_resample_reduce")) == 1 and m3.values[0, 1, 1] and m3.values.sum() == 1
+        np.testing.assert_array_equal(m3.values, oidx.missing_any(da.values, ot, "YS"))
+        # an edit of a step that is neither the first, a middle nor the last one (round 4 compared the NaN counts of
+        # those three steps only) is seen too — the fingerprint samples every row
+        gen.select_resample_op(da, "mean", "YS")
+        da.values[500, 2, 3] = np.nan
+        trace = dev.start_trace()
+        m4 = misser(da, "YS", "D")
+        dev.stop_trace()
+        assert len(_calls(trace, "xh_resample_reduce")) == 1 and m4.values[1, 2, 3]
+        np.testing.assert_array_equal(m4.values, oidx.missing_any(da.values, ot, "YS"))

@@ -20,6 +20,16 @@ def G():
     return np.load(PATH)
 
 
+def has(G, key, since):
+    """A key the generator writes since its round `since`: a fixture of that format or a later one MUST hold it (a
+    missing key used to pass silently); only a fixture older than the key may lack it."""
+    if key in G.files:
+        return True
+    fmt = int(G["format"]) if "format" in G.files else 4
+    assert fmt < since, f"{key} is missing from a format-{fmt} fixture: regenerate tests/golden/sdba_vectors.npz"
+    return False
+
+
 @needs_fixture
 def test_nodes_and_quantile(dev, G):
     np.testing.assert_allclose(xsdba.equally_spaced_nodes(20), G["nodes_20"], rtol=1e-15)
@@ -42,7 +52,7 @@ def test_eqm_qdm_dqm_against_xsdba(dev, G, kind):
                                        err_msg=f"{interp} {extrap}")
     qdm = xsdba.QuantileDeltaMapping.train(r, h, nquantiles=20, kind=kind, device=dev)
     for interp in ("nearest", "linear", "cubic"):
-        if f"qdm_{k}_{interp}" in G.files:   # (cubic: fixtures generated since round 5)
+        if interp != "cubic" or has(G, f"qdm_{k}_{interp}", 5):   # (cubic: fixtures generated since round 5)
             np.testing.assert_allclose(qdm.adjust(s, interp=interp), G[f"qdm_{k}_{interp}"], rtol=2e-6 if interp == "cubic" else RTOL,
                                        equal_nan=True, err_msg=interp)
     dqm = xsdba.DetrendedQuantileMapping.train(r, h, nquantiles=20, kind=kind, device=dev)
@@ -62,13 +72,13 @@ def test_grouped_eqm_against_xsdba(dev, G, group, window):
     np.testing.assert_allclose(eqm.hist_q, G[f"eqmg_{tag}_hist_q"], rtol=RTOL, equal_nan=True)
     np.testing.assert_allclose(eqm.af, G[f"eqmg_{tag}_af"], rtol=RTOL, atol=1e-6, equal_nan=True)
     np.testing.assert_allclose(eqm.adjust(G["sim"], interp="nearest", time=ta), G[f"eqmg_{tag}_scen"], rtol=RTOL, equal_nan=True)
-    if f"eqmg_{tag}_scen_linear" in G.files:   # (fixtures generated before round 5 lack the linear keys)
+    if has(G, f"eqmg_{tag}_scen_linear", 5):   # (fixtures generated before round 5 lack the linear keys)
         np.testing.assert_allclose(eqm.adjust(G["sim"], interp="linear", time=ta), G[f"eqmg_{tag}_scen_linear"], rtol=RTOL, equal_nan=True)
         qdm = xsdba.QuantileDeltaMapping.train(G["ref"], G["hist"], nquantiles=15, kind="+", group=group, window=window, time=ta, device=dev)
         # (month: the regular (quantile, group) grid has no unique Delaunay triangulation — see test_qdm_grouped_matches_oracle)
         tol = dict(rtol=RTOL) if tag == "dayofyear" else dict(rtol=1e-3, atol=0.05)
         np.testing.assert_allclose(qdm.adjust(G["sim"], interp="linear", time=ta), G[f"qdmg_{tag}_scen_linear"], equal_nan=True, **tol)
-        if f"dqmg_{tag}_af" in G.files:   # DQM with the (windowed) Grouper: round 5
+        if has(G, f"dqmg_{tag}_af", 5):   # DQM with the (windowed) Grouper: round 5
             dqm = xsdba.DetrendedQuantileMapping.train(G["ref"], G["hist"], nquantiles=15, kind="+", group=group, window=window, time=ta,
                                                        device=dev)
             np.testing.assert_allclose(dqm.scaling, G[f"dqmg_{tag}_scaling"], rtol=RTOL)

@@ -65,6 +65,7 @@ class MockDevice(Device):
         self._pool, self._pool_bytes, self._pool_cap, self._pinned = {}, 0, 0, {}
         self._bufs = {}
         self._inputs, self._inputs_bytes, self._inputs_cap, self._inputs_min = {}, 0, 0, 1 << 62   # (no input cache)
+        self._inputs_mode, self._keep_depth, self._forget_hooks = "scope", 0, []   # (scopes exist, no field is ever large enough)
 
     def empty(self, shape, dtype) -> DeviceArray:
         shape = (shape,) if np.isscalar(shape) else tuple(shape)

@@ -6,3 +6,12 @@ Layers: ``csrc/`` hand-written HIP kernels behind the C ABI of ``inc
 """
 
 __version__ = "0.1.0"
+
+
+def keep_inputs(device=None):
+    """``with xclim_amd.keep_inputs(): ...`` — inside the block a large host field handed to several calls (``percentile_doy``
+    then ``tx90p``; an index then its missing-value check) crosses PCIe ONCE (``Device.resident``).  The contract: no
+    field is edited in place inside the block.  Outside such a block every call uploads its inputs."""
+    from ._capi import get_device
+
+    return (device or get_device()).keep_inputs()

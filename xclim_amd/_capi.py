@@ -294,7 +294,16 @@ class Device:
         # device copies of large host inputs, recognised again across calls (resident())
         self._inputs: dict = {}
         self._inputs_bytes = 0
-        self._inputs_cap = int(os.environ.get("XCLIM_AMD_INPUT_CACHE_BYTES", str(64 << 30)))
+        # "scope" (default): only inside `with dev.keep_inputs():` (patch.install() opens one around every Indicator
+        # call); "always": across every call of the process (the caller promises not to edit fields in place, or calls
+        # forget_inputs() after doing so); "off"
+        self._inputs_mode = os.environ.get("XCLIM_AMD_INPUT_CACHE", "scope").lower()
+        if self._inputs_mode not in ("scope", "always", "off"):
+            raise ValueError(f"XCLIM_AMD_INPUT_CACHE must be scope, always or off, got {self._inputs_mode!r}")
+        self._keep_depth = 0
+        self._forget_hooks: list = []  # run by forget_inputs(): caches that live and die with the input copies (xr_adapter's tables)
+        cap = os.environ.get("XCLIM_AMD_INPUT_CACHE_BYTES")
+        self._inputs_cap = int(cap) if cap is not None else None  # None: half of the free device memory at first use
         self._inputs_min = int(os.environ.get("XCLIM_AMD_INPUT_CACHE_MIN", str(32 << 20)))
 
     # ---- memory ----
@@ -310,6 +319,12 @@ class Device:
         rc = self.lib.xh_malloc(self.ctx, nbytes, C.byref(p))
         if rc != XH_OK and self._pool_bytes:
             self.trim()  # out of memory with buffers parked in the pool: give them back and retry once
+            rc = self.lib.xh_malloc(self.ctx, nbytes, C.byref(p))
+        while rc != XH_OK and self._inputs:
+            # ... or with remembered input copies (resident()): the least recently used one goes, its memory passes
+            # through the pool back to the driver, and the allocation is tried again
+            self._drop_input(next(iter(self._inputs)))
+            self.trim()
             rc = self.lib.xh_malloc(self.ctx, nbytes, C.byref(p))
         _check(self.lib, rc)
         return DeviceArray(self, p.value, shape, dtype, alloc=nbytes)
@@ -403,27 +418,60 @@ class Device:
     # SAME field, and so do an index and the missing-value check after it) ----
     @staticmethod
     def _host_fingerprint(flat: np.ndarray):
-        """Guard against a buffer edited in place between two calls: the bit patterns of ~2^16 evenly spaced samples plus
-        the first and last 4096 elements, summed as integers (every element of arrays up to 2^16 elements; ~0.5 ms on a
-        1.5 GB field against 27 ms for its upload — 2^20 samples cost 4-5 ms per call, a page miss each).  An
-        edit that touches none of the samples is NOT seen: after writing into a field in place call
-        :meth:`forget_inputs` (or set XCLIM_AMD_INPUT_CACHE_BYTES=0)."""
+        """Second guard against a buffer edited in place while it is remembered: the bit patterns of ~2^16 evenly spaced
+        samples plus the first and last 4096 elements, summed as integers (every element of arrays up to 2^16 elements;
+        ~0.5 ms on a 1.5 GB field against 27 ms for its upload).  An edit that touches none of the samples is NOT seen,
+        and a full checksum costs as much as the transfer it would save (host memory bandwidth ~ PCIe bandwidth) — which
+        is why the cache is SCOPED (:meth:`keep_inputs`) instead of trusting this."""
         n = flat.size
         step = max(1, n >> 16)
         u = flat.view(np.uint32 if flat.dtype.itemsize == 4 else np.uint64)
         return (n, int(u[::step].sum(dtype=np.uint64)), int(u[:4096].sum(dtype=np.uint64)), int(u[-4096:].sum(dtype=np.uint64)))
 
+    def keep_inputs(self):
+        """Context manager: inside it, large host inputs stay on the device from one call to the next
+        (:meth:`resident`); at the exit of the outermost scope every copy is dropped.  The contract of a scope: no field
+        handed to this library is edited IN PLACE while the scope is open (or :meth:`forget_inputs` is called after the
+        edit).  ``patch.install()`` opens one around every ``Indicator.__call__`` — compute, its ``percentile_doy`` /
+        ``resample_doy`` helpers and the missing-value check read the same DataArray and no user code runs in between;
+        user code chains calls with ``with xclim_amd.keep_inputs(): per = percentile_doy(tasmax); out = tx90p(tasmax, per)``.
+        Outside a scope every call uploads its inputs (the behaviour before round 5) unless XCLIM_AMD_INPUT_CACHE=always."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            with self.lock:
+                self._keep_depth += 1
+            try:
+                yield self
+            finally:
+                with self.lock:
+                    self._keep_depth -= 1
+                    last = self._keep_depth == 0
+                if last and self._inputs_mode != "always":
+                    self.forget_inputs()
+
+        return scope()
+
+    def _inputs_active(self) -> bool:
+        return self._inputs_mode == "always" or (self._inputs_mode == "scope" and self._keep_depth > 0)
+
     def resident(self, arr: np.ndarray) -> DeviceArray:
-        """Device copy of a C-contiguous float32 / float64 host array.  Large arrays (>= XCLIM_AMD_INPUT_CACHE_MIN bytes,
-        default 32 MiB) are remembered by (address, shape, dtype) together with a weak reference to the object that owns
-        the memory and a content fingerprint; the next call with the same buffer gets the SAME device memory (a view: the
-        kernels only read their inputs) instead of another PCIe transfer.  The cache holds at most
-        XCLIM_AMD_INPUT_CACHE_BYTES (default 64 GiB, 0 = off), least recently used first out, and an entry dies with its
-        host array."""
+        """Device copy of a C-contiguous float32 / float64 host array.  Inside a :meth:`keep_inputs` scope large arrays
+        (>= XCLIM_AMD_INPUT_CACHE_MIN bytes, default 32 MiB) are remembered by (address, shape, dtype) together with a weak
+        reference to the object that owns the memory and a content fingerprint; the next call with the same buffer gets
+        the SAME device memory (a view: the kernels only read their inputs) instead of another PCIe transfer.  The cache
+        holds at most XCLIM_AMD_INPUT_CACHE_BYTES (default: half of the device memory free at first use; 0 = off), least
+        recently used first out — also when an allocation fails (:meth:`empty`) —, and an entry dies with its host array
+        or with the scope.  Outside a scope: a plain upload."""
         import weakref
 
-        if (not isinstance(arr, np.ndarray) or not arr.flags.c_contiguous or arr.nbytes < self._inputs_min
-                or arr.nbytes > self._inputs_cap or arr.dtype not in (np.float32, np.float64)):
+        if (not self._inputs_active() or not isinstance(arr, np.ndarray) or not arr.flags.c_contiguous
+                or arr.nbytes < self._inputs_min or arr.dtype not in (np.float32, np.float64)):
+            return self.to_device(arr)
+        if self._inputs_cap is None:
+            self._inputs_cap = self.mem_info()[0] // 2
+        if arr.nbytes > self._inputs_cap:
             return self.to_device(arr)
         owner = arr
         while isinstance(owner.base, np.ndarray):
@@ -472,6 +520,8 @@ class Device:
         with self.lock:
             self._inputs.clear()
             self._inputs_bytes = 0
+        for hook in list(self._forget_hooks):
+            hook()
 
     def wrap(self, ptr: int, shape, dtype) -> DeviceArray:
         """Wrap foreign device memory (e.g. a torch tensor's data_ptr()) without taking ownership."""

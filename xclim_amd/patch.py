@@ -175,6 +175,24 @@ def install(env=None, modules=None) -> list[str]:
         orig["MissingAny.__call__"] = _saved[("xclim.core.missing", "MissingAny.__call__")]
         cls.__call__ = wrappers["MissingAny.__call__"]
         done.append("xclim.core.missing.MissingAny.__call__")
+    # Indicator.__call__ (core/indicator.py:865-944): parse -> compute (the index, its percentile / resample helpers) ->
+    # missing-value check (:1522-1549), all on the same DataArrays and without user code in between: ONE scope of
+    # device-resident inputs (Device.keep_inputs) per call, dropped when the call returns
+    ind_mod = resolve("xclim.core.indicator")
+    icls = getattr(ind_mod, "Indicator", None) if ind_mod is not None else None
+    if icls is not None:
+        if ("xclim.core.indicator", "Indicator.__call__") not in _saved:
+            _saved[("xclim.core.indicator", "Indicator.__call__")] = icls.__call__
+        icall = _saved[("xclim.core.indicator", "Indicator.__call__")]
+
+        def _indicator_call(self, *args, **kwds):
+            with get_device().keep_inputs():
+                return icall(self, *args, **kwds)
+
+        _indicator_call.__wrapped__ = icall
+        _indicator_call.__doc__ = icall.__doc__
+        icls.__call__ = _indicator_call
+        done.append("xclim.core.indicator.Indicator.__call__")
     # xsdba (third party, re-exported by src/xclim/sdba.py:10): the per-cell multi-quantile entry point; xsdba's own
     # modules reach it through the module object (``nbu.quantile``), so the one attribute is enough
     patch("xsdba.nbutils", "quantile", wrappers["sdba_quantile"])

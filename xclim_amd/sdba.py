@@ -769,6 +769,12 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
                 src = K.select_rows(dev, s_perm, inv_perm)     # ... and in time order
             wm_perm = K.select_rows(dev, K.window_nanmean(dev, src, self.group.window), perm)
         off = 0
+        plane_nearest = interp != "linear" and self._plane_nearest(grouped_nearest)   # (decided — and warned about — once)
+        # interp="linear": every group's block is detrended into ONE group-major buffer and the (quantile, group) plane is
+        # interpolated over the whole series in a single xh_plane_linear call, as EQM.adjust does (one call per
+        # group packed the (G, nq, C) tables and synchronised 365 times for a day-of-year grouping)
+        detr_perm = dev.empty((T, C_), np.float32) if interp == "linear" else None
+        trends = []
         for g, n in enumerate(counts):
             n = int(n)
             if n == 0:
@@ -783,15 +789,23 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             scaled = blk if (prescaled or windowed) else K.trend_apply(dev, blk, sc_g, None, fwd)
             fit_on = scaled if not windowed else dev.wrap(wm_perm.ptr + off * C_ * 4, (n, C_), np.float32)
             p0, p1 = K.poly_trend(dev, fit_on, detrend, u=u)
-            detr = K.trend_apply(dev, scaled, p0, p1, inv, u=u)
             if interp == "linear":
-                scen0 = K.plane_linear(dev, detr, gcoord[rows], self._af, xq_all=self._hist_q, kind=self.kind)
-            elif self._plane_nearest(grouped_nearest):
+                K.trend_apply(dev, scaled, p0, p1, inv, u=u, out=dev.wrap(detr_perm.ptr + off * C_ * 4, (n, C_), np.float32))
+                trends.append((off, n, p0, p1, u))
+                off += n
+                continue
+            detr = K.trend_apply(dev, scaled, p0, p1, inv, u=u)
+            if plane_nearest:
                 scen0 = K.eqm_adjust_g2d(dev, detr, self._af, self._hist_q, g + 1, self.kind, extrapolation)
             else:
                 scen0 = K.eqm_adjust(dev, detr, af_g, hq_g, self.kind, interp, extrapolation)
             K.trend_apply(dev, scen0, p0, p1, fwd, out=out, u=u)
             off += n
+        if interp == "linear":
+            scen0 = K.plane_linear(dev, detr_perm, gcoord[perm], self._af, xq_all=self._hist_q, kind=self.kind)
+            for off, n, p0, p1, u in trends:
+                K.trend_apply(dev, dev.wrap(scen0.ptr + off * C_ * 4, (n, C_), np.float32), p0, p1, fwd,
+                              out=dev.wrap(scen_perm.ptr + off * C_ * 4, (n, C_), np.float32), u=u)
         scen = K.select_rows(dev, scen_perm, inv_perm)
         dev.sync()
         return scen if keep else scen.get().reshape((T,) + self.cell_shape)

@@ -281,6 +281,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     import weakref
 
     valid_cache = {}
+    valid_hooked = []  # devices whose forget_inputs() also clears this cache
 
     def _buffer_key(x, freq, indexer):
         ai = x.__array_interface__
@@ -308,6 +309,12 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     def remember_valid(da, x, freq, valid, indexer=None):
         """`x`: the C-contiguous time-first values the kernel read.  Only buffers that ARE the DataArray's own storage can be
         recognised again (a transposed / non-contiguous input was copied by _tfirst: nothing to remember)."""
+        d = dev()
+        if not d._inputs_active():  # only inside a keep_inputs scope (Indicator.__call__ opens one): same contract as the input copies
+            return
+        if d not in valid_hooked:
+            valid_hooked.append(d)
+            d._forget_hooks.append(valid_cache.clear)
         base = da.values if isinstance(da, DA) else None
         if base is None or not isinstance(base, np.ndarray) or base.__array_interface__["data"][0] != x.__array_interface__["data"][0]:
             return
@@ -336,6 +343,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     # transposed and uploaded again (3 GB for a 1440 x 720 grid).  Guarded like the input cache: weak reference to the
     # owner + the bit patterns of three day-of-year rows.
     table_cache = {}
+    hooked = []
 
     def _owner_of(v):
         while isinstance(getattr(v, "base", None), np.ndarray):
@@ -343,32 +351,49 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         return v
 
     def _rows_fingerprint(tv):
+        """Bit patterns of up to 32 evenly spaced day-of-year rows (three rows let an edit of any other row
+        through), each sampled at up to 2^14 evenly spaced cells: ~1 ms on the 3 GB table of a 1440 x 720 grid."""
+        if tv.dtype != np.float64 or not tv.size:
+            return None
         n = tv.shape[0]
-        rows = np.ascontiguousarray(tv[sorted({0, n // 2, n - 1})])
-        return int(rows.view(np.uint64).sum(dtype=np.uint64)) if rows.dtype == np.float64 else None
+        rows = tv[np.unique(np.linspace(0, n - 1, min(n, 32)).astype(np.intp))].reshape(-1, int(np.prod(tv.shape[1:], dtype=np.int64)))
+        rows = np.ascontiguousarray(rows[:, ::max(1, rows.shape[1] >> 14)])
+        return int(rows.view(np.uint64).sum(dtype=np.uint64)), int(np.isnan(rows).sum())
 
     def remember_table(vals, p):
-        """vals: the host array (ndoy, *cells, nper) the returned DataArray is built on; p: the device DoyPercentile."""
+        """vals: the host array (ndoy, *cells, nper) the returned DataArray is built on; p: the device DoyPercentile.
+        Like the input copies (Device.resident) the device table is only remembered inside a ``keep_inputs`` scope and dies
+        with it — or with the host array, whichever comes first (the entry holds NO reference to the host data: address,
+        shape and strides of each percentile's slice only)."""
+        d = dev()
+        if not d._inputs_active():
+            return
         owner = _owner_of(vals)
         try:
             ref = weakref.ref(owner)
         except TypeError:
             return
+        if d not in hooked:
+            hooked.append(d)
+            d._forget_hooks.append(table_cache.clear)
         if len(table_cache) > 8:
             table_cache.clear()
-        table_cache[id(owner)] = (ref, vals, p, [_rows_fingerprint(vals[..., j]) for j in range(vals.shape[-1])])
+        slices = []
+        for j in range(vals.shape[-1]):
+            v = vals[..., j]
+            slices.append((v.ctypes.data, v.shape, v.strides, _rows_fingerprint(v)))
+        table_cache[id(owner)] = (ref, slices, p)
+        weakref.finalize(owner, table_cache.pop, id(owner), None)
 
     def recall_table(tv):
         """tv: (ndoy, *cells) float64 view.  -> device DoyPercentile of that one percentile, or None."""
         owner = _owner_of(tv)
         hit = table_cache.get(id(owner))
-        if hit is None or hit[0]() is not owner:
+        if hit is None or hit[0]() is not owner or not dev()._inputs_active():
             return None
-        _, vals, p, fps = hit
-        for j in range(vals.shape[-1]):
-            cand = vals[..., j]
-            if (cand.shape == tv.shape and cand.strides == tv.strides and cand.ctypes.data == tv.ctypes.data
-                    and fps[j] is not None and fps[j] == _rows_fingerprint(tv)):
+        _, slices, p = hit
+        for j, (addr, shape, strides, fp) in enumerate(slices):
+            if shape == tv.shape and strides == tv.strides and addr == tv.ctypes.data and fp is not None and fp == _rows_fingerprint(tv):
                 return p.sel(p.percentiles[j])
         return None
 
