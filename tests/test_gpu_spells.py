@@ -737,3 +737,33 @@ def test_thresholded_events_reference_known_answers(dev):
     np.testing.assert_array_equal(out["event_effective_length"][:, :3, 0], [[6, 6, 4], [3, 5, np.nan]])
     np.testing.assert_array_equal(out["event_sum"][:, :3, 0], [[22, 12, 10], [5, 17, np.nan]])
     np.testing.assert_array_equal(out["event_start"][:, :3, 0], [[3, 16, 27], [0, 6, np.nan]])  # days into the month
+
+
+@pytest.mark.parametrize("axis", [1, 2, -1])
+def test_run_lengths_along_another_axis(dev, rng, axis):
+    """rl:223, 275, 338, 381, 437, 643, 693: ``dim`` is any dimension of the DataArray.  The numpy mirrors take the run axis as
+    an integer ``dim`` (axis moved first, same kernels, full-shape results get the axis back); the oracle runs along axis 0 of
+    the moved array.  Resampling belongs to the time axis and is refused with another ``dim``."""
+    from oracle import run_length as orl
+    from xclim_amd import run_length as hrl
+
+    m = (rng.random((40, 37, 23)) < 0.6).astype(np.float32)
+    m[rng.random(m.shape) < 0.02] = np.nan
+    mv = np.moveaxis(m, axis, 0)
+    for index in ("first", "last"):
+        np.testing.assert_array_equal(hrl.rle(m, axis, index, device=dev), np.moveaxis(orl.rle(mv, index), 0, axis))
+        np.testing.assert_array_equal(hrl.rle_statistics(m, "max", 2, axis, None, False, index, device=dev), orl.rle_statistics(mv, "max", 2, index=index, ufunc_1dim=False))
+    np.testing.assert_array_equal(hrl.longest_run(m, axis, None, False, device=dev), orl.longest_run(mv, ufunc_1dim=False))
+    np.testing.assert_array_equal(hrl.windowed_run_count(m, 3, axis, None, False, device=dev), orl.windowed_run_count(mv, 3, ufunc_1dim=False))
+    np.testing.assert_array_equal(hrl.windowed_run_events(m, 3, axis, None, False, device=dev), orl.windowed_run_events(mv, 3, ufunc_1dim=False))
+    # (the default dispatch: a grid this small takes the 1-D rules around NaN steps in both, rl:33-78)
+    np.testing.assert_array_equal(hrl.longest_run(m, axis, device=dev), orl.longest_run(mv))
+    np.testing.assert_array_equal(hrl.first_run(m, 3, axis, device=dev), orl.first_run(mv, 3))
+    np.testing.assert_array_equal(hrl.last_run(m, 3, axis, device=dev), orl.last_run(mv, 3))
+    np.testing.assert_array_equal(hrl._cumsum_reset(m, axis, "last", device=dev), np.moveaxis(orl.cumsum_reset(mv, "last"), 0, axis))
+    from xclim_amd.timeaxis import TimeAxis
+
+    with pytest.raises(ValueError, match="resample the time axis"):
+        hrl.longest_run(m, axis, "YS", time=TimeAxis.daily("2001-01-01", m.shape[axis], "noleap"), device=dev)
+    with pytest.raises(NotImplementedError, match="integer axis"):
+        hrl.longest_run(m, "lat", device=dev)

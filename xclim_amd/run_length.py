@@ -554,8 +554,15 @@ def first_run_ufunc(x, window: int, dim="time", *, device=None):
     return first_run(x, window, dim, device=device)
 
 
+_FULL_SHAPE = ("_cumsum_reset", "rle", "keep_longest_run", "runs_with_holes", "suspicious_run")  # results shaped like the input
+
+
 def _time_dim_only(fn):
-    """The kernels march along axis 0 = time; a different ``dim`` must not be ignored silently."""
+    """The kernels march along axis 0.  ``dim``: "time" (axis 0, the run dimension of every index function) or — the mirrors
+    take plain arrays, which have no dimension names — an INTEGER axis (rl:223, 275, 338: any ``dim`` of the DataArray):
+    that axis is moved first (a view; the upload copies it once), the same kernels run, full-shape results get their axis
+    back.  Resampling (``freq`` / ``time``) belongs to the time axis, so it needs ``dim="time"``.  Any other name is refused
+    rather than ignored."""
     import functools
     import inspect
 
@@ -563,8 +570,25 @@ def _time_dim_only(fn):
 
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
-        if sig.bind_partial(*args, **kwargs).arguments.get("dim", "time") != "time":
-            raise NotImplementedError(f"{fn.__name__}: only dim='time' (axis 0) is supported on the HIP path")
+        ba = sig.bind_partial(*args, **kwargs)
+        dim = ba.arguments.get("dim", "time")
+        if isinstance(dim, (int, np.integer)) and not isinstance(dim, bool):
+            if ba.arguments.get("freq") is not None or ba.arguments.get("time") is not None:
+                raise ValueError(f"{fn.__name__}: freq / time resample the time axis: use dim='time' (axis 0)")
+            if ba.arguments.get("keep") or ba.arguments.get("coord"):
+                raise NotImplementedError(f"{fn.__name__}: keep= / coord= need the run axis first (dim='time')")
+            ax = int(dim)
+            for name in ("da", "arr", "x", "mask", "da_start", "da_stop"):
+                v = ba.arguments.get(name)
+                if v is not None:
+                    if isinstance(v, DeviceArray):
+                        raise NotImplementedError(f"{fn.__name__}: device arrays must have the run axis first (dim='time')")
+                    ba.arguments[name] = np.moveaxis(np.asarray(v), ax, 0)
+            ba.arguments["dim"] = "time"
+            out = fn(*ba.args, **ba.kwargs)
+            return np.moveaxis(out, 0, ax) if fn.__name__ in _FULL_SHAPE else out
+        if dim != "time":
+            raise NotImplementedError(f"{fn.__name__}: dim is 'time' (axis 0) or an integer axis on the HIP path, got {dim!r}")
         return fn(*args, **kwargs)
 
     return wrapper

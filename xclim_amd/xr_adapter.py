@@ -34,7 +34,8 @@ wrappers remember it per input buffer and the replaced ``MissingAny.__call__`` (
 the same DataArray right after the compute, core/indicator.py:1522-1549) answers from it — compute and missing-value
 mask in ONE pass over the data; unit conversion costs no pass either, because the reference converts the THRESHOLD to
 the data's units (``convert_units_to(thresh, data)``), not the data.  A call a wrapper cannot serve (callable ``op``, thresholds with unexpected dims, ``dim != "time"``) is
-forwarded to the ORIGINAL function (``orig``), never approximated.
+forwarded to the ORIGINAL function (``orig``), never approximated.  The run-length functions accept any ``dim`` of an
+in-memory DataArray when no resampling is asked for (the DataArray is transposed so that ``dim`` comes first).
 """
 
 from __future__ import annotations
@@ -699,38 +700,85 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
     def _rl_out(a, out, freq, name=None):
         return wrap_cells(a, out, name=name) if freq is None else wrap_periods(a, out, freq, name=name)
 
+    # ---- run lengths along another dimension (rl:223, 275, 338: ``dim`` is any dimension of the DataArray) --------------------
+    # Without a resampling frequency nothing in these functions is about TIME: the DataArray is transposed so that `dim`
+    # comes first and the same kernels march along it (the numpy mirrors take the axis as ``dim=0``).  What stays with the
+    # reference: a resampling frequency on another dimension, chunked inputs, ``coord=<datetime accessor name>``.
+    def _along(da, dim):
+        """(DataArray with `dim` first, its values as a float mask) — or None when the call belongs to the reference"""
+        if isinstance(da, _LazyBase):
+            da = da._get()
+        if not isinstance(da, DA) or dim not in da.dims or is_chunked(da):
+            return None
+        a = da.transpose(dim, ...)
+        x = np.ascontiguousarray(a.values)
+        return a, (x.astype(np.float32) if x.dtype == bool else x)
+
+    def _wrap_others(a, dim, data, name=None):
+        """(*other dims) result: every coordinate that does not run along `dim` stays (xarray's reductions keep them)"""
+        coords = {k: v for k, v in a.coords.items() if dim not in getattr(v, "dims", ())}
+        return DA(np.asarray(data), coords=coords, dims=tuple(d for d in a.dims if d != dim), name=name)
+
+    def _rl_other_dim(name, host_call, da, dim, freq, *fb_args):
+        got = _along(da, dim) if freq is None else None
+        if got is None:
+            return fallback(name, *fb_args)
+        a, x = got
+        return _wrap_others(a, dim, host_call(x))
+
     def rle(da, dim="time", index="first"):  # rl:223-272
-        if dim != "time" or (isinstance(da, DA) and is_chunked(da)):  # (a chunked full-shape result: the reference's dask path)
+        if isinstance(da, DA) and is_chunked(da):  # (a chunked full-shape result: the reference's dask path)
             return fallback("rle", da, dim, index)
+        if dim != "time":
+            got = _along(da, dim)
+            if got is None:
+                return fallback("rle", da, dim, index)
+            a, x = got
+            return DA(hrl.rle(x, 0, index, device=dev()), coords=dict(a.coords), dims=a.dims, attrs=dict(da.attrs))
         a, x, _ = _mask_values(da)
         return wrap_full(a, hrl.rle(x, dim, index, device=dev()), da.attrs if isinstance(da, DA) else None)
 
     def rle_statistics(da, reducer, window, dim="time", freq=None, ufunc_1dim="from_context", index="first"):  # rl:275-335
         if dim != "time":
-            return fallback("rle_statistics", da, reducer, window, dim, freq, ufunc_1dim, index)
+            return _rl_other_dim("rle_statistics", lambda x: hrl.rle_statistics(x, reducer, window, 0, None, ufunc_1dim, index, device=dev()),
+                                 da, dim, freq, da, reducer, window, dim, freq, ufunc_1dim, index)
         a, x, t = _mask_values(da)
         return _rl_out(a, rl_blocks(a, x, lambda xb: hrl.rle_statistics(xb, reducer, window, dim, freq, ufunc_1dim, index, time=t, device=dev())), freq)
 
     def longest_run(da, dim="time", freq=None, ufunc_1dim="from_context", index="first"):  # rl:338-378
         if dim != "time":
-            return fallback("longest_run", da, dim, freq, ufunc_1dim, index)
+            return _rl_other_dim("longest_run", lambda x: hrl.longest_run(x, 0, None, ufunc_1dim, index, device=dev()),
+                                 da, dim, freq, da, dim, freq, ufunc_1dim, index)
         a, x, t = _mask_values(da)
         return _rl_out(a, rl_blocks(a, x, lambda xb: hrl.longest_run(xb, dim, freq, ufunc_1dim, index, time=t, device=dev())), freq)
 
     def windowed_run_events(da, window, dim="time", freq=None, ufunc_1dim="from_context", index="first"):  # rl:381-434
         if dim != "time":
-            return fallback("windowed_run_events", da, window, dim, freq, ufunc_1dim, index)
+            return _rl_other_dim("windowed_run_events", lambda x: hrl.windowed_run_events(x, window, 0, None, ufunc_1dim, index, device=dev()),
+                                 da, dim, freq, da, window, dim, freq, ufunc_1dim, index)
         a, x, t = _mask_values(da)
         return _rl_out(a, rl_blocks(a, x, lambda xb: hrl.windowed_run_events(xb, window, dim, freq, ufunc_1dim, index, time=t, device=dev())), freq)
 
     def windowed_run_count(da, window, dim="time", freq=None, ufunc_1dim="from_context", index="first"):  # rl:437-488
         if dim != "time":
-            return fallback("windowed_run_count", da, window, dim, freq, ufunc_1dim, index)
+            return _rl_other_dim("windowed_run_count", lambda x: hrl.windowed_run_count(x, window, 0, None, ufunc_1dim, index, device=dev()),
+                                 da, dim, freq, da, window, dim, freq, ufunc_1dim, index)
         a, x, t = _mask_values(da)
         return _rl_out(a, rl_blocks(a, x, lambda xb: hrl.windowed_run_count(xb, window, dim, freq, ufunc_1dim, index, time=t, device=dev())), freq)
 
     def _boundary(name, host, da, window, dim, freq, coord, ufunc_1dim):
-        if dim != "time" or coord not in (None, False, "dayofyear", "year", "month", "day"):
+        if dim != "time":
+            # the index along `dim`, or (coord=True) the coordinate value there — rl:586-596: ``lazy_indexing(da[dim], out)``
+            got = _along(da, dim) if freq is None and (not coord or coord is True) else None
+            if got is None or (coord is True and np.asarray(got[0][dim].values).dtype.kind not in "iuf"):
+                return fallback(name, da, window, dim, freq, coord, ufunc_1dim)
+            a, x = got
+            idx = np.asarray(host(x, window, 0, None, None, ufunc_1dim, device=dev()))
+            if coord is True:
+                crd = np.asarray(a[dim].values, dtype=np.float64)
+                idx = np.where(np.isnan(idx), np.nan, crd[np.nan_to_num(idx).astype(np.int64)])
+            return _wrap_others(a, dim, idx)
+        if coord not in (None, False, "dayofyear", "year", "month", "day"):
             return fallback(name, da, window, dim, freq, coord, ufunc_1dim)  # coord=True: datetime labels (reference path)
         a, x, t = _mask_values(da)
         return _rl_out(a, rl_blocks(a, x, lambda xb: host(xb, window, dim, freq, coord or None, ufunc_1dim, time=t, device=dev())), freq)
