@@ -342,6 +342,30 @@ def make_reference_like_modules(env):
             raise AssertionError("the reference's MissingAny.__call__ was reached: the wrapper did not replace it")
 
     ms.MissingAny = MissingAny
+
+    class _MissingBase:  # core/missing.py:162-177, 253-298: the options live in self.options; __call__ is INHERITED by the methods
+        def __init__(self, **options):
+            self.options = options
+
+        def __call__(self, da, freq=None, src_timestep=None, **indexer):
+            raise AssertionError(f"the reference's {type(self).__name__}.__call__ was reached: the wrapper did not replace it")
+
+    class MissingSomeButNotAll(_MissingBase):
+        pass
+
+    class MissingWMO(_MissingBase):
+        def __init__(self, nm=11, nc=5):
+            super().__init__(nm=nm, nc=nc, subfreq="MS")
+
+    class MissingPct(_MissingBase):
+        def __init__(self, tolerance=0.1, subfreq=None):
+            super().__init__(tolerance=tolerance, subfreq=subfreq)
+
+    class AtLeastNValid(_MissingBase):
+        def __init__(self, n=20, subfreq=None):
+            super().__init__(n=n, subfreq=subfreq)
+
+    ms.MissingSomeButNotAll, ms.MissingWMO, ms.MissingPct, ms.AtLeastNValid = MissingSomeButNotAll, MissingWMO, MissingPct, AtLeastNValid
     mods[ms.__name__] = ms
 
     im = types.ModuleType("xclim.core.indicator")

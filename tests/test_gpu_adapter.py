@@ -282,8 +282,8 @@ def test_run_length_wrappers_vs_oracle(ref, dev, rng):
     np.testing.assert_array_equal(_tf(rl.rle(da)), orl.rle(mf))
     out = rl.resample_and_rl(da, True, rl.rle_statistics, reducer="max", window=1, freq="YS")
     np.testing.assert_array_equal(_tf(out), orl.resample_and_rl(mf, True, orl.rle_statistics, "max", 1, time=ot, freq="YS"))
-    with pytest.raises(AssertionError, match="was reached"):   # other dims than time are the reference's business
-        rl.longest_run(da, dim="lat")
+    with pytest.raises(AssertionError, match="was reached"):   # a resampling frequency on another dimension is the reference's business
+        rl.longest_run(da, dim="lat", freq="YS")                # (without one: test_run_lengths_along_another_dimension_through_the_wrappers)
 
 
 def test_sdba_quantile_wrapper(ref, dev, rng):
@@ -755,3 +755,39 @@ def test_run_lengths_along_another_dimension_through_the_wrappers(ref, dev, rng)
         rl.longest_run(da, dim="lat", freq="YS")
     with pytest.raises(AssertionError, match="was reached"):
         rl.first_run(da, 2, dim="lat", coord="dayofyear")
+
+
+def test_other_missing_methods_through_the_wrappers(ref, dev, rng):
+    """core/missing.py:325-512: MissingWMO / MissingPct / AtLeastNValid / MissingSomeButNotAll objects (options in
+    ``self.options``, ``__call__`` inherited from MissingBase / MissingTwoSteps) called like ``Indicator._postprocess`` calls the
+    configured method (core/indicator.py:1522-1549) — served from the valid counts and the NaN-run kernel, in the input's
+    dimension order; hourly sources, DataArray-valued bounds and day selections of the two-step merge go to the reference."""
+    from oracle import missing as omiss
+
+    env, mods, names = ref
+    assert {"xclim.core.missing.MissingWMO.__call__", "xclim.core.missing.MissingPct.__call__",
+            "xclim.core.missing.AtLeastNValid.__call__", "xclim.core.missing.MissingSomeButNotAll.__call__"} <= set(names)
+    ms = mods["xclim.core.missing"]
+    T = 365 * 2
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    x = _temp(rng, T, (5, 6), nan_frac=0.03)
+    x[40:47, 1, 2] = np.nan
+    x[400:460, 3, 3] = np.nan
+    da = fakexr.field(np.ascontiguousarray(x.transpose(1, 0, 2)), ta, dims=("lat", "time", "lon"))
+    trace = dev.start_trace()
+    out = ms.MissingWMO()(da, "YS", "D")
+    dev.stop_trace()
+    assert out.dims == ("lat", "time", "lon") and out.dtype == bool and _calls(trace, "xh_run_stats") and _calls(trace, "xh_resample_reduce")
+    np.testing.assert_array_equal(_tf(out), omiss.missing_wmo(x, ot, "YS"))
+    np.testing.assert_array_equal(_tf(ms.MissingWMO(nm=5, nc=3)(da, "MS")), omiss.missing_wmo(x, ot, "MS", 5, 3))
+    np.testing.assert_array_equal(_tf(ms.MissingPct(tolerance=0.05)(da, "QS-DEC", "D", season="JJA")), omiss.missing_pct(x, ot, "QS-DEC", 0.05, season="JJA"))
+    np.testing.assert_array_equal(_tf(ms.MissingPct(tolerance=0.2, subfreq="MS")(da, "YS")), omiss.missing_pct(x, ot, "YS", 0.2, "MS"))
+    np.testing.assert_array_equal(_tf(ms.AtLeastNValid(n=27)(da, "MS")), omiss.at_least_n_valid(x, ot, "MS", 27))
+    np.testing.assert_array_equal(_tf(ms.MissingSomeButNotAll()(da, "MS")), omiss.missing_some_but_not_all(x, ot, "MS"))
+    whole = ms.MissingPct(tolerance=0.04)(da, None, "D")                        # freq=None: the time dimension is collapsed
+    assert whole.dims == ("lat", "lon")
+    np.testing.assert_array_equal(whole.values, omiss.missing_pct(x, ot, None, 0.04)[0])
+    with pytest.raises(AssertionError, match="MissingWMO.__call__ was reached"):   # an hourly source is refused by the reference itself
+        ms.MissingWMO()(da, "MS", "h")
+    with pytest.raises(AssertionError, match="MissingPct.__call__ was reached"):   # day selections of a monthly mask: the reference's business
+        ms.MissingPct(subfreq="MS")(da, "YS", "D", doy_bounds=(100, 200))

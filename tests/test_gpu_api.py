@@ -1882,3 +1882,83 @@ def test_select_time_with_doy_bounds_that_carry_a_time_dimension(dev, rng, inclu
     assert np.isnan(got[int(seg[-2]):]).all() and (~np.isnan(got)).any()     # the unlabelled last period is masked
     got2 = select_time(x, ta, doy_bounds=(start, end), include_bounds=include, bounds_time=bt, bounds_freq=freq, device=dev)
     np.testing.assert_array_equal(got2, exp)
+
+
+@pytest.mark.parametrize("calendar", ["standard", "noleap", "360_day"])
+def test_missing_methods_match_oracle(dev, rng, calendar):
+    """core/missing.py:325-512 (VERDICT r4 missing #7): MissingSomeButNotAll, MissingWMO, MissingPct, AtLeastNValid — and
+    MissingAny with freq=None — from the valid counts of xh_resample_reduce and, for WMO, the longest run of NaN steps per month
+    (xh_run_stats on the x != x mask); bit-exact (boolean) against the oracle's group loops, with and without a time
+    selection, one- and two-step (subfreq="MS")."""
+    from oracle import missing as omiss
+    from xclim_amd import missing as hmiss
+
+    T = 800
+    if calendar == "standard":
+        ta, ot = TimeAxis.daily("2000-03-15", T, "standard"), OTime.standard("2000-03-15", T)
+    else:
+        ta = TimeAxis.daily("2000-01-01", T + 74, calendar).subset(slice(74, None))
+        ot = OTime.noleap(2000, T + 74, calendar).isel(slice(74, None))
+    x = rng.normal(280, 5, (T, 6, 9)).astype(np.float32)
+    x[rng.random(x.shape) < 0.04] = np.nan                  # scattered missing days
+    for c in range(9):                                       # runs of 2 .. 12 missing days, whole missing months, an empty cell
+        t0 = int(rng.integers(0, T - 40))
+        x[t0:t0 + 2 + c + (c > 5) * 3, c % 6, c] = np.nan
+    x[100:170, 2, 3] = np.nan
+    x[:, 5, 8] = np.nan
+    x[:, 0, 0] = 281.0                                        # a complete cell
+    for freq in ("MS", "YS", "QS-DEC", "YS-JUL"):
+        for ix in ({}, {"month": [1, 6, 7]}, {"season": "JJA"}):
+            np.testing.assert_array_equal(hmiss.missing_wmo(x, freq, ta, device=dev, **ix), omiss.missing_wmo(x, ot, freq, **ix), err_msg=f"wmo {freq} {ix}")
+            np.testing.assert_array_equal(hmiss.missing_wmo(x, freq, ta, nm=5, nc=3, device=dev, **ix), omiss.missing_wmo(x, ot, freq, 5, 3, **ix))
+            for sub in (None, "MS"):
+                np.testing.assert_array_equal(hmiss.missing_pct(x, freq, ta, 0.1, sub, device=dev, **ix), omiss.missing_pct(x, ot, freq, 0.1, sub, **ix),
+                                              err_msg=f"pct {freq} {sub} {ix}")
+                np.testing.assert_array_equal(hmiss.at_least_n_valid(x, freq, ta, 20, sub, device=dev, **ix), omiss.at_least_n_valid(x, ot, freq, 20, sub, **ix),
+                                              err_msg=f"n {freq} {sub} {ix}")
+            np.testing.assert_array_equal(hmiss.missing_some_but_not_all(x, freq, ta, device=dev, **ix), omiss.missing_some_but_not_all(x, ot, freq, **ix))
+            np.testing.assert_array_equal(hmiss.missing_any(x, freq, ta, device=dev, **ix), omiss.missing_any(x, ot, freq, **ix))
+        np.testing.assert_array_equal(hmiss.missing_pct(x, freq, ta, 0.02, device=dev, doy_bounds=(150, 250)), omiss.missing_pct(x, ot, freq, 0.02, doy_bounds=(150, 250)))
+    for ix in ({}, {"month": [7]}):                           # freq=None: the whole series is one period (core/missing.py:124-127)
+        np.testing.assert_array_equal(hmiss.missing_any(x, None, ta, device=dev, **ix), omiss.missing_any(x, ot, None, **ix))
+        np.testing.assert_array_equal(hmiss.missing_pct(x, None, ta, 0.05, device=dev, **ix), omiss.missing_pct(x, ot, None, 0.05, **ix))
+        np.testing.assert_array_equal(hmiss.missing_pct(x, None, ta, 0.3, "MS", device=dev, **ix), omiss.missing_pct(x, ot, None, 0.3, "MS", **ix))
+        np.testing.assert_array_equal(hmiss.missing_wmo(x, None, ta, device=dev, **ix), omiss.missing_wmo(x, ot, None, **ix))
+    assert hmiss.missing_wmo(x, "YS", ta, device=dev).any() and not hmiss.missing_wmo(x, "YS", ta, device=dev)[1, 0, 0]
+    with pytest.raises(ValueError, match="not valid for MissingWMO"):
+        hmiss.missing_wmo(x, "MS", ta, nm=31, device=dev)
+    with pytest.raises(ValueError, match="not valid for MissingPct"):
+        hmiss.missing_pct(x, "MS", ta, tolerance=1.5, device=dev)
+
+
+def test_reference_missing_answers_on_the_device(dev):
+    """/root/reference/tests/test_missing.py:166-285 through the HIP path (the same answers the oracle is pinned to in
+    tests/test_oracle_reference_answers.py)."""
+    from xclim_amd import missing as hmiss
+
+    t = lambda n: TimeAxis.daily("2000-07-01", n, "standard")  # noqa: E731
+    a = np.arange(360.0, dtype=np.float32)
+    a[5:7] = np.nan
+    a[40:45] = np.nan
+    a[70:92:2] = np.nan
+    out = hmiss.missing_wmo(a, "MS", t(360), device=dev)
+    assert not out[0] and out[1] and out[2]
+    a = np.arange(350.0, dtype=np.float32)
+    a[5:16] = np.nan
+    np.testing.assert_array_equal(hmiss.missing_wmo(a, "QS-JAN", t(350), device=dev), [True, False, False, True])
+    np.testing.assert_array_equal(hmiss.missing_wmo(np.arange(31.0, dtype=np.float32), "YS", t(31), device=dev), [True])
+    a = np.arange(360.0, dtype=np.float32)
+    a[5:7] = np.nan
+    a[40:45] = np.nan
+    out = hmiss.missing_pct(a, "MS", t(360), tolerance=0.1, device=dev)
+    assert not out[0] and out[1]
+    a = np.arange(360.0, dtype=np.float32)
+    a[5:10] = np.nan
+    a[40:55] = np.nan
+    np.testing.assert_array_equal(hmiss.at_least_n_valid(a, "MS", t(360), n=20, device=dev)[:2], [False, True])
+    a = np.arange(360.0, dtype=np.float32)
+    a[:40] = np.nan
+    out = hmiss.missing_some_but_not_all(a, "MS", t(360), device=dev)
+    assert not out[0] and out[1] and not out[2]
+    np.testing.assert_array_equal(hmiss.missing_any(np.zeros(360, np.float32), None, t(360), device=dev), [False])
+    np.testing.assert_array_equal(hmiss.missing_any(np.zeros(360, np.float32), None, t(360), device=dev, month=[7]), [False])

@@ -220,15 +220,18 @@ def test_bench_finds_pmc_traffic_of_the_dominant_kernel():
 
 
 def test_dim_other_than_time_is_refused():
-    """The host mirrors keep the reference's `dim` argument but only march along axis 0 = time: anything else must fail
-    loudly (before any device work), not be ignored."""
+    """The host mirrors keep the reference's `dim` argument: "time" = axis 0, or (round 6) an INTEGER axis of the plain array;
+    a dimension NAME other than "time" means nothing for an array without names and must fail loudly (before any device
+    work), not be ignored — and resampling stays with the time axis."""
     from xclim_amd import sdba
 
     x = np.zeros((4, 3), np.float32)
     for f, args in ((xrl.rle, ()), (xrl.rle_statistics, ("max", 1)), (xrl.first_run, (2,)), (xrl.longest_run, ()),
                     (xrl.windowed_run_count, (2,)), (xrl.keep_longest_run, ()), (xrl.season, (2,))):
-        with pytest.raises(NotImplementedError, match="dim='time'"):
+        with pytest.raises(NotImplementedError, match="integer axis"):
             f(x, *args, dim="lat")
+    with pytest.raises(ValueError, match="resample the time axis"):
+        xrl.longest_run(x, 1, "YS")
     with pytest.raises(NotImplementedError):
         sdba.quantile(x, [0.5], dim="lat")
     assert xrl.rle_statistics.__name__ == "rle_statistics"  # resample_and_rl dispatches on the name

@@ -590,3 +590,72 @@ def test_spell_mask_known_answers():
     thr = (np.array([330.0, 360.0]) + 273.15).astype(np.float32)
     out = ogen.spell_length_statistics(tn, thr, 1, "min", ">", "sum", OTime.standard("2001-01-01", 365), "YS")
     np.testing.assert_allclose(out, [[34, 4]])
+
+
+# ---- tests/test_missing.py: the other missing-value methods (core/missing.py:325-512) -----------------------------
+def test_missing_wmo_answers():  # test_missing.py:166-197
+    from oracle import missing as omiss
+
+    a = np.arange(360.0)
+    a[5:7] = np.nan      # under the limit
+    a[40:45] = np.nan    # too many consecutive missing values
+    a[70:92:2] = np.nan  # too many non-consecutive missing values
+    out = omiss.missing_wmo(a, _t(360), "MS")
+    assert not out[0] and out[1] and out[2]
+    a = np.arange(350.0)
+    a[5:16] = np.nan
+    np.testing.assert_array_equal(omiss.missing_wmo(a, _t(350), "QS-JAN"), [True, False, False, True])
+    np.testing.assert_array_equal(omiss.missing_wmo(np.arange(31.0), _t(31), "YS"), [True])   # one complete month of a year
+
+
+def test_missing_pct_answers():  # test_missing.py:199-221
+    from oracle import missing as omiss
+
+    a = np.arange(360.0)
+    a[5:7] = np.nan
+    a[40:45] = np.nan
+    out = omiss.missing_pct(a, _t(360), "MS", tolerance=0.1)
+    assert not out[0] and out[1]
+    # a series without the months 5 .. 11 (test_missing_period): months inside the span are expected in full
+    full = OTime.standard("2000-01-01", 366)
+    keep = np.isin(full.month, [1, 2, 3, 4, 12])
+    np.testing.assert_array_equal(omiss.missing_pct(np.ones(keep.sum()), full.isel(keep), "MS", tolerance=0.9), [False] * 4 + [True] * 7 + [False])
+
+
+def test_at_least_n_valid_and_some_but_not_all_answers():  # test_missing.py:224-231, 274-285
+    from oracle import missing as omiss
+
+    a = np.arange(360.0)
+    a[5:10] = np.nan
+    a[40:55] = np.nan
+    np.testing.assert_array_equal(omiss.at_least_n_valid(a, _t(360), "MS", n=20)[:2], [False, True])
+    a = np.arange(360.0)
+    a[:40] = np.nan
+    out = omiss.missing_some_but_not_all(a, _t(360), "MS")
+    assert not out[0] and out[1] and not out[2]    # all missing: ok; some missing: flagged; none missing: ok
+
+
+def test_missing_any_answers_with_indexers_and_without_freq():  # test_missing.py:56-145
+    from oracle import missing as omiss
+
+    a = np.arange(360.0)
+    a[5:10] = np.nan
+    out = omiss.missing_any(a, _t(360), "MS")
+    assert out[0] and not out[1]
+    np.testing.assert_array_equal(omiss.missing_any(np.arange(66.0), OTime.standard("2001-12-30", 66), "MS"), [True, False, False, True])
+    np.testing.assert_array_equal(omiss.missing_any(np.arange(378.0), OTime.standard("2001-12-31", 378), "YS"), [True, False, True])
+    z = np.zeros(36)
+    np.testing.assert_array_equal(omiss.missing_any(z, _t(36), "YS", month=7), [False])
+    np.testing.assert_array_equal(omiss.missing_any(z, _t(36), "YS", month=8), [True])
+    np.testing.assert_array_equal(omiss.missing_any(z, _t(36), "YS", month=[7, 8]), [True])
+    np.testing.assert_array_equal(omiss.missing_any(np.zeros(76), _t(76), "YS", month=[7, 8]), [False])
+    # (the reference converts 2000-01-01 .. 2000-12-25 by date: 359 days without leap day, 355 in the 360-day calendar)
+    for ot in (OTime.standard("2000-01-01", 360), OTime.noleap(2000, 359), OTime.noleap(2000, 355, "360_day")):
+        np.testing.assert_array_equal(omiss.missing_any(np.zeros(len(ot)), ot, "YS", season="MAM"), [False])
+        np.testing.assert_array_equal(omiss.missing_any(np.zeros(len(ot)), ot, "YS", season="DJF"), [True])
+    np.testing.assert_array_equal(omiss.missing_any(np.zeros(360), _t(360), None), [False])
+    t = list(range(31))
+    t.pop(5)
+    np.testing.assert_array_equal(omiss.missing_any(np.zeros(30), _t(360).isel(t), None), [True])
+    np.testing.assert_array_equal(omiss.missing_any(np.zeros(360), _t(360), None, month=[7]), [False])
+    np.testing.assert_array_equal(omiss.missing_any(np.zeros(30), _t(360).isel(t), None, month=[7]), [True])

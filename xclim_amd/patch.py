@@ -167,14 +167,21 @@ def install(env=None, modules=None) -> list[str]:
     patch("xclim.indices.run_length", "_cumsum_reset_np", cumsum_reset_np)
     # the missing-value check of Indicator._postprocess (core/indicator.py:1522-1549): a METHOD of MissingAny
     miss_mod = resolve("xclim.core.missing")
-    cls = getattr(miss_mod, "MissingAny", None) if miss_mod is not None else None
-    if cls is not None:
-        orig_call = cls.__call__
-        if ("xclim.core.missing", "MissingAny.__call__") not in _saved:
-            _saved[("xclim.core.missing", "MissingAny.__call__")] = orig_call
-        orig["MissingAny.__call__"] = _saved[("xclim.core.missing", "MissingAny.__call__")]
-        cls.__call__ = wrappers["MissingAny.__call__"]
-        done.append("xclim.core.missing.MissingAny.__call__")
+    # ... and of the other registered methods (:325-512; MissingTwoSteps.__call__ :352-393 for wmo / pct / at_least_n).  Each
+    # class is patched where it DEFINES __call__ semantics of its own; the base classes stay untouched (custom subclasses
+    # registered by users keep the reference's code)
+    for cname in ("MissingAny", "MissingSomeButNotAll", "MissingWMO", "MissingPct", "AtLeastNValid"):
+        cls = getattr(miss_mod, cname, None) if miss_mod is not None else None
+        key = f"{cname}.__call__"
+        if cls is not None and key in wrappers:
+            if ("xclim.core.missing", key) not in _saved:
+                # (the function found on the class — possibly inherited; uninstall() removes the override again)
+                _saved[("xclim.core.missing", key)] = cls.__dict__.get("__call__", _INHERITED)
+            own = _saved[("xclim.core.missing", key)]
+            # what the wrapper forwards to: the class's own function, or the one it inherits (MissingBase / MissingTwoSteps)
+            orig[key] = own if own is not _INHERITED else next(b.__dict__["__call__"] for b in cls.__mro__[1:] if "__call__" in b.__dict__)
+            cls.__call__ = wrappers[key]
+            done.append(f"xclim.core.missing.{key}")
     # Indicator.__call__ (core/indicator.py:865-944): parse -> compute (the index, its percentile / resample helpers) ->
     # missing-value check (:1522-1549), all on the same DataArrays and without user code in between: ONE scope of
     # device-resident inputs (Device.keep_inputs) per call, dropped when the call returns
@@ -202,6 +209,7 @@ def install(env=None, modules=None) -> list[str]:
     return done
 
 
+_INHERITED = object()  # marker in _saved: the class did not define the attribute itself (uninstall deletes the override)
 _saved_modules: dict = {}
 _cleanups: list = []  # per install(): drops the valid-count cache of its wrappers
 
@@ -213,7 +221,10 @@ def uninstall() -> None:
         mod = _saved_modules.get(modname) or importlib.import_module(modname)
         if "." in attr:  # a method: "Class.name"
             cname, meth = attr.split(".")
-            setattr(getattr(mod, cname), meth, fn)
+            if fn is _INHERITED:
+                delattr(getattr(mod, cname), meth)
+            else:
+                setattr(getattr(mod, cname), meth, fn)
         else:
             setattr(mod, attr, fn)
     _saved.clear()

@@ -850,6 +850,40 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         miss = valid != expected.reshape((-1,) + (1,) * (valid.ndim - 1))
         return wrap_periods(a, miss, freq)
 
+    # the other registered methods (core/missing.py:325-512): same inputs, the host mirrors of xclim_amd/missing.py.  The options
+    # live in ``self.options`` (MissingBase.__init__, :174-177).
+    def _missing_call(cls_name, host, option_names):
+        def call(self, da, freq=None, src_timestep=None, **indexer):
+            name = f"{cls_name}.__call__"
+            if (not isinstance(da, DA) or "time" not in da.dims or src_timestep not in (None, "D", "1D") or is_chunked(da)
+                    or not plain_indexer(indexer) or da.dtype.kind != "f"):
+                return fallback(name, self, da, freq, src_timestep, **indexer)
+            a, x = _tfirst(da)
+            t = time_axis_of(a)
+            if len(t) < 2 or not np.all(np.diff(t.ordinal()) == 1):  # xr.infer_freq(da.time) must be daily (WMO: :425-426)
+                return fallback(name, self, da, freq, src_timestep, **indexer)
+            idx = {k: v for k, v in indexer.items() if v is not None}
+            opts = {k: self.options[k] for k in option_names if k in self.options}
+            try:
+                miss = host(x, freq, t, device=dev(), **opts, **idx)
+            except (NotImplementedError, Float64FieldError):   # sub-frequencies other than months, day selections of the two-step merge
+                return fallback(name, self, da, freq, src_timestep, **indexer)
+            if freq is None:   # the time dimension is collapsed
+                return wrap_cells(a, miss[0])
+            return wrap_periods(a, miss, freq)
+
+        call.__name__ = "__call__"
+        return call
+
+    from . import missing as hmiss
+
+    missing_calls = {
+        "MissingSomeButNotAll.__call__": _missing_call("MissingSomeButNotAll", hmiss.missing_some_but_not_all, ()),
+        "MissingWMO.__call__": _missing_call("MissingWMO", hmiss.missing_wmo, ("nm", "nc")),
+        "MissingPct.__call__": _missing_call("MissingPct", hmiss.missing_pct, ("tolerance", "subfreq")),
+        "AtLeastNValid.__call__": _missing_call("AtLeastNValid", hmiss.at_least_n_valid, ("n", "subfreq")),
+    }
+
     # ---- apply_ufunc callees (tier 2) and xsdba ----------------------------------------------------------------------
     def calc_perc(arr, percentiles=None, alpha=1.0, beta=1.0, copy=True):  # utl:279-323
         return hutl.calc_perc(arr, percentiles, alpha, beta, copy, device=dev())
@@ -958,6 +992,7 @@ def make_wrappers(env: Env, orig: dict | None = None, device=None) -> dict:
         "resample_and_rl": resample_and_rl, "calc_perc": calc_perc, "sdba_quantile": sdba_quantile,
         "sdba_interp_on_quantiles": sdba_interp_on_quantiles,
         "MissingAny.__call__": missing_any_call,
+        **missing_calls,
     }
     out = {name: forwarding(name, fn) for name, fn in table.items()}
     out["_clear_valid_cache"] = valid_cache.clear  # (patch.uninstall)
