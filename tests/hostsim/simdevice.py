@@ -74,10 +74,7 @@ UNIT_REWRITES = {
         (r'asm\("v_max_f32 %0, %0, %1" : "\+v"\((\w+)\) : "v"\(([^;]+?)\)\);', r"\1 = fmaxf(\1, \2);"),
         (r'asm\("v_min3_f32 %0, %0, %1, %2" : "\+v"\((\w+)\) : "v"\(([^;]+?)\), "v"\(([^;]+?)\)\);', r"\1 = fminf(fminf(\1, \2), \3);"),
         (r'asm\("v_max3_f32 %0, %0, %1, %2" : "\+v"\((\w+)\) : "v"\(([^;]+?)\), "v"\(([^;]+?)\)\);', r"\1 = fmaxf(fmaxf(\1, \2), \3);"),
-        # hs_qdm_pick reads the column's records with v_readlane from per-lane searches (divergent): published once, peeked after
-        (r"(if \(lane \+ 64 < nrec\) \{ rw0b = [^\n]*\n)", r"\1  sim_publish(0, rw0a); sim_publish(1, rw1a); sim_publish(2, rw0b); sim_publish(3, rw1b);\n"),
-        (r"__builtin_amdgcn_readlane\(\(int\)rw0a, r\)", "sim_peek(0, r)"), (r"__builtin_amdgcn_readlane\(\(int\)rw1a, r\)", "sim_peek(1, r)"),
-        (r"__builtin_amdgcn_readlane\(\(int\)rw0b, r - 64\)", "sim_peek(2, r - 64)"), (r"__builtin_amdgcn_readlane\(\(int\)rw1b, r - 64\)", "sim_peek(3, r - 64)"),
+        # (round 6: hs_qdm_pick scans the column's records in LDS — no v_readlane from divergent code is left to emulate)
         (r"typedef __attribute__\(\(address_space\(3\)\)\) uint32_t lds_u32;", ""),
         (r"uint32_t addr = \(uint32_t\)\(uintptr_t\)\(lds_u32\*\)\(cand \+ lbase\[colo\]\) \+ pos \* 4u;", "uint32_t* addr = (uint32_t*)(cand + lbase[colo]) + pos;"),
         (r'asm volatile\(\s*"s_mov_b64 %\[sv\], exec\\n\\t".*?: "vcc", "memory"\);', "(void)sv; if (bit) { uint32_t b_; memcpy(&b_, &v[u], 4); *addr++ = b_; }"),

@@ -70,6 +70,7 @@ constexpr int HS_POOL = HS_CW * 512;   // candidate keys of one tile in LDS
 constexpr int HS_CAPMAX = 2048;        // ... at most this many for one column in the register sort
 constexpr int HS_CAPBIG = 8192;        // ... and this many at all (2049 .. 8192: a bitonic sort in LDS, in place in the column's list)
 constexpr int HS_MAXQ = 32;            // quantiles per call on this path
+constexpr int HS_QREC_MAX = 2 * (HS_MAXQ + 1);  // QDM: records (collected bins) per column, two per class boundary
 constexpr uint32_t HS_NANKEY = 0xFFFFFFFFu;
 constexpr uint32_t HS_KEY_MINF = 0x00800000u, HS_KEY_MAXF = 0xFF7FFFFFu;  // keys of -FLT_MAX / +FLT_MAX
 constexpr uint32_t HS_SPEC_LO = 0xFFFEu, HS_SPEC_HI = 0xFFFDu, HS_SPEC_NONE = 0xFFFFu;
@@ -949,26 +950,23 @@ __device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm,
 // QDM epilogue of one column (one wave; its candidates sorted in `list`, keys; c0 / cmax = the copies of the column's minimum
 // / maximum counted by pass 2): per class boundary the rank that decides it (qdmrank.h), its run of equal values among the candidates (or a pure bin),
 // the cut value -> gcut; the class factors -> gfac.  A rank outside the collected bins, or a run longer than the scan cap,
-// puts the column on the list for the exact-rank kernels (returns true).  tv: 64 words of LDS scratch.
+// puts the column on the list for the exact-rank kernels (returns true).  ws: 2 * HS_QREC_MAX + 64 words of LDS scratch.
 template <int CW>
-__device__ __forceinline__ bool hs_qdm_pick(const HsArgs& A, const uint32_t* list, int64_t tile, int k, int64_t ck, int lane, uint32_t* tv,
+__device__ __forceinline__ bool hs_qdm_pick(const HsArgs& A, const uint32_t* list, int64_t tile, int k, int64_t ck, int lane, uint32_t* ws,
                                             uint32_t c0, uint32_t cmax) {
   const int nq = A.nq, ntest = nq + 1, nrec = 2 * (nq + 1);
   const uint32_t n = A.meta_n[ck];
   const uint2 lh = A.lohi[ck];
-  // the column's records: one (or two) per lane, read back with v_readlane inside the searches below — fetched from memory
-  // one by one, every probe of run_at was a dependent L2 round trip (k_hs_collect in QDM mode: 19.9 ms against 11.1 for the
-  // quantile mode at config 4)
+  // The column's records go to LDS once (`ws`: per-wave scratch inside the tables of the streaming loop, which are dead in the
+  // epilogue) and every lane — one class boundary each — scans them with broadcast reads and selects, no branch, no scalar
+  // code.  Round 5 kept them in two registers per lane and read them back with v_readlane in a loop that `continue`d per
+  // record: 42 iterations of readlane -> scalar compare -> divergent branch per search, two searches per boundary —
+  // 7.0 of the 43.8 ms of QuantileDeltaMapping.adjust at 30 years x 1440 x 720 (tools/experiments/r06/qdm_c4_abl.py:
+  // XH_HIST_ABL=128 switches this function off), a chain of scalar-to-vector hazards that 16 waves of a CU ran in lock-step.
   const uint32_t* __restrict__ rec = A.qrec + (tile * nrec) * 2 * CW + k;
-  uint32_t rw0a = 0u, rw1a = HS_REC_NONE << 16, rw0b = 0u, rw1b = HS_REC_NONE << 16;
-  if (lane < nrec) { rw0a = rec[(lane * 2 + 0) * CW]; rw1a = rec[(lane * 2 + 1) * CW]; }
-  if (lane + 64 < nrec) { rw0b = rec[((lane + 64) * 2 + 0) * CW]; rw1b = rec[((lane + 64) * 2 + 1) * CW]; }
-  auto R0 = [&](int r) -> uint32_t {  // (r is wave-uniform; v_readlane reads lanes outside the execution mask too)
-    return (uint32_t)(r < 64 ? __builtin_amdgcn_readlane((int)rw0a, r) : __builtin_amdgcn_readlane((int)rw0b, r - 64));
-  };
-  auto R1 = [&](int r) -> uint32_t {
-    return (uint32_t)(r < 64 ? __builtin_amdgcn_readlane((int)rw1a, r) : __builtin_amdgcn_readlane((int)rw1b, r - 64));
-  };
+  uint2* recs = reinterpret_cast<uint2*>(ws);
+  uint32_t* tv = ws + 2 * HS_QREC_MAX;
+  for (int i = lane; i < nrec; i += 64) recs[i] = make_uint2(rec[(i * 2 + 0) * CW], rec[(i * 2 + 1) * CW]);
   constexpr uint32_t CAP = 256u;
   // the column's valid nodes (NaN factors dropped), compacted through the wave: tv[pos] = node index
   const float myaf = lane < nq ? A.af[(int64_t)lane * A.af_qs + ck] : xh_nan32();
@@ -978,27 +976,29 @@ __device__ __forceinline__ bool hs_qdm_pick(const HsArgs& A, const uint32_t* lis
   __builtin_amdgcn_wave_barrier();
   // a record that holds global rank r: value + run [a, b) of equal values around it.  found: 1 ok | 0 not collected / cap
   auto run_at = [&](uint32_t r, uint32_t& key, uint32_t& a, uint32_t& b) -> bool {
+    uint32_t w0 = 0u, w1 = HS_REC_NONE << 16;   // the FIRST record whose rank range holds r (the ranges are disjoint anyway)
     for (int i = 0; i < nrec; ++i) {
-      const uint32_t w1 = R1(i), kind = w1 >> 16;
-      if (kind == HS_REC_NONE) continue;
-      const uint32_t w0 = R0(i), bel = w0 & 0xFFFFu, cnt = w0 >> 16;
-      if (r < bel || r >= bel + cnt) continue;
-      if (kind != HS_REC_REG) {  // a pure bin: one value (as the canonical key the sorted candidates carry: -0.0 -> +0.0)
-        key = hs_key(xh_key2f(kind == HS_REC_LO ? lh.x : lh.y) + 0.0f);
-        a = bel;
-        b = bel + cnt;
-        return true;
-      }
-      const uint32_t cs = w1 & 0xFFFFu, pos = cs + (r - bel);
-      key = list[pos];
-      uint32_t l = pos, h = pos + 1u, steps = 0u;
-      while (l > cs && list[l - 1u] == key && steps < CAP) { --l; ++steps; }
-      while (h < cs + cnt && list[h] == key && steps < CAP) { ++h; ++steps; }
-      a = bel + (l - cs);
-      b = bel + (h - cs);
-      return steps < CAP;
+      const uint2 w = recs[i];
+      const bool hit = (w1 >> 16) == HS_REC_NONE && (w.y >> 16) != HS_REC_NONE && r - (w.x & 0xFFFFu) < (w.x >> 16) && r >= (w.x & 0xFFFFu);
+      w0 = hit ? w.x : w0;
+      w1 = hit ? w.y : w1;
     }
-    return false;
+    const uint32_t kind = w1 >> 16, bel = w0 & 0xFFFFu, cnt = w0 >> 16;
+    if (kind == HS_REC_NONE) return false;
+    if (kind != HS_REC_REG) {  // a pure bin: one value (as the canonical key the sorted candidates carry: -0.0 -> +0.0)
+      key = hs_key(xh_key2f(kind == HS_REC_LO ? lh.x : lh.y) + 0.0f);
+      a = bel;
+      b = bel + cnt;
+      return true;
+    }
+    const uint32_t cs = w1 & 0xFFFFu, pos = cs + (r - bel);
+    key = list[pos];
+    uint32_t l = pos, h = pos + 1u, steps = 0u;
+    while (l > cs && list[l - 1u] == key && steps < CAP) { --l; ++steps; }
+    while (h < cs + cnt && list[h] == key && steps < CAP) { ++h; ++steps; }
+    a = bel + (l - cs);
+    b = bel + (h - cs);
+    return steps < CAP;
   };
   bool flag = false;
   const bool ok = n > 0u && nvn >= 2u && c0 < n;
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
     // decides whether any lane of the wave holds a copy at all, and only then the copies are counted into LDS.
     constexpr bool qdm = QDM;
     ring.run(x, T, st, cc, rl, [&](const float (&v)[HS_U]) {
-      if (qdm) {
+      if (qdm && !(abl & 256)) {  // (diagnostics bit 256: no counting of the extremes' copies)
         const float vmn = valmn[col], vmx = valmx[col];
         float m = v[0], M = v[0];
 #pragma unroll
@@ -1216,7 +1216,8 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
       else if (ms > 0u) hs_sort_column<1>(list, ms, lane, zero);  // (one candidate: only turned into its key)
       __builtin_amdgcn_wave_barrier();
       if (!QDM) hs_pick_store<CW>(list, mm, tile, k, ck, lane, ntgt, nq, qs, meta_n, lohi, crank, tv, out, ocs, oqs);
-      else if (hs_qdm_pick<CW>(A, list, tile, k, ck, lane, tv, cntmn[k], cntmx[k]) && lane == 0)
+      else if (abl & 128) {  // diagnostics: no QDM epilogue (results wrong)
+      } else if (hs_qdm_pick<CW>(A, list, tile, k, ck, lane, tab + wv * (2 * HS_QREC_MAX + 64), cntmn[k], cntmx[k]) && lane == 0)
         A.flist[atomicAdd(&stat->nflag, 1u)] = (uint32_t)ck;  // (behind pass 1's own entries: the host reads the count afterwards)
     }
     __syncthreads();  // cand / tab / bm / cursor are rewritten by the next tile
@@ -1419,7 +1420,7 @@ int hs_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const 
 #undef XH_HS_GEOM
     XH_LAUNCH_CHECK();
   }
-  const char* eabl = xh_diag_env("XH_HIST_ABL");  // diagnostics: 1 = no candidate sort, 2 = pass 1 loads only, 4 = no pass-1 tile epilogue (wrong results)
+  const char* eabl = xh_diag_env("XH_HIST_ABL");  // diagnostics: 1 = no candidate sort, 2 = pass 1 loads only, 4 = no pass-1 tile epilogue, 32 = no appends, 64 = pass 2 loads only, 128 = no QDM epilogue, 256 = no counting of the extremes (wrong results)
   const int abl = eabl ? atoi(eabl) : 0;
   // the streaming ring: 5 sets of 8 loads (32 to 40 loads per lane in flight).  Diagnostics: XH_HIST_RING=162 = two sets of 16
   // (round 3's ping-pong: 16 to 32 in flight; config-4 train 40.5 against 36.7-38.2 ms on the same box, profiles/r04/)
