@@ -43,6 +43,12 @@ INDICES = {
         "tx_tn_days_above": {"args": {"tasmin": "*", "tasmax": "*"}},
         "days_over_precip_thresh": {"args": {"pr": "*", "pr_per": "*"}, "assume": {"contains": True}},
         "heat_wave_max_length": {"args": {"tasmin": "*", "tasmax": "*"}},     # rl.resample_and_rl(..., window, reducer)
+        # round 6
+        "heat_wave_total_length": {"args": {"tasmin": "*", "tasmax": "*"}},
+        "tg90p": {"args": {"tas": "*", "tas_per": "*"}},
+        "tg10p": {"args": {"tas": "*", "tas_per": "*"}},
+        "tn90p": {"args": {"tasmin": "*", "tasmin_per": "*"}},
+        "tx10p": {"args": {"tasmax": "*", "tasmax_per": "*"}},
     },
     "_threshold.py": {
         "maximum_consecutive_dry_days": {"args": {"pr": "*"}},
@@ -67,12 +73,29 @@ INDICES = {
         "days_with_snow": {"args": {"prsn": "*"}},                               # domain_count
         "snd_season_end": {"args": {"snd": "*"}},                                # season(2 positional)
         "dry_spell_frequency": {"args": {"pr": "*"}},                            # spell_length_statistics(**indexer)
+        # round 6: every other body of the module that only calls replaced functions and the unit helpers (recorded with
+        # the default scenario: DataArray parameters symbolic, scalars at their defaults)
+        **{n: {"args": {"sfcWind": "*"}} for n in ("calm_days", "windy_days")},
+        **{n: {"args": {"tas": "*"}} for n in ("cold_spell_frequency", "cold_spell_max_length", "cold_spell_total_length", "tg_days_above",
+                                               "tg_days_below", "heating_degree_days", "growing_season_end", "first_day_temperature_below")},
+        **{n: {"args": {"tasmin": "*"}} for n in ("frost_season_length", "frost_free_season_start", "frost_free_season_end",
+                                                  "frost_free_season_length", "frost_free_spell_max_length", "tn_days_above",
+                                                  "warm_night_frequency", "maximum_consecutive_frost_days",
+                                                  "maximum_consecutive_frost_free_days")},
+        **{n: {"args": {"tasmax": "*"}} for n in ("heat_wave_index", "hot_spell_total_length", "tx_days_below", "warm_day_frequency",
+                                                  "maximum_consecutive_tx_days")},
+        **{n: {"args": {"pr": "*"}} for n in ("dry_spell_total_length", "dry_spell_max_length", "wet_spell_frequency",
+                                              "wet_spell_total_length", "wet_spell_max_length")},
     },
     "_simple.py": {
         "tg_mean": {"args": {"tas": "*"}},
         "tx_max": {"args": {"tasmax": "*"}},
         "tn_min": {"args": {"tasmin": "*"}},
         "frost_days": {"args": {"tasmin": "*"}},
+        # round 6
+        "tg_min": {"args": {"tas": "*"}}, "tn_max": {"args": {"tasmin": "*"}}, "tn_mean": {"args": {"tasmin": "*"}},
+        "tx_mean": {"args": {"tasmax": "*"}}, "tx_min": {"args": {"tasmax": "*"}}, "hot_days": {"args": {"tasmax": "*"}},
+        "ice_days": {"args": {"tasmax": "*"}}, "max_1day_precipitation_amount": {"args": {"pr": "*"}},
     },
 }
 
@@ -117,6 +140,8 @@ class Recorder:
         raise TypeError(f"cannot record a value of type {type(x).__name__}")
 
     def op(self, kind, **fields):
+        if len(self.ops) > 500:  # (a body that loops over a symbolic value would record forever)
+            raise RuntimeError("more than 500 operations: the body is not a straight-line call program")
         self.ops.append(dict(op=kind, **fields))
         return Sym(self, {"v": len(self.ops) - 1})
 

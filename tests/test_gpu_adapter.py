@@ -522,10 +522,132 @@ def test_reference_call_programs_through_the_wrappers(ref, dev, rng):
                 "hot_spell_frequency", "hot_spell_max_length", "cold_spell_days", "growing_season_length", "heat_wave_frequency",
                 "tx_tn_days_above", "tx90p", "tn10p", "warm_spell_duration_index", "cold_spell_duration_index",
                 "days_over_precip_thresh", "days_with_snow", "heat_wave_max_length", "dry_spell_frequency"}
-    assert replayed | not_replayed == set(progs) and not (replayed & not_replayed)
-    assert len(progs) >= 32 and all(hasattr(mods[p["module"]], n) for n, p in progs.items())
+    assert (replayed | not_replayed | ROUND6_PROGRAMS) == set(progs) and not (replayed & not_replayed)
+    assert len(progs) >= 74 and all(hasattr(mods[p["module"]], n) for n, p in progs.items())
     with pytest.raises(NotImplementedError, match="recorded program holds"):
         mv.days_over_precip_thresh(pr, per_p, bootstrap=True)       # the body is recorded for bootstrap=False (percentile_bootstrap stripped)
+
+
+# the bodies recorded in round 6 (tests/golden/make_call_programs.py: every other index of _threshold / _multivariate / _simple
+# that only calls replaced functions and the unit helpers), all replayed by the test below
+ROUND6_PROGRAMS = {
+    "calm_days", "windy_days", "tg_days_above", "tg_days_below", "tn_days_above", "tx_days_below", "warm_day_frequency",
+    "warm_night_frequency", "hot_days", "ice_days", "tg_min", "tn_max", "tn_mean", "tx_mean", "tx_min",
+    "max_1day_precipitation_amount", "heating_degree_days", "cold_spell_frequency", "cold_spell_max_length",
+    "cold_spell_total_length", "frost_free_spell_max_length", "heat_wave_index", "hot_spell_total_length", "heat_wave_total_length",
+    "maximum_consecutive_frost_days", "maximum_consecutive_frost_free_days", "maximum_consecutive_tx_days", "dry_spell_total_length",
+    "dry_spell_max_length", "wet_spell_frequency", "wet_spell_total_length", "wet_spell_max_length", "growing_season_end",
+    "frost_season_length", "frost_free_season_start", "frost_free_season_end", "frost_free_season_length",
+    "first_day_temperature_below", "tg90p", "tg10p", "tn90p", "tx10p"}
+
+
+def test_reference_call_programs_round6_through_the_wrappers(ref, dev, rng):
+    """42 more bodies of the reference's index modules (74 of the 123 functions of _threshold / _multivariate / _simple are
+    recorded now): replayed through the wrappers against the oracle, family by family — threshold counts with unit-string
+    defaults, plain resample reductions, degree days, the compare -> ``rl.resample_and_rl`` spell family (incl. the three
+    ``maximum_consecutive_*`` bodies that call ANOTHER index of the same module by name), the ``spell_length_statistics``
+    family behind ``rate2amount``, ``generic.season`` with every ``stat``, ``first_day_threshold_reached`` and the four
+    remaining per-doy percentile counts."""
+    import callprog
+
+    env, mods, _ = ref
+    progs = callprog.load_programs()
+    assert ROUND6_PROGRAMS <= set(progs)
+    T = 365 * 3
+    ta, ot = TimeAxis.daily("2001-01-01", T, "noleap"), OTime.noleap(2001, T)
+    tg = (_temp(rng, T, (3, 4), nan_frac=0.002) - 8.0).astype(np.float32)
+    tn, tx = (tg - 4).astype(np.float32), (tg + 5).astype(np.float32)
+    tas, tasmin, tasmax = (fakexr.field(v, ta, attrs={"units": "K"}) for v in (tg, tn, tx))
+    prv = np.where(rng.random((T, 3, 4)) < 0.35, rng.gamma(0.8, 8.0, (T, 3, 4)) / 86400.0, 0.0).astype(np.float32)
+    pr = fakexr.field(prv, ta, attrs={"units": "kg m-2 s-1"})
+    wv = np.abs(rng.normal(5.0, 4.0, (T, 3, 4))).astype(np.float32)
+    wind = fakexr.field(wv, ta, attrs={"units": "m s-1"})
+    mv, th, sp, cal = (mods[m] for m in ("xclim.indices._multivariate", "xclim.indices._threshold", "xclim.indices._simple", "xclim.core.calendar"))
+    K0 = 273.15
+    f32 = np.float32
+    done = set()
+
+    def check(name, got, exp, exact=True, units=None):
+        (np.testing.assert_array_equal if exact else (lambda a, b, **k: np.testing.assert_allclose(a, b, rtol=1e-6, equal_nan=True, **k)))(
+            got.values, exp, err_msg=name)
+        if units is not None:
+            assert got.attrs.get("units") == units, (name, got.attrs)
+        done.add(name)
+
+    # -- threshold counts: (module, name, field, values, op, threshold in the data's units, default freq, call keywords)
+    for mod, name, da, x, op, thr, freq, kw in (
+            (th, "calm_days", wind, wv, "<", 2.0, "MS", {}), (th, "windy_days", wind, wv, ">=", 10.8, "MS", {}),
+            (th, "tg_days_above", tas, tg, ">", K0 + 10, "YS", {}), (th, "tg_days_below", tas, tg, "<", K0 + 10, "YS", {}),
+            (th, "tn_days_above", tasmin, tn, ">", K0 + 6, "YS", {"thresh": "6 degC"}),
+            (th, "tx_days_below", tasmax, tx, "<=", K0 + 25, "MS", {"op": "<=", "freq": "MS"}),
+            (th, "warm_day_frequency", tasmax, tx, ">", K0 + 20, "YS", {"thresh": "20 degC"}),
+            (th, "warm_night_frequency", tasmin, tn, ">", K0 + 8, "YS", {"thresh": "8 degC"}),
+            (sp, "hot_days", tasmax, tx, ">", K0 + 25, "YS", {}), (sp, "ice_days", tasmax, tx, "<", K0, "YS", {})):
+        check(name, getattr(mod, name)(da, **kw), ogen.threshold_count(x, op, f32(thr), ot, freq), units="days")
+    # -- plain reductions
+    for name, da, x, op in (("tg_min", tas, tg, "min"), ("tn_max", tasmin, tn, "max"), ("tn_mean", tasmin, tn, "mean"),
+                            ("tx_mean", tasmax, tx, "mean"), ("tx_min", tasmax, tx, "min"), ("max_1day_precipitation_amount", pr, prv, "max")):
+        check(name, getattr(sp, name)(da, freq="MS"), ogen.select_resample_op(x, op, ot, "MS"), exact=op != "mean")
+    check("heating_degree_days", th.heating_degree_days(tas, thresh="12 degC"), ogen.cumulative_difference(tg, f32(K0 + 12), "<", ot, "YS"), exact=False)
+    # -- compare -> rl.resample_and_rl (default freq of the cold family: YS-JUL)
+    run = lambda x, op, thr, stat, w, freq, before=True: oidx.run_index(x, op, thr, stat, w, ot, freq, before)  # noqa: E731
+    for before in (True, False):
+        check("cold_spell_frequency", th.cold_spell_frequency(tas, thresh="2 degC", window=3, resample_before_rl=before),
+              run(tg, "<", f32(K0 + 2), "events", 3, "YS-JUL", before), units="")
+        check("cold_spell_total_length", th.cold_spell_total_length(tas, thresh="2 degC", window=3, resample_before_rl=before),
+              run(tg, "<", f32(K0 + 2), "count", 3, "YS-JUL", before), units="days")
+        check("heat_wave_index", th.heat_wave_index(tasmax, thresh="15 degC", window=4, resample_before_rl=before),
+              run(tx, ">", f32(K0 + 15), "count", 4, "YS", before), units="days")
+        check("hot_spell_total_length", th.hot_spell_total_length(tasmax, thresh="15 degC", window=2, freq="MS", resample_before_rl=before),
+              run(tx, ">", f32(K0 + 15), "count", 2, "MS", before), units="days")
+        check("cold_spell_max_length", th.cold_spell_max_length(tas, thresh="2 degC", window=2, resample_before_rl=before),
+              oidx.longest_run_index(tg, "<", f32(K0 + 2), 2, ot, "YS-JUL", before), units="days")
+        check("frost_free_spell_max_length", th.frost_free_spell_max_length(tasmin, window=3, resample_before_rl=before),
+              oidx.longest_run_index(tn, ">=", f32(K0), 3, ot, "YS-JUL", before), units="days")
+        # ... and the bodies that call ANOTHER index of the module by name (window=1)
+        check("maximum_consecutive_frost_days", th.maximum_consecutive_frost_days(tasmin, resample_before_rl=before),
+              oidx.longest_run_index(tn, "<", f32(K0), 1, ot, "YS-JUL", before), units="days")
+        check("maximum_consecutive_frost_free_days", th.maximum_consecutive_frost_free_days(tasmin, resample_before_rl=before),
+              oidx.longest_run_index(tn, ">=", f32(K0), 1, ot, "YS", before), units="days")
+        check("maximum_consecutive_tx_days", th.maximum_consecutive_tx_days(tasmax, thresh="12 degC", resample_before_rl=before),
+              oidx.longest_run_index(tx, ">", f32(K0 + 12), 1, ot, "YS", before), units="days")
+    cond = ((tn > f32(K0 + 2)) & (tx > f32(K0 + 12))).astype(np.float32)
+    check("heat_wave_total_length", mv.heat_wave_total_length(tasmin, tasmax, thresh_tasmin="2 degC", thresh_tasmax="12 degC", window=2),
+          orl.resample_and_rl(cond, True, orl.windowed_run_count, 2, time=ot, freq="YS"), units="days")
+    # -- spell_length_statistics behind convert_units_to(pr, "mm/d", context="hydro") + rate2amount
+    amount = (prv * f32(86400.0)).astype(np.float32)
+    for name, op, red, w in (("dry_spell_total_length", "<", "sum", 3), ("dry_spell_max_length", "<", "max", 2), ("wet_spell_frequency", ">=", "count", 2),
+                             ("wet_spell_total_length", ">=", "sum", 2), ("wet_spell_max_length", ">=", "max", 1)):
+        for before in (True, False):
+            check(name, getattr(th, name)(pr, thresh="2 mm", window=w, resample_before_rl=before),
+                  ogen.spell_length_statistics(amount, 2.0, w, "sum", op, red, ot, "YS", before))
+    # -- generic.season with every stat, first_day_threshold_reached
+    seg_of = lambda freq: ta.segments(freq)[0]  # noqa: E731
+
+    def to_doy(idx, freq):   # index inside the period -> day of the year (what coord="dayofyear" returns)
+        seg, out = seg_of(freq), np.full(idx.shape, np.nan)
+        for p in range(idx.shape[0]):
+            ok = ~np.isnan(idx[p])
+            out[p][ok] = ta.doy[int(seg[p]) + idx[p][ok].astype(int)]
+        return out
+
+    b, e, ln = orl.season_per_period(tg > f32(K0 + 5), 5, "07-01", ot, "YS")
+    check("growing_season_end", th.growing_season_end(tas), to_doy(e, "YS"))
+    b, e, ln = orl.season_per_period(tn >= f32(K0), 4, "07-01", ot, "YS")
+    check("frost_free_season_start", th.frost_free_season_start(tasmin, window=4), to_doy(b, "YS"))
+    check("frost_free_season_end", th.frost_free_season_end(tasmin, window=4), to_doy(e, "YS"))
+    check("frost_free_season_length", th.frost_free_season_length(tasmin, window=4), ln, units="days")
+    b, e, ln = orl.season_per_period(tn < f32(K0), 3, "01-01", ot, "YS-JUL")
+    check("frost_season_length", th.frost_season_length(tasmin, window=3), ln, units="days")
+    first = np.stack([orl.first_run_after_date(tg[idx] < f32(K0 + 1), 2, "07-01", ot.isel(idx)) for _, idx in orl.groups(ot, "YS")])
+    check("first_day_temperature_below", th.first_day_temperature_below(tas, thresh="1 degC", window=2), to_doy(first, "YS"))
+    # -- the remaining per-doy percentile counts
+    for name, da, x, per, op in (("tg90p", tas, tg, 88.0, ">"), ("tg10p", tas, tg, 12.0, "<"), ("tn90p", tasmin, tn, 88.0, ">"), ("tx10p", tasmax, tx, 12.0, "<")):
+        p_da = cal.percentile_doy(da, window=5, per=per).sel(percentiles=per)
+        p_o, doys = ocal.percentile_doy(x, ot, 5, per)
+        exp = (oidx.tx90p if op == ">" else oidx.tx10p)(x, p_o[..., 0], doys, ot, "YS")
+        check(name, getattr(mv, name)(da, p_da), exp, units="days")
+    assert done == ROUND6_PROGRAMS, sorted(ROUND6_PROGRAMS - done)
 
 
 @pytest.mark.parametrize("interp", ["nearest", "linear", "cubic"])
