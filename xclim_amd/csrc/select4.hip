@@ -71,7 +71,7 @@ constexpr int HS_CAPMAX = 2048;        // ... at most this many for one column i
 constexpr int HS_CAPBIG = 8192;        // ... and this many at all (2049 .. 8192: a bitonic sort in LDS, in place in the column's list)
 constexpr int HS_MAXQ = 32;            // quantiles per call on this path
 constexpr int HS_QREC_MAX = 2 * (HS_MAXQ + 1);  // QDM: records (collected bins) per column, two per class boundary
-constexpr int HS_QWS = 2 * HS_QREC_MAX + 64 + HS_MAXQ + 2 * HS_MAXQ;  // ... and the per-wave scratch of its epilogue: records | valid nodes | factors | quantiles (words)
+constexpr int HS_QWS = 2 * HS_QREC_MAX + 64 + HS_MAXQ + 2 * HS_MAXQ + 4;  // ... and the per-wave scratch of its epilogue: records | valid nodes | factors | quantiles | n, lo, hi (words)
 static_assert((HS_NT / 64) * HS_QWS <= 64 * HS_CW + 32 * HS_CW && HS_QWS % 2 == 0, "the epilogue's scratch lives in the dead tables of the streaming loop");
 constexpr uint32_t HS_NANKEY = 0xFFFFFFFFu;
 constexpr uint32_t HS_KEY_MINF = 0x00800000u, HS_KEY_MAXF = 0xFF7FFFFFu;  // keys of -FLT_MAX / +FLT_MAX
@@ -958,58 +958,52 @@ __device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm,
 // / maximum counted by pass 2): per class boundary the rank that decides it (qdmrank.h), its run of equal values among the candidates (or a pure bin),
 // the cut value -> gcut; the class factors -> gfac.  A rank outside the collected bins, or a run longer than the scan cap,
 // puts the column on the list for the exact-rank kernels (returns true).  ws: HS_QWS words of LDS scratch.
-// what hs_qdm_pick reads from global memory for one column: requested BEFORE the column's candidates are sorted, so that the
-// sort runs under the flying loads (asked for inside the pick, every column paid one L2 / HBM round trip after its sort)
-struct HsQdmPre {
-  uint32_t n, r0, r1;  // valid samples; the lane's record (nrec <= 64: HS_MAXQ = 32 -> 66 records: lanes 0 .. 1 hold a second one)
-  uint32_t r0b, r1b;
-  uint2 lh;
-  float af;            // lane j < nq: the factor of node j
-  double q;            // lane j < nq: quantile j
-};
+// What hs_qdm_pick reads from global memory for one column goes to the wave's LDS scratch BEFORE the column's candidates are
+// sorted — as plain load -> LDS-store pairs: kept in registers across the sort instead (a first version of this round), the
+// nine values per lane were spilled to scratch around it (128-VGPR cap of a 1024-thread workgroup): 5 GB of scratch traffic
+// per call in the PMC passes and nothing gained.
 template <int CW>
-__device__ __forceinline__ HsQdmPre hs_qdm_prefetch(const HsArgs& A, int64_t tile, int k, int64_t ck, int lane) {
+__device__ __forceinline__ void hs_qdm_stage(const HsArgs& A, int64_t tile, int k, int64_t ck, int lane, uint32_t* ws) {
   const int nq = A.nq, nrec = 2 * (nq + 1);
   const uint32_t* __restrict__ rec = A.qrec + (tile * nrec) * 2 * CW + k;
-  HsQdmPre P;
-  P.n = A.meta_n[ck];
-  P.lh = A.lohi[ck];
-  const int i0 = lane < nrec ? lane : nrec - 1, i1 = lane + 64 < nrec ? lane + 64 : nrec - 1;  // (clamped: no load inside a conditional)
-  P.r0 = rec[(i0 * 2 + 0) * CW];
-  P.r1 = rec[(i0 * 2 + 1) * CW];
-  P.r0b = rec[(i1 * 2 + 0) * CW];
-  P.r1b = rec[(i1 * 2 + 1) * CW];
-  const int j = lane < nq ? lane : nq - 1;
-  P.af = A.af[(int64_t)j * A.af_qs + ck];
-  P.q = A.qs[j];
-  return P;
+  uint2* recs = reinterpret_cast<uint2*>(ws);
+  uint32_t* tv = ws + 2 * HS_QREC_MAX;
+  float* afs = reinterpret_cast<float*>(tv + 64);
+  double* qss = reinterpret_cast<double*>(afs + HS_MAXQ);
+  uint32_t* hdr = reinterpret_cast<uint32_t*>(qss + HS_MAXQ);  // n | lo | hi
+  for (int i = lane; i < nrec; i += 64) recs[i] = make_uint2(rec[(i * 2 + 0) * CW], rec[(i * 2 + 1) * CW]);
+  if (lane < nq) {
+    afs[lane] = A.af[(int64_t)lane * A.af_qs + ck];
+    qss[lane] = A.qs[lane];
+  }
+  if (lane == 0) {
+    const uint2 lh = A.lohi[ck];
+    hdr[0] = A.meta_n[ck];
+    hdr[1] = lh.x;
+    hdr[2] = lh.y;
+  }
 }
 
 template <int CW>
-__device__ __forceinline__ bool hs_qdm_pick(const HsArgs& A, const HsQdmPre& P, const uint32_t* list, int64_t ck, int lane, uint32_t* ws,
+__device__ __forceinline__ bool hs_qdm_pick(const HsArgs& A, const uint32_t* list, int64_t ck, int lane, uint32_t* ws,
                                             uint32_t c0, uint32_t cmax) {
   const int nq = A.nq, ntest = nq + 1, nrec = 2 * (nq + 1);
-  const uint32_t n = P.n;
-  const uint2 lh = P.lh;
-  // The column's records go to LDS once (`ws`: per-wave scratch inside the tables of the streaming loop, which are dead in the
-  // epilogue) and every lane — one class boundary each — scans them with broadcast reads and selects, no branch, no scalar
-  // code.  Round 5 kept them in two registers per lane and read them back with v_readlane in a loop that `continue`d per
-  // record: 42 iterations of readlane -> scalar compare -> divergent branch per search, two searches per boundary —
-  // 7.0 of the 43.8 ms of QuantileDeltaMapping.adjust at 30 years x 1440 x 720 (tools/experiments/r06/qdm_c4_abl.py:
+  // The column's records sit in LDS (`ws`: per-wave scratch inside the tables of the streaming loop, which are dead in the
+  // epilogue; staged by hs_qdm_stage) and every lane — one class boundary each — scans them with broadcast reads and selects,
+  // no branch, no scalar code.  Round 5 kept them in two registers per lane and read them back with v_readlane in a loop that
+  // `continue`d per record: 42 iterations of readlane -> scalar compare -> divergent branch per search, two searches per
+  // boundary — 7.0 of the 43.8 ms of QuantileDeltaMapping.adjust at 30 years x 1440 x 720 (tools/experiments/r06/qdm_c4_abl.py:
   // XH_HIST_ABL=128 switches this function off), a chain of scalar-to-vector hazards that 16 waves of a CU ran in lock-step.
   uint2* recs = reinterpret_cast<uint2*>(ws);
   uint32_t* tv = ws + 2 * HS_QREC_MAX;
   float* afs = reinterpret_cast<float*>(tv + 64);       // [nq] the column's factors (the class factors below read them by node)
   double* qss = reinterpret_cast<double*>(afs + HS_MAXQ);  // [nq] the quantiles
-  if (lane < nrec) recs[lane] = make_uint2(P.r0, P.r1);
-  if (lane + 64 < nrec) recs[lane + 64] = make_uint2(P.r0b, P.r1b);
-  if (lane < nq) {
-    afs[lane] = P.af;
-    qss[lane] = P.q;
-  }
+  const uint32_t* hdr = reinterpret_cast<const uint32_t*>(qss + HS_MAXQ);
+  const uint32_t n = hdr[0];
+  const uint2 lh = make_uint2(hdr[1], hdr[2]);
   constexpr uint32_t CAP = 256u;
   // the column's valid nodes (NaN factors dropped), compacted through the wave: tv[pos] = node index
-  const float myaf = lane < nq ? P.af : xh_nan32();
+  const float myaf = lane < nq ? afs[lane] : xh_nan32();
   const unsigned long long vmask = __ballot(myaf == myaf);
   const uint32_t nvn = (uint32_t)__popcll(vmask);
   if (myaf == myaf) tv[__popcll(vmask & ((1ull << lane) - 1ull))] = (uint32_t)lane;
@@ -1243,8 +1237,7 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
       if (mm == HS_FLAGGED || (meta_base[ck] >> 16) != (uint32_t)round) continue;
       const uint32_t m = cursor[k];
       if (m != mm && lane == 0) atomicAdd(&stat->errors, 1u);
-      HsQdmPre pre;
-      if constexpr (QDM) pre = hs_qdm_prefetch<CW>(A, tile, k, ck, lane);
+      if constexpr (QDM) hs_qdm_stage<CW>(A, tile, k, ck, lane, tab + wv * HS_QWS);
       uint32_t* list = cand + (meta_base[ck] & 0xFFFFu);
       const uint32_t ms = m < mm ? m : mm;
       const float zero = QDM ? 0.0f : -0.0f;
@@ -1259,7 +1252,7 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
       __builtin_amdgcn_wave_barrier();
       if (!QDM) hs_pick_store<CW>(list, mm, tile, k, ck, lane, ntgt, nq, qs, meta_n, lohi, crank, tv, out, ocs, oqs);
       else if (abl & 128) {  // diagnostics: no QDM epilogue (results wrong)
-      } else if (hs_qdm_pick<CW>(A, pre, list, ck, lane, tab + wv * HS_QWS, cntmn[k], cntmx[k]) && lane == 0)
+      } else if (hs_qdm_pick<CW>(A, list, ck, lane, tab + wv * HS_QWS, cntmn[k], cntmx[k]) && lane == 0)
         A.flist[atomicAdd(&stat->nflag, 1u)] = (uint32_t)ck;  // (behind pass 1's own entries: the host reads the count afterwards)
     }
     __syncthreads();  // cand / tab / bm / cursor are rewritten by the next tile
