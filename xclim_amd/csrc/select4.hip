@@ -918,14 +918,11 @@ __device__ __forceinline__ void hs_sort_lds(uint32_t* __restrict__ list, uint32_
 // One column, its candidates sorted in `list` (LDS): pick the 2 nq order statistics by position, Hyndman-Fan lerp
 // (utl:464-491), store the nq quantiles.  One wave; tv = 64 words of LDS scratch.
 template <int CW>
-__device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm, int64_t tile, int k, int64_t ck, int lane, int ntgt,
-                                              int nq, const double* __restrict__ qs, const uint32_t* __restrict__ meta_n,
-                                              const uint2* __restrict__ lohi, const uint16_t* __restrict__ crank, uint32_t* tv,
+__device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm, int k, int64_t ck, int lane, int ntgt,
+                                              int nq, double qq, uint32_t n, uint2 lhk, const uint16_t* crank_s, uint32_t* tv,
                                               float* __restrict__ out, int64_t ocs, int64_t oqs) {
-  const uint32_t n = meta_n[ck];
-  const uint2 lhk = lohi[ck];
   if (lane < ntgt) {
-    const uint32_t cr = crank[(tile * ntgt + lane) * CW + k];
+    const uint32_t cr = crank_s[lane * CW + k];  // (the tile's [ntgt][CW] table, in LDS)
     uint32_t key = HS_NANKEY;
     if (cr == HS_SPEC_LO) key = lhk.x;
     else if (cr == HS_SPEC_HI) key = lhk.y;
@@ -939,7 +936,7 @@ __device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm,
     if (n == 0u) r = xh_nan64();
     else if (n < 2u) r = (double)left;
     else {
-      const double nn = (double)n, qq = qs[lane];
+      const double nn = (double)n;
       const double vi = nn * qq + (1.0 + qq * (1.0 - 1.0 - 1.0)) - 1.0;
       if (vi >= nn - 1.0 || vi < 0.0) r = (double)left;
       else {
@@ -963,7 +960,8 @@ __device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm,
 // nine values per lane were spilled to scratch around it (128-VGPR cap of a 1024-thread workgroup): 5 GB of scratch traffic
 // per call in the PMC passes and nothing gained.
 template <int CW>
-__device__ __forceinline__ void hs_qdm_stage(const HsArgs& A, int64_t tile, int k, int64_t ck, int lane, uint32_t* ws) {
+__device__ __forceinline__ void hs_qdm_stage(const HsArgs& A, int64_t tile, int k, int64_t ck, int lane, uint32_t* ws, uint32_t n,
+                                             uint32_t lo, uint32_t hi) {
   const int nq = A.nq, nrec = 2 * (nq + 1);
   const uint32_t* __restrict__ rec = A.qrec + (tile * nrec) * 2 * CW + k;
   uint2* recs = reinterpret_cast<uint2*>(ws);
@@ -977,10 +975,9 @@ __device__ __forceinline__ void hs_qdm_stage(const HsArgs& A, int64_t tile, int 
     qss[lane] = A.qs[lane];
   }
   if (lane == 0) {
-    const uint2 lh = A.lohi[ck];
-    hdr[0] = A.meta_n[ck];
-    hdr[1] = lh.x;
-    hdr[2] = lh.y;
+    hdr[0] = n;
+    hdr[1] = lo;
+    hdr[2] = hi;
   }
 }
 
@@ -1073,9 +1070,12 @@ __device__ __forceinline__ bool hs_qdm_pick(const HsArgs& A, const uint32_t* lis
 // ---- pass 2: collect the samples of the target bins, sort them per column, pick + lerp ---------------------------------
 // LDS: cand [64 * 512] candidates (the columns' lists back to back) | tab [64][64] bit pairs per regular index | bm [32][64]
 // bin bitmap (exact path) | cursor [64] | colok [64] | lbase [64] list offsets | cntmn / cntmx / valmn / valmx [64] (QDM) | tv [waves][64] picked keys
+// | cmeta [5][64] the columns' candidate count, list base | round, valid samples, window ends (round 6: the epilogue read them
+// from global memory column by column — five dependent L2 round trips per column in front of and behind its sort)
 constexpr size_t hs_lds2() {
-  return (size_t)HS_POOL * 4 + 64 * HS_CW * 4 + 32 * HS_CW * 4 + 7 * HS_CW * 4 + (size_t)(HS_NT / 64) * 64 * 4;
+  return (size_t)HS_POOL * 4 + 64 * HS_CW * 4 + 32 * HS_CW * 4 + 7 * HS_CW * 4 + (size_t)(HS_NT / 64) * 64 * 4 + 5 * HS_CW * 4;
 }
+static_assert(hs_lds2() <= 160 * 1024, "pass 2: LDS");
 
 // One tile of pass 2 (collect round `round`).  `rev`: the full batches are streamed from the last one down (fused kernel).
 // The ring is primed here.  Returns without streaming when no column of the tile belongs to this round.
@@ -1108,6 +1108,7 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
   float* valmn = reinterpret_cast<float*>(cntmx + CW);  // ... and the two values (read per batch: they must not live in registers)
   float* valmx = valmn + CW;
   uint32_t* tvall = reinterpret_cast<uint32_t*>(valmx + CW);
+  uint32_t* cmeta = tvall + (NT / 64) * 64;  // [0] meta_m | [1] meta_base | [2] meta_n | [3] lo | [4] hi, each [CW]
   const int tid = threadIdx.x, col = tid & (CW - 1), rl = tid / CW;
   const int lane = tid & 63, wv = tid >> 6;
   const int ntgt = 2 * nq;
@@ -1125,6 +1126,11 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
       lbase[tid] = collect ? (mbase & 0xFFFFu) : 0u;
       cntmn[tid] = 0u;
       cntmx[tid] = 0u;
+      cmeta[0 * CW + tid] = cvalid ? meta_m[cc] : HS_FLAGGED;
+      cmeta[1 * CW + tid] = mbase;
+      cmeta[2 * CW + tid] = meta_n[cc];
+      cmeta[3 * CW + tid] = lh.x;
+      cmeta[4 * CW + tid] = lh.y;
       if (QDM) {
         valmn[tid] = A.colmin[cc];
         valmx[tid] = A.colmax[cc];
@@ -1228,17 +1234,28 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
     if ((abl & 96) && dummy == 0x12345679u) atomicAdd(&stat->errors, 1u);
     __syncthreads();
     if (abl & 96) return;
-    // ---- one wave per column: sort, pick, lerp (utl:464-491), store
+    // ---- one wave per column: sort, pick, lerp (utl:464-491), store.  Nothing in the column loop reads global memory in the
+    // quantile mode: the columns' metadata sit in LDS since the tile's start, the positions of the targets among the sorted
+    // candidates (crank, [ntgt][CW] u16 per tile) are copied into the dead tables of the streaming loop by the whole workgroup,
+    // the quantiles wait in a register pair.
     uint32_t* tv = tvall + wv * 64;
+    const uint16_t* crank_s = reinterpret_cast<const uint16_t*>(tab);
+    double qv = 0.0;
+    if constexpr (!QDM) {
+      const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(crank + tile * ntgt * CW);
+      for (int i = tid; i < ntgt * CW / 2; i += NT) tab[i] = src[i];
+      qv = qs[lane < nq ? lane : 0];
+      __syncthreads();
+    }
     for (int k = wv; k < CW; k += NT / 64) {
       const int64_t ck = tile * CW + k;
       if (ck >= C) break;  // (wave-uniform)
-      const uint32_t mm = meta_m[ck];
-      if (mm == HS_FLAGGED || (meta_base[ck] >> 16) != (uint32_t)round) continue;
+      const uint32_t mm = cmeta[0 * CW + k], mb = cmeta[1 * CW + k];
+      if (mm == HS_FLAGGED || (mb >> 16) != (uint32_t)round) continue;
       const uint32_t m = cursor[k];
       if (m != mm && lane == 0) atomicAdd(&stat->errors, 1u);
-      if constexpr (QDM) hs_qdm_stage<CW>(A, tile, k, ck, lane, tab + wv * HS_QWS);
-      uint32_t* list = cand + (meta_base[ck] & 0xFFFFu);
+      if constexpr (QDM) hs_qdm_stage<CW>(A, tile, k, ck, lane, tab + wv * HS_QWS, cmeta[2 * CW + k], cmeta[3 * CW + k], cmeta[4 * CW + k]);
+      uint32_t* list = cand + (mb & 0xFFFFu);
       const uint32_t ms = m < mm ? m : mm;
       const float zero = QDM ? 0.0f : -0.0f;
       if (abl & 1) {
@@ -1250,7 +1267,7 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
       else if (ms > 64u) hs_sort_column<2>(list, ms, lane, zero);
       else if (ms > 0u) hs_sort_column<1>(list, ms, lane, zero);  // (one candidate: only turned into its key)
       __builtin_amdgcn_wave_barrier();
-      if (!QDM) hs_pick_store<CW>(list, mm, tile, k, ck, lane, ntgt, nq, qs, meta_n, lohi, crank, tv, out, ocs, oqs);
+      if (!QDM) hs_pick_store<CW>(list, mm, k, ck, lane, ntgt, nq, qv, cmeta[2 * CW + k], make_uint2(cmeta[3 * CW + k], cmeta[4 * CW + k]), crank_s, tv, out, ocs, oqs);
       else if (abl & 128) {  // diagnostics: no QDM epilogue (results wrong)
       } else if (hs_qdm_pick<CW>(A, list, ck, lane, tab + wv * HS_QWS, cntmn[k], cntmx[k]) && lane == 0)
         A.flist[atomicAdd(&stat->nflag, 1u)] = (uint32_t)ck;  // (behind pass 1's own entries: the host reads the count afterwards)
