@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s best meas
 # idle) ran up to 40 % slower on one of ~10 boxes of the pool; they are not part of the measurement either way
 WAKEUP_STEPS = 30
 
-PMC_TABLES = ("profiles/r05/pmc_hbm_traffic.json", "profiles/r04/pmc_hbm_traffic.json", "profiles/r03/pmc_hbm_traffic.json", "profiles/r02/pmc_hbm_traffic.json")
+PMC_TABLES = ("profiles/r06/pmc_hbm_traffic.json", "profiles/r05/pmc_hbm_traffic.json", "profiles/r04/pmc_hbm_traffic.json", "profiles/r03/pmc_hbm_traffic.json", "profiles/r02/pmc_hbm_traffic.json")
 
 
 def pmc_traffic(kernel, grid):
@@ -82,7 +82,7 @@ def valu_bound(kernel):
     tools/summarize_sq.py -> profiles/r03/valu_busy.json): VALU instructions per SIMD x the measured issue cost of a
     wave64 instruction (2.5 cycles of the ~2.4 GHz clock for add / xor / mov, 4.3 for min / max / cmp:
     profiles/r03/valu_ubench.txt, bank_ubench.txt) over the kernel's cycles.  busy_hi near 1 = no faster without issuing fewer instructions.  None when not profiled."""
-    for rel in ("profiles/r05/valu_busy.json", "profiles/r04/valu_busy.json", "profiles/r03/valu_busy.json"):
+    for rel in ("profiles/r06/valu_busy.json", "profiles/r05/valu_busy.json", "profiles/r04/valu_busy.json", "profiles/r03/valu_busy.json"):
         try:
             table = json.load(open(os.path.join(ROOT, rel)))
         except (OSError, ValueError):
@@ -94,7 +94,7 @@ def valu_bound(kernel):
     return None
 
 
-PMC_30YR = "profiles/r05/pmc_hbm_traffic_30yr.json"
+PMC_30YR = "profiles/r06/pmc_hbm_traffic_30yr.json"
 
 
 def pmc_traffic_30yr(*kernels):
