@@ -915,10 +915,24 @@ __device__ __forceinline__ void hs_sort_lds(uint32_t* __restrict__ list, uint32_
   }
 }
 
+// element at (0-based) position p of the merge of two ascending runs A[0, nA) and B[0, nB) (keys; p < nA + nB): the merge-path
+// split — the smallest i with B[p - i - 1] <= A[i] (or i at an end) takes i elements of A and p - i of B in front of it
+__device__ __forceinline__ uint32_t hs_merged_at(const uint32_t* A, uint32_t nA, const uint32_t* B, uint32_t nB, uint32_t p) {
+  uint32_t lo = p > nB ? p - nB : 0u, hi = p < nA ? p : nA;
+  while (lo < hi) {
+    const uint32_t i = (lo + hi) >> 1, j = p - i;  // (i < hi <= min(p, nA): j >= 1, A[i] exists; j <= nB by lo's start)
+    if (B[j - 1u] <= A[i]) hi = i; else lo = i + 1u;
+  }
+  const uint32_t j = p - lo;
+  const uint32_t a = lo < nA ? A[lo] : HS_NANKEY, b = j < nB ? B[j] : HS_NANKEY;
+  return a < b ? a : b;
+}
+
 // One column, its candidates sorted in `list` (LDS): pick the 2 nq order statistics by position, Hyndman-Fan lerp
 // (utl:464-491), store the nq quantiles.  One wave; tv = 64 words of LDS scratch.
+// nA = 0: `list` is sorted as a whole; otherwise two sorted runs, [0, nA) and [nA, mm)
 template <int CW>
-__device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm, int k, int64_t ck, int lane, int ntgt,
+__device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm, uint32_t nA, int k, int64_t ck, int lane, int ntgt,
                                               int nq, double qq, uint32_t n, uint2 lhk, const uint16_t* crank_s, uint32_t* tv,
                                               float* __restrict__ out, int64_t ocs, int64_t oqs) {
   if (lane < ntgt) {
@@ -926,7 +940,7 @@ __device__ __forceinline__ void hs_pick_store(const uint32_t* list, uint32_t mm,
     uint32_t key = HS_NANKEY;
     if (cr == HS_SPEC_LO) key = lhk.x;
     else if (cr == HS_SPEC_HI) key = lhk.y;
-    else if (cr < mm) key = list[cr];
+    else if (cr < mm) key = nA ? hs_merged_at(list, nA, list + nA, mm - nA, cr) : list[cr];
     tv[lane] = key;
   }
   __builtin_amdgcn_wave_barrier();
@@ -1258,7 +1272,19 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
       uint32_t* list = cand + (mb & 0xFFFFu);
       const uint32_t ms = m < mm ? m : mm;
       const float zero = QDM ? 0.0f : -0.0f;
+      // Quantile mode, 257 .. 512 candidates (the typical column of a 30-year series holds ~275): TWO sorted runs — the first
+      // 256 keys through the 256-slot network (36 stages on 4 registers), the rest through the 64 / 128 / 256-slot one — and
+      // the <= 2 nq targets picked from their merge by a merge-path search (<= 9 steps of two LDS reads per target, the targets
+      // in parallel) instead of one 512-slot network (45 stages on 8 registers) for ~275 keys.
+      uint32_t runA = 0u;
       if (abl & 1) {
+      } else if (!QDM && ms > 256u && ms <= 512u && m == mm && !(abl & 2048)) {
+        runA = 256u;
+        hs_sort_column<4>(list, 256u, lane, zero);
+        const uint32_t rest = ms - 256u;
+        if (rest > 128u) hs_sort_column<4>(list + 256, rest, lane, zero);
+        else if (rest > 64u) hs_sort_column<2>(list + 256, rest, lane, zero);
+        else hs_sort_column<1>(list + 256, rest, lane, zero);
       } else if (ms > (uint32_t)HS_CAPMAX) hs_sort_lds(list, ms, lane, zero);
       else if (ms > 1024u) hs_sort_column<32>(list, ms, lane, zero);
       else if (ms > 512u) hs_sort_column<16>(list, ms, lane, zero);
@@ -1267,7 +1293,7 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
       else if (ms > 64u) hs_sort_column<2>(list, ms, lane, zero);
       else if (ms > 0u) hs_sort_column<1>(list, ms, lane, zero);  // (one candidate: only turned into its key)
       __builtin_amdgcn_wave_barrier();
-      if (!QDM) hs_pick_store<CW>(list, mm, k, ck, lane, ntgt, nq, qv, cmeta[2 * CW + k], make_uint2(cmeta[3 * CW + k], cmeta[4 * CW + k]), crank_s, tv, out, ocs, oqs);
+      if (!QDM) hs_pick_store<CW>(list, mm, runA, k, ck, lane, ntgt, nq, qv, cmeta[2 * CW + k], make_uint2(cmeta[3 * CW + k], cmeta[4 * CW + k]), crank_s, tv, out, ocs, oqs);
       else if (abl & 128) {  // diagnostics: no QDM epilogue (results wrong)
       } else if (hs_qdm_pick<CW>(A, list, ck, lane, tab + wv * HS_QWS, cntmn[k], cntmx[k]) && lane == 0)
         A.flist[atomicAdd(&stat->nflag, 1u)] = (uint32_t)ck;  // (behind pass 1's own entries: the host reads the count afterwards)
@@ -1472,7 +1498,7 @@ int hs_run(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const 
 #undef XH_HS_GEOM
     XH_LAUNCH_CHECK();
   }
-  const char* eabl = xh_diag_env("XH_HIST_ABL");  // diagnostics: 1 = no candidate sort, 2 = pass 1 loads only, 4 = no pass-1 tile epilogue, 32 = no appends, 64 = pass 2 loads only, 128 = no QDM epilogue, 256 = no counting of the extremes (wrong results)
+  const char* eabl = xh_diag_env("XH_HIST_ABL");  // diagnostics: 1 = no candidate sort, 2 = pass 1 loads only, 4 = no pass-1 tile epilogue, 32 = no appends, 64 = pass 2 loads only, 128 = no QDM epilogue, 256 = no counting of the extremes (wrong results); 2048 = one 512-slot sort instead of two runs (same results: A/B)
   const int abl = eabl ? atoi(eabl) : 0;
   // the streaming ring: 5 sets of 8 loads (32 to 40 loads per lane in flight).  Diagnostics: XH_HIST_RING=162 = two sets of 16
   // (round 3's ping-pong: 16 to 32 in flight; config-4 train 40.5 against 36.7-38.2 ms on the same box, profiles/r04/)
