@@ -22,5 +22,5 @@ out = {}
 os.environ["XH_DIAGNOSTICS"] = "1"
 for abl in sys.argv[1:] or ["0"]:
     os.environ["XH_HIST_ABL"] = abl
-    out[abl] = bench.event_time(dev, lambda: K.qdm_adjust(dev, sim, af, q, "+", "nearest", "constant", out=scen), 2)
+    out.setdefault(abl, []).append(round(bench.event_time(dev, lambda: K.qdm_adjust(dev, sim, af, q, "+", "nearest", "constant", out=scen), 2), 3))
 print(json.dumps(out))
