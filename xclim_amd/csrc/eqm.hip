@@ -64,10 +64,19 @@ k_eqm_adjust(const float* __restrict__ sim, int64_t T, int64_t C, int64_t st, co
   const float inf = __uint_as_float(0x7F800000u);
   float firstx = 0.f, firsty = xh_nan32(), lastx = 0.f, lasty = xh_nan32();
   int m = 0;
+  // every node of the cell is requested before the first one is used: unconditional loads from a clamped row into register
+  // arrays (a load inside `if (j < nq)`, consumed in the same iteration, was followed by s_waitcnt vmcnt(0) — the 2 x nq node
+  // loads of a cell were nq dependent round trips at the start of every block: DESIGN.md §7, the compiler rule)
+  float xl[NQMAX], yl[NQMAX];
 #pragma unroll
   for (int j = 0; j < NQMAX; ++j) {
-    float xj = xh_nan32(), yj = xh_nan32();
-    if (j < nq) { xj = hq[(int64_t)j * C + c]; yj = af[(int64_t)j * C + c]; }
+    const int jj = j < nq ? j : nq - 1;
+    xl[j] = hq[(int64_t)jj * C + c];
+    yl[j] = af[(int64_t)jj * C + c];
+  }
+#pragma unroll
+  for (int j = 0; j < NQMAX; ++j) {
+    const float xj = j < nq ? xl[j] : xh_nan32(), yj = j < nq ? yl[j] : xh_nan32();
     bool valid = (xj == xj) && (yj == yj);
     nx[j] = valid ? xj : xh_nan32();
     ny[j] = yj;
@@ -170,10 +179,19 @@ k_eqm_adjust_g2d(const float* __restrict__ sim, int64_t n, int64_t C, int64_t st
   float nx[NQMAX], ny[NQMAX];
   float firstx = 0.f, firsty = xh_nan32(), lastx = 0.f, lasty = xh_nan32();
   int m = 0;
+  // every node of the cell is requested before the first one is used: unconditional loads from a clamped row into register
+  // arrays (a load inside `if (j < nq)`, consumed in the same iteration, was followed by s_waitcnt vmcnt(0) — the 2 x nq node
+  // loads of a cell were nq dependent round trips at the start of every block: DESIGN.md §7, the compiler rule)
+  float xl[NQMAX], yl[NQMAX];
 #pragma unroll
   for (int j = 0; j < NQMAX; ++j) {
-    float xj = xh_nan32(), yj = xh_nan32();
-    if (j < nq) { xj = hq[(int64_t)j * C + c]; yj = af[(int64_t)j * C + c]; }
+    const int jj = j < nq ? j : nq - 1;
+    xl[j] = hq[(int64_t)jj * C + c];
+    yl[j] = af[(int64_t)jj * C + c];
+  }
+#pragma unroll
+  for (int j = 0; j < NQMAX; ++j) {
+    const float xj = j < nq ? xl[j] : xh_nan32(), yj = j < nq ? yl[j] : xh_nan32();
     const bool valid = (xj == xj) && (yj == yj);
     nx[j] = valid ? xj : xh_nan32();
     ny[j] = yj;
