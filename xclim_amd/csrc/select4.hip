@@ -1285,8 +1285,19 @@ __device__ __forceinline__ void hs_collect_tile(const HsArgs& A, HsRing<HS_U, NS
         if (rest > 128u) hs_sort_column<4>(list + 256, rest, lane, zero);
         else if (rest > 64u) hs_sort_column<2>(list + 256, rest, lane, zero);
         else hs_sort_column<1>(list + 256, rest, lane, zero);
-      } else if (ms > (uint32_t)HS_CAPMAX) hs_sort_lds(list, ms, lane, zero);
-      else if (ms > 1024u) hs_sort_column<32>(list, ms, lane, zero);
+      } else if (!QDM && ms > 1024u && ms <= 2048u && m == mm && !(abl & 2048)) {
+        // the same for 1025 .. 2048 candidates (series of 55 152 steps: ~1230 per column): the 2048-slot network on 32 registers
+        // per lane was measured at 3.7 x its instruction count (anatomy of eqm_55k: 8.5 of 67 ms) — two runs on 16 registers
+        runA = 1024u;
+        hs_sort_column<16>(list, 1024u, lane, zero);
+        const uint32_t rest = ms - 1024u;
+        if (rest > 512u) hs_sort_column<16>(list + 1024, rest, lane, zero);
+        else if (rest > 256u) hs_sort_column<8>(list + 1024, rest, lane, zero);
+        else if (rest > 128u) hs_sort_column<4>(list + 1024, rest, lane, zero);
+        else if (rest > 64u) hs_sort_column<2>(list + 1024, rest, lane, zero);
+        else hs_sort_column<1>(list + 1024, rest, lane, zero);
+      } else if (ms > (uint32_t)HS_CAPMAX) { if (!(abl & 8192)) hs_sort_lds(list, ms, lane, zero); }
+      else if (ms > 1024u) { if (!(abl & 16384)) hs_sort_column<32>(list, ms, lane, zero); }
       else if (ms > 512u) hs_sort_column<16>(list, ms, lane, zero);
       else if (ms > 256u) hs_sort_column<8>(list, ms, lane, zero);
       else if (ms > 128u) hs_sort_column<4>(list, ms, lane, zero);
