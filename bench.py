@@ -639,6 +639,7 @@ def bench_full_configs(dev, K, C, long_series=True):
         a.free()
     out["eqm_doy_linear"] = bench_plane_linear(dev, K, C // 8)
     out["eqm_month_linear"] = bench_plane_month(dev, K, C // 8)
+    out["eqm_doy_window31"] = bench_doy_window(dev, K, C // 8)
     out["tx90p_bootstrap_band"] = bench_bootstrap(dev, K, C // 8)
     out["c5_slab"] = bench_c5_slab(dev, K)
     if not long_series:
@@ -741,6 +742,51 @@ def bench_plane_month(dev, K, Cb):
                                            "pair of rows) + the Delaunay walk of the listed queries (gathers + fp64): ~28 ms on these nodes, 85 ms "
                                            "on the noisier nodes of a model trained on the synthetic field (tools/experiments/r05/gpu_r05_p.sh)")}
     for a in (d_hq, d_af, sim, scen, gd):
+        a.free()
+    return res
+
+
+def bench_doy_window(dev, K, Cb):
+    """The documented standard configuration END TO END through the host mirror (docs/sdba.rst:64-65:
+    ``EmpiricalQuantileMapping.train(ref, hist, nquantiles=20, group=Grouper("time.dayofyear", window=31))`` then
+    ``.adjust(sim, interp=...)``), 30 years on a 1440 x 90 band, device-resident series, wall clock of the Python calls
+    (365 x 2 quantile problems of 930 samples per cell in training: transposes + k_select_quantile per group and field).  The
+    adjust legs run on the TRAINED node tables (smooth from one day of the year to the next), not on the random ones of
+    extra.eqm_doy_linear."""
+    import time
+
+    from xclim_amd import sdba
+    from xclim_amd.timeaxis import TimeAxis
+
+    T = 10950
+    ta = TimeAxis.daily("1981-01-01", T, "noleap")
+    base = seasonal_base(T)
+    ref = K.fill_synthetic(dev, T, Cb, 0, 4, base, 3.0)
+    hist = K.fill_synthetic(dev, T, Cb, 0, 5, base + np.float32(1.5), 3.3)
+    sim = K.fill_synthetic(dev, T, Cb, 0, 6, base + np.float32(3.5), 3.3)
+
+    def timed(fn, n):
+        r = fn()
+        dev.sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        dev.sync()
+        return (time.perf_counter() - t0) / n * 1e3, r
+
+    ms_tr, eqm = timed(lambda: sdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=20, kind="+", group="time.dayofyear", window=31,
+                                                                  time=ta, device=dev), 1)
+    ms_near, _ = timed(lambda: eqm.adjust(sim, interp="nearest", time=ta, keep=True), 2)
+    ms_lin, _ = timed(lambda: eqm.adjust(sim, interp="linear", time=ta, keep=True), 2)
+    E = float(T) * Cb
+    res = {"train_ms": ms_tr, "adjust_nearest_ms": ms_near, "adjust_linear_ms": ms_lin, "grid": [T, 1440, 90], "groups": 365, "window": 31,
+           "nodes": 20, "train_samples_GB": 2 * 365 * 930 * 4.0 * Cb / 1e9,
+           "train_GB/s": 2 * 365 * 930 * 4.0 * Cb / ms_tr / 1e6, "adjust_linear_GB/s": 8 * E / ms_lin / 1e6,
+           "adjust_linear_frac": 8 * E / ms_lin / 1e6 / HBM_PEAK_GBS,
+           "note": "wall clock of the host mirror calls (device-resident inputs); training = 730 selection problems of 930 samples per "
+                   "cell (the windowed sample of a group kept as a ring of rows), 0.75 TB/s over the samples it selects from: the "
+                   "weakest selection size of the family (DESIGN.md section 7)"}
+    for a in (ref, hist, sim):
         a.free()
     return res
 
