@@ -464,6 +464,17 @@ int xh_quantile_series(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_
  * ref_q / hist_q (kind 1 "*").  af, hist_q (nq, C) float32. */
 int xh_eqm_train(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, int64_t sc,
                  const double* q /* host */, int nq, int kind, float* af, float* hist_q);
+/* eqm_train over a SLIDING row sample: the G groups of Grouper("time.dayofyear", window=W) on a series where every year holds
+ * every day (xsdba >= 0.4 base.Grouper + _adjustment.eqm_train per windowed block; documented standard configuration:
+ * /root/reference/docs/sdba.rst:64-65, re-exported by /root/reference/src/xclim/sdba.py:10).  rows0 [n0 <= 1024] (host): the
+ * time steps of the first group's sample, -1 = beyond the series; leave / enter [G - 1][per <= 64] (host): the time steps that
+ * leave / enter the sample from group g to g + 1 (-1 = none).  Every cell keeps its window sorted and updates it per step
+ * (winsel.hip) — results bit-identical to xh_eqm_train on each group's gathered sample.  af, hist_q (G, nq <= 32, C) float32.
+ * XH_ERR_NOTIMPL (no error text) for other shapes: gather each group's sample and call xh_eqm_train. */
+int xh_eqm_train_window(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st,
+                        const int32_t* rows0 /* host */, int n0, const int32_t* enter /* host */,
+                        const int32_t* leave /* host */, int G, int per, const double* q /* host */, int nq, int kind,
+                        float* af, float* hist_q);
 /* qm_adjust: af_t = interp_on_quantiles(sim, hist_q, af) (interp 0 nearest, 1 linear, 2 cubic [not-a-knot spline as
  * scipy interp1d(kind="cubic"), nq <= 32, >= 4 valid nodes per cell else NaN]; extrap 0 constant,
  * 1 nan); scen = sim + af_t (kind 0) or sim * af_t (kind 1); kind 2: scen = af_t, the interpolated factor itself

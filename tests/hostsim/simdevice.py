@@ -32,7 +32,7 @@ UNIT_DEFINES = {"eqm": ["-D__all(x)=((x)!=0)"],
 
 
 # units whose kernels talk through LDS / the wave in WAVE-UNIFORM control flow: every workgroup as a set of fibers (simt.h)
-FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core", "reduce2", "pdoy_top", "pdoy_quad", "pdoy_walk", "select3", "qdm2", "select2", "select4")
+FIBER_UNITS = ("f64", "select", "select5", "tcount", "qdm", "quantile", "doystats", "core", "reduce2", "pdoy_top", "pdoy_quad", "pdoy_walk", "select3", "qdm2", "select2", "select4", "winsel")
 # topnet.h (the comparator networks of the register percentile kernels) issues v_min_f32 / v_max_f32 and a NaN-replace-and-count
 # triple as inline ISA: four statements, rewritten to the C++ they stand for (NaN never enters the min / max: the callers replace
 # it first), in a copy of the header that the fiber units include instead
@@ -67,6 +67,8 @@ UNIT_REWRITES = {
     # row_shl / row_shr / row_ror) = the value of lane ^ m; the sign of a float difference is one v_med3_i32 on its bits; column
     # extremes through v_min / v_max (which return the other operand for a NaN one, like fminf / fmaxf); the candidate appends are
     # sixteen LDS writes under the execution mask (v_cmpx) at an address kept as a 32-bit LDS offset
+    # winsel.hip (the sliding sorted window of the day-of-year training): the same DPP lane exchanges as select4's wave sort
+    "winsel": [(r"(__device__ __forceinline__ uint32_t ws_lane_xor\(uint32_t v, int m\) \{).*?\n\}\n", r"\1 return (uint32_t)__shfl_xor((int)v, m); }\n")],
     "select4": [
         (r"(__device__ __forceinline__ uint32_t hs_lane_xor\(uint32_t v, int m\) \{).*?\n\}\n", r"\1 return (uint32_t)__shfl_xor((int)v, m); }\n"),
         (r'asm\("v_med3_i32 %0, %1, -1, 1" : "=v"\(r\) : "v"\(z\)\);', "{ int zi_; memcpy(&zi_, &z, 4); r = zi_ < -1 ? -1 : (zi_ > 1 ? 1 : zi_); }"),

@@ -1962,3 +1962,42 @@ def test_reference_missing_answers_on_the_device(dev):
     assert not out[0] and out[1] and not out[2]
     np.testing.assert_array_equal(hmiss.missing_any(np.zeros(360, np.float32), None, t(360), device=dev), [False])
     np.testing.assert_array_equal(hmiss.missing_any(np.zeros(360, np.float32), None, t(360), device=dev, month=[7]), [False])
+
+
+@pytest.mark.parametrize("years,window,nq,kind", [(2, 3, 5, "+"), (4, 5, 7, "+"), (6, 9, 20, "*"), (3, 31, 12, "+"), (30, 31, 20, "+")])
+def test_eqm_doy_window_sliding_matches_per_group(dev, rng, monkeypatch, years, window, nq, kind):
+    """winsel.hip (round 6): day-of-year groups with a window — every cell keeps its window SORTED from one day to the next
+    (xh_eqm_train_window) instead of selecting each of the 365 groups from its gathered sample (xh_eqm_train per group: the
+    route of rounds 2-5, kept behind XH_WINSEL=0).  BIT-IDENTICAL tables: NaN samples, ties (rounded values), infinities, an
+    empty cell, windows that reach beyond both ends of the series, 30 years x 31 days = 930 samples."""
+    from xclim_amd import sdba as xsdba
+
+    T = 365 * years
+    cells = 29 if years < 30 else 40
+    cells = 9 if years == 2 else cells      # (the shape the CPU tier runs on the host simulation)
+    ta = TimeAxis.daily("2001-01-01", T, "noleap")
+    t = np.arange(T)[:, None]
+    ref = (288 + 10 * np.sin(2 * np.pi * t / 365) + rng.normal(0, 3, (T, cells))).astype(np.float32)
+    hist = (ref[::-1] * 1.01 + rng.normal(0, 1, (T, cells))).astype(np.float32)
+    ref[rng.random(ref.shape) < 0.03] = np.nan
+    hist[rng.random(hist.shape) < 0.02] = np.nan
+    if years == 6:
+        ref = np.round(ref, 1)        # ties: many equal samples leave and enter
+        hist = np.round(hist, 0)
+    hist[:, 3] = np.nan                # a cell without samples
+    ref[40:50, 5] = np.inf
+    hist[100:103, 6] = -np.inf
+    monkeypatch.setenv("XH_DIAGNOSTICS", "1")
+    monkeypatch.setenv("XH_WINSEL", "1")
+    trace = dev.start_trace()
+    a = xsdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=nq, kind=kind, group="time.dayofyear", window=window, time=ta, device=dev)
+    dev.stop_trace()
+    assert [n for n, _ in trace].count("xh_eqm_train_window") == 1 and "xh_eqm_train" not in [n for n, _ in trace]
+    monkeypatch.setenv("XH_WINSEL", "0")
+    trace = dev.start_trace()
+    b = xsdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=nq, kind=kind, group="time.dayofyear", window=window, time=ta, device=dev)
+    dev.stop_trace()
+    assert [n for n, _ in trace].count("xh_eqm_train") == 365
+    np.testing.assert_array_equal(a.hist_q, b.hist_q)
+    np.testing.assert_array_equal(a.af, b.af)
+    assert np.isnan(a.hist_q[:, :, 3]).all() and np.isfinite(a.hist_q[:, :, 0]).all()

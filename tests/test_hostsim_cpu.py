@@ -3,9 +3,9 @@ with g++ against a stand-in for the HIP runtime and run on the CPU:
   * thread by thread — detrend, window, runlen, reduce, spell, elemwise, eqm, wquantile (no LDS traffic between threads),
     and plane.hip with its wave-aggregated work-list appends as waves of one lane;
   * every workgroup as a set of FIBERS (simt.h: __syncthreads, wave-uniform shuffles / votes / readlane, atomics) — f64, select,
-    select2, select3, select4, select5, tcount, qdm, qdm2, quantile, doystats, reduce2, pdoy_top, pdoy_quad, pdoy_walk and the
+    select2, select3, select4, select5, tcount, qdm, qdm2, quantile, doystats, reduce2, pdoy_top, pdoy_quad, pdoy_walk, winsel and the
     kernels of core.hip (transposes, synthetic fields).
-63 of the 93 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
+64 of the 94 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
 other 30 are runtime services (memory, streams, RCCL).  The register percentile kernels (pdoy_top / pdoy_quad / pdoy_walk) run on
 fibers too, with the four ISA statements of topnet.h rewritten to the C++ they stand for, and so do the register sorting networks
 (select3 / qdm2: the DPP split across the lane pair as a shuffle), select2's wave counts on VCC and the streaming two-pass selection
@@ -240,4 +240,12 @@ def test_quantile_mapping_api_on_the_simulation(sim):
     series beyond 32768 steps (rocPRIM for the flagged columns), and the slow ones here (day-of-year groupings, bootstrap,
     20 000+ steps)."""
     _child_run(sim, ["tests/test_gpu_api.py"], at_least=60,
-               skip="not (qdm or eqm or dqm or sdba) or bootstrap or adapt or sub_groupings or beyond or dayofyear or 32768 or 20000")
+               skip="not (qdm or eqm or dqm or sdba) or bootstrap or adapt or sub_groupings or beyond or dayofyear or 32768 or 20000 "
+                    "or sliding_matches_per_group")   # (winsel.hip: its own test below, the small shapes)
+
+
+def test_sliding_window_training_on_the_simulation(sim):
+    """winsel.hip (round 6: the sorted sliding window of the day-of-year training) on fibers — DPP lane exchanges as shuffles —
+    against the per-group selection, bit for bit: the smallest shape of tests/test_gpu_api.py's A/B test (NaN samples, ties,
+    infinities, an empty cell, windows that reach beyond the series)."""
+    _child_run(sim, ["tests/test_gpu_api.py"], at_least=1, skip="not (sliding_matches_per_group and 2-3-5)")

@@ -576,6 +576,34 @@ def eqm_train(dev: Device, ref: DeviceArray, hist: DeviceArray, q, kind="+", tim
     return af, hq
 
 
+def eqm_train_window(dev: Device, ref: DeviceArray, hist: DeviceArray, rows0, enter, leave, q, kind="+", out=None):
+    """xh_eqm_train_window: EQM training over a sliding row sample (day-of-year groups with a window).  rows0 (n0,): the time
+    steps of the first group's sample; enter / leave (G - 1, per): the steps that enter / leave from one group to the next (-1 =
+    none).  Returns (af, hist_q) as (G, nq, C) device arrays, or None when the kernel does not take the shape (the caller
+    gathers every group's sample and calls :func:`eqm_train`)."""
+    from ._capi import XH_ERR_NOTIMPL, XclimHipError
+
+    q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+    T, C_ = _tc(ref)
+    rows0 = np.ascontiguousarray(rows0, dtype=np.int32)
+    enter = np.ascontiguousarray(enter, dtype=np.int32).reshape(-1, enter.shape[-1] if np.ndim(enter) == 2 else 1)
+    leave = np.ascontiguousarray(leave, dtype=np.int32).reshape(enter.shape)
+    G, per = enter.shape[0] + 1, enter.shape[1]
+    if out is not None:
+        af, hq = out
+    else:
+        af = dev.empty((G, len(q), C_), np.float32)
+        hq = dev.empty((G, len(q), C_), np.float32)
+    try:
+        dev.call("xh_eqm_train_window", _vp(ref.ptr), _vp(hist.ptr), T, C_, C_, np_ptr(rows0), len(rows0), np_ptr(enter), np_ptr(leave),
+                 G, per, np_ptr(q), len(q), {"+": 0, "*": 1}[kind], _vp(af.ptr), _vp(hq.ptr))
+    except XclimHipError as e:
+        if e.code == XH_ERR_NOTIMPL:
+            return None
+        raise
+    return af, hq
+
+
 def eqm_adjust(dev: Device, sim: DeviceArray, af: DeviceArray, hist_q: DeviceArray, kind="+", interp="nearest",
                extrapolation="constant", out: DeviceArray | None = None) -> DeviceArray:
     T, C_ = _tc(sim)
