@@ -244,8 +244,35 @@ def test_quantile_mapping_api_on_the_simulation(sim):
                     "or sliding_matches_per_group")   # (winsel.hip: its own test below, the small shapes)
 
 
-def test_sliding_window_training_on_the_simulation(sim):
+def test_sliding_window_training_on_the_simulation(sim, rng):
     """winsel.hip (round 6: the sorted sliding window of the day-of-year training) on fibers — DPP lane exchanges as shuffles —
-    against the per-group selection, bit for bit: the smallest shape of tests/test_gpu_api.py's A/B test (NaN samples, ties,
-    infinities, an empty cell, windows that reach beyond the series)."""
-    _child_run(sim, ["tests/test_gpu_api.py"], at_least=1, skip="not (sliding_matches_per_group and 2-3-5)")
+    against xh_eqm_train on every group's gathered sample, bit for bit: the first 40 steps of a 3-year series with a window of 7
+    days (NaN samples, ties, an infinity, an empty cell, a window that reaches beyond the start of the series).  The whole
+    schedule, larger windows and 30 years: tests/test_gpu_api.py::test_eqm_doy_window_sliding_matches_per_group on the GPU."""
+    from xclim_amd import sdba as xsdba
+    from xclim_amd.timeaxis import TimeAxis
+
+    T, cells, nq = 365 * 3, 5, 6
+    ta = TimeAxis.daily("2001-01-01", T, "noleap")
+    t = np.arange(T)[:, None]
+    ref = np.round(288 + 10 * np.sin(2 * np.pi * t / 365) + rng.normal(0, 3, (T, cells)), 1).astype(np.float32)
+    hist = (ref[::-1] * 1.01 + rng.normal(0, 1, (T, cells))).astype(np.float32)
+    ref[rng.random(ref.shape) < 0.04] = np.nan
+    hist[:, 3] = np.nan
+    ref[2:5, 1] = np.inf
+    rows0, enter, leave = xsdba.Grouper("time.dayofyear", 7).ring_schedule(ta)
+    G = 41
+    q = (np.arange(nq) + 0.5) / nq
+    d_ref, d_hist = sim.to_device(ref), sim.to_device(hist)
+    af, hq = K.eqm_train_window(sim, d_ref, d_hist, rows0, enter[:G - 1], leave[:G - 1], q, "+")
+    af, hq = af.get(), hq.get()
+    rows = rows0.copy()
+    for g in range(G):
+        a_g, h_g = K.eqm_train(sim, K.select_rows(sim, d_ref, rows), K.select_rows(sim, d_hist, rows), q, "+")
+        np.testing.assert_array_equal(hq[g], h_g.get(), err_msg=f"group {g}")
+        np.testing.assert_array_equal(af[g], a_g.get(), err_msg=f"group {g}")
+        if g + 1 < G:   # one row per year leaves, one enters (the order of a sample's rows does not matter)
+            for y in range(enter.shape[1]):
+                hit = np.nonzero(rows == leave[g, y])[0]
+                rows[hit[0] if leave[g, y] >= 0 and len(hit) else np.nonzero(rows < 0)[0][0]] = enter[g, y]
+    assert np.isnan(hq[:, :, 3]).all() and np.isfinite(hq[:, :, 0]).all()
