@@ -2000,3 +2000,35 @@ def test_eqm_doy_window_sliding_matches_per_group(dev, rng, monkeypatch, years, 
     np.testing.assert_array_equal(a.hist_q, b.hist_q)
     np.testing.assert_array_equal(a.af, b.af)
     assert np.isnan(a.hist_q[:, :, 3]).all() and np.isfinite(a.hist_q[:, :, 0]).all()
+
+
+@pytest.mark.parametrize("years,window", [(6, 7), (30, 31)])
+def test_eqm_doy_window_sliding_standard_calendar(dev, rng, monkeypatch, years, window):
+    """The same on a calendar WITH leap days (Grouper.sliding_stretches: the schedule from the groups' sample rows — what leaves
+    and enters between consecutive days of the year, up to 64 rows each way): with 30 years and a window of 31 days day 366 (only
+    the leap years have it: 682 rows would leave at once) is not part of the stretch and is selected from its gathered sample;
+    bit-identical to the per-group path."""
+    from xclim_amd import sdba as xsdba
+
+    T = int(365.25 * years) + 100
+    ta = TimeAxis.daily("2000-01-01", T, "standard")
+    cells, nq = 23, 10
+    t = np.arange(T)[:, None]
+    ref = np.round(288 + 10 * np.sin(2 * np.pi * t / 365.25) + rng.normal(0, 3, (T, cells)), 1).astype(np.float32)
+    hist = (ref[::-1] * 1.01 + rng.normal(0, 1, (T, cells))).astype(np.float32)
+    ref[rng.random(ref.shape) < 0.03] = np.nan
+    hist[:, 2] = np.nan
+    stretches, rest, _ = xsdba.Grouper("time.dayofyear", window).sliding_stretches(ta)
+    assert len(stretches) == 1 and stretches[0][0] == 0 and rest == ([] if years == 6 else [365])
+    monkeypatch.setenv("XH_DIAGNOSTICS", "1")
+    monkeypatch.setenv("XH_WINSEL", "1")
+    trace = dev.start_trace()
+    a = xsdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=nq, kind="+", group="time.dayofyear", window=window, time=ta, device=dev)
+    dev.stop_trace()
+    names = [n for n, _ in trace]
+    assert names.count("xh_eqm_train_window") == 1 and names.count("xh_eqm_train") == len(rest)
+    monkeypatch.setenv("XH_WINSEL", "0")
+    b = xsdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=nq, kind="+", group="time.dayofyear", window=window, time=ta, device=dev)
+    assert a.hist_q.shape == (366, nq, cells)
+    np.testing.assert_array_equal(a.hist_q, b.hist_q)
+    np.testing.assert_array_equal(a.af, b.af)

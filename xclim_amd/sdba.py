@@ -150,6 +150,44 @@ class Grouper:
         leave = np.stack([rows_at(d - 1, -half) for d in range(1, tb.shape[1])])
         return rows0, enter, leave
 
+    def sliding_stretches(self, time, max_per: int = 64, cap: int = 1024, min_len: int = 8):
+        """The general form of :meth:`ring_schedule` for calendars with gaps (leap days: the standard calendar): from the groups'
+        sample rows, the stretches of CONSECUTIVE groups whose samples differ by at most ``max_per`` rows each way —
+        ``[(g0, rows0, enter, leave), ...]`` with ``enter`` / ``leave`` of shape (groups - 1, per), -1 padded — and the groups
+        no stretch covers (day 366 of a standard calendar: only the leap years have it, its sample shares little with its
+        neighbours').  A gap-free calendar gives one stretch with the rows of :meth:`ring_schedule`."""
+        ring = self.ring_schedule(time)
+        rows_of = None
+        if ring is not None:
+            return [(0,) + ring], [], rows_of
+        if not (self.prop == "dayofyear" and self.window > 1):
+            return [], None, rows_of
+        rows_of = self.sample_rows(time)
+        sets = [np.unique(r[r >= 0]) for r in rows_of]
+        G = len(sets)
+        ent = [np.setdiff1d(sets[g + 1], sets[g], assume_unique=True) for g in range(G - 1)]
+        lev = [np.setdiff1d(sets[g], sets[g + 1], assume_unique=True) for g in range(G - 1)]
+        ok = [max(len(ent[g]), len(lev[g])) <= max_per and len(sets[g]) <= cap and len(sets[g + 1]) <= cap for g in range(G - 1)]
+        stretches, covered, g = [], np.zeros(G, dtype=bool), 0
+        while g < G - 1:
+            if not ok[g]:
+                g += 1
+                continue
+            e = g
+            while e < G - 1 and ok[e]:
+                e += 1
+            if e - g + 1 >= min_len:   # groups g .. e
+                per = max(1, max(max(len(ent[k]), len(lev[k])) for k in range(g, e)))
+                en = np.full((e - g, per), -1, dtype=np.int64)
+                lv = np.full((e - g, per), -1, dtype=np.int64)
+                for k in range(g, e):
+                    en[k - g, :len(ent[k])] = ent[k]
+                    lv[k - g, :len(lev[k])] = lev[k]
+                stretches.append((g, rows_of[g], en, lv))
+                covered[g:e + 1] = True
+            g = e + 1
+        return stretches, [int(k) for k in np.nonzero(~covered)[0]], rows_of
+
     @staticmethod
     def pooled_rows(rows: np.ndarray, R: int) -> np.ndarray:
         """Sample rows of the time axis -> rows of the pooled (T * R, C) matrix (-1 stays -1, R times)."""
@@ -408,10 +446,23 @@ class EmpiricalQuantileMapping:
         plane = len(q) * C_ * 4
         # day-of-year groups with a window on gap-free years: every cell keeps its window sorted from one day to the next
         # (xh_eqm_train_window, round 6: 508 -> ~60 ms for 30 years x 1440 x 90) — bit-identical to the per-group selection below
-        ring = grp.ring_schedule(time) if R == 1 else None
-        if ring is not None and K.eqm_train_window(dev, r, h, *ring, q, kind, out=(af, hq)) is not None:
-            dev.sync()
-            return cls(dev, af, hq, q, kind, cell_shape, grp, labels)
+        stretches, rest, rows_of = grp.sliding_stretches(time) if R == 1 else ([], None, None)
+        if stretches:
+            def slab(a, g0, n):
+                return dev.wrap(a.ptr + g0 * plane, (n, len(q), C_), np.float32)
+
+            done = True
+            for g0, rows0, en, lv in stretches:
+                n = en.shape[0] + 1
+                if K.eqm_train_window(dev, r, h, rows0, en, lv, q, kind, out=(slab(af, g0, n), slab(hq, g0, n))) is None:
+                    done = False   # (not the kernel's shape after all: everything through the per-group path below)
+                    break
+            if done:
+                for g in rest:     # the groups no stretch covers (day 366 of a standard calendar): selected from their gathered sample
+                    K.eqm_train(dev, K.select_rows(dev, r, rows_of[g]), K.select_rows(dev, h, rows_of[g]), q, kind,
+                                out=(slab(af, g, 1).reshape(len(q), C_), slab(hq, g, 1).reshape(len(q), C_)))
+                dev.sync()
+                return cls(dev, af, hq, q, kind, cell_shape, grp, labels)
         for g, (rg, hg) in grp.group_samples(dev, (r, h), time, R):
             out_g = tuple(dev.wrap(a.ptr + g * plane, (len(q), C_), np.float32) for a in (af, hq))
             K.eqm_train(dev, rg, hg, q, kind, out=out_g)
