@@ -147,10 +147,10 @@ __device__ __forceinline__ uint32_t ws_sort1(uint32_t v, int lane) {
   return v;
 }
 
-// LDS per wave: the window [1024] | marks [516 words: per window position a byte "entering keys that go in front of the next
+// LDS per wave: the window [1024] | trash [64] | marks [516 words: per window position a byte "entering keys that go in front of the next
 // element" and a byte "this element leaves"] | leaving positions [64] | entering keys [64] | picked keys [64]; per workgroup: the
 // staged samples of a step [2 * WS_PER][WS_WAVES]
-constexpr int ws_words_per_wave() { return WS_CAP + 516 + 3 * 64; }
+constexpr int ws_words_per_wave() { return WS_CAP + 64 + 516 + 3 * 64; }
 // (per = 30 years: 77 824 + 3 840 bytes — two workgroups share a CU's 160 KiB)
 inline size_t ws_lds(int per) { return (size_t)WS_WAVES * ws_words_per_wave() * 4 + (size_t)2 * (size_t)per * WS_WAVES * 4; }
 
@@ -162,7 +162,7 @@ k_window_quantiles(const float* __restrict__ x, int64_t T, int64_t C, int64_t st
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   uint32_t* wbase = smem + wv * ws_words_per_wave();
   uint32_t* bufA = wbase;
-  uint32_t* marks = wbase + WS_CAP;         // [516] two bytes per window position: [2 p] entering keys with upper bound p, [2 p + 1] leaves
+  uint32_t* marks = wbase + WS_CAP + 64;    // (cur[1024 + lane]: the slot a lane's dropped elements are written to) [516] two bytes per window position: [2 p] entering keys with upper bound p, [2 p + 1] leaves
   uint32_t* lpos = marks + 516;             // sorted positions (in the current window) of the leaving samples
   uint32_t* ekey = lpos + 64;               // sorted keys of the entering samples
   uint32_t* tv = ekey + 64;                 // picked keys
@@ -343,13 +343,12 @@ k_window_quantiles(const float* __restrict__ x, int64_t T, int64_t C, int64_t st
         const uint32_t i = i0 + (uint32_t)j;
         run += m & 0xFFu;                                   // entering keys with ub <= i
         const bool gone = (m >> 8) != 0u;
-        dst[j] = (i < n && !gone) ? i - (run >> 16) + (run & 0xFFFFu) : WS_INF;
+        dst[j] = (i < n && !gone) ? i - (run >> 16) + (run & 0xFFFFu) : 1024u + (uint32_t)lane;   // (dropped: a private trash slot)
         run += gone ? 0x10000u : 0u;                        // leaving positions < the next i
       }
       __builtin_amdgcn_wave_barrier();  // every lane holds its stretch: the window may be overwritten
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (dst[j] != WS_INF) cur[dst[j]] = e[j];
+      for (int j = 0; j < 16; ++j) cur[dst[j]] = e[j];   // (unconditional: sixteen stores under one execution mask)
       if ((uint32_t)lane < ne) cur[epos] = ke;
       // the marks go back to zero
       if ((uint32_t)lane < nl) m8[2u * lp + 1u] = 0;
