@@ -475,6 +475,16 @@ int xh_eqm_train_window(xh_ctx* ctx, const float* ref, const float* hist, int64_
                         const int32_t* rows0 /* host */, int n0, const int32_t* enter /* host */,
                         const int32_t* leave /* host */, int G, int per, const double* q /* host */, int nq, int kind,
                         float* af, float* hist_q);
+/* dqm_train over the same sliding row sample (xsdba._adjustment.dqm_train per day-of-year group with a window; not in the
+ * reference tree — /root/reference/src/xclim/sdba.py:10 re-exports xsdba): ref and hist are normalised by the mean of the
+ * group's sample (x - mean for kind 0, x / mean for kind 1: fp64 operation, fp32 result as xh_trend_apply), af / hist_q are
+ * the corrections / quantiles of the normalised samples.  scaling (G, C) float64 = mean(ref) - mean(hist) resp. mean(ref) /
+ * mean(hist); mu_hist (G, C) float64 = the means of hist.  The means are fp64 sums over the sorted window: equal to
+ * xh_poly_trend(degree 0) on the gathered sample up to the summation order.  XH_ERR_NOTIMPL as xh_eqm_train_window. */
+int xh_dqm_train_window(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st,
+                        const int32_t* rows0 /* host */, int n0, const int32_t* enter /* host */,
+                        const int32_t* leave /* host */, int G, int per, const double* q /* host */, int nq, int kind,
+                        float* af, float* hist_q, double* scaling, double* mu_hist);
 /* qm_adjust: af_t = interp_on_quantiles(sim, hist_q, af) (interp 0 nearest, 1 linear, 2 cubic [not-a-knot spline as
  * scipy interp1d(kind="cubic"), nq <= 32, >= 4 valid nodes per cell else NaN]; extrap 0 constant,
  * 1 nan); scen = sim + af_t (kind 0) or sim * af_t (kind 1); kind 2: scen = af_t, the interpolated factor itself
@@ -569,6 +579,19 @@ int xh_trend_apply_u(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t 
  * xsdba, re-exported by /root/reference/src/xclim/sdba.py:10; parity unpinned).  float64 running sum, float32 result. */
 int xh_window_nanmean(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int window, float* out,
                       int64_t out_st);
+/* PolyDetrend / apply_correction over GROUPS of rows in one launch (DetrendedQuantileMapping.adjust with a sub-grouping; xsdba
+ * detrending.PolyDetrend(group=...) + u.broadcast — not in the reference tree, /root/reference/src/xclim/sdba.py:10).  rows (host,
+ * offs[G] entries): the row numbers of group 0, then of group 1, ...; offs (host, G + 1): where every group's rows start; u (DEVICE
+ * float64, T): the coordinate of every row of x (e.g. days since the mean date of the row's group).  p0, p1: (G, C) float64.
+ * xh_poly_trend_groups: the least-squares fit over each group's valid samples (p1 NULL for degree 0) — bit-identical to
+ * xh_poly_trend_u on the gathered rows.  xh_trend_apply_groups: out[t, c] = x[t, c] OP (p0[g, c] + p1[g, c] u[t]) for the rows t of
+ * every group g (mode as xh_trend_apply; p1 NULL: a per-group constant, u may then be NULL; rows in no group are not written; x ==
+ * out allowed) — bit-identical to xh_trend_apply_u. */
+int xh_poly_trend_groups(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* rows /* host */,
+                         const int64_t* offs /* host */, int G, const double* u, int degree, double* p0, double* p1);
+int xh_trend_apply_groups(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* rows /* host */,
+                          const int64_t* offs /* host */, int G, const double* u, const double* p0, const double* p1, int mode,
+                          float* out, int64_t out_st);
 
 #ifdef __cplusplus
 }

@@ -2032,3 +2032,65 @@ def test_eqm_doy_window_sliding_standard_calendar(dev, rng, monkeypatch, years, 
     assert a.hist_q.shape == (366, nq, cells)
     np.testing.assert_array_equal(a.hist_q, b.hist_q)
     np.testing.assert_array_equal(a.af, b.af)
+
+
+@pytest.mark.parametrize("years,window,nq,kind,cal", [(4, 5, 7, "+", "noleap"), (6, 9, 20, "*", "noleap"), (30, 31, 20, "+", "noleap"),
+                                                      (30, 31, 15, "*", "standard")])
+def test_dqm_doy_window_sliding_matches_per_group(dev, rng, monkeypatch, years, window, nq, kind, cal):
+    """xh_dqm_train_window (round 6): the training of a DETRENDED quantile mapping with day-of-year groups and a window through the
+    sorted sliding window — the mean of every group's sample from the window, the picked samples normalised — against the
+    per-group chain it replaces (XH_WINSEL=0: gather, xh_poly_trend degree 0, xh_trend_apply, xh_eqm_train per group).  The means
+    differ in their summation order only (1e-14); the tables are BIT-IDENTICAL wherever the two means are, and within 1e-6
+    elsewhere.  Cells: NaN samples, ties, infinities in the window, a negative mean (kind "*": the order reverses), all zeros
+    (0 / 0), no valid sample; a standard calendar (day 366 from its gathered sample)."""
+    from xclim_amd import sdba as xsdba
+
+    T = 365 * years + (years // 4 + 60 if cal == "standard" else 0)
+    cells = 29 if years < 30 else 40
+    ta = TimeAxis.daily("2000-01-01", T, cal)
+    t = np.arange(T)[:, None]
+    ref = (28 + 10 * np.sin(2 * np.pi * t / 365) + rng.normal(0, 3, (T, cells))).astype(np.float32)
+    hist = (ref[::-1] * 1.01 + rng.normal(0, 1, (T, cells))).astype(np.float32)
+    ref[rng.random(ref.shape) < 0.03] = np.nan
+    hist[rng.random(hist.shape) < 0.02] = np.nan
+    if years == 6:
+        ref = np.round(ref, 1)
+        hist = np.round(hist, 0)
+    hist[:, 3] = np.nan
+    ref[40:50, 5] = np.inf
+    hist[100:103, 6] = -np.inf
+    ref[:, 7] = -ref[:, 7]
+    hist[:, 8] = 0.0
+    hist[300:330, 9] = 1e38       # (kind "*": x / mean overflows for none, the mean stays finite; "+": nothing special)
+    monkeypatch.setenv("XH_DIAGNOSTICS", "1")
+    monkeypatch.setenv("XH_WINSEL", "1")
+    trace = dev.start_trace()
+    a = xsdba.DetrendedQuantileMapping.train(ref, hist, nquantiles=nq, kind=kind, group="time.dayofyear", window=window, time=ta, device=dev)
+    dev.stop_trace()
+    names = [n for n, _ in trace]
+    G = 365 if cal == "noleap" else 366
+    rest = 0 if cal == "noleap" else 1
+    assert names.count("xh_dqm_train_window") == 1 and names.count("xh_eqm_train") == rest
+    monkeypatch.setenv("XH_WINSEL", "0")
+    trace = dev.start_trace()
+    b = xsdba.DetrendedQuantileMapping.train(ref, hist, nquantiles=nq, kind=kind, group="time.dayofyear", window=window, time=ta, device=dev)
+    dev.stop_trace()
+    assert [n for n, _ in trace].count("xh_eqm_train") == G
+    sa, sb = a.scaling, b.scaling
+    assert sa.shape == (G, cells)
+    np.testing.assert_allclose(sa, sb, rtol=1e-13, equal_nan=True)
+    same = (sa == sb) | (np.isnan(sa) & np.isnan(sb))          # (scaling = mean(ref) OP mean(hist): equal bits <- equal means, nearly always)
+    assert same.mean() > 0.5
+    ha, hb = a.hist_q, b.hist_q
+    fa, fb = a.af, b.af
+    m = np.broadcast_to(same[:, None, :], ha.shape)
+    np.testing.assert_array_equal(ha[m], hb[m])
+    np.testing.assert_array_equal(fa[m], fb[m])
+    with np.errstate(all="ignore"):
+        np.testing.assert_allclose(ha, hb, rtol=1e-6, atol=1e-6)
+        ok = np.isfinite(fb) & (np.abs(hb) > 1e-3)
+        np.testing.assert_allclose(fa[ok], fb[ok], rtol=2e-5, atol=1e-5)
+    assert np.isnan(ha[:, :, 3]).all() and np.isfinite(ha[:, :, 0]).all()
+    if kind == "*":
+        assert np.isnan(ha[:, :, 8]).all()
+

@@ -5,7 +5,7 @@ with g++ against a stand-in for the HIP runtime and run on the CPU:
   * every workgroup as a set of FIBERS (simt.h: __syncthreads, wave-uniform shuffles / votes / readlane, atomics) — f64, select,
     select2, select3, select4, select5, tcount, qdm, qdm2, quantile, doystats, reduce2, pdoy_top, pdoy_quad, pdoy_walk, winsel and the
     kernels of core.hip (transposes, synthetic fields).
-64 of the 94 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
+65 of the 95 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
 other 30 are runtime services (memory, streams, RCCL).  The register percentile kernels (pdoy_top / pdoy_quad / pdoy_walk) run on
 fibers too, with the four ISA statements of topnet.h rewritten to the C++ they stand for, and so do the register sorting networks
 (select3 / qdm2: the DPP split across the lane pair as a shuffle), select2's wave counts on VCC and the streaming two-pass selection
@@ -276,3 +276,58 @@ def test_sliding_window_training_on_the_simulation(sim, rng):
                 hit = np.nonzero(rows == leave[g, y])[0]
                 rows[hit[0] if leave[g, y] >= 0 and len(hit) else np.nonzero(rows < 0)[0][0]] = enter[g, y]
     assert np.isnan(hq[:, :, 3]).all() and np.isfinite(hq[:, :, 0]).all()
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_sliding_window_dqm_training_on_the_simulation(sim, rng, kind):
+    """xh_dqm_train_window (winsel.hip with the normalisation of dqm_train) against the per-group chain it replaces — xh_poly_trend
+    (degree 0), xh_trend_apply, xh_eqm_train on every group's gathered sample: the means to summation order, the tables bit for
+    bit wherever the means agree in all their bits (checked: nearly everywhere) and to one part in 10^6 elsewhere.  Cells: plain,
+    NaN samples, an infinity in the window (every finite sample becomes -inf / 0, the infinite one NaN: the window is
+    normalised and sorted again), a negative mean ("*": the order reverses), all zeros ("*": 0 / 0), no valid sample."""
+    from xclim_amd import sdba as xsdba
+    from xclim_amd.timeaxis import TimeAxis
+
+    T, cells, nq = 365 * 3, 6, 5
+    ta = TimeAxis.daily("2001-01-01", T, "noleap")
+    t = np.arange(T)[:, None]
+    ref = np.round(20 + 10 * np.sin(2 * np.pi * t / 365) + rng.normal(0, 3, (T, cells)), 1).astype(np.float32)
+    hist = (ref[::-1] * 1.01 + rng.normal(0, 1, (T, cells))).astype(np.float32)
+    ref[rng.random(ref.shape) < 0.04] = np.nan
+    hist[:, 3] = np.nan
+    ref[2:5, 1] = np.inf
+    hist[7, 1] = -np.inf
+    ref[:, 4] = -ref[:, 4]
+    hist[:, 5] = 0.0
+    rows0, enter, leave = xsdba.Grouper("time.dayofyear", 7).ring_schedule(ta)
+    G = 16
+    q = (np.arange(nq) + 0.5) / nq
+    d_ref, d_hist = sim.to_device(ref), sim.to_device(hist)
+    af, hq, sc, muh = (a.get() for a in K.eqm_train_window(sim, d_ref, d_hist, rows0, enter[:G - 1], leave[:G - 1], q, kind, normalised=True))
+    inv = "-" if kind == "+" else "/"
+    rows = rows0.copy()
+    exact = 0
+    for g in range(G):
+        rg, hg = K.select_rows(sim, d_ref, rows), K.select_rows(sim, d_hist, rows)
+        mu_r, _ = K.poly_trend(sim, rg, 0)
+        mu_h, _ = K.poly_trend(sim, hg, 0)
+        a_g, h_g = K.eqm_train(sim, K.trend_apply(sim, rg, mu_r, None, inv), K.trend_apply(sim, hg, mu_h, None, inv), q, kind)
+        mr, mh = mu_r.get(), mu_h.get()
+        np.testing.assert_allclose(muh[g], mh, rtol=1e-14, err_msg=f"group {g}")
+        with np.errstate(all="ignore"):
+            np.testing.assert_allclose(sc[g], mr - mh if kind == "+" else mr / mh, rtol=1e-14, err_msg=f"group {g}")
+        same = (muh[g] == mh) | (np.isnan(mh) & np.isnan(muh[g]))
+        exact += int(same.sum())
+        np.testing.assert_array_equal(hq[g][:, same], h_g.get()[:, same], err_msg=f"group {g}")
+        np.testing.assert_allclose(hq[g], h_g.get(), rtol=1e-6, atol=1e-6, err_msg=f"group {g}")
+        np.testing.assert_allclose(af[g], a_g.get(), rtol=1e-6, atol=2e-6, err_msg=f"group {g}")
+        if g + 1 < G:
+            for y in range(enter.shape[1]):
+                hit = np.nonzero(rows == leave[g, y])[0]
+                rows[hit[0] if leave[g, y] >= 0 and len(hit) else np.nonzero(rows < 0)[0][0]] = enter[g, y]
+    assert exact > G * cells // 2
+    assert np.isnan(hq[:, :, 3]).all() and np.isfinite(hq[:, :, 0]).all()
+    if kind == "*":
+        assert np.isnan(hq[:, :, 5]).all()         # 0 / 0: no sample survives the normalisation
+        assert (np.diff(af[:, :, 4], axis=1) * 0 == 0).all()
+

@@ -151,6 +151,7 @@ SIGNATURES: dict[str, list] = {
     "xh_quantile_series": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp],
     "xh_eqm_train": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _vp, _vp],
     "xh_eqm_train_window": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _vp, _int, _int, _vp, _vp],
+    "xh_dqm_train_window": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _vp, _int, _int, _vp, _vp, _vp, _vp],
     "xh_eqm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64],
     "xh_eqm_adjust_g2d": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _int, _vp, _i64],
     "xh_apply_factor": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64],
@@ -167,6 +168,8 @@ SIGNATURES: dict[str, list] = {
     "xh_poly_trend_u": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp],
     "xh_trend_apply_u": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _i64],
     "xh_window_nanmean": [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64],
+    "xh_poly_trend_groups": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _int, _vp, _vp],
+    "xh_trend_apply_groups": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _int, _vp, _i64],
 }
 _RESTYPES = {"xh_last_error": C.c_char_p}
 

@@ -88,6 +88,114 @@ k_trend_apply(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, con
   });
 }
 
+// ---- the same two pieces over GROUPS of rows in ONE launch (DetrendedQuantileMapping.adjust with a sub-grouping: 365 day-of-year
+// groups took 365 x 4 launches on gathered blocks — launch-bound, 87 ms for a 30-year 1440 x 90 band).  The rows stay where they
+// are: a group is a list of row numbers (its steps in time order), the coefficients are (G, C) tables.
+//   k_poly_trend_groups   thread = VEC cells of one group: the sums of k_poly_trend over the group's rows, in the list's order
+//                         (bit-identical to xh_poly_trend_u on the gathered block), u[t] = the row's own coordinate
+//   k_trend_apply_groups  thread = VEC cells of one group: out[t, c] = x[t, c] OP (p0[g, c] + p1[g, c] u[t]) for the group's rows t
+//                         (the coefficients are read once per group, not once per row; rows in no group are not written)
+template <int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_poly_trend_groups(const float* __restrict__ x, int64_t C, int64_t st, const int32_t* __restrict__ rows,
+                    const int64_t* __restrict__ offs, const double* __restrict__ ucoord, int degree, double* __restrict__ p0,
+                    double* __restrict__ p1) {
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int64_t g = blockIdx.y;
+  const int64_t k0 = offs[g], k1 = offs[g + 1];
+  double n[VEC], su[VEC], suu[VEC], sx[VEC], sux[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) n[i] = su[i] = suu[i] = sx[i] = sux[i] = 0.0;
+  auto take = [&](double u, const VecF<VEC>& xv) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float f = xv.v[i];
+      const bool ok = f == f;
+      const double v = ok ? (double)f : 0.0, w = ok ? 1.0 : 0.0;
+      n[i] += w;
+      su[i] += w * u;
+      suu[i] += w * u * u;
+      sx[i] += v;
+      sux[i] += u * v;
+    }
+  };
+  int64_t k = k0;
+  for (; k + 4 <= k1; k += 4) {   // four rows in flight
+    const int32_t t0 = rows[k], t1 = rows[k + 1], t2 = rows[k + 2], t3 = rows[k + 3];
+    const VecF<VEC> a0 = xh_load<VEC>(x + (int64_t)t0 * st + c), a1 = xh_load<VEC>(x + (int64_t)t1 * st + c),
+                    a2 = xh_load<VEC>(x + (int64_t)t2 * st + c), a3 = xh_load<VEC>(x + (int64_t)t3 * st + c);
+    take(ucoord[t0], a0);
+    take(ucoord[t1], a1);
+    take(ucoord[t2], a2);
+    take(ucoord[t3], a3);
+  }
+  for (; k < k1; ++k) {
+    const int32_t t = rows[k];
+    take(ucoord[t], xh_load<VEC>(x + (int64_t)t * st + c));
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    double a = xh_nan64(), b = 0.0;
+    if (n[i] > 0.0) {
+      if (degree == 0) a = sx[i] / n[i];
+      else {
+        const double den = n[i] * suu[i] - su[i] * su[i];
+        if (den > 0.0) {
+          b = (n[i] * sux[i] - su[i] * sx[i]) / den;
+          a = (sx[i] - b * su[i]) / n[i];
+        } else a = sx[i] / n[i];
+      }
+    }
+    p0[g * C + c + i] = a;
+    if (p1) p1[g * C + c + i] = (n[i] > 0.0) ? b : xh_nan64();
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_trend_apply_groups(const float* x, int64_t C, int64_t st, const int32_t* __restrict__ rows,
+                     const int64_t* __restrict__ offs, const double* __restrict__ ucoord, const double* __restrict__ p0,
+                     const double* __restrict__ p1, int mode, float* out, int64_t out_st) {   // (x may be out: no __restrict__)
+  const int64_t c = ((int64_t)blockIdx.x * XH_BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int64_t g = blockIdx.y;
+  const int64_t k0 = offs[g], k1 = offs[g + 1];
+  double a[VEC], b[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { a[i] = p0[g * C + c + i]; b[i] = p1 ? p1[g * C + c + i] : 0.0; }
+  auto put = [&](int32_t t, const VecF<VEC>& xv) {
+    const double u = ucoord ? ucoord[t] : 0.0;
+    float r[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const double tr = a[i] + b[i] * u, v = (double)xv.v[i];
+      const double o = mode == 0 ? v + tr : (mode == 1 ? v - tr : (mode == 2 ? v * tr : v / tr));
+      r[i] = (float)o;
+    }
+    float* dst = out + (int64_t)t * out_st + c;
+    if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+    else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) dst[i] = r[i];
+    }
+  };
+  int64_t k = k0;
+  for (; k + 4 <= k1; k += 4) {
+    const int32_t t0 = rows[k], t1 = rows[k + 1], t2 = rows[k + 2], t3 = rows[k + 3];
+    const VecF<VEC> a0 = xh_load<VEC>(x + (int64_t)t0 * st + c), a1 = xh_load<VEC>(x + (int64_t)t1 * st + c),
+                    a2 = xh_load<VEC>(x + (int64_t)t2 * st + c), a3 = xh_load<VEC>(x + (int64_t)t3 * st + c);
+    put(t0, a0);
+    put(t1, a1);
+    put(t2, a2);
+    put(t3, a3);
+  }
+  for (; k < k1; ++k) {
+    const int32_t t = rows[k];
+    put(t, xh_load<VEC>(x + (int64_t)t * st + c));
+  }
+}
+
 }  // namespace
 
 // Centred window mean over the valid samples (xsdba.detrending._polydetrend_get_trend with a windowed Grouper:
@@ -205,6 +313,71 @@ int xh_window_nanmean(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t
   if (T == 0 || C == 0) return XH_OK;
   const dim3 grid((unsigned)cdiv64(C, XH_BLOCK), (unsigned)cdiv64(T, WM_ROWS));
   hipLaunchKernelGGL(k_window_nanmean, grid, dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, window / 2, out, out_st);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+// PolyDetrend per group in one launch: rows (host, offs[G] entries): the row numbers of group 0, then of group 1, ... (a group's
+// rows in the order its sums are taken), offs (host, G + 1): where each group's rows start; u (DEVICE float64, T): the
+// coordinate of every ROW of x (e.g. days since the mean date of the row's group).  p0, p1 (G, C) float64 (p1 NULL for degree 0).
+// Bit-identical to xh_poly_trend_u on each group's gathered rows.
+int xh_poly_trend_groups(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* rows, const int64_t* offs, int G,
+                         const double* u, int degree, double* p0, double* p1) {
+  XH_REQUIRE(ctx && x && rows && offs && u && p0, XH_ERR_ARG, "xh_poly_trend_groups: NULL argument");
+  XH_REQUIRE(T >= 1 && C >= 0 && G >= 1 && st >= C, XH_ERR_ARG, "xh_poly_trend_groups: bad shape");
+  XH_REQUIRE(degree == 0 || degree == 1, XH_ERR_NOTIMPL, "xh_poly_trend_groups: degree must be 0 or 1");
+  XH_REQUIRE(degree == 0 || p1, XH_ERR_ARG, "xh_poly_trend_groups: p1 is NULL");
+  XH_REQUIRE(offs[0] == 0, XH_ERR_ARG, "xh_poly_trend_groups: offs[0] must be 0");
+  for (int g = 0; g < G; ++g) XH_REQUIRE(offs[g + 1] >= offs[g], XH_ERR_ARG, "xh_poly_trend_groups: offs must not decrease");
+  const int64_t nr = offs[G];
+  XH_REQUIRE(nr < (1ll << 31), XH_ERR_ARG, "xh_poly_trend_groups: too many rows");
+  for (int64_t k = 0; k < nr; ++k) XH_REQUIRE(rows[k] >= 0 && rows[k] < T, XH_ERR_ARG, "xh_poly_trend_groups: row %lld out of range", (long long)k);
+  if (C == 0) return XH_OK;
+  size_t cur = 0;
+  void *d_rows = nullptr, *d_offs = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, offs, sizeof(int64_t) * (size_t)(G + 1), &d_offs);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, rows, sizeof(int32_t) * (size_t)(nr > 0 ? nr : 1), &d_rows);
+  if (rc) return rc;
+  if (xh_pick_vec(x, C, st) == 4)
+    hipLaunchKernelGGL((k_poly_trend_groups<4>), dim3((unsigned)cdiv64(cdiv64(C, 4), XH_BLOCK), (unsigned)G), dim3(XH_BLOCK), 0, ctx->stream, x,
+                       C, st, (const int32_t*)d_rows, (const int64_t*)d_offs, u, degree, p0, p1);
+  else
+    hipLaunchKernelGGL((k_poly_trend_groups<1>), dim3((unsigned)cdiv64(C, XH_BLOCK), (unsigned)G), dim3(XH_BLOCK), 0, ctx->stream, x, C, st,
+                       (const int32_t*)d_rows, (const int64_t*)d_offs, u, degree, p0, p1);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+// apply_correction with the coefficients of every row's GROUP: out[t, c] = x[t, c] OP (p0[g, c] + p1[g, c] u[t]) for the rows t of
+// group g (rows / offs as in xh_poly_trend_groups; rows in no group are left as they are; a row listed twice is written twice with
+// the same value only if it is in one group — do not list a row in two groups); u (DEVICE float64, T) or NULL with p1 NULL (a
+// per-group constant: the scaling of dqm_adjust); p0, p1 (G, C) float64.  x == out is allowed (elementwise).  Bit-identical to
+// xh_trend_apply_u on each group's gathered rows.
+int xh_trend_apply_groups(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, const int32_t* rows, const int64_t* offs, int G,
+                          const double* u, const double* p0, const double* p1, int mode, float* out, int64_t out_st) {
+  XH_REQUIRE(ctx && x && rows && offs && p0 && out, XH_ERR_ARG, "xh_trend_apply_groups: NULL argument");
+  XH_REQUIRE(T >= 1 && C >= 0 && G >= 1 && st >= C && out_st >= C, XH_ERR_ARG, "xh_trend_apply_groups: bad shape");
+  XH_REQUIRE(mode >= 0 && mode <= 3, XH_ERR_ARG, "xh_trend_apply_groups: mode must be 0 (+), 1 (-), 2 (*) or 3 (/)");
+  XH_REQUIRE(u || !p1, XH_ERR_ARG, "xh_trend_apply_groups: a slope table needs the rows' coordinate");
+  XH_REQUIRE(offs[0] == 0, XH_ERR_ARG, "xh_trend_apply_groups: offs[0] must be 0");
+  for (int g = 0; g < G; ++g) XH_REQUIRE(offs[g + 1] >= offs[g], XH_ERR_ARG, "xh_trend_apply_groups: offs must not decrease");
+  const int64_t nr = offs[G];
+  XH_REQUIRE(nr < (1ll << 31), XH_ERR_ARG, "xh_trend_apply_groups: too many rows");
+  for (int64_t k = 0; k < nr; ++k) XH_REQUIRE(rows[k] >= 0 && rows[k] < T, XH_ERR_ARG, "xh_trend_apply_groups: row %lld out of range", (long long)k);
+  if (C == 0 || nr == 0) return XH_OK;
+  size_t cur = 0;
+  void *d_rows = nullptr, *d_offs = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, offs, sizeof(int64_t) * (size_t)(G + 1), &d_offs);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, rows, sizeof(int32_t) * (size_t)nr, &d_rows);
+  if (rc) return rc;
+  const int vec = (xh_pick_vec(x, C, st) == 4 && xh_pick_vec(out, C, out_st) == 4) ? 4 : 1;
+  const dim3 grid((unsigned)cdiv64(cdiv64(C, vec), XH_BLOCK), (unsigned)G);
+  if (vec == 4)
+    hipLaunchKernelGGL((k_trend_apply_groups<4>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, (const int32_t*)d_rows, (const int64_t*)d_offs, u,
+                       p0, p1, mode, out, out_st);
+  else
+    hipLaunchKernelGGL((k_trend_apply_groups<1>), grid, dim3(XH_BLOCK), 0, ctx->stream, x, C, st, (const int32_t*)d_rows, (const int64_t*)d_offs, u,
+                       p0, p1, mode, out, out_st);
   XH_LAUNCH_CHECK();
   return XH_OK;
 }

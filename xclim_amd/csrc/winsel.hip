@@ -154,10 +154,34 @@ constexpr int ws_words_per_wave() { return WS_CAP + 64 + 516 + 3 * 64; }
 // (per = 30 years: 77 824 + 3 840 bytes — two workgroups share a CU's 160 KiB)
 inline size_t ws_lds(int per) { return (size_t)WS_WAVES * ws_words_per_wave() * 4 + (size_t)2 * (size_t)per * WS_WAVES * 4; }
 
+// the targets' positions in a sorted sample of n (type 7; utl:395, 417-491): lane t < 2 nq holds the position of target t
+// (qt = its quantile), lane j < nq the lerp weight of quantile j (qq)
+__device__ __forceinline__ void ws_positions(uint32_t n, double qt, double qq, int lane, uint32_t& ppos, bool& pedge, double& pgamma) {
+  ppos = 0u;
+  if (n >= 2u) {
+    const double nn = (double)n;
+    const double vi = nn * qt + (1.0 + qt * (1.0 - 1.0 - 1.0)) - 1.0;
+    if (vi >= nn - 1.0) ppos = n - 1u;
+    else if (vi < 0.0) ppos = 0u;
+    else ppos = (uint32_t)floor(vi) + (uint32_t)(lane & 1);
+    const double v2 = nn * qq + (1.0 + qq * (1.0 - 1.0 - 1.0)) - 1.0;
+    pedge = v2 >= nn - 1.0 || v2 < 0.0;
+    pgamma = v2 - floor(v2);
+  }
+}
+
+// NORM (the training of a DETRENDED quantile mapping, xsdba._adjustment.dqm_train): the quantiles are those of the sample
+// normalised by its own mean — x - mu ("+", nmode 1) or x / mu ("*", nmode 3), in the arithmetic of xh_trend_apply (fp64
+// operation, fp32 result) — and the mean of every group's sample goes to mu_out (G, C).  The mean is the fp64 sum over the
+// sorted window (16 elements per lane, then over the lanes) / n.  The normalisation keeps the order of the samples when mu is
+// finite (and positive for "*"): the picked samples are normalised, nothing else changes.  Otherwise (an infinite sample in the
+// window, mu <= 0 for "*") samples can turn NaN and drop out of the sample, or the order reverses: the wave normalises the
+// whole window and sorts it again for that group (the 1024-slot network of the first window).
+template <bool NORM>
 __global__ void __launch_bounds__(WS_WAVES * 64)
 k_window_quantiles(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, const int32_t* __restrict__ rows0, int n0,
                    const int32_t* __restrict__ enter, const int32_t* __restrict__ leave, int G, int per,
-                   const double* __restrict__ qs, int nq, float* __restrict__ out) {
+                   const double* __restrict__ qs, int nq, float* __restrict__ out, int nmode, double* __restrict__ mu_out) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   uint32_t* wbase = smem + wv * ws_words_per_wave();
@@ -226,32 +250,80 @@ k_window_quantiles(const float* __restrict__ x, int64_t T, int64_t C, int64_t st
     // ---- the quantiles of the current window (positions: the window is sorted; type 7, utl:395, 417-491)
     if (n != nprev) {  // (wave-uniform)
       nprev = n;
-      ppos = 0u;
-      if (n >= 2u) {
-        const double nn = (double)n;
-        const double vi = nn * qt + (1.0 + qt * (1.0 - 1.0 - 1.0)) - 1.0;
-        if (vi >= nn - 1.0) ppos = n - 1u;
-        else if (vi < 0.0) ppos = 0u;
-        else ppos = (uint32_t)floor(vi) + (uint32_t)(lane & 1);
-        const double v2 = nn * qq + (1.0 + qq * (1.0 - 1.0 - 1.0)) - 1.0;
-        pedge = v2 >= nn - 1.0 || v2 < 0.0;
-        pgamma = v2 - floor(v2);
-      }
+      ws_positions(n, qt, qq, lane, ppos, pedge, pgamma);
     }
-    if (lane < ntgt) tv[lane] = n > 0u ? cur[ppos] : WS_INF;
+    double mu = 0.0;
+    bool ordered = true;   // the normalisation keeps the window's order and all of its samples
+    if (NORM) {
+      const uint4* c4 = reinterpret_cast<const uint4*>(cur + (uint32_t)lane * 16u);
+      const uint4 q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
+      const uint32_t e[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+      double sum = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += ((uint32_t)lane * 16u + (uint32_t)r < n) ? (double)ws_unkey(e[r]) : 0.0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) sum += __shfl_xor(sum, d);   // (a + b == b + a: every lane ends with the same bits)
+      mu = n > 0u ? sum / (double)n : xh_nan64();
+      if (lane == 0 && cvalid) mu_out[(int64_t)g * C + c] = mu;
+      const bool fin = mu - mu == 0.0;
+      ordered = __builtin_amdgcn_readfirstlane((int)(fin && (nmode == 1 || mu > 0.0))) != 0;
+    }
+    auto norm = [&](float f) -> float {
+      if (!NORM) return f;
+      const double v = (double)f;
+      return (float)(nmode == 1 ? v - mu : v / mu);
+    };
+    uint32_t nn = n;       // the sample the quantiles are taken from (NORM, not ordered: the normalised window without its NaNs)
+    bool edge = pedge;
+    double gamma = pgamma;
+    uint32_t topkey = 0u;
+    if (!NORM || ordered) {
+      if (lane < ntgt) tv[lane] = n > 0u ? cur[ppos] : WS_INF;
+      topkey = n > 0u ? cur[n - 1u] : WS_INF;
+    } else {
+      uint32_t v[16];
+      nn = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t i = (uint32_t)lane * 16u + (uint32_t)r;
+        const float y = norm(ws_unkey(cur[i]));
+        const bool ok = i < n && y == y;
+        v[r] = ok ? ws_key(y + (-0.0f)) : WS_INF;
+        nn += ok ? 1u : 0u;
+      }
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) nn += (uint32_t)__shfl_xor((int)nn, d);
+      ws_wave_sort<16>(v, lane);
+      uint32_t pp = 0u;
+      ws_positions(nn, qt, qq, lane, pp, edge, gamma);
+      auto at = [&](uint32_t p) -> uint32_t {   // element p of the sorted sample (lane p / 16 holds it in v[p % 16])
+        uint32_t val = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t t = (uint32_t)__shfl((int)v[r], (int)(p >> 4));
+          val = (p & 15u) == (uint32_t)r ? t : val;
+        }
+        return val;
+      };
+      const uint32_t got = at(pp);
+      topkey = at(nn > 0u ? nn - 1u : 0u);
+      if (lane < ntgt) tv[lane] = nn > 0u ? got : WS_INF;
+    }
     __builtin_amdgcn_wave_barrier();
     if (lane < nq && cvalid) {
       double r;
-      if (n == 0u) r = xh_nan64();
+      if (nn == 0u) r = xh_nan64();
       else {
-        const float left = ws_unkey(tv[2 * lane]), right = ws_unkey(tv[2 * lane + 1]);
-        if (n < 2u || pedge) r = (double)left;
+        const bool raw = !NORM || ordered;    // the picked keys are window samples still to be normalised
+        const float l0 = ws_unkey(tv[2 * lane]), r0 = ws_unkey(tv[2 * lane + 1]), t0 = ws_unkey(topkey);
+        const float left = raw ? norm(l0) : l0, right = raw ? norm(r0) : r0;
+        if (nn < 2u || edge) r = (double)left;
         else {
           const float diff = right - left;
-          r = (double)left + (double)diff * pgamma;
-          if (pgamma >= 0.5) r = (double)right - (double)diff * (1.0 - pgamma);
+          r = (double)left + (double)diff * gamma;
+          if (gamma >= 0.5) r = (double)right - (double)diff * (1.0 - gamma);
         }
-        if (r != r) r = (double)ws_unkey(cur[n - 1u]);  // inf - inf: the largest valid sample (utl:552-554)
+        if (r != r) r = (double)(raw ? norm(t0) : t0);  // inf - inf: the largest valid sample (utl:552-554)
       }
       out[((int64_t)g * nq + lane) * C + c] = (float)r;
     }
@@ -367,27 +439,27 @@ k_correction(const float* __restrict__ hq, int64_t n, int kind, float* __restric
   af[i] = kind == 0 ? (r - h) : (r / h);
 }
 
-}  // namespace
+__global__ void __launch_bounds__(XH_BLOCK)
+k_scaling(const double* __restrict__ mu_h, int64_t n, int kind, double* __restrict__ sc) {  // sc holds mu_ref on entry
+  const int64_t i = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double r = sc[i], h = mu_h[i];
+  sc[i] = kind == 0 ? (r - h) : (r / h);
+}
 
-extern "C" {
-
-// EQM training over a sliding row sample (see the head of this file).  rows0 [n0 <= 1024]: the rows of the first group's sample
-// (-1: beyond the series); leave / enter [G - 1][per <= 64]: the rows that leave / enter at the step from group g to g + 1 (-1:
-// none).  af, hist_q: (G, nq, C).  XH_ERR_NOTIMPL (no error text): not this kernel's shape — the caller selects every group
-// from its gathered sample (xh_eqm_train).
-int xh_eqm_train_window(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, const int32_t* rows0,
-                        int n0, const int32_t* enter, const int32_t* leave, int G, int per, const double* q, int nq, int kind,
-                        float* af, float* hist_q) {
-  XH_REQUIRE(ctx && ref && hist && rows0 && q && af && hist_q && (G == 1 || (enter && leave)), XH_ERR_ARG,
-             "xh_eqm_train_window: NULL argument");
-  XH_REQUIRE(T >= 1 && C >= 0 && G >= 1 && n0 >= 1 && per >= 0 && nq >= 1 && st >= C, XH_ERR_ARG, "xh_eqm_train_window: bad shape");
-  XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "xh_eqm_train_window: kind must be 0 (+) or 1 (*)");
+// both entry points: the arguments checked, the schedule on the device, the two window kernels and the correction
+int ws_train(xh_ctx* ctx, const char* who, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, const int32_t* rows0,
+             int n0, const int32_t* enter, const int32_t* leave, int G, int per, const double* q, int nq, int kind, float* af,
+             float* hist_q, double* scaling, double* mu_hist) {
+  XH_REQUIRE(ctx && ref && hist && rows0 && q && af && hist_q && (G == 1 || (enter && leave)), XH_ERR_ARG, "%s: NULL argument", who);
+  XH_REQUIRE(T >= 1 && C >= 0 && G >= 1 && n0 >= 1 && per >= 0 && nq >= 1 && st >= C, XH_ERR_ARG, "%s: bad shape", who);
+  XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "%s: kind must be 0 (+) or 1 (*)", who);
   if (n0 > WS_CAP || per > WS_PER || nq > WS_MAXQ) return XH_ERR_NOTIMPL;
   if (const char* e = xh_diag_env("XH_WINSEL"))
     if (!atoi(e)) return XH_ERR_NOTIMPL;
-  for (int i = 0; i < n0; ++i) XH_REQUIRE(rows0[i] >= -1 && rows0[i] < T, XH_ERR_ARG, "xh_eqm_train_window: rows0[%d] out of range", i);
+  for (int i = 0; i < n0; ++i) XH_REQUIRE(rows0[i] >= -1 && rows0[i] < T, XH_ERR_ARG, "%s: rows0[%d] out of range", who, i);
   for (int64_t i = 0; i < (int64_t)(G - 1) * per; ++i)
-    XH_REQUIRE(enter[i] >= -1 && enter[i] < T && leave[i] >= -1 && leave[i] < T, XH_ERR_ARG, "xh_eqm_train_window: step row out of range");
+    XH_REQUIRE(enter[i] >= -1 && enter[i] < T && leave[i] >= -1 && leave[i] < T, XH_ERR_ARG, "%s: step row out of range", who);
   if (C == 0) return XH_OK;
   // the window never outgrows its buffers: the valid samples are at most n0 + sum(entering - leaving) <= the rows present
   {
@@ -407,19 +479,60 @@ int xh_eqm_train_window(xh_ctx* ctx, const float* ref, const float* hist, int64_
   if (!rc && G > 1) rc = xh_scratch_upload(ctx, &cur, enter, sizeof(int32_t) * (size_t)(G - 1) * (size_t)per, &d_en);
   if (!rc && G > 1) rc = xh_scratch_upload(ctx, &cur, leave, sizeof(int32_t) * (size_t)(G - 1) * (size_t)per, &d_lv);
   if (rc) return rc;
-  XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_window_quantiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_lds(WS_PER)));
-  const dim3 grid((unsigned)cdiv64(C, WS_WAVES));
-  // ref_q goes to `af` first, then af = correction(ref_q, hist_q) in place (as xh_eqm_train)
-  hipLaunchKernelGGL(k_window_quantiles, grid, dim3(WS_WAVES * 64), ws_lds(per), ctx->stream, ref, T, C, st, (const int32_t*)d_r0, n0,
-                     (const int32_t*)d_en, (const int32_t*)d_lv, G, per, (const double*)d_q, nq, af);
-  XH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_window_quantiles, grid, dim3(WS_WAVES * 64), ws_lds(per), ctx->stream, hist, T, C, st, (const int32_t*)d_r0, n0,
-                     (const int32_t*)d_en, (const int32_t*)d_lv, G, per, (const double*)d_q, nq, hist_q);
-  XH_LAUNCH_CHECK();
+  const dim3 grid((unsigned)cdiv64(C, WS_WAVES)), block(WS_WAVES * 64);
   const int64_t tot = (int64_t)G * nq * C;
+  // ref_q goes to `af` first, then af = correction(ref_q, hist_q) in place (as xh_eqm_train)
+  if (!scaling) {
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_window_quantiles<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_lds(WS_PER)));
+    hipLaunchKernelGGL(k_window_quantiles<false>, grid, block, ws_lds(per), ctx->stream, ref, T, C, st, (const int32_t*)d_r0, n0,
+                       (const int32_t*)d_en, (const int32_t*)d_lv, G, per, (const double*)d_q, nq, af, 0, (double*)nullptr);
+    XH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_window_quantiles<false>, grid, block, ws_lds(per), ctx->stream, hist, T, C, st, (const int32_t*)d_r0, n0,
+                       (const int32_t*)d_en, (const int32_t*)d_lv, G, per, (const double*)d_q, nq, hist_q, 0, (double*)nullptr);
+    XH_LAUNCH_CHECK();
+  } else {
+    const int nmode = kind == 0 ? 1 : 3;   // xh_trend_apply's "-" and "/"
+    XH_CHECK_HIP(hipFuncSetAttribute((const void*)k_window_quantiles<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_lds(WS_PER)));
+    hipLaunchKernelGGL(k_window_quantiles<true>, grid, block, ws_lds(per), ctx->stream, ref, T, C, st, (const int32_t*)d_r0, n0,
+                       (const int32_t*)d_en, (const int32_t*)d_lv, G, per, (const double*)d_q, nq, af, nmode, scaling);
+    XH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_window_quantiles<true>, grid, block, ws_lds(per), ctx->stream, hist, T, C, st, (const int32_t*)d_r0, n0,
+                       (const int32_t*)d_en, (const int32_t*)d_lv, G, per, (const double*)d_q, nq, hist_q, nmode, mu_hist);
+    XH_LAUNCH_CHECK();
+    const int64_t ng = (int64_t)G * C;
+    hipLaunchKernelGGL(k_scaling, dim3((unsigned)cdiv64(ng, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, (const double*)mu_hist, ng, kind, scaling);
+    XH_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(k_correction, dim3((unsigned)cdiv64(tot, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, hist_q, tot, kind, af);
   XH_LAUNCH_CHECK();
   return XH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// EQM training over a sliding row sample (see the head of this file).  rows0 [n0 <= 1024]: the rows of the first group's sample
+// (-1: beyond the series); leave / enter [G - 1][per <= 64]: the rows that leave / enter at the step from group g to g + 1 (-1:
+// none).  af, hist_q: (G, nq, C).  XH_ERR_NOTIMPL (no error text): not this kernel's shape — the caller selects every group
+// from its gathered sample (xh_eqm_train).
+int xh_eqm_train_window(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, const int32_t* rows0,
+                        int n0, const int32_t* enter, const int32_t* leave, int G, int per, const double* q, int nq, int kind,
+                        float* af, float* hist_q) {
+  return ws_train(ctx, "xh_eqm_train_window", ref, hist, T, C, st, rows0, n0, enter, leave, G, per, q, nq, kind, af, hist_q, nullptr,
+                  nullptr);
+}
+
+// DQM training over the same sliding sample (xsdba._adjustment.dqm_train per day-of-year group with a window): af / hist_q from the
+// quantiles of the samples normalised by their own means (x - mean for "+", x / mean for "*"; xh_poly_trend degree 0 +
+// xh_trend_apply + xh_eqm_train per group otherwise), scaling (G, C) float64 = mean(ref) - mean(hist) resp. the ratio, mu_hist
+// (G, C) float64 = the means of hist (the second mean table the correction needs: an output like the others).
+int xh_dqm_train_window(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, const int32_t* rows0,
+                        int n0, const int32_t* enter, const int32_t* leave, int G, int per, const double* q, int nq, int kind,
+                        float* af, float* hist_q, double* scaling, double* mu_hist) {
+  XH_REQUIRE(scaling && mu_hist, XH_ERR_ARG, "xh_dqm_train_window: NULL argument");
+  return ws_train(ctx, "xh_dqm_train_window", ref, hist, T, C, st, rows0, n0, enter, leave, G, per, q, nq, kind, af, hist_q, scaling,
+                  mu_hist);
 }
 
 }  // extern "C"

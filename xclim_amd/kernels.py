@@ -576,11 +576,13 @@ def eqm_train(dev: Device, ref: DeviceArray, hist: DeviceArray, q, kind="+", tim
     return af, hq
 
 
-def eqm_train_window(dev: Device, ref: DeviceArray, hist: DeviceArray, rows0, enter, leave, q, kind="+", out=None):
+def eqm_train_window(dev: Device, ref: DeviceArray, hist: DeviceArray, rows0, enter, leave, q, kind="+", out=None, normalised=False):
     """xh_eqm_train_window: EQM training over a sliding row sample (day-of-year groups with a window).  rows0 (n0,): the time
     steps of the first group's sample; enter / leave (G - 1, per): the steps that enter / leave from one group to the next (-1 =
     none).  Returns (af, hist_q) as (G, nq, C) device arrays, or None when the kernel does not take the shape (the caller
-    gathers every group's sample and calls :func:`eqm_train`)."""
+    gathers every group's sample and calls :func:`eqm_train`).  ``normalised=True`` (xh_dqm_train_window, the training of a
+    detrended quantile mapping): the quantiles of the samples divided by / shifted by their own means; returns (af, hist_q,
+    scaling, mu_hist), the last two (G, C) float64 (``out`` then holds four arrays)."""
     from ._capi import XH_ERR_NOTIMPL, XclimHipError
 
     q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
@@ -590,18 +592,23 @@ def eqm_train_window(dev: Device, ref: DeviceArray, hist: DeviceArray, rows0, en
     leave = np.ascontiguousarray(leave, dtype=np.int32).reshape(enter.shape)
     G, per = enter.shape[0] + 1, enter.shape[1]
     if out is not None:
-        af, hq = out
+        af, hq = out[:2]
     else:
         af = dev.empty((G, len(q), C_), np.float32)
         hq = dev.empty((G, len(q), C_), np.float32)
+    res, extra, name = (af, hq), (), "xh_eqm_train_window"
+    if normalised:
+        # xh_dqm_train_window: the samples normalised by their own means (dqm_train); + scaling, mu_hist (G, C) float64
+        sc, muh = out[2:4] if out is not None else (dev.empty((G, C_), np.float64), dev.empty((G, C_), np.float64))
+        res, extra, name = (af, hq, sc, muh), (_vp(sc.ptr), _vp(muh.ptr)), "xh_dqm_train_window"
     try:
-        dev.call("xh_eqm_train_window", _vp(ref.ptr), _vp(hist.ptr), T, C_, C_, np_ptr(rows0), len(rows0), np_ptr(enter), np_ptr(leave),
-                 G, per, np_ptr(q), len(q), {"+": 0, "*": 1}[kind], _vp(af.ptr), _vp(hq.ptr))
+        dev.call(name, _vp(ref.ptr), _vp(hist.ptr), T, C_, C_, np_ptr(rows0), len(rows0), np_ptr(enter), np_ptr(leave),
+                 G, per, np_ptr(q), len(q), {"+": 0, "*": 1}[kind], _vp(af.ptr), _vp(hq.ptr), *extra)
     except XclimHipError as e:
         if e.code == XH_ERR_NOTIMPL:
             return None
         raise
-    return af, hq
+    return res
 
 
 def eqm_adjust(dev: Device, sim: DeviceArray, af: DeviceArray, hist_q: DeviceArray, kind="+", interp="nearest",
@@ -666,6 +673,35 @@ def trend_apply(dev: Device, x: DeviceArray, p0: DeviceArray, p1, op: str, out: 
     else:
         dev.call("xh_trend_apply_u", _vp(x.ptr), T, C_, C_, 1, _vp(u.ptr), _vp(p0.ptr), _vp(p1.ptr if p1 is not None else 0), mode,
                  _vp(out.ptr), C_)
+    return out
+
+
+def poly_trend_groups(dev: Device, x: DeviceArray, rows, offs, u: DeviceArray, degree: int = 1):
+    """xh_poly_trend_groups: the per-cell trend of every GROUP of rows in one launch.  rows: the row numbers group after group,
+    offs (G + 1): where each group's rows start, u (device float64, T): the coordinate of every row.  (p0, p1): (G, C) float64
+    device arrays (p1 None for degree 0)."""
+    T, C_ = _tc(x)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    G = len(offs) - 1
+    p0 = dev.empty((G, C_), np.float64)
+    p1 = dev.empty((G, C_), np.float64) if degree >= 1 else None
+    dev.call("xh_poly_trend_groups", _vp(x.ptr), T, C_, C_, np_ptr(rows), np_ptr(offs), G, _vp(u.ptr), int(degree), _vp(p0.ptr),
+             _vp(p1.ptr if p1 is not None else 0))
+    return p0, p1
+
+
+def trend_apply_groups(dev: Device, x: DeviceArray, rows, offs, p0: DeviceArray, p1, op: str, u: DeviceArray | None = None,
+                       out: DeviceArray | None = None) -> DeviceArray:
+    """xh_trend_apply_groups: x OP (p0[g, c] + p1[g, c] u[t]) for the rows t of every group g (p0, p1: (G, C) float64 device arrays;
+    p1 None: a per-group constant).  Rows in no group keep what ``out`` held (a fresh ``out`` is NaN-free only if every row is
+    listed)."""
+    T, C_ = _tc(x)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    out = out if out is not None else dev.empty((T, C_), np.float32)
+    dev.call("xh_trend_apply_groups", _vp(x.ptr), T, C_, C_, np_ptr(rows), np_ptr(offs), len(offs) - 1, _vp(u.ptr if u is not None else 0),
+             _vp(p0.ptr), _vp(p1.ptr if p1 is not None else 0), {"+": 0, "-": 1, "*": 2, "/": 3}[op], _vp(out.ptr), C_)
     return out
 
 

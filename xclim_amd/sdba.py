@@ -707,6 +707,36 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         af = dev.empty((G, len(q), C_), np.float32)
         hq = dev.empty((G, len(q), C_), np.float32)
         plane = len(q) * C_ * 4
+        # day-of-year groups with a window on gap-free years: the sorted window of the EQM training (xh_eqm_train_window) also
+        # carries the mean of every group's sample and normalises the samples it picks (xh_dqm_train_window, round 6: 3 970 ->
+        # ~190 ms for 30 years x 1440 x 90; per group otherwise: a gather, two means, two normalisations, two selections and a
+        # host round trip of the means)
+        stretches, rest, rows_of = grp.sliding_stretches(time)
+        if stretches:
+            scal_d = dev.empty((G, C_), np.float64)
+            muh = dev.empty((G, C_), np.float64)
+
+            def slab(a, g0, n):
+                return dev.wrap(a.ptr + g0 * plane, (n, len(q), C_), np.float32)
+
+            def rows64(a, g0, n):
+                return dev.wrap(a.ptr + g0 * C_ * 8, (n, C_), np.float64)
+
+            done = True
+            for g0, rows0, en, lv in stretches:
+                n = en.shape[0] + 1
+                if K.eqm_train_window(dev, r, h, rows0, en, lv, q, kind, normalised=True,
+                                      out=(slab(af, g0, n), slab(hq, g0, n), rows64(scal_d, g0, n), rows64(muh, g0, n))) is None:
+                    done = False   # (not the kernel's shape after all: everything through the per-group path below)
+                    break
+            if done:
+                for g in rest:     # the groups no stretch covers (day 366 of a standard calendar): from their gathered sample
+                    _, _, sg = one(K.select_rows(dev, r, rows_of[g]), K.select_rows(dev, h, rows_of[g]),
+                                   out=(slab(af, g, 1).reshape(len(q), C_), slab(hq, g, 1).reshape(len(q), C_)))
+                    row = dev.to_device(np.ascontiguousarray(sg), dtype=np.float64)
+                    dev.copy_d2d(scal_d.ptr + g * C_ * 8, row.ptr, C_ * 8)
+                dev.sync()
+                return cls(dev, af, hq, q, kind, cell_shape, grp, labels, scaling=scal_d)
         scal = np.empty((G, C_), np.float64)
         for g, (rg, hg) in grp.group_samples(dev, (r, h), time):
             out_g = tuple(dev.wrap(a.ptr + g * plane, (len(q), C_), np.float32) for a in (af, hq))
