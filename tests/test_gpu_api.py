@@ -2094,3 +2094,52 @@ def test_dqm_doy_window_sliding_matches_per_group(dev, rng, monkeypatch, years, 
     if kind == "*":
         assert np.isnan(ha[:, :, 8]).all()
 
+
+@pytest.mark.parametrize("C", [37, 256])
+def test_dqm_groups_kernels_match_per_group_calls(dev, rng, C):
+    """xh_poly_trend_groups / xh_trend_apply_groups (round 6: the per-group fit and the per-group trend of a grouped
+    DetrendedQuantileMapping.adjust in ONE launch each, a group = a list of rows) against xh_poly_trend_u / xh_trend_apply_u on
+    every group's gathered rows — bit for bit: groups of unequal size, an empty group, rows in no group (left untouched), NaN
+    samples, a cell without samples, degree 0 and 1, all four operations, in place."""
+    from xclim_amd import kernels as K
+
+    T, G = 400, 9
+    x = rng.normal(10, 4, (T, C)).astype(np.float32)
+    x[rng.random(x.shape) < 0.1] = np.nan
+    x[:, 2] = np.nan
+    gid = rng.integers(-1, G, T)
+    gid[gid == 4] = 5                  # group 4 is empty
+    perm = np.argsort(gid, kind="stable")
+    perm = perm[gid[perm] >= 0]
+    counts = np.bincount(gid[gid >= 0], minlength=G)
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    u = rng.normal(0, 50, T)
+    d_x, d_u = dev.to_device(x), dev.to_device(u, dtype=np.float64)
+    for degree in (0, 1):
+        p0, p1 = K.poly_trend_groups(dev, d_x, perm, offs, d_u, degree)
+        P0, P1 = p0.get(), (p1.get() if p1 is not None else None)
+        for op in "+-*/":
+            out = dev.to_device(np.full((T, C), -7.0, np.float32))
+            K.trend_apply_groups(dev, d_x, perm, offs, p0, p1, op, u=d_u, out=out)
+            got = out.get()
+            assert (got[gid < 0] == -7.0).all()
+            for g in range(G):
+                rows = perm[offs[g]:offs[g + 1]]
+                if not len(rows):
+                    assert np.isnan(P0[g]).all()
+                    continue
+                blk = K.select_rows(dev, d_x, rows)
+                ug = dev.to_device(np.ascontiguousarray(u[rows]), dtype=np.float64)
+                q0, q1 = K.poly_trend(dev, blk, degree, u=ug)
+                np.testing.assert_array_equal(P0[g], q0.get())
+                if degree:
+                    np.testing.assert_array_equal(P1[g], q1.get())
+                np.testing.assert_array_equal(got[rows], K.trend_apply(dev, blk, q0, q1, op, u=ug).get())
+        # in place, and a per-group constant without a coordinate
+        y = dev.to_device(x)
+        K.trend_apply_groups(dev, y, perm, offs, p0, None, "-", out=y)
+        exp = x.astype(np.float64) - P0[np.maximum(gid, 0)]
+        keep = gid >= 0
+        np.testing.assert_array_equal(y.get()[keep], exp.astype(np.float32)[keep])
+        np.testing.assert_array_equal(y.get()[~keep], x[~keep])
+

@@ -5,7 +5,7 @@ with g++ against a stand-in for the HIP runtime and run on the CPU:
   * every workgroup as a set of FIBERS (simt.h: __syncthreads, wave-uniform shuffles / votes / readlane, atomics) — f64, select,
     select2, select3, select4, select5, tcount, qdm, qdm2, quantile, doystats, reduce2, pdoy_top, pdoy_quad, pdoy_walk, winsel and the
     kernels of core.hip (transposes, synthetic fields).
-65 of the 95 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
+67 of the 97 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
 other 30 are runtime services (memory, streams, RCCL).  The register percentile kernels (pdoy_top / pdoy_quad / pdoy_walk) run on
 fibers too, with the four ISA statements of topnet.h rewritten to the C++ they stand for, and so do the register sorting networks
 (select3 / qdm2: the DPP split across the lane pair as a shuffle), select2's wave counts on VCC and the streaming two-pass selection

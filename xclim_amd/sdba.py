@@ -853,11 +853,36 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             inv2 = np.empty(T, dtype=np.int64)
             inv2[perm2] = np.arange(T)
             src = K.select_rows(dev, sc_p2, inv2)
+        windowed = self.group.window > 1
+        if interp == "linear" or self._plane_nearest(grouped_nearest):
+            # the (quantile, group) plane serves the whole series in one launch, and so do the scaling, the per-group fit and the
+            # trend (xh_trend_apply_groups / xh_poly_trend_groups, round 6: a group is a list of rows, the coefficients are
+            # (G, C) tables, nothing is permuted) — bit-identical to the per-group loop below, which launched four kernels per
+            # group on gathered blocks (365 groups: 87 ms for a 30-year 1440 x 90 band, now ~20)
+            offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            u_time = np.zeros(T, dtype=np.float64)
+            for g in range(len(counts)):
+                r = perm[offs[g]:offs[g + 1]]
+                if len(r):
+                    u_time[r] = days[r] - days[r].mean()
+            u_d = dev.to_device(u_time, dtype=np.float64)
+            scaled = src if prescaled else K.trend_apply_groups(dev, s, perm, offs, self._scaling, None, fwd)
+            fit_on = K.window_nanmean(dev, scaled, self.group.window) if windowed else scaled
+            p0, p1 = K.poly_trend_groups(dev, fit_on, perm, offs, u_d, detrend)
+            del fit_on
+            detr = K.trend_apply_groups(dev, scaled, perm, offs, p0, p1, inv, u=u_d)
+            del scaled
+            if interp == "linear":
+                scen0 = K.plane_linear(dev, detr, gcoord, self._af, xq_all=self._hist_q, kind=self.kind)
+            else:
+                scen0 = K.plane_nearest(dev, detr, gi + 1.0, self._af, self._hist_q, self.kind, extrapolation)
+            scen = K.trend_apply_groups(dev, scen0, perm, offs, p0, p1, fwd, u=u_d, out=detr)
+            dev.sync()
+            return scen if keep else scen.get().reshape((T,) + self.cell_shape)
         s_perm = K.select_rows(dev, src, perm)
         scen_perm = dev.empty((T, C_), np.float32)
         inv_perm = np.empty(T, dtype=np.int64)
         inv_perm[perm] = np.arange(T)
-        windowed = self.group.window > 1
         wm_perm = None
         if windowed:
             # PolyDetrend with a windowed Grouper (xsdba.detrending._polydetrend_get_trend: ``da.mean(dim[1:])`` before polyfit):
@@ -877,12 +902,8 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
                 src = K.select_rows(dev, s_perm, inv_perm)     # ... and in time order
             wm_perm = K.select_rows(dev, K.window_nanmean(dev, src, self.group.window), perm)
         off = 0
-        plane_nearest = interp != "linear" and self._plane_nearest(grouped_nearest)   # (decided — and warned about — once)
-        # interp="linear": every group's block is detrended into ONE group-major buffer and the (quantile, group) plane is
-        # interpolated over the whole series in a single xh_plane_linear call, as EQM.adjust does (one call per
-        # group packed the (G, nq, C) tables and synchronised 365 times for a day-of-year grouping)
-        detr_perm = dev.empty((T, C_), np.float32) if interp == "linear" else None
-        trends = []
+        # (what is left here: every step through the nodes of its OWN group — grouped_nearest="group", seasons, more than 32
+        # nodes, "cubic": one xh_eqm_adjust per group on its gathered block)
         for g, n in enumerate(counts):
             n = int(n)
             if n == 0:
@@ -897,23 +918,10 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             scaled = blk if (prescaled or windowed) else K.trend_apply(dev, blk, sc_g, None, fwd)
             fit_on = scaled if not windowed else dev.wrap(wm_perm.ptr + off * C_ * 4, (n, C_), np.float32)
             p0, p1 = K.poly_trend(dev, fit_on, detrend, u=u)
-            if interp == "linear":
-                K.trend_apply(dev, scaled, p0, p1, inv, u=u, out=dev.wrap(detr_perm.ptr + off * C_ * 4, (n, C_), np.float32))
-                trends.append((off, n, p0, p1, u))
-                off += n
-                continue
             detr = K.trend_apply(dev, scaled, p0, p1, inv, u=u)
-            if plane_nearest:
-                scen0 = K.eqm_adjust_g2d(dev, detr, self._af, self._hist_q, g + 1, self.kind, extrapolation)
-            else:
-                scen0 = K.eqm_adjust(dev, detr, af_g, hq_g, self.kind, interp, extrapolation)
+            scen0 = K.eqm_adjust(dev, detr, af_g, hq_g, self.kind, interp, extrapolation)
             K.trend_apply(dev, scen0, p0, p1, fwd, out=out, u=u)
             off += n
-        if interp == "linear":
-            scen0 = K.plane_linear(dev, detr_perm, gcoord[perm], self._af, xq_all=self._hist_q, kind=self.kind)
-            for off, n, p0, p1, u in trends:
-                K.trend_apply(dev, dev.wrap(scen0.ptr + off * C_ * 4, (n, C_), np.float32), p0, p1, fwd,
-                              out=dev.wrap(scen_perm.ptr + off * C_ * 4, (n, C_), np.float32), u=u)
         scen = K.select_rows(dev, scen_perm, inv_perm)
         dev.sync()
         return scen if keep else scen.get().reshape((T,) + self.cell_shape)
