@@ -779,8 +779,18 @@ def bench_doy_window(dev, K, Cb):
                                                                   time=ta, device=dev), 1)
     ms_near, _ = timed(lambda: eqm.adjust(sim, interp="nearest", time=ta, keep=True), 2)
     ms_lin, _ = timed(lambda: eqm.adjust(sim, interp="linear", time=ta, keep=True), 2)
+    # the other two mappings on the same configuration (round 6: QDM ranks all 365 groups in one launch — xh_qdm_adjust_groups;
+    # DQM trains through the normalising instance of the sliding window — xh_dqm_train_window — and detrends all groups in one
+    # launch per stage — xh_poly_trend_groups / xh_trend_apply_groups)
+    qdm = sdba.QuantileDeltaMapping(dev, eqm._af, eqm._hist_q, eqm.quantiles, eqm.kind, eqm.cell_shape, eqm.group, eqm.group_labels)
+    ms_qdm, _ = timed(lambda: qdm.adjust(sim, interp="nearest", time=ta, keep=True), 2)
+    ms_dtr, dqm = timed(lambda: sdba.DetrendedQuantileMapping.train(ref, hist, nquantiles=20, kind="+", group="time.dayofyear", window=31,
+                                                                    time=ta, device=dev), 1)
+    ms_dad, _ = timed(lambda: dqm.adjust(sim, interp="nearest", time=ta, keep=True), 2)
+    del qdm, dqm
     E = float(T) * Cb
-    res = {"train_ms": ms_tr, "adjust_nearest_ms": ms_near, "adjust_linear_ms": ms_lin, "grid": [T, 1440, 90], "groups": 365, "window": 31,
+    res = {"train_ms": ms_tr, "adjust_nearest_ms": ms_near, "adjust_linear_ms": ms_lin, "qdm_adjust_nearest_ms": ms_qdm,
+           "dqm_train_ms": ms_dtr, "dqm_adjust_nearest_ms": ms_dad, "grid": [T, 1440, 90], "groups": 365, "window": 31,
            "nodes": 20, "train_samples_GB": 2 * 365 * 930 * 4.0 * Cb / 1e9,
            "train_GB/s": 2 * 365 * 930 * 4.0 * Cb / ms_tr / 1e6, "adjust_linear_GB/s": 8 * E / ms_lin / 1e6,
            "adjust_linear_frac": 8 * E / ms_lin / 1e6 / HBM_PEAK_GBS,

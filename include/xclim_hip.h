@@ -539,6 +539,14 @@ int xh_plane_nearest(xh_ctx* ctx, const float* xnew, const float* base, int64_t 
  * reference tree). */
 int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, int64_t sc, const float* af,
                   const double* q /* host */, int nq, int kind, int interp, int extrap, float* scen);
+/* qdm_adjust for ALL groups of a sub-grouping with small groups in one launch (a day-of-year grouping: one row per year; xsdba
+ * ranks inside each group: group.apply(rank, sim, main_only=True)).  rows (host, offs[G] entries): the row numbers of group 0,
+ * then of group 1, ...; offs (host, G + 1); af (G, nq, C) float32: every group's factors.  scen is written at the listed rows only
+ * (not in place).  Bit-identical to xh_qdm_adjust on each group's gathered rows.  XH_ERR_NOTIMPL (no error text): a group of
+ * more than 64 rows or nq > 32 — gather each group and call xh_qdm_adjust. */
+int xh_qdm_adjust_groups(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, const int32_t* rows /* host */,
+                         const int64_t* offs /* host */, int G, const float* af, const double* q /* host */, int nq, int kind,
+                         int interp, int extrap, float* scen, int64_t scen_st);
 /* xsdba.nbutils.vecquantiles(da, rnk, dim) (upstream xsdba, re-exported by /root/reference/src/xclim/sdba.py:10): ONE
  * quantile per cell at that cell's own probability q_cell[c] (DEVICE float64, NaN -> NaN), Hyndman-Fan type 7 over the
  * valid samples (= /root/reference/src/xclim/core/utils.py:370-491 with alpha = beta = 1).  x (T, C) with element strides

@@ -2143,3 +2143,49 @@ def test_dqm_groups_kernels_match_per_group_calls(dev, rng, C):
         np.testing.assert_array_equal(y.get()[keep], exp.astype(np.float32)[keep])
         np.testing.assert_array_equal(y.get()[~keep], x[~keep])
 
+
+@pytest.mark.parametrize("years,kind,interp,extrap", [(5, "+", "nearest", "constant"), (30, "*", "linear", "constant"),
+                                                      (40, "+", "linear", "constant"), (64, "*", "nearest", "nan")])
+def test_qdm_small_groups_match_per_group_calls(dev, rng, monkeypatch, years, kind, interp, extrap):
+    """xh_qdm_adjust_groups (round 6): QuantileDeltaMapping.adjust with a day-of-year grouping — every step ranked among the steps
+    of its own group, all 365 groups in ONE launch (keys in registers, <= 64 rows per group) — against the loop it replaces
+    (XH_QDM_GROUPS=0: a gather and xh_qdm_adjust per group), BIT FOR BIT: NaN samples, ties (dry days: zeros tie, -0.0 with 0.0),
+    constant groups, a cell without samples, NaN factors (dropped nodes), a cell with fewer than two valid nodes, 5 to 64 years
+    (both register sizes), day 366 of a standard calendar (a smaller group)."""
+    from xclim_amd import sdba as xsdba
+
+    cells, nq = 37, 12
+    T = 365 * years + years // 4
+    ta = TimeAxis.daily("2000-01-01", T, "standard")
+    t = np.arange(T)[:, None]
+    ref = (10 + 8 * np.sin(2 * np.pi * t / 365.25) + rng.normal(0, 3, (T, cells))).astype(np.float32) + (20 if kind == "*" else 0)
+    hist = (ref * 1.05 + rng.normal(0, 1, (T, cells))).astype(np.float32)
+    sim = (hist + 2 + rng.normal(0, 1, (T, cells))).astype(np.float32)
+    sim[rng.random(sim.shape) < 0.05] = np.nan
+    sim[:, 1] = np.round(sim[:, 1])                                 # ties
+    sim[:, 2] = np.where(rng.random(T) < 0.6, 0.0, sim[:, 2])       # dry days
+    sim[::7, 2] = -0.0
+    sim[:, 3] = np.nan
+    sim[:, 4] = 5.0                                                 # every group constant: pct = 0 / 0
+    hist[:, 5] = np.nan                                             # all factors NaN: no node
+    m = xsdba.QuantileDeltaMapping.train(ref, hist, nquantiles=nq, kind=kind, group="time.dayofyear", window=1, time=ta, device=dev)
+    af = m.af.copy()
+    af[:, 3:6, 6] = np.nan                                          # dropped nodes
+    af[:, 1:, 7] = np.nan                                           # one valid node: no interpolation
+    m._af = dev.to_device(np.ascontiguousarray(af.reshape(af.shape[0], nq, cells)))
+    monkeypatch.setenv("XH_DIAGNOSTICS", "1")
+    monkeypatch.setenv("XH_QDM_GROUPS", "1")
+    trace = dev.start_trace()
+    a = m.adjust(sim, interp=interp, extrapolation=extrap, time=ta)
+    dev.stop_trace()
+    names = [n for n, _ in trace]
+    assert names.count("xh_qdm_adjust_groups") == 1 and "xh_qdm_adjust" not in names
+    monkeypatch.setenv("XH_QDM_GROUPS", "0")
+    trace = dev.start_trace()
+    b = m.adjust(sim, interp=interp, extrapolation=extrap, time=ta)
+    dev.stop_trace()
+    assert [n for n, _ in trace].count("xh_qdm_adjust") == 366
+    np.testing.assert_array_equal(a, b)
+    assert np.isnan(a[:, 3]).all() and np.isnan(a[:, 5]).all() and np.isnan(a[:, 7]).all()
+    assert np.isfinite(a[:, 0]).mean() > (0.9 if extrap == "constant" else 0.7)   # ("nan": the ranks beyond the end nodes)
+

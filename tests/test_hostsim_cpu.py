@@ -5,7 +5,7 @@ with g++ against a stand-in for the HIP runtime and run on the CPU:
   * every workgroup as a set of FIBERS (simt.h: __syncthreads, wave-uniform shuffles / votes / readlane, atomics) — f64, select,
     select2, select3, select4, select5, tcount, qdm, qdm2, quantile, doystats, reduce2, pdoy_top, pdoy_quad, pdoy_walk, winsel and the
     kernels of core.hip (transposes, synthetic fields).
-67 of the 97 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
+68 of the 98 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
 other 30 are runtime services (memory, streams, RCCL).  The register percentile kernels (pdoy_top / pdoy_quad / pdoy_walk) run on
 fibers too, with the four ISA statements of topnet.h rewritten to the C++ they stand for, and so do the register sorting networks
 (select3 / qdm2: the DPP split across the lane pair as a shuffle), select2's wave counts on VCC and the streaming two-pass selection
@@ -241,7 +241,7 @@ def test_quantile_mapping_api_on_the_simulation(sim):
     20 000+ steps)."""
     _child_run(sim, ["tests/test_gpu_api.py"], at_least=60,
                skip="not (qdm or eqm or dqm or sdba) or bootstrap or adapt or sub_groupings or beyond or dayofyear or 32768 or 20000 "
-                    "or sliding_matches_per_group")   # (winsel.hip: its own test below, the small shapes)
+                    "or sliding_matches_per_group or small_groups")   # (winsel.hip, k_qdm_groups: their own tests below, small shapes)
 
 
 def test_sliding_window_training_on_the_simulation(sim, rng):
@@ -330,4 +330,36 @@ def test_sliding_window_dqm_training_on_the_simulation(sim, rng, kind):
     if kind == "*":
         assert np.isnan(hq[:, :, 5]).all()         # 0 / 0: no sample survives the normalisation
         assert (np.diff(af[:, :, 4], axis=1) * 0 == 0).all()
+
+
+@pytest.mark.parametrize("interp", ["nearest", "linear"])
+def test_qdm_small_groups_on_the_simulation(sim, rng, interp):
+    """k_qdm_groups (qdm.hip, round 6: all groups of a day-of-year grouping ranked in registers in one launch) against xh_qdm_adjust
+    on every group's gathered rows, bit for bit: 12 groups of 0 to 9 rows, NaN samples, ties, the two zeros, a constant cell, NaN
+    factors.  30 to 64 rows per group: tests/test_gpu_api.py::test_qdm_small_groups_match_per_group_calls on the GPU."""
+    T, C, G, nq = 60, 6, 12, 7
+    x = np.round(rng.normal(3, 2, (T, C)), 1).astype(np.float32)
+    x[rng.random(x.shape) < 0.1] = np.nan
+    x[:, 1] = np.where(rng.random(T) < 0.5, 0.0, x[:, 1])
+    x[::3, 1] = -0.0
+    x[:, 2] = 4.0
+    gid = rng.integers(0, G, T)
+    gid[gid == 7] = 8
+    perm = np.argsort(gid, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(gid, minlength=G))])
+    af = rng.normal(1, 0.3, (G, nq, C)).astype(np.float32)
+    af[:, 2:4, 3] = np.nan
+    af[:, 1:, 4] = np.nan
+    q = (np.arange(nq) + 0.5) / nq
+    d_x, d_af = sim.to_device(x), sim.to_device(af)
+    for kind, extrap in (("+", "constant"), ("*", "nan"), ("factor", "constant")):
+        out = sim.to_device(np.full((T, C), -3.0, np.float32))
+        got = K.qdm_adjust_groups(sim, d_x, perm, offs, d_af, q, kind, interp, extrap, out=out).get()
+        for g in range(G):
+            rows = perm[offs[g]:offs[g + 1]]
+            if len(rows):
+                exp = K.qdm_adjust(sim, K.select_rows(sim, d_x, rows), sim.to_device(af[g]), q, kind, interp, extrap).get()
+                np.testing.assert_array_equal(got[rows], exp, err_msg=f"{kind} group {g}")
+    # a group of more than 64 rows is not this kernel's: the caller gathers it
+    assert K.qdm_adjust_groups(sim, d_x, np.r_[np.arange(T), np.arange(10)], np.array([0, T + 10]), d_af, q) is None
 

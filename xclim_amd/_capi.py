@@ -158,6 +158,7 @@ SIGNATURES: dict[str, list] = {
     "xh_plane_nearest": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _i64],
     "xh_plane_linear": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _vp, _i64],
     "xh_qdm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp],
+    "xh_qdm_adjust_groups": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64],
     "xh_quantile_cells": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp],
     "xh_adapt_freq": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _dbl, _u64, _vp, _i64, _vp],
     "xh_mask_doy_cells": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64],
@@ -291,9 +292,15 @@ class Device:
         # Freed buffers are kept per exact size and handed out again: hipMalloc / hipFree cost ~0.1-0.4 ms each and
         # hipFree synchronises the device, which is as long as a whole kernel of this library.  Re-use is safe because
         # every kernel of a context runs on its one stream (stream order protects a buffer that is still being read).
-        self._pool: dict[int, list[int]] = {}
+        self._pool: dict[int, list[tuple[int, int]]] = {}   # size -> [(release number, address)], oldest first
+        self._pool_seq = 0
         self._pool_bytes = 0
-        self._pool_cap = int(os.environ.get("XCLIM_AMD_POOL_BYTES", str(32 << 30)))
+        # cap: XCLIM_AMD_POOL_BYTES, else a quarter of the device's memory (72 GB of an MI355X's 288; at least 32 GiB) — a grouped
+        # DQM adjust of a 30-year 1440 x 90 band turns over four 5.7 GB buffers per call, and giving those back to the driver
+        # costs two seconds per call (hipFree + hipMalloc of multi-GB ranges) against 27 ms of kernels.  A failed allocation
+        # empties the pool and retries (empty()).
+        cap = os.environ.get("XCLIM_AMD_POOL_BYTES")
+        self._pool_cap = int(cap) if cap is not None else None  # None: decided at the first release
         self._pinned: dict[int, int] = {}  # page-locked host ranges we own or registered: address -> bytes
         # device copies of large host inputs, recognised again across calls (resident())
         self._inputs: dict = {}
@@ -318,7 +325,10 @@ class Device:
             free = self._pool.get(nbytes)
             if free:
                 self._pool_bytes -= nbytes
-                return DeviceArray(self, free.pop(), shape, dtype, alloc=nbytes)
+                _, ptr = free.pop()        # (the most recently released one)
+                if not free:
+                    del self._pool[nbytes]
+                return DeviceArray(self, ptr, shape, dtype, alloc=nbytes)
         p = _vp()
         rc = self.lib.xh_malloc(self.ctx, nbytes, C.byref(p))
         if rc != XH_OK and self._pool_bytes:
@@ -334,19 +344,43 @@ class Device:
         return DeviceArray(self, p.value, shape, dtype, alloc=nbytes)
 
     def _release(self, ptr: int, nbytes: int) -> None:
+        """A freed buffer is parked (per exact size).  Over the cap, or with more than 8 of one size, the OLDEST parked buffers go
+        back to the driver — of any size: the pool follows the working set (a bench leg on 45 GB fields must not leave the pool
+        full of sizes nobody asks for again while the next leg's 5.7 GB buffers go through hipFree / hipMalloc on every call)."""
+        victims = []
         with self.lock:
-            if nbytes and self._pool_bytes + nbytes <= self._pool_cap and len(self._pool.get(nbytes, ())) < 8:
-                self._pool.setdefault(nbytes, []).append(ptr)
+            if self._pool_cap is None:
+                try:
+                    self._pool_cap = max(32 << 30, self.mem_info()[1] // 4)
+                except Exception:
+                    self._pool_cap = 32 << 30
+            if not nbytes or nbytes > self._pool_cap:
+                victims.append(ptr)
+            else:
+                self._pool_seq = getattr(self, "_pool_seq", 0) + 1
+                self._pool.setdefault(nbytes, []).append((self._pool_seq, ptr))
                 self._pool_bytes += nbytes
-                return
-        self.lib.xh_free(self.ctx, _vp(ptr))
+                while True:
+                    if len(self._pool.get(nbytes, ())) > 8:
+                        size = nbytes
+                    elif self._pool_bytes > self._pool_cap:
+                        size = min((lst[0][0], sz) for sz, lst in self._pool.items())[1]
+                    else:
+                        break
+                    _, p = self._pool[size].pop(0)
+                    if not self._pool[size]:
+                        del self._pool[size]
+                    self._pool_bytes -= size
+                    victims.append(p)
+        for p in victims:
+            self.lib.xh_free(self.ctx, _vp(p))
 
     def trim(self) -> None:
         """Return every pooled buffer to the driver."""
         with self.lock:
             pool, self._pool, self._pool_bytes = self._pool, {}, 0
         for ptrs in pool.values():
-            for ptr in ptrs:
+            for _, ptr in ptrs:
                 self.lib.xh_free(self.ctx, _vp(ptr))
 
     # ---- pinned host memory + copy lanes (block adapter, blocks.py) ----

@@ -262,6 +262,108 @@ int launch_qdm(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_
   return XH_OK;
 }
 
+// ---- small groups: QuantileDeltaMapping.adjust with a day-of-year grouping ranks every step among the steps of its OWN group —
+// one per year, 30 rows for a 30-year series — and 365 groups meant 365 gathers + 365 launches of the column kernels on 30-row
+// blocks (launch-bound: 80 ms for a 30-year 1440 x 90 band).  Here ONE launch: thread = one cell of one group (rows <= PER,
+// listed by row number — nothing is gathered).  The group's keys sit in registers; every row is then taken in turn: its key
+// against the PER register keys (below / equal counts -> the doubled average rank), pct and the node lookup in the arithmetic of
+// stage E above (bit-identical), the result stored at the row's own place.  The nodes of the cell (the non-NaN factors,
+// compacted) live in the thread's LDS column: values + their indices into the common quantile nodes.
+template <int PER>
+__global__ void __launch_bounds__(256)
+k_qdm_groups(const float* __restrict__ x, int64_t C, int64_t st, const int32_t* __restrict__ rows, const int64_t* __restrict__ offs,
+             const float* __restrict__ af, const double* __restrict__ qnodes, int nq, int kind, int interp, int extrap,
+             float* __restrict__ out, int64_t ost) {
+  extern __shared__ double qg_lds[];
+  double* qn = qg_lds;                                         // [nq] the common nodes
+  float* ys = reinterpret_cast<float*>(qn + QDM_MAXQ);         // [nq][256] the cell's valid factors
+  unsigned char* xi = reinterpret_cast<unsigned char*>(ys + (size_t)nq * 256);  // [nq][256] their node numbers
+  const int tid = threadIdx.x;
+  if (tid < nq) qn[tid] = qnodes[tid];
+  __syncthreads();
+  const int64_t c = (int64_t)blockIdx.x * 256 + tid;
+  if (c >= C) return;
+  const int64_t g = blockIdx.y;
+  const int64_t k0 = offs[g];
+  const int m = (int)(offs[g + 1] - k0);                        // rows of the group (<= PER)
+  int nvn = 0;
+  for (int j = 0; j < nq; ++j) {
+    const float a = af[((int64_t)g * nq + j) * C + c];
+    if (a == a) { ys[nvn * 256 + tid] = a; xi[nvn * 256 + tid] = (unsigned char)j; ++nvn; }
+  }
+  uint32_t key[PER];
+  uint32_t n = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int32_t row = rows[k0 + (j < m ? j : 0)];
+    const float f = x[(int64_t)row * st + c];
+    const uint32_t kk = j < m ? xh_f2key(f + 0.0f) : 0xFFFFFFFFu;   // (-0.0 + 0.0 = +0.0: the two zeros tie)
+    key[j] = kk;
+    n += kk != 0xFFFFFFFFu ? 1u : 0u;
+    kmin = kk < kmin ? kk : kmin;
+    kmax = kk + 1u > kmax ? kk + 1u : kmax;
+  }
+  kmax -= 1u;
+  uint32_t cnt0 = 0, cntm = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    cnt0 += key[j] == kmin ? 1u : 0u;
+    cntm += key[j] == kmax ? 1u : 0u;
+  }
+  if (n == 0) { cnt0 = 0; cntm = 0; }
+  const double dn = (double)n;
+  const double mn = ((double)(cnt0 + 1u) / 2.0) / dn;
+  const double mx = ((double)(2u * n - cntm + 1u) / 2.0) / dn;
+  const double mxmn = mx - mn;
+  const double inv_dn = 1.0 / dn, inv_mxmn = 1.0 / mxmn;
+  auto xs = [&](int j) -> double { return qn[xi[j * 256 + tid]]; };
+  float fnext = m > 0 ? x[(int64_t)rows[k0] * st + c] : 0.f;
+  for (int j = 0; j < m; ++j) {
+    const int32_t row = rows[k0 + j];
+    const float raw = fnext;
+    if (j + 1 < m) fnext = x[(int64_t)rows[k0 + j + 1] * st + c];   // (re-read from the cache: the keys are indexed statically only)
+    const uint32_t kk = xh_f2key(raw + 0.0f);
+    float res = xh_nan32();
+    if (kk != 0xFFFFFFFFu && nvn >= 2) {
+      uint32_t below = 0, equal = 0;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        below += key[i] < kk ? 1u : 0u;
+        equal += key[i] == kk ? 1u : 0u;
+      }
+      const double rnk = xh_div_int((double)(2u * below + equal + 1u) * 0.5, dn, inv_dn);
+      const double pnum = mx * (rnk - mn);
+      const double pct = mxmn == 0.0 ? xh_nan64() : xh_div_int(pnum, mxmn, inv_mxmn);
+      if (pct == pct) {
+        const double x0 = xs(0), xl = xs(nvn - 1);
+        float a;
+        if (pct < x0) a = extrap == 0 ? ys[tid] : xh_nan32();
+        else if (pct > xl) a = extrap == 0 ? ys[(nvn - 1) * 256 + tid] : xh_nan32();
+        else if (interp == 0) {  // searchsorted(x_bds, pct, side="left"), clipped; x_bds[j] = x[j] / 2 + x[j + 1] / 2
+          int lo = 0, hi = nvn - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (xs(mid) / 2.0 + xs(mid + 1) / 2.0 < pct) lo = mid + 1; else hi = mid;
+          }
+          a = ys[lo * 256 + tid];
+        } else {
+          int lo = 0, hi = nvn;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (xs(mid) < pct) lo = mid + 1; else hi = mid;
+          }
+          lo = lo < 1 ? 1 : (lo > nvn - 1 ? nvn - 1 : lo);
+          const float ylo = ys[(lo - 1) * 256 + tid], yhi = ys[lo * 256 + tid];
+          const double slope = (double)(yhi - ylo) / (xs(lo) - xs(lo - 1));
+          a = (float)(slope * (pct - xs(lo - 1)) + (double)ylo);
+        }
+        res = kind == 0 ? raw + a : (kind == 1 ? raw * a : a);
+      }
+    }
+    out[(int64_t)row * ost + c] = res;
+  }
+}
+
 }  // namespace
 
 // exact-rank kernel on time-minor columns (column c at xcols + c * col_stride, factors af[j * af_qs + c]); also the
@@ -356,6 +458,52 @@ int xh_qdm_adjust(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t s
     rc = xh_transpose_f32(ctx, bout, nb, T, Tp, scen + c0, st);
     if (rc) return rc;
   }
+  return XH_OK;
+}
+
+// QuantileDeltaMapping.adjust for ALL groups of a sub-grouping whose groups are small (a day-of-year grouping: one row per year):
+// rows (host, offs[G] entries): the row numbers of group 0, then of group 1, ...; offs (host, G + 1); af (G, nq, C): every
+// group's factors; the ranks are taken inside each group (xsdba: group.apply(rank, sim, main_only=True)).  scen[t] is written
+// for the listed rows only.  Bit-identical to xh_qdm_adjust on each group's gathered rows.  XH_ERR_NOTIMPL (no error text):
+// a group of more than 64 rows or more than 32 nodes — gather the groups and call xh_qdm_adjust.
+int xh_qdm_adjust_groups(xh_ctx* ctx, const float* sim, int64_t T, int64_t C, int64_t st, const int32_t* rows, const int64_t* offs,
+                         int G, const float* af, const double* q, int nq, int kind, int interp, int extrap, float* scen,
+                         int64_t scen_st) {
+  XH_REQUIRE(ctx && sim && rows && offs && af && q && scen, XH_ERR_ARG, "xh_qdm_adjust_groups: NULL argument");
+  XH_REQUIRE(T >= 1 && C >= 0 && G >= 1 && nq >= 1 && st >= C && scen_st >= C, XH_ERR_ARG, "xh_qdm_adjust_groups: bad shape");
+  XH_REQUIRE(kind >= 0 && kind <= 2, XH_ERR_ARG, "xh_qdm_adjust_groups: kind must be 0 (+), 1 (*) or 2 (the interpolated factor only)");
+  XH_REQUIRE(interp == 0 || interp == 1, XH_ERR_NOTIMPL, "xh_qdm_adjust_groups: interp must be 0 (nearest) or 1 (linear)");
+  XH_REQUIRE(extrap == 0 || extrap == 1, XH_ERR_ARG, "xh_qdm_adjust_groups: extrap must be 0 (constant) or 1 (nan)");
+  XH_REQUIRE(sim != scen, XH_ERR_ARG, "xh_qdm_adjust_groups: not in place");
+  for (int j = 1; j < nq; ++j)
+    XH_REQUIRE(q[j] > q[j - 1], XH_ERR_ARG, "xh_qdm_adjust_groups: the quantile nodes must be strictly increasing");
+  XH_REQUIRE(offs[0] == 0, XH_ERR_ARG, "xh_qdm_adjust_groups: offs[0] must be 0");
+  int64_t most = 0;
+  for (int g = 0; g < G; ++g) {
+    XH_REQUIRE(offs[g + 1] >= offs[g], XH_ERR_ARG, "xh_qdm_adjust_groups: offs must not decrease");
+    most = offs[g + 1] - offs[g] > most ? offs[g + 1] - offs[g] : most;
+  }
+  const int64_t nr = offs[G];
+  for (int64_t k = 0; k < nr; ++k) XH_REQUIRE(rows[k] >= 0 && rows[k] < T, XH_ERR_ARG, "xh_qdm_adjust_groups: row %lld out of range", (long long)k);
+  if (most > 64 || nq > 32) return XH_ERR_NOTIMPL;
+  if (const char* e = xh_diag_env("XH_QDM_GROUPS"))
+    if (!atoi(e)) return XH_ERR_NOTIMPL;
+  if (C == 0 || nr == 0) return XH_OK;
+  size_t cur = 0;
+  void *d_q = nullptr, *d_rows = nullptr, *d_offs = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, q, sizeof(double) * (size_t)nq, &d_q);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, offs, sizeof(int64_t) * (size_t)(G + 1), &d_offs);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, rows, sizeof(int32_t) * (size_t)nr, &d_rows);
+  if (rc) return rc;
+  const size_t lds = sizeof(double) * QDM_MAXQ + (size_t)nq * 256 * 5;
+  const dim3 grid((unsigned)cdiv64(C, 256), (unsigned)G);
+#define XH_QG(PER)                                                                                                                 \
+  hipLaunchKernelGGL((k_qdm_groups<PER>), grid, dim3(256), lds, ctx->stream, sim, C, st, (const int32_t*)d_rows, (const int64_t*)d_offs, \
+                     af, (const double*)d_q, nq, kind, interp, extrap, scen, scen_st)
+  if (most <= 32) XH_QG(32);
+  else XH_QG(64);
+#undef XH_QG
+  XH_LAUNCH_CHECK();
   return XH_OK;
 }
 

@@ -676,6 +676,33 @@ def trend_apply(dev: Device, x: DeviceArray, p0: DeviceArray, p1, op: str, out: 
     return out
 
 
+def qdm_adjust_groups(dev: Device, sim: DeviceArray, rows, offs, af_all: DeviceArray, q, kind="+", interp="nearest",
+                      extrapolation="constant", out: DeviceArray | None = None):
+    """xh_qdm_adjust_groups: QDM adjust of every (small) group of rows in one launch — rows: the row numbers group after group,
+    offs (G + 1), af_all (G, nq, C).  Returns scen (T, C) (rows in no group keep what ``out`` held), or None when the kernel does
+    not take the shape (a group of more than 64 rows, more than 32 nodes): gather each group and call :func:`qdm_adjust`."""
+    from ._capi import XH_ERR_NOTIMPL, XclimHipError
+
+    q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+    if interp not in ("nearest", "linear"):
+        return None
+    T, C_ = _tc(sim)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    if int(np.diff(offs).max(initial=0)) > 64 or len(q) > 32:
+        return None
+    scen = out if out is not None else dev.empty((T, C_), np.float32)
+    try:
+        dev.call("xh_qdm_adjust_groups", _vp(sim.ptr), T, C_, C_, np_ptr(rows), np_ptr(offs), len(offs) - 1, _vp(af_all.ptr), np_ptr(q), len(q),
+                 {"+": 0, "*": 1, "factor": 2}[kind], {"nearest": 0, "linear": 1}[interp], {"constant": 0, "nan": 1}[extrapolation],
+                 _vp(scen.ptr), C_)
+    except XclimHipError as e:
+        if e.code == XH_ERR_NOTIMPL:
+            return None
+        raise
+    return scen
+
+
 def poly_trend_groups(dev: Device, x: DeviceArray, rows, offs, u: DeviceArray, degree: int = 1):
     """xh_poly_trend_groups: the per-cell trend of every GROUP of rows in one launch.  rows: the row numbers group after group,
     offs (G + 1): where each group's rows start, u (device float64, T): the coordinate of every row.  (p0, p1): (G, C) float64

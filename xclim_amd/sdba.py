@@ -618,6 +618,15 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
         counts = np.bincount(gi, minlength=len(self.group_labels))
         T, C_ = s.shape
         nq = len(self.quantiles)
+        if not (interp == "linear" and self.group.prop == "month"):
+            # small groups (a day-of-year grouping: one step per year, up to 64): every group ranked in registers, ONE launch over
+            # the series where it lies (xh_qdm_adjust_groups, round 6: 80 -> ~8 ms for 365 groups of a 30-year 1440 x 90 band;
+            # the loop below gathers and launches per group) — bit-identical
+            offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            scen = K.qdm_adjust_groups(dev, s, perm, offs, self._af, self.quantiles, self.kind, interp, extrapolation)
+            if scen is not None:
+                dev.sync()
+                return scen if keep else scen.get().reshape((T,) + self.cell_shape)
         s_perm = K.select_rows(dev, s, perm)
         scen_perm = dev.empty((T, C_), np.float32)
         # "linear" over the (quantile, group) plane (xsdba: interp_on_quantiles(sim_q, quantiles, af) with the quantile
