@@ -265,7 +265,9 @@ int launch_qdm(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols, int64_
 // ---- small groups: QuantileDeltaMapping.adjust with a day-of-year grouping ranks every step among the steps of its OWN group —
 // one per year, 30 rows for a 30-year series — and 365 groups meant 365 gathers + 365 launches of the column kernels on 30-row
 // blocks (launch-bound: 80 ms for a 30-year 1440 x 90 band).  Here ONE launch: thread = one cell of one group (rows <= PER,
-// listed by row number — nothing is gathered).  The group's keys sit in registers; every row is then taken in turn: its key
+// listed by row number — nothing is gathered).  PER stops at 64: the kernel is VALU-bound (4 instructions per key pair + ~150 of
+// fp64 per row: 11 ms for 30 rows per group) and quadratic in the group size — instances with 128 / 192 / 256 keys in registers
+// were built and measured (round 6): 120 ms for 100 rows per group, 227 ms for 151, against 143 ms for the per-group path.  The group's keys sit in registers; every row is then taken in turn: its key
 // against the PER register keys (below / equal counts -> the doubled average rank), pct and the node lookup in the arithmetic of
 // stage E above (bit-identical), the result stored at the row's own place.  The nodes of the cell (the non-NaN factors,
 // compacted) live in the thread's LDS column: values + their indices into the common quantile nodes.
