@@ -787,10 +787,13 @@ def bench_doy_window(dev, K, Cb):
     ms_dtr, dqm = timed(lambda: sdba.DetrendedQuantileMapping.train(ref, hist, nquantiles=20, kind="+", group="time.dayofyear", window=31,
                                                                     time=ta, device=dev), 1)
     ms_dad, _ = timed(lambda: dqm.adjust(sim, interp="nearest", time=ta, keep=True), 2)
-    del qdm, dqm
+    # ... and the grouping WITHOUT a window (365 groups of one row per year: xh_eqm_train_groups / xh_dqm_train_groups, one launch per field)
+    ms_tr1, m1 = timed(lambda: sdba.EmpiricalQuantileMapping.train(ref, hist, nquantiles=20, kind="+", group="time.dayofyear", time=ta, device=dev), 2)
+    ms_dtr1, m2 = timed(lambda: sdba.DetrendedQuantileMapping.train(ref, hist, nquantiles=20, kind="+", group="time.dayofyear", time=ta, device=dev), 2)
+    del qdm, dqm, m1, m2
     E = float(T) * Cb
     res = {"train_ms": ms_tr, "adjust_nearest_ms": ms_near, "adjust_linear_ms": ms_lin, "qdm_adjust_nearest_ms": ms_qdm,
-           "dqm_train_ms": ms_dtr, "dqm_adjust_nearest_ms": ms_dad, "grid": [T, 1440, 90], "groups": 365, "window": 31,
+           "dqm_train_ms": ms_dtr, "dqm_adjust_nearest_ms": ms_dad, "train_nowindow_ms": ms_tr1, "dqm_train_nowindow_ms": ms_dtr1, "grid": [T, 1440, 90], "groups": 365, "window": 31,
            "nodes": 20, "train_samples_GB": 2 * 365 * 930 * 4.0 * Cb / 1e9,
            "train_GB/s": 2 * 365 * 930 * 4.0 * Cb / ms_tr / 1e6, "adjust_linear_GB/s": 8 * E / ms_lin / 1e6,
            "adjust_linear_frac": 8 * E / ms_lin / 1e6 / HBM_PEAK_GBS,

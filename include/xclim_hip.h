@@ -485,6 +485,17 @@ int xh_dqm_train_window(xh_ctx* ctx, const float* ref, const float* hist, int64_
                         const int32_t* rows0 /* host */, int n0, const int32_t* enter /* host */,
                         const int32_t* leave /* host */, int G, int per, const double* q /* host */, int nq, int kind,
                         float* af, float* hist_q, double* scaling, double* mu_hist);
+/* eqm_train / dqm_train for ALL groups of a sub-grouping with small groups (a day-of-year grouping WITHOUT a window: one row per
+ * year) in one launch per field.  rows (host, offs[G] entries): the row numbers of group 0, then of group 1, ... (the order a
+ * group's mean is summed in); offs (host, G + 1).  af, hist_q (G, nq, C) float32; scaling, mu_hist (G, C) float64 as
+ * xh_dqm_train_window.  Bit-identical to xh_eqm_train (resp. xh_poly_trend degree 0 + xh_trend_apply + xh_eqm_train) on each
+ * group's gathered rows.  XH_ERR_NOTIMPL (no error text): a group of more than 64 rows. */
+int xh_eqm_train_groups(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st,
+                        const int32_t* rows /* host */, const int64_t* offs /* host */, int G, const double* q /* host */, int nq,
+                        int kind, float* af, float* hist_q);
+int xh_dqm_train_groups(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st,
+                        const int32_t* rows /* host */, const int64_t* offs /* host */, int G, const double* q /* host */, int nq,
+                        int kind, float* af, float* hist_q, double* scaling, double* mu_hist);
 /* qm_adjust: af_t = interp_on_quantiles(sim, hist_q, af) (interp 0 nearest, 1 linear, 2 cubic [not-a-knot spline as
  * scipy interp1d(kind="cubic"), nq <= 32, >= 4 valid nodes per cell else NaN]; extrap 0 constant,
  * 1 nan); scen = sim + af_t (kind 0) or sim * af_t (kind 1); kind 2: scen = af_t, the interpolated factor itself

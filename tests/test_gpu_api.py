@@ -2069,7 +2069,7 @@ def test_dqm_doy_window_sliding_matches_per_group(dev, rng, monkeypatch, years, 
     dev.stop_trace()
     names = [n for n, _ in trace]
     G = 365 if cal == "noleap" else 366
-    rest = 0 if cal == "noleap" else 1
+    rest = 1 if (cal == "standard" and window > 1) else 0   # (day 366 with a window: 682 rows would leave at once)
     assert names.count("xh_dqm_train_window") == 1 and names.count("xh_eqm_train") == rest
     monkeypatch.setenv("XH_WINSEL", "0")
     trace = dev.start_trace()
@@ -2188,4 +2188,50 @@ def test_qdm_small_groups_match_per_group_calls(dev, rng, monkeypatch, years, ki
     np.testing.assert_array_equal(a, b)
     assert np.isnan(a[:, 3]).all() and np.isnan(a[:, 5]).all() and np.isnan(a[:, 7]).all()
     assert np.isfinite(a[:, 0]).mean() > (0.9 if extrap == "constant" else 0.7)   # ("nan": the ranks beyond the end nodes)
+
+
+@pytest.mark.parametrize("years,nq,kind,cal", [(5, 9, "+", "noleap"), (30, 20, "*", "standard"), (33, 15, "+", "noleap"), (64, 7, "*", "noleap")])
+def test_doy_training_without_window_in_one_launch(dev, rng, monkeypatch, years, nq, kind, cal):
+    """xh_eqm_train_groups / xh_dqm_train_groups (round 6): group="time.dayofyear" WITHOUT a window — 365 groups of one row per
+    year — trained in one launch per field (thread = one cell of one group: the rows as keys in registers, a bitonic network,
+    quantiles by position; DQM: the group's mean in the rows' order and the samples normalised before the sort) against the
+    per-group loop (XH_TRAIN_GROUPS=0), BIT FOR BIT — tables AND scaling: NaN samples, ties, infinities, a negative mean, an all-zero
+    cell (0 / 0), a cell without samples, both register sizes, day 366 of a standard calendar (a smaller group)."""
+    from xclim_amd import sdba as xsdba
+
+    T = 365 * years + (years // 4 + 30 if cal == "standard" else 0)
+    cells = 41
+    ta = TimeAxis.daily("2000-01-01", T, cal)
+    t = np.arange(T)[:, None]
+    ref = (28 + 10 * np.sin(2 * np.pi * t / 365) + rng.normal(0, 3, (T, cells))).astype(np.float32)
+    hist = (ref[::-1] * 1.01 + rng.normal(0, 1, (T, cells))).astype(np.float32)
+    ref[rng.random(ref.shape) < 0.05] = np.nan
+    hist[rng.random(hist.shape) < 0.02] = np.nan
+    ref[:, 1] = np.round(ref[:, 1])
+    hist[:, 3] = np.nan
+    ref[40:50, 5] = np.inf
+    hist[100:103, 6] = -np.inf
+    ref[:, 7] = -ref[:, 7]
+    hist[:, 8] = 0.0
+    monkeypatch.setenv("XH_DIAGNOSTICS", "1")
+    for Model, entry in ((xsdba.EmpiricalQuantileMapping, "xh_eqm_train_groups"), (xsdba.DetrendedQuantileMapping, "xh_dqm_train_groups")):
+        monkeypatch.setenv("XH_TRAIN_GROUPS", "1")
+        trace = dev.start_trace()
+        a = Model.train(ref, hist, nquantiles=nq, kind=kind, group="time.dayofyear", time=ta, device=dev)
+        dev.stop_trace()
+        names = [n for n, _ in trace]
+        assert names.count(entry) == 1 and "xh_eqm_train" not in names
+        monkeypatch.setenv("XH_TRAIN_GROUPS", "0")
+        trace = dev.start_trace()
+        b = Model.train(ref, hist, nquantiles=nq, kind=kind, group="time.dayofyear", time=ta, device=dev)
+        dev.stop_trace()
+        G = 365 if cal == "noleap" else 366
+        assert [n for n, _ in trace].count("xh_eqm_train") == G and a.hist_q.shape == (G, nq, cells)
+        np.testing.assert_array_equal(a.hist_q, b.hist_q)
+        np.testing.assert_array_equal(a.af, b.af)
+        if Model is xsdba.DetrendedQuantileMapping:
+            np.testing.assert_array_equal(a.scaling, b.scaling)
+            if kind == "*":
+                assert np.isnan(a.hist_q[:, :, 8]).all()
+        assert np.isnan(a.hist_q[:, :, 3]).all() and np.isfinite(a.hist_q[:, :, 0]).all()
 

@@ -5,7 +5,7 @@ with g++ against a stand-in for the HIP runtime and run on the CPU:
   * every workgroup as a set of FIBERS (simt.h: __syncthreads, wave-uniform shuffles / votes / readlane, atomics) — f64, select,
     select2, select3, select4, select5, tcount, qdm, qdm2, quantile, doystats, reduce2, pdoy_top, pdoy_quad, pdoy_walk, winsel and the
     kernels of core.hip (transposes, synthetic fields).
-68 of the 98 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
+70 of the 100 entry points of include/xclim_hip.h exist in that build: every compute entry point but xh_adapt_freq (rocPRIM); the
 other 30 are runtime services (memory, streams, RCCL).  The register percentile kernels (pdoy_top / pdoy_quad / pdoy_walk) run on
 fibers too, with the four ISA statements of topnet.h rewritten to the C++ they stand for, and so do the register sorting networks
 (select3 / qdm2: the DPP split across the lane pair as a shuffle), select2's wave counts on VCC and the streaming two-pass selection
@@ -241,7 +241,7 @@ def test_quantile_mapping_api_on_the_simulation(sim):
     20 000+ steps)."""
     _child_run(sim, ["tests/test_gpu_api.py"], at_least=60,
                skip="not (qdm or eqm or dqm or sdba) or bootstrap or adapt or sub_groupings or beyond or dayofyear or 32768 or 20000 "
-                    "or sliding or small_groups")   # (winsel.hip, k_qdm_groups: their own tests below, small shapes)
+                    "or sliding or small_groups or without_window")   # (winsel.hip, k_qdm_groups: their own tests below, small shapes)
 
 
 def test_sliding_window_training_on_the_simulation(sim, rng):
@@ -362,4 +362,46 @@ def test_qdm_small_groups_on_the_simulation(sim, rng, interp):
                 np.testing.assert_array_equal(got[rows], exp, err_msg=f"{kind} group {g}")
     # a group of more than 64 rows is not this kernel's: the caller gathers it
     assert K.qdm_adjust_groups(sim, d_x, np.r_[np.arange(T), np.arange(10)], np.array([0, T + 10]), d_af, q) is None
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_small_group_training_on_the_simulation(sim, rng, kind):
+    """k_group_quantiles (winsel.hip, round 6: the training of all groups of a day-of-year grouping without a window in one launch)
+    against xh_eqm_train — and, normalised, xh_poly_trend + xh_trend_apply + xh_eqm_train — on every group's gathered rows, bit
+    for bit (tables, means, scaling): 10 groups of 0 to 9 rows, NaN samples, ties, an infinity, a negative-mean cell, zeros."""
+    T, C, G, nq = 50, 7, 10, 5
+    x = np.round(rng.normal(6, 3, (T, C)), 1).astype(np.float32)
+    y = (x[::-1] * 1.1 + rng.normal(0, 1, (T, C))).astype(np.float32)
+    x[rng.random(x.shape) < 0.1] = np.nan
+    y[:, 2] = np.nan
+    x[3, 1] = np.inf
+    x[:, 4] = -x[:, 4]
+    y[:, 5] = 0.0
+    gid = rng.integers(0, G, T)
+    gid[gid == 6] = 7
+    perm = np.argsort(gid, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(gid, minlength=G))])
+    q = (np.arange(nq) + 0.5) / nq
+    d_x, d_y = sim.to_device(x), sim.to_device(y)
+    af, hq = (a.get() for a in K.eqm_train_groups(sim, d_x, d_y, perm, offs, q, kind))
+    naf, nhq, sc, muh = (a.get() for a in K.eqm_train_groups(sim, d_x, d_y, perm, offs, q, kind, normalised=True))
+    inv = "-" if kind == "+" else "/"
+    for g in range(G):
+        rows = perm[offs[g]:offs[g + 1]]
+        if not len(rows):
+            assert np.isnan(hq[g]).all() and np.isnan(nhq[g]).all() and np.isnan(muh[g]).all()
+            continue
+        xg, yg = K.select_rows(sim, d_x, rows), K.select_rows(sim, d_y, rows)
+        a_g, h_g = K.eqm_train(sim, xg, yg, q, kind)
+        np.testing.assert_array_equal(hq[g], h_g.get(), err_msg=f"group {g}")
+        np.testing.assert_array_equal(af[g], a_g.get(), err_msg=f"group {g}")
+        mu_x, _ = K.poly_trend(sim, xg, 0)
+        mu_y, _ = K.poly_trend(sim, yg, 0)
+        a_g, h_g = K.eqm_train(sim, K.trend_apply(sim, xg, mu_x, None, inv), K.trend_apply(sim, yg, mu_y, None, inv), q, kind)
+        np.testing.assert_array_equal(muh[g], mu_y.get(), err_msg=f"group {g}")
+        with np.errstate(all="ignore"):
+            np.testing.assert_array_equal(sc[g], mu_x.get() - mu_y.get() if kind == "+" else mu_x.get() / mu_y.get(), err_msg=f"group {g}")
+        np.testing.assert_array_equal(nhq[g], h_g.get(), err_msg=f"group {g}")
+        np.testing.assert_array_equal(naf[g], a_g.get(), err_msg=f"group {g}")
+    assert K.eqm_train_groups(sim, d_x, d_y, np.tile(np.arange(T), 2), np.array([0, 2 * T]), q, kind) is None   # 100 rows in a group
 

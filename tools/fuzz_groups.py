@@ -1,6 +1,8 @@
-"""Differential fuzzing of the grouped entry points of round 6 — xh_qdm_adjust_groups, xh_poly_trend_groups, xh_trend_apply_groups
+"""Differential fuzzing of the grouped entry points of round 6 — xh_qdm_adjust_groups, xh_poly_trend_groups, xh_trend_apply_groups,
+xh_eqm_train_groups, xh_dqm_train_groups
 (all groups of a sub-grouping in ONE launch, a group = a list of rows) — BITWISE against the per-group calls they replace
-(xh_qdm_adjust / xh_poly_trend_u / xh_trend_apply_u on each group's gathered rows): random group counts and sizes (empty groups,
+(xh_qdm_adjust / xh_poly_trend_u / xh_trend_apply_u / xh_eqm_train [+ xh_poly_trend, xh_trend_apply for the detrended training] on
+each group's gathered rows): random group counts and sizes (empty groups,
 rows in no group, up to 64 rows per group for the rank kernel), NaN samples, ties and the two zeros, constant cells, infinities,
 NaN factors (dropped nodes), 1 to 32 nodes, all kinds / interpolations / extrapolations / operations, cell counts around the
 vector width.  usage: python tools/fuzz_groups.py [seconds]"""
@@ -20,7 +22,7 @@ dev = get_fuzz_device()
 SMALL = os.environ.get("FUZZ_DEVICE") == "hostsim"
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "2026")))
-t_end, stats = time.time() + budget, {"qdm": 0, "trend": 0}
+t_end, stats = time.time() + budget, {"qdm": 0, "trend": 0, "train": 0}
 
 
 def same(a, b):
@@ -64,7 +66,40 @@ while time.time() < t_end:
     d_x = dev.to_device(x)
     listed = np.zeros(T, dtype=bool)
     listed[rows] = True
-    if it % 2:
+    if it % 3 == 2:
+        y = (x[::-1] * rng.choice([1.0, -1.0, 1.1]) + rng.normal(0, 1, x.shape)).astype(np.float32)
+        if rng.random() < 0.2:
+            y[:, int(rng.integers(0, C))] = 0.0
+        d_y = dev.to_device(y)
+        nq = int(rng.integers(1, 40))
+        q = np.sort(rng.random(nq)) if rng.random() < 0.3 else (np.arange(nq) + 0.5) / nq
+        kind = str(rng.choice(["+", "*"]))
+        res = K.eqm_train_groups(dev, d_x, d_y, rows, offs, q, kind)
+        resn = K.eqm_train_groups(dev, d_x, d_y, rows, offs, q, kind, normalised=True)
+        if res is None or resn is None:
+            fail("train: refused", G=G, most=most)
+        af, hq = (a.get() for a in res)
+        naf, nhq, sc, muh = (a.get() for a in resn)
+        inv = "-" if kind == "+" else "/"
+        for g in range(G):
+            r = rows[offs[g]:offs[g + 1]]
+            if not len(r):
+                if not (np.isnan(hq[g]).all() and np.isnan(nhq[g]).all() and np.isnan(muh[g]).all()):
+                    fail("train: an empty group is not NaN", g=g)
+                continue
+            xg, yg = K.select_rows(dev, d_x, r), K.select_rows(dev, d_y, r)
+            a_g, h_g = K.eqm_train(dev, xg, yg, q, kind)
+            if not (same(hq[g], h_g.get()) and same(af[g], a_g.get())):
+                fail("eqm_train_groups", it=it, G=G, g=g, n=len(r), C=C, nq=nq, kind=kind, mode=mode)
+            mu_x, _ = K.poly_trend(dev, xg, 0)
+            mu_y, _ = K.poly_trend(dev, yg, 0)
+            a_g, h_g = K.eqm_train(dev, K.trend_apply(dev, xg, mu_x, None, inv), K.trend_apply(dev, yg, mu_y, None, inv), q, kind)
+            with np.errstate(all="ignore"):
+                esc = mu_x.get() - mu_y.get() if kind == "+" else mu_x.get() / mu_y.get()
+            if not (same(muh[g], mu_y.get()) and same(sc[g], esc) and same(nhq[g], h_g.get()) and same(naf[g], a_g.get())):
+                fail("dqm_train_groups", it=it, G=G, g=g, n=len(r), C=C, nq=nq, kind=kind, mode=mode)
+        stats["train"] += 1
+    elif it % 3 == 1:
         nq = int(rng.integers(1, 33))
         q = np.sort(rng.random(nq)) if rng.random() < 0.3 else (np.arange(nq) + 0.5) / nq
         if len(np.unique(q)) < nq:

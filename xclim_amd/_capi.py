@@ -152,6 +152,8 @@ SIGNATURES: dict[str, list] = {
     "xh_eqm_train": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _vp, _vp],
     "xh_eqm_train_window": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _vp, _int, _int, _vp, _vp],
     "xh_dqm_train_window": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, _vp, _int, _int, _vp, _vp, _vp, _vp],
+    "xh_eqm_train_groups": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _int, _int, _vp, _vp],
+    "xh_dqm_train_groups": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _int, _int, _vp, _vp, _vp, _vp],
     "xh_eqm_adjust": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64],
     "xh_eqm_adjust_g2d": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _int, _vp, _i64],
     "xh_apply_factor": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64],

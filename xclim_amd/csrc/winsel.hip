@@ -431,6 +431,105 @@ k_window_quantiles(const float* __restrict__ x, int64_t T, int64_t C, int64_t st
   }
 }
 
+// ---- small groups: the training with a day-of-year grouping WITHOUT a window — 365 groups of one row per year.  Nothing slides
+// (every step replaces the whole sample) and the per-group path is launch-bound (365 gathers + selections on 30-row blocks:
+// 121 ms for the EQM tables of a 30-year 1440 x 90 band, 470 ms for DQM with its means and normalisations).  ONE launch:
+// thread = one cell of one group, the group's rows (<= PER, listed by row number) as keys in registers, a bitonic network over
+// the register array, the sorted keys to the thread's LDS column, the quantiles by position (type 7, the lerp of every
+// selection kernel: ws_positions).  NORM (dqm_train): the mean over the valid samples in the list's order (bit-identical to
+// xh_poly_trend degree 0 on the gathered rows), every sample normalised BEFORE the sort exactly as xh_trend_apply does (a
+// sample that turns NaN drops out like any NaN).
+template <int PER, int NT, bool NORM>
+__global__ void __launch_bounds__(NT)
+k_group_quantiles(const float* __restrict__ x, int64_t C, int64_t st, const int32_t* __restrict__ rows, const int64_t* __restrict__ offs,
+                  const double* __restrict__ qs, int nq, float* __restrict__ out, int nmode, double* __restrict__ mu_out) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t gq_keys[];   // [PER][NT]
+  const int tid = threadIdx.x;
+  const int64_t c = (int64_t)blockIdx.x * NT + tid;
+  if (c >= C) return;
+  const int64_t g = blockIdx.y;
+  const int64_t k0 = offs[g];
+  const int m = (int)(offs[g + 1] - k0);
+  float f[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int32_t row = j < m ? rows[k0 + j] : 0;
+    const float t = x[(int64_t)row * st + c];
+    f[j] = j < m ? t : xh_nan32();
+  }
+  if (NORM) {
+    double sx = 0.0, cnt = 0.0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const bool ok = f[j] == f[j];
+      cnt += ok ? 1.0 : 0.0;
+      sx += ok ? (double)f[j] : 0.0;
+    }
+    const double mu = cnt > 0.0 ? sx / cnt : xh_nan64();
+    mu_out[g * C + c] = mu;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const double v = (double)f[j];
+      f[j] = (float)(nmode == 1 ? v - mu : v / mu);
+    }
+  }
+  uint32_t v[PER];
+  uint32_t n = 0u;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const bool ok = f[j] == f[j];
+    v[j] = ok ? ws_key(f[j] + (-0.0f)) : WS_INF;
+    n += ok ? 1u : 0u;
+  }
+#pragma unroll
+  for (int k = 2; k <= PER; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const uint32_t a = v[i], b = v[l];
+          const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+          const bool up = (i & k) == 0;
+          v[i] = up ? lo : hi;
+          v[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) gq_keys[j * NT + tid] = v[j];
+  // (the column is the thread's own: no barrier)
+  for (int j = 0; j < nq; ++j) {
+    double r;
+    if (n == 0u) r = xh_nan64();
+    else {
+      const double q = qs[j], nn = (double)n;
+      uint32_t plo = 0u, phi = 0u;
+      bool edge = true;
+      double gamma = 0.0;
+      if (n >= 2u) {
+        const double vi = nn * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;
+        if (vi >= nn - 1.0) plo = phi = n - 1u;
+        else if (vi < 0.0) plo = phi = 0u;
+        else { plo = (uint32_t)floor(vi); phi = plo + 1u; }
+        edge = vi >= nn - 1.0 || vi < 0.0;
+        gamma = vi - floor(vi);
+      }
+      const float left = ws_unkey(gq_keys[plo * NT + tid]), right = ws_unkey(gq_keys[phi * NT + tid]);
+      if (n < 2u || edge) r = (double)left;
+      else {
+        const float diff = right - left;
+        r = (double)left + (double)diff * gamma;
+        if (gamma >= 0.5) r = (double)right - (double)diff * (1.0 - gamma);
+      }
+      if (r != r) r = (double)ws_unkey(gq_keys[(n - 1u) * NT + tid]);  // inf - inf: the largest valid sample (utl:552-554)
+    }
+    out[(g * nq + j) * C + c] = (float)r;
+  }
+}
+
 __global__ void __launch_bounds__(XH_BLOCK)
 k_correction(const float* __restrict__ hq, int64_t n, int kind, float* __restrict__ af) {  // af holds ref_q on entry
   const int64_t i = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
@@ -508,6 +607,52 @@ int ws_train(xh_ctx* ctx, const char* who, const float* ref, const float* hist, 
   return XH_OK;
 }
 
+// both small-group entry points (see k_group_quantiles)
+int gq_train(xh_ctx* ctx, const char* who, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, const int32_t* rows,
+             const int64_t* offs, int G, const double* q, int nq, int kind, float* af, float* hist_q, double* scaling, double* mu_hist) {
+  XH_REQUIRE(ctx && ref && hist && rows && offs && q && af && hist_q, XH_ERR_ARG, "%s: NULL argument", who);
+  XH_REQUIRE(T >= 1 && C >= 0 && G >= 1 && nq >= 1 && st >= C, XH_ERR_ARG, "%s: bad shape", who);
+  XH_REQUIRE(kind == 0 || kind == 1, XH_ERR_ARG, "%s: kind must be 0 (+) or 1 (*)", who);
+  XH_REQUIRE(offs[0] == 0, XH_ERR_ARG, "%s: offs[0] must be 0", who);
+  int64_t most = 0;
+  for (int g = 0; g < G; ++g) {
+    XH_REQUIRE(offs[g + 1] >= offs[g], XH_ERR_ARG, "%s: offs must not decrease", who);
+    most = offs[g + 1] - offs[g] > most ? offs[g + 1] - offs[g] : most;
+  }
+  const int64_t nr = offs[G];
+  for (int64_t k = 0; k < nr; ++k) XH_REQUIRE(rows[k] >= 0 && rows[k] < T, XH_ERR_ARG, "%s: row %lld out of range", who, (long long)k);
+  if (most > 64 || nq > 1024) return XH_ERR_NOTIMPL;
+  if (const char* e = xh_diag_env("XH_TRAIN_GROUPS"))
+    if (!atoi(e)) return XH_ERR_NOTIMPL;
+  if (C == 0) return XH_OK;
+  size_t cur = 0;
+  void *d_q = nullptr, *d_rows = nullptr, *d_offs = nullptr;
+  int rc = xh_scratch_upload(ctx, &cur, q, sizeof(double) * (size_t)nq, &d_q);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, offs, sizeof(int64_t) * (size_t)(G + 1), &d_offs);
+  if (!rc) rc = xh_scratch_upload(ctx, &cur, rows, sizeof(int32_t) * (size_t)(nr > 0 ? nr : 1), &d_rows);
+  if (rc) return rc;
+  const int nmode = kind == 0 ? 1 : 3;   // xh_trend_apply's "-" and "/"
+#define XH_GQ(PER, NT, NORM, X, OUT, MU)                                                                                              \
+  hipLaunchKernelGGL((k_group_quantiles<PER, NT, NORM>), dim3((unsigned)cdiv64(C, NT), (unsigned)G), dim3(NT), (size_t)PER * NT * 4, ctx->stream, X, C, \
+                     st, (const int32_t*)d_rows, (const int64_t*)d_offs, (const double*)d_q, nq, OUT, nmode, MU)
+  // ref_q goes to `af` first, then af = correction(ref_q, hist_q) in place (as xh_eqm_train)
+  if (!scaling) {
+    if (most <= 32) { XH_GQ(32, 256, false, ref, af, (double*)nullptr); XH_GQ(32, 256, false, hist, hist_q, (double*)nullptr); }
+    else { XH_GQ(64, 128, false, ref, af, (double*)nullptr); XH_GQ(64, 128, false, hist, hist_q, (double*)nullptr); }
+  } else {
+    if (most <= 32) { XH_GQ(32, 256, true, ref, af, scaling); XH_GQ(32, 256, true, hist, hist_q, mu_hist); }
+    else { XH_GQ(64, 128, true, ref, af, scaling); XH_GQ(64, 128, true, hist, hist_q, mu_hist); }
+    const int64_t ng = (int64_t)G * C;
+    hipLaunchKernelGGL(k_scaling, dim3((unsigned)cdiv64(ng, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, (const double*)mu_hist, ng, kind, scaling);
+  }
+#undef XH_GQ
+  XH_LAUNCH_CHECK();
+  const int64_t tot = (int64_t)G * nq * C;
+  hipLaunchKernelGGL(k_correction, dim3((unsigned)cdiv64(tot, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, hist_q, tot, kind, af);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -533,6 +678,23 @@ int xh_dqm_train_window(xh_ctx* ctx, const float* ref, const float* hist, int64_
   XH_REQUIRE(scaling && mu_hist, XH_ERR_ARG, "xh_dqm_train_window: NULL argument");
   return ws_train(ctx, "xh_dqm_train_window", ref, hist, T, C, st, rows0, n0, enter, leave, G, per, q, nq, kind, af, hist_q, scaling,
                   mu_hist);
+}
+
+// EQM / DQM training for ALL groups of a sub-grouping with small groups in one launch per field (a day-of-year grouping without a
+// window: one row per year).  rows (host, offs[G] entries): the row numbers of group 0, then of group 1, ... (a group's rows in
+// the order its mean is summed); offs (host, G + 1).  af, hist_q: (G, nq, C).  Bit-identical to xh_eqm_train on each group's
+// gathered rows; xh_dqm_train_groups: to xh_poly_trend (degree 0) + xh_trend_apply + xh_eqm_train per group, scaling / mu_hist
+// (G, C) float64 as xh_dqm_train_window.  XH_ERR_NOTIMPL (no error text): a group of more than 64 rows.
+int xh_eqm_train_groups(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, const int32_t* rows,
+                        const int64_t* offs, int G, const double* q, int nq, int kind, float* af, float* hist_q) {
+  return gq_train(ctx, "xh_eqm_train_groups", ref, hist, T, C, st, rows, offs, G, q, nq, kind, af, hist_q, nullptr, nullptr);
+}
+
+int xh_dqm_train_groups(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, const int32_t* rows,
+                        const int64_t* offs, int G, const double* q, int nq, int kind, float* af, float* hist_q, double* scaling,
+                        double* mu_hist) {
+  XH_REQUIRE(scaling && mu_hist, XH_ERR_ARG, "xh_dqm_train_groups: NULL argument");
+  return gq_train(ctx, "xh_dqm_train_groups", ref, hist, T, C, st, rows, offs, G, q, nq, kind, af, hist_q, scaling, mu_hist);
 }
 
 }  // extern "C"

@@ -611,6 +611,36 @@ def eqm_train_window(dev: Device, ref: DeviceArray, hist: DeviceArray, rows0, en
     return res
 
 
+def eqm_train_groups(dev: Device, ref: DeviceArray, hist: DeviceArray, rows, offs, q, kind="+", normalised=False):
+    """xh_eqm_train_groups / xh_dqm_train_groups: the training of ALL (small) groups in one launch per field — rows: the row
+    numbers group after group, offs (G + 1).  Returns (af, hist_q) (G, nq, C) — with ``normalised`` (dqm_train: the samples
+    normalised by their group's mean) also (scaling, mu_hist) (G, C) float64 — or None when a group has more than 64 rows
+    (gather each group and call :func:`eqm_train`)."""
+    from ._capi import XH_ERR_NOTIMPL, XclimHipError
+
+    q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+    T, C_ = _tc(ref)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    G = len(offs) - 1
+    if int(np.diff(offs).max(initial=0)) > 64:
+        return None
+    af = dev.empty((G, len(q), C_), np.float32)
+    hq = dev.empty((G, len(q), C_), np.float32)
+    res, extra, name = (af, hq), (), "xh_eqm_train_groups"
+    if normalised:
+        sc, muh = dev.empty((G, C_), np.float64), dev.empty((G, C_), np.float64)
+        res, extra, name = (af, hq, sc, muh), (_vp(sc.ptr), _vp(muh.ptr)), "xh_dqm_train_groups"
+    try:
+        dev.call(name, _vp(ref.ptr), _vp(hist.ptr), T, C_, C_, np_ptr(rows), np_ptr(offs), G, np_ptr(q), len(q), {"+": 0, "*": 1}[kind],
+                 _vp(af.ptr), _vp(hq.ptr), *extra)
+    except XclimHipError as e:
+        if e.code == XH_ERR_NOTIMPL:
+            return None
+        raise
+    return res
+
+
 def eqm_adjust(dev: Device, sim: DeviceArray, af: DeviceArray, hist_q: DeviceArray, kind="+", interp="nearest",
                extrapolation="constant", out: DeviceArray | None = None) -> DeviceArray:
     T, C_ = _tc(sim)

@@ -233,6 +233,20 @@ class Grouper:
         pos = np.clip(np.searchsorted(lab, val), 0, len(lab) - 1)
         return np.where(lab[pos] == val, pos, -1)
 
+    def small_groups(self, time, most: int = 64):
+        """``(rows, offs)`` — the time steps of group 0, then of group 1, ... and where each group starts — for a sub-grouping
+        WITHOUT a window whose groups hold at most ``most`` steps (a day-of-year grouping: one per year), else None: the
+        shape of the one-launch training kernels (xh_eqm_train_groups)."""
+        if self.prop == "group" or self.window != 1:
+            return None
+        gi = self.index(time)
+        G = len(self.labels(time))
+        counts = np.bincount(gi[gi >= 0], minlength=G)
+        if counts.max(initial=0) > most:
+            return None
+        order = np.argsort(gi, kind="stable")
+        return order[gi[order] >= 0].astype(np.int64), np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+
     def sample_rows(self, time) -> list:
         """For every group the rows of its training sample: the centred window around each of its time steps, -1 (NaN)
         beyond the ends of the series — rolling(time=window, center=True).construct + groupby in xsdba."""
@@ -446,6 +460,14 @@ class EmpiricalQuantileMapping:
         plane = len(q) * C_ * 4
         # day-of-year groups with a window on gap-free years: every cell keeps its window sorted from one day to the next
         # (xh_eqm_train_window, round 6: 508 -> ~60 ms for 30 years x 1440 x 90) — bit-identical to the per-group selection below
+        small = grp.small_groups(time) if R == 1 else None
+        if small is not None:
+            # no window, small groups (365 days of the year x one row per year): all groups in ONE launch per field, keys in
+            # registers (xh_eqm_train_groups, round 6: 121 -> ~10 ms for 30 years x 1440 x 90) — bit-identical to the loop below
+            res = K.eqm_train_groups(dev, r, h, small[0], small[1], q, kind)
+            if res is not None:
+                dev.sync()
+                return cls(dev, res[0], res[1], q, kind, cell_shape, grp, labels)
         stretches, rest, rows_of = grp.sliding_stretches(time) if R == 1 else ([], None, None)
         if stretches:
             def slab(a, g0, n):
@@ -720,6 +742,12 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
         # carries the mean of every group's sample and normalises the samples it picks (xh_dqm_train_window, round 6: 3 970 ->
         # ~190 ms for 30 years x 1440 x 90; per group otherwise: a gather, two means, two normalisations, two selections and a
         # host round trip of the means)
+        small = grp.small_groups(time)
+        if small is not None:   # (no window, small groups: one launch per field — xh_dqm_train_groups, 470 -> ~10 ms)
+            res = K.eqm_train_groups(dev, r, h, small[0], small[1], q, kind, normalised=True)
+            if res is not None:
+                dev.sync()
+                return cls(dev, res[0], res[1], q, kind, cell_shape, grp, labels, scaling=res[2])
         stretches, rest, rows_of = grp.sliding_stretches(time)
         if stretches:
             scal_d = dev.empty((G, C_), np.float64)
