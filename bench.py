@@ -641,6 +641,7 @@ def bench_full_configs(dev, K, C, long_series=True):
     out["eqm_month_linear"] = bench_plane_month(dev, K, C // 8)
     out["eqm_doy_window31"] = bench_doy_window(dev, K, C // 8)
     out["tx90p_bootstrap_band"] = bench_bootstrap(dev, K, C // 8)
+    out["eqm_930_celsius"] = bench_zero_straddle(dev, K, C // 8)
     out["c5_slab"] = bench_c5_slab(dev, K)
     if not long_series:
         return out
@@ -804,6 +805,26 @@ def bench_doy_window(dev, K, Cb):
                    "twice: entering and leaving)"}
     for a in (ref, hist, sim):
         a.free()
+    return res
+
+
+def bench_zero_straddle(dev, K, Cb):
+    """eqm_train on a 930-row sample (a month group of 30 years; k_select_quantile: histogram selection in LDS) of the same
+    synthetic field in kelvin and in degrees Celsius.  The histogram bins were linear in the order-preserving KEY (log-like in
+    the value): fine for 288 +- 15, but a field that straddles zero spreads over a few binade-wide bins and the exact search
+    inside a bin turned quadratic — 1.36 against 19.7 ms (round 6, tools/experiments/r06/zero_straddle_time.py).  Keys on both
+    sides of zero now take bins linear in the value (common.h xh_value_bins: k_select_quantile, k_select_grp, k_qdm_columns)."""
+    T = 930
+    q = np.array([(i + 0.5) / 20 for i in range(20)])
+    res = {"rows": T, "grid": [T, 1440, 90], "kernel": "k_select_quantile<64, 16, 512> x 2 (select.hip)"}
+    for name, mean in (("kelvin", 288.0), ("celsius", 15.0), ("anomaly", 0.0)):
+        base = seasonal_base(T, mean=mean)
+        ref = K.fill_synthetic(dev, T, Cb, 0, 4, base, 3.0)
+        hist = K.fill_synthetic(dev, T, Cb, 0, 5, base + np.float32(1.5), 3.3)
+        af, hq = dev.empty((20, Cb), np.float32), dev.empty((20, Cb), np.float32)
+        res[name + "_ms"] = event_time(dev, lambda: K.eqm_train(dev, ref, hist, q, "+", out=(af, hq)), 3)
+        for a in (ref, hist, af, hq):
+            a.free()
     return res
 
 

@@ -2235,3 +2235,38 @@ def test_doy_training_without_window_in_one_launch(dev, rng, monkeypatch, years,
                 assert np.isnan(a.hist_q[:, :, 8]).all()
         assert np.isnan(a.hist_q[:, :, 3]).all() and np.isfinite(a.hist_q[:, :, 0]).all()
 
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("group", ["time.month", "time.season"])
+def test_dqm_training_without_window_matches_per_group_chain(dev, rng, kind, group):
+    """DetrendedQuantileMapping.train with a sub-grouping and no window (round 6): the group means are one xh_poly_trend_groups
+    per field, the normalisation one xh_trend_apply_groups per field over the series where it lies, the tables the grouped EQM
+    training of the normalised series — against dqm_train group by group on gathered rows (xh_poly_trend degree 0,
+    xh_trend_apply, xh_eqm_train), BIT FOR BIT: tables and scaling; NaN samples, a cell without samples, a negative mean."""
+    from xclim_amd import kernels as K
+    from xclim_amd import sdba as xsdba
+
+    T, cells, nq = 365 * 3, 9, 8
+    ta = TimeAxis.daily("2001-01-01", T, "noleap")
+    t = np.arange(T)[:, None]
+    ref = (20 + 8 * np.sin(2 * np.pi * t / 365) + rng.normal(0, 3, (T, cells))).astype(np.float32)
+    hist = (ref[::-1] * 1.05 + rng.normal(0, 1, (T, cells))).astype(np.float32)
+    ref[rng.random(ref.shape) < 0.05] = np.nan
+    hist[:, 2] = np.nan
+    ref[:, 3] = -ref[:, 3]
+    m = xsdba.DetrendedQuantileMapping.train(ref, hist, nquantiles=nq, kind=kind, group=group, time=ta, device=dev)
+    grp = xsdba.Grouper(group)
+    gi = grp.index(ta, m.group_labels)
+    d_r, d_h = dev.to_device(ref), dev.to_device(hist)
+    inv = "-" if kind == "+" else "/"
+    for g in range(len(m.group_labels)):
+        rows = np.nonzero(gi == g)[0]
+        rg, hg = K.select_rows(dev, d_r, rows), K.select_rows(dev, d_h, rows)
+        mu_r, _ = K.poly_trend(dev, rg, 0)
+        mu_h, _ = K.poly_trend(dev, hg, 0)
+        a_g, h_g = K.eqm_train(dev, K.trend_apply(dev, rg, mu_r, None, inv), K.trend_apply(dev, hg, mu_h, None, inv), m.quantiles, kind)
+        np.testing.assert_array_equal(m.hist_q[g], h_g.get(), err_msg=f"group {g}")
+        np.testing.assert_array_equal(m.af[g], a_g.get(), err_msg=f"group {g}")
+        with np.errstate(all="ignore"):
+            np.testing.assert_array_equal(m.scaling[g], mu_r.get() - mu_h.get() if kind == "+" else mu_r.get() / mu_h.get())
+

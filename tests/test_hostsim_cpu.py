@@ -241,7 +241,7 @@ def test_quantile_mapping_api_on_the_simulation(sim):
     20 000+ steps)."""
     _child_run(sim, ["tests/test_gpu_api.py"], at_least=60,
                skip="not (qdm or eqm or dqm or sdba) or bootstrap or adapt or sub_groupings or beyond or dayofyear or 32768 or 20000 "
-                    "or sliding or small_groups or without_window")   # (winsel.hip, k_qdm_groups: their own tests below, small shapes)
+                    "or sliding or small_groups or doy_training_without_window")   # (winsel.hip, k_qdm_groups: their own tests below, small shapes)
 
 
 def test_sliding_window_training_on_the_simulation(sim, rng):

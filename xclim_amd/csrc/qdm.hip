@@ -129,8 +129,9 @@ k_qdm_columns(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t col
     const uint32_t range = n > 0 ? kmax - kmin2 : 0u;
     int shift = 32 - __clz((int)range) - (31 - __clz(NB));
     shift = (range == 0u || shift < 0) ? 0 : shift;
+    const XhValueBins vb = xh_value_bins(kmin2, kmax, n > 0, NB);  // (keys on both sides of zero: bins linear in the value)
     auto binof = [&](uint32_t kk) -> uint32_t {  // NB: dummy bin (NaN keys and the copies of the minimum)
-      const uint32_t b = (kk - kmin2) >> shift;
+      const uint32_t b = vb.on ? xh_value_bin(vb, kk) : ((kk - kmin2) >> shift);
       return (kk == 0xFFFFFFFFu || kk == kmin) ? (uint32_t)NB : (b < (uint32_t)NB ? b : (uint32_t)NB - 1u);
     };
     // ---- B: histogram

@@ -175,8 +175,9 @@ k_select_quantile(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t
     const uint32_t range = (n > 0) ? (kmax - kmin2) : 0u;
     int shift = 0;
     while ((range >> shift) >= (uint32_t)NB) shift++;
+    const XhValueBins vb = xh_value_bins(kmin2, kmax, n > 0, NB - 1);  // (keys on both sides of zero: bins linear in the value)
     auto binof = [&](uint32_t kk) -> uint32_t {  // (never called for kmin copies / NaN keys)
-      const uint32_t bb = 1u + ((kk - kmin2) >> shift);
+      const uint32_t bb = 1u + (vb.on ? xh_value_bin(vb, kk) : ((kk - kmin2) >> shift));
       return bb < (uint32_t)NB ? bb : (uint32_t)NB - 1u;
     };
     // ---- histogram
@@ -399,8 +400,9 @@ k_select_grp(const float* __restrict__ x, int64_t T, int64_t ncols, int64_t stri
     // smallest shift with (range >> shift) < NB; the top value bin is merged into bin NB - 1 when that index is reached
     int shift = 32 - __clz((int)range) - (31 - __clz(NB));  // bits(range) - log2(NB)
     shift = (range == 0u || shift < 0) ? 0 : shift;
+    const XhValueBins vb = xh_value_bins(kmin2, kmax, n > 0, NB - 1);  // (keys on both sides of zero: bins linear in the value)
     auto binof = [&](uint32_t kk) -> uint32_t {
-      const uint32_t b = 1u + ((kk - kmin2) >> shift);
+      const uint32_t b = 1u + (vb.on ? xh_value_bin(vb, kk) : ((kk - kmin2) >> shift));
       return kk == kmin ? 0u : (b < (uint32_t)NB ? b : (uint32_t)NB - 1u);
     };
 #pragma unroll

@@ -748,6 +748,24 @@ class DetrendedQuantileMapping(EmpiricalQuantileMapping):
             if res is not None:
                 dev.sync()
                 return cls(dev, res[0], res[1], q, kind, cell_shape, grp, labels, scaling=res[2])
+        if grp.window == 1:
+            # no window: every step is in exactly one group, so the group means are ONE xh_poly_trend_groups per field over the
+            # series where it lies (summed in time order: what xh_poly_trend gives on the gathered block), the normalisation is
+            # ONE xh_trend_apply_groups per field, and the tables are the grouped EQM training of the normalised series —
+            # bit-identical to the per-group loop below (month groups of a 30-year 1440 x 90 band: 128 -> ~40 ms)
+            gi = grp.index(time, labels)
+            order = np.argsort(gi, kind="stable")
+            offs = np.concatenate([[0], np.cumsum(np.bincount(gi, minlength=G))]).astype(np.int64)
+            zero_u = dev.zeros((r.shape[0],), np.float64)
+            mu_r, _ = K.poly_trend_groups(dev, r, order, offs, zero_u, 0)
+            mu_h, _ = K.poly_trend_groups(dev, h, order, offs, zero_u, 0)
+            rn = K.trend_apply_groups(dev, r, order, offs, mu_r, None, inv)
+            hn = K.trend_apply_groups(dev, h, order, offs, mu_h, None, inv)
+            eq = EmpiricalQuantileMapping.train(rn, hn, nquantiles=q, kind=kind, group=grp, time=time, device=dev)
+            mr, mh = mu_r.get(), mu_h.get()
+            with np.errstate(all="ignore"):
+                scal = mr - mh if kind == ADDITIVE else mr / mh
+            return cls(dev, eq._af, eq._hist_q, q, kind, cell_shape, grp, labels, scaling=dev.to_device(np.ascontiguousarray(scal), dtype=np.float64))
         stretches, rest, rows_of = grp.sliding_stretches(time)
         if stretches:
             scal_d = dev.empty((G, C_), np.float64)
