@@ -2191,7 +2191,7 @@ def test_qdm_small_groups_match_per_group_calls(dev, rng, monkeypatch, years, ki
 
 
 @pytest.mark.parametrize("years,nq,kind,cal", [(5, 9, "+", "noleap"), (30, 20, "*", "standard"), (33, 15, "+", "noleap"), (64, 7, "*", "noleap")])
-def test_doy_training_without_window_in_one_launch(dev, rng, monkeypatch, years, nq, kind, cal):
+def test_eqm_dqm_doy_training_without_window_in_one_launch(dev, rng, monkeypatch, years, nq, kind, cal):
     """xh_eqm_train_groups / xh_dqm_train_groups (round 6): group="time.dayofyear" WITHOUT a window — 365 groups of one row per
     year — trained in one launch per field (thread = one cell of one group: the rows as keys in registers, a bitonic network,
     quantiles by position; DQM: the group's mean in the rows' order and the samples normalised before the sort) against the
