@@ -2270,3 +2270,38 @@ def test_dqm_training_without_window_matches_per_group_chain(dev, rng, kind, gro
         with np.errstate(all="ignore"):
             np.testing.assert_array_equal(m.scaling[g], mu_r.get() - mu_h.get() if kind == "+" else mu_r.get() / mu_h.get())
 
+
+@pytest.mark.parametrize("T", [365, 930, 3000])
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_eqm_train_nan_nodes_masks_and_zero_over_zero(dev, rng, kind, T):
+    """The NaN rule of the training tables (utl:552-554: a NaN node of a series with valid samples is its largest valid sample) as
+    two passes since round 6 — pass 1 corrects the columns without a NaN node and lists the 64-column groups that hold one, pass 2
+    scans the series of those columns — on a field with a land / sea mask (all-NaN columns keep their NaN), columns with
+    infinities (inf - inf in the lerp: the node becomes the largest valid sample) and, in the SAME group, a column whose
+    correction is itself NaN (0 / 0: not a node to repair, and not to be corrected twice), against the oracle."""
+    C, nq = 200, 20
+    ref = (10 + rng.normal(0, 3, (T, C))).astype(np.float32)
+    hist = (11 + rng.normal(0, 3, (T, C))).astype(np.float32)
+    mask = rng.random(C) < 0.3
+    mask[[3, 5, 70, 71]] = False
+    ref[:, mask] = np.nan
+    hist[:, mask] = np.nan
+    hist[rng.integers(0, T, 40), 3] = np.inf          # several infinite samples: neighbouring order statistics are both inf
+    ref[rng.integers(0, T, 40), 70] = -np.inf
+    ref[:, 5] = 0.0                                   # 0 / 0 and 0 - 0 next to column 3
+    hist[:, 5] = 0.0
+    hist[:, 71] = np.nan                              # hist without samples, ref with
+    af, hq = (a.get() for a in K_eqm_train(dev, ref, hist, nq, kind))
+    eaf, ehq = osdba.eqm_train(ref, hist, nq, kind)
+    np.testing.assert_allclose(hq, ehq, rtol=1e-6, equal_nan=True)
+    with np.errstate(all="ignore"):
+        np.testing.assert_allclose(af, eaf, rtol=1e-5, atol=1e-5 if kind == "+" else 0, equal_nan=True)
+    assert np.isnan(af[:, mask]).all() and np.isnan(hq[:, 71]).all() and not np.isnan(hq[:, 3]).any()
+
+
+def K_eqm_train(dev, ref, hist, nq, kind):
+    from xclim_amd import kernels as K
+
+    q = osdba.equally_spaced_nodes(nq) if hasattr(osdba, "equally_spaced_nodes") else (np.arange(nq) + 0.5) / nq
+    return K.eqm_train(dev, dev.to_device(ref), dev.to_device(hist), q, kind)
+

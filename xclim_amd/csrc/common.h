@@ -73,6 +73,9 @@ const char* xh_diag_env(const char* name);
   } while (0)
 
 // Upload a small host table into the context scratch (bump allocated per call via `*cursor`).
+int xh_nanmax_fix(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int nq, float* out);  // select.hip
+int xh_correction_fix(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, int64_t sc, int nq, int kind,
+                      float* af, float* hist_q);  // select.hip
 int xh_scratch_upload(xh_ctx* ctx, size_t* cursor, const void* host, size_t bytes, void** dptr);
 int xh_big_scratch(xh_ctx* ctx, size_t bytes, void** dptr);
 // >= elems floats each of NaN, -inf, +inf (persistent; any of the three pointers may be NULL)

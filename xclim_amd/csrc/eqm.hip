@@ -11,45 +11,10 @@
 // Per-column quantiles: exact multi-select kernels in select.hip (xh_select_columns).
 
 // af from ref_q / hist_q  (get_correction), one thread per COLUMN, with the nanmax rule of utl:552-554 folded in (see
-// k_nanmax_fix below): a NaN node of a series that has valid samples is that series' largest valid sample.  The thread
+// k_nanmax_fix in select.hip): a NaN node of a series that has valid samples is that series' largest valid sample.  The thread
 // reads the column's 2 * nq nodes — the bytes an elementwise correction reads anyway — so that EQM training pays no separate
 // pass for the rule; the series themselves are scanned only for columns that hold such a node (infinities in the data).
-__global__ void __launch_bounds__(XH_BLOCK)
-k_correction_fix(const float* __restrict__ ref, const float* __restrict__ hist, int64_t T, int64_t C, int64_t st, int64_t sc,
-                 int nq, int kind, float* __restrict__ af, float* __restrict__ hist_q) {
-  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
-  if (c >= C) return;
-  bool badr = false, badh = false;
-  for (int j = 0; j < nq; ++j) {
-    const float r = af[(int64_t)j * C + c], h = hist_q[(int64_t)j * C + c];
-    badr |= r != r;
-    badh |= h != h;
-  }
-  auto colmax = [&](const float* __restrict__ x, bool& any) {
-    float m = __uint_as_float(0xFF800000u);
-    any = false;
-    for (int64_t t = 0; t < T; ++t) {
-      const float v = x[t * st + c * sc];
-      if (v == v) {
-        any = true;
-        m = v > m ? v : m;
-      }
-    }
-    return m;
-  };
-  float mr = 0.f, mh = 0.f;
-  if (badr) mr = colmax(ref, badr);  // (badr / badh stay set only when the series has a valid sample)
-  if (badh) mh = colmax(hist, badh);
-  for (int j = 0; j < nq; ++j) {
-    float r = af[(int64_t)j * C + c], h = hist_q[(int64_t)j * C + c];
-    if (badr && r != r) r = mr;
-    if (badh && h != h) {
-      h = mh;
-      hist_q[(int64_t)j * C + c] = h;
-    }
-    af[(int64_t)j * C + c] = kind == 0 ? (r - h) : (r / h);
-  }
-}
+// (k_correction_fix: select.hip, next to k_nanmax_fix — its column scans are a workgroup's work since round 6)
 
 // ---- adjust -------------------------------------------------------------------------------------------------
 // One lane per cell, marching along time (time-major).  The nq nodes of the cell stay in registers; the node
@@ -410,37 +375,6 @@ k_eqm_adjust_cubic(const float* __restrict__ sim, int64_t T, int64_t C, int64_t 
   for (; t < tb; ++t) adjust_one(t, sim[t * st + c]);
 }
 
-// utl:552-554 — "when an interpolation is in NaN range ... clip to the array max value": a NaN node of a column that has
-// valid samples becomes the column's largest valid sample.  The selection kernels produce such NaNs only from infinities
-// (inf - inf in the lerp between two order statistics), so this is a pass over the (nq, C) nodes — 1/18 of the series'
-// bytes at nq = 20, T = 365 — plus one scan of each column that actually holds one; columns without valid samples keep
-// their NaN.  out: (nq, C) with unit column stride.
-__global__ void __launch_bounds__(XH_BLOCK)
-k_nanmax_fix(const float* __restrict__ x, int64_t T, int64_t C, int64_t st, int64_t sc, int nq, float* __restrict__ out) {
-  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
-  if (c >= C) return;
-  bool bad = false;
-  for (int j = 0; j < nq; ++j) {
-    const float v = out[(int64_t)j * C + c];
-    bad |= v != v;
-  }
-  if (!bad) return;
-  float m = __uint_as_float(0xFF800000u);
-  bool any = false;
-  for (int64_t t = 0; t < T; ++t) {
-    const float v = x[t * st + c * sc];
-    if (v == v) {
-      any = true;
-      m = v > m ? v : m;
-    }
-  }
-  if (!any) return;
-  for (int j = 0; j < nq; ++j) {
-    const float v = out[(int64_t)j * C + c];
-    if (v != v) out[(int64_t)j * C + c] = m;
-  }
-}
-
 static int quantile_series_core(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
                                 const double* d_q, int nq, float* out);
 
@@ -448,9 +382,7 @@ static int quantile_series_impl(xh_ctx* ctx, const float* x, int64_t T, int64_t 
                                 const double* d_q, int nq, float* out) {
   const int rc = quantile_series_core(ctx, x, T, C, st, sc, d_q, nq, out);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_nanmax_fix, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, x, T, C, st, sc, nq, out);
-  XH_LAUNCH_CHECK();
-  return XH_OK;
+  return xh_nanmax_fix(ctx, x, T, C, st, sc, nq, out);   // (select.hip)
 }
 
 static int quantile_series_core(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc,
@@ -557,10 +489,7 @@ int xh_eqm_train(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, in
   if (rc) return rc;
   rc = quantile_series_core(ctx, hist, T, C, st, sc, (const double*)d_q, nq, hist_q);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_correction_fix, dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, ref, hist, T, C, st, sc,
-                     nq, kind, af, hist_q);
-  XH_LAUNCH_CHECK();
-  return XH_OK;
+  return xh_correction_fix(ctx, ref, hist, T, C, st, sc, nq, kind, af, hist_q);
 }
 
 // Grouped adjustment with xsdba's 2-D "nearest" (see k_eqm_adjust_g2d): sim (n, C) = the steps of ONE group (coordinate

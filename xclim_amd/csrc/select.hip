@@ -635,3 +635,150 @@ int xh_select_columns(xh_ctx* ctx, const float* xcols, int64_t T, int64_t ncols,
   if (T > 32768) return xh_select_columns_radix(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
   return launch_select<1024, 32, 2048>(ctx, xcols, T, ncols, col_stride, d_q, nq, out, out_cstride, out_qstride);
 }
+
+// ---- the NaN nodes of the selection results (called by eqm.hip after every quantile_series)
+// utl:552-554 — "when an interpolation is in NaN range ... clip to the array max value": a NaN node of a column that has
+// valid samples becomes the column's largest valid sample.  The selection kernels produce such NaNs only from infinities
+// (inf - inf in the lerp between two order statistics), so this is a pass over the (nq, C) nodes — 1/18 of the series'
+// bytes at nq = 20, T = 365 — plus one scan of each column that actually holds one; columns without valid samples keep
+// their NaN.  out: (nq, C) with unit column stride.
+// Round 6: two passes (before: one thread per column scanning its T rows one load at a time — a field with a land / sea mask
+// has NaN nodes in 30 % of its columns, every wave held one, and the fix-up took 4.7 ms behind a 0.55 ms selection at
+// T = 10950, 0.1 ms behind 0.03 at T = 365).  Pass 1 keeps the elementwise shape and only LISTS the 64-column groups that
+// hold a NaN node; pass 2 is a fixed grid of 1024-thread workgroups that finds nothing to do in the common case.
+constexpr int NF_WAVES = 16;
+// the largest valid sample of the workgroup's 64 columns that ask for it (want; lane = column), rows split over the 16 waves;
+// returns (to wave 0's lanes) whether the column has a valid sample, its maximum in m
+__device__ __forceinline__ bool nf_colmax(const float* __restrict__ x, int64_t T, int64_t st, int64_t sc, int64_t c, bool want, int lane,
+                                          int w, float (*s_max)[64], int (*s_any)[64], float& m) {
+  const int64_t chunk = cdiv64(T, NF_WAVES);
+  const int64_t ta = (int64_t)w * chunk;
+  int64_t tb = ta + chunk;
+  if (tb > T) tb = T;
+  m = __uint_as_float(0xFF800000u);
+  bool any = false;
+  if (want) {
+    const float* __restrict__ xc = x + c * sc;
+    int64_t t = ta;
+    for (; t + 8 <= tb; t += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = xc[(t + u) * st];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v[u] == v[u]) { any = true; m = v[u] > m ? v[u] : m; }
+    }
+    for (; t < tb; ++t) {
+      const float v = xc[t * st];
+      if (v == v) { any = true; m = v > m ? v : m; }
+    }
+  }
+  __syncthreads();   // (the arrays may still be read from the previous call)
+  s_max[w][lane] = m;
+  s_any[w][lane] = any ? 1 : 0;
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int k = 0; k < NF_WAVES; ++k) {
+      any |= s_any[k][lane] != 0;
+      m = s_max[k][lane] > m ? s_max[k][lane] : m;
+    }
+  }
+  return any;
+}
+
+// Pass 1 (one thread per column, the shape of an elementwise kernel): look at the column's nodes.  CORR (EQM training: af holds
+// ref_q on entry): a column without a NaN node gets its correction here — the bytes an elementwise correction reads anyway, so
+// the rule costs the common case nothing.  A wave (= 64 adjacent columns) that holds a NaN node appends its group to `list`.
+template <bool CORR>
+__global__ void __launch_bounds__(XH_BLOCK)
+k_nanfix_flag(int64_t C, int nq, int kind, float* __restrict__ af, float* __restrict__ hist_q, uint32_t* __restrict__ list,
+              uint32_t* __restrict__ count, unsigned char* __restrict__ flags) {
+  const int64_t c = (int64_t)blockIdx.x * XH_BLOCK + threadIdx.x;
+  int bad = 0;
+  if (c < C) {
+    for (int j = 0; j < nq; ++j) {
+      const float r = af[(int64_t)j * C + c];
+      bad |= r != r ? 1 : 0;
+      if (CORR) {
+        const float h = hist_q[(int64_t)j * C + c];
+        bad |= h != h ? 2 : 0;
+      }
+    }
+    if (CORR && !bad)
+      for (int j = 0; j < nq; ++j) {
+        const float r = af[(int64_t)j * C + c], h = hist_q[(int64_t)j * C + c];
+        af[(int64_t)j * C + c] = kind == 0 ? (r - h) : (r / h);
+      }
+  }
+  // (pass 2 must see THESE flags: a corrected column of a listed group may hold a NaN of its own — 0 / 0 — that is no node)
+  if (__ballot(bad != 0) != 0ull) {
+    if (c < C) flags[c] = (unsigned char)bad;
+    if ((threadIdx.x & 63) == 0) list[atomicAdd(count, 1u)] = (uint32_t)(c >> 6);
+  }
+}
+
+// Pass 2 (a fixed grid; workgroup = 64 adjacent columns x 16 row chunks, looping over the listed groups — none in the common
+// case): the NaN nodes of a column that has valid samples become its largest valid sample (the series are scanned by all 16
+// waves, 8 loads in flight per lane, 256-byte row segments); CORR: then the correction of the group's flagged columns.
+template <bool CORR>
+__global__ void __launch_bounds__(64 * NF_WAVES)
+k_nanfix_scan(const float* __restrict__ ref, const float* __restrict__ hist, int64_t T, int64_t C, int64_t st, int64_t sc, int nq, int kind,
+              float* __restrict__ af, float* __restrict__ hist_q, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+              const unsigned char* __restrict__ flags) {
+  __shared__ float s_max[NF_WAVES][64];
+  __shared__ int s_any[NF_WAVES][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t n = *count;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {   // (uniform)
+    const int64_t c = (int64_t)list[i] * 64 + lane;
+    const int bad = c < C ? (int)flags[c] : 0;   // (pass 1's view of the nodes)
+    float mr = 0.f, mh = 0.f;
+    bool fixr = nf_colmax(ref, T, st, sc, c, (bad & 1) != 0, lane, w, s_max, s_any, mr) && (bad & 1) != 0;
+    bool fixh = false;
+    if (CORR) fixh = nf_colmax(hist, T, st, sc, c, (bad & 2) != 0, lane, w, s_max, s_any, mh) && (bad & 2) != 0;
+    if (w != 0 || c >= C || bad == 0) continue;   // (the other columns of the group were corrected in pass 1)
+    for (int j = 0; j < nq; ++j) {
+      float r = af[(int64_t)j * C + c];
+      if (fixr && r != r) r = mr;
+      if (CORR) {
+        float h = hist_q[(int64_t)j * C + c];
+        if (fixh && h != h) {
+          h = mh;
+          hist_q[(int64_t)j * C + c] = h;
+        }
+        af[(int64_t)j * C + c] = kind == 0 ? (r - h) : (r / h);
+      } else af[(int64_t)j * C + c] = r;
+    }
+  }
+}
+
+template <bool CORR>
+static int nanfix_launch(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, int64_t sc, int nq, int kind,
+                         float* af, float* hist_q) {
+  if (C <= 0 || T <= 0) return XH_OK;
+  const int64_t groups = cdiv64(C, 64);
+  void* ws = nullptr;
+  int rc = xh_big_scratch(ctx, sizeof(uint32_t) * (size_t)(groups + 16) + (size_t)groups * 64, &ws);   // (the selection kernels are done with it: stream order)
+  if (rc) return rc;
+  uint32_t* count = static_cast<uint32_t*>(ws);
+  uint32_t* list = count + 16;
+  unsigned char* flags = reinterpret_cast<unsigned char*>(list + groups);
+  XH_CHECK_HIP(hipMemsetAsync(count, 0, 64, ctx->stream));
+  hipLaunchKernelGGL((k_nanfix_flag<CORR>), dim3((unsigned)cdiv64(C, XH_BLOCK)), dim3(XH_BLOCK), 0, ctx->stream, C, nq, kind, af, hist_q, list, count, flags);
+  XH_LAUNCH_CHECK();
+  const int64_t grid = groups < 2048 ? groups : 2048;
+  hipLaunchKernelGGL((k_nanfix_scan<CORR>), dim3((unsigned)grid), dim3(64 * NF_WAVES), 0, ctx->stream, ref, hist, T, C, st, sc, nq, kind, af,
+                     hist_q, (const uint32_t*)list, (const uint32_t*)count, (const unsigned char*)flags);
+  XH_LAUNCH_CHECK();
+  return XH_OK;
+}
+
+int xh_nanmax_fix(xh_ctx* ctx, const float* x, int64_t T, int64_t C, int64_t st, int64_t sc, int nq, float* out) {
+  return nanfix_launch<false>(ctx, x, nullptr, T, C, st, sc, nq, 0, out, nullptr);
+}
+
+int xh_correction_fix(xh_ctx* ctx, const float* ref, const float* hist, int64_t T, int64_t C, int64_t st, int64_t sc, int nq, int kind,
+                      float* af, float* hist_q) {
+  return nanfix_launch<true>(ctx, ref, hist, T, C, st, sc, nq, kind, af, hist_q);
+}
