@@ -266,7 +266,8 @@ k_window_quantiles(const float* __restrict__ x, int64_t T, int64_t C, int64_t st
       mu = n > 0u ? sum / (double)n : xh_nan64();
       if (lane == 0 && cvalid) mu_out[(int64_t)g * C + c] = mu;
       const bool fin = mu - mu == 0.0;
-      ordered = __builtin_amdgcn_readfirstlane((int)(fin && (nmode == 1 || mu > 0.0))) != 0;
+      // (an empty window — a masked cell — has nothing to normalise: not the re-sorting path)
+      ordered = __builtin_amdgcn_readfirstlane((int)(n == 0u || (fin && (nmode == 1 || mu > 0.0)))) != 0;
     }
     auto norm = [&](float f) -> float {
       if (!NORM) return f;
